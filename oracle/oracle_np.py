@@ -1,0 +1,263 @@
+"""ORACLE - numpy restatement of the reference's perturbation inner loop.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``eval_driving_safety_amd/`` may import this
+module; only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg do, and only as the checker.  The shipped path is the HIP library behind
+``include/advengine.h``.
+
+Parity status: PINNED for every function below except where a docstring says
+"unpinned".  ``tests/golden/make_golden.py`` executes the reference's own statements
+(lifted out of its scripts by AST line range) under torch-CPU on seeded inputs;
+``tests/test_oracle_golden.py`` demands bit-for-bit agreement of this file with those
+outputs.  All citations are relative to /root/reference.
+
+Arithmetic conventions that make the restatement bit-exact (each was checked against
+torch 2.10 CPU):
+  * a float32 tensor combined with a Python float computes in float32 with the scalar
+    rounded to float32 first (``x * 0.229`` == ``x * float32(0.229)``);
+  * ``torch.clamp(min=a, max=b)`` rounds a, b to float32, propagates NaN, and is
+    ``min(max(x, a), b)``;
+  * ``torch.sign`` is ``(x > 0) - (x < 0)``: sign(nan) = sign(-0.0) = +0.0;
+  * every intermediate is rounded to float32 separately (no fused multiply-add).
+"""
+import numpy as np
+
+F32 = np.float32
+
+# attack/DSGN/pgd_attack.py:153-154
+DSGN_MEAN = (0.485, 0.456, 0.406)
+DSGN_STD = (0.229, 0.224, 0.225)
+# attack/Stereo-RCNN/pgd_attack.py:190-203 (same constants in patch_attack.py:272-277)
+SRCNN_PIXEL_MEANS = (102.9801, 115.9465, 122.7717)
+SRCNN_LO = tuple(F32(0 - m) for m in SRCNN_PIXEL_MEANS)
+SRCNN_HI = tuple(F32(255 - m) for m in SRCNN_PIXEL_MEANS)
+
+
+def _f32(a):
+    a = np.asarray(a)
+    assert a.dtype == np.float32, a.dtype
+    return a
+
+
+def torch_sign(g):
+    """torch.sign for float32: (g > 0) - (g < 0); nan and +-0 give +0."""
+    g = _f32(g)
+    return (g > 0).astype(F32) - (g < 0).astype(F32)
+
+
+def torch_clamp(x, lo, hi):
+    """torch.clamp(x, min=lo, max=hi) with float32 bounds; NaN propagates."""
+    with np.errstate(invalid="ignore"):
+        return np.minimum(np.maximum(x, F32(lo)), F32(hi))
+
+
+# ----------------------------------------------------------------------------- a1 / a2
+def denormalize(im):
+    """attack/DSGN/pgd_attack.py:196-200 - ``im[c] = im[c] * std[c] + mean[c]``.
+
+    The reference touches only batch element 0 (quirk Q1); its callers always have
+    batch 1.  Here every batch element is processed the same way.  Returns a new array.
+    """
+    im = _f32(im)
+    out = np.empty_like(im)
+    for c in range(3):
+        out[:, c] = im[:, c] * F32(DSGN_STD[c]) + F32(DSGN_MEAN[c])
+    return out
+
+
+def normalize(im):
+    """attack/DSGN/pgd_attack.py:203-207 - ``(im[c] - mean[c]) / std[c]`` (true division)."""
+    im = _f32(im)
+    out = np.empty_like(im)
+    with np.errstate(invalid="ignore"):
+        for c in range(3):
+            out[:, c] = (im[:, c] - F32(DSGN_MEAN[c])) / F32(DSGN_STD[c])
+    return out
+
+
+# ----------------------------------------------------------------------------- a3
+def pgd_step_norm01(x, grad, clean, alpha, eps):
+    """One DSGN PGD step, attack/DSGN/pgd_attack.py:339-354.
+
+    x      normalised image [N,3,H,W] (the tensor the detector saw)
+    grad   d loss / d x, same shape
+    clean  DENORMALISED clean image (pgd_attack.py:297-298; ``ori`` at :254-255 is the
+           same tensor, quirk Q2)
+    returns the next normalised iterate.
+    """
+    x, grad, clean = _f32(x), _f32(grad), _f32(clean)
+    with np.errstate(invalid="ignore", over="ignore"):
+        d = denormalize(x)                                         # :339-340
+        adv = d + F32(alpha) * torch_sign(grad)                    # :343-344
+        eta = torch_clamp(adv - clean, -eps, eps)                  # :346-347
+        y = torch_clamp(clean + eta, 0, 1)                         # :349-350
+        return normalize(y)                                        # :353-354
+
+
+# ----------------------------------------------------------------------------- a13
+def pgd_step_meansub255(x, grad, clean, alpha, eps255):
+    """One Stereo R-CNN PGD step, attack/Stereo-RCNN/pgd_attack.py:177-217.
+
+    Images are BGR minus PIXEL_MEANS on the 0..255 scale; ``eps255`` is already
+    ``255 * args.eps`` (pgd_attack.py:57); ``clean`` is the un-attacked input (:122-123).
+    """
+    x, grad, clean = _f32(x), _f32(grad), _f32(clean)
+    with np.errstate(invalid="ignore", over="ignore"):
+        adv = x + F32(alpha) * torch_sign(grad)                    # :177-179
+        eta = torch_clamp(adv - clean, -eps255, eps255)            # :181-184
+        holder = clean + eta                                       # :186-187
+        out = np.empty_like(holder)
+        for c in range(3):                                         # :189-207
+            out[:, c] = torch_clamp(holder[:, c], SRCNN_LO[c], SRCNN_HI[c])
+        return out                                                 # :209-217
+
+
+# ----------------------------------------------------------------------------- a5
+def tensor2im_u8(x_norm, crop_h, crop_w):
+    """attack/DSGN/pgd_attack.py:157-193 (tensor2im + save_img's crop) for one image.
+
+    x_norm [3,H,W] normalised float32 -> uint8 [crop_h, crop_w, 3].  Denormalise in
+    float32, times 255 in float32, then ``astype(uint8)`` which TRUNCATES toward zero
+    (and wraps modulo 256 for out-of-range values, as the C conversion numpy performs on
+    x86-64 does: float -> int32 -> low byte).  PIL's ``crop((0, 0, w, h))`` keeps the
+    top-left w x h window.
+    """
+    x = _f32(x_norm)
+    assert x.ndim == 3 and x.shape[0] == 3
+    im = np.empty_like(x)
+    for c in range(3):                                             # :173-174
+        im[c] = x[c] * F32(DSGN_STD[c]) + F32(DSGN_MEAN[c])
+    im = im * F32(255)                                             # :175
+    im = np.transpose(im, (1, 2, 0))                               # :176
+    with np.errstate(invalid="ignore"):
+        u8 = im.astype(np.int32).astype(np.uint8)                  # :179
+    return np.ascontiguousarray(u8[:crop_h, :crop_w])              # :192
+
+
+def srcnn_hwc_plus_means(x):
+    """attack/Stereo-RCNN/pgd_attack.py:233-236 - CHW -> HWC, ``+= cfg.PIXEL_MEANS``.
+
+    PIXEL_MEANS is a float64 array in the upstream config, so numpy's in-place add
+    computes in float64 and rounds once to float32.
+    """
+    x = _f32(x)
+    hwc = np.ascontiguousarray(np.transpose(x, (1, 2, 0)))
+    means = np.array([[list(SRCNN_PIXEL_MEANS)]], dtype=np.float64)
+    return (hwc.astype(np.float64) + means).astype(F32)
+
+
+def srcnn_export_u8(x):
+    """What ``cv2.imwrite`` (pgd_attack.py:237) stores for the float32 HWC image of
+    ``srcnn_hwc_plus_means``: OpenCV converts to 8-bit with saturate_cast, i.e. round
+    half to even then clip to [0, 255].  UNPINNED: cv2 is not in the reference tree nor
+    in this image; this follows OpenCV's documented conversion."""
+    f = srcnn_hwc_plus_means(x)
+    with np.errstate(invalid="ignore"):
+        r = np.rint(f.astype(np.float64))
+    r = np.where(np.isnan(r), 0, r)
+    return np.clip(r, 0, 255).astype(np.uint8)
+
+
+# ----------------------------------------------------------------------------- a6 / a7
+def init_patch_dims(short_side, ratio):
+    """attack/DSGN/patch_attack.py:213-218 (384) / attack/Stereo-RCNN/patch_attack.py:60-65 (600)."""
+    patch_dim = int(short_side * ratio)
+    if patch_dim % 2 == 0:
+        patch_dim += 1
+    return patch_dim, int(patch_dim / 2)
+
+
+# column bands of generate_round_mask, as fractions of the image width:
+# attack/DSGN/patch_attack.py:240 ('random'); attack/DSGN/predict_and_save_patch.py:366-373
+ATK_MODE_BANDS = {"random": (0.2, 0.8), "sp_left": (0.2, 0.4),
+                  "sp_straight": (0.4, 0.6), "sp_right": (0.6, 0.8)}
+
+
+def round_mask_centers(rng, h, w, radius, atk_mode="random"):
+    """Centres drawn by generate_round_mask (attack/DSGN/patch_attack.py:239-243;
+    attack/Stereo-RCNN/patch_attack.py:81-84): two ``randint`` calls on the Python
+    ``random`` stream, row first; right-eye column is ``int(cx - 40 * 1.6)``.
+    ``rng`` is the ``random`` module or a ``random.Random``."""
+    lo, hi = ATK_MODE_BANDS[atk_mode]
+    cy = rng.randint(int(h * 0.4), int(h - radius - 1))
+    cx = rng.randint(int(w * lo), int(w * hi))
+    return [cy, cx], [cy, int(cx - (40 * 1.6))]
+
+
+def disc_mask(h, w, cy, cx, radius):
+    """attack/DSGN/patch_attack.py:245-248 - float32 [h,w], 1 inside the closed disc."""
+    Y, X = np.ogrid[:h, :w]
+    dist = np.sqrt((Y - cy) ** 2 + (X - cx) ** 2)
+    return (dist <= radius).astype("float32")
+
+
+# ----------------------------------------------------------------------------- a8
+def patch_paste(img, patch, cy, cx, radius):
+    """attack/DSGN/patch_attack.py:326-333,369-376: zero-pad the patch to the image size
+    with its centre at (cy, cx), then ``(1 - M) * img + M * P`` over the WHOLE image.
+    img [1,3,H,W], patch [1,3,D,D] with D = 2*radius+1.  Returns a new array."""
+    img, patch = _f32(img), _f32(patch)
+    _, _, h, w = img.shape
+    d = 2 * radius + 1
+    assert patch.shape[-2:] == (d, d)
+    assert cy - radius >= 0 and cx - radius >= 0 and cy + radius < h and cx + radius < w
+    P = np.zeros_like(img)
+    P[:, :, cy - radius:cy + radius + 1, cx - radius:cx + radius + 1] = patch
+    M = disc_mask(h, w, cy, cx, radius)[None, None]
+    with np.errstate(invalid="ignore"):
+        return (F32(1) - M) * img + M * P
+
+
+# ----------------------------------------------------------------------------- a11 / a12
+def patch_delta(grad_l, grad_r, cy, cx_l, cx_r, radius, eps, alpha=1e3):
+    """attack/DSGN/patch_attack.py:416-430 up to the clamp: the bounding-SQUARE windows
+    of the two gradients, ``clamp(0.5 * alpha * (gL + gR), -eps, eps)``.  ``0.5 * alpha``
+    is a Python float product (500.0) applied as one float32 scalar."""
+    gl, gr = _f32(grad_l), _f32(grad_r)
+    wl = gl[:, :, cy - radius:cy + radius + 1, cx_l - radius:cx_l + radius + 1]
+    wr = gr[:, :, cy - radius:cy + radius + 1, cx_r - radius:cx_r + radius + 1]
+    with np.errstate(invalid="ignore", over="ignore"):
+        return torch_clamp(F32(0.5 * alpha) * (wl + wr), -eps, eps)
+
+
+def patch_update(patch, grad_l, grad_r, cy, cx_l, cx_r, radius, eps, alpha=1e3, lo=None, hi=None):
+    """``patch -= delta`` (attack/DSGN/patch_attack.py:427-430); with ``lo``/``hi`` the
+    Stereo R-CNN per-channel range clamp follows (attack/Stereo-RCNN/patch_attack.py:268-281)."""
+    out = _f32(patch) - patch_delta(grad_l, grad_r, cy, cx_l, cx_r, radius, eps, alpha)
+    if lo is not None:
+        for c in range(3):
+            out[:, c] = torch_clamp(out[:, c], lo[c], hi[c])
+    return out
+
+
+def patch_apply_delta(patch, delta, lo=None, hi=None):
+    """``patch - delta`` then the optional per-channel clamp: the second half of
+    patch_update, split off so that a summed (multi-image / all-reduced) delta can be applied."""
+    out = _f32(patch) - _f32(delta)
+    if lo is not None:
+        for c in range(3):
+            out[:, c] = torch_clamp(out[:, c], lo[c], hi[c])
+    return out
+
+
+# ----------------------------------------------------------------------------- a16
+def kitti_label_line(cls, bbox, score, corners, dims):
+    """One line of attack/DSGN/predict_and_save_pgd.py:250-284.
+
+    cls 1/2/other -> Pedestrian/Car/Cyclist (:273); corners [8,3] float32 give the box
+    centre (float32 mean, :262); ``dims`` = (h, w, l, ry) is what upstream DSGN's
+    ``get_dimensions`` returns for the centred corners (UNPINNED - not in the reference
+    tree, supplied by the caller); alpha = -atan2(x, z) + ry; y is shifted by h/2 (:280).
+    """
+    corners = np.asarray(corners, dtype=np.float32).reshape(8, 3)
+    # torch-CPU's float32 mean over dim 0 of an [8,3] tensor keeps four running sums over rows
+    # j, j+4 and folds them left to right (found by search, pinned by the golden label text)
+    x = corners
+    center = ((((x[0] + x[4]) + (x[1] + x[5])) + (x[2] + x[6])) + (x[3] + x[7])) / F32(8)
+    h, w, l, ry = dims
+    name = "Pedestrian" if cls == 1 else "Car" if cls == 2 else "Cyclist"
+    alpha = -np.arctan2(center[0], center[2]) + ry
+    y = center[1] + F32(h / 2.0)
+    return ("{} -1 -1 {:.4f} {:.4f} {:.4f} {:.4f} {:.4f} {:.6f} {:.6f} {:.6f} {:.6f} {:.6f} {:.6f} {:.6f} {:.8f}\n"
+            .format(name, alpha, bbox[0], bbox[1], bbox[2], bbox[3], h, w, l,
+                    center[0], y, center[2], ry, score))

@@ -1,0 +1,422 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by EXECUTING the reference.
+
+Runs only in the development container (needs /root/reference and CPU torch);
+nothing here travels to the GPU box except the .npz/.json files it writes.
+
+The reference scripts cannot be imported (module-level imports of the un-vendored
+DSGN / Stereo R-CNN repos, argparse at import time), and their hot loops are inline
+in ``main()`` / ``__main__``.  So this script parses each file with ``ast`` and
+
+  * executes top-level helper ``def``s and constant assignments as they stand
+    (``denormalize``, ``normalize``, ``tensor2im``, ``save_img``, ``init_patch``,
+    ``generate_round_mask``, ``kitti_output`` ...), and
+  * lifts the hot-loop STATEMENTS out of ``main()`` by source line range and executes
+    those very AST nodes in a namespace holding seeded inputs
+
+so every expected output below was computed by the reference's own statements under
+torch-CPU, not by a restatement.  What is synthetic is only the input: images, the
+gradient that autograd would have left in ``img.grad``, patch start values.
+
+No reference source text is written to the fixtures - only arrays, scalars, digests.
+
+usage:  python tests/golden/make_golden.py           (rewrites tests/golden/*.npz)
+"""
+import ast
+import hashlib
+import io
+import json
+import os
+import random
+import sys
+import tempfile
+import types
+import warnings
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import synth  # noqa: E402
+
+REF = os.environ.get("ADV_REFERENCE_ROOT", "/root/reference")
+warnings.filterwarnings("ignore")
+torch.set_num_threads(1)
+
+
+# --------------------------------------------------------------------------- AST helpers
+def _parse(rel):
+    path = os.path.join(REF, rel)
+    with open(path) as f:
+        src = f.read()
+    return ast.parse(src, filename=path), path
+
+
+def exec_toplevel(rel, names, ns):
+    """exec top-level FunctionDef / Assign nodes whose (target) name is in `names`."""
+    tree, path = _parse(rel)
+    picked = []
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in names:
+            picked.append(node)
+        elif isinstance(node, ast.Assign) and any(
+                isinstance(t, ast.Name) and t.id in names for t in node.targets):
+            picked.append(node)
+    found = {n.name if isinstance(n, ast.FunctionDef) else n.targets[0].id for n in picked}
+    missing = set(names) - found
+    assert not missing, (rel, missing)
+    exec(compile(ast.Module(body=picked, type_ignores=[]), path, "exec"), ns)
+    return ns
+
+
+def exec_lines(rel, lo, hi, ns):
+    """exec the outermost statements of `rel` lying wholly inside source lines [lo, hi]."""
+    tree, path = _parse(rel)
+    picked = []
+
+    def visit(body):
+        for node in body:
+            if node.lineno >= lo and node.end_lineno <= hi:
+                picked.append(node)
+                continue
+            for field in ("body", "orelse", "finalbody"):
+                sub = getattr(node, field, None)
+                if isinstance(sub, list) and sub and isinstance(sub[0], ast.stmt):
+                    visit(sub)
+
+    visit(tree.body)
+    assert picked, (rel, lo, hi)
+    exec(compile(ast.Module(body=picked, type_ignores=[]), path, "exec"), ns)
+    return ns
+
+
+def sha(a):
+    a = np.ascontiguousarray(a)
+    return hashlib.sha256(a.tobytes()).hexdigest()
+
+
+def leaf(a):
+    t = torch.from_numpy(np.array(a, copy=True))
+    t.requires_grad = True
+    return t
+
+
+# --------------------------------------------------------------------------- DSGN PGD
+DSGN_PGD = "attack/DSGN/pgd_attack.py"
+
+
+def dsgn_pgd_case(seed, h, w, crop_h, crop_w, alpha, eps, n_iter, grad_scale=1.0,
+                  specials=False, keep_arrays=True):
+    from PIL import Image
+    ns = {"torch": torch, "np": np, "Image": Image}
+    exec_toplevel(DSGN_PGD, ["mean", "std", "tensor2im", "save_img", "denormalize", "normalize"], ns)
+    x0L = synth.dsgn_normalised(seed, h, w)
+    x0R = synth.dsgn_normalised(seed + 1, h, w)
+    ns.update(imgL=torch.from_numpy(x0L.copy()), imgR=torch.from_numpy(x0R.copy()),
+              alpha=alpha, eps=eps)
+    exec_lines(DSGN_PGD, 254, 255, ns)          # ori_img*_data
+    exec_lines(DSGN_PGD, 297, 298, ns)          # clean_img*_data
+    cleanL = ns["clean_imgL_data"].numpy().copy()
+    cleanR = ns["clean_imgR_data"].numpy().copy()
+    assert np.array_equal(cleanL, ns["ori_imgL_data"].numpy())
+
+    def export(t):
+        with tempfile.TemporaryDirectory() as td:
+            p = os.path.join(td, "x.png")
+            ns["save_img"](t.clone().detach_().cpu()[0], p, crop_w, crop_h)
+            return np.array(Image.open(p).convert("RGB"))
+
+    out = {"x0L": x0L, "x0R": x0R, "cleanL": cleanL, "cleanR": cleanR,
+           "u8L_0": export(ns["imgL"]), "u8R_0": export(ns["imgR"])}
+    digests = {}
+    for k in range(n_iter):
+        gL = synth.gradient(1000 * seed + 2 * k, x0L.shape, grad_scale, specials=specials)
+        gR = synth.gradient(1000 * seed + 2 * k + 1, x0R.shape, grad_scale, specials=specials)
+        ns["imgL"].requires_grad = True           # pgd_attack.py:305-306
+        ns["imgR"].requires_grad = True
+        ns["imgL"].grad = torch.from_numpy(gL.copy())
+        ns["imgR"].grad = torch.from_numpy(gR.copy())
+        exec_lines(DSGN_PGD, 339, 354, ns)        # THE reference PGD step
+        xl, xr = ns["imgL"].numpy().copy(), ns["imgR"].numpy().copy()
+        u8l, u8r = export(ns["imgL"]), export(ns["imgR"])
+        digests["xL_%d" % (k + 1)] = sha(xl)
+        digests["xR_%d" % (k + 1)] = sha(xr)
+        digests["u8L_%d" % (k + 1)] = sha(u8l)
+        digests["u8R_%d" % (k + 1)] = sha(u8r)
+        if keep_arrays:
+            out["gL_%d" % k], out["gR_%d" % k] = gL, gR
+            out["xL_%d" % (k + 1)], out["xR_%d" % (k + 1)] = xl, xr
+            out["u8L_%d" % (k + 1)], out["u8R_%d" % (k + 1)] = u8l, u8r
+    meta = dict(seed=seed, h=h, w=w, crop_h=crop_h, crop_w=crop_w, alpha=alpha, eps=eps,
+                n_iter=n_iter, grad_scale=grad_scale, specials=specials, digests=digests)
+    if not keep_arrays:
+        out = {k: v for k, v in out.items() if k.startswith("u8") and False}
+    return out, meta
+
+
+# --------------------------------------------------------------------------- S-RCNN PGD
+SR_PGD = "attack/Stereo-RCNN/pgd_attack.py"
+
+
+def srcnn_pgd_case(seed, h, w, alpha, eps_arg, n_iter, grad_scale=1.0, specials=False,
+                   keep_arrays=True):
+    cfg = types.SimpleNamespace(PIXEL_MEANS=np.array([[list(synth.SRCNN_PIXEL_MEANS)]]))
+    ns = {"torch": torch, "np": np, "cfg": cfg}
+    x0L = synth.srcnn_meansub(seed, h, w)
+    x0R = synth.srcnn_meansub(seed + 1, h, w)
+    eps = 255 * eps_arg                           # pgd_attack.py:57  (args.eps * 255)
+    ns.update(im_left_data=torch.from_numpy(x0L.copy()), im_right_data=torch.from_numpy(x0R.copy()),
+              alpha=alpha, eps=eps)
+    exec_lines(SR_PGD, 122, 123, ns)              # clean_im_*_data = im_*_data.data
+    out = {"x0L": x0L, "x0R": x0R}
+    digests = {}
+
+    def hwc_plus_means(name):
+        # pgd_attack.py:233-236 (left) / 239-242 (right) minus the cv2.imwrite line
+        sub = dict(ns)
+        if name == "L":
+            exec_lines(SR_PGD, 233, 236, sub)
+            return sub["img_left"].copy()
+        exec_lines(SR_PGD, 239, 242, sub)
+        return sub["img_right"].copy()
+
+    for k in range(n_iter):
+        gL = synth.gradient(2000 * seed + 2 * k, x0L.shape, grad_scale, specials=specials)
+        gR = synth.gradient(2000 * seed + 2 * k + 1, x0R.shape, grad_scale, specials=specials)
+        ns["im_left_data"].requires_grad = True   # pgd_attack.py:153-154
+        ns["im_right_data"].requires_grad = True
+        ns["im_left_data"].grad = torch.from_numpy(gL.copy())
+        ns["im_right_data"].grad = torch.from_numpy(gR.copy())
+        exec_lines(SR_PGD, 177, 217, ns)          # THE reference PGD step
+        xl, xr = ns["im_left_data"].numpy().copy(), ns["im_right_data"].numpy().copy()
+        fl, fr = hwc_plus_means("L"), hwc_plus_means("R")
+        digests["xL_%d" % (k + 1)] = sha(xl)
+        digests["xR_%d" % (k + 1)] = sha(xr)
+        digests["hwcL_%d" % (k + 1)] = sha(fl)
+        if keep_arrays:
+            out["gL_%d" % k], out["gR_%d" % k] = gL, gR
+            out["xL_%d" % (k + 1)], out["xR_%d" % (k + 1)] = xl, xr
+            out["hwcL_%d" % (k + 1)], out["hwcR_%d" % (k + 1)] = fl, fr
+    meta = dict(seed=seed, h=h, w=w, alpha=alpha, eps_arg=eps_arg, eps=eps, n_iter=n_iter,
+                grad_scale=grad_scale, specials=specials, digests=digests)
+    return out, meta
+
+
+# --------------------------------------------------------------------------- patch attacks
+DSGN_PATCH = "attack/DSGN/patch_attack.py"
+SR_PATCH = "attack/Stereo-RCNN/patch_attack.py"
+
+
+def patch_case(model, seed, ratio, eps, iters, grad_scale, zero_patch=False):
+    """Full-size (shape is hard-coded in the reference) paste + update trace."""
+    if model == "dsgn":
+        rel, H, W = DSGN_PATCH, 384, 1248
+        L, R = "imgL", "imgR"
+        pad_lines, paste_lines, upd_lines = (326, 333), (369, 376), (416, 430)
+        mk = synth.dsgn_normalised
+        plo, phi = -2.0, 2.5
+    else:
+        rel, H, W = SR_PATCH, 600, 1987
+        L, R = "im_left_data", "im_right_data"
+        pad_lines, paste_lines, upd_lines = (178, 185), (221, 230), (257, 281)
+        mk = synth.srcnn_meansub
+        plo, phi = -140.0, 170.0                  # beyond the per-channel clamp on both sides
+    ns = {"torch": torch, "np": np, "nn": nn, "random": random, "os": os}
+    exec_toplevel(rel, ["init_patch", "generate_round_mask"], ns)
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as td:
+        os.chdir(td)
+        try:
+            patch_dim, radius, patch0 = ns["init_patch"](ratio, "p")
+        finally:
+            os.chdir(cwd)
+    assert patch0.shape == (1, 3, patch_dim, patch_dim) and not patch0.any()
+    if not zero_patch:
+        patch0 = synth.patch_init(seed + 5, patch_dim, plo, phi)
+    random.seed(seed)
+    center_l, center_r, mask_l, mask_r = ns["generate_round_mask"](radius)
+    ns.update(center_l=center_l, center_r=center_r, radius=radius,
+              mask_l=torch.from_numpy(mask_l), mask_r=torch.from_numpy(mask_r),
+              patch=torch.from_numpy(patch0.copy()), alpha=1e3, eps=eps)
+    exec_lines(rel, *pad_lines, ns)
+    xL, xR = mk(seed + 10, H, W), mk(seed + 11, H, W)
+    ns[L], ns[R] = leaf(xL), leaf(xR)
+    cy, cxl, cxr, r = center_l[0], center_l[1], center_r[1], radius
+    win = lambda a, cx: np.ascontiguousarray(a[:, :, cy - r:cy + r + 1, cx - r:cx + r + 1])
+    out = {"patch_0": patch0, "mask_win": np.ascontiguousarray(mask_l[0, 0, cy - r:cy + r + 1, cxl - r:cxl + r + 1])}
+    digests = {"mask_l": sha(mask_l[0, 0]), "mask_r": sha(mask_r[0, 0])}
+    for k in range(iters):
+        exec_lines(rel, *paste_lines, ns)         # THE reference paste
+        pl, pr = ns[L].data.numpy(), ns[R].data.numpy()
+        digests["pastedL_%d" % k], digests["pastedR_%d" % k] = sha(pl), sha(pr)
+        out["pastedL_win_%d" % k], out["pastedR_win_%d" % k] = win(pl, cxl), win(pr, cxr)
+        # autograd ACCUMULATES into the same leaf across inner iterations (the reference never
+        # zeroes img.grad): emulate by adding this iteration's gradient to .grad
+        gL = synth.gradient(3000 * seed + 2 * k, xL.shape, grad_scale)
+        gR = synth.gradient(3000 * seed + 2 * k + 1, xR.shape, grad_scale)
+        for name, g in ((L, gL), (R, gR)):
+            t = ns[name]
+            t.grad = torch.from_numpy(g.copy()) if t.grad is None else t.grad + torch.from_numpy(g)
+        out["gradL_win_%d" % k] = win(ns[L].grad.numpy(), cxl)
+        out["gradR_win_%d" % k] = win(ns[R].grad.numpy(), cxr)
+        digests["gradL_%d" % k], digests["gradR_%d" % k] = sha(ns[L].grad.numpy()), sha(ns[R].grad.numpy())
+        exec_lines(rel, *upd_lines, ns)           # THE reference patch update
+        out["patch_%d" % (k + 1)] = ns["patch"].numpy().copy()
+    meta = dict(model=model, seed=seed, ratio=ratio, eps=eps, iters=iters, grad_scale=grad_scale,
+                zero_patch=zero_patch, H=H, W=W, patch_dim=int(patch_dim), radius=int(radius),
+                center_l=[int(v) for v in center_l], center_r=[int(v) for v in center_r],
+                mask_area=int(mask_l[0, 0].sum()), digests=digests)
+    return out, meta
+
+
+def mask_and_dims_cases():
+    """init_patch dims for a sweep of ratios; generate_round_mask centres per seed, for the two
+    trainers and for the two detect-under-attack scripts' atk_mode column bands."""
+    res = {"init_patch": [], "centers": []}
+    for model, rel, short in (("dsgn", DSGN_PATCH, 384), ("srcnn", SR_PATCH, 600)):
+        ns = {"np": np, "os": os, "random": random}
+        exec_toplevel(rel, ["init_patch", "generate_round_mask"], ns)
+        for ratio in (0.05, 0.1, 0.13, 0.2, 0.25, 0.26, 0.2605, 0.3, 0.333, 0.5):
+            cwd = os.getcwd()
+            with tempfile.TemporaryDirectory() as td:
+                os.chdir(td)
+                try:
+                    d, r, p = ns["init_patch"](ratio, "p")
+                    saved = np.load(os.path.join(td, "p", "epoch0", "patch.npy"))
+                finally:
+                    os.chdir(cwd)
+            assert saved.dtype == np.float32 and saved.shape == (1, 3, d, d)
+            res["init_patch"].append(dict(model=model, ratio=ratio, patch_dim=int(d), radius=int(r)))
+        r = {"dsgn": 38, "srcnn": 30}[model]
+        for seed in range(6):
+            random.seed(seed)
+            cl, cr, ml, mr = ns["generate_round_mask"](r)
+            res["centers"].append(dict(model=model, script="patch_attack", atk_mode="random", seed=seed,
+                                       radius=r, center_l=[int(v) for v in cl], center_r=[int(v) for v in cr],
+                                       area=int(ml[0, 0].sum()), mask_l=sha(ml[0, 0]), mask_r=sha(mr[0, 0]),
+                                       mask_shape=list(ml.shape), mask_dtype=str(ml.dtype)))
+    for model, rel in (("dsgn", "attack/DSGN/predict_and_save_patch.py"),
+                       ("srcnn", "attack/Stereo-RCNN/predict_and_save_patch.py")):
+        r = {"dsgn": 38, "srcnn": 30}[model]
+        for mode in ("random", "sp_left", "sp_straight", "sp_right"):
+            ns = {"np": np, "os": os, "random": random, "args": types.SimpleNamespace(atk_mode=mode)}
+            exec_toplevel(rel, ["generate_round_mask"], ns)
+            for seed in range(4):
+                random.seed(seed)
+                cl, cr, ml, mr = ns["generate_round_mask"](r)
+                res["centers"].append(dict(model=model, script="predict_and_save_patch", atk_mode=mode,
+                                           seed=seed, radius=r, center_l=[int(v) for v in cl],
+                                           center_r=[int(v) for v in cr], area=int(ml[0, 0].sum()),
+                                           mask_l=sha(ml[0, 0]), mask_r=sha(mr[0, 0]),
+                                           mask_shape=list(ml.shape), mask_dtype=str(ml.dtype)))
+    return res
+
+
+# --------------------------------------------------------------------------- label writer
+def label_case():
+    """kitti_output's text formatting (attack/DSGN/predict_and_save_pgd.py:250-284).
+    `get_dimensions` is upstream DSGN code that is not in the reference; it is stubbed with a
+    function that reads (h, w, l, ry) off the test vector, so only the reference's own centre /
+    alpha / y-shift arithmetic and its format string are pinned here."""
+    rel = "attack/DSGN/predict_and_save_pgd.py"
+    rs = np.random.RandomState(7)
+    n = 5
+    labels = torch.tensor([2, 2, 1, 3, 2])
+    bbox = torch.from_numpy((rs.rand(n, 4) * 300).astype(np.float32))
+    scores = torch.from_numpy(rs.rand(n).astype(np.float32))
+    corners = torch.from_numpy((rs.randn(n, 24) * 3 + 10).astype(np.float32))
+    dims = (rs.rand(n, 4) * 3).astype(np.float32)
+    state = {"i": 0}
+
+    def get_dimensions(c):
+        d = dims[state["i"]]
+        state["i"] += 1
+        return float(d[0]), float(d[1]), float(d[2]), float(d[3] - 1.5)
+
+    class Pred:
+        def __init__(self):
+            self.bbox = bbox
+            self.f = {"labels": labels, "scores": scores, "box_corner3d": corners}
+
+        def get_field(self, k):
+            return self.f[k]
+
+        def has_field(self, k):
+            return k in self.f
+
+    cfg = types.SimpleNamespace(learn_viewpoint=False)
+    ns = {"np": np, "os": os, "torch": torch, "cfg": cfg, "get_dimensions": get_dimensions,
+          "print": lambda *a, **k: None}
+    exec_toplevel(rel, ["kitti_output"], ns)
+    with tempfile.TemporaryDirectory() as td:
+        ns["kitti_output"]([Pred()], [42], td)
+        with open(os.path.join(td, "000042.txt")) as f:
+            text = f.read()
+    return dict(labels=labels.tolist(), bbox=bbox.numpy().tolist(), scores=scores.numpy().tolist(),
+                corners=corners.numpy().tolist(),
+                dims=[[float(d[0]), float(d[1]), float(d[2]), float(d[3] - 1.5)] for d in dims],
+                image_index=42, text=text)
+
+
+# --------------------------------------------------------------------------- main
+def save_npz(name, arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrays)
+    return os.path.getsize(path)
+
+
+def main():
+    index = {"torch": torch.__version__, "numpy": np.__version__, "cases": {}}
+
+    pgd = [
+        # name,               seed  h   w  ch  cw  alpha     eps      N  gscale specials
+        ("dsgn_pgd_default",    1, 24, 40, 21, 37, 1 / 255,  0.3,     4, 1.0, False),   # script defaults (:53-55)
+        ("dsgn_pgd_fgsm",       2, 24, 40, 24, 40, 8 / 255,  8 / 255, 1, 1.0, False),   # BASELINE config 1
+        ("dsgn_pgd_cfg2",       3, 16, 28, 15, 27, 1 / 255,  0.03,   20, 1e-3, False),  # BASELINE config 2
+        ("dsgn_pgd_specials",   4, 12, 20, 12, 20, 2 / 255,  0.05,    3, 1.0, True),    # nan/inf/-0 gradients
+        ("dsgn_pgd_ragged",     5,  7, 13,  5, 11, 1 / 255,  0.01,    3, 1.0, False),   # W not a multiple of 4
+    ]
+    for name, seed, h, w, ch, cw, a, e, n, gs, sp in pgd:
+        arrays, meta = dsgn_pgd_case(seed, h, w, ch, cw, a, e, n, gs, sp)
+        meta["bytes"] = save_npz(name + ".npz", arrays)
+        index["cases"][name] = meta
+    # one full-size KITTI-shaped pair: digests only, inputs regenerate from the seed
+    _, meta = dsgn_pgd_case(6, 384, 1248, 375, 1242, 1 / 255, 0.03, 2, 1e-3, False, keep_arrays=False)
+    index["cases"]["dsgn_pgd_fullsize"] = meta
+
+    sr = [
+        ("srcnn_pgd_default",  11, 20, 33, 1.0, 0.3,  4, 1.0, False),   # script defaults (:41-44)
+        ("srcnn_pgd_cfg3",     12, 14, 27, 1.0, 0.03, 20, 1.0, False),  # BASELINE config 3
+        ("srcnn_pgd_specials", 13, 10, 18, 2.5, 0.05, 3, 1.0, True),
+    ]
+    for name, seed, h, w, a, e, n, gs, sp in sr:
+        arrays, meta = srcnn_pgd_case(seed, h, w, a, e, n, gs, sp)
+        meta["bytes"] = save_npz(name + ".npz", arrays)
+        index["cases"][name] = meta
+    _, meta = srcnn_pgd_case(14, 600, 1987, 1.0, 0.03, 2, 1.0, False, keep_arrays=False)
+    index["cases"]["srcnn_pgd_fullsize"] = meta
+
+    pt = [
+        ("dsgn_patch_default", "dsgn", 21, 0.2, 8 / 255, 2, 4e-5, False),   # script defaults (:53-56)
+        ("dsgn_patch_zero",    "dsgn", 22, 0.2, 8 / 255, 2, 4e-5, True),    # fresh zeros patch (init_patch)
+        ("dsgn_patch_100px",   "dsgn", 23, 0.2605, 8 / 255, 2, 4e-5, False),  # BASELINE config 4 (D=101)
+        ("srcnn_patch_default", "srcnn", 31, 0.1, 0.1, 2, 1.5e-4, False),   # script defaults (:43-47)
+    ]
+    for name, model, seed, ratio, eps, iters, gs, zp in pt:
+        arrays, meta = patch_case(model, seed, ratio, eps, iters, gs, zp)
+        meta["bytes"] = save_npz(name + ".npz", arrays)
+        index["cases"][name] = meta
+
+    index["masks"] = mask_and_dims_cases()
+    index["label"] = label_case()
+    with open(os.path.join(HERE, "index.json"), "w") as f:
+        json.dump(index, f, indent=1, sort_keys=True)
+    tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE)
+              if f.endswith((".npz", ".json")))
+    print("wrote %d cases, %.1f KiB" % (len(index["cases"]), tot / 1024))
+
+
+if __name__ == "__main__":
+    main()

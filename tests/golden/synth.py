@@ -1,0 +1,66 @@
+"""Seeded synthetic inputs shared by the golden-vector generator and the tests.
+
+Everything here is drawn from ``numpy.random.RandomState`` (the legacy MT19937
+stream numpy freezes across releases), so a test can regenerate the exact input
+a fixture was produced from instead of storing megabytes of pixels.
+
+This file is test infrastructure: it holds no reference code and nothing under
+``eval_driving_safety_amd/`` imports it.
+"""
+import numpy as np
+
+DSGN_MEAN = (0.485, 0.456, 0.406)
+DSGN_STD = (0.229, 0.224, 0.225)
+SRCNN_PIXEL_MEANS = (102.9801, 115.9465, 122.7717)
+
+
+def u8_image(seed, h, w):
+    """uint8 RGB-like image [h, w, 3]; low-pass so neighbouring pixels correlate."""
+    rs = np.random.RandomState(seed)
+    base = rs.randint(0, 256, size=(h // 4 + 2, w // 4 + 2, 3)).astype(np.float32)
+    up = np.repeat(np.repeat(base, 4, axis=0), 4, axis=1)[:h, :w]
+    noise = rs.randint(-6, 7, size=(h, w, 3)).astype(np.float32)
+    return np.clip(up + noise, 0, 255).astype(np.uint8)
+
+
+def dsgn_normalised(seed, h, w):
+    """[1,3,h,w] float32 the way a DSGN-style loader hands it to the attack:
+    u8/255 then (x-mean)/std, all in float32."""
+    u8 = u8_image(seed, h, w)
+    x = u8.astype(np.float32) / np.float32(255.0)
+    x = np.ascontiguousarray(x.transpose(2, 0, 1))[None]
+    for c in range(3):
+        x[0, c] = (x[0, c] - np.float32(DSGN_MEAN[c])) / np.float32(DSGN_STD[c])
+    return x
+
+
+def srcnn_meansub(seed, h, w):
+    """[1,3,h,w] float32 BGR minus PIXEL_MEANS (0..255 scale)."""
+    u8 = u8_image(seed, h, w)
+    x = u8.astype(np.float32)
+    x = np.ascontiguousarray(x.transpose(2, 0, 1))[None]
+    for c in range(3):
+        x[0, c] = x[0, c] - np.float32(SRCNN_PIXEL_MEANS[c])
+    return x
+
+
+def gradient(seed, shape, scale=1.0, zero_frac=0.05, specials=False):
+    """float32 gradient-like tensor with a share of exact zeros (sign(0) = 0 path)
+    and, optionally, +-inf / nan / -0.0 entries at fixed flat positions."""
+    rs = np.random.RandomState(seed)
+    g = (rs.randn(*shape) * scale).astype(np.float32)
+    z = rs.rand(*shape) < zero_frac
+    g[z] = 0.0
+    if specials:
+        flat = g.reshape(-1)
+        n = flat.size
+        flat[7 % n] = np.float32("nan")
+        flat[11 % n] = np.float32("inf")
+        flat[13 % n] = -np.float32("inf")
+        flat[17 % n] = np.float32(-0.0)
+    return g
+
+
+def patch_init(seed, d, lo=-2.0, hi=2.5):
+    rs = np.random.RandomState(seed)
+    return (rs.rand(1, 3, d, d) * (hi - lo) + lo).astype(np.float32)
