@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""bench.py - KITTI stereo-pairs/s of 20-step PGD on DSGN-shaped inputs (BASELINE.json configs[1]),
+perturbation path, on N MI355X GPUs of one node.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One STEP = one complete 20-iteration L-inf PGD attack (eps 0.03, alpha 1/255, the reference's
+script default) of a resident batch of stereo pairs, exactly the per-image work of the reference's
+loop body around the detector call (attack/DSGN/pgd_attack.py:279-374):
+    clean = denormalize(x0)                         (:297-298)  adv_denormalize_f32
+    export iterate 0 as 8-bit HWC                   (:279-294)  adv_export_u8_f32
+    20 x { step + project + re-normalise + export } (:339-374)  adv_pgd_step_f32 (one launch, both eyes
+                                                                of every pair of the batch)
+The detector's forward/backward (upstream DSGN, not part of the reference tree) is the caller's: its
+gradient is a resident synthetic buffer here, so `value` is the throughput of the perturbation engine
+with inputs in HBM, not of an end-to-end attack.  PNG encoding / disk are outside the timed region.
+
+Pairs shard by image over ranks with no collective: every rank attacks its own
+`--pairs` pairs, so scaling is weak and value = pairs of all ranks / max-over-ranks time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H, W = 384, 1248            # DSGN network input (hard-asserted by the reference, patch_attack.py:318-320)
+CROP_H, CROP_W = 375, 1242  # KITTI native size the PNGs are cropped back to (pgd_attack.py:192)
+N_ITER, EPS, ALPHA = 20, 0.03, 1.0 / 255.0
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pairs", type=int, default=256, help="stereo pairs resident per GPU (per step)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs in the CPU-baseline sample (0 = auto)")
+    return ap.parse_args()
+
+
+def cpu_baseline(sample_pairs):
+    """The oracle (a port: op-for-op restatement of the reference lines, pinned by golden vectors)
+    timed on this host: the same step as above for `sample_pairs` pairs."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import synth
+    try:
+        from oracle import oracle_c
+        impl, cores = oracle_c, oracle_c.num_threads()
+        kind_note = "C oracle (oracle/oracle.c, OpenMP)"
+    except Exception:
+        from oracle import oracle_np as impl
+        cores, kind_note = 1, "numpy oracle (oracle/oracle_np.py)"
+    x0 = np.concatenate([synth.dsgn_normalised(i, H, W) for i in range(2)])
+    g = synth.gradient(3, x0.shape, 1.0)
+    t_budget, done, t0 = 20.0, 0, time.perf_counter()
+    target = sample_pairs if sample_pairs > 0 else 10 ** 9
+    while done < target:
+        clean = impl.denormalize(x0)
+        for i in range(2):
+            impl.tensor2im_u8(x0[i], CROP_H, CROP_W)
+        x = x0
+        for _ in range(N_ITER):
+            x = impl.pgd_step_norm01(x, g, clean, ALPHA, EPS)
+            for i in range(2):
+                impl.tensor2im_u8(x[i], CROP_H, CROP_W)
+        done += 1
+        if sample_pairs <= 0 and time.perf_counter() - t0 > t_budget:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "stereo-pairs/s", "cores": int(cores), "kind": "port",
+            "sample": "%d KITTI-shaped pairs x 20-step PGD + 8-bit export, %s, %.1f s" % (done, kind_note, dt)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    if world != args.gpus and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    from eval_driving_safety_amd import ops   # raises if libadvengine.so is not built
+    sp = ops.Space.dsgn()
+
+    n_img = 2 * args.pairs                    # both eyes of every pair in one launch
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    x0 = torch.randint(0, 256, (n_img, 3, H, W), device=dev, generator=gen, dtype=torch.int32).float().div_(255.0)
+    ops.normalize(x0, sp, out=x0)             # what the DSGN loader hands over: normalised float32
+    grad = torch.randn((n_img, 3, H, W), device=dev, generator=gen)
+    clean = torch.empty_like(x0)
+    x = torch.empty_like(x0)
+    u8 = ops.alloc_u8(n_img, CROP_H, W, dev)
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+
+    def step(k=None):
+        ops.denormalize(x0, sp, out=clean)
+        ops.export_u8(x0, sp, (CROP_H, CROP_W), out=u8)
+        if k is not None:
+            ev0[k].record()
+        ops.pgd_step(x0, grad, clean, sp, ALPHA, EPS, out=x, u8_out=u8, crop=(CROP_H, CROP_W))
+        for _ in range(N_ITER - 1):
+            ops.pgd_step(x, grad, clean, sp, ALPHA, EPS, out=x, u8_out=u8, crop=(CROP_H, CROP_W))
+        if k is not None:
+            ev1[k].record()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # dominant kernel: pgd_step_vec4<AFFINE, rows-dword u8>; HIP events on the launch stream
+    kern_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / (args.steps * N_ITER)
+    elems = 3 * H * W
+    alg_bytes = n_img * (16 * elems + 3 * CROP_H * CROP_W)     # 16 B/elt + the 8-bit export
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        out = {
+            "metric": "KITTI stereo-pairs/sec for 20-step PGD on DSGN (perturbation path; detector fwd+bwd is the caller's)",
+            "value": world * args.pairs * args.steps / elapsed,
+            "unit": "stereo-pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: 20-step PGD Linf eps=0.03 alpha=1/255, DSGN pixel space, "
+                                   "KITTI 1242x375 padded to 1248x384, %d stereo pairs resident per GPU, gradient = "
+                                   "resident synthetic buffer, 8-bit HWC export of all 21 iterates" % args.pairs,
+                       "pairs_per_gpu": args.pairs, "pgd_iters": N_ITER, "eps": EPS, "alpha": ALPHA,
+                       "parallelism": "image-sharded x%d, no collective" % world},
+            "roofline": {"bound": "hbm", "kernel": "pgd_step_vec4<AFFINE,U8_ROWS_DWORD>",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "avg_launch_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_pairs)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

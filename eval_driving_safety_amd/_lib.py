@@ -1,0 +1,109 @@
+"""ctypes binding of libadvengine.so (C ABI: include/advengine.h).
+
+torch is imported BEFORE the library is opened on purpose: PyTorch-ROCm ships its own
+libamdhip64.so.7, and the dynamic loader then resolves this library's NEEDED entry of the
+same soname to that already-loaded runtime, so device pointers and streams handed over
+from torch tensors belong to the runtime the kernels are launched with.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libadvengine.so")
+
+ADV_OK = 0
+ADV_EINVAL = -22
+ADV_EALIGN = -14
+ADV_ELAUNCH = -5
+ADV_SPACE_AFFINE = 0
+ADV_SPACE_IDENTITY = 1
+ABI_VERSION = 1
+
+
+class AdvSpace(ctypes.Structure):
+    """adv_space_t"""
+    _fields_ = [("kind", ctypes.c_int32),
+                ("scale", ctypes.c_float * 3),
+                ("shift", ctypes.c_float * 3),
+                ("lo", ctypes.c_float * 3),
+                ("hi", ctypes.c_float * 3),
+                ("export_add", ctypes.c_double * 3)]
+
+
+class AdvEngineError(RuntimeError):
+    def __init__(self, fn, code, detail):
+        super().__init__("%s failed: %s (code %d)" % (fn, detail, code))
+        self.code = code
+
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_L = ctypes.c_int64
+_F = ctypes.c_float
+_SP = ctypes.POINTER(AdvSpace)
+_F3 = ctypes.POINTER(ctypes.c_float)
+
+# name -> argtypes; every function returns int unless listed in _OTHER_RESTYPE
+SIGNATURES = {
+    "adv_denormalize_f32": [_P, _P, _L, _I, _I, _SP, _P],
+    "adv_normalize_f32": [_P, _P, _L, _I, _I, _SP, _P],
+    "adv_pgd_step_f32": [_P, _P, _P, _P, _P, _L, _I, _I, _SP, _F, _F, _I, _I, _L, _L, _P],
+    "adv_export_u8_f32": [_P, _P, _L, _I, _I, _SP, _I, _I, _L, _L, _P],
+    "adv_disc_mask_f32": [_P, _I, _I, _I, _I, _I, _P],
+    "adv_patch_paste_f32": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "adv_patch_paste_batch_f32": [_P, _P, _L, _I, _I, _I, _P, _I, _P],
+    "adv_patch_update_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _F, _F3, _F3, _P, _P],
+    "adv_patch_delta_batch_f32": [_P, _P, _L, _I, _I, _I, _P, _I, _F, _F, _P, _P],
+    "adv_patch_apply_f32": [_P, _P, _I, _F3, _F3, _P],
+}
+_OTHER = {
+    "adv_abi_version": ([], _I),
+    "adv_last_hip_error": ([], _I),
+    "adv_strerror": ([_I], ctypes.c_char_p),
+    "adv_space_dsgn": ([_SP], None),
+    "adv_space_srcnn": ([_SP], None),
+}
+EXPORTED = sorted(list(SIGNATURES) + list(_OTHER))
+
+_lib = None
+
+
+def load():
+    """Open libadvengine.so (once).  Raises if it has not been built - there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libadvengine.so is missing at %s - build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C eval_driving_safety_amd/csrc` (needs hipcc, targets gfx950). "
+            "This package has no CPU / PyTorch fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    for name, (argtypes, restype) in _OTHER.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = restype
+    got = lib.adv_abi_version()
+    if got != ABI_VERSION:
+        raise ImportError("libadvengine.so ABI %d, binding expects %d - rebuild" % (got, ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(name, code):
+    if code != ADV_OK:
+        lib = load()
+        detail = lib.adv_strerror(code).decode()
+        if code == ADV_ELAUNCH:
+            detail += " [hipError_t %d]" % lib.adv_last_hip_error()
+        raise AdvEngineError(name, code, detail)
+
+
+def call(name, *args):
+    check(name, getattr(load(), name)(*args))

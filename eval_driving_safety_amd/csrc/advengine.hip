@@ -1,0 +1,696 @@
+// libadvengine.so - perturbation inner loop of the stereo-detector attacks, for gfx950 (MI355X).
+//
+// Every kernel here is HBM-bound float32 streaming work; none of it is GEMM-shaped, so no MFMA.
+// What matters (cdna_hip_programming.md G2/G11/G13, Appendix B "Element-wise"): 16-byte
+// accesses per lane, fully coalesced 1 KiB wave transactions, enough independent loads in
+// flight per lane, and one pass over memory per PGD step instead of the reference's ~12.
+//
+// Arithmetic contract: bit-identical to torch-CPU float32 (see include/advengine.h).  This file
+// is compiled with -ffp-contract=off and the pragma below; HIP's default float division is the
+// correctly rounded one (-fhip-fp32-correctly-rounded-divide-sqrt) and f32 denormals are kept.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+
+#include "advengine.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+thread_local int g_last_hip_error = 0;
+
+constexpr int kBlock = 256;  // 4 waves of 64: one per SIMD of a CU
+
+struct SpaceK {  // by-value kernel argument (lives in the kernarg segment -> scalar loads)
+  float scale[3];
+  float shift[3];
+  float lo[3];
+  float hi[3];
+  double export_add[3];
+};
+
+// ------------------------------------------------------------------------------------------
+// scalar building blocks, each the float32 operation torch performs
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float t_sign(float g) {  // torch.sign: (g > 0) - (g < 0)
+  return (g > 0.0f ? 1.0f : 0.0f) - (g < 0.0f ? 1.0f : 0.0f);
+}
+
+__device__ __forceinline__ float t_clamp(float x, float lo, float hi) {  // NaN stays NaN
+  return x < lo ? lo : (x > hi ? hi : x);
+}
+
+template <int KIND>
+__device__ __forceinline__ float pgd_elem(float x, float g, float cl, float sc, float sh, float lo,
+                                          float hi, float alpha, float eps) {
+  float d = x;
+  if (KIND == ADV_SPACE_AFFINE) {
+    d = x * sc;
+    d = d + sh;
+  }
+  const float a = d + alpha * t_sign(g);
+  const float eta = t_clamp(a - cl, -eps, eps);
+  const float y = t_clamp(cl + eta, lo, hi);
+  if (KIND == ADV_SPACE_AFFINE) return (y - sh) / sc;
+  return y;
+}
+
+// numpy's float32 -> uint8 astype on x86-64 is cvttss2si + low byte: NaN and |v| >= 2^31 give
+// 0x80000000 whose low byte is 0.
+__device__ __forceinline__ uint32_t trunc_low_byte(float v) {
+  if (!(fabsf(v) < 2147483648.0f)) return 0u;
+  return static_cast<uint32_t>(static_cast<int>(v)) & 0xffu;
+}
+
+// OpenCV saturate_cast<uchar>(float): cvRound (round half to even, 0x80000000 when not
+// representable) then clip to [0,255].
+__device__ __forceinline__ uint32_t round_sat_byte(float v) {
+  if (!(fabsf(v) < 2147483648.0f)) return 0u;
+  const int i = static_cast<int>(rintf(v));
+  return i < 0 ? 0u : (i > 255 ? 255u : static_cast<uint32_t>(i));
+}
+
+template <int KIND>
+__device__ __forceinline__ uint32_t export_byte(float xo, float sc, float sh, double add) {
+  if (KIND == ADV_SPACE_AFFINE) {
+    float v = xo * sc;
+    v = v + sh;
+    v = v * 255.0f;
+    return trunc_low_byte(v);
+  }
+  const float f = static_cast<float>(static_cast<double>(xo) + add);
+  return round_sat_byte(f);
+}
+
+__device__ __forceinline__ float comp(const float4& v, int j) {
+  return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w));
+}
+
+// 4 pixels x 3 channels -> 12 interleaved bytes (HWC) in three dwords
+template <int KIND>
+__device__ __forceinline__ uint3 pack_hwc4(const float4 o[3], const SpaceK& sp) {
+  uint32_t b[12];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) b[j * 3 + c] = export_byte<KIND>(comp(o[c], j), sp.scale[c], sp.shift[c], sp.export_add[c]);
+  }
+  uint3 r;
+  r.x = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+  r.y = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+  r.z = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
+  return r;
+}
+
+enum U8Mode { U8_NONE = 0, U8_ROWS_DWORD = 1, U8_BYTES = 2 };
+
+struct U8Dst {
+  uint8_t* base;
+  long long row_stride;
+  long long image_stride;
+  int crop_h;
+  int ncols;  // columns stored per row: w when the pitch holds whole rows, else crop_w
+};
+
+// ------------------------------------------------------------------------------------------
+// K1/K2 (+K5 fused): one PGD step.  A lane owns 4 consecutive pixels of one image in all three
+// channel planes: nine independent 16-byte loads, three 16-byte stores, and (optionally) the 12
+// interleaved export bytes, which for consecutive lanes are consecutive in memory.
+//   grid.y strides over images, grid.x strides over the HW/4 pixel groups of an image.
+// ------------------------------------------------------------------------------------------
+template <int KIND, int U8>
+__global__ __launch_bounds__(kBlock) void pgd_step_vec4(const float4* __restrict__ x, const float4* __restrict__ g,
+                                                        const float4* __restrict__ cl, float4* xo, long long n_img,
+                                                        int hw4, int w, SpaceK sp, float alpha, float eps, U8Dst u8) {
+  for (long long img = blockIdx.y; img < n_img; img += gridDim.y) {
+    const long long plane0 = img * 3LL * hw4;
+    for (int q = blockIdx.x * kBlock + threadIdx.x; q < hw4; q += gridDim.x * kBlock) {
+      float4 X[3], G[3], C[3], O[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const long long i = plane0 + static_cast<long long>(c) * hw4 + q;
+        X[c] = x[i];
+        G[c] = g[i];
+        C[c] = cl[i];
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        O[c].x = pgd_elem<KIND>(X[c].x, G[c].x, C[c].x, sp.scale[c], sp.shift[c], sp.lo[c], sp.hi[c], alpha, eps);
+        O[c].y = pgd_elem<KIND>(X[c].y, G[c].y, C[c].y, sp.scale[c], sp.shift[c], sp.lo[c], sp.hi[c], alpha, eps);
+        O[c].z = pgd_elem<KIND>(X[c].z, G[c].z, C[c].z, sp.scale[c], sp.shift[c], sp.lo[c], sp.hi[c], alpha, eps);
+        O[c].w = pgd_elem<KIND>(X[c].w, G[c].w, C[c].w, sp.scale[c], sp.shift[c], sp.lo[c], sp.hi[c], alpha, eps);
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) xo[plane0 + static_cast<long long>(c) * hw4 + q] = O[c];
+
+      if (U8 == U8_ROWS_DWORD) {  // w % 4 == 0, whole rows, every address 4-byte aligned
+        const int p = q * 4;
+        const int row = p / w;
+        if (row < u8.crop_h) {
+          const int col = p - row * w;
+          uint3* dst = reinterpret_cast<uint3*>(u8.base + img * u8.image_stride + row * u8.row_stride + col * 3LL);
+          *dst = pack_hwc4<KIND>(O, sp);
+        }
+      } else if (U8 == U8_BYTES) {  // any pitch / crop: per-pixel byte stores
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int p = q * 4 + j;
+          const int row = p / w;
+          const int col = p - row * w;
+          if (row < u8.crop_h && col < u8.ncols) {
+            uint8_t* dst = u8.base + img * u8.image_stride + row * u8.row_stride + col * 3LL;
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+              dst[c] = static_cast<uint8_t>(export_byte<KIND>(comp(O[c], j), sp.scale[c], sp.shift[c], sp.export_add[c]));
+          }
+        }
+      }
+    }
+  }
+}
+
+// general shapes (HW % 4 != 0 or pointers not 16-byte aligned): one pixel (3 channels) per lane
+template <int KIND>
+__global__ __launch_bounds__(kBlock) void pgd_step_scalar(const float* __restrict__ x, const float* __restrict__ g,
+                                                          const float* __restrict__ cl, float* xo, long long n_img,
+                                                          int hw, int w, SpaceK sp, float alpha, float eps, U8Dst u8) {
+  for (long long img = blockIdx.y; img < n_img; img += gridDim.y) {
+    const long long plane0 = img * 3LL * hw;
+    for (int p = blockIdx.x * kBlock + threadIdx.x; p < hw; p += gridDim.x * kBlock) {
+      float o[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const long long i = plane0 + static_cast<long long>(c) * hw + p;
+        o[c] = pgd_elem<KIND>(x[i], g[i], cl[i], sp.scale[c], sp.shift[c], sp.lo[c], sp.hi[c], alpha, eps);
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) xo[plane0 + static_cast<long long>(c) * hw + p] = o[c];
+      if (u8.base != nullptr) {
+        const int row = p / w;
+        const int col = p - row * w;
+        if (row < u8.crop_h && col < u8.ncols) {
+          uint8_t* dst = u8.base + img * u8.image_stride + row * u8.row_stride + col * 3LL;
+#pragma unroll
+          for (int c = 0; c < 3; ++c)
+            dst[c] = static_cast<uint8_t>(export_byte<KIND>(o[c], sp.scale[c], sp.shift[c], sp.export_add[c]));
+        }
+      }
+    }
+  }
+}
+
+// K5 alone: read the image once, write the HWC bytes
+template <int KIND>
+__global__ __launch_bounds__(kBlock) void export_u8_kernel(const float* __restrict__ x, long long n_img, int hw, int w,
+                                                           SpaceK sp, U8Dst u8, int dword_rows) {
+  for (long long img = blockIdx.y; img < n_img; img += gridDim.y) {
+    const long long plane0 = img * 3LL * hw;
+    if (dword_rows) {  // hw % 4 == 0, w % 4 == 0, x 16-byte aligned, aligned pitches
+      const int hw4 = hw >> 2;
+      const float4* x4 = reinterpret_cast<const float4*>(x + plane0);
+      for (int q = blockIdx.x * kBlock + threadIdx.x; q < hw4; q += gridDim.x * kBlock) {
+        const int p = q * 4;
+        const int row = p / w;
+        if (row >= u8.crop_h) break;  // rows only grow with q
+        float4 O[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) O[c] = x4[static_cast<long long>(c) * hw4 + q];
+        const int col = p - row * w;
+        uint3* dst = reinterpret_cast<uint3*>(u8.base + img * u8.image_stride + row * u8.row_stride + col * 3LL);
+        *dst = pack_hwc4<KIND>(O, sp);
+      }
+    } else {
+      for (int p = blockIdx.x * kBlock + threadIdx.x; p < hw; p += gridDim.x * kBlock) {
+        const int row = p / w;
+        const int col = p - row * w;
+        if (row < u8.crop_h && col < u8.ncols) {
+          uint8_t* dst = u8.base + img * u8.image_stride + row * u8.row_stride + col * 3LL;
+#pragma unroll
+          for (int c = 0; c < 3; ++c)
+            dst[c] = static_cast<uint8_t>(
+                export_byte<KIND>(x[plane0 + static_cast<long long>(c) * hw + p], sp.scale[c], sp.shift[c], sp.export_add[c]));
+        }
+      }
+    }
+  }
+}
+
+// a1 / a2: per-channel affine maps.  DIR 0: x*scale+shift, DIR 1: (x-shift)/scale
+template <int DIR>
+__device__ __forceinline__ float affine_elem(float x, float sc, float sh) {
+  if (DIR == 0) {
+    float d = x * sc;
+    return d + sh;
+  }
+  return (x - sh) / sc;
+}
+
+template <int DIR>
+__global__ __launch_bounds__(kBlock) void affine_kernel(const float* __restrict__ x, float* out, long long n_img, int hw,
+                                                        SpaceK sp, int vec4) {
+  for (long long img = blockIdx.y; img < n_img; img += gridDim.y) {
+    const long long plane0 = img * 3LL * hw;
+    if (vec4) {
+      const int hw4 = hw >> 2;
+      const float4* x4 = reinterpret_cast<const float4*>(x + plane0);
+      float4* o4 = reinterpret_cast<float4*>(out + plane0);
+      for (int q = blockIdx.x * kBlock + threadIdx.x; q < hw4; q += gridDim.x * kBlock) {
+        float4 X[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) X[c] = x4[static_cast<long long>(c) * hw4 + q];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          float4 o;
+          o.x = affine_elem<DIR>(X[c].x, sp.scale[c], sp.shift[c]);
+          o.y = affine_elem<DIR>(X[c].y, sp.scale[c], sp.shift[c]);
+          o.z = affine_elem<DIR>(X[c].z, sp.scale[c], sp.shift[c]);
+          o.w = affine_elem<DIR>(X[c].w, sp.scale[c], sp.shift[c]);
+          o4[static_cast<long long>(c) * hw4 + q] = o;
+        }
+      }
+    } else {
+      for (int p = blockIdx.x * kBlock + threadIdx.x; p < hw; p += gridDim.x * kBlock) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const long long i = plane0 + static_cast<long long>(c) * hw + p;
+          out[i] = affine_elem<DIR>(x[i], sp.scale[c], sp.shift[c]);
+        }
+      }
+    }
+  }
+}
+
+// a7: the disc mask as a tensor (for callers that still want one)
+__global__ __launch_bounds__(kBlock) void disc_mask_kernel(float* mask, int h, int w, int cy, int cx, long long r2) {
+  const int total = h * w;
+  for (int p = blockIdx.x * kBlock + threadIdx.x; p < total; p += gridDim.x * kBlock) {
+    const int y = p / w;
+    const int x = p - y * w;
+    const long long dy = y - cy, dx = x - cx;
+    mask[p] = (dy * dy + dx * dx <= r2) ? 1.0f : 0.0f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K3: patch paste.  Only the d x d bounding square is touched; the mask is analytic.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void paste_elem(float* img_plane, const float* patch_plane, int w, int d, int r, int i, int j,
+                                           int y, int x) {
+  const int dy = i - r, dx = j - r;
+  const float m = (dy * dy + dx * dx <= r * r) ? 1.0f : 0.0f;  // mask_l, patch_attack.py:245-248
+  const float one_minus = 1.0f - m;                             // (1 - mask_l)
+  float* px = img_plane + static_cast<long long>(y) * w + x;
+  const float a = one_minus * (*px);                            // torch.mul((1 - mask_l), imgL.data)
+  const float b = m * patch_plane[i * d + j];                   // torch.mul(mask_l, patch_l)
+  *px = a + b;
+}
+
+__global__ __launch_bounds__(kBlock) void patch_paste_kernel(float* img, const float* __restrict__ patch, long long n_img,
+                                                             int h, int w, int d, int r, int cy0, int cx0,
+                                                             const int32_t* __restrict__ centers) {
+  const int dd = d * d;
+  for (long long b = blockIdx.y; b < n_img; b += gridDim.y) {
+    const int cy = centers ? centers[2 * b] : cy0;
+    const int cx = centers ? centers[2 * b + 1] : cx0;
+    for (int e = blockIdx.x * kBlock + threadIdx.x; e < 3 * dd; e += gridDim.x * kBlock) {
+      const int c = e / dd;
+      const int ij = e - c * dd;
+      const int i = ij / d;
+      const int j = ij - i * d;
+      const int y = cy - r + i, x = cx - r + j;
+      if (y < 0 || y >= h || x < 0 || x >= w) continue;
+      paste_elem(img + (b * 3 + c) * static_cast<long long>(h) * w, patch + static_cast<long long>(c) * dd, w, d, r, i, j, y, x);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K4: patch delta / update.  One lane per patch element; the n image pairs are folded in
+// index order so the float32 sum is reproducible.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float delta_elem(const float* gl, const float* gr, long long b, int c, int h, int w, int i,
+                                            int j, int cy, int cxl, int cxr, int r, float half_alpha, float eps) {
+  const int y = cy - r + i;
+  const long long plane = (b * 3 + c) * static_cast<long long>(h) * w + static_cast<long long>(y) * w;
+  const float s = gl[plane + (cxl - r + j)] + gr[plane + (cxr - r + j)];  // imgL_grad + imgR_grad
+  return t_clamp(half_alpha * s, -eps, eps);                              // clamp(0.5*alpha*(...), -eps, eps)
+}
+
+struct Lim3 {
+  float lo[3];
+  float hi[3];
+  int on;
+};
+
+// MODE 0: patch update for one pair (scalar centres); MODE 1: summed delta of n pairs (device centres)
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void patch_delta_kernel(float* patch, const float* __restrict__ gl,
+                                                             const float* __restrict__ gr, long long n_pairs, int h, int w,
+                                                             int d, int r, int cy0, int cxl0, int cxr0,
+                                                             const int32_t* __restrict__ centers, float half_alpha,
+                                                             float eps, Lim3 lim, float* delta_out) {
+  const int dd = d * d;
+  const int e = blockIdx.x * kBlock + threadIdx.x;
+  if (e >= 3 * dd) return;
+  const int c = e / dd;
+  const int ij = e - c * dd;
+  const int i = ij / d;
+  const int j = ij - i * d;
+  if (MODE == 0) {
+    const float dl = delta_elem(gl, gr, 0, c, h, w, i, j, cy0, cxl0, cxr0, r, half_alpha, eps);
+    float p = patch[e] - dl;  // patch -= ...
+    if (lim.on) p = t_clamp(p, lim.lo[c], lim.hi[c]);
+    patch[e] = p;
+    if (delta_out) delta_out[e] = dl;
+  } else {
+    float acc = 0.0f;
+    for (long long b = 0; b < n_pairs; ++b) {
+      const int cy = centers[3 * b], cxl = centers[3 * b + 1], cxr = centers[3 * b + 2];
+      float dl = 0.0f;
+      const bool ok = cy - r >= 0 && cy + r < h && cxl - r >= 0 && cxl + r < w && cxr - r >= 0 && cxr + r < w;
+      if (ok) dl = delta_elem(gl, gr, b, c, h, w, i, j, cy, cxl, cxr, r, half_alpha, eps);
+      acc = (b == 0) ? dl : acc + dl;
+    }
+    delta_out[e] = acc;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void patch_apply_kernel(float* patch, const float* __restrict__ delta, int d, Lim3 lim) {
+  const int dd = d * d;
+  const int e = blockIdx.x * kBlock + threadIdx.x;
+  if (e >= 3 * dd) return;
+  float p = patch[e] - delta[e];
+  if (lim.on) p = t_clamp(p, lim.lo[e / dd], lim.hi[e / dd]);
+  patch[e] = p;
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+inline bool aligned(const void* p, uintptr_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
+
+inline SpaceK to_kernel_space(const adv_space_t* s) {
+  SpaceK k;
+  for (int c = 0; c < 3; ++c) {
+    k.scale[c] = s->scale[c];
+    k.shift[c] = s->shift[c];
+    k.lo[c] = s->lo[c];
+    k.hi[c] = s->hi[c];
+    k.export_add[c] = s->export_add[c];
+  }
+  return k;
+}
+
+inline int finish_launch() {
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    g_last_hip_error = static_cast<int>(e);
+    return ADV_ELAUNCH;
+  }
+  return ADV_OK;
+}
+
+// Streaming kernels: cap the grid near 256 CUs x 8 resident blocks and stride over the rest
+// (cdna_hip_programming.md Guideline 11).
+inline dim3 stream_grid(long long work_items_per_image, long long n_img) {
+  long long bx = (work_items_per_image + kBlock - 1) / kBlock;
+  if (bx < 1) bx = 1;
+  long long by = n_img < 1 ? 1 : n_img;
+  const long long kTarget = 256LL * 16;
+  if (by > 65535) by = 65535;
+  if (bx * by > kTarget) {
+    long long want_x = kTarget / by;
+    if (want_x < 1) want_x = 1;
+    if (want_x < bx) bx = want_x;
+  }
+  return dim3(static_cast<unsigned>(bx), static_cast<unsigned>(by), 1);
+}
+
+struct U8Plan {
+  U8Dst dst;
+  int mode;
+};
+
+inline int plan_u8(uint8_t* u8, int h, int w, int crop_h, int crop_w, long long row_stride, long long image_stride,
+                   bool vec_ok, U8Plan* out) {
+  out->dst = U8Dst{nullptr, 0, 0, 0, 0};
+  out->mode = U8_NONE;
+  if (u8 == nullptr) return ADV_OK;
+  if (crop_h < 1 || crop_h > h || crop_w < 1 || crop_w > w) return ADV_EINVAL;
+  if (row_stride < 3LL * crop_w) return ADV_EINVAL;
+  if (image_stride < row_stride * (crop_h - 1) + 3LL * crop_w) return ADV_EINVAL;
+  const bool whole_rows = row_stride >= 3LL * w;
+  out->dst = U8Dst{u8, row_stride, image_stride, crop_h, whole_rows ? w : crop_w};
+  const bool dword_ok = vec_ok && whole_rows && (w % 4 == 0) && (row_stride % 4 == 0) && (image_stride % 4 == 0) &&
+                        aligned(u8, 4) && image_stride >= row_stride * (crop_h - 1) + 3LL * w;
+  out->mode = dword_ok ? U8_ROWS_DWORD : U8_BYTES;
+  return ADV_OK;
+}
+
+inline int check_space(const adv_space_t* s) {
+  if (s == nullptr) return ADV_EINVAL;
+  if (s->kind != ADV_SPACE_AFFINE && s->kind != ADV_SPACE_IDENTITY) return ADV_EINVAL;
+  return ADV_OK;
+}
+
+template <int KIND>
+int launch_pgd(const float* x, const float* g, const float* cl, float* xo, long long n, int h, int w, const SpaceK& sp,
+               float alpha, float eps, uint8_t* u8, int crop_h, int crop_w, long long rs, long long is, hipStream_t st) {
+  const long long hw = static_cast<long long>(h) * w;
+  const bool vec = (hw % 4 == 0) && aligned(x, 16) && aligned(g, 16) && aligned(cl, 16) && aligned(xo, 16);
+  U8Plan plan;
+  const int rc = plan_u8(u8, h, w, crop_h, crop_w, rs, is, vec, &plan);
+  if (rc != ADV_OK) return rc;
+  if (vec) {
+    const int hw4 = static_cast<int>(hw / 4);
+    const dim3 grid = stream_grid(hw4, n);
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    const float4* c4 = reinterpret_cast<const float4*>(cl);
+    float4* o4 = reinterpret_cast<float4*>(xo);
+    if (plan.mode == U8_NONE)
+      hipLaunchKernelGGL((pgd_step_vec4<KIND, U8_NONE>), grid, dim3(kBlock), 0, st, x4, g4, c4, o4, n, hw4, w, sp, alpha, eps, plan.dst);
+    else if (plan.mode == U8_ROWS_DWORD)
+      hipLaunchKernelGGL((pgd_step_vec4<KIND, U8_ROWS_DWORD>), grid, dim3(kBlock), 0, st, x4, g4, c4, o4, n, hw4, w, sp, alpha, eps, plan.dst);
+    else
+      hipLaunchKernelGGL((pgd_step_vec4<KIND, U8_BYTES>), grid, dim3(kBlock), 0, st, x4, g4, c4, o4, n, hw4, w, sp, alpha, eps, plan.dst);
+  } else {
+    const dim3 grid = stream_grid(hw, n);
+    hipLaunchKernelGGL((pgd_step_scalar<KIND>), grid, dim3(kBlock), 0, st, x, g, cl, xo, n, static_cast<int>(hw), w, sp, alpha, eps, plan.dst);
+  }
+  return finish_launch();
+}
+
+inline Lim3 make_lim(const float* lo, const float* hi) {
+  Lim3 l;
+  l.on = (lo != nullptr && hi != nullptr) ? 1 : 0;
+  for (int c = 0; c < 3; ++c) {
+    l.lo[c] = l.on ? lo[c] : 0.0f;
+    l.hi[c] = l.on ? hi[c] : 0.0f;
+  }
+  return l;
+}
+
+inline bool window_inside(int h, int w, int cy, int cx, int r) {
+  return r >= 0 && cy - r >= 0 && cx - r >= 0 && cy + r < h && cx + r < w;
+}
+
+constexpr long long kMaxPlane = 1LL << 30;  // h*w fits comfortably in int
+
+}  // namespace
+
+// ==========================================================================================
+// C ABI
+// ==========================================================================================
+extern "C" {
+
+int adv_abi_version(void) { return ADV_ABI_VERSION; }
+
+int adv_last_hip_error(void) { return g_last_hip_error; }
+
+const char* adv_strerror(int code) {
+  switch (code) {
+    case ADV_OK: return "ok";
+    case ADV_EINVAL: return "invalid argument";
+    case ADV_EALIGN: return "float pointer not 4-byte aligned";
+    case ADV_ELAUNCH: return "HIP kernel launch failed (see adv_last_hip_error)";
+    default: return "unknown advengine error";
+  }
+}
+
+void adv_space_dsgn(adv_space_t* s) {
+  // attack/DSGN/pgd_attack.py:153-154; Python doubles rounded to float32 as torch does
+  const double mean[3] = {0.485, 0.456, 0.406};
+  const double stdv[3] = {0.229, 0.224, 0.225};
+  s->kind = ADV_SPACE_AFFINE;
+  for (int c = 0; c < 3; ++c) {
+    s->scale[c] = static_cast<float>(stdv[c]);
+    s->shift[c] = static_cast<float>(mean[c]);
+    s->lo[c] = 0.0f;  // torch.clamp(..., min=0, max=1), pgd_attack.py:349-350
+    s->hi[c] = 1.0f;
+    s->export_add[c] = 0.0;
+  }
+}
+
+void adv_space_srcnn(adv_space_t* s) {
+  // attack/Stereo-RCNN/pgd_attack.py:189-207: min=(0 - m_c), max=(255 - m_c) as Python doubles
+  const double m[3] = {102.9801, 115.9465, 122.7717};
+  s->kind = ADV_SPACE_IDENTITY;
+  for (int c = 0; c < 3; ++c) {
+    s->scale[c] = 1.0f;
+    s->shift[c] = 0.0f;
+    s->lo[c] = static_cast<float>(0 - m[c]);
+    s->hi[c] = static_cast<float>(255 - m[c]);
+    s->export_add[c] = m[c];
+  }
+}
+
+static int check_image_args(const void* a, const void* b, long long n, int h, int w) {
+  if (a == nullptr || b == nullptr) return ADV_EINVAL;
+  if (n < 1 || h < 1 || w < 1 || static_cast<long long>(h) * w > kMaxPlane) return ADV_EINVAL;
+  if (!aligned(a, 4) || !aligned(b, 4)) return ADV_EALIGN;
+  return ADV_OK;
+}
+
+static int launch_affine(int dir, const float* x, float* out, int64_t n, int h, int w, const adv_space_t* space,
+                         adv_stream_t stream) {
+  int rc = check_image_args(x, out, n, h, w);
+  if (rc != ADV_OK) return rc;
+  rc = check_space(space);
+  if (rc != ADV_OK) return rc;
+  if (space->kind != ADV_SPACE_AFFINE) return ADV_EINVAL;
+  const long long hw = static_cast<long long>(h) * w;
+  const int vec = (hw % 4 == 0) && aligned(x, 16) && aligned(out, 16);
+  const dim3 grid = stream_grid(vec ? hw / 4 : hw, n);
+  const SpaceK sp = to_kernel_space(space);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dir == 0)
+    hipLaunchKernelGGL((affine_kernel<0>), grid, dim3(kBlock), 0, st, x, out, static_cast<long long>(n), static_cast<int>(hw), sp, vec);
+  else
+    hipLaunchKernelGGL((affine_kernel<1>), grid, dim3(kBlock), 0, st, x, out, static_cast<long long>(n), static_cast<int>(hw), sp, vec);
+  return finish_launch();
+}
+
+int adv_denormalize_f32(const float* x, float* out, int64_t n, int h, int w, const adv_space_t* space, adv_stream_t stream) {
+  return launch_affine(0, x, out, n, h, w, space, stream);
+}
+
+int adv_normalize_f32(const float* x, float* out, int64_t n, int h, int w, const adv_space_t* space, adv_stream_t stream) {
+  return launch_affine(1, x, out, n, h, w, space, stream);
+}
+
+int adv_pgd_step_f32(const float* x, const float* grad, const float* clean, float* x_out, uint8_t* u8_out, int64_t n,
+                     int h, int w, const adv_space_t* space, float alpha, float eps, int crop_h, int crop_w,
+                     int64_t u8_row_stride, int64_t u8_image_stride, adv_stream_t stream) {
+  int rc = check_image_args(x, x_out, n, h, w);
+  if (rc != ADV_OK) return rc;
+  rc = check_image_args(grad, clean, n, h, w);
+  if (rc != ADV_OK) return rc;
+  rc = check_space(space);
+  if (rc != ADV_OK) return rc;
+  if (!(eps >= 0.0f)) return ADV_EINVAL;  // also rejects NaN
+  const SpaceK sp = to_kernel_space(space);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (space->kind == ADV_SPACE_AFFINE)
+    return launch_pgd<ADV_SPACE_AFFINE>(x, grad, clean, x_out, n, h, w, sp, alpha, eps, u8_out, crop_h, crop_w, u8_row_stride, u8_image_stride, st);
+  return launch_pgd<ADV_SPACE_IDENTITY>(x, grad, clean, x_out, n, h, w, sp, alpha, eps, u8_out, crop_h, crop_w, u8_row_stride, u8_image_stride, st);
+}
+
+int adv_export_u8_f32(const float* x, uint8_t* u8_out, int64_t n, int h, int w, const adv_space_t* space, int crop_h,
+                      int crop_w, int64_t u8_row_stride, int64_t u8_image_stride, adv_stream_t stream) {
+  int rc = check_image_args(x, u8_out, n, h, w);
+  if (rc == ADV_EALIGN && aligned(x, 4)) rc = ADV_OK;  // the byte destination needs no alignment
+  if (rc != ADV_OK) return rc;
+  rc = check_space(space);
+  if (rc != ADV_OK) return rc;
+  const long long hw = static_cast<long long>(h) * w;
+  const bool vec = (hw % 4 == 0) && aligned(x, 16);
+  U8Plan plan;
+  rc = plan_u8(u8_out, h, w, crop_h, crop_w, u8_row_stride, u8_image_stride, vec, &plan);
+  if (rc != ADV_OK) return rc;
+  const int dword_rows = plan.mode == U8_ROWS_DWORD ? 1 : 0;
+  const dim3 grid = stream_grid(dword_rows ? hw / 4 : hw, n);
+  const SpaceK sp = to_kernel_space(space);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (space->kind == ADV_SPACE_AFFINE)
+    hipLaunchKernelGGL((export_u8_kernel<ADV_SPACE_AFFINE>), grid, dim3(kBlock), 0, st, x, static_cast<long long>(n), static_cast<int>(hw), w, sp, plan.dst, dword_rows);
+  else
+    hipLaunchKernelGGL((export_u8_kernel<ADV_SPACE_IDENTITY>), grid, dim3(kBlock), 0, st, x, static_cast<long long>(n), static_cast<int>(hw), w, sp, plan.dst, dword_rows);
+  return finish_launch();
+}
+
+int adv_disc_mask_f32(float* mask_out, int h, int w, int cy, int cx, int r, adv_stream_t stream) {
+  if (mask_out == nullptr || h < 1 || w < 1 || r < 0 || static_cast<long long>(h) * w > kMaxPlane) return ADV_EINVAL;
+  if (!aligned(mask_out, 4)) return ADV_EALIGN;
+  const dim3 grid = stream_grid(static_cast<long long>(h) * w, 1);
+  hipLaunchKernelGGL(disc_mask_kernel, grid, dim3(kBlock), 0, static_cast<hipStream_t>(stream), mask_out, h, w, cy, cx,
+                     static_cast<long long>(r) * r);
+  return finish_launch();
+}
+
+static int check_patch_args(const void* a, const void* b, int h, int w, int d, int r) {
+  if (a == nullptr || b == nullptr) return ADV_EINVAL;
+  if (h < 1 || w < 1 || r < 0 || d != 2 * r + 1 || d > h || d > w || static_cast<long long>(h) * w > kMaxPlane) return ADV_EINVAL;
+  if (!aligned(a, 4) || !aligned(b, 4)) return ADV_EALIGN;
+  return ADV_OK;
+}
+
+int adv_patch_paste_f32(float* img, const float* patch, int h, int w, int d, int cy, int cx, int r, adv_stream_t stream) {
+  const int rc = check_patch_args(img, patch, h, w, d, r);
+  if (rc != ADV_OK) return rc;
+  if (!window_inside(h, w, cy, cx, r)) return ADV_EINVAL;
+  const dim3 grid((3 * d * d + kBlock - 1) / kBlock, 1, 1);
+  hipLaunchKernelGGL(patch_paste_kernel, grid, dim3(kBlock), 0, static_cast<hipStream_t>(stream), img, patch, 1LL, h, w, d, r, cy, cx,
+                     static_cast<const int32_t*>(nullptr));
+  return finish_launch();
+}
+
+int adv_patch_paste_batch_f32(float* img, const float* patch, int64_t n, int h, int w, int d, const int32_t* centers, int r,
+                              adv_stream_t stream) {
+  const int rc = check_patch_args(img, patch, h, w, d, r);
+  if (rc != ADV_OK) return rc;
+  if (centers == nullptr || n < 1) return ADV_EINVAL;
+  if (!aligned(centers, 4)) return ADV_EALIGN;
+  const dim3 grid((3 * d * d + kBlock - 1) / kBlock, static_cast<unsigned>(n > 65535 ? 65535 : n), 1);
+  hipLaunchKernelGGL(patch_paste_kernel, grid, dim3(kBlock), 0, static_cast<hipStream_t>(stream), img, patch, static_cast<long long>(n), h, w,
+                     d, r, 0, 0, centers);
+  return finish_launch();
+}
+
+int adv_patch_update_f32(float* patch, const float* grad_l, const float* grad_r, int h, int w, int d, int cy, int cx_l,
+                         int cx_r, int r, float half_alpha, float eps, const float* lo, const float* hi, float* delta_out,
+                         adv_stream_t stream) {
+  int rc = check_patch_args(patch, grad_l, h, w, d, r);
+  if (rc != ADV_OK) return rc;
+  if (grad_r == nullptr || (lo == nullptr) != (hi == nullptr) || !(eps >= 0.0f)) return ADV_EINVAL;
+  if (!aligned(grad_r, 4) || (delta_out && !aligned(delta_out, 4))) return ADV_EALIGN;
+  if (!window_inside(h, w, cy, cx_l, r) || !window_inside(h, w, cy, cx_r, r)) return ADV_EINVAL;
+  const dim3 grid((3 * d * d + kBlock - 1) / kBlock, 1, 1);
+  hipLaunchKernelGGL((patch_delta_kernel<0>), grid, dim3(kBlock), 0, static_cast<hipStream_t>(stream), patch, grad_l, grad_r, 1LL, h, w, d,
+                     r, cy, cx_l, cx_r, static_cast<const int32_t*>(nullptr), half_alpha, eps, make_lim(lo, hi), delta_out);
+  return finish_launch();
+}
+
+int adv_patch_delta_batch_f32(const float* grad_l, const float* grad_r, int64_t n, int h, int w, int d, const int32_t* centers,
+                              int r, float half_alpha, float eps, float* delta_out, adv_stream_t stream) {
+  int rc = check_patch_args(grad_l, grad_r, h, w, d, r);
+  if (rc != ADV_OK) return rc;
+  if (centers == nullptr || delta_out == nullptr || n < 1 || !(eps >= 0.0f)) return ADV_EINVAL;
+  if (!aligned(centers, 4) || !aligned(delta_out, 4)) return ADV_EALIGN;
+  const dim3 grid((3 * d * d + kBlock - 1) / kBlock, 1, 1);
+  hipLaunchKernelGGL((patch_delta_kernel<1>), grid, dim3(kBlock), 0, static_cast<hipStream_t>(stream), static_cast<float*>(nullptr), grad_l,
+                     grad_r, static_cast<long long>(n), h, w, d, r, 0, 0, 0, centers, half_alpha, eps, make_lim(nullptr, nullptr), delta_out);
+  return finish_launch();
+}
+
+int adv_patch_apply_f32(float* patch, const float* delta, int d, const float* lo, const float* hi, adv_stream_t stream) {
+  if (patch == nullptr || delta == nullptr || d < 1 || (lo == nullptr) != (hi == nullptr)) return ADV_EINVAL;
+  if (!aligned(patch, 4) || !aligned(delta, 4)) return ADV_EALIGN;
+  const dim3 grid((3 * d * d + kBlock - 1) / kBlock, 1, 1);
+  hipLaunchKernelGGL(patch_apply_kernel, grid, dim3(kBlock), 0, static_cast<hipStream_t>(stream), patch, delta, d, make_lim(lo, hi));
+  return finish_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,281 @@
+"""Host-side operators over torch ROCm tensors -> libadvengine.so.
+
+Each function is the counterpart of one inline block of the reference's attack scripts (cited
+per function, paths relative to the reference root) and keeps its argument meaning.  Tensors
+stay where they are: the kernels are enqueued on the caller's current torch stream, nothing
+is copied, allocated (except a result tensor when ``out`` is not given) or synchronised.
+
+torch is plumbing here (device memory + streams); all arithmetic is in the HIP library.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import AdvSpace
+
+_lib.load()  # fail at import time if the HIP library is not built
+
+
+class Space:
+    """Per-channel pixel space (adv_space_t)."""
+
+    def __init__(self, c_space, name):
+        self.c = c_space
+        self.name = name
+
+    @staticmethod
+    def dsgn():
+        """ImageNet-normalised RGB in [0,1]: attack/DSGN/pgd_attack.py:153-154,196-207,349-350."""
+        s = AdvSpace()
+        _lib.load().adv_space_dsgn(ctypes.byref(s))
+        return Space(s, "dsgn_norm01")
+
+    @staticmethod
+    def srcnn():
+        """BGR minus PIXEL_MEANS on 0..255: attack/Stereo-RCNN/pgd_attack.py:189-207."""
+        s = AdvSpace()
+        _lib.load().adv_space_srcnn(ctypes.byref(s))
+        return Space(s, "srcnn_meansub255")
+
+    @property
+    def affine(self):
+        return self.c.kind == _lib.ADV_SPACE_AFFINE
+
+    @property
+    def lo(self):
+        return tuple(self.c.lo)
+
+    @property
+    def hi(self):
+        return tuple(self.c.hi)
+
+    def ref(self):
+        return ctypes.byref(self.c)
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _img(t, name):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda):
+        raise TypeError("%s must be a CUDA/ROCm tensor (there is no CPU path)" % name)
+    if t.dtype != torch.float32:
+        raise TypeError("%s must be float32, got %s" % (name, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    if t.dim() == 3:
+        t = t.unsqueeze(0)
+    if t.dim() != 4 or t.shape[1] != 3:
+        raise ValueError("%s must be [N,3,H,W] or [3,H,W], got %s" % (name, tuple(t.shape)))
+    return t
+
+
+def _same(a, b, na, nb):
+    if a.shape != b.shape or a.device != b.device:
+        raise ValueError("%s %s/%s and %s %s/%s differ" % (na, tuple(a.shape), a.device, nb, tuple(b.shape), b.device))
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _f3(v):
+    return None if v is None else (ctypes.c_float * 3)(*[float(x) for x in v])
+
+
+class _on:
+    """make the tensor's device current for the launch (no-op in the one-process-per-GPU case)"""
+
+    def __init__(self, t):
+        self.dev = t.device
+        self.ctx = None
+
+    def __enter__(self):
+        if torch.cuda.current_device() != self.dev.index:
+            self.ctx = torch.cuda.device(self.dev)
+            self.ctx.__enter__()
+
+    def __exit__(self, *a):
+        if self.ctx is not None:
+            self.ctx.__exit__(*a)
+
+
+# --------------------------------------------------------------------------------------------
+def denormalize(x, space, out=None):
+    """attack/DSGN/pgd_attack.py:196-200 for every image of the batch; ``out=x`` is in place."""
+    xi = _img(x, "x")
+    out = torch.empty_like(x) if out is None else out
+    oi = _img(out, "out")
+    _same(xi, oi, "x", "out")
+    n, _, h, w = xi.shape
+    with _on(x):
+        _lib.call("adv_denormalize_f32", _ptr(xi), _ptr(oi), n, h, w, space.ref(), _stream(x))
+    return out
+
+
+def normalize(x, space, out=None):
+    """attack/DSGN/pgd_attack.py:203-207."""
+    xi = _img(x, "x")
+    out = torch.empty_like(x) if out is None else out
+    oi = _img(out, "out")
+    _same(xi, oi, "x", "out")
+    n, _, h, w = xi.shape
+    with _on(x):
+        _lib.call("adv_normalize_f32", _ptr(xi), _ptr(oi), n, h, w, space.ref(), _stream(x))
+    return out
+
+
+def alloc_u8(n, crop_h, w, device):
+    """Export buffer with whole (uncropped-width) rows: [n, crop_h, w, 3] uint8."""
+    return torch.empty((n, crop_h, w, 3), dtype=torch.uint8, device=device)
+
+
+def _u8_args(u8, n, h, w, crop):
+    if u8 is None:
+        return ctypes.c_void_p(0), h, w, 0, 0
+    crop_h, crop_w = crop if crop is not None else (h, w)
+    if u8.dtype != torch.uint8 or not u8.is_cuda or u8.dim() != 4 or u8.shape[0] != n or u8.shape[3] != 3:
+        raise ValueError("u8_out must be a CUDA uint8 tensor [n, rows, cols, 3]")
+    if u8.stride(3) != 1 or u8.stride(2) != 3:
+        raise ValueError("u8_out pixels must be packed HWC")
+    if u8.shape[1] < crop_h or u8.shape[2] < crop_w:
+        raise ValueError("u8_out %s is smaller than the crop %s" % (tuple(u8.shape), (crop_h, crop_w)))
+    row_stride = u8.stride(1)
+    if u8.shape[2] < w:                       # dense cropped rows: only crop_w columns exist
+        if row_stride < 3 * crop_w:
+            raise ValueError("u8_out rows are too short")
+        if row_stride >= 3 * w:               # cannot happen for a contiguous tensor; keep the ABI rule explicit
+            raise ValueError("ambiguous u8 pitch")
+    return _ptr(u8), crop_h, crop_w, row_stride, u8.stride(0)
+
+
+def pgd_step(x, grad, clean, space, alpha, eps, out=None, u8_out=None, crop=None):
+    """One PGD/FGSM step for a batch of images in one pass over memory.
+
+    DSGN (affine space):  attack/DSGN/pgd_attack.py:339-354 - x is the normalised image the
+    detector saw, grad = x.grad, clean the DENORMALISED clean image (:297-298).
+    Stereo R-CNN (identity space): attack/Stereo-RCNN/pgd_attack.py:177-217 - eps is already
+    ``255 * args.eps`` (:57).
+
+    ``out`` (default: new tensor; pass ``x`` for in place) receives the next iterate;
+    ``u8_out`` (optional, ``alloc_u8``) the 8-bit HWC image the reference would write to PNG
+    for it (DSGN tensor2im, pgd_attack.py:157-179; Stereo R-CNN :233-237), rows/cols beyond
+    ``crop=(h, w)`` being padding.
+    """
+    xi, gi, ci = _img(x, "x"), _img(grad, "grad"), _img(clean, "clean")
+    _same(xi, gi, "x", "grad")
+    _same(xi, ci, "x", "clean")
+    out = torch.empty_like(x) if out is None else out
+    oi = _img(out, "out")
+    _same(xi, oi, "x", "out")
+    n, _, h, w = xi.shape
+    u8p, crop_h, crop_w, rs, is_ = _u8_args(u8_out, n, h, w, crop)
+    with _on(x):
+        _lib.call("adv_pgd_step_f32", _ptr(xi), _ptr(gi), _ptr(ci), _ptr(oi), u8p, n, h, w, space.ref(),
+                  float(alpha), float(eps), crop_h, crop_w, rs, is_, _stream(x))
+    return out
+
+
+def export_u8(x, space, crop=None, out=None):
+    """The 8-bit HWC image of ``x`` as the reference saves it (iterate 0 = the clean pair,
+    attack/DSGN/pgd_attack.py:279-294).  Returns [n, crop_h, W, 3]; columns >= crop_w are padding."""
+    xi = _img(x, "x")
+    n, _, h, w = xi.shape
+    crop = (h, w) if crop is None else crop
+    out = alloc_u8(n, crop[0], w, x.device) if out is None else out
+    u8p, crop_h, crop_w, rs, is_ = _u8_args(out, n, h, w, crop)
+    with _on(x):
+        _lib.call("adv_export_u8_f32", _ptr(xi), u8p, n, h, w, space.ref(), crop_h, crop_w, rs, is_, _stream(x))
+    return out
+
+
+def disc_mask(h, w, cy, cx, radius, device):
+    """generate_round_mask's mask (attack/DSGN/patch_attack.py:245-248) as float32 [h,w]."""
+    out = torch.empty((h, w), dtype=torch.float32, device=device)
+    with _on(out):
+        _lib.call("adv_disc_mask_f32", _ptr(out), h, w, int(cy), int(cx), int(radius), _stream(out))
+    return out
+
+
+def _patch(p, name="patch"):
+    if not (isinstance(p, torch.Tensor) and p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+        raise TypeError("%s must be a contiguous float32 CUDA tensor" % name)
+    if p.dim() == 4 and p.shape[0] == 1:
+        p = p[0]
+    if p.dim() != 3 or p.shape[0] != 3 or p.shape[1] != p.shape[2] or p.shape[1] % 2 != 1:
+        raise ValueError("%s must be [1,3,D,D] or [3,D,D] with D odd, got %s" % (name, tuple(p.shape)))
+    return p
+
+
+def patch_paste(img, patch, cy, cx, radius):
+    """In-place paste of the round patch into ONE image,
+    attack/DSGN/patch_attack.py:326-333,369-376 (Stereo R-CNN :178-185,221-230)."""
+    ii, pp = _img(img, "img"), _patch(patch)
+    if ii.shape[0] != 1:
+        raise ValueError("patch_paste takes one image; use patch_paste_batch")
+    _, _, h, w = ii.shape
+    with _on(img):
+        _lib.call("adv_patch_paste_f32", _ptr(ii), _ptr(pp), h, w, pp.shape[1], int(cy), int(cx), int(radius), _stream(img))
+    return img
+
+
+def _centers(c, n, k):
+    if not (isinstance(c, torch.Tensor) and c.is_cuda and c.dtype == torch.int32 and c.is_contiguous()
+            and tuple(c.shape) == (n, k)):
+        raise TypeError("centers must be a contiguous int32 CUDA tensor [%d,%d]" % (n, k))
+    return c
+
+
+def patch_paste_batch(img, patch, centers, radius):
+    """Paste into every image of [N,3,H,W]; ``centers`` int32 [N,2] = (cy, cx) on the device."""
+    ii, pp = _img(img, "img"), _patch(patch)
+    n, _, h, w = ii.shape
+    cc = _centers(centers, n, 2)
+    with _on(img):
+        _lib.call("adv_patch_paste_batch_f32", _ptr(ii), _ptr(pp), n, h, w, pp.shape[1], _ptr(cc), int(radius), _stream(img))
+    return img
+
+
+def patch_update(patch, grad_l, grad_r, cy, cx_l, cx_r, radius, eps, alpha=1e3, lo=None, hi=None, delta_out=None):
+    """In-place per-image patch update, attack/DSGN/patch_attack.py:416-430; with lo/hi the
+    Stereo R-CNN per-channel clamp follows (attack/Stereo-RCNN/patch_attack.py:257-281)."""
+    pp = _patch(patch)
+    gl, gr = _img(grad_l, "grad_l"), _img(grad_r, "grad_r")
+    _same(gl, gr, "grad_l", "grad_r")
+    if gl.shape[0] != 1:
+        raise ValueError("patch_update takes one image pair; use patch_delta_batch + patch_apply")
+    _, _, h, w = gl.shape
+    dp = ctypes.c_void_p(0) if delta_out is None else _ptr(_patch(delta_out, "delta_out"))
+    with _on(patch):
+        _lib.call("adv_patch_update_f32", _ptr(pp), _ptr(gl), _ptr(gr), h, w, pp.shape[1], int(cy), int(cx_l), int(cx_r),
+                  int(radius), float(0.5 * alpha), float(eps), _f3(lo), _f3(hi), dp, _stream(patch))
+    return patch
+
+
+def patch_delta_batch(grad_l, grad_r, centers, radius, eps, alpha=1e3, out=None):
+    """Sum over N image pairs of clamp(0.5*alpha*(gL_win + gR_win), +-eps), evaluated against one
+    patch snapshot (data-parallel form of patch_attack.py:416-430).  centers int32 [N,3] =
+    (cy, cxL, cxR).  Returns [3,D,D] - the buffer the multi-GPU all-reduce carries."""
+    gl, gr = _img(grad_l, "grad_l"), _img(grad_r, "grad_r")
+    _same(gl, gr, "grad_l", "grad_r")
+    n, _, h, w = gl.shape
+    cc = _centers(centers, n, 3)
+    d = 2 * int(radius) + 1
+    out = torch.empty((3, d, d), dtype=torch.float32, device=gl.device) if out is None else out
+    oo = _patch(out, "out")
+    with _on(gl):
+        _lib.call("adv_patch_delta_batch_f32", _ptr(gl), _ptr(gr), n, h, w, d, _ptr(cc), int(radius), float(0.5 * alpha),
+                  float(eps), _ptr(oo), _stream(gl))
+    return out
+
+
+def patch_apply(patch, delta, lo=None, hi=None):
+    """patch -= delta, then the optional per-channel clamp (second half of patch_update)."""
+    pp, dd = _patch(patch), _patch(delta, "delta")
+    if pp.shape != dd.shape:
+        raise ValueError("patch and delta shapes differ")
+    with _on(patch):
+        _lib.call("adv_patch_apply_f32", _ptr(pp), _ptr(dd), pp.shape[1], _f3(lo), _f3(hi), _stream(patch))
+    return patch

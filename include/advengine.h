@@ -1,0 +1,148 @@
+/*
+ * advengine.h - C ABI of libadvengine.so, the MI355X (gfx950) perturbation engine.
+ *
+ * The reference (DexterJZ/eval_driving_safety) has no FFI: its hot path is inline
+ * torch code inside four scripts.  Each entry point below replaces one such block and
+ * cites it (paths relative to the reference root).  INTEGRATION.md shows the ctypes
+ * stub a maintainer would add to the reference scripts to call them.
+ *
+ * Conventions (all entry points)
+ *   - every image pointer is DEVICE memory owned by the caller, float32, contiguous
+ *     NCHW with C = ADV_CHANNELS = 3;  `n` counts [3,H,W] images, so a stereo batch of
+ *     B pairs is n = 2B (or two calls with n = B);
+ *   - enqueue-only on `stream` (a hipStream_t; NULL = the null stream): no allocation,
+ *     no synchronisation, no host read-back, safe to capture in a hipGraph;
+ *   - no global state; safe to call from several host threads on different streams;
+ *   - returns 0 or a negative ADV_E* code; nothing is launched when an error is
+ *     returned;  adv_last_hip_error() gives the hipError_t behind ADV_ELAUNCH;
+ *   - results are bit-identical to the reference's torch-CPU arithmetic (float32,
+ *     every operation rounded separately, true division, NaN-propagating clamp).
+ */
+#ifndef ADVENGINE_H
+#define ADVENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADV_ABI_VERSION 1
+#define ADV_CHANNELS 3
+
+#define ADV_OK 0
+#define ADV_EINVAL (-22)  /* bad argument: null pointer, non-positive size, window outside the image ... */
+#define ADV_EALIGN (-14)  /* a float pointer is not 4-byte aligned */
+#define ADV_ELAUNCH (-5)  /* hipLaunchKernel failed; see adv_last_hip_error() */
+
+typedef void* adv_stream_t; /* hipStream_t */
+
+/* Pixel space of the stored image, per channel.
+ *   ADV_SPACE_AFFINE    stored = (pixel - shift) / scale with pixel in [lo, hi]
+ *                       (DSGN: ImageNet-normalised RGB, pixel in [0,1];
+ *                        attack/DSGN/pgd_attack.py:153-154,196-207)
+ *   ADV_SPACE_IDENTITY  stored = pixel, pixel in [lo, hi]
+ *                       (Stereo R-CNN: BGR minus PIXEL_MEANS on the 0..255 scale;
+ *                        attack/Stereo-RCNN/pgd_attack.py:189-207) */
+enum { ADV_SPACE_AFFINE = 0, ADV_SPACE_IDENTITY = 1 };
+
+typedef struct adv_space {
+  int32_t kind;
+  float scale[3];
+  float shift[3];
+  float lo[3];
+  float hi[3];
+  double export_add[3]; /* IDENTITY only: added in float64 before the 8-bit conversion
+                           (cfg.PIXEL_MEANS, attack/Stereo-RCNN/pgd_attack.py:236) */
+} adv_space_t;
+
+/* Fill `s` with the reference's constants. */
+void adv_space_dsgn(adv_space_t* s);  /* mean/std of attack/DSGN/pgd_attack.py:153-154, range [0,1] */
+void adv_space_srcnn(adv_space_t* s); /* range [-m_c, 255-m_c], m = (102.9801,115.9465,122.7717) */
+
+int adv_abi_version(void);
+const char* adv_strerror(int code);
+int adv_last_hip_error(void); /* thread-local */
+
+/* a1  denormalize(), attack/DSGN/pgd_attack.py:196-200 :  out = x * scale_c + shift_c.
+ *     (The reference touches batch element 0 only; here all n images.)  out may alias x.
+ *     AFFINE spaces only. */
+int adv_denormalize_f32(const float* x, float* out, int64_t n, int h, int w,
+                        const adv_space_t* space, adv_stream_t stream);
+
+/* a2  normalize(), attack/DSGN/pgd_attack.py:203-207 :  out = (x - shift_c) / scale_c. */
+int adv_normalize_f32(const float* x, float* out, int64_t n, int h, int w,
+                      const adv_space_t* space, adv_stream_t stream);
+
+/* a3 / a13 (+ a5)  one PGD / FGSM step for n images in ONE pass over memory.
+ *   AFFINE   attack/DSGN/pgd_attack.py:339-354
+ *            d = x*scale+shift; a = d + alpha*sign(grad); eta = clamp(a - clean, +-eps);
+ *            y = clamp(clean + eta, lo, hi); x_out = (y - shift)/scale
+ *   IDENTITY attack/Stereo-RCNN/pgd_attack.py:177-217
+ *            a = x + alpha*sign(grad); eta = clamp(a - clean, +-eps);
+ *            x_out = clamp(clean + eta, lo_c, hi_c)            (eps already times 255, :57)
+ *   x, grad, clean, x_out : [n,3,h,w].  `clean` is in pixel space (the DENORMALISED clean
+ *   image for AFFINE, pgd_attack.py:297-298).  x_out may alias x (in place).
+ *   sign(nan) = sign(+-0) = 0 as torch.sign; clamp propagates NaN as torch.clamp.
+ *   u8_out (nullable): the 8-bit HWC image the reference writes to PNG for this iterate,
+ *     AFFINE   tensor2im, attack/DSGN/pgd_attack.py:157-179: trunc(((x_out*scale+shift)*255))
+ *     IDENTITY attack/Stereo-RCNN/pgd_attack.py:233-237: sat_u8(rint(float32(x_out + export_add)))
+ *   rows [0,crop_h) and columns [0,crop_w) of image i go to
+ *     u8_out + i*u8_image_stride + row*u8_row_stride + col*3      (strides in bytes).
+ *   With u8_row_stride >= 3*w whole rows (all w columns) are stored, which keeps every
+ *   store aligned; the columns >= crop_w are then padding the consumer crops away
+ *   (save_img's crop, pgd_attack.py:192). */
+int adv_pgd_step_f32(const float* x, const float* grad, const float* clean, float* x_out,
+                     uint8_t* u8_out, int64_t n, int h, int w, const adv_space_t* space,
+                     float alpha, float eps, int crop_h, int crop_w, int64_t u8_row_stride,
+                     int64_t u8_image_stride, adv_stream_t stream);
+
+/* a5  the 8-bit export alone (iterate 0 = the clean image, pgd_attack.py:279-294). */
+int adv_export_u8_f32(const float* x, uint8_t* u8_out, int64_t n, int h, int w,
+                      const adv_space_t* space, int crop_h, int crop_w, int64_t u8_row_stride,
+                      int64_t u8_image_stride, adv_stream_t stream);
+
+/* a7  generate_round_mask's mask, attack/DSGN/patch_attack.py:245-248: float32 [h,w],
+ *     1.0 where (y-cy)^2 + (x-cx)^2 <= r^2 (equal to the reference's float64 sqrt test). */
+int adv_disc_mask_f32(float* mask_out, int h, int w, int cy, int cx, int r, adv_stream_t stream);
+
+/* a8  patch paste, attack/DSGN/patch_attack.py:326-333,369-376 (Stereo R-CNN :178-185,221-230):
+ *     img = (1-M)*img + M*pad0(patch), M the disc of radius r centred (cy,cx), patch [3,d,d],
+ *     d = 2r+1.  Evaluated literally on the d x d bounding square; outside it the reference
+ *     computes 1*img + 0*0, i.e. leaves img as it is (a -0.0 there would become +0.0 in the
+ *     reference and stays -0.0 here - the only deviation).  In place.  One image. */
+int adv_patch_paste_f32(float* img, const float* patch, int h, int w, int d, int cy, int cx,
+                        int r, adv_stream_t stream);
+
+/* a8 batched: image i of [n,3,h,w] gets the patch at (centers[2i], centers[2i+1]) = (cy,cx);
+ *     `centers` is DEVICE int32 [n,2].  Elements whose target falls outside the image are
+ *     skipped. */
+int adv_patch_paste_batch_f32(float* img, const float* patch, int64_t n, int h, int w, int d,
+                              const int32_t* centers, int r, adv_stream_t stream);
+
+/* a11 / a12  the reference's per-image patch update in one launch,
+ *     attack/DSGN/patch_attack.py:416-430, attack/Stereo-RCNN/patch_attack.py:257-281:
+ *     delta = clamp(half_alpha * (gradL[win(cy,cxL)] + gradR[win(cy,cxR)]), +-eps);
+ *     patch = patch - delta;  if lo/hi given (HOST float[3]):  patch_c = clamp(patch_c, lo_c, hi_c).
+ *     win = the (2r+1)^2 bounding SQUARE (not the disc).  half_alpha = 0.5*alpha = 500 in the
+ *     reference.  delta_out (nullable, [3,d,d]) receives delta. */
+int adv_patch_update_f32(float* patch, const float* grad_l, const float* grad_r, int h, int w,
+                         int d, int cy, int cx_l, int cx_r, int r, float half_alpha, float eps,
+                         const float* lo, const float* hi, float* delta_out, adv_stream_t stream);
+
+/* data-parallel form of a11: the clamped deltas of n image pairs evaluated against one patch
+ *     snapshot, summed in index order:  delta_out = d_0 + d_1 + ... + d_{n-1}  ([3,d,d]).
+ *     centers: DEVICE int32 [n,3] = (cy, cxL, cxR).  This buffer is what the RCCL all-reduce
+ *     of the universal-patch attack carries. */
+int adv_patch_delta_batch_f32(const float* grad_l, const float* grad_r, int64_t n, int h, int w,
+                              int d, const int32_t* centers, int r, float half_alpha, float eps,
+                              float* delta_out, adv_stream_t stream);
+
+/* second half of a11/a12:  patch = patch - delta;  optional per-channel clamp (HOST float[3]). */
+int adv_patch_apply_f32(float* patch, const float* delta, int d, const float* lo,
+                        const float* hi, adv_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADVENGINE_H */

@@ -148,13 +148,15 @@ def srcnn_hwc_plus_means(x):
 
 def srcnn_export_u8(x):
     """What ``cv2.imwrite`` (pgd_attack.py:237) stores for the float32 HWC image of
-    ``srcnn_hwc_plus_means``: OpenCV converts to 8-bit with saturate_cast, i.e. round
-    half to even then clip to [0, 255].  UNPINNED: cv2 is not in the reference tree nor
-    in this image; this follows OpenCV's documented conversion."""
+    ``srcnn_hwc_plus_means``: OpenCV converts to 8-bit with saturate_cast<uchar>(float) =
+    cvRound (round half to even; on x86-64 a value that does not fit int32, or NaN, becomes
+    INT_MIN) then clip to [0, 255].  UNPINNED: cv2 is neither in the reference tree nor in this
+    image; this follows OpenCV's documented conversion."""
     f = srcnn_hwc_plus_means(x)
     with np.errstate(invalid="ignore"):
-        r = np.rint(f.astype(np.float64))
-    r = np.where(np.isnan(r), 0, r)
+        ok = np.abs(f) < F32(2147483648.0)
+        r = np.rint(np.where(ok, f, F32(0)).astype(np.float64))
+    r = np.where(ok, r, -1.0)
     return np.clip(r, 0, 255).astype(np.uint8)
 
 
