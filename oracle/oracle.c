@@ -1,0 +1,153 @@
+/*
+ * ORACLE - plain-C restatement of the reference's perturbation inner loop.
+ *
+ * TEST INFRASTRUCTURE ONLY: linked by nothing under eval_driving_safety_amd/.  Used by tests/
+ * (as a second, independent checker beside oracle_np.py) and by bench.py's cpu_baseline leg
+ * (kind "port").  Parity status: PINNED - tests/test_oracle_golden.py compares every function
+ * with golden vectors computed by the reference's own statements (tests/golden/make_golden.py).
+ *
+ * Build: gcc -O3 -ffp-contract=off -fopenmp (see Makefile).  No -ffast-math: every float
+ * operation rounds on its own, exactly as the separate torch kernels of the reference do.
+ * Citations are relative to /root/reference.
+ */
+#include <math.h>
+#include <stdint.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* attack/DSGN/pgd_attack.py:153-154 (Python doubles, used as float32 by torch) */
+static const double kMean[3] = {0.485, 0.456, 0.406};
+static const double kStd[3] = {0.229, 0.224, 0.225};
+/* attack/Stereo-RCNN/pgd_attack.py:189-207 */
+static const double kPixelMeans[3] = {102.9801, 115.9465, 122.7717};
+
+static inline float t_sign(float g) { return (float)(g > 0.0f) - (float)(g < 0.0f); } /* torch.sign */
+static inline float t_clamp(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); } /* NaN stays */
+
+int orc_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+/* attack/DSGN/pgd_attack.py:196-200, all n images */
+void orc_denormalize(const float* x, float* out, long n, long hw) {
+#pragma omp parallel for schedule(static)
+  for (long pc = 0; pc < n * 3; ++pc) {
+    const int c = (int)(pc % 3);
+    const float sc = (float)kStd[c], sh = (float)kMean[c];
+    const float* xi = x + pc * hw;
+    float* oi = out + pc * hw;
+    for (long i = 0; i < hw; ++i) {
+      const float d = xi[i] * sc;
+      oi[i] = d + sh;
+    }
+  }
+}
+
+/* attack/DSGN/pgd_attack.py:203-207 */
+void orc_normalize(const float* x, float* out, long n, long hw) {
+#pragma omp parallel for schedule(static)
+  for (long pc = 0; pc < n * 3; ++pc) {
+    const int c = (int)(pc % 3);
+    const float sc = (float)kStd[c], sh = (float)kMean[c];
+    const float* xi = x + pc * hw;
+    float* oi = out + pc * hw;
+    for (long i = 0; i < hw; ++i) oi[i] = (xi[i] - sh) / sc;
+  }
+}
+
+/* attack/DSGN/pgd_attack.py:339-354 */
+void orc_pgd_step_norm01(const float* x, const float* g, const float* clean, float* out, long n, long hw,
+                         float alpha, float eps) {
+#pragma omp parallel for schedule(static)
+  for (long pc = 0; pc < n * 3; ++pc) {
+    const int c = (int)(pc % 3);
+    const float sc = (float)kStd[c], sh = (float)kMean[c];
+    const long o = pc * hw;
+    for (long i = 0; i < hw; ++i) {
+      float d = x[o + i] * sc;                               /* :339 denormalize */
+      d = d + sh;
+      const float step = alpha * t_sign(g[o + i]);
+      const float a = d + step;                              /* :343 */
+      const float eta = t_clamp(a - clean[o + i], -eps, eps); /* :346 */
+      const float y = t_clamp(clean[o + i] + eta, 0.0f, 1.0f); /* :349 */
+      out[o + i] = (y - sh) / sc;                            /* :353 normalize */
+    }
+  }
+}
+
+/* attack/Stereo-RCNN/pgd_attack.py:177-217; eps already times 255 (:57) */
+void orc_pgd_step_meansub255(const float* x, const float* g, const float* clean, float* out, long n, long hw,
+                             float alpha, float eps) {
+#pragma omp parallel for schedule(static)
+  for (long pc = 0; pc < n * 3; ++pc) {
+    const int c = (int)(pc % 3);
+    const float lo = (float)(0 - kPixelMeans[c]), hi = (float)(255 - kPixelMeans[c]);
+    const long o = pc * hw;
+    for (long i = 0; i < hw; ++i) {
+      const float step = alpha * t_sign(g[o + i]);
+      const float a = x[o + i] + step;                        /* :177 */
+      const float eta = t_clamp(a - clean[o + i], -eps, eps); /* :181 */
+      const float holder = clean[o + i] + eta;                /* :186 */
+      out[o + i] = t_clamp(holder, lo, hi);                   /* :189-207 */
+    }
+  }
+}
+
+/* attack/DSGN/pgd_attack.py:157-193: one [3,h,w] image -> uint8 [crop_h,crop_w,3], truncating */
+void orc_tensor2im_u8(const float* x, uint8_t* out, int h, int w, int crop_h, int crop_w) {
+  const long hw = (long)h * w;
+#pragma omp parallel for schedule(static)
+  for (int r = 0; r < crop_h; ++r) {
+    for (int col = 0; col < crop_w; ++col) {
+      for (int c = 0; c < 3; ++c) {
+        float v = x[c * hw + (long)r * w + col] * (float)kStd[c]; /* :174 */
+        v = v + (float)kMean[c];
+        v = v * 255.0f;                                           /* :175 */
+        int iv = 0;                                               /* :179 astype(uint8): cvttss2si, low byte */
+        if (fabsf(v) < 2147483648.0f) iv = (int)v;
+        out[((long)r * crop_w + col) * 3 + c] = (uint8_t)(iv & 0xff);
+      }
+    }
+  }
+}
+
+/* attack/DSGN/patch_attack.py:326-333,369-376 over the WHOLE image, as the reference does */
+void orc_patch_paste(float* img, const float* patch, int h, int w, int cy, int cx, int r) {
+  const int d = 2 * r + 1;
+#pragma omp parallel for schedule(static)
+  for (int cyy = 0; cyy < 3 * h; ++cyy) {
+    const int c = cyy / h, y = cyy % h;
+    for (int x = 0; x < w; ++x) {
+      const double dy = y - cy, dx = x - cx;
+      const float m = (sqrt(dy * dy + dx * dx) <= (double)r) ? 1.0f : 0.0f; /* :245-248 */
+      const int i = y - (cy - r), j = x - (cx - r);
+      const float p = (i >= 0 && i < d && j >= 0 && j < d) ? patch[(c * d + i) * d + j] : 0.0f; /* ConstantPad2d */
+      float* px = img + ((long)c * h + y) * w + x;
+      const float a = (1.0f - m) * (*px);
+      const float b = m * p;
+      *px = a + b;
+    }
+  }
+}
+
+/* attack/DSGN/patch_attack.py:416-430 (+ attack/Stereo-RCNN/patch_attack.py:272-281 when lo/hi given) */
+void orc_patch_update(float* patch, const float* gl, const float* gr, int h, int w, int cy, int cxl, int cxr, int r,
+                      float half_alpha, float eps, const float* lo, const float* hi, float* delta_out) {
+  const int d = 2 * r + 1;
+  for (int c = 0; c < 3; ++c)
+    for (int i = 0; i < d; ++i)
+      for (int j = 0; j < d; ++j) {
+        const long row = ((long)c * h + (cy - r + i)) * w;
+        const float s = gl[row + cxl - r + j] + gr[row + cxr - r + j];
+        const float dl = t_clamp(half_alpha * s, -eps, eps);
+        float p = patch[(c * d + i) * d + j] - dl;
+        if (lo) p = t_clamp(p, lo[c], hi[c]);
+        patch[(c * d + i) * d + j] = p;
+        if (delta_out) delta_out[(c * d + i) * d + j] = dl;
+      }
+}

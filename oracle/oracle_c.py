@@ -1,0 +1,91 @@
+"""ctypes face of oracle/oracle.c with the same function names as oracle_np (the subset the
+CPU baseline and the cross-check tests use).  TEST INFRASTRUCTURE ONLY - see oracle.c."""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PATH = os.path.join(_HERE, "_build", "liboracle.so")
+if not os.path.exists(_PATH):
+    raise ImportError("oracle/_build/liboracle.so not built (make -C oracle)")
+_lib = ctypes.CDLL(_PATH)
+_fp = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+_u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+_lib.orc_num_threads.restype = ctypes.c_int
+_lib.orc_denormalize.argtypes = [_fp, _fp, ctypes.c_long, ctypes.c_long]
+_lib.orc_normalize.argtypes = [_fp, _fp, ctypes.c_long, ctypes.c_long]
+_lib.orc_pgd_step_norm01.argtypes = [_fp, _fp, _fp, _fp, ctypes.c_long, ctypes.c_long, ctypes.c_float, ctypes.c_float]
+_lib.orc_pgd_step_meansub255.argtypes = _lib.orc_pgd_step_norm01.argtypes
+_lib.orc_tensor2im_u8.argtypes = [_fp, _u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+_lib.orc_patch_paste.argtypes = [_fp, _fp] + [ctypes.c_int] * 5
+_lib.orc_patch_update.argtypes = [_fp, _fp, _fp] + [ctypes.c_int] * 6 + [ctypes.c_float, ctypes.c_float,
+                                                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+for _f in ("orc_denormalize", "orc_normalize", "orc_pgd_step_norm01", "orc_pgd_step_meansub255", "orc_tensor2im_u8",
+           "orc_patch_paste", "orc_patch_update"):
+    getattr(_lib, _f).restype = None
+
+
+def num_threads():
+    return _lib.orc_num_threads()
+
+
+def _nhw(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    assert a.ndim == 4 and a.shape[1] == 3
+    return a, a.shape[0], a.shape[2] * a.shape[3]
+
+
+def denormalize(im):
+    a, n, hw = _nhw(im)
+    out = np.empty_like(a)
+    _lib.orc_denormalize(a, out, n, hw)
+    return out
+
+
+def normalize(im):
+    a, n, hw = _nhw(im)
+    out = np.empty_like(a)
+    _lib.orc_normalize(a, out, n, hw)
+    return out
+
+
+def pgd_step_norm01(x, grad, clean, alpha, eps):
+    a, n, hw = _nhw(x)
+    out = np.empty_like(a)
+    _lib.orc_pgd_step_norm01(a, np.ascontiguousarray(grad), np.ascontiguousarray(clean), out, n, hw, alpha, eps)
+    return out
+
+
+def pgd_step_meansub255(x, grad, clean, alpha, eps255):
+    a, n, hw = _nhw(x)
+    out = np.empty_like(a)
+    _lib.orc_pgd_step_meansub255(a, np.ascontiguousarray(grad), np.ascontiguousarray(clean), out, n, hw, alpha, eps255)
+    return out
+
+
+def tensor2im_u8(x_norm, crop_h, crop_w):
+    a = np.ascontiguousarray(x_norm, dtype=np.float32)
+    assert a.ndim == 3 and a.shape[0] == 3
+    out = np.empty((crop_h, crop_w, 3), np.uint8)
+    _lib.orc_tensor2im_u8(a, out, a.shape[1], a.shape[2], crop_h, crop_w)
+    return out
+
+
+def patch_paste(img, patch, cy, cx, radius):
+    out = np.array(img, dtype=np.float32, copy=True)
+    assert out.shape[0] == 1
+    _lib.orc_patch_paste(out, np.ascontiguousarray(patch, dtype=np.float32), out.shape[2], out.shape[3], cy, cx, radius)
+    return out
+
+
+def patch_update(patch, grad_l, grad_r, cy, cx_l, cx_r, radius, eps, alpha=1e3, lo=None, hi=None):
+    out = np.array(patch, dtype=np.float32, copy=True)
+    gl, gr = np.ascontiguousarray(grad_l, dtype=np.float32), np.ascontiguousarray(grad_r, dtype=np.float32)
+    assert gl.shape[0] == 1
+    lo_a = None if lo is None else (ctypes.c_float * 3)(*[float(v) for v in lo])
+    hi_a = None if hi is None else (ctypes.c_float * 3)(*[float(v) for v in hi])
+    _lib.orc_patch_update(out, gl, gr, gl.shape[2], gl.shape[3], cy, cx_l, cx_r, radius, 0.5 * alpha, eps,
+                          None if lo_a is None else ctypes.cast(lo_a, ctypes.c_void_p),
+                          None if hi_a is None else ctypes.cast(hi_a, ctypes.c_void_p), None)
+    return out
