@@ -21,7 +21,22 @@ namespace {
 
 thread_local int g_last_hip_error = 0;
 
-constexpr int kBlock = 256;  // 4 waves of 64: one per SIMD of a CU
+constexpr int kBlock = 256;  // small / irregular kernels: 4 waves of 64, one per SIMD of a CU
+
+// Streaming kernels (measured on MI355X with tools/k1_tune.hip, 512 KITTI-shaped images resident,
+// profiles/r01_k1_tuning.md): ONE wave per workgroup, every lane owning kUnroll pixel groups half an
+// image apart, one workgroup per such pair of tiles (no capped grid, no multi-trip loop), and
+// non-temporal loads AND stores (nothing is re-read before the next detector pass) ran at
+// 6.0-6.3 TB/s algorithmic against 4.65 TB/s for 256-thread blocks on a grid capped at 4096.
+constexpr int kWave = 64;
+constexpr int kUnroll = 2;
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef uint32_t v3u __attribute__((ext_vector_type(3)));
+
+__device__ __forceinline__ v4f ld_stream(const v4f* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void st_stream(v4f* p, v4f v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void st_stream(v3u* p, v3u v) { __builtin_nontemporal_store(v, p); }
 
 struct SpaceK {  // by-value kernel argument (lives in the kernarg segment -> scalar loads)
   float scale[3];
@@ -84,26 +99,6 @@ __device__ __forceinline__ uint32_t export_byte(float xo, float sc, float sh, do
   return round_sat_byte(f);
 }
 
-__device__ __forceinline__ float comp(const float4& v, int j) {
-  return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w));
-}
-
-// 4 pixels x 3 channels -> 12 interleaved bytes (HWC) in three dwords
-template <int KIND>
-__device__ __forceinline__ uint3 pack_hwc4(const float4 o[3], const SpaceK& sp) {
-  uint32_t b[12];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) b[j * 3 + c] = export_byte<KIND>(comp(o[c], j), sp.scale[c], sp.shift[c], sp.export_add[c]);
-  }
-  uint3 r;
-  r.x = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
-  r.y = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
-  r.z = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
-  return r;
-}
-
 enum U8Mode { U8_NONE = 0, U8_ROWS_DWORD = 1, U8_BYTES = 2 };
 
 struct U8Dst {
@@ -114,57 +109,90 @@ struct U8Dst {
   int ncols;  // columns stored per row: w when the pitch holds whole rows, else crop_w
 };
 
+// 4 pixels x 3 channels -> 12 interleaved bytes (HWC) in three dwords
+template <int KIND>
+__device__ __forceinline__ v3u pack_hwc4(const v4f o[3], const SpaceK& sp) {
+  uint32_t b[12];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) b[j * 3 + c] = export_byte<KIND>(o[c][j], sp.scale[c], sp.shift[c], sp.export_add[c]);
+  }
+  v3u r;
+  r[0] = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+  r[1] = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+  r[2] = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
+  return r;
+}
+
+// the export bytes of one pixel group q of image img (shared by the fused and stand-alone kernels)
+template <int KIND, int U8>
+__device__ __forceinline__ void store_u8_group(const v4f O[3], long long img, int q, int w, const SpaceK& sp, const U8Dst& u8) {
+  if (U8 == U8_ROWS_DWORD) {  // w % 4 == 0, whole rows, every address 4-byte aligned
+    const int p = q * 4;
+    const int row = p / w;
+    if (row < u8.crop_h) {
+      const int col = p - row * w;
+      st_stream(reinterpret_cast<v3u*>(u8.base + img * u8.image_stride + row * u8.row_stride + col * 3LL), pack_hwc4<KIND>(O, sp));
+    }
+  } else if (U8 == U8_BYTES) {  // any pitch / crop: per-pixel byte stores
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int p = q * 4 + j;
+      const int row = p / w;
+      const int col = p - row * w;
+      if (row < u8.crop_h && col < u8.ncols) {
+        uint8_t* dst = u8.base + img * u8.image_stride + row * u8.row_stride + col * 3LL;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          dst[c] = static_cast<uint8_t>(export_byte<KIND>(O[c][j], sp.scale[c], sp.shift[c], sp.export_add[c]));
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // K1/K2 (+K5 fused): one PGD step.  A lane owns 4 consecutive pixels of one image in all three
-// channel planes: nine independent 16-byte loads, three 16-byte stores, and (optionally) the 12
-// interleaved export bytes, which for consecutive lanes are consecutive in memory.
-//   grid.y strides over images, grid.x strides over the HW/4 pixel groups of an image.
+// channel planes (kUnroll such groups, half an image apart): 9 independent 16-byte loads per
+// group, three 16-byte stores, and (optionally) the 12 interleaved export bytes, which for
+// consecutive lanes are consecutive in memory.  grid.y = images, grid.x = tiles of 64 groups.
+// x_out may alias x: every lane reads its own elements before it writes them.
 // ------------------------------------------------------------------------------------------
 template <int KIND, int U8>
-__global__ __launch_bounds__(kBlock) void pgd_step_vec4(const float4* __restrict__ x, const float4* __restrict__ g,
-                                                        const float4* __restrict__ cl, float4* xo, long long n_img,
-                                                        int hw4, int w, SpaceK sp, float alpha, float eps, U8Dst u8) {
+__global__ __launch_bounds__(kWave) void pgd_step_vec4(const v4f* x, const v4f* __restrict__ g, const v4f* __restrict__ cl,
+                                                       v4f* xo, long long n_img, int hw4, int w, SpaceK sp, float alpha,
+                                                       float eps, U8Dst u8) {
+  const int stride = gridDim.x * kWave;
   for (long long img = blockIdx.y; img < n_img; img += gridDim.y) {
     const long long plane0 = img * 3LL * hw4;
-    for (int q = blockIdx.x * kBlock + threadIdx.x; q < hw4; q += gridDim.x * kBlock) {
-      float4 X[3], G[3], C[3], O[3];
+    for (int q0 = blockIdx.x * kWave + threadIdx.x; q0 < hw4; q0 += stride * kUnroll) {
+      v4f X[kUnroll][3], G[kUnroll][3], C[kUnroll][3];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const long long i = plane0 + static_cast<long long>(c) * hw4 + q;
-        X[c] = x[i];
-        G[c] = g[i];
-        C[c] = cl[i];
-      }
+      for (int u = 0; u < kUnroll; ++u) {
+        const int q = q0 + u * stride;
+        if (q < hw4) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        O[c].x = pgd_elem<KIND>(X[c].x, G[c].x, C[c].x, sp.scale[c], sp.shift[c], sp.lo[c], sp.hi[c], alpha, eps);
-        O[c].y = pgd_elem<KIND>(X[c].y, G[c].y, C[c].y, sp.scale[c], sp.shift[c], sp.lo[c], sp.hi[c], alpha, eps);
-        O[c].z = pgd_elem<KIND>(X[c].z, G[c].z, C[c].z, sp.scale[c], sp.shift[c], sp.lo[c], sp.hi[c], alpha, eps);
-        O[c].w = pgd_elem<KIND>(X[c].w, G[c].w, C[c].w, sp.scale[c], sp.shift[c], sp.lo[c], sp.hi[c], alpha, eps);
-      }
-#pragma unroll
-      for (int c = 0; c < 3; ++c) xo[plane0 + static_cast<long long>(c) * hw4 + q] = O[c];
-
-      if (U8 == U8_ROWS_DWORD) {  // w % 4 == 0, whole rows, every address 4-byte aligned
-        const int p = q * 4;
-        const int row = p / w;
-        if (row < u8.crop_h) {
-          const int col = p - row * w;
-          uint3* dst = reinterpret_cast<uint3*>(u8.base + img * u8.image_stride + row * u8.row_stride + col * 3LL);
-          *dst = pack_hwc4<KIND>(O, sp);
-        }
-      } else if (U8 == U8_BYTES) {  // any pitch / crop: per-pixel byte stores
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int p = q * 4 + j;
-          const int row = p / w;
-          const int col = p - row * w;
-          if (row < u8.crop_h && col < u8.ncols) {
-            uint8_t* dst = u8.base + img * u8.image_stride + row * u8.row_stride + col * 3LL;
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-              dst[c] = static_cast<uint8_t>(export_byte<KIND>(comp(O[c], j), sp.scale[c], sp.shift[c], sp.export_add[c]));
+          for (int c = 0; c < 3; ++c) {
+            const long long i = plane0 + static_cast<long long>(c) * hw4 + q;
+            X[u][c] = ld_stream(x + i);
+            G[u][c] = ld_stream(g + i);
+            C[u][c] = ld_stream(cl + i);
           }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        const int q = q0 + u * stride;
+        if (q < hw4) {
+          v4f O[3];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              O[c][j] = pgd_elem<KIND>(X[u][c][j], G[u][c][j], C[u][c][j], sp.scale[c], sp.shift[c], sp.lo[c], sp.hi[c], alpha, eps);
+            st_stream(xo + plane0 + static_cast<long long>(c) * hw4 + q, O[c]);
+          }
+          store_u8_group<KIND, U8>(O, img, q, w, sp, u8);
         }
       }
     }
@@ -203,35 +231,35 @@ __global__ __launch_bounds__(kBlock) void pgd_step_scalar(const float* __restric
 
 // K5 alone: read the image once, write the HWC bytes
 template <int KIND>
-__global__ __launch_bounds__(kBlock) void export_u8_kernel(const float* __restrict__ x, long long n_img, int hw, int w,
-                                                           SpaceK sp, U8Dst u8, int dword_rows) {
+__global__ __launch_bounds__(kWave) void export_u8_vec4(const v4f* __restrict__ x, long long n_img, int hw4, int w, SpaceK sp,
+                                                        U8Dst u8) {
+  const int stride = gridDim.x * kWave;
+  for (long long img = blockIdx.y; img < n_img; img += gridDim.y) {
+    const long long plane0 = img * 3LL * hw4;
+    for (int q = blockIdx.x * kWave + threadIdx.x; q < hw4; q += stride) {
+      if ((q * 4) / w >= u8.crop_h) break;  // rows only grow with q
+      v4f O[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) O[c] = ld_stream(x + plane0 + static_cast<long long>(c) * hw4 + q);
+      store_u8_group<KIND, U8_ROWS_DWORD>(O, img, q, w, sp, u8);
+    }
+  }
+}
+
+template <int KIND>
+__global__ __launch_bounds__(kBlock) void export_u8_scalar(const float* __restrict__ x, long long n_img, int hw, int w, SpaceK sp,
+                                                           U8Dst u8) {
   for (long long img = blockIdx.y; img < n_img; img += gridDim.y) {
     const long long plane0 = img * 3LL * hw;
-    if (dword_rows) {  // hw % 4 == 0, w % 4 == 0, x 16-byte aligned, aligned pitches
-      const int hw4 = hw >> 2;
-      const float4* x4 = reinterpret_cast<const float4*>(x + plane0);
-      for (int q = blockIdx.x * kBlock + threadIdx.x; q < hw4; q += gridDim.x * kBlock) {
-        const int p = q * 4;
-        const int row = p / w;
-        if (row >= u8.crop_h) break;  // rows only grow with q
-        float4 O[3];
+    for (int p = blockIdx.x * kBlock + threadIdx.x; p < hw; p += gridDim.x * kBlock) {
+      const int row = p / w;
+      const int col = p - row * w;
+      if (row < u8.crop_h && col < u8.ncols) {
+        uint8_t* dst = u8.base + img * u8.image_stride + row * u8.row_stride + col * 3LL;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) O[c] = x4[static_cast<long long>(c) * hw4 + q];
-        const int col = p - row * w;
-        uint3* dst = reinterpret_cast<uint3*>(u8.base + img * u8.image_stride + row * u8.row_stride + col * 3LL);
-        *dst = pack_hwc4<KIND>(O, sp);
-      }
-    } else {
-      for (int p = blockIdx.x * kBlock + threadIdx.x; p < hw; p += gridDim.x * kBlock) {
-        const int row = p / w;
-        const int col = p - row * w;
-        if (row < u8.crop_h && col < u8.ncols) {
-          uint8_t* dst = u8.base + img * u8.image_stride + row * u8.row_stride + col * 3LL;
-#pragma unroll
-          for (int c = 0; c < 3; ++c)
-            dst[c] = static_cast<uint8_t>(
-                export_byte<KIND>(x[plane0 + static_cast<long long>(c) * hw + p], sp.scale[c], sp.shift[c], sp.export_add[c]));
-        }
+        for (int c = 0; c < 3; ++c)
+          dst[c] = static_cast<uint8_t>(
+              export_byte<KIND>(x[plane0 + static_cast<long long>(c) * hw + p], sp.scale[c], sp.shift[c], sp.export_add[c]));
       }
     }
   }
@@ -248,35 +276,46 @@ __device__ __forceinline__ float affine_elem(float x, float sc, float sh) {
 }
 
 template <int DIR>
-__global__ __launch_bounds__(kBlock) void affine_kernel(const float* __restrict__ x, float* out, long long n_img, int hw,
-                                                        SpaceK sp, int vec4) {
+__global__ __launch_bounds__(kWave) void affine_vec4(const v4f* x, v4f* out, long long n_img, int hw4, SpaceK sp) {
+  const int stride = gridDim.x * kWave;
   for (long long img = blockIdx.y; img < n_img; img += gridDim.y) {
-    const long long plane0 = img * 3LL * hw;
-    if (vec4) {
-      const int hw4 = hw >> 2;
-      const float4* x4 = reinterpret_cast<const float4*>(x + plane0);
-      float4* o4 = reinterpret_cast<float4*>(out + plane0);
-      for (int q = blockIdx.x * kBlock + threadIdx.x; q < hw4; q += gridDim.x * kBlock) {
-        float4 X[3];
+    const long long plane0 = img * 3LL * hw4;
+    for (int q0 = blockIdx.x * kWave + threadIdx.x; q0 < hw4; q0 += stride * kUnroll) {
+      v4f X[kUnroll][3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) X[c] = x4[static_cast<long long>(c) * hw4 + q];
+      for (int u = 0; u < kUnroll; ++u) {
+        const int q = q0 + u * stride;
+        if (q < hw4) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          float4 o;
-          o.x = affine_elem<DIR>(X[c].x, sp.scale[c], sp.shift[c]);
-          o.y = affine_elem<DIR>(X[c].y, sp.scale[c], sp.shift[c]);
-          o.z = affine_elem<DIR>(X[c].z, sp.scale[c], sp.shift[c]);
-          o.w = affine_elem<DIR>(X[c].w, sp.scale[c], sp.shift[c]);
-          o4[static_cast<long long>(c) * hw4 + q] = o;
+          for (int c = 0; c < 3; ++c) X[u][c] = ld_stream(x + plane0 + static_cast<long long>(c) * hw4 + q);
         }
       }
-    } else {
-      for (int p = blockIdx.x * kBlock + threadIdx.x; p < hw; p += gridDim.x * kBlock) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const long long i = plane0 + static_cast<long long>(c) * hw + p;
-          out[i] = affine_elem<DIR>(x[i], sp.scale[c], sp.shift[c]);
+      for (int u = 0; u < kUnroll; ++u) {
+        const int q = q0 + u * stride;
+        if (q < hw4) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            v4f o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = affine_elem<DIR>(X[u][c][j], sp.scale[c], sp.shift[c]);
+            st_stream(out + plane0 + static_cast<long long>(c) * hw4 + q, o);
+          }
         }
+      }
+    }
+  }
+}
+
+template <int DIR>
+__global__ __launch_bounds__(kBlock) void affine_scalar(const float* x, float* out, long long n_img, int hw, SpaceK sp) {
+  for (long long img = blockIdx.y; img < n_img; img += gridDim.y) {
+    const long long plane0 = img * 3LL * hw;
+    for (int p = blockIdx.x * kBlock + threadIdx.x; p < hw; p += gridDim.x * kBlock) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const long long i = plane0 + static_cast<long long>(c) * hw + p;
+        out[i] = affine_elem<DIR>(x[i], sp.scale[c], sp.shift[c]);
       }
     }
   }
@@ -412,8 +451,15 @@ inline int finish_launch() {
   return ADV_OK;
 }
 
-// Streaming kernels: cap the grid near 256 CUs x 8 resident blocks and stride over the rest
-// (cdna_hip_programming.md Guideline 11).
+// Vector streaming kernels: one 64-lane workgroup per `unroll` tiles of 64 pixel groups, grid.y = images.
+inline dim3 wave_grid(long long groups_per_image, long long n_img, int unroll) {
+  long long bx = (groups_per_image + static_cast<long long>(kWave) * unroll - 1) / (static_cast<long long>(kWave) * unroll);
+  if (bx < 1) bx = 1;
+  long long by = n_img < 1 ? 1 : (n_img > 65535 ? 65535 : n_img);
+  return dim3(static_cast<unsigned>(bx), static_cast<unsigned>(by), 1);
+}
+
+// Scalar fall-back kernels (irregular shapes): 256-thread blocks, grid-stride beyond ~16 blocks per CU.
 inline dim3 stream_grid(long long work_items_per_image, long long n_img) {
   long long bx = (work_items_per_image + kBlock - 1) / kBlock;
   if (bx < 1) bx = 1;
@@ -465,17 +511,17 @@ int launch_pgd(const float* x, const float* g, const float* cl, float* xo, long 
   if (rc != ADV_OK) return rc;
   if (vec) {
     const int hw4 = static_cast<int>(hw / 4);
-    const dim3 grid = stream_grid(hw4, n);
-    const float4* x4 = reinterpret_cast<const float4*>(x);
-    const float4* g4 = reinterpret_cast<const float4*>(g);
-    const float4* c4 = reinterpret_cast<const float4*>(cl);
-    float4* o4 = reinterpret_cast<float4*>(xo);
+    const dim3 grid = wave_grid(hw4, n, kUnroll);
+    const v4f* x4 = reinterpret_cast<const v4f*>(x);
+    const v4f* g4 = reinterpret_cast<const v4f*>(g);
+    const v4f* c4 = reinterpret_cast<const v4f*>(cl);
+    v4f* o4 = reinterpret_cast<v4f*>(xo);
     if (plan.mode == U8_NONE)
-      hipLaunchKernelGGL((pgd_step_vec4<KIND, U8_NONE>), grid, dim3(kBlock), 0, st, x4, g4, c4, o4, n, hw4, w, sp, alpha, eps, plan.dst);
+      hipLaunchKernelGGL((pgd_step_vec4<KIND, U8_NONE>), grid, dim3(kWave), 0, st, x4, g4, c4, o4, n, hw4, w, sp, alpha, eps, plan.dst);
     else if (plan.mode == U8_ROWS_DWORD)
-      hipLaunchKernelGGL((pgd_step_vec4<KIND, U8_ROWS_DWORD>), grid, dim3(kBlock), 0, st, x4, g4, c4, o4, n, hw4, w, sp, alpha, eps, plan.dst);
+      hipLaunchKernelGGL((pgd_step_vec4<KIND, U8_ROWS_DWORD>), grid, dim3(kWave), 0, st, x4, g4, c4, o4, n, hw4, w, sp, alpha, eps, plan.dst);
     else
-      hipLaunchKernelGGL((pgd_step_vec4<KIND, U8_BYTES>), grid, dim3(kBlock), 0, st, x4, g4, c4, o4, n, hw4, w, sp, alpha, eps, plan.dst);
+      hipLaunchKernelGGL((pgd_step_vec4<KIND, U8_BYTES>), grid, dim3(kWave), 0, st, x4, g4, c4, o4, n, hw4, w, sp, alpha, eps, plan.dst);
   } else {
     const dim3 grid = stream_grid(hw, n);
     hipLaunchKernelGGL((pgd_step_scalar<KIND>), grid, dim3(kBlock), 0, st, x, g, cl, xo, n, static_cast<int>(hw), w, sp, alpha, eps, plan.dst);
@@ -562,14 +608,26 @@ static int launch_affine(int dir, const float* x, float* out, int64_t n, int h, 
   if (rc != ADV_OK) return rc;
   if (space->kind != ADV_SPACE_AFFINE) return ADV_EINVAL;
   const long long hw = static_cast<long long>(h) * w;
-  const int vec = (hw % 4 == 0) && aligned(x, 16) && aligned(out, 16);
-  const dim3 grid = stream_grid(vec ? hw / 4 : hw, n);
+  const bool vec = (hw % 4 == 0) && aligned(x, 16) && aligned(out, 16);
   const SpaceK sp = to_kernel_space(space);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (dir == 0)
-    hipLaunchKernelGGL((affine_kernel<0>), grid, dim3(kBlock), 0, st, x, out, static_cast<long long>(n), static_cast<int>(hw), sp, vec);
-  else
-    hipLaunchKernelGGL((affine_kernel<1>), grid, dim3(kBlock), 0, st, x, out, static_cast<long long>(n), static_cast<int>(hw), sp, vec);
+  const long long nn = n;
+  if (vec) {
+    const int hw4 = static_cast<int>(hw / 4);
+    const dim3 grid = wave_grid(hw4, nn, kUnroll);
+    const v4f* x4 = reinterpret_cast<const v4f*>(x);
+    v4f* o4 = reinterpret_cast<v4f*>(out);
+    if (dir == 0)
+      hipLaunchKernelGGL((affine_vec4<0>), grid, dim3(kWave), 0, st, x4, o4, nn, hw4, sp);
+    else
+      hipLaunchKernelGGL((affine_vec4<1>), grid, dim3(kWave), 0, st, x4, o4, nn, hw4, sp);
+  } else {
+    const dim3 grid = stream_grid(hw, nn);
+    if (dir == 0)
+      hipLaunchKernelGGL((affine_scalar<0>), grid, dim3(kBlock), 0, st, x, out, nn, static_cast<int>(hw), sp);
+    else
+      hipLaunchKernelGGL((affine_scalar<1>), grid, dim3(kBlock), 0, st, x, out, nn, static_cast<int>(hw), sp);
+  }
   return finish_launch();
 }
 
@@ -610,14 +668,24 @@ int adv_export_u8_f32(const float* x, uint8_t* u8_out, int64_t n, int h, int w, 
   U8Plan plan;
   rc = plan_u8(u8_out, h, w, crop_h, crop_w, u8_row_stride, u8_image_stride, vec, &plan);
   if (rc != ADV_OK) return rc;
-  const int dword_rows = plan.mode == U8_ROWS_DWORD ? 1 : 0;
-  const dim3 grid = stream_grid(dword_rows ? hw / 4 : hw, n);
   const SpaceK sp = to_kernel_space(space);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (space->kind == ADV_SPACE_AFFINE)
-    hipLaunchKernelGGL((export_u8_kernel<ADV_SPACE_AFFINE>), grid, dim3(kBlock), 0, st, x, static_cast<long long>(n), static_cast<int>(hw), w, sp, plan.dst, dword_rows);
-  else
-    hipLaunchKernelGGL((export_u8_kernel<ADV_SPACE_IDENTITY>), grid, dim3(kBlock), 0, st, x, static_cast<long long>(n), static_cast<int>(hw), w, sp, plan.dst, dword_rows);
+  const long long nn = n;
+  if (plan.mode == U8_ROWS_DWORD) {
+    const int hw4 = static_cast<int>(hw / 4);
+    const dim3 grid = wave_grid(static_cast<long long>(crop_h) * w / 4, nn, 1);
+    const v4f* x4 = reinterpret_cast<const v4f*>(x);
+    if (space->kind == ADV_SPACE_AFFINE)
+      hipLaunchKernelGGL((export_u8_vec4<ADV_SPACE_AFFINE>), grid, dim3(kWave), 0, st, x4, nn, hw4, w, sp, plan.dst);
+    else
+      hipLaunchKernelGGL((export_u8_vec4<ADV_SPACE_IDENTITY>), grid, dim3(kWave), 0, st, x4, nn, hw4, w, sp, plan.dst);
+  } else {
+    const dim3 grid = stream_grid(hw, nn);
+    if (space->kind == ADV_SPACE_AFFINE)
+      hipLaunchKernelGGL((export_u8_scalar<ADV_SPACE_AFFINE>), grid, dim3(kBlock), 0, st, x, nn, static_cast<int>(hw), w, sp, plan.dst);
+    else
+      hipLaunchKernelGGL((export_u8_scalar<ADV_SPACE_IDENTITY>), grid, dim3(kBlock), 0, st, x, nn, static_cast<int>(hw), w, sp, plan.dst);
+  }
   return finish_launch();
 }
 

@@ -25,6 +25,20 @@ static const double kPixelMeans[3] = {102.9801, 115.9465, 122.7717};
 static inline float t_sign(float g) { return (float)(g > 0.0f) - (float)(g < 0.0f); } /* torch.sign */
 static inline float t_clamp(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); } /* NaN stays */
 
+/* work split: (image, channel) planes x chunks of kChunk elements, so that a 2-image call still
+ * spreads over all cores */
+#define kChunk 16384L
+#define PLANE_CHUNK_LOOP(n, hw)                                             \
+  const long chunks_ = ((hw) + kChunk - 1) / kChunk;                        \
+  _Pragma("omp parallel for schedule(static)")                              \
+  for (long job_ = 0; job_ < (n) * 3 * chunks_; ++job_)
+
+#define PLANE_CHUNK_VARS(hw)                                                \
+  const long pc = job_ / chunks_;                                           \
+  const long i0 = (job_ % chunks_) * kChunk;                                \
+  const long i1 = (i0 + kChunk < (hw)) ? i0 + kChunk : (hw);                \
+  const int c = (int)(pc % 3);
+
 int orc_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();
@@ -35,13 +49,12 @@ int orc_num_threads(void) {
 
 /* attack/DSGN/pgd_attack.py:196-200, all n images */
 void orc_denormalize(const float* x, float* out, long n, long hw) {
-#pragma omp parallel for schedule(static)
-  for (long pc = 0; pc < n * 3; ++pc) {
-    const int c = (int)(pc % 3);
+  PLANE_CHUNK_LOOP(n, hw) {
+    PLANE_CHUNK_VARS(hw)
     const float sc = (float)kStd[c], sh = (float)kMean[c];
     const float* xi = x + pc * hw;
     float* oi = out + pc * hw;
-    for (long i = 0; i < hw; ++i) {
+    for (long i = i0; i < i1; ++i) {
       const float d = xi[i] * sc;
       oi[i] = d + sh;
     }
@@ -50,25 +63,23 @@ void orc_denormalize(const float* x, float* out, long n, long hw) {
 
 /* attack/DSGN/pgd_attack.py:203-207 */
 void orc_normalize(const float* x, float* out, long n, long hw) {
-#pragma omp parallel for schedule(static)
-  for (long pc = 0; pc < n * 3; ++pc) {
-    const int c = (int)(pc % 3);
+  PLANE_CHUNK_LOOP(n, hw) {
+    PLANE_CHUNK_VARS(hw)
     const float sc = (float)kStd[c], sh = (float)kMean[c];
     const float* xi = x + pc * hw;
     float* oi = out + pc * hw;
-    for (long i = 0; i < hw; ++i) oi[i] = (xi[i] - sh) / sc;
+    for (long i = i0; i < i1; ++i) oi[i] = (xi[i] - sh) / sc;
   }
 }
 
 /* attack/DSGN/pgd_attack.py:339-354 */
 void orc_pgd_step_norm01(const float* x, const float* g, const float* clean, float* out, long n, long hw,
                          float alpha, float eps) {
-#pragma omp parallel for schedule(static)
-  for (long pc = 0; pc < n * 3; ++pc) {
-    const int c = (int)(pc % 3);
+  PLANE_CHUNK_LOOP(n, hw) {
+    PLANE_CHUNK_VARS(hw)
     const float sc = (float)kStd[c], sh = (float)kMean[c];
     const long o = pc * hw;
-    for (long i = 0; i < hw; ++i) {
+    for (long i = i0; i < i1; ++i) {
       float d = x[o + i] * sc;                               /* :339 denormalize */
       d = d + sh;
       const float step = alpha * t_sign(g[o + i]);
@@ -83,12 +94,11 @@ void orc_pgd_step_norm01(const float* x, const float* g, const float* clean, flo
 /* attack/Stereo-RCNN/pgd_attack.py:177-217; eps already times 255 (:57) */
 void orc_pgd_step_meansub255(const float* x, const float* g, const float* clean, float* out, long n, long hw,
                              float alpha, float eps) {
-#pragma omp parallel for schedule(static)
-  for (long pc = 0; pc < n * 3; ++pc) {
-    const int c = (int)(pc % 3);
+  PLANE_CHUNK_LOOP(n, hw) {
+    PLANE_CHUNK_VARS(hw)
     const float lo = (float)(0 - kPixelMeans[c]), hi = (float)(255 - kPixelMeans[c]);
     const long o = pc * hw;
-    for (long i = 0; i < hw; ++i) {
+    for (long i = i0; i < i1; ++i) {
       const float step = alpha * t_sign(g[o + i]);
       const float a = x[o + i] + step;                        /* :177 */
       const float eta = t_clamp(a - clean[o + i], -eps, eps); /* :181 */
