@@ -1,0 +1,152 @@
+"""Model adapters: what the attack drivers call for "detector forward + loss + backward".
+
+The detectors are not part of the reference tree (they are the upstream DSGN / Stereo R-CNN
+repositories the user clones), so they are not part of this package either.  An adapter wraps whatever
+detector the caller has and returns d loss / d image for the stacked stereo batch:
+
+    loss, grad = adapter.loss_and_grad(x, extra)      # x, grad: [2B,3,H,W]; left eyes first
+
+``DsgnAdapter`` / ``StereoRcnnAdapter`` restate the objective lines of the scripts around an upstream
+model object handed in by the caller; ``ToyStereoAdapter`` is a small fixed-seed differentiable stereo
+matcher used by the tests, smoke() and the CLI's ``--model toy`` plumbing mode.
+"""
+import torch
+import torch.nn.functional as F
+
+
+def split_eyes(x):
+    b = x.shape[0] // 2
+    return x[:b], x[b:]
+
+
+class _LeafGrad:
+    """make the stacked buffer a leaf for one forward/backward, hand back its gradient"""
+
+    def __init__(self, x):
+        self.x = x
+
+    def __enter__(self):
+        self.x.grad = None
+        self.x.requires_grad_(True)
+        return self.x
+
+    def __exit__(self, *a):
+        self.x.requires_grad_(False)
+        self.x.grad = None
+
+    def take(self):
+        g = self.x.grad
+        if g is None:
+            raise RuntimeError("the detector loss does not depend on the images")
+        return g.detach()
+
+
+class ToyStereoAdapter:
+    """Fixed-seed two-layer siamese feature net + a 4-plane correlation 'cost volume' + smooth-L1 to a
+    synthetic target.  NOT a detector - a deterministic differentiable stand-in with the same call shape,
+    so that loop-level behaviour can be tested without DSGN / Stereo R-CNN."""
+
+    def __init__(self, device, seed=0, channels=8, planes=(0, 4, 8, 16)):
+        gen = torch.Generator().manual_seed(seed)
+        self.w1 = (torch.randn(channels, 3, 3, 3, generator=gen) * 0.2).to(device)
+        self.w2 = (torch.randn(channels, channels, 3, 3, generator=gen) * 0.1).to(device)
+        self.planes = planes
+        self.target = 0.25
+
+    def features(self, img):
+        f = F.relu(F.conv2d(img, self.w1, stride=2, padding=1))
+        return F.conv2d(f, self.w2, stride=2, padding=1)
+
+    def loss(self, imgL, imgR):
+        fl, fr = self.features(imgL), self.features(imgR)
+        costs = []
+        for d in self.planes:                       # left feature against the right feature shifted by d
+            shifted = fr if d == 0 else F.pad(fr, (d, 0))[..., :fr.shape[-1]]
+            costs.append((fl * shifted).mean(dim=1))
+        cost = torch.stack(costs, dim=1)
+        prob = torch.softmax(cost, dim=1)
+        depth = sum(p * prob[:, i] for i, p in enumerate(self.planes))
+        return F.smooth_l1_loss(depth / max(self.planes), torch.full_like(depth, self.target))
+
+    def loss_and_grad(self, x, extra=None):
+        h = _LeafGrad(x)
+        with h as leaf:
+            imgL, imgR = split_eyes(leaf)
+            loss = self.loss(imgL, imgR)
+            loss.backward()
+            return loss.detach(), h.take()
+
+    def inject_fake_target(self, extra, centers_l, centers_r, radius):
+        pass
+
+
+class DsgnAdapter:
+    """attack/DSGN/pgd_attack.py:300-336 around an upstream DSGN ``StereoNet`` (eval mode) and its
+    ``RPN3DLoss``.  ``extra`` must carry: calibs_fu, calibs_baseline, calibs_Proj, calibs_Proj_R (:262-266),
+    disp_true [B,H,W], targets, calib, calib_R, ious, labels_map (the BatchCollator fields, :103-126).
+    Written for batch 1 per sample exactly as the reference indexes it (``o[mask[0]]``, quirk Q3)."""
+
+    DISP_WEIGHTS = [0.5, 0.7, 1.0]          # :313
+
+    def __init__(self, model, cfg, rpn3d_loss_cls):
+        self.model, self.cfg, self.rpn3d_loss_cls = model, cfg, rpn3d_loss_cls
+
+    def loss_and_grad(self, x, extra):
+        cfg = self.cfg
+        h = _LeafGrad(x)
+        with h as leaf:
+            imgL, imgR = split_eyes(leaf)
+            outputs = self.model(imgL, imgR, extra.calibs_fu, extra.calibs_baseline, extra.calibs_Proj,
+                                 calibs_Proj_R=extra.calibs_Proj_R)                              # :308
+            loss = 0.
+            if getattr(cfg, "PlaneSweepVolume", True) and cfg.loss_disp:                         # :310-319
+                disp_true = extra.disp_true
+                mask = ((disp_true > cfg.min_depth) & (disp_true <= cfg.max_depth)).detach()     # :269-270
+                depth_preds = [torch.squeeze(o, 1) for o in outputs["depth_preds"]]
+                wts = self.DISP_WEIGHTS
+                for i, o in enumerate(depth_preds):
+                    loss = loss + wts[3 - len(depth_preds) + i] * F.smooth_l1_loss(o[mask[0]], disp_true[mask],
+                                                                                    reduction="mean")
+            if cfg.RPN3D_ENABLE:                                                                 # :321-330
+                rpn3d_loss = self.rpn3d_loss_cls(cfg)(
+                    outputs["bbox_cls"], outputs["bbox_reg"], outputs["bbox_centerness"], extra.targets,
+                    extra.calib, extra.calib_R, ious=extra.ious, labels_map=extra.labels_map)[0]
+                loss = loss + rpn3d_loss
+            self.model.zero_grad()                                                               # :333
+            loss.backward()                                                                      # :336
+            return loss.detach(), h.take()
+
+    def inject_fake_target(self, extra, centers_l, centers_r, radius):
+        from . import patchgeom
+        if extra.targets is not None:                                                            # patch_attack.py:336
+            patchgeom.inject_fake_target_dsgn(extra.targets[0].bbox.data, extra.targets[0].box3d.data)
+
+
+class StereoRcnnAdapter:
+    """attack/Stereo-RCNN/pgd_attack.py:151-174 around the upstream ``_StereoRCNN`` with the substitute
+    files of the reference (losses computed in eval mode).  ``extra``: im_info, gt_boxes_left/right/merge,
+    gt_dim_orien, gt_kpts, num_boxes; ``uncert`` = the six learned log-variances from the checkpoint (:97)."""
+
+    def __init__(self, model, uncert):
+        self.model, self.uncert = model, uncert
+
+    def loss_and_grad(self, x, extra):
+        u = self.uncert
+        h = _LeafGrad(x)
+        with h as leaf:
+            imgL, imgR = split_eyes(leaf)
+            out = self.model(imgL, imgR, extra.im_info, extra.gt_boxes_left, extra.gt_boxes_right,
+                             extra.gt_boxes_merge, extra.gt_dim_orien, extra.gt_kpts, extra.num_boxes)   # :156-163
+            terms = out[8:14]   # rpn_loss_cls, rpn_loss_box_left_right, RCNN_loss_cls, _bbox, _dim_orien, _kpts
+            loss = 0.
+            for k in range(6):                                                                   # :165-171
+                loss = loss + terms[k].mean() * torch.exp(-u[k]) + u[k]
+            self.model.zero_grad()                                                               # :173
+            loss.backward()                                                                      # :174
+            return loss.detach(), h.take()
+
+    def inject_fake_target(self, extra, centers_l, centers_r, radius):
+        from . import patchgeom
+        extra.num_boxes.data = torch.tensor(1)                                                   # patch_attack.py:188
+        patchgeom.inject_fake_target_srcnn(extra.gt_boxes_left, extra.gt_boxes_right, extra.gt_boxes_merge,
+                                           centers_l[0], centers_r[0], radius)

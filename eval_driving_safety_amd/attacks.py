@@ -1,0 +1,266 @@
+"""Attack drivers: the host-side mirror of the reference's four attack scripts around the HIP kernels.
+
+    PgdAttack     attack/DSGN/pgd_attack.py:229-374 and attack/Stereo-RCNN/pgd_attack.py:105-243
+    PatchTrainer  attack/DSGN/patch_attack.py:278-443 and attack/Stereo-RCNN/patch_attack.py:99-293
+
+The detector is the caller's: anything with ``loss_and_grad(x, extra) -> (loss, grad)`` where ``x`` is
+the stacked stereo batch [2B,3,H,W] (left eyes first, then right eyes) and ``grad`` = d loss / d x.
+Keeping both eyes of all B pairs in ONE buffer is what lets a PGD step be a single kernel launch.
+
+Differences from the reference, all deliberate and listed in DESIGN.md: any batch size B (the
+reference's in-place denormalize only works for B = 1, quirk Q1); one clean buffer instead of two
+identical ones (Q2); explicit clone of the Stereo R-CNN clean image (Q6); a seedable patch-position
+stream (Q9); device-side loss accumulation (Q17); PNG encoding off the critical path.
+"""
+import os
+
+import torch
+
+from . import patchgeom, pixelio
+from .dist import Comm
+
+
+def split_eyes(x):
+    """views (imgL, imgR) of a stacked [2B,3,H,W] batch"""
+    b = x.shape[0] // 2
+    return x[:b], x[b:]
+
+
+def _default_ops():
+    from . import ops       # raises if libadvengine.so is not built: there is no other compute path
+    return ops
+
+
+class StereoBatch:
+    """What a loader hands to the drivers (the reference's BatchCollator dict, attack/DSGN/pgd_attack.py:103-126,
+    reduced to what the loop itself touches).  imgL/imgR: float32 [B,3,H,W] in the detector's input space;
+    names: file stem per pair; sizes: (w, h) of the original image per pair or None; extra: opaque, handed to
+    the model adapter (calibration, targets, depth map ...)."""
+
+    def __init__(self, imgL, imgR, names, sizes=None, extra=None):
+        assert imgL.shape == imgR.shape and imgL.dim() == 4 and imgL.shape[1] == 3
+        self.imgL, self.imgR, self.names, self.sizes, self.extra = imgL, imgR, list(names), sizes, extra
+
+    def __len__(self):
+        return self.imgL.shape[0]
+
+
+class PgdAttack:
+    """Iterative L-inf PGD / FGSM (iters = 1) through a stereo detector.
+
+    model_kind 'dsgn':  pixel space = ImageNet-normalised RGB, files ``dsgn_pgd_iters_{k}/image_{2,3}/{name}.png``
+                        cropped to the original (w, h), 8-bit by truncation (attack/DSGN/pgd_attack.py:157-193).
+    model_kind 'srcnn': pixel space = BGR minus PIXEL_MEANS, ``eps`` is the script argument and is scaled by
+                        255 here (attack/Stereo-RCNN/pgd_attack.py:57), files ``stereo_rcnn_pgd_iters_{k}/...``
+                        at network scale (quirk Q14).  Iterate 0 is written to the intended ``image_2/<name>``
+                        path, not the reference's ``image_2<name>`` (quirk Q5).
+    The loss is ASCENDED (untargeted), as in both scripts.
+    """
+
+    def __init__(self, model_kind, alpha, eps, iters, out_root=".", save=True, save_every=1, writer_workers=4,
+                 ops=None, device=None):
+        self.ops = ops if ops is not None else _default_ops()
+        self.kind = model_kind
+        if model_kind == "dsgn":
+            self.space, self.prefix, self.eps = self.ops.Space.dsgn(), "dsgn", float(eps)
+        elif model_kind == "srcnn":
+            self.space, self.prefix, self.eps = self.ops.Space.srcnn(), "stereo_rcnn", 255 * float(eps)
+        else:
+            raise ValueError("model_kind must be 'dsgn' or 'srcnn'")
+        self.alpha, self.iters = float(alpha), int(iters)
+        self.out_root, self.save, self.save_every = out_root, save, max(1, int(save_every))
+        self.device = device
+        self.writer = pixelio.PngWriter(writer_workers, bgr=(model_kind == "srcnn")) if save else None
+
+    # -- file surface --------------------------------------------------------------------------
+    def _emit(self, k, u8, batch):
+        if not self.save or (k % self.save_every != 0 and k != self.iters):
+            return
+        host = u8.cpu().numpy()                      # [2B, rows, W, 3]
+        b = len(batch)
+        for eye in (0, 1):
+            d = os.path.join(self.out_root, pixelio.iter_dir(self.prefix, k, eye))
+            for i, name in enumerate(batch.names):
+                stem = name if name.lower().endswith(".png") else name + ".png"
+                w, h = batch.sizes[i] if batch.sizes is not None else (None, None)
+                self.writer.put(os.path.join(d, stem), host[eye * b + i], crop_w=w, crop_h=h)
+
+    # -- one batch -----------------------------------------------------------------------------
+    def run_batch(self, batch, adapter):
+        """Attack B stereo pairs; returns the final stacked iterate [2B,3,H,W] (device)."""
+        ops, sp = self.ops, self.space
+        dev = self.device if self.device is not None else batch.imgL.device
+        x = torch.cat([batch.imgL, batch.imgR], dim=0).to(dev, dtype=torch.float32).contiguous()
+        n, _, h, w = x.shape
+        rows = h if batch.sizes is None else max(s[1] for s in batch.sizes)
+        cols = w if batch.sizes is None else max(s[0] for s in batch.sizes)
+        u8 = ops.alloc_u8(n, rows, w, dev) if self.save else None
+        # clean image in pixel space: pgd_attack.py:297-298 (DSGN) / :122-123 (Stereo R-CNN)
+        clean = ops.denormalize(x, sp) if sp.affine else x.clone()
+        if self.save:                                # iterate 0 = the un-attacked pair, :279-294
+            ops.export_u8(x, sp, (rows, cols), out=u8)
+            self._emit(0, u8, batch)
+        losses = []
+        for k in range(self.iters):
+            loss, grad = adapter.loss_and_grad(x, batch.extra)           # detector fwd + loss + bwd (:305-336)
+            losses.append(loss)
+            ops.pgd_step(x, grad.contiguous(), clean, sp, self.alpha, self.eps, out=x, u8_out=u8,
+                         crop=(rows, cols) if self.save else None)       # :339-354 (+ :357-374 export)
+            if self.save:
+                self._emit(k + 1, u8, batch)
+        self.last_losses = losses
+        return x
+
+    def run(self, loader, adapter, comm=None, debugnum=None):
+        """Iterate a loader; with a Comm of world > 1 every rank takes the batches i % world == rank
+        (no collective: attacked pairs are independent and write distinct files)."""
+        comm = comm if comm is not None else Comm()
+        done = 0
+        for i, batch in enumerate(loader):
+            if debugnum is not None and i * len(batch) > debugnum:       # pgd_attack.py:246-248 (quirk Q15)
+                break
+            if i % comm.world != comm.rank:
+                continue
+            self.run_batch(batch, adapter)
+            done += len(batch)
+        self.close()
+        return done
+
+    def close(self):
+        if self.writer is not None:
+            self.writer.close()
+            self.writer = None
+
+
+class PatchTrainer:
+    """Universal round adversarial patch, pasted at a random position in both eyes and trained by
+    DESCENDING the detection loss towards a fake target.
+
+    Reference semantics (world 1, B = 1): per image, ``iters`` times { paste, fwd+bwd, patch -= clamp(500 *
+    (gL_win + gR_win), +-eps) [, per-channel range clamp for Stereo R-CNN] }, the gradient buffer accumulating
+    across the inner iterations because the scripts never zero ``img.grad`` (attack/DSGN/patch_attack.py:409-417;
+    ``accumulate_grad=False`` turns that off).
+    Data-parallel rule (B > 1 and/or world > 1): all images of a round are evaluated against the
+    same patch snapshot, their clamped deltas are summed (in index order on a rank, all-reduce(SUM) across
+    ranks) and applied at once; ``average=True`` divides the sum by the number of contributing pairs.
+    """
+
+    ALPHA = 1e3     # hard-coded in both scripts (patch_attack.py:279 / :101)
+
+    def __init__(self, model_kind, ratio, eps, iters, epochs, out_root=".", seed=None, rng=None, comm=None,
+                 accumulate_grad=True, average=False, ops=None, device=None):
+        self.ops = ops if ops is not None else _default_ops()
+        self.kind = model_kind
+        if model_kind == "dsgn":
+            self.space, self.prefix, self.shape = self.ops.Space.dsgn(), "dsgn", patchgeom.DSGN_SHAPE
+            self.lo = self.hi = None                 # the DSGN patch is never range-clamped (quirk Q10)
+        elif model_kind == "srcnn":
+            self.space, self.prefix, self.shape = self.ops.Space.srcnn(), "stereo_rcnn", patchgeom.SRCNN_SHAPE
+            self.lo, self.hi = self.space.lo, self.space.hi
+        else:
+            raise ValueError("model_kind must be 'dsgn' or 'srcnn'")
+        self.ratio, self.eps, self.iters, self.epochs = ratio, float(eps), int(iters), int(epochs)
+        self.out_root = out_root
+        self.comm = comm if comm is not None else Comm()
+        self.accumulate_grad, self.average = accumulate_grad, average
+        self.device = device
+        self.patch_dim, self.radius = patchgeom.init_patch_dims(self.shape[0], ratio)
+        # one position stream per rank so that ranks do not paste at identical places
+        s = None if seed is None else seed + 7919 * self.comm.rank
+        self.sampler = patchgeom.CenterSampler(self.shape[0], self.shape[1], self.radius, "random", seed=s, rng=rng)
+        self.patch = None
+        self.positions = []                          # (epoch, round, name, center_l, center_r) log
+
+    def init_patch(self, device):
+        d0 = pixelio.patch_dir(self.prefix, self.ratio, 0, self.out_root)
+        if self.comm.rank == 0:
+            host, _ = pixelio.load_or_init_patch(d0, self.patch_dim)
+        self.comm.barrier()
+        if self.comm.rank != 0:
+            host, _ = pixelio.load_or_init_patch(d0, self.patch_dim)
+        self.patch = torch.from_numpy(host).to(device).contiguous()
+        return self.patch
+
+    # -- one round: B pairs on this rank against one patch snapshot ----------------------------------
+    def train_batch(self, batch, adapter, contributes=True):
+        ops, r = self.ops, self.radius
+        dev = self.patch.device
+        b = len(batch) if batch is not None else 0
+        if batch is not None and tuple(batch.imgL.shape[2:]) != tuple(self.shape):
+            batch, b = None, 0                       # wrong-shape pairs are skipped, patch_attack.py:318-320
+        if not contributes:
+            batch, b = None, 0
+        x = None
+        if b:
+            x = torch.cat([batch.imgL, batch.imgR], dim=0).to(dev, dtype=torch.float32).contiguous()
+            cl, cr = zip(*[self.sampler.draw() for _ in range(b)])
+            for i in range(b):
+                self.positions.append((batch.names[i], list(cl[i]), list(cr[i])))
+            if hasattr(adapter, "inject_fake_target"):
+                adapter.inject_fake_target(batch.extra, cl, cr, r)       # patch_attack.py:336-354 / :187-207
+            centers2 = torch.tensor([[c[0], c[1]] for c in cl] + [[c[0], c[1]] for c in cr], dtype=torch.int32, device=dev)
+            centers3 = torch.tensor([[l[0], l[1], rr[1]] for l, rr in zip(cl, cr)], dtype=torch.int32, device=dev)
+        single = (b == 1 and self.comm.world == 1 and not self.average)
+        loss_sum = torch.zeros((), dtype=torch.float32, device=dev)
+        gacc = None
+        for it in range(self.iters):
+            if b:
+                if single:                                                   # the reference's own sequence
+                    ops.patch_paste(x[0:1], self.patch, cl[0][0], cl[0][1], r)    # :369-376
+                    ops.patch_paste(x[1:2], self.patch, cr[0][0], cr[0][1], r)
+                else:
+                    ops.patch_paste_batch(x, self.patch, centers2, r)
+                loss, grad = adapter.loss_and_grad(x, batch.extra)           # :384-412
+                loss_sum = loss_sum + loss.detach().to(dev, torch.float32)   # :414, kept on the device
+                gacc = grad if (gacc is None or not self.accumulate_grad) else gacc + grad
+                gl, gr = split_eyes(gacc.contiguous())
+            if single:
+                ops.patch_update(self.patch, gl, gr, cl[0][0], cl[0][1], cr[0][1], r, self.eps, alpha=self.ALPHA,
+                                 lo=self.lo, hi=self.hi)                     # :416-430 (+ :272-281)
+            else:
+                if b:
+                    delta = ops.patch_delta_batch(gl, gr, centers3, r, self.eps, alpha=self.ALPHA)
+                else:
+                    delta = torch.zeros((3, self.patch_dim, self.patch_dim), dtype=torch.float32, device=dev)
+                count = torch.tensor([float(b)], device=dev)
+                self.comm.all_reduce_sum_(delta)                             # RCCL over xGMI (gloo in CPU tests)
+                if self.average:
+                    self.comm.all_reduce_sum_(count)
+                    delta = delta / torch.clamp(count, min=1.0)
+                ops.patch_apply(self.patch, delta, lo=self.lo, hi=self.hi)
+        return loss_sum, b
+
+    def train(self, loader_factory, adapter, n_items=None, debugnum=None):
+        """``loader_factory()`` -> an iterable of StereoBatch, re-created every epoch.  With world > 1 the
+        batches are dealt round-robin; every rank runs the same number of rounds (a rank that has run out of
+        batches contributes a zero delta) so the all-reduces stay matched."""
+        dev = self.device if self.device is not None else torch.device("cuda", torch.cuda.current_device())
+        if self.patch is None:
+            self.init_patch(dev)
+        comm = self.comm
+        for epoch in range(self.epochs):
+            if comm.rank == 0:
+                print("Epoch {0}".format(epoch))                             # patch_attack.py:293
+            loss_sum = torch.zeros((), dtype=torch.float32, device=dev)
+            loss_num = 0
+            mine, total = [], 0
+            for i, batch in enumerate(loader_factory()):
+                if debugnum is not None and i * len(batch) > debugnum:       # :314-316
+                    break
+                total += 1
+                if i % comm.world == comm.rank:
+                    mine.append(batch)
+            for rnd in range(comm.rounds(total)):
+                batch = mine[rnd] if rnd < len(mine) else None
+                ls, b = self.train_batch(batch, adapter, contributes=batch is not None)
+                loss_sum = loss_sum + ls
+                loss_num += 1 if b else 0
+            stats = torch.stack([loss_sum, torch.tensor(float(loss_num), device=dev)])
+            comm.all_reduce_sum_(stats)
+            if comm.rank == 0 and float(stats[1]) > 0:
+                print("Average loss for epoch{0}: {1}".format(str(epoch + 1), float(stats[0] / stats[1])))  # :434-435
+        if comm.rank == 0:                                                   # :438-443
+            pixelio.save_patch(pixelio.patch_dir(self.prefix, self.ratio, self.epochs, self.out_root),
+                               self.patch.detach().cpu().numpy()[None] if self.patch.dim() == 3 else self.patch.detach().cpu().numpy())
+        comm.barrier()
+        return self.patch

@@ -1,0 +1,47 @@
+"""Counterpart of attack/DSGN/pgd_attack.py (flags :35-56, loop :229-374)."""
+import argparse
+
+import torch
+
+from . import _common
+from .. import adapters, data
+from ..attacks import PgdAttack
+from ..dist import Comm
+
+
+def build_parser():
+    parser = argparse.ArgumentParser(description="PGD attack")
+    _common.add_scaffolding(parser)
+    parser.add_argument("--iter", type=int, default=4, help="iteration number of pgd attack")
+    parser.add_argument("--alpha", type=float, default=(1.0 / 255))
+    parser.add_argument("--eps", type=float, default=0.3)
+    return parser
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    if args.debugnum is None:
+        args.debugnum = 100                                   # :64-65
+    dev = _common.setup_device()
+    comm = Comm.from_env(device=dev)
+    torch.manual_seed(args.seed)                              # :86-87
+    torch.cuda.manual_seed(args.seed)
+    batch = args.btest if args.btest else 1
+    if args.model == "toy":
+        adapter = adapters.ToyStereoAdapter(dev, seed=args.seed)
+    else:
+        try:
+            from dsgn.models import StereoNet                 # noqa: F401  (upstream)
+        except Exception:
+            _common.upstream_unavailable("dsgn (upstream DSGN)")
+        raise SystemExit("wire your DSGN checkpoint through adapters.DsgnAdapter(model, cfg, RPN3DLoss); see INTEGRATION.md")
+    loader = data.SyntheticStereo(args.synthetic, "dsgn", batch, seed=args.seed) if args.synthetic \
+        else data.KittiFolder(args.data_path, args.split_file, batch)
+    atk = PgdAttack("dsgn", args.alpha, args.eps, args.iter, out_root=args.out_root, save_every=args.save_every, device=dev)
+    n = atk.run(loader, adapter, comm, debugnum=args.debugnum if args.debug else None)
+    print("rank %d attacked %d stereo pairs" % (comm.rank, n))
+    comm.close()
+
+
+if __name__ == "__main__":
+    main()

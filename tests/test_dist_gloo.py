@@ -1,0 +1,114 @@
+"""world_size-2 tests on CPU (gloo) of the multi-GPU rules: PGD shards by image with no
+collective; the universal patch exchanges one all-reduce(SUM) of the clamped delta per inner iteration.
+The HIP ops are replaced by the oracle-backed shim (tests only)."""
+import os
+import random
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+H, W = 384, 1248
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _pairs(n):
+    import synth
+    return [(synth.dsgn_normalised(70 + 2 * i, H, W), synth.dsgn_normalised(71 + 2 * i, H, W)) for i in range(n)]
+
+
+def _worker(rank, world, port, out_dir, n_pairs, mode):
+    for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    import _oracle_ops
+    from eval_driving_safety_amd import adapters, attacks
+    from eval_driving_safety_amd.dist import Comm
+    comm = Comm.from_env(backend="gloo")
+    assert comm.world == world and comm.rank == rank
+    cpu = torch.device("cpu")
+    toy = adapters.ToyStereoAdapter(cpu, seed=4)
+    pairs = _pairs(n_pairs)
+
+    def factory():
+        return [attacks.StereoBatch(torch.from_numpy(l.copy()), torch.from_numpy(r.copy()), ["%06d" % i], [(1242, 375)])
+                for i, (l, r) in enumerate(pairs)]
+
+    if mode == "patch":
+        tr = attacks.PatchTrainer("dsgn", 0.2, 8 / 255, 2, 1, out_root=out_dir, seed=9, comm=comm, ops=_oracle_ops, device=cpu)
+        patch = tr.train(factory, toy)
+        np.save(os.path.join(out_dir, "patch_rank%d.npy" % rank), patch.numpy())
+    else:
+        atk = attacks.PgdAttack("dsgn", 1 / 255, 0.03, 1, out_root=out_dir, ops=_oracle_ops, device=cpu)
+        n = atk.run(factory(), toy, comm)
+        with open(os.path.join(out_dir, "done_rank%d.txt" % rank), "w") as f:
+            f.write(str(n))
+    comm.close()
+
+
+def _spawn(tmp_path, n_pairs, mode):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path), n_pairs, mode), nprocs=2, join=True)
+
+
+@pytest.mark.timeout(600)
+def test_patch_allreduce_rule_world2(tmp_path):
+    import _oracle_ops  # noqa: F401
+    from oracle import oracle_np as O
+    from eval_driving_safety_amd import adapters
+    n_pairs = 3                                   # odd: rank 1 idles in the second round and adds a zero delta
+    _spawn(tmp_path, n_pairs, "patch")
+    p0 = np.load(os.path.join(str(tmp_path), "patch_rank0.npy"))
+    p1 = np.load(os.path.join(str(tmp_path), "patch_rank1.npy"))
+    assert p0.tobytes() == p1.tobytes(), "ranks disagree on the patch"
+    # expected: per round, every rank's pair is evaluated against the same snapshot; deltas summed; applied once
+    toy = adapters.ToyStereoAdapter(torch.device("cpu"), seed=4)
+    pairs = _pairs(n_pairs)
+    D, r = O.init_patch_dims(384, 0.2)
+    patch = np.zeros((1, 3, D, D), np.float32)
+    rngs = [random.Random(9 + 7919 * k) for k in range(2)]
+    for rnd in range(2):
+        live = []
+        for rank in range(2):
+            i = rnd * 2 + rank
+            if i < n_pairs:
+                cl, cr = O.round_mask_centers(rngs[rank], H, W, r)
+                live.append([np.concatenate(pairs[i]).copy(), cl, cr, None])
+        for it in range(2):
+            total = np.zeros((1, 3, D, D), np.float32)
+            for k, (x, cl, cr, gacc) in enumerate(live):
+                x[0:1] = O.patch_paste(x[0:1], patch, cl[0], cl[1], r)
+                x[1:2] = O.patch_paste(x[1:2], patch, cr[0], cr[1], r)
+                _, g = toy.loss_and_grad(torch.from_numpy(x.copy()))
+                gacc = g.numpy() if gacc is None else gacc + g.numpy()
+                live[k][3] = gacc
+                d = O.patch_delta(gacc[0:1], gacc[1:2], cl[0], cl[1], cr[1], r, 8 / 255)
+                total = d if k == 0 else total + d
+            patch = O.patch_apply_delta(patch, total)
+    assert np.abs(patch).max() > 0
+    assert p0.tobytes() == patch.tobytes()
+    assert os.path.exists(os.path.join(str(tmp_path), "dsgn_patch_ratio_0.2", "epoch1", "patch.npy"))
+
+
+@pytest.mark.timeout(600)
+def test_pgd_shards_by_image_world2(tmp_path):
+    _spawn(tmp_path, 3, "pgd")
+    done = [int(open(os.path.join(str(tmp_path), "done_rank%d.txt" % k)).read()) for k in range(2)]
+    assert done == [2, 1]
+    for k in (0, 1):
+        for folder in ("image_2", "image_3"):
+            files = sorted(os.listdir(os.path.join(str(tmp_path), "dsgn_pgd_iters_%d" % k, folder)))
+            assert files == ["000000.png", "000001.png", "000002.png"]

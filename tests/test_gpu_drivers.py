@@ -1,0 +1,122 @@
+"""The attack drivers on the real HIP path (toy detector on the GPU supplies gradients; the oracle
+replays the same gradients on the host).  Bit-exact."""
+import os
+import random
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import synth
+from oracle import oracle_np as O
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class _Recorder:
+    """wraps an adapter and keeps the gradients it returned"""
+
+    def __init__(self, inner):
+        self.inner, self.grads = inner, []
+
+    def loss_and_grad(self, x, extra=None):
+        loss, g = self.inner.loss_and_grad(x, extra)
+        self.grads.append(g.detach().cpu().numpy().copy())
+        return loss, g
+
+    def inject_fake_target(self, *a):
+        pass
+
+
+def test_pgd_driver_batch_of_pairs_on_hip(tmp_path):
+    from PIL import Image
+    from eval_driving_safety_amd import adapters, attacks, data
+    dev = torch.device("cuda", 0)
+    batch = next(iter(data.SyntheticStereo(3, "dsgn", batch=3, seed=2)))
+    rec = _Recorder(adapters.ToyStereoAdapter(dev, seed=1))
+    atk = attacks.PgdAttack("dsgn", 1 / 255, 0.03, 4, out_root=str(tmp_path), device=dev)
+    x = atk.run_batch(batch, rec)
+    atk.close()
+    xm = torch.cat([batch.imgL, batch.imgR]).numpy().copy()
+    clean = O.denormalize(xm)
+    for k in range(4):
+        xm = O.pgd_step_norm01(xm, rec.grads[k], clean, 1 / 255, 0.03)
+    assert x.cpu().numpy().tobytes() == xm.tobytes()
+    got = np.array(Image.open(os.path.join(str(tmp_path), "dsgn_pgd_iters_4", "image_3", "000001.png")).convert("RGB"))
+    assert got.shape == (375, 1242, 3)
+    assert np.array_equal(got, O.tensor2im_u8(xm[3 + 1], 375, 1242))
+    got0 = np.array(Image.open(os.path.join(str(tmp_path), "dsgn_pgd_iters_0", "image_2", "000000.png")).convert("RGB"))
+    assert np.array_equal(got0, O.tensor2im_u8(batch.imgL[0].numpy(), 375, 1242))
+
+
+@pytest.mark.parametrize("kind", ["dsgn", "srcnn"])
+def test_patch_trainer_reference_sequence_on_hip(kind, tmp_path):
+    from eval_driving_safety_amd import adapters, attacks, data, patchgeom
+    dev = torch.device("cuda", 0)
+    H, W = patchgeom.DSGN_SHAPE if kind == "dsgn" else patchgeom.SRCNN_SHAPE
+    batches = list(data.SyntheticStereo(2, kind, batch=1, seed=3))
+    rec = _Recorder(adapters.ToyStereoAdapter(dev, seed=2))
+    eps = 8 / 255 if kind == "dsgn" else 0.1
+    ratio = 0.2 if kind == "dsgn" else 0.1
+    tr = attacks.PatchTrainer(kind, ratio, eps, 2, 1, out_root=str(tmp_path), seed=11, device=dev)
+    tr.ALPHA = 1e3
+    patch = tr.train(lambda: batches, rec)
+    rng = random.Random(11)
+    D, r = O.init_patch_dims(H if kind == "dsgn" else 600, ratio)
+    p = np.zeros((1, 3, D, D), np.float32)
+    lo, hi = (None, None) if kind == "dsgn" else (O.SRCNN_LO, O.SRCNN_HI)
+    gi = 0
+    for b in batches:
+        cl, cr = O.round_mask_centers(rng, H, W, r)
+        gacc = None
+        for it in range(2):
+            g = rec.grads[gi]
+            gi += 1
+            gacc = g if gacc is None else gacc + g
+            p = O.patch_update(p, gacc[0:1], gacc[1:2], cl[0], cl[1], cr[1], r, eps, lo=lo, hi=hi)
+    assert patch.cpu().numpy().tobytes() == p.tobytes()
+    assert np.abs(p).max() > 0
+
+
+def test_patch_trainer_batched_rule_on_hip(tmp_path):
+    """B = 3 pairs per round against one snapshot: summed deltas, applied once"""
+    from eval_driving_safety_amd import adapters, attacks, data
+    dev = torch.device("cuda", 0)
+    batch = next(iter(data.SyntheticStereo(3, "dsgn", batch=3, seed=5)))
+    rec = _Recorder(adapters.ToyStereoAdapter(dev, seed=3))
+    tr = attacks.PatchTrainer("dsgn", 0.2, 8 / 255, 2, 1, out_root=str(tmp_path), seed=4, device=dev)
+    patch = tr.train(lambda: [batch], rec)
+    rng = random.Random(4)
+    D, r = O.init_patch_dims(384, 0.2)
+    cs = [O.round_mask_centers(rng, 384, 1248, r) for _ in range(3)]
+    p = np.zeros((1, 3, D, D), np.float32)
+    gacc = None
+    for it in range(2):
+        gacc = rec.grads[it] if gacc is None else gacc + rec.grads[it]
+        total = None
+        for i, (cl, cr) in enumerate(cs):
+            d = O.patch_delta(gacc[i:i + 1], gacc[3 + i:4 + i], cl[0], cl[1], cr[1], r, 8 / 255)
+            total = d if total is None else total + d
+        p = O.patch_apply_delta(p, total)
+    assert patch.cpu().numpy().tobytes() == p.tobytes()
+
+
+def test_cli_toy_run_writes_the_reference_layout(tmp_path):
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    cmd = [sys.executable, "-m", "eval_driving_safety_amd.cli.dsgn_pgd_attack", "--model", "toy", "--synthetic", "2",
+           "-btest", "1", "-d", "0", "--iter", "2", "--eps", "0.03", "--out_root", str(tmp_path)]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout
+    for k in range(3):
+        for folder in ("image_2", "image_3"):
+            assert sorted(os.listdir(os.path.join(str(tmp_path), "dsgn_pgd_iters_%d" % k, folder))) == ["000000.png", "000001.png"]
+    cmd = [sys.executable, "-m", "eval_driving_safety_amd.cli.srcnn_patch_attack", "--model", "toy", "--synthetic", "2",
+           "--iter", "1", "--epochs", "1", "--out_root", str(tmp_path), "--pos_seed", "1"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout
+    p = np.load(os.path.join(str(tmp_path), "stereo_rcnn_patch_ratio_0.1", "epoch1", "patch.npy"))
+    assert p.shape == (1, 3, 61, 61) and p.dtype == np.float32 and np.abs(p).max() > 0
+    assert "Average loss for epoch1" in out.stdout

@@ -1,0 +1,255 @@
+"""CPU tests of everything around the kernels: the C-ABI surface, the host geometry/RNG logic against
+the reference-generated golden index, the file surface, and the attack drivers run end-to-end with the
+oracle standing in for the HIP ops (tests only - product code has no such path)."""
+import ctypes
+import os
+import random
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import _oracle_ops
+import synth
+from oracle import oracle_np as O
+from eval_driving_safety_amd import _lib, adapters, attacks, data, patchgeom, pixelio
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ------------------------------------------------------------------------------------ C ABI
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "advengine.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(adv_[a-z0-9_]+)\s*\(", header)))
+    assert len(declared) >= 15
+    lib = _lib.load()                         # works without a GPU: nothing is launched
+    for name in declared:
+        assert hasattr(lib, name), "libadvengine.so lacks %s" % name
+    assert sorted(_lib.EXPORTED) == declared, "ctypes binding and header disagree"
+    assert lib.adv_abi_version() == 1
+    assert lib.adv_strerror(-22) == b"invalid argument"
+
+
+def test_space_constants_are_the_reference_constants():
+    lib = _lib.load()
+    s = _lib.AdvSpace()
+    lib.adv_space_dsgn(ctypes.byref(s))
+    assert s.kind == _lib.ADV_SPACE_AFFINE
+    assert [np.float32(v) for v in s.scale] == [np.float32(v) for v in O.DSGN_STD]
+    assert [np.float32(v) for v in s.shift] == [np.float32(v) for v in O.DSGN_MEAN]
+    lib.adv_space_srcnn(ctypes.byref(s))
+    assert s.kind == _lib.ADV_SPACE_IDENTITY
+    assert [np.float32(v) for v in s.lo] == list(O.SRCNN_LO) and [np.float32(v) for v in s.hi] == list(O.SRCNN_HI)
+    assert list(s.export_add) == list(O.SRCNN_PIXEL_MEANS)
+
+
+def test_argument_errors_without_a_gpu():
+    """validation happens before any launch, so the error paths are testable on CPU"""
+    lib = _lib.load()
+    s = _lib.AdvSpace()
+    lib.adv_space_dsgn(ctypes.byref(s))
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert lib.adv_pgd_step_f32(None, p, p, p, None, 1, 2, 2, ctypes.byref(s), 0.1, 0.1, 2, 2, 0, 0, None) == _lib.ADV_EINVAL
+    assert lib.adv_pgd_step_f32(p, p, p, p, None, 1, 2, 2, ctypes.byref(s), 0.1, -0.1, 2, 2, 0, 0, None) == _lib.ADV_EINVAL
+    assert lib.adv_pgd_step_f32(p, p, p, p, None, 0, 2, 2, ctypes.byref(s), 0.1, 0.1, 2, 2, 0, 0, None) == _lib.ADV_EINVAL
+    odd = ctypes.c_void_p(p.value + 2)
+    assert lib.adv_pgd_step_f32(odd, p, p, p, None, 1, 2, 2, ctypes.byref(s), 0.1, 0.1, 2, 2, 0, 0, None) == _lib.ADV_EALIGN
+    assert lib.adv_patch_paste_f32(p, p, 4, 4, 3, 0, 1, 1, None) == _lib.ADV_EINVAL      # window leaves the image
+    assert lib.adv_patch_paste_f32(p, p, 4, 4, 4, 2, 2, 1, None) == _lib.ADV_EINVAL      # d != 2r+1
+    lib.adv_space_srcnn(ctypes.byref(s))
+    assert lib.adv_denormalize_f32(p, p, 1, 2, 2, ctypes.byref(s), None) == _lib.ADV_EINVAL
+
+
+def test_ops_refuse_cpu_tensors():
+    from eval_driving_safety_amd import ops
+    x = torch.zeros((1, 3, 4, 4))
+    with pytest.raises(TypeError):
+        ops.pgd_step(x, x, x, ops.Space.dsgn(), 0.1, 0.1)
+
+
+# ------------------------------------------------------------------------------------ geometry / RNG
+def test_init_patch_dims_against_reference(golden_index):
+    for row in golden_index["masks"]["init_patch"]:
+        short = 384 if row["model"] == "dsgn" else 600
+        assert patchgeom.init_patch_dims(short, row["ratio"]) == (row["patch_dim"], row["radius"]), row
+
+
+def test_center_sampler_reproduces_the_reference_stream(golden_index):
+    for row in golden_index["masks"]["centers"]:
+        h, w = patchgeom.DSGN_SHAPE if row["model"] == "dsgn" else patchgeom.SRCNN_SHAPE
+        random.seed(row["seed"])
+        cl, cr = patchgeom.CenterSampler(h, w, row["radius"], row["atk_mode"], rng=random).draw()
+        assert cl == row["center_l"] and cr == row["center_r"], row
+        cl2, _ = patchgeom.CenterSampler(h, w, row["radius"], row["atk_mode"], seed=row["seed"]).draw()
+        assert cl2 == row["center_l"]                       # random.Random(seed) == random.seed(seed)
+    with pytest.raises(Exception):
+        patchgeom.CenterSampler(384, 1248, 38, "sideways")
+
+
+def test_fake_targets():
+    bbox, box3d = torch.ones((3, 4)), torch.ones((3, 7))
+    patchgeom.inject_fake_target_dsgn(bbox, box3d)
+    assert torch.allclose(bbox[0], torch.tensor(patchgeom.DSGN_FAKE_BBOX)) and not bbox[1:].any()
+    assert torch.allclose(box3d[0], torch.tensor(patchgeom.DSGN_FAKE_BOX3D)) and not box3d[1:].any()
+    gl, gr, gm = (torch.ones((1, 30, 5)) for _ in range(3))
+    assert patchgeom.inject_fake_target_srcnn(gl, gr, gm, [300, 700], [300, 636], 30) == 1
+    assert gl[0, 0].tolist() == [670, 270, 730, 330, 0] and gr[0, 0].tolist() == [606, 270, 666, 330, 0]
+    assert torch.equal(gm, gl) and not gl[0, 1:].any()
+
+
+# ------------------------------------------------------------------------------------ file surface
+def test_kitti_label_text_matches_reference(golden_index, tmp_path):
+    L = golden_index["label"]
+    dets = []
+    for i in range(len(L["labels"])):
+        x = np.float32(L["corners"][i]).reshape(8, 3)
+        center = ((((x[0] + x[4]) + (x[1] + x[5])) + (x[2] + x[6])) + (x[3] + x[7])) / np.float32(8)
+        dets.append((L["labels"][i], np.float32(L["bbox"][i]), np.float32(L["scores"][i]), center, L["dims"][i]))
+    pixelio.write_kitti_labels(str(tmp_path), L["image_index"], dets)
+    text = open(os.path.join(str(tmp_path), "000042.txt")).read()
+    assert text == L["text"]
+    # the consumer's parse (evaluation/convert_scenarios.py:74-93): split on ' ', fields 0..14
+    for line in text.strip().split("\n"):
+        f = line.split(" ")
+        assert len(f) == 16 and f[0] in ("Car", "Pedestrian", "Cyclist")
+        [float(v) for v in f[1:]]
+
+
+def test_patch_files(tmp_path):
+    d0 = pixelio.patch_dir("dsgn", 0.2, 0, str(tmp_path))
+    assert d0.endswith(os.path.join("dsgn_patch_ratio_0.2", "epoch0"))
+    p, existed = pixelio.load_or_init_patch(d0, 77)
+    assert not existed and p.shape == (1, 3, 77, 77) and p.dtype == np.float32 and not p.any()
+    saved = np.load(os.path.join(d0, "patch.npy"))
+    assert saved.shape == (1, 3, 77, 77) and saved.dtype == np.float32
+    pixelio.save_patch(d0, np.full((3, 77, 77), 0.5, np.float32))
+    p, existed = pixelio.load_or_init_patch(d0, 77)
+    assert existed and p.shape == (1, 3, 77, 77) and float(p.mean()) == 0.5
+    with pytest.raises(ValueError):
+        pixelio.load_or_init_patch(d0, 61)
+
+
+# ------------------------------------------------------------------------------------ drivers on CPU
+class _CpuToy(adapters.ToyStereoAdapter):
+    def __init__(self, seed=0):
+        super().__init__(torch.device("cpu"), seed=seed)
+
+
+def _small_batch(n_pairs, h=48, w=64, seed=0, sizes=True):
+    ls = [torch.from_numpy(synth.dsgn_normalised(seed + 2 * i, h, w)[0]) for i in range(n_pairs)]
+    rs = [torch.from_numpy(synth.dsgn_normalised(seed + 2 * i + 1, h, w)[0]) for i in range(n_pairs)]
+    names = ["%06d" % (7 + i) for i in range(n_pairs)]
+    return attacks.StereoBatch(torch.stack(ls), torch.stack(rs), names, [(w - 3, h - 2)] * n_pairs if sizes else None)
+
+
+def test_pgd_driver_files_and_iterates(tmp_path):
+    from PIL import Image
+    batch = _small_batch(2)
+    toy = _CpuToy()
+    atk = attacks.PgdAttack("dsgn", 1 / 255, 0.03, 3, out_root=str(tmp_path), ops=_oracle_ops, device=torch.device("cpu"))
+    x = atk.run_batch(batch, toy)
+    atk.close()
+    # manual loop with the oracle
+    xm = torch.cat([batch.imgL, batch.imgR]).numpy().copy()
+    clean = O.denormalize(xm)
+    want_png = {0: xm.copy()}
+    for k in range(3):
+        _, g = toy.loss_and_grad(torch.from_numpy(xm.copy()))
+        xm = O.pgd_step_norm01(xm, g.numpy(), clean, 1 / 255, 0.03)
+        want_png[k + 1] = xm.copy()
+    assert x.numpy().tobytes() == xm.tobytes()
+    for k in range(4):
+        for eye, folder in ((0, "image_2"), (1, "image_3")):
+            for i, name in enumerate(batch.names):
+                path = os.path.join(str(tmp_path), "dsgn_pgd_iters_%d" % k, folder, name + ".png")
+                got = np.array(Image.open(path).convert("RGB"))
+                assert got.shape == (46, 61, 3)
+                assert np.array_equal(got, O.tensor2im_u8(want_png[k][eye * 2 + i], 46, 61)), path
+    assert sorted(os.listdir(str(tmp_path))) == ["dsgn_pgd_iters_%d" % k for k in range(4)]
+
+
+def test_srcnn_pgd_driver_scales_eps_and_writes_bgr(tmp_path):
+    from PIL import Image
+    h, w = 40, 56
+    l = torch.from_numpy(synth.srcnn_meansub(1, h, w))
+    r = torch.from_numpy(synth.srcnn_meansub(2, h, w))
+    batch = attacks.StereoBatch(l, r, ["000011.png"], None)
+    toy = _CpuToy(seed=1)
+    atk = attacks.PgdAttack("srcnn", 1.0, 0.03, 2, out_root=str(tmp_path), ops=_oracle_ops, device=torch.device("cpu"))
+    assert atk.eps == 255 * 0.03                                            # pgd_attack.py:57
+    x = atk.run_batch(batch, toy)
+    atk.close()
+    xm = torch.cat([l, r]).numpy().copy()
+    clean = xm.copy()
+    for k in range(2):
+        _, g = toy.loss_and_grad(torch.from_numpy(xm.copy()))
+        xm = O.pgd_step_meansub255(xm, g.numpy(), clean, 1.0, 255 * 0.03)
+    assert x.numpy().tobytes() == xm.tobytes()
+    got = np.array(Image.open(os.path.join(str(tmp_path), "stereo_rcnn_pgd_iters_2", "image_2", "000011.png")).convert("RGB"))
+    assert np.array_equal(got[:, :, ::-1], O.srcnn_export_u8(xm[0]))       # file is RGB, tensor is BGR
+
+
+def test_patch_trainer_reproduces_the_reference_sequence(tmp_path):
+    """world 1, batch 1: paste -> fwd/bwd -> update with the gradient ACCUMULATING over the inner
+    iterations, sequentially over images and epochs; positions from the seeded stream."""
+    H, W = patchgeom.DSGN_SHAPE
+    pairs = [(synth.dsgn_normalised(50 + 2 * i, H, W), synth.dsgn_normalised(51 + 2 * i, H, W)) for i in range(2)]
+
+    def factory():
+        return [attacks.StereoBatch(torch.from_numpy(l.copy()), torch.from_numpy(r.copy()), ["%06d" % i], [(1242, 375)])
+                for i, (l, r) in enumerate(pairs)]
+
+    toy = _CpuToy(seed=2)
+    tr = attacks.PatchTrainer("dsgn", 0.2, 8 / 255, 2, 2, out_root=str(tmp_path), seed=5, ops=_oracle_ops, device=torch.device("cpu"))
+    patch = tr.train(factory, toy)
+    # manual
+    rng = random.Random(5)
+    D, r = O.init_patch_dims(384, 0.2)
+    p = np.zeros((1, 3, D, D), np.float32)
+    for epoch in range(2):
+        for l, rr in pairs:
+            cl, cr = O.round_mask_centers(rng, H, W, r)
+            x = np.concatenate([l, rr]).copy()
+            gacc = None
+            for it in range(2):
+                x[0:1] = O.patch_paste(x[0:1], p, cl[0], cl[1], r)
+                x[1:2] = O.patch_paste(x[1:2], p, cr[0], cr[1], r)
+                _, g = toy.loss_and_grad(torch.from_numpy(x.copy()))
+                gacc = g.numpy() if gacc is None else gacc + g.numpy()
+                p = O.patch_update(p, gacc[0:1], gacc[1:2], cl[0], cl[1], cr[1], r, 8 / 255)
+    assert patch.numpy().tobytes() == p.tobytes()
+    assert np.abs(p).max() > 0
+    saved = np.load(os.path.join(str(tmp_path), "dsgn_patch_ratio_0.2", "epoch2", "patch.npy"))
+    assert saved.shape == (1, 3, 77, 77) and saved.tobytes() == p.tobytes()
+    assert os.path.exists(os.path.join(str(tmp_path), "dsgn_patch_ratio_0.2", "epoch0", "patch.npy"))
+
+
+def test_patch_trainer_skips_wrong_shapes(tmp_path):
+    b = _small_batch(1, sizes=False)
+    tr = attacks.PatchTrainer("dsgn", 0.2, 8 / 255, 1, 1, out_root=str(tmp_path), seed=1, ops=_oracle_ops, device=torch.device("cpu"))
+    patch = tr.train(lambda: [b], _CpuToy())
+    assert not patch.numpy().any()                                   # patch_attack.py:318-320: skipped
+
+
+# ------------------------------------------------------------------------------------ CLI surface
+def test_cli_defaults_match_the_reference_scripts():
+    from eval_driving_safety_amd.cli import dsgn_pgd_attack, dsgn_patch_attack, srcnn_pgd_attack, srcnn_patch_attack
+    a = dsgn_pgd_attack.build_parser().parse_args(["-btest", "1", "-d", "0"])
+    assert (a.iter, a.alpha, a.eps, a.seed, a.split_file, a.data_path) == (4, 1.0 / 255, 0.3, 1, "./data/kitti/val.txt", "./data/kitti/training")
+    a = dsgn_patch_attack.build_parser().parse_args([])
+    assert (a.iter, a.eps, a.epochs, a.ratio) == (2, 8.0 / 255, 80, 0.2)
+    a = srcnn_pgd_attack.build_parser().parse_args([])
+    assert (a.iter, a.alpha, a.eps) == (4, 1.0, 0.3)
+    a = srcnn_patch_attack.build_parser().parse_args([])
+    assert (a.iter, a.eps, a.epochs, a.ratio) == (2, 0.1, 40, 0.1)
+
+
+def test_synthetic_source_shapes():
+    b = next(iter(data.SyntheticStereo(2, "dsgn", batch=2)))
+    assert tuple(b.imgL.shape) == (2, 3, 384, 1248) and b.sizes == [(1242, 375)] * 2 and b.names == ["000000", "000001"]
+    assert float(b.imgL[:, :, 375:].abs().max()) == 0.0          # zero padding after normalisation
+    b = next(iter(data.SyntheticStereo(1, "srcnn")))
+    assert tuple(b.imgL.shape) == (1, 3, 600, 1987) and b.sizes is None
