@@ -76,7 +76,7 @@ class PgdAttack:
     def _emit(self, k, u8, batch):
         if not self.save or (k % self.save_every != 0 and k != self.iters):
             return
-        host = u8.cpu().numpy()                      # [2B, rows, W, 3]
+        host = u8.detach().to("cpu", copy=True).numpy()    # [2B, rows, W, 3]; a private copy: the encoder threads read it later
         b = len(batch)
         for eye in (0, 1):
             d = os.path.join(self.out_root, pixelio.iter_dir(self.prefix, k, eye))
