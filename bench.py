@@ -80,6 +80,25 @@ def cpu_baseline(sample_pairs):
             "sample": "%d KITTI-shaped pairs x 20-step PGD + 8-bit export, %s, %.1f s" % (done, kind_note, dt)}
 
 
+def pmc_traffic(pairs):
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC summary
+    (profiles/*_pmc_hbm.json, written by tools/summarize_prof.py from separate rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE passes of this same bench; gfx950 correction 2*FETCH_SIZE + WRITE_SIZE), scaled to `pairs`.
+    Counters cannot be read from inside the timed run, so this is a recorded measurement, not a live one."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.json")))
+    if not files:
+        return None, None
+    try:
+        with open(files[-1]) as f:
+            d = json.load(f)
+        k = [v for name, v in d["kernels"].items() if name.startswith("pgd_step_vec4<0, 1>")][0]
+        prof_pairs = d["bench_lines_under_profiler"][-1]["config"]["pairs_per_gpu"]
+        return k["hbm_bytes_per_launch"] * pairs / prof_pairs, os.path.basename(files[-1])
+    except Exception:
+        return None, None
+
+
 def main():
     args = parse()
     import torch
@@ -149,6 +168,7 @@ def main():
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
 
     if rank == 0:
+        traffic, traffic_src = pmc_traffic(args.pairs)
         out = {
             "metric": "KITTI stereo-pairs/sec for 20-step PGD on DSGN (perturbation path; detector fwd+bwd is the caller's)",
             "value": world * args.pairs * args.steps / elapsed,
@@ -164,7 +184,8 @@ def main():
                        "parallelism": "image-sharded x%d, no collective" % world},
             "roofline": {"bound": "hbm", "kernel": "pgd_step_vec4<AFFINE,U8_ROWS_DWORD>",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "avg_launch_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "avg_launch_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_pairs)
