@@ -57,6 +57,8 @@ SIGNATURES = {
     "adv_patch_update_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _F, _F3, _F3, _P, _P],
     "adv_patch_delta_batch_f32": [_P, _P, _L, _I, _I, _I, _P, _I, _F, _F, _P, _P],
     "adv_patch_apply_f32": [_P, _P, _I, _F3, _F3, _P],
+    "adv_psv_build_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "adv_psv_build_bwd_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
 }
 _OTHER = {
     "adv_abi_version": ([], _I),

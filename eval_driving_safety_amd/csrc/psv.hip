@@ -1,0 +1,295 @@
+// K7: plane-sweep cost-volume build (forward + adjoint) for gfx950.
+//
+// Pure data movement: the forward writes B*2C*D*H*W floats (368 MB per DSGN sample) from two small
+// feature maps, the backward reads as many and reduces over the D depth planes.  Both are HBM-bound;
+// the design goal is that HBM sees each cost-volume byte exactly once, in whole aligned 16-byte
+// lane accesses, and the feature maps once:
+//   * a workgroup owns kRows consecutive feature rows of one (sample, channel) and ALL depth planes, so
+//     the rows it needs are read from HBM once and every (c,d) slice it writes is one contiguous run
+//     of kRows*W floats;
+//   * the per-plane disparity shift s makes the right-eye access unaligned (x - s).  The rows are
+//     staged in LDS next to a zero apron; a lane then fetches the two ALIGNED float4 that straddle
+//     its shifted position (conflict-free ds_read_b128) and picks the 4 floats with a select on
+//     s mod 4, which is uniform over the wave - no unaligned or byte-granular memory access at all;
+//   * the backward keeps the D-sum in registers (one lane owns 4 x-positions of one row for all
+//     planes, added in plane order), so there are no atomics and the float32 result is reproducible.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "advengine.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr int kRows = 4;
+
+__device__ __forceinline__ v4f zero4() { return (v4f){0.0f, 0.0f, 0.0f, 0.0f}; }
+
+// 4 consecutive floats starting `rem` floats into the aligned pair (a, b); rem is wave-uniform
+__device__ __forceinline__ v4f funnel(v4f a, v4f b, int rem) {
+  switch (rem) {
+    case 0: return a;
+    case 1: return (v4f){a.y, a.z, a.w, b.x};
+    case 2: return (v4f){a.z, a.w, b.x, b.y};
+    default: return (v4f){a.w, b.x, b.y, b.z};
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// forward.  grid = (ceil(H/kRows), C, B * dsplit); block = kRows * W/4 lanes rounded up to a wave.
+// LDS per row: [ W/4 zero float4 | W/4 float4 of the right-eye row | 1 spare ], so that index
+// (W/4 + x4 - ceil(s/4) ...) never leaves the buffer for 0 <= s <= W.
+// ---------------------------------------------------------------------------------------------------
+template <bool NT>
+__global__ void psv_fwd_vec4(const v4f* __restrict__ left, const v4f* __restrict__ right, const int32_t* __restrict__ shift,
+                             v4f* __restrict__ cost, int C, int D, int H, int w4, int dsplit) {
+  extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+  v4f* lds = reinterpret_cast<v4f*>(lds_raw);
+  const int row_pitch = 2 * w4 + 1;
+  const int b = blockIdx.z / dsplit;
+  const int dpart = blockIdx.z - b * dsplit;
+  const int c = blockIdx.y;
+  const int y0 = blockIdx.x * kRows;
+  const int r = threadIdx.x / w4;
+  const int x4 = threadIdx.x - r * w4;
+  const bool active = r < kRows && (y0 + r) < H;
+  const long long plane = static_cast<long long>(H) * w4;
+
+  v4f lv = zero4();
+  if (active) {
+    const long long src = (static_cast<long long>(b) * C + c) * plane + static_cast<long long>(y0 + r) * w4 + x4;
+    lv = left[src];
+    lds[r * row_pitch + x4] = zero4();
+    lds[r * row_pitch + w4 + x4] = right[src];
+    if (x4 == 0) lds[r * row_pitch + 2 * w4] = zero4();
+  }
+  __syncthreads();
+  if (!active) return;
+
+  const int d_per = (D + dsplit - 1) / dsplit;
+  const int d_lo = dpart * d_per;
+  const int d_hi = (d_lo + d_per < D) ? d_lo + d_per : D;
+  const long long out_l = ((static_cast<long long>(b) * 2 * C + c) * D) * plane + static_cast<long long>(y0 + r) * w4 + x4;
+  const long long out_r = out_l + static_cast<long long>(C) * D * plane;
+  const int x = x4 * 4;
+  for (int d = d_lo; d < d_hi; ++d) {
+    int s = shift[b * D + d];  // uniform -> scalar load
+    s = s < 0 ? 0 : (s > 4 * w4 ? 4 * w4 : s);
+    // left half: keep x >= s
+    v4f lo = lv;
+    if (x < s) lo.x = 0.0f;
+    if (x + 1 < s) lo.y = 0.0f;
+    if (x + 2 < s) lo.z = 0.0f;
+    if (x + 3 < s) lo.w = 0.0f;
+    // right half: floats [x - s, x - s + 4) of the zero-extended row
+    const int p = 4 * w4 + x - s;  // >= 0, index in floats from the start of the LDS row
+    const int base = p >> 2;
+    const int rem = p & 3;         // == (-s) & 3: uniform
+    const v4f a = lds[r * row_pitch + base];
+    const v4f bb = lds[r * row_pitch + base + 1];
+    const v4f ro = funnel(a, bb, rem);
+    if (NT) {
+      __builtin_nontemporal_store(lo, cost + out_l + static_cast<long long>(d) * plane);
+      __builtin_nontemporal_store(ro, cost + out_r + static_cast<long long>(d) * plane);
+    } else {
+      cost[out_l + static_cast<long long>(d) * plane] = lo;
+      cost[out_r + static_cast<long long>(d) * plane] = ro;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward.  Same ownership.  Left half: aligned loads, masked, summed in registers.  Right half: the
+// plane's rows go through a 2-deep LDS ring ([row | zero apron]) so that the shifted read x + s is again
+// two aligned float4 + a uniform select; one barrier per plane.
+// ---------------------------------------------------------------------------------------------------
+template <bool NT>
+__global__ void psv_bwd_vec4(const v4f* __restrict__ gcost, const int32_t* __restrict__ shift, v4f* __restrict__ gleft,
+                             v4f* __restrict__ gright, int C, int D, int H, int w4) {
+  extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+  v4f* lds = reinterpret_cast<v4f*>(lds_raw);
+  const int row_pitch = 2 * w4 + 1;
+  const int buf_pitch = kRows * row_pitch;
+  const int b = blockIdx.z;
+  const int c = blockIdx.y;
+  const int y0 = blockIdx.x * kRows;
+  const int r = threadIdx.x / w4;
+  const int x4 = threadIdx.x - r * w4;
+  const bool active = r < kRows && (y0 + r) < H;
+  const long long plane = static_cast<long long>(H) * w4;
+  const long long in_l = ((static_cast<long long>(b) * 2 * C + c) * D) * plane + static_cast<long long>(y0 + r) * w4 + x4;
+  const long long in_r = in_l + static_cast<long long>(C) * D * plane;
+  const int x = x4 * 4;
+
+  if (active) {  // zero aprons of both ring buffers, once
+    lds[r * row_pitch + w4 + x4] = zero4();
+    lds[buf_pitch + r * row_pitch + w4 + x4] = zero4();
+    if (x4 == 0) {
+      lds[r * row_pitch + 2 * w4] = zero4();
+      lds[buf_pitch + r * row_pitch + 2 * w4] = zero4();
+    }
+  }
+  v4f accl = zero4(), accr = zero4();
+  v4f gl_next = zero4(), gr_next = zero4();
+  if (active && D > 0) {
+    gl_next = NT ? __builtin_nontemporal_load(gcost + in_l) : gcost[in_l];
+    gr_next = NT ? __builtin_nontemporal_load(gcost + in_r) : gcost[in_r];
+  }
+  for (int d = 0; d < D; ++d) {
+    const v4f gl = gl_next, gr = gr_next;
+    v4f* buf = lds + (d & 1) * buf_pitch;
+    if (active) buf[r * row_pitch + x4] = gr;
+    if (active && d + 1 < D) {  // prefetch the next plane while this one is exchanged through LDS
+      gl_next = NT ? __builtin_nontemporal_load(gcost + in_l + static_cast<long long>(d + 1) * plane) : gcost[in_l + static_cast<long long>(d + 1) * plane];
+      gr_next = NT ? __builtin_nontemporal_load(gcost + in_r + static_cast<long long>(d + 1) * plane) : gcost[in_r + static_cast<long long>(d + 1) * plane];
+    }
+    __syncthreads();  // plane d is in buf; the other buffer (plane d-1) is free to be overwritten next trip
+    int s = shift[b * D + d];
+    s = s < 0 ? 0 : (s > 4 * w4 ? 4 * w4 : s);
+    if (active) {
+      v4f m = gl;
+      if (x < s) m.x = 0.0f;
+      if (x + 1 < s) m.y = 0.0f;
+      if (x + 2 < s) m.z = 0.0f;
+      if (x + 3 < s) m.w = 0.0f;
+      accl = (d == 0) ? m : accl + m;
+      const int p = x + s;  // floats [x + s, x + s + 4) of the zero-extended plane row
+      const int base = p >> 2;
+      const int rem = p & 3;
+      const v4f a = buf[r * row_pitch + base];
+      const v4f bb = buf[r * row_pitch + base + 1];
+      const v4f t = funnel(a, bb, rem);
+      accr = (d == 0) ? t : accr + t;
+    }
+  }
+  if (active) {
+    const long long dst = (static_cast<long long>(b) * C + c) * plane + static_cast<long long>(y0 + r) * w4 + x4;
+    gleft[dst] = accl;
+    gright[dst] = accr;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// general widths (W % 4 != 0 or unaligned pointers): one lane per element, no LDS
+// ---------------------------------------------------------------------------------------------------
+__global__ void psv_fwd_scalar(const float* __restrict__ left, const float* __restrict__ right, const int32_t* __restrict__ shift,
+                               float* __restrict__ cost, int B, int C, int D, int H, int W) {
+  const long long total = static_cast<long long>(B) * C * D * H * W;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += gridDim.x * 256LL) {
+    const int x = static_cast<int>(i % W);
+    long long t = i / W;
+    const int y = static_cast<int>(t % H);
+    t /= H;
+    const int d = static_cast<int>(t % D);
+    t /= D;
+    const int c = static_cast<int>(t % C);
+    const int b = static_cast<int>(t / C);
+    int s = shift[b * D + d];
+    s = s < 0 ? 0 : s;
+    const long long src = ((static_cast<long long>(b) * C + c) * H + y) * W;
+    const long long dl = (((static_cast<long long>(b) * 2 * C + c) * D + d) * H + y) * W + x;
+    const long long dr = dl + static_cast<long long>(C) * D * H * W;
+    const bool in = x >= s;
+    cost[dl] = in ? left[src + x] : 0.0f;
+    cost[dr] = in ? right[src + x - s] : 0.0f;
+  }
+}
+
+__global__ void psv_bwd_scalar(const float* __restrict__ gcost, const int32_t* __restrict__ shift, float* __restrict__ gleft,
+                               float* __restrict__ gright, int B, int C, int D, int H, int W) {
+  const long long total = static_cast<long long>(B) * C * H * W;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += gridDim.x * 256LL) {
+    const int x = static_cast<int>(i % W);
+    long long t = i / W;
+    const int y = static_cast<int>(t % H);
+    t /= H;
+    const int c = static_cast<int>(t % C);
+    const int b = static_cast<int>(t / C);
+    float al = 0.0f, ar = 0.0f;
+    for (int d = 0; d < D; ++d) {
+      int s = shift[b * D + d];
+      s = s < 0 ? 0 : s;
+      const long long gl = (((static_cast<long long>(b) * 2 * C + c) * D + d) * H + y) * W;
+      const long long gr = gl + static_cast<long long>(C) * D * H * W;
+      const float vl = x >= s ? gcost[gl + x] : 0.0f;
+      const float vr = (x + s < W) ? gcost[gr + x + s] : 0.0f;
+      al = d == 0 ? vl : al + vl;
+      ar = d == 0 ? vr : ar + vr;
+    }
+    gleft[i] = al;
+    gright[i] = ar;
+  }
+}
+
+inline bool aligned(const void* p, uintptr_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
+
+inline int finish() {
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? ADV_OK : ADV_ELAUNCH;
+}
+
+inline int check(const void* a, const void* b, const void* c, const void* d, int B, int C, int D, int H, int W) {
+  if (!a || !b || !c || !d) return ADV_EINVAL;
+  if (B < 1 || C < 1 || D < 1 || H < 1 || W < 1 || B > 65535 || C > 65535) return ADV_EINVAL;
+  if (static_cast<long long>(H) * W > (1LL << 30)) return ADV_EINVAL;
+  if (!aligned(a, 4) || !aligned(b, 4) || !aligned(c, 4) || !aligned(d, 4)) return ADV_EALIGN;
+  return ADV_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int adv_psv_build_f32(const float* left, const float* right, const int32_t* shift, float* cost, int b, int c, int d, int h,
+                      int w, adv_stream_t stream) {
+  const int rc = check(left, right, shift, cost, b, c, d, h, w);
+  if (rc != ADV_OK) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int w4 = w / 4;
+  const int threads = ((kRows * w4 + 63) / 64) * 64;
+  const size_t lds = static_cast<size_t>(kRows) * (2 * w4 + 1) * sizeof(v4f);
+  const bool vec = (w % 4 == 0) && threads <= 1024 && lds <= 65536 && aligned(left, 16) && aligned(right, 16) && aligned(cost, 16);
+  if (vec) {
+    // split the planes over 2 workgroups when one (row-tile, channel, sample) grid would leave CUs idle
+    const long long tiles = static_cast<long long>((h + kRows - 1) / kRows) * c * b;
+    const int dsplit = (tiles < 2048 && d >= 8) ? 2 : 1;
+    if (static_cast<long long>(b) * dsplit > 65535) return ADV_EINVAL;
+    const dim3 grid((h + kRows - 1) / kRows, c, b * dsplit);
+    hipLaunchKernelGGL((psv_fwd_vec4<true>), grid, dim3(threads), lds, st, reinterpret_cast<const v4f*>(left),
+                       reinterpret_cast<const v4f*>(right), shift, reinterpret_cast<v4f*>(cost), c, d, h, w4, dsplit);
+  } else {
+    const long long total = static_cast<long long>(b) * c * d * h * w;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 1 << 20) blocks = 1 << 20;
+    hipLaunchKernelGGL(psv_fwd_scalar, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, left, right, shift, cost, b, c, d, h, w);
+  }
+  return finish();
+}
+
+int adv_psv_build_bwd_f32(const float* grad_cost, const int32_t* shift, float* grad_left, float* grad_right, int b, int c,
+                          int d, int h, int w, adv_stream_t stream) {
+  const int rc = check(grad_cost, shift, grad_left, grad_right, b, c, d, h, w);
+  if (rc != ADV_OK) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int w4 = w / 4;
+  const int threads = ((kRows * w4 + 63) / 64) * 64;
+  const size_t lds = 2 * static_cast<size_t>(kRows) * (2 * w4 + 1) * sizeof(v4f);
+  const bool vec = (w % 4 == 0) && threads <= 1024 && lds <= 65536 && aligned(grad_cost, 16) && aligned(grad_left, 16) && aligned(grad_right, 16);
+  if (vec) {
+    const dim3 grid((h + kRows - 1) / kRows, c, b);
+    hipLaunchKernelGGL((psv_bwd_vec4<true>), grid, dim3(threads), lds, st, reinterpret_cast<const v4f*>(grad_cost), shift,
+                       reinterpret_cast<v4f*>(grad_left), reinterpret_cast<v4f*>(grad_right), c, d, h, w4);
+  } else {
+    const long long total = static_cast<long long>(b) * c * h * w;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 1 << 20) blocks = 1 << 20;
+    hipLaunchKernelGGL(psv_bwd_scalar, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, grad_cost, shift, grad_left, grad_right, b, c, d, h, w);
+  }
+  return finish();
+}
+
+}  // extern "C"

@@ -142,6 +142,27 @@ int adv_patch_delta_batch_f32(const float* grad_l, const float* grad_r, int64_t 
 int adv_patch_apply_f32(float* patch, const float* delta, int d, const float* lo,
                         const float* hi, adv_stream_t stream);
 
+/* K7  plane-sweep cost-volume build of a DSGN-style detector (the op the reference reaches through
+ *     `model(imgL, imgR, ...)`, attack/DSGN/pgd_attack.py:308; it lives in the upstream DSGN repository,
+ *     not in the reference tree, so this follows the published algorithm - PSMNet-style concatenation
+ *     volume with one integer disparity shift per depth plane - and its parity is pinned against the
+ *     oracle only, NOT against upstream code).
+ *       left, right : [B,C,H,W] float32 feature maps (1/4 resolution in DSGN: C=32, 96 x 312)
+ *       shift       : DEVICE int32 [B,D], s >= 0 = disparity of depth plane d in feature pixels
+ *                     (fu * baseline / depth_d / downsample, rounded by the caller)
+ *       cost        : [B,2C,D,H,W];  for x >= s:  cost[b,c,d,y,x]   = left[b,c,y,x]
+ *                                                  cost[b,C+c,d,y,x] = right[b,c,y,x-s]
+ *                                    for x <  s:  both 0.
+ *     Every element of `cost` is written (no memset needed). */
+int adv_psv_build_f32(const float* left, const float* right, const int32_t* shift, float* cost, int b,
+                      int c, int d, int h, int w, adv_stream_t stream);
+
+/* K7 backward: the exact adjoint.  grad_left[b,c,y,x]  = sum_d [x >= s_d]     grad_cost[b,c,d,y,x]
+ *                                  grad_right[b,c,y,x] = sum_d [x + s_d < W]  grad_cost[b,C+c,d,y,x+s_d]
+ *     summed over d = 0..D-1 in that order in float32 (reproducible; no atomics). */
+int adv_psv_build_bwd_f32(const float* grad_cost, const int32_t* shift, float* grad_left,
+                          float* grad_right, int b, int c, int d, int h, int w, adv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -263,3 +263,43 @@ def kitti_label_line(cls, bbox, score, corners, dims):
     return ("{} -1 -1 {:.4f} {:.4f} {:.4f} {:.4f} {:.4f} {:.6f} {:.6f} {:.6f} {:.6f} {:.6f} {:.6f} {:.6f} {:.8f}\n"
             .format(name, alpha, bbox[0], bbox[1], bbox[2], bbox[3], h, w, l,
                     center[0], y, center[2], ry, score))
+
+
+# ----------------------------------------------------------------------------- K7
+def psv_build(left, right, shift):
+    """Plane-sweep concatenation cost volume of a DSGN-style detector (reached through the model call,
+    attack/DSGN/pgd_attack.py:308).  UNPINNED against upstream DSGN (its CUDA op is not in the reference
+    tree); this restates the published construction: per depth plane d one integer disparity shift s,
+    cost[b, :C, d, :, s:] = left[..., s:], cost[b, C:, d, :, s:] = right[..., :W-s], zero elsewhere."""
+    left, right = _f32(left), _f32(right)
+    b, c, h, w = left.shape
+    d = shift.shape[1]
+    cost = np.zeros((b, 2 * c, d, h, w), np.float32)
+    for bi in range(b):
+        for di in range(d):
+            s = max(0, min(int(shift[bi, di]), w))
+            cost[bi, :c, di, :, s:] = left[bi, :, :, s:]
+            cost[bi, c:, di, :, s:] = right[bi, :, :, :w - s]
+    return cost
+
+
+def psv_build_bwd(grad_cost, shift):
+    """Exact adjoint of psv_build; the sum over planes runs d = 0, 1, ... in float32."""
+    g = _f32(grad_cost)
+    b, c2, d, h, w = g.shape
+    c = c2 // 2
+    gl = np.zeros((b, c, h, w), np.float32)
+    gr = np.zeros((b, c, h, w), np.float32)
+    for bi in range(b):
+        for di in range(d):
+            s = max(0, min(int(shift[bi, di]), w))
+            tl = np.zeros((c, h, w), np.float32)
+            tr = np.zeros((c, h, w), np.float32)
+            tl[:, :, s:] = g[bi, :c, di, :, s:]
+            tr[:, :, :w - s] = g[bi, c:, di, :, s:]
+            if di == 0:
+                gl[bi], gr[bi] = tl, tr
+            else:
+                gl[bi] += tl
+                gr[bi] += tr
+    return gl, gr

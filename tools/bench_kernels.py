@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Per-kernel timings of the secondary kernels (everything except the PGD step that bench.py measures):
+affine maps, stand-alone export, patch paste / delta / apply, PSV cost-volume forward / backward.
+HIP events on torch's current stream; prints one JSON line per kernel with algorithmic GB/s."""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from eval_driving_safety_amd import ops  # noqa: E402
+
+
+def timeit(fn, reps=20, warm=3):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def line(name, ms, nbytes, **kw):
+    print(json.dumps(dict(kernel=name, ms=round(ms, 4), algorithmic_GB=round(nbytes / 1e9, 4),
+                          GBps=round(nbytes / ms / 1e6, 1), frac_of_8TBps=round(nbytes / ms / 1e6 / 8000, 3), **kw)))
+
+
+def main():
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    H, W = 384, 1248
+    # ---- PSV at the DSGN shape
+    for B in (1, 4, 16):
+        C, D, h, w = 32, 48, H // 4, W // 4
+        left = torch.randn((B, C, h, w), device=dev)
+        right = torch.randn((B, C, h, w), device=dev)
+        depth = 2.0 + 0.8 * torch.arange(D, device=dev)
+        shift = (721.5377 * 0.54 / depth / 4).round().to(torch.int32).repeat(B, 1).contiguous()
+        cost = torch.empty((B, 2 * C, D, h, w), device=dev)
+        vol = cost.numel() * 4
+        feat = 2 * left.numel() * 4
+        line("psv_build fwd", timeit(lambda: ops.psv_build(left, right, shift, out=cost)), vol + feat, B=B)
+        g = torch.randn_like(cost)
+        line("psv_build bwd", timeit(lambda: ops.psv_build_bwd(g, shift)), vol + feat, B=B)
+        del cost, g
+    # ---- affine / export at 512 images
+    n = 512
+    sp = ops.Space.dsgn()
+    x = torch.randn((n, 3, H, W), device=dev)
+    out = torch.empty_like(x)
+    E = x.numel() * 4
+    line("denormalize", timeit(lambda: ops.denormalize(x, sp, out=out)), 2 * E, images=n)
+    line("normalize", timeit(lambda: ops.normalize(x, sp, out=out)), 2 * E, images=n)
+    u8 = ops.alloc_u8(n, 375, W, dev)
+    line("export_u8", timeit(lambda: ops.export_u8(x, sp, (375, 1242), out=u8)), n * (3 * 375 * W * 4 + 3 * 375 * 1242), images=n)
+    del out
+    # ---- Stereo R-CNN shaped PGD step (config 3): 64 pairs of 600x1987
+    ns = 128
+    sps = ops.Space.srcnn()
+    xs = torch.randn((ns, 3, 600, 1987), device=dev) * 50
+    gs = torch.randn_like(xs)
+    cs = xs.clone()
+    u8s = ops.alloc_u8(ns, 600, 1987, dev)
+    Es = xs.numel() * 4
+    line("pgd_step srcnn (in place, no u8)", timeit(lambda: ops.pgd_step(xs, gs, cs, sps, 1.0, 7.65, out=xs)), 4 * Es, images=ns)
+    line("pgd_step srcnn (in place, byte-path u8: W%4!=0)", timeit(lambda: ops.pgd_step(xs, gs, cs, sps, 1.0, 7.65, out=xs, u8_out=u8s), reps=5),
+         4 * Es + ns * 3 * 600 * 1987, images=ns)
+    del xs, gs, cs, u8s
+    # ---- patch kernels, batch of 64 pairs
+    B, r = 64, 38
+    d = 2 * r + 1
+    img = x[:2 * B]
+    patch = torch.randn((1, 3, d, d), device=dev)
+    c2 = torch.stack([torch.randint(160, 340, (2 * B,), device=dev), torch.randint(300, 1000, (2 * B,), device=dev)], 1).to(torch.int32).contiguous()
+    line("patch_paste_batch", timeit(lambda: ops.patch_paste_batch(img, patch, c2, r)), 2 * B * 2 * 3 * d * d * 4, pairs=B)
+    c3 = torch.stack([c2[:B, 0], c2[:B, 1], c2[:B, 1] - 64], 1).contiguous()
+    gl, gr = img[:B], img[B:]
+    line("patch_delta_batch", timeit(lambda: ops.patch_delta_batch(gl, gr, c3, r, 8 / 255)), B * 2 * 3 * d * d * 4 + 3 * d * d * 4, pairs=B)
+    delta = torch.zeros((3, d, d), device=dev)
+    line("patch_apply", timeit(lambda: ops.patch_apply(patch, delta)), 3 * 3 * d * d * 4)
+    one = x[:1]
+    line("patch_paste (1 image)", timeit(lambda: ops.patch_paste(one, patch, 200, 600, r)), 2 * 3 * d * d * 4)
+    line("patch_update (1 pair)", timeit(lambda: ops.patch_update(patch, x[:1], x[1:2], 200, 600, 536, r, 8 / 255)), 4 * 3 * d * d * 4)
+
+
+if __name__ == "__main__":
+    main()
