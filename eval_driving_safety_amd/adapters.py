@@ -80,6 +80,68 @@ class ToyStereoAdapter:
         pass
 
 
+class PsvStereoAdapter:
+    """A DSGN-SHAPED depth branch with seeded random weights, for end-to-end timing of the attack loop and as
+    the autograd consumer of the K7 kernels: siamese 2D features at 1/4 resolution (32 channels) -> plane-sweep
+    concatenation volume [B,64,48,96,312] (HIP: ops.PsvBuild) -> three 3D convolutions (MIOpen through torch)
+    -> softmax over the 48 depth planes -> expected depth -> smooth-L1 against a sparse depth map, i.e. the
+    ``disp_loss`` term of attack/DSGN/pgd_attack.py:310-319.  It is NOT DSGN (no 3DGV, no detection head, no
+    trained weights): detection parity is unpinned by construction; it exists so that "20-step PGD through a
+    plane-sweep network" can be measured end to end on this hardware."""
+
+    def __init__(self, device, seed=0, channels=32, planes=48, min_depth=2.0, depth_step=0.8, fu=721.5377,
+                 baseline=0.54, downsample=4, mid=32):
+        from . import ops
+        self.ops = ops
+        gen = torch.Generator().manual_seed(seed)
+
+        def w(*shape):
+            fan_in = 1
+            for v in shape[1:]:
+                fan_in *= v
+            return (torch.randn(*shape, generator=gen) * (2.0 / fan_in) ** 0.5).to(device)
+
+        self.f1, self.f2, self.f3 = w(16, 3, 3, 3), w(channels, 16, 3, 3), w(channels, channels, 3, 3)
+        self.c1, self.c2, self.c3 = w(mid, 2 * channels, 3, 3, 3), w(mid, mid, 3, 3, 3), w(1, mid, 3, 3, 3)
+        self.depth = (min_depth + depth_step * torch.arange(planes, dtype=torch.float32)).to(device)
+        self.fu, self.baseline, self.downsample = fu, baseline, downsample
+        self.device = device
+
+    def shifts(self, b):
+        disp = self.fu * self.baseline / self.depth / self.downsample       # feature-pixel disparity per plane
+        return disp.round().to(torch.int32).repeat(b, 1).contiguous()
+
+    def features(self, img):
+        f = F.relu(F.conv2d(img, self.f1, stride=2, padding=1))
+        f = F.relu(F.conv2d(f, self.f2, stride=2, padding=1))
+        return F.conv2d(f, self.f3, padding=1)
+
+    def depth_pred(self, imgL, imgR):
+        fl, fr = self.features(imgL), self.features(imgR)
+        cost = self.ops.PsvBuild.apply(fl.contiguous(), fr.contiguous(), self.shifts(imgL.shape[0]))
+        v = F.relu(F.conv3d(cost, self.c1, padding=1))
+        v = F.relu(F.conv3d(v, self.c2, padding=1))
+        v = F.conv3d(v, self.c3, padding=1).squeeze(1)                       # [B,D,h,w]
+        prob = torch.softmax(v, dim=1)
+        depth = (prob * self.depth.view(1, -1, 1, 1)).sum(dim=1, keepdim=True)
+        return F.interpolate(depth, scale_factor=self.downsample, mode="bilinear", align_corners=False).squeeze(1)
+
+    def loss_and_grad(self, x, extra):
+        """extra.disp_true [B,H,W] sparse metric depth (0 = no measurement); mask as pgd_attack.py:269"""
+        h = _LeafGrad(x)
+        with h as leaf:
+            imgL, imgR = split_eyes(leaf)
+            pred = self.depth_pred(imgL, imgR)
+            gt = extra.disp_true
+            mask = (gt > float(self.depth[0])) & (gt <= float(self.depth[-1]) + 0.8)
+            loss = F.smooth_l1_loss(pred[mask], gt[mask], reduction="mean")
+            loss.backward()
+            return loss.detach(), h.take()
+
+    def inject_fake_target(self, extra, centers_l, centers_r, radius):
+        pass
+
+
 class DsgnAdapter:
     """attack/DSGN/pgd_attack.py:300-336 around an upstream DSGN ``StereoNet`` (eval mode) and its
     ``RPN3DLoss``.  ``extra`` must carry: calibs_fu, calibs_baseline, calibs_Proj, calibs_Proj_R (:262-266),

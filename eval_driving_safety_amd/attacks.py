@@ -73,17 +73,21 @@ class PgdAttack:
         self.writer = pixelio.PngWriter(writer_workers, bgr=(model_kind == "srcnn")) if save else None
 
     # -- file surface --------------------------------------------------------------------------
-    def _emit(self, k, u8, batch):
-        if not self.save or (k % self.save_every != 0 and k != self.iters):
-            return
-        host = u8.detach().to("cpu", copy=True).numpy()    # [2B, rows, W, 3]; a private copy: the encoder threads read it later
+    def _wanted(self, k):
+        return self.save and (k % self.save_every == 0 or k == self.iters)
+
+    def _fan_out(self, k, batch):
         b = len(batch)
-        for eye in (0, 1):
-            d = os.path.join(self.out_root, pixelio.iter_dir(self.prefix, k, eye))
-            for i, name in enumerate(batch.names):
-                stem = name if name.lower().endswith(".png") else name + ".png"
-                w, h = batch.sizes[i] if batch.sizes is not None else (None, None)
-                self.writer.put(os.path.join(d, stem), host[eye * b + i], crop_w=w, crop_h=h)
+        names, sizes = list(batch.names), batch.sizes
+
+        def fan_out(host):                           # host: [2B, rows, W, 3] uint8, private copy
+            for eye in (0, 1):
+                d = os.path.join(self.out_root, pixelio.iter_dir(self.prefix, k, eye))
+                for i, name in enumerate(names):
+                    stem = name if name.lower().endswith(".png") else name + ".png"
+                    w, h = sizes[i] if sizes is not None else (None, None)
+                    self.writer.put(os.path.join(d, stem), host[eye * b + i], crop_w=w, crop_h=h)
+        return fan_out
 
     # -- one batch -----------------------------------------------------------------------------
     def run_batch(self, batch, adapter):
@@ -94,20 +98,24 @@ class PgdAttack:
         n, _, h, w = x.shape
         rows = h if batch.sizes is None else max(s[1] for s in batch.sizes)
         cols = w if batch.sizes is None else max(s[0] for s in batch.sizes)
-        u8 = ops.alloc_u8(n, rows, w, dev) if self.save else None
+        exporter = pixelio.AsyncExporter(self.writer, lambda: ops.alloc_u8(n, rows, w, dev), dev) if self.save else None
         # clean image in pixel space: pgd_attack.py:297-298 (DSGN) / :122-123 (Stereo R-CNN)
         clean = ops.denormalize(x, sp) if sp.affine else x.clone()
-        if self.save:                                # iterate 0 = the un-attacked pair, :279-294
-            ops.export_u8(x, sp, (rows, cols), out=u8)
-            self._emit(0, u8, batch)
+        if self._wanted(0):                          # iterate 0 = the un-attacked pair, :279-294
+            ops.export_u8(x, sp, (rows, cols), out=exporter.next_buffer())
+            exporter.submit(self._fan_out(0, batch))
         losses = []
         for k in range(self.iters):
             loss, grad = adapter.loss_and_grad(x, batch.extra)           # detector fwd + loss + bwd (:305-336)
             losses.append(loss)
-            ops.pgd_step(x, grad.contiguous(), clean, sp, self.alpha, self.eps, out=x, u8_out=u8,
-                         crop=(rows, cols) if self.save else None)       # :339-354 (+ :357-374 export)
-            if self.save:
-                self._emit(k + 1, u8, batch)
+            want = self._wanted(k + 1)
+            ops.pgd_step(x, grad.contiguous(), clean, sp, self.alpha, self.eps, out=x,
+                         u8_out=exporter.next_buffer() if want else None,
+                         crop=(rows, cols) if want else None)            # :339-354 (+ :357-374 export)
+            if want:
+                exporter.submit(self._fan_out(k + 1, batch))
+        if exporter is not None:
+            exporter.close()
         self.last_losses = losses
         return x
 
@@ -174,10 +182,10 @@ class PatchTrainer:
     def init_patch(self, device):
         d0 = pixelio.patch_dir(self.prefix, self.ratio, 0, self.out_root)
         if self.comm.rank == 0:
-            host, _ = pixelio.load_or_init_patch(d0, self.patch_dim)
+            host, _ = pixelio.load_or_init_patch(d0, self.patch_dim, allow_resize=(self.kind == "dsgn"))
         self.comm.barrier()
         if self.comm.rank != 0:
-            host, _ = pixelio.load_or_init_patch(d0, self.patch_dim)
+            host, _ = pixelio.load_or_init_patch(d0, self.patch_dim, allow_resize=(self.kind == "dsgn"))
         self.patch = torch.from_numpy(host).to(device).contiguous()
         return self.patch
 

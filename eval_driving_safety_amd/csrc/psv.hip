@@ -4,9 +4,8 @@
 // feature maps, the backward reads as many and reduces over the D depth planes.  Both are HBM-bound;
 // the design goal is that HBM sees each cost-volume byte exactly once, in whole aligned 16-byte
 // lane accesses, and the feature maps once:
-//   * a workgroup owns kRows consecutive feature rows of one (sample, channel) and ALL depth planes, so
-//     the rows it needs are read from HBM once and every (c,d) slice it writes is one contiguous run
-//     of kRows*W floats;
+//   * a workgroup owns kRows consecutive feature rows of one (sample, channel): of one depth plane in the
+//     forward (long contiguous write runs), of ALL planes in the backward (the D-sum stays in registers);
 //   * the per-plane disparity shift s makes the right-eye access unaligned (x - s).  The rows are
 //     staged in LDS next to a zero apron; a lane then fetches the two ALIGNED float4 that straddle
 //     its shifted position (conflict-free ds_read_b128) and picks the 4 floats with a select on
@@ -40,25 +39,30 @@ __device__ __forceinline__ v4f funnel(v4f a, v4f b, int rem) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// forward.  grid = (ceil(H/kRows), C, B * dsplit); block = kRows * W/4 lanes rounded up to a wave.
+// forward.  grid = (ceil(H/kRows), D, B*C): one workgroup per (row tile, depth plane, sample*channel).
+// Every workgroup writes two contiguous runs of kRows*W floats and consecutive workgroups write
+// consecutive runs of the same (c,d) slice; the feature rows are re-read once per plane, which the
+// L2 / Infinity Cache absorbs (7.7 MB of features per DSGN sample).  Measured against the
+// "one workgroup owns all planes of its rows" decomposition (gpurun_out/psv_sweep.log, round 1):
+// 0.71 / 0.81 / 0.75 of HBM peak at B = 1 / 4 / 16 versus 0.64 / 0.67 / 0.70; non-temporal stores
+// are worth +30 % here (0.54 without).
 // LDS per row: [ W/4 zero float4 | W/4 float4 of the right-eye row | 1 spare ], so that index
 // (W/4 + x4 - ceil(s/4) ...) never leaves the buffer for 0 <= s <= W.
 // ---------------------------------------------------------------------------------------------------
 template <bool NT>
-__global__ void psv_fwd_vec4(const v4f* __restrict__ left, const v4f* __restrict__ right, const int32_t* __restrict__ shift,
-                             v4f* __restrict__ cost, int C, int D, int H, int w4, int dsplit) {
+__global__ void psv_fwd_plane(const v4f* __restrict__ left, const v4f* __restrict__ right, const int32_t* __restrict__ shift,
+                              v4f* __restrict__ cost, int C, int D, int H, int w4) {
   extern __shared__ __attribute__((aligned(16))) float lds_raw[];
   v4f* lds = reinterpret_cast<v4f*>(lds_raw);
   const int row_pitch = 2 * w4 + 1;
-  const int b = blockIdx.z / dsplit;
-  const int dpart = blockIdx.z - b * dsplit;
-  const int c = blockIdx.y;
+  const int b = blockIdx.z / C;
+  const int c = blockIdx.z - b * C;
+  const int d = blockIdx.y;
   const int y0 = blockIdx.x * kRows;
   const int r = threadIdx.x / w4;
   const int x4 = threadIdx.x - r * w4;
   const bool active = r < kRows && (y0 + r) < H;
   const long long plane = static_cast<long long>(H) * w4;
-
   v4f lv = zero4();
   if (active) {
     const long long src = (static_cast<long long>(b) * C + c) * plane + static_cast<long long>(y0 + r) * w4 + x4;
@@ -69,36 +73,23 @@ __global__ void psv_fwd_vec4(const v4f* __restrict__ left, const v4f* __restrict
   }
   __syncthreads();
   if (!active) return;
-
-  const int d_per = (D + dsplit - 1) / dsplit;
-  const int d_lo = dpart * d_per;
-  const int d_hi = (d_lo + d_per < D) ? d_lo + d_per : D;
-  const long long out_l = ((static_cast<long long>(b) * 2 * C + c) * D) * plane + static_cast<long long>(y0 + r) * w4 + x4;
-  const long long out_r = out_l + static_cast<long long>(C) * D * plane;
+  int s = shift[b * D + d];
+  s = s < 0 ? 0 : (s > 4 * w4 ? 4 * w4 : s);
   const int x = x4 * 4;
-  for (int d = d_lo; d < d_hi; ++d) {
-    int s = shift[b * D + d];  // uniform -> scalar load
-    s = s < 0 ? 0 : (s > 4 * w4 ? 4 * w4 : s);
-    // left half: keep x >= s
-    v4f lo = lv;
-    if (x < s) lo.x = 0.0f;
-    if (x + 1 < s) lo.y = 0.0f;
-    if (x + 2 < s) lo.z = 0.0f;
-    if (x + 3 < s) lo.w = 0.0f;
-    // right half: floats [x - s, x - s + 4) of the zero-extended row
-    const int p = 4 * w4 + x - s;  // >= 0, index in floats from the start of the LDS row
-    const int base = p >> 2;
-    const int rem = p & 3;         // == (-s) & 3: uniform
-    const v4f a = lds[r * row_pitch + base];
-    const v4f bb = lds[r * row_pitch + base + 1];
-    const v4f ro = funnel(a, bb, rem);
-    if (NT) {
-      __builtin_nontemporal_store(lo, cost + out_l + static_cast<long long>(d) * plane);
-      __builtin_nontemporal_store(ro, cost + out_r + static_cast<long long>(d) * plane);
-    } else {
-      cost[out_l + static_cast<long long>(d) * plane] = lo;
-      cost[out_r + static_cast<long long>(d) * plane] = ro;
-    }
+  if (x < s) lv.x = 0.0f;
+  if (x + 1 < s) lv.y = 0.0f;
+  if (x + 2 < s) lv.z = 0.0f;
+  if (x + 3 < s) lv.w = 0.0f;
+  const int p = 4 * w4 + x - s;
+  const v4f ro = funnel(lds[r * row_pitch + (p >> 2)], lds[r * row_pitch + (p >> 2) + 1], p & 3);
+  const long long out_l = ((static_cast<long long>(b) * 2 * C + c) * D + d) * plane + static_cast<long long>(y0 + r) * w4 + x4;
+  const long long out_r = out_l + static_cast<long long>(C) * D * plane;
+  if (NT) {
+    __builtin_nontemporal_store(lv, cost + out_l);
+    __builtin_nontemporal_store(ro, cost + out_r);
+  } else {
+    cost[out_l] = lv;
+    cost[out_r] = ro;
   }
 }
 
@@ -254,13 +245,10 @@ int adv_psv_build_f32(const float* left, const float* right, const int32_t* shif
   const size_t lds = static_cast<size_t>(kRows) * (2 * w4 + 1) * sizeof(v4f);
   const bool vec = (w % 4 == 0) && threads <= 1024 && lds <= 65536 && aligned(left, 16) && aligned(right, 16) && aligned(cost, 16);
   if (vec) {
-    // split the planes over 2 workgroups when one (row-tile, channel, sample) grid would leave CUs idle
-    const long long tiles = static_cast<long long>((h + kRows - 1) / kRows) * c * b;
-    const int dsplit = (tiles < 2048 && d >= 8) ? 2 : 1;
-    if (static_cast<long long>(b) * dsplit > 65535) return ADV_EINVAL;
-    const dim3 grid((h + kRows - 1) / kRows, c, b * dsplit);
-    hipLaunchKernelGGL((psv_fwd_vec4<true>), grid, dim3(threads), lds, st, reinterpret_cast<const v4f*>(left),
-                       reinterpret_cast<const v4f*>(right), shift, reinterpret_cast<v4f*>(cost), c, d, h, w4, dsplit);
+    if (static_cast<long long>(b) * c > 65535 || d > 65535) return ADV_EINVAL;
+    hipLaunchKernelGGL((psv_fwd_plane<true>), dim3((h + kRows - 1) / kRows, d, b * c), dim3(threads), lds, st,
+                       reinterpret_cast<const v4f*>(left), reinterpret_cast<const v4f*>(right), shift,
+                       reinterpret_cast<v4f*>(cost), c, d, h, w4);
   } else {
     const long long total = static_cast<long long>(b) * c * d * h * w;
     long long blocks = (total + 255) / 256;

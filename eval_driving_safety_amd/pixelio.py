@@ -61,6 +61,121 @@ class PngWriter:
             raise self.err
 
 
+class AsyncExporter:
+    """Moves the 8-bit iterates device -> pinned host -> PNG encoder threads without stalling the attack
+    stream (the reference blocks on ``.cpu()`` + numpy + zlib twice per PGD step, pgd_attack.py:357-374).
+
+    Two device export buffers alternate: the PGD kernel of step k writes buffer k % 2 while the copy engine
+    drains buffer (k-1) % 2 on a side stream into a pinned slot; a drain thread waits for that copy's event,
+    takes a private copy and hands per-image views to the PngWriter.  For CPU tensors (the oracle-backed
+    test shim) it degrades to a synchronous copy.
+    """
+
+    SLOTS = 2
+
+    def __init__(self, writer, alloc, device):
+        import torch
+        self.torch = torch
+        self.writer = writer
+        self.dev_bufs = [alloc() for _ in range(self.SLOTS)]
+        self.cuda = self.dev_bufs[0].is_cuda
+        self.turn = 0
+        self.err = None
+        if self.cuda:
+            self.stream = torch.cuda.Stream(device=device)
+            self.pinned = [torch.empty(b.shape, dtype=b.dtype, pin_memory=True) for b in self.dev_bufs]
+            self.copied = [None] * self.SLOTS                 # event: D2H of the slot finished
+            self.free = [threading.Semaphore(1) for _ in range(self.SLOTS)]
+            self.jobs = queue.Queue()
+            self.thread = threading.Thread(target=self._drain, daemon=True)
+            self.thread.start()
+
+    def next_buffer(self):
+        """device buffer the next kernel may write (its previous copy-out has been ordered before reuse)"""
+        slot = self.turn % self.SLOTS
+        if self.cuda and self.copied[slot] is not None:
+            self.torch.cuda.current_stream().wait_event(self.copied[slot])
+        return self.dev_bufs[slot]
+
+    def submit(self, fan_out):
+        """the kernel writing next_buffer() has been enqueued on the current stream; ``fan_out(host_array)``
+        is called later with the [n, rows, W, 3] uint8 host copy and must enqueue the PNG jobs"""
+        slot = self.turn % self.SLOTS
+        self.turn += 1
+        buf = self.dev_bufs[slot]
+        if not self.cuda:
+            fan_out(buf.detach().to("cpu", copy=True).numpy())
+            return
+        torch = self.torch
+        ready = torch.cuda.Event()
+        ready.record()
+        self.free[slot].acquire()                             # the drain thread is done with this pinned slot
+        self.stream.wait_event(ready)
+        with torch.cuda.stream(self.stream):
+            self.pinned[slot].copy_(buf, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record()
+        self.copied[slot] = done
+        self.jobs.put((slot, done, fan_out))
+
+    def _drain(self):
+        while True:
+            item = self.jobs.get()
+            if item is None:
+                return
+            slot, done, fan_out = item
+            try:
+                done.synchronize()
+                host = self.pinned[slot].numpy().copy()
+                self.free[slot].release()
+                fan_out(host)
+            except Exception as e:
+                self.err = e
+                self.free[slot].release()
+
+    def close(self):
+        if self.cuda:
+            self.jobs.put(None)
+            self.thread.join()
+        if self.err is not None:
+            raise self.err
+
+
+def resize_patch_bilinear(patch, new_dim):
+    """``cv2.resize(patch_hwc, (new_dim, new_dim), interpolation=cv2.INTER_LINEAR)`` of init_patch
+    (attack/DSGN/patch_attack.py:224-227: a patch trained on the other detector is resized on resume).
+    UNPINNED: cv2 is neither in the reference tree nor in this image; this follows OpenCV's documented
+    float32 algorithm - pixel centres aligned, fx = (dx+0.5)*scale-0.5, edge clamp, separable float32
+    interpolation, horizontal pass first.  patch [1,3,D,D] -> [1,3,new_dim,new_dim]."""
+    a = np.asarray(patch, dtype=np.float32)[0]                 # [3, D, D]
+    src = a.shape[1]
+    if src == new_dim:
+        return a[None].copy()
+    scale = np.float64(src) / np.float64(new_dim)
+
+    def taps(n_dst):
+        idx = np.empty(n_dst, np.int64)
+        w1 = np.empty(n_dst, np.float32)
+        for d in range(n_dst):
+            f = (d + 0.5) * scale - 0.5
+            s = int(np.floor(f))
+            f = np.float32(f - s)
+            if s < 0:
+                s, f = 0, np.float32(0)
+            if s >= src - 1:
+                s, f = src - 1, np.float32(0)
+            idx[d], w1[d] = s, f
+        return idx, w1
+
+    ix, wx = taps(new_dim)
+    ix1 = np.minimum(ix + 1, src - 1)
+    rows = a[:, :, ix] * (np.float32(1) - wx) + a[:, :, ix1] * wx          # horizontal pass
+    iy, wy = ix, wx                                                          # square patch: same taps
+    iy1 = np.minimum(iy + 1, src - 1)
+    out = rows[:, iy, :] * (np.float32(1) - wy)[None, :, None] + rows[:, iy1, :] * wy[None, :, None]
+    return out[None].astype(np.float32)
+
+
 def patch_dir(prefix, ratio, epoch, root="."):
     """``{dsgn,stereo_rcnn}_patch_ratio_{ratio}/epoch{E}`` (attack/DSGN/patch_attack.py:286,438)."""
     return os.path.join(root, "%s_patch_ratio_%s" % (prefix, ratio), "epoch%s" % epoch)
@@ -75,16 +190,18 @@ def save_patch(path_dir, patch):
     np.save(os.path.join(path_dir, "patch.npy"), a)
 
 
-def load_or_init_patch(path_dir, patch_dim):
-    """init_patch (attack/Stereo-RCNN/patch_attack.py:67-76): resume from ``epoch0/patch.npy`` if the
-    directory exists, else zeros (saved).  A patch of another size (the DSGN script's cross-model
-    transfer, attack/DSGN/patch_attack.py:220-227, resizes with cv2) is rejected here - see DESIGN.md."""
+def load_or_init_patch(path_dir, patch_dim, allow_resize=False):
+    """init_patch: resume from ``epoch0/patch.npy`` if the directory exists, else zeros (saved).
+    Stereo R-CNN loads the file as it is (attack/Stereo-RCNN/patch_attack.py:67-69); the DSGN script
+    resizes a patch of another size bilinearly (cross-model transfer, attack/DSGN/patch_attack.py:220-227):
+    ``allow_resize=True``."""
     f = os.path.join(path_dir, "patch.npy")
     if os.path.isdir(path_dir) and os.path.exists(f):
         patch = np.load(f).astype(np.float32)
         if patch.shape != (1, 3, patch_dim, patch_dim):
-            raise ValueError("existing patch %s is %s, expected %s (resize it offline)"
-                             % (f, patch.shape, (1, 3, patch_dim, patch_dim)))
+            if allow_resize and patch.ndim == 4 and patch.shape[:2] == (1, 3) and patch.shape[2] == patch.shape[3]:
+                return resize_patch_bilinear(patch, patch_dim), True
+            raise ValueError("existing patch %s is %s, expected %s" % (f, patch.shape, (1, 3, patch_dim, patch_dim)))
         return patch, True
     patch = np.zeros((1, 3, patch_dim, patch_dim), dtype=np.float32)
     save_patch(path_dir, patch)

@@ -132,6 +132,30 @@ def test_patch_files(tmp_path):
         pixelio.load_or_init_patch(d0, 61)
 
 
+def test_patch_resize_bilinear(tmp_path):
+    """cross-model transfer branch of init_patch (attack/DSGN/patch_attack.py:220-227); unpinned vs cv2,
+    checked for the properties of OpenCV's INTER_LINEAR: identity at equal size, exact on affine ramps
+    in the interior, edge clamp, separability."""
+    p = synth.patch_init(3, 61, -100, 100)
+    assert pixelio.resize_patch_bilinear(p, 61).tobytes() == p.tobytes()
+    yy, xx = np.mgrid[:61, :61].astype(np.float32)
+    ramp = np.stack([2 * xx + 1, 3 * yy - 2, xx + yy])[None]
+    out = pixelio.resize_patch_bilinear(ramp, 77)
+    assert out.shape == (1, 3, 77, 77) and out.dtype == np.float32
+    d = np.arange(77)
+    f = (d + 0.5) * (61 / 77) - 0.5
+    inner = (f > 0) & (f < 60)
+    np.testing.assert_allclose(out[0, 0][:, inner], np.broadcast_to(2 * f[inner] + 1, (77, inner.sum())), rtol=0, atol=2e-4)
+    np.testing.assert_allclose(out[0, 1][inner, :], np.broadcast_to((3 * f[inner] - 2)[:, None], (inner.sum(), 77)), rtol=0, atol=2e-4)
+    assert out[0, 0][0, 0] == ramp[0, 0, 0, 0] and out[0, 0][0, -1] == ramp[0, 0, 0, -1]          # clamped edges
+    d0 = pixelio.patch_dir("dsgn", 0.2, 0, str(tmp_path))
+    pixelio.save_patch(d0, p)
+    got, existed = pixelio.load_or_init_patch(d0, 77, allow_resize=True)
+    assert existed and got.shape == (1, 3, 77, 77)
+    with pytest.raises(ValueError):
+        pixelio.load_or_init_patch(d0, 77)
+
+
 # ------------------------------------------------------------------------------------ drivers on CPU
 class _CpuToy(adapters.ToyStereoAdapter):
     def __init__(self, seed=0):
