@@ -272,3 +272,54 @@ class PatchTrainer:
                                self.patch.detach().cpu().numpy()[None] if self.patch.dim() == 3 else self.patch.detach().cpu().numpy())
         comm.barrier()
         return self.patch
+
+
+class DetectUnderAttack:
+    """Counterpart of the four ``predict_and_save_*`` scripts: run the detector without
+    gradients on attacked stereo pairs and write one KITTI label file per image.
+
+    mode 'pgd'   : the loader already yields attacked images (the ``*_pgd_iters_k`` folders swapped in for
+                   ``image_2/3``, attack/DSGN/README.md:30,69) - nothing is modified here.
+    mode 'patch' : the trained patch is pasted at a position drawn per image from the ``atk_mode`` column band
+                   (attack/DSGN/predict_and_save_patch.py:361-391,430-459; Stereo R-CNN :82-112), wrong-shape
+                   pairs are skipped (:423-425).
+    ``detector.detect(x, extra)`` -> per pair a list of (cls, bbox[4], score, center[3], (h, w, l, ry)); the
+    post-processing that produces those (FCOS3D post-processor + NMS, ``get_dimensions``) is upstream code.
+    """
+
+    def __init__(self, model_kind, mode, label_dir, patch=None, atk_mode="random", seed=None, rng=None, ops=None,
+                 device=None):
+        self.ops = ops if ops is not None else _default_ops()
+        if mode not in ("pgd", "patch"):
+            raise ValueError("mode must be 'pgd' or 'patch'")
+        self.kind, self.mode, self.label_dir, self.device = model_kind, mode, label_dir, device
+        self.shape = patchgeom.DSGN_SHAPE if model_kind == "dsgn" else patchgeom.SRCNN_SHAPE
+        self.patch, self.sampler, self.positions = None, None, []
+        if mode == "patch":
+            if patch is None:
+                raise Exception("Patch directory NOT found.")            # predict_and_save_patch.py:356
+            self.patch = patch
+            self.radius = int(patch.shape[-1]) // 2
+            self.sampler = patchgeom.CenterSampler(self.shape[0], self.shape[1], self.radius, atk_mode, seed=seed, rng=rng)
+
+    def run(self, loader, detector, debugnum=None):
+        written = 0
+        for i, batch in enumerate(loader):
+            if debugnum is not None and i * len(batch) > debugnum:
+                break
+            dev = self.device if self.device is not None else batch.imgL.device
+            x = torch.cat([batch.imgL, batch.imgR], dim=0).to(dev, dtype=torch.float32).contiguous()
+            b = len(batch)
+            if self.mode == "patch":
+                if tuple(x.shape[2:]) != tuple(self.shape):
+                    continue
+                cl, cr = zip(*[self.sampler.draw() for _ in range(b)])
+                self.positions.extend(zip(batch.names, cl, cr))
+                centers = torch.tensor([[c[0], c[1]] for c in cl] + [[c[0], c[1]] for c in cr], dtype=torch.int32, device=dev)
+                self.ops.patch_paste_batch(x, self.patch.to(dev), centers, self.radius)
+            with torch.no_grad():
+                dets = detector.detect(x, batch.extra)
+            for name, d in zip(batch.names, dets):
+                pixelio.write_kitti_labels(self.label_dir, int(os.path.splitext(name)[0]), d)
+                written += 1
+        return written

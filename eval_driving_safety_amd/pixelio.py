@@ -229,3 +229,40 @@ def write_kitti_labels(output_path, image_index, detections):
     with open(os.path.join(output_path, "{:06d}.txt".format(image_index)), "w") as f:
         for det in detections:
             f.write(kitti_label_line(*det))
+
+
+# --- result folders of the detect-under-attack scripts -------------------------------------------------
+def dsgn_tag(tag="", iter_num=None, alpha=None, ratio=None, epochs=None, debugnum=None, train=False):
+    """args.tag as the DSGN scripts extend it (attack/DSGN/predict_and_save_pgd.py:84-94,
+    predict_and_save_patch.py:88-98): debug{n}, _train, _iter{i}_alpha{a} / _ratio{r}_epochs{E}."""
+    if debugnum is not None:
+        tag += "debug{}".format(debugnum)
+    if train:
+        tag += "_train"
+    if alpha and iter_num:
+        tag += "_iter{0}_alpha{1}".format(str(iter_num), str(alpha))
+    if ratio is not None and epochs is not None:
+        tag += "_ratio{0}_epochs{1}".format(str(ratio), str(epochs))
+    return tag
+
+
+def dsgn_label_dir(loadmodel, tag):
+    """``<dirname(loadmodel)>/kitti_output{tag}`` (predict_and_save_pgd.py:334-341)"""
+    return os.path.join(os.path.dirname(loadmodel), "kitti_output" + tag)
+
+
+def srcnn_result_dir(iter_num=None, alpha=None, ratio=None, epochs=None):
+    """``result_stereo_rcnn_pgd_{iter}_{alpha}`` (attack/Stereo-RCNN/predict_and_save_pgd.py:75) or
+    ``result_stereo_rcnn_ratio_{r}/epoch{E}`` (predict_and_save_patch.py:137)"""
+    if ratio is not None:
+        return "result_stereo_rcnn_ratio_{0}/epoch{1}".format(ratio, epochs)
+    return "result_stereo_rcnn_pgd_{0}_{1}".format(iter_num, alpha)
+
+
+def srcnn_im_info_prescaled(im_info, scale_target=600, native_height=375):
+    """The Stereo R-CNN attack saves its adversarial PNGs at network scale; when they are read back the
+    eval script forces ``im_info[0][2] = 600 / 375`` so boxes map to KITTI coordinates
+    (attack/Stereo-RCNN/predict_and_save_pgd.py:134-136, quirk Q14).  Returns a modified copy."""
+    info = np.array(im_info, dtype=np.float32, copy=True)
+    info[0][2] = float(scale_target) / float(native_height)
+    return info

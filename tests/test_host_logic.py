@@ -258,6 +258,47 @@ def test_patch_trainer_skips_wrong_shapes(tmp_path):
     assert not patch.numpy().any()                                   # patch_attack.py:318-320: skipped
 
 
+def test_detect_under_attack_patch_mode(tmp_path):
+    """paste at atk_mode positions, then labels; the consumer's parse of evaluation/convert_scenarios.py"""
+    H, W = patchgeom.DSGN_SHAPE
+    patch = torch.from_numpy(synth.patch_init(1, 77))
+    l, r = synth.dsgn_normalised(90, H, W), synth.dsgn_normalised(91, H, W)
+    seen = {}
+
+    class Det:
+        def detect(self, x, extra):
+            seen["x"] = x.clone()
+            return [[(2, np.float32([10, 20, 30, 40]), np.float32(0.9), np.float32([1.0, 1.5, 20.0]), (1.5, 1.6, 3.9, -1.57)),
+                     (1, np.float32([1, 2, 3, 4]), np.float32(0.5), np.float32([-2.0, 1.2, 9.0]), (1.7, 0.6, 0.8, 0.3))]]
+
+    dua = attacks.DetectUnderAttack("dsgn", "patch", str(tmp_path / "kitti_output_x"), patch=patch, atk_mode="sp_left",
+                                    seed=3, ops=_oracle_ops, device=torch.device("cpu"))
+    small = _small_batch(1, sizes=False)                                  # wrong shape: skipped
+    big = attacks.StereoBatch(torch.from_numpy(l), torch.from_numpy(r), ["000123"], [(1242, 375)])
+    assert dua.run([small, big], Det()) == 1
+    (name, cl, cr), = dua.positions
+    rng = random.Random(3)
+    wl, wr = O.round_mask_centers(rng, H, W, 38, "sp_left")
+    assert (cl, cr) == (wl, wr) and int(W * 0.2) <= cl[1] <= int(W * 0.4)
+    assert seen["x"][0:1].numpy().tobytes() == O.patch_paste(l, patch.numpy(), cl[0], cl[1], 38).tobytes()
+    assert seen["x"][1:2].numpy().tobytes() == O.patch_paste(r, patch.numpy(), cr[0], cr[1], 38).tobytes()
+    lines = open(os.path.join(str(tmp_path), "kitti_output_x", "000123.txt")).read().strip().split("\n")
+    assert [ln.split(" ")[0] for ln in lines] == ["Car", "Pedestrian"] and all(len(ln.split(" ")) == 16 for ln in lines)
+    with pytest.raises(Exception):
+        attacks.DetectUnderAttack("dsgn", "patch", str(tmp_path), patch=None, ops=_oracle_ops)
+
+
+def test_result_folder_names():
+    assert pixelio.dsgn_tag("", 4, 0.00392) == "_iter4_alpha0.00392"
+    assert pixelio.dsgn_tag("", ratio=0.2, epochs=80) == "_ratio0.2_epochs80"
+    assert pixelio.dsgn_label_dir("./outputs/temp/DSGN_car_pretrained/finetune_53.tar", "_ratio0.2_epochs80") == \
+        "./outputs/temp/DSGN_car_pretrained/kitti_output_ratio0.2_epochs80"
+    assert pixelio.srcnn_result_dir(1, 1) == "result_stereo_rcnn_pgd_1_1"
+    assert pixelio.srcnn_result_dir(ratio=0.1, epochs=40) == "result_stereo_rcnn_ratio_0.1/epoch40"
+    info = pixelio.srcnn_im_info_prescaled(np.float32([[600, 1987, 1.0]]))
+    assert info[0][2] == np.float32(600 / 375) and info[0][0] == 600
+
+
 # ------------------------------------------------------------------------------------ CLI surface
 def test_cli_defaults_match_the_reference_scripts():
     from eval_driving_safety_amd.cli import dsgn_pgd_attack, dsgn_patch_attack, srcnn_pgd_attack, srcnn_patch_attack

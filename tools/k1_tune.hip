@@ -154,7 +154,9 @@ static float time_ms(hipStream_t s, int reps, const std::function<void()>& f) {
 
 int main(int argc, char** argv) {
   const int pairs = argc > 1 ? atoi(argv[1]) : 256;
-  const int H = 384, W = 1248, CROP_H = 375, CROP_W = 1242;
+  const int H = argc > 2 ? atoi(argv[2]) : 384, W = argc > 3 ? atoi(argv[3]) : 1248;
+  const int CROP_H = argc > 2 ? H : 375, CROP_W = argc > 2 ? W : 1242;
+  const bool u8ok = (W % 4) == 0;
   const long long n_img = 2LL * pairs;
   const int hw4 = H * W / 4;
   const long long elems = n_img * 3LL * H * W;
@@ -214,6 +216,22 @@ int main(int argc, char** argv) {
   }
 
   float* xo_sep = xo;
+  if (!u8ok) {  // Stereo R-CNN-like shapes: no aligned u8 rows; study plane misalignment with u8 off
+    for (int inplace = 0; inplace < 2; ++inplace) {
+      xo = inplace ? x : xo_sep;
+      printf("---- %s\n", inplace ? "in place (x_out == x)" : "out of place");
+      RUN(false, false, 1, 64, false, false, 0);
+      RUN(false, true, 1, 64, false, false, 0);
+      RUN(true, true, 1, 64, false, false, 0);
+      RUN(true, false, 1, 64, false, false, 0);
+      RUN(false, false, 2, 64, false, false, 0);
+      RUN(false, true, 2, 64, false, false, 0);
+      RUN(true, true, 2, 64, false, false, 0);
+      RUN(true, true, 2, 256, false, false, 0);
+      RUN(false, false, 2, 256, false, false, 0);
+    }
+    return 0;
+  }
   for (int inplace = 0; inplace < 2; ++inplace) {
     xo = inplace ? x : xo_sep;
     printf("---- %s\n", inplace ? "in place (x_out == x)" : "out of place");
