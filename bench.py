@@ -109,8 +109,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # test hooks (a 1-GPU box cannot host two RCCL ranks): ADV_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and
+        # ADV_BENCH_BACKEND=gloo swaps the backend, so the world > 1 code path can be smoke-tested anywhere
+        share = os.environ.get("ADV_BENCH_SHARE_GPU") == "1"
+        backend = os.environ.get("ADV_BENCH_BACKEND", "nccl")
+        torch.cuda.set_device(0 if share else local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
     if world != args.gpus and rank == 0:
@@ -161,6 +168,33 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # Outside the timed region, N > 1 only: latency of the one collective the attacks have - the all-reduce(SUM)
+    # of the universal-patch delta [3,D,D] (D = 101: BASELINE configs[3], 122 KB) over RCCL / xGMI - checked
+    # against the closed form so that the multi-GPU patch path is exercised on real links every time the scaling
+    # bench runs.  Never part of `value`.
+    patch_comm = None
+    if world > 1:
+        try:
+            d = 101
+            delta = torch.full((3, d, d), float(rank + 1), device=dev)
+            for _ in range(5):
+                dist.all_reduce(delta.clone())
+            torch.cuda.synchronize()
+            dist.barrier()
+            reps = 50
+            bufs = [delta.clone() for _ in range(reps)]
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            c0.record()
+            for b in bufs:
+                dist.all_reduce(b)
+            c1.record()
+            torch.cuda.synchronize()
+            ok = bool((bufs[-1] == world * (world + 1) / 2).all().item())
+            patch_comm = {"collective": "all_reduce(SUM) of the patch delta [3,101,101] f32 (122412 B) over RCCL",
+                          "avg_us": 1e3 * c0.elapsed_time(c1) / reps, "correct": ok}
+        except Exception as e:                       # report, never fail the throughput line
+            patch_comm = {"error": repr(e)}
+
     # dominant kernel: pgd_step_vec4<AFFINE, rows-dword u8>; HIP events on the launch stream
     kern_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / (args.steps * N_ITER)
     elems = 3 * H * W
@@ -187,6 +221,8 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
         }
+        if patch_comm is not None:
+            out["patch_allreduce"] = patch_comm
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_pairs)
         print(json.dumps(out))
