@@ -168,33 +168,6 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # Outside the timed region, N > 1 only: latency of the one collective the attacks have - the all-reduce(SUM)
-    # of the universal-patch delta [3,D,D] (D = 101: BASELINE configs[3], 122 KB) over RCCL / xGMI - checked
-    # against the closed form so that the multi-GPU patch path is exercised on real links every time the scaling
-    # bench runs.  Never part of `value`.
-    patch_comm = None
-    if world > 1:
-        try:
-            d = 101
-            delta = torch.full((3, d, d), float(rank + 1), device=dev)
-            for _ in range(5):
-                dist.all_reduce(delta.clone())
-            torch.cuda.synchronize()
-            dist.barrier()
-            reps = 50
-            bufs = [delta.clone() for _ in range(reps)]
-            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            c0.record()
-            for b in bufs:
-                dist.all_reduce(b)
-            c1.record()
-            torch.cuda.synchronize()
-            ok = bool((bufs[-1] == world * (world + 1) / 2).all().item())
-            patch_comm = {"collective": "all_reduce(SUM) of the patch delta [3,101,101] f32 (122412 B) over RCCL",
-                          "avg_us": 1e3 * c0.elapsed_time(c1) / reps, "correct": ok}
-        except Exception as e:                       # report, never fail the throughput line
-            patch_comm = {"error": repr(e)}
-
     # dominant kernel: pgd_step_vec4<AFFINE, rows-dword u8>; HIP events on the launch stream
     kern_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / (args.steps * N_ITER)
     elems = 3 * H * W
@@ -221,11 +194,51 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
         }
-        if patch_comm is not None:
-            out["patch_allreduce"] = patch_comm
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_pairs)
-        print(json.dumps(out))
+    else:
+        out = None
+
+    # Outside the timed region, N > 1 only: latency of the one collective the attacks have - the all-reduce(SUM)
+    # of the universal-patch delta [3,D,D] (D = 101: BASELINE configs[3], 122 KB) over RCCL / xGMI - checked
+    # against the closed form, so the multi-GPU patch path runs on real links whenever the scaling bench does.
+    # Never part of `value`; a watchdog prints the throughput line without it if the collective stalls.
+    if world > 1:
+        import threading
+
+        def bail():
+            if rank == 0:
+                out["patch_allreduce"] = {"error": "timed out after 120 s"}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(120.0, bail)
+        dog.daemon = True
+        dog.start()
+        try:
+            d = 101
+            delta = torch.full((3, d, d), float(rank + 1), device=dev)
+            for _ in range(5):
+                dist.all_reduce(delta.clone())
+            torch.cuda.synchronize()
+            reps = 50
+            bufs = [delta.clone() for _ in range(reps)]
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            c0.record()
+            for b in bufs:
+                dist.all_reduce(b)
+            c1.record()
+            torch.cuda.synchronize()
+            ok = bool((bufs[-1] == world * (world + 1) / 2).all().item())
+            patch_comm = {"collective": "all_reduce(SUM) of the patch delta [3,101,101] f32 (122412 B) over RCCL",
+                          "avg_us": 1e3 * c0.elapsed_time(c1) / reps, "correct": ok}
+        except Exception as e:                       # report, never fail the throughput line
+            patch_comm = {"error": repr(e)}
+        dog.cancel()
+        if rank == 0:
+            out["patch_allreduce"] = patch_comm
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
