@@ -343,3 +343,61 @@ class PsvBuild(torch.autograd.Function):
         (shift,) = ctx.saved_tensors
         gl, gr = psv_build_bwd(grad_cost.contiguous(), shift)
         return gl, gr, None
+
+
+# --------------------------------------------------------------------------------------------
+# Stereo R-CNN RoI path (attack/Stereo-RCNN/stereo_rcnn.py:44-45,132-134; predict_and_save_pgd.py:300)
+def roi_align(feat, rois, pooled, spatial_scale, sampling_ratio=0):
+    """feat [B,C,H,W], rois [R,5] = (batch idx, x1, y1, x2, y2) -> [R,C,PH,PW] (legacy RoIAlign)."""
+    f, r = _feat(feat, "feat"), _feat(rois, "rois")
+    if f.dim() != 4 or r.dim() != 2 or r.shape[1] != 5:
+        raise ValueError("feat must be [B,C,H,W], rois [R,5]")
+    b, c, h, w = f.shape
+    ph, pw = (pooled, pooled) if isinstance(pooled, int) else pooled
+    out = torch.empty((r.shape[0], c, ph, pw), dtype=torch.float32, device=f.device)
+    with _on(f):
+        _lib.call("adv_roi_align_fwd_f32", _ptr(f), _ptr(r), _ptr(out), b, c, h, w, r.shape[0], ph, pw, float(spatial_scale),
+                  int(sampling_ratio), _stream(f))
+    return out
+
+
+def roi_align_bwd(grad_out, rois, feat_shape, spatial_scale, sampling_ratio=0):
+    g, r = _feat(grad_out, "grad_out"), _feat(rois, "rois")
+    b, c, h, w = feat_shape
+    if g.dim() != 4 or g.shape[0] != r.shape[0] or g.shape[1] != c:
+        raise ValueError("grad_out must be [R,C,PH,PW]")
+    gf = torch.empty((b, c, h, w), dtype=torch.float32, device=g.device)
+    with _on(g):
+        _lib.call("adv_roi_align_bwd_f32", _ptr(g), _ptr(r), _ptr(gf), b, c, h, w, r.shape[0], g.shape[2], g.shape[3],
+                  float(spatial_scale), int(sampling_ratio), _stream(g))
+    return gf
+
+
+class RoIAlign(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, rois, pooled, spatial_scale, sampling_ratio):
+        ctx.save_for_backward(rois)
+        ctx.meta = (tuple(feat.shape), spatial_scale, sampling_ratio)
+        return roi_align(feat.contiguous(), rois.contiguous(), pooled, spatial_scale, sampling_ratio)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (rois,) = ctx.saved_tensors
+        shape, scale, sr = ctx.meta
+        return roi_align_bwd(grad_out.contiguous(), rois, shape, scale, sr), None, None, None, None
+
+
+def nms(boxes, scores, thresh):
+    """``nms(boxes[order], scores[order], thresh)`` of attack/Stereo-RCNN/predict_and_save_pgd.py:300: boxes
+    [N,4] must already be in descending-score order (the reference sorts before calling); returns the kept
+    indices (int64, ascending = descending score).  ``scores`` is accepted for signature parity and unused."""
+    bx = _feat(boxes, "boxes")
+    if bx.dim() != 2 or bx.shape[1] != 4:
+        raise ValueError("boxes must be [N,4]")
+    n = bx.shape[0]
+    keep = torch.empty((max(n, 1),), dtype=torch.int64, device=bx.device)
+    count = torch.zeros((1,), dtype=torch.int32, device=bx.device)
+    work = torch.empty((max(1, n * ((n + 63) // 64)),), dtype=torch.int64, device=bx.device)
+    with _on(bx):
+        _lib.call("adv_nms_f32", _ptr(bx), n, float(thresh), _ptr(keep), _ptr(count), _ptr(work), _stream(bx))
+    return keep[:int(count.item())]

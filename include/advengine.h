@@ -163,6 +163,31 @@ int adv_psv_build_f32(const float* left, const float* right, const int32_t* shif
 int adv_psv_build_bwd_f32(const float* grad_cost, const int32_t* shift, float* grad_left,
                           float* grad_right, int b, int c, int d, int h, int w, adv_stream_t stream);
 
+/* ---- Stereo R-CNN RoI path natives.  The ops are `from model.roi_layers import ROIAlign, nms`
+ *      (attack/Stereo-RCNN/stereo_rcnn.py:18,44-45,132-134; predict_and_save_pgd.py:26,300) - compiled
+ *      extensions of the upstream Stereo R-CNN checkout, absent from the reference tree.  These follow the
+ *      published maskrcnn-benchmark algorithms the upstream extension is built from; parity is pinned against
+ *      the oracle only (UNPINNED against upstream). */
+
+/* RoIAlign forward (legacy, non-"aligned" pixel model): rois [R,5] = (batch index, x1, y1, x2, y2) in image
+ *     coordinates, scaled by spatial_scale; sampling_ratio <= 0 -> ceil(roi_size / pooled_size) samples per bin
+ *     (the reference constructs ROIAlign(..., 1/16, 0) and passes the FPN level's scale per call);
+ *     out [R,C,PH,PW] = mean of the bilinear samples of each bin. */
+int adv_roi_align_fwd_f32(const float* feat, const float* rois, float* out, int b, int c, int h, int w, int r,
+                          int ph, int pw, float spatial_scale, int sampling_ratio, adv_stream_t stream);
+
+/* RoIAlign backward: grad_feat [B,C,H,W] is zero-filled by this call, then every sample scatters
+ *     grad_out * weight / count to its 4 neighbours with float atomics (sum order varies between runs: results are
+ *     equal to the oracle within float32 rounding, not bitwise). */
+int adv_roi_align_bwd_f32(const float* grad_out, const float* rois, float* grad_feat, int b, int c, int h, int w,
+                          int r, int ph, int pw, float spatial_scale, int sampling_ratio, adv_stream_t stream);
+
+/* Greedy NMS over n boxes [n,4] = (x1,y1,x2,y2) ALREADY SORTED by descending score, legacy "+1" areas,
+ *     suppress when IoU > thresh.  keep_out [n] int64 receives the kept indices in order, num_keep_out [1] int32
+ *     their count (both DEVICE); workspace: DEVICE, n * ceil(n/64) uint64.  Deterministic (bit-exact indices). */
+int adv_nms_f32(const float* boxes, int n, float thresh, int64_t* keep_out, int32_t* num_keep_out,
+                uint64_t* workspace, adv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -303,3 +303,110 @@ def psv_build_bwd(grad_cost, shift):
                 gl[bi] += tl
                 gr[bi] += tr
     return gl, gr
+
+
+# ----------------------------------------------------------------------------- RoI path (8f row 3)
+def _roi_taps(height, width, y, x):
+    """bilinear_interpolate pre-computation of maskrcnn-benchmark's ROIAlign (float32, same op order as the
+    kernel).  UNPINNED against the upstream Stereo R-CNN extension (not in the reference tree)."""
+    valid = not (y < F32(-1.0) or y > F32(height) or x < F32(-1.0) or x > F32(width))
+    y = F32(0) if y <= 0 else y
+    x = F32(0) if x <= 0 else x
+    y_low, x_low = int(y), int(x)
+    if y_low >= height - 1:
+        y_high = y_low = height - 1
+        y = F32(y_low)
+    else:
+        y_high = y_low + 1
+    if x_low >= width - 1:
+        x_high = x_low = width - 1
+        x = F32(x_low)
+    else:
+        x_high = x_low + 1
+    ly, lx = F32(y - F32(y_low)), F32(x - F32(x_low))
+    hy, hx = F32(F32(1) - ly), F32(F32(1) - lx)
+    return valid, y_low, x_low, y_high, x_high, F32(hy * hx), F32(hy * lx), F32(ly * hx), F32(ly * lx)
+
+
+def _roi_bins(roi, scale, ph, pw, sampling_ratio):
+    scale = F32(scale)
+    sw, sh = F32(roi[1] * scale), F32(roi[2] * scale)
+    ew, eh = F32(roi[3] * scale), F32(roi[4] * scale)
+    rw, rh = max(F32(ew - sw), F32(1)), max(F32(eh - sh), F32(1))
+    bh, bw = F32(rh / F32(ph)), F32(rw / F32(pw))
+    gh = sampling_ratio if sampling_ratio > 0 else int(np.ceil(F32(rh / F32(ph))))
+    gw = sampling_ratio if sampling_ratio > 0 else int(np.ceil(F32(rw / F32(pw))))
+    return int(roi[0]), sh, sw, bh, bw, gh, gw
+
+
+def _roi_samples(roi, scale, ph, pw, sampling_ratio, height, width):
+    """yield (ph_i, pw_i, count, taps) for every sample of every bin"""
+    b, sh, sw, bh, bw, gh, gw = _roi_bins(roi, scale, ph, pw, sampling_ratio)
+    for i in range(ph):
+        for j in range(pw):
+            for iy in range(gh):
+                y = F32(F32(sh + F32(F32(i) * bh)) + F32(F32(F32(F32(iy) + F32(0.5)) * bh) / F32(gh)))
+                for ix in range(gw):
+                    x = F32(F32(sw + F32(F32(j) * bw)) + F32(F32(F32(F32(ix) + F32(0.5)) * bw) / F32(gw)))
+                    yield i, j, F32(gh * gw), _roi_taps(height, width, y, x)
+    return b
+
+
+def roi_align(feat, rois, pooled, spatial_scale, sampling_ratio=0):
+    feat, rois = _f32(feat), _f32(rois)
+    _, c, h, w = feat.shape
+    ph, pw = (pooled, pooled) if isinstance(pooled, int) else pooled
+    out = np.zeros((rois.shape[0], c, ph, pw), np.float32)
+    for r, roi in enumerate(rois):
+        plane = feat[int(roi[0])]
+        count = None
+        for i, j, count, (valid, yl, xl, yh, xh, w1, w2, w3, w4) in _roi_samples(roi, spatial_scale, ph, pw, sampling_ratio, h, w):
+            if valid:
+                v = ((w1 * plane[:, yl, xl] + w2 * plane[:, yl, xh]) + w3 * plane[:, yh, xl]) + w4 * plane[:, yh, xh]
+            else:
+                v = np.zeros(c, np.float32)
+            out[r, :, i, j] = out[r, :, i, j] + v
+        if count is not None:
+            out[r] = out[r] / count
+    return out
+
+
+def roi_align_bwd(grad_out, rois, feat_shape, spatial_scale, sampling_ratio=0):
+    g, rois = _f32(grad_out), _f32(rois)
+    b, c, h, w = feat_shape
+    ph, pw = g.shape[2:]
+    gf = np.zeros((b, c, h, w), np.float64)          # float64 accumulation: the kernel's atomic order is not fixed
+    for r, roi in enumerate(rois):
+        bi = int(roi[0])
+        for i, j, count, (valid, yl, xl, yh, xh, w1, w2, w3, w4) in _roi_samples(roi, spatial_scale, ph, pw, sampling_ratio, h, w):
+            if valid:
+                gv = g[r, :, i, j]
+                gf[bi, :, yl, xl] += F32(gv * w1) / count
+                gf[bi, :, yl, xh] += F32(gv * w2) / count
+                gf[bi, :, yh, xl] += F32(gv * w3) / count
+                gf[bi, :, yh, xh] += F32(gv * w4) / count
+    return gf.astype(np.float32)
+
+
+def nms(boxes, thresh):
+    """Greedy NMS, boxes [N,4] pre-sorted by descending score, legacy +1 areas, float32 IoU in the kernel's
+    op order; returns kept indices."""
+    bx = _f32(boxes)
+    n = bx.shape[0]
+    removed = np.zeros(n, bool)
+    keep = []
+    area = (bx[:, 2] - bx[:, 0] + F32(1)) * (bx[:, 3] - bx[:, 1] + F32(1))
+    for i in range(n):
+        if removed[i]:
+            continue
+        keep.append(i)
+        if i + 1 < n:
+            rest = bx[i + 1:]
+            left, right = np.maximum(bx[i, 0], rest[:, 0]), np.minimum(bx[i, 2], rest[:, 2])
+            top, bottom = np.maximum(bx[i, 1], rest[:, 1]), np.minimum(bx[i, 3], rest[:, 3])
+            ww = np.maximum(right - left + F32(1), F32(0))
+            hh = np.maximum(bottom - top + F32(1), F32(0))
+            inter = ww * hh
+            iou = inter / (area[i] + area[i + 1:] - inter)
+            removed[i + 1:] |= iou > F32(thresh)
+    return np.array(keep, dtype=np.int64)

@@ -1,0 +1,88 @@
+"""Stereo R-CNN RoI path natives: RoIAlign forward (bit-exact vs the oracle), backward
+(float atomics: within float32 rounding of a float64-accumulated oracle), NMS (exact indices).
+CPU part: the oracle's RoIAlign against torch autograd of an equivalent dense formulation."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle_np as O
+
+
+def _rois(rs, n, b, img_h, img_w):
+    x1 = rs.rand(n) * img_w * 0.8
+    y1 = rs.rand(n) * img_h * 0.8
+    bw = rs.rand(n) * img_w * 0.5 + 2
+    bh = rs.rand(n) * img_h * 0.5 + 2
+    rois = np.stack([rs.randint(0, b, n), x1, y1, np.minimum(x1 + bw, img_w + 10), np.minimum(y1 + bh, img_h + 10)], 1).astype(np.float32)
+    rois[0, 1:] = [0, 0, 1, 1]                         # tiny roi: width/height clamp to 1
+    if n > 1:
+        rois[1, 1:] = [-20, -20, img_w + 40, img_h + 40]   # leaves the map on every side
+    return rois
+
+
+def test_oracle_roi_align_adjoint_and_constant():
+    rs = np.random.RandomState(0)
+    feat = rs.randn(2, 3, 12, 16).astype(np.float32)
+    rois = _rois(rs, 5, 2, 12 * 16, 16 * 16)
+    out = O.roi_align(feat, rois, (3, 4), 1 / 16.0)
+    g = rs.randn(*out.shape).astype(np.float32)
+    gf = O.roi_align_bwd(g, rois, feat.shape, 1 / 16.0)
+    lhs = float((out.astype(np.float64) * g).sum())
+    rhs = float((feat.astype(np.float64) * gf).sum())
+    assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs))
+    ones = np.ones((1, 2, 10, 10), np.float32)
+    inside = np.array([[0, 16, 16, 100, 120]], np.float32)       # fully inside -> every bin averages to 1
+    assert np.allclose(O.roi_align(ones, inside, 7, 1 / 16.0), 1.0, atol=1e-6)
+
+
+def test_oracle_nms_small_cases():
+    boxes = np.float32([[0, 0, 10, 10], [1, 1, 11, 11], [20, 20, 30, 30], [0, 0, 10, 10], [21, 21, 29, 29]])
+    assert O.nms(boxes, 0.5).tolist() == [0, 2]
+    assert O.nms(boxes, 0.95).tolist() == [0, 1, 2, 4]
+    assert O.nms(boxes[:0], 0.5).tolist() == []
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [
+    dict(b=2, c=5, h=12, w=16, n=9, pooled=(3, 4), scale=1 / 16.0, sr=0),
+    dict(b=1, c=16, h=38, w=125, n=24, pooled=7, scale=1 / 16.0, sr=0),      # FPN P4 of a 600x1987 image
+    dict(b=1, c=8, h=150, w=497, n=12, pooled=14, scale=1 / 4.0, sr=0),       # FPN P2, keypoint head 14x14
+    dict(b=2, c=4, h=20, w=20, n=7, pooled=2, scale=0.25, sr=2),
+])
+def test_hip_roi_align(cfg):
+    from eval_driving_safety_amd import ops
+    rs = np.random.RandomState(cfg["h"] + cfg["n"])
+    feat = rs.randn(cfg["b"], cfg["c"], cfg["h"], cfg["w"]).astype(np.float32)
+    rois = _rois(rs, cfg["n"], cfg["b"], cfg["h"] / cfg["scale"], cfg["w"] / cfg["scale"])
+    dev = torch.device("cuda", 0)
+    tf, tr = torch.tensor(feat, device=dev), torch.tensor(rois, device=dev)
+    out = ops.roi_align(tf, tr, cfg["pooled"], cfg["scale"], cfg["sr"])
+    want = O.roi_align(feat, rois, cfg["pooled"], cfg["scale"], cfg["sr"])
+    assert out.cpu().numpy().tobytes() == want.tobytes(), "forward not bit-exact"
+    g = rs.randn(*want.shape).astype(np.float32)
+    gf = ops.roi_align_bwd(torch.tensor(g, device=dev), tr, feat.shape, cfg["scale"], cfg["sr"])
+    wf = O.roi_align_bwd(g, rois, feat.shape, cfg["scale"], cfg["sr"])
+    np.testing.assert_allclose(gf.cpu().numpy(), wf, rtol=2e-5, atol=2e-5)
+    # autograd wrapper
+    tf2 = tf.clone().requires_grad_(True)
+    o2 = ops.RoIAlign.apply(tf2, tr, cfg["pooled"], cfg["scale"], cfg["sr"])
+    (o2 * torch.tensor(g, device=dev)).sum().backward()
+    np.testing.assert_allclose(tf2.grad.cpu().numpy(), wf, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [0, 1, 5, 64, 65, 300, 2000])
+def test_hip_nms_exact_indices(n):
+    from eval_driving_safety_amd import ops
+    rs = np.random.RandomState(n)
+    ctr = rs.rand(n, 2) * 300
+    wh = rs.rand(n, 2) * 80 + 4
+    boxes = np.concatenate([ctr - wh / 2, ctr + wh / 2], 1).astype(np.float32)
+    if n >= 5:
+        boxes[3] = boxes[0]                                  # exact duplicate: IoU 1
+        boxes[4] = boxes[1] + np.float32(0.25)
+    scores = np.sort(rs.rand(n).astype(np.float32))[::-1].copy()
+    dev = torch.device("cuda", 0)
+    for thresh in (0.3, 0.5):
+        keep = ops.nms(torch.tensor(boxes, device=dev).reshape(n, 4), torch.tensor(scores, device=dev), thresh)
+        assert keep.cpu().numpy().tolist() == O.nms(boxes.reshape(n, 4), thresh).tolist(), (n, thresh)
