@@ -225,7 +225,7 @@ int adv_roi_align_bwd_f32(const float* grad_out, const float* rois, float* grad_
 
 int adv_nms_f32(const float* boxes, int n, float thresh, int64_t* keep_out, int32_t* num_keep_out, uint64_t* workspace,
                 adv_stream_t stream) {
-  if (!boxes || !keep_out || !num_keep_out || !workspace || n < 0) return ADV_EINVAL;
+  if (!num_keep_out || n < 0 || (n > 0 && (!boxes || !keep_out || !workspace))) return ADV_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (n == 0) return hipMemsetAsync(num_keep_out, 0, sizeof(int32_t), st) == hipSuccess ? ADV_OK : ADV_ELAUNCH;
   const int col_blocks = (n + 63) / 64;

@@ -395,6 +395,8 @@ def nms(boxes, scores, thresh):
     if bx.dim() != 2 or bx.shape[1] != 4:
         raise ValueError("boxes must be [N,4]")
     n = bx.shape[0]
+    if n == 0:
+        return torch.empty((0,), dtype=torch.int64, device=bx.device)
     keep = torch.empty((max(n, 1),), dtype=torch.int64, device=bx.device)
     count = torch.zeros((1,), dtype=torch.int32, device=bx.device)
     work = torch.empty((max(1, n * ((n + 63) // 64)),), dtype=torch.int64, device=bx.device)
