@@ -29,9 +29,48 @@ def line(name, ms, nbytes, **kw):
                           GBps=round(nbytes / ms / 1e6, 1), frac_of_8TBps=round(nbytes / ms / 1e6 / 8000, 3), **kw)))
 
 
+DSGN_MEAN = (0.485, 0.456, 0.406)
+DSGN_STD = (0.229, 0.224, 0.225)
+
+
+def torch_eager_pgd_step(x, grad, clean, alpha, eps):
+    """The reference's own formulation (attack/DSGN/pgd_attack.py:339-354) as PyTorch-ROCm eager ops on the GPU,
+    made batch-correct: what running the reference script on this GPU would launch per step (baseline only)."""
+    d = x.clone()
+    for c in range(3):
+        d[:, c] = d[:, c] * DSGN_STD[c] + DSGN_MEAN[c]
+    adv = d + alpha * grad.sign()
+    eta = torch.clamp(adv - clean, min=-eps, max=eps)
+    y = torch.clamp(clean + eta, min=0, max=1)
+    for c in range(3):
+        y[:, c] = (y[:, c] - DSGN_MEAN[c]) / DSGN_STD[c]
+    return y.detach()
+
+
+def pgd_vs_eager(dev):
+    H, W = 384, 1248
+    sp = ops.Space.dsgn()
+    for n in (2, 64, 512):                       # one pair (the reference's batch), 32 pairs, 256 pairs
+        x = torch.randn((n, 3, H, W), device=dev)
+        g = torch.randn_like(x)
+        clean = torch.rand_like(x)
+        nbytes = 16 * x.numel()
+        reps = 200 if n == 2 else 20
+        t_hip = timeit(lambda: ops.pgd_step(x, g, clean, sp, 1 / 255, 0.03, out=x), reps=reps)
+        line("pgd_step HIP (in place, no export)", t_hip, nbytes, images=n)
+        if n <= 64:
+            t_eager = timeit(lambda: torch_eager_pgd_step(x, g, clean, 1 / 255, 0.03), reps=max(5, reps // 4))
+            line("pgd_step PyTorch-ROCm eager (reference formulation)", t_eager, nbytes, images=n, speedup_of_hip=round(t_eager / t_hip, 2))
+        del x, g, clean
+        torch.cuda.empty_cache()
+
+
 def main():
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
+    if "--eager" in sys.argv:
+        pgd_vs_eager(dev)
+        return
     H, W = 384, 1248
     # ---- PSV at the DSGN shape
     for B in (1, 4, 16):
