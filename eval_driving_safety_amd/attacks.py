@@ -105,13 +105,20 @@ class PgdAttack:
             ops.export_u8(x, sp, (rows, cols), out=exporter.next_buffer())
             exporter.submit(self._fan_out(0, batch))
         losses = []
+        # in place where the planes are whole cache lines (DSGN); two alternating buffers where they are not
+        # (Stereo R-CNN), because the line-aligned kernel for such shapes fuses the export only out of place
+        pingpong = self.save and getattr(ops, "prefers_out_of_place", lambda *_: False)(h, w)
+        spare = torch.empty_like(x) if pingpong else None
         for k in range(self.iters):
             loss, grad = adapter.loss_and_grad(x, batch.extra)           # detector fwd + loss + bwd (:305-336)
             losses.append(loss)
             want = self._wanted(k + 1)
-            ops.pgd_step(x, grad.contiguous(), clean, sp, self.alpha, self.eps, out=x,
+            nxt = spare if pingpong else x
+            ops.pgd_step(x, grad.contiguous(), clean, sp, self.alpha, self.eps, out=nxt,
                          u8_out=exporter.next_buffer() if want else None,
                          crop=(rows, cols) if want else None)            # :339-354 (+ :357-374 export)
+            if pingpong:
+                x, spare = nxt, x
             if want:
                 exporter.submit(self._fan_out(k + 1, batch))
         if exporter is not None:

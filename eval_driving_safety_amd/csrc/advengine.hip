@@ -199,6 +199,109 @@ __global__ __launch_bounds__(kWave) void pgd_step_vec4(const v4f* x, const v4f* 
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// K1/K2 for planes that are NOT a whole number of 128-byte cache lines (Stereo R-CNN: 600 x 1987 floats
+// = 37 256.25 lines).  There the three channel planes of an image start at different offsets within a
+// line, so no common pixel tiling is line-aligned in all of them: the plain kernel's 1 KiB wave accesses
+// straddle 9 lines instead of 8 (PMC: 1.094 x the algorithmic read bytes, 0.65 of peak instead of 0.76).
+// Here every channel gets its OWN tile origin, shifted by its misalignment m_c (in float4, 0..7), so that
+// every wave access of every plane is line-aligned; the fused export needs the three channels of the
+// SAME pixels, so each lane packs its 4 pixels of a channel into one 32-bit word, the words are exchanged
+// through LDS (index shifted by m_c - m_0), and the <= 7 pixel groups per channel that belong to a
+// neighbouring tile are recomputed by a few "halo" lanes (<= 6 extra lines per 288 fetched).
+// Workgroup = 256 lanes = 256 pixel groups per channel; grid = (tiles, images).
+// ------------------------------------------------------------------------------------------
+constexpr int kShiftBlock = 256;
+constexpr int kHalo = 8;
+
+template <int KIND>
+__device__ __forceinline__ uint32_t pack_channel4(const v4f& o, float sc, float sh, double add) {
+  return export_byte<KIND>(o[0], sc, sh, add) | (export_byte<KIND>(o[1], sc, sh, add) << 8) |
+         (export_byte<KIND>(o[2], sc, sh, add) << 16) | (export_byte<KIND>(o[3], sc, sh, add) << 24);
+}
+
+template <int KIND, int U8>
+__global__ __launch_bounds__(kShiftBlock) void pgd_step_shifted(const v4f* x, const v4f* __restrict__ g,
+                                                                const v4f* __restrict__ cl, v4f* xo, long long n_img, int hw4,
+                                                                int w, int base_f4, SpaceK sp, float alpha, float eps, U8Dst u8) {
+  __shared__ uint32_t words[3][kShiftBlock + 2 * kHalo];
+  const int j = threadIdx.x;
+  for (long long img = blockIdx.y; img < n_img; img += gridDim.y) {
+    const long long plane0 = img * 3LL * hw4;
+    int m[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) m[c] = static_cast<int>((base_f4 + plane0 + static_cast<long long>(c) * hw4) & 7);
+    const int tile = blockIdx.x * kShiftBlock;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int q = tile - m[c] + j;  // this lane's pixel group in channel c: line-aligned per wave
+      if (q >= 0 && q < hw4) {
+        const long long i = plane0 + static_cast<long long>(c) * hw4 + q;
+        const v4f X = ld_stream(x + i), G = ld_stream(g + i), C = ld_stream(cl + i);
+        v4f O;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) O[k] = pgd_elem<KIND>(X[k], G[k], C[k], sp.scale[c], sp.shift[c], sp.lo[c], sp.hi[c], alpha, eps);
+        st_stream(xo + i, O);
+        if (U8 != U8_NONE) words[c][kHalo + j] = pack_channel4<KIND>(O, sp.scale[c], sp.shift[c], sp.export_add[c]);
+      }
+    }
+    if (U8 != U8_NONE) {
+      // halo: channel c holds reference group (tile - m0 + jj) at local index jj + s, s = m_c - m_0; the indices
+      // that fall outside [0, 256) are recomputed here (values only - their x_out is stored by the owning tile)
+#pragma unroll
+      for (int c = 1; c < 3; ++c) {
+        const int s = m[c] - m[0];
+        const int as = s < 0 ? -s : s;
+        if (j < as) {
+          const int local = s > 0 ? kShiftBlock + j : -as + j;
+          const int q = tile - m[c] + local;
+          if (q >= 0 && q < hw4) {
+            const long long i = plane0 + static_cast<long long>(c) * hw4 + q;
+            const v4f X = x[i], G = g[i], C = cl[i];
+            v4f O;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) O[k] = pgd_elem<KIND>(X[k], G[k], C[k], sp.scale[c], sp.shift[c], sp.lo[c], sp.hi[c], alpha, eps);
+            words[c][kHalo + local] = pack_channel4<KIND>(O, sp.scale[c], sp.shift[c], sp.export_add[c]);
+          }
+        }
+      }
+      __syncthreads();
+      const int q0 = tile - m[0] + j;
+      if (q0 >= 0 && q0 < hw4) {
+        const uint32_t w0 = words[0][kHalo + j];
+        const uint32_t w1 = words[1][kHalo + j + (m[1] - m[0])];
+        const uint32_t w2 = words[2][kHalo + j + (m[2] - m[0])];
+        if (U8 == U8_ROWS_DWORD) {
+          const int p = q0 * 4;
+          const int row = p / w;
+          if (row < u8.crop_h) {
+            const int col = p - row * w;
+            v3u r;  // bytes: p0c0 p0c1 p0c2 p1c0 | p1c1 p1c2 p2c0 p2c1 | p2c2 p3c0 p3c1 p3c2
+            r[0] = (w0 & 0xffu) | ((w1 & 0xffu) << 8) | ((w2 & 0xffu) << 16) | (((w0 >> 8) & 0xffu) << 24);
+            r[1] = ((w1 >> 8) & 0xffu) | (((w2 >> 8) & 0xffu) << 8) | (((w0 >> 16) & 0xffu) << 16) | (((w1 >> 16) & 0xffu) << 24);
+            r[2] = ((w2 >> 16) & 0xffu) | (((w0 >> 24) & 0xffu) << 8) | (((w1 >> 24) & 0xffu) << 16) | (((w2 >> 24) & 0xffu) << 24);
+            st_stream(reinterpret_cast<v3u*>(u8.base + img * u8.image_stride + row * u8.row_stride + col * 3LL), r);
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int p = q0 * 4 + k;
+            const int row = p / w;
+            const int col = p - row * w;
+            if (row < u8.crop_h && col < u8.ncols) {
+              uint8_t* dst = u8.base + img * u8.image_stride + row * u8.row_stride + col * 3LL;
+              dst[0] = static_cast<uint8_t>((w0 >> (8 * k)) & 0xffu);
+              dst[1] = static_cast<uint8_t>((w1 >> (8 * k)) & 0xffu);
+              dst[2] = static_cast<uint8_t>((w2 >> (8 * k)) & 0xffu);
+            }
+          }
+        }
+      }
+      __syncthreads();  // words[] is reused by the next image of this workgroup
+    }
+  }
+}
+
 // general shapes (HW % 4 != 0 or pointers not 16-byte aligned): one pixel (3 channels) per lane
 template <int KIND>
 __global__ __launch_bounds__(kBlock) void pgd_step_scalar(const float* __restrict__ x, const float* __restrict__ g,
@@ -509,7 +612,30 @@ int launch_pgd(const float* x, const float* g, const float* cl, float* xo, long 
   U8Plan plan;
   const int rc = plan_u8(u8, h, w, crop_h, crop_w, rs, is, vec, &plan);
   if (rc != ADV_OK) return rc;
-  if (vec) {
+  const uintptr_t res = reinterpret_cast<uintptr_t>(x) & 127;
+  const bool same_residue = (reinterpret_cast<uintptr_t>(g) & 127) == res && (reinterpret_cast<uintptr_t>(cl) & 127) == res &&
+                            (reinterpret_cast<uintptr_t>(xo) & 127) == res;
+  // the shifted kernel's halo lanes re-read x of pixel groups owned by a neighbouring workgroup, which an in-place
+  // update may already have overwritten: with the export on it therefore needs x_out != x (no overlap at all)
+  const bool overlap = !(reinterpret_cast<const char*>(xo) + n * 3 * hw * 4 <= reinterpret_cast<const char*>(x) ||
+                         reinterpret_cast<const char*>(x) + n * 3 * hw * 4 <= reinterpret_cast<const char*>(xo));
+  if (vec && same_residue && (((hw / 4) & 7) != 0 || res != 0) && (plan.mode == U8_NONE || !overlap)) {
+    // planes are not whole cache lines (or the buffers start inside one): per-channel shifted tiles
+    const int hw4 = static_cast<int>(hw / 4);
+    const int tiles = (hw4 + 7 + kShiftBlock - 1) / kShiftBlock;
+    const dim3 grid(tiles, static_cast<unsigned>(n > 65535 ? 65535 : n), 1);
+    const int base_f4 = static_cast<int>(res / 16);
+    const v4f* x4 = reinterpret_cast<const v4f*>(x);
+    const v4f* g4 = reinterpret_cast<const v4f*>(g);
+    const v4f* c4 = reinterpret_cast<const v4f*>(cl);
+    v4f* o4 = reinterpret_cast<v4f*>(xo);
+    if (plan.mode == U8_NONE)
+      hipLaunchKernelGGL((pgd_step_shifted<KIND, U8_NONE>), grid, dim3(kShiftBlock), 0, st, x4, g4, c4, o4, n, hw4, w, base_f4, sp, alpha, eps, plan.dst);
+    else if (plan.mode == U8_ROWS_DWORD)
+      hipLaunchKernelGGL((pgd_step_shifted<KIND, U8_ROWS_DWORD>), grid, dim3(kShiftBlock), 0, st, x4, g4, c4, o4, n, hw4, w, base_f4, sp, alpha, eps, plan.dst);
+    else
+      hipLaunchKernelGGL((pgd_step_shifted<KIND, U8_BYTES>), grid, dim3(kShiftBlock), 0, st, x4, g4, c4, o4, n, hw4, w, base_f4, sp, alpha, eps, plan.dst);
+  } else if (vec) {
     const int hw4 = static_cast<int>(hw / 4);
     const dim3 grid = wave_grid(hw4, n, kUnroll);
     const v4f* x4 = reinterpret_cast<const v4f*>(x);

@@ -147,7 +147,8 @@ def test_golden_patch(name, golden, golden_index, ops):
 
 # ------------------------------------------------------------------------------- oracle: shapes / batches / paths
 @pytest.mark.parametrize("kind", ["dsgn", "srcnn"])
-@pytest.mark.parametrize("shape", [(1, 3, 8, 12), (3, 3, 5, 7), (2, 3, 9, 10), (4, 3, 64, 96), (1, 3, 1, 1), (2, 3, 3, 4)])
+@pytest.mark.parametrize("shape", [(1, 3, 8, 12), (3, 3, 5, 7), (2, 3, 9, 10), (4, 3, 64, 96), (1, 3, 1, 1), (2, 3, 3, 4),
+                                   (3, 3, 6, 10), (2, 3, 10, 26), (5, 3, 20, 66), (2, 3, 5, 12), (3, 3, 33, 100), (2, 3, 600, 1987)])
 def test_pgd_batches_and_ragged_shapes(kind, shape, ops):
     n, _, h, w = shape
     rs = np.random.RandomState(h * 131 + w)
@@ -176,6 +177,48 @@ def test_pgd_batches_and_ragged_shapes(kind, shape, ops):
         same_bits(host(dense)[i], exp(want[i], ch, cw), "dense u8")
         same_bits(host(pitched)[i, :, :cw], exp(want[i], ch, cw), "pitched u8")
         same_bits(host(ops.export_u8(dev(want), sp, (ch, cw)))[i, :, :cw], exp(want[i], ch, cw), "export_u8")
+
+
+@pytest.mark.parametrize("kind", ["dsgn", "srcnn"])
+@pytest.mark.parametrize("offset_floats", [0, 4, 12, 28])
+def test_pgd_planes_that_are_not_whole_cache_lines(kind, offset_floats, ops):
+    """the shifted-tile kernel: every mix of in place / out of place, export on / off, buffers starting inside a
+    128-byte line (all four with the same residue), planes of 65 and 1033 float4"""
+    for h, w in ((10, 26), (37, 100), (4, 1033 * 1)):
+        if (h * w) % 4:
+            continue
+        n = 3
+        shape = (n, 3, h, w)
+        numel = int(np.prod(shape))
+        if kind == "dsgn":
+            sp, step, alpha, eps = ops.Space.dsgn(), O.pgd_step_norm01, 2 / 255, 0.02
+            x = np.concatenate([synth.dsgn_normalised(300 + i, h, w) for i in range(n)])
+            clean = O.denormalize(np.concatenate([synth.dsgn_normalised(400 + i, h, w) for i in range(n)]))
+            exp = O.tensor2im_u8
+        else:
+            sp, step, alpha, eps = ops.Space.srcnn(), O.pgd_step_meansub255, 1.0, 7.65
+            x = np.concatenate([synth.srcnn_meansub(300 + i, h, w) for i in range(n)])
+            clean = np.concatenate([synth.srcnn_meansub(400 + i, h, w) for i in range(n)])
+            exp = lambda a, hh, ww: O.srcnn_export_u8(a)[:hh, :ww]
+        g = synth.gradient(h * w + offset_floats, shape, 1.0, specials=True)
+        want = step(x, g, clean, alpha, eps)
+
+        def placed(a):
+            buf = torch.zeros(numel + 64, dtype=torch.float32, device="cuda")
+            v = buf[offset_floats:offset_floats + numel].view(shape)
+            v.copy_(dev(a))
+            return v
+
+        for inplace in (False, True):
+            for with_u8 in (False, True):
+                tx, tg, tc = placed(x), placed(g), placed(clean)
+                out = tx if inplace else placed(np.zeros(shape, np.float32))
+                u8 = ops.alloc_u8(n, h, w, "cuda") if with_u8 else None
+                ops.pgd_step(tx, tg, tc, sp, alpha, eps, out=out, u8_out=u8)
+                same_bits(host(out), want, "%s %dx%d off %d inplace %s u8 %s" % (kind, h, w, offset_floats, inplace, with_u8))
+                if with_u8:
+                    for i in range(n):
+                        same_bits(host(u8)[i], exp(want[i], h, w), "u8 %s %dx%d off %d inplace %s" % (kind, h, w, offset_floats, inplace))
 
 
 def test_pgd_unaligned_pointers_take_the_scalar_path(ops):
