@@ -108,7 +108,11 @@ def main():
     line("pgd_step srcnn (in place, no u8)", timeit(lambda: ops.pgd_step(xs, gs, cs, sps, 1.0, 7.65, out=xs)), 4 * Es, images=ns)
     line("pgd_step srcnn (in place, byte-path u8: W%4!=0)", timeit(lambda: ops.pgd_step(xs, gs, cs, sps, 1.0, 7.65, out=xs, u8_out=u8s), reps=5),
          4 * Es + ns * 3 * 600 * 1987, images=ns)
-    del xs, gs, cs, u8s
+    xo = torch.empty_like(xs)
+    line("pgd_step srcnn (out of place, no u8)", timeit(lambda: ops.pgd_step(xs, gs, cs, sps, 1.0, 7.65, out=xo)), 4 * Es, images=ns)
+    line("pgd_step srcnn (out of place, byte-path u8, line-aligned kernel)",
+         timeit(lambda: ops.pgd_step(xs, gs, cs, sps, 1.0, 7.65, out=xo, u8_out=u8s), reps=5), 4 * Es + ns * 3 * 600 * 1987, images=ns)
+    del xs, gs, cs, u8s, xo
     # ---- patch kernels, batch of 64 pairs
     B, r = 64, 38
     d = 2 * r + 1
