@@ -142,13 +142,9 @@ def _u8_args(u8, n, h, w, crop):
         raise ValueError("u8_out pixels must be packed HWC")
     if u8.shape[1] < crop_h or u8.shape[2] < crop_w:
         raise ValueError("u8_out %s is smaller than the crop %s" % (tuple(u8.shape), (crop_h, crop_w)))
-    row_stride = u8.stride(1)
-    if u8.shape[2] < w:                       # dense cropped rows: only crop_w columns exist
-        if row_stride < 3 * crop_w:
-            raise ValueError("u8_out rows are too short")
-        if row_stride >= 3 * w:               # cannot happen for a contiguous tensor; keep the ABI rule explicit
-            raise ValueError("ambiguous u8 pitch")
-    return _ptr(u8), crop_h, crop_w, row_stride, u8.stride(0)
+    # rows of >= w pixels: the library stores whole rows with aligned 12-byte stores; shorter rows: only the
+    # crop_w columns, byte by byte (include/advengine.h, adv_pgd_step_f32)
+    return _ptr(u8), crop_h, crop_w, u8.stride(1), u8.stride(0)
 
 
 def prefers_out_of_place(h, w):

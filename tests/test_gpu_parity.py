@@ -349,3 +349,41 @@ def test_config2_size_properties(ops):
     assert float(d.min()) >= -2e-7 and float(d.max()) <= 1 + 2e-7
     # with random-sign gradients most pixels have moved, none stayed beyond the ball
     assert float((d - clean).abs().mean()) > 1e-3
+
+
+def test_calls_are_capturable_in_a_hip_graph(ops):
+    """the header promises enqueue-only entry points: capture a 3-step PGD + paste + patch update sequence with
+    torch's stream capture, replay it twice on fresh inputs, compare with the oracle"""
+    h, w, r = 96, 160, 9
+    sp = ops.Space.dsgn()
+    x_np = np.concatenate([synth.dsgn_normalised(60, h, w), synth.dsgn_normalised(61, h, w)])
+    g_np = synth.gradient(62, x_np.shape, 1.0)
+    clean_np = O.denormalize(x_np)
+    patch_np = synth.patch_init(63, 2 * r + 1)
+    x, g, clean, patch = dev(x_np), dev(g_np), dev(clean_np), dev(patch_np)
+    u8 = ops.alloc_u8(2, h, w, "cuda")
+    static_x = x.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                     # warm-up outside capture, as torch recommends
+        ops.pgd_step(static_x, g, clean, sp, 1 / 255, 0.03, out=static_x, u8_out=u8)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for _ in range(3):
+            ops.pgd_step(static_x, g, clean, sp, 1 / 255, 0.03, out=static_x, u8_out=u8)
+        ops.patch_paste(static_x[0:1], patch, 40, 70, r)
+        ops.patch_update(patch, g[0:1], g[1:2], 40, 70, 50, r, 8 / 255)
+    for trial in range(2):
+        static_x.copy_(x)
+        patch.copy_(dev(patch_np))
+        graph.replay()
+        torch.cuda.synchronize()
+        want = x_np
+        for _ in range(3):
+            want = O.pgd_step_norm01(want, g_np, clean_np, 1 / 255, 0.03)
+        same_bits(host(u8)[1], O.tensor2im_u8(want[1], h, w), "u8 from the graph, trial %d" % trial)
+        want = want.copy()
+        want[0:1] = O.patch_paste(want[0:1], patch_np, 40, 70, r)
+        same_bits(host(static_x), want, "iterate from the graph, trial %d" % trial)
+        same_bits(host(patch), O.patch_update(patch_np, g_np[0:1], g_np[1:2], 40, 70, 50, r, 8 / 255), "patch from the graph")
