@@ -266,3 +266,38 @@ def srcnn_im_info_prescaled(im_info, scale_target=600, native_height=375):
     info = np.array(im_info, dtype=np.float32, copy=True)
     info[0][2] = float(scale_target) / float(native_height)
     return info
+
+
+# --- the consumer's view of a label file (validation of what this engine writes) ---------------------------
+def load_label(label_path):
+    """How ``evaluation/convert_scenarios.py:52-95`` reads a label file: split on single spaces, fields
+    0 type, 1 truncated, 2 occluded, 3 alpha, 4-7 bbox, 8-10 (h, w, l), 11-13 (x, y, z), 14 rotation_y.
+    Returns a list of [type, truncated, occluded, alpha, [bbox], [h, w, l], [x, y, z], ry]."""
+    label = []
+    with open(label_path, "r") as f:
+        for line in f:
+            e = line.strip().split(" ")
+            label.append([e[0], float(e[1]), float(e[2]), float(e[3]), [float(v) for v in e[4:8]],
+                          [float(v) for v in e[8:11]], [float(v) for v in e[11:14]], float(e[14])])
+    return label
+
+
+SCENARIO_TYPES = ("Car", "Van", "Truck", "Misc")     # evaluation/convert_scenarios.py:117
+
+
+def scenario_obstacles(label):
+    """The static obstacles ``convert_scenario`` (evaluation/convert_scenarios.py:116-133) builds from a label:
+    only Car/Van/Truck/Misc, rotation wrapped into [-pi, pi], rectangle width = w, length = l, position
+    (z, -x) in the scenario frame, orientation -(ry - pi/2).  For checking label files without CommonRoad."""
+    out = []
+    for item in label:
+        if item[0] not in SCENARIO_TYPES:
+            continue
+        orient = item[7]
+        while orient < -np.pi:
+            orient += 2 * np.pi
+        while orient > np.pi:
+            orient -= 2 * np.pi
+        out.append(dict(width=item[5][1], length=item[5][2], position=[item[6][2], -item[6][0]],
+                        orientation=-(orient - 0.5 * np.pi)))
+    return out

@@ -360,6 +360,48 @@ def label_case():
                 image_index=42, text=text)
 
 
+# --------------------------------------------------------------------------- consumer side
+def scenario_case(label_text):
+    """What the reference's own consumer makes of a label file: ``load_label`` (evaluation/convert_scenarios.py:52-95,
+    executed as it stands) and the obstacle loop of ``convert_scenario`` (:116-133, the very statements) with the
+    CommonRoad classes replaced by recorders (CommonRoad is not installed here; only constructor arguments matter)."""
+    rel = "evaluation/convert_scenarios.py"
+    ns = {"np": np, "os": os}
+    exec_toplevel(rel, ["load_label"], ns)
+    extra = ("Van -1 -1 0.1 1 2 3 4 2.0 1.9 5.1 -3.5 1.6 14.25 4.5 0.7\n"        # ry > pi: wrapped by the consumer
+             "Truck -1 -1 0.1 1 2 3 4 3.0 2.5 9.0 6.0 1.7 30.0 -3.9 0.6\n"       # ry < -pi
+             "Tram -1 -1 0.1 1 2 3 4 3.0 2.5 9.0 6.0 1.7 30.0 0.0 0.6\n")        # ignored type
+    text = label_text + extra
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "000042.txt")
+        with open(path, "w") as f:
+            f.write(text)
+        label = ns["load_label"](path)
+    added = []
+
+    class Rec:
+        def __init__(self, *a, **k):
+            self.a, self.k = a, k
+
+    class Scenario:
+        n = 100
+
+        def generate_object_id(self):
+            Scenario.n += 1
+            return Scenario.n
+
+        def add_objects(self, o):
+            shape, state = o.a[2], o.a[3]
+            added.append(dict(id=o.a[0], width=float(shape.k["width"]), length=float(shape.k["length"]),
+                              position=[float(v) for v in state.k["position"]], orientation=float(state.k["orientation"]),
+                              time_step=int(state.k["time_step"])))
+
+    ns.update(label=label, scenario=Scenario(), Rectangle=Rec, State=Rec, StaticObstacle=Rec,
+              ObstacleType=types.SimpleNamespace(PARKED_VEHICLE="parked"))
+    exec_lines(rel, 116, 133, ns)
+    return dict(text=text, label=label, obstacles=added)
+
+
 # --------------------------------------------------------------------------- main
 def save_npz(name, arrays):
     path = os.path.join(HERE, name)
@@ -411,6 +453,7 @@ def main():
 
     index["masks"] = mask_and_dims_cases()
     index["label"] = label_case()
+    index["scenario"] = scenario_case(index["label"]["text"])
     with open(os.path.join(HERE, "index.json"), "w") as f:
         json.dump(index, f, indent=1, sort_keys=True)
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE)

@@ -118,6 +118,21 @@ def test_kitti_label_text_matches_reference(golden_index, tmp_path):
         [float(v) for v in f[1:]]
 
 
+def test_consumer_view_of_label_files(golden_index, tmp_path):
+    """load_label + the obstacle mapping against what the reference's own consumer code produced"""
+    S = golden_index["scenario"]
+    path = tmp_path / "000042.txt"
+    path.write_text(S["text"])
+    label = pixelio.load_label(str(path))
+    assert label == S["label"]
+    obs = pixelio.scenario_obstacles(label)
+    assert len(obs) == len(S["obstacles"]) == 5
+    for got, want in zip(obs, S["obstacles"]):
+        assert got["width"] == want["width"] and got["length"] == want["length"]
+        assert got["position"] == want["position"] and got["orientation"] == want["orientation"]
+    assert all(-np.pi <= 0.5 * np.pi - o["orientation"] <= np.pi for o in obs)
+
+
 def test_patch_files(tmp_path):
     d0 = pixelio.patch_dir("dsgn", 0.2, 0, str(tmp_path))
     assert d0.endswith(os.path.join("dsgn_patch_ratio_0.2", "epoch0"))
