@@ -12,6 +12,7 @@ reference's in-place denormalize only works for B = 1, quirk Q1); one clean buff
 identical ones (Q2); explicit clone of the Stereo R-CNN clean image (Q6); a seedable patch-position
 stream (Q9); device-side loss accumulation (Q17); PNG encoding off the critical path.
 """
+import itertools
 import os
 
 import torch
@@ -24,6 +25,18 @@ def split_eyes(x):
     """views (imgL, imgR) of a stacked [2B,3,H,W] batch"""
     b = x.shape[0] // 2
     return x[:b], x[b:]
+
+
+def _owned(loader, comm):
+    """(global batch index, batch) of the batches this rank owns (i % world == rank).  Loaders with ``shard`` and
+    ``__len__`` (data.SyntheticStereo, data.KittiFolder) never materialise the other ranks' batches."""
+    if comm.world > 1 and hasattr(loader, "shard"):
+        for k, batch in enumerate(loader.shard(comm.rank, comm.world)):
+            yield comm.rank + k * comm.world, batch
+        return
+    for i, batch in enumerate(loader):
+        if i % comm.world == comm.rank:
+            yield i, batch
 
 
 def _default_ops():
@@ -131,11 +144,9 @@ class PgdAttack:
         (no collective: attacked pairs are independent and write distinct files)."""
         comm = comm if comm is not None else Comm()
         done = 0
-        for i, batch in enumerate(loader):
+        for i, batch in _owned(loader, comm):
             if debugnum is not None and i * len(batch) > debugnum:       # pgd_attack.py:246-248 (quirk Q15)
                 break
-            if i % comm.world != comm.rank:
-                continue
             self.run_batch(batch, adapter)
             done += len(batch)
         self.close()
@@ -258,15 +269,23 @@ class PatchTrainer:
                 print("Epoch {0}".format(epoch))                             # patch_attack.py:293
             loss_sum = torch.zeros((), dtype=torch.float32, device=dev)
             loss_num = 0
-            mine, total = [], 0
-            for i, batch in enumerate(loader_factory()):
-                if debugnum is not None and i * len(batch) > debugnum:       # :314-316
-                    break
-                total += 1
-                if i % comm.world == comm.rank:
-                    mine.append(batch)
+            loader = loader_factory()
+            if hasattr(loader, "__len__") and hasattr(loader, "shard"):
+                total = len(loader)
+                if debugnum is not None:                                     # :314-316 (batch_idx * B > debugnum stops)
+                    total = min(total, debugnum // max(1, getattr(loader, "batch", 1)) + 1)
+                mine = (b for i, b in itertools.takewhile(lambda ib: ib[0] < total, _owned(loader, comm)))  # lazy
+            else:
+                mine, total = [], 0
+                for i, batch in enumerate(loader):
+                    if debugnum is not None and i * len(batch) > debugnum:
+                        break
+                    total += 1
+                    if i % comm.world == comm.rank:
+                        mine.append(batch)
+                mine = iter(mine)
             for rnd in range(comm.rounds(total)):
-                batch = mine[rnd] if rnd < len(mine) else None
+                batch = next(mine, None)
                 ls, b = self.train_batch(batch, adapter, contributes=batch is not None)
                 loss_sum = loss_sum + ls
                 loss_num += 1 if b else 0

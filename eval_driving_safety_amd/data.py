@@ -33,30 +33,43 @@ def dsgn_transform(u8_chw, pad_to=(384, 1248)):
 
 
 class SyntheticStereo:
-    """Seeded KITTI-shaped stereo pairs: the right eye is the left one shifted by a constant disparity."""
+    """Seeded KITTI-shaped stereo pairs: the right eye is the left one shifted by a constant disparity.
+    Every pair has its own seed, so a rank can skip the batches it does not own at no cost (``shard``)."""
 
     def __init__(self, n_pairs, model_kind="dsgn", batch=1, seed=0, first_index=0):
         self.n, self.kind, self.batch, self.seed, self.first = n_pairs, model_kind, batch, seed, first_index
 
+    def __len__(self):
+        return (self.n + self.batch - 1) // self.batch
+
+    def _pair(self, i):
+        gen = torch.Generator().manual_seed(self.seed * 1000003 + i)
+        if self.kind == "dsgn":
+            left = _synthetic_u8(gen, KITTI_H, KITTI_W)
+            right = torch.roll(left, shifts=-24, dims=2)
+            return dsgn_transform(left), dsgn_transform(right), (KITTI_W, KITTI_H)
+        left = _synthetic_u8(gen, 600, 1987)
+        right = torch.roll(left, shifts=-38, dims=2)
+        m = torch.tensor(SRCNN_PIXEL_MEANS).view(3, 1, 1)
+        return left - m, right - m, None
+
+    def _batch(self, k):
+        ls, rs, names, sizes = [], [], [], []
+        for i in range(k * self.batch, min(self.n, (k + 1) * self.batch)):
+            l, r, size = self._pair(i)
+            ls.append(l)
+            rs.append(r)
+            sizes.append(size)
+            names.append("%06d" % (self.first + i))
+        return StereoBatch(torch.stack(ls), torch.stack(rs), names, sizes if self.kind == "dsgn" else None)
+
+    def shard(self, rank, world):
+        """the batches k with k % world == rank, in order"""
+        for k in range(rank, len(self), world):
+            yield self._batch(k)
+
     def __iter__(self):
-        gen = torch.Generator().manual_seed(self.seed)
-        for s in range(0, self.n, self.batch):
-            ls, rs, names, sizes = [], [], [], []
-            for i in range(s, min(self.n, s + self.batch)):
-                if self.kind == "dsgn":
-                    left = _synthetic_u8(gen, KITTI_H, KITTI_W)
-                    right = torch.roll(left, shifts=-24, dims=2)
-                    ls.append(dsgn_transform(left))
-                    rs.append(dsgn_transform(right))
-                    sizes.append((KITTI_W, KITTI_H))
-                else:
-                    left = _synthetic_u8(gen, 600, 1987)
-                    right = torch.roll(left, shifts=-38, dims=2)
-                    m = torch.tensor(SRCNN_PIXEL_MEANS).view(3, 1, 1)
-                    ls.append(left - m)
-                    rs.append(right - m)
-                names.append("%06d" % (self.first + i))
-            yield StereoBatch(torch.stack(ls), torch.stack(rs), names, sizes if self.kind == "dsgn" else None)
+        return self.shard(0, 1)
 
 
 class KittiFolder:
@@ -68,17 +81,26 @@ class KittiFolder:
             self.ids = [l.strip() for l in f if l.strip()]
         self.root, self.batch = data_path, batch
 
-    def __iter__(self):
+    def __len__(self):
+        return (len(self.ids) + self.batch - 1) // self.batch
+
+    def _batch(self, k):
         from PIL import Image
-        for s in range(0, len(self.ids), self.batch):
-            ls, rs, names, sizes = [], [], [], []
-            for name in self.ids[s:s + self.batch]:
-                pair = []
-                for eye in ("image_2", "image_3"):
-                    im = Image.open(os.path.join(self.root, eye, name + ".png")).convert("RGB")
-                    pair.append(torch.from_numpy(np.ascontiguousarray(np.array(im).transpose(2, 0, 1))))
-                sizes.append((pair[0].shape[2], pair[0].shape[1]))
-                ls.append(dsgn_transform(pair[0]))
-                rs.append(dsgn_transform(pair[1]))
-                names.append(name)
-            yield StereoBatch(torch.stack(ls), torch.stack(rs), names, sizes)
+        ls, rs, names, sizes = [], [], [], []
+        for name in self.ids[k * self.batch:(k + 1) * self.batch]:
+            pair = []
+            for eye in ("image_2", "image_3"):
+                im = Image.open(os.path.join(self.root, eye, name + ".png")).convert("RGB")
+                pair.append(torch.from_numpy(np.ascontiguousarray(np.array(im).transpose(2, 0, 1))))
+            sizes.append((pair[0].shape[2], pair[0].shape[1]))
+            ls.append(dsgn_transform(pair[0]))
+            rs.append(dsgn_transform(pair[1]))
+            names.append(name)
+        return StereoBatch(torch.stack(ls), torch.stack(rs), names, sizes)
+
+    def shard(self, rank, world):
+        for k in range(rank, len(self), world):
+            yield self._batch(k)
+
+    def __iter__(self):
+        return self.shard(0, 1)
