@@ -120,3 +120,41 @@ def test_cli_toy_run_writes_the_reference_layout(tmp_path):
     p = np.load(os.path.join(str(tmp_path), "stereo_rcnn_patch_ratio_0.1", "epoch1", "patch.npy"))
     assert p.shape == (1, 3, 61, 61) and p.dtype == np.float32 and np.abs(p).max() > 0
     assert "Average loss for epoch1" in out.stdout
+
+
+def test_attack_folders_feed_detect_under_attack(tmp_path):
+    """the file contract end to end: PGD folders -> swapped in as image_2/image_3 (attack/DSGN/README.md:30,69) ->
+    detect-under-attack -> KITTI label files -> the consumer's parser (evaluation/convert_scenarios.py:52-95)"""
+    from PIL import Image
+    from eval_driving_safety_amd import adapters, attacks, data, pixelio
+    dev = torch.device("cuda", 0)
+    src = data.SyntheticStereo(2, "dsgn", batch=2, seed=9, first_index=40)
+    atk = attacks.PgdAttack("dsgn", 1 / 255, 0.03, 2, out_root=str(tmp_path), device=dev)
+    final = None
+    for batch in src:
+        final = atk.run_batch(batch, adapters.ToyStereoAdapter(dev, seed=5)).cpu().numpy()
+    atk.close()
+    attacked = os.path.join(str(tmp_path), "dsgn_pgd_iters_2")
+    (tmp_path / "val.txt").write_text("000040\n000041\n")
+    seen = []
+
+    class Det:
+        def detect(self, x, extra):
+            seen.append(x.cpu().numpy())
+            return [[(2, np.float32([100, 120, 180, 190]), np.float32(0.8), np.float32([2.0, 1.6, 25.0]), (1.5, 1.7, 4.1, 4.0))]
+                    for _ in range(x.shape[0] // 2)]
+
+    label_dir = pixelio.dsgn_label_dir(str(tmp_path / "ckpt" / "finetune_53.tar"), pixelio.dsgn_tag("", 2, 1 / 255))
+    dua = attacks.DetectUnderAttack("dsgn", "pgd", label_dir, device=dev)
+    assert dua.run(data.KittiFolder(attacked, str(tmp_path / "val.txt"), batch=2), Det()) == 2
+    # what the detector saw is the 8-bit file content, re-normalised by the loader
+    png = np.array(Image.open(os.path.join(attacked, "image_3", "000041.png")).convert("RGB"))
+    assert np.array_equal(png, O.tensor2im_u8(final[3], 375, 1242))
+    redo = data.dsgn_transform(torch.from_numpy(np.ascontiguousarray(png.transpose(2, 0, 1)))).numpy()
+    assert np.array_equal(seen[0][3], redo)
+    assert np.abs(seen[0][3][:, :375, :1242] - final[3][:, :375, :1242]).max() < 1.2 / 255 / 0.224   # one 8-bit quantum
+    label = pixelio.load_label(os.path.join(label_dir, "000041.txt"))
+    assert label[0][0] == "Car" and label[0][5] == [1.5, 1.7, 4.1]
+    obs = pixelio.scenario_obstacles(label)
+    assert len(obs) == 1 and obs[0]["position"] == [25.0, -2.0] and abs(obs[0]["orientation"] - (0.5 * np.pi - (4.0 - 2 * np.pi))) < 1e-12
+    assert label_dir.endswith("kitti_output_iter2_alpha%s" % str(1 / 255))
