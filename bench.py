@@ -40,7 +40,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=256, help="stereo pairs resident per GPU (per step)")
+    ap.add_argument("--pairs", type=int, default=0, help="stereo pairs resident per GPU (per step); 0 = 256 (dsgn) / 96 (srcnn)")
+    ap.add_argument("--workload", default="dsgn", choices=["dsgn", "srcnn"],
+                    help="dsgn = BASELINE configs[1] (the headline, default); srcnn = configs[2]: 20-step PGD in the Stereo R-CNN "
+                         "pixel space on 600x1987 pairs (alpha 1.0, eps 0.03*255) - a parity-test configuration, timed on request")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs in the CPU-baseline sample (0 = auto)")
     return ap.parse_args()
@@ -101,6 +104,12 @@ def pmc_traffic(pairs):
 
 def main():
     args = parse()
+    global H, W, CROP_H, CROP_W, ALPHA, EPS
+    srcnn = args.workload == "srcnn"
+    if srcnn:   # attack/Stereo-RCNN/pgd_attack.py: network scale 600x1987, no crop (quirk Q14), alpha 1.0, eps = 255*0.03 (:57)
+        H, W, CROP_H, CROP_W, ALPHA, EPS = 600, 1987, 600, 1987, 1.0, 255 * 0.03
+    if args.pairs <= 0:
+        args.pairs = 96 if srcnn else 256
     import torch
     import torch.distributed as dist
 
@@ -125,27 +134,37 @@ def main():
     dev = torch.device("cuda", torch.cuda.current_device())
 
     from eval_driving_safety_amd import ops   # raises if libadvengine.so is not built
-    sp = ops.Space.dsgn()
+    sp = ops.Space.srcnn() if srcnn else ops.Space.dsgn()
 
     n_img = 2 * args.pairs                    # both eyes of every pair in one launch
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    x0 = torch.randint(0, 256, (n_img, 3, H, W), device=dev, generator=gen, dtype=torch.int32).float().div_(255.0)
-    ops.normalize(x0, sp, out=x0)             # what the DSGN loader hands over: normalised float32
+    x0 = torch.randint(0, 256, (n_img, 3, H, W), device=dev, generator=gen, dtype=torch.int32).float()
+    if srcnn:
+        x0 -= torch.tensor([102.9801, 115.9465, 122.7717], device=dev).view(1, 3, 1, 1)   # BGR minus PIXEL_MEANS
+    else:
+        x0.div_(255.0)
+        ops.normalize(x0, sp, out=x0)         # what the DSGN loader hands over: normalised float32
     grad = torch.randn((n_img, 3, H, W), device=dev, generator=gen)
     clean = torch.empty_like(x0)
     x = torch.empty_like(x0)
+    spare = torch.empty_like(x0) if srcnn else None   # planes are not whole cache lines: alternate buffers
     u8 = ops.alloc_u8(n_img, CROP_H, W, dev)
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
 
     def step(k=None):
-        ops.denormalize(x0, sp, out=clean)
+        if srcnn:
+            clean.copy_(x0)                   # explicit clone of the clean pair (pgd_attack.py:122-123, quirk Q6)
+        else:
+            ops.denormalize(x0, sp, out=clean)
         ops.export_u8(x0, sp, (CROP_H, CROP_W), out=u8)
         if k is not None:
             ev0[k].record()
         ops.pgd_step(x0, grad, clean, sp, ALPHA, EPS, out=x, u8_out=u8, crop=(CROP_H, CROP_W))
+        cur, nxt = x, (spare if srcnn else x)
         for _ in range(N_ITER - 1):
-            ops.pgd_step(x, grad, clean, sp, ALPHA, EPS, out=x, u8_out=u8, crop=(CROP_H, CROP_W))
+            ops.pgd_step(cur, grad, clean, sp, ALPHA, EPS, out=nxt, u8_out=u8, crop=(CROP_H, CROP_W))
+            cur, nxt = nxt, cur
         if k is not None:
             ev1[k].record()
 
@@ -175,26 +194,30 @@ def main():
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
 
     if rank == 0:
-        traffic, traffic_src = pmc_traffic(args.pairs)
+        traffic, traffic_src = (None, None) if srcnn else pmc_traffic(args.pairs)
         out = {
-            "metric": "KITTI stereo-pairs/sec for 20-step PGD on DSGN (perturbation path; detector fwd+bwd is the caller's)",
+            "metric": "KITTI stereo-pairs/sec for 20-step PGD on %s (perturbation path; detector fwd+bwd is the caller's)"
+                      % ("Stereo R-CNN" if srcnn else "DSGN"),
             "value": world * args.pairs * args.steps / elapsed,
             "unit": "stereo-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: 20-step PGD Linf eps=0.03 alpha=1/255, DSGN pixel space, "
-                                   "KITTI 1242x375 padded to 1248x384, %d stereo pairs resident per GPU, gradient = "
-                                   "resident synthetic buffer, 8-bit HWC export of all 21 iterates" % args.pairs,
+            "config": {"workload": ("BASELINE configs[2]: 20-step PGD Linf eps=0.03*255 alpha=1.0, Stereo R-CNN pixel space (BGR minus "
+                                    "PIXEL_MEANS), 600x1987 network-scale pairs, %d stereo pairs resident per GPU, gradient = resident "
+                                    "synthetic buffer, 8-bit HWC export of all 21 iterates" % args.pairs) if srcnn else
+                                   ("BASELINE configs[1]: 20-step PGD Linf eps=0.03 alpha=1/255, DSGN pixel space, "
+                                    "KITTI 1242x375 padded to 1248x384, %d stereo pairs resident per GPU, gradient = "
+                                    "resident synthetic buffer, 8-bit HWC export of all 21 iterates" % args.pairs),
                        "pairs_per_gpu": args.pairs, "pgd_iters": N_ITER, "eps": EPS, "alpha": ALPHA,
                        "parallelism": "image-sharded x%d, no collective" % world},
-            "roofline": {"bound": "hbm", "kernel": "pgd_step_vec4<AFFINE,U8_ROWS_DWORD>",
+            "roofline": {"bound": "hbm", "kernel": "pgd_step_shifted<IDENTITY,U8_BYTES>" if srcnn else "pgd_step_vec4<AFFINE,U8_ROWS_DWORD>",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not srcnn:
             out["cpu_baseline"] = cpu_baseline(args.cpu_pairs)
     else:
         out = None
