@@ -387,3 +387,46 @@ def test_calls_are_capturable_in_a_hip_graph(ops):
         want[0:1] = O.patch_paste(want[0:1], patch_np, 40, 70, r)
         same_bits(host(static_x), want, "iterate from the graph, trial %d" % trial)
         same_bits(host(patch), O.patch_update(patch_np, g_np[0:1], g_np[1:2], 40, 70, 50, r, 8 / 255), "patch from the graph")
+
+
+def test_extreme_float_values(ops):
+    """denormals, huge magnitudes, infinities and NaN in every operand; alpha / eps of 0 and of denormal size.
+    torch-CPU (and the numpy oracle) keep float32 denormals; so must the kernels (no flush-to-zero)."""
+    specials = np.array([0.0, -0.0, 1e-45, -1e-45, 1e-40, -3e-39, 1.17549435e-38, 3.4028235e38, -3.4028235e38, np.inf, -np.inf,
+                         np.nan, 1.0, -1.0, 0.5, 0.485, 0.229, 2.6399999, -2.1179039, 1e-7, 255.0, -122.7717], dtype=np.float32)
+    rs = np.random.RandomState(0)
+    n = specials.size
+    h, w = 8, n * 2
+    grid = np.stack(np.meshgrid(np.arange(n), np.arange(n), indexing="ij"), -1).reshape(-1, 2)
+    with np.errstate(all="ignore"):
+        for kind in ("dsgn", "srcnn"):
+            for alpha, eps in ((0.0, 0.0), (1e-45, 1e-45), (1 / 255, 0.03), (3e38, 3e38), (1.0, 0.0)):
+                x = specials[rs.randint(0, n, size=(2, 3, h, w))]
+                g = specials[rs.randint(0, n, size=(2, 3, h, w))]
+                cl = specials[rs.randint(0, n, size=(2, 3, h, w))]
+                x.reshape(-1)[:grid.shape[0]] = specials[grid[:, 0]][: x.size]
+                cl.reshape(-1)[:grid.shape[0]] = specials[grid[:, 1]][: x.size]
+                if kind == "dsgn":
+                    want = O.pgd_step_norm01(x, g, cl, alpha, eps)
+                    got = ops.pgd_step(dev(x), dev(g), dev(cl), ops.Space.dsgn(), alpha, eps)
+                    same_bits(host(ops.denormalize(dev(x), ops.Space.dsgn())), O.denormalize(x), "denormalize extremes")
+                    same_bits(host(ops.normalize(dev(x), ops.Space.dsgn())), O.normalize(x), "normalize extremes")
+                else:
+                    want = O.pgd_step_meansub255(x, g, cl, alpha, eps)
+                    got = ops.pgd_step(dev(x), dev(g), dev(cl), ops.Space.srcnn(), alpha, eps)
+                same_bits(host(got), want, "%s alpha %g eps %g" % (kind, alpha, eps))
+    # and the patch kernels
+    patch = specials[rs.randint(0, n, size=(1, 3, 5, 5))]
+    img = specials[rs.randint(0, n, size=(1, 3, 12, 16))]
+    t = dev(img)
+    ops.patch_paste(t, dev(patch), 5, 7, 2)
+    with np.errstate(all="ignore"):
+        want = O.patch_paste(img, patch, 5, 7, 2)
+    win = (slice(None), slice(None), slice(3, 8), slice(5, 10))
+    same_bits(host(t)[win], want[win], "paste extremes (bounding square)")
+    gl = specials[rs.randint(0, n, size=(1, 3, 12, 16))]
+    gr = specials[rs.randint(0, n, size=(1, 3, 12, 16))]
+    p = dev(patch)
+    ops.patch_update(p, dev(gl), dev(gr), 5, 7, 4, 2, 8 / 255, lo=O.SRCNN_LO, hi=O.SRCNN_HI)
+    with np.errstate(all="ignore"):
+        same_bits(host(p), O.patch_update(patch, gl, gr, 5, 7, 4, 2, 8 / 255, lo=O.SRCNN_LO, hi=O.SRCNN_HI), "update extremes")
