@@ -46,9 +46,13 @@ def torch_sign(g):
 
 
 def torch_clamp(x, lo, hi):
-    """torch.clamp(x, min=lo, max=hi) with float32 bounds; NaN propagates."""
+    """torch.clamp(x, min=lo, max=hi) with float32 bounds.  NaN propagates, and on ties between zeros of
+    different sign the INPUT wins (ATen: ``min_ps(max, max_ps(min, x))`` returns its second operand on
+    equality; the scalar tail ``std::min(std::max(x, lo), hi)`` agrees).  np.minimum / np.maximum are not used
+    because their SIMD paths resolve +-0 ties the other way (pinned by the golden case srcnn_pgd_zero_eps)."""
+    lo, hi = F32(lo), F32(hi)
     with np.errstate(invalid="ignore"):
-        return np.minimum(np.maximum(x, F32(lo)), F32(hi))
+        return np.where(x < lo, lo, np.where(x > hi, hi, x)).astype(np.float32)
 
 
 # ----------------------------------------------------------------------------- a1 / a2

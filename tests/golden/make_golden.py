@@ -161,11 +161,19 @@ SR_PGD = "attack/Stereo-RCNN/pgd_attack.py"
 
 
 def srcnn_pgd_case(seed, h, w, alpha, eps_arg, n_iter, grad_scale=1.0, specials=False,
-                   keep_arrays=True):
+                   keep_arrays=True, zero_ties=False):
     cfg = types.SimpleNamespace(PIXEL_MEANS=np.array([[list(synth.SRCNN_PIXEL_MEANS)]]))
     ns = {"torch": torch, "np": np, "cfg": cfg}
     x0L = synth.srcnn_meansub(seed, h, w)
     x0R = synth.srcnn_meansub(seed + 1, h, w)
+    if zero_ties:   # +-0 and tiny values, so that clamp bounds of -0.0 / +0.0 (eps = 0) meet zeros of either sign
+        for a, s0 in ((x0L, seed), (x0R, seed + 1)):
+            rs = np.random.RandomState(s0)
+            pick = rs.randint(0, 6, size=a.shape)
+            a[pick == 0] = np.float32(0.0)
+            a[pick == 1] = np.float32(-0.0)
+            a[pick == 2] = np.float32(1e-42)
+            a[pick == 3] = np.float32(-1e-42)
     eps = 255 * eps_arg                           # pgd_attack.py:57  (args.eps * 255)
     ns.update(im_left_data=torch.from_numpy(x0L.copy()), im_right_data=torch.from_numpy(x0R.copy()),
               alpha=alpha, eps=eps)
@@ -435,6 +443,11 @@ def main():
     ]
     for name, seed, h, w, a, e, n, gs, sp in sr:
         arrays, meta = srcnn_pgd_case(seed, h, w, a, e, n, gs, sp)
+        meta["bytes"] = save_npz(name + ".npz", arrays)
+        index["cases"][name] = meta
+    # eps = 0 and alpha = 0 / tiny with signed zeros in the image: pins how torch.clamp resolves +-0 ties
+    for name, seed, a, e in (("srcnn_pgd_zero_eps", 15, 0.0, 0.0), ("srcnn_pgd_zero_eps_tiny_alpha", 16, 1e-42, 0.0)):
+        arrays, meta = srcnn_pgd_case(seed, 9, 16, a, e, 3, 1.0, True, zero_ties=True)
         meta["bytes"] = save_npz(name + ".npz", arrays)
         index["cases"][name] = meta
     _, meta = srcnn_pgd_case(14, 600, 1987, 1.0, 0.03, 2, 1.0, False, keep_arrays=False)

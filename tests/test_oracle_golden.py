@@ -23,7 +23,7 @@ def same_bits(a, b):
 
 
 DSGN_PGD = ["dsgn_pgd_default", "dsgn_pgd_fgsm", "dsgn_pgd_cfg2", "dsgn_pgd_specials", "dsgn_pgd_ragged"]
-SRCNN_PGD = ["srcnn_pgd_default", "srcnn_pgd_cfg3", "srcnn_pgd_specials"]
+SRCNN_PGD = ["srcnn_pgd_default", "srcnn_pgd_cfg3", "srcnn_pgd_specials", "srcnn_pgd_zero_eps", "srcnn_pgd_zero_eps_tiny_alpha"]
 
 
 @pytest.mark.parametrize("name", DSGN_PGD)
