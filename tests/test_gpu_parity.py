@@ -436,3 +436,45 @@ def test_extreme_float_values(ops):
     ops.patch_update(p, dev(gl), dev(gr), 5, 7, 4, 2, 8 / 255, lo=O.SRCNN_LO, hi=O.SRCNN_HI)
     with np.errstate(all="ignore"):
         same_bits(host(p), O.patch_update(patch, gl, gr, 5, 7, 4, 2, 8 / 255, lo=O.SRCNN_LO, hi=O.SRCNN_HI), "update extremes", any_nan=True)
+
+
+def test_more_images_than_grid_rows(ops):
+    """n > 65535 images: grid.y saturates and the kernels loop over images"""
+    n, h, w = 70001, 1, 8
+    rs = np.random.RandomState(1)
+    x = (rs.randn(n, 3, h, w)).astype(np.float32)
+    g = rs.randn(n, 3, h, w).astype(np.float32)
+    clean = rs.rand(n, 3, h, w).astype(np.float32)
+    sp = ops.Space.dsgn()
+    u8 = ops.alloc_u8(n, h, w, "cuda")
+    got = ops.pgd_step(dev(x), dev(g), dev(clean), sp, 1 / 255, 0.03, u8_out=u8)
+    want = O.pgd_step_norm01(x, g, clean, 1 / 255, 0.03)
+    same_bits(host(got), want, "70001 images")
+    for i in (0, 65534, 65535, 65536, 70000):
+        same_bits(host(u8)[i], O.tensor2im_u8(want[i], h, w), "u8 of image %d" % i)
+    same_bits(host(ops.denormalize(dev(x), sp)), O.denormalize(x), "denormalize 70001 images")
+    # Stereo R-CNN space with planes of 2 float4 (not whole cache lines): the shifted kernel's image loop
+    xs = (x * 50).astype(np.float32)
+    got = ops.pgd_step(dev(xs), dev(g), dev(xs), ops.Space.srcnn(), 1.0, 7.65, u8_out=u8)
+    want = O.pgd_step_meansub255(xs, g, xs, 1.0, 7.65)
+    same_bits(host(got), want, "70001 images, shifted kernel")
+    same_bits(host(u8)[69999], O.srcnn_export_u8(want[69999]), "u8 shifted kernel")
+
+
+def test_patch_windows_touching_the_image_border(ops):
+    h, w, r = 40, 56, 6
+    d = 2 * r + 1
+    img = synth.dsgn_normalised(70, h, w)
+    patch = synth.patch_init(71, d)
+    gl, gr = synth.gradient(72, img.shape, 5e-5), synth.gradient(73, img.shape, 5e-5)
+    for cy, cx in ((r, r), (h - 1 - r, w - 1 - r), (r, w - 1 - r), (h - 1 - r, r)):
+        t = dev(img)
+        ops.patch_paste(t, dev(patch), cy, cx, r)
+        same_bits(host(t), O.patch_paste(img, patch, cy, cx, r), "paste at (%d,%d)" % (cy, cx))
+        p = dev(patch)
+        ops.patch_update(p, dev(gl), dev(gr), cy, cx, cx, r, 8 / 255)
+        same_bits(host(p), O.patch_update(patch, gl, gr, cy, cx, cx, r, 8 / 255), "update at (%d,%d)" % (cy, cx))
+    from eval_driving_safety_amd._lib import AdvEngineError
+    for cy, cx in ((r - 1, r), (r, w - r), (h - r, r)):
+        with pytest.raises(AdvEngineError):
+            ops.patch_paste(dev(img), dev(patch), cy, cx, r)

@@ -69,6 +69,9 @@ def test_hip_psv_matches_oracle(shape):
     shift[-1, -1] = 0
     if d > 2:
         shift[0, 1] = w                                                 # a plane that is entirely zero
+    if d > 3:
+        shift[0, 2] = -3                                                # negative: treated as 0
+        shift[-1, 0] = w + 17                                           # beyond the row: treated as W
     dev = torch.device("cuda", 0)
     tl, tr, ts = torch.tensor(left, device=dev), torch.tensor(right, device=dev), torch.tensor(shift, device=dev)
     cost = ops.psv_build(tl, tr, ts)
