@@ -45,6 +45,7 @@ def parse():
                     help="dsgn = BASELINE configs[1] (the headline, default); srcnn = configs[2]: 20-step PGD in the Stereo R-CNN "
                          "pixel space on 600x1987 pairs (alpha 1.0, eps 0.03*255) - a parity-test configuration, timed on request")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the (separately reported) surrogate-detector attack")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs in the CPU-baseline sample (0 = auto)")
     return ap.parse_args()
 
@@ -219,6 +220,16 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline and not srcnn:
             out["cpu_baseline"] = cpu_baseline(args.cpu_pairs)
+        if world == 1 and not args.no_end_to_end and not srcnn:
+            # the end-to-end number is reported BESIDE the kernel-path one, never folded into `value`
+            del x0, grad, clean, x, u8
+            torch.cuda.empty_cache()
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import bench_end_to_end
+                out["end_to_end"] = bench_end_to_end.measure(pairs=1, iters=N_ITER, reps=2, warm_iters=2)
+            except Exception as e:
+                out["end_to_end"] = {"error": repr(e)}
     else:
         out = None
 
