@@ -266,6 +266,44 @@ def test_patch_trainer_reproduces_the_reference_sequence(tmp_path):
     assert os.path.exists(os.path.join(str(tmp_path), "dsgn_patch_ratio_0.2", "epoch0", "patch.npy"))
 
 
+def test_patch_trainer_batched_sum_and_average(tmp_path):
+    """B = 2 pairs per round against one snapshot: deltas summed (default) or averaged (average=True);
+    accumulate_grad=False uses only the current iteration's gradient"""
+    H, W = patchgeom.DSGN_SHAPE
+    l = np.concatenate([synth.dsgn_normalised(80, H, W), synth.dsgn_normalised(82, H, W)])
+    r = np.concatenate([synth.dsgn_normalised(81, H, W), synth.dsgn_normalised(83, H, W)])
+    toy = _CpuToy(seed=6)
+    D, rad = O.init_patch_dims(384, 0.2)
+    results = {}
+    for mode, kw in (("sum", {}), ("avg", {"average": True}), ("noacc", {"accumulate_grad": False})):
+        out = tmp_path / mode
+        tr = attacks.PatchTrainer("dsgn", 0.2, 8 / 255, 2, 1, out_root=str(out), seed=2, ops=_oracle_ops, device=torch.device("cpu"), **kw)
+        batch = attacks.StereoBatch(torch.from_numpy(l.copy()), torch.from_numpy(r.copy()), ["000000", "000001"], [(1242, 375)] * 2)
+        results[mode] = tr.train(lambda: [batch], toy).numpy().copy()
+    rng = random.Random(2)
+    cs = [O.round_mask_centers(rng, H, W, rad) for _ in range(2)]
+    for mode in ("sum", "avg", "noacc"):
+        p = np.zeros((1, 3, D, D), np.float32)
+        x = np.concatenate([l, r]).copy()
+        gacc = None
+        for it in range(2):
+            for i, (cl, cr) in enumerate(cs):
+                x[i:i + 1] = O.patch_paste(x[i:i + 1], p, cl[0], cl[1], rad)
+                x[2 + i:3 + i] = O.patch_paste(x[2 + i:3 + i], p, cr[0], cr[1], rad)
+            _, g = toy.loss_and_grad(torch.from_numpy(x.copy()))
+            g = g.numpy()
+            gacc = g if (gacc is None or mode == "noacc") else gacc + g
+            total = None
+            for i, (cl, cr) in enumerate(cs):
+                d = O.patch_delta(gacc[i:i + 1], gacc[2 + i:3 + i], cl[0], cl[1], cr[1], rad, 8 / 255)
+                total = d if total is None else total + d
+            if mode == "avg":
+                total = total / np.float32(2)
+            p = O.patch_apply_delta(p, total)
+        assert results[mode].tobytes() == p.tobytes(), mode
+    assert results["sum"].tobytes() != results["avg"].tobytes()
+
+
 def test_patch_trainer_skips_wrong_shapes(tmp_path):
     b = _small_batch(1, sizes=False)
     tr = attacks.PatchTrainer("dsgn", 0.2, 8 / 255, 1, 1, out_root=str(tmp_path), seed=1, ops=_oracle_ops, device=torch.device("cpu"))
