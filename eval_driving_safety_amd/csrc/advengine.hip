@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdint>
 
+#include "adv_internal.h"
 #include "advengine.h"
 
 #pragma clang fp contract(off)
@@ -545,14 +546,7 @@ inline SpaceK to_kernel_space(const adv_space_t* s) {
   return k;
 }
 
-inline int finish_launch() {
-  const hipError_t e = hipGetLastError();
-  if (e != hipSuccess) {
-    g_last_hip_error = static_cast<int>(e);
-    return ADV_ELAUNCH;
-  }
-  return ADV_OK;
-}
+inline int finish_launch() { return adv_internal_finish_launch(); }
 
 // Vector streaming kernels: one 64-lane workgroup per `unroll` tiles of 64 pixel groups, grid.y = images.
 inline dim3 wave_grid(long long groups_per_image, long long n_img, int unroll) {
@@ -672,6 +666,8 @@ inline bool window_inside(int h, int w, int cy, int cx, int r) {
 constexpr long long kMaxPlane = 1LL << 30;  // h*w fits comfortably in int
 
 }  // namespace
+
+void adv_internal_set_last_hip_error(int e) { g_last_hip_error = e; }
 
 // ==========================================================================================
 // C ABI

@@ -16,6 +16,7 @@
 
 #include <cstdint>
 
+#include "adv_internal.h"
 #include "advengine.h"
 
 #pragma clang fp contract(off)
@@ -218,10 +219,7 @@ __global__ void psv_bwd_scalar(const float* __restrict__ gcost, const int32_t* _
 
 inline bool aligned(const void* p, uintptr_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
 
-inline int finish() {
-  const hipError_t e = hipGetLastError();
-  return e == hipSuccess ? ADV_OK : ADV_ELAUNCH;
-}
+inline int finish() { return adv_internal_finish_launch(); }
 
 inline int check(const void* a, const void* b, const void* c, const void* d, int B, int C, int D, int H, int W) {
   if (!a || !b || !c || !d) return ADV_EINVAL;

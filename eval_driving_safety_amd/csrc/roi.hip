@@ -5,6 +5,7 @@
 
 #include <cstdint>
 
+#include "adv_internal.h"
 #include "advengine.h"
 
 #pragma clang fp contract(off)
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(64) void nms_scan(const unsigned long long* __restr
   if (threadIdx.x == 0) *num_keep = kept;
 }
 
-inline int finish() { return hipGetLastError() == hipSuccess ? ADV_OK : ADV_ELAUNCH; }
+inline int finish() { return adv_internal_finish_launch(); }
 inline bool aligned4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3) == 0; }
 
 inline int check_roi(const void* a, const void* b, const void* c, int B, int C, int H, int W, int R, int PH, int PW) {

@@ -28,6 +28,7 @@ extern "C" {
 #endif
 
 #define ADV_ABI_VERSION 1
+#define ADV_API __attribute__((visibility("default"))) /* the library is built with -fvisibility=hidden */
 #define ADV_CHANNELS 3
 
 #define ADV_OK 0
@@ -57,21 +58,21 @@ typedef struct adv_space {
 } adv_space_t;
 
 /* Fill `s` with the reference's constants. */
-void adv_space_dsgn(adv_space_t* s);  /* mean/std of attack/DSGN/pgd_attack.py:153-154, range [0,1] */
-void adv_space_srcnn(adv_space_t* s); /* range [-m_c, 255-m_c], m = (102.9801,115.9465,122.7717) */
+ADV_API void adv_space_dsgn(adv_space_t* s);  /* mean/std of attack/DSGN/pgd_attack.py:153-154, range [0,1] */
+ADV_API void adv_space_srcnn(adv_space_t* s); /* range [-m_c, 255-m_c], m = (102.9801,115.9465,122.7717) */
 
-int adv_abi_version(void);
-const char* adv_strerror(int code);
-int adv_last_hip_error(void); /* thread-local */
+ADV_API int adv_abi_version(void);
+ADV_API const char* adv_strerror(int code);
+ADV_API int adv_last_hip_error(void); /* thread-local */
 
 /* a1  denormalize(), attack/DSGN/pgd_attack.py:196-200 :  out = x * scale_c + shift_c.
  *     (The reference touches batch element 0 only; here all n images.)  out may alias x.
  *     AFFINE spaces only. */
-int adv_denormalize_f32(const float* x, float* out, int64_t n, int h, int w,
+ADV_API int adv_denormalize_f32(const float* x, float* out, int64_t n, int h, int w,
                         const adv_space_t* space, adv_stream_t stream);
 
 /* a2  normalize(), attack/DSGN/pgd_attack.py:203-207 :  out = (x - shift_c) / scale_c. */
-int adv_normalize_f32(const float* x, float* out, int64_t n, int h, int w,
+ADV_API int adv_normalize_f32(const float* x, float* out, int64_t n, int h, int w,
                       const adv_space_t* space, adv_stream_t stream);
 
 /* a3 / a13 (+ a5)  one PGD / FGSM step for n images in ONE pass over memory.
@@ -92,32 +93,32 @@ int adv_normalize_f32(const float* x, float* out, int64_t n, int h, int w,
  *   With u8_row_stride >= 3*w whole rows (all w columns) are stored, which keeps every
  *   store aligned; the columns >= crop_w are then padding the consumer crops away
  *   (save_img's crop, pgd_attack.py:192). */
-int adv_pgd_step_f32(const float* x, const float* grad, const float* clean, float* x_out,
+ADV_API int adv_pgd_step_f32(const float* x, const float* grad, const float* clean, float* x_out,
                      uint8_t* u8_out, int64_t n, int h, int w, const adv_space_t* space,
                      float alpha, float eps, int crop_h, int crop_w, int64_t u8_row_stride,
                      int64_t u8_image_stride, adv_stream_t stream);
 
 /* a5  the 8-bit export alone (iterate 0 = the clean image, pgd_attack.py:279-294). */
-int adv_export_u8_f32(const float* x, uint8_t* u8_out, int64_t n, int h, int w,
+ADV_API int adv_export_u8_f32(const float* x, uint8_t* u8_out, int64_t n, int h, int w,
                       const adv_space_t* space, int crop_h, int crop_w, int64_t u8_row_stride,
                       int64_t u8_image_stride, adv_stream_t stream);
 
 /* a7  generate_round_mask's mask, attack/DSGN/patch_attack.py:245-248: float32 [h,w],
  *     1.0 where (y-cy)^2 + (x-cx)^2 <= r^2 (equal to the reference's float64 sqrt test). */
-int adv_disc_mask_f32(float* mask_out, int h, int w, int cy, int cx, int r, adv_stream_t stream);
+ADV_API int adv_disc_mask_f32(float* mask_out, int h, int w, int cy, int cx, int r, adv_stream_t stream);
 
 /* a8  patch paste, attack/DSGN/patch_attack.py:326-333,369-376 (Stereo R-CNN :178-185,221-230):
  *     img = (1-M)*img + M*pad0(patch), M the disc of radius r centred (cy,cx), patch [3,d,d],
  *     d = 2r+1.  Evaluated literally on the d x d bounding square; outside it the reference
  *     computes 1*img + 0*0, i.e. leaves img as it is (a -0.0 there would become +0.0 in the
  *     reference and stays -0.0 here - the only deviation).  In place.  One image. */
-int adv_patch_paste_f32(float* img, const float* patch, int h, int w, int d, int cy, int cx,
+ADV_API int adv_patch_paste_f32(float* img, const float* patch, int h, int w, int d, int cy, int cx,
                         int r, adv_stream_t stream);
 
 /* a8 batched: image i of [n,3,h,w] gets the patch at (centers[2i], centers[2i+1]) = (cy,cx);
  *     `centers` is DEVICE int32 [n,2].  Elements whose target falls outside the image are
  *     skipped. */
-int adv_patch_paste_batch_f32(float* img, const float* patch, int64_t n, int h, int w, int d,
+ADV_API int adv_patch_paste_batch_f32(float* img, const float* patch, int64_t n, int h, int w, int d,
                               const int32_t* centers, int r, adv_stream_t stream);
 
 /* a11 / a12  the reference's per-image patch update in one launch,
@@ -126,7 +127,7 @@ int adv_patch_paste_batch_f32(float* img, const float* patch, int64_t n, int h, 
  *     patch = patch - delta;  if lo/hi given (HOST float[3]):  patch_c = clamp(patch_c, lo_c, hi_c).
  *     win = the (2r+1)^2 bounding SQUARE (not the disc).  half_alpha = 0.5*alpha = 500 in the
  *     reference.  delta_out (nullable, [3,d,d]) receives delta. */
-int adv_patch_update_f32(float* patch, const float* grad_l, const float* grad_r, int h, int w,
+ADV_API int adv_patch_update_f32(float* patch, const float* grad_l, const float* grad_r, int h, int w,
                          int d, int cy, int cx_l, int cx_r, int r, float half_alpha, float eps,
                          const float* lo, const float* hi, float* delta_out, adv_stream_t stream);
 
@@ -134,12 +135,12 @@ int adv_patch_update_f32(float* patch, const float* grad_l, const float* grad_r,
  *     snapshot, summed in index order:  delta_out = d_0 + d_1 + ... + d_{n-1}  ([3,d,d]).
  *     centers: DEVICE int32 [n,3] = (cy, cxL, cxR).  This buffer is what the RCCL all-reduce
  *     of the universal-patch attack carries. */
-int adv_patch_delta_batch_f32(const float* grad_l, const float* grad_r, int64_t n, int h, int w,
+ADV_API int adv_patch_delta_batch_f32(const float* grad_l, const float* grad_r, int64_t n, int h, int w,
                               int d, const int32_t* centers, int r, float half_alpha, float eps,
                               float* delta_out, adv_stream_t stream);
 
 /* second half of a11/a12:  patch = patch - delta;  optional per-channel clamp (HOST float[3]). */
-int adv_patch_apply_f32(float* patch, const float* delta, int d, const float* lo,
+ADV_API int adv_patch_apply_f32(float* patch, const float* delta, int d, const float* lo,
                         const float* hi, adv_stream_t stream);
 
 /* K7  plane-sweep cost-volume build of a DSGN-style detector (the op the reference reaches through
@@ -154,13 +155,13 @@ int adv_patch_apply_f32(float* patch, const float* delta, int d, const float* lo
  *                                                  cost[b,C+c,d,y,x] = right[b,c,y,x-s]
  *                                    for x <  s:  both 0.
  *     Every element of `cost` is written (no memset needed). */
-int adv_psv_build_f32(const float* left, const float* right, const int32_t* shift, float* cost, int b,
+ADV_API int adv_psv_build_f32(const float* left, const float* right, const int32_t* shift, float* cost, int b,
                       int c, int d, int h, int w, adv_stream_t stream);
 
 /* K7 backward: the exact adjoint.  grad_left[b,c,y,x]  = sum_d [x >= s_d]     grad_cost[b,c,d,y,x]
  *                                  grad_right[b,c,y,x] = sum_d [x + s_d < W]  grad_cost[b,C+c,d,y,x+s_d]
  *     summed over d = 0..D-1 in that order in float32 (reproducible; no atomics). */
-int adv_psv_build_bwd_f32(const float* grad_cost, const int32_t* shift, float* grad_left,
+ADV_API int adv_psv_build_bwd_f32(const float* grad_cost, const int32_t* shift, float* grad_left,
                           float* grad_right, int b, int c, int d, int h, int w, adv_stream_t stream);
 
 /* ---- Stereo R-CNN RoI path natives.  The ops are `from model.roi_layers import ROIAlign, nms`
@@ -173,19 +174,19 @@ int adv_psv_build_bwd_f32(const float* grad_cost, const int32_t* shift, float* g
  *     coordinates, scaled by spatial_scale; sampling_ratio <= 0 -> ceil(roi_size / pooled_size) samples per bin
  *     (the reference constructs ROIAlign(..., 1/16, 0) and passes the FPN level's scale per call);
  *     out [R,C,PH,PW] = mean of the bilinear samples of each bin. */
-int adv_roi_align_fwd_f32(const float* feat, const float* rois, float* out, int b, int c, int h, int w, int r,
+ADV_API int adv_roi_align_fwd_f32(const float* feat, const float* rois, float* out, int b, int c, int h, int w, int r,
                           int ph, int pw, float spatial_scale, int sampling_ratio, adv_stream_t stream);
 
 /* RoIAlign backward: grad_feat [B,C,H,W] is zero-filled by this call, then every sample scatters
  *     grad_out * weight / count to its 4 neighbours with float atomics (sum order varies between runs: results are
  *     equal to the oracle within float32 rounding, not bitwise). */
-int adv_roi_align_bwd_f32(const float* grad_out, const float* rois, float* grad_feat, int b, int c, int h, int w,
+ADV_API int adv_roi_align_bwd_f32(const float* grad_out, const float* rois, float* grad_feat, int b, int c, int h, int w,
                           int r, int ph, int pw, float spatial_scale, int sampling_ratio, adv_stream_t stream);
 
 /* Greedy NMS over n boxes [n,4] = (x1,y1,x2,y2) ALREADY SORTED by descending score, legacy "+1" areas,
  *     suppress when IoU > thresh.  keep_out [n] int64 receives the kept indices in order, num_keep_out [1] int32
  *     their count (both DEVICE); workspace: DEVICE, n * ceil(n/64) uint64.  Deterministic (bit-exact indices). */
-int adv_nms_f32(const float* boxes, int n, float thresh, int64_t* keep_out, int32_t* num_keep_out,
+ADV_API int adv_nms_f32(const float* boxes, int n, float thresh, int64_t* keep_out, int32_t* num_keep_out,
                 uint64_t* workspace, adv_stream_t stream);
 
 #ifdef __cplusplus
