@@ -12,6 +12,19 @@ for p in (ROOT, GOLDEN):
         sys.path.insert(0, p)
 
 
+def pytest_sessionstart(session):
+    """A fresh checkout has no built artefacts (they are git-ignored): build them once, so that the suite does
+    not depend on somebody having called __graft_entry__.build() first.  hipcc cross-compiles without a GPU."""
+    need = [os.path.join(ROOT, "eval_driving_safety_amd", "libadvengine.so"), os.path.join(ROOT, "oracle", "_build", "liboracle.so")]
+    if all(os.path.exists(p) for p in need):
+        return
+    try:
+        import __graft_entry__
+        __graft_entry__.build()
+    except Exception as e:          # leave it to the tests to report what is missing
+        print("conftest: build() failed: %r" % (e,), file=sys.stderr)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
