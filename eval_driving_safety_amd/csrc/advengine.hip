@@ -212,7 +212,10 @@ __global__ __launch_bounds__(kWave) void pgd_step_vec4(const v4f* x, const v4f* 
 // neighbouring tile are recomputed by a few "halo" lanes (<= 6 extra lines per 288 fetched).
 // Workgroup = 256 lanes = 256 pixel groups per channel; grid = (tiles, images).
 // ------------------------------------------------------------------------------------------
-constexpr int kShiftBlock = 256;
+#ifndef ADV_SHIFT_BLOCK
+#define ADV_SHIFT_BLOCK 256
+#endif
+constexpr int kShiftBlock = ADV_SHIFT_BLOCK;
 constexpr int kHalo = 8;
 
 template <int KIND>
