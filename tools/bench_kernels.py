@@ -65,9 +65,41 @@ def pgd_vs_eager(dev):
         torch.cuda.empty_cache()
 
 
+def pcie(dev):
+    """what a caller pays if the stereo pairs start in (pinned) host memory and the 8-bit iterates end there:
+    measured H2D / D2H rates and the resulting PCIe-inclusive bound in pairs/s for the 20-step attack"""
+    import time
+    pairs = 32
+    n = 2 * pairs
+    H, W = 384, 1248
+    host_x = torch.empty((n, 3, H, W), dtype=torch.float32, pin_memory=True)
+    dev_x = torch.empty((n, 3, H, W), dtype=torch.float32, device=dev)
+    host_u8 = torch.empty((n, 375, W, 3), dtype=torch.uint8, pin_memory=True)
+    dev_u8 = torch.empty((n, 375, W, 3), dtype=torch.uint8, device=dev)
+    out = {}
+    for name, dst, src in (("h2d_f32", dev_x, host_x), ("d2h_u8", host_u8, dev_u8)):
+        dst.copy_(src, non_blocking=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            dst.copy_(src, non_blocking=True)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 10
+        out[name + "_GBps"] = round(src.numel() * src.element_size() / dt / 1e9, 2)
+    bytes_in = 2 * 3 * H * W * 4                    # both eyes, float32
+    bytes_out = 21 * 2 * 375 * W * 3                # 21 exported iterates, whole rows
+    t = bytes_in / (out["h2d_f32_GBps"] * 1e9) + bytes_out / (out["d2h_u8_GBps"] * 1e9)
+    out.update(bytes_in_per_pair=bytes_in, bytes_out_per_pair=bytes_out, pcie_bound_pairs_per_s=round(1 / t, 1),
+               note="transfers serialised; H2D and D2H can overlap each other and the kernels on separate streams")
+    print(json.dumps(out))
+
+
 def main():
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
+    if "--pcie" in sys.argv:
+        pcie(dev)
+        return
     if "--eager" in sys.argv:
         pgd_vs_eager(dev)
         return
