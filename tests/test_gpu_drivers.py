@@ -158,3 +158,25 @@ def test_attack_folders_feed_detect_under_attack(tmp_path):
     obs = pixelio.scenario_obstacles(label)
     assert len(obs) == 1 and obs[0]["position"] == [25.0, -2.0] and abs(obs[0]["orientation"] - (0.5 * np.pi - (4.0 - 2 * np.pi))) < 1e-12
     assert label_dir.endswith("kitti_output_iter2_alpha%s" % str(1 / 255))
+
+
+def test_baseline_config1_fgsm_four_pairs(tmp_path):
+    """BASELINE.json configs[0]: 1-step FGSM, eps = alpha = 8/255, DSGN pixel space, 4 KITTI-shaped pairs - the HIP
+    path against the CPU oracle fed with the same gradients; every pixel moved by exactly +-8/255 or hit the range"""
+    from eval_driving_safety_amd import adapters, attacks, data
+    dev = torch.device("cuda", 0)
+    batch = next(iter(data.SyntheticStereo(4, "dsgn", batch=4, seed=21)))
+    rec = _Recorder(adapters.ToyStereoAdapter(dev, seed=8))
+    atk = attacks.PgdAttack("dsgn", 8 / 255, 8 / 255, 1, out_root=str(tmp_path), device=dev)
+    x = atk.run_batch(batch, rec).cpu().numpy()
+    atk.close()
+    x0 = torch.cat([batch.imgL, batch.imgR]).numpy()
+    clean = O.denormalize(x0)
+    want = O.pgd_step_norm01(x0, rec.grads[0], clean, 8 / 255, 8 / 255)
+    assert x.tobytes() == want.tobytes()
+    moved = np.abs(O.denormalize(x) - clean)
+    g = rec.grads[0]
+    inner = (clean > 8 / 255 + 1e-3) & (clean < 1 - 8 / 255 - 1e-3) & (g != 0)
+    assert np.allclose(moved[inner], 8 / 255, atol=2e-7)
+    assert sorted(os.listdir(str(tmp_path))) == ["dsgn_pgd_iters_0", "dsgn_pgd_iters_1"]
+    assert len(os.listdir(os.path.join(str(tmp_path), "dsgn_pgd_iters_1", "image_2"))) == 4
