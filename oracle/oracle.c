@@ -161,3 +161,31 @@ void orc_patch_update(float* patch, const float* gl, const float* gr, int h, int
         if (delta_out) delta_out[(c * d + i) * d + j] = dl;
       }
 }
+
+/* attack/Stereo-RCNN/pgd_attack.py:233-237: CHW -> HWC, += PIXEL_MEANS in float64 rounded once to float32 (:236),
+ * then the 8-bit conversion cv2.imwrite applies (saturate_cast<uchar>: round half to even, clip) - UNPINNED (cv2 absent). */
+void orc_srcnn_export(const float* x, float* hwc_out, uint8_t* u8_out, int h, int w) {
+  const long hw = (long)h * w;
+#pragma omp parallel for schedule(static)
+  for (int r = 0; r < h; ++r)
+    for (int col = 0; col < w; ++col)
+      for (int c = 0; c < 3; ++c) {
+        const float f = (float)((double)x[c * hw + (long)r * w + col] + kPixelMeans[c]);
+        const long o = ((long)r * w + col) * 3 + c;
+        if (hwc_out) hwc_out[o] = f;
+        if (u8_out) {
+          int iv = -1;
+          if (fabsf(f) < 2147483648.0f) iv = (int)rintf(f);
+          u8_out[o] = (uint8_t)(iv < 0 ? 0 : (iv > 255 ? 255 : iv));
+        }
+      }
+}
+
+/* attack/DSGN/patch_attack.py:245-248 */
+void orc_disc_mask(float* mask, int h, int w, int cy, int cx, int r) {
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) {
+      const double dy = y - cy, dx = x - cx;
+      mask[(long)y * w + x] = (sqrt(dy * dy + dx * dx) <= (double)r) ? 1.0f : 0.0f;
+    }
+}

@@ -21,6 +21,10 @@ _lib.orc_tensor2im_u8.argtypes = [_fp, _u8p, ctypes.c_int, ctypes.c_int, ctypes.
 _lib.orc_patch_paste.argtypes = [_fp, _fp] + [ctypes.c_int] * 5
 _lib.orc_patch_update.argtypes = [_fp, _fp, _fp] + [ctypes.c_int] * 6 + [ctypes.c_float, ctypes.c_float,
                                                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+_lib.orc_srcnn_export.argtypes = [_fp, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+_lib.orc_srcnn_export.restype = None
+_lib.orc_disc_mask.argtypes = [_fp] + [ctypes.c_int] * 5
+_lib.orc_disc_mask.restype = None
 for _f in ("orc_denormalize", "orc_normalize", "orc_pgd_step_norm01", "orc_pgd_step_meansub255", "orc_tensor2im_u8",
            "orc_patch_paste", "orc_patch_update"):
     getattr(_lib, _f).restype = None
@@ -88,4 +92,24 @@ def patch_update(patch, grad_l, grad_r, cy, cx_l, cx_r, radius, eps, alpha=1e3, 
     _lib.orc_patch_update(out, gl, gr, gl.shape[2], gl.shape[3], cy, cx_l, cx_r, radius, 0.5 * alpha, eps,
                           None if lo_a is None else ctypes.cast(lo_a, ctypes.c_void_p),
                           None if hi_a is None else ctypes.cast(hi_a, ctypes.c_void_p), None)
+    return out
+
+
+def srcnn_hwc_plus_means(x):
+    a = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.empty((a.shape[1], a.shape[2], 3), np.float32)
+    _lib.orc_srcnn_export(a, out.ctypes.data_as(ctypes.c_void_p), None, a.shape[1], a.shape[2])
+    return out
+
+
+def srcnn_export_u8(x):
+    a = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.empty((a.shape[1], a.shape[2], 3), np.uint8)
+    _lib.orc_srcnn_export(a, None, out.ctypes.data_as(ctypes.c_void_p), a.shape[1], a.shape[2])
+    return out
+
+
+def disc_mask(h, w, cy, cx, radius):
+    out = np.empty((h, w), np.float32)
+    _lib.orc_disc_mask(out, h, w, cy, cx, radius)
     return out

@@ -32,6 +32,8 @@ def test_c_srcnn_pgd(name, golden, golden_index):
         for k in range(m["n_iter"]):
             x = C.pgd_step_meansub255(x, g["g%s_%d" % (eye, k)], clean, m["alpha"], m["eps"])
             same_bits(x, g["x%s_%d" % (eye, k + 1)])
+            same_bits(C.srcnn_hwc_plus_means(x[0]), g["hwc%s_%d" % (eye, k + 1)])
+            same_bits(C.srcnn_export_u8(x[0]), O.srcnn_export_u8(x[0]))
 
 
 @pytest.mark.parametrize("name", PATCH)
@@ -54,3 +56,9 @@ def test_c_patch(name, golden, golden_index):
         gaccR = gr if gaccR is None else gaccR + gr
         patch = C.patch_update(patch, gaccL, gaccR, cy, cxl, cxr, r, m["eps"], lo=lo, hi=hi)
         same_bits(patch, g["patch_%d" % (k + 1)])
+
+
+def test_c_disc_masks(golden_index):
+    for row in golden_index["masks"]["centers"][:8]:
+        h, w = (384, 1248) if row["model"] == "dsgn" else (600, 1987)
+        assert sha(C.disc_mask(h, w, row["center_l"][0], row["center_l"][1], row["radius"])) == row["mask_l"]
