@@ -70,8 +70,10 @@ class PgdAttack:
     The loss is ASCENDED (untargeted), as in both scripts.
     """
 
-    def __init__(self, model_kind, alpha, eps, iters, out_root=".", save=True, save_every=1, writer_workers=4,
+    def __init__(self, model_kind, alpha, eps, iters, out_root=".", save=True, save_every=1, writer_workers=None,
                  ops=None, device=None):
+        if writer_workers is None:                   # PNG (zlib) encoding is the I/O wall: 42 files per pair at N = 20
+            writer_workers = min(16, max(4, (os.cpu_count() or 8) // 4))
         self.ops = ops if ops is not None else _default_ops()
         self.kind = model_kind
         if model_kind == "dsgn":
