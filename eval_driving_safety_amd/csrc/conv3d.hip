@@ -1,0 +1,164 @@
+// 3x3x3 / stride 1 / pad 1 convolution as an implicit GEMM on the gfx950 float32 matrix cores.
+//
+//   D[cout][voxel] += W[cout][k] * X[k][voxel],   k = (input channel, tap)
+// with v_mfma_f32_32x32x2_f32: the A operand is one weight per lane (row = output channel = lane & 31, k = lane >> 5),
+// the B operand one input value per lane (k = lane >> 5, column = voxel = lane & 31), 16 accumulators per lane whose
+// column index is the lane - so the epilogue writes, per accumulator register, 32 consecutive floats of one output
+// channel (coalesced 128 B), and no transposition is ever needed.
+//
+// A workgroup (4 waves) owns an output tile of kTD x kTH rows of 32 voxels and 32 output channels; per chunk of kCK
+// input channels the input tile with its one-voxel halo and the 27 x kCK x 32 weights are staged in LDS, then every
+// wave runs 27 * kCK/2 MFMAs on each of its kNB rows.  LDS reads are conflict-free by construction: the 32 lanes of a
+// half-wave read 32 consecutive floats (the tap only shifts the start), the two halves read different channels.
+// The accumulation order is fixed (chunk, tap, channel pair; the MFMA itself is a k-ordered fmaf chain), so results
+// are reproducible and the oracle can match them bit for bit.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "adv_internal.h"
+#include "advengine.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kCK = 8;    // input channels per LDS stage
+constexpr int kTD = 2;    // tile depth
+constexpr int kTH = 8;    // tile height
+constexpr int kTW = 32;   // tile width = MFMA N
+constexpr int kTWP = 36;  // padded LDS row (34 used)
+constexpr int kNB = (kTD * kTH) / 4;  // rows per wave
+constexpr int kSX = kCK * (kTD + 2) * (kTH + 2) * kTWP;
+constexpr int kSW = 27 * kCK * 32;
+
+__global__ __launch_bounds__(256) void conv3d_k3_mfma(const float* __restrict__ x, const float* __restrict__ wp, float* __restrict__ y,
+                                                      int Cin, int Cout, int cout_pad, int D, int H, int W, int tiles_w, int cblocks,
+                                                      int relu) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* sx = lds;
+  float* sw = lds + kSX;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l32 = lane & 31;
+  const int wt = blockIdx.x % tiles_w, ht = blockIdx.x / tiles_w;
+  const int w0 = wt * kTW, h0 = ht * kTH, d0 = blockIdx.y * kTD;
+  const int b = blockIdx.z / cblocks, cob = blockIdx.z - b * cblocks;
+  const long long plane = static_cast<long long>(H) * W;
+  const long long vol = plane * D;
+
+  f32x16 acc[kNB];
+#pragma unroll
+  for (int i = 0; i < kNB; ++i)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[i][v] = 0.0f;
+
+  for (int c0 = 0; c0 < Cin; c0 += kCK) {
+    // ---- stage the input tile (+ halo, zero padded) of kCK channels
+    for (int idx = tid; idx < kCK * (kTD + 2) * (kTH + 2) * 34; idx += 256) {
+      const int ww = idx % 34;
+      int t = idx / 34;
+      const int hh = t % (kTH + 2);
+      t /= (kTH + 2);
+      const int dd = t % (kTD + 2);
+      const int c = t / (kTD + 2);
+      const int gd = d0 + dd - 1, gh = h0 + hh - 1, gw = w0 + ww - 1;
+      float v = 0.0f;
+      if (gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W)
+        v = x[(static_cast<long long>(b) * Cin + c0 + c) * vol + gd * plane + static_cast<long long>(gh) * W + gw];
+      sx[((c * (kTD + 2) + dd) * (kTH + 2) + hh) * kTWP + ww] = v;
+    }
+    // ---- stage the weights of this chunk: [27][kCK][32]
+    for (int idx = tid; idx < kSW; idx += 256) {
+      const int n = idx & 31;
+      const int c = (idx >> 5) % kCK;
+      const int tap = idx / (32 * kCK);
+      sw[idx] = wp[(static_cast<long long>(tap) * Cin + c0 + c) * cout_pad + cob * 32 + n];
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int tap = 0; tap < 27; ++tap) {
+      const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+#pragma unroll
+      for (int kk = 0; kk < kCK / 2; ++kk) {
+        const int c = 2 * kk + half;
+        const float a = sw[(tap * kCK + c) * 32 + l32];
+#pragma unroll
+        for (int i = 0; i < kNB; ++i) {
+          const int row = wave * kNB + i;
+          const int td = row / kTH, th = row - td * kTH;
+          const float bv = sx[((c * (kTD + 2) + td + kd) * (kTH + 2) + th + kh) * kTWP + l32 + kw];
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[i], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // ---- epilogue: accumulator register v of lane l is D[cout = 8*(v/4) + 4*(l/32) + v%4][voxel = l%32]
+  const int gw = w0 + l32;
+#pragma unroll
+  for (int i = 0; i < kNB; ++i) {
+    const int row = wave * kNB + i;
+    const int td = row / kTH, th = row - td * kTH;
+    const int gd = d0 + td, gh = h0 + th;
+    if (gd >= D || gh >= H || gw >= W) continue;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int co = cob * 32 + 8 * (v >> 2) + 4 * half + (v & 3);
+      if (co < Cout) {
+        float r = acc[i][v];
+        if (relu) r = r > 0.0f ? r : 0.0f;
+        y[(static_cast<long long>(b) * Cout + co) * vol + gd * plane + static_cast<long long>(gh) * W + gw] = r;
+      }
+    }
+  }
+}
+
+__global__ void conv3d_k3_prep(const float* __restrict__ w, float* __restrict__ wp, int cout, int cin, int transpose, int cin_p,
+                               int cout_p, int cout_pad) {
+  const long long total = 27LL * cin_p * cout_pad;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += gridDim.x * 256LL) {
+    const int n = static_cast<int>(i % cout_pad);
+    const int c = static_cast<int>((i / cout_pad) % cin_p);
+    const int tap = static_cast<int>(i / (static_cast<long long>(cout_pad) * cin_p));
+    float v = 0.0f;
+    if (n < cout_p) {
+      if (!transpose)
+        v = w[(static_cast<long long>(n) * cin + c) * 27 + tap];         // W[co = n][ci = c][tap]
+      else
+        v = w[(static_cast<long long>(c) * cin + n) * 27 + (26 - tap)];  // W[co = c][ci = n][flipped tap]
+    }
+    wp[i] = v;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int adv_conv3d_k3_prep_weights_f32(const float* w, float* w_prep, int cout, int cin, int transpose, adv_stream_t stream) {
+  if (!w || !w_prep || cout < 1 || cin < 1) return ADV_EINVAL;
+  const int cin_p = transpose ? cout : cin, cout_p = transpose ? cin : cout;
+  const int cout_pad = ((cout_p + 31) / 32) * 32;
+  const long long total = 27LL * cin_p * cout_pad;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(conv3d_k3_prep, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, static_cast<hipStream_t>(stream), w, w_prep, cout,
+                     cin, transpose, cin_p, cout_p, cout_pad);
+  return adv_internal_finish_launch();
+}
+
+int adv_conv3d_k3_f32(const float* x, const float* w_prep, float* y, int b, int cin, int cout, int d, int h, int w, int relu,
+                      adv_stream_t stream) {
+  if (!x || !w_prep || !y || b < 1 || cin < 1 || cout < 1 || d < 1 || h < 1 || w < 1) return ADV_EINVAL;
+  if (cin % kCK != 0) return ADV_EINVAL;
+  const int tiles_w = (w + kTW - 1) / kTW, tiles_h = (h + kTH - 1) / kTH, tiles_d = (d + kTD - 1) / kTD;
+  const int cblocks = (cout + 31) / 32;
+  if (tiles_d > 65535 || static_cast<long long>(b) * cblocks > 65535) return ADV_EINVAL;
+  const dim3 grid(tiles_w * tiles_h, tiles_d, b * cblocks);
+  const size_t lds = static_cast<size_t>(kSX + kSW) * sizeof(float);
+  hipLaunchKernelGGL(conv3d_k3_mfma, grid, dim3(256), lds, static_cast<hipStream_t>(stream), x, w_prep, y, cin, cout, cblocks * 32, d, h, w,
+                     tiles_w, cblocks, relu);
+  return adv_internal_finish_launch();
+}
+
+}  // extern "C"

@@ -405,3 +405,47 @@ def nms(boxes, scores, thresh):
     with _on(bx):
         _lib.call("adv_nms_f32", _ptr(bx), n, float(thresh), _ptr(keep), _ptr(count), _ptr(work), _stream(bx))
     return keep[:int(count.item())]
+
+
+# --------------------------------------------------------------------------------------------
+# dense 3x3x3 convolution on the float32 matrix cores (the contraction applied to the K7 cost volume)
+def conv3d_k3_prep(weight, transpose=False):
+    """[Cout,Cin,3,3,3] -> the kernel's layout [27, Cin', 32*ceil(Cout'/32)]; transpose=True prepares the adjoint
+    (gradient w.r.t. the input).  Do it once per weight tensor - the attacks never change the weights."""
+    wt = _feat(weight, "weight")
+    if wt.dim() != 5 or tuple(wt.shape[2:]) != (3, 3, 3):
+        raise ValueError("weight must be [Cout,Cin,3,3,3]")
+    cout, cin = wt.shape[:2]
+    cin_p, cout_p = (cout, cin) if transpose else (cin, cout)
+    out = torch.empty((27, cin_p, 32 * ((cout_p + 31) // 32)), dtype=torch.float32, device=wt.device)
+    with _on(wt):
+        _lib.call("adv_conv3d_k3_prep_weights_f32", _ptr(wt), _ptr(out), cout, cin, int(transpose), _stream(wt))
+    return out
+
+
+def conv3d_k3(x, w_prep, cout, relu=False):
+    """conv3d(x [B,Cin,D,H,W], stride 1, padding 1, no bias) with prepared weights -> [B,cout,D,H,W]"""
+    xi, wp = _feat(x, "x"), _feat(w_prep, "w_prep")
+    if xi.dim() != 5 or wp.dim() != 3 or wp.shape[0] != 27 or wp.shape[1] != xi.shape[1] or wp.shape[2] < cout:
+        raise ValueError("x must be [B,Cin,D,H,W] and w_prep [27,Cin,>=cout]")
+    b, cin, d, h, w = xi.shape
+    y = torch.empty((b, cout, d, h, w), dtype=torch.float32, device=xi.device)
+    with _on(xi):
+        _lib.call("adv_conv3d_k3_f32", _ptr(xi), _ptr(wp), _ptr(y), b, cin, cout, d, h, w, int(relu), _stream(xi))
+    return y
+
+
+class Conv3dK3(torch.autograd.Function):
+    """y = conv3d(x, weight); gradient flows to x only (the attacks differentiate w.r.t. the images, the detector's
+    weights are constants), through the same kernel with the transposed / flipped weights."""
+
+    @staticmethod
+    def forward(ctx, x, w_prep, w_prep_t, cout):
+        ctx.save_for_backward(w_prep_t)
+        ctx.cin = x.shape[1]
+        return conv3d_k3(x.contiguous(), w_prep, cout)
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        (w_prep_t,) = ctx.saved_tensors
+        return conv3d_k3(grad_y.contiguous(), w_prep_t, ctx.cin), None, None, None

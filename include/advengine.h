@@ -189,6 +189,23 @@ ADV_API int adv_roi_align_bwd_f32(const float* grad_out, const float* rois, floa
 ADV_API int adv_nms_f32(const float* boxes, int n, float thresh, int64_t* keep_out, int32_t* num_keep_out,
                 uint64_t* workspace, adv_stream_t stream);
 
+/* ---- dense 3x3x3 convolution on the matrix cores (float32 MFMA), the contraction a plane-sweep detector applies to
+ *      the K7 cost volume (DSGN's 3D hourglass, reached through attack/DSGN/pgd_attack.py:308; upstream code - the
+ *      semantics here are those of torch.nn.functional.conv3d(stride 1, padding 1, no bias); floating point: parity
+ *      within 1e-4 relative of a float32 reference, and bit-exact against the oracle's k-ordered fmaf chain). */
+
+/* Re-layout conv weights [Cout,Cin,3,3,3] for the kernel: w_prep [27][Cin'][32*ceil(Cout'/32)] (zero padded).
+ *     transpose = 0: Cin' = cin, Cout' = cout                       (forward)
+ *     transpose = 1: Cin' = cout, Cout' = cin, taps flipped        (backward w.r.t. the input: the adjoint conv) */
+ADV_API int adv_conv3d_k3_prep_weights_f32(const float* w, float* w_prep, int cout, int cin, int transpose,
+                                           adv_stream_t stream);
+
+/* y [B,Cout,D,H,W] = conv3d(x [B,Cin,D,H,W], w_prep), stride 1, zero padding 1; relu != 0 fuses max(y, 0).
+ *     Cin must be a multiple of 8.  Implicit GEMM on v_mfma_f32_32x32x2_f32: M = 32 output channels, N = 32
+ *     consecutive voxels along W, K = (input channel, tap); input tile + halo and the weights staged in LDS. */
+ADV_API int adv_conv3d_k3_f32(const float* x, const float* w_prep, float* y, int b, int cin, int cout, int d, int h,
+                              int w, int relu, adv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,6 +25,8 @@ _lib.orc_srcnn_export.argtypes = [_fp, ctypes.c_void_p, ctypes.c_void_p, ctypes.
 _lib.orc_srcnn_export.restype = None
 _lib.orc_disc_mask.argtypes = [_fp] + [ctypes.c_int] * 5
 _lib.orc_disc_mask.restype = None
+_lib.orc_conv3d_k3.argtypes = [_fp, _fp, _fp] + [ctypes.c_int] * 8
+_lib.orc_conv3d_k3.restype = None
 for _f in ("orc_denormalize", "orc_normalize", "orc_pgd_step_norm01", "orc_pgd_step_meansub255", "orc_tensor2im_u8",
            "orc_patch_paste", "orc_patch_update"):
     getattr(_lib, _f).restype = None
@@ -113,3 +115,15 @@ def disc_mask(h, w, cy, cx, radius):
     out = np.empty((h, w), np.float32)
     _lib.orc_disc_mask(out, h, w, cy, cx, radius)
     return out
+
+
+def conv3d_k3(x, w, relu=False, transpose=False):
+    """x [B,C,D,H,W], w [Cout,Cin,3,3,3] -> conv3d(stride 1, pad 1) or, with transpose, its adjoint applied to x"""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    cout, cin = w.shape[:2]
+    b, c, d, h, ww = x.shape
+    assert c == (cout if transpose else cin)
+    y = np.empty((b, cin if transpose else cout, d, h, ww), np.float32)
+    _lib.orc_conv3d_k3(x, w, y, b, cin, cout, d, h, ww, int(relu), int(transpose))
+    return y

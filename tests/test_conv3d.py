@@ -1,0 +1,71 @@
+"""3x3x3 convolution on the float32 matrix cores: bit-exact against the C oracle's k-ordered fmaf chain, within
+float32 rounding of torch's conv3d (the floating-point reference), forward and adjoint."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+C = pytest.importorskip("oracle.oracle_c", reason="make -C oracle first (build() does it)")
+
+
+def _case(b, cin, cout, d, h, w, seed=0):
+    rs = np.random.RandomState(seed)
+    x = rs.randn(b, cin, d, h, w).astype(np.float32)
+    wt = (rs.randn(cout, cin, 3, 3, 3) * 0.1).astype(np.float32)
+    return x, wt
+
+
+def test_oracle_conv_matches_torch_and_is_self_adjoint():
+    x, wt = _case(1, 8, 5, 3, 6, 7)
+    y = C.conv3d_k3(x, wt)
+    ref = F.conv3d(torch.tensor(x), torch.tensor(wt), padding=1).numpy()
+    np.testing.assert_allclose(y, ref, rtol=1e-5, atol=1e-5)
+    g = np.random.RandomState(1).randn(*y.shape).astype(np.float32)
+    gx = C.conv3d_k3(g, wt, transpose=True)
+    tx = torch.tensor(x, requires_grad=True)
+    F.conv3d(tx, torch.tensor(wt), padding=1).backward(torch.tensor(g))
+    np.testing.assert_allclose(gx, tx.grad.numpy(), rtol=1e-5, atol=1e-5)
+    assert np.array_equal(C.conv3d_k3(x, wt, relu=True), np.maximum(y, 0))
+
+
+SHAPES = [(1, 8, 5, 3, 6, 7), (2, 16, 32, 2, 8, 32), (1, 8, 33, 3, 9, 40), (1, 24, 64, 5, 10, 45), (1, 8, 1, 2, 3, 4)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", SHAPES)
+def test_hip_conv3d_bit_exact_vs_oracle(shape):
+    from eval_driving_safety_amd import ops
+    b, cin, cout, d, h, w = shape
+    x, wt = _case(*shape, seed=sum(shape))
+    dev = torch.device("cuda", 0)
+    tx, tw = torch.tensor(x, device=dev), torch.tensor(wt, device=dev)
+    wp = ops.conv3d_k3_prep(tw)
+    y = ops.conv3d_k3(tx, wp, cout)
+    want = C.conv3d_k3(x, wt)
+    assert y.cpu().numpy().tobytes() == want.tobytes(), "forward"
+    assert ops.conv3d_k3(tx, wp, cout, relu=True).cpu().numpy().tobytes() == np.maximum(want, 0).tobytes(), "relu"
+    if cout % 8 == 0:                                   # the adjoint needs Cin' = cout to be a multiple of 8
+        g = np.random.RandomState(3).randn(*want.shape).astype(np.float32)
+        wpt = ops.conv3d_k3_prep(tw, transpose=True)
+        gx = ops.conv3d_k3(torch.tensor(g, device=dev), wpt, cin)
+        assert gx.cpu().numpy().tobytes() == C.conv3d_k3(g, wt, transpose=True).tobytes(), "adjoint"
+
+
+@pytest.mark.gpu
+def test_hip_conv3d_autograd_vs_torch_at_cost_volume_scale():
+    """a slab of the DSGN-sized volume: 64 -> 32 channels, 8 x 96 x 312 voxels, against torch's conv3d on the GPU"""
+    from eval_driving_safety_amd import ops
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(0)
+    x = torch.randn((1, 64, 8, 96, 312), device=dev, generator=gen)
+    wt = torch.randn((32, 64, 3, 3, 3), device=dev, generator=gen) * 0.05
+    xr = x.clone().requires_grad_(True)
+    ref = F.conv3d(xr, wt, padding=1)
+    g = torch.randn(ref.shape, device=dev, generator=gen)
+    ref.backward(g)
+    xm = x.clone().requires_grad_(True)
+    y = ops.Conv3dK3.apply(xm, ops.conv3d_k3_prep(wt), ops.conv3d_k3_prep(wt, transpose=True), 32)
+    y.backward(g)
+    scale = float(ref.abs().max())
+    assert float((y - ref).abs().max()) <= 1e-4 * scale
+    assert float((xm.grad - xr.grad).abs().max()) <= 1e-4 * float(xr.grad.abs().max())

@@ -94,9 +94,31 @@ def pcie(dev):
     print(json.dumps(out))
 
 
+def conv(dev):
+    """the 3x3x3 convolutions applied to the DSGN-sized cost volume: MFMA kernel vs torch (MIOpen), TFLOP/s against the
+    157.3 TFLOP/s float32 matrix peak"""
+    import torch.nn.functional as F
+    D, H, W = 48, 96, 312
+    for cin, cout in ((64, 32), (32, 32), (32, 64)):
+        x = torch.randn((1, cin, D, H, W), device=dev)
+        wt = torch.randn((cout, cin, 3, 3, 3), device=dev) * 0.05
+        wp = ops.conv3d_k3_prep(wt)
+        flops = 2.0 * cin * cout * 27 * D * H * W
+        ms = timeit(lambda: ops.conv3d_k3(x, wp, cout), reps=10)
+        F.conv3d(x, wt, padding=1)                   # MIOpen solver search outside the timing
+        ms_t = timeit(lambda: F.conv3d(x, wt, padding=1), reps=10)
+        print(json.dumps(dict(kernel="conv3d_k3 %d->%d on [1,%d,%d,%d,%d]" % (cin, cout, cin, D, H, W), ms=round(ms, 3),
+                              TFLOPs=round(flops / ms / 1e9, 1), frac_of_157TF=round(flops / ms / 1e9 / 157.3, 3),
+                              torch_miopen_ms=round(ms_t, 3), speedup_vs_miopen=round(ms_t / ms, 2))))
+        del x, wt, wp
+
+
 def main():
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
+    if "--conv" in sys.argv:
+        conv(dev)
+        return
     if "--pcie" in sys.argv:
         pcie(dev)
         return
