@@ -32,7 +32,7 @@ constexpr int kNB = (kTD * kTH) / 4;  // rows per wave
 constexpr int kSX = kCK * (kTD + 2) * (kTH + 2) * kTWP;
 constexpr int kSW = 27 * kCK * 32;
 
-__global__ __launch_bounds__(256) void conv3d_k3_mfma(const float* __restrict__ x, const float* __restrict__ wp, float* __restrict__ y,
+__global__ __launch_bounds__(256) void conv3d_k3_mfma_generic(const float* __restrict__ x, const float* __restrict__ wp, float* __restrict__ y,
                                                       int Cin, int Cout, int cout_pad, int D, int H, int W, int tiles_w, int cblocks,
                                                       int relu) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -113,6 +113,162 @@ __global__ __launch_bounds__(256) void conv3d_k3_mfma(const float* __restrict__ 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// main kernel (W % 4 == 0): the same tiling with
+//   * 16-byte global loads and ds_write_b128 for the interior of the input tile (the LDS row is laid out so that the
+//     interior starts 16-byte aligned: [3 pad | left halo | 32 interior | right halo | 3 pad]), scalars only for
+//     the two halo columns;
+//   * the NEXT chunk's input tile and weights fetched into registers before the MFMA loop of the current chunk and
+//     written to LDS after it (global latency hidden behind ~27k cycles of matrix work per chunk);
+//   * the tap loop unrolled over kw so that LDS operand reads run ahead of the MFMAs that consume them.
+// ---------------------------------------------------------------------------------------------------------------
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr int kP = 40;                                       // padded LDS row, interior at column 4
+constexpr int kRows = kCK * (kTD + 2) * (kTH + 2);           // 320 tile rows per chunk
+constexpr int kXPass = kRows / 32;                           // 10 float4 per lane
+constexpr int kHaloPerLane = (2 * kRows + 255) / 256;        // 3
+constexpr int kWF4 = kSW / 4;                                // 1728 float4 of weights per chunk
+constexpr int kWPass = (kWF4 + 255) / 256;                   // 7
+constexpr int kSX2 = kRows * kP;
+
+struct Stage {
+  v4f xi[kXPass];
+  float xh[kHaloPerLane];
+  v4f wv[kWPass];
+};
+
+__device__ __forceinline__ void stage_fetch(Stage& st, const float* __restrict__ x, const float* __restrict__ wp, int tid, int b, int c0,
+                                            int Cin, int cout_pad, int cob, int D, int H, int W, int d0, int h0, int w0,
+                                            long long plane, long long vol) {
+  const int j = tid & 7, r0 = tid >> 3;
+#pragma unroll
+  for (int p = 0; p < kXPass; ++p) {
+    const int row = p * 32 + r0;
+    const int c = row / ((kTD + 2) * (kTH + 2));
+    const int rem = row - c * ((kTD + 2) * (kTH + 2));
+    const int dd = rem / (kTH + 2), hh = rem - dd * (kTH + 2);
+    const int gd = d0 + dd - 1, gh = h0 + hh - 1, gw = w0 + 4 * j;
+    v4f v = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+    if (gd >= 0 && gd < D && gh >= 0 && gh < H && gw < W)
+      v = *reinterpret_cast<const v4f*>(x + (static_cast<long long>(b) * Cin + c0 + c) * vol + gd * plane + static_cast<long long>(gh) * W + gw);
+    st.xi[p] = v;
+  }
+#pragma unroll
+  for (int p = 0; p < kHaloPerLane; ++p) {
+    const int s = p * 256 + tid;
+    float v = 0.0f;
+    if (s < 2 * kRows) {
+      const int row = s >> 1, side = s & 1;
+      const int c = row / ((kTD + 2) * (kTH + 2));
+      const int rem = row - c * ((kTD + 2) * (kTH + 2));
+      const int dd = rem / (kTH + 2), hh = rem - dd * (kTH + 2);
+      const int gd = d0 + dd - 1, gh = h0 + hh - 1, gw = side ? w0 + kTW : w0 - 1;
+      if (gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W)
+        v = x[(static_cast<long long>(b) * Cin + c0 + c) * vol + gd * plane + static_cast<long long>(gh) * W + gw];
+    }
+    st.xh[p] = v;
+  }
+#pragma unroll
+  for (int p = 0; p < kWPass; ++p) {
+    const int f = p * 256 + tid;
+    v4f v = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+    if (f < kWF4) {
+      const int n4 = f & 7, c = (f >> 3) & (kCK - 1), tap = f >> 6;
+      v = *reinterpret_cast<const v4f*>(wp + (static_cast<long long>(tap) * Cin + c0 + c) * cout_pad + cob * 32 + 4 * n4);
+    }
+    st.wv[p] = v;
+  }
+}
+
+__device__ __forceinline__ void stage_commit(const Stage& st, float* sx, float* sw, int tid) {
+  const int j = tid & 7, r0 = tid >> 3;
+#pragma unroll
+  for (int p = 0; p < kXPass; ++p) *reinterpret_cast<v4f*>(sx + (p * 32 + r0) * kP + 4 + 4 * j) = st.xi[p];
+#pragma unroll
+  for (int p = 0; p < kHaloPerLane; ++p) {
+    const int s = p * 256 + tid;
+    if (s < 2 * kRows) sx[(s >> 1) * kP + ((s & 1) ? 4 + kTW : 3)] = st.xh[p];
+  }
+#pragma unroll
+  for (int p = 0; p < kWPass; ++p) {
+    const int f = p * 256 + tid;
+    if (f < kWF4) *reinterpret_cast<v4f*>(sw + 4 * f) = st.wv[p];
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void conv3d_k3_mfma(const float* __restrict__ x, const float* __restrict__ wp, float* __restrict__ y,
+                                                      int Cin, int Cout, int cout_pad, int D, int H, int W, int tiles_w, int cblocks,
+                                                      int relu) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* sx = lds;
+  float* sw = lds + kSX2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l32 = lane & 31;
+  const int wt = blockIdx.x % tiles_w, ht = blockIdx.x / tiles_w;
+  const int w0 = wt * kTW, h0 = ht * kTH, d0 = blockIdx.y * kTD;
+  const int b = blockIdx.z / cblocks, cob = blockIdx.z - b * cblocks;
+  const long long plane = static_cast<long long>(H) * W;
+  const long long vol = plane * D;
+
+  f32x16 acc[kNB];
+#pragma unroll
+  for (int i = 0; i < kNB; ++i)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[i][v] = 0.0f;
+
+  Stage st;
+  stage_fetch(st, x, wp, tid, b, 0, Cin, cout_pad, cob, D, H, W, d0, h0, w0, plane, vol);
+  stage_commit(st, sx, sw, tid);
+  __syncthreads();
+  for (int c0 = 0; c0 < Cin; c0 += kCK) {
+    const bool more = c0 + kCK < Cin;
+    if (more) stage_fetch(st, x, wp, tid, b, c0 + kCK, Cin, cout_pad, cob, D, H, W, d0, h0, w0, plane, vol);
+#pragma unroll 1
+    for (int t9 = 0; t9 < 9; ++t9) {  // (kd, kh); kw unrolled below
+      const int kd = t9 / 3, kh = t9 - kd * 3;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int tap = t9 * 3 + kw;
+#pragma unroll
+        for (int kk = 0; kk < kCK / 2; ++kk) {
+          const int c = 2 * kk + half;
+          const float a = sw[(tap * kCK + c) * 32 + l32];
+#pragma unroll
+          for (int i = 0; i < kNB; ++i) {
+            const int row = wave * kNB + i;
+            const int td = row / kTH, th = row - td * kTH;
+            const float bv = sx[((c * (kTD + 2) + td + kd) * (kTH + 2) + th + kh) * kP + l32 + kw + 3];
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[i], 0, 0, 0);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (more) {
+      stage_commit(st, sx, sw, tid);
+      __syncthreads();
+    }
+  }
+  const int gw = w0 + l32;
+#pragma unroll
+  for (int i = 0; i < kNB; ++i) {
+    const int row = wave * kNB + i;
+    const int td = row / kTH, th = row - td * kTH;
+    const int gd = d0 + td, gh = h0 + th;
+    if (gd >= D || gh >= H || gw >= W) continue;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int co = cob * 32 + 8 * (v >> 2) + 4 * half + (v & 3);
+      if (co < Cout) {
+        float r = acc[i][v];
+        if (relu) r = r > 0.0f ? r : 0.0f;
+        y[(static_cast<long long>(b) * Cout + co) * vol + gd * plane + static_cast<long long>(gh) * W + gw] = r;
+      }
+    }
+  }
+}
+
 __global__ void conv3d_k3_prep(const float* __restrict__ w, float* __restrict__ wp, int cout, int cin, int transpose, int cin_p,
                                int cout_p, int cout_pad) {
   const long long total = 27LL * cin_p * cout_pad;
@@ -155,9 +311,16 @@ int adv_conv3d_k3_f32(const float* x, const float* w_prep, float* y, int b, int 
   const int cblocks = (cout + 31) / 32;
   if (tiles_d > 65535 || static_cast<long long>(b) * cblocks > 65535) return ADV_EINVAL;
   const dim3 grid(tiles_w * tiles_h, tiles_d, b * cblocks);
-  const size_t lds = static_cast<size_t>(kSX + kSW) * sizeof(float);
-  hipLaunchKernelGGL(conv3d_k3_mfma, grid, dim3(256), lds, static_cast<hipStream_t>(stream), x, w_prep, y, cin, cout, cblocks * 32, d, h, w,
-                     tiles_w, cblocks, relu);
+  const bool fast = (w % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_prep)) & 15) == 0;
+  if (fast) {
+    const size_t lds = static_cast<size_t>(kSX2 + kSW) * sizeof(float);
+    hipLaunchKernelGGL(conv3d_k3_mfma, grid, dim3(256), lds, static_cast<hipStream_t>(stream), x, w_prep, y, cin, cout, cblocks * 32, d, h,
+                       w, tiles_w, cblocks, relu);
+  } else {
+    const size_t lds = static_cast<size_t>(kSX + kSW) * sizeof(float);
+    hipLaunchKernelGGL(conv3d_k3_mfma_generic, grid, dim3(256), lds, static_cast<hipStream_t>(stream), x, w_prep, y, cin, cout,
+                       cblocks * 32, d, h, w, tiles_w, cblocks, relu);
+  }
   return adv_internal_finish_launch();
 }
 
