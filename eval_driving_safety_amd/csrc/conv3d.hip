@@ -6,7 +6,7 @@
 // column index is the lane - so the epilogue writes, per accumulator register, 32 consecutive floats of one output
 // channel (coalesced 128 B), and no transposition is ever needed.
 //
-// A workgroup (4 waves) owns an output tile of kTD x kTH rows of 32 voxels and 32 output channels; per chunk of kCK
+// A workgroup (4 waves) owns an output tile of kTD x kTH rows of 32 voxels and 32 output channels; per chunk of kCK = 4
 // input channels the input tile with its one-voxel halo and the 27 x kCK x 32 weights are staged in LDS, then every
 // wave runs 27 * kCK/2 MFMAs on each of its kNB rows.  LDS reads are conflict-free by construction: the 32 lanes of a
 // half-wave read 32 consecutive floats (the tap only shifts the start), the two halves read different channels.
@@ -23,7 +23,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kCK = 8;    // input channels per LDS stage
+constexpr int kCK = 4;    // input channels per LDS stage (both kernels: one accumulation order)
 constexpr int kTD = 2;    // tile depth
 constexpr int kTH = 8;    // tile height
 constexpr int kTW = 32;   // tile width = MFMA N
@@ -124,13 +124,16 @@ __global__ __launch_bounds__(256) void conv3d_k3_mfma_generic(const float* __res
 // ---------------------------------------------------------------------------------------------------------------
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+constexpr int kFC = 4;                                       // input channels per stage of the main kernel
 constexpr int kP = 40;                                       // padded LDS row, interior at column 4
-constexpr int kRows = kCK * (kTD + 2) * (kTH + 2);           // 320 tile rows per chunk
-constexpr int kXPass = kRows / 32;                           // 10 float4 per lane
-constexpr int kHaloPerLane = (2 * kRows + 255) / 256;        // 3
-constexpr int kWF4 = kSW / 4;                                // 1728 float4 of weights per chunk
-constexpr int kWPass = (kWF4 + 255) / 256;                   // 7
-constexpr int kSX2 = kRows * kP;
+constexpr int kRows = kFC * (kTD + 2) * (kTH + 2);           // 160 tile rows per stage
+constexpr int kXPass = kRows / 32;                           // 5 float4 per lane
+constexpr int kHaloPerLane = (2 * kRows + 255) / 256;        // 2
+constexpr int kFSW = 27 * kFC * 32;                          // weights per stage
+constexpr int kWF4 = kFSW / 4;                               // 864 float4
+constexpr int kWPass = (kWF4 + 255) / 256;                   // 4
+constexpr int kSX2 = kRows * kP;                             // one input buffer (floats)
+constexpr int kStageFloats = kSX2 + kFSW;                    // one LDS stage; two of them are resident (double buffer)
 
 struct Stage {
   v4f xi[kXPass];
@@ -174,7 +177,7 @@ __device__ __forceinline__ void stage_fetch(Stage& st, const float* __restrict__
     const int f = p * 256 + tid;
     v4f v = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
     if (f < kWF4) {
-      const int n4 = f & 7, c = (f >> 3) & (kCK - 1), tap = f >> 6;
+      const int n4 = f & 7, c = (f >> 3) & (kFC - 1), tap = f / (8 * kFC);
       v = *reinterpret_cast<const v4f*>(wp + (static_cast<long long>(tap) * Cin + c0 + c) * cout_pad + cob * 32 + 4 * n4);
     }
     st.wv[p] = v;
@@ -201,8 +204,6 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma(const float* __restrict
                                                       int Cin, int Cout, int cout_pad, int D, int H, int W, int tiles_w, int cblocks,
                                                       int relu) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* sx = lds;
-  float* sw = lds + kSX2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l32 = lane & 31;
   const int wt = blockIdx.x % tiles_w, ht = blockIdx.x / tiles_w;
@@ -217,13 +218,18 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma(const float* __restrict
 #pragma unroll
     for (int v = 0; v < 16; ++v) acc[i][v] = 0.0f;
 
+  // two LDS stages: while the waves run the MFMAs of stage `cur`, the next chunk travels global -> registers ->
+  // the other stage; ONE barrier per chunk
   Stage st;
   stage_fetch(st, x, wp, tid, b, 0, Cin, cout_pad, cob, D, H, W, d0, h0, w0, plane, vol);
-  stage_commit(st, sx, sw, tid);
+  stage_commit(st, lds, lds + kSX2, tid);
   __syncthreads();
-  for (int c0 = 0; c0 < Cin; c0 += kCK) {
-    const bool more = c0 + kCK < Cin;
-    if (more) stage_fetch(st, x, wp, tid, b, c0 + kCK, Cin, cout_pad, cob, D, H, W, d0, h0, w0, plane, vol);
+  int cur = 0;
+  for (int c0 = 0; c0 < Cin; c0 += kFC) {
+    const bool more = c0 + kFC < Cin;
+    const float* sxc = lds + cur * kStageFloats;
+    const float* swc = sxc + kSX2;
+    if (more) stage_fetch(st, x, wp, tid, b, c0 + kFC, Cin, cout_pad, cob, D, H, W, d0, h0, w0, plane, vol);
 #pragma unroll 1
     for (int t9 = 0; t9 < 9; ++t9) {  // (kd, kh); kw unrolled below
       const int kd = t9 / 3, kh = t9 - kd * 3;
@@ -231,24 +237,25 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma(const float* __restrict
       for (int kw = 0; kw < 3; ++kw) {
         const int tap = t9 * 3 + kw;
 #pragma unroll
-        for (int kk = 0; kk < kCK / 2; ++kk) {
+        for (int kk = 0; kk < kFC / 2; ++kk) {
           const int c = 2 * kk + half;
-          const float a = sw[(tap * kCK + c) * 32 + l32];
+          const float a = swc[(tap * kFC + c) * 32 + l32];
 #pragma unroll
           for (int i = 0; i < kNB; ++i) {
             const int row = wave * kNB + i;
             const int td = row / kTH, th = row - td * kTH;
-            const float bv = sx[((c * (kTD + 2) + td + kd) * (kTH + 2) + th + kh) * kP + l32 + kw + 3];
+            const float bv = sxc[((c * (kTD + 2) + td + kd) * (kTH + 2) + th + kh) * kP + l32 + kw + 3];
             acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[i], 0, 0, 0);
           }
         }
       }
     }
-    __syncthreads();
     if (more) {
-      stage_commit(st, sx, sw, tid);
-      __syncthreads();
+      float* nx = lds + (cur ^ 1) * kStageFloats;
+      stage_commit(st, nx, nx + kSX2, tid);
     }
+    __syncthreads();
+    cur ^= 1;
   }
   const int gw = w0 + l32;
 #pragma unroll
@@ -313,7 +320,7 @@ int adv_conv3d_k3_f32(const float* x, const float* w_prep, float* y, int b, int 
   const dim3 grid(tiles_w * tiles_h, tiles_d, b * cblocks);
   const bool fast = (w % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_prep)) & 15) == 0;
   if (fast) {
-    const size_t lds = static_cast<size_t>(kSX2 + kSW) * sizeof(float);
+    const size_t lds = 2 * static_cast<size_t>(kStageFloats) * sizeof(float);
     hipLaunchKernelGGL(conv3d_k3_mfma, grid, dim3(256), lds, static_cast<hipStream_t>(stream), x, w_prep, y, cin, cout, cblocks * 32, d, h,
                        w, tiles_w, cblocks, relu);
   } else {

@@ -191,7 +191,7 @@ void orc_disc_mask(float* mask, int h, int w, int cy, int cx, int r) {
 }
 
 /* 3x3x3 / stride 1 / zero-pad 1 convolution, float32, in the accumulation order of the MFMA kernel
- * (csrc/conv3d.hip): input channels in chunks of 8, inside a chunk tap-major, inside a tap channel pairs, every
+ * (csrc/conv3d.hip): input channels in chunks of 4, inside a chunk tap-major, inside a tap channel pairs, every
  * product folded with one fmaf (v_mfma_f32_32x32x2_f32 is a k-ordered fmaf chain: cdna_hip_programming.md, "FP32-input
  * MFMA").  transpose != 0 computes the adjoint (gradient w.r.t. the input): channels swapped, taps flipped.
  * The detector's convolutions are upstream code; this pins the kernel's arithmetic, not DSGN's. */
@@ -206,12 +206,12 @@ void orc_conv3d_k3(const float* x, const float* w, float* y, int B, int cin, int
         for (int h = 0; h < H; ++h)
           for (int ww = 0; ww < W; ++ww) {
             float acc = 0.0f;
-            for (int c0 = 0; c0 < ci_n; c0 += 8)
+            for (int c0 = 0; c0 < ci_n; c0 += 4)
               for (int tap = 0; tap < 27; ++tap) {
                 const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
                 const int gd = d + kd - 1, gh = h + kh - 1, gw = ww + kw - 1;
                 const int in = gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W;
-                for (int c = c0; c < c0 + 8 && c < ci_n; ++c) {
+                for (int c = c0; c < c0 + 4 && c < ci_n; ++c) {
                   const float wv = transpose ? w[((long)c * cin + co) * 27 + (26 - tap)] : w[((long)co * cin + c) * 27 + tap];
                   const float xv = in ? x[((long)b * ci_n + c) * vol + gd * plane + (long)gh * W + gw] : 0.0f;
                   acc = fmaf(wv, xv, acc);
