@@ -83,14 +83,15 @@ class ToyStereoAdapter:
 class PsvStereoAdapter:
     """A DSGN-SHAPED depth branch with seeded random weights, for end-to-end timing of the attack loop and as
     the autograd consumer of the K7 kernels: siamese 2D features at 1/4 resolution (32 channels) -> plane-sweep
-    concatenation volume [B,64,48,96,312] (HIP: ops.PsvBuild) -> three 3D convolutions (MIOpen through torch)
+    concatenation volume [B,64,48,96,312] (HIP: ops.PsvBuild) -> three 3D convolutions (the two wide ones on the
+    float32-MFMA kernel ops.Conv3dK3, the 32->1 one through torch)
     -> softmax over the 48 depth planes -> expected depth -> smooth-L1 against a sparse depth map, i.e. the
     ``disp_loss`` term of attack/DSGN/pgd_attack.py:310-319.  It is NOT DSGN (no 3DGV, no detection head, no
     trained weights): detection parity is unpinned by construction; it exists so that "20-step PGD through a
     plane-sweep network" can be measured end to end on this hardware."""
 
     def __init__(self, device, seed=0, channels=32, planes=48, min_depth=2.0, depth_step=0.8, fu=721.5377,
-                 baseline=0.54, downsample=4, mid=32):
+                 baseline=0.54, downsample=4, mid=32, mfma_conv=True):
         from . import ops
         self.ops = ops
         gen = torch.Generator().manual_seed(seed)
@@ -106,6 +107,13 @@ class PsvStereoAdapter:
         self.depth = (min_depth + depth_step * torch.arange(planes, dtype=torch.float32)).to(device)
         self.fu, self.baseline, self.downsample = fu, baseline, downsample
         self.device = device
+        # the two wide 3x3x3 convolutions run on libadvengine's float32-MFMA kernel (weights re-laid-out once, for the
+        # forward and for the adjoint); mfma_conv=False routes them through torch / MIOpen instead
+        self.mfma_conv = mfma_conv and (2 * channels) % 4 == 0 and mid % 4 == 0
+        if self.mfma_conv:
+            self.p1, self.p1t = ops.conv3d_k3_prep(self.c1), ops.conv3d_k3_prep(self.c1, transpose=True)
+            self.p2, self.p2t = ops.conv3d_k3_prep(self.c2), ops.conv3d_k3_prep(self.c2, transpose=True)
+            self.mid = mid
 
     def shifts(self, b):
         disp = self.fu * self.baseline / self.depth / self.downsample       # feature-pixel disparity per plane
@@ -119,8 +127,12 @@ class PsvStereoAdapter:
     def depth_pred(self, imgL, imgR):
         fl, fr = self.features(imgL), self.features(imgR)
         cost = self.ops.PsvBuild.apply(fl.contiguous(), fr.contiguous(), self.shifts(imgL.shape[0]))
-        v = F.relu(F.conv3d(cost, self.c1, padding=1))
-        v = F.relu(F.conv3d(v, self.c2, padding=1))
+        if self.mfma_conv:
+            v = F.relu(self.ops.Conv3dK3.apply(cost, self.p1, self.p1t, self.mid))
+            v = F.relu(self.ops.Conv3dK3.apply(v, self.p2, self.p2t, self.mid))
+        else:
+            v = F.relu(F.conv3d(cost, self.c1, padding=1))
+            v = F.relu(F.conv3d(v, self.c2, padding=1))
         v = F.conv3d(v, self.c3, padding=1).squeeze(1)                       # [B,D,h,w]
         prob = torch.softmax(v, dim=1)
         depth = (prob * self.depth.view(1, -1, 1, 1)).sum(dim=1, keepdim=True)
