@@ -227,7 +227,7 @@ def main():
             try:
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 import bench_end_to_end
-                out["end_to_end"] = bench_end_to_end.measure(pairs=1, iters=N_ITER, reps=2, warm_iters=2)
+                out["end_to_end"] = bench_end_to_end.measure(pairs=1, iters=N_ITER, reps=3)
             except Exception as e:
                 out["end_to_end"] = {"error": repr(e)}
     else:
