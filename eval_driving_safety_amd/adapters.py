@@ -113,6 +113,7 @@ class PsvStereoAdapter:
         if self.mfma_conv:
             self.p1, self.p1t = ops.conv3d_k3_prep(self.c1), ops.conv3d_k3_prep(self.c1, transpose=True)
             self.p2, self.p2t = ops.conv3d_k3_prep(self.c2), ops.conv3d_k3_prep(self.c2, transpose=True)
+            self.p3 = ops.conv3d_k3_prep(self.c3)     # 32 -> 1: forward on the kernel (padded to 32 rows), adjoint via torch
             self.mid = mid
 
     def shifts(self, b):
@@ -133,7 +134,10 @@ class PsvStereoAdapter:
         else:
             v = F.relu(F.conv3d(cost, self.c1, padding=1))
             v = F.relu(F.conv3d(v, self.c2, padding=1))
-        v = F.conv3d(v, self.c3, padding=1).squeeze(1)                       # [B,D,h,w]
+        if self.mfma_conv:
+            v = self.ops.Conv3dK3.apply(v, self.p3, None, 1, self.c3).squeeze(1)
+        else:
+            v = F.conv3d(v, self.c3, padding=1).squeeze(1)                   # [B,D,h,w]
         prob = torch.softmax(v, dim=1)
         depth = (prob * self.depth.view(1, -1, 1, 1)).sum(dim=1, keepdim=True)
         return F.interpolate(depth, scale_factor=self.downsample, mode="bilinear", align_corners=False).squeeze(1)

@@ -437,15 +437,20 @@ def conv3d_k3(x, w_prep, cout, relu=False):
 
 class Conv3dK3(torch.autograd.Function):
     """y = conv3d(x, weight); gradient flows to x only (the attacks differentiate w.r.t. the images, the detector's
-    weights are constants), through the same kernel with the transposed / flipped weights."""
+    weights are constants), through the same kernel with the transposed / flipped weights.  When the adjoint does not
+    fit the kernel (its input channel count = cout is not a multiple of 4, e.g. a 32->1 layer) pass ``w_prep_t=None`` and
+    the original ``weight``: the backward then uses torch's conv3d_input."""
 
     @staticmethod
-    def forward(ctx, x, w_prep, w_prep_t, cout):
-        ctx.save_for_backward(w_prep_t)
-        ctx.cin = x.shape[1]
+    def forward(ctx, x, w_prep, w_prep_t, cout, weight=None):
+        ctx.has_t = w_prep_t is not None
+        ctx.save_for_backward(w_prep_t if ctx.has_t else weight)
+        ctx.xshape = tuple(x.shape)
         return conv3d_k3(x.contiguous(), w_prep, cout)
 
     @staticmethod
     def backward(ctx, grad_y):
-        (w_prep_t,) = ctx.saved_tensors
-        return conv3d_k3(grad_y.contiguous(), w_prep_t, ctx.cin), None, None, None
+        (w,) = ctx.saved_tensors
+        if ctx.has_t:
+            return conv3d_k3(grad_y.contiguous(), w, ctx.xshape[1]), None, None, None, None
+        return torch.nn.grad.conv3d_input(ctx.xshape, w, grad_y, padding=1), None, None, None, None

@@ -70,3 +70,22 @@ def test_hip_conv3d_autograd_vs_torch_at_cost_volume_scale():
     scale = float(ref.abs().max())
     assert float((y - ref).abs().max()) <= 1e-4 * scale
     assert float((xm.grad - xr.grad).abs().max()) <= 1e-4 * float(xr.grad.abs().max())
+
+
+@pytest.mark.gpu
+def test_hip_conv3d_single_output_channel_with_torch_adjoint():
+    from eval_driving_safety_amd import ops
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(1)
+    x = torch.randn((1, 32, 6, 24, 40), device=dev, generator=gen)
+    wt = torch.randn((1, 32, 3, 3, 3), device=dev, generator=gen) * 0.05
+    xr = x.clone().requires_grad_(True)
+    ref = F.conv3d(xr, wt, padding=1)
+    g = torch.randn(ref.shape, device=dev, generator=gen)
+    ref.backward(g)
+    xm = x.clone().requires_grad_(True)
+    y = ops.Conv3dK3.apply(xm, ops.conv3d_k3_prep(wt), None, 1, wt)
+    y.backward(g)
+    assert y.cpu().numpy().tobytes() == C.conv3d_k3(x.cpu().numpy(), wt.cpu().numpy()).tobytes()
+    assert float((y - ref).abs().max()) <= 1e-4 * float(ref.detach().abs().max())
+    assert float((xm.grad - xr.grad).abs().max()) <= 1e-4 * float(xr.grad.abs().max())
