@@ -86,6 +86,6 @@ def test_hip_conv3d_single_output_channel_with_torch_adjoint():
     xm = x.clone().requires_grad_(True)
     y = ops.Conv3dK3.apply(xm, ops.conv3d_k3_prep(wt), None, 1, wt)
     y.backward(g)
-    assert y.cpu().numpy().tobytes() == C.conv3d_k3(x.cpu().numpy(), wt.cpu().numpy()).tobytes()
+    assert y.detach().cpu().numpy().tobytes() == C.conv3d_k3(x.cpu().numpy(), wt.cpu().numpy()).tobytes()
     assert float((y - ref).abs().max()) <= 1e-4 * float(ref.detach().abs().max())
     assert float((xm.grad - xr.grad).abs().max()) <= 1e-4 * float(xr.grad.abs().max())
