@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 #include "adv_internal.h"
 #include "advengine.h"
@@ -124,47 +125,57 @@ __global__ __launch_bounds__(256) void conv3d_k3_mfma_generic(const float* __res
 // ---------------------------------------------------------------------------------------------------------------
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-constexpr int kFC = 4;                                       // input channels per stage of the main kernel
-constexpr int kP = 40;                                       // padded LDS row, interior at column 4
-constexpr int kRows = kFC * (kTD + 2) * (kTH + 2);           // 160 tile rows per stage
-constexpr int kXPass = kRows / 32;                           // 5 float4 per lane
-constexpr int kHaloPerLane = (2 * kRows + 255) / 256;        // 2
-constexpr int kFSW = 27 * kFC * 32;                          // weights per stage
-constexpr int kWF4 = kFSW / 4;                               // 864 float4
-constexpr int kWPass = (kWF4 + 255) / 256;                   // 4
-constexpr int kSX2 = kRows * kP;                             // one input buffer (floats)
-constexpr int kStageFloats = kSX2 + kFSW;                    // one LDS stage; two of them are resident (double buffer)
+constexpr int kFC = 4;      // input channels per stage of the main kernel
+constexpr int kP = 40;      // padded LDS row, interior at column 4
+constexpr int kFSW = 27 * kFC * 32;  // weights per stage (floats)
+constexpr int kWF4 = kFSW / 4;       // 864 float4
 
-struct Stage {
-  v4f xi[kXPass];
-  float xh[kHaloPerLane];
-  v4f wv[kWPass];
+// compile-time geometry of the main kernel for a tile depth TD (waves = 2*TD, 4 rows of 32 voxels per wave)
+template <int TD>
+struct Geo {
+  static constexpr int kThreads = 128 * TD;
+  static constexpr int kRows = kFC * (TD + 2) * (kTH + 2);                          // tile rows per stage
+  static constexpr int kRowsPerPass = kThreads / 8;
+  static constexpr int kXPass = (kRows + kRowsPerPass - 1) / kRowsPerPass;          // float4 per lane
+  static constexpr int kHaloPerLane = (2 * kRows + kThreads - 1) / kThreads;
+  static constexpr int kWPass = (kWF4 + kThreads - 1) / kThreads;
+  static constexpr int kSX = kRows * kP;                                            // one input buffer (floats)
+  static constexpr int kStageFloats = kSX + kFSW;                                   // one LDS stage; two are resident
 };
 
-__device__ __forceinline__ void stage_fetch(Stage& st, const float* __restrict__ x, const float* __restrict__ wp, int tid, int b, int c0,
+template <int TD>
+struct Stage {
+  v4f xi[Geo<TD>::kXPass];
+  float xh[Geo<TD>::kHaloPerLane];
+  v4f wv[Geo<TD>::kWPass];
+};
+
+template <int TD>
+__device__ __forceinline__ void stage_fetch(Stage<TD>& st, const float* __restrict__ x, const float* __restrict__ wp, int tid, int b, int c0,
                                             int Cin, int cout_pad, int cob, int D, int H, int W, int d0, int h0, int w0,
                                             long long plane, long long vol) {
+  using G = Geo<TD>;
   const int j = tid & 7, r0 = tid >> 3;
 #pragma unroll
-  for (int p = 0; p < kXPass; ++p) {
-    const int row = p * 32 + r0;
-    const int c = row / ((kTD + 2) * (kTH + 2));
-    const int rem = row - c * ((kTD + 2) * (kTH + 2));
+  for (int p = 0; p < G::kXPass; ++p) {
+    const int row = p * G::kRowsPerPass + r0;
+    const int c = row / ((TD + 2) * (kTH + 2));
+    const int rem = row - c * ((TD + 2) * (kTH + 2));
     const int dd = rem / (kTH + 2), hh = rem - dd * (kTH + 2);
     const int gd = d0 + dd - 1, gh = h0 + hh - 1, gw = w0 + 4 * j;
     v4f v = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
-    if (gd >= 0 && gd < D && gh >= 0 && gh < H && gw < W)
+    if (row < G::kRows && gd >= 0 && gd < D && gh >= 0 && gh < H && gw < W)
       v = *reinterpret_cast<const v4f*>(x + (static_cast<long long>(b) * Cin + c0 + c) * vol + gd * plane + static_cast<long long>(gh) * W + gw);
     st.xi[p] = v;
   }
 #pragma unroll
-  for (int p = 0; p < kHaloPerLane; ++p) {
-    const int s = p * 256 + tid;
+  for (int p = 0; p < G::kHaloPerLane; ++p) {
+    const int s = p * G::kThreads + tid;
     float v = 0.0f;
-    if (s < 2 * kRows) {
+    if (s < 2 * G::kRows) {
       const int row = s >> 1, side = s & 1;
-      const int c = row / ((kTD + 2) * (kTH + 2));
-      const int rem = row - c * ((kTD + 2) * (kTH + 2));
+      const int c = row / ((TD + 2) * (kTH + 2));
+      const int rem = row - c * ((TD + 2) * (kTH + 2));
       const int dd = rem / (kTH + 2), hh = rem - dd * (kTH + 2);
       const int gd = d0 + dd - 1, gh = h0 + hh - 1, gw = side ? w0 + kTW : w0 - 1;
       if (gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W)
@@ -173,8 +184,8 @@ __device__ __forceinline__ void stage_fetch(Stage& st, const float* __restrict__
     st.xh[p] = v;
   }
 #pragma unroll
-  for (int p = 0; p < kWPass; ++p) {
-    const int f = p * 256 + tid;
+  for (int p = 0; p < G::kWPass; ++p) {
+    const int f = p * G::kThreads + tid;
     v4f v = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
     if (f < kWF4) {
       const int n4 = f & 7, c = (f >> 3) & (kFC - 1), tap = f / (8 * kFC);
@@ -184,30 +195,37 @@ __device__ __forceinline__ void stage_fetch(Stage& st, const float* __restrict__
   }
 }
 
-__device__ __forceinline__ void stage_commit(const Stage& st, float* sx, float* sw, int tid) {
+template <int TD>
+__device__ __forceinline__ void stage_commit(const Stage<TD>& st, float* sx, float* sw, int tid) {
+  using G = Geo<TD>;
   const int j = tid & 7, r0 = tid >> 3;
 #pragma unroll
-  for (int p = 0; p < kXPass; ++p) *reinterpret_cast<v4f*>(sx + (p * 32 + r0) * kP + 4 + 4 * j) = st.xi[p];
-#pragma unroll
-  for (int p = 0; p < kHaloPerLane; ++p) {
-    const int s = p * 256 + tid;
-    if (s < 2 * kRows) sx[(s >> 1) * kP + ((s & 1) ? 4 + kTW : 3)] = st.xh[p];
+  for (int p = 0; p < G::kXPass; ++p) {
+    const int row = p * G::kRowsPerPass + r0;
+    if (row < G::kRows) *reinterpret_cast<v4f*>(sx + row * kP + 4 + 4 * j) = st.xi[p];
   }
 #pragma unroll
-  for (int p = 0; p < kWPass; ++p) {
-    const int f = p * 256 + tid;
+  for (int p = 0; p < G::kHaloPerLane; ++p) {
+    const int s = p * G::kThreads + tid;
+    if (s < 2 * G::kRows) sx[(s >> 1) * kP + ((s & 1) ? 4 + kTW : 3)] = st.xh[p];
+  }
+#pragma unroll
+  for (int p = 0; p < G::kWPass; ++p) {
+    const int f = p * G::kThreads + tid;
     if (f < kWF4) *reinterpret_cast<v4f*>(sw + 4 * f) = st.wv[p];
   }
 }
 
-__global__ __launch_bounds__(256, 2) void conv3d_k3_mfma(const float* __restrict__ x, const float* __restrict__ wp, float* __restrict__ y,
-                                                      int Cin, int Cout, int cout_pad, int D, int H, int W, int tiles_w, int cblocks,
-                                                      int relu) {
+template <int TD>
+__global__ __launch_bounds__(128 * TD, (TD == 2) ? 2 : 2) void conv3d_k3_mfma(const float* __restrict__ x, const float* __restrict__ wp,
+                                                                              float* __restrict__ y, int Cin, int Cout, int cout_pad, int D,
+                                                                              int H, int W, int tiles_w, int cblocks, int relu) {
+  using G = Geo<TD>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l32 = lane & 31;
   const int wt = blockIdx.x % tiles_w, ht = blockIdx.x / tiles_w;
-  const int w0 = wt * kTW, h0 = ht * kTH, d0 = blockIdx.y * kTD;
+  const int w0 = wt * kTW, h0 = ht * kTH, d0 = blockIdx.y * TD;
   const int b = blockIdx.z / cblocks, cob = blockIdx.z - b * cblocks;
   const long long plane = static_cast<long long>(H) * W;
   const long long vol = plane * D;
@@ -220,18 +238,18 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma(const float* __restrict
 
   // two LDS stages: while the waves run the MFMAs of stage `cur`, the next chunk travels global -> registers ->
   // the other stage; ONE barrier per chunk
-  Stage st;
-  stage_fetch(st, x, wp, tid, b, 0, Cin, cout_pad, cob, D, H, W, d0, h0, w0, plane, vol);
-  stage_commit(st, lds, lds + kSX2, tid);
+  Stage<TD> st;
+  stage_fetch<TD>(st, x, wp, tid, b, 0, Cin, cout_pad, cob, D, H, W, d0, h0, w0, plane, vol);
+  stage_commit<TD>(st, lds, lds + G::kSX, tid);
   __syncthreads();
   int cur = 0;
   for (int c0 = 0; c0 < Cin; c0 += kFC) {
     const bool more = c0 + kFC < Cin;
-    const float* sxc = lds + cur * kStageFloats;
-    const float* swc = sxc + kSX2;
-    if (more) stage_fetch(st, x, wp, tid, b, c0 + kFC, Cin, cout_pad, cob, D, H, W, d0, h0, w0, plane, vol);
-#pragma unroll 1
-    for (int t9 = 0; t9 < 9; ++t9) {  // (kd, kh); kw unrolled below
+    const float* sxc = lds + cur * G::kStageFloats;
+    const float* swc = sxc + G::kSX;
+    if (more) stage_fetch<TD>(st, x, wp, tid, b, c0 + kFC, Cin, cout_pad, cob, D, H, W, d0, h0, w0, plane, vol);
+#pragma unroll
+    for (int t9 = 0; t9 < 9; ++t9) {  // (kd, kh); fully unrolled so that LDS operand reads run ahead of their MFMAs
       const int kd = t9 / 3, kh = t9 - kd * 3;
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
@@ -244,15 +262,15 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma(const float* __restrict
           for (int i = 0; i < kNB; ++i) {
             const int row = wave * kNB + i;
             const int td = row / kTH, th = row - td * kTH;
-            const float bv = sxc[((c * (kTD + 2) + td + kd) * (kTH + 2) + th + kh) * kP + l32 + kw + 3];
+            const float bv = sxc[((c * (TD + 2) + td + kd) * (kTH + 2) + th + kh) * kP + l32 + kw + 3];
             acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[i], 0, 0, 0);
           }
         }
       }
     }
     if (more) {
-      float* nx = lds + (cur ^ 1) * kStageFloats;
-      stage_commit(st, nx, nx + kSX2, tid);
+      float* nx = lds + (cur ^ 1) * G::kStageFloats;
+      stage_commit<TD>(st, nx, nx + G::kSX, tid);
     }
     __syncthreads();
     cur ^= 1;
@@ -314,18 +332,24 @@ int adv_conv3d_k3_f32(const float* x, const float* w_prep, float* y, int b, int 
                       adv_stream_t stream) {
   if (!x || !w_prep || !y || b < 1 || cin < 1 || cout < 1 || d < 1 || h < 1 || w < 1) return ADV_EINVAL;
   if (cin % kCK != 0) return ADV_EINVAL;
-  const int tiles_w = (w + kTW - 1) / kTW, tiles_h = (h + kTH - 1) / kTH, tiles_d = (d + kTD - 1) / kTD;
+  const int tiles_w = (w + kTW - 1) / kTW, tiles_h = (h + kTH - 1) / kTH;
   const int cblocks = (cout + 31) / 32;
-  if (tiles_d > 65535 || static_cast<long long>(b) * cblocks > 65535) return ADV_EINVAL;
-  const dim3 grid(tiles_w * tiles_h, tiles_d, b * cblocks);
+  if (static_cast<long long>(b) * cblocks > 65535) return ADV_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
   const bool fast = (w % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_prep)) & 15) == 0;
-  if (fast) {
-    const size_t lds = 2 * static_cast<size_t>(kStageFloats) * sizeof(float);
-    hipLaunchKernelGGL(conv3d_k3_mfma, grid, dim3(256), lds, static_cast<hipStream_t>(stream), x, w_prep, y, cin, cout, cblocks * 32, d, h,
-                       w, tiles_w, cblocks, relu);
+  const char* env = getenv("ADV_CONV_TD");  // tuning knob for the tile depth of the main kernel (2 or 4)
+  const int td = env ? atoi(env) : 2;
+  if (fast && td == 4) {
+    const dim3 grid(tiles_w * tiles_h, (d + 3) / 4, b * cblocks);
+    hipLaunchKernelGGL((conv3d_k3_mfma<4>), grid, dim3(Geo<4>::kThreads), 2 * static_cast<size_t>(Geo<4>::kStageFloats) * sizeof(float), st, x,
+                       w_prep, y, cin, cout, cblocks * 32, d, h, w, tiles_w, cblocks, relu);
+  } else if (fast) {
+    const dim3 grid(tiles_w * tiles_h, (d + 1) / 2, b * cblocks);
+    hipLaunchKernelGGL((conv3d_k3_mfma<2>), grid, dim3(Geo<2>::kThreads), 2 * static_cast<size_t>(Geo<2>::kStageFloats) * sizeof(float), st, x,
+                       w_prep, y, cin, cout, cblocks * 32, d, h, w, tiles_w, cblocks, relu);
   } else {
-    const size_t lds = static_cast<size_t>(kSX + kSW) * sizeof(float);
-    hipLaunchKernelGGL(conv3d_k3_mfma_generic, grid, dim3(256), lds, static_cast<hipStream_t>(stream), x, w_prep, y, cin, cout,
+    const dim3 grid(tiles_w * tiles_h, (d + kTD - 1) / kTD, b * cblocks);
+    hipLaunchKernelGGL(conv3d_k3_mfma_generic, grid, dim3(256), static_cast<size_t>(kSX + kSW) * sizeof(float), st, x, w_prep, y, cin, cout,
                        cblocks * 32, d, h, w, tiles_w, cblocks, relu);
   }
   return adv_internal_finish_launch();
