@@ -15,7 +15,6 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
-#include <cstdlib>
 
 #include "adv_internal.h"
 #include "advengine.h"
@@ -337,13 +336,8 @@ int adv_conv3d_k3_f32(const float* x, const float* w_prep, float* y, int b, int 
   if (static_cast<long long>(b) * cblocks > 65535) return ADV_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool fast = (w % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_prep)) & 15) == 0;
-  const char* env = getenv("ADV_CONV_TD");  // tuning knob for the tile depth of the main kernel (2 or 4)
-  const int td = env ? atoi(env) : 2;
-  if (fast && td == 4) {
-    const dim3 grid(tiles_w * tiles_h, (d + 3) / 4, b * cblocks);
-    hipLaunchKernelGGL((conv3d_k3_mfma<4>), grid, dim3(Geo<4>::kThreads), 2 * static_cast<size_t>(Geo<4>::kStageFloats) * sizeof(float), st, x,
-                       w_prep, y, cin, cout, cblocks * 32, d, h, w, tiles_w, cblocks, relu);
-  } else if (fast) {
+  // tile depth 2 (4 waves) and 4 (8 waves, one workgroup per CU) measured the same within 1-2 % (profiles/r01_conv3d_mfma.jsonl)
+  if (fast) {
     const dim3 grid(tiles_w * tiles_h, (d + 1) / 2, b * cblocks);
     hipLaunchKernelGGL((conv3d_k3_mfma<2>), grid, dim3(Geo<2>::kThreads), 2 * static_cast<size_t>(Geo<2>::kStageFloats) * sizeof(float), st, x,
                        w_prep, y, cin, cout, cblocks * 32, d, h, w, tiles_w, cblocks, relu);
