@@ -43,11 +43,29 @@ def measure(pairs=1, iters=20, reps=2, warm_iters=None, mfma_conv=True):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     first, last = float(atk.last_losses[0]), float(atk.last_losses[-1])
+    mfma = None
+    if mfma_conv:   # the dominant kernel of the end-to-end path, timed alone on the cost-volume shape: MFMA roofline
+        from eval_driving_safety_amd import ops
+        xv = torch.randn((pairs, 64, 48, 96, 312), device=dev)
+        for _ in range(2):
+            ops.conv3d_k3(xv, net.p1, 32)
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        for _ in range(10):
+            ops.conv3d_k3(xv, net.p1, 32)
+        c1.record()
+        torch.cuda.synchronize()
+        ms = c0.elapsed_time(c1) / 10
+        flops = 2.0 * 64 * 32 * 27 * pairs * 48 * 96 * 312
+        mfma = {"bound": "mfma", "kernel": "conv3d_k3_mfma<2> 64->32 on [%d,64,48,96,312]" % pairs, "achieved": flops / ms / 1e9,
+                "peak": 157.3, "unit": "TFLOP/s", "frac": flops / ms / 1e9 / 157.3, "avg_launch_ms": ms,
+                "note": "float32 matrix peak (MI355X_MICROARCH.md); PMC: MFMA pipe 73 % busy (profiles/r01_conv3d_mfma_pmc.json)"}
+        del xv
     return {
         "metric": "end-to-end stereo-pairs/s, %d-step PGD through a DSGN-shaped plane-sweep depth net (surrogate, random weights)" % iters,
         "value": pairs / dt, "unit": "stereo-pairs/s", "pairs": pairs, "iters": iters,
         "s_per_attack": dt, "detector_fwd_bwd_ms": model_ms,
-        "loss_first_iter": first, "loss_last_iter": last, "loss_rose": last > first,
+        "loss_first_iter": first, "loss_last_iter": last, "loss_rose": last > first, "roofline": mfma,
         "convs": "libadvengine float32-MFMA conv3d (64->32, 32->32) + torch for 32->1" if mfma_conv else "torch / MIOpen",
         "note": "NOT the headline metric and NOT DSGN: 2D features -> HIP plane-sweep volume [B,64,48,96,312] -> 3 x conv3d "
                 "-> soft-argmin depth -> smooth-L1; dtype f32; cost volume + PGD step by libadvengine.so"}
