@@ -180,3 +180,26 @@ def test_baseline_config1_fgsm_four_pairs(tmp_path):
     assert np.allclose(moved[inner], 8 / 255, atol=2e-7)
     assert sorted(os.listdir(str(tmp_path))) == ["dsgn_pgd_iters_0", "dsgn_pgd_iters_1"]
     assert len(os.listdir(os.path.join(str(tmp_path), "dsgn_pgd_iters_1", "image_2"))) == 4
+
+
+def test_surrogate_detector_gradients_agree_between_mfma_and_miopen_convs():
+    """the DSGN-shaped surrogate with its 3D convolutions on libadvengine's MFMA kernel vs on torch / MIOpen: same
+    loss and image gradient up to float32 summation order; and a 3-step attack raises the loss"""
+    import types
+    from eval_driving_safety_amd import adapters, attacks, data
+    dev = torch.device("cuda", 0)
+    batch = next(iter(data.SyntheticStereo(1, "dsgn", batch=1, seed=4)))
+    gen = torch.Generator().manual_seed(2)
+    gt = torch.rand((1, 384, 1248), generator=gen) * 38.4 + 2.0
+    gt = torch.where(torch.rand((1, 384, 1248), generator=gen) < 0.05, gt, torch.zeros(()))
+    extra = types.SimpleNamespace(disp_true=gt.to(dev))
+    x = torch.cat([batch.imgL, batch.imgR]).to(dev)
+    la, ga = adapters.PsvStereoAdapter(dev, seed=0, mfma_conv=True).loss_and_grad(x.clone(), extra)
+    lb, gb = adapters.PsvStereoAdapter(dev, seed=0, mfma_conv=False).loss_and_grad(x.clone(), extra)
+    assert abs(float(la) - float(lb)) <= 1e-4 * abs(float(lb))
+    assert float((ga - gb).abs().max()) <= 2e-3 * float(gb.abs().max())
+    assert float(ga[1].abs().sum()) > 0                      # the right eye receives gradient through the cost volume
+    batch.extra = extra
+    atk = attacks.PgdAttack("dsgn", 1 / 255, 0.03, 3, save=False, device=dev)
+    atk.run_batch(batch, adapters.PsvStereoAdapter(dev, seed=0))
+    assert float(atk.last_losses[-1]) > float(atk.last_losses[0])
