@@ -51,6 +51,8 @@ SIGNATURES = {
     "adv_normalize_f32": [_P, _P, _L, _I, _I, _SP, _P],
     "adv_pgd_step_f32": [_P, _P, _P, _P, _P, _L, _I, _I, _SP, _F, _F, _I, _I, _L, _L, _P],
     "adv_export_u8_f32": [_P, _P, _L, _I, _I, _SP, _I, _I, _L, _L, _P],
+    "adv_denormalize_index_f32": [_P, _P, _P, _P, _L, _I, _I, _SP, _P],
+    "adv_pgd_step_indexed_f32": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _SP, _F, _F, _I, _I, _L, _L, _P],
     "adv_disc_mask_f32": [_P, _I, _I, _I, _I, _I, _P],
     "adv_patch_paste_f32": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "adv_patch_paste_batch_f32": [_P, _P, _L, _I, _I, _I, _P, _I, _P],

@@ -201,6 +201,110 @@ __global__ __launch_bounds__(kWave) void pgd_step_vec4(const v4f* x, const v4f* 
 }
 
 // ------------------------------------------------------------------------------------------
+// K1 with the clean image held as an 8-bit INDEX (AFFINE spaces).  The clean image of an attack is re-read by
+// every one of its N steps, and it is not an arbitrary float image: it came from 8-bit pixels v through
+//     t = v / 255;  x0 = (t - shift) / scale;  clean = x0 * scale + shift            (all float32)
+// i.e. ToTensor, Normalize, then the script's denormalize (attack/DSGN/pgd_attack.py:196-200,297-298).  When
+// adv_denormalize_index_f32 has VERIFIED, element by element and bit by bit, that clean == F_c(v) for the index
+// v it stores, the step kernel reads the 1-byte index and recomputes the float (two divisions, far below the
+// VALU budget of an HBM-bound kernel) instead of reading 4 bytes: 14 instead of 17 bytes per element and
+// launch, bit-identical results.  If a single element failed the check (*ok == 0: resized or otherwise
+// processed inputs) the same launch falls back to the float32 clean buffer - the flag is read on the device, no
+// host round trip.
+// ------------------------------------------------------------------------------------------
+template <int DIR>
+__device__ __forceinline__ float affine_elem(float x, float sc, float sh);
+
+__device__ __forceinline__ float clean_from_index(uint32_t v, float sc, float sh) {
+  float t = static_cast<float>(v) / 255.0f;
+  t = (t - sh) / sc;
+  t = t * sc;
+  return t + sh;
+}
+
+template <int U8>
+__global__ __launch_bounds__(kWave) void pgd_step_vec4_idx(const v4f* x, const v4f* __restrict__ g, const v4f* __restrict__ cl,
+                                                           const uint32_t* __restrict__ idx, const int* __restrict__ ok, v4f* xo,
+                                                           long long n_img, int hw4, int w, SpaceK sp, float alpha, float eps, U8Dst u8) {
+  const bool use_idx = (*ok) != 0;  // uniform: a scalar load
+  const int stride = gridDim.x * kWave;
+  for (long long img = blockIdx.y; img < n_img; img += gridDim.y) {
+    const long long plane0 = img * 3LL * hw4;
+    for (int q0 = blockIdx.x * kWave + threadIdx.x; q0 < hw4; q0 += stride * kUnroll) {
+      v4f X[kUnroll][3], G[kUnroll][3], C[kUnroll][3];
+      uint32_t I[kUnroll][3];
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        const int q = q0 + u * stride;
+        if (q < hw4) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const long long i = plane0 + static_cast<long long>(c) * hw4 + q;
+            X[u][c] = ld_stream(x + i);
+            G[u][c] = ld_stream(g + i);
+            if (use_idx)
+              I[u][c] = __builtin_nontemporal_load(idx + i);
+            else
+              C[u][c] = ld_stream(cl + i);
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        const int q = q0 + u * stride;
+        if (q < hw4) {
+          v4f O[3];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            if (use_idx) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) C[u][c][j] = clean_from_index((I[u][c] >> (8 * j)) & 0xffu, sp.scale[c], sp.shift[c]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              O[c][j] = pgd_elem<ADV_SPACE_AFFINE>(X[u][c][j], G[u][c][j], C[u][c][j], sp.scale[c], sp.shift[c], sp.lo[c], sp.hi[c], alpha, eps);
+            st_stream(xo + plane0 + static_cast<long long>(c) * hw4 + q, O[c]);
+          }
+          store_u8_group<ADV_SPACE_AFFINE, U8>(O, img, q, w, sp, u8);
+        }
+      }
+    }
+  }
+}
+
+// a1 fused with the index build: clean = x*scale+shift; v = rint(clean*255) clamped to 0..255; *ok is cleared when
+// F_c(v) and clean differ in any bit (the caller sets *ok = 1 first).
+__global__ __launch_bounds__(kWave) void denormalize_index_vec4(const v4f* x, v4f* clean, uint32_t* idx, int* ok, long long n_img, int hw4,
+                                                                SpaceK sp) {
+  const int stride = gridDim.x * kWave;
+  bool bad = false;
+  for (long long img = blockIdx.y; img < n_img; img += gridDim.y) {
+    const long long plane0 = img * 3LL * hw4;
+    for (int q = blockIdx.x * kWave + threadIdx.x; q < hw4; q += stride) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const long long i = plane0 + static_cast<long long>(c) * hw4 + q;
+        const v4f X = ld_stream(x + i);
+        v4f O;
+        uint32_t word = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          O[j] = affine_elem<0>(X[j], sp.scale[c], sp.shift[c]);
+          float r = rintf(O[j] * 255.0f);
+          r = r < 0.0f ? 0.0f : (r > 255.0f ? 255.0f : r);  // NaN compares false twice and converts to 0 below
+          const uint32_t v = (r == r) ? static_cast<uint32_t>(r) : 0u;
+          bad |= __float_as_uint(clean_from_index(v, sp.scale[c], sp.shift[c])) != __float_as_uint(O[j]);
+          word |= v << (8 * j);
+        }
+        st_stream(clean + i, O);
+        __builtin_nontemporal_store(word, idx + i);
+      }
+    }
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) *ok = 0;
+}
+
+// ------------------------------------------------------------------------------------------
 // K1/K2 for planes that are NOT a whole number of 128-byte cache lines (Stereo R-CNN: 600 x 1987 floats
 // = 37 256.25 lines).  There the three channel planes of an image start at different offsets within a
 // line, so no common pixel tiling is line-aligned in all of them: the plain kernel's 1 KiB wave accesses
@@ -779,6 +883,61 @@ int adv_pgd_step_f32(const float* x, const float* grad, const float* clean, floa
   if (space->kind == ADV_SPACE_AFFINE)
     return launch_pgd<ADV_SPACE_AFFINE>(x, grad, clean, x_out, n, h, w, sp, alpha, eps, u8_out, crop_h, crop_w, u8_row_stride, u8_image_stride, st);
   return launch_pgd<ADV_SPACE_IDENTITY>(x, grad, clean, x_out, n, h, w, sp, alpha, eps, u8_out, crop_h, crop_w, u8_row_stride, u8_image_stride, st);
+}
+
+int adv_denormalize_index_f32(const float* x, float* clean_out, uint8_t* index_out, int32_t* ok_out, int64_t n, int h, int w,
+                              const adv_space_t* space, adv_stream_t stream) {
+  int rc = check_image_args(x, clean_out, n, h, w);
+  if (rc != ADV_OK) return rc;
+  rc = check_space(space);
+  if (rc != ADV_OK) return rc;
+  if (space->kind != ADV_SPACE_AFFINE || index_out == nullptr || ok_out == nullptr) return ADV_EINVAL;
+  const long long hw = static_cast<long long>(h) * w;
+  if (hw % 4 != 0 || !aligned(x, 16) || !aligned(clean_out, 16) || !aligned(index_out, 4) || !aligned(ok_out, 4)) return ADV_EALIGN;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ok_out), 1, 1, st) != hipSuccess) return ADV_ELAUNCH;
+  const int hw4 = static_cast<int>(hw / 4);
+  hipLaunchKernelGGL(denormalize_index_vec4, wave_grid(hw4, n, 1), dim3(kWave), 0, st, reinterpret_cast<const v4f*>(x),
+                     reinterpret_cast<v4f*>(clean_out), reinterpret_cast<uint32_t*>(index_out), reinterpret_cast<int*>(ok_out),
+                     static_cast<long long>(n), hw4, to_kernel_space(space));
+  return finish_launch();
+}
+
+int adv_pgd_step_indexed_f32(const float* x, const float* grad, const float* clean, const uint8_t* clean_index, const int32_t* clean_index_ok,
+                             float* x_out, uint8_t* u8_out, int64_t n, int h, int w, const adv_space_t* space, float alpha, float eps,
+                             int crop_h, int crop_w, int64_t u8_row_stride, int64_t u8_image_stride, adv_stream_t stream) {
+  int rc = check_image_args(x, x_out, n, h, w);
+  if (rc != ADV_OK) return rc;
+  rc = check_image_args(grad, clean, n, h, w);
+  if (rc != ADV_OK) return rc;
+  rc = check_space(space);
+  if (rc != ADV_OK) return rc;
+  if (!(eps >= 0.0f) || space->kind != ADV_SPACE_AFFINE || clean_index == nullptr || clean_index_ok == nullptr) return ADV_EINVAL;
+  const long long hw = static_cast<long long>(h) * w;
+  if (hw % 4 != 0 || !aligned(x, 16) || !aligned(grad, 16) || !aligned(clean, 16) || !aligned(x_out, 16) || !aligned(clean_index, 4) ||
+      !aligned(clean_index_ok, 4))
+    return ADV_EALIGN;
+  U8Plan plan;
+  rc = plan_u8(u8_out, h, w, crop_h, crop_w, u8_row_stride, u8_image_stride, true, &plan);
+  if (rc != ADV_OK) return rc;
+  const SpaceK sp = to_kernel_space(space);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int hw4 = static_cast<int>(hw / 4);
+  const dim3 grid = wave_grid(hw4, n, kUnroll);
+  const v4f* x4 = reinterpret_cast<const v4f*>(x);
+  const v4f* g4 = reinterpret_cast<const v4f*>(grad);
+  const v4f* c4 = reinterpret_cast<const v4f*>(clean);
+  const uint32_t* i4 = reinterpret_cast<const uint32_t*>(clean_index);
+  const int* okp = reinterpret_cast<const int*>(clean_index_ok);
+  v4f* o4 = reinterpret_cast<v4f*>(x_out);
+  const long long nn = n;
+  if (plan.mode == U8_NONE)
+    hipLaunchKernelGGL((pgd_step_vec4_idx<U8_NONE>), grid, dim3(kWave), 0, st, x4, g4, c4, i4, okp, o4, nn, hw4, w, sp, alpha, eps, plan.dst);
+  else if (plan.mode == U8_ROWS_DWORD)
+    hipLaunchKernelGGL((pgd_step_vec4_idx<U8_ROWS_DWORD>), grid, dim3(kWave), 0, st, x4, g4, c4, i4, okp, o4, nn, hw4, w, sp, alpha, eps, plan.dst);
+  else
+    hipLaunchKernelGGL((pgd_step_vec4_idx<U8_BYTES>), grid, dim3(kWave), 0, st, x4, g4, c4, i4, okp, o4, nn, hw4, w, sp, alpha, eps, plan.dst);
+  return finish_launch();
 }
 
 int adv_export_u8_f32(const float* x, uint8_t* u8_out, int64_t n, int h, int w, const adv_space_t* space, int crop_h,

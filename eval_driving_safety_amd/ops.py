@@ -127,6 +127,35 @@ def normalize(x, space, out=None):
     return out
 
 
+class CleanIndex:
+    """The clean image of an attack held as one byte per element (see ``denormalize_indexed``): ``index`` uint8
+    [N,3,H,W], ``ok`` int32 [1] on the device (1 = every element verified; read by the kernels, never by the host)."""
+
+    def __init__(self, index, ok):
+        self.index, self.ok = index, ok
+
+
+def can_index_clean(x, space):
+    xi = x if x.dim() == 4 else x.unsqueeze(0)
+    return space.affine and (xi.shape[2] * xi.shape[3]) % 4 == 0 and x.data_ptr() % 16 == 0
+
+
+def denormalize_indexed(x, space, out=None):
+    """``denormalize`` plus the 8-bit index of the result: returns (clean, CleanIndex).  Pass the CleanIndex to
+    ``pgd_step(..., clean_index=...)``: every step then reads 1 byte instead of 4 for the clean image whenever the
+    device-side check succeeded (images that came from 8-bit pixels via ToTensor + Normalize), with identical results."""
+    xi = _img(x, "x")
+    out = torch.empty_like(x) if out is None else out
+    oi = _img(out, "out")
+    _same(xi, oi, "x", "out")
+    n, _, h, w = xi.shape
+    index = torch.empty((n, 3, h, w), dtype=torch.uint8, device=x.device)
+    ok = torch.empty((1,), dtype=torch.int32, device=x.device)
+    with _on(x):
+        _lib.call("adv_denormalize_index_f32", _ptr(xi), _ptr(oi), _ptr(index), _ptr(ok), n, h, w, space.ref(), _stream(x))
+    return out, CleanIndex(index, ok)
+
+
 def alloc_u8(n, crop_h, w, device):
     """Export buffer with whole (uncropped-width) rows: [n, crop_h, w, 3] uint8."""
     return torch.empty((n, crop_h, w, 3), dtype=torch.uint8, device=device)
@@ -153,7 +182,7 @@ def prefers_out_of_place(h, w):
     return (h * w) % 4 == 0 and ((h * w) // 4) % 8 != 0
 
 
-def pgd_step(x, grad, clean, space, alpha, eps, out=None, u8_out=None, crop=None):
+def pgd_step(x, grad, clean, space, alpha, eps, out=None, u8_out=None, crop=None, clean_index=None):
     """One PGD/FGSM step for a batch of images in one pass over memory.
 
     DSGN (affine space):  attack/DSGN/pgd_attack.py:339-354 - x is the normalised image the
@@ -161,6 +190,7 @@ def pgd_step(x, grad, clean, space, alpha, eps, out=None, u8_out=None, crop=None
     Stereo R-CNN (identity space): attack/Stereo-RCNN/pgd_attack.py:177-217 - eps is already
     ``255 * args.eps`` (:57).
 
+    ``clean_index`` (from ``denormalize_indexed``) lets the kernel read the clean image as bytes - same results.
     ``out`` (default: new tensor; pass ``x`` for in place) receives the next iterate;
     ``u8_out`` (optional, ``alloc_u8``) the 8-bit HWC image the reference would write to PNG
     for it (DSGN tensor2im, pgd_attack.py:157-179; Stereo R-CNN :233-237), rows/cols beyond
@@ -175,8 +205,14 @@ def pgd_step(x, grad, clean, space, alpha, eps, out=None, u8_out=None, crop=None
     n, _, h, w = xi.shape
     u8p, crop_h, crop_w, rs, is_ = _u8_args(u8_out, n, h, w, crop)
     with _on(x):
-        _lib.call("adv_pgd_step_f32", _ptr(xi), _ptr(gi), _ptr(ci), _ptr(oi), u8p, n, h, w, space.ref(),
-                  float(alpha), float(eps), crop_h, crop_w, rs, is_, _stream(x))
+        if clean_index is not None:
+            if tuple(clean_index.index.shape) != tuple(xi.shape) or clean_index.index.dtype != torch.uint8:
+                raise ValueError("clean_index does not belong to this batch")
+            _lib.call("adv_pgd_step_indexed_f32", _ptr(xi), _ptr(gi), _ptr(ci), _ptr(clean_index.index), _ptr(clean_index.ok), _ptr(oi), u8p,
+                      n, h, w, space.ref(), float(alpha), float(eps), crop_h, crop_w, rs, is_, _stream(x))
+        else:
+            _lib.call("adv_pgd_step_f32", _ptr(xi), _ptr(gi), _ptr(ci), _ptr(oi), u8p, n, h, w, space.ref(),
+                      float(alpha), float(eps), crop_h, crop_w, rs, is_, _stream(x))
     return out
 
 

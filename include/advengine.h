@@ -98,6 +98,24 @@ ADV_API int adv_pgd_step_f32(const float* x, const float* grad, const float* cle
                      float alpha, float eps, int crop_h, int crop_w, int64_t u8_row_stride,
                      int64_t u8_image_stride, adv_stream_t stream);
 
+/* a1 + index: denormalize as above AND try to hold the clean image as one byte per element.  A clean image is
+ *     re-read by every PGD step, and it normally stems from 8-bit pixels v through
+ *         t = v/255;  x0 = (t - shift)/scale;  clean = x0*scale + shift        (float32: ToTensor, Normalize, denormalize)
+ *     index_out [n,3,h,w] uint8 receives v = rint(clean*255); *ok_out (DEVICE int32) is set to 1 and cleared if for any
+ *     element that chain applied to v does not reproduce clean BIT FOR BIT.  Requires h*w % 4 == 0 and 16-byte
+ *     aligned images.  AFFINE spaces only. */
+ADV_API int adv_denormalize_index_f32(const float* x, float* clean_out, uint8_t* index_out, int32_t* ok_out, int64_t n,
+                                      int h, int w, const adv_space_t* space, adv_stream_t stream);
+
+/* a3 with the indexed clean image: identical results to adv_pgd_step_f32.  When *clean_index_ok != 0 (read on the
+ *     device, no host round trip) the kernel reads the 1-byte index and recomputes clean with the chain above instead
+ *     of reading the float32 `clean` (14 instead of 17 bytes per element); otherwise it reads `clean` as usual.
+ *     Same requirements as adv_denormalize_index_f32. */
+ADV_API int adv_pgd_step_indexed_f32(const float* x, const float* grad, const float* clean, const uint8_t* clean_index,
+                                     const int32_t* clean_index_ok, float* x_out, uint8_t* u8_out, int64_t n, int h,
+                                     int w, const adv_space_t* space, float alpha, float eps, int crop_h, int crop_w,
+                                     int64_t u8_row_stride, int64_t u8_image_stride, adv_stream_t stream);
+
 /* a5  the 8-bit export alone (iterate 0 = the clean image, pgd_attack.py:279-294). */
 ADV_API int adv_export_u8_f32(const float* x, uint8_t* u8_out, int64_t n, int h, int w,
                       const adv_space_t* space, int crop_h, int crop_w, int64_t u8_row_stride,

@@ -478,3 +478,51 @@ def test_patch_windows_touching_the_image_border(ops):
     for cy, cx in ((r - 1, r), (r, w - r), (h - r, r)):
         with pytest.raises(AdvEngineError):
             ops.patch_paste(dev(img), dev(patch), cy, cx, r)
+
+
+@pytest.mark.parametrize("name", DSGN_PGD + ["fullsize"])
+def test_indexed_clean_image_path(name, golden, golden_index, ops):
+    """the clean image held as one byte per element: verified on the device, results unchanged"""
+    sp = ops.Space.dsgn()
+    if name == "fullsize":
+        m = golden_index["cases"]["dsgn_pgd_fullsize"]
+        x = dev(synth.dsgn_normalised(m["seed"], m["h"], m["w"]))
+        clean, ci = ops.denormalize_indexed(x, sp)
+        assert int(ci.ok.item()) == 1, "8-bit derived input must verify"
+        u8 = ops.alloc_u8(1, m["crop_h"], m["w"], x.device)
+        for k in range(m["n_iter"]):
+            g = dev(synth.gradient(1000 * m["seed"] + 2 * k, tuple(x.shape), m["grad_scale"]))
+            ops.pgd_step(x, g, clean, sp, m["alpha"], m["eps"], out=x, u8_out=u8, crop=(m["crop_h"], m["crop_w"]), clean_index=ci)
+            assert sha(host(x)) == m["digests"]["xL_%d" % (k + 1)]
+            assert sha(host(u8)[0, :, :m["crop_w"]]) == m["digests"]["u8L_%d" % (k + 1)]
+        return
+    g, m = golden(name), golden_index["cases"][name]
+    if (m["h"] * m["w"]) % 4:
+        with pytest.raises(Exception):
+            ops.denormalize_indexed(dev(g["x0L"]), sp)
+        return
+    x = dev(g["x0L"])
+    clean, ci = ops.denormalize_indexed(x, sp)
+    same_bits(host(clean), g["cleanL"], "clean")
+    assert int(ci.ok.item()) == 1
+    same_bits(host(ci.index).astype(np.float32), np.rint(g["cleanL"] * np.float32(255)), "index = round(clean*255)")
+    for k in range(m["n_iter"]):
+        x = ops.pgd_step(x, dev(g["gL_%d" % k]), clean, sp, m["alpha"], m["eps"], clean_index=ci)
+        same_bits(host(x), g["xL_%d" % (k + 1)], "%s xL_%d (indexed)" % (name, k + 1))
+
+
+def test_indexed_clean_falls_back_when_the_image_is_not_8bit_derived(ops):
+    sp = ops.Space.dsgn()
+    rs = np.random.RandomState(3)
+    x = rs.randn(2, 3, 16, 24).astype(np.float32)            # arbitrary floats: no 8-bit origin
+    g = synth.gradient(4, x.shape)
+    clean, ci = ops.denormalize_indexed(dev(x), sp)
+    assert int(ci.ok.item()) == 0
+    same_bits(host(clean), O.denormalize(x), "clean")
+    got = ops.pgd_step(dev(x), dev(g), clean, sp, 1 / 255, 0.03, clean_index=ci)
+    same_bits(host(got), O.pgd_step_norm01(x, g, O.denormalize(x), 1 / 255, 0.03), "fallback path")
+    # one wrong element out of a verified image is enough to clear the flag
+    y = synth.dsgn_normalised(7, 16, 24)
+    y[0, 1, 5, 7] = np.nextafter(y[0, 1, 5, 7], np.float32(10))
+    _, ci = ops.denormalize_indexed(dev(y), sp)
+    assert int(ci.ok.item()) == 0
