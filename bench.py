@@ -45,6 +45,8 @@ def parse():
                     help="dsgn = BASELINE configs[1] (the headline, default); srcnn = configs[2]: 20-step PGD in the Stereo R-CNN "
                          "pixel space on 600x1987 pairs (alpha 1.0, eps 0.03*255) - a parity-test configuration, timed on request")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-clean-index", action="store_true",
+                    help="read the clean image as float32 in every step instead of as the verified 8-bit index (dsgn workload)")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the (separately reported) surrogate-detector attack")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs in the CPU-baseline sample (0 = auto)")
     return ap.parse_args()
@@ -153,18 +155,24 @@ def main():
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
 
+    use_index = (not srcnn) and (not args.no_clean_index)
+    cidx = [None]
+
     def step(k=None):
         if srcnn:
             clean.copy_(x0)                   # explicit clone of the clean pair (pgd_attack.py:122-123, quirk Q6)
+        elif use_index:                       # denormalize + verified 8-bit index of the clean image (read as bytes by the 20 steps)
+            _, cidx[0] = ops.denormalize_indexed(x0, sp, out=clean, reuse=cidx[0])
         else:
             ops.denormalize(x0, sp, out=clean)
         ops.export_u8(x0, sp, (CROP_H, CROP_W), out=u8)
         if k is not None:
             ev0[k].record()
-        ops.pgd_step(x0, grad, clean, sp, ALPHA, EPS, out=x, u8_out=u8, crop=(CROP_H, CROP_W))
+        kw = {"clean_index": cidx[0]} if use_index else {}
+        ops.pgd_step(x0, grad, clean, sp, ALPHA, EPS, out=x, u8_out=u8, crop=(CROP_H, CROP_W), **kw)
         cur, nxt = x, (spare if srcnn else x)
         for _ in range(N_ITER - 1):
-            ops.pgd_step(cur, grad, clean, sp, ALPHA, EPS, out=nxt, u8_out=u8, crop=(CROP_H, CROP_W))
+            ops.pgd_step(cur, grad, clean, sp, ALPHA, EPS, out=nxt, u8_out=u8, crop=(CROP_H, CROP_W), **kw)
             cur, nxt = nxt, cur
         if k is not None:
             ev1[k].record()
@@ -213,7 +221,8 @@ def main():
                                     "resident synthetic buffer, 8-bit HWC export of all 21 iterates" % args.pairs),
                        "pairs_per_gpu": args.pairs, "pgd_iters": N_ITER, "eps": EPS, "alpha": ALPHA,
                        "parallelism": "image-sharded x%d, no collective" % world},
-            "roofline": {"bound": "hbm", "kernel": "pgd_step_shifted<IDENTITY,U8_BYTES>" if srcnn else "pgd_step_vec4<AFFINE,U8_ROWS_DWORD>",
+            "roofline": {"bound": "hbm", "kernel": "pgd_step_shifted<IDENTITY,U8_BYTES>" if srcnn else
+                         ("pgd_step_vec4_idx<U8_ROWS_DWORD>" if use_index else "pgd_step_vec4<AFFINE,U8_ROWS_DWORD>"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},

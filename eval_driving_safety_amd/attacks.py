@@ -115,7 +115,13 @@ class PgdAttack:
         cols = w if batch.sizes is None else max(s[0] for s in batch.sizes)
         exporter = pixelio.AsyncExporter(self.writer, lambda: ops.alloc_u8(n, rows, w, dev), dev) if self.save else None
         # clean image in pixel space: pgd_attack.py:297-298 (DSGN) / :122-123 (Stereo R-CNN)
-        clean = ops.denormalize(x, sp) if sp.affine else x.clone()
+        # (for 8-bit derived inputs the clean image is also kept as one byte per element: the N steps then read it
+        #  as bytes; verified on the device, results identical - ops.denormalize_indexed)
+        cidx = None
+        if sp.affine and getattr(ops, "can_index_clean", lambda *_: False)(x, sp):
+            clean, cidx = ops.denormalize_indexed(x, sp)
+        else:
+            clean = ops.denormalize(x, sp) if sp.affine else x.clone()
         if self._wanted(0):                          # iterate 0 = the un-attacked pair, :279-294
             ops.export_u8(x, sp, (rows, cols), out=exporter.next_buffer())
             exporter.submit(self._fan_out(0, batch))
@@ -131,7 +137,8 @@ class PgdAttack:
             nxt = spare if pingpong else x
             ops.pgd_step(x, grad.contiguous(), clean, sp, self.alpha, self.eps, out=nxt,
                          u8_out=exporter.next_buffer() if want else None,
-                         crop=(rows, cols) if want else None)            # :339-354 (+ :357-374 export)
+                         crop=(rows, cols) if want else None,            # :339-354 (+ :357-374 export)
+                         **({"clean_index": cidx} if cidx is not None else {}))
             if pingpong:
                 x, spare = nxt, x
             if want:

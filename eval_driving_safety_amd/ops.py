@@ -140,7 +140,7 @@ def can_index_clean(x, space):
     return space.affine and (xi.shape[2] * xi.shape[3]) % 4 == 0 and x.data_ptr() % 16 == 0
 
 
-def denormalize_indexed(x, space, out=None):
+def denormalize_indexed(x, space, out=None, reuse=None):
     """``denormalize`` plus the 8-bit index of the result: returns (clean, CleanIndex).  Pass the CleanIndex to
     ``pgd_step(..., clean_index=...)``: every step then reads 1 byte instead of 4 for the clean image whenever the
     device-side check succeeded (images that came from 8-bit pixels via ToTensor + Normalize), with identical results."""
@@ -149,8 +149,11 @@ def denormalize_indexed(x, space, out=None):
     oi = _img(out, "out")
     _same(xi, oi, "x", "out")
     n, _, h, w = xi.shape
-    index = torch.empty((n, 3, h, w), dtype=torch.uint8, device=x.device)
-    ok = torch.empty((1,), dtype=torch.int32, device=x.device)
+    if reuse is not None and tuple(reuse.index.shape) == (n, 3, h, w):
+        index, ok = reuse.index, reuse.ok             # a CleanIndex of the same shape: overwrite its buffers
+    else:
+        index = torch.empty((n, 3, h, w), dtype=torch.uint8, device=x.device)
+        ok = torch.empty((1,), dtype=torch.int32, device=x.device)
     with _on(x):
         _lib.call("adv_denormalize_index_f32", _ptr(xi), _ptr(oi), _ptr(index), _ptr(ok), n, h, w, space.ref(), _stream(x))
     return out, CleanIndex(index, ok)
