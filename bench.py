@@ -145,7 +145,9 @@ def main():
     if srcnn:
         x0 -= torch.tensor([102.9801, 115.9465, 122.7717], device=dev).view(1, 3, 1, 1)   # BGR minus PIXEL_MEANS
     else:
-        x0.div_(255.0)
+        # ToTensor's v/255 as a TRUE division (what the CPU loader computes); torch-on-GPU would turn a division by a
+        # Python scalar into a multiplication by the reciprocal, which is not the same float32 function
+        x0.div_(torch.full((), 255.0, device=dev))
         ops.normalize(x0, sp, out=x0)         # what the DSGN loader hands over: normalised float32
     grad = torch.randn((n_img, 3, H, W), device=dev, generator=gen)
     clean = torch.empty_like(x0)
@@ -202,6 +204,7 @@ def main():
     alg_bytes = n_img * (16 * elems + 3 * CROP_H * CROP_W)     # 16 B/elt + the 8-bit export
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
 
+    index_verified = bool(int(cidx[0].ok.item())) if use_index and cidx[0] is not None else None
     if rank == 0:
         traffic, traffic_src = (None, None) if srcnn else pmc_traffic(args.pairs)
         out = {
@@ -225,7 +228,8 @@ def main():
                          ("pgd_step_vec4_idx<U8_ROWS_DWORD>" if use_index else "pgd_step_vec4<AFFINE,U8_ROWS_DWORD>"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src,
-                         "avg_launch_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
+                         "avg_launch_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                         "clean_image_read_as": ("uint8 index (verified on the device)" if index_verified else "float32")},
         }
         if world == 1 and not args.no_cpu_baseline and not srcnn:
             out["cpu_baseline"] = cpu_baseline(args.cpu_pairs)
