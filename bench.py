@@ -9,10 +9,11 @@ perturbation path, on N MI355X GPUs of one node.
 One STEP = one complete 20-iteration L-inf PGD attack (eps 0.03, alpha 1/255, the reference's
 script default) of a resident batch of stereo pairs, exactly the per-image work of the reference's
 loop body around the detector call (attack/DSGN/pgd_attack.py:279-374):
-    clean = denormalize(x0)                         (:297-298)  adv_denormalize_f32
+    clean = denormalize(x0)                         (:297-298)  adv_denormalize_index_f32 (also emits the clean image as a
+                                                                device-verified 8-bit index; --no-clean-index: adv_denormalize_f32)
     export iterate 0 as 8-bit HWC                   (:279-294)  adv_export_u8_f32
-    20 x { step + project + re-normalise + export } (:339-374)  adv_pgd_step_f32 (one launch, both eyes
-                                                                of every pair of the batch)
+    20 x { step + project + re-normalise + export } (:339-374)  adv_pgd_step_indexed_f32 / adv_pgd_step_f32 (one launch,
+                                                                both eyes of every pair of the batch)
 The detector's forward/backward (upstream DSGN, not part of the reference tree) is the caller's: its
 gradient is a resident synthetic buffer here, so `value` is the throughput of the perturbation engine
 with inputs in HBM, not of an end-to-end attack.  PNG encoding / disk are outside the timed region.
