@@ -32,6 +32,21 @@ def test_library_exports_every_declared_symbol():
     assert lib.adv_strerror(-22) == b"invalid argument"
 
 
+def test_header_is_valid_c99(tmp_path):
+    """the boundary is a C ABI: the header must compile as plain C, and a C program must link against the library"""
+    import subprocess
+    src = tmp_path / "t.c"
+    src.write_text('#include "advengine.h"\n#include <stdio.h>\nint main(void) { adv_space_t s; adv_space_dsgn(&s); '
+                   'printf("%d %d %.3f\\n", adv_abi_version(), s.kind, s.scale[0]); return adv_pgd_step_f32(0, 0, 0, 0, 0, 1, 2, 2, &s, '
+                   '0.1f, 0.1f, 2, 2, 0, 0, 0) == ADV_EINVAL ? 0 : 1; }\n')
+    exe = tmp_path / "t"
+    lib_dir = os.path.join(ROOT, "eval_driving_safety_amd")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                    "-L", lib_dir, "-l:libadvengine.so", "-Wl,-rpath," + lib_dir], check=True)
+    out = subprocess.run([str(exe)], stdout=subprocess.PIPE, text=True)
+    assert out.returncode == 0 and out.stdout.split() == ["1", "0", "0.229"]
+
+
 def test_space_constants_are_the_reference_constants():
     lib = _lib.load()
     s = _lib.AdvSpace()
