@@ -9,11 +9,14 @@ perturbation path, on N MI355X GPUs of one node.
 One STEP = one complete 20-iteration L-inf PGD attack (eps 0.03, alpha 1/255, the reference's
 script default) of a resident batch of stereo pairs, exactly the per-image work of the reference's
 loop body around the detector call (attack/DSGN/pgd_attack.py:279-374):
-    clean = denormalize(x0)                         (:297-298)  adv_denormalize_index_f32 (also emits the clean image as a
-                                                                device-verified 8-bit index; --no-clean-index: adv_denormalize_f32)
-    export iterate 0 as 8-bit HWC                   (:279-294)  adv_export_u8_f32
-    20 x { step + project + re-normalise + export } (:339-374)  adv_pgd_step_indexed_f32 / adv_pgd_step_f32 (one launch,
-                                                                both eyes of every pair of the batch)
+    clean = denormalize(x0), export iterate 0       (:279-298)  adv_clean_index_build_f32 (one pass: clean image, its
+                                                                per-image device-verified 8-bit index, the 8-bit export)
+    20 x { step + project + re-normalise + export } (:339-374)  adv_pgd_step_indexed_f32 (one launch, both eyes of every
+                                                                pair of the batch, two alternating iterate buffers)
+The input is what the reference's loader hands over: 8-bit 375x1242 images (low-pass
+noise; the right eye is the left one shifted by a ground-plane disparity) -> /255 -> ImageNet normalisation ->
+ZERO-PADDED in normalised space to 384x1248.  `float_path` in the JSON line is the same attack with every stream read
+as float32 (adv_denormalize_f32 + adv_export_u8_f32 + adv_pgd_step_f32), timed in the same run.
 The detector's forward/backward (upstream DSGN, not part of the reference tree) is the caller's: its
 gradient is a resident synthetic buffer here, so `value` is the throughput of the perturbation engine
 with inputs in HBM, not of an end-to-end attack.  PNG encoding / disk are outside the timed region.
@@ -34,6 +37,7 @@ H, W = 384, 1248            # DSGN network input (hard-asserted by the reference
 CROP_H, CROP_W = 375, 1242  # KITTI native size the PNGs are cropped back to (pgd_attack.py:192)
 N_ITER, EPS, ALPHA = 20, 0.03, 1.0 / 255.0
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
+SR_H, SR_W = 600, 1987      # Stereo R-CNN network scale (attack/Stereo-RCNN/patch_attack.py:170-172)
 
 
 def parse():
@@ -47,15 +51,21 @@ def parse():
                          "pixel space on 600x1987 pairs (alpha 1.0, eps 0.03*255) - a parity-test configuration, timed on request")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-clean-index", action="store_true",
-                    help="read the clean image as float32 in every step instead of as the verified 8-bit index (dsgn workload)")
+                    help="headline = the all-float32 path (the clean image read as float32 in every step)")
+    ap.add_argument("--in-place", action="store_true", help="update the iterate in place instead of alternating two buffers")
+    ap.add_argument("--unpadded", action="store_true", help="fill the whole 384x1248 frame with 8-bit pixels (round-1 input; no padding)")
+    ap.add_argument("--no-float-path", action="store_true", help="skip the second (all-float32) measurement")
+    ap.add_argument("--no-srcnn", action="store_true", help="skip the configs[2] (Stereo R-CNN shape) object")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the (separately reported) surrogate-detector attack")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs in the CPU-baseline sample (0 = auto)")
     return ap.parse_args()
 
 
+# ---------------------------------------------------------------------------------------------- CPU baselines
 def cpu_baseline(sample_pairs):
-    """The oracle (a port: op-for-op restatement of the reference lines, pinned by golden vectors)
-    timed on this host: the same step as above for `sample_pairs` pairs."""
+    """The oracle (a port: op-for-op restatement of the reference lines, pinned by golden vectors) timed on this host:
+    the same step as above for a bounded sample; beside it the reference's own torch-CPU formulation (the ~12
+    elementwise torch ops per eye of attack/DSGN/pgd_attack.py:339-354 plus tensor2im) on all host threads."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import synth
@@ -66,9 +76,9 @@ def cpu_baseline(sample_pairs):
     except Exception:
         from oracle import oracle_np as impl
         cores, kind_note = 1, "numpy oracle (oracle/oracle_np.py)"
-    x0 = np.concatenate([synth.dsgn_normalised(i, H, W) for i in range(2)])
+    x0 = np.concatenate([synth.dsgn_padded(i, CROP_H, CROP_W, H, W) for i in range(2)])
     g = synth.gradient(3, x0.shape, 1.0)
-    t_budget, done, t0 = 20.0, 0, time.perf_counter()
+    t_budget, done, t0 = 12.0, 0, time.perf_counter()
     target = sample_pairs if sample_pairs > 0 else 10 ** 9
     while done < target:
         clean = impl.denormalize(x0)
@@ -83,13 +93,74 @@ def cpu_baseline(sample_pairs):
         if sample_pairs <= 0 and time.perf_counter() - t0 > t_budget:
             break
     dt = time.perf_counter() - t0
-    return {"value": done / dt, "unit": "stereo-pairs/s", "cores": int(cores), "kind": "port",
-            "sample": "%d KITTI-shaped pairs x 20-step PGD + 8-bit export, %s, %.1f s" % (done, kind_note, dt)}
+    out = {"value": done / dt, "unit": "stereo-pairs/s", "cores": int(cores), "kind": "port",
+           "sample": "%d KITTI-shaped pairs x 20-step PGD + 8-bit export, %s, %.1f s" % (done, kind_note, dt)}
+    try:
+        out["torch_cpu"] = torch_cpu_baseline(x0, g)
+    except Exception as e:                                   # never lose the bench line over the second baseline
+        out["torch_cpu"] = {"error": repr(e)}
+    return out
 
 
-def pmc_traffic(pairs, kernel_prefix="pgd_step_vec4<0, 1>"):
+def torch_cpu_baseline(x0_np, g_np, budget_s=10.0):
+    """attack/DSGN/pgd_attack.py:196-207,339-354 + tensor2im (:157-179) as torch-CPU eager ops, one pair per pass as the
+    reference runs it (batch 1), every host thread available to torch."""
+    import numpy as np
+    import torch
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+
+    def denormalize(im):                                     # :196-200
+        for i in range(3):
+            im.data[0][i] = im.data[0][i] * std[i] + mean[i]
+        return im
+
+    def normalize(im):                                       # :203-207
+        for i in range(3):
+            im.data[0][i] = (im.data[0][i] - mean[i]) / std[i]
+        return im
+
+    def tensor2im(t):                                        # :157-179 (+ the crop of save_img, :192)
+        a = t.cpu().float().numpy()
+        for i in range(3):
+            a[i] = a[i] * std[i] + mean[i]
+        a = a * 255
+        return np.transpose(a, (1, 2, 0)).astype(np.uint8)[:CROP_H, :CROP_W]
+
+    xs = [torch.from_numpy(x0_np[i:i + 1].copy()) for i in range(2)]
+    gs = [torch.from_numpy(g_np[i:i + 1].copy()) for i in range(2)]
+    done, t0 = 0, time.perf_counter()
+    while True:
+        imgs = [x.clone() for x in xs]
+        cleans = [denormalize(x.clone()) for x in xs]
+        for im in imgs:
+            tensor2im(im[0])
+        for _ in range(N_ITER):
+            for e in range(2):
+                im = denormalize(imgs[e])
+                adv = im + ALPHA * gs[e].sign()
+                eta = torch.clamp(adv - cleans[e], min=-EPS, max=EPS)
+                im = torch.clamp(cleans[e] + eta, min=0, max=1)
+                imgs[e] = normalize(im).detach()
+                tensor2im(imgs[e][0])
+        done += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = [l.split(":", 1)[1].strip() for l in f if l.startswith("model name")][0]
+    except Exception:
+        pass
+    return {"value": done / dt, "unit": "stereo-pairs/s", "threads": threads, "cpu": model, "kind": "reference formulation (torch-CPU eager)",
+            "sample": "%d KITTI-shaped pairs x 20-step PGD + tensor2im, batch 1 as the reference runs it, %.1f s" % (done, dt)}
+
+
+def pmc_traffic(pairs, kernel_prefix):
     """HBM bytes per launch of the dominant kernel from the newest committed PMC summary
-    (profiles/*_pmc_hbm.json, written by tools/summarize_prof.py from separate rocprofv3 --pmc FETCH_SIZE /
+    (profiles/*_pmc_hbm*.json, written by tools/summarize_prof.py from separate rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE passes of this same bench; gfx950 correction 2*FETCH_SIZE + WRITE_SIZE), scaled to `pairs`.
     Counters cannot be read from inside the timed run, so this is a recorded measurement, not a live one."""
     import glob
@@ -105,12 +176,92 @@ def pmc_traffic(pairs, kernel_prefix="pgd_step_vec4<0, 1>"):
     return None, None
 
 
+# ---------------------------------------------------------------------------------------------- synthetic input
+def kitti_like_input(torch, ops, sp, pairs, dev, gen, padded=True):
+    """[2*pairs,3,384,1248] float32 as the DSGN loader hands it over: 8-bit low-pass noise images of 375x1242, the right
+    eye = the left one shifted row by row by a ground-plane disparity fu*b/z (z from 40 m at the top to 5 m at the
+    bottom), ToTensor (v/255 as a TRUE division - torch on a GPU would turn a division by a Python scalar into a
+    multiplication by the reciprocal, which is not the float32 function a CPU loader computes), ImageNet
+    normalisation, zero padding in normalised space (data.dsgn_transform does the same on the host)."""
+    F = torch.nn.functional
+    vh, vw = (CROP_H, CROP_W) if padded else (H, W)
+    out = torch.zeros((2 * pairs, 3, H, W), device=dev)
+    z = torch.linspace(40.0, 5.0, vh, device=dev)
+    disp = (721.5377 * 0.54 / z).round().long()                              # 10 .. 78 px
+    cols = (torch.arange(vw, device=dev)[None, :] + disp[:, None]).clamp_(max=vw - 1)   # right(x) = left(x + d)
+    two55 = torch.full((), 255.0, device=dev)
+    chunk = 32
+    for p0 in range(0, pairs, chunk):
+        b = min(chunk, pairs - p0)
+        low = torch.randint(0, 256, (b, 3, vh // 8 + 2, vw // 8 + 2), device=dev, generator=gen, dtype=torch.int32).float()
+        left = F.interpolate(low, size=(vh, vw), mode="bilinear", align_corners=False)
+        left += torch.randint(-8, 9, (b, 3, vh, vw), device=dev, generator=gen, dtype=torch.int32).float()
+        left.clamp_(0, 255).round_()
+        right = torch.gather(left, 3, cols[None, None].expand(b, 3, vh, vw))
+        for eye, img in ((0, left), (1, right)):
+            t = img.div(two55).contiguous()
+            ops.normalize(t, sp, out=t)                                      # (t - mean) / std, true division
+            out[eye * pairs + p0:eye * pairs + p0 + b, :, :vh, :vw] = t
+    return out, (vh, vw)
+
+
+class PgdBench:
+    """one resident batch and its buffers; `attack()` enqueues one complete 20-step attack"""
+
+    def __init__(self, torch, ops, sp, x0, grad, valid, crop, use_index, in_place, affine=True):
+        self.torch, self.ops, self.sp = torch, ops, sp
+        self.x0, self.grad, self.valid, self.crop = x0, grad, valid, crop
+        self.use_index, self.in_place, self.affine = use_index, in_place, affine
+        n = x0.shape[0]
+        self.clean = torch.empty_like(x0)
+        self.a = torch.empty_like(x0)
+        self.b = None if in_place else torch.empty_like(x0)
+        self.u8 = ops.alloc_u8(n, crop[0], x0.shape[3], x0.device)
+        self.cidx = None
+
+    def attack(self, ev0=None, ev1=None):
+        ops, sp = self.ops, self.sp
+        if not self.affine:
+            self.clean.copy_(self.x0)        # explicit clone of the clean pair (Stereo R-CNN pgd_attack.py:122-123, quirk Q6)
+            ops.export_u8(self.x0, sp, self.crop, out=self.u8)
+        elif self.use_index:                 # denormalize + per-image verified 8-bit index + iterate-0 export, one pass
+            _, self.cidx = ops.denormalize_indexed(self.x0, sp, out=self.clean, reuse=self.cidx, valid=self.valid,
+                                                   u8_out=self.u8, crop=self.crop)
+        else:
+            ops.denormalize(self.x0, sp, out=self.clean)
+            ops.export_u8(self.x0, sp, self.crop, out=self.u8)
+        if ev0 is not None:
+            ev0.record()
+        kw = {"clean_index": self.cidx} if (self.affine and self.use_index) else {}
+        cur, nxt = self.x0, self.a
+        for _ in range(N_ITER):
+            ops.pgd_step(cur, self.grad, self.clean, sp, ALPHA, EPS, out=nxt, u8_out=self.u8, crop=self.crop, **kw)
+            cur, nxt = nxt, (nxt if self.in_place else (self.b if nxt is self.a else self.a))
+        if ev1 is not None:
+            ev1.record()
+
+    def timed(self, steps, warmup, fence):
+        torch = self.torch
+        ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+        ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+        for _ in range(warmup):
+            self.attack()
+        fence()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            self.attack(ev0[k], ev1[k])
+        fence()
+        elapsed = time.perf_counter() - t0
+        kern_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / (steps * N_ITER)   # HIP events on the launch stream
+        return elapsed, kern_ms
+
+
 def main():
     args = parse()
     global H, W, CROP_H, CROP_W, ALPHA, EPS
     srcnn = args.workload == "srcnn"
     if srcnn:   # attack/Stereo-RCNN/pgd_attack.py: network scale 600x1987, no crop (quirk Q14), alpha 1.0, eps = 255*0.03 (:57)
-        H, W, CROP_H, CROP_W, ALPHA, EPS = 600, 1987, 600, 1987, 1.0, 255 * 0.03
+        H, W, CROP_H, CROP_W, ALPHA, EPS = SR_H, SR_W, SR_H, SR_W, 1.0, 255 * 0.03
     if args.pairs <= 0:
         args.pairs = 96 if srcnn else 256
     import torch
@@ -139,75 +290,56 @@ def main():
     from eval_driving_safety_amd import ops   # raises if libadvengine.so is not built
     sp = ops.Space.srcnn() if srcnn else ops.Space.dsgn()
 
-    n_img = 2 * args.pairs                    # both eyes of every pair in one launch
-    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    x0 = torch.randint(0, 256, (n_img, 3, H, W), device=dev, generator=gen, dtype=torch.int32).float()
-    if srcnn:
-        x0 -= torch.tensor([102.9801, 115.9465, 122.7717], device=dev).view(1, 3, 1, 1)   # BGR minus PIXEL_MEANS
-    else:
-        # ToTensor's v/255 as a TRUE division (what the CPU loader computes); torch-on-GPU would turn a division by a
-        # Python scalar into a multiplication by the reciprocal, which is not the same float32 function
-        x0.div_(torch.full((), 255.0, device=dev))
-        ops.normalize(x0, sp, out=x0)         # what the DSGN loader hands over: normalised float32
-    grad = torch.randn((n_img, 3, H, W), device=dev, generator=gen)
-    clean = torch.empty_like(x0)
-    x = torch.empty_like(x0)
-    spare = torch.empty_like(x0) if srcnn else None   # planes are not whole cache lines: alternate buffers
-    u8 = ops.alloc_u8(n_img, CROP_H, W, dev)
-    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-
-    use_index = (not srcnn) and (not args.no_clean_index)
-    cidx = [None]
-
-    def step(k=None):
-        if srcnn:
-            clean.copy_(x0)                   # explicit clone of the clean pair (pgd_attack.py:122-123, quirk Q6)
-        elif use_index:                       # denormalize + verified 8-bit index of the clean image (read as bytes by the 20 steps)
-            _, cidx[0] = ops.denormalize_indexed(x0, sp, out=clean, reuse=cidx[0])
-        else:
-            ops.denormalize(x0, sp, out=clean)
-        ops.export_u8(x0, sp, (CROP_H, CROP_W), out=u8)
-        if k is not None:
-            ev0[k].record()
-        kw = {"clean_index": cidx[0]} if use_index else {}
-        ops.pgd_step(x0, grad, clean, sp, ALPHA, EPS, out=x, u8_out=u8, crop=(CROP_H, CROP_W), **kw)
-        cur, nxt = x, (spare if srcnn else x)
-        for _ in range(N_ITER - 1):
-            ops.pgd_step(cur, grad, clean, sp, ALPHA, EPS, out=nxt, u8_out=u8, crop=(CROP_H, CROP_W), **kw)
-            cur, nxt = nxt, cur
-        if k is not None:
-            ev1[k].record()
-
     def fence():
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            if dist.get_backend() == "gloo":
+                dist.barrier()
+            else:
+                dist.barrier(device_ids=[torch.cuda.current_device()])
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(k)
-    fence()
-    elapsed = time.perf_counter() - t0
+    n_img = 2 * args.pairs                    # both eyes of every pair in one launch
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    if srcnn:
+        x0 = torch.randint(0, 256, (n_img, 3, H, W), device=dev, generator=gen, dtype=torch.int32).float()
+        x0 -= torch.tensor([102.9801, 115.9465, 122.7717], device=dev).view(1, 3, 1, 1)   # BGR minus PIXEL_MEANS
+        valid = (H, W)
+    else:
+        x0, valid = kitti_like_input(torch, ops, sp, args.pairs, dev, gen, padded=not args.unpadded)
+    grad = torch.randn((n_img, 3, H, W), device=dev, generator=gen)
+    crop = (CROP_H, CROP_W)
+    use_index = (not srcnn) and (not args.no_clean_index)
+    main_b = PgdBench(torch, ops, sp, x0, grad, valid, crop, use_index, args.in_place, affine=not srcnn)
+    elapsed, kern_ms = main_b.timed(args.steps, args.warmup, fence)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # dominant kernel: pgd_step_vec4<AFFINE, rows-dword u8>; HIP events on the launch stream
-    kern_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / (args.steps * N_ITER)
     elems = 3 * H * W
     alg_bytes = n_img * (16 * elems + 3 * CROP_H * CROP_W)     # 16 B/elt + the 8-bit export
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    flags = main_b.cidx.verified() if use_index and main_b.cidx is not None else None
+    n_indexed = sum(flags) if flags is not None else 0
 
-    index_verified = bool(int(cidx[0].ok.item())) if use_index and cidx[0] is not None else None
+    # the same attack with every stream read as float32, timed in the same run (dsgn workload, rank 0's own clock)
+    float_path = None
+    if not srcnn and use_index and not args.no_float_path:
+        del main_b.a, main_b.b
+        fb = PgdBench(torch, ops, sp, x0, grad, valid, crop, False, args.in_place)
+        fe, fk = fb.timed(max(2, args.steps // 3), 1, fence)
+        fsteps = max(2, args.steps // 3)
+        float_path = {"value": world * args.pairs * fsteps / fe, "unit": "stereo-pairs/s", "ms_per_step": 1e3 * fe / fsteps,
+                      "kernel": "pgd_step_vec4<AFFINE,U8_ROWS_DWORD>", "avg_launch_ms": fk,
+                      "achieved": alg_bytes / (fk * 1e-3) / 1e9, "frac": alg_bytes / (fk * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                      "note": "adv_denormalize_f32 + adv_export_u8_f32 + 20 x adv_pgd_step_f32: what a batch of images WITHOUT "
+                              "an 8-bit origin takes (it reads exactly the algorithmic bytes)"}
+        del fb
+
     if rank == 0:
-        traffic, traffic_src = (None, None) if srcnn else pmc_traffic(
-            args.pairs, "pgd_step_vec4_idx<1>" if index_verified else "pgd_step_vec4<0, 1>")
+        kern_name = ("pgd_step_shifted<IDENTITY>" if srcnn else ("pgd_step_vec4_idx<U8_ROWS_DWORD>" if n_indexed else "pgd_step_vec4<AFFINE,U8_ROWS_DWORD>"))
+        traffic, traffic_src = (None, None) if srcnn else pmc_traffic(args.pairs, "pgd_step_vec4_idx<1>" if n_indexed else "pgd_step_vec4<0, 1>")
         out = {
             "metric": "KITTI stereo-pairs/sec for 20-step PGD on %s (perturbation path; detector fwd+bwd is the caller's)"
                       % ("Stereo R-CNN" if srcnn else "DSGN"),
@@ -220,40 +352,54 @@ def main():
             "config": {"workload": ("BASELINE configs[2]: 20-step PGD Linf eps=0.03*255 alpha=1.0, Stereo R-CNN pixel space (BGR minus "
                                     "PIXEL_MEANS), 600x1987 network-scale pairs, %d stereo pairs resident per GPU, gradient = resident "
                                     "synthetic buffer, 8-bit HWC export of all 21 iterates" % args.pairs) if srcnn else
-                                   ("BASELINE configs[1]: 20-step PGD Linf eps=0.03 alpha=1/255, DSGN pixel space, "
-                                    "KITTI 1242x375 padded to 1248x384, %d stereo pairs resident per GPU, gradient = "
-                                    "resident synthetic buffer, 8-bit HWC export of all 21 iterates" % args.pairs),
+                                   ("BASELINE configs[1]: 20-step PGD Linf eps=0.03 alpha=1/255, DSGN pixel space, 8-bit KITTI-shaped "
+                                    "%s, %d stereo pairs resident per GPU, gradient = resident synthetic buffer, 8-bit HWC export of "
+                                    "all 21 iterates" % ("1242x375 images normalised and zero-padded to 1248x384 as the loader does"
+                                                         if not args.unpadded else "images filling the whole 1248x384 frame (no padding)",
+                                                         args.pairs)),
                        "pairs_per_gpu": args.pairs, "pgd_iters": N_ITER, "eps": EPS, "alpha": ALPHA,
+                       "iterate_buffers": "in place" if args.in_place else "two alternating",
                        "parallelism": "image-sharded x%d, no collective" % world},
-            "roofline": {"bound": "hbm", "kernel": "pgd_step_shifted<IDENTITY,U8_BYTES>" if srcnn else
-                         ("pgd_step_vec4_idx<U8_ROWS_DWORD>" if use_index else "pgd_step_vec4<AFFINE,U8_ROWS_DWORD>"),
+            "roofline": {"bound": "hbm", "kernel": kern_name,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                         "clean_image_read_as": ("uint8 index (verified on the device)" if index_verified else "float32"),
+                         "clean_image_read_as": ("uint8 index for %d of %d images (verified per image on the device)" % (n_indexed, n_img)
+                                                 if use_index else "float32"),
                          # `achieved` follows the contract (ALGORITHMIC bytes: 16 B/elt + export); the kernel really moves
                          # `traffic` bytes - less when the clean image is read as bytes - so the HBM itself is this busy:
                          "hbm_utilisation": (traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None},
         }
-        if world == 1 and not args.no_cpu_baseline and not srcnn:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_pairs)
-        if world == 1 and not args.no_end_to_end and not srcnn:
-            # SURVEY 8(d): the end-to-end number is reported BESIDE the kernel-path one, never folded into `value`
-            del x0, grad, clean, x, u8
+        if float_path is not None:
+            out["float_path"] = float_path
+    else:
+        out = None
+    del main_b, x0, grad
+    torch.cuda.empty_cache()
+
+    if rank == 0 and world == 1:
+        if not srcnn and not args.no_srcnn:
+            try:
+                out["configs2_srcnn"] = srcnn_object(torch, ops, dev, fence)
+            except Exception as e:
+                out["configs2_srcnn"] = {"error": repr(e)}
             torch.cuda.empty_cache()
+        if not args.no_cpu_baseline and not srcnn:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_pairs)
+        if not args.no_end_to_end and not srcnn:
+            # SURVEY 8(d): the end-to-end number is reported BESIDE the kernel-path one, never folded into `value`
             try:
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 import bench_end_to_end
                 out["end_to_end"] = bench_end_to_end.measure(pairs=1, iters=N_ITER, reps=3)
             except Exception as e:
                 out["end_to_end"] = {"error": repr(e)}
-    else:
-        out = None
 
     # Outside the timed region, N > 1 only: latency of the one collective the attacks have - the all-reduce(SUM)
     # of the universal-patch delta [3,D,D] (D = 101: BASELINE configs[3], 122 KB) over RCCL / xGMI - checked
     # against the closed form, so the multi-GPU patch path runs on real links whenever the scaling bench does.
-    # Never part of `value`; a watchdog prints the throughput line without it if the collective stalls.
+    # Never part of `value`.  If the collective stalls, the watchdog prints the throughput line with the error and the
+    # process exits NON-ZERO, so that a launcher can tell a stall from success.
     if world > 1:
         import threading
 
@@ -261,7 +407,7 @@ def main():
             if rank == 0:
                 out["patch_allreduce"] = {"error": "timed out after 120 s"}
                 print(json.dumps(out), flush=True)
-            os._exit(0)
+            os._exit(3)
 
         dog = threading.Timer(120.0, bail)
         dog.daemon = True
@@ -281,7 +427,7 @@ def main():
             c1.record()
             torch.cuda.synchronize()
             ok = bool((bufs[-1] == world * (world + 1) / 2).all().item())
-            patch_comm = {"collective": "all_reduce(SUM) of the patch delta [3,101,101] f32 (122412 B) over RCCL",
+            patch_comm = {"collective": "all_reduce(SUM) of the patch delta [3,101,101] f32 (122412 B) over %s" % dist.get_backend(),
                           "avg_us": 1e3 * c0.elapsed_time(c1) / reps, "correct": ok}
         except Exception as e:                       # report, never fail the throughput line
             patch_comm = {"error": repr(e)}
@@ -292,6 +438,31 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def srcnn_object(torch, ops, dev, fence, pairs=64, steps=3):
+    """BASELINE configs[2] beside the headline: 20-step PGD in the Stereo R-CNN pixel space (attack/Stereo-RCNN/
+    pgd_attack.py:177-243) on 600x1987 pairs, alpha 1.0, eps 0.03*255, 8-bit export of every iterate."""
+    global ALPHA, EPS
+    sp = ops.Space.srcnn()
+    n_img = 2 * pairs
+    gen = torch.Generator(device=dev).manual_seed(99)
+    x0 = torch.randint(0, 256, (n_img, 3, SR_H, SR_W), device=dev, generator=gen, dtype=torch.int32).float()
+    x0 -= torch.tensor([102.9801, 115.9465, 122.7717], device=dev).view(1, 3, 1, 1)
+    grad = torch.randn((n_img, 3, SR_H, SR_W), device=dev, generator=gen)
+    keep = (ALPHA, EPS)
+    ALPHA, EPS = 1.0, 255 * 0.03
+    try:
+        b = PgdBench(torch, ops, sp, x0, grad, (SR_H, SR_W), (SR_H, SR_W), False, False, affine=False)
+        elapsed, kern_ms = b.timed(steps, 1, fence)
+    finally:
+        ALPHA, EPS = keep
+    alg = n_img * (16 * 3 * SR_H * SR_W + 3 * SR_H * SR_W)
+    return {"metric": "stereo-pairs/s, 20-step PGD in the Stereo R-CNN pixel space (perturbation path)", "value": pairs * steps / elapsed,
+            "unit": "stereo-pairs/s", "pairs": pairs, "steps": steps, "ms_per_step": 1e3 * elapsed / steps,
+            "roofline": {"bound": "hbm", "kernel": "pgd_step_shifted<IDENTITY>", "achieved": alg / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": alg / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": kern_ms,
+                         "algorithmic_bytes_per_launch": alg}}
 
 
 if __name__ == "__main__":

@@ -19,7 +19,7 @@ ADV_EALIGN = -14
 ADV_ELAUNCH = -5
 ADV_SPACE_AFFINE = 0
 ADV_SPACE_IDENTITY = 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class AdvSpace(ctypes.Structure):
@@ -30,6 +30,16 @@ class AdvSpace(ctypes.Structure):
                 ("lo", ctypes.c_float * 3),
                 ("hi", ctypes.c_float * 3),
                 ("export_add", ctypes.c_double * 3)]
+
+
+class AdvCleanIndex(ctypes.Structure):
+    """adv_clean_index_t (all pointers are device memory)"""
+    _fields_ = [("index", ctypes.c_void_p),
+                ("ok", ctypes.c_void_p),
+                ("lut", ctypes.c_void_p),
+                ("valid_hw", ctypes.c_void_p),
+                ("valid_h", ctypes.c_int32),
+                ("valid_w", ctypes.c_int32)]
 
 
 class AdvEngineError(RuntimeError):
@@ -44,6 +54,7 @@ _L = ctypes.c_int64
 _F = ctypes.c_float
 _SP = ctypes.POINTER(AdvSpace)
 _F3 = ctypes.POINTER(ctypes.c_float)
+_CI = ctypes.POINTER(AdvCleanIndex)
 
 # name -> argtypes; every function returns int unless listed in _OTHER_RESTYPE
 SIGNATURES = {
@@ -51,8 +62,8 @@ SIGNATURES = {
     "adv_normalize_f32": [_P, _P, _L, _I, _I, _SP, _P],
     "adv_pgd_step_f32": [_P, _P, _P, _P, _P, _L, _I, _I, _SP, _F, _F, _I, _I, _L, _L, _P],
     "adv_export_u8_f32": [_P, _P, _L, _I, _I, _SP, _I, _I, _L, _L, _P],
-    "adv_denormalize_index_f32": [_P, _P, _P, _P, _L, _I, _I, _SP, _P],
-    "adv_pgd_step_indexed_f32": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _SP, _F, _F, _I, _I, _L, _L, _P],
+    "adv_clean_index_build_f32": [_P, _P, _CI, _P, _L, _I, _I, _SP, _I, _I, _L, _L, _P],
+    "adv_pgd_step_indexed_f32": [_P, _P, _P, _CI, _P, _P, _L, _I, _I, _SP, _F, _F, _I, _I, _L, _L, _P],
     "adv_disc_mask_f32": [_P, _I, _I, _I, _I, _I, _P],
     "adv_patch_paste_f32": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "adv_patch_paste_batch_f32": [_P, _P, _L, _I, _I, _I, _P, _I, _P],

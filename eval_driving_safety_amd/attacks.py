@@ -71,7 +71,7 @@ class PgdAttack:
     """
 
     def __init__(self, model_kind, alpha, eps, iters, out_root=".", save=True, save_every=1, writer_workers=None,
-                 ops=None, device=None):
+                 ops=None, device=None, in_place=False):
         if writer_workers is None:                   # PNG (zlib) encoding is the I/O wall: 42 files per pair at N = 20
             writer_workers = min(16, max(4, (os.cpu_count() or 8) // 4))
         self.ops = ops if ops is not None else _default_ops()
@@ -84,7 +84,7 @@ class PgdAttack:
             raise ValueError("model_kind must be 'dsgn' or 'srcnn'")
         self.alpha, self.iters = float(alpha), int(iters)
         self.out_root, self.save, self.save_every = out_root, save, max(1, int(save_every))
-        self.device = device
+        self.device, self.in_place = device, in_place
         self.writer = pixelio.PngWriter(writer_workers, bgr=(model_kind == "srcnn")) if save else None
 
     # -- file surface --------------------------------------------------------------------------
@@ -116,19 +116,26 @@ class PgdAttack:
         exporter = pixelio.AsyncExporter(self.writer, lambda: ops.alloc_u8(n, rows, w, dev), dev) if self.save else None
         # clean image in pixel space: pgd_attack.py:297-298 (DSGN) / :122-123 (Stereo R-CNN)
         # (for 8-bit derived inputs the clean image is also kept as one byte per element: the N steps then read it
-        #  as bytes; verified on the device, results identical - ops.denormalize_indexed)
+        #  as bytes; verified per image on the device, results identical - ops.denormalize_indexed.  The loader's zero
+        #  padding beyond each image's own (h, w) is part of what is verified.)
         cidx = None
+        want0 = self._wanted(0)                      # iterate 0 = the un-attacked pair, :279-294
         if sp.affine and getattr(ops, "can_index_clean", lambda *_: False)(x, sp):
-            clean, cidx = ops.denormalize_indexed(x, sp)
+            valid = None if batch.sizes is None else [(s[1], s[0]) for s in batch.sizes] * 2     # both eyes
+            clean, cidx = ops.denormalize_indexed(x, sp, valid=valid, u8_out=exporter.next_buffer() if want0 else None,
+                                                  crop=(rows, cols) if want0 else None)
         else:
             clean = ops.denormalize(x, sp) if sp.affine else x.clone()
-        if self._wanted(0):                          # iterate 0 = the un-attacked pair, :279-294
-            ops.export_u8(x, sp, (rows, cols), out=exporter.next_buffer())
+            if want0:
+                ops.export_u8(x, sp, (rows, cols), out=exporter.next_buffer())
+        if want0:
             exporter.submit(self._fan_out(0, batch))
+        self.last_clean_index = cidx
         losses = []
-        # in place where the planes are whole cache lines (DSGN); two alternating buffers where they are not
-        # (Stereo R-CNN), because the line-aligned kernel for such shapes fuses the export only out of place
-        pingpong = self.save and getattr(ops, "prefers_out_of_place", lambda *_: False)(h, w)
+        # Two alternating buffers: the step kernels measured 3-5 % faster writing a different buffer than the one they
+        # read (profiles/r02_k1_idx_tuning.md), and the line-aligned kernel for planes that are not whole cache lines
+        # (Stereo R-CNN) fuses the export only out of place.  ``in_place=True`` trades that for one buffer less.
+        pingpong = not self.in_place
         spare = torch.empty_like(x) if pingpong else None
         for k in range(self.iters):
             loss, grad = adapter.loss_and_grad(x, batch.extra)           # detector fwd + loss + bwd (:305-336)

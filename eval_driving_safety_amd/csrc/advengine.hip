@@ -152,6 +152,37 @@ __device__ __forceinline__ void store_u8_group(const v4f O[3], long long img, in
   }
 }
 
+// the same for values that are ALREADY in [0,1] pixel space (the denormalised clean image): byte = trunc(v * 255),
+// which is what tensor2im computes from the normalised image (attack/DSGN/pgd_attack.py:174-178)
+template <int U8>
+__device__ __forceinline__ void store_u8_pixel_group(const v4f O[3], long long img, int q, int w, const U8Dst& u8) {
+  if (U8 == U8_NONE) return;
+  const int p = q * 4;
+  const int row = p / w;
+  if (row >= u8.crop_h) return;
+  const int col = p - row * w;
+  uint8_t* dst = u8.base + img * u8.image_stride + row * u8.row_stride + col * 3LL;
+  uint32_t b[12];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) b[j * 3 + c] = trunc_low_byte(O[c][j] * 255.0f);
+  if (U8 == U8_ROWS_DWORD) {  // w % 4 == 0 (required by the index build): the group never leaves its row
+    v3u r;
+    r[0] = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+    r[1] = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+    r[2] = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
+    st_stream(reinterpret_cast<v3u*>(dst), r);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (col + j < u8.ncols) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dst[j * 3 + c] = static_cast<uint8_t>(b[j * 3 + c]);
+      }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // K1/K2 (+K5 fused): one PGD step.  A lane owns 4 consecutive pixels of one image in all three
 // channel planes (kUnroll such groups, half an image apart): 9 independent 16-byte loads per
@@ -204,13 +235,17 @@ __global__ __launch_bounds__(kWave) void pgd_step_vec4(const v4f* x, const v4f* 
 // K1 with the clean image held as an 8-bit INDEX (AFFINE spaces).  The clean image of an attack is re-read by
 // every one of its N steps, and it is not an arbitrary float image: it came from 8-bit pixels v through
 //     t = v / 255;  x0 = (t - shift) / scale;  clean = x0 * scale + shift            (all float32)
-// i.e. ToTensor, Normalize, then the script's denormalize (attack/DSGN/pgd_attack.py:196-200,297-298).  When
-// adv_denormalize_index_f32 has VERIFIED, element by element and bit by bit, that clean == F_c(v) for the index
-// v it stores, the step kernel reads the 1-byte index and recomputes the float (two divisions, far below the
-// VALU budget of an HBM-bound kernel) instead of reading 4 bytes: 14 instead of 17 bytes per element and
-// launch, bit-identical results.  If a single element failed the check (*ok == 0: resized or otherwise
-// processed inputs) the same launch falls back to the float32 clean buffer - the flag is read on the device, no
-// host round trip.
+// i.e. ToTensor, Normalize, then the script's denormalize (attack/DSGN/pgd_attack.py:196-200,297-298), and the
+// loader zero-pads the normalised image to the network size, so that outside the valid_h x valid_w corner the
+// clean value is exactly shift_c (0 * scale + shift).  clean_index_build VERIFIES both facts per image, element
+// by element and bit by bit, against a 3 x 256 table T_c[v] of that chain; the step kernel then reads the
+// 1-byte index and looks the float up in an LDS copy of the table (13 instead of 16 bytes per element and
+// launch, no division, bit-identical results).  An image with a single failing element (resized or otherwise
+// processed inputs) keeps ok[img] == 0 and the same launch reads its float32 clean buffer instead - the flags
+// are read on the device (one scalar load per workgroup), no host round trip, no effect on the other images.
+// Measured on 512 KITTI-shaped images (tools/k1_idx_tune.hip, profiles/r02_k1_idx_tuning.md): table in LDS
+// 1.573 ms, table gathered from global memory 1.600 ms, round 1's two IEEE divisions 1.592 ms; 4-wave
+// workgroups or more than one trip per workgroup are 3-15 % slower.
 // ------------------------------------------------------------------------------------------
 template <int DIR>
 __device__ __forceinline__ float affine_elem(float x, float sc, float sh);
@@ -222,13 +257,36 @@ __device__ __forceinline__ float clean_from_index(uint32_t v, float sc, float sh
   return t + sh;
 }
 
+constexpr int kLutSize = 3 * 256;
+
+struct IdxK {  // by-value kernel argument: the device side of adv_clean_index_t
+  uint32_t* idx;         // [n,3,hw4] words of 4 index bytes
+  int* ok;               // [n]
+  float* lut;            // [3*256]
+  const int* valid_hw;   // [n,2] or nullptr
+  int vh, vw;
+};
+
+__global__ __launch_bounds__(256) void clean_lut_kernel(float* lut, SpaceK sp) {
+  for (int e = threadIdx.x; e < kLutSize; e += 256) lut[e] = clean_from_index(e & 255, sp.scale[e >> 8], sp.shift[e >> 8]);
+}
+
+__device__ __forceinline__ void stage_lut(float* lds, const float* __restrict__ lut_g) {
+  for (int k = threadIdx.x; k < kLutSize / 4; k += kWave) reinterpret_cast<v4f*>(lds)[k] = reinterpret_cast<const v4f*>(lut_g)[k];
+  __syncthreads();
+}
+
 template <int U8>
-__global__ __launch_bounds__(kWave) void pgd_step_vec4_idx(const v4f* x, const v4f* __restrict__ g, const v4f* __restrict__ cl,
-                                                           const uint32_t* __restrict__ idx, const int* __restrict__ ok, v4f* xo,
-                                                           long long n_img, int hw4, int w, SpaceK sp, float alpha, float eps, U8Dst u8) {
-  const bool use_idx = (*ok) != 0;  // uniform: a scalar load
+__global__ __launch_bounds__(kWave) void pgd_step_vec4_idx(const v4f* x, const v4f* __restrict__ g, const v4f* __restrict__ cl, IdxK ik,
+                                                           v4f* xo, long long n_img, int hw4, int w, SpaceK sp, float alpha, float eps,
+                                                           U8Dst u8) {
+  __shared__ float lut[kLutSize];
+  stage_lut(lut, ik.lut);
   const int stride = gridDim.x * kWave;
   for (long long img = blockIdx.y; img < n_img; img += gridDim.y) {
+    const bool use_idx = ik.ok[img] != 0;  // uniform: scalar loads
+    const int vh = ik.valid_hw ? ik.valid_hw[2 * img] : ik.vh;
+    const int vw = ik.valid_hw ? ik.valid_hw[2 * img + 1] : ik.vw;
     const long long plane0 = img * 3LL * hw4;
     for (int q0 = blockIdx.x * kWave + threadIdx.x; q0 < hw4; q0 += stride * kUnroll) {
       v4f X[kUnroll][3], G[kUnroll][3], C[kUnroll][3];
@@ -243,7 +301,7 @@ __global__ __launch_bounds__(kWave) void pgd_step_vec4_idx(const v4f* x, const v
             X[u][c] = ld_stream(x + i);
             G[u][c] = ld_stream(g + i);
             if (use_idx)
-              I[u][c] = __builtin_nontemporal_load(idx + i);
+              I[u][c] = __builtin_nontemporal_load(ik.idx + i);
             else
               C[u][c] = ld_stream(cl + i);
           }
@@ -253,12 +311,18 @@ __global__ __launch_bounds__(kWave) void pgd_step_vec4_idx(const v4f* x, const v
       for (int u = 0; u < kUnroll; ++u) {
         const int q = q0 + u * stride;
         if (q < hw4) {
+          const int p = q * 4;  // w % 4 == 0: the 4 pixels of a group share their row
+          const int row = p / w;
+          const int col = p - row * w;
           v4f O[3];
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
             if (use_idx) {
 #pragma unroll
-              for (int j = 0; j < 4; ++j) C[u][c][j] = clean_from_index((I[u][c] >> (8 * j)) & 0xffu, sp.scale[c], sp.shift[c]);
+              for (int j = 0; j < 4; ++j) {
+                const float t = lut[c * 256 + ((I[u][c] >> (8 * j)) & 0xffu)];
+                C[u][c][j] = (row < vh && col + j < vw) ? t : sp.shift[c];
+              }
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -272,36 +336,49 @@ __global__ __launch_bounds__(kWave) void pgd_step_vec4_idx(const v4f* x, const v
   }
 }
 
-// a1 fused with the index build: clean = x*scale+shift; v = rint(clean*255) clamped to 0..255; *ok is cleared when
-// F_c(v) and clean differ in any bit (the caller sets *ok = 1 first).
-__global__ __launch_bounds__(kWave) void denormalize_index_vec4(const v4f* x, v4f* clean, uint32_t* idx, int* ok, long long n_img, int hw4,
-                                                                SpaceK sp) {
+// a1 fused with the index build, its verification and (optionally) the 8-bit export of iterate 0:
+// clean = x*scale+shift; inside the valid corner v = rint(clean*255) clamped to 0..255 and T_c[v] must equal clean
+// bit for bit, outside it clean must equal shift_c bit for bit; ok[img] is cleared otherwise (the host side sets
+// it to 1 first).  The export byte of iterate 0 is trunc(clean*255): tensor2im applies the same x*scale+shift.
+template <int U8>
+__global__ __launch_bounds__(kWave) void clean_index_build_vec4(const v4f* x, v4f* clean, IdxK ik, long long n_img, int hw4, int w, SpaceK sp,
+                                                                U8Dst u8) {
+  __shared__ float lut[kLutSize];
+  stage_lut(lut, ik.lut);
   const int stride = gridDim.x * kWave;
-  bool bad = false;
   for (long long img = blockIdx.y; img < n_img; img += gridDim.y) {
+    const int vh = ik.valid_hw ? ik.valid_hw[2 * img] : ik.vh;
+    const int vw = ik.valid_hw ? ik.valid_hw[2 * img + 1] : ik.vw;
     const long long plane0 = img * 3LL * hw4;
+    bool bad = false;
     for (int q = blockIdx.x * kWave + threadIdx.x; q < hw4; q += stride) {
+      const int p = q * 4;
+      const int row = p / w;
+      const int col = p - row * w;
+      v4f O[3];
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         const long long i = plane0 + static_cast<long long>(c) * hw4 + q;
         const v4f X = ld_stream(x + i);
-        v4f O;
         uint32_t word = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          O[j] = affine_elem<0>(X[j], sp.scale[c], sp.shift[c]);
-          float r = rintf(O[j] * 255.0f);
+          O[c][j] = affine_elem<0>(X[j], sp.scale[c], sp.shift[c]);
+          float r = rintf(O[c][j] * 255.0f);
           r = r < 0.0f ? 0.0f : (r > 255.0f ? 255.0f : r);  // NaN compares false twice and converts to 0 below
           const uint32_t v = (r == r) ? static_cast<uint32_t>(r) : 0u;
-          bad |= __float_as_uint(clean_from_index(v, sp.scale[c], sp.shift[c])) != __float_as_uint(O[j]);
-          word |= v << (8 * j);
+          const bool inside = row < vh && col + j < vw;
+          const float want = inside ? lut[c * 256 + v] : sp.shift[c];
+          bad |= __float_as_uint(want) != __float_as_uint(O[c][j]);
+          word |= (inside ? v : 0u) << (8 * j);
         }
-        st_stream(clean + i, O);
-        __builtin_nontemporal_store(word, idx + i);
+        st_stream(clean + i, O[c]);
+        __builtin_nontemporal_store(word, ik.idx + i);
       }
+      store_u8_pixel_group<U8>(O, img, q, w, u8);
     }
+    if (__any(bad) && (threadIdx.x & 63) == 0) ik.ok[img] = 0;
   }
-  if (__any(bad) && (threadIdx.x & 63) == 0) *ok = 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -885,58 +962,80 @@ int adv_pgd_step_f32(const float* x, const float* grad, const float* clean, floa
   return launch_pgd<ADV_SPACE_IDENTITY>(x, grad, clean, x_out, n, h, w, sp, alpha, eps, u8_out, crop_h, crop_w, u8_row_stride, u8_image_stride, st);
 }
 
-int adv_denormalize_index_f32(const float* x, float* clean_out, uint8_t* index_out, int32_t* ok_out, int64_t n, int h, int w,
-                              const adv_space_t* space, adv_stream_t stream) {
+static int check_clean_index(const adv_clean_index_t* ci, int h, int w, IdxK* out) {
+  if (ci == nullptr || ci->index == nullptr || ci->ok == nullptr || ci->lut == nullptr) return ADV_EINVAL;
+  if (!aligned(ci->index, 4) || !aligned(ci->ok, 4) || !aligned(ci->lut, 16) || (ci->valid_hw && !aligned(ci->valid_hw, 4))) return ADV_EALIGN;
+  if (ci->valid_hw == nullptr && (ci->valid_h < 0 || ci->valid_h > h || ci->valid_w < 0 || ci->valid_w > w)) return ADV_EINVAL;
+  *out = IdxK{reinterpret_cast<uint32_t*>(ci->index), reinterpret_cast<int*>(ci->ok), ci->lut, reinterpret_cast<const int*>(ci->valid_hw),
+              ci->valid_h, ci->valid_w};
+  return ADV_OK;
+}
+
+int adv_clean_index_build_f32(const float* x, float* clean_out, const adv_clean_index_t* ci, uint8_t* u8_out, int64_t n, int h, int w,
+                              const adv_space_t* space, int crop_h, int crop_w, int64_t u8_row_stride, int64_t u8_image_stride,
+                              adv_stream_t stream) {
   int rc = check_image_args(x, clean_out, n, h, w);
   if (rc != ADV_OK) return rc;
   rc = check_space(space);
   if (rc != ADV_OK) return rc;
-  if (space->kind != ADV_SPACE_AFFINE || index_out == nullptr || ok_out == nullptr) return ADV_EINVAL;
-  const long long hw = static_cast<long long>(h) * w;
-  if (hw % 4 != 0 || !aligned(x, 16) || !aligned(clean_out, 16) || !aligned(index_out, 4) || !aligned(ok_out, 4)) return ADV_EALIGN;
+  if (space->kind != ADV_SPACE_AFFINE) return ADV_EINVAL;
+  IdxK ik;
+  rc = check_clean_index(ci, h, w, &ik);
+  if (rc != ADV_OK) return rc;
+  if (w % 4 != 0 || !aligned(x, 16) || !aligned(clean_out, 16)) return ADV_EALIGN;
+  U8Plan plan;
+  rc = plan_u8(u8_out, h, w, crop_h, crop_w, u8_row_stride, u8_image_stride, true, &plan);
+  if (rc != ADV_OK) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ok_out), 1, 1, st) != hipSuccess) return ADV_ELAUNCH;
-  const int hw4 = static_cast<int>(hw / 4);
-  hipLaunchKernelGGL(denormalize_index_vec4, wave_grid(hw4, n, 1), dim3(kWave), 0, st, reinterpret_cast<const v4f*>(x),
-                     reinterpret_cast<v4f*>(clean_out), reinterpret_cast<uint32_t*>(index_out), reinterpret_cast<int*>(ok_out),
-                     static_cast<long long>(n), hw4, to_kernel_space(space));
+  const SpaceK sp = to_kernel_space(space);
+  if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ci->ok), 1, static_cast<size_t>(n), st) != hipSuccess) return ADV_ELAUNCH;
+  hipLaunchKernelGGL(clean_lut_kernel, dim3(1), dim3(256), 0, st, ci->lut, sp);
+  const int hw4 = static_cast<int>(static_cast<long long>(h) * w / 4);
+  const dim3 grid = wave_grid(hw4, n, 1);
+  const v4f* x4 = reinterpret_cast<const v4f*>(x);
+  v4f* c4 = reinterpret_cast<v4f*>(clean_out);
+  const long long nn = n;
+  if (plan.mode == U8_NONE)
+    hipLaunchKernelGGL((clean_index_build_vec4<U8_NONE>), grid, dim3(kWave), 0, st, x4, c4, ik, nn, hw4, w, sp, plan.dst);
+  else if (plan.mode == U8_ROWS_DWORD)
+    hipLaunchKernelGGL((clean_index_build_vec4<U8_ROWS_DWORD>), grid, dim3(kWave), 0, st, x4, c4, ik, nn, hw4, w, sp, plan.dst);
+  else
+    hipLaunchKernelGGL((clean_index_build_vec4<U8_BYTES>), grid, dim3(kWave), 0, st, x4, c4, ik, nn, hw4, w, sp, plan.dst);
   return finish_launch();
 }
 
-int adv_pgd_step_indexed_f32(const float* x, const float* grad, const float* clean, const uint8_t* clean_index, const int32_t* clean_index_ok,
-                             float* x_out, uint8_t* u8_out, int64_t n, int h, int w, const adv_space_t* space, float alpha, float eps,
-                             int crop_h, int crop_w, int64_t u8_row_stride, int64_t u8_image_stride, adv_stream_t stream) {
+int adv_pgd_step_indexed_f32(const float* x, const float* grad, const float* clean, const adv_clean_index_t* ci, float* x_out,
+                             uint8_t* u8_out, int64_t n, int h, int w, const adv_space_t* space, float alpha, float eps, int crop_h,
+                             int crop_w, int64_t u8_row_stride, int64_t u8_image_stride, adv_stream_t stream) {
   int rc = check_image_args(x, x_out, n, h, w);
   if (rc != ADV_OK) return rc;
   rc = check_image_args(grad, clean, n, h, w);
   if (rc != ADV_OK) return rc;
   rc = check_space(space);
   if (rc != ADV_OK) return rc;
-  if (!(eps >= 0.0f) || space->kind != ADV_SPACE_AFFINE || clean_index == nullptr || clean_index_ok == nullptr) return ADV_EINVAL;
-  const long long hw = static_cast<long long>(h) * w;
-  if (hw % 4 != 0 || !aligned(x, 16) || !aligned(grad, 16) || !aligned(clean, 16) || !aligned(x_out, 16) || !aligned(clean_index, 4) ||
-      !aligned(clean_index_ok, 4))
-    return ADV_EALIGN;
+  if (!(eps >= 0.0f) || space->kind != ADV_SPACE_AFFINE) return ADV_EINVAL;
+  IdxK ik;
+  rc = check_clean_index(ci, h, w, &ik);
+  if (rc != ADV_OK) return rc;
+  if (w % 4 != 0 || !aligned(x, 16) || !aligned(grad, 16) || !aligned(clean, 16) || !aligned(x_out, 16)) return ADV_EALIGN;
   U8Plan plan;
   rc = plan_u8(u8_out, h, w, crop_h, crop_w, u8_row_stride, u8_image_stride, true, &plan);
   if (rc != ADV_OK) return rc;
   const SpaceK sp = to_kernel_space(space);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const int hw4 = static_cast<int>(hw / 4);
+  const int hw4 = static_cast<int>(static_cast<long long>(h) * w / 4);
   const dim3 grid = wave_grid(hw4, n, kUnroll);
   const v4f* x4 = reinterpret_cast<const v4f*>(x);
   const v4f* g4 = reinterpret_cast<const v4f*>(grad);
   const v4f* c4 = reinterpret_cast<const v4f*>(clean);
-  const uint32_t* i4 = reinterpret_cast<const uint32_t*>(clean_index);
-  const int* okp = reinterpret_cast<const int*>(clean_index_ok);
   v4f* o4 = reinterpret_cast<v4f*>(x_out);
   const long long nn = n;
   if (plan.mode == U8_NONE)
-    hipLaunchKernelGGL((pgd_step_vec4_idx<U8_NONE>), grid, dim3(kWave), 0, st, x4, g4, c4, i4, okp, o4, nn, hw4, w, sp, alpha, eps, plan.dst);
+    hipLaunchKernelGGL((pgd_step_vec4_idx<U8_NONE>), grid, dim3(kWave), 0, st, x4, g4, c4, ik, o4, nn, hw4, w, sp, alpha, eps, plan.dst);
   else if (plan.mode == U8_ROWS_DWORD)
-    hipLaunchKernelGGL((pgd_step_vec4_idx<U8_ROWS_DWORD>), grid, dim3(kWave), 0, st, x4, g4, c4, i4, okp, o4, nn, hw4, w, sp, alpha, eps, plan.dst);
+    hipLaunchKernelGGL((pgd_step_vec4_idx<U8_ROWS_DWORD>), grid, dim3(kWave), 0, st, x4, g4, c4, ik, o4, nn, hw4, w, sp, alpha, eps, plan.dst);
   else
-    hipLaunchKernelGGL((pgd_step_vec4_idx<U8_BYTES>), grid, dim3(kWave), 0, st, x4, g4, c4, i4, okp, o4, nn, hw4, w, sp, alpha, eps, plan.dst);
+    hipLaunchKernelGGL((pgd_step_vec4_idx<U8_BYTES>), grid, dim3(kWave), 0, st, x4, g4, c4, ik, o4, nn, hw4, w, sp, alpha, eps, plan.dst);
   return finish_launch();
 }
 

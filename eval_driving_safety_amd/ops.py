@@ -128,35 +128,82 @@ def normalize(x, space, out=None):
 
 
 class CleanIndex:
-    """The clean image of an attack held as one byte per element (see ``denormalize_indexed``): ``index`` uint8
-    [N,3,H,W], ``ok`` int32 [1] on the device (1 = every element verified; read by the kernels, never by the host)."""
+    """The clean image of an attack held as one byte per element (adv_clean_index_t): ``index`` uint8 [N,3,H,W],
+    ``ok`` int32 [N] (1 = every element of that image verified on the device; read by the kernels, never by the
+    host on the attack path), ``lut`` float32 [3,256], ``valid`` = (valid_h, valid_w) for the whole batch or an
+    int32 device tensor [N,2] with one such pair per image: outside that corner the loader's zero padding is
+    expected (clean == shift_c)."""
 
-    def __init__(self, index, ok):
-        self.index, self.ok = index, ok
+    def __init__(self, index, ok, lut, valid):
+        self.index, self.ok, self.lut, self.valid = index, ok, lut, valid
+        c = _lib.AdvCleanIndex()
+        c.index, c.ok, c.lut = index.data_ptr(), ok.data_ptr(), lut.data_ptr()
+        if isinstance(valid, torch.Tensor):
+            c.valid_hw, c.valid_h, c.valid_w = valid.data_ptr(), 0, 0
+        else:
+            c.valid_hw, c.valid_h, c.valid_w = None, int(valid[0]), int(valid[1])
+        self.c = c
+
+    def ref(self):
+        return ctypes.byref(self.c)
+
+    def verified(self):
+        """host copy of the per-image flags (synchronises: tests / reporting only)"""
+        return [bool(v) for v in self.ok.cpu().tolist()]
 
 
 def can_index_clean(x, space):
     xi = x if x.dim() == 4 else x.unsqueeze(0)
-    return space.affine and (xi.shape[2] * xi.shape[3]) % 4 == 0 and x.data_ptr() % 16 == 0
+    return space.affine and xi.shape[3] % 4 == 0 and x.data_ptr() % 16 == 0
 
 
-def denormalize_indexed(x, space, out=None, reuse=None):
+def _valid_arg(valid, n, h, w, device):
+    """None -> the whole frame; (vh, vw) -> every image; a list of n (vh, vw) -> int32 device tensor [n,2]"""
+    if valid is None:
+        return (h, w)
+    if isinstance(valid, torch.Tensor):
+        if not (valid.is_cuda and valid.dtype == torch.int32 and valid.is_contiguous() and tuple(valid.shape) == (n, 2)):
+            raise TypeError("valid must be a contiguous int32 CUDA tensor [%d,2]" % n)
+        return valid
+    valid = list(valid)
+    if len(valid) == 2 and not isinstance(valid[0], (tuple, list)):
+        vh, vw = int(valid[0]), int(valid[1])
+        if not (0 <= vh <= h and 0 <= vw <= w):
+            raise ValueError("valid corner %s exceeds the frame %s" % ((vh, vw), (h, w)))
+        return (vh, vw)
+    if len(valid) != n:
+        raise ValueError("valid must hold one (valid_h, valid_w) per image (%d), got %d" % (n, len(valid)))
+    if len(set(tuple(v) for v in valid)) == 1:
+        return _valid_arg(tuple(valid[0]), n, h, w, device)
+    for vh, vw in valid:
+        if not (0 <= vh <= h and 0 <= vw <= w):
+            raise ValueError("valid corner %s exceeds the frame %s" % ((vh, vw), (h, w)))
+    return torch.tensor([[int(a), int(b)] for a, b in valid], dtype=torch.int32, device=device)
+
+
+def denormalize_indexed(x, space, out=None, reuse=None, valid=None, u8_out=None, crop=None):
     """``denormalize`` plus the 8-bit index of the result: returns (clean, CleanIndex).  Pass the CleanIndex to
-    ``pgd_step(..., clean_index=...)``: every step then reads 1 byte instead of 4 for the clean image whenever the
-    device-side check succeeded (images that came from 8-bit pixels via ToTensor + Normalize), with identical results."""
+    ``pgd_step(..., clean_index=...)``: every step then reads 1 byte instead of 4 for the clean image of every image
+    whose device-side check succeeded (images that came from 8-bit pixels via ToTensor + Normalize, zero-padded
+    beyond ``valid`` = (valid_h, valid_w) or one such pair per image), with identical results.
+    ``u8_out``/``crop``: also write the 8-bit export of ``x`` (iterate 0), as ``export_u8`` would."""
     xi = _img(x, "x")
     out = torch.empty_like(x) if out is None else out
     oi = _img(out, "out")
     _same(xi, oi, "x", "out")
     n, _, h, w = xi.shape
-    if reuse is not None and tuple(reuse.index.shape) == (n, 3, h, w):
-        index, ok = reuse.index, reuse.ok             # a CleanIndex of the same shape: overwrite its buffers
+    valid = _valid_arg(valid, n, h, w, x.device)
+    if reuse is not None and tuple(reuse.index.shape) == (n, 3, h, w) and reuse.index.device == x.device:
+        ci = CleanIndex(reuse.index, reuse.ok, reuse.lut, valid)      # same shape: overwrite its buffers
     else:
-        index = torch.empty((n, 3, h, w), dtype=torch.uint8, device=x.device)
-        ok = torch.empty((1,), dtype=torch.int32, device=x.device)
+        ci = CleanIndex(torch.empty((n, 3, h, w), dtype=torch.uint8, device=x.device),
+                        torch.empty((n,), dtype=torch.int32, device=x.device),
+                        torch.empty((3, 256), dtype=torch.float32, device=x.device), valid)
+    u8p, crop_h, crop_w, rs, is_ = _u8_args(u8_out, n, h, w, crop)
     with _on(x):
-        _lib.call("adv_denormalize_index_f32", _ptr(xi), _ptr(oi), _ptr(index), _ptr(ok), n, h, w, space.ref(), _stream(x))
-    return out, CleanIndex(index, ok)
+        _lib.call("adv_clean_index_build_f32", _ptr(xi), _ptr(oi), ci.ref(), u8p, n, h, w, space.ref(), crop_h, crop_w, rs, is_,
+                  _stream(x))
+    return out, ci
 
 
 def alloc_u8(n, crop_h, w, device):
@@ -211,7 +258,7 @@ def pgd_step(x, grad, clean, space, alpha, eps, out=None, u8_out=None, crop=None
         if clean_index is not None:
             if tuple(clean_index.index.shape) != tuple(xi.shape) or clean_index.index.dtype != torch.uint8:
                 raise ValueError("clean_index does not belong to this batch")
-            _lib.call("adv_pgd_step_indexed_f32", _ptr(xi), _ptr(gi), _ptr(ci), _ptr(clean_index.index), _ptr(clean_index.ok), _ptr(oi), u8p,
+            _lib.call("adv_pgd_step_indexed_f32", _ptr(xi), _ptr(gi), _ptr(ci), clean_index.ref(), _ptr(oi), u8p,
                       n, h, w, space.ref(), float(alpha), float(eps), crop_h, crop_w, rs, is_, _stream(x))
         else:
             _lib.call("adv_pgd_step_f32", _ptr(xi), _ptr(gi), _ptr(ci), _ptr(oi), u8p, n, h, w, space.ref(),

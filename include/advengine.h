@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ADV_ABI_VERSION 1
+#define ADV_ABI_VERSION 2
 #define ADV_API __attribute__((visibility("default"))) /* the library is built with -fvisibility=hidden */
 #define ADV_CHANNELS 3
 
@@ -98,23 +98,36 @@ ADV_API int adv_pgd_step_f32(const float* x, const float* grad, const float* cle
                      float alpha, float eps, int crop_h, int crop_w, int64_t u8_row_stride,
                      int64_t u8_image_stride, adv_stream_t stream);
 
-/* a1 + index: denormalize as above AND try to hold the clean image as one byte per element.  A clean image is
- *     re-read by every PGD step, and it normally stems from 8-bit pixels v through
+/* The clean image of an attack held as ONE BYTE per element.  A clean image is re-read by every PGD step, and it normally
+ *     stems from 8-bit pixels v through
  *         t = v/255;  x0 = (t - shift)/scale;  clean = x0*scale + shift        (float32: ToTensor, Normalize, denormalize)
- *     index_out [n,3,h,w] uint8 receives v = rint(clean*255); *ok_out (DEVICE int32) is set to 1 and cleared if for any
- *     element that chain applied to v does not reproduce clean BIT FOR BIT.  Requires h*w % 4 == 0 and 16-byte
- *     aligned images.  AFFINE spaces only. */
-ADV_API int adv_denormalize_index_f32(const float* x, float* clean_out, uint8_t* index_out, int32_t* ok_out, int64_t n,
-                                      int h, int w, const adv_space_t* space, adv_stream_t stream);
+ *     zero-padded IN NORMALISED SPACE to the network size, so that outside the image's valid_h x valid_w corner the clean
+ *     value is exactly shift_c.  All pointers are DEVICE memory owned by the caller; nothing here is read by the host. */
+typedef struct adv_clean_index {
+  uint8_t* index;          /* [n,3,h,w]  v = rint(clean*255) inside the valid corner, 0 outside                       */
+  int32_t* ok;             /* [n]        1 = every element of image i verified bit for bit, 0 = read its float clean  */
+  float* lut;              /* [3*256]    T_c[v] = the chain above applied to v (16-byte aligned)                      */
+  const int32_t* valid_hw; /* [n,2] = (valid_h, valid_w) per image, or NULL: the two fields below for every image     */
+  int32_t valid_h, valid_w;
+} adv_clean_index_t;
 
-/* a3 with the indexed clean image: identical results to adv_pgd_step_f32.  When *clean_index_ok != 0 (read on the
- *     device, no host round trip) the kernel reads the 1-byte index and recomputes clean with the chain above instead
- *     of reading the float32 `clean` (14 instead of 17 bytes per element); otherwise it reads `clean` as usual.
- *     Same requirements as adv_denormalize_index_f32. */
-ADV_API int adv_pgd_step_indexed_f32(const float* x, const float* grad, const float* clean, const uint8_t* clean_index,
-                                     const int32_t* clean_index_ok, float* x_out, uint8_t* u8_out, int64_t n, int h,
-                                     int w, const adv_space_t* space, float alpha, float eps, int crop_h, int crop_w,
-                                     int64_t u8_row_stride, int64_t u8_image_stride, adv_stream_t stream);
+/* a1 + index (+ a5 for iterate 0): clean_out = x*scale+shift as adv_denormalize_f32, AND fill ci->lut, ci->index, ci->ok:
+ *     ok[i] = 1 iff for every element of image i   clean == T_c[index]  (inside the valid corner)
+ *                                                 clean == shift_c     (outside it)            BIT FOR BIT.
+ *     u8_out (nullable) receives the 8-bit export of x (= iterate 0, attack/DSGN/pgd_attack.py:279-294) exactly as
+ *     adv_export_u8_f32 would write it.  Requires w % 4 == 0 and 16-byte aligned images.  AFFINE spaces only. */
+ADV_API int adv_clean_index_build_f32(const float* x, float* clean_out, const adv_clean_index_t* ci, uint8_t* u8_out,
+                                      int64_t n, int h, int w, const adv_space_t* space, int crop_h, int crop_w,
+                                      int64_t u8_row_stride, int64_t u8_image_stride, adv_stream_t stream);
+
+/* a3 with the indexed clean image: identical results to adv_pgd_step_f32.  Images with ok[i] != 0 (read on the device,
+ *     no host round trip) are stepped reading the 1-byte index and an LDS copy of the table instead of the float32
+ *     `clean` (13 instead of 16 bytes per element, no division); the others read `clean` as usual, in the same launch.
+ *     Same requirements as adv_clean_index_build_f32, which must have filled *ci for this batch. */
+ADV_API int adv_pgd_step_indexed_f32(const float* x, const float* grad, const float* clean, const adv_clean_index_t* ci,
+                                     float* x_out, uint8_t* u8_out, int64_t n, int h, int w, const adv_space_t* space,
+                                     float alpha, float eps, int crop_h, int crop_w, int64_t u8_row_stride,
+                                     int64_t u8_image_stride, adv_stream_t stream);
 
 /* a5  the 8-bit export alone (iterate 0 = the clean image, pgd_attack.py:279-294). */
 ADV_API int adv_export_u8_f32(const float* x, uint8_t* u8_out, int64_t n, int h, int w,

@@ -108,12 +108,16 @@ DSGN_PGD = "attack/DSGN/pgd_attack.py"
 
 
 def dsgn_pgd_case(seed, h, w, crop_h, crop_w, alpha, eps, n_iter, grad_scale=1.0,
-                  specials=False, keep_arrays=True):
+                  specials=False, keep_arrays=True, padded=False):
     from PIL import Image
     ns = {"torch": torch, "np": np, "Image": Image}
     exec_toplevel(DSGN_PGD, ["mean", "std", "tensor2im", "save_img", "denormalize", "normalize"], ns)
-    x0L = synth.dsgn_normalised(seed, h, w)
-    x0R = synth.dsgn_normalised(seed + 1, h, w)
+    if padded:      # the image is crop_h x crop_w, zero-padded in normalised space to the network size h x w
+        x0L = synth.dsgn_padded(seed, crop_h, crop_w, h, w)
+        x0R = synth.dsgn_padded(seed + 1, crop_h, crop_w, h, w)
+    else:
+        x0L = synth.dsgn_normalised(seed, h, w)
+        x0R = synth.dsgn_normalised(seed + 1, h, w)
     ns.update(imgL=torch.from_numpy(x0L.copy()), imgR=torch.from_numpy(x0R.copy()),
               alpha=alpha, eps=eps)
     exec_lines(DSGN_PGD, 254, 255, ns)          # ori_img*_data
@@ -151,6 +155,8 @@ def dsgn_pgd_case(seed, h, w, crop_h, crop_w, alpha, eps, n_iter, grad_scale=1.0
             out["u8L_%d" % (k + 1)], out["u8R_%d" % (k + 1)] = u8l, u8r
     meta = dict(seed=seed, h=h, w=w, crop_h=crop_h, crop_w=crop_w, alpha=alpha, eps=eps,
                 n_iter=n_iter, grad_scale=grad_scale, specials=specials, digests=digests)
+    if padded:
+        meta["padded"] = True
     if not keep_arrays:
         out = {k: v for k, v in out.items() if k.startswith("u8") and False}
     return out, meta
@@ -435,6 +441,13 @@ def main():
     # one full-size KITTI-shaped pair: digests only, inputs regenerate from the seed
     _, meta = dsgn_pgd_case(6, 384, 1248, 375, 1242, 1 / 255, 0.03, 2, 1e-3, False, keep_arrays=False)
     index["cases"]["dsgn_pgd_fullsize"] = meta
+    # the same with the loader's zero padding (normalised space) around a crop_h x crop_w image: small with arrays,
+    # and one KITTI-shaped 375x1242 pair inside 384x1248 as digests
+    arrays, meta = dsgn_pgd_case(8, 16, 28, 13, 22, 1 / 255, 0.03, 4, 1.0, False, padded=True)
+    meta["bytes"] = save_npz("dsgn_pgd_padded.npz", arrays)
+    index["cases"]["dsgn_pgd_padded"] = meta
+    _, meta = dsgn_pgd_case(9, 384, 1248, 375, 1242, 1 / 255, 0.03, 2, 1e-3, False, keep_arrays=False, padded=True)
+    index["cases"]["dsgn_pgd_fullsize_padded"] = meta
 
     sr = [
         ("srcnn_pgd_default",  11, 20, 33, 1.0, 0.3,  4, 1.0, False),   # script defaults (:41-44)

@@ -34,6 +34,14 @@ def dsgn_normalised(seed, h, w):
     return x
 
 
+def dsgn_padded(seed, valid_h, valid_w, h, w):
+    """[1,3,h,w]: ``dsgn_normalised(seed, valid_h, valid_w)`` zero-padded bottom/right IN NORMALISED SPACE to the
+    network size, as the DSGN loader hands a 375x1242 KITTI image to the 384x1248 network."""
+    out = np.zeros((1, 3, h, w), np.float32)
+    out[:, :, :valid_h, :valid_w] = dsgn_normalised(seed, valid_h, valid_w)
+    return out
+
+
 def srcnn_meansub(seed, h, w):
     """[1,3,h,w] float32 BGR minus PIXEL_MEANS (0..255 scale)."""
     u8 = u8_image(seed, h, w)

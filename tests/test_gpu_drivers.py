@@ -45,11 +45,33 @@ def test_pgd_driver_batch_of_pairs_on_hip(tmp_path):
     for k in range(4):
         xm = O.pgd_step_norm01(xm, rec.grads[k], clean, 1 / 255, 0.03)
     assert x.cpu().numpy().tobytes() == xm.tobytes()
+    # the loader's zero-padded 375x1242 images take the 8-bit-index path, every image of the batch
+    assert atk.last_clean_index is not None and atk.last_clean_index.verified() == [True] * 6
     got = np.array(Image.open(os.path.join(str(tmp_path), "dsgn_pgd_iters_4", "image_3", "000001.png")).convert("RGB"))
     assert got.shape == (375, 1242, 3)
     assert np.array_equal(got, O.tensor2im_u8(xm[3 + 1], 375, 1242))
     got0 = np.array(Image.open(os.path.join(str(tmp_path), "dsgn_pgd_iters_0", "image_2", "000000.png")).convert("RGB"))
     assert np.array_equal(got0, O.tensor2im_u8(batch.imgL[0].numpy(), 375, 1242))
+
+
+def test_pgd_driver_one_foreign_image_keeps_the_rest_on_the_index_path(tmp_path):
+    """a pair whose left image has no 8-bit origin (here: re-scaled after loading) falls back to the float32 clean
+    image on its own; the other images of the same launches stay indexed; everything equals the oracle"""
+    from eval_driving_safety_amd import adapters, attacks, data
+    dev = torch.device("cuda", 0)
+    batch = next(iter(data.SyntheticStereo(3, "dsgn", batch=3, seed=4)))
+    batch.imgL[1, :, :375, :1242] *= 0.999
+    rec = _Recorder(adapters.ToyStereoAdapter(dev, seed=1))
+    for in_place in (False, True):
+        rec.grads = []
+        atk = attacks.PgdAttack("dsgn", 1 / 255, 0.03, 3, save=False, device=dev, in_place=in_place)
+        x = atk.run_batch(batch, rec)
+        assert atk.last_clean_index.verified() == [True, False, True, True, True, True]
+        xm = torch.cat([batch.imgL, batch.imgR]).numpy().copy()
+        clean = O.denormalize(xm)
+        for k in range(3):
+            xm = O.pgd_step_norm01(xm, rec.grads[k], clean, 1 / 255, 0.03)
+        assert x.cpu().numpy().tobytes() == xm.tobytes()
 
 
 @pytest.mark.parametrize("kind", ["dsgn", "srcnn"])

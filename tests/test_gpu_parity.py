@@ -57,7 +57,7 @@ def same_bits(a, b, what="", any_nan=False):
 
 
 # ------------------------------------------------------------------------------- golden: PGD
-DSGN_PGD = ["dsgn_pgd_default", "dsgn_pgd_fgsm", "dsgn_pgd_cfg2", "dsgn_pgd_specials", "dsgn_pgd_ragged"]
+DSGN_PGD = ["dsgn_pgd_default", "dsgn_pgd_fgsm", "dsgn_pgd_cfg2", "dsgn_pgd_specials", "dsgn_pgd_ragged", "dsgn_pgd_padded"]
 SRCNN_PGD = ["srcnn_pgd_default", "srcnn_pgd_cfg3", "srcnn_pgd_specials", "srcnn_pgd_zero_eps", "srcnn_pgd_zero_eps_tiny_alpha"]
 
 
@@ -480,49 +480,111 @@ def test_patch_windows_touching_the_image_border(ops):
             ops.patch_paste(dev(img), dev(patch), cy, cx, r)
 
 
-@pytest.mark.parametrize("name", DSGN_PGD + ["fullsize"])
+def _make_input(m, off=0):
+    if m.get("padded"):
+        return synth.dsgn_padded(m["seed"] + off, m["crop_h"], m["crop_w"], m["h"], m["w"])
+    return synth.dsgn_normalised(m["seed"] + off, m["h"], m["w"])
+
+
+@pytest.mark.parametrize("name", DSGN_PGD + ["dsgn_pgd_fullsize", "dsgn_pgd_fullsize_padded"])
 def test_indexed_clean_image_path(name, golden, golden_index, ops):
-    """the clean image held as one byte per element: verified on the device, results unchanged"""
+    """the clean image held as one byte per element: verified per image on the device, results unchanged - on
+    whole-frame 8-bit images and on images zero-padded in normalised space as the DSGN loader pads them"""
     sp = ops.Space.dsgn()
-    if name == "fullsize":
-        m = golden_index["cases"]["dsgn_pgd_fullsize"]
-        x = dev(synth.dsgn_normalised(m["seed"], m["h"], m["w"]))
-        clean, ci = ops.denormalize_indexed(x, sp)
-        assert int(ci.ok.item()) == 1, "8-bit derived input must verify"
-        u8 = ops.alloc_u8(1, m["crop_h"], m["w"], x.device)
-        for k in range(m["n_iter"]):
-            g = dev(synth.gradient(1000 * m["seed"] + 2 * k, tuple(x.shape), m["grad_scale"]))
-            ops.pgd_step(x, g, clean, sp, m["alpha"], m["eps"], out=x, u8_out=u8, crop=(m["crop_h"], m["crop_w"]), clean_index=ci)
-            assert sha(host(x)) == m["digests"]["xL_%d" % (k + 1)]
-            assert sha(host(u8)[0, :, :m["crop_w"]]) == m["digests"]["u8L_%d" % (k + 1)]
+    m = golden_index["cases"][name]
+    valid = (m["crop_h"], m["crop_w"]) if m.get("padded") else None
+    if name.startswith("dsgn_pgd_fullsize"):
+        for eye, off in (("L", 0), ("R", 1)):
+            x = dev(_make_input(m, off))
+            u8 = ops.alloc_u8(1, m["crop_h"], m["w"], x.device)
+            clean, ci = ops.denormalize_indexed(x, sp, valid=valid, u8_out=u8, crop=(m["crop_h"], m["crop_w"]))
+            assert ci.verified() == [True], "8-bit derived input must verify"
+            same_bits(host(u8), host(ops.export_u8(x, sp, (m["crop_h"], m["crop_w"]))), "fused iterate-0 export")
+            if m.get("padded"):    # without the padding rule the same image must NOT verify (0.485 is not an 8-bit level)
+                assert ops.denormalize_indexed(x, sp)[1].verified() == [False]
+            spare = torch.empty_like(x)
+            for k in range(m["n_iter"]):
+                g = dev(synth.gradient(1000 * m["seed"] + 2 * k + off, tuple(x.shape), m["grad_scale"]))
+                ops.pgd_step(x, g, clean, sp, m["alpha"], m["eps"], out=spare, u8_out=u8, crop=(m["crop_h"], m["crop_w"]), clean_index=ci)
+                x, spare = spare, x
+                assert sha(host(x)) == m["digests"]["x%s_%d" % (eye, k + 1)]
+                assert sha(host(u8)[0, :, :m["crop_w"]]) == m["digests"]["u8%s_%d" % (eye, k + 1)]
         return
-    g, m = golden(name), golden_index["cases"][name]
-    if (m["h"] * m["w"]) % 4:
+    g = golden(name)
+    if m["w"] % 4:
+        assert not ops.can_index_clean(dev(g["x0L"]), sp)
         with pytest.raises(Exception):
             ops.denormalize_indexed(dev(g["x0L"]), sp)
         return
     x = dev(g["x0L"])
-    clean, ci = ops.denormalize_indexed(x, sp)
+    u8 = ops.alloc_u8(1, m["crop_h"], m["w"], x.device)
+    clean, ci = ops.denormalize_indexed(x, sp, valid=valid, u8_out=u8, crop=(m["crop_h"], m["crop_w"]))
     same_bits(host(clean), g["cleanL"], "clean")
-    assert int(ci.ok.item()) == 1
-    same_bits(host(ci.index).astype(np.float32), np.rint(g["cleanL"] * np.float32(255)), "index = round(clean*255)")
+    same_bits(host(u8)[0, :, :m["crop_w"]], g["u8L_0"], "iterate-0 export fused into the index build")
+    assert ci.verified() == [True]
+    want_index = np.rint(g["cleanL"] * np.float32(255))
+    if valid is not None:
+        want_index[:, :, valid[0]:, :] = 0
+        want_index[:, :, :, valid[1]:] = 0
+    same_bits(host(ci.index).astype(np.float32), want_index, "index = round(clean*255) inside the valid corner, 0 outside")
+    lut = host(ci.lut)
+    for c in range(3):      # the table is the ToTensor -> Normalize -> denormalize chain of every 8-bit level
+        v = np.arange(256, dtype=np.float32) / np.float32(255)
+        t = (v - np.float32(synth.DSGN_MEAN[c])) / np.float32(synth.DSGN_STD[c])
+        same_bits(lut[c], t * np.float32(synth.DSGN_STD[c]) + np.float32(synth.DSGN_MEAN[c]), "lut channel %d" % c)
     for k in range(m["n_iter"]):
-        x = ops.pgd_step(x, dev(g["gL_%d" % k]), clean, sp, m["alpha"], m["eps"], clean_index=ci)
+        x = ops.pgd_step(x, dev(g["gL_%d" % k]), clean, sp, m["alpha"], m["eps"], u8_out=u8, crop=(m["crop_h"], m["crop_w"]), clean_index=ci)
         same_bits(host(x), g["xL_%d" % (k + 1)], "%s xL_%d (indexed)" % (name, k + 1))
+        same_bits(host(u8)[0, :, :m["crop_w"]], g["u8L_%d" % (k + 1)], "%s u8L_%d (indexed)" % (name, k + 1))
 
 
-def test_indexed_clean_falls_back_when_the_image_is_not_8bit_derived(ops):
+def test_indexed_clean_flags_are_per_image(ops):
+    """one image without an 8-bit origin (or with a dirty padding border) takes the float path; the others of the same
+    launch stay on the index path; every image equals the oracle either way"""
     sp = ops.Space.dsgn()
+    h, w, vh, vw = 24, 40, 21, 37
     rs = np.random.RandomState(3)
-    x = rs.randn(2, 3, 16, 24).astype(np.float32)            # arbitrary floats: no 8-bit origin
+    imgs = [synth.dsgn_padded(20 + i, vh, vw, h, w) for i in range(5)]
+    imgs[1] = rs.randn(1, 3, h, w).astype(np.float32)                  # arbitrary floats: no 8-bit origin
+    imgs[3] = imgs[3].copy()
+    imgs[3][0, 2, h - 1, w - 1] = np.float32(1e-3)                     # padding that is not the loader's zero
+    one_off = imgs[4].copy()
+    one_off[0, 1, 5, 7] = np.nextafter(one_off[0, 1, 5, 7], np.float32(10))   # one wrong element is enough
+    imgs.append(one_off)
+    x = np.concatenate(imgs)
     g = synth.gradient(4, x.shape)
-    clean, ci = ops.denormalize_indexed(dev(x), sp)
-    assert int(ci.ok.item()) == 0
+    clean, ci = ops.denormalize_indexed(dev(x), sp, valid=(vh, vw))
+    assert ci.verified() == [True, False, True, False, True, False]
     same_bits(host(clean), O.denormalize(x), "clean")
+    want = x
+    cur = dev(x)
+    for k in range(3):
+        cur = ops.pgd_step(cur, dev(g), clean, sp, 1 / 255, 0.03, clean_index=ci)
+        want = O.pgd_step_norm01(want, g, O.denormalize(x), 1 / 255, 0.03)
+        same_bits(host(cur), want, "mixed index / float batch, step %d" % k)
+    # per-image valid corners (KITTI frames differ by a few pixels): [n,2] on the device
+    sizes = [(21, 37), (24, 40), (19, 33), (21, 36)]
+    x = np.concatenate([synth.dsgn_padded(30 + i, vh_, vw_, h, w) for i, (vh_, vw_) in enumerate(sizes)])
+    clean, ci = ops.denormalize_indexed(dev(x), sp, valid=sizes)
+    assert ci.verified() == [True] * 4 and isinstance(ci.valid, torch.Tensor)
+    g = synth.gradient(5, x.shape)
     got = ops.pgd_step(dev(x), dev(g), clean, sp, 1 / 255, 0.03, clean_index=ci)
-    same_bits(host(got), O.pgd_step_norm01(x, g, O.denormalize(x), 1 / 255, 0.03), "fallback path")
-    # one wrong element out of a verified image is enough to clear the flag
-    y = synth.dsgn_normalised(7, 16, 24)
-    y[0, 1, 5, 7] = np.nextafter(y[0, 1, 5, 7], np.float32(10))
-    _, ci = ops.denormalize_indexed(dev(y), sp)
-    assert int(ci.ok.item()) == 0
+    same_bits(host(got), O.pgd_step_norm01(x, g, O.denormalize(x), 1 / 255, 0.03), "per-image valid corners")
+    # a valid corner that is too large for an image exposes its padding to the 8-bit check: that image falls back
+    _, ci = ops.denormalize_indexed(dev(x), sp, valid=[(21, 37)] * 4)
+    assert ci.verified() == [True, False, False, False]
+
+
+def test_indexed_extreme_values_fall_back(ops):
+    """NaN / inf / huge inputs never verify and never crash the index build"""
+    sp = ops.Space.dsgn()
+    x = synth.dsgn_normalised(3, 8, 16)
+    for bad in (np.float32("nan"), np.float32("inf"), -np.float32("inf"), np.float32(3e38), np.float32(-1e-45)):
+        y = x.copy()
+        y[0, 0, 3, 5] = bad
+        clean, ci = ops.denormalize_indexed(dev(y), sp)
+        assert ci.verified() == [False]
+        same_bits(host(clean), O.denormalize(y), "clean", any_nan=True)
+        g = synth.gradient(6, y.shape)
+        got = ops.pgd_step(dev(y), dev(g), clean, sp, 1 / 255, 0.03, clean_index=ci)
+        same_bits(host(got), O.pgd_step_norm01(y, g, O.denormalize(y), 1 / 255, 0.03), "fallback", any_nan=True)

@@ -22,7 +22,7 @@ def same_bits(a, b):
         raise AssertionError("bit mismatch, first differing byte %d of %d" % (bad[0], a.nbytes))
 
 
-DSGN_PGD = ["dsgn_pgd_default", "dsgn_pgd_fgsm", "dsgn_pgd_cfg2", "dsgn_pgd_specials", "dsgn_pgd_ragged"]
+DSGN_PGD = ["dsgn_pgd_default", "dsgn_pgd_fgsm", "dsgn_pgd_cfg2", "dsgn_pgd_specials", "dsgn_pgd_ragged", "dsgn_pgd_padded"]
 SRCNN_PGD = ["srcnn_pgd_default", "srcnn_pgd_cfg3", "srcnn_pgd_specials", "srcnn_pgd_zero_eps", "srcnn_pgd_zero_eps_tiny_alpha"]
 
 
@@ -41,10 +41,14 @@ def test_dsgn_pgd_steps(name, golden, golden_index):
             assert sha(x) == m["digests"]["x%s_%d" % (eye, k + 1)]
 
 
-def test_dsgn_pgd_fullsize_digests(golden_index):
-    m = golden_index["cases"]["dsgn_pgd_fullsize"]
+@pytest.mark.parametrize("case", ["dsgn_pgd_fullsize", "dsgn_pgd_fullsize_padded"])
+def test_dsgn_pgd_fullsize_digests(case, golden_index):
+    m = golden_index["cases"][case]
     for eye, off in (("L", 0), ("R", 1)):
-        x = synth.dsgn_normalised(m["seed"] + off, m["h"], m["w"])
+        if m.get("padded"):     # a 375x1242 image zero-padded in normalised space to the 384x1248 network size
+            x = synth.dsgn_padded(m["seed"] + off, m["crop_h"], m["crop_w"], m["h"], m["w"])
+        else:
+            x = synth.dsgn_normalised(m["seed"] + off, m["h"], m["w"])
         clean = O.denormalize(x)
         for k in range(m["n_iter"]):
             g = synth.gradient(1000 * m["seed"] + 2 * k + off, x.shape, m["grad_scale"])
