@@ -12,7 +12,7 @@ loop body around the detector call (attack/DSGN/pgd_attack.py:279-374):
     clean = denormalize(x0), export iterate 0       (:279-298)  adv_clean_index_build_f32 (one pass: clean image, its
                                                                 per-image device-verified 8-bit index, the 8-bit export)
     20 x { step + project + re-normalise + export } (:339-374)  adv_pgd_step_indexed_f32 (one launch, both eyes of every
-                                                                pair of the batch, two alternating iterate buffers)
+                                                                pair of the batch, the iterate updated in place)
 The input is what the reference's loader hands over: 8-bit 375x1242 images (low-pass
 noise; the right eye is the left one shifted by a ground-plane disparity) -> /255 -> ImageNet normalisation ->
 ZERO-PADDED in normalised space to 384x1248.  `float_path` in the JSON line is the same attack with every stream read
@@ -52,12 +52,13 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-clean-index", action="store_true",
                     help="headline = the all-float32 path (the clean image read as float32 in every step)")
-    ap.add_argument("--in-place", action="store_true", help="update the iterate in place instead of alternating two buffers")
+    ap.add_argument("--alternate", action="store_true", help="alternate two iterate buffers instead of updating in place (same speed within 1 %%)")
     ap.add_argument("--unpadded", action="store_true", help="fill the whole 384x1248 frame with 8-bit pixels (round-1 input; no padding)")
     ap.add_argument("--no-float-path", action="store_true", help="skip the second (all-float32) measurement")
     ap.add_argument("--no-srcnn", action="store_true", help="skip the configs[2] (Stereo R-CNN shape) object")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the (separately reported) surrogate-detector attack")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs in the CPU-baseline sample (0 = auto)")
+    ap.add_argument("--torch-cpu-baseline", action="store_true", help="(internal) print the torch-CPU baseline object and exit; touches no GPU")
     return ap.parse_args()
 
 
@@ -95,21 +96,33 @@ def cpu_baseline(sample_pairs):
     dt = time.perf_counter() - t0
     out = {"value": done / dt, "unit": "stereo-pairs/s", "cores": int(cores), "kind": "port",
            "sample": "%d KITTI-shaped pairs x 20-step PGD + 8-bit export, %s, %.1f s" % (done, kind_note, dt)}
-    try:
-        out["torch_cpu"] = torch_cpu_baseline(x0, g)
-    except Exception as e:                                   # never lose the bench line over the second baseline
-        out["torch_cpu"] = {"error": repr(e)}
+    out["torch_cpu"] = torch_cpu_subprocess()
     return out
 
 
-def torch_cpu_baseline(x0_np, g_np, budget_s=10.0):
+def torch_cpu_subprocess(timeout_s=90):
+    """run `bench.py --torch-cpu-baseline` in a fresh process: its intra-op thread pool must not fight the C oracle's
+    OpenMP team (measured: 125 s per pair when both live in one process, 256 + 128 spinning threads)"""
+    import subprocess
+    try:
+        p = subprocess.run([sys.executable, os.path.abspath(__file__), "--torch-cpu-baseline"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           text=True, timeout=timeout_s, env=dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES=""))
+        return json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    except Exception as e:                                   # never lose the bench line over the second baseline
+        return {"error": repr(e)}
+
+
+def torch_cpu_baseline(budget_s=10.0):
     """attack/DSGN/pgd_attack.py:196-207,339-354 + tensor2im (:157-179) as torch-CPU eager ops, one pair per pass as the
-    reference runs it (batch 1), every host thread available to torch."""
+    reference runs it (batch 1), torch's default intra-op thread count (= what the reference script would get)."""
     import numpy as np
     import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import synth
+    x0_np = np.concatenate([synth.dsgn_padded(i, CROP_H, CROP_W, H, W) for i in range(2)])
+    g_np = synth.gradient(3, x0_np.shape, 1.0)
     mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
-    threads = os.cpu_count() or 1
-    torch.set_num_threads(threads)
+    threads = torch.get_num_threads()
 
     def denormalize(im):                                     # :196-200
         for i in range(3):
@@ -259,6 +272,9 @@ class PgdBench:
 def main():
     args = parse()
     global H, W, CROP_H, CROP_W, ALPHA, EPS
+    if args.torch_cpu_baseline:
+        print(json.dumps(torch_cpu_baseline()), flush=True)
+        return
     srcnn = args.workload == "srcnn"
     if srcnn:   # attack/Stereo-RCNN/pgd_attack.py: network scale 600x1987, no crop (quirk Q14), alpha 1.0, eps = 255*0.03 (:57)
         H, W, CROP_H, CROP_W, ALPHA, EPS = SR_H, SR_W, SR_H, SR_W, 1.0, 255 * 0.03
@@ -310,7 +326,7 @@ def main():
     grad = torch.randn((n_img, 3, H, W), device=dev, generator=gen)
     crop = (CROP_H, CROP_W)
     use_index = (not srcnn) and (not args.no_clean_index)
-    main_b = PgdBench(torch, ops, sp, x0, grad, valid, crop, use_index, args.in_place, affine=not srcnn)
+    main_b = PgdBench(torch, ops, sp, x0, grad, valid, crop, use_index, (not args.alternate), affine=not srcnn)
     elapsed, kern_ms = main_b.timed(args.steps, args.warmup, fence)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -327,7 +343,7 @@ def main():
     float_path = None
     if not srcnn and use_index and not args.no_float_path:
         del main_b.a, main_b.b
-        fb = PgdBench(torch, ops, sp, x0, grad, valid, crop, False, args.in_place)
+        fb = PgdBench(torch, ops, sp, x0, grad, valid, crop, False, (not args.alternate))
         fe, fk = fb.timed(max(2, args.steps // 3), 1, fence)
         fsteps = max(2, args.steps // 3)
         float_path = {"value": world * args.pairs * fsteps / fe, "unit": "stereo-pairs/s", "ms_per_step": 1e3 * fe / fsteps,
@@ -358,7 +374,7 @@ def main():
                                                          if not args.unpadded else "images filling the whole 1248x384 frame (no padding)",
                                                          args.pairs)),
                        "pairs_per_gpu": args.pairs, "pgd_iters": N_ITER, "eps": EPS, "alpha": ALPHA,
-                       "iterate_buffers": "in place" if args.in_place else "two alternating",
+                       "iterate_buffers": "in place" if (not args.alternate) else "two alternating",
                        "parallelism": "image-sharded x%d, no collective" % world},
             "roofline": {"bound": "hbm", "kernel": kern_name,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

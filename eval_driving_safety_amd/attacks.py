@@ -71,7 +71,7 @@ class PgdAttack:
     """
 
     def __init__(self, model_kind, alpha, eps, iters, out_root=".", save=True, save_every=1, writer_workers=None,
-                 ops=None, device=None, in_place=False):
+                 ops=None, device=None, in_place=True):
         if writer_workers is None:                   # PNG (zlib) encoding is the I/O wall: 42 files per pair at N = 20
             writer_workers = min(16, max(4, (os.cpu_count() or 8) // 4))
         self.ops = ops if ops is not None else _default_ops()
@@ -132,9 +132,9 @@ class PgdAttack:
             exporter.submit(self._fan_out(0, batch))
         self.last_clean_index = cidx
         losses = []
-        # Two alternating buffers: the step kernels measured 3-5 % faster writing a different buffer than the one they
-        # read (profiles/r02_k1_idx_tuning.md), and the line-aligned kernel for planes that are not whole cache lines
-        # (Stereo R-CNN) fuses the export only out of place.  ``in_place=True`` trades that for one buffer less.
+        # In place by default: every step kernel (also the line-aligned one for Stereo R-CNN's planes) reads only the
+        # elements it writes.  Two alternating buffers measured the same within 1 % (profiles/r02_k1_idx_tuning.md);
+        # ``in_place=False`` keeps the previous iterate intact for callers that want it.
         pingpong = not self.in_place
         spare = torch.empty_like(x) if pingpong else None
         for k in range(self.iters):

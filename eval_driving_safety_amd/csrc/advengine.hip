@@ -100,7 +100,11 @@ __device__ __forceinline__ uint32_t export_byte(float xo, float sc, float sh, do
   return round_sat_byte(f);
 }
 
-enum U8Mode { U8_NONE = 0, U8_ROWS_DWORD = 1, U8_BYTES = 2 };
+// U8_ROWS_DWORD: w % 4 == 0 and whole rows -> a pixel group never leaves its row, one aligned 12-byte store;
+// U8_FLAT_DWORD: dense uncropped image (pitch 3*w, all h rows; Stereo R-CNN's 600 x 1987, which is never cropped) ->
+//                the HWC bytes of pixel group q are the 12 bytes at offset 12*q whatever w is;
+// U8_BYTES: anything else, byte stores.
+enum U8Mode { U8_NONE = 0, U8_ROWS_DWORD = 1, U8_BYTES = 2, U8_FLAT_DWORD = 3 };
 
 struct U8Dst {
   uint8_t* base;
@@ -136,6 +140,8 @@ __device__ __forceinline__ void store_u8_group(const v4f O[3], long long img, in
       const int col = p - row * w;
       st_stream(reinterpret_cast<v3u*>(u8.base + img * u8.image_stride + row * u8.row_stride + col * 3LL), pack_hwc4<KIND>(O, sp));
     }
+  } else if (U8 == U8_FLAT_DWORD) {
+    st_stream(reinterpret_cast<v3u*>(u8.base + img * u8.image_stride + 12LL * q), pack_hwc4<KIND>(O, sp));
   } else if (U8 == U8_BYTES) {  // any pitch / crop: per-pixel byte stores
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -387,17 +393,20 @@ __global__ __launch_bounds__(kWave) void clean_index_build_vec4(const v4f* x, v4
 // line, so no common pixel tiling is line-aligned in all of them: the plain kernel's 1 KiB wave accesses
 // straddle 9 lines instead of 8 (PMC: 1.094 x the algorithmic read bytes, 0.65 of peak instead of 0.76).
 // Here every channel gets its OWN tile origin, shifted by its misalignment m_c (in float4, 0..7), so that
-// every wave access of every plane is line-aligned; the fused export needs the three channels of the
-// SAME pixels, so each lane packs its 4 pixels of a channel into one 32-bit word, the words are exchanged
-// through LDS (index shifted by m_c - m_0), and the <= 7 pixel groups per channel that belong to a
-// neighbouring tile are recomputed by a few "halo" lanes (<= 6 extra lines per 288 fetched).
+// every wave access of every plane is line-aligned: workgroup `tile` owns pixel groups
+// [tile - m_c, tile - m_c + 256) of channel c.  The fused export needs the three channels of the SAME pixels:
+// each lane packs its 4 pixels of a channel into one 32-bit word, the words are exchanged through LDS, and the
+// groups all three channels of this workgroup cover - [tile - m_min, tile - m_max + 256), all but <= 7 - leave as
+// aligned 12-byte stores.  The few groups at the two ends, whose channels are split between this workgroup and a
+// neighbour, are written by BOTH as single bytes, each storing the channels it owns (distinct bytes, no race).
+// No lane ever reads an element it does not own, so x_out may alias x (in place) with the export on - round 1's
+// version re-read neighbours' x in "halo" lanes and could not.
 // Workgroup = 256 lanes = 256 pixel groups per channel; grid = (tiles, images).
 // ------------------------------------------------------------------------------------------
 #ifndef ADV_SHIFT_BLOCK
 #define ADV_SHIFT_BLOCK 256
 #endif
 constexpr int kShiftBlock = ADV_SHIFT_BLOCK;
-constexpr int kHalo = 8;
 
 template <int KIND>
 __device__ __forceinline__ uint32_t pack_channel4(const v4f& o, float sc, float sh, double add) {
@@ -405,18 +414,40 @@ __device__ __forceinline__ uint32_t pack_channel4(const v4f& o, float sc, float 
          (export_byte<KIND>(o[2], sc, sh, add) << 16) | (export_byte<KIND>(o[3], sc, sh, add) << 24);
 }
 
+// the 4 bytes of channel c of pixel group q, one by one (any layout)
+template <int U8>
+__device__ __forceinline__ void store_channel_bytes(uint32_t word, int c, long long img, int q, int w, const U8Dst& u8) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int p = q * 4 + k;
+    uint8_t* dst;
+    if (U8 == U8_FLAT_DWORD) {
+      dst = u8.base + img * u8.image_stride + 3LL * p + c;
+    } else {
+      const int row = p / w;
+      const int col = p - row * w;
+      if (row >= u8.crop_h || col >= u8.ncols) continue;
+      dst = u8.base + img * u8.image_stride + row * u8.row_stride + col * 3LL + c;
+    }
+    *dst = static_cast<uint8_t>((word >> (8 * k)) & 0xffu);
+  }
+}
+
 template <int KIND, int U8>
 __global__ __launch_bounds__(kShiftBlock) void pgd_step_shifted(const v4f* x, const v4f* __restrict__ g,
                                                                 const v4f* __restrict__ cl, v4f* xo, long long n_img, int hw4,
                                                                 int w, int base_f4, SpaceK sp, float alpha, float eps, U8Dst u8) {
-  __shared__ uint32_t words[3][kShiftBlock + 2 * kHalo];
+  __shared__ uint32_t words[3][kShiftBlock];
   const int j = threadIdx.x;
+  constexpr bool kExchange = (U8 == U8_ROWS_DWORD || U8 == U8_FLAT_DWORD);
   for (long long img = blockIdx.y; img < n_img; img += gridDim.y) {
     const long long plane0 = img * 3LL * hw4;
     int m[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) m[c] = static_cast<int>((base_f4 + plane0 + static_cast<long long>(c) * hw4) & 7);
+    const int m_min = min(m[0], min(m[1], m[2])), m_max = max(m[0], max(m[1], m[2]));
     const int tile = blockIdx.x * kShiftBlock;
+    const int common_lo = tile - m_min, common_hi = min(tile - m_max + kShiftBlock, hw4);  // groups all 3 channels cover here
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const int q = tile - m[c] + j;  // this lane's pixel group in channel c: line-aligned per wave
@@ -427,58 +458,36 @@ __global__ __launch_bounds__(kShiftBlock) void pgd_step_shifted(const v4f* x, co
 #pragma unroll
         for (int k = 0; k < 4; ++k) O[k] = pgd_elem<KIND>(X[k], G[k], C[k], sp.scale[c], sp.shift[c], sp.lo[c], sp.hi[c], alpha, eps);
         st_stream(xo + i, O);
-        if (U8 != U8_NONE) words[c][kHalo + j] = pack_channel4<KIND>(O, sp.scale[c], sp.shift[c], sp.export_add[c]);
-      }
-    }
-    if (U8 != U8_NONE) {
-      // halo: channel c holds reference group (tile - m0 + jj) at local index jj + s, s = m_c - m_0; the indices
-      // that fall outside [0, 256) are recomputed here (values only - their x_out is stored by the owning tile)
-#pragma unroll
-      for (int c = 1; c < 3; ++c) {
-        const int s = m[c] - m[0];
-        const int as = s < 0 ? -s : s;
-        if (j < as) {
-          const int local = s > 0 ? kShiftBlock + j : -as + j;
-          const int q = tile - m[c] + local;
-          if (q >= 0 && q < hw4) {
-            const long long i = plane0 + static_cast<long long>(c) * hw4 + q;
-            const v4f X = x[i], G = g[i], C = cl[i];
-            v4f O;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) O[k] = pgd_elem<KIND>(X[k], G[k], C[k], sp.scale[c], sp.shift[c], sp.lo[c], sp.hi[c], alpha, eps);
-            words[c][kHalo + local] = pack_channel4<KIND>(O, sp.scale[c], sp.shift[c], sp.export_add[c]);
+        if (U8 != U8_NONE) {
+          const uint32_t word = pack_channel4<KIND>(O, sp.scale[c], sp.shift[c], sp.export_add[c]);
+          if (kExchange) {
+            words[c][j] = word;
+            if (q < common_lo || q >= common_hi) store_channel_bytes<U8>(word, c, img, q, w, u8);  // <= 7 groups per end
+          } else {
+            store_channel_bytes<U8>(word, c, img, q, w, u8);
           }
         }
       }
+    }
+    if (kExchange) {
       __syncthreads();
-      const int q0 = tile - m[0] + j;
-      if (q0 >= 0 && q0 < hw4) {
-        const uint32_t w0 = words[0][kHalo + j];
-        const uint32_t w1 = words[1][kHalo + j + (m[1] - m[0])];
-        const uint32_t w2 = words[2][kHalo + j + (m[2] - m[0])];
-        if (U8 == U8_ROWS_DWORD) {
+      const int q0 = common_lo + j;
+      if (q0 >= 0 && q0 < common_hi) {
+        const uint32_t w0 = words[0][j + m[0] - m_min];
+        const uint32_t w1 = words[1][j + m[1] - m_min];
+        const uint32_t w2 = words[2][j + m[2] - m_min];
+        v3u r;  // bytes: p0c0 p0c1 p0c2 p1c0 | p1c1 p1c2 p2c0 p2c1 | p2c2 p3c0 p3c1 p3c2
+        r[0] = (w0 & 0xffu) | ((w1 & 0xffu) << 8) | ((w2 & 0xffu) << 16) | (((w0 >> 8) & 0xffu) << 24);
+        r[1] = ((w1 >> 8) & 0xffu) | (((w2 >> 8) & 0xffu) << 8) | (((w0 >> 16) & 0xffu) << 16) | (((w1 >> 16) & 0xffu) << 24);
+        r[2] = ((w2 >> 16) & 0xffu) | (((w0 >> 24) & 0xffu) << 8) | (((w1 >> 24) & 0xffu) << 16) | (((w2 >> 24) & 0xffu) << 24);
+        if (U8 == U8_FLAT_DWORD) {
+          st_stream(reinterpret_cast<v3u*>(u8.base + img * u8.image_stride + 12LL * q0), r);
+        } else {
           const int p = q0 * 4;
           const int row = p / w;
           if (row < u8.crop_h) {
             const int col = p - row * w;
-            v3u r;  // bytes: p0c0 p0c1 p0c2 p1c0 | p1c1 p1c2 p2c0 p2c1 | p2c2 p3c0 p3c1 p3c2
-            r[0] = (w0 & 0xffu) | ((w1 & 0xffu) << 8) | ((w2 & 0xffu) << 16) | (((w0 >> 8) & 0xffu) << 24);
-            r[1] = ((w1 >> 8) & 0xffu) | (((w2 >> 8) & 0xffu) << 8) | (((w0 >> 16) & 0xffu) << 16) | (((w1 >> 16) & 0xffu) << 24);
-            r[2] = ((w2 >> 16) & 0xffu) | (((w0 >> 24) & 0xffu) << 8) | (((w1 >> 24) & 0xffu) << 16) | (((w2 >> 24) & 0xffu) << 24);
             st_stream(reinterpret_cast<v3u*>(u8.base + img * u8.image_stride + row * u8.row_stride + col * 3LL), r);
-          }
-        } else {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const int p = q0 * 4 + k;
-            const int row = p / w;
-            const int col = p - row * w;
-            if (row < u8.crop_h && col < u8.ncols) {
-              uint8_t* dst = u8.base + img * u8.image_stride + row * u8.row_stride + col * 3LL;
-              dst[0] = static_cast<uint8_t>((w0 >> (8 * k)) & 0xffu);
-              dst[1] = static_cast<uint8_t>((w1 >> (8 * k)) & 0xffu);
-              dst[2] = static_cast<uint8_t>((w2 >> (8 * k)) & 0xffu);
-            }
           }
         }
       }
@@ -518,18 +527,18 @@ __global__ __launch_bounds__(kBlock) void pgd_step_scalar(const float* __restric
 }
 
 // K5 alone: read the image once, write the HWC bytes
-template <int KIND>
+template <int KIND, int U8>
 __global__ __launch_bounds__(kWave) void export_u8_vec4(const v4f* __restrict__ x, long long n_img, int hw4, int w, SpaceK sp,
                                                         U8Dst u8) {
   const int stride = gridDim.x * kWave;
   for (long long img = blockIdx.y; img < n_img; img += gridDim.y) {
     const long long plane0 = img * 3LL * hw4;
     for (int q = blockIdx.x * kWave + threadIdx.x; q < hw4; q += stride) {
-      if ((q * 4) / w >= u8.crop_h) break;  // rows only grow with q
+      if (U8 == U8_ROWS_DWORD && (q * 4) / w >= u8.crop_h) break;  // rows only grow with q
       v4f O[3];
 #pragma unroll
       for (int c = 0; c < 3; ++c) O[c] = ld_stream(x + plane0 + static_cast<long long>(c) * hw4 + q);
-      store_u8_group<KIND, U8_ROWS_DWORD>(O, img, q, w, sp, u8);
+      store_u8_group<KIND, U8>(O, img, q, w, sp, u8);
     }
   }
 }
@@ -761,7 +770,7 @@ struct U8Plan {
 };
 
 inline int plan_u8(uint8_t* u8, int h, int w, int crop_h, int crop_w, long long row_stride, long long image_stride,
-                   bool vec_ok, U8Plan* out) {
+                   bool vec_ok, U8Plan* out, bool allow_flat = true) {
   out->dst = U8Dst{nullptr, 0, 0, 0, 0};
   out->mode = U8_NONE;
   if (u8 == nullptr) return ADV_OK;
@@ -772,7 +781,9 @@ inline int plan_u8(uint8_t* u8, int h, int w, int crop_h, int crop_w, long long 
   out->dst = U8Dst{u8, row_stride, image_stride, crop_h, whole_rows ? w : crop_w};
   const bool dword_ok = vec_ok && whole_rows && (w % 4 == 0) && (row_stride % 4 == 0) && (image_stride % 4 == 0) &&
                         aligned(u8, 4) && image_stride >= row_stride * (crop_h - 1) + 3LL * w;
-  out->mode = dword_ok ? U8_ROWS_DWORD : U8_BYTES;
+  const bool flat_ok = allow_flat && vec_ok && row_stride == 3LL * w && crop_h == h && crop_w == w && (image_stride % 4 == 0) && aligned(u8, 4) &&
+                       image_stride >= 3LL * h * w;
+  out->mode = dword_ok ? U8_ROWS_DWORD : (flat_ok ? U8_FLAT_DWORD : U8_BYTES);
   return ADV_OK;
 }
 
@@ -793,11 +804,7 @@ int launch_pgd(const float* x, const float* g, const float* cl, float* xo, long 
   const uintptr_t res = reinterpret_cast<uintptr_t>(x) & 127;
   const bool same_residue = (reinterpret_cast<uintptr_t>(g) & 127) == res && (reinterpret_cast<uintptr_t>(cl) & 127) == res &&
                             (reinterpret_cast<uintptr_t>(xo) & 127) == res;
-  // the shifted kernel's halo lanes re-read x of pixel groups owned by a neighbouring workgroup, which an in-place
-  // update may already have overwritten: with the export on it therefore needs x_out != x (no overlap at all)
-  const bool overlap = !(reinterpret_cast<const char*>(xo) + n * 3 * hw * 4 <= reinterpret_cast<const char*>(x) ||
-                         reinterpret_cast<const char*>(x) + n * 3 * hw * 4 <= reinterpret_cast<const char*>(xo));
-  if (vec && same_residue && (((hw / 4) & 7) != 0 || res != 0) && (plan.mode == U8_NONE || !overlap)) {
+  if (vec && same_residue && (((hw / 4) & 7) != 0 || res != 0)) {
     // planes are not whole cache lines (or the buffers start inside one): per-channel shifted tiles
     const int hw4 = static_cast<int>(hw / 4);
     const int tiles = (hw4 + 7 + kShiftBlock - 1) / kShiftBlock;
@@ -807,12 +814,15 @@ int launch_pgd(const float* x, const float* g, const float* cl, float* xo, long 
     const v4f* g4 = reinterpret_cast<const v4f*>(g);
     const v4f* c4 = reinterpret_cast<const v4f*>(cl);
     v4f* o4 = reinterpret_cast<v4f*>(xo);
-    if (plan.mode == U8_NONE)
-      hipLaunchKernelGGL((pgd_step_shifted<KIND, U8_NONE>), grid, dim3(kShiftBlock), 0, st, x4, g4, c4, o4, n, hw4, w, base_f4, sp, alpha, eps, plan.dst);
-    else if (plan.mode == U8_ROWS_DWORD)
-      hipLaunchKernelGGL((pgd_step_shifted<KIND, U8_ROWS_DWORD>), grid, dim3(kShiftBlock), 0, st, x4, g4, c4, o4, n, hw4, w, base_f4, sp, alpha, eps, plan.dst);
-    else
-      hipLaunchKernelGGL((pgd_step_shifted<KIND, U8_BYTES>), grid, dim3(kShiftBlock), 0, st, x4, g4, c4, o4, n, hw4, w, base_f4, sp, alpha, eps, plan.dst);
+#define ADV_LAUNCH_SHIFTED(MODE) \
+  hipLaunchKernelGGL((pgd_step_shifted<KIND, MODE>), grid, dim3(kShiftBlock), 0, st, x4, g4, c4, o4, n, hw4, w, base_f4, sp, alpha, eps, plan.dst)
+    switch (plan.mode) {
+      case U8_NONE: ADV_LAUNCH_SHIFTED(U8_NONE); break;
+      case U8_ROWS_DWORD: ADV_LAUNCH_SHIFTED(U8_ROWS_DWORD); break;
+      case U8_FLAT_DWORD: ADV_LAUNCH_SHIFTED(U8_FLAT_DWORD); break;
+      default: ADV_LAUNCH_SHIFTED(U8_BYTES); break;
+    }
+#undef ADV_LAUNCH_SHIFTED
   } else if (vec) {
     const int hw4 = static_cast<int>(hw / 4);
     const dim3 grid = wave_grid(hw4, n, kUnroll);
@@ -820,12 +830,15 @@ int launch_pgd(const float* x, const float* g, const float* cl, float* xo, long 
     const v4f* g4 = reinterpret_cast<const v4f*>(g);
     const v4f* c4 = reinterpret_cast<const v4f*>(cl);
     v4f* o4 = reinterpret_cast<v4f*>(xo);
-    if (plan.mode == U8_NONE)
-      hipLaunchKernelGGL((pgd_step_vec4<KIND, U8_NONE>), grid, dim3(kWave), 0, st, x4, g4, c4, o4, n, hw4, w, sp, alpha, eps, plan.dst);
-    else if (plan.mode == U8_ROWS_DWORD)
-      hipLaunchKernelGGL((pgd_step_vec4<KIND, U8_ROWS_DWORD>), grid, dim3(kWave), 0, st, x4, g4, c4, o4, n, hw4, w, sp, alpha, eps, plan.dst);
-    else
-      hipLaunchKernelGGL((pgd_step_vec4<KIND, U8_BYTES>), grid, dim3(kWave), 0, st, x4, g4, c4, o4, n, hw4, w, sp, alpha, eps, plan.dst);
+#define ADV_LAUNCH_VEC4(MODE) \
+  hipLaunchKernelGGL((pgd_step_vec4<KIND, MODE>), grid, dim3(kWave), 0, st, x4, g4, c4, o4, n, hw4, w, sp, alpha, eps, plan.dst)
+    switch (plan.mode) {
+      case U8_NONE: ADV_LAUNCH_VEC4(U8_NONE); break;
+      case U8_ROWS_DWORD: ADV_LAUNCH_VEC4(U8_ROWS_DWORD); break;
+      case U8_FLAT_DWORD: ADV_LAUNCH_VEC4(U8_FLAT_DWORD); break;
+      default: ADV_LAUNCH_VEC4(U8_BYTES); break;
+    }
+#undef ADV_LAUNCH_VEC4
   } else {
     const dim3 grid = stream_grid(hw, n);
     hipLaunchKernelGGL((pgd_step_scalar<KIND>), grid, dim3(kBlock), 0, st, x, g, cl, xo, n, static_cast<int>(hw), w, sp, alpha, eps, plan.dst);
@@ -984,7 +997,7 @@ int adv_clean_index_build_f32(const float* x, float* clean_out, const adv_clean_
   if (rc != ADV_OK) return rc;
   if (w % 4 != 0 || !aligned(x, 16) || !aligned(clean_out, 16)) return ADV_EALIGN;
   U8Plan plan;
-  rc = plan_u8(u8_out, h, w, crop_h, crop_w, u8_row_stride, u8_image_stride, true, &plan);
+  rc = plan_u8(u8_out, h, w, crop_h, crop_w, u8_row_stride, u8_image_stride, true, &plan, false);
   if (rc != ADV_OK) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const SpaceK sp = to_kernel_space(space);
@@ -1019,7 +1032,7 @@ int adv_pgd_step_indexed_f32(const float* x, const float* grad, const float* cle
   if (rc != ADV_OK) return rc;
   if (w % 4 != 0 || !aligned(x, 16) || !aligned(grad, 16) || !aligned(clean, 16) || !aligned(x_out, 16)) return ADV_EALIGN;
   U8Plan plan;
-  rc = plan_u8(u8_out, h, w, crop_h, crop_w, u8_row_stride, u8_image_stride, true, &plan);
+  rc = plan_u8(u8_out, h, w, crop_h, crop_w, u8_row_stride, u8_image_stride, true, &plan, false);
   if (rc != ADV_OK) return rc;
   const SpaceK sp = to_kernel_space(space);
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -1054,14 +1067,18 @@ int adv_export_u8_f32(const float* x, uint8_t* u8_out, int64_t n, int h, int w, 
   const SpaceK sp = to_kernel_space(space);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const long long nn = n;
-  if (plan.mode == U8_ROWS_DWORD) {
+  if (plan.mode == U8_ROWS_DWORD || plan.mode == U8_FLAT_DWORD) {
     const int hw4 = static_cast<int>(hw / 4);
-    const dim3 grid = wave_grid(static_cast<long long>(crop_h) * w / 4, nn, 1);
+    const dim3 grid = wave_grid(plan.mode == U8_ROWS_DWORD ? static_cast<long long>(crop_h) * w / 4 : hw4, nn, 1);
     const v4f* x4 = reinterpret_cast<const v4f*>(x);
-    if (space->kind == ADV_SPACE_AFFINE)
-      hipLaunchKernelGGL((export_u8_vec4<ADV_SPACE_AFFINE>), grid, dim3(kWave), 0, st, x4, nn, hw4, w, sp, plan.dst);
-    else
-      hipLaunchKernelGGL((export_u8_vec4<ADV_SPACE_IDENTITY>), grid, dim3(kWave), 0, st, x4, nn, hw4, w, sp, plan.dst);
+    const bool rows = plan.mode == U8_ROWS_DWORD;
+    if (space->kind == ADV_SPACE_AFFINE) {
+      if (rows) hipLaunchKernelGGL((export_u8_vec4<ADV_SPACE_AFFINE, U8_ROWS_DWORD>), grid, dim3(kWave), 0, st, x4, nn, hw4, w, sp, plan.dst);
+      else hipLaunchKernelGGL((export_u8_vec4<ADV_SPACE_AFFINE, U8_FLAT_DWORD>), grid, dim3(kWave), 0, st, x4, nn, hw4, w, sp, plan.dst);
+    } else {
+      if (rows) hipLaunchKernelGGL((export_u8_vec4<ADV_SPACE_IDENTITY, U8_ROWS_DWORD>), grid, dim3(kWave), 0, st, x4, nn, hw4, w, sp, plan.dst);
+      else hipLaunchKernelGGL((export_u8_vec4<ADV_SPACE_IDENTITY, U8_FLAT_DWORD>), grid, dim3(kWave), 0, st, x4, nn, hw4, w, sp, plan.dst);
+    }
   } else {
     const dim3 grid = stream_grid(hw, nn);
     if (space->kind == ADV_SPACE_AFFINE)

@@ -226,12 +226,6 @@ def _u8_args(u8, n, h, w, crop):
     return _ptr(u8), crop_h, crop_w, u8.stride(1), u8.stride(0)
 
 
-def prefers_out_of_place(h, w):
-    """True when the [3,h,w] planes are not whole 128-byte lines (Stereo R-CNN's 600x1987): the line-aligned
-    kernel for such shapes can only fuse the 8-bit export when ``out`` is a different buffer than ``x``."""
-    return (h * w) % 4 == 0 and ((h * w) // 4) % 8 != 0
-
-
 def pgd_step(x, grad, clean, space, alpha, eps, out=None, u8_out=None, crop=None, clean_index=None):
     """One PGD/FGSM step for a batch of images in one pass over memory.
 

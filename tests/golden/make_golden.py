@@ -374,6 +374,36 @@ def label_case():
                 image_index=42, text=text)
 
 
+# --------------------------------------------------------------------------- depth statistics
+def depth_stats_case():
+    """error_estimating / depth_error_estimating / project_disp_to_depth_map / project_disp_to_depth of
+    attack/DSGN/predict_and_save_pgd.py:202-247,304-329 executed as they stand (cfg.max_depth and the upstream
+    calibration object replaced by plain stand-ins: P, f_u, and an identity project_image_to_velo)."""
+    rel = "attack/DSGN/predict_and_save_pgd.py"
+    cfg = types.SimpleNamespace(max_depth=40.4)
+    ns = {"torch": torch, "np": np, "cfg": cfg}
+    exec_toplevel(rel, ["error_estimating", "depth_error_estimating", "project_disp_to_depth_map", "project_disp_to_depth"], ns)
+    pred, gt = synth.depth_stats_inputs(77)
+    P = np.array([[721.5377, 0, 609.5593, 44.85728], [0, 721.5377, 172.854, 0.2163791], [0, 0, 1, 0.002745884]])
+    PR = P.copy()
+    PR[0, 3] = -339.5242
+    calib = types.SimpleNamespace(P=P, f_u=721.5377, project_image_to_velo=lambda pts: pts)
+    calib_R = types.SimpleNamespace(P=PR)
+    tp, tg = torch.from_numpy(pred), torch.from_numpy(gt)
+    out = {"seed": 77, "max_depth": cfg.max_depth, "P": P.tolist(), "P_R": PR.tolist(), "f_u": 721.5377}
+    out["error_estimating"] = list(ns["error_estimating"](tp, tg))
+    out["error_estimating_maxdisp50"] = list(ns["error_estimating"](tp, tg, maxdisp=50))
+    out["error_estimating_valid_images"] = list(ns["error_estimating"](tp[[0, 2]], tg[[0, 2]]))
+    out["depth_error_depth"] = list(ns["depth_error_estimating"](tp, tg, depth_disp=True, calib_batch=[calib] * 3, calib_R_batch=[calib_R] * 3))
+    disp = torch.from_numpy(np.abs(pred) + 1)
+    out["depth_error_disp"] = list(ns["depth_error_estimating"](disp, tg, depth_disp=False, calib_batch=[calib] * 3, calib_R_batch=[calib_R] * 3))
+    out["depth_map_depth"] = sha(ns["project_disp_to_depth_map"](calib, pred[0].copy(), max_high=1., baseline=0.54, depth_disp=True))
+    out["depth_map_disp"] = sha(ns["project_disp_to_depth_map"](calib, pred[2].copy(), max_high=1., baseline=0.532, depth_disp=False))
+    cloud = ns["project_disp_to_depth"](calib, pred[0].copy(), max_high=30., baseline=0.54, depth_disp=True)
+    out["cloud_rows"], out["cloud"] = int(cloud.shape[0]), sha(cloud)
+    return out
+
+
 # --------------------------------------------------------------------------- consumer side
 def scenario_case(label_text):
     """What the reference's own consumer makes of a label file: ``load_label`` (evaluation/convert_scenarios.py:52-95,
@@ -480,6 +510,7 @@ def main():
     index["masks"] = mask_and_dims_cases()
     index["label"] = label_case()
     index["scenario"] = scenario_case(index["label"]["text"])
+    index["depth_stats"] = depth_stats_case()
     with open(os.path.join(HERE, "index.json"), "w") as f:
         json.dump(index, f, indent=1, sort_keys=True)
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE)

@@ -72,3 +72,15 @@ def gradient(seed, shape, scale=1.0, zero_frac=0.05, specials=False):
 def patch_init(seed, d, lo=-2.0, hi=2.5):
     rs = np.random.RandomState(seed)
     return (rs.rand(1, 3, d, d) * (hi - lo) + lo).astype(np.float32)
+
+
+def depth_stats_inputs(seed, n=3, h=12, w=20):
+    """seeded (pred, gt) pairs shared with the tests: gt is sparse (zeros = no measurement) and reaches beyond every
+    validity bound; image 1 has no valid pixel at all"""
+    rs = np.random.RandomState(seed)
+    gt = (rs.rand(n, h, w) * 90).astype(np.float32)
+    gt[rs.rand(n, h, w) < 0.5] = 0
+    gt[1] = 0
+    pred = (gt + rs.randn(n, h, w).astype(np.float32) * 4 + 0.5).astype(np.float32)
+    pred[gt == 0] = (rs.rand(int((gt == 0).sum())) * 60 - 2).astype(np.float32)
+    return pred, gt

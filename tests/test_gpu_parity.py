@@ -588,3 +588,31 @@ def test_indexed_extreme_values_fall_back(ops):
         g = synth.gradient(6, y.shape)
         got = ops.pgd_step(dev(y), dev(g), clean, sp, 1 / 255, 0.03, clean_index=ci)
         same_bits(host(got), O.pgd_step_norm01(y, g, O.denormalize(y), 1 / 255, 0.03), "fallback", any_nan=True)
+
+
+@pytest.mark.parametrize("shape", [(600, 1987), (20, 33), (12, 50), (30, 36)])
+def test_srcnn_shape_in_place_with_export(shape, ops):
+    """planes that are not whole cache lines: in-place update WITH the fused export (dense = aligned 12-byte stores,
+    cropped = byte stores), several images per launch (every image has its own plane misalignment), vs the oracle"""
+    h, w = shape
+    sp = ops.Space.srcnn()
+    n = 3
+    x0 = np.concatenate([synth.srcnn_meansub(40 + i, h, w) for i in range(n)])
+    g = synth.gradient(41, x0.shape, 1.0)
+    want = x0
+    x = dev(x0)
+    clean = x.clone()
+    u8 = ops.alloc_u8(n, h, w, x.device)
+    u8c = ops.alloc_u8(n, h - 2, w, x.device)
+    for k in range(3):
+        want = O.pgd_step_meansub255(want, g, x0, 1.0, 7.65)
+        if k == 1:      # cropped export: byte stores
+            ops.pgd_step(x, dev(g), clean, sp, 1.0, 7.65, out=x, u8_out=u8c, crop=(h - 2, w - 3))
+            for i in range(n):
+                same_bits(host(u8c)[i, :, :w - 3], O.srcnn_export_u8(want[i])[:h - 2, :w - 3], "cropped export, image %d" % i)
+        else:           # dense export, in place
+            ops.pgd_step(x, dev(g), clean, sp, 1.0, 7.65, out=x, u8_out=u8)
+            for i in range(n):
+                same_bits(host(u8)[i], O.srcnn_export_u8(want[i]), "dense export, image %d step %d" % (i, k))
+        same_bits(host(x), want, "in-place iterate %d" % k)
+    same_bits(host(ops.export_u8(x, sp)), np.stack([O.srcnn_export_u8(want[i]) for i in range(n)]), "stand-alone dense export")

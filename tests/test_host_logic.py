@@ -386,3 +386,35 @@ def test_synthetic_source_shapes():
     assert float(b.imgL[:, :, 375:].abs().max()) == 0.0          # zero padding after normalisation
     b = next(iter(data.SyntheticStereo(1, "srcnn")))
     assert tuple(b.imgL.shape) == (1, 3, 600, 1987) and b.sizes is None
+
+
+def test_depth_statistics_match_the_reference(golden_index):
+    """error_estimating / depth_error_estimating / project_disp_to_depth* (attack/DSGN/predict_and_save_pgd.py:202-247,
+    304-329) against the values the reference's own functions produced for the same seeded inputs"""
+    import hashlib
+    import types
+    import torch
+    from eval_driving_safety_amd import depthstats as D
+    G = golden_index["depth_stats"]
+    pred, gt = synth.depth_stats_inputs(G["seed"])
+    tp, tg = torch.from_numpy(pred), torch.from_numpy(gt)
+    calib = types.SimpleNamespace(P=np.array(G["P"]), f_u=G["f_u"])
+    calib_R = types.SimpleNamespace(P=np.array(G["P_R"]))
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+    def same(got, want):
+        assert len(got) == len(want)
+        for a, b in zip(got, want):
+            assert (a != a and b != b) or a == b, (got, want)
+
+    same(D.error_estimating(tp, tg), G["error_estimating"])                      # an image without valid pixels: NaN, as the reference
+    same(D.error_estimating(tp, tg, maxdisp=50), G["error_estimating_maxdisp50"])
+    same(D.error_estimating(tp[[0, 2]], tg[[0, 2]]), G["error_estimating_valid_images"])
+    same(D.depth_error_estimating(tp, tg, max_depth=G["max_depth"], depth_disp=True), G["depth_error_depth"])
+    disp = torch.from_numpy(np.abs(pred) + 1)
+    same(D.depth_error_estimating(disp, tg, depth_disp=False, calib_batch=[calib] * 3, calib_R_batch=[calib_R] * 3), G["depth_error_disp"])
+    assert sha(D.project_disp_to_depth_map(G["f_u"], pred[0].copy(), 0.54, True)) == G["depth_map_depth"]
+    assert sha(D.project_disp_to_depth_map(G["f_u"], pred[2].copy(), 0.532, False)) == G["depth_map_disp"]
+    pts = D.project_disp_to_points(G["f_u"], pred[0].copy(), 0.54, True)
+    pts = pts[(pts[:, 0] >= 0) & (pts[:, 2] < 30.)]           # the reference's filter after its (here: identity) velo transform
+    assert pts.shape[0] == G["cloud_rows"] and sha(pts) == G["cloud"]

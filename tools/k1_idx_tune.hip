@@ -275,29 +275,33 @@ int main(int argc, char** argv) {
            FD, gx_, ms, alg / ms / 1e6, moved / ms / 1e6, moved / ms / 1e6 / 8000.0);                                        \
   }
 
-  for (int inplace = 1; inplace >= 0; --inplace) {
-    const float* xin = x;
-    float* xout = inplace ? x : xo;
-    printf("---- %s\n", inplace ? "in place" : "out of place");
+  const int REPS = argc > 2 ? atoi(argv[2]) : 20;
+#undef RUN
+#define RUN(MODE, PAD, BL, TR, FD, IDXP, TAG)                                                                                \
+  {                                                                                                                          \
+    const int gx_ = (hw4 + BL * 2 * TR - 1) / (BL * 2 * TR);                                                                 \
+    dim3 grid(gx_, (unsigned)n_img);                                                                                         \
+    int flip = 0;                                                                                                            \
+    float ms = time_ms(s, REPS, [&] {                                                                                        \
+      const float* xin_ = bufmode == 2 ? (flip ? xo : x) : x;                                                                \
+      float* xout_ = bufmode == 0 ? x : (bufmode == 1 ? xo : (flip ? x : xo));                                               \
+      flip ^= 1;                                                                                                             \
+      hipLaunchKernelGGL((k1i<MODE, PAD, BL, TR, FD>), grid, dim3(BL), 0, s, (const v4f*)xin_, (const v4f*)g, (const v4f*)cl, \
+                         (const uint32_t*)(IDXP), ok, lut, (v4f*)xout_, u8, n_img, hw4, W, CROP_H, CROP_H, CROP_W, sp, alpha, eps); \
+    });                                                                                                                      \
+    const double moved = MODE == M_FLOAT ? real_f : real_idx;                                                                \
+    printf("%-6s mode%d pad%d block%3d trips%d gx%4d reps%4d : %7.3f ms  alg %7.1f GB/s  moved %7.1f GB/s (%.3f of 8 TB/s)\n", TAG, MODE, PAD, BL, TR, \
+           gx_, REPS, ms, alg / ms / 1e6, moved / ms / 1e6, moved / ms / 1e6 / 8000.0);                                      \
+  }
+  const char* names[3] = {"in place (x -> x)", "fixed out of place (x -> xo, x never written)", "alternating (x -> xo -> x ...)"};
+  for (int bufmode = 0; bufmode < 3; ++bufmode) {
+    printf("---- %s\n", names[bufmode]);
     for (int rep = 0; rep < 2; ++rep) {
       RUN(M_FLOAT, false, 64, 1, false, idx_smooth, "float");
-      RUN(M_FLOAT, false, 64, 1, true, idx_smooth, "float");
-      RUN(M_DIV, false, 64, 1, false, idx_smooth, "div");
       RUN(M_DIV, true, 64, 1, false, idx_smooth, "div");
       RUN(M_LDS, true, 64, 1, false, idx_smooth, "lds-s");
       RUN(M_LDS, true, 64, 1, false, idx_rand, "lds-r");
-      RUN(M_LDS, false, 64, 1, false, idx_smooth, "lds-s");
-      RUN(M_LDS, true, 64, 2, false, idx_smooth, "lds-s");
-      RUN(M_LDS, true, 64, 4, false, idx_smooth, "lds-s");
-      RUN(M_LDS, true, 128, 1, false, idx_smooth, "lds-s");
-      RUN(M_LDS, true, 256, 1, false, idx_smooth, "lds-s");
-      RUN(M_LDS, true, 256, 2, false, idx_smooth, "lds-s");
       RUN(M_GLB, true, 64, 1, false, idx_smooth, "glb-s");
-      RUN(M_GLB, true, 64, 1, false, idx_rand, "glb-r");
-      RUN(M_LDS, true, 64, 1, true, idx_smooth, "lds-s");
-      RUN(M_LDS, true, 64, 1, true, idx_rand, "lds-r");
-      RUN(M_LDS, true, 64, 2, true, idx_smooth, "lds-s");
-      RUN(M_GLB, true, 64, 1, true, idx_smooth, "glb-s");
     }
   }
   return 0;
