@@ -39,6 +39,17 @@ def _owned(loader, comm):
             yield i, batch
 
 
+def _stack_on_device(batch, dev):
+    """[2B,3,H,W] float32 on ``dev``, left eyes first; page-locked inputs (data.KittiFolder) are copied without blocking"""
+    b = len(batch)
+    if batch.imgL.device.type == "cpu" and torch.device(dev).type == "cuda" and batch.imgL.dtype == torch.float32:
+        x = torch.empty((2 * b,) + tuple(batch.imgL.shape[1:]), dtype=torch.float32, device=dev)
+        x[:b].copy_(batch.imgL, non_blocking=batch.imgL.is_pinned())
+        x[b:].copy_(batch.imgR, non_blocking=batch.imgR.is_pinned())
+        return x
+    return torch.cat([batch.imgL, batch.imgR], dim=0).to(dev, dtype=torch.float32).contiguous()
+
+
 def _default_ops():
     from . import ops       # raises if libadvengine.so is not built: there is no other compute path
     return ops
@@ -109,7 +120,7 @@ class PgdAttack:
         """Attack B stereo pairs; returns the final stacked iterate [2B,3,H,W] (device)."""
         ops, sp = self.ops, self.space
         dev = self.device if self.device is not None else batch.imgL.device
-        x = torch.cat([batch.imgL, batch.imgR], dim=0).to(dev, dtype=torch.float32).contiguous()
+        x = _stack_on_device(batch, dev)
         n, _, h, w = x.shape
         rows = h if batch.sizes is None else max(s[1] for s in batch.sizes)
         cols = w if batch.sizes is None else max(s[0] for s in batch.sizes)
@@ -211,6 +222,7 @@ class PatchTrainer:
         s = None if seed is None else seed + 7919 * self.comm.rank
         self.sampler = patchgeom.CenterSampler(self.shape[0], self.shape[1], self.radius, "random", seed=s, rng=rng)
         self.patch = None
+        self._xbuf = None
         self.positions = []                          # (epoch, round, name, center_l, center_r) log
 
     def init_patch(self, device):
@@ -234,17 +246,25 @@ class PatchTrainer:
             batch, b = None, 0
         x = None
         if b:
-            x = torch.cat([batch.imgL, batch.imgR], dim=0).to(dev, dtype=torch.float32).contiguous()
+            x = _stack_on_device(batch, dev)
             cl, cr = zip(*[self.sampler.draw() for _ in range(b)])
             for i in range(b):
                 self.positions.append((batch.names[i], list(cl[i]), list(cr[i])))
             if hasattr(adapter, "inject_fake_target"):
                 adapter.inject_fake_target(batch.extra, cl, cr, r)       # patch_attack.py:336-354 / :187-207
-            centers2 = torch.tensor([[c[0], c[1]] for c in cl] + [[c[0], c[1]] for c in cr], dtype=torch.int32, device=dev)
-            centers3 = torch.tensor([[l[0], l[1], rr[1]] for l, rr in zip(cl, cr)], dtype=torch.int32, device=dev)
+            # one small upload per round: paste centres [2b,2] and update windows [b,3] are views of the same buffer
+            flat = [v for c in cl for v in (c[0], c[1])] + [v for c in cr for v in (c[0], c[1])] + \
+                   [v for l, rr in zip(cl, cr) for v in (l[0], l[1], rr[1])]
+            cbuf = torch.tensor(flat, dtype=torch.int32).to(dev, non_blocking=True)
+            centers2, centers3 = cbuf[:4 * b].view(2 * b, 2), cbuf[4 * b:].view(b, 3)
         single = (b == 1 and self.comm.world == 1 and not self.average)
         loss_sum = torch.zeros((), dtype=torch.float32, device=dev)
         gacc = None
+        dd = 3 * self.patch_dim * self.patch_dim
+        if not single and (self._xbuf is None or self._xbuf.device != dev):
+            # the exchange buffer, allocated once: [3*D*D] delta + 1 element carrying the number of contributing pairs,
+            # so that ``average`` needs no second collective
+            self._xbuf = torch.zeros((dd + 1,), dtype=torch.float32, device=dev)
         for it in range(self.iters):
             if b:
                 if single:                                                   # the reference's own sequence
@@ -260,15 +280,15 @@ class PatchTrainer:
                 ops.patch_update(self.patch, gl, gr, cl[0][0], cl[0][1], cr[0][1], r, self.eps, alpha=self.ALPHA,
                                  lo=self.lo, hi=self.hi)                     # :416-430 (+ :272-281)
             else:
+                delta = self._xbuf[:dd].view(3, self.patch_dim, self.patch_dim)
                 if b:
-                    delta = ops.patch_delta_batch(gl, gr, centers3, r, self.eps, alpha=self.ALPHA)
+                    ops.patch_delta_batch(gl, gr, centers3, r, self.eps, alpha=self.ALPHA, out=delta)
                 else:
-                    delta = torch.zeros((3, self.patch_dim, self.patch_dim), dtype=torch.float32, device=dev)
-                count = torch.tensor([float(b)], device=dev)
-                self.comm.all_reduce_sum_(delta)                             # RCCL over xGMI (gloo in CPU tests)
+                    delta.zero_()
+                self._xbuf[dd:].fill_(float(b))
+                self.comm.all_reduce_sum_(self._xbuf)                        # RCCL over xGMI (gloo in CPU tests): ONE message
                 if self.average:
-                    self.comm.all_reduce_sum_(count)
-                    delta = delta / torch.clamp(count, min=1.0)
+                    delta = delta / torch.clamp(self._xbuf[dd:], min=1.0)
                 ops.patch_apply(self.patch, delta, lo=self.lo, hi=self.hi)
         return loss_sum, b
 
@@ -286,11 +306,11 @@ class PatchTrainer:
             loss_sum = torch.zeros((), dtype=torch.float32, device=dev)
             loss_num = 0
             loader = loader_factory()
-            if hasattr(loader, "__len__") and hasattr(loader, "shard"):
+            if hasattr(loader, "__len__"):                                   # lazily: never hold more than the prefetch depth
                 total = len(loader)
                 if debugnum is not None:                                     # :314-316 (batch_idx * B > debugnum stops)
                     total = min(total, debugnum // max(1, getattr(loader, "batch", 1)) + 1)
-                mine = (b for i, b in itertools.takewhile(lambda ib: ib[0] < total, _owned(loader, comm)))  # lazy
+                mine = (b for i, b in itertools.takewhile(lambda ib: ib[0] < total, _owned(loader, comm)))
             else:
                 mine, total = [], 0
                 for i, batch in enumerate(loader):
@@ -344,21 +364,31 @@ class DetectUnderAttack:
             self.radius = int(patch.shape[-1]) // 2
             self.sampler = patchgeom.CenterSampler(self.shape[0], self.shape[1], self.radius, atk_mode, seed=seed, rng=rng)
 
+    def prepare(self, batch):
+        """the stacked batch [2B,3,H,W] the detector sees: as loaded (mode 'pgd'), or with the patch pasted at a fresh
+        position per pair (mode 'patch'); None when the pair is skipped (wrong shape, predict_and_save_patch.py:423-425)"""
+        dev = self.device if self.device is not None else batch.imgL.device
+        x = _stack_on_device(batch, dev)
+        if self.mode == "patch":
+            if tuple(x.shape[2:]) != tuple(self.shape):
+                return None
+            b = len(batch)
+            cl, cr = zip(*[self.sampler.draw() for _ in range(b)])
+            self.positions.extend(zip(batch.names, cl, cr))
+            centers = torch.tensor([[c[0], c[1]] for c in cl] + [[c[0], c[1]] for c in cr], dtype=torch.int32, device=dev)
+            if self.patch.device != x.device:
+                self.patch = self.patch.to(x.device)
+            self.ops.patch_paste_batch(x, self.patch, centers, self.radius)
+        return x
+
     def run(self, loader, detector, debugnum=None):
         written = 0
         for i, batch in enumerate(loader):
             if debugnum is not None and i * len(batch) > debugnum:
                 break
-            dev = self.device if self.device is not None else batch.imgL.device
-            x = torch.cat([batch.imgL, batch.imgR], dim=0).to(dev, dtype=torch.float32).contiguous()
-            b = len(batch)
-            if self.mode == "patch":
-                if tuple(x.shape[2:]) != tuple(self.shape):
-                    continue
-                cl, cr = zip(*[self.sampler.draw() for _ in range(b)])
-                self.positions.extend(zip(batch.names, cl, cr))
-                centers = torch.tensor([[c[0], c[1]] for c in cl] + [[c[0], c[1]] for c in cr], dtype=torch.int32, device=dev)
-                self.ops.patch_paste_batch(x, self.patch.to(dev), centers, self.radius)
+            x = self.prepare(batch)
+            if x is None:
+                continue
             with torch.no_grad():
                 dets = detector.detect(x, batch.extra)
             for name, d in zip(batch.names, dets):

@@ -1,45 +1,58 @@
-import argparse
+"""Shared pieces of the command-line counterparts (flags of attack/DSGN/pgd_attack.py:35-68)."""
 import os
 import sys
 
 import torch
 
+from . import upstream
 
-def add_scaffolding(parser):
-    """flags shared by the DSGN scripts (attack/DSGN/pgd_attack.py:35-51)"""
+
+def add_scaffolding(parser, loadmodel=None, btest=None, devices=None):
+    """flags shared by the DSGN scripts (attack/DSGN/pgd_attack.py:35-51; the detect-under-patch script changes three
+    defaults, predict_and_save_patch.py:40,51-52)"""
     parser.add_argument("-cfg", "--cfg", "--config", default=None, help="config path")
     parser.add_argument("--data_path", default="./data/kitti/training", help="select model")
-    parser.add_argument("--loadmodel", default=None, help="loading model")
+    parser.add_argument("--loadmodel", default=loadmodel, help="loading model")
     parser.add_argument("--seed", type=int, default=1, metavar="S", help="random seed (default: 1)")
     parser.add_argument("--split_file", default="./data/kitti/val.txt", help="split file")
-    parser.add_argument("--btest", "-btest", type=int, default=None)
-    parser.add_argument("--devices", "-d", type=str, default=None)
+    parser.add_argument("--btest", "-btest", type=int, default=btest)
+    parser.add_argument("--devices", "-d", type=str, default=devices)
     parser.add_argument("--tag", "-t", type=str, default="")
     parser.add_argument("--debug", action="store_true", default=False, help="debug mode")
     parser.add_argument("--debugnum", default=None, type=int, help="debug mode")
     add_engine_flags(parser)
 
 
+def add_detect_flags(parser):
+    """flags the two DSGN detect scripts add (attack/DSGN/predict_and_save_pgd.py:45-56)"""
+    parser.add_argument("--save_path", type=str, default="./outputs/result", metavar="S", help="path to save the predict")
+    parser.add_argument("--save_lidar", action="store_true", help="if true, save the numpy file, not the png file")
+    parser.add_argument("--save_depth_map", action="store_true", help="if true, save the numpy file, not the png file")
+    parser.add_argument("--train", "-train", action="store_true", default=False, help="test on train set")
+    parser.add_argument("--save_feat_map", action="store_true", help="will save feature maps")
+    parser.add_argument("--save_feat_path", type=str, default="", help="path to save feature maps")
+
+
 def add_engine_flags(parser):
     g = parser.add_argument_group("engine (not in the reference)")
     g.add_argument("--model", default="upstream", choices=["upstream", "toy"],
-                   help="'upstream' imports the user's DSGN / Stereo R-CNN checkout; 'toy' runs the plumbing "
-                        "with a fixed-seed differentiable stand-in on synthetic KITTI-shaped pairs")
-    g.add_argument("--synthetic", type=int, default=0, metavar="N", help="attack N synthetic pairs instead of --data_path")
-    g.add_argument("--out_root", default=".", help="where the *_pgd_iters_k / *_patch_ratio_r folders go")
+                   help="'upstream' builds the detector from the user's DSGN / Stereo R-CNN checkout exactly as the reference "
+                        "script does; 'toy' runs the plumbing with a fixed-seed differentiable stand-in on synthetic pairs")
+    g.add_argument("--synthetic", type=int, default=0, metavar="N", help="attack N synthetic pairs instead of the dataset")
+    g.add_argument("--out_root", default=".", help="where the *_pgd_iters_k / *_patch_ratio_r / result_* folders go")
     g.add_argument("--save_every", type=int, default=1, help="write every k-th iterate (reference: every one)")
     g.add_argument("--pos_seed", type=int, default=None, help="seed of the patch-position stream (reference: unseeded)")
+    g.add_argument("--loader_workers", type=int, default=None,
+                   help="decode threads of the folder reader (default: the reference's 12, attack/DSGN/pgd_attack.py:79; 0 with --debug)")
 
 
-def setup_device():
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        sys.exit("no ROCm device: this engine has no CPU path")
-    torch.cuda.set_device(local)
-    return torch.device("cuda", local)
+def setup_device(devices=None, mem_info=None):
+    """-> (torch.device, the resolved --devices string)"""
+    return upstream.pick_device(devices, mem_info)
 
 
-def upstream_unavailable(what):
-    sys.exit("%s is not importable. The detectors are third-party checkouts the reference expects you to clone "
-             "(attack/DSGN/README.md:18, attack/Stereo-RCNN/README.md:18); run from inside that checkout, or pass "
-             "--model toy --synthetic N to exercise the attack engine without it." % what)
+def upstream_or_exit(build):
+    try:
+        return build()
+    except upstream.UpstreamMissing as e:
+        sys.exit(str(e))

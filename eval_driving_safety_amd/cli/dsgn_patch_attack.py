@@ -1,9 +1,9 @@
-"""Counterpart of attack/DSGN/patch_attack.py (flags :35-57, loop :278-443)."""
+"""Counterpart of attack/DSGN/patch_attack.py (flags :35-57, scaffolding :59-152, loop :278-443)."""
 import argparse
 
 import torch
 
-from . import _common
+from . import _common, upstream
 from .. import adapters, data
 from ..attacks import PatchTrainer
 from ..dist import Comm
@@ -23,21 +23,20 @@ def main(argv=None):
     args = build_parser().parse_args(argv)
     if args.debugnum is None:
         args.debugnum = 100
-    dev = _common.setup_device()
+    dev, args.devices_resolved = _common.setup_device(args.devices)
     comm = Comm.from_env(device=dev)
     torch.manual_seed(args.seed)
     torch.cuda.manual_seed(args.seed)
-    batch = args.btest if args.btest else 1
     if args.model == "toy":
         adapter = adapters.ToyStereoAdapter(dev, seed=args.seed)
+        batch = args.btest if args.btest else 1
+        workers = args.loader_workers if args.loader_workers is not None else (0 if args.debug else 12)
+        factory = (lambda: data.SyntheticStereo(args.synthetic, "dsgn", batch, seed=args.seed)) if args.synthetic \
+            else (lambda: data.KittiFolder(args.data_path, args.split_file, batch, workers=workers))
     else:
-        try:
-            from dsgn.models import StereoNet                 # noqa: F401  (upstream)
-        except Exception:
-            _common.upstream_unavailable("dsgn (upstream DSGN)")
-        raise SystemExit("wire your DSGN checkpoint through adapters.DsgnAdapter(model, cfg, RPN3DLoss); see INTEGRATION.md")
-    factory = (lambda: data.SyntheticStereo(args.synthetic, "dsgn", batch, seed=args.seed)) if args.synthetic \
-        else (lambda: data.KittiFolder(args.data_path, args.split_file, batch))
+        rt = _common.upstream_or_exit(lambda: upstream.DsgnRuntime(args, dev, attack=True))
+        adapter = adapters.DsgnAdapter(rt.model, rt.cfg, rt.RPN3DLoss)
+        factory = lambda: upstream.dsgn_attack_loader(rt)
     trainer = PatchTrainer("dsgn", args.ratio, args.eps, args.iter, args.epochs, out_root=args.out_root,
                            seed=args.pos_seed, comm=comm, device=dev)
     trainer.train(factory, adapter, debugnum=args.debugnum if args.debug else None)

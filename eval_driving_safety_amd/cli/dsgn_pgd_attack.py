@@ -1,9 +1,9 @@
-"""Counterpart of attack/DSGN/pgd_attack.py (flags :35-56, loop :229-374)."""
+"""Counterpart of attack/DSGN/pgd_attack.py (flags :35-56, scaffolding :58-147, loop :229-374)."""
 import argparse
 
 import torch
 
-from . import _common
+from . import _common, upstream
 from .. import adapters, data
 from ..attacks import PgdAttack
 from ..dist import Comm
@@ -22,21 +22,20 @@ def main(argv=None):
     args = build_parser().parse_args(argv)
     if args.debugnum is None:
         args.debugnum = 100                                   # :64-65
-    dev = _common.setup_device()
+    dev, args.devices_resolved = _common.setup_device(args.devices)
     comm = Comm.from_env(device=dev)
     torch.manual_seed(args.seed)                              # :86-87
     torch.cuda.manual_seed(args.seed)
-    batch = args.btest if args.btest else 1
     if args.model == "toy":
         adapter = adapters.ToyStereoAdapter(dev, seed=args.seed)
+        batch = args.btest if args.btest else 1
+        workers = args.loader_workers if args.loader_workers is not None else (0 if args.debug else 12)
+        loader = data.SyntheticStereo(args.synthetic, "dsgn", batch, seed=args.seed) if args.synthetic \
+            else data.KittiFolder(args.data_path, args.split_file, batch, workers=workers)
     else:
-        try:
-            from dsgn.models import StereoNet                 # noqa: F401  (upstream)
-        except Exception:
-            _common.upstream_unavailable("dsgn (upstream DSGN)")
-        raise SystemExit("wire your DSGN checkpoint through adapters.DsgnAdapter(model, cfg, RPN3DLoss); see INTEGRATION.md")
-    loader = data.SyntheticStereo(args.synthetic, "dsgn", batch, seed=args.seed) if args.synthetic \
-        else data.KittiFolder(args.data_path, args.split_file, batch)
+        rt = _common.upstream_or_exit(lambda: upstream.DsgnRuntime(args, dev, attack=True))
+        adapter = adapters.DsgnAdapter(rt.model, rt.cfg, rt.RPN3DLoss)
+        loader = upstream.dsgn_attack_loader(rt)
     atk = PgdAttack("dsgn", args.alpha, args.eps, args.iter, out_root=args.out_root, save_every=args.save_every, device=dev)
     n = atk.run(loader, adapter, comm, debugnum=args.debugnum if args.debug else None)
     print("rank %d attacked %d stereo pairs" % (comm.rank, n))

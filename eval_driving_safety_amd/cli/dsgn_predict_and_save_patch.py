@@ -1,0 +1,37 @@
+"""Counterpart of attack/DSGN/predict_and_save_patch.py (flags :35-66, loop :394-554): paste the trained patch at a
+position drawn from the ``--atk_mode`` column band into every clean pair, detect, write the KITTI label files."""
+import argparse
+
+import torch
+
+from . import _common, _dsgn_detect, upstream
+
+
+def build_parser():
+    parser = argparse.ArgumentParser(description="Patch attack predict and save")
+    _common.add_scaffolding(parser, loadmodel="./outputs/temp/DSGN_car_pretrained/finetune_53.tar", btest=1, devices="0")
+    _common.add_detect_flags(parser)
+    parser.add_argument("--ratio", dest="ratio", type=float, default=0.2)
+    parser.add_argument("--epochs", dest="epochs", type=int, default=80)
+    parser.add_argument("--patch_dir", dest="patch_dir", type=str, help="path to folder that save all trained patches")
+    parser.add_argument("--atk_mode", dest="atk_mode", type=str, default="random",
+                        help="four patch attack modes(random, sp_left, sp_straight, sp_right)")
+    return parser
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    if args.debugnum is None:
+        args.debugnum = 100
+    dev, args.devices_resolved = _common.setup_device(args.devices)
+    torch.manual_seed(args.seed)
+    torch.cuda.manual_seed(args.seed)
+    rt = _common.upstream_or_exit(lambda: upstream.DsgnRuntime(args, dev, attack=False))
+    if args.ratio or args.epochs:                                              # :96-97
+        args.tag += "_ratio{0}_epochs{1}".format(args.ratio, args.epochs)
+    written, label_dir = _dsgn_detect.run(args, rt, "patch", dev)
+    print("wrote %d label files to %s" % (written, label_dir))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,9 +1,7 @@
-"""Counterpart of attack/Stereo-RCNN/patch_attack.py (flags :38-55, loop :99-293)."""
+"""Counterpart of attack/Stereo-RCNN/patch_attack.py (flags :38-55, scaffolding :99-150, loop :152-293)."""
 import argparse
 
-import torch
-
-from . import _common
+from . import _common, upstream
 from .. import adapters, data
 from ..attacks import PatchTrainer
 from ..dist import Comm
@@ -17,29 +15,28 @@ def build_parser():
     parser.add_argument("--ratio", dest="ratio", type=float, default=0.1)
     parser.add_argument("--debug", action="store_true", default=False, help="debug mode")
     parser.add_argument("--debugnum", default=None, type=int, help="debug mode")
-    parser.add_argument("--seed", type=int, default=3, help="cfg.RNG_SEED upstream")
+    parser.add_argument("--seed", type=int, default=3, help="seed of the toy stand-in (upstream: cfg.RNG_SEED)")
+    parser.add_argument("--devices", "-d", type=str, default="0", help="GPU index (the reference always uses the current device)")
     _common.add_engine_flags(parser)
     return parser
 
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
-    dev = _common.setup_device()
+    dev, _ = _common.setup_device(args.devices)
     comm = Comm.from_env(device=dev)
     if args.model == "toy":
         adapter = adapters.ToyStereoAdapter(dev, seed=args.seed, planes=(0, 8, 16, 32))
+        if not args.synthetic:
+            raise SystemExit("--model toy needs --synthetic N (the Stereo R-CNN roidb loader is upstream code)")
+        factory = lambda: data.SyntheticStereo(args.synthetic, "srcnn", 1, seed=args.seed)
     else:
-        try:
-            from model.stereo_rcnn.resnet import resnet       # noqa: F401  (upstream)
-        except Exception:
-            _common.upstream_unavailable("model.stereo_rcnn (upstream Stereo R-CNN)")
-        raise SystemExit("wire your checkpoint through adapters.StereoRcnnAdapter(model, uncert); see INTEGRATION.md")
-    if not args.synthetic:
-        raise SystemExit("the Stereo R-CNN roidb loader is upstream code; use --synthetic N or drive PatchTrainer from your loader")
-    factory = lambda: data.SyntheticStereo(args.synthetic, "srcnn", 1, seed=args.seed)
+        rt = _common.upstream_or_exit(lambda: upstream.SrcnnRuntime(dev, training=True, workers=8))     # :128-129
+        adapter = adapters.StereoRcnnAdapter(rt.model, rt.uncert)
+        factory = lambda: upstream.srcnn_loader(rt)
     trainer = PatchTrainer("srcnn", args.ratio, args.eps, args.iter, args.epochs, out_root=args.out_root,
                            seed=args.pos_seed, comm=comm, device=dev)
-    trainer.train(factory, adapter, debugnum=args.debugnum if args.debug else None)
+    trainer.train(factory, adapter, debugnum=(args.debugnum - 1) if (args.debug and args.debugnum is not None) else None)
     comm.close()
 
 

@@ -231,6 +231,37 @@ def write_kitti_labels(output_path, image_index, detections):
             f.write(kitti_label_line(*det))
 
 
+def boxlist_detections(prediction, get_dimensions, learn_viewpoint=False):
+    """The (cls, bbox, score, center, dims) tuples of one upstream ``BoxList`` prediction, as ``kitti_output`` derives
+    them (attack/DSGN/predict_and_save_pgd.py:253-271): centre = mean of the 8 box corners, (h, w, l, ry) from the
+    upstream ``get_dimensions`` of the centred corners, optional viewpoint correction; a prediction without 3D corners
+    gives zeros."""
+    labels = prediction.get_field("labels").cpu()
+    boxes = prediction.bbox.cpu()
+    scores = prediction.get_field("scores").cpu()
+    corners = prediction.get_field("box_corner3d").cpu() if prediction.has_field("box_corner3d") else None
+    out = []
+    for i in range(len(labels)):
+        if corners is not None:
+            assert labels[i] != 0
+            c = corners[i].reshape(8, 3)
+            center = c.mean(dim=0)
+            h, w, l, ry = get_dimensions((c - center.view(1, 3)).transpose(0, 1))
+            if learn_viewpoint:
+                ry = ry - np.arctan2(center[2], center[0]) + np.pi / 2
+        else:
+            h, w, l, ry, center = 0., 0., 0., 0., [0., 0., 0.]
+        out.append((labels[i], boxes[i], scores[i], center, (h, w, l, ry)))
+    return out
+
+
+def kitti_output(box_pred_left, image_indexes, output_path, get_dimensions, learn_viewpoint=False, log=print):
+    """``kitti_output`` of the DSGN detect scripts (predict_and_save_pgd.py:250-284): one label file per image"""
+    for prediction, image_index in zip(box_pred_left, image_indexes):
+        write_kitti_labels(output_path, image_index, boxlist_detections(prediction, get_dimensions, learn_viewpoint))
+        log("Wrote {}".format(image_index))
+
+
 # --- result folders of the detect-under-attack scripts -------------------------------------------------
 def dsgn_tag(tag="", iter_num=None, alpha=None, ratio=None, epochs=None, debugnum=None, train=False):
     """args.tag as the DSGN scripts extend it (attack/DSGN/predict_and_save_pgd.py:84-94,

@@ -99,7 +99,11 @@ def patch_delta_batch(grad_l, grad_r, centers, radius, eps, alpha=1e3, out=None)
     for i in range(gl.shape[0]):
         d = O.patch_delta(gl[i:i + 1], gr[i:i + 1], int(c[i, 0]), int(c[i, 1]), int(c[i, 2]), radius, eps, alpha)
         acc = d if acc is None else acc + d
-    return torch.from_numpy(np.ascontiguousarray(acc[0]))
+    res = torch.from_numpy(np.ascontiguousarray(acc[0]))
+    if out is not None:
+        out.copy_(res)
+        return out
+    return res
 
 
 def patch_apply(patch, delta, lo=None, hi=None):

@@ -1,0 +1,226 @@
+"""The ``--model upstream`` branch of the CLIs, end to end, with stand-in packages that carry the names and call
+signatures of the upstream DSGN / Stereo R-CNN checkouts (tests/fake_upstream/): construction of cfg / model / loader as
+the reference scripts do it, the attack loops through DsgnAdapter / StereoRcnnAdapter, the reference's folder layouts,
+the detect-under-attack scripts with label files, depth statistics and result files."""
+import os
+import subprocess
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FAKE = os.path.join(ROOT, "tests", "fake_upstream")
+UPSTREAM_NAMES = ("dsgn", "env_utils", "model", "roi_data_layer", "_init_paths")
+
+
+@pytest.fixture
+def checkout(request):
+    """put one fake checkout on sys.path for the test, and forget its modules afterwards"""
+    def use(name):
+        path = os.path.join(FAKE, name)
+        sys.path.insert(0, path)
+        request.addfinalizer(lambda: sys.path.remove(path))
+        return path
+    yield use
+    for m in [m for m in sys.modules if m.split(".")[0] in UPSTREAM_NAMES]:
+        del sys.modules[m]
+
+
+def make_kitti_folder(root, ids, seed=0):
+    from PIL import Image
+    import synth
+    for eye in ("image_2", "image_3"):
+        os.makedirs(os.path.join(root, eye), exist_ok=True)
+    for k, name in enumerate(ids):
+        left = synth.u8_image(seed + k, 375, 1242)
+        Image.fromarray(left).save(os.path.join(root, "image_2", name + ".png"))
+        Image.fromarray(np.roll(left, -24, axis=1)).save(os.path.join(root, "image_3", name + ".png"))
+    with open(os.path.join(root, "val.txt"), "w") as f:
+        f.write("\n".join(ids) + "\n")
+    return os.path.join(root, "val.txt")
+
+
+def make_dsgn_checkpoint(path):
+    sys.path.insert(0, os.path.join(FAKE, "dsgn_checkout"))
+    try:
+        from dsgn.models import StereoNet
+        model = torch.nn.DataParallel(StereoNet(cfg=None))
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        torch.save({"state_dict": model.state_dict()}, path)
+    finally:
+        sys.path.remove(os.path.join(FAKE, "dsgn_checkout"))
+        for m in [m for m in sys.modules if m.split(".")[0] in UPSTREAM_NAMES]:
+            del sys.modules[m]
+
+
+# ----------------------------------------------------------------------------------------------- CPU: builders
+def test_devices_flag_as_the_reference_reads_it():
+    from eval_driving_safety_amd.cli import upstream
+    mem = lambda: [50, 10, 30, 40]
+    assert upstream.resolve_devices(None, mem) == "1"                  # least-used GPU (pgd_attack.py:58-59)
+    assert upstream.resolve_devices("", mem) == "1"
+    assert upstream.resolve_devices("2", mem) == "2"
+    assert upstream.resolve_devices("1-2", mem) == "1,2"               # inclusive range (:61-65)
+    assert upstream.resolve_devices("-2", mem) == "0,1,2"
+    assert upstream.resolve_devices("1-", mem) == "1,2,3"
+    assert upstream.resolve_devices("0,3", mem) == "0,3"
+    assert upstream.resolve_devices(0, mem) == "0"                     # predict_and_save_patch.py:52 default is the int 0
+
+
+def _dsgn_args(tmp, **kw):
+    a = types.SimpleNamespace(cfg=None, data_path=str(tmp), loadmodel=str(tmp / "outputs" / "fake" / "finetune_53.tar"), seed=1,
+                              split_file=str(tmp / "val.txt"), btest=1, devices="0", devices_resolved="0", tag="", debug=True, debugnum=100,
+                              train=False)
+    a.__dict__.update(kw)
+    return a
+
+
+def test_dsgn_runtime_builds_what_the_script_builds(tmp_path, checkout):
+    from eval_driving_safety_amd import adapters
+    from eval_driving_safety_amd.cli import upstream
+    checkout("dsgn_checkout")
+    make_kitti_folder(str(tmp_path), ["000003", "000011"])
+    args = _dsgn_args(tmp_path)
+    make_dsgn_checkpoint(args.loadmodel)
+    checkout("dsgn_checkout")
+    rt = upstream.DsgnRuntime(args, torch.device("cpu"), attack=True)
+    assert rt.cfg.debug is True and args.tag == "debug100" and args.btest == 1         # pgd_attack.py:73-77
+    assert isinstance(rt.model, torch.nn.DataParallel) and not rt.model.training
+    batches = list(upstream.dsgn_attack_loader(rt))
+    assert len(batches) == 2 and batches[0].names == ["000003"] and batches[0].sizes == [(1242, 375)]
+    b = batches[1]
+    assert tuple(b.imgL.shape) == (1, 3, 384, 1248) and float(b.imgL[:, :, 375:].abs().max()) == 0
+    e = b.extra
+    assert float(e.calibs_baseline[0]) > 0 and abs(float(e.calibs_baseline[0]) - 0.5327) < 1e-3       # abs(), :263-264
+    assert tuple(e.calibs_Proj.shape) == (1, 3, 4) and e.targets[0].bbox.shape == (2, 4) and e.ious == ("ious",)
+    x = torch.cat([b.imgL, b.imgR])
+    loss, grad = adapters.DsgnAdapter(rt.model, rt.cfg, rt.RPN3DLoss).loss_and_grad(x, e)
+    assert float(loss) > 0 and float(grad[0].abs().sum()) > 0 and float(grad[1].abs().sum()) > 0
+    # the detect scripts' view: 7-list collate, baseline NOT made absolute, post-processor output
+    args2 = _dsgn_args(tmp_path, debug=False, train=False)
+    rt2 = upstream.DsgnRuntime(args2, torch.device("cpu"), attack=False)
+    b2 = next(iter(rt2.detect_batches()))
+    assert float(b2.extra.calibs_baseline[0]) > 0 and b2.extra.image_sizes == ((375, 1242),) and b2.extra.image_indexes == (3,)
+    pred_disp, box_pred = rt2.predict(torch.cat([b2.imgL, b2.imgR]), b2.extra)
+    assert tuple(pred_disp.shape) == (1, 384, 1248) and box_pred[0][0].has_field("box_corner3d")
+
+
+def test_dsgn_runtime_reports_a_missing_checkout(tmp_path):
+    from eval_driving_safety_amd.cli import upstream
+    with pytest.raises(upstream.UpstreamMissing) as e:
+        upstream.DsgnRuntime(_dsgn_args(tmp_path), torch.device("cpu"), attack=True)
+    assert "attack/DSGN/README.md" in str(e.value)
+
+
+def make_srcnn_checkpoint(path):
+    sys.path.insert(0, os.path.join(FAKE, "srcnn_checkout"))
+    try:
+        from model.stereo_rcnn.resnet import resnet
+        net = resnet(("__background__", "Car"), 101, pretrained=False)
+        net.create_architecture()
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        torch.save({"model": net.state_dict(), "uncert": torch.tensor([0.1, -0.2, 0.3, 0.0, 0.5, -0.4])}, path)
+    finally:
+        sys.path.remove(os.path.join(FAKE, "srcnn_checkout"))
+        for m in [m for m in sys.modules if m.split(".")[0] in UPSTREAM_NAMES]:
+            del sys.modules[m]
+
+
+def test_srcnn_runtime_builds_what_the_script_builds(tmp_path, checkout):
+    from eval_driving_safety_amd import adapters
+    from eval_driving_safety_amd.cli import upstream
+    pth = str(tmp_path / "models_stereo" / "stereo_rcnn_12_6477.pth")
+    make_srcnn_checkpoint(pth)
+    checkout("srcnn_checkout")
+    rt = upstream.SrcnnRuntime(torch.device("cpu"), training=True, workers=0, model_pth=pth)
+    assert rt.cfg.TRAIN.USE_FLIPPED is False and rt.uncert.tolist() == pytest.approx([0.1, -0.2, 0.3, 0.0, 0.5, -0.4])
+    batches = list(upstream.srcnn_loader(rt))
+    assert len(batches) == 3 and batches[0].names == ["000007.png"] and tuple(batches[0].imgL.shape) == (1, 3, 600, 1987)
+    b = batches[0]
+    loss, grad = adapters.StereoRcnnAdapter(rt.model, rt.uncert).loss_and_grad(torch.cat([b.imgL, b.imgR]), b.extra)
+    assert float(grad.abs().sum()) > 0 and int(b.extra.num_boxes) == 1
+    ad = adapters.StereoRcnnAdapter(rt.model, rt.uncert)
+    ad.inject_fake_target(b.extra, [[300, 900]], [[300, 836]], 30)                      # patch_attack.py:187-207
+    assert b.extra.gt_boxes_left[0, 0].tolist() == [870.0, 270.0, 930.0, 330.0, 0.0] and b.extra.gt_boxes_right[0, 0, 0] == 806.0
+
+
+# ----------------------------------------------------------------------------------------------- GPU: the CLIs end to end
+def _run(mod, argv, cwd, checkout_dir, **env):
+    e = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, os.path.join(FAKE, checkout_dir)]), **env)
+    out = subprocess.run([sys.executable, "-m", "eval_driving_safety_amd.cli." + mod] + argv, cwd=cwd, env=e, stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-4000:]
+    return out.stdout
+
+
+@pytest.mark.gpu
+def test_dsgn_clis_on_an_upstream_shaped_checkout(tmp_path):
+    from PIL import Image
+    ids = ["000003", "000011", "000020"]
+    data = tmp_path / "data" / "kitti" / "training"
+    os.makedirs(str(data))
+    split = make_kitti_folder(str(data), ids)
+    ckpt = "outputs/temp/DSGN_car_pretrained/finetune_53.tar"
+    make_dsgn_checkpoint(str(tmp_path / ckpt))
+    common = ["--data_path", str(data), "--split_file", split, "--loadmodel", ckpt, "-btest", "1", "-d", "0", "--debug", "--debugnum", "1"]
+    # --- pgd_attack.py: debugnum 1 attacks images 0 and 1 (batch_idx * 1 > 1 stops, quirk Q15)
+    out = _run("dsgn_pgd_attack", common + ["--iter", "2", "--eps", "0.03"], str(tmp_path), "dsgn_checkout")
+    assert "Loaded " + ckpt in out and "Using GPU:0" in out
+    for k in range(3):
+        for eye in ("image_2", "image_3"):
+            assert sorted(os.listdir(str(tmp_path / ("dsgn_pgd_iters_%d" % k) / eye))) == ["000003.png", "000011.png"]
+    clean = np.array(Image.open(str(data / "image_2" / "000011.png")))
+    it0 = np.array(Image.open(str(tmp_path / "dsgn_pgd_iters_0" / "image_2" / "000011.png")))
+    it2 = np.array(Image.open(str(tmp_path / "dsgn_pgd_iters_2" / "image_2" / "000011.png")))
+    assert it0.shape == (375, 1242, 3) and np.abs(it0.astype(int) - clean.astype(int)).max() <= 1     # trunc((v/255)*255) may lose 1 LSB
+    d = np.abs(it2.astype(int) - clean.astype(int))
+    assert 1 <= d.max() <= 3 and (d > 0).mean() > 0.5                                                  # two steps of 1/255 inside eps
+    # --- predict_and_save_pgd.py on the attacked folder (swapped in for image_2/3, README.md:30,69)
+    atk = tmp_path / "attacked"
+    os.makedirs(str(atk))
+    for eye in ("image_2", "image_3"):
+        os.symlink(str(tmp_path / "dsgn_pgd_iters_2" / eye), str(atk / eye))
+    with open(str(atk / "val.txt"), "w") as f:
+        f.write("000003\n000011\n")
+    out = _run("dsgn_predict_and_save_pgd", ["--data_path", str(atk), "--split_file", str(atk / "val.txt"), "--loadmodel", ckpt, "-btest", "1",
+                                            "-d", "0", "--iter", "2", "--alpha", "0.00392", "--save_depth_map", "--save_lidar",
+                                            "--save_path", str(tmp_path / "res")], str(tmp_path), "dsgn_checkout")
+    label_dir = tmp_path / "outputs/temp/DSGN_car_pretrained" / "kitti_output_iter2_alpha0.00392"
+    assert sorted(os.listdir(str(label_dir))) == ["000003.txt", "000011.txt"]
+    line = open(str(label_dir / "000011.txt")).read().strip().split(" ")
+    assert line[0] == "Car" and len(line) == 16 and abs(float(line[8]) - 1.6) < 1e-4 and abs(float(line[10]) - 4.0) < 1e-4
+    assert "Mean depth error(m):" in out and "Mean Error" in out and "Median Error" in out and "Wrote 11" in out
+    res = open(str(tmp_path / "outputs/temp/DSGN_car_pretrained" / "result_finetune_53.txt")).read()
+    assert res.startswith("Mean Error: ") and "Median Error: " in res
+    assert np.load(str(tmp_path / "res" / "depth_maps" / "000003.npy")).shape == (375, 1242)
+    assert os.path.getsize(str(tmp_path / "res" / "000003.bin")) % 16 == 0
+    # --- patch_attack.py (2 images x 1 epoch) and predict_and_save_patch.py with the trained patch
+    out = _run("dsgn_patch_attack", common + ["--iter", "1", "--epochs", "1", "--ratio", "0.2", "--pos_seed", "5"], str(tmp_path), "dsgn_checkout")
+    assert "Epoch 0" in out and "Average loss for epoch1" in out
+    p0 = np.load(str(tmp_path / "dsgn_patch_ratio_0.2" / "epoch0" / "patch.npy"))
+    p1 = np.load(str(tmp_path / "dsgn_patch_ratio_0.2" / "epoch1" / "patch.npy"))
+    assert p0.shape == p1.shape == (1, 3, 77, 77) and not p0.any() and np.abs(p1).max() > 0
+    out = _run("dsgn_predict_and_save_patch", ["--data_path", str(data), "--split_file", split, "--loadmodel", ckpt, "--ratio", "0.2", "--epochs", "1",
+                                              "--patch_dir", str(tmp_path), "--atk_mode", "sp_left", "--pos_seed", "2",
+                                              "--save_path", str(tmp_path / "res2")], str(tmp_path), "dsgn_checkout")
+    label_dir = tmp_path / "outputs/temp/DSGN_car_pretrained" / "kitti_output_ratio0.2_epochs1"
+    assert sorted(os.listdir(str(label_dir))) == ["000003.txt", "000011.txt", "000020.txt"]
+
+
+@pytest.mark.gpu
+def test_srcnn_attack_clis_on_an_upstream_shaped_checkout(tmp_path):
+    make_srcnn_checkpoint(str(tmp_path / "models_stereo" / "stereo_rcnn_12_6477.pth"))
+    out = _run("srcnn_pgd_attack", ["--iter", "2", "--eps", "0.03", "--debug", "--debugnum", "2"], str(tmp_path), "srcnn_checkout")
+    assert "Start iteration:  2" in out and "attacked 2 stereo pairs" in out
+    for k in range(3):
+        assert sorted(os.listdir(str(tmp_path / ("stereo_rcnn_pgd_iters_%d" % k) / "image_3"))) == ["000007.png", "000010.png"]
+    from PIL import Image
+    a = np.array(Image.open(str(tmp_path / "stereo_rcnn_pgd_iters_0" / "image_2" / "000007.png")))
+    b = np.array(Image.open(str(tmp_path / "stereo_rcnn_pgd_iters_2" / "image_2" / "000007.png")))
+    assert a.shape == (600, 1987, 3) and 1 <= np.abs(a.astype(int) - b.astype(int)).max() <= 3        # network scale (quirk Q14), alpha 1 px
+    out = _run("srcnn_patch_attack", ["--iter", "1", "--epochs", "1", "--debug", "--debugnum", "2", "--pos_seed", "3"], str(tmp_path), "srcnn_checkout")
+    p = np.load(str(tmp_path / "stereo_rcnn_patch_ratio_0.1" / "epoch1" / "patch.npy"))
+    assert p.shape == (1, 3, 61, 61) and np.abs(p).max() > 0 and "Average loss for epoch1" in out

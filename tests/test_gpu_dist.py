@@ -1,0 +1,86 @@
+"""The world > 1 code on a GPU: two ranks share cuda:0 of the 1-GPU box, the collective runs over gloo
+(RCCL refuses two ranks on one device), everything else is the production path: bench.py's N > 1 branch, and
+PatchTrainer with the HIP ops and a real Comm, checked bit for bit against a host replay of the data-parallel rule."""
+import json
+import os
+import random
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _torchrun(script_and_args, timeout=900, **env):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port())] + script_and_args
+    e = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4", **env)
+    return subprocess.run(cmd, cwd=ROOT, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+
+
+def test_bench_two_ranks_on_one_gpu():
+    out = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--pairs", "8"],
+                    ADV_BENCH_SHARE_GPU="1", ADV_BENCH_BACKEND="gloo")
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line, from rank 0"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["config"]["pairs_per_gpu"] == 8
+    assert d["value"] > 0 and abs(d["value"] - 2 * 8 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]     # whole-job pairs / max time
+    assert d["roofline"]["clean_image_read_as"].startswith("uint8 index for 16 of 16")
+    assert d["patch_allreduce"]["correct"] is True and d["patch_allreduce"]["avg_us"] > 0
+    assert "cpu_baseline" not in d                                                                              # rank 0 at N = 1 only
+
+
+@pytest.mark.parametrize("average", [False, True])
+def test_patch_trainer_two_ranks_hip_ops_real_comm(tmp_path, average):
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from oracle import oracle_np as O
+    import synth
+    n_pairs, H, W = 3, 384, 1248              # odd: rank 1 idles in the second round and contributes a zero delta
+    out = _torchrun([os.path.join(ROOT, "tests", "_dist_gpu_worker.py"), str(tmp_path), str(n_pairs), "1" if average else "0"])
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
+    p = [np.load(os.path.join(str(tmp_path), "patch_rank%d.npy" % k)) for k in range(2)]
+    grads = [np.load(os.path.join(str(tmp_path), "grads_rank%d.npy" % k)) for k in range(2)]
+    assert p[0].tobytes() == p[1].tobytes(), "ranks disagree on the patch"
+    assert grads[0].shape[0] == 4 and grads[1].shape[0] == 2                      # 2 rounds x 2 iterations / 1 round x 2
+    # host replay of the rule with the gradients the detector returned on each rank
+    D, r = O.init_patch_dims(384, 0.2)
+    patch = np.zeros((1, 3, D, D), np.float32)
+    rngs = [random.Random(9 + 7919 * k) for k in range(2)]
+    used = [0, 0]
+    for rnd in range(2):
+        live = []
+        for rank in range(2):
+            if rnd * 2 + rank < n_pairs:
+                cl, cr = O.round_mask_centers(rngs[rank], H, W, r)
+                live.append([rank, cl, cr, None])
+        for it in range(2):
+            total, count = None, 0
+            for item in live:
+                rank, cl, cr, gacc = item
+                g = grads[rank][used[rank]]
+                used[rank] += 1
+                gacc = g if gacc is None else gacc + g
+                item[3] = gacc
+                d = O.patch_delta(gacc[0:1], gacc[1:2], cl[0], cl[1], cr[1], r, 8 / 255)
+                total = d if total is None else total + d
+                count += 1
+            if average:
+                total = total / np.float32(max(count, 1))
+            patch = O.patch_apply_delta(patch, total)
+    assert np.abs(patch).max() > 0
+    assert p[0].reshape(patch.shape).tobytes() == patch.tobytes()
+    assert os.path.exists(os.path.join(str(tmp_path), "dsgn_patch_ratio_0.2", "epoch1", "patch.npy"))

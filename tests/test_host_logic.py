@@ -133,6 +133,34 @@ def test_kitti_label_text_matches_reference(golden_index, tmp_path):
         [float(v) for v in f[1:]]
 
 
+def test_kitti_output_of_upstream_boxlists_matches_reference(golden_index, tmp_path):
+    """the BoxList-shaped predictions of the upstream post-processor through pixelio.kitti_output: the same text the
+    reference's own kitti_output wrote for them (get_dimensions is upstream code: stubbed identically in both)"""
+    L = golden_index["label"]
+    state = {"i": 0}
+
+    def get_dimensions(c):
+        assert tuple(c.shape) == (3, 8)
+        d = L["dims"][state["i"]]
+        state["i"] += 1
+        return d[0], d[1], d[2], d[3]
+
+    class Pred:
+        bbox = torch.tensor(L["bbox"], dtype=torch.float32)
+        f = {"labels": torch.tensor(L["labels"]), "scores": torch.tensor(L["scores"], dtype=torch.float32),
+             "box_corner3d": torch.tensor(L["corners"], dtype=torch.float32)}
+
+        def get_field(self, k):
+            return self.f[k]
+
+        def has_field(self, k):
+            return k in self.f
+
+    logged = []
+    pixelio.kitti_output([Pred()], [L["image_index"]], str(tmp_path), get_dimensions, log=logged.append)
+    assert open(os.path.join(str(tmp_path), "000042.txt")).read() == L["text"] and logged == ["Wrote 42"]
+
+
 def test_consumer_view_of_label_files(golden_index, tmp_path):
     """load_label + the obstacle mapping against what the reference's own consumer code produced"""
     S = golden_index["scenario"]
