@@ -75,6 +75,8 @@ SIGNATURES = {
     "adv_roi_align_fwd_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P],
     "adv_roi_align_bwd_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P],
     "adv_nms_f32": [_P, _I, _F, _P, _P, _P, _P],
+    "adv_dense_align_cost_f32": [_P, _P, _I, _I, _I, _P, _P, _I, _P, _F, _F, _I, _P, _P],
+    "adv_dense_align_argmin_f32": [_P, _I, _I, _P, _F, _P, _P, _P],
     "adv_conv3d_k3_prep_weights_f32": [_P, _P, _I, _I, _I, _P],
     "adv_conv3d_k3_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
 }

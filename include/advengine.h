@@ -220,6 +220,25 @@ ADV_API int adv_roi_align_bwd_f32(const float* grad_out, const float* rois, floa
 ADV_API int adv_nms_f32(const float* boxes, int n, float thresh, int64_t* keep_out, int32_t* num_keep_out,
                 uint64_t* workspace, adv_stream_t stream);
 
+/* Dense photometric box alignment - `dense_align.align_parallel` of the upstream Stereo R-CNN checkout, called at
+ *     attack/Stereo-RCNN/predict_and_save_pgd.py:381 (absent from the reference tree: this follows the published algorithm,
+ *     Stereo R-CNN sec. 5, and is pinned against the oracle only).  For object b and candidate k
+ *         z   = z_center[b] + (k - (K-1)/2) * step
+ *         cost[b,k] = mean over the pixels (u,v) of roi[b] = (u0, v0, u1, v1) (half-open, network-scale pixels) of
+ *                     sum_c ( left[c,v,u] - lerp(right[c,v,.], u - fb / (z + dz[b, u-u0])) )^2
+ *     pixels whose right-image column falls outside [0, w-1) or whose depth is <= 0 are skipped; a candidate keeping fewer
+ *     than a quarter of the region is +inf.  left/right [3,h,w] float32, roi DEVICE int32 [n,4], dz DEVICE [n,dz_stride]
+ *     (depth offset of every pixel column from the box centre, metres), z_center DEVICE [n], fb = f * baseline * scale.
+ *     Summation order is fixed (lane-strided partial sums, 64-lane shuffle tree, then the four waves in order). */
+ADV_API int adv_dense_align_cost_f32(const float* left, const float* right, int h, int w, int n, const int32_t* roi,
+                                     const float* dz, int dz_stride, const float* z_center, float fb, float step, int k,
+                                     float* cost_out, adv_stream_t stream);
+
+/* The depth of the cheapest candidate per object (first minimum; inf/NaN never win; no finite candidate: z_center is kept
+ *     and cost_min_out = +inf).  Chain: coarse cost -> argmin -> fine cost around it -> argmin, all enqueue-only. */
+ADV_API int adv_dense_align_argmin_f32(const float* cost, int n, int k, const float* z_center, float step, float* z_out,
+                                       float* cost_min_out, adv_stream_t stream);
+
 /* ---- dense 3x3x3 convolution on the matrix cores (float32 MFMA), the contraction a plane-sweep detector applies to
  *      the K7 cost volume (DSGN's 3D hourglass, reached through attack/DSGN/pgd_attack.py:308; upstream code - the
  *      semantics here are those of torch.nn.functional.conv3d(stride 1, padding 1, no bias); floating point: parity

@@ -27,6 +27,10 @@ _lib.orc_disc_mask.argtypes = [_fp] + [ctypes.c_int] * 5
 _lib.orc_disc_mask.restype = None
 _lib.orc_conv3d_k3.argtypes = [_fp, _fp, _fp] + [ctypes.c_int] * 8
 _lib.orc_conv3d_k3.restype = None
+_i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+_lib.orc_dense_align_cost.argtypes = [_fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _i32p, _fp, ctypes.c_int, _fp, ctypes.c_float,
+                                      ctypes.c_float, ctypes.c_int, _fp]
+_lib.orc_dense_align_cost.restype = None
 for _f in ("orc_denormalize", "orc_normalize", "orc_pgd_step_norm01", "orc_pgd_step_meansub255", "orc_tensor2im_u8",
            "orc_patch_paste", "orc_patch_update"):
     getattr(_lib, _f).restype = None
@@ -127,3 +131,35 @@ def conv3d_k3(x, w, relu=False, transpose=False):
     y = np.empty((b, cin if transpose else cout, d, h, ww), np.float32)
     _lib.orc_conv3d_k3(x, w, y, b, cin, cout, d, h, ww, int(relu), int(transpose))
     return y
+
+
+def dense_align_cost(left, right, roi, dz, z_center, fb, step, k):
+    """csrc/align.hip's cost in the kernel's own summation order: left/right [3,H,W], roi int32 [n,4], dz [n,stride],
+    z_center [n] -> cost [n,k]"""
+    left = np.ascontiguousarray(left, dtype=np.float32)
+    right = np.ascontiguousarray(right, dtype=np.float32)
+    roi = np.ascontiguousarray(roi, dtype=np.int32)
+    dz = np.ascontiguousarray(dz, dtype=np.float32)
+    zc = np.ascontiguousarray(z_center, dtype=np.float32)
+    n = roi.shape[0]
+    cost = np.empty((n, k), np.float32)
+    _lib.orc_dense_align_cost(left, right, left.shape[1], left.shape[2], n, roi, dz, dz.shape[1], zc, float(fb), float(step), int(k), cost)
+    return cost
+
+
+def dense_align_argmin(cost, z_center, step):
+    """first minimum per object; inf/NaN never win (csrc/align.hip: dense_align_argmin_kernel)"""
+    cost = np.asarray(cost, np.float32)
+    n, k = cost.shape
+    z = np.empty(n, np.float32)
+    cmin = np.empty(n, np.float32)
+    half = np.float32(0.5) * np.float32(k - 1)
+    for b in range(n):
+        best, bc = -1, np.float32(np.inf)
+        for j in range(k):
+            if cost[b, j] < bc:
+                best, bc = j, cost[b, j]
+        kk = np.float32(best) if best >= 0 else half
+        z[b] = np.float32(z_center[b]) + (kk - half) * np.float32(step)
+        cmin[b] = bc
+    return z, cmin

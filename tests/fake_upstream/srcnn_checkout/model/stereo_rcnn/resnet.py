@@ -19,7 +19,7 @@ class resnet(nn.Module):
     def forward(self, im_left, im_right, im_info, gt_l, gt_r, gt_m, gt_dim_orien, gt_kpts, num_boxes):
         f = torch.cat([self.c1(im_left / 64.0), self.c1(im_right / 64.0)], 1)
         o = self.c2(F.relu(f))
-        box = gt_l[:, 0, :4].mean() * 1e-4
+        box = gt_l.reshape(-1)[:4].mean() * 1e-4
         losses = [(o[:, k] * o[:, k]).mean(dim=(1, 2)) + box for k in range(6)]
         n = 4
         rois = torch.zeros(1, n, 5, device=im_left.device)
@@ -31,4 +31,7 @@ class resnet(nn.Module):
         dim = torch.zeros(1, n, 10, device=im_left.device)
         kpts = torch.rand(1, n, 4 * 28, device=im_left.device)
         lp, rp = torch.rand(1, n, 28, device=im_left.device), torch.rand(1, n, 28, device=im_left.device)
-        return (rois, rois.clone(), cls_prob, bbox_pred, dim, kpts, lp, rp) + tuple(losses) + (None,)
+        rois_right = rois.clone()
+        rois_right[0, :, 1] -= 38.0          # the loader's right eye is the left one shifted by 38 network pixels
+        rois_right[0, :, 3] -= 38.0
+        return (rois, rois_right, cls_prob, bbox_pred, dim, kpts, lp, rp) + tuple(losses) + (None,)

@@ -224,3 +224,26 @@ def test_srcnn_attack_clis_on_an_upstream_shaped_checkout(tmp_path):
     out = _run("srcnn_patch_attack", ["--iter", "1", "--epochs", "1", "--debug", "--debugnum", "2", "--pos_seed", "3"], str(tmp_path), "srcnn_checkout")
     p = np.load(str(tmp_path / "stereo_rcnn_patch_ratio_0.1" / "epoch1" / "patch.npy"))
     assert p.shape == (1, 3, 61, 61) and np.abs(p).max() > 0 and "Average loss for epoch1" in out
+
+
+@pytest.mark.gpu
+def test_srcnn_detect_clis_on_an_upstream_shaped_checkout(tmp_path):
+    """predict_and_save_{pgd,patch}: upstream decoders + HIP paste / NMS / dense alignment, the reference's result folders"""
+    make_srcnn_checkpoint(str(tmp_path / "models_stereo" / "stereo_rcnn_12_6477.pth"))
+    out = _run("srcnn_predict_and_save_pgd", ["--iter", "2", "--alpha", "1.0"], str(tmp_path), "srcnn_checkout")
+    rd = tmp_path / "result_stereo_rcnn_pgd_2_1.0"
+    files = sorted(os.listdir(str(rd)))
+    assert files == ["000007.txt", "000010.txt", "000013.txt"], (files, out[-2000:])
+    rows = [l.split() for l in open(str(rd / "000007.txt"))]
+    # rois 0 and 1 overlap (IoU > 0.3): NMS keeps the better one; roi 3 scores below 0.05; -> two cars per image
+    assert len(rows) == 2 and all(r[0] == "Car" for r in rows)
+    z = [float(r[13]) for r in rows]
+    z_true = 721.5377 * 0.54 / (38.0 / 1.6)                    # the fake right eye is shifted by 38 network px = 23.75 original px
+    # dense alignment locks the visible SURFACE onto the photometric disparity; the box (width 1.6 m, seen side-on) has its
+    # near face 0.8 m before the centre, so the centre depth written to the file is z_true + 0.8 (to one 0.05 m step)
+    assert all(abs(v - (z_true + 0.8)) < 0.08 for v in z), (z, z_true)
+    os.makedirs(str(tmp_path / "stereo_rcnn_patch_ratio_0.1" / "epoch3"))
+    np.save(str(tmp_path / "stereo_rcnn_patch_ratio_0.1" / "epoch3" / "patch.npy"), (np.random.RandomState(0).rand(1, 3, 61, 61) * 100 - 50).astype(np.float32))
+    out = _run("srcnn_predict_and_save_patch", ["--ratio", "0.1", "--epochs", "3", "--patch_dir", str(tmp_path), "--atk_mode", "sp_right",
+                                                "--pos_seed", "1"], str(tmp_path), "srcnn_checkout")
+    assert sorted(os.listdir(str(tmp_path / "result_stereo_rcnn_ratio_0.1" / "epoch3"))) == ["000007.txt", "000010.txt", "000013.txt"]
