@@ -19,7 +19,7 @@ ADV_EALIGN = -14
 ADV_ELAUNCH = -5
 ADV_SPACE_AFFINE = 0
 ADV_SPACE_IDENTITY = 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class AdvSpace(ctypes.Structure):
@@ -73,7 +73,7 @@ SIGNATURES = {
     "adv_psv_build_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "adv_psv_build_bwd_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "adv_roi_align_fwd_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P],
-    "adv_roi_align_bwd_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P],
+    "adv_roi_align_bwd_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P, _P],
     "adv_nms_f32": [_P, _I, _F, _P, _P, _P, _P],
     "adv_dense_align_cost_f32": [_P, _P, _I, _I, _I, _P, _P, _I, _P, _F, _F, _I, _P, _P],
     "adv_dense_align_argmin_f32": [_P, _I, _I, _P, _F, _P, _P, _P],
@@ -82,6 +82,7 @@ SIGNATURES = {
 }
 _OTHER = {
     "adv_abi_version": ([], _I),
+    "adv_roi_align_bwd_workspace_ints": ([_I, _I, _I, _I], ctypes.c_int64),
     "adv_last_hip_error": ([], _I),
     "adv_strerror": ([_I], ctypes.c_char_p),
     "adv_space_dsgn": ([_SP], None),

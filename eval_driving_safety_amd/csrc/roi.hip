@@ -1,6 +1,7 @@
 // Stereo R-CNN RoI-path natives for gfx950: RoIAlign forward/backward and greedy NMS.
 // Small, latency-bound kernels (a few hundred RoIs x 256 channels x 7x7 / 14x14 bins); the design points are
-// coalescing along the bin index, wave64-wide suppression masks for NMS, and determinism where it is cheap.
+// coalescing along the bin index (forward), a gather-shaped, atomic-free and therefore bit-reproducible backward,
+// and wave64-wide suppression masks for NMS.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -99,31 +100,141 @@ __global__ __launch_bounds__(kBlock) void roi_align_fwd(const float* __restrict_
   }
 }
 
-__global__ __launch_bounds__(kBlock) void roi_align_bwd(const float* __restrict__ gout, const float* __restrict__ rois,
-                                                        float* gfeat, int C, int H, int W, long long total, int PH, int PW,
-                                                        float scale, int sampling_ratio) {
-  for (long long i = blockIdx.x * static_cast<long long>(kBlock) + threadIdx.x; i < total; i += static_cast<long long>(gridDim.x) * kBlock) {
-    const int pw = static_cast<int>(i % PW);
-    const int ph = static_cast<int>((i / PW) % PH);
-    const int c = static_cast<int>((i / (static_cast<long long>(PW) * PH)) % C);
-    const long long r = i / (static_cast<long long>(PW) * PH * C);
-    const Bin b = bin_of(rois + r * 5, scale, PH, PW, sampling_ratio);
-    float* plane = gfeat + (static_cast<long long>(b.batch) * C + c) * H * W;
+// ---- RoIAlign backward as a deterministic GATHER (no float atomics).
+// The textbook backward scatters every sample's four weighted contributions with atomicAdd: the float32 sum order then
+// depends on the schedule, and the gradient of the Stereo R-CNN attack is not reproducible from run to run.  Here every
+// lane OWNS one feature pixel (for a block of kChanBlock channels, accumulators in registers) and collects, in one fixed
+// order - roi index, then sample row, then sample column, then tap 1..4 - the contributions of exactly those samples
+// whose bilinear taps touch its pixel.  Two things make that affordable:
+//   * a first kernel writes, per 8 x 32-pixel tile, the ascending list of rois whose sample window can reach the tile
+//     (wave ballot + prefix popcount keep the list ordered), so a lane only visits the handful of rois around it;
+//   * bilinear weights are separable (w1 = hy*hx ...): per roi a lane classifies its few candidate sample rows and
+//     columns (which of its two taps hits the pixel, with which weight) per axis, and the double loop only multiplies.
+// The candidate ranges are a two-sample-wide superset of the samples that can touch the pixel; every candidate is tested
+// with the forward's own tap arithmetic (taps_at), so membership is exact whatever the float rounding of the range.
+constexpr int kTileY = 8, kTileX = 32;  // 256 lanes: one pixel each, x fastest (coalesced stores)
+constexpr int kChanBlock = 8;
+
+struct Axis1 {  // one sample coordinate against one pixel coordinate
+  float w_low, w_high;  // weight when the sample's low / high tap is this pixel (0 otherwise)
+  bool hit_low, hit_high, valid;
+};
+
+// the per-axis half of taps_at: clamp, low/high index, the two 1-D weights
+__device__ __forceinline__ Axis1 axis_taps(int size, float v, int pixel) {
+  Axis1 a;
+  a.valid = !(v < -1.0f || v > static_cast<float>(size));
+  if (v <= 0.0f) v = 0.0f;
+  int low = static_cast<int>(v), high;
+  if (low >= size - 1) {
+    high = low = size - 1;
+    v = static_cast<float>(low);
+  } else {
+    high = low + 1;
+  }
+  const float l = v - static_cast<float>(low), h = 1.0f - l;
+  a.hit_low = low == pixel;
+  a.hit_high = high == pixel;
+  a.w_low = h;   // "hy" / "hx"
+  a.w_high = l;  // "ly" / "lx"
+  return a;
+}
+
+// window of feature pixels the samples of a roi can touch along one axis (conservative), clipped to the map
+__device__ __forceinline__ void roi_window(float start, float extent, int size, int* lo, int* hi) {
+  const float a = fmaxf(start, 0.0f) - 1.0f, b = start + extent + 1.0f;
+  *lo = max(0, static_cast<int>(floorf(a)));
+  *hi = min(size - 1, static_cast<int>(ceilf(b)));
+}
+
+__global__ __launch_bounds__(64) void roi_tile_lists(const float* __restrict__ rois, int R, int H, int W, int tiles_y, int tiles_x, int PH,
+                                                     int PW, float scale, int sampling_ratio, int* __restrict__ lists) {
+  // one wave per (tile, image): lists[tile][0] = count, lists[tile][1..] = roi indices ascending
+  const int tile = blockIdx.x, img = blockIdx.y;
+  const int ty = (tile / tiles_x) * kTileY, tx = (tile % tiles_x) * kTileX;
+  int* out = lists + (static_cast<long long>(img) * tiles_y * tiles_x + tile) * (R + 1);
+  int count = 0;
+  for (int r0 = 0; r0 < R; r0 += 64) {
+    const int r = r0 + threadIdx.x;
+    bool hit = false;
+    if (r < R) {
+      const Bin b = bin_of(rois + static_cast<long long>(r) * 5, scale, PH, PW, sampling_ratio);
+      if (b.batch == img) {
+        int y_lo, y_hi, x_lo, x_hi;
+        roi_window(b.start_h, b.bin_h * static_cast<float>(PH), H, &y_lo, &y_hi);
+        roi_window(b.start_w, b.bin_w * static_cast<float>(PW), W, &x_lo, &x_hi);
+        hit = y_lo < ty + kTileY && y_hi >= ty && x_lo < tx + kTileX && x_hi >= tx;
+      }
+    }
+    const unsigned long long m = __ballot(hit);
+    if (hit) out[1 + count + __popcll(m & ((1ULL << threadIdx.x) - 1ULL))] = r;
+    count += __popcll(m);
+  }
+  if (threadIdx.x == 0) out[0] = count;
+}
+
+// candidate sample indices k (over PH*grid bins x samples) whose coordinate start + (k + 0.5) * step can touch `pixel`
+__device__ __forceinline__ void cand_range(float start, float step, int n_samples, int pixel, int size, int* k_lo, int* k_hi) {
+  float lo = static_cast<float>(pixel) - 1.0f, hi = static_cast<float>(pixel) + 1.0f;
+  if (pixel == 0) lo = -1.0f;                                 // samples in [-1, 0] clamp onto pixel 0
+  if (pixel == size - 1) hi = static_cast<float>(size);        // samples in [size-1, size] clamp onto the last pixel
+  const float a = (lo - start) / step - 0.5f, b = (hi - start) / step - 0.5f;
+  *k_lo = max(0, static_cast<int>(floorf(a)) - 2);
+  *k_hi = min(n_samples - 1, static_cast<int>(ceilf(b)) + 2);
+}
+
+__global__ __launch_bounds__(kBlock) void roi_align_bwd_gather(const float* __restrict__ gout, const float* __restrict__ rois,
+                                                               const int* __restrict__ lists, float* __restrict__ gfeat, int C, int H, int W,
+                                                               int R, int tiles_y, int tiles_x, int PH, int PW, float scale,
+                                                               int sampling_ratio) {
+  const int tile = blockIdx.x, img = blockIdx.z;
+  const int c0 = blockIdx.y * kChanBlock;
+  const int py = (tile / tiles_x) * kTileY + static_cast<int>(threadIdx.x) / kTileX;
+  const int px = (tile % tiles_x) * kTileX + static_cast<int>(threadIdx.x) % kTileX;
+  const bool inside = py < H && px < W;
+  const int* list = lists + (static_cast<long long>(img) * tiles_y * tiles_x + tile) * (R + 1);
+  const int n_list = list[0];
+  float acc[kChanBlock];
+#pragma unroll
+  for (int c = 0; c < kChanBlock; ++c) acc[c] = 0.0f;
+  for (int li = 0; li < n_list; ++li) {
+    const int r = list[1 + li];  // uniform over the workgroup
+    const Bin b = bin_of(rois + static_cast<long long>(r) * 5, scale, PH, PW, sampling_ratio);
     const float count = static_cast<float>(b.grid_h * b.grid_w);
-    const float g = gout[i];
-    for (int iy = 0; iy < b.grid_h; ++iy) {
+    int ky_lo, ky_hi, kx_lo, kx_hi;
+    cand_range(b.start_h, b.bin_h / static_cast<float>(b.grid_h), PH * b.grid_h, py, H, &ky_lo, &ky_hi);
+    cand_range(b.start_w, b.bin_w / static_cast<float>(b.grid_w), PW * b.grid_w, px, W, &kx_lo, &kx_hi);
+    if (!inside) ky_hi = ky_lo - 1;
+    for (int ky = ky_lo; ky <= ky_hi; ++ky) {
+      const int ph = ky / b.grid_h, iy = ky - ph * b.grid_h;
       const float y = b.start_h + static_cast<float>(ph) * b.bin_h + (static_cast<float>(iy) + 0.5f) * b.bin_h / static_cast<float>(b.grid_h);
-      for (int ix = 0; ix < b.grid_w; ++ix) {
+      const Axis1 ay = axis_taps(H, y, py);
+      if (!ay.valid || !(ay.hit_low || ay.hit_high)) continue;
+      for (int kx = kx_lo; kx <= kx_hi; ++kx) {
+        const int pw = kx / b.grid_w, ix = kx - pw * b.grid_w;
         const float x = b.start_w + static_cast<float>(pw) * b.bin_w + (static_cast<float>(ix) + 0.5f) * b.bin_w / static_cast<float>(b.grid_w);
-        const Taps t = taps_at(H, W, y, x);
-        if (t.valid) {
-          atomicAdd(plane + t.y_low * W + t.x_low, g * t.w1 / count);
-          atomicAdd(plane + t.y_low * W + t.x_high, g * t.w2 / count);
-          atomicAdd(plane + t.y_high * W + t.x_low, g * t.w3 / count);
-          atomicAdd(plane + t.y_high * W + t.x_high, g * t.w4 / count);
+        const Axis1 ax = axis_taps(W, x, px);
+        if (!ax.valid || !(ax.hit_low || ax.hit_high)) continue;
+        // taps 1..4 of this sample = (y_low,x_low) (y_low,x_high) (y_high,x_low) (y_high,x_high), in that order
+        const float w1 = ay.w_low * ax.w_low, w2 = ay.w_low * ax.w_high, w3 = ay.w_high * ax.w_low, w4 = ay.w_high * ax.w_high;
+        const float* g = gout + ((static_cast<long long>(r) * C + c0) * PH + ph) * PW + pw;
+#pragma unroll
+        for (int c = 0; c < kChanBlock; ++c) {
+          if (c0 + c < C) {
+            const float gv = g[static_cast<long long>(c) * PH * PW];
+            if (ay.hit_low && ax.hit_low) acc[c] = acc[c] + gv * w1 / count;
+            if (ay.hit_low && ax.hit_high) acc[c] = acc[c] + gv * w2 / count;
+            if (ay.hit_high && ax.hit_low) acc[c] = acc[c] + gv * w3 / count;
+            if (ay.hit_high && ax.hit_high) acc[c] = acc[c] + gv * w4 / count;
+          }
         }
       }
     }
+  }
+  if (inside) {
+#pragma unroll
+    for (int c = 0; c < kChanBlock; ++c)
+      if (c0 + c < C) gfeat[((static_cast<long long>(img) * C + c0 + c) * H + py) * W + px] = acc[c];
   }
 }
 
@@ -211,16 +322,25 @@ int adv_roi_align_fwd_f32(const float* feat, const float* rois, float* out, int 
   return finish();
 }
 
+int64_t adv_roi_align_bwd_workspace_ints(int b, int h, int w, int r) {
+  if (b < 1 || h < 1 || w < 1 || r < 0) return 0;
+  const long long tiles = static_cast<long long>((h + kTileY - 1) / kTileY) * ((w + kTileX - 1) / kTileX);
+  return static_cast<int64_t>(b) * tiles * (r + 1);
+}
+
 int adv_roi_align_bwd_f32(const float* grad_out, const float* rois, float* grad_feat, int b, int c, int h, int w, int r, int ph,
-                          int pw, float spatial_scale, int sampling_ratio, adv_stream_t stream) {
+                          int pw, float spatial_scale, int sampling_ratio, int32_t* workspace, adv_stream_t stream) {
   const int rc = check_roi(grad_out, rois, grad_feat, b, c, h, w, r, ph, pw);
   if (rc != ADV_OK) return rc;
+  if (workspace == nullptr || b > 65535) return ADV_EINVAL;
+  if (!aligned4(workspace)) return ADV_EALIGN;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (hipMemsetAsync(grad_feat, 0, static_cast<size_t>(b) * c * h * w * sizeof(float), st) != hipSuccess) return ADV_ELAUNCH;
-  if (r == 0) return ADV_OK;
-  const long long total = static_cast<long long>(r) * c * ph * pw;
-  hipLaunchKernelGGL(roi_align_bwd, dim3(grid_for(total)), dim3(kBlock), 0, st, grad_out, rois, grad_feat, c, h, w, total, ph, pw,
-                     spatial_scale, sampling_ratio);
+  const int tiles_y = (h + kTileY - 1) / kTileY, tiles_x = (w + kTileX - 1) / kTileX;
+  // every element of grad_feat is written by its owning lane (zeros where no roi reaches): no memset needed
+  hipLaunchKernelGGL(roi_tile_lists, dim3(tiles_y * tiles_x, b), dim3(64), 0, st, rois, r, h, w, tiles_y, tiles_x, ph, pw, spatial_scale,
+                     sampling_ratio, reinterpret_cast<int*>(workspace));
+  hipLaunchKernelGGL(roi_align_bwd_gather, dim3(tiles_y * tiles_x, (c + kChanBlock - 1) / kChanBlock, b), dim3(kBlock), 0, st, grad_out, rois,
+                     reinterpret_cast<const int*>(workspace), grad_feat, c, h, w, r, tiles_y, tiles_x, ph, pw, spatial_scale, sampling_ratio);
   return finish();
 }
 

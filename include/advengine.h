@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ADV_ABI_VERSION 2
+#define ADV_ABI_VERSION 3
 #define ADV_API __attribute__((visibility("default"))) /* the library is built with -fvisibility=hidden */
 #define ADV_CHANNELS 3
 
@@ -208,11 +208,15 @@ ADV_API int adv_psv_build_bwd_f32(const float* grad_cost, const int32_t* shift, 
 ADV_API int adv_roi_align_fwd_f32(const float* feat, const float* rois, float* out, int b, int c, int h, int w, int r,
                           int ph, int pw, float spatial_scale, int sampling_ratio, adv_stream_t stream);
 
-/* RoIAlign backward: grad_feat [B,C,H,W] is zero-filled by this call, then every sample scatters
- *     grad_out * weight / count to its 4 neighbours with float atomics (sum order varies between runs: results are
- *     equal to the oracle within float32 rounding, not bitwise). */
+/* RoIAlign backward, deterministic: every element of grad_feat [B,C,H,W] is written (no memset needed) as the float32 sum,
+ *     in ONE fixed order - roi index, sample row, sample column, tap 1..4 - of the contributions
+ *     grad_out[r,c,ph,pw] * weight / count of the samples whose bilinear taps touch it.  No float atomics: two runs give
+ *     the same bits, and the result equals the oracle's ordered sum bit for bit.  workspace: DEVICE int32,
+ *     adv_roi_align_bwd_workspace_ints(b, h, w, r) elements (per 8 x 32-pixel tile the ascending list of rois that reach it). */
+ADV_API int64_t adv_roi_align_bwd_workspace_ints(int b, int h, int w, int r);
 ADV_API int adv_roi_align_bwd_f32(const float* grad_out, const float* rois, float* grad_feat, int b, int c, int h, int w,
-                          int r, int ph, int pw, float spatial_scale, int sampling_ratio, adv_stream_t stream);
+                          int r, int ph, int pw, float spatial_scale, int sampling_ratio, int32_t* workspace,
+                          adv_stream_t stream);
 
 /* Greedy NMS over n boxes [n,4] = (x1,y1,x2,y2) ALREADY SORTED by descending score, legacy "+1" areas,
  *     suppress when IoU > thresh.  keep_out [n] int64 receives the kept indices in order, num_keep_out [1] int32

@@ -392,6 +392,31 @@ def roi_align_bwd(grad_out, rois, feat_shape, spatial_scale, sampling_ratio=0):
     return gf.astype(np.float32)
 
 
+def roi_align_bwd_ordered(grad_out, rois, feat_shape, spatial_scale, sampling_ratio=0):
+    """The backward as csrc/roi.hip's gather kernel sums it: float32, contributions added per feature element in the order
+    roi index, sample row (ph, iy), sample column (pw, ix), tap 1..4 - each contribution rounded as (g * w) / count."""
+    g, rois = _f32(grad_out), _f32(rois)
+    b, c, h, w = feat_shape
+    ph, pw = g.shape[2:]
+    gf = np.zeros((b, c, h, w), np.float32)
+    for r, roi in enumerate(rois):
+        bi, sh, sw, bh, bw, gh, gw = _roi_bins(roi, spatial_scale, ph, pw, sampling_ratio)
+        count = F32(gh * gw)
+        for i in range(ph):
+            for iy in range(gh):
+                y = F32(F32(sh + F32(F32(i) * bh)) + F32(F32(F32(F32(iy) + F32(0.5)) * bh) / F32(gh)))
+                for j in range(pw):
+                    gv = g[r, :, i, j]
+                    for ix in range(gw):
+                        x = F32(F32(sw + F32(F32(j) * bw)) + F32(F32(F32(F32(ix) + F32(0.5)) * bw) / F32(gw)))
+                        valid, yl, xl, yh, xh, w1, w2, w3, w4 = _roi_taps(h, w, y, x)
+                        if not valid:
+                            continue
+                        for (yy, xx, wt) in ((yl, xl, w1), (yl, xh, w2), (yh, xl, w3), (yh, xh, w4)):
+                            gf[bi, :, yy, xx] = gf[bi, :, yy, xx] + F32(gv * wt) / count
+    return gf
+
+
 def nms(boxes, thresh):
     """Greedy NMS, boxes [N,4] pre-sorted by descending score, legacy +1 areas, float32 IoU in the kernel's
     op order; returns kept indices."""

@@ -1,5 +1,5 @@
 """Stereo R-CNN RoI path natives: RoIAlign forward (bit-exact vs the oracle), backward
-(float atomics: within float32 rounding of a float64-accumulated oracle), NMS (exact indices).
+(deterministic gather: bit-exact vs the oracle's ordered float32 sum, and within rounding of a float64 sum), NMS (exact indices).
 CPU part: the oracle's RoIAlign against torch autograd of an equivalent dense formulation."""
 import numpy as np
 import pytest
@@ -30,6 +30,8 @@ def test_oracle_roi_align_adjoint_and_constant():
     lhs = float((out.astype(np.float64) * g).sum())
     rhs = float((feat.astype(np.float64) * gf).sum())
     assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs))
+    # the float32 sum in the gather kernel's order is the same gradient up to float32 rounding
+    np.testing.assert_allclose(O.roi_align_bwd_ordered(g, rois, feat.shape, 1 / 16.0), gf, rtol=2e-5, atol=2e-5)
     ones = np.ones((1, 2, 10, 10), np.float32)
     inside = np.array([[0, 16, 16, 100, 120]], np.float32)       # fully inside -> every bin averages to 1
     assert np.allclose(O.roi_align(ones, inside, 7, 1 / 16.0), 1.0, atol=1e-6)
@@ -63,6 +65,11 @@ def test_hip_roi_align(cfg):
     gf = ops.roi_align_bwd(torch.tensor(g, device=dev), tr, feat.shape, cfg["scale"], cfg["sr"])
     wf = O.roi_align_bwd(g, rois, feat.shape, cfg["scale"], cfg["sr"])
     np.testing.assert_allclose(gf.cpu().numpy(), wf, rtol=2e-5, atol=2e-5)
+    # deterministic gather: the float32 sum in the fixed order (roi, sample row, sample column, tap) - bit for bit,
+    # and the same bits on a second run (the scatter-with-atomics formulation gives neither)
+    assert gf.cpu().numpy().tobytes() == O.roi_align_bwd_ordered(g, rois, feat.shape, cfg["scale"], cfg["sr"]).tobytes(), "backward not bit-exact"
+    again = ops.roi_align_bwd(torch.tensor(g, device=dev), tr, feat.shape, cfg["scale"], cfg["sr"])
+    assert torch.equal(gf, again)
     # autograd wrapper
     tf2 = tf.clone().requires_grad_(True)
     o2 = ops.RoIAlign.apply(tf2, tr, cfg["pooled"], cfg["scale"], cfg["sr"])
