@@ -72,6 +72,8 @@ SIGNATURES = {
     "adv_patch_apply_f32": [_P, _P, _I, _F3, _F3, _P],
     "adv_psv_build_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "adv_psv_build_bwd_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "adv_psv_build_lerp_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "adv_psv_build_lerp_bwd_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "adv_roi_align_fwd_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P],
     "adv_roi_align_bwd_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P, _P],
     "adv_nms_f32": [_P, _I, _F, _P, _P, _P, _P],

@@ -91,7 +91,7 @@ class PsvStereoAdapter:
     plane-sweep network" can be measured end to end on this hardware."""
 
     def __init__(self, device, seed=0, channels=32, planes=48, min_depth=2.0, depth_step=0.8, fu=721.5377,
-                 baseline=0.54, downsample=4, mid=32, mfma_conv=True):
+                 baseline=0.54, downsample=4, mid=32, mfma_conv=True, interp=True):
         from . import ops
         self.ops = ops
         gen = torch.Generator().manual_seed(seed)
@@ -107,6 +107,9 @@ class PsvStereoAdapter:
         self.depth = (min_depth + depth_step * torch.arange(planes, dtype=torch.float32)).to(device)
         self.fu, self.baseline, self.downsample = fu, baseline, downsample
         self.device = device
+        # interp=True: the fractional per-plane disparities fu*b/depth/4 go to the interpolating cost volume
+        # (ops.PsvBuildLerp); interp=False rounds them to integers (ops.PsvBuild, round 1's behaviour)
+        self.interp = interp
         # the two wide 3x3x3 convolutions run on libadvengine's float32-MFMA kernel (weights re-laid-out once, for the
         # forward and for the adjoint); mfma_conv=False routes them through torch / MIOpen instead
         self.mfma_conv = mfma_conv and (2 * channels) % 4 == 0 and mid % 4 == 0
@@ -118,6 +121,8 @@ class PsvStereoAdapter:
 
     def shifts(self, b):
         disp = self.fu * self.baseline / self.depth / self.downsample       # feature-pixel disparity per plane
+        if self.interp:
+            return disp.to(torch.float32).repeat(b, 1).contiguous()
         return disp.round().to(torch.int32).repeat(b, 1).contiguous()
 
     def features(self, img):
@@ -127,7 +132,8 @@ class PsvStereoAdapter:
 
     def depth_pred(self, imgL, imgR):
         fl, fr = self.features(imgL), self.features(imgR)
-        cost = self.ops.PsvBuild.apply(fl.contiguous(), fr.contiguous(), self.shifts(imgL.shape[0]))
+        build = self.ops.PsvBuildLerp if self.interp else self.ops.PsvBuild
+        cost = build.apply(fl.contiguous(), fr.contiguous(), self.shifts(imgL.shape[0]))
         if self.mfma_conv:
             v = F.relu(self.ops.Conv3dK3.apply(cost, self.p1, self.p1t, self.mid))
             v = F.relu(self.ops.Conv3dK3.apply(v, self.p2, self.p2t, self.mid))

@@ -50,8 +50,46 @@ __device__ __forceinline__ v4f funnel(v4f a, v4f b, int rem) {
 // LDS per row: [ W/4 zero float4 | W/4 float4 of the right-eye row | 1 spare ], so that index
 // (W/4 + x4 - ceil(s/4) ...) never leaves the buffer for 0 <= s <= W.
 // ---------------------------------------------------------------------------------------------------
-template <bool NT>
-__global__ void psv_fwd_plane(const v4f* __restrict__ left, const v4f* __restrict__ right, const int32_t* __restrict__ shift,
+// One depth plane's disparity.  Integer form: shift s.  Interpolating form (LERP): a float shift sf, split into
+// s0 = floor(sf) and w1 = sf - s0; the right-eye value at x - sf is w0 * R[x - s0] + w1 * R[x - s0 - 1] with w0 = 1 - w1
+// (R zero-extended), and both halves are zero for x < sc = ceil(sf).  With w1 == 0 it degenerates to the integer form.
+struct PlaneShift {
+  int s0, sc;
+  float w0, w1;
+};
+
+template <bool LERP>
+__device__ __forceinline__ PlaneShift plane_shift(const void* shift, int idx, int w) {
+  PlaneShift p;
+  if (LERP) {
+    float sf = static_cast<const float*>(shift)[idx];
+    sf = sf >= 0.0f ? sf : 0.0f;  // also maps NaN to 0
+    sf = sf > static_cast<float>(w) ? static_cast<float>(w) : sf;
+    const float fl = floorf(sf);
+    p.s0 = static_cast<int>(fl);
+    p.w1 = sf - fl;
+    p.w0 = 1.0f - p.w1;
+    p.sc = p.w1 > 0.0f ? p.s0 + 1 : p.s0;
+  } else {
+    int s = static_cast<const int32_t*>(shift)[idx];
+    s = s < 0 ? 0 : (s > w ? w : s);
+    p.s0 = p.sc = s;
+    p.w0 = 1.0f;
+    p.w1 = 0.0f;
+  }
+  return p;
+}
+
+__device__ __forceinline__ v4f mask_below(v4f v, int x, int sc) {
+  if (x < sc) v.x = 0.0f;
+  if (x + 1 < sc) v.y = 0.0f;
+  if (x + 2 < sc) v.z = 0.0f;
+  if (x + 3 < sc) v.w = 0.0f;
+  return v;
+}
+
+template <bool NT, bool LERP>
+__global__ void psv_fwd_plane(const v4f* __restrict__ left, const v4f* __restrict__ right, const void* __restrict__ shift,
                               v4f* __restrict__ cost, int C, int D, int H, int w4) {
   extern __shared__ __attribute__((aligned(16))) float lds_raw[];
   v4f* lds = reinterpret_cast<v4f*>(lds_raw);
@@ -74,15 +112,16 @@ __global__ void psv_fwd_plane(const v4f* __restrict__ left, const v4f* __restric
   }
   __syncthreads();
   if (!active) return;
-  int s = shift[b * D + d];
-  s = s < 0 ? 0 : (s > 4 * w4 ? 4 * w4 : s);
+  const PlaneShift ps = plane_shift<LERP>(shift, b * D + d, 4 * w4);
   const int x = x4 * 4;
-  if (x < s) lv.x = 0.0f;
-  if (x + 1 < s) lv.y = 0.0f;
-  if (x + 2 < s) lv.z = 0.0f;
-  if (x + 3 < s) lv.w = 0.0f;
-  const int p = 4 * w4 + x - s;
-  const v4f ro = funnel(lds[r * row_pitch + (p >> 2)], lds[r * row_pitch + (p >> 2) + 1], p & 3);
+  lv = mask_below(lv, x, ps.sc);
+  const int p = 4 * w4 + x - ps.s0;
+  v4f ro = funnel(lds[r * row_pitch + (p >> 2)], lds[r * row_pitch + (p >> 2) + 1], p & 3);
+  if (LERP) {  // the neighbour one pixel further left, from the same LDS row: no extra HBM traffic
+    const int p1 = p - 1;
+    const v4f r1 = p1 >= 0 ? funnel(lds[r * row_pitch + (p1 >> 2)], lds[r * row_pitch + (p1 >> 2) + 1], p1 & 3) : zero4();
+    ro = mask_below(ps.w0 * ro + ps.w1 * r1, x, ps.sc);
+  }
   const long long out_l = ((static_cast<long long>(b) * 2 * C + c) * D + d) * plane + static_cast<long long>(y0 + r) * w4 + x4;
   const long long out_r = out_l + static_cast<long long>(C) * D * plane;
   if (NT) {
@@ -99,8 +138,8 @@ __global__ void psv_fwd_plane(const v4f* __restrict__ left, const v4f* __restric
 // plane's rows go through a 2-deep LDS ring ([row | zero apron]) so that the shifted read x + s is again
 // two aligned float4 + a uniform select; one barrier per plane.
 // ---------------------------------------------------------------------------------------------------
-template <bool NT>
-__global__ void psv_bwd_vec4(const v4f* __restrict__ gcost, const int32_t* __restrict__ shift, v4f* __restrict__ gleft,
+template <bool NT, bool LERP>
+__global__ void psv_bwd_vec4(const v4f* __restrict__ gcost, const void* __restrict__ shift, v4f* __restrict__ gleft,
                              v4f* __restrict__ gright, int C, int D, int H, int w4) {
   extern __shared__ __attribute__((aligned(16))) float lds_raw[];
   v4f* lds = reinterpret_cast<v4f*>(lds_raw);
@@ -134,27 +173,24 @@ __global__ void psv_bwd_vec4(const v4f* __restrict__ gcost, const int32_t* __res
   for (int d = 0; d < D; ++d) {
     const v4f gl = gl_next, gr = gr_next;
     v4f* buf = lds + (d & 1) * buf_pitch;
-    if (active) buf[r * row_pitch + x4] = gr;
+    const PlaneShift ps = plane_shift<LERP>(shift, b * D + d, 4 * w4);
+    // (LERP: the forward zeroes its output below sc, so those gradient elements do not flow back)
+    if (active) buf[r * row_pitch + x4] = LERP ? mask_below(gr, x, ps.sc) : gr;
     if (active && d + 1 < D) {  // prefetch the next plane while this one is exchanged through LDS
       gl_next = NT ? __builtin_nontemporal_load(gcost + in_l + static_cast<long long>(d + 1) * plane) : gcost[in_l + static_cast<long long>(d + 1) * plane];
       gr_next = NT ? __builtin_nontemporal_load(gcost + in_r + static_cast<long long>(d + 1) * plane) : gcost[in_r + static_cast<long long>(d + 1) * plane];
     }
     __syncthreads();  // plane d is in buf; the other buffer (plane d-1) is free to be overwritten next trip
-    int s = shift[b * D + d];
-    s = s < 0 ? 0 : (s > 4 * w4 ? 4 * w4 : s);
     if (active) {
-      v4f m = gl;
-      if (x < s) m.x = 0.0f;
-      if (x + 1 < s) m.y = 0.0f;
-      if (x + 2 < s) m.z = 0.0f;
-      if (x + 3 < s) m.w = 0.0f;
+      const v4f m = mask_below(gl, x, ps.sc);
       accl = (d == 0) ? m : accl + m;
-      const int p = x + s;  // floats [x + s, x + s + 4) of the zero-extended plane row
-      const int base = p >> 2;
-      const int rem = p & 3;
-      const v4f a = buf[r * row_pitch + base];
-      const v4f bb = buf[r * row_pitch + base + 1];
-      const v4f t = funnel(a, bb, rem);
+      const int p = x + ps.s0;  // floats [x + s0, x + s0 + 4) of the zero-extended plane row
+      v4f t = funnel(buf[r * row_pitch + (p >> 2)], buf[r * row_pitch + (p >> 2) + 1], p & 3);
+      if (LERP) {
+        const int p1 = p + 1;
+        const v4f t1 = funnel(buf[r * row_pitch + (p1 >> 2)], buf[r * row_pitch + (p1 >> 2) + 1], p1 & 3);
+        t = ps.w0 * t + ps.w1 * t1;
+      }
       accr = (d == 0) ? t : accr + t;
     }
   }
@@ -168,7 +204,8 @@ __global__ void psv_bwd_vec4(const v4f* __restrict__ gcost, const int32_t* __res
 // ---------------------------------------------------------------------------------------------------
 // general widths (W % 4 != 0 or unaligned pointers): one lane per element, no LDS
 // ---------------------------------------------------------------------------------------------------
-__global__ void psv_fwd_scalar(const float* __restrict__ left, const float* __restrict__ right, const int32_t* __restrict__ shift,
+template <bool LERP>
+__global__ void psv_fwd_scalar(const float* __restrict__ left, const float* __restrict__ right, const void* __restrict__ shift,
                                float* __restrict__ cost, int B, int C, int D, int H, int W) {
   const long long total = static_cast<long long>(B) * C * D * H * W;
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += gridDim.x * 256LL) {
@@ -180,18 +217,23 @@ __global__ void psv_fwd_scalar(const float* __restrict__ left, const float* __re
     t /= D;
     const int c = static_cast<int>(t % C);
     const int b = static_cast<int>(t / C);
-    int s = shift[b * D + d];
-    s = s < 0 ? 0 : s;
+    const PlaneShift ps = plane_shift<LERP>(shift, b * D + d, W);
     const long long src = ((static_cast<long long>(b) * C + c) * H + y) * W;
     const long long dl = (((static_cast<long long>(b) * 2 * C + c) * D + d) * H + y) * W + x;
     const long long dr = dl + static_cast<long long>(C) * D * H * W;
-    const bool in = x >= s;
+    const bool in = x >= ps.sc;
     cost[dl] = in ? left[src + x] : 0.0f;
-    cost[dr] = in ? right[src + x - s] : 0.0f;
+    float rv = in ? right[src + x - ps.s0] : 0.0f;
+    if (LERP && in) {
+      const float r1 = x - ps.s0 - 1 >= 0 ? right[src + x - ps.s0 - 1] : 0.0f;
+      rv = ps.w0 * rv + ps.w1 * r1;
+    }
+    cost[dr] = rv;
   }
 }
 
-__global__ void psv_bwd_scalar(const float* __restrict__ gcost, const int32_t* __restrict__ shift, float* __restrict__ gleft,
+template <bool LERP>
+__global__ void psv_bwd_scalar(const float* __restrict__ gcost, const void* __restrict__ shift, float* __restrict__ gleft,
                                float* __restrict__ gright, int B, int C, int D, int H, int W) {
   const long long total = static_cast<long long>(B) * C * H * W;
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += gridDim.x * 256LL) {
@@ -203,12 +245,16 @@ __global__ void psv_bwd_scalar(const float* __restrict__ gcost, const int32_t* _
     const int b = static_cast<int>(t / C);
     float al = 0.0f, ar = 0.0f;
     for (int d = 0; d < D; ++d) {
-      int s = shift[b * D + d];
-      s = s < 0 ? 0 : s;
+      const PlaneShift ps = plane_shift<LERP>(shift, b * D + d, W);
       const long long gl = (((static_cast<long long>(b) * 2 * C + c) * D + d) * H + y) * W;
       const long long gr = gl + static_cast<long long>(C) * D * H * W;
-      const float vl = x >= s ? gcost[gl + x] : 0.0f;
-      const float vr = (x + s < W) ? gcost[gr + x + s] : 0.0f;
+      const float vl = x >= ps.sc ? gcost[gl + x] : 0.0f;
+      const int xo = x + ps.s0;
+      float vr = (xo < W && xo >= ps.sc) ? gcost[gr + xo] : 0.0f;
+      if (LERP) {
+        const float v1 = (xo + 1 < W && xo + 1 >= ps.sc) ? gcost[gr + xo + 1] : 0.0f;
+        vr = ps.w0 * vr + ps.w1 * v1;
+      }
       al = d == 0 ? vl : al + vl;
       ar = d == 0 ? vr : ar + vr;
     }
@@ -229,6 +275,44 @@ inline int check(const void* a, const void* b, const void* c, const void* d, int
   return ADV_OK;
 }
 
+template <bool LERP>
+int launch_psv_fwd(const float* left, const float* right, const void* shift, float* cost, int b, int c, int d, int h, int w, hipStream_t st) {
+  const int w4 = w / 4;
+  const int threads = ((kRows * w4 + 63) / 64) * 64;
+  const size_t lds = static_cast<size_t>(kRows) * (2 * w4 + 1) * sizeof(v4f);
+  const bool vec = (w % 4 == 0) && threads <= 1024 && lds <= 65536 && aligned(left, 16) && aligned(right, 16) && aligned(cost, 16);
+  if (vec) {
+    if (static_cast<long long>(b) * c > 65535 || d > 65535) return ADV_EINVAL;
+    hipLaunchKernelGGL((psv_fwd_plane<true, LERP>), dim3((h + kRows - 1) / kRows, d, b * c), dim3(threads), lds, st,
+                       reinterpret_cast<const v4f*>(left), reinterpret_cast<const v4f*>(right), shift, reinterpret_cast<v4f*>(cost), c, d, h, w4);
+  } else {
+    const long long total = static_cast<long long>(b) * c * d * h * w;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 1 << 20) blocks = 1 << 20;
+    hipLaunchKernelGGL((psv_fwd_scalar<LERP>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, left, right, shift, cost, b, c, d, h, w);
+  }
+  return finish();
+}
+
+template <bool LERP>
+int launch_psv_bwd(const float* grad_cost, const void* shift, float* grad_left, float* grad_right, int b, int c, int d, int h, int w,
+                   hipStream_t st) {
+  const int w4 = w / 4;
+  const int threads = ((kRows * w4 + 63) / 64) * 64;
+  const size_t lds = 2 * static_cast<size_t>(kRows) * (2 * w4 + 1) * sizeof(v4f);
+  const bool vec = (w % 4 == 0) && threads <= 1024 && lds <= 65536 && aligned(grad_cost, 16) && aligned(grad_left, 16) && aligned(grad_right, 16);
+  if (vec) {
+    hipLaunchKernelGGL((psv_bwd_vec4<true, LERP>), dim3((h + kRows - 1) / kRows, c, b), dim3(threads), lds, st,
+                       reinterpret_cast<const v4f*>(grad_cost), shift, reinterpret_cast<v4f*>(grad_left), reinterpret_cast<v4f*>(grad_right), c, d, h, w4);
+  } else {
+    const long long total = static_cast<long long>(b) * c * h * w;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 1 << 20) blocks = 1 << 20;
+    hipLaunchKernelGGL((psv_bwd_scalar<LERP>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, grad_cost, shift, grad_left, grad_right, b, c, d, h, w);
+  }
+  return finish();
+}
+
 }  // namespace
 
 extern "C" {
@@ -237,45 +321,28 @@ int adv_psv_build_f32(const float* left, const float* right, const int32_t* shif
                       int w, adv_stream_t stream) {
   const int rc = check(left, right, shift, cost, b, c, d, h, w);
   if (rc != ADV_OK) return rc;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  const int w4 = w / 4;
-  const int threads = ((kRows * w4 + 63) / 64) * 64;
-  const size_t lds = static_cast<size_t>(kRows) * (2 * w4 + 1) * sizeof(v4f);
-  const bool vec = (w % 4 == 0) && threads <= 1024 && lds <= 65536 && aligned(left, 16) && aligned(right, 16) && aligned(cost, 16);
-  if (vec) {
-    if (static_cast<long long>(b) * c > 65535 || d > 65535) return ADV_EINVAL;
-    hipLaunchKernelGGL((psv_fwd_plane<true>), dim3((h + kRows - 1) / kRows, d, b * c), dim3(threads), lds, st,
-                       reinterpret_cast<const v4f*>(left), reinterpret_cast<const v4f*>(right), shift,
-                       reinterpret_cast<v4f*>(cost), c, d, h, w4);
-  } else {
-    const long long total = static_cast<long long>(b) * c * d * h * w;
-    long long blocks = (total + 255) / 256;
-    if (blocks > 1 << 20) blocks = 1 << 20;
-    hipLaunchKernelGGL(psv_fwd_scalar, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, left, right, shift, cost, b, c, d, h, w);
-  }
-  return finish();
+  return launch_psv_fwd<false>(left, right, shift, cost, b, c, d, h, w, static_cast<hipStream_t>(stream));
 }
 
 int adv_psv_build_bwd_f32(const float* grad_cost, const int32_t* shift, float* grad_left, float* grad_right, int b, int c,
                           int d, int h, int w, adv_stream_t stream) {
   const int rc = check(grad_cost, shift, grad_left, grad_right, b, c, d, h, w);
   if (rc != ADV_OK) return rc;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  const int w4 = w / 4;
-  const int threads = ((kRows * w4 + 63) / 64) * 64;
-  const size_t lds = 2 * static_cast<size_t>(kRows) * (2 * w4 + 1) * sizeof(v4f);
-  const bool vec = (w % 4 == 0) && threads <= 1024 && lds <= 65536 && aligned(grad_cost, 16) && aligned(grad_left, 16) && aligned(grad_right, 16);
-  if (vec) {
-    const dim3 grid((h + kRows - 1) / kRows, c, b);
-    hipLaunchKernelGGL((psv_bwd_vec4<true>), grid, dim3(threads), lds, st, reinterpret_cast<const v4f*>(grad_cost), shift,
-                       reinterpret_cast<v4f*>(grad_left), reinterpret_cast<v4f*>(grad_right), c, d, h, w4);
-  } else {
-    const long long total = static_cast<long long>(b) * c * h * w;
-    long long blocks = (total + 255) / 256;
-    if (blocks > 1 << 20) blocks = 1 << 20;
-    hipLaunchKernelGGL(psv_bwd_scalar, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, grad_cost, shift, grad_left, grad_right, b, c, d, h, w);
-  }
-  return finish();
+  return launch_psv_bwd<false>(grad_cost, shift, grad_left, grad_right, b, c, d, h, w, static_cast<hipStream_t>(stream));
+}
+
+int adv_psv_build_lerp_f32(const float* left, const float* right, const float* shift, float* cost, int b, int c, int d, int h,
+                           int w, adv_stream_t stream) {
+  const int rc = check(left, right, shift, cost, b, c, d, h, w);
+  if (rc != ADV_OK) return rc;
+  return launch_psv_fwd<true>(left, right, shift, cost, b, c, d, h, w, static_cast<hipStream_t>(stream));
+}
+
+int adv_psv_build_lerp_bwd_f32(const float* grad_cost, const float* shift, float* grad_left, float* grad_right, int b, int c,
+                               int d, int h, int w, adv_stream_t stream) {
+  const int rc = check(grad_cost, shift, grad_left, grad_right, b, c, d, h, w);
+  if (rc != ADV_OK) return rc;
+  return launch_psv_bwd<true>(grad_cost, shift, grad_left, grad_right, b, c, d, h, w, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

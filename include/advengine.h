@@ -195,6 +195,21 @@ ADV_API int adv_psv_build_f32(const float* left, const float* right, const int32
 ADV_API int adv_psv_build_bwd_f32(const float* grad_cost, const int32_t* shift, float* grad_left,
                           float* grad_right, int b, int c, int d, int h, int w, adv_stream_t stream);
 
+/* K7, interpolating form: the per-plane disparity fu * baseline / depth_d / downsample is fractional for almost every
+ *     plane, so `shift` is DEVICE float32 [B,D], sf >= 0.  With s0 = floor(sf), w1 = sf - s0, w0 = 1 - w1, sc = ceil(sf):
+ *         for x >= sc:  cost[b,c,d,y,x]   = left[b,c,y,x]
+ *                       cost[b,C+c,d,y,x] = w0 * right[b,c,y,x-s0] + w1 * right[b,c,y,x-s0-1]     (right zero-extended)
+ *         for x <  sc:  both 0.
+ *     The two neighbours come from the same LDS-staged row (no extra HBM traffic); w1 == 0 reproduces
+ *     adv_psv_build_f32.  Like the integer form it follows the published construction and is UNPINNED against upstream. */
+ADV_API int adv_psv_build_lerp_f32(const float* left, const float* right, const float* shift, float* cost, int b, int c,
+                                   int d, int h, int w, adv_stream_t stream);
+
+/* its exact adjoint (w.r.t. left and right; the shifts are constants of the attack), per plane
+ *     w0 * g[x+s0] + w1 * g[x+s0+1], summed over d = 0..D-1 in that order in float32 (no atomics). */
+ADV_API int adv_psv_build_lerp_bwd_f32(const float* grad_cost, const float* shift, float* grad_left, float* grad_right,
+                                       int b, int c, int d, int h, int w, adv_stream_t stream);
+
 /* ---- Stereo R-CNN RoI path natives.  The ops are `from model.roi_layers import ROIAlign, nms`
  *      (attack/Stereo-RCNN/stereo_rcnn.py:18,44-45,132-134; predict_and_save_pgd.py:26,300) - compiled
  *      extensions of the upstream Stereo R-CNN checkout, absent from the reference tree.  These follow the

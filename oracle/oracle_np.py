@@ -309,6 +309,61 @@ def psv_build_bwd(grad_cost, shift):
     return gl, gr
 
 
+def _lerp_plane(sf, w):
+    sf = F32(sf)
+    sf = F32(0) if not (sf >= 0) else sf
+    sf = F32(w) if sf > F32(w) else sf
+    s0 = int(np.floor(sf))
+    w1 = F32(sf - F32(s0))
+    return s0, (s0 + 1 if w1 > 0 else s0), F32(F32(1) - w1), w1
+
+
+def psv_build_lerp(left, right, shift):
+    """Interpolating form of psv_build (csrc/psv.hip, LERP): float shift sf per plane; for x >= ceil(sf)
+    cost_r[x] = w0 * right[x - s0] + w1 * right[x - s0 - 1] (zero-extended), s0 = floor(sf), w1 = sf - s0.  UNPINNED."""
+    left, right = _f32(left), _f32(right)
+    b, c, h, w = left.shape
+    d = shift.shape[1]
+    cost = np.zeros((b, 2 * c, d, h, w), np.float32)
+    for bi in range(b):
+        rz = np.concatenate([np.zeros((c, h, w + 1), np.float32), right[bi]], axis=2)       # rz[..., w + 1 + i] = right[i]
+        for di in range(d):
+            s0, sc, w0, w1 = _lerp_plane(shift[bi, di], w)
+            x = np.arange(sc, w)
+            if x.size == 0:
+                continue
+            cost[bi, :c, di, :, sc:] = left[bi, :, :, sc:]
+            a = rz[:, :, w + 1 + x - s0]
+            bb = rz[:, :, w + 1 + x - s0 - 1]
+            cost[bi, c:, di, :, sc:] = F32(w0) * a + F32(w1) * bb
+    return cost
+
+
+def psv_build_lerp_bwd(grad_cost, shift):
+    """exact adjoint of psv_build_lerp: per plane w0 * g[x + s0] + w1 * g[x + s0 + 1] over the unmasked outputs, planes
+    summed d = 0, 1, ... in float32"""
+    g = _f32(grad_cost)
+    b, c2, d, h, w = g.shape
+    c = c2 // 2
+    gl = np.zeros((b, c, h, w), np.float32)
+    gr = np.zeros((b, c, h, w), np.float32)
+    for bi in range(b):
+        for di in range(d):
+            s0, sc, w0, w1 = _lerp_plane(shift[bi, di], w)
+            tl = np.zeros((c, h, w), np.float32)
+            tl[:, :, sc:] = g[bi, :c, di, :, sc:]
+            gm = np.zeros((c, h, 2 * w + 2), np.float32)                                    # masked, zero-extended gradient row
+            gm[:, :, sc:w] = g[bi, c:, di, :, sc:]
+            x = np.arange(w)
+            tr = F32(w0) * gm[:, :, x + s0] + F32(w1) * gm[:, :, x + s0 + 1]
+            if di == 0:
+                gl[bi], gr[bi] = tl, tr
+            else:
+                gl[bi] += tl
+                gr[bi] += tr
+    return gl, gr
+
+
 # ----------------------------------------------------------------------------- RoI path (8f row 3)
 def _roi_taps(height, width, y, x):
     """bilinear_interpolate pre-computation of maskrcnn-benchmark's ROIAlign (float32, same op order as the

@@ -96,3 +96,71 @@ def test_hip_psv_autograd_function():
     (cost * w).sum().backward()
     wl, wr = O.psv_build_bwd(w.cpu().numpy(), shift)
     assert tl.grad.cpu().numpy().tobytes() == wl.tobytes() and tr.grad.cpu().numpy().tobytes() == wr.tobytes()
+
+
+# ------------------------------------------------------------------------------------------ interpolating form
+def _float_shifts(b, d, w, seed):
+    rs = np.random.RandomState(seed)
+    sf = np.sort((rs.rand(b, d) * min(w, 60)).astype(np.float32), axis=1)[:, ::-1].copy()
+    sf[0, 0] = np.float32(7.0)                                           # integral: degenerates to the integer form
+    sf[-1, -1] = np.float32(0.0)
+    if d > 2:
+        sf[0, 1] = np.float32(w)                                         # a plane that is entirely zero
+    if d > 3:
+        sf[0, 2] = np.float32(-2.5)                                      # negative: treated as 0
+        sf[-1, 0] = np.float32(w + 17.3)                                 # beyond the row: treated as W
+    if d > 4:
+        sf[0, 3] = np.float32(w - 0.25)                                  # only the last column survives
+    return sf
+
+
+@pytest.mark.parametrize("shape", [(1, 3, 6, 4, 16), (2, 2, 7, 3, 12)])
+def test_oracle_lerp_is_the_adjoint_pair_and_contains_the_integer_form(shape):
+    b, c, d, h, w = shape
+    left, right, shift = _inputs(b, c, d, h, w, seed=sum(shape))
+    # integral float shifts reproduce the integer volume (up to the sign of zero) and its adjoint
+    assert np.array_equal(O.psv_build_lerp(left, right, shift.astype(np.float32)), O.psv_build(left, right, shift))
+    sf = _float_shifts(b, d, w, 5)
+    cost = O.psv_build_lerp(left, right, sf)
+    # against a direct definition: value of the zero-extended right row at x - sf by linear interpolation
+    for bi in range(b):
+        for di in range(d):
+            s = float(np.clip(sf[bi, di], 0, w))
+            for x in range(w):
+                pos = x - s
+                if x < np.ceil(s):
+                    assert not cost[bi, :, di, :, x].any()
+                    continue
+                i0 = int(np.floor(pos + 1e-9)) if abs(pos - round(pos)) < 1e-6 else int(np.floor(pos))
+                frac = pos - i0
+                v = (1 - frac) * right[bi, :, :, i0] + (frac * right[bi, :, :, i0 + 1] if i0 + 1 < w and frac > 0 else 0)
+                np.testing.assert_allclose(cost[bi, c:, di, :, x], v, rtol=1e-5, atol=1e-5)
+                assert np.array_equal(cost[bi, :c, di, :, x], left[bi, :, :, x])
+    g = np.random.RandomState(1).randn(*cost.shape).astype(np.float32)
+    gl, gr = O.psv_build_lerp_bwd(g, sf)
+    lhs = float((cost.astype(np.float64) * g).sum())
+    rhs = float((left.astype(np.float64) * gl).sum() + (right.astype(np.float64) * gr).sum())
+    assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", GPU_SHAPES)
+def test_hip_psv_lerp_matches_oracle(shape):
+    from eval_driving_safety_amd import ops
+    b, c, d, h, w = shape
+    left, right, _ = _inputs(b, c, d, h, w, seed=sum(shape))
+    sf = _float_shifts(b, d, w, sum(shape))
+    dev = torch.device("cuda", 0)
+    tl, tr, ts = torch.tensor(left, device=dev), torch.tensor(right, device=dev), torch.tensor(sf, device=dev)
+    cost = ops.psv_build_lerp(tl, tr, ts)
+    want = O.psv_build_lerp(left, right, sf)
+    assert cost.cpu().numpy().tobytes() == want.tobytes(), "forward"
+    g = np.random.RandomState(2).randn(*want.shape).astype(np.float32)
+    gl, gr = ops.psv_build_lerp_bwd(torch.tensor(g, device=dev), ts)
+    wl, wr = O.psv_build_lerp_bwd(g, sf)
+    assert gl.cpu().numpy().tobytes() == wl.tobytes(), "grad_left"
+    assert gr.cpu().numpy().tobytes() == wr.tobytes(), "grad_right"
+    # autograd face
+    tl2, tr2 = tl.clone().requires_grad_(True), tr.clone().requires_grad_(True)
+    (ops.PsvBuildLerp.apply(tl2, tr2, ts) * torch.tensor(g, device=dev)).sum().backward()
+    assert tl2.grad.cpu().numpy().tobytes() == wl.tobytes() and tr2.grad.cpu().numpy().tobytes() == wr.tobytes()
