@@ -11,7 +11,8 @@ import os
 import torch  # noqa: F401  (see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libadvengine.so")
+# ADVENGINE_LIB: tuning builds of the same library (tools/); the default is the in-tree build next to this file
+LIB_PATH = os.environ.get("ADVENGINE_LIB") or os.path.join(_HERE, "libadvengine.so")
 
 ADV_OK = 0
 ADV_EINVAL = -22

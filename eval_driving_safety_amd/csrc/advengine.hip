@@ -401,12 +401,19 @@ __global__ __launch_bounds__(kWave) void clean_index_build_vec4(const v4f* x, v4
 // neighbour, are written by BOTH as single bytes, each storing the channels it owns (distinct bytes, no race).
 // No lane ever reads an element it does not own, so x_out may alias x (in place) with the export on - round 1's
 // version re-read neighbours' x in "halo" lanes and could not.
-// Workgroup = 256 lanes = 256 pixel groups per channel; grid = (tiles, images).
+// Workgroup = ONE wave = 64 pixel groups per channel, grid = (tiles, images): measured on 128 images of 600 x 1987 with the
+// export fused and the update in place (tools/sb_sweep.sh, profiles/r02_srcnn_shape_sweep.log): 64 lanes x 1 sub-tile
+// 1.267 ms = 0.768 of peak; 64 x 2: 0.732; 128 x 1: 0.729; 256 x 1 (round 1): 0.724; 256 x 2: 0.704; 512 x 1: 0.691.
 // ------------------------------------------------------------------------------------------
 #ifndef ADV_SHIFT_BLOCK
-#define ADV_SHIFT_BLOCK 256
+#define ADV_SHIFT_BLOCK 64
 #endif
-constexpr int kShiftBlock = ADV_SHIFT_BLOCK;
+#ifndef ADV_SHIFT_UNROLL
+#define ADV_SHIFT_UNROLL 1
+#endif
+constexpr int kShiftBlock = ADV_SHIFT_BLOCK;      // lanes per workgroup
+constexpr int kShiftUnroll = ADV_SHIFT_UNROLL;    // consecutive sub-tiles of kShiftBlock groups per workgroup
+constexpr int kShiftTile = kShiftBlock * kShiftUnroll;
 
 template <int KIND>
 __device__ __forceinline__ uint32_t pack_channel4(const v4f& o, float sc, float sh, double add) {
@@ -437,57 +444,79 @@ template <int KIND, int U8>
 __global__ __launch_bounds__(kShiftBlock) void pgd_step_shifted(const v4f* x, const v4f* __restrict__ g,
                                                                 const v4f* __restrict__ cl, v4f* xo, long long n_img, int hw4,
                                                                 int w, int base_f4, SpaceK sp, float alpha, float eps, U8Dst u8) {
-  __shared__ uint32_t words[3][kShiftBlock];
-  const int j = threadIdx.x;
   constexpr bool kExchange = (U8 == U8_ROWS_DWORD || U8 == U8_FLAT_DWORD);
+  __shared__ uint32_t words[kExchange ? 3 : 1][kExchange ? kShiftTile : 1];
+  const int j = threadIdx.x;
   for (long long img = blockIdx.y; img < n_img; img += gridDim.y) {
     const long long plane0 = img * 3LL * hw4;
     int m[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) m[c] = static_cast<int>((base_f4 + plane0 + static_cast<long long>(c) * hw4) & 7);
     const int m_min = min(m[0], min(m[1], m[2])), m_max = max(m[0], max(m[1], m[2]));
-    const int tile = blockIdx.x * kShiftBlock;
-    const int common_lo = tile - m_min, common_hi = min(tile - m_max + kShiftBlock, hw4);  // groups all 3 channels cover here
+    const int tile = blockIdx.x * kShiftTile;
+    const int common_lo = tile - m_min, common_hi = min(tile - m_max + kShiftTile, hw4);  // groups all 3 channels cover here
+    // all loads first (3 channels x kShiftUnroll groups x 3 arrays in flight per lane), then the arithmetic
+    v4f X[kShiftUnroll][3], G[kShiftUnroll][3], C[kShiftUnroll][3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const int q = tile - m[c] + j;  // this lane's pixel group in channel c: line-aligned per wave
-      if (q >= 0 && q < hw4) {
-        const long long i = plane0 + static_cast<long long>(c) * hw4 + q;
-        const v4f X = ld_stream(x + i), G = ld_stream(g + i), C = ld_stream(cl + i);
-        v4f O;
+    for (int u = 0; u < kShiftUnroll; ++u) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) O[k] = pgd_elem<KIND>(X[k], G[k], C[k], sp.scale[c], sp.shift[c], sp.lo[c], sp.hi[c], alpha, eps);
-        st_stream(xo + i, O);
-        if (U8 != U8_NONE) {
-          const uint32_t word = pack_channel4<KIND>(O, sp.scale[c], sp.shift[c], sp.export_add[c]);
-          if (kExchange) {
-            words[c][j] = word;
-            if (q < common_lo || q >= common_hi) store_channel_bytes<U8>(word, c, img, q, w, u8);  // <= 7 groups per end
-          } else {
-            store_channel_bytes<U8>(word, c, img, q, w, u8);
+      for (int c = 0; c < 3; ++c) {
+        const int q = tile - m[c] + u * kShiftBlock + j;  // this lane's pixel group in channel c: line-aligned per wave
+        if (q >= 0 && q < hw4) {
+          const long long i = plane0 + static_cast<long long>(c) * hw4 + q;
+          X[u][c] = ld_stream(x + i);
+          G[u][c] = ld_stream(g + i);
+          C[u][c] = ld_stream(cl + i);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kShiftUnroll; ++u) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int q = tile - m[c] + u * kShiftBlock + j;
+        if (q >= 0 && q < hw4) {
+          const long long i = plane0 + static_cast<long long>(c) * hw4 + q;
+          v4f O;
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            O[k] = pgd_elem<KIND>(X[u][c][k], G[u][c][k], C[u][c][k], sp.scale[c], sp.shift[c], sp.lo[c], sp.hi[c], alpha, eps);
+          st_stream(xo + i, O);
+          if (U8 != U8_NONE) {
+            const uint32_t word = pack_channel4<KIND>(O, sp.scale[c], sp.shift[c], sp.export_add[c]);
+            if (kExchange) {
+              words[c][u * kShiftBlock + j] = word;
+              if (q < common_lo || q >= common_hi) store_channel_bytes<U8>(word, c, img, q, w, u8);  // <= 7 groups per end
+            } else {
+              store_channel_bytes<U8>(word, c, img, q, w, u8);
+            }
           }
         }
       }
     }
     if (kExchange) {
       __syncthreads();
-      const int q0 = common_lo + j;
-      if (q0 >= 0 && q0 < common_hi) {
-        const uint32_t w0 = words[0][j + m[0] - m_min];
-        const uint32_t w1 = words[1][j + m[1] - m_min];
-        const uint32_t w2 = words[2][j + m[2] - m_min];
-        v3u r;  // bytes: p0c0 p0c1 p0c2 p1c0 | p1c1 p1c2 p2c0 p2c1 | p2c2 p3c0 p3c1 p3c2
-        r[0] = (w0 & 0xffu) | ((w1 & 0xffu) << 8) | ((w2 & 0xffu) << 16) | (((w0 >> 8) & 0xffu) << 24);
-        r[1] = ((w1 >> 8) & 0xffu) | (((w2 >> 8) & 0xffu) << 8) | (((w0 >> 16) & 0xffu) << 16) | (((w1 >> 16) & 0xffu) << 24);
-        r[2] = ((w2 >> 16) & 0xffu) | (((w0 >> 24) & 0xffu) << 8) | (((w1 >> 24) & 0xffu) << 16) | (((w2 >> 24) & 0xffu) << 24);
-        if (U8 == U8_FLAT_DWORD) {
-          st_stream(reinterpret_cast<v3u*>(u8.base + img * u8.image_stride + 12LL * q0), r);
-        } else {
-          const int p = q0 * 4;
-          const int row = p / w;
-          if (row < u8.crop_h) {
-            const int col = p - row * w;
-            st_stream(reinterpret_cast<v3u*>(u8.base + img * u8.image_stride + row * u8.row_stride + col * 3LL), r);
+#pragma unroll
+      for (int u = 0; u < kShiftUnroll; ++u) {
+        const int jj = u * kShiftBlock + j;
+        const int q0 = common_lo + jj;
+        if (q0 >= 0 && q0 < common_hi) {
+          const uint32_t w0 = words[0][jj + m[0] - m_min];
+          const uint32_t w1 = words[1][jj + m[1] - m_min];
+          const uint32_t w2 = words[2][jj + m[2] - m_min];
+          v3u r;  // bytes: p0c0 p0c1 p0c2 p1c0 | p1c1 p1c2 p2c0 p2c1 | p2c2 p3c0 p3c1 p3c2
+          r[0] = (w0 & 0xffu) | ((w1 & 0xffu) << 8) | ((w2 & 0xffu) << 16) | (((w0 >> 8) & 0xffu) << 24);
+          r[1] = ((w1 >> 8) & 0xffu) | (((w2 >> 8) & 0xffu) << 8) | (((w0 >> 16) & 0xffu) << 16) | (((w1 >> 16) & 0xffu) << 24);
+          r[2] = ((w2 >> 16) & 0xffu) | (((w0 >> 24) & 0xffu) << 8) | (((w1 >> 24) & 0xffu) << 16) | (((w2 >> 24) & 0xffu) << 24);
+          if (U8 == U8_FLAT_DWORD) {
+            st_stream(reinterpret_cast<v3u*>(u8.base + img * u8.image_stride + 12LL * q0), r);
+          } else {
+            const int p = q0 * 4;
+            const int row = p / w;
+            if (row < u8.crop_h) {
+              const int col = p - row * w;
+              st_stream(reinterpret_cast<v3u*>(u8.base + img * u8.image_stride + row * u8.row_stride + col * 3LL), r);
+            }
           }
         }
       }
@@ -807,7 +836,7 @@ int launch_pgd(const float* x, const float* g, const float* cl, float* xo, long 
   if (vec && same_residue && (((hw / 4) & 7) != 0 || res != 0)) {
     // planes are not whole cache lines (or the buffers start inside one): per-channel shifted tiles
     const int hw4 = static_cast<int>(hw / 4);
-    const int tiles = (hw4 + 7 + kShiftBlock - 1) / kShiftBlock;
+    const int tiles = (hw4 + 7 + kShiftTile - 1) / kShiftTile;
     const dim3 grid(tiles, static_cast<unsigned>(n > 65535 ? 65535 : n), 1);
     const int base_f4 = static_cast<int>(res / 16);
     const v4f* x4 = reinterpret_cast<const v4f*>(x);
