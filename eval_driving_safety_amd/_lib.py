@@ -56,6 +56,7 @@ _F = ctypes.c_float
 _SP = ctypes.POINTER(AdvSpace)
 _F3 = ctypes.POINTER(ctypes.c_float)
 _CI = ctypes.POINTER(AdvCleanIndex)
+_I3 = ctypes.POINTER(ctypes.c_int32)
 
 # name -> argtypes; every function returns int unless listed in _OTHER_RESTYPE
 SIGNATURES = {
@@ -82,6 +83,7 @@ SIGNATURES = {
     "adv_dense_align_argmin_f32": [_P, _I, _I, _P, _F, _P, _P, _P],
     "adv_conv3d_k3_prep_weights_f32": [_P, _P, _I, _I, _I, _P],
     "adv_conv3d_k3_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "adv_conv3d_k3_ex_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, ctypes.c_uint32, _I3, _I3, _I3, _P],
 }
 _OTHER = {
     "adv_abi_version": ([], _I),

@@ -23,28 +23,61 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Where and how a workgroup's results are written: optional per-channel bias (folded batch-norm shift), optional ReLU,
+// and an output lattice out[(i * os + oo)] per axis - the identity for an ordinary convolution, stride 2 with offset
+// (pd, ph, pw) for one parity class of a transposed convolution.  tap_mask: bit t set = tap t = kd*9 + kh*3 + kw is used.
+struct Epi {
+  const float* bias;
+  int relu;
+  unsigned tap_mask;
+  int od, oh, ow;     // output tensor dims
+  int sd, sh, sw;     // output lattice stride
+  int fd, fh, fw;     // output lattice offset
+};
+
+constexpr unsigned kAllTaps = (1u << 27) - 1u;
+
+__device__ __forceinline__ void epi_store(const Epi& e, float* __restrict__ y, long long b, int Cout, int co, int gd, int gh, int gw, float r) {
+  const int zd = gd * e.sd + e.fd, zh = gh * e.sh + e.fh, zw = gw * e.sw + e.fw;
+  if (zd >= e.od || zh >= e.oh || zw >= e.ow) return;
+  if (e.bias) r = r + e.bias[co];
+  if (e.relu) r = r > 0.0f ? r : 0.0f;
+  y[((b * Cout + co) * e.od + zd) * (static_cast<long long>(e.oh) * e.ow) + static_cast<long long>(zh) * e.ow + zw] = r;
+}
+
 constexpr int kCK = 4;    // input channels per LDS stage (both kernels: one accumulation order)
 constexpr int kTD = 2;    // tile depth
 constexpr int kTH = 8;    // tile height
 constexpr int kTW = 32;   // tile width = MFMA N
-constexpr int kTWP = 36;  // padded LDS row (34 used)
 constexpr int kNB = (kTD * kTH) / 4;  // rows per wave
-constexpr int kSX = kCK * (kTD + 2) * (kTH + 2) * kTWP;
 constexpr int kSW = 27 * kCK * 32;
 
+// input tile of the generic kernel for convolution stride S: an output tile of kTD x kTH x 32 voxels reads
+// (S*(kTD-1)+3) x (S*(kTH-1)+3) x (S*31+3) inputs per channel
+template <int S>
+struct GenGeo {
+  static constexpr int kID = S * (kTD - 1) + 3, kIH = S * (kTH - 1) + 3, kIW = S * (kTW - 1) + 3;
+  static constexpr int kRow = kIW + 2;                                   // padded LDS row
+  static constexpr int kSX = kCK * kID * kIH * kRow;
+};
+
+// S = 1: any W / alignment (the main kernel below handles W % 4 == 0); S = 2: the strided convolution of an hourglass
+// (out = ceil(in / 2) per axis, padding 1).  D, H, W are the OUTPUT grid of the tile decomposition; iD, iH, iW the input dims.
+template <int S>
 __global__ __launch_bounds__(256) void conv3d_k3_mfma_generic(const float* __restrict__ x, const float* __restrict__ wp, float* __restrict__ y,
-                                                      int Cin, int Cout, int cout_pad, int D, int H, int W, int tiles_w, int cblocks,
-                                                      int relu) {
+                                                      int Cin, int Cout, int cout_pad, int D, int H, int W, int iD, int iH, int iW,
+                                                      int tiles_w, int cblocks, Epi epi) {
+  using GG = GenGeo<S>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* sx = lds;
-  float* sw = lds + kSX;
+  float* sw = lds + GG::kSX;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l32 = lane & 31;
   const int wt = blockIdx.x % tiles_w, ht = blockIdx.x / tiles_w;
   const int w0 = wt * kTW, h0 = ht * kTH, d0 = blockIdx.y * kTD;
   const int b = blockIdx.z / cblocks, cob = blockIdx.z - b * cblocks;
-  const long long plane = static_cast<long long>(H) * W;
-  const long long vol = plane * D;
+  const long long plane = static_cast<long long>(iH) * iW;
+  const long long vol = plane * iD;
 
   f32x16 acc[kNB];
 #pragma unroll
@@ -54,18 +87,18 @@ __global__ __launch_bounds__(256) void conv3d_k3_mfma_generic(const float* __res
 
   for (int c0 = 0; c0 < Cin; c0 += kCK) {
     // ---- stage the input tile (+ halo, zero padded) of kCK channels
-    for (int idx = tid; idx < kCK * (kTD + 2) * (kTH + 2) * 34; idx += 256) {
-      const int ww = idx % 34;
-      int t = idx / 34;
-      const int hh = t % (kTH + 2);
-      t /= (kTH + 2);
-      const int dd = t % (kTD + 2);
-      const int c = t / (kTD + 2);
-      const int gd = d0 + dd - 1, gh = h0 + hh - 1, gw = w0 + ww - 1;
+    for (int idx = tid; idx < kCK * GG::kID * GG::kIH * GG::kIW; idx += 256) {
+      const int ww = idx % GG::kIW;
+      int t = idx / GG::kIW;
+      const int hh = t % GG::kIH;
+      t /= GG::kIH;
+      const int dd = t % GG::kID;
+      const int c = t / GG::kID;
+      const int gd = S * d0 + dd - 1, gh = S * h0 + hh - 1, gw = S * w0 + ww - 1;
       float v = 0.0f;
-      if (gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W)
-        v = x[(static_cast<long long>(b) * Cin + c0 + c) * vol + gd * plane + static_cast<long long>(gh) * W + gw];
-      sx[((c * (kTD + 2) + dd) * (kTH + 2) + hh) * kTWP + ww] = v;
+      if (gd >= 0 && gd < iD && gh >= 0 && gh < iH && gw >= 0 && gw < iW)
+        v = x[(static_cast<long long>(b) * Cin + c0 + c) * vol + gd * plane + static_cast<long long>(gh) * iW + gw];
+      sx[((c * GG::kID + dd) * GG::kIH + hh) * GG::kRow + ww] = v;
     }
     // ---- stage the weights of this chunk: [27][kCK][32]
     for (int idx = tid; idx < kSW; idx += 256) {
@@ -77,6 +110,7 @@ __global__ __launch_bounds__(256) void conv3d_k3_mfma_generic(const float* __res
     __syncthreads();
 #pragma unroll 1
     for (int tap = 0; tap < 27; ++tap) {
+      if (!((epi.tap_mask >> tap) & 1u)) continue;  // uniform: an unused tap of a transposed-convolution parity class
       const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
 #pragma unroll
       for (int kk = 0; kk < kCK / 2; ++kk) {
@@ -86,7 +120,7 @@ __global__ __launch_bounds__(256) void conv3d_k3_mfma_generic(const float* __res
         for (int i = 0; i < kNB; ++i) {
           const int row = wave * kNB + i;
           const int td = row / kTH, th = row - td * kTH;
-          const float bv = sx[((c * (kTD + 2) + td + kd) * (kTH + 2) + th + kh) * kTWP + l32 + kw];
+          const float bv = sx[((c * GG::kID + S * td + kd) * GG::kIH + S * th + kh) * GG::kRow + S * l32 + kw];
           acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[i], 0, 0, 0);
         }
       }
@@ -104,11 +138,7 @@ __global__ __launch_bounds__(256) void conv3d_k3_mfma_generic(const float* __res
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
       const int co = cob * 32 + 8 * (v >> 2) + 4 * half + (v & 3);
-      if (co < Cout) {
-        float r = acc[i][v];
-        if (relu) r = r > 0.0f ? r : 0.0f;
-        y[(static_cast<long long>(b) * Cout + co) * vol + gd * plane + static_cast<long long>(gh) * W + gw] = r;
-      }
+      if (co < Cout) epi_store(epi, y, b, Cout, co, gd, gh, gw, acc[i][v]);
     }
   }
 }
@@ -215,10 +245,12 @@ __device__ __forceinline__ void stage_commit(const Stage<TD>& st, float* sx, flo
   }
 }
 
-template <int TD>
-__global__ __launch_bounds__(128 * TD, (TD == 2) ? 2 : 2) void conv3d_k3_mfma(const float* __restrict__ x, const float* __restrict__ wp,
-                                                                              float* __restrict__ y, int Cin, int Cout, int cout_pad, int D,
-                                                                              int H, int W, int tiles_w, int cblocks, int relu) {
+// MASKED = false: every tap, no branch in the unrolled tap loop (the ordinary convolution: operand reads run ahead of the
+// MFMAs); MASKED = true: taps are skipped by epi.tap_mask (one parity class of a transposed convolution).
+template <int TD, bool MASKED>
+__global__ __launch_bounds__(128 * TD, 2) void conv3d_k3_mfma(const float* __restrict__ x, const float* __restrict__ wp,
+                                                              float* __restrict__ y, int Cin, int Cout, int cout_pad, int D, int H, int W,
+                                                              int tiles_w, int cblocks, Epi epi) {
   using G = Geo<TD>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -253,6 +285,7 @@ __global__ __launch_bounds__(128 * TD, (TD == 2) ? 2 : 2) void conv3d_k3_mfma(co
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
         const int tap = t9 * 3 + kw;
+        if (MASKED && !((epi.tap_mask >> tap) & 1u)) continue;  // scalar branch, transposed-convolution classes only
 #pragma unroll
         for (int kk = 0; kk < kFC / 2; ++kk) {
           const int c = 2 * kk + half;
@@ -284,11 +317,7 @@ __global__ __launch_bounds__(128 * TD, (TD == 2) ? 2 : 2) void conv3d_k3_mfma(co
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
       const int co = cob * 32 + 8 * (v >> 2) + 4 * half + (v & 3);
-      if (co < Cout) {
-        float r = acc[i][v];
-        if (relu) r = r > 0.0f ? r : 0.0f;
-        y[(static_cast<long long>(b) * Cout + co) * vol + gd * plane + static_cast<long long>(gh) * W + gw] = r;
-      }
+      if (co < Cout) epi_store(epi, y, b, Cout, co, gd, gh, gw, acc[i][v]);
     }
   }
 }
@@ -327,26 +356,68 @@ int adv_conv3d_k3_prep_weights_f32(const float* w, float* w_prep, int cout, int 
   return adv_internal_finish_launch();
 }
 
+static int launch_conv(const float* x, const float* w_prep, float* y, int b, int cin, int cout, int d, int h, int w, int stride,
+                       const Epi& epi, hipStream_t st) {
+  // (d, h, w) = input dims; the tile grid runs over the convolution's own output grid gd x gh x gw
+  const int gd = stride == 2 ? (d + 1) / 2 : d, gh = stride == 2 ? (h + 1) / 2 : h, gw = stride == 2 ? (w + 1) / 2 : w;
+  const int tiles_w = (gw + kTW - 1) / kTW, tiles_h = (gh + kTH - 1) / kTH;
+  const int cblocks = (cout + 31) / 32;
+  if (static_cast<long long>(b) * cblocks > 65535) return ADV_EINVAL;
+  const bool fast = stride == 1 && (w % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_prep)) & 15) == 0;
+  // tile depth 2 (4 waves) and 4 (8 waves, one workgroup per CU) measured the same within 1-2 % (profiles/r01_conv3d_mfma.jsonl)
+  if (fast) {
+    const dim3 grid(tiles_w * tiles_h, (d + 1) / 2, b * cblocks);
+    const size_t lds = 2 * static_cast<size_t>(Geo<2>::kStageFloats) * sizeof(float);
+    if (epi.tap_mask == kAllTaps)
+      hipLaunchKernelGGL((conv3d_k3_mfma<2, false>), grid, dim3(Geo<2>::kThreads), lds, st, x, w_prep, y, cin, cout, cblocks * 32, d, h, w,
+                         tiles_w, cblocks, epi);
+    else
+      hipLaunchKernelGGL((conv3d_k3_mfma<2, true>), grid, dim3(Geo<2>::kThreads), lds, st, x, w_prep, y, cin, cout, cblocks * 32, d, h, w,
+                         tiles_w, cblocks, epi);
+  } else if (stride == 1) {
+    const dim3 grid(tiles_w * tiles_h, (gd + kTD - 1) / kTD, b * cblocks);
+    hipLaunchKernelGGL((conv3d_k3_mfma_generic<1>), grid, dim3(256), static_cast<size_t>(GenGeo<1>::kSX + kSW) * sizeof(float), st, x, w_prep, y,
+                       cin, cout, cblocks * 32, gd, gh, gw, d, h, w, tiles_w, cblocks, epi);
+  } else {
+    const dim3 grid(tiles_w * tiles_h, (gd + kTD - 1) / kTD, b * cblocks);
+    const size_t lds = static_cast<size_t>(GenGeo<2>::kSX + kSW) * sizeof(float);
+    static bool raised = false;  // > 64 KiB of dynamic LDS needs the attribute once per process (idempotent)
+    if (!raised) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_k3_mfma_generic<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              static_cast<int>(lds)) != hipSuccess)
+        return ADV_ELAUNCH;
+      raised = true;
+    }
+    hipLaunchKernelGGL((conv3d_k3_mfma_generic<2>), grid, dim3(256), lds, st, x, w_prep, y, cin, cout, cblocks * 32, gd, gh, gw, d, h, w,
+                       tiles_w, cblocks, epi);
+  }
+  return adv_internal_finish_launch();
+}
+
 int adv_conv3d_k3_f32(const float* x, const float* w_prep, float* y, int b, int cin, int cout, int d, int h, int w, int relu,
                       adv_stream_t stream) {
   if (!x || !w_prep || !y || b < 1 || cin < 1 || cout < 1 || d < 1 || h < 1 || w < 1) return ADV_EINVAL;
   if (cin % kCK != 0) return ADV_EINVAL;
-  const int tiles_w = (w + kTW - 1) / kTW, tiles_h = (h + kTH - 1) / kTH;
-  const int cblocks = (cout + 31) / 32;
-  if (static_cast<long long>(b) * cblocks > 65535) return ADV_EINVAL;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  const bool fast = (w % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_prep)) & 15) == 0;
-  // tile depth 2 (4 waves) and 4 (8 waves, one workgroup per CU) measured the same within 1-2 % (profiles/r01_conv3d_mfma.jsonl)
-  if (fast) {
-    const dim3 grid(tiles_w * tiles_h, (d + 1) / 2, b * cblocks);
-    hipLaunchKernelGGL((conv3d_k3_mfma<2>), grid, dim3(Geo<2>::kThreads), 2 * static_cast<size_t>(Geo<2>::kStageFloats) * sizeof(float), st, x,
-                       w_prep, y, cin, cout, cblocks * 32, d, h, w, tiles_w, cblocks, relu);
-  } else {
-    const dim3 grid(tiles_w * tiles_h, (d + kTD - 1) / kTD, b * cblocks);
-    hipLaunchKernelGGL(conv3d_k3_mfma_generic, grid, dim3(256), static_cast<size_t>(kSX + kSW) * sizeof(float), st, x, w_prep, y, cin, cout,
-                       cblocks * 32, d, h, w, tiles_w, cblocks, relu);
+  const Epi epi{nullptr, relu, kAllTaps, d, h, w, 1, 1, 1, 0, 0, 0};
+  return launch_conv(x, w_prep, y, b, cin, cout, d, h, w, 1, epi, static_cast<hipStream_t>(stream));
+}
+
+int adv_conv3d_k3_ex_f32(const float* x, const float* w_prep, const float* bias, float* y, int b, int cin, int cout, int d, int h, int w,
+                         int stride, int relu, uint32_t tap_mask, const int32_t* out_dims, const int32_t* out_stride,
+                         const int32_t* out_offset, adv_stream_t stream) {
+  if (!x || !w_prep || !y || b < 1 || cin < 1 || cout < 1 || d < 1 || h < 1 || w < 1) return ADV_EINVAL;
+  if (cin % kCK != 0 || (stride != 1 && stride != 2) || (tap_mask & ~kAllTaps)) return ADV_EINVAL;
+  if ((out_dims == nullptr) != (out_stride == nullptr) || (out_dims == nullptr) != (out_offset == nullptr)) return ADV_EINVAL;
+  const int gd = stride == 2 ? (d + 1) / 2 : d, gh = stride == 2 ? (h + 1) / 2 : h, gw = stride == 2 ? (w + 1) / 2 : w;
+  Epi epi{bias, relu, tap_mask, gd, gh, gw, 1, 1, 1, 0, 0, 0};
+  if (out_dims) {
+    for (int k = 0; k < 3; ++k)
+      if (out_dims[k] < 1 || out_stride[k] < 1 || out_offset[k] < 0) return ADV_EINVAL;
+    epi.od = out_dims[0], epi.oh = out_dims[1], epi.ow = out_dims[2];
+    epi.sd = out_stride[0], epi.sh = out_stride[1], epi.sw = out_stride[2];
+    epi.fd = out_offset[0], epi.fh = out_offset[1], epi.fw = out_offset[2];
   }
-  return adv_internal_finish_launch();
+  return launch_conv(x, w_prep, y, b, cin, cout, d, h, w, stride, epi, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

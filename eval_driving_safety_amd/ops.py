@@ -559,16 +559,80 @@ def conv3d_k3_prep(weight, transpose=False):
     return out
 
 
-def conv3d_k3(x, w_prep, cout, relu=False):
-    """conv3d(x [B,Cin,D,H,W], stride 1, padding 1, no bias) with prepared weights -> [B,cout,D,H,W]"""
+ALL_TAPS = (1 << 27) - 1
+
+
+def _i3(v):
+    return None if v is None else (ctypes.c_int32 * 3)(*[int(a) for a in v])
+
+
+def _conv3d_ex(x, w_prep, cout, stride=1, relu=False, bias=None, tap_mask=ALL_TAPS, out=None, out_stride=None, out_offset=None):
     xi, wp = _feat(x, "x"), _feat(w_prep, "w_prep")
     if xi.dim() != 5 or wp.dim() != 3 or wp.shape[0] != 27 or wp.shape[1] != xi.shape[1] or wp.shape[2] < cout:
         raise ValueError("x must be [B,Cin,D,H,W] and w_prep [27,Cin,>=cout]")
     b, cin, d, h, w = xi.shape
-    y = torch.empty((b, cout, d, h, w), dtype=torch.float32, device=xi.device)
+    if bias is not None:
+        bias = _feat(bias, "bias")
+        if tuple(bias.shape) != (cout,):
+            raise ValueError("bias must be [cout]")
+    grid = tuple((v + 1) // 2 for v in (d, h, w)) if stride == 2 else (d, h, w)
+    if out is None:
+        out = torch.empty((b, cout) + grid, dtype=torch.float32, device=xi.device)
+        dims = None
+    else:
+        out = _feat(out, "out")
+        if out.dim() != 5 or out.shape[0] != b or out.shape[1] != cout:
+            raise ValueError("out must be [B,cout,D',H',W']")
+        dims = tuple(out.shape[2:])
     with _on(xi):
-        _lib.call("adv_conv3d_k3_f32", _ptr(xi), _ptr(wp), _ptr(y), b, cin, cout, d, h, w, int(relu), _stream(xi))
-    return y
+        _lib.call("adv_conv3d_k3_ex_f32", _ptr(xi), _ptr(wp), None if bias is None else _ptr(bias), _ptr(out), b, cin, cout, d, h, w, int(stride),
+                  int(relu), int(tap_mask), _i3(dims), _i3(out_stride if dims else None), _i3(out_offset if dims else None), _stream(xi))
+    return out
+
+
+def conv3d_k3(x, w_prep, cout, relu=False, bias=None):
+    """conv3d(x [B,Cin,D,H,W], stride 1, padding 1) (+ bias [cout]) (+ ReLU) with prepared weights -> [B,cout,D,H,W]"""
+    return _conv3d_ex(x, w_prep, cout, 1, relu, bias)
+
+
+def conv3d_k3_s2(x, w_prep, cout, relu=False, bias=None):
+    """the strided 3x3x3 convolution of an hourglass: stride 2, padding 1 -> [B,cout,ceil(D/2),ceil(H/2),ceil(W/2)]"""
+    return _conv3d_ex(x, w_prep, cout, 2, relu, bias)
+
+
+def conv_transpose3d_k3_s2_prep(weight_t):
+    """ConvTranspose3d weights [Cin,Cout,3,3,3] (kernel 3, stride 2, padding 1, output_padding 1) -> the eight output
+    parity classes [(w_prep, tap_mask, (pd,ph,pw))].  Output voxel o = 2j + p takes input j + (t - 1) through kernel tap k:
+    p = 0: (t, k) = (1, 1);  p = 1: (t, k) = (1, 2), (2, 0)  per axis - so class (pd,ph,pw) is an ordinary convolution over
+    the INPUT grid with 1-8 taps, written to every second output voxel."""
+    wt = _feat(weight_t, "weight_t")
+    if wt.dim() != 5 or tuple(wt.shape[2:]) != (3, 3, 3):
+        raise ValueError("weight_t must be [Cin,Cout,3,3,3]")
+    pairs = {0: ((1, 1),), 1: ((1, 2), (2, 0))}
+    out = []
+    for pd in (0, 1):
+        for ph in (0, 1):
+            for pw in (0, 1):
+                wc = torch.zeros((wt.shape[1], wt.shape[0], 3, 3, 3), dtype=torch.float32, device=wt.device)
+                mask = 0
+                for td, kd in pairs[pd]:
+                    for th, kh in pairs[ph]:
+                        for tw, kw in pairs[pw]:
+                            wc[:, :, td, th, tw] = wt[:, :, kd, kh, kw].t()
+                            mask |= 1 << (td * 9 + th * 3 + tw)
+                out.append((conv3d_k3_prep(wc.contiguous()), mask, (pd, ph, pw)))
+    return out
+
+
+def conv_transpose3d_k3_s2(x, classes, cout, relu=False, bias=None):
+    """conv_transpose3d(x [B,Cin,D,H,W], kernel 3, stride 2, padding 1, output_padding 1) -> [B,cout,2D,2H,2W]: eight
+    masked-tap launches of the stride-1 MFMA kernel, each writing one parity class of the output."""
+    xi = _feat(x, "x")
+    b, _, d, h, w = xi.shape
+    out = torch.empty((b, cout, 2 * d, 2 * h, 2 * w), dtype=torch.float32, device=xi.device)
+    for w_prep, mask, off in classes:
+        _conv3d_ex(xi, w_prep, cout, 1, relu, bias, mask, out, (2, 2, 2), off)
+    return out
 
 
 class Conv3dK3(torch.autograd.Function):
@@ -696,3 +760,33 @@ def dense_align(calib, scale, im_left, im_right, boxes, kpts, poses):
     succ = torch.isfinite(cost) & (z > 0)
     disp = torch.where(succ, (f * bl) / z, torch.zeros_like(z))
     return succ.to(torch.int32), disp
+
+
+class Conv3dK3S2(torch.autograd.Function):
+    """y = conv3d(x, weight, stride 2, padding 1); the gradient w.r.t. x is the transposed convolution of grad_y with the
+    same weights (``classes_t = conv_transpose3d_k3_s2_prep(weight)``), cropped to x's size when a dimension is odd."""
+
+    @staticmethod
+    def forward(ctx, x, w_prep, classes_t, cout):
+        ctx.classes_t, ctx.xshape = classes_t, tuple(x.shape)
+        return conv3d_k3_s2(x.contiguous(), w_prep, cout)
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        g = conv_transpose3d_k3_s2(grad_y.contiguous(), ctx.classes_t, ctx.xshape[1])
+        d, h, w = ctx.xshape[2:]
+        return g[:, :, :d, :h, :w].contiguous(), None, None, None
+
+
+class ConvTranspose3dK3S2(torch.autograd.Function):
+    """y = conv_transpose3d(x, weight_t, stride 2, padding 1, output_padding 1); the gradient w.r.t. x is the strided
+    convolution of grad_y with weight_t read as [out = Cin, in = Cout] (``w_prep_fwd = conv3d_k3_prep(weight_t)``)."""
+
+    @staticmethod
+    def forward(ctx, x, classes, w_prep_fwd, cout):
+        ctx.w_prep_fwd, ctx.cin = w_prep_fwd, x.shape[1]
+        return conv_transpose3d_k3_s2(x.contiguous(), classes, cout)
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        return conv3d_k3_s2(grad_y.contiguous(), ctx.w_prep_fwd, ctx.cin), None, None, None

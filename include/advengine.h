@@ -275,6 +275,20 @@ ADV_API int adv_conv3d_k3_prep_weights_f32(const float* w, float* w_prep, int co
 ADV_API int adv_conv3d_k3_f32(const float* x, const float* w_prep, float* y, int b, int cin, int cout, int d, int h,
                               int w, int relu, adv_stream_t stream);
 
+/* The same kernel family with what a plane-sweep detector's 3D hourglass needs around the plain convolution:
+ *     bias       DEVICE [cout] or NULL, added after the accumulation (a folded batch-norm shift; its scale goes into the weights)
+ *     stride     1, or 2 = the strided 3x3x3 convolution (padding 1): output grid ceil(d/2) x ceil(h/2) x ceil(w/2)
+ *     tap_mask   bit t set = tap t = kd*9 + kh*3 + kw takes part (0x7ffffff = all)
+ *     out_dims / out_stride / out_offset (HOST int32[3] each, or all NULL): result voxel i of the convolution's own grid is
+ *                written to y[.., i*out_stride + out_offset] of a [b,cout,out_dims] tensor.
+ *     A transposed convolution (kernel 3, stride 2, padding 1, output_padding 1 - the adjoint of the strided one, and the
+ *     hourglass's up-sampling layer) is EIGHT such calls, one per output parity class (pd,ph,pw): stride 1, the class's 1-8
+ *     taps in tap_mask, out_stride 2, out_offset (pd,ph,pw) - every tap of every class is used exactly once, so the matrix
+ *     cores do 27 multiply-adds per INPUT voxel, not 27 per output voxel (ops.conv_transpose3d_k3_s2 prepares the classes). */
+ADV_API int adv_conv3d_k3_ex_f32(const float* x, const float* w_prep, const float* bias, float* y, int b, int cin, int cout,
+                                 int d, int h, int w, int stride, int relu, uint32_t tap_mask, const int32_t* out_dims,
+                                 const int32_t* out_stride, const int32_t* out_offset, adv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -288,3 +288,39 @@ void orc_dense_align_cost(const float* left, const float* right, int h, int w, i
       cost[(long)b * k_cand + k] = (m > 0 && 4 * m >= total) ? s / (float)m : INFINITY;
     }
 }
+
+
+/* csrc/conv3d.hip with its epilogue options, in the kernel's accumulation order (chunks of 4 input channels, taps
+ * ascending - masked ones skipped -, channels ascending, one fmaf each), then + bias, then ReLU.  w is an ordinary conv
+ * weight [cout][cin][27]; (D,H,W) the INPUT dims; stride 1 or 2 (padding 1); result voxel i goes to i*os + oo of a
+ * [B,cout,oD,oH,oW] tensor (positions outside it are dropped).  Upstream detector op: unpinned, as orc_conv3d_k3. */
+void orc_conv3d_k3_ex(const float* x, const float* w, const float* bias, float* y, int B, int cin, int cout, int D, int H, int W,
+                      int stride, int relu, unsigned tap_mask, const int* odims, const int* ostride, const int* ooff) {
+  const int gD = stride == 2 ? (D + 1) / 2 : D, gH = stride == 2 ? (H + 1) / 2 : H, gW = stride == 2 ? (W + 1) / 2 : W;
+  const long plane = (long)H * W, vol = plane * D;
+  const long oplane = (long)odims[1] * odims[2], ovol = oplane * odims[0];
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int b = 0; b < B; ++b)
+    for (int co = 0; co < cout; ++co)
+      for (int d = 0; d < gD; ++d)
+        for (int h = 0; h < gH; ++h)
+          for (int ww = 0; ww < gW; ++ww) {
+            const int zd = d * ostride[0] + ooff[0], zh = h * ostride[1] + ooff[1], zw = ww * ostride[2] + ooff[2];
+            if (zd >= odims[0] || zh >= odims[1] || zw >= odims[2]) continue;
+            float acc = 0.0f;
+            for (int c0 = 0; c0 < cin; c0 += 4)
+              for (int tap = 0; tap < 27; ++tap) {
+                if (!((tap_mask >> tap) & 1u)) continue;
+                const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+                const int gd = stride * d + kd - 1, gh = stride * h + kh - 1, gw = stride * ww + kw - 1;
+                const int in = gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W;
+                for (int c = c0; c < c0 + 4 && c < cin; ++c) {
+                  const float xv = in ? x[((long)b * cin + c) * vol + gd * plane + (long)gh * W + gw] : 0.0f;
+                  acc = fmaf(w[((long)co * cin + c) * 27 + tap], xv, acc);
+                }
+              }
+            if (bias) acc = acc + bias[co];
+            if (relu) acc = acc > 0.0f ? acc : 0.0f;
+            y[((long)b * cout + co) * ovol + zd * oplane + (long)zh * odims[2] + zw] = acc;
+          }
+}

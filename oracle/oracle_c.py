@@ -31,6 +31,8 @@ _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 _lib.orc_dense_align_cost.argtypes = [_fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _i32p, _fp, ctypes.c_int, _fp, ctypes.c_float,
                                       ctypes.c_float, ctypes.c_int, _fp]
 _lib.orc_dense_align_cost.restype = None
+_lib.orc_conv3d_k3_ex.argtypes = [_fp, _fp, ctypes.c_void_p, _fp] + [ctypes.c_int] * 8 + [ctypes.c_uint, _i32p, _i32p, _i32p]
+_lib.orc_conv3d_k3_ex.restype = None
 for _f in ("orc_denormalize", "orc_normalize", "orc_pgd_step_norm01", "orc_pgd_step_meansub255", "orc_tensor2im_u8",
            "orc_patch_paste", "orc_patch_update"):
     getattr(_lib, _f).restype = None
@@ -163,3 +165,41 @@ def dense_align_argmin(cost, z_center, step):
         z[b] = np.float32(z_center[b]) + (kk - half) * np.float32(step)
         cmin[b] = bc
     return z, cmin
+
+
+def conv3d_k3_ex(x, w, bias=None, stride=1, relu=False, tap_mask=(1 << 27) - 1, out=None, out_stride=(1, 1, 1), out_offset=(0, 0, 0)):
+    """csrc/conv3d.hip's extended entry point: x [B,Cin,D,H,W], w [Cout,Cin,3,3,3] (ordinary conv layout)"""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    cout, cin = w.shape[:2]
+    b, c, d, h, ww = x.shape
+    assert c == cin
+    grid = tuple((v + 1) // 2 for v in (d, h, ww)) if stride == 2 else (d, h, ww)
+    if out is None:
+        out = np.zeros((b, cout) + grid, np.float32)
+    bp = None if bias is None else np.ascontiguousarray(bias, dtype=np.float32).ctypes.data_as(ctypes.c_void_p)
+    _lib.orc_conv3d_k3_ex(x, w, bp, out, b, cin, cout, d, h, ww, int(stride), int(relu), int(tap_mask),
+                          np.array(out.shape[2:], np.int32), np.array(out_stride, np.int32), np.array(out_offset, np.int32))
+    return out
+
+
+def conv_transpose3d_k3_s2(x, weight_t, bias=None, relu=False):
+    """kernel 3, stride 2, padding 1, output_padding 1, as the eight parity-class convolutions of ops.conv_transpose3d_k3_s2"""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    wt = np.ascontiguousarray(weight_t, dtype=np.float32)
+    cin, cout = wt.shape[:2]
+    b, _, d, h, w = x.shape
+    out = np.zeros((b, cout, 2 * d, 2 * h, 2 * w), np.float32)
+    pairs = {0: ((1, 1),), 1: ((1, 2), (2, 0))}
+    for pd in (0, 1):
+        for ph in (0, 1):
+            for pw in (0, 1):
+                wc = np.zeros((cout, cin, 3, 3, 3), np.float32)
+                mask = 0
+                for td, kd in pairs[pd]:
+                    for th, kh in pairs[ph]:
+                        for tw, kw in pairs[pw]:
+                            wc[:, :, td, th, tw] = wt[:, :, kd, kh, kw].T
+                            mask |= 1 << (td * 9 + th * 3 + tw)
+                conv3d_k3_ex(x, wc, bias, 1, relu, mask, out, (2, 2, 2), (pd, ph, pw))
+    return out

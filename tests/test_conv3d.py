@@ -89,3 +89,86 @@ def test_hip_conv3d_single_output_channel_with_torch_adjoint():
     assert y.detach().cpu().numpy().tobytes() == C.conv3d_k3(x.cpu().numpy(), wt.cpu().numpy()).tobytes()
     assert float((y - ref).abs().max()) <= 1e-4 * float(ref.detach().abs().max())
     assert float((xm.grad - xr.grad).abs().max()) <= 1e-4 * float(xr.grad.abs().max())
+
+
+# ------------------------------------------------------------------------------------------ hourglass layers
+def test_oracle_strided_and_transposed_conv_match_torch():
+    """the oracle's stride-2 convolution, the transposed convolution as eight masked parity classes, bias and ReLU,
+    against torch's conv3d / conv_transpose3d (CPU)"""
+    rs = np.random.RandomState(5)
+    x = rs.randn(2, 8, 5, 6, 7).astype(np.float32)                     # odd and even dims
+    wt = (rs.randn(12, 8, 3, 3, 3) * 0.1).astype(np.float32)
+    bias = rs.randn(12).astype(np.float32)
+    y = C.conv3d_k3_ex(x, wt, bias=bias, stride=2)
+    ref = F.conv3d(torch.tensor(x), torch.tensor(wt), torch.tensor(bias), stride=2, padding=1).numpy()
+    assert y.shape == ref.shape == (2, 12, 3, 3, 4)
+    np.testing.assert_allclose(y, ref, rtol=1e-5, atol=1e-5)
+    assert np.array_equal(C.conv3d_k3_ex(x, wt, bias=bias, stride=2, relu=True), np.maximum(y, 0))
+    assert np.array_equal(C.conv3d_k3_ex(x, wt), C.conv3d_k3(x, wt))   # the plain convolution is the default
+    w_t = (rs.randn(8, 5, 3, 3, 3) * 0.1).astype(np.float32)           # ConvTranspose3d layout [Cin, Cout, 3,3,3]
+    up = C.conv_transpose3d_k3_s2(x, w_t)
+    ref = F.conv_transpose3d(torch.tensor(x), torch.tensor(w_t), stride=2, padding=1, output_padding=1).numpy()
+    assert up.shape == ref.shape == (2, 5, 10, 12, 14)
+    np.testing.assert_allclose(up, ref, rtol=1e-5, atol=1e-5)
+    # and it IS the adjoint of the strided convolution with the same weights
+    xs = rs.randn(1, 5, 10, 12, 14).astype(np.float32)
+    down = C.conv3d_k3_ex(xs, w_t, stride=2)                           # w_t read as [out = 8, in = 5]
+    lhs = float((down.astype(np.float64) * x[:1]).sum())
+    rhs = float((xs.astype(np.float64) * C.conv_transpose3d_k3_s2(x[:1], w_t)).sum())
+    assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs))
+
+
+HG_SHAPES = [(1, 8, 12, 5, 6, 7), (2, 16, 32, 4, 8, 32), (1, 8, 33, 3, 9, 40), (1, 32, 64, 6, 16, 44)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", HG_SHAPES)
+def test_hip_hourglass_layers_bit_exact_vs_oracle(shape):
+    from eval_driving_safety_amd import ops
+    b, cin, cout, d, h, w = shape
+    x, wt = _case(*shape, seed=sum(shape))
+    rs = np.random.RandomState(9)
+    bias = rs.randn(cout).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    tx, tw, tb = torch.tensor(x, device=dev), torch.tensor(wt, device=dev), torch.tensor(bias, device=dev)
+    wp = ops.conv3d_k3_prep(tw)
+    # bias + ReLU epilogue of the plain convolution
+    got = ops.conv3d_k3(tx, wp, cout, relu=True, bias=tb)
+    assert got.cpu().numpy().tobytes() == C.conv3d_k3_ex(x, wt, bias=bias, relu=True).tobytes(), "bias + relu"
+    # stride 2
+    got = ops.conv3d_k3_s2(tx, wp, cout, bias=tb)
+    want = C.conv3d_k3_ex(x, wt, bias=bias, stride=2)
+    assert got.cpu().numpy().tobytes() == want.tobytes(), "stride 2"
+    ref = F.conv3d(tx, tw, tb, stride=2, padding=1)
+    assert float((got - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+    # transposed convolution: eight masked-tap launches of the stride-1 kernel
+    w_t = (rs.randn(cin, cout, 3, 3, 3) * 0.1).astype(np.float32)
+    classes = ops.conv_transpose3d_k3_s2_prep(torch.tensor(w_t, device=dev))
+    assert sorted(bin(m).count("1") for _, m, _ in classes) == [1, 2, 2, 2, 4, 4, 4, 8]     # 27 taps in all
+    got = ops.conv_transpose3d_k3_s2(tx, classes, cout, bias=tb, relu=True)
+    want = C.conv_transpose3d_k3_s2(x, w_t, bias=bias, relu=True)
+    assert got.cpu().numpy().tobytes() == want.tobytes(), "transposed"
+    ref = F.relu(F.conv_transpose3d(tx, torch.tensor(w_t, device=dev), tb, stride=2, padding=1, output_padding=1))
+    assert float((got - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.gpu
+def test_hip_hourglass_autograd_vs_torch():
+    """down (stride 2) and up (transposed) layers as autograd functions: gradients w.r.t. the input within 1e-4 of torch's"""
+    from eval_driving_safety_amd import ops
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(2)
+    x = torch.randn((1, 32, 12, 24, 80), device=dev, generator=gen)
+    wd = torch.randn((64, 32, 3, 3, 3), device=dev, generator=gen) * 0.05           # down: 32 -> 64
+    wu = torch.randn((64, 32, 3, 3, 3), device=dev, generator=gen) * 0.05           # up (ConvTranspose layout [in = 64, out = 32])
+    xr = x.clone().requires_grad_(True)
+    ref = F.conv_transpose3d(F.relu(F.conv3d(xr, wd, stride=2, padding=1)), wu, stride=2, padding=1, output_padding=1)
+    g = torch.randn(ref.shape, device=dev, generator=gen)
+    ref.backward(g)
+    xm = x.clone().requires_grad_(True)
+    down = ops.Conv3dK3S2.apply(xm, ops.conv3d_k3_prep(wd), ops.conv_transpose3d_k3_s2_prep(wd), 64)
+    up = ops.ConvTranspose3dK3S2.apply(F.relu(down), ops.conv_transpose3d_k3_s2_prep(wu), ops.conv3d_k3_prep(wu), 32)
+    up.backward(g)
+    assert tuple(up.shape) == tuple(ref.shape) == (1, 32, 12, 24, 80)
+    assert float((up - ref).abs().max()) <= 1e-4 * float(ref.detach().abs().max())
+    assert float((xm.grad - xr.grad).abs().max()) <= 1e-4 * float(xr.grad.abs().max())

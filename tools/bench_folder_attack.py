@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Third, clearly separate number: stereo-pairs/s of the whole `cli.dsgn_pgd_attack --model toy` path
+on a FOLDER of KITTI-shaped PNGs - decode (12 prefetch threads vs none) -> H2D -> 4-step PGD with the toy detector ->
+8-bit export -> D2H -> PNG encode of every iterate.  It measures the I/O plumbing around the engine, not the engine:
+the toy detector's forward/backward and zlib dominate.  Prints one JSON line per loader setting."""
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
+from eval_driving_safety_amd import adapters, attacks, data  # noqa: E402
+
+
+def main():
+    from PIL import Image
+    import synth
+    n, batch, iters = int(os.environ.get("PAIRS", "48")), 4, 4
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    with tempfile.TemporaryDirectory() as root:
+        for eye in ("image_2", "image_3"):
+            os.makedirs(os.path.join(root, eye))
+        for i in range(n):
+            left = synth.u8_image(i, 375, 1242)
+            Image.fromarray(left).save(os.path.join(root, "image_2", "%06d.png" % i))
+            Image.fromarray(np.roll(left, -24, axis=1)).save(os.path.join(root, "image_3", "%06d.png" % i))
+        with open(os.path.join(root, "val.txt"), "w") as f:
+            f.write("\n".join("%06d" % i for i in range(n)) + "\n")
+        toy = adapters.ToyStereoAdapter(dev, seed=1)
+        for workers, save in ((0, True), (12, True), (12, False)):
+            out = os.path.join(root, "out_%d_%d" % (workers, save))
+            loader = data.KittiFolder(root, os.path.join(root, "val.txt"), batch, workers=workers)
+            atk = attacks.PgdAttack("dsgn", 1 / 255, 0.03, iters, out_root=out, save=save, device=dev)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            done = atk.run(loader, toy)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            print(json.dumps({"path": "KittiFolder(PNG) -> PgdAttack(toy detector, %d steps, batch %d) -> %s" % (iters, batch, "PNG folders of every iterate" if save else "no files"),
+                              "decode_threads": workers, "pairs": done, "pairs_per_s": round(done / dt, 2), "seconds": round(dt, 2),
+                              "png_files_written": (iters + 1) * 2 * done if save else 0}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
