@@ -400,16 +400,19 @@ def main():
             except Exception as e:
                 out["configs2_srcnn"] = {"error": repr(e)}
             torch.cuda.empty_cache()
-        if not args.no_cpu_baseline and not srcnn:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_pairs)
         if not args.no_end_to_end and not srcnn:
-            # the end-to-end number is reported BESIDE the kernel-path one, never folded into `value`
+            # the end-to-end number is reported BESIDE the kernel-path one, never folded into `value`.
+            # (Measured BEFORE the CPU baselines: their OpenMP teams keep spinning on the host cores afterwards.)
             try:
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 import bench_end_to_end
                 out["end_to_end"] = bench_end_to_end.measure(pairs=1, iters=N_ITER, reps=3)
+                out["end_to_end_hourglass"] = bench_end_to_end.measure(pairs=1, iters=N_ITER, reps=2, hourglass=True)
             except Exception as e:
                 out["end_to_end"] = {"error": repr(e)}
+            torch.cuda.empty_cache()
+        if not args.no_cpu_baseline and not srcnn:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_pairs)
 
     # Outside the timed region, N > 1 only: latency of the one collective the attacks have - the all-reduce(SUM)
     # of the universal-patch delta [3,D,D] (D = 101: BASELINE configs[3], 122 KB) over RCCL / xGMI - checked

@@ -82,16 +82,19 @@ class ToyStereoAdapter:
 
 class PsvStereoAdapter:
     """A DSGN-SHAPED depth branch with seeded random weights, for end-to-end timing of the attack loop and as
-    the autograd consumer of the K7 kernels: siamese 2D features at 1/4 resolution (32 channels) -> plane-sweep
-    concatenation volume [B,64,48,96,312] (HIP: ops.PsvBuild) -> three 3D convolutions (the two wide ones on the
-    float32-MFMA kernel ops.Conv3dK3, the 32->1 one through torch)
-    -> softmax over the 48 depth planes -> expected depth -> smooth-L1 against a sparse depth map, i.e. the
-    ``disp_loss`` term of attack/DSGN/pgd_attack.py:310-319.  It is NOT DSGN (no 3DGV, no detection head, no
-    trained weights): detection parity is unpinned by construction; it exists so that "20-step PGD through a
-    plane-sweep network" can be measured end to end on this hardware."""
+    the autograd consumer of the K7 and convolution kernels: siamese 2D features at 1/4 resolution (32 channels) ->
+    plane-sweep concatenation volume [B,64,48,96,312] (HIP: ops.PsvBuildLerp, fractional per-plane disparities) ->
+    3D convolutions on the float32 matrix cores -> softmax over the 48 depth planes -> expected depth -> smooth-L1
+    against a sparse depth map, i.e. the ``disp_loss`` term of attack/DSGN/pgd_attack.py:310-319.
+      hourglass=False  three convolutions 64->32->32->1 (round 1's stack)
+      hourglass=True   a 3D hourglass as plane-sweep detectors use it: 64->32, 32->32, then 32->64 stride 2, 64->64,
+                       64->64 stride 2, 64->64, transposed 64->64 (+ skip), transposed 64->32 (+ skip), 32->1;
+                       every layer but the last carries a bias (a folded batch-norm) and a fused ReLU
+    It is NOT DSGN (no 3DGV, no detection head, no trained weights): detection parity is unpinned by construction; it
+    exists so that "20-step PGD through a plane-sweep network" can be measured end to end on this hardware."""
 
     def __init__(self, device, seed=0, channels=32, planes=48, min_depth=2.0, depth_step=0.8, fu=721.5377,
-                 baseline=0.54, downsample=4, mid=32, mfma_conv=True, interp=True):
+                 baseline=0.54, downsample=4, mid=32, mfma_conv=True, interp=True, hourglass=False):
         from . import ops
         self.ops = ops
         gen = torch.Generator().manual_seed(seed)
@@ -110,14 +113,30 @@ class PsvStereoAdapter:
         # interp=True: the fractional per-plane disparities fu*b/depth/4 go to the interpolating cost volume
         # (ops.PsvBuildLerp); interp=False rounds them to integers (ops.PsvBuild, round 1's behaviour)
         self.interp = interp
-        # the two wide 3x3x3 convolutions run on libadvengine's float32-MFMA kernel (weights re-laid-out once, for the
+        # the 3x3x3 convolutions run on libadvengine's float32-MFMA kernels (weights re-laid-out once, for the
         # forward and for the adjoint); mfma_conv=False routes them through torch / MIOpen instead
         self.mfma_conv = mfma_conv and (2 * channels) % 4 == 0 and mid % 4 == 0
+        self.hourglass, self.mid = hourglass, mid
         if self.mfma_conv:
             self.p1, self.p1t = ops.conv3d_k3_prep(self.c1), ops.conv3d_k3_prep(self.c1, transpose=True)
             self.p2, self.p2t = ops.conv3d_k3_prep(self.c2), ops.conv3d_k3_prep(self.c2, transpose=True)
             self.p3 = ops.conv3d_k3_prep(self.c3)     # 32 -> 1: forward on the kernel (padded to 32 rows), adjoint via torch
-            self.mid = mid
+        if hourglass:
+            m2 = 2 * mid
+            self.hg = {"d1": w(m2, mid, 3, 3, 3), "m1": w(m2, m2, 3, 3, 3), "d2": w(m2, m2, 3, 3, 3), "m2": w(m2, m2, 3, 3, 3),
+                       "u1": w(m2, m2, 3, 3, 3), "u2": w(m2, mid, 3, 3, 3)}                # u*: ConvTranspose layout [in, out, 3,3,3]
+            self.hb = {k: (torch.randn(v.shape[1] if k.startswith("u") else v.shape[0], generator=gen) * 0.05).to(device)
+                       for k, v in self.hg.items()}
+            self.b1 = (torch.randn(mid, generator=gen) * 0.05).to(device)
+            self.b2 = (torch.randn(mid, generator=gen) * 0.05).to(device)
+            if self.mfma_conv:
+                P = ops.conv3d_k3_prep
+                self.hp = {"d1": (P(self.hg["d1"]), ops.conv_transpose3d_k3_s2_prep(self.hg["d1"])),
+                           "d2": (P(self.hg["d2"]), ops.conv_transpose3d_k3_s2_prep(self.hg["d2"])),
+                           "m1": (P(self.hg["m1"]), P(self.hg["m1"], transpose=True)),
+                           "m2": (P(self.hg["m2"]), P(self.hg["m2"], transpose=True)),
+                           "u1": (ops.conv_transpose3d_k3_s2_prep(self.hg["u1"]), P(self.hg["u1"])),
+                           "u2": (ops.conv_transpose3d_k3_s2_prep(self.hg["u2"]), P(self.hg["u2"]))}
 
     def shifts(self, b):
         disp = self.fu * self.baseline / self.depth / self.downsample       # feature-pixel disparity per plane
@@ -130,20 +149,46 @@ class PsvStereoAdapter:
         f = F.relu(F.conv2d(f, self.f2, stride=2, padding=1))
         return F.conv2d(f, self.f3, padding=1)
 
+    def _volume_net(self, cost):
+        """cost volume [B,64,D,h,w] -> per-plane scores [B,D,h,w]"""
+        ops = self.ops
+        if not self.hourglass:
+            if self.mfma_conv:
+                v = ops.Conv3dK3.apply(cost, self.p1, self.p1t, self.mid, None, None, True)
+                v = ops.Conv3dK3.apply(v, self.p2, self.p2t, self.mid, None, None, True)
+                return ops.Conv3dK3.apply(v, self.p3, None, 1, self.c3).squeeze(1)
+            v = F.relu(F.conv3d(cost, self.c1, padding=1))
+            v = F.relu(F.conv3d(v, self.c2, padding=1))
+            return F.conv3d(v, self.c3, padding=1).squeeze(1)
+        g, hb, m2 = self.hg, self.hb, 2 * self.mid
+        if self.mfma_conv:
+            hp = self.hp
+            s0 = ops.Conv3dK3.apply(cost, self.p1, self.p1t, self.mid, None, self.b1, True)
+            s0 = ops.Conv3dK3.apply(s0, self.p2, self.p2t, self.mid, None, self.b2, True)
+            s1 = ops.Conv3dK3S2.apply(s0, hp["d1"][0], hp["d1"][1], m2, hb["d1"], True)
+            s1 = ops.Conv3dK3.apply(s1, hp["m1"][0], hp["m1"][1], m2, None, hb["m1"], True)
+            s2 = ops.Conv3dK3S2.apply(s1, hp["d2"][0], hp["d2"][1], m2, hb["d2"], True)
+            s2 = ops.Conv3dK3.apply(s2, hp["m2"][0], hp["m2"][1], m2, None, hb["m2"], True)
+            u1 = ops.ConvTranspose3dK3S2.apply(s2, hp["u1"][0], hp["u1"][1], m2, hb["u1"], False)
+            u1 = F.relu(u1 + s1)
+            u2 = ops.ConvTranspose3dK3S2.apply(u1, hp["u2"][0], hp["u2"][1], self.mid, hb["u2"], False)
+            u2 = F.relu(u2 + s0)
+            return ops.Conv3dK3.apply(u2, self.p3, None, 1, self.c3).squeeze(1)
+        s0 = F.relu(F.conv3d(cost, self.c1, self.b1, padding=1))
+        s0 = F.relu(F.conv3d(s0, self.c2, self.b2, padding=1))
+        s1 = F.relu(F.conv3d(s0, g["d1"], hb["d1"], stride=2, padding=1))
+        s1 = F.relu(F.conv3d(s1, g["m1"], hb["m1"], padding=1))
+        s2 = F.relu(F.conv3d(s1, g["d2"], hb["d2"], stride=2, padding=1))
+        s2 = F.relu(F.conv3d(s2, g["m2"], hb["m2"], padding=1))
+        u1 = F.relu(F.conv_transpose3d(s2, g["u1"], hb["u1"], stride=2, padding=1, output_padding=1) + s1)
+        u2 = F.relu(F.conv_transpose3d(u1, g["u2"], hb["u2"], stride=2, padding=1, output_padding=1) + s0)
+        return F.conv3d(u2, self.c3, padding=1).squeeze(1)
+
     def depth_pred(self, imgL, imgR):
         fl, fr = self.features(imgL), self.features(imgR)
         build = self.ops.PsvBuildLerp if self.interp else self.ops.PsvBuild
         cost = build.apply(fl.contiguous(), fr.contiguous(), self.shifts(imgL.shape[0]))
-        if self.mfma_conv:
-            v = F.relu(self.ops.Conv3dK3.apply(cost, self.p1, self.p1t, self.mid))
-            v = F.relu(self.ops.Conv3dK3.apply(v, self.p2, self.p2t, self.mid))
-        else:
-            v = F.relu(F.conv3d(cost, self.c1, padding=1))
-            v = F.relu(F.conv3d(v, self.c2, padding=1))
-        if self.mfma_conv:
-            v = self.ops.Conv3dK3.apply(v, self.p3, None, 1, self.c3).squeeze(1)
-        else:
-            v = F.conv3d(v, self.c3, padding=1).squeeze(1)                   # [B,D,h,w]
+        v = self._volume_net(cost)                                           # [B,D,h,w]
         prob = torch.softmax(v, dim=1)
         depth = (prob * self.depth.view(1, -1, 1, 1)).sum(dim=1, keepdim=True)
         return F.interpolate(depth, scale_factor=self.downsample, mode="bilinear", align_corners=False).squeeze(1)

@@ -16,10 +16,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from eval_driving_safety_amd import adapters, attacks, data  # noqa: E402
 
 
-def measure(pairs=1, iters=20, reps=2, warm_iters=None, mfma_conv=True):
+def measure(pairs=1, iters=20, reps=2, warm_iters=None, mfma_conv=True, hourglass=False):
     """-> dict; the first (untimed) attack absorbs MIOpen's solver search"""
     dev = torch.device("cuda", torch.cuda.current_device())
-    net = adapters.PsvStereoAdapter(dev, seed=0, mfma_conv=mfma_conv)
+    net = adapters.PsvStereoAdapter(dev, seed=0, mfma_conv=mfma_conv, hourglass=hourglass)
     batch = next(iter(data.SyntheticStereo(pairs, "dsgn", batch=pairs, seed=0)))
     gen = torch.Generator().manual_seed(1)
     gt = torch.rand((pairs, 384, 1248), generator=gen) * 38.4 + 2.0
@@ -66,9 +66,11 @@ def measure(pairs=1, iters=20, reps=2, warm_iters=None, mfma_conv=True):
         "value": pairs / dt, "unit": "stereo-pairs/s", "pairs": pairs, "iters": iters,
         "s_per_attack": dt, "detector_fwd_bwd_ms": model_ms,
         "loss_first_iter": first, "loss_last_iter": last, "loss_rose": last > first, "roofline": mfma,
-        "convs": "libadvengine float32-MFMA conv3d (64->32, 32->32) + torch for 32->1" if mfma_conv else "torch / MIOpen",
-        "note": "NOT the headline metric and NOT DSGN: 2D features -> HIP plane-sweep volume [B,64,48,96,312] -> 3 x conv3d "
-                "-> soft-argmin depth -> smooth-L1; dtype f32; cost volume + PGD step by libadvengine.so"}
+        "convs": ("libadvengine float32-MFMA conv3d (all 3D layers; the adjoint of the last 32->1 layer through torch)" if mfma_conv else "torch / MIOpen"),
+        "volume_net": ("3D hourglass: 64->32, 32->32, 32->64 /2, 64->64, 64->64 /2, 64->64, transposed 64->64 + skip, transposed 64->32 + skip, 32->1"
+                       if hourglass else "three convolutions 64->32->32->1"),
+        "note": "NOT the headline metric and NOT DSGN: 2D features -> HIP plane-sweep volume [B,64,48,96,312] (fractional disparities) -> "
+                "3D convolutions -> soft-argmin depth -> smooth-L1; dtype f32; cost volume + convolutions + PGD step by libadvengine.so"}
 
 
 def main():
@@ -77,9 +79,10 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--miopen", action="store_true", help="route the wide convolutions through torch / MIOpen instead")
+    ap.add_argument("--hourglass", action="store_true", help="the 3D-hourglass volume network instead of three convolutions")
     args = ap.parse_args()
     torch.cuda.set_device(0)
-    print(json.dumps(measure(args.pairs, args.iters, args.reps, mfma_conv=not args.miopen)))
+    print(json.dumps(measure(args.pairs, args.iters, args.reps, mfma_conv=not args.miopen, hourglass=args.hourglass)))
 
 
 if __name__ == "__main__":
