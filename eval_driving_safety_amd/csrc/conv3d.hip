@@ -381,13 +381,11 @@ static int launch_conv(const float* x, const float* w_prep, float* y, int b, int
   } else {
     const dim3 grid(tiles_w * tiles_h, (gd + kTD - 1) / kTD, b * cblocks);
     const size_t lds = static_cast<size_t>(GenGeo<2>::kSX + kSW) * sizeof(float);
-    static bool raised = false;  // > 64 KiB of dynamic LDS needs the attribute once per process (idempotent)
-    if (!raised) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_k3_mfma_generic<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              static_cast<int>(lds)) != hipSuccess)
-        return ADV_ELAUNCH;
-      raised = true;
-    }
+    // more than 64 KiB of dynamic LDS needs the attribute; set on every call (idempotent, a host-side table write) so that
+    // the library keeps no state of its own
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_k3_mfma_generic<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            static_cast<int>(lds)) != hipSuccess)
+      return ADV_ELAUNCH;
     hipLaunchKernelGGL((conv3d_k3_mfma_generic<2>), grid, dim3(256), lds, st, x, w_prep, y, cin, cout, cblocks * 32, gd, gh, gw, d, h, w,
                        tiles_w, cblocks, epi);
   }
