@@ -446,3 +446,21 @@ def test_depth_statistics_match_the_reference(golden_index):
     pts = D.project_disp_to_points(G["f_u"], pred[0].copy(), 0.54, True)
     pts = pts[(pts[:, 0] >= 0) & (pts[:, 2] < 30.)]           # the reference's filter after its (here: identity) velo transform
     assert pts.shape[0] == G["cloud_rows"] and sha(pts) == G["cloud"]
+
+
+def test_ops_surface_is_complete():
+    """every host-side operator the drivers, CLIs and INTEGRATION.md name is there (importing ops needs no GPU)"""
+    from eval_driving_safety_amd import ops
+    names = ["Space", "denormalize", "normalize", "CleanIndex", "can_index_clean", "denormalize_indexed", "alloc_u8", "pgd_step", "export_u8",
+             "disc_mask", "patch_paste", "patch_paste_batch", "patch_update", "patch_delta_batch", "patch_apply",
+             "psv_build", "psv_build_bwd", "PsvBuild", "psv_build_lerp", "psv_build_lerp_bwd", "PsvBuildLerp",
+             "roi_align", "roi_align_bwd", "RoIAlign", "nms",
+             "conv3d_k3_prep", "conv3d_k3", "conv3d_k3_s2", "conv_transpose3d_k3_s2_prep", "conv_transpose3d_k3_s2",
+             "Conv3dK3", "Conv3dK3S2", "ConvTranspose3dK3S2",
+             "dense_align_cost", "dense_align_argmin", "dense_align_search", "box_depth_offsets", "dense_align"]
+    missing = [n for n in names if not hasattr(ops, n)]
+    assert not missing, missing
+    # and every exported C symbol is reachable from some operator
+    src = open(ops.__file__).read()
+    unused = [s for s in _lib.SIGNATURES if s not in src]
+    assert not unused, unused
