@@ -592,7 +592,16 @@ def _conv3d_ex(x, w_prep, cout, stride=1, relu=False, bias=None, tap_mask=ALL_TA
 
 def conv3d_k3(x, w_prep, cout, relu=False, bias=None):
     """conv3d(x [B,Cin,D,H,W], stride 1, padding 1) (+ bias [cout]) (+ ReLU) with prepared weights -> [B,cout,D,H,W]"""
-    return _conv3d_ex(x, w_prep, cout, 1, relu, bias)
+    if bias is not None:
+        return _conv3d_ex(x, w_prep, cout, 1, relu, bias)
+    xi, wp = _feat(x, "x"), _feat(w_prep, "w_prep")
+    if xi.dim() != 5 or wp.dim() != 3 or wp.shape[0] != 27 or wp.shape[1] != xi.shape[1] or wp.shape[2] < cout:
+        raise ValueError("x must be [B,Cin,D,H,W] and w_prep [27,Cin,>=cout]")
+    b, cin, d, h, w = xi.shape
+    y = torch.empty((b, cout, d, h, w), dtype=torch.float32, device=xi.device)
+    with _on(xi):
+        _lib.call("adv_conv3d_k3_f32", _ptr(xi), _ptr(wp), _ptr(y), b, cin, cout, d, h, w, int(relu), _stream(xi))
+    return y
 
 
 def conv3d_k3_s2(x, w_prep, cout, relu=False, bias=None):
