@@ -616,3 +616,40 @@ def test_srcnn_shape_in_place_with_export(shape, ops):
                 same_bits(host(u8)[i], O.srcnn_export_u8(want[i]), "dense export, image %d step %d" % (i, k))
         same_bits(host(x), want, "in-place iterate %d" % k)
     same_bits(host(ops.export_u8(x, sp)), np.stack([O.srcnn_export_u8(want[i]) for i in range(n)]), "stand-alone dense export")
+
+
+def test_indexed_equals_float_path_at_bench_scale(ops):
+    """BASELINE configs[1] at the bench's own scale: 256 zero-padded KITTI-shaped pairs (512 images) built exactly as bench.py
+    builds them; the indexed kernel and the all-float32 kernel (itself pinned by the golden vectors) must agree on every
+    bit of every iterate and every export byte, all 512 images must verify, and sampled images must equal the oracle."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    dev_ = torch.device("cuda", 0)
+    sp = ops.Space.dsgn()
+    pairs = 256
+    gen = torch.Generator(device=dev_).manual_seed(77)
+    x0, valid = bench.kitti_like_input(torch, ops, sp, pairs, dev_, gen, padded=True)
+    assert valid == (375, 1242) and float(x0[:, :, 375:].abs().max()) == 0 and float(x0[:, :, :, 1242:].abs().max()) == 0
+    grad = torch.randn(x0.shape, device=dev_, generator=gen)
+    crop = (375, 1242)
+    u8_i, u8_f = ops.alloc_u8(2 * pairs, 375, 1248, dev_), ops.alloc_u8(2 * pairs, 375, 1248, dev_)
+    clean_i, ci = ops.denormalize_indexed(x0, sp, valid=valid, u8_out=u8_i, crop=crop)
+    assert all(ci.verified()), "every loader-shaped image must take the index path"
+    clean_f = ops.denormalize(x0, sp)
+    assert torch.equal(clean_i, clean_f)
+    ops.export_u8(x0, sp, crop, out=u8_f)
+    assert torch.equal(u8_i[:, :, :1242], u8_f[:, :, :1242]), "iterate-0 export"
+    xi, xf = x0.clone(), x0.clone()
+    sample = [0, 255, 256, 511]
+    want = host(x0[sample])
+    clean_s, grad_s = O.denormalize(want), host(grad[sample])
+    for k in range(3):
+        ops.pgd_step(xi, grad, clean_i, sp, 1 / 255, 0.03, out=xi, u8_out=u8_i, crop=crop, clean_index=ci)
+        ops.pgd_step(xf, grad, clean_f, sp, 1 / 255, 0.03, out=xf, u8_out=u8_f, crop=crop)
+        assert torch.equal(xi, xf), "iterate %d differs between the indexed and the float32 kernel" % (k + 1)
+        assert torch.equal(u8_i[:, :, :1242], u8_f[:, :, :1242]), "export %d" % (k + 1)
+        want = O.pgd_step_norm01(want, grad_s, clean_s, 1 / 255, 0.03)
+        same_bits(host(xi[sample]), want, "sampled images vs oracle, step %d" % (k + 1))

@@ -111,6 +111,26 @@ def conv(dev):
                               TFLOPs=round(flops / ms / 1e9, 1), frac_of_157TF=round(flops / ms / 1e9 / 157.3, 3),
                               torch_miopen_ms=round(ms_t, 3), speedup_vs_miopen=round(ms_t / ms, 2))))
         del x, wt, wp
+    # the hourglass's other layer types (round 2): stride 2 and transposed, against torch / MIOpen
+    x = torch.randn((1, 32, D, H, W), device=dev)
+    wd = torch.randn((64, 32, 3, 3, 3), device=dev) * 0.05
+    wp = ops.conv3d_k3_prep(wd)
+    flops = 2.0 * 32 * 64 * 27 * (D // 2) * (H // 2) * (W // 2)
+    ms = timeit(lambda: ops.conv3d_k3_s2(x, wp, 64), reps=10)
+    F.conv3d(x, wd, stride=2, padding=1)
+    ms_t = timeit(lambda: F.conv3d(x, wd, stride=2, padding=1), reps=10)
+    print(json.dumps(dict(kernel="conv3d_k3 stride 2, 32->64 on [1,32,%d,%d,%d]" % (D, H, W), ms=round(ms, 3), TFLOPs=round(flops / ms / 1e9, 1),
+                          frac_of_157TF=round(flops / ms / 1e9 / 157.3, 3), torch_miopen_ms=round(ms_t, 3), speedup_vs_miopen=round(ms_t / ms, 2))))
+    xs = torch.randn((1, 64, D // 2, H // 2, W // 2), device=dev)
+    wu = torch.randn((64, 32, 3, 3, 3), device=dev) * 0.05
+    classes = ops.conv_transpose3d_k3_s2_prep(wu)
+    flops = 2.0 * 64 * 32 * 27 * (D // 2) * (H // 2) * (W // 2)                 # 27 multiply-adds per INPUT voxel
+    ms = timeit(lambda: ops.conv_transpose3d_k3_s2(xs, classes, 32), reps=10)
+    F.conv_transpose3d(xs, wu, stride=2, padding=1, output_padding=1)
+    ms_t = timeit(lambda: F.conv_transpose3d(xs, wu, stride=2, padding=1, output_padding=1), reps=10)
+    print(json.dumps(dict(kernel="conv_transpose3d_k3 stride 2 (8 masked classes), 64->32 on [1,64,%d,%d,%d]" % (D // 2, H // 2, W // 2), ms=round(ms, 3),
+                          TFLOPs=round(flops / ms / 1e9, 1), frac_of_157TF=round(flops / ms / 1e9 / 157.3, 3), torch_miopen_ms=round(ms_t, 3),
+                          speedup_vs_miopen=round(ms_t / ms, 2))))
 
 
 def main():
@@ -139,6 +159,9 @@ def main():
         line("psv_build fwd", timeit(lambda: ops.psv_build(left, right, shift, out=cost)), vol + feat, B=B)
         g = torch.randn_like(cost)
         line("psv_build bwd", timeit(lambda: ops.psv_build_bwd(g, shift)), vol + feat, B=B)
+        shift_f = (721.5377 * 0.54 / depth / 4).to(torch.float32).repeat(B, 1).contiguous()      # fractional disparities
+        line("psv_build_lerp fwd", timeit(lambda: ops.psv_build_lerp(left, right, shift_f, out=cost)), vol + feat, B=B)
+        line("psv_build_lerp bwd", timeit(lambda: ops.psv_build_lerp_bwd(g, shift_f)), vol + feat, B=B)
         del cost, g
     # ---- affine / export at 512 images
     n = 512
@@ -160,11 +183,11 @@ def main():
     u8s = ops.alloc_u8(ns, 600, 1987, dev)
     Es = xs.numel() * 4
     line("pgd_step srcnn (in place, no u8)", timeit(lambda: ops.pgd_step(xs, gs, cs, sps, 1.0, 7.65, out=xs)), 4 * Es, images=ns)
-    line("pgd_step srcnn (in place, byte-path u8: W%4!=0)", timeit(lambda: ops.pgd_step(xs, gs, cs, sps, 1.0, 7.65, out=xs, u8_out=u8s), reps=5),
+    line("pgd_step srcnn (in place, dense u8: flat 12-byte stores)", timeit(lambda: ops.pgd_step(xs, gs, cs, sps, 1.0, 7.65, out=xs, u8_out=u8s), reps=5),
          4 * Es + ns * 3 * 600 * 1987, images=ns)
     xo = torch.empty_like(xs)
     line("pgd_step srcnn (out of place, no u8)", timeit(lambda: ops.pgd_step(xs, gs, cs, sps, 1.0, 7.65, out=xo)), 4 * Es, images=ns)
-    line("pgd_step srcnn (out of place, byte-path u8, line-aligned kernel)",
+    line("pgd_step srcnn (out of place, dense u8, line-aligned kernel)",
          timeit(lambda: ops.pgd_step(xs, gs, cs, sps, 1.0, 7.65, out=xo, u8_out=u8s), reps=5), 4 * Es + ns * 3 * 600 * 1987, images=ns)
     del xs, gs, cs, u8s, xo
     # ---- patch kernels, batch of 64 pairs
