@@ -130,13 +130,13 @@ class PsvStereoAdapter:
             self.b1 = (torch.randn(mid, generator=gen) * 0.05).to(device)
             self.b2 = (torch.randn(mid, generator=gen) * 0.05).to(device)
             if self.mfma_conv:
-                P = ops.conv3d_k3_prep
-                self.hp = {"d1": (P(self.hg["d1"]), ops.conv_transpose3d_k3_s2_prep(self.hg["d1"])),
-                           "d2": (P(self.hg["d2"]), ops.conv_transpose3d_k3_s2_prep(self.hg["d2"])),
+                P, S2 = ops.conv3d_k3_prep, ops.conv3d_k3_s2_prep
+                self.hp = {"d1": (S2(self.hg["d1"]), ops.conv_transpose3d_k3_s2_prep(self.hg["d1"])),
+                           "d2": (S2(self.hg["d2"]), ops.conv_transpose3d_k3_s2_prep(self.hg["d2"])),
                            "m1": (P(self.hg["m1"]), P(self.hg["m1"], transpose=True)),
                            "m2": (P(self.hg["m2"]), P(self.hg["m2"], transpose=True)),
-                           "u1": (ops.conv_transpose3d_k3_s2_prep(self.hg["u1"]), P(self.hg["u1"])),
-                           "u2": (ops.conv_transpose3d_k3_s2_prep(self.hg["u2"]), P(self.hg["u2"]))}
+                           "u1": (ops.conv_transpose3d_k3_s2_prep(self.hg["u1"]), S2(self.hg["u1"])),
+                           "u2": (ops.conv_transpose3d_k3_s2_prep(self.hg["u2"]), S2(self.hg["u2"]))}
 
     def shifts(self, b):
         disp = self.fu * self.baseline / self.depth / self.downsample       # feature-pixel disparity per plane

@@ -30,12 +30,18 @@ struct Epi {
   const float* bias;
   int relu;
   unsigned tap_mask;
+  unsigned class_masks[8];  // class_channels > 0: input channels [k*class_channels, (k+1)*class_channels) use class_masks[k]
+  int class_channels;       //                      (the eight parity sub-volumes of a space-to-depth input), else tap_mask
   int od, oh, ow;     // output tensor dims
   int sd, sh, sw;     // output lattice stride
   int fd, fh, fw;     // output lattice offset
 };
 
 constexpr unsigned kAllTaps = (1u << 27) - 1u;
+
+__device__ __forceinline__ unsigned chunk_mask(const Epi& e, int c0) {
+  return e.class_channels > 0 ? e.class_masks[c0 / e.class_channels] : e.tap_mask;
+}
 
 __device__ __forceinline__ void epi_store(const Epi& e, float* __restrict__ y, long long b, int Cout, int co, int gd, int gh, int gw, float r) {
   const int zd = gd * e.sd + e.fd, zh = gh * e.sh + e.fh, zw = gw * e.sw + e.fw;
@@ -108,9 +114,10 @@ __global__ __launch_bounds__(256) void conv3d_k3_mfma_generic(const float* __res
       sw[idx] = wp[(static_cast<long long>(tap) * Cin + c0 + c) * cout_pad + cob * 32 + n];
     }
     __syncthreads();
+    const unsigned mask = chunk_mask(epi, c0);
 #pragma unroll 1
     for (int tap = 0; tap < 27; ++tap) {
-      if (!((epi.tap_mask >> tap) & 1u)) continue;  // uniform: an unused tap of a transposed-convolution parity class
+      if (!((mask >> tap) & 1u)) continue;  // uniform: an unused tap of a parity class
       const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
 #pragma unroll
       for (int kk = 0; kk < kCK / 2; ++kk) {
@@ -279,13 +286,14 @@ __global__ __launch_bounds__(128 * TD, 2) void conv3d_k3_mfma(const float* __res
     const float* sxc = lds + cur * G::kStageFloats;
     const float* swc = sxc + G::kSX;
     if (more) stage_fetch<TD>(st, x, wp, tid, b, c0 + kFC, Cin, cout_pad, cob, D, H, W, d0, h0, w0, plane, vol);
+    const unsigned mask = MASKED ? chunk_mask(epi, c0) : kAllTaps;
 #pragma unroll
     for (int t9 = 0; t9 < 9; ++t9) {  // (kd, kh); fully unrolled so that LDS operand reads run ahead of their MFMAs
       const int kd = t9 / 3, kh = t9 - kd * 3;
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
         const int tap = t9 * 3 + kw;
-        if (MASKED && !((epi.tap_mask >> tap) & 1u)) continue;  // scalar branch, transposed-convolution classes only
+        if (MASKED && !((mask >> tap) & 1u)) continue;  // scalar branch, parity-class convolutions only
 #pragma unroll
         for (int kk = 0; kk < kFC / 2; ++kk) {
           const int c = 2 * kk + half;
@@ -319,6 +327,29 @@ __global__ __launch_bounds__(128 * TD, 2) void conv3d_k3_mfma(const float* __res
       const int co = cob * 32 + 8 * (v >> 2) + 4 * half + (v & 3);
       if (co < Cout) epi_store(epi, y, b, Cout, co, gd, gh, gw, acc[i][v]);
     }
+  }
+}
+
+// xs[b, p*C + c, jd, jh, jw] = x[b, c, 2jd+pd, 2jh+ph, 2jw+pw], p = (pd*2+ph)*2+pw, zero beyond the input: the eight parity
+// sub-volumes of x side by side in the channel dimension.  A stride-2 3x3x3 convolution of x is then a stride-1 convolution
+// of xs in which sub-volume p uses only the taps its parity allows (27 taps over the eight classes - no wasted MFMA work),
+// so the strided layers of an hourglass run on the tuned stride-1 kernel.  HBM-bound permute, writes coalesced.
+__global__ __launch_bounds__(256) void space_to_depth2(const float* __restrict__ x, float* __restrict__ xs, int B, int C, int D, int H, int W,
+                                                       int D2, int H2, int W2) {
+  const long long total = static_cast<long long>(B) * 8 * C * D2 * H2 * W2;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += gridDim.x * 256LL) {
+    const int jw = static_cast<int>(i % W2);
+    long long t = i / W2;
+    const int jh = static_cast<int>(t % H2);
+    t /= H2;
+    const int jd = static_cast<int>(t % D2);
+    t /= D2;
+    const int c = static_cast<int>(t % C);
+    t /= C;
+    const int p = static_cast<int>(t % 8);
+    const long long b = t / 8;
+    const int gd = 2 * jd + (p >> 2), gh = 2 * jh + ((p >> 1) & 1), gw = 2 * jw + (p & 1);
+    xs[i] = (gd < D && gh < H && gw < W) ? x[((b * C + c) * D + gd) * (static_cast<long long>(H) * W) + static_cast<long long>(gh) * W + gw] : 0.0f;
   }
 }
 
@@ -368,7 +399,7 @@ static int launch_conv(const float* x, const float* w_prep, float* y, int b, int
   if (fast) {
     const dim3 grid(tiles_w * tiles_h, (d + 1) / 2, b * cblocks);
     const size_t lds = 2 * static_cast<size_t>(Geo<2>::kStageFloats) * sizeof(float);
-    if (epi.tap_mask == kAllTaps)
+    if (epi.tap_mask == kAllTaps && epi.class_channels == 0)
       hipLaunchKernelGGL((conv3d_k3_mfma<2, false>), grid, dim3(Geo<2>::kThreads), lds, st, x, w_prep, y, cin, cout, cblocks * 32, d, h, w,
                          tiles_w, cblocks, epi);
     else
@@ -396,18 +427,37 @@ int adv_conv3d_k3_f32(const float* x, const float* w_prep, float* y, int b, int 
                       adv_stream_t stream) {
   if (!x || !w_prep || !y || b < 1 || cin < 1 || cout < 1 || d < 1 || h < 1 || w < 1) return ADV_EINVAL;
   if (cin % kCK != 0) return ADV_EINVAL;
-  const Epi epi{nullptr, relu, kAllTaps, d, h, w, 1, 1, 1, 0, 0, 0};
+  const Epi epi{nullptr, relu, kAllTaps, {0, 0, 0, 0, 0, 0, 0, 0}, 0, d, h, w, 1, 1, 1, 0, 0, 0};
   return launch_conv(x, w_prep, y, b, cin, cout, d, h, w, 1, epi, static_cast<hipStream_t>(stream));
 }
 
+int adv_space_to_depth2_f32(const float* x, float* xs, int b, int c, int d, int h, int w, adv_stream_t stream) {
+  if (!x || !xs || b < 1 || c < 1 || d < 1 || h < 1 || w < 1) return ADV_EINVAL;
+  const int d2 = (d + 1) / 2, h2 = (h + 1) / 2, w2 = (w + 1) / 2;
+  const long long total = static_cast<long long>(b) * 8 * c * d2 * h2 * w2;
+  long long blocks = (total + 255) / 256;
+  if (blocks > (1 << 20)) blocks = 1 << 20;
+  hipLaunchKernelGGL(space_to_depth2, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, static_cast<hipStream_t>(stream), x, xs, b, c, d, h, w, d2,
+                     h2, w2);
+  return adv_internal_finish_launch();
+}
+
 int adv_conv3d_k3_ex_f32(const float* x, const float* w_prep, const float* bias, float* y, int b, int cin, int cout, int d, int h, int w,
-                         int stride, int relu, uint32_t tap_mask, const int32_t* out_dims, const int32_t* out_stride,
-                         const int32_t* out_offset, adv_stream_t stream) {
+                         int stride, int relu, uint32_t tap_mask, const uint32_t* class_masks, int class_channels, const int32_t* out_dims,
+                         const int32_t* out_stride, const int32_t* out_offset, adv_stream_t stream) {
   if (!x || !w_prep || !y || b < 1 || cin < 1 || cout < 1 || d < 1 || h < 1 || w < 1) return ADV_EINVAL;
   if (cin % kCK != 0 || (stride != 1 && stride != 2) || (tap_mask & ~kAllTaps)) return ADV_EINVAL;
   if ((out_dims == nullptr) != (out_stride == nullptr) || (out_dims == nullptr) != (out_offset == nullptr)) return ADV_EINVAL;
   const int gd = stride == 2 ? (d + 1) / 2 : d, gh = stride == 2 ? (h + 1) / 2 : h, gw = stride == 2 ? (w + 1) / 2 : w;
-  Epi epi{bias, relu, tap_mask, gd, gh, gw, 1, 1, 1, 0, 0, 0};
+  Epi epi{bias, relu, tap_mask, {0, 0, 0, 0, 0, 0, 0, 0}, 0, gd, gh, gw, 1, 1, 1, 0, 0, 0};
+  if (class_masks != nullptr) {
+    if (class_channels < kCK || class_channels % kCK != 0 || cin != 8 * class_channels) return ADV_EINVAL;
+    for (int k = 0; k < 8; ++k) {
+      if (class_masks[k] & ~kAllTaps) return ADV_EINVAL;
+      epi.class_masks[k] = class_masks[k];
+    }
+    epi.class_channels = class_channels;
+  }
   if (out_dims) {
     for (int k = 0; k < 3; ++k)
       if (out_dims[k] < 1 || out_stride[k] < 1 || out_offset[k] < 0) return ADV_EINVAL;

@@ -566,7 +566,8 @@ def _i3(v):
     return None if v is None else (ctypes.c_int32 * 3)(*[int(a) for a in v])
 
 
-def _conv3d_ex(x, w_prep, cout, stride=1, relu=False, bias=None, tap_mask=ALL_TAPS, out=None, out_stride=None, out_offset=None):
+def _conv3d_ex(x, w_prep, cout, stride=1, relu=False, bias=None, tap_mask=ALL_TAPS, out=None, out_stride=None, out_offset=None,
+               class_masks=None):
     xi, wp = _feat(x, "x"), _feat(w_prep, "w_prep")
     if xi.dim() != 5 or wp.dim() != 3 or wp.shape[0] != 27 or wp.shape[1] != xi.shape[1] or wp.shape[2] < cout:
         raise ValueError("x must be [B,Cin,D,H,W] and w_prep [27,Cin,>=cout]")
@@ -584,9 +585,11 @@ def _conv3d_ex(x, w_prep, cout, stride=1, relu=False, bias=None, tap_mask=ALL_TA
         if out.dim() != 5 or out.shape[0] != b or out.shape[1] != cout:
             raise ValueError("out must be [B,cout,D',H',W']")
         dims = tuple(out.shape[2:])
+    cm = None if class_masks is None else (ctypes.c_uint32 * 8)(*[int(m) for m in class_masks])
     with _on(xi):
         _lib.call("adv_conv3d_k3_ex_f32", _ptr(xi), _ptr(wp), None if bias is None else _ptr(bias), _ptr(out), b, cin, cout, d, h, w, int(stride),
-                  int(relu), int(tap_mask), _i3(dims), _i3(out_stride if dims else None), _i3(out_offset if dims else None), _stream(xi))
+                  int(relu), int(tap_mask), cm, 0 if cm is None else cin // 8, _i3(dims), _i3(out_stride if dims else None),
+                  _i3(out_offset if dims else None), _stream(xi))
     return out
 
 
@@ -604,9 +607,51 @@ def conv3d_k3(x, w_prep, cout, relu=False, bias=None):
     return y
 
 
-def conv3d_k3_s2(x, w_prep, cout, relu=False, bias=None):
-    """the strided 3x3x3 convolution of an hourglass: stride 2, padding 1 -> [B,cout,ceil(D/2),ceil(H/2),ceil(W/2)]"""
-    return _conv3d_ex(x, w_prep, cout, 2, relu, bias)
+def space_to_depth2(x, out=None):
+    """[B,C,D,H,W] -> [B,8C,ceil(D/2),ceil(H/2),ceil(W/2)]: the eight parity sub-volumes side by side in the channel dimension"""
+    xi = _feat(x, "x")
+    b, c, d, h, w = xi.shape
+    shape = (b, 8 * c, (d + 1) // 2, (h + 1) // 2, (w + 1) // 2)
+    out = torch.empty(shape, dtype=torch.float32, device=xi.device) if out is None else _feat(out, "out")
+    if tuple(out.shape) != shape:
+        raise ValueError("out must be %s" % (shape,))
+    with _on(xi):
+        _lib.call("adv_space_to_depth2_f32", _ptr(xi), _ptr(out), b, c, d, h, w, _stream(xi))
+    return out
+
+
+def conv3d_k3_s2_prep(weight):
+    """[Cout,Cin,3,3,3] -> (w_prep over the 8*Cin space-to-depth channels, the eight class tap masks).
+    out[o] = W0 x[2o-1] + W1 x[2o] + W2 x[2o+1] per axis = W1 e[o] + W0 odd[o-1] + W2 odd[o] with e[j] = x[2j], odd[j] = x[2j+1]:
+    the even sub-volume uses tap index 1 (offset 0) with kernel element 1; the odd one tap 0 (offset -1) with element 0 and
+    tap 1 with element 2."""
+    wt = _feat(weight, "weight")
+    if wt.dim() != 5 or tuple(wt.shape[2:]) != (3, 3, 3):
+        raise ValueError("weight must be [Cout,Cin,3,3,3]")
+    cout, cin = wt.shape[:2]
+    pairs = {0: ((1, 1),), 1: ((0, 0), (1, 2))}                                   # parity -> ((tap index, kernel element), ...)
+    w8 = torch.zeros((cout, 8 * cin, 3, 3, 3), dtype=torch.float32, device=wt.device)
+    masks = []
+    for p in range(8):
+        mask = 0
+        for td, kd in pairs[p >> 2]:
+            for th, kh in pairs[(p >> 1) & 1]:
+                for tw, kw in pairs[p & 1]:
+                    w8[:, p * cin:(p + 1) * cin, td, th, tw] = wt[:, :, kd, kh, kw]
+                    mask |= 1 << (td * 9 + th * 3 + tw)
+        masks.append(mask)
+    return conv3d_k3_prep(w8), tuple(masks)
+
+
+def conv3d_k3_s2(x, prep, cout, relu=False, bias=None):
+    """the strided 3x3x3 convolution of an hourglass: stride 2, padding 1 -> [B,cout,ceil(D/2),ceil(H/2),ceil(W/2)].
+    ``prep`` = ``conv3d_k3_s2_prep(weight)``: space-to-depth + the tuned stride-1 MFMA kernel with per-class tap masks (no
+    wasted matrix work).  A plain ``conv3d_k3_prep(weight)`` tensor is accepted too and takes the direct strided kernel
+    (no workspace, slower)."""
+    if isinstance(prep, torch.Tensor):
+        return _conv3d_ex(x, prep, cout, 2, relu, bias)
+    w_prep8, masks = prep
+    return _conv3d_ex(space_to_depth2(x), w_prep8, cout, 1, relu, bias, class_masks=masks)
 
 
 def conv_transpose3d_k3_s2_prep(weight_t):
@@ -693,7 +738,7 @@ class Conv3dK3S2(torch.autograd.Function):
 
 class ConvTranspose3dK3S2(torch.autograd.Function):
     """y = conv_transpose3d(x, weight_t, stride 2, padding 1, output_padding 1); the gradient w.r.t. x is the strided
-    convolution of grad_y with weight_t read as [out = Cin, in = Cout] (``w_prep_fwd = conv3d_k3_prep(weight_t)``)."""
+    convolution of grad_y with weight_t read as [out = Cin, in = Cout] (``w_prep_fwd = conv3d_k3_s2_prep(weight_t)``)."""
 
     @staticmethod
     def forward(ctx, x, classes, w_prep_fwd, cout, bias=None, relu=False):

@@ -284,10 +284,19 @@ ADV_API int adv_conv3d_k3_f32(const float* x, const float* w_prep, float* y, int
  *     A transposed convolution (kernel 3, stride 2, padding 1, output_padding 1 - the adjoint of the strided one, and the
  *     hourglass's up-sampling layer) is EIGHT such calls, one per output parity class (pd,ph,pw): stride 1, the class's 1-8
  *     taps in tap_mask, out_stride 2, out_offset (pd,ph,pw) - every tap of every class is used exactly once, so the matrix
- *     cores do 27 multiply-adds per INPUT voxel, not 27 per output voxel (ops.conv_transpose3d_k3_s2 prepares the classes). */
+ *     cores do 27 multiply-adds per INPUT voxel, not 27 per output voxel (ops.conv_transpose3d_k3_s2 prepares the classes).
+ *     class_masks (HOST uint32[8] or NULL) + class_channels: input channels [k*class_channels, (k+1)*class_channels) use
+ *                class_masks[k] instead of tap_mask (cin must be 8*class_channels).  With adv_space_to_depth2_f32 this is the
+ *                FAST strided convolution: conv(x, stride 2) == conv(space_to_depth2(x), stride 1) where parity sub-volume p
+ *                keeps only the taps its parity allows (27 taps over the eight sub-volumes), on the tuned stride-1 kernel. */
 ADV_API int adv_conv3d_k3_ex_f32(const float* x, const float* w_prep, const float* bias, float* y, int b, int cin, int cout,
-                                 int d, int h, int w, int stride, int relu, uint32_t tap_mask, const int32_t* out_dims,
-                                 const int32_t* out_stride, const int32_t* out_offset, adv_stream_t stream);
+                                 int d, int h, int w, int stride, int relu, uint32_t tap_mask, const uint32_t* class_masks,
+                                 int class_channels, const int32_t* out_dims, const int32_t* out_stride,
+                                 const int32_t* out_offset, adv_stream_t stream);
+
+/* xs [b, 8c, ceil(d/2), ceil(h/2), ceil(w/2)]:  xs[b, p*c + ch, jd, jh, jw] = x[b, ch, 2jd+pd, 2jh+ph, 2jw+pw], p = (pd*2+ph)*2+pw,
+ *     zero beyond the input.  HBM-bound permute (one pass); xs is caller-owned workspace. */
+ADV_API int adv_space_to_depth2_f32(const float* x, float* xs, int b, int c, int d, int h, int w, adv_stream_t stream);
 
 #ifdef __cplusplus
 }

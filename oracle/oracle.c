@@ -293,9 +293,11 @@ void orc_dense_align_cost(const float* left, const float* right, int h, int w, i
 /* csrc/conv3d.hip with its epilogue options, in the kernel's accumulation order (chunks of 4 input channels, taps
  * ascending - masked ones skipped -, channels ascending, one fmaf each), then + bias, then ReLU.  w is an ordinary conv
  * weight [cout][cin][27]; (D,H,W) the INPUT dims; stride 1 or 2 (padding 1); result voxel i goes to i*os + oo of a
- * [B,cout,oD,oH,oW] tensor (positions outside it are dropped).  Upstream detector op: unpinned, as orc_conv3d_k3. */
+ * [B,cout,oD,oH,oW] tensor (positions outside it are dropped); class_channels > 0: input channel c uses
+ * class_masks[c / class_channels] (the parity sub-volumes of a space-to-depth input).  Upstream detector op: unpinned. */
 void orc_conv3d_k3_ex(const float* x, const float* w, const float* bias, float* y, int B, int cin, int cout, int D, int H, int W,
-                      int stride, int relu, unsigned tap_mask, const int* odims, const int* ostride, const int* ooff) {
+                      int stride, int relu, unsigned tap_mask, const int* odims, const int* ostride, const int* ooff,
+                      const unsigned* class_masks, int class_channels) {
   const int gD = stride == 2 ? (D + 1) / 2 : D, gH = stride == 2 ? (H + 1) / 2 : H, gW = stride == 2 ? (W + 1) / 2 : W;
   const long plane = (long)H * W, vol = plane * D;
   const long oplane = (long)odims[1] * odims[2], ovol = oplane * odims[0];
@@ -310,7 +312,8 @@ void orc_conv3d_k3_ex(const float* x, const float* w, const float* bias, float* 
             float acc = 0.0f;
             for (int c0 = 0; c0 < cin; c0 += 4)
               for (int tap = 0; tap < 27; ++tap) {
-                if (!((tap_mask >> tap) & 1u)) continue;
+                const unsigned mask = class_channels > 0 ? class_masks[c0 / class_channels] : tap_mask;
+                if (!((mask >> tap) & 1u)) continue;
                 const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
                 const int gd = stride * d + kd - 1, gh = stride * h + kh - 1, gw = stride * ww + kw - 1;
                 const int in = gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W;

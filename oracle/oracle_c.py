@@ -31,7 +31,7 @@ _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 _lib.orc_dense_align_cost.argtypes = [_fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _i32p, _fp, ctypes.c_int, _fp, ctypes.c_float,
                                       ctypes.c_float, ctypes.c_int, _fp]
 _lib.orc_dense_align_cost.restype = None
-_lib.orc_conv3d_k3_ex.argtypes = [_fp, _fp, ctypes.c_void_p, _fp] + [ctypes.c_int] * 8 + [ctypes.c_uint, _i32p, _i32p, _i32p]
+_lib.orc_conv3d_k3_ex.argtypes = [_fp, _fp, ctypes.c_void_p, _fp] + [ctypes.c_int] * 8 + [ctypes.c_uint, _i32p, _i32p, _i32p, ctypes.c_void_p, ctypes.c_int]
 _lib.orc_conv3d_k3_ex.restype = None
 for _f in ("orc_denormalize", "orc_normalize", "orc_pgd_step_norm01", "orc_pgd_step_meansub255", "orc_tensor2im_u8",
            "orc_patch_paste", "orc_patch_update"):
@@ -167,7 +167,8 @@ def dense_align_argmin(cost, z_center, step):
     return z, cmin
 
 
-def conv3d_k3_ex(x, w, bias=None, stride=1, relu=False, tap_mask=(1 << 27) - 1, out=None, out_stride=(1, 1, 1), out_offset=(0, 0, 0)):
+def conv3d_k3_ex(x, w, bias=None, stride=1, relu=False, tap_mask=(1 << 27) - 1, out=None, out_stride=(1, 1, 1), out_offset=(0, 0, 0),
+                 class_masks=None):
     """csrc/conv3d.hip's extended entry point: x [B,Cin,D,H,W], w [Cout,Cin,3,3,3] (ordinary conv layout)"""
     x = np.ascontiguousarray(x, dtype=np.float32)
     w = np.ascontiguousarray(w, dtype=np.float32)
@@ -178,9 +179,42 @@ def conv3d_k3_ex(x, w, bias=None, stride=1, relu=False, tap_mask=(1 << 27) - 1, 
     if out is None:
         out = np.zeros((b, cout) + grid, np.float32)
     bp = None if bias is None else np.ascontiguousarray(bias, dtype=np.float32).ctypes.data_as(ctypes.c_void_p)
+    cm = None if class_masks is None else np.array(class_masks, np.uint32)
     _lib.orc_conv3d_k3_ex(x, w, bp, out, b, cin, cout, d, h, ww, int(stride), int(relu), int(tap_mask),
-                          np.array(out.shape[2:], np.int32), np.array(out_stride, np.int32), np.array(out_offset, np.int32))
+                          np.array(out.shape[2:], np.int32), np.array(out_stride, np.int32), np.array(out_offset, np.int32),
+                          None if cm is None else cm.ctypes.data_as(ctypes.c_void_p), 0 if cm is None else cin // 8)
     return out
+
+
+def space_to_depth2(x):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    b, c, d, h, w = x.shape
+    d2, h2, w2 = (d + 1) // 2, (h + 1) // 2, (w + 1) // 2
+    pad = np.zeros((b, c, 2 * d2, 2 * h2, 2 * w2), np.float32)
+    pad[:, :, :d, :h, :w] = x
+    out = np.empty((b, 8 * c, d2, h2, w2), np.float32)
+    for p in range(8):
+        out[:, p * c:(p + 1) * c] = pad[:, :, (p >> 2)::2, ((p >> 1) & 1)::2, (p & 1)::2]
+    return out
+
+
+def conv3d_k3_s2(x, w, bias=None, relu=False):
+    """the strided convolution as ops.conv3d_k3_s2 computes it: space-to-depth + a stride-1 convolution over 8*Cin channels
+    in which parity sub-volume p keeps only the taps its parity allows (same accumulation order as the kernel)"""
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    cout, cin = w.shape[:2]
+    pairs = {0: ((1, 1),), 1: ((0, 0), (1, 2))}
+    w8 = np.zeros((cout, 8 * cin, 3, 3, 3), np.float32)
+    masks = []
+    for p in range(8):
+        mask = 0
+        for td, kd in pairs[p >> 2]:
+            for th, kh in pairs[(p >> 1) & 1]:
+                for tw, kw in pairs[p & 1]:
+                    w8[:, p * cin:(p + 1) * cin, td, th, tw] = w[:, :, kd, kh, kw]
+                    mask |= 1 << (td * 9 + th * 3 + tw)
+        masks.append(mask)
+    return conv3d_k3_ex(space_to_depth2(x), w8, bias=bias, relu=relu, class_masks=masks)
 
 
 def conv_transpose3d_k3_s2(x, weight_t, bias=None, relu=False):

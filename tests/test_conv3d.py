@@ -105,6 +105,7 @@ def test_oracle_strided_and_transposed_conv_match_torch():
     np.testing.assert_allclose(y, ref, rtol=1e-5, atol=1e-5)
     assert np.array_equal(C.conv3d_k3_ex(x, wt, bias=bias, stride=2, relu=True), np.maximum(y, 0))
     assert np.array_equal(C.conv3d_k3_ex(x, wt), C.conv3d_k3(x, wt))   # the plain convolution is the default
+    np.testing.assert_allclose(C.conv3d_k3_s2(x, wt, bias=bias), ref, rtol=1e-5, atol=1e-5)   # space-to-depth formulation
     w_t = (rs.randn(8, 5, 3, 3, 3) * 0.1).astype(np.float32)           # ConvTranspose3d layout [Cin, Cout, 3,3,3]
     up = C.conv_transpose3d_k3_s2(x, w_t)
     ref = F.conv_transpose3d(torch.tensor(x), torch.tensor(w_t), stride=2, padding=1, output_padding=1).numpy()
@@ -135,12 +136,18 @@ def test_hip_hourglass_layers_bit_exact_vs_oracle(shape):
     # bias + ReLU epilogue of the plain convolution
     got = ops.conv3d_k3(tx, wp, cout, relu=True, bias=tb)
     assert got.cpu().numpy().tobytes() == C.conv3d_k3_ex(x, wt, bias=bias, relu=True).tobytes(), "bias + relu"
-    # stride 2
+    # stride 2: the direct strided kernel, and space-to-depth + the stride-1 kernel with per-class tap masks
     got = ops.conv3d_k3_s2(tx, wp, cout, bias=tb)
     want = C.conv3d_k3_ex(x, wt, bias=bias, stride=2)
-    assert got.cpu().numpy().tobytes() == want.tobytes(), "stride 2"
+    assert got.cpu().numpy().tobytes() == want.tobytes(), "stride 2 (direct)"
     ref = F.conv3d(tx, tw, tb, stride=2, padding=1)
     assert float((got - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+    assert ops.space_to_depth2(tx).cpu().numpy().tobytes() == C.space_to_depth2(x).tobytes(), "space to depth"
+    s2 = ops.conv3d_k3_s2_prep(tw)
+    assert sorted(bin(m).count("1") for m in s2[1]) == [1, 2, 2, 2, 4, 4, 4, 8]
+    got = ops.conv3d_k3_s2(tx, s2, cout, bias=tb, relu=True)
+    assert got.cpu().numpy().tobytes() == C.conv3d_k3_s2(x, wt, bias=bias, relu=True).tobytes(), "stride 2 (space-to-depth)"
+    assert float((got - F.relu(ref)).abs().max()) <= 1e-4 * float(ref.abs().max())
     # transposed convolution: eight masked-tap launches of the stride-1 kernel
     w_t = (rs.randn(cin, cout, 3, 3, 3) * 0.1).astype(np.float32)
     classes = ops.conv_transpose3d_k3_s2_prep(torch.tensor(w_t, device=dev))
@@ -166,8 +173,8 @@ def test_hip_hourglass_autograd_vs_torch():
     g = torch.randn(ref.shape, device=dev, generator=gen)
     ref.backward(g)
     xm = x.clone().requires_grad_(True)
-    down = ops.Conv3dK3S2.apply(xm, ops.conv3d_k3_prep(wd), ops.conv_transpose3d_k3_s2_prep(wd), 64)
-    up = ops.ConvTranspose3dK3S2.apply(F.relu(down), ops.conv_transpose3d_k3_s2_prep(wu), ops.conv3d_k3_prep(wu), 32)
+    down = ops.Conv3dK3S2.apply(xm, ops.conv3d_k3_s2_prep(wd), ops.conv_transpose3d_k3_s2_prep(wd), 64)
+    up = ops.ConvTranspose3dK3S2.apply(F.relu(down), ops.conv_transpose3d_k3_s2_prep(wu), ops.conv3d_k3_s2_prep(wu), 32)
     up.backward(g)
     assert tuple(up.shape) == tuple(ref.shape) == (1, 32, 12, 24, 80)
     assert float((up - ref).abs().max()) <= 1e-4 * float(ref.detach().abs().max())
