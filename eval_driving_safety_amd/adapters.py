@@ -193,6 +193,15 @@ class PsvStereoAdapter:
         depth = (prob * self.depth.view(1, -1, 1, 1)).sum(dim=1, keepdim=True)
         return F.interpolate(depth, scale_factor=self.downsample, mode="bilinear", align_corners=False).squeeze(1)
 
+    def synthetic_extra(self, batch, seed=1):
+        """a sparse synthetic depth map per pair (5 % of the pixels, 2 .. 40.4 m) for runs without a dataset"""
+        import types
+        b, hh, ww = len(batch), batch.imgL.shape[2], batch.imgL.shape[3]
+        gen = torch.Generator().manual_seed(seed)
+        gt = torch.rand((b, hh, ww), generator=gen) * 38.4 + 2.0
+        gt = torch.where(torch.rand((b, hh, ww), generator=gen) < 0.05, gt, torch.zeros(()))
+        return types.SimpleNamespace(disp_true=gt.to(self.device))
+
     def loss_and_grad(self, x, extra):
         """extra.disp_true [B,H,W] sparse metric depth (0 = no measurement); mask as pgd_attack.py:269"""
         h = _LeafGrad(x)

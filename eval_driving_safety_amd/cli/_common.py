@@ -35,9 +35,11 @@ def add_detect_flags(parser):
 
 def add_engine_flags(parser):
     g = parser.add_argument_group("engine (not in the reference)")
-    g.add_argument("--model", default="upstream", choices=["upstream", "toy"],
+    g.add_argument("--model", default="upstream", choices=["upstream", "shaped", "toy"],
                    help="'upstream' builds the detector from the user's DSGN / Stereo R-CNN checkout exactly as the reference "
-                        "script does; 'toy' runs the plumbing with a fixed-seed differentiable stand-in on synthetic pairs")
+                        "script does; 'shaped' runs a detector-SHAPED network with random weights built on this package's kernels "
+                        "(plane-sweep volume + MFMA 3D hourglass for DSGN; FPN + stereo RPN + RoIAlign heads for Stereo R-CNN); "
+                        "'toy' runs the plumbing with a tiny fixed-seed stand-in")
     g.add_argument("--synthetic", type=int, default=0, metavar="N", help="attack N synthetic pairs instead of the dataset")
     g.add_argument("--out_root", default=".", help="where the *_pgd_iters_k / *_patch_ratio_r / result_* folders go")
     g.add_argument("--save_every", type=int, default=1, help="write every k-th iterate (reference: every one)")
@@ -56,3 +58,25 @@ def upstream_or_exit(build):
         return build()
     except upstream.UpstreamMissing as e:
         sys.exit(str(e))
+
+
+class WithExtra:
+    """a loader whose batches get their ``extra`` from ``make(batch)`` (synthetic ground truth for the shaped detectors)"""
+
+    def __init__(self, loader, make):
+        self.loader, self.make = loader, make
+        self.batch = getattr(loader, "batch", 1)
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _wrap(self, it):
+        for b in it:
+            b.extra = self.make(b)
+            yield b
+
+    def shard(self, rank, world):
+        return self._wrap(self.loader.shard(rank, world))
+
+    def __iter__(self):
+        return self._wrap(iter(self.loader))

@@ -27,12 +27,16 @@ def main(argv=None):
     comm = Comm.from_env(device=dev)
     torch.manual_seed(args.seed)
     torch.cuda.manual_seed(args.seed)
-    if args.model == "toy":
-        adapter = adapters.ToyStereoAdapter(dev, seed=args.seed)
+    if args.model in ("toy", "shaped"):
         batch = args.btest if args.btest else 1
         workers = args.loader_workers if args.loader_workers is not None else (0 if args.debug else 12)
-        factory = (lambda: data.SyntheticStereo(args.synthetic, "dsgn", batch, seed=args.seed)) if args.synthetic \
+        base = (lambda: data.SyntheticStereo(args.synthetic, "dsgn", batch, seed=args.seed)) if args.synthetic \
             else (lambda: data.KittiFolder(args.data_path, args.split_file, batch, workers=workers))
+        if args.model == "toy":
+            adapter, factory = adapters.ToyStereoAdapter(dev, seed=args.seed), base
+        else:
+            adapter = adapters.PsvStereoAdapter(dev, seed=args.seed, hourglass=True)
+            factory = lambda: _common.WithExtra(base(), adapter.synthetic_extra)
     else:
         rt = _common.upstream_or_exit(lambda: upstream.DsgnRuntime(args, dev, attack=True))
         adapter = adapters.DsgnAdapter(rt.model, rt.cfg, rt.RPN3DLoss)

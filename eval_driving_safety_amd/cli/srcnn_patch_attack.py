@@ -25,11 +25,17 @@ def main(argv=None):
     args = build_parser().parse_args(argv)
     dev, _ = _common.setup_device(args.devices)
     comm = Comm.from_env(device=dev)
-    if args.model == "toy":
-        adapter = adapters.ToyStereoAdapter(dev, seed=args.seed, planes=(0, 8, 16, 32))
+    if args.model in ("toy", "shaped"):
         if not args.synthetic:
-            raise SystemExit("--model toy needs --synthetic N (the Stereo R-CNN roidb loader is upstream code)")
-        factory = lambda: data.SyntheticStereo(args.synthetic, "srcnn", 1, seed=args.seed)
+            raise SystemExit("--model %s needs --synthetic N (the Stereo R-CNN roidb loader is upstream code)" % args.model)
+        base = lambda: data.SyntheticStereo(args.synthetic, "srcnn", 1, seed=args.seed)
+        if args.model == "toy":
+            adapter, factory = adapters.ToyStereoAdapter(dev, seed=args.seed, planes=(0, 8, 16, 32)), base
+        else:
+            import torch
+            from .. import surrogates
+            adapter = adapters.StereoRcnnAdapter(surrogates.StereoRcnnShaped(seed=args.seed).to(dev).eval(), torch.zeros(6, device=dev))
+            factory = lambda: _common.WithExtra(base(), lambda b: surrogates.synthetic_srcnn_extra(b, dev))
     else:
         rt = _common.upstream_or_exit(lambda: upstream.SrcnnRuntime(dev, training=True, workers=8))     # :128-129
         adapter = adapters.StereoRcnnAdapter(rt.model, rt.uncert)

@@ -25,11 +25,17 @@ def main(argv=None):
     dev, _ = _common.setup_device(args.devices)
     comm = Comm.from_env(device=dev)
     print("Start iteration: ", args.iter)                                   # :59
-    if args.model == "toy":
-        adapter = adapters.ToyStereoAdapter(dev, seed=args.seed, planes=(0, 8, 16, 32))
+    if args.model in ("toy", "shaped"):
         if not args.synthetic:
-            raise SystemExit("--model toy needs --synthetic N (the Stereo R-CNN roidb loader is upstream code)")
+            raise SystemExit("--model %s needs --synthetic N (the Stereo R-CNN roidb loader is upstream code)" % args.model)
         loader = data.SyntheticStereo(args.synthetic, "srcnn", 1, seed=args.seed)
+        if args.model == "toy":
+            adapter = adapters.ToyStereoAdapter(dev, seed=args.seed, planes=(0, 8, 16, 32))
+        else:   # FPN + stereo RPN + RoIAlign heads on this package's kernels, random weights, synthetic ground truth
+            import torch
+            from .. import surrogates
+            adapter = adapters.StereoRcnnAdapter(surrogates.StereoRcnnShaped(seed=args.seed).to(dev).eval(), torch.zeros(6, device=dev))
+            loader = _common.WithExtra(loader, lambda b: surrogates.synthetic_srcnn_extra(b, dev))
     else:
         rt = _common.upstream_or_exit(lambda: upstream.SrcnnRuntime(dev, training=True, workers=0))
         adapter = adapters.StereoRcnnAdapter(rt.model, rt.uncert)

@@ -1,0 +1,232 @@
+"""A Stereo R-CNN-SHAPED detector with seeded random weights: the consumer of this package's RoI-path kernels
+(``ops.RoIAlign`` forward + deterministic backward, ``ops.nms``) inside an attack loop, with the call signature of the
+upstream network the reference's scripts drive (attack/Stereo-RCNN/stereo_rcnn.py:143-326, stereo_rpn.py:62-138):
+
+    model(im_left, im_right, im_info, gt_boxes_left, gt_boxes_right, gt_boxes_merge, gt_dim_orien, gt_kpts, num_boxes)
+        -> (rois_left, rois_right, cls_prob, bbox_pred, bbox_pred_dim, kpts_prob, left_prob, right_prob,
+            rpn_loss_cls, rpn_loss_box_left_right, RCNN_loss_cls, RCNN_loss_bbox, RCNN_loss_dim_orien, RCNN_loss_kpts, rois_label)
+
+so ``adapters.StereoRcnnAdapter(model, uncert)`` and the Stereo R-CNN CLIs (``--model shaped``) run it unchanged.  It is
+NOT Stereo R-CNN: a four-level feature pyramid of a few plain convolutions instead of ResNet-101, no trained weights, a
+simplified target assignment - detection parity is unpinned by construction.  What it keeps is the STRUCTURE the kernels
+serve: siamese backbone + FPN on both eyes, a stereo RPN on concatenated left/right features with six regression outputs
+(x, y, w, h shared in y/h between the eyes: dx, dy, dw, dh, dx', dw'), proposals through NMS, pyramid RoIAlign 7x7 on
+both eyes (concatenated) for the box / dimension heads and 14x14 on the left eye for the keypoint head, and - as the
+reference's substitute files do (stereo_rcnn.py:199-200,233-240) - all six losses computed in eval mode.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def _iou(a, b):
+    """[N,4] x [M,4] -> [N,M], legacy +1 areas (as the RoI path uses them)"""
+    lt = torch.max(a[:, None, :2], b[None, :, :2])
+    rb = torch.min(a[:, None, 2:], b[None, :, 2:])
+    wh = (rb - lt + 1).clamp(min=0)
+    inter = wh[..., 0] * wh[..., 1]
+    area_a = (a[:, 2] - a[:, 0] + 1) * (a[:, 3] - a[:, 1] + 1)
+    area_b = (b[:, 2] - b[:, 0] + 1) * (b[:, 3] - b[:, 1] + 1)
+    return inter / (area_a[:, None] + area_b[None, :] - inter)
+
+
+def _encode(src, dst):
+    """(dx, dy, dw, dh) that move boxes ``src`` onto ``dst``"""
+    sw, sh = src[:, 2] - src[:, 0] + 1, src[:, 3] - src[:, 1] + 1
+    sx, sy = src[:, 0] + 0.5 * sw, src[:, 1] + 0.5 * sh
+    dw, dh = dst[:, 2] - dst[:, 0] + 1, dst[:, 3] - dst[:, 1] + 1
+    dx, dy = dst[:, 0] + 0.5 * dw, dst[:, 1] + 0.5 * dh
+    return torch.stack([(dx - sx) / sw, (dy - sy) / sh, torch.log(dw / sw), torch.log(dh / sh)], 1)
+
+
+def _decode(src, d):
+    sw, sh = src[:, 2] - src[:, 0] + 1, src[:, 3] - src[:, 1] + 1
+    sx, sy = src[:, 0] + 0.5 * sw, src[:, 1] + 0.5 * sh
+    cx, cy = d[:, 0] * sw + sx, d[:, 1] * sh + sy
+    w, h = torch.exp(d[:, 2].clamp(max=4.0)) * sw, torch.exp(d[:, 3].clamp(max=4.0)) * sh
+    return torch.stack([cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w - 1, cy + 0.5 * h - 1], 1)
+
+
+class StereoRcnnShaped(nn.Module):
+    LEVELS = (2, 3, 4, 5)                # pyramid levels P2..P5, strides 4..32
+    ANCHOR_RATIOS = (0.5, 1.0, 2.0)
+    GRID = 28                            # cfg.KPTS_GRID
+
+    def __init__(self, classes=("__background__", "Car"), num_layers=101, pretrained=False, channels=32, seed=0, post_nms=64,
+                 pre_nms=400, roi_align=None, nms=None):
+        super().__init__()
+        self.classes, self.n_classes = classes, len(classes)
+        self.post_nms, self.pre_nms = post_nms, pre_nms
+        self._roi_align, self._nms = roi_align, nms                      # injectable for the torch-reference comparison in the tests
+        c = channels
+        g = torch.Generator().manual_seed(seed)
+        self.stem = nn.Conv2d(3, 16, 7, stride=2, padding=3)
+        self.c2 = nn.Conv2d(16, c, 3, padding=1)
+        self.c3, self.c4, self.c5 = (nn.Conv2d(c, c, 3, stride=2, padding=1) for _ in range(3))
+        self.lat = nn.ModuleList(nn.Conv2d(c, c, 1) for _ in range(4))
+        self.smooth = nn.ModuleList(nn.Conv2d(c, c, 3, padding=1) for _ in range(4))
+        a = len(self.ANCHOR_RATIOS)
+        self.rpn_conv = nn.Conv2d(c, c, 3, padding=1)                    # shared by both eyes (stereo_rpn.py:73-80)
+        self.rpn_cls = nn.Conv2d(2 * c, a, 1)                            # objectness on the concatenated left|right feature
+        self.rpn_reg = nn.Conv2d(2 * c, 6 * a, 1)                        # dx, dy, dw, dh, dx', dw'
+        self.fc = nn.Linear(2 * c * 49, 256)
+        self.cls_score = nn.Linear(256, self.n_classes)
+        self.bbox_pred = nn.Linear(256, 6 * self.n_classes)
+        self.dim_orien_pred = nn.Linear(256, 5 * self.n_classes)
+        self.kpts_conv = nn.Conv2d(c, c, 3, padding=1)
+        self.kpts_class = nn.Conv2d(c, 6, 1)                             # 4 keypoint types + left border + right border
+        with torch.no_grad():
+            for p in self.parameters():
+                if p.dim() > 1:
+                    fan_in = p[0].numel()
+                    p.copy_(torch.randn(p.shape, generator=g) * (1.0 / fan_in) ** 0.5)
+                else:
+                    p.zero_()
+
+    def create_architecture(self):       # upstream builds its modules here (pgd_attack.py:92); nothing left to do
+        return self
+
+    # -- backbone + pyramid (one eye) -------------------------------------------------------------------------------
+    def pyramid(self, im):
+        x = F.max_pool2d(F.relu(self.stem(im / 64.0)), 3, stride=2, padding=1)
+        c2 = F.relu(self.c2(x))
+        c3 = F.relu(self.c3(c2))
+        c4 = F.relu(self.c4(c3))
+        c5 = F.relu(self.c5(c4))
+        feats = [c2, c3, c4, c5]
+        p = [None] * 4
+        p[3] = self.lat[3](feats[3])
+        for i in (2, 1, 0):               # _upsample_add (stereo_rcnn.py:92-108): bilinear to the lateral map's size
+            up = F.interpolate(p[i + 1], size=feats[i].shape[2:], mode="bilinear", align_corners=False)
+            p[i] = up + self.lat[i](feats[i])
+        return [self.smooth[i](p[i]) for i in range(4)]
+
+    def anchors(self, level_idx, h, w, device):
+        stride = 4 * 2 ** level_idx
+        size = 8.0 * stride
+        ys, xs = torch.meshgrid(torch.arange(h, device=device), torch.arange(w, device=device), indexing="ij")
+        cx, cy = (xs.reshape(-1).float() + 0.5) * stride, (ys.reshape(-1).float() + 0.5) * stride
+        out = []
+        for r in self.ANCHOR_RATIOS:
+            aw, ah = size / math.sqrt(r), size * math.sqrt(r)
+            out.append(torch.stack([cx - 0.5 * aw, cy - 0.5 * ah, cx + 0.5 * aw - 1, cy + 0.5 * ah - 1], 1))
+        return torch.stack(out, 1).reshape(-1, 4)                        # location-major, ratio-minor: matches the conv outputs
+
+    # -- RoI pooling over the pyramid (stereo_rcnn.py:110-141) ---------------------------------------------------------
+    def pyramid_roi_feat(self, feats, rois, im_info, pooled):
+        from . import ops
+        align = self._roi_align or (lambda f, r, p, s: ops.RoIAlign.apply(f, r, p, s, 0))
+        h = rois[:, 4] - rois[:, 2] + 1
+        w = rois[:, 3] - rois[:, 1] + 1
+        level = torch.round(torch.log(torch.sqrt(h * w) / 224.0) + 4).clamp(2, 5)
+        out = rois.new_zeros((rois.shape[0], feats[0].shape[1], pooled, pooled))
+        for i, l in enumerate(self.LEVELS):
+            idx = torch.nonzero(level == l).view(-1)
+            if idx.numel() == 0:
+                continue
+            scale = feats[i].shape[2] / float(im_info[0][0])
+            out = out.index_add(0, idx, align(feats[i].contiguous(), rois[idx].contiguous(), pooled, scale))
+        return out
+
+    def forward(self, im_left, im_right, im_info, gt_boxes_left, gt_boxes_right, gt_boxes_merge, gt_dim_orien, gt_kpts, num_boxes):
+        from . import ops
+        nms = self._nms or ops.nms
+        dev = im_left.device
+        H, W = float(im_info[0][0]), float(im_info[0][1])
+        fl, fr = self.pyramid(im_left), self.pyramid(im_right)
+        # ---- stereo RPN on every level
+        scores, deltas, anchors = [], [], []
+        for i in range(4):
+            both = torch.cat([F.relu(self.rpn_conv(fl[i])), F.relu(self.rpn_conv(fr[i]))], 1)
+            s, d = self.rpn_cls(both), self.rpn_reg(both)
+            scores.append(s.permute(0, 2, 3, 1).reshape(-1))
+            deltas.append(d.permute(0, 2, 3, 1).reshape(-1, 6))
+            anchors.append(self.anchors(i, s.shape[2], s.shape[3], dev))
+        scores, deltas, anchors = torch.cat(scores), torch.cat(deltas), torch.cat(anchors)
+        n_gt = int(num_boxes.reshape(-1)[0]) if torch.is_tensor(num_boxes) else int(num_boxes)
+        gt_l, gt_r = gt_boxes_left.reshape(-1, 5)[:n_gt, :4], gt_boxes_right.reshape(-1, 5)[:n_gt, :4]
+        # RPN losses against the ground truth (objectness BCE on IoU labels, smooth-L1 on the six deltas of positive anchors)
+        if n_gt > 0:
+            iou = _iou(anchors, gt_l)
+            best, arg = iou.max(1)
+            pos, neg = best >= 0.5, best < 0.3
+            pos[iou.argmax(0)] = True
+            label = pos.float()
+            keep = pos | neg
+            rpn_loss_cls = F.binary_cross_entropy_with_logits(scores[keep], label[keep]).unsqueeze(0)
+            tl, tr = _encode(anchors[pos], gt_l[arg[pos]]), _encode(anchors[pos], gt_r[arg[pos]])
+            target = torch.cat([tl, tr[:, 0:1], tr[:, 2:3]], 1)
+            rpn_loss_box = F.smooth_l1_loss(deltas[pos], target, reduction="mean").unsqueeze(0)
+        else:
+            rpn_loss_cls = rpn_loss_box = scores.sum().unsqueeze(0) * 0
+        # ---- proposals: top scores -> decode both eyes (y and h shared) -> clip -> NMS on the left boxes (HIP, deterministic)
+        with torch.no_grad():
+            order = torch.argsort(scores, descending=True)[:self.pre_nms]
+            d, a = deltas[order], anchors[order]
+            left = _decode(a, d[:, :4])
+            right = _decode(a, torch.stack([d[:, 4], d[:, 1], d[:, 5], d[:, 3]], 1))
+            for b in (left, right):
+                b[:, 0::2].clamp_(0, W - 1)
+                b[:, 1::2].clamp_(0, H - 1)
+            keep = nms(left.contiguous(), scores[order].contiguous(), 0.7)[:self.post_nms]
+            left, right = left[keep], right[keep]
+            if n_gt > 0:                  # the ground truth joins the proposals, as in the proposal-target layer (stereo_rcnn.py:201-204)
+                left, right = torch.cat([gt_l, left]), torch.cat([gt_r, right])
+            zeros = left.new_zeros((left.shape[0], 1))
+            rois_l, rois_r = torch.cat([zeros, left], 1), torch.cat([zeros, right], 1)
+            if n_gt > 0:
+                iou = _iou(left, gt_l)
+                best, arg = iou.max(1)
+                rois_label = (best >= 0.5).long()
+            else:
+                arg = torch.zeros(left.shape[0], dtype=torch.long, device=dev)
+                rois_label = torch.zeros(left.shape[0], dtype=torch.long, device=dev)
+        # ---- box / dimension heads on the concatenated left|right 7x7 features, keypoint head on the left 14x14 feature
+        pooled = torch.cat([self.pyramid_roi_feat(fl, rois_l, im_info, 7), self.pyramid_roi_feat(fr, rois_r, im_info, 7)], 1)
+        top = F.relu(self.fc(pooled.flatten(1)))
+        cls_score, bbox_pred, dim_pred = self.cls_score(top), self.bbox_pred(top), self.dim_orien_pred(top)
+        cls_prob = F.softmax(cls_score, 1)
+        k = self.kpts_class(F.relu(self.kpts_conv(self.pyramid_roi_feat(fl, rois_l, im_info, 14))))
+        k = F.interpolate(k, size=(14, self.GRID), mode="bilinear", align_corners=False).mean(2)      # [R, 6, 28]
+        kpts_prob = F.softmax(k[:, :4].reshape(k.shape[0], -1), 1)
+        left_prob, right_prob = F.softmax(k[:, 4], 1), F.softmax(k[:, 5], 1)
+        # ---- RCNN losses (computed in eval mode, as the reference's substitute files do)
+        RCNN_loss_cls = F.cross_entropy(cls_score, rois_label).unsqueeze(0)
+        fg = torch.nonzero(rois_label > 0).view(-1)
+        if fg.numel() > 0:
+            tl, tr = _encode(left[fg], gt_l[arg[fg]]), _encode(right[fg], gt_r[arg[fg]])
+            target = torch.cat([tl, tr[:, 0:1], tr[:, 2:3]], 1)
+            pred = bbox_pred.view(-1, self.n_classes, 6)[fg, rois_label[fg]]
+            RCNN_loss_bbox = F.smooth_l1_loss(pred, target, reduction="mean").unsqueeze(0)
+            do = gt_dim_orien.reshape(-1, 5)[:n_gt][arg[fg]]
+            RCNN_loss_dim_orien = F.smooth_l1_loss(dim_pred.view(-1, self.n_classes, 5)[fg, rois_label[fg]], do, reduction="mean").unsqueeze(0)
+            kp = gt_kpts.reshape(-1, 6)[:n_gt][arg[fg]]
+            bw = (left[fg, 2] - left[fg, 0] + 1)
+            bins = (((kp[:, 0] - left[fg, 0]) / bw) * self.GRID).long().clamp(0, self.GRID - 1)
+            RCNN_loss_kpts = F.nll_loss(torch.log(kpts_prob[fg].view(-1, 4, self.GRID)[:, 0] + 1e-12), bins).unsqueeze(0)
+        else:
+            RCNN_loss_bbox = RCNN_loss_dim_orien = RCNN_loss_kpts = cls_score.sum().unsqueeze(0) * 0
+        r = rois_l.shape[0]
+        return (rois_l.view(1, r, 5), rois_r.view(1, r, 5), cls_prob.view(1, r, -1), bbox_pred.view(1, r, -1), dim_pred.view(1, r, -1),
+                kpts_prob.view(1, r, -1), left_prob.view(1, r, -1), right_prob.view(1, r, -1),
+                rpn_loss_cls, rpn_loss_box, RCNN_loss_cls, RCNN_loss_bbox, RCNN_loss_dim_orien, RCNN_loss_kpts, rois_label)
+
+
+def synthetic_srcnn_extra(batch, device, max_boxes=30):
+    """ground truth for a synthetic 600x1987 pair in the roibatchLoader layout (roibatchLoader.py:61-90): one car box per
+    eye (the right one shifted by the synthetic disparity), dimension / orientation and keypoint rows, zero padded"""
+    import types
+    b = len(batch)
+    left = torch.zeros((b, max_boxes, 5), device=device)
+    left[:, 0] = torch.tensor([820.0, 300.0, 1100.0, 470.0, 1.0], device=device)
+    right = left.clone()
+    right[:, 0, 0] -= 38.0
+    right[:, 0, 2] -= 38.0
+    dim_orien = torch.zeros((b, max_boxes, 5), device=device)
+    dim_orien[:, 0] = torch.tensor([0.1, -0.05, 0.2, 0.3, 0.9], device=device)
+    kpts = torch.zeros((b, max_boxes, 6), device=device)
+    kpts[:, 0] = torch.tensor([900.0, 1.0, 0.0, 830.0, 1090.0, 0.0], device=device)
+    return types.SimpleNamespace(im_info=torch.tensor([[600.0, 1987.0, 1.6]], device=device), gt_boxes_left=left, gt_boxes_right=right,
+                                 gt_boxes_merge=left.clone(), gt_dim_orien=dim_orien, gt_kpts=kpts, num_boxes=torch.tensor([1], device=device))
