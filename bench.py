@@ -286,8 +286,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # ADV_BENCH_FORCE_DIST=1: take the distributed code path (process group, barriers, MAX-reduce, patch all-reduce probe) even
+    # with WORLD_SIZE=1, so that the RCCL branch can be exercised on a single-GPU box
+    use_dist = world > 1 or os.environ.get("ADV_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         # test hooks (a 1-GPU box cannot host two RCCL ranks): ADV_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and
         # ADV_BENCH_BACKEND=gloo swaps the backend, so the world > 1 code path can be smoke-tested anywhere
         share = os.environ.get("ADV_BENCH_SHARE_GPU") == "1"
@@ -308,7 +315,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             if dist.get_backend() == "gloo":
                 dist.barrier()
             else:
@@ -328,7 +335,7 @@ def main():
     use_index = (not srcnn) and (not args.no_clean_index)
     main_b = PgdBench(torch, ops, sp, x0, grad, valid, crop, use_index, (not args.alternate), affine=not srcnn)
     elapsed, kern_ms = main_b.timed(args.steps, args.warmup, fence)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -419,7 +426,7 @@ def main():
     # against the closed form, so the multi-GPU patch path runs on real links whenever the scaling bench does.
     # Never part of `value`.  If the collective stalls, the watchdog prints the throughput line with the error and the
     # process exits NON-ZERO, so that a launcher can tell a stall from success.
-    if world > 1:
+    if use_dist:
         import threading
 
         def bail():
@@ -455,7 +462,7 @@ def main():
             out["patch_allreduce"] = patch_comm
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -84,3 +84,17 @@ def test_patch_trainer_two_ranks_hip_ops_real_comm(tmp_path, average):
     assert np.abs(patch).max() > 0
     assert p[0].reshape(patch.shape).tobytes() == patch.tobytes()
     assert os.path.exists(os.path.join(str(tmp_path), "dsgn_patch_ratio_0.2", "epoch1", "patch.npy"))
+
+
+def test_bench_distributed_branch_over_rccl_with_one_rank():
+    """the RCCL ("nccl") branch of bench.py - process group on the GPU, barrier(device_ids), MAX-reduce of the time, the
+    patch-delta all-reduce probe - with a world of one rank (all a 1-GPU box can host; RCCL refuses two ranks per device)"""
+    env = dict(os.environ, PYTHONPATH=ROOT, ADV_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0",
+               WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--pairs", "8",
+                          "--no-cpu-baseline", "--no-end-to-end", "--no-srcnn", "--no-float-path"], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["value"] > 0
+    assert d["patch_allreduce"]["correct"] is True and "nccl" in d["patch_allreduce"]["collective"]
