@@ -184,14 +184,64 @@ class PsvStereoAdapter:
         u2 = F.relu(F.conv_transpose3d(u1, g["u2"], hb["u2"], stride=2, padding=1, output_padding=1) + s0)
         return F.conv3d(u2, self.c3, padding=1).squeeze(1)
 
-    def depth_pred(self, imgL, imgR):
+    def plane_prob(self, imgL, imgR):
         fl, fr = self.features(imgL), self.features(imgR)
         build = self.ops.PsvBuildLerp if self.interp else self.ops.PsvBuild
         cost = build.apply(fl.contiguous(), fr.contiguous(), self.shifts(imgL.shape[0]))
-        v = self._volume_net(cost)                                           # [B,D,h,w]
-        prob = torch.softmax(v, dim=1)
+        return torch.softmax(self._volume_net(cost), dim=1)                  # [B,D,h,w]
+
+    def depth_pred(self, imgL, imgR):
+        prob = self.plane_prob(imgL, imgR)
         depth = (prob * self.depth.view(1, -1, 1, 1)).sum(dim=1, keepdim=True)
         return F.interpolate(depth, scale_factor=self.downsample, mode="bilinear", align_corners=False).squeeze(1)
+
+    # -- a bird's-eye-view box head on the plane probabilities, for the detect-under-attack drivers --------------------
+    def _bev_weights(self):
+        if not hasattr(self, "_bev"):
+            gen = torch.Generator().manual_seed(4321)
+            w1 = (torch.randn(16, 1, 3, 3, generator=gen) * 0.6).to(self.device)
+            w2 = (torch.randn(9, 16, 3, 3, generator=gen) * 0.25).to(self.device)
+            self._bev = (w1, w2)
+        return self._bev
+
+    def detect(self, x, extra=None, topk=24, nms_thresh=0.25, cu=609.5593, cv=172.854):
+        """-> per stereo pair a list of (cls, bbox[4], score, center[3], (h, w, l, ry)) for ``DetectUnderAttack`` /
+        ``pixelio.write_kitti_labels``.  Plane probabilities -> occupancy over (depth plane, image column) -> a small 2D head
+        (score + box regression per cell) -> the ``topk`` cells by score -> greedy NMS on their bird's-eye-view footprints
+        (``ops.nms``, deterministic) -> 3D boxes and their projected 2D boxes.  Random weights: the boxes mean nothing, the
+        PIPELINE (attacked images -> detector -> label files -> scenario conversion) is what this exercises."""
+        import math
+        b = x.shape[0] // 2
+        with torch.no_grad():
+            prob = self.plane_prob(x[:b], x[b:])
+            w1, w2 = self._bev_weights()
+            bev = prob.amax(dim=2)                                           # [B,D,w]
+            out = F.conv2d(F.relu(F.conv2d(bev[:, None] * 8.0, w1, padding=1)), w2, padding=1)     # [B,9,D,w]
+            results = []
+            for i in range(b):
+                o = out[i]
+                score = torch.sigmoid(o[0]).reshape(-1)
+                top = torch.argsort(score, descending=True)[:topk]
+                di, ui = torch.div(top, o.shape[2], rounding_mode="floor"), top % o.shape[2]
+                reg = o[1:, di, ui]                                          # [8,K]
+                z = self.depth[di] + 0.4 * torch.tanh(reg[1])
+                u = (ui.float() + 0.5 + torch.tanh(reg[0])) * self.downsample
+                xc = (u - cu) * z / self.fu
+                hh, ww, ll = 1.5 + 0.2 * torch.tanh(reg[2]), 1.6 + 0.2 * torch.tanh(reg[3]), 3.9 + 0.5 * torch.tanh(reg[4])
+                ry = torch.atan2(reg[5], reg[6] + 1e-6)
+                yc = 1.0 + 0.3 * torch.tanh(reg[7])
+                foot = torch.stack([xc - ll / 2, z - ww / 2, xc + ll / 2, z + ww / 2], 1) * 10.0   # decimetres: "+1" IoU areas stay small
+                keep = self.ops.nms(foot.contiguous(), score[top].contiguous(), nms_thresh)
+                dets = []
+                for k in keep.tolist():
+                    cx_, cy_, cz_ = float(xc[k]), float(yc[k]), float(z[k])
+                    h_, w_, l_ = float(hh[k]), float(ww[k]), float(ll[k])
+                    us = [(cx_ + sx * l_ / 2) * self.fu / cz_ + cu for sx in (-1, 1)]
+                    vs = [(cy_ + sy * h_ / 2) * self.fu / cz_ + cv for sy in (-1, 1)]
+                    bbox = [min(us), min(vs), max(us), max(vs)]
+                    dets.append((2, bbox, float(score[top][k]), [cx_, cy_, cz_], (h_, w_, l_, float(ry[k]))))
+                results.append(dets)
+        return results
 
     def synthetic_extra(self, batch, seed=1):
         """a sparse synthetic depth map per pair (5 % of the pixels, 2 .. 40.4 m) for runs without a dataset"""

@@ -156,3 +156,30 @@ def run(args, rt, mode, dev):
             print("Median Error", all_err_med)
             f.write("Median Error: {}\n".format(all_err_med))
     return written, label_dir
+
+
+def run_shaped(args, mode, dev):
+    """``--model shaped``: the same file surface around the DSGN-shaped surrogate (adapters.PsvStereoAdapter.detect) - a PNG
+    folder in, ``<out_root>/kitti_output{tag}/NNNNNN.txt`` out - without an upstream checkout (no depth ground truth, so no
+    depth statistics)."""
+    from .. import adapters, data
+    if mode == "pgd" and args.alpha and args.iter:
+        args.tag += "_iter{0}_alpha{1}".format(str(args.iter), str(args.alpha))
+    if mode == "patch":
+        args.tag += "_ratio{0}_epochs{1}".format(args.ratio, args.epochs)
+    label_dir = os.path.join(args.out_root, "kitti_output" + args.tag)
+    if os.path.exists(label_dir):
+        shutil.rmtree(label_dir)
+    os.makedirs(label_dir)
+    patch = None
+    if mode == "patch":
+        _, _, host = load_patch_for_detection(args.patch_dir, args.ratio, args.epochs)
+        patch = torch.from_numpy(host).to(dev)
+    batch = args.btest if args.btest else 1
+    workers = args.loader_workers if args.loader_workers is not None else (0 if args.debug else 12)
+    loader = data.SyntheticStereo(args.synthetic, "dsgn", batch, seed=args.seed) if args.synthetic \
+        else data.KittiFolder(args.data_path, args.split_file, batch, workers=workers)
+    det = DetectUnderAttack("dsgn", mode, label_dir, patch=patch, atk_mode=getattr(args, "atk_mode", "random"), seed=args.pos_seed, device=dev)
+    n = det.run(loader, adapters.PsvStereoAdapter(dev, seed=args.seed, hourglass=True), debugnum=args.debugnum if args.debug else None)
+    print("wrote %d label files to %s" % (n, label_dir))
+    return n, label_dir

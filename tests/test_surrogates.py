@@ -118,3 +118,32 @@ def test_shaped_detectors_through_the_clis(tmp_path):
     a = np.array(Image.open(str(tmp_path / "dsgn_pgd_iters_0" / "image_3" / "000000.png")))
     b = np.array(Image.open(str(tmp_path / "dsgn_pgd_iters_2" / "image_3" / "000000.png")))
     assert a.shape == (375, 1242, 3) and 1 <= np.abs(a.astype(int) - b.astype(int)).max() <= 3
+
+
+def test_own_pipeline_attack_detect_labels_scenario(tmp_path):
+    """no upstream checkout anywhere: PNG folder -> dsgn_pgd_attack --model shaped -> dsgn_predict_and_save_pgd --model shaped on
+    the clean and on the attacked folder -> KITTI label files -> the consumer's parse (evaluation/convert_scenarios.py rules)"""
+    from PIL import Image
+    from eval_driving_safety_amd import pixelio
+    import synth
+    data_dir = tmp_path / "kitti"
+    for eye in ("image_2", "image_3"):
+        os.makedirs(str(data_dir / eye))
+    for i, name in enumerate(("000004", "000009")):
+        left = synth.u8_image(50 + i, 375, 1242)
+        Image.fromarray(left).save(str(data_dir / "image_2" / (name + ".png")))
+        Image.fromarray(np.roll(left, -20, axis=1)).save(str(data_dir / "image_3" / (name + ".png")))
+    (data_dir / "val.txt").write_text("000004\n000009\n")
+    common = ["--model", "shaped", "--split_file", str(data_dir / "val.txt"), "-btest", "1", "-d", "0", "--out_root", str(tmp_path)]
+    _run("dsgn_pgd_attack", common + ["--data_path", str(data_dir), "--iter", "3", "--eps", "0.03"], str(tmp_path))
+    attacked = tmp_path / "dsgn_pgd_iters_3"
+    assert sorted(os.listdir(str(attacked / "image_2"))) == ["000004.png", "000009.png"]
+    _run("dsgn_predict_and_save_pgd", common + ["--data_path", str(data_dir), "--tag", "_clean"], str(tmp_path))
+    _run("dsgn_predict_and_save_pgd", common + ["--data_path", str(attacked), "--iter", "3", "--alpha", "0.0039"], str(tmp_path))
+    for folder in ("kitti_output_clean", "kitti_output_iter3_alpha0.0039"):
+        files = sorted(os.listdir(str(tmp_path / folder)))
+        assert files == ["000004.txt", "000009.txt"], (folder, files)
+        label = pixelio.load_label(str(tmp_path / folder / "000004.txt"))
+        assert len(label) >= 1 and all(item[0] == "Car" and 2.0 <= item[6][2] <= 41.0 for item in label)
+        obstacles = pixelio.scenario_obstacles(label)
+        assert len(obstacles) == len(label) and all(o["length"] > 3.0 and o["width"] > 1.0 for o in obstacles)
