@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 #include "adv_internal.h"
 #include "advengine.h"
@@ -160,6 +161,7 @@ __global__ __launch_bounds__(256) void conv3d_k3_mfma_generic(const float* __res
 //   * the tap loop unrolled over kw so that LDS operand reads run ahead of the MFMAs that consume them.
 // ---------------------------------------------------------------------------------------------------------------
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef v4f v4f_u __attribute__((aligned(4)));  // a float4 the compiler may not assume 16-byte aligned
 
 constexpr int kFC = 4;      // input channels per stage of the main kernel
 constexpr int kP = 40;      // padded LDS row, interior at column 4
@@ -200,8 +202,18 @@ __device__ __forceinline__ void stage_fetch(Stage<TD>& st, const float* __restri
     const int dd = rem / (kTH + 2), hh = rem - dd * (kTH + 2);
     const int gd = d0 + dd - 1, gh = h0 + hh - 1, gw = w0 + 4 * j;
     v4f v = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
-    if (row < G::kRows && gd >= 0 && gd < D && gh >= 0 && gh < H && gw < W)
-      v = *reinterpret_cast<const v4f*>(x + (static_cast<long long>(b) * Cin + c0 + c) * vol + gd * plane + static_cast<long long>(gh) * W + gw);
+    if (row < G::kRows && gd >= 0 && gd < D && gh >= 0 && gh < H && gw < W) {
+      const float* src = x + (static_cast<long long>(b) * Cin + c0 + c) * vol + gd * plane + static_cast<long long>(gh) * W + gw;
+      if (gw + 3 < W) {
+        // W % 4 != 0: the row starts are only 4- or 8-byte aligned; global_load_dwordx4 takes dword-aligned addresses
+        // (unaligned access mode is the ROCm default), at the price of an extra cache line now and then
+        v = *reinterpret_cast<const v4f_u*>(src);
+      } else {  // the row ends inside this group: element by element, the rest stays zero (it belongs to the next row)
+        v.x = src[0];
+        if (gw + 1 < W) v.y = src[1];
+        if (gw + 2 < W) v.z = src[2];
+      }
+    }
     st.xi[p] = v;
   }
 #pragma unroll
@@ -394,7 +406,10 @@ static int launch_conv(const float* x, const float* w_prep, float* y, int b, int
   const int tiles_w = (gw + kTW - 1) / kTW, tiles_h = (gh + kTH - 1) / kTH;
   const int cblocks = (cout + 31) / 32;
   if (static_cast<long long>(b) * cblocks > 65535) return ADV_EINVAL;
-  const bool fast = stride == 1 && (w % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_prep)) & 15) == 0;
+  // the main kernel takes every width (rows that are not 16-byte aligned are loaded as dword-aligned float4);
+  // ADV_CONV_GENERIC=1 forces the scalar-staging kernel (kept as the reference implementation of the tiling)
+  const bool fast = stride == 1 && (reinterpret_cast<uintptr_t>(w_prep) & 15) == 0 && (reinterpret_cast<uintptr_t>(x) & 3) == 0 &&
+                    getenv("ADV_CONV_GENERIC") == nullptr;
   // tile depth 2 (4 waves) and 4 (8 waves, one workgroup per CU) measured the same within 1-2 % (profiles/r01_conv3d_mfma.jsonl)
   if (fast) {
     const dim3 grid(tiles_w * tiles_h, (d + 1) / 2, b * cblocks);

@@ -29,7 +29,7 @@ def test_oracle_conv_matches_torch_and_is_self_adjoint():
 
 
 SHAPES = [(1, 8, 5, 3, 6, 7), (2, 16, 32, 2, 8, 32), (1, 8, 33, 3, 9, 40), (1, 24, 64, 5, 10, 45), (1, 8, 1, 2, 3, 4),
-          (1, 4, 12, 3, 17, 36), (1, 12, 8, 4, 8, 64)]
+          (1, 4, 12, 3, 17, 36), (1, 12, 8, 4, 8, 64), (1, 8, 16, 5, 9, 78), (2, 4, 8, 3, 5, 33), (1, 4, 4, 2, 2, 1)]
 
 
 @pytest.mark.gpu
