@@ -115,3 +115,27 @@ def test_classifiers_run_on_the_gpu():
             opt.step()
             losses.append(float(loss))
         assert all(np.isfinite(losses))
+
+
+def test_classifier_cli_train_then_validate(tmp_path):
+    """`cli.classifier driving_constraint train` writes cnn_5.pth (every 5th epoch, train.py:109-118); `validate` loads it by key"""
+    import subprocess
+    import sys
+    from PIL import Image
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rs = np.random.RandomState(1)
+    os.makedirs(str(tmp_path / "data" / "image_2"))
+    rows = ["img_name,label"]
+    for i in range(4):
+        Image.fromarray(rs.randint(0, 255, (60, 90, 3)).astype(np.uint8)).save(str(tmp_path / "data" / "image_2" / ("%d.png" % i)))
+        rows.append("%d.png,%d" % (i, i % 2))
+    for name in ("training_csv.csv", "validation_csv.csv"):
+        (tmp_path / "data" / name).write_text("\n".join(rows) + "\n")
+    env = dict(os.environ, PYTHONPATH=root, OMP_NUM_THREADS="4")
+    run = lambda *a: subprocess.run([sys.executable, "-m", "eval_driving_safety_amd.cli.classifier"] + list(a), cwd=str(tmp_path), env=env,
+                                    stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    out = run("driving_constraint", "train", "--epochs", "5", "--device", "cpu")
+    assert out.returncode == 0, out.stdout[-2000:]
+    assert os.listdir(str(tmp_path / "model")) == ["cnn_5.pth"] and "warning: no --imagenet_weights" in out.stdout
+    out = run("driving_constraint", "validate", "--checkpoint", "model/cnn_5.pth", "--device", "cpu")
+    assert out.returncode == 0 and "Got " in out.stdout and "/ 4 with accuracy" in out.stdout, out.stdout[-2000:]
