@@ -60,7 +60,7 @@ def pick_device(devices, mem_info=None):
     if not torch.cuda.is_available():
         raise SystemExit("no ROCm device: this engine has no CPU path")
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        index = int(os.environ.get("LOCAL_RANK", "0"))
+        index = 0 if os.environ.get("ADV_SHARE_GPU") == "1" else int(os.environ.get("LOCAL_RANK", "0"))   # ADV_SHARE_GPU: 1-GPU test boxes
         resolved = str(index)
     else:
         resolved = resolve_devices(devices, mem_info or used_memory_per_gpu)

@@ -26,8 +26,8 @@ class Comm:
         if not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver
-            if backend is None:
-                backend = "nccl" if torch.cuda.is_available() else "gloo"
+            if backend is None:   # ADV_COMM_BACKEND=gloo: tests that put two ranks on ONE GPU (RCCL refuses that)
+                backend = os.environ.get("ADV_COMM_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
             kw = {}
             if backend == "nccl" and device is not None:
                 kw["device_id"] = device

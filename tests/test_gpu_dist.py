@@ -98,3 +98,25 @@ def test_bench_distributed_branch_over_rccl_with_one_rank():
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 1 and d["value"] > 0
     assert d["patch_allreduce"]["correct"] is True and "nccl" in d["patch_allreduce"]["collective"]
+
+
+def test_attack_clis_under_torchrun_two_ranks(tmp_path):
+    """the CLIs as `python -m torch.distributed.run --nproc-per-node 2 -m eval_driving_safety_amd.cli...`:
+    PGD shards the pairs by image with no collective, the patch trainer all-reduces its delta and rank 0 writes the patch"""
+    import numpy as np
+
+    def launch(mod, argv):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), "-m", "eval_driving_safety_amd.cli." + mod] + argv
+        e = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4", ADV_COMM_BACKEND="gloo", ADV_SHARE_GPU="1")
+        out = subprocess.run(cmd, cwd=str(tmp_path), env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+        assert out.returncode == 0, out.stdout[-3000:]
+        return out.stdout
+
+    out = launch("dsgn_pgd_attack", ["--model", "toy", "--synthetic", "5", "-btest", "1", "--iter", "2", "--eps", "0.03"])
+    assert "rank 0 attacked 3 stereo pairs" in out and "rank 1 attacked 2 stereo pairs" in out
+    for k in range(3):
+        assert sorted(os.listdir(str(tmp_path / ("dsgn_pgd_iters_%d" % k) / "image_2"))) == ["%06d.png" % i for i in range(5)]
+    out = launch("dsgn_patch_attack", ["--model", "toy", "--synthetic", "3", "-btest", "1", "--iter", "1", "--epochs", "1", "--pos_seed", "4"])
+    p = np.load(str(tmp_path / "dsgn_patch_ratio_0.2" / "epoch1" / "patch.npy"))
+    assert p.shape == (1, 3, 77, 77) and np.abs(p).max() > 0 and out.count("Average loss for epoch1") == 1
