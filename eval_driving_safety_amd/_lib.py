@@ -20,6 +20,7 @@ ADV_EALIGN = -14
 ADV_ELAUNCH = -5
 ADV_SPACE_AFFINE = 0
 ADV_SPACE_IDENTITY = 1
+ADV_SPACE_AFFINE_RCP = 2
 ABI_VERSION = 3
 
 
@@ -93,6 +94,7 @@ _OTHER = {
     "adv_strerror": ([_I], ctypes.c_char_p),
     "adv_space_dsgn": ([_SP], None),
     "adv_space_srcnn": ([_SP], None),
+    "adv_space_dsgn_gpu_reference": ([_SP], None),
 }
 EXPORTED = sorted(list(SIGNATURES) + list(_OTHER))
 

@@ -45,6 +45,8 @@ struct SpaceK {  // by-value kernel argument (lives in the kernarg segment -> sc
   float lo[3];
   float hi[3];
   double export_add[3];
+  float rcp[3];  // 1.0f / scale, float32
+  int use_rcp;   // ADV_SPACE_AFFINE_RCP: re-normalise with (y - shift) * rcp, as torch ON A GPU evaluates tensor / python_scalar
 };
 
 // ------------------------------------------------------------------------------------------
@@ -58,9 +60,16 @@ __device__ __forceinline__ float t_clamp(float x, float lo, float hi) {  // NaN 
   return x < lo ? lo : (x > hi ? hi : x);
 }
 
+// (y - shift) / scale: a true IEEE division (torch-CPU), or - uniform branch on a kernel argument - the multiplication by the
+// float32 reciprocal that torch's CUDA/ROCm kernels substitute when the divisor is a Python scalar
+__device__ __forceinline__ float renorm(float y, float sc, float sh, float rcp, int use_rcp) {
+  const float t = y - sh;
+  return use_rcp ? t * rcp : t / sc;
+}
+
 template <int KIND>
 __device__ __forceinline__ float pgd_elem(float x, float g, float cl, float sc, float sh, float lo,
-                                          float hi, float alpha, float eps) {
+                                          float hi, float alpha, float eps, float rcp = 0.0f, int use_rcp = 0) {
   float d = x;
   if (KIND == ADV_SPACE_AFFINE) {
     d = x * sc;
@@ -69,7 +78,7 @@ __device__ __forceinline__ float pgd_elem(float x, float g, float cl, float sc, 
   const float a = d + alpha * t_sign(g);
   const float eta = t_clamp(a - cl, -eps, eps);
   const float y = t_clamp(cl + eta, lo, hi);
-  if (KIND == ADV_SPACE_AFFINE) return (y - sh) / sc;
+  if (KIND == ADV_SPACE_AFFINE) return renorm(y, sc, sh, rcp, use_rcp);
   return y;
 }
 
@@ -227,7 +236,7 @@ __global__ __launch_bounds__(kWave) void pgd_step_vec4(const v4f* x, const v4f* 
           for (int c = 0; c < 3; ++c) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-              O[c][j] = pgd_elem<KIND>(X[u][c][j], G[u][c][j], C[u][c][j], sp.scale[c], sp.shift[c], sp.lo[c], sp.hi[c], alpha, eps);
+              O[c][j] = pgd_elem<KIND>(X[u][c][j], G[u][c][j], C[u][c][j], sp.scale[c], sp.shift[c], sp.lo[c], sp.hi[c], alpha, eps, sp.rcp[c], sp.use_rcp);
             st_stream(xo + plane0 + static_cast<long long>(c) * hw4 + q, O[c]);
           }
           store_u8_group<KIND, U8>(O, img, q, w, sp, u8);
@@ -254,7 +263,7 @@ __global__ __launch_bounds__(kWave) void pgd_step_vec4(const v4f* x, const v4f* 
 // workgroups or more than one trip per workgroup are 3-15 % slower.
 // ------------------------------------------------------------------------------------------
 template <int DIR>
-__device__ __forceinline__ float affine_elem(float x, float sc, float sh);
+__device__ __forceinline__ float affine_elem(float x, float sc, float sh, float rcp = 0.0f, int use_rcp = 0);
 
 __device__ __forceinline__ float clean_from_index(uint32_t v, float sc, float sh) {
   float t = static_cast<float>(v) / 255.0f;
@@ -332,7 +341,7 @@ __global__ __launch_bounds__(kWave) void pgd_step_vec4_idx(const v4f* x, const v
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-              O[c][j] = pgd_elem<ADV_SPACE_AFFINE>(X[u][c][j], G[u][c][j], C[u][c][j], sp.scale[c], sp.shift[c], sp.lo[c], sp.hi[c], alpha, eps);
+              O[c][j] = pgd_elem<ADV_SPACE_AFFINE>(X[u][c][j], G[u][c][j], C[u][c][j], sp.scale[c], sp.shift[c], sp.lo[c], sp.hi[c], alpha, eps, sp.rcp[c], sp.use_rcp);
             st_stream(xo + plane0 + static_cast<long long>(c) * hw4 + q, O[c]);
           }
           store_u8_group<ADV_SPACE_AFFINE, U8>(O, img, q, w, sp, u8);
@@ -480,7 +489,7 @@ __global__ __launch_bounds__(kShiftBlock) void pgd_step_shifted(const v4f* x, co
           v4f O;
 #pragma unroll
           for (int k = 0; k < 4; ++k)
-            O[k] = pgd_elem<KIND>(X[u][c][k], G[u][c][k], C[u][c][k], sp.scale[c], sp.shift[c], sp.lo[c], sp.hi[c], alpha, eps);
+            O[k] = pgd_elem<KIND>(X[u][c][k], G[u][c][k], C[u][c][k], sp.scale[c], sp.shift[c], sp.lo[c], sp.hi[c], alpha, eps, sp.rcp[c], sp.use_rcp);
           st_stream(xo + i, O);
           if (U8 != U8_NONE) {
             const uint32_t word = pack_channel4<KIND>(O, sp.scale[c], sp.shift[c], sp.export_add[c]);
@@ -537,7 +546,7 @@ __global__ __launch_bounds__(kBlock) void pgd_step_scalar(const float* __restric
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         const long long i = plane0 + static_cast<long long>(c) * hw + p;
-        o[c] = pgd_elem<KIND>(x[i], g[i], cl[i], sp.scale[c], sp.shift[c], sp.lo[c], sp.hi[c], alpha, eps);
+        o[c] = pgd_elem<KIND>(x[i], g[i], cl[i], sp.scale[c], sp.shift[c], sp.lo[c], sp.hi[c], alpha, eps, sp.rcp[c], sp.use_rcp);
       }
 #pragma unroll
       for (int c = 0; c < 3; ++c) xo[plane0 + static_cast<long long>(c) * hw + p] = o[c];
@@ -593,12 +602,12 @@ __global__ __launch_bounds__(kBlock) void export_u8_scalar(const float* __restri
 
 // a1 / a2: per-channel affine maps.  DIR 0: x*scale+shift, DIR 1: (x-shift)/scale
 template <int DIR>
-__device__ __forceinline__ float affine_elem(float x, float sc, float sh) {
+__device__ __forceinline__ float affine_elem(float x, float sc, float sh, float rcp, int use_rcp) {
   if (DIR == 0) {
     float d = x * sc;
     return d + sh;
   }
-  return (x - sh) / sc;
+  return renorm(x, sc, sh, rcp, use_rcp);
 }
 
 template <int DIR>
@@ -624,7 +633,7 @@ __global__ __launch_bounds__(kWave) void affine_vec4(const v4f* x, v4f* out, lon
           for (int c = 0; c < 3; ++c) {
             v4f o;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = affine_elem<DIR>(X[u][c][j], sp.scale[c], sp.shift[c]);
+            for (int j = 0; j < 4; ++j) o[j] = affine_elem<DIR>(X[u][c][j], sp.scale[c], sp.shift[c], sp.rcp[c], sp.use_rcp);
             st_stream(out + plane0 + static_cast<long long>(c) * hw4 + q, o);
           }
         }
@@ -641,7 +650,7 @@ __global__ __launch_bounds__(kBlock) void affine_scalar(const float* x, float* o
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         const long long i = plane0 + static_cast<long long>(c) * hw + p;
-        out[i] = affine_elem<DIR>(x[i], sp.scale[c], sp.shift[c]);
+        out[i] = affine_elem<DIR>(x[i], sp.scale[c], sp.shift[c], sp.rcp[c], sp.use_rcp);
       }
     }
   }
@@ -764,7 +773,12 @@ inline SpaceK to_kernel_space(const adv_space_t* s) {
     k.lo[c] = s->lo[c];
     k.hi[c] = s->hi[c];
     k.export_add[c] = s->export_add[c];
+    // torch's GPU division by a Python scalar b multiplies by float(1.0 / b) with the reciprocal taken in DOUBLE from the
+    // double b (measured on torch 2.10 + ROCm: float(1/0.224) = 4.46428585, whereas 1.0f / 0.224f = 4.46428537); for
+    // AFFINE_RCP spaces export_add[c] carries that double divisor
+    k.rcp[c] = s->kind == ADV_SPACE_AFFINE_RCP ? static_cast<float>(1.0 / s->export_add[c]) : 1.0f / s->scale[c];
   }
+  k.use_rcp = s->kind == ADV_SPACE_AFFINE_RCP ? 1 : 0;
   return k;
 }
 
@@ -816,9 +830,14 @@ inline int plan_u8(uint8_t* u8, int h, int w, int crop_h, int crop_w, long long 
   return ADV_OK;
 }
 
+inline bool is_affine(const adv_space_t* s) { return s->kind == ADV_SPACE_AFFINE || s->kind == ADV_SPACE_AFFINE_RCP; }
+
 inline int check_space(const adv_space_t* s) {
   if (s == nullptr) return ADV_EINVAL;
-  if (s->kind != ADV_SPACE_AFFINE && s->kind != ADV_SPACE_IDENTITY) return ADV_EINVAL;
+  if (s->kind != ADV_SPACE_AFFINE && s->kind != ADV_SPACE_IDENTITY && s->kind != ADV_SPACE_AFFINE_RCP) return ADV_EINVAL;
+  if (s->kind == ADV_SPACE_AFFINE_RCP)
+    for (int c = 0; c < 3; ++c)
+      if (!(s->export_add[c] > 0.0)) return ADV_EINVAL;  // the double divisor must be given
   return ADV_OK;
 }
 
@@ -928,6 +947,13 @@ void adv_space_dsgn(adv_space_t* s) {
   }
 }
 
+void adv_space_dsgn_gpu_reference(adv_space_t* s) {
+  const double stdv[3] = {0.229, 0.224, 0.225};
+  adv_space_dsgn(s);
+  s->kind = ADV_SPACE_AFFINE_RCP;
+  for (int c = 0; c < 3; ++c) s->export_add[c] = stdv[c];  // the divisor as the Python double the script divides by
+}
+
 void adv_space_srcnn(adv_space_t* s) {
   // attack/Stereo-RCNN/pgd_attack.py:189-207: min=(0 - m_c), max=(255 - m_c) as Python doubles
   const double m[3] = {102.9801, 115.9465, 122.7717};
@@ -954,7 +980,7 @@ static int launch_affine(int dir, const float* x, float* out, int64_t n, int h, 
   if (rc != ADV_OK) return rc;
   rc = check_space(space);
   if (rc != ADV_OK) return rc;
-  if (space->kind != ADV_SPACE_AFFINE) return ADV_EINVAL;
+  if (!is_affine(space)) return ADV_EINVAL;
   const long long hw = static_cast<long long>(h) * w;
   const bool vec = (hw % 4 == 0) && aligned(x, 16) && aligned(out, 16);
   const SpaceK sp = to_kernel_space(space);
@@ -999,7 +1025,7 @@ int adv_pgd_step_f32(const float* x, const float* grad, const float* clean, floa
   if (!(eps >= 0.0f)) return ADV_EINVAL;  // also rejects NaN
   const SpaceK sp = to_kernel_space(space);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (space->kind == ADV_SPACE_AFFINE)
+  if (is_affine(space))
     return launch_pgd<ADV_SPACE_AFFINE>(x, grad, clean, x_out, n, h, w, sp, alpha, eps, u8_out, crop_h, crop_w, u8_row_stride, u8_image_stride, st);
   return launch_pgd<ADV_SPACE_IDENTITY>(x, grad, clean, x_out, n, h, w, sp, alpha, eps, u8_out, crop_h, crop_w, u8_row_stride, u8_image_stride, st);
 }
@@ -1020,7 +1046,7 @@ int adv_clean_index_build_f32(const float* x, float* clean_out, const adv_clean_
   if (rc != ADV_OK) return rc;
   rc = check_space(space);
   if (rc != ADV_OK) return rc;
-  if (space->kind != ADV_SPACE_AFFINE) return ADV_EINVAL;
+  if (!is_affine(space)) return ADV_EINVAL;
   IdxK ik;
   rc = check_clean_index(ci, h, w, &ik);
   if (rc != ADV_OK) return rc;
@@ -1055,7 +1081,7 @@ int adv_pgd_step_indexed_f32(const float* x, const float* grad, const float* cle
   if (rc != ADV_OK) return rc;
   rc = check_space(space);
   if (rc != ADV_OK) return rc;
-  if (!(eps >= 0.0f) || space->kind != ADV_SPACE_AFFINE) return ADV_EINVAL;
+  if (!(eps >= 0.0f) || !is_affine(space)) return ADV_EINVAL;
   IdxK ik;
   rc = check_clean_index(ci, h, w, &ik);
   if (rc != ADV_OK) return rc;
@@ -1101,7 +1127,7 @@ int adv_export_u8_f32(const float* x, uint8_t* u8_out, int64_t n, int h, int w, 
     const dim3 grid = wave_grid(plan.mode == U8_ROWS_DWORD ? static_cast<long long>(crop_h) * w / 4 : hw4, nn, 1);
     const v4f* x4 = reinterpret_cast<const v4f*>(x);
     const bool rows = plan.mode == U8_ROWS_DWORD;
-    if (space->kind == ADV_SPACE_AFFINE) {
+    if (is_affine(space)) {
       if (rows) hipLaunchKernelGGL((export_u8_vec4<ADV_SPACE_AFFINE, U8_ROWS_DWORD>), grid, dim3(kWave), 0, st, x4, nn, hw4, w, sp, plan.dst);
       else hipLaunchKernelGGL((export_u8_vec4<ADV_SPACE_AFFINE, U8_FLAT_DWORD>), grid, dim3(kWave), 0, st, x4, nn, hw4, w, sp, plan.dst);
     } else {
@@ -1110,7 +1136,7 @@ int adv_export_u8_f32(const float* x, uint8_t* u8_out, int64_t n, int h, int w, 
     }
   } else {
     const dim3 grid = stream_grid(hw, nn);
-    if (space->kind == ADV_SPACE_AFFINE)
+    if (is_affine(space))
       hipLaunchKernelGGL((export_u8_scalar<ADV_SPACE_AFFINE>), grid, dim3(kBlock), 0, st, x, nn, static_cast<int>(hw), w, sp, plan.dst);
     else
       hipLaunchKernelGGL((export_u8_scalar<ADV_SPACE_IDENTITY>), grid, dim3(kBlock), 0, st, x, nn, static_cast<int>(hw), w, sp, plan.dst);

@@ -25,9 +25,14 @@ class Space:
         self.name = name
 
     @staticmethod
-    def dsgn():
-        """ImageNet-normalised RGB in [0,1]: attack/DSGN/pgd_attack.py:153-154,196-207,349-350."""
+    def dsgn(reference_on_gpu=False):
+        """ImageNet-normalised RGB in [0,1]: attack/DSGN/pgd_attack.py:153-154,196-207,349-350.
+        ``reference_on_gpu``: re-normalise with the float32 reciprocal, as torch's GPU kernels evaluate ``tensor / std[c]`` -
+        bit-identical to a GPU run of the reference script; the default is bit-identical to a CPU run."""
         s = AdvSpace()
+        if reference_on_gpu:
+            _lib.load().adv_space_dsgn_gpu_reference(ctypes.byref(s))
+            return Space(s, "dsgn_norm01_gpu_reference")
         _lib.load().adv_space_dsgn(ctypes.byref(s))
         return Space(s, "dsgn_norm01")
 
@@ -40,7 +45,7 @@ class Space:
 
     @property
     def affine(self):
-        return self.c.kind == _lib.ADV_SPACE_AFFINE
+        return self.c.kind in (_lib.ADV_SPACE_AFFINE, _lib.ADV_SPACE_AFFINE_RCP)
 
     @property
     def lo(self):

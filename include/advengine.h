@@ -45,7 +45,13 @@ typedef void* adv_stream_t; /* hipStream_t */
  *   ADV_SPACE_IDENTITY  stored = pixel, pixel in [lo, hi]
  *                       (Stereo R-CNN: BGR minus PIXEL_MEANS on the 0..255 scale;
  *                        attack/Stereo-RCNN/pgd_attack.py:189-207) */
-enum { ADV_SPACE_AFFINE = 0, ADV_SPACE_IDENTITY = 1 };
+/*   ADV_SPACE_AFFINE_RCP as AFFINE, but the re-normalisation is (pixel - shift) * (1.0f / scale): what torch's CUDA / ROCm
+ *                       kernels compute for `tensor / python_scalar`: a multiplication by float(1.0 / b), the reciprocal taken in
+ *                       double from the Python double b - export_add[c] must hold that double divisor (0.229, 0.224, 0.225).  The
+ *                       reference's scripts call normalize() on CUDA tensors (attack/DSGN/pgd_attack.py:203-207,353-354), so
+ *                       THIS kind reproduces a GPU run of the reference bit for bit, AFFINE a CPU run (the north_star's
+ *                       "reference CPU path"); the two stay within a few ulp of each other. */
+enum { ADV_SPACE_AFFINE = 0, ADV_SPACE_IDENTITY = 1, ADV_SPACE_AFFINE_RCP = 2 };
 
 typedef struct adv_space {
   int32_t kind;
@@ -59,6 +65,7 @@ typedef struct adv_space {
 
 /* Fill `s` with the reference's constants. */
 ADV_API void adv_space_dsgn(adv_space_t* s);  /* mean/std of attack/DSGN/pgd_attack.py:153-154, range [0,1] */
+ADV_API void adv_space_dsgn_gpu_reference(adv_space_t* s); /* the same constants, kind ADV_SPACE_AFFINE_RCP */
 ADV_API void adv_space_srcnn(adv_space_t* s); /* range [-m_c, 255-m_c], m = (102.9801,115.9465,122.7717) */
 
 ADV_API int adv_abi_version(void);

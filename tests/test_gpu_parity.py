@@ -653,3 +653,47 @@ def test_indexed_equals_float_path_at_bench_scale(ops):
         assert torch.equal(u8_i[:, :, :1242], u8_f[:, :, :1242]), "export %d" % (k + 1)
         want = O.pgd_step_norm01(want, grad_s, clean_s, 1 / 255, 0.03)
         same_bits(host(xi[sample]), want, "sampled images vs oracle, step %d" % (k + 1))
+
+
+def test_gpu_reference_numerics_match_torch_on_this_gpu(ops):
+    """Space.dsgn(reference_on_gpu=True): the reference's own formulation executed by torch ON THE GPU (where `tensor / std[c]`
+    becomes a multiplication by the float32 reciprocal) is reproduced bit for bit - float path and indexed path alike - while
+    the default space reproduces the CPU run (golden vectors) and stays within a few ulp of it"""
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    alpha, eps = 1.0 / 255, 0.03
+    x_np = np.concatenate([synth.dsgn_padded(61, 21, 37, 24, 40), synth.dsgn_padded(62, 21, 37, 24, 40)])
+    g = dev(synth.gradient(63, x_np.shape))
+
+    def denormalize(im):                      # attack/DSGN/pgd_attack.py:196-200, batch-correct
+        out = im.clone()
+        for c in range(3):
+            out[:, c] = out[:, c] * std[c] + mean[c]
+        return out
+
+    def normalize(im):                        # :203-207
+        out = im.clone()
+        for c in range(3):
+            out[:, c] = (out[:, c] - mean[c]) / std[c]
+        return out
+
+    sp_gpu, sp_cpu = ops.Space.dsgn(reference_on_gpu=True), ops.Space.dsgn()
+    x = dev(x_np)
+    clean_t = denormalize(x)
+    clean, ci = ops.denormalize_indexed(x, sp_gpu, valid=(21, 37))
+    assert torch.equal(clean, clean_t) and ci.verified() == [True, True]
+    cur_t, cur, cur_i, cur_c = x.clone(), x.clone(), x.clone(), x.clone()
+    differs = False
+    for k in range(4):
+        d = denormalize(cur_t)                                                   # :339-354 as torch-ROCm eager ops
+        adv = d + alpha * g.sign()
+        eta = torch.clamp(adv - clean_t, min=-eps, max=eps)
+        cur_t = normalize(torch.clamp(clean_t + eta, min=0, max=1)).detach()
+        cur = ops.pgd_step(cur, g, clean, sp_gpu, alpha, eps)
+        cur_i = ops.pgd_step(cur_i, g, clean, sp_gpu, alpha, eps, clean_index=ci)
+        assert torch.equal(cur, cur_t), "float path vs torch on the GPU, step %d" % (k + 1)
+        assert torch.equal(cur_i, cur_t), "indexed path vs torch on the GPU, step %d" % (k + 1)
+        cur_c = ops.pgd_step(cur_c, g, clean, sp_cpu, alpha, eps)
+        differs |= not torch.equal(cur_c, cur_t)
+        assert float((cur_c - cur_t).abs().max()) <= 2e-6                        # a few ulp: the iterate feeds back
+    assert differs, "the CPU-path and GPU-path re-normalisations should not be identical functions"
+    assert torch.equal(ops.normalize(clean, sp_gpu), normalize(clean_t))
