@@ -82,13 +82,16 @@ class PgdAttack:
     """
 
     def __init__(self, model_kind, alpha, eps, iters, out_root=".", save=True, save_every=1, writer_workers=None,
-                 ops=None, device=None, in_place=True):
+                 ops=None, device=None, in_place=True, reference_on_gpu=False):
         if writer_workers is None:                   # PNG (zlib) encoding is the I/O wall: 42 files per pair at N = 20
             writer_workers = min(16, max(4, (os.cpu_count() or 8) // 4))
         self.ops = ops if ops is not None else _default_ops()
         self.kind = model_kind
         if model_kind == "dsgn":
-            self.space, self.prefix, self.eps = self.ops.Space.dsgn(), "dsgn", float(eps)
+            # reference_on_gpu: reproduce a GPU run of the reference script bit for bit (torch's GPU kernels multiply by the
+            # reciprocal where the CPU ones divide); the default reproduces its CPU run (arithmetic contract)
+            self.space = self.ops.Space.dsgn(reference_on_gpu=True) if reference_on_gpu else self.ops.Space.dsgn()
+            self.prefix, self.eps = "dsgn", float(eps)
         elif model_kind == "srcnn":
             self.space, self.prefix, self.eps = self.ops.Space.srcnn(), "stereo_rcnn", 255 * float(eps)
         else:

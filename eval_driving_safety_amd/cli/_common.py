@@ -44,6 +44,9 @@ def add_engine_flags(parser):
     g.add_argument("--out_root", default=".", help="where the *_pgd_iters_k / *_patch_ratio_r / result_* folders go")
     g.add_argument("--save_every", type=int, default=1, help="write every k-th iterate (reference: every one)")
     g.add_argument("--pos_seed", type=int, default=None, help="seed of the patch-position stream (reference: unseeded)")
+    g.add_argument("--reference_on_gpu", action="store_true",
+                   help="DSGN PGD: re-normalise as torch's GPU kernels do (multiply by the reciprocal) - bit-identical to a GPU run of "
+                        "the reference script; default: bit-identical to its CPU run")
     g.add_argument("--loader_workers", type=int, default=None,
                    help="decode threads of the folder reader (default: the reference's 12, attack/DSGN/pgd_attack.py:79; 0 with --debug)")
 
