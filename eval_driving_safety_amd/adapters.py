@@ -120,7 +120,8 @@ class PsvStereoAdapter:
         if self.mfma_conv:
             self.p1, self.p1t = ops.conv3d_k3_prep(self.c1), ops.conv3d_k3_prep(self.c1, transpose=True)
             self.p2, self.p2t = ops.conv3d_k3_prep(self.c2), ops.conv3d_k3_prep(self.c2, transpose=True)
-            self.p3 = ops.conv3d_k3_prep(self.c3)     # 32 -> 1: forward on the kernel (padded to 32 rows), adjoint via torch
+            # 32 -> 1: the narrow vector-ALU kernels, forward (Cout = 1) and adjoint (Cin = 1)
+            self.p3, self.p3t = ops.conv3d_k3_prep(self.c3), ops.conv3d_k3_prep(self.c3, transpose=True)
         if hourglass:
             m2 = 2 * mid
             self.hg = {"d1": w(m2, mid, 3, 3, 3), "m1": w(m2, m2, 3, 3, 3), "d2": w(m2, m2, 3, 3, 3), "m2": w(m2, m2, 3, 3, 3),
@@ -156,7 +157,7 @@ class PsvStereoAdapter:
             if self.mfma_conv:
                 v = ops.Conv3dK3.apply(cost, self.p1, self.p1t, self.mid, None, None, True)
                 v = ops.Conv3dK3.apply(v, self.p2, self.p2t, self.mid, None, None, True)
-                return ops.Conv3dK3.apply(v, self.p3, None, 1, self.c3).squeeze(1)
+                return ops.Conv3dK3.apply(v, self.p3, self.p3t, 1).squeeze(1)
             v = F.relu(F.conv3d(cost, self.c1, padding=1))
             v = F.relu(F.conv3d(v, self.c2, padding=1))
             return F.conv3d(v, self.c3, padding=1).squeeze(1)
@@ -173,7 +174,7 @@ class PsvStereoAdapter:
             u1 = F.relu(u1 + s1)
             u2 = ops.ConvTranspose3dK3S2.apply(u1, hp["u2"][0], hp["u2"][1], self.mid, hb["u2"], False)
             u2 = F.relu(u2 + s0)
-            return ops.Conv3dK3.apply(u2, self.p3, None, 1, self.c3).squeeze(1)
+            return ops.Conv3dK3.apply(u2, self.p3, self.p3t, 1).squeeze(1)
         s0 = F.relu(F.conv3d(cost, self.c1, self.b1, padding=1))
         s0 = F.relu(F.conv3d(s0, self.c2, self.b2, padding=1))
         s1 = F.relu(F.conv3d(s0, g["d1"], hb["d1"], stride=2, padding=1))

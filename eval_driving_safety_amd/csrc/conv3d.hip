@@ -188,7 +188,7 @@ struct Stage {
   v4f wv[Geo<TD>::kWPass];
 };
 
-template <int TD>
+template <int TD, bool WEIGHTS = true>
 __device__ __forceinline__ void stage_fetch(Stage<TD>& st, const float* __restrict__ x, const float* __restrict__ wp, int tid, int b, int c0,
                                             int Cin, int cout_pad, int cob, int D, int H, int W, int d0, int h0, int w0,
                                             long long plane, long long vol) {
@@ -231,6 +231,7 @@ __device__ __forceinline__ void stage_fetch(Stage<TD>& st, const float* __restri
     }
     st.xh[p] = v;
   }
+  if (!WEIGHTS) return;
 #pragma unroll
   for (int p = 0; p < G::kWPass; ++p) {
     const int f = p * G::kThreads + tid;
@@ -243,7 +244,7 @@ __device__ __forceinline__ void stage_fetch(Stage<TD>& st, const float* __restri
   }
 }
 
-template <int TD>
+template <int TD, bool WEIGHTS = true>
 __device__ __forceinline__ void stage_commit(const Stage<TD>& st, float* sx, float* sw, int tid) {
   using G = Geo<TD>;
   const int j = tid & 7, r0 = tid >> 3;
@@ -257,6 +258,7 @@ __device__ __forceinline__ void stage_commit(const Stage<TD>& st, float* sx, flo
     const int s = p * G::kThreads + tid;
     if (s < 2 * G::kRows) sx[(s >> 1) * kP + ((s & 1) ? 4 + kTW : 3)] = st.xh[p];
   }
+  if (!WEIGHTS) return;
 #pragma unroll
   for (int p = 0; p < G::kWPass; ++p) {
     const int f = p * G::kThreads + tid;
@@ -342,6 +344,173 @@ __global__ __launch_bounds__(128 * TD, 2) void conv3d_k3_mfma(const float* __res
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Narrow layers on the vector ALUs.  The matrix kernel pads the output channels to 32 rows, so the LAST layer of a
+// cost-volume network (32 -> 1: per-plane scores) would spend 31/32 of its MFMA work on zeros, and its adjoint (1 -> 32,
+// Cin = 1) has K = 27: both are cheaper as plain fmaf chains.  Same accumulation order as the matrix kernel and the oracle
+// (stage of 4 channels, tap, channel), so the results are bit-identical to what the padded matrix kernel produces.
+//   narrow_out<CO>: Cout <= CO <= 8.  Input tile staged exactly as in the main kernel (two LDS stages); the stage's weights sit
+//                   beside it as [tap][o][4 channels], read with one broadcast ds_read_b128 per (tap, o) (scalar loads were
+//                   tried first: SMEM shares lgkmcnt with LDS and returns out of order, so every weight use drained the LDS
+//                   queue - 0.84 ms against 0.65 ms for the padded matrix kernel); a thread owns the two depth slices of one
+//                   (row, column) of the 2 x 8 x 32 tile and reuses every LDS operand for both.
+//   narrow_in<CI> : Cin = CI < 4.  One thread per voxel and 32 output channels in registers: per tap one cached global load of
+//                   the (small) input and 32 fmaf with the weights broadcast from LDS, then one coalesced store per output
+//                   channel.  HBM-bound on writing the Cout-channel result.
+// ---------------------------------------------------------------------------------------------------------------
+template <int CO>
+__global__ __launch_bounds__(256, 2) void conv3d_k3_narrow_out(const float* __restrict__ x, const float* __restrict__ wp, float* __restrict__ y,
+                                                               int Cin, int Cout, int cout_pad, int D, int H, int W, int tiles_w, Epi epi) {
+  using G = Geo<2>;
+  constexpr int kNW = 27 * kFC * CO;                 // weights per stage, LDS layout [tap][o][c]: one ds_read_b128 = the 4 channels
+  constexpr int kWPer = (kNW + 255) / 256;
+  constexpr int kStage = G::kSX + kNW;
+  constexpr int kUnrollDD = 1;   // a runtime loop over the four input depth slices keeps the hoisted LDS reads inside the register budget
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, th = tid >> 5, l32 = tid & 31;
+  const int wt = blockIdx.x % tiles_w, ht = blockIdx.x / tiles_w;
+  const int w0 = wt * kTW, h0 = ht * kTH, d0 = blockIdx.y * 2;
+  const int b = blockIdx.z;
+  const long long plane = static_cast<long long>(H) * W;
+  const long long vol = plane * D;
+  float acc0[CO], acc1[CO];
+#pragma unroll
+  for (int o = 0; o < CO; ++o) acc0[o] = 0.0f, acc1[o] = 0.0f;
+  Stage<2> st;
+  float wn[kWPer];
+  auto fetch_w = [&](int c0) {
+#pragma unroll
+    for (int p = 0; p < kWPer; ++p) {
+      const int f = p * 256 + tid;                   // f = (tap*CO + o)*4 + c
+      const int c = f & 3, o = (f >> 2) % CO, tap = f / (4 * CO);
+      wn[p] = f < kNW ? wp[(static_cast<long long>(tap) * Cin + c0 + c) * cout_pad + o] : 0.0f;
+    }
+  };
+  auto commit_w = [&](float* sw) {
+#pragma unroll
+    for (int p = 0; p < kWPer; ++p) {
+      const int f = p * 256 + tid;
+      if (f < kNW) sw[f] = wn[p];
+    }
+  };
+  stage_fetch<2, false>(st, x, wp, tid, b, 0, Cin, cout_pad, 0, D, H, W, d0, h0, w0, plane, vol);
+  fetch_w(0);
+  stage_commit<2, false>(st, lds, nullptr, tid);
+  commit_w(lds + G::kSX);
+  __syncthreads();
+  int cur = 0;
+  for (int c0 = 0; c0 < Cin; c0 += kFC) {
+    const bool more = c0 + kFC < Cin;
+    const float* sxc = lds + cur * kStage;
+    const float* swc = sxc + G::kSX;
+    if (more) {
+      stage_fetch<2, false>(st, x, wp, tid, b, c0 + kFC, Cin, cout_pad, 0, D, H, W, d0, h0, w0, plane, vol);
+      fetch_w(c0 + kFC);
+    }
+#pragma unroll kUnrollDD
+    for (int dd = 0; dd < 4; ++dd)
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          float v[kFC];
+#pragma unroll
+          for (int c = 0; c < kFC; ++c) v[c] = sxc[((c * 4 + dd) * (kTH + 2) + th + kh) * kP + l32 + kw + 3];
+          if (dd < 3) {
+#pragma unroll
+            for (int o = 0; o < CO; ++o) {
+              const v4f w4 = *reinterpret_cast<const v4f*>(swc + ((dd * 9 + kh * 3 + kw) * CO + o) * 4);  // one address for the wave: LDS broadcast
+              acc0[o] = __builtin_fmaf(w4.x, v[0], acc0[o]);
+              acc0[o] = __builtin_fmaf(w4.y, v[1], acc0[o]);
+              acc0[o] = __builtin_fmaf(w4.z, v[2], acc0[o]);
+              acc0[o] = __builtin_fmaf(w4.w, v[3], acc0[o]);
+            }
+          }
+          if (dd > 0) {
+#pragma unroll
+            for (int o = 0; o < CO; ++o) {
+              const v4f w4 = *reinterpret_cast<const v4f*>(swc + (((dd - 1) * 9 + kh * 3 + kw) * CO + o) * 4);
+              acc1[o] = __builtin_fmaf(w4.x, v[0], acc1[o]);
+              acc1[o] = __builtin_fmaf(w4.y, v[1], acc1[o]);
+              acc1[o] = __builtin_fmaf(w4.z, v[2], acc1[o]);
+              acc1[o] = __builtin_fmaf(w4.w, v[3], acc1[o]);
+            }
+          }
+        }
+    if (more) {
+      float* nx = lds + (cur ^ 1) * kStage;
+      stage_commit<2, false>(st, nx, nullptr, tid);
+      commit_w(nx + G::kSX);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  const int gh = h0 + th, gw = w0 + l32;
+  if (gh >= H || gw >= W) return;
+#pragma unroll
+  for (int o = 0; o < CO; ++o) {
+    if (o < Cout && d0 < D) epi_store(epi, y, b, Cout, o, d0, gh, gw, acc0[o]);
+    if (o < Cout && d0 + 1 < D) epi_store(epi, y, b, Cout, o, d0 + 1, gh, gw, acc1[o]);
+  }
+}
+
+template <int CI>
+__global__ __launch_bounds__(256, CI == 1 ? 4 : 2) void conv3d_k3_narrow_in(const float* __restrict__ x, const float* __restrict__ wp, float* __restrict__ y,
+                                                              int Cout, int cout_pad, int D, int H, int W, long long voxels, Epi epi) {
+  __shared__ __attribute__((aligned(16))) float sw[27 * CI * 32];  // one block of 32 output channels: [tap][c][32]
+  constexpr int kUnrollKW = CI == 1 ? 3 : 1;  // more than one channel: keep the hoisted weight reads inside the register budget
+  const long long i = blockIdx.x * 256LL + threadIdx.x;
+  const int b = blockIdx.y;
+  const bool live = i < voxels;
+  const int gw = static_cast<int>(i % W);
+  const int gh = static_cast<int>((i / W) % H);
+  const int gd = static_cast<int>(i / (static_cast<long long>(W) * H));
+  const long long plane = static_cast<long long>(H) * W;
+  const float* xb = x + static_cast<long long>(b) * CI * D * plane;
+#pragma unroll 1
+  for (int cb = 0; cb < cout_pad; cb += 32) {
+    __syncthreads();
+    for (int f = threadIdx.x; f < 27 * CI * 8; f += 256)
+      *reinterpret_cast<v4f*>(sw + 4 * f) = *reinterpret_cast<const v4f*>(wp + static_cast<long long>(f >> 3) * cout_pad + cb + 4 * (f & 7));
+    __syncthreads();
+    float acc[32];
+#pragma unroll
+    for (int o = 0; o < 32; ++o) acc[o] = 0.0f;
+#pragma unroll 1
+    for (int kd = 0; kd < 3; ++kd)
+#pragma unroll 1
+      for (int kh = 0; kh < 3; ++kh) {
+        const int zd = gd + kd - 1, zh = gh + kh - 1;
+        const bool row = live && zd >= 0 && zd < D && zh >= 0 && zh < H;
+        const float* xr = xb + zd * plane + static_cast<long long>(zh) * W;
+#pragma unroll kUnrollKW
+        for (int kw = 0; kw < 3; ++kw) {
+          const int zw = gw + kw - 1;
+          const bool in = row && zw >= 0 && zw < W;
+#pragma unroll
+          for (int c = 0; c < CI; ++c) {
+            const float v = in ? xr[c * D * plane + zw] : 0.0f;
+            const float* wk = sw + (((kd * 3 + kh) * 3 + kw) * CI + c) * 32;  // the same address in every lane: LDS broadcast
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              const v4f w4 = *reinterpret_cast<const v4f*>(wk + 4 * q);
+              acc[4 * q + 0] = __builtin_fmaf(w4.x, v, acc[4 * q + 0]);
+              acc[4 * q + 1] = __builtin_fmaf(w4.y, v, acc[4 * q + 1]);
+              acc[4 * q + 2] = __builtin_fmaf(w4.z, v, acc[4 * q + 2]);
+              acc[4 * q + 3] = __builtin_fmaf(w4.w, v, acc[4 * q + 3]);
+            }
+          }
+        }
+      }
+    if (live) {
+#pragma unroll
+      for (int o = 0; o < 32; ++o)
+        if (cb + o < Cout) epi_store(epi, y, b, Cout, cb + o, gd, gh, gw, acc[o]);
+    }
+  }
+}
+
 // xs[b, p*C + c, jd, jh, jw] = x[b, c, 2jd+pd, 2jh+ph, 2jw+pw], p = (pd*2+ph)*2+pw, zero beyond the input: the eight parity
 // sub-volumes of x side by side in the channel dimension.  A stride-2 3x3x3 convolution of x is then a stride-1 convolution
 // of xs in which sub-volume p uses only the taps its parity allows (27 taps over the eight classes - no wasted MFMA work),
@@ -406,6 +575,32 @@ static int launch_conv(const float* x, const float* w_prep, float* y, int b, int
   const int tiles_w = (gw + kTW - 1) / kTW, tiles_h = (gh + kTH - 1) / kTH;
   const int cblocks = (cout + 31) / 32;
   if (static_cast<long long>(b) * cblocks > 65535) return ADV_EINVAL;
+  const bool plain = stride == 1 && epi.tap_mask == kAllTaps && epi.class_channels == 0;
+  const bool narrow_ok = getenv("ADV_CONV_NO_NARROW") == nullptr;  // test hook: the padded matrix kernel instead
+  if (cin < kCK) {  // 1..3 input channels (the adjoint of a layer with 1..3 outputs): vector-ALU kernel, HBM-bound on the result
+    if (!plain) return ADV_EINVAL;
+    const long long voxels = static_cast<long long>(d) * h * w;
+    const dim3 grid(static_cast<unsigned>((voxels + 255) / 256), b);
+    if (cin == 1)
+      hipLaunchKernelGGL((conv3d_k3_narrow_in<1>), grid, dim3(256), 0, st, x, w_prep, y, cout, cblocks * 32, d, h, w, voxels, epi);
+    else if (cin == 2)
+      hipLaunchKernelGGL((conv3d_k3_narrow_in<2>), grid, dim3(256), 0, st, x, w_prep, y, cout, cblocks * 32, d, h, w, voxels, epi);
+    else
+      hipLaunchKernelGGL((conv3d_k3_narrow_in<3>), grid, dim3(256), 0, st, x, w_prep, y, cout, cblocks * 32, d, h, w, voxels, epi);
+    return adv_internal_finish_launch();
+  }
+  if (plain && cout <= 8 && narrow_ok && (reinterpret_cast<uintptr_t>(x) & 3) == 0) {
+    const dim3 grid(tiles_w * tiles_h, (d + 1) / 2, b);
+    const int co_t = cout == 1 ? 1 : (cout <= 4 ? 4 : 8);
+    const size_t lds = 2 * static_cast<size_t>(Geo<2>::kSX + 27 * kFC * co_t) * sizeof(float);
+    if (cout == 1)
+      hipLaunchKernelGGL((conv3d_k3_narrow_out<1>), grid, dim3(256), lds, st, x, w_prep, y, cin, cout, cblocks * 32, d, h, w, tiles_w, epi);
+    else if (cout <= 4)
+      hipLaunchKernelGGL((conv3d_k3_narrow_out<4>), grid, dim3(256), lds, st, x, w_prep, y, cin, cout, cblocks * 32, d, h, w, tiles_w, epi);
+    else
+      hipLaunchKernelGGL((conv3d_k3_narrow_out<8>), grid, dim3(256), lds, st, x, w_prep, y, cin, cout, cblocks * 32, d, h, w, tiles_w, epi);
+    return adv_internal_finish_launch();
+  }
   // the main kernel takes every width (rows that are not 16-byte aligned are loaded as dword-aligned float4);
   // ADV_CONV_GENERIC=1 forces the scalar-staging kernel (kept as the reference implementation of the tiling)
   const bool fast = stride == 1 && (reinterpret_cast<uintptr_t>(w_prep) & 15) == 0 && (reinterpret_cast<uintptr_t>(x) & 3) == 0 &&
@@ -441,7 +636,7 @@ static int launch_conv(const float* x, const float* w_prep, float* y, int b, int
 int adv_conv3d_k3_f32(const float* x, const float* w_prep, float* y, int b, int cin, int cout, int d, int h, int w, int relu,
                       adv_stream_t stream) {
   if (!x || !w_prep || !y || b < 1 || cin < 1 || cout < 1 || d < 1 || h < 1 || w < 1) return ADV_EINVAL;
-  if (cin % kCK != 0) return ADV_EINVAL;
+  if (cin % kCK != 0 && cin > kCK) return ADV_EINVAL;
   const Epi epi{nullptr, relu, kAllTaps, {0, 0, 0, 0, 0, 0, 0, 0}, 0, d, h, w, 1, 1, 1, 0, 0, 0};
   return launch_conv(x, w_prep, y, b, cin, cout, d, h, w, 1, epi, static_cast<hipStream_t>(stream));
 }
@@ -461,7 +656,7 @@ int adv_conv3d_k3_ex_f32(const float* x, const float* w_prep, const float* bias,
                          int stride, int relu, uint32_t tap_mask, const uint32_t* class_masks, int class_channels, const int32_t* out_dims,
                          const int32_t* out_stride, const int32_t* out_offset, adv_stream_t stream) {
   if (!x || !w_prep || !y || b < 1 || cin < 1 || cout < 1 || d < 1 || h < 1 || w < 1) return ADV_EINVAL;
-  if (cin % kCK != 0 || (stride != 1 && stride != 2) || (tap_mask & ~kAllTaps)) return ADV_EINVAL;
+  if ((cin % kCK != 0 && cin > kCK) || (stride != 1 && stride != 2) || (tap_mask & ~kAllTaps)) return ADV_EINVAL;
   if ((out_dims == nullptr) != (out_stride == nullptr) || (out_dims == nullptr) != (out_offset == nullptr)) return ADV_EINVAL;
   const int gd = stride == 2 ? (d + 1) / 2 : d, gh = stride == 2 ? (h + 1) / 2 : h, gw = stride == 2 ? (w + 1) / 2 : w;
   Epi epi{bias, relu, tap_mask, {0, 0, 0, 0, 0, 0, 0, 0}, 0, gd, gh, gw, 1, 1, 1, 0, 0, 0};

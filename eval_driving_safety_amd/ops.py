@@ -696,8 +696,8 @@ def conv_transpose3d_k3_s2(x, classes, cout, relu=False, bias=None):
 
 class Conv3dK3(torch.autograd.Function):
     """y = [relu](conv3d(x, weight) [+ bias]); gradient flows to x only (the attacks differentiate w.r.t. the images, the
-    detector's weights are constants), through the same kernel with the transposed / flipped weights.  When the adjoint
-    does not fit the kernel (its input channel count = cout is not a multiple of 4, e.g. a 32->1 layer) pass
+    detector's weights are constants), through the same kernel family with the transposed / flipped weights (cout a
+    multiple of 4 -> the matrix kernel, cout 1..3 -> the narrow vector-ALU kernel).  Any other cout: pass
     ``w_prep_t=None`` and the original ``weight``: the backward then uses torch's conv3d_input.  With ``relu`` the
     activation is fused into the forward's epilogue and its mask is applied to the incoming gradient."""
 

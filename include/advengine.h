@@ -277,8 +277,10 @@ ADV_API int adv_conv3d_k3_prep_weights_f32(const float* w, float* w_prep, int co
                                            adv_stream_t stream);
 
 /* y [B,Cout,D,H,W] = conv3d(x [B,Cin,D,H,W], w_prep), stride 1, zero padding 1; relu != 0 fuses max(y, 0).
- *     Cin must be a multiple of 4.  Implicit GEMM on v_mfma_f32_32x32x2_f32: M = 32 output channels, N = 32
- *     consecutive voxels along W, K = (input channel, tap); input tile + halo and the weights staged in LDS. */
+ *     Cin must be a multiple of 4, or 1..3.  Implicit GEMM on v_mfma_f32_32x32x2_f32: M = 32 output channels, N = 32
+ *     consecutive voxels along W, K = (input channel, tap); input tile + halo and the weights staged in LDS.
+ *     Narrow layers leave the matrix cores: cout <= 8 (a network's last "score" layer, 32 -> 1) and cin <= 3 (its adjoint)
+ *     run as fmaf chains on the vector ALUs in the SAME accumulation order - bit-identical to the padded matrix kernel. */
 ADV_API int adv_conv3d_k3_f32(const float* x, const float* w_prep, float* y, int b, int cin, int cout, int d, int h,
                               int w, int relu, adv_stream_t stream);
 

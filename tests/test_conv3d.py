@@ -45,7 +45,7 @@ def test_hip_conv3d_bit_exact_vs_oracle(shape):
     want = C.conv3d_k3(x, wt)
     assert y.cpu().numpy().tobytes() == want.tobytes(), "forward"
     assert ops.conv3d_k3(tx, wp, cout, relu=True).cpu().numpy().tobytes() == np.maximum(want, 0).tobytes(), "relu"
-    if cout % 4 == 0:                                   # the adjoint needs Cin' = cout to be a multiple of 4
+    if cout % 4 == 0 or cout < 4:                       # the adjoint needs Cin' = cout to be a multiple of 4, or 1..3
         g = np.random.RandomState(3).randn(*want.shape).astype(np.float32)
         wpt = ops.conv3d_k3_prep(tw, transpose=True)
         gx = ops.conv3d_k3(torch.tensor(g, device=dev), wpt, cin)
@@ -89,6 +89,56 @@ def test_hip_conv3d_single_output_channel_with_torch_adjoint():
     assert y.detach().cpu().numpy().tobytes() == C.conv3d_k3(x.cpu().numpy(), wt.cpu().numpy()).tobytes()
     assert float((y - ref).abs().max()) <= 1e-4 * float(ref.detach().abs().max())
     assert float((xm.grad - xr.grad).abs().max()) <= 1e-4 * float(xr.grad.abs().max())
+
+
+NARROW = [(1, 32, 1, 6, 24, 40), (2, 8, 1, 3, 9, 33), (1, 12, 3, 4, 8, 78), (1, 8, 8, 5, 10, 45), (1, 16, 5, 2, 17, 36), (1, 4, 2, 1, 1, 1)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", NARROW)
+def test_hip_narrow_layers_bit_exact_vs_oracle_and_vs_padded_matrix_kernel(shape, monkeypatch):
+    """Cout <= 8 runs on the vector ALUs (narrow_out), its adjoint with 1..3 input channels too (narrow_in): the same bits as the
+    oracle's fmaf chain AND as the matrix kernel that pads the channels to 32 rows (ADV_CONV_NO_NARROW=1)."""
+    from eval_driving_safety_amd import ops
+    b, cin, cout, d, h, w = shape
+    x, wt = _case(*shape, seed=sum(shape) + 7)
+    dev = torch.device("cuda", 0)
+    tx, tw = torch.tensor(x, device=dev), torch.tensor(wt, device=dev)
+    wp = ops.conv3d_k3_prep(tw)
+    bias = torch.linspace(-0.3, 0.4, cout, device=dev)
+    y = ops.conv3d_k3(tx, wp, cout)
+    yb = ops.conv3d_k3(tx, wp, cout, relu=True, bias=bias)
+    want = C.conv3d_k3(x, wt)
+    assert y.cpu().numpy().tobytes() == want.tobytes(), "narrow forward vs oracle"
+    assert yb.cpu().numpy().tobytes() == C.conv3d_k3_ex(x, wt, bias=bias.cpu().numpy(), relu=True).tobytes(), "bias + relu"
+    monkeypatch.setenv("ADV_CONV_NO_NARROW", "1")
+    assert torch.equal(ops.conv3d_k3(tx, wp, cout), y), "narrow forward vs the padded matrix kernel"
+    monkeypatch.delenv("ADV_CONV_NO_NARROW")
+    if cout < 4:
+        g = np.random.RandomState(5).randn(*want.shape).astype(np.float32)
+        wpt = ops.conv3d_k3_prep(tw, transpose=True)
+        gx = ops.conv3d_k3(torch.tensor(g, device=dev), wpt, cin)
+        assert gx.cpu().numpy().tobytes() == C.conv3d_k3(g, wt, transpose=True).tobytes(), "narrow adjoint vs oracle"
+
+
+@pytest.mark.gpu
+def test_hip_single_output_layer_autograd_on_the_narrow_kernels():
+    """32 -> 1 (the per-plane score layer of a cost-volume network) forward AND backward on libadvengine, against torch"""
+    from eval_driving_safety_amd import ops
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(2)
+    x = torch.randn((2, 32, 6, 24, 78), device=dev, generator=gen)
+    wt = torch.randn((1, 32, 3, 3, 3), device=dev, generator=gen) * 0.05
+    xr = x.clone().requires_grad_(True)
+    ref = F.conv3d(xr, wt, padding=1)
+    g = torch.randn(ref.shape, device=dev, generator=gen)
+    ref.backward(g)
+    xm = x.clone().requires_grad_(True)
+    y = ops.Conv3dK3.apply(xm, ops.conv3d_k3_prep(wt), ops.conv3d_k3_prep(wt, transpose=True), 1)
+    y.backward(g)
+    assert float((y - ref).abs().max()) <= 1e-4 * float(ref.detach().abs().max())
+    assert float((xm.grad - xr.grad).abs().max()) <= 1e-4 * float(xr.grad.abs().max())
+    assert xm.grad.cpu().numpy().tobytes() == C.conv3d_k3(g.cpu().numpy(), wt.cpu().numpy(), transpose=True).tobytes()
 
 
 # ------------------------------------------------------------------------------------------ hourglass layers

@@ -66,7 +66,7 @@ def measure(pairs=1, iters=20, reps=2, warm_iters=None, mfma_conv=True, hourglas
         "value": pairs / dt, "unit": "stereo-pairs/s", "pairs": pairs, "iters": iters,
         "s_per_attack": dt, "detector_fwd_bwd_ms": model_ms,
         "loss_first_iter": first, "loss_last_iter": last, "loss_rose": last > first, "roofline": mfma,
-        "convs": ("libadvengine float32-MFMA conv3d (all 3D layers; the adjoint of the last 32->1 layer through torch)" if mfma_conv else "torch / MIOpen"),
+        "convs": ("libadvengine float32-MFMA conv3d (all 3D layers, forward and adjoint; the 32->1 score layer on the narrow vector-ALU kernels)" if mfma_conv else "torch / MIOpen"),
         "volume_net": ("3D hourglass: 64->32, 32->32, 32->64 /2, 64->64, 64->64 /2, 64->64, transposed 64->64 + skip, transposed 64->32 + skip, 32->1"
                        if hourglass else "three convolutions 64->32->32->1"),
         "note": "NOT the headline metric and NOT DSGN: 2D features -> HIP plane-sweep volume [B,64,48,96,312] (fractional disparities) -> "

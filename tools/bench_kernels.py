@@ -137,9 +137,37 @@ def conv(dev):
                           speedup_vs_miopen=round(ms_t / ms, 2))))
 
 
+def conv_narrow(dev):
+    """the 32 -> 1 score layer and its adjoint: narrow vector-ALU kernels vs the padded matrix kernel vs torch / MIOpen"""
+    import os
+    import torch.nn.functional as F
+    D, H, W = 48, 96, 312
+    x = torch.randn((1, 32, D, H, W), device=dev)
+    wt = torch.randn((1, 32, 3, 3, 3), device=dev) * 0.05
+    wp, wpt = ops.conv3d_k3_prep(wt), ops.conv3d_k3_prep(wt, transpose=True)
+    ms = timeit(lambda: ops.conv3d_k3(x, wp, 1), reps=10)
+    os.environ["ADV_CONV_NO_NARROW"] = "1"
+    ms_pad = timeit(lambda: ops.conv3d_k3(x, wp, 1), reps=10)
+    del os.environ["ADV_CONV_NO_NARROW"]
+    F.conv3d(x, wt, padding=1)
+    ms_t = timeit(lambda: F.conv3d(x, wt, padding=1), reps=10)
+    nbytes = x.numel() * 4 + D * H * W * 4
+    print(json.dumps(dict(kernel="conv3d_k3 32->1 narrow_out<1> on [1,32,%d,%d,%d]" % (D, H, W), ms=round(ms, 3), GBps=round(nbytes / ms / 1e6, 1),
+                          frac_of_8TBps=round(nbytes / ms / 1e6 / 8000, 3), padded_matrix_kernel_ms=round(ms_pad, 3), torch_miopen_ms=round(ms_t, 3))))
+    g = torch.randn((1, 1, D, H, W), device=dev)
+    ms = timeit(lambda: ops.conv3d_k3(g, wpt, 32), reps=10)
+    torch.nn.grad.conv3d_input(x.shape, wt, g, padding=1)
+    ms_t = timeit(lambda: torch.nn.grad.conv3d_input(x.shape, wt, g, padding=1), reps=10)
+    print(json.dumps(dict(kernel="conv3d_k3 adjoint 1->32 narrow_in<1> on [1,1,%d,%d,%d]" % (D, H, W), ms=round(ms, 3), GBps=round(nbytes / ms / 1e6, 1),
+                          frac_of_8TBps=round(nbytes / ms / 1e6 / 8000, 3), torch_miopen_ms=round(ms_t, 3))))
+
+
 def main():
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
+    if "--conv-narrow" in sys.argv:
+        conv_narrow(dev)
+        return
     if "--conv" in sys.argv:
         conv(dev)
         return
