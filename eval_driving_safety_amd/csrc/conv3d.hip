@@ -156,8 +156,9 @@ __global__ __launch_bounds__(256) void conv3d_k3_mfma_generic(const float* __res
 //   * 16-byte global loads and ds_write_b128 for the interior of the input tile (the LDS row is laid out so that the
 //     interior starts 16-byte aligned: [3 pad | left halo | 32 interior | right halo | 3 pad]), scalars only for
 //     the two halo columns;
-//   * the NEXT chunk's input tile and weights fetched into registers before the MFMA loop of the current chunk and
-//     written to LDS after it (global latency hidden behind ~27k cycles of matrix work per chunk);
+//   * the NEXT chunk's input tile and weights fetched into registers before the MFMA loop of the current chunk (a dozen
+//     unconditional loads at offsets precomputed once per tile - struct Plan) and written to the other LDS buffer two thirds
+//     of the way through it (global latency and the LDS stores hidden behind ~27k cycles of matrix work per chunk);
 //   * the tap loop unrolled over kw so that LDS operand reads run ahead of the MFMAs that consume them.
 // ---------------------------------------------------------------------------------------------------------------
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -188,81 +189,109 @@ struct Stage {
   v4f wv[Geo<TD>::kWPass];
 };
 
+// What a lane fetches for every stage, worked out ONCE per tile: only the channel base moves from stage to stage, so the
+// per-stage fetch is a handful of unconditional loads at precomputed offsets (no index arithmetic, no branches - the compiler
+// is free to sink them into the MFMA stream), and everything conditional (zero padding, rows that end inside a float4) is a
+// select at commit time, when the data has long arrived.
+//   xo[p]   element offset of the float4 of tile row p*kRowsPerPass + tid/8, columns 4*(tid%8) .. +3, relative to the stage's
+//           first channel; clamped so that the 16 bytes never leave the row (a row that ends inside the group is loaded
+//           from W-4 and shifted left by k = 1..3 at commit); 0 for a group that is entirely padding
+//   xk/xok  2 bits / 1 bit per pass: the shift, and "not padding"
+//   ho/hok  the same for the two halo columns (one float each); lanes beyond 2*kRows park their value in an unused pad column
+//   wo[p]   element offset of the lane's weight float4 relative to wp + c0*cout_pad + cob*32
+template <int TD>
+struct Plan {
+  int xo[Geo<TD>::kXPass];
+  int ho[Geo<TD>::kHaloPerLane];
+  int wo[Geo<TD>::kWPass];
+  unsigned xk, xok, hok;
+};
+
 template <int TD, bool WEIGHTS = true>
-__device__ __forceinline__ void stage_fetch(Stage<TD>& st, const float* __restrict__ x, const float* __restrict__ wp, int tid, int b, int c0,
-                                            int Cin, int cout_pad, int cob, int D, int H, int W, int d0, int h0, int w0,
-                                            long long plane, long long vol) {
+__device__ __forceinline__ void make_plan(Plan<TD>& pl, int tid, int Cin, int cout_pad, int D, int H, int W, int d0, int h0, int w0,
+                                          int plane, int vol) {
   using G = Geo<TD>;
+  static_assert(G::kRows % G::kRowsPerPass == 0, "every pass of the interior fetch is full");
+  constexpr int kPerC = (TD + 2) * (kTH + 2);
   const int j = tid & 7, r0 = tid >> 3;
+  pl.xk = 0, pl.xok = 0, pl.hok = 0;
 #pragma unroll
   for (int p = 0; p < G::kXPass; ++p) {
     const int row = p * G::kRowsPerPass + r0;
-    const int c = row / ((TD + 2) * (kTH + 2));
-    const int rem = row - c * ((TD + 2) * (kTH + 2));
+    const int c = row / kPerC, rem = row - c * kPerC;
     const int dd = rem / (kTH + 2), hh = rem - dd * (kTH + 2);
     const int gd = d0 + dd - 1, gh = h0 + hh - 1, gw = w0 + 4 * j;
-    v4f v = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
-    if (row < G::kRows && gd >= 0 && gd < D && gh >= 0 && gh < H && gw < W) {
-      const float* src = x + (static_cast<long long>(b) * Cin + c0 + c) * vol + gd * plane + static_cast<long long>(gh) * W + gw;
-      if (gw + 3 < W) {
-        // W % 4 != 0: the row starts are only 4- or 8-byte aligned; global_load_dwordx4 takes dword-aligned addresses
-        // (unaligned access mode is the ROCm default), at the price of an extra cache line now and then
-        v = *reinterpret_cast<const v4f_u*>(src);
-      } else {  // the row ends inside this group: element by element, the rest stays zero (it belongs to the next row)
-        v.x = src[0];
-        if (gw + 1 < W) v.y = src[1];
-        if (gw + 2 < W) v.z = src[2];
-      }
-    }
-    st.xi[p] = v;
+    const bool ok = gd >= 0 && gd < D && gh >= 0 && gh < H && gw < W;
+    const int gws = gw + 3 < W ? gw : W - 4;
+    pl.xo[p] = ok ? c * vol + gd * plane + gh * W + gws : 0;
+    pl.xok |= (ok ? 1u : 0u) << p;
+    pl.xk |= (ok ? static_cast<unsigned>(gw - gws) : 0u) << (2 * p);
   }
 #pragma unroll
   for (int p = 0; p < G::kHaloPerLane; ++p) {
     const int s = p * G::kThreads + tid;
-    float v = 0.0f;
-    if (s < 2 * G::kRows) {
-      const int row = s >> 1, side = s & 1;
-      const int c = row / ((TD + 2) * (kTH + 2));
-      const int rem = row - c * ((TD + 2) * (kTH + 2));
-      const int dd = rem / (kTH + 2), hh = rem - dd * (kTH + 2);
-      const int gd = d0 + dd - 1, gh = h0 + hh - 1, gw = side ? w0 + kTW : w0 - 1;
-      if (gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W)
-        v = x[(static_cast<long long>(b) * Cin + c0 + c) * vol + gd * plane + static_cast<long long>(gh) * W + gw];
-    }
-    st.xh[p] = v;
+    const bool real = s < 2 * G::kRows;
+    const int row = (real ? s : s - 2 * G::kRows) >> 1, side = s & 1;
+    const int c = row / kPerC, rem = row - c * kPerC;
+    const int dd = rem / (kTH + 2), hh = rem - dd * (kTH + 2);
+    const int gd = d0 + dd - 1, gh = h0 + hh - 1, gw = side ? w0 + kTW : w0 - 1;
+    const bool ok = real && gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W;
+    pl.ho[p] = ok ? c * vol + gd * plane + gh * W + gw : 0;
+    pl.hok |= (ok ? 1u : 0u) << p;
   }
   if (!WEIGHTS) return;
 #pragma unroll
   for (int p = 0; p < G::kWPass; ++p) {
-    const int f = p * G::kThreads + tid;
-    v4f v = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
-    if (f < kWF4) {
-      const int n4 = f & 7, c = (f >> 3) & (kFC - 1), tap = f / (8 * kFC);
-      v = *reinterpret_cast<const v4f*>(wp + (static_cast<long long>(tap) * Cin + c0 + c) * cout_pad + cob * 32 + 4 * n4);
-    }
-    st.wv[p] = v;
+    int f = p * G::kThreads + tid;
+    if (f >= kWF4) f -= G::kThreads;           // the last pass is partial: its idle lanes repeat an earlier float4 (same data, same slot)
+    const int n4 = f & 7, c = (f >> 3) & (kFC - 1), tap = f / (8 * kFC);
+    pl.wo[p] = (tap * Cin + c) * cout_pad + 4 * n4;
   }
 }
 
 template <int TD, bool WEIGHTS = true>
-__device__ __forceinline__ void stage_commit(const Stage<TD>& st, float* sx, float* sw, int tid) {
+__device__ __forceinline__ void stage_fetch(Stage<TD>& st, const Plan<TD>& pl, const float* __restrict__ xc, const float* __restrict__ wc) {
+  using G = Geo<TD>;
+#pragma unroll
+  for (int p = 0; p < G::kXPass; ++p) st.xi[p] = *reinterpret_cast<const v4f_u*>(xc + pl.xo[p]);  // dword-aligned float4 (any W)
+#pragma unroll
+  for (int p = 0; p < G::kHaloPerLane; ++p) st.xh[p] = xc[pl.ho[p]];
+  if (!WEIGHTS) return;
+#pragma unroll
+  for (int p = 0; p < G::kWPass; ++p) st.wv[p] = *reinterpret_cast<const v4f*>(wc + pl.wo[p]);
+}
+
+template <int TD, bool WEIGHTS = true>
+__device__ __forceinline__ void stage_commit(const Stage<TD>& st, const Plan<TD>& pl, float* sx, float* sw, int tid) {
   using G = Geo<TD>;
   const int j = tid & 7, r0 = tid >> 3;
 #pragma unroll
   for (int p = 0; p < G::kXPass; ++p) {
     const int row = p * G::kRowsPerPass + r0;
-    if (row < G::kRows) *reinterpret_cast<v4f*>(sx + row * kP + 4 + 4 * j) = st.xi[p];
+    const v4f t = st.xi[p];
+    const unsigned k = (pl.xk >> (2 * p)) & 3u;
+    const bool ok = (pl.xok >> p) & 1u;
+    v4f v;
+    v.x = k == 0 ? t.x : (k == 1 ? t.y : (k == 2 ? t.z : t.w));
+    v.y = k == 0 ? t.y : (k == 1 ? t.z : (k == 2 ? t.w : 0.0f));
+    v.z = k == 0 ? t.z : (k == 1 ? t.w : 0.0f);
+    v.w = k == 0 ? t.w : 0.0f;
+    if (!ok) v = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+    *reinterpret_cast<v4f*>(sx + row * kP + 4 + 4 * j) = v;
   }
 #pragma unroll
   for (int p = 0; p < G::kHaloPerLane; ++p) {
     const int s = p * G::kThreads + tid;
-    if (s < 2 * G::kRows) sx[(s >> 1) * kP + ((s & 1) ? 4 + kTW : 3)] = st.xh[p];
+    const bool real = s < 2 * G::kRows;
+    const int row = (real ? s : s - 2 * G::kRows) >> 1, side = s & 1;
+    sx[row * kP + (real ? (side ? 4 + kTW : 3) : side)] = ((pl.hok >> p) & 1u) ? st.xh[p] : 0.0f;   // idle lanes: pad columns 0 / 1
   }
   if (!WEIGHTS) return;
 #pragma unroll
   for (int p = 0; p < G::kWPass; ++p) {
-    const int f = p * G::kThreads + tid;
-    if (f < kWF4) *reinterpret_cast<v4f*>(sw + 4 * f) = st.wv[p];
+    int f = p * G::kThreads + tid;
+    if (f >= kWF4) f -= G::kThreads;
+    *reinterpret_cast<v4f*>(sw + 4 * f) = st.wv[p];
   }
 }
 
@@ -273,6 +302,10 @@ __global__ __launch_bounds__(128 * TD, 2) void conv3d_k3_mfma(const float* __res
                                                               float* __restrict__ y, int Cin, int Cout, int cout_pad, int D, int H, int W,
                                                               int tiles_w, int cblocks, Epi epi) {
   using G = Geo<TD>;
+  // before which (kd,kh) group of the tap loop the next stage is written to the other LDS buffer - in the shadow of this
+  // stage's MFMAs instead of after them (measured: 64->32 1.468 -> 1.437 ms, 32->64 1.395 -> 1.32 ms at 6; the masked
+  // classes, with fewer MFMAs per stage, 0.60 -> 0.55 ms at 3; profiles/r02_conv3d_staging.jsonl)
+  constexpr int kCommitAt = MASKED ? 3 : 6;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l32 = lane & 31;
@@ -291,19 +324,27 @@ __global__ __launch_bounds__(128 * TD, 2) void conv3d_k3_mfma(const float* __res
   // two LDS stages: while the waves run the MFMAs of stage `cur`, the next chunk travels global -> registers ->
   // the other stage; ONE barrier per chunk
   Stage<TD> st;
-  stage_fetch<TD>(st, x, wp, tid, b, 0, Cin, cout_pad, cob, D, H, W, d0, h0, w0, plane, vol);
-  stage_commit<TD>(st, lds, lds + G::kSX, tid);
+  Plan<TD> pl;
+  make_plan<TD>(pl, tid, Cin, cout_pad, D, H, W, d0, h0, w0, static_cast<int>(plane), static_cast<int>(vol));
+  const float* xb = x + static_cast<long long>(b) * Cin * vol;
+  const float* wb = wp + cob * 32;
+  stage_fetch<TD>(st, pl, xb, wb);
+  stage_commit<TD>(st, pl, lds, lds + G::kSX, tid);
   __syncthreads();
   int cur = 0;
   for (int c0 = 0; c0 < Cin; c0 += kFC) {
     const bool more = c0 + kFC < Cin;
     const float* sxc = lds + cur * G::kStageFloats;
     const float* swc = sxc + G::kSX;
-    if (more) stage_fetch<TD>(st, x, wp, tid, b, c0 + kFC, Cin, cout_pad, cob, D, H, W, d0, h0, w0, plane, vol);
+    if (more) stage_fetch<TD>(st, pl, xb + (c0 + kFC) * vol, wb + static_cast<long long>(c0 + kFC) * cout_pad);
     const unsigned mask = MASKED ? chunk_mask(epi, c0) : kAllTaps;
 #pragma unroll
     for (int t9 = 0; t9 < 9; ++t9) {  // (kd, kh); fully unrolled so that LDS operand reads run ahead of their MFMAs
       const int kd = t9 / 3, kh = t9 - kd * 3;
+      if (t9 == kCommitAt && more) {  // the next stage goes to the OTHER buffer in the shadow of this stage's MFMAs
+        float* nx = lds + (cur ^ 1) * G::kStageFloats;
+        stage_commit<TD>(st, pl, nx, nx + G::kSX, tid);
+      }
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
         const int tap = t9 * 3 + kw;
@@ -321,10 +362,6 @@ __global__ __launch_bounds__(128 * TD, 2) void conv3d_k3_mfma(const float* __res
           }
         }
       }
-    }
-    if (more) {
-      float* nx = lds + (cur ^ 1) * G::kStageFloats;
-      stage_commit<TD>(st, nx, nx + G::kSX, tid);
     }
     __syncthreads();
     cur ^= 1;
@@ -394,9 +431,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_narrow_out(const float* __re
       if (f < kNW) sw[f] = wn[p];
     }
   };
-  stage_fetch<2, false>(st, x, wp, tid, b, 0, Cin, cout_pad, 0, D, H, W, d0, h0, w0, plane, vol);
+  Plan<2> pl;
+  make_plan<2, false>(pl, tid, Cin, cout_pad, D, H, W, d0, h0, w0, static_cast<int>(plane), static_cast<int>(vol));
+  const float* xb = x + static_cast<long long>(b) * Cin * vol;
+  stage_fetch<2, false>(st, pl, xb, nullptr);
   fetch_w(0);
-  stage_commit<2, false>(st, lds, nullptr, tid);
+  stage_commit<2, false>(st, pl, lds, nullptr, tid);
   commit_w(lds + G::kSX);
   __syncthreads();
   int cur = 0;
@@ -405,7 +445,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_narrow_out(const float* __re
     const float* sxc = lds + cur * kStage;
     const float* swc = sxc + G::kSX;
     if (more) {
-      stage_fetch<2, false>(st, x, wp, tid, b, c0 + kFC, Cin, cout_pad, 0, D, H, W, d0, h0, w0, plane, vol);
+      stage_fetch<2, false>(st, pl, xb + (c0 + kFC) * vol, nullptr);
       fetch_w(c0 + kFC);
     }
 #pragma unroll kUnrollDD
@@ -440,7 +480,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_narrow_out(const float* __re
         }
     if (more) {
       float* nx = lds + (cur ^ 1) * kStage;
-      stage_commit<2, false>(st, nx, nullptr, tid);
+      stage_commit<2, false>(st, pl, nx, nullptr, tid);
       commit_w(nx + G::kSX);
     }
     __syncthreads();
@@ -576,6 +616,9 @@ static int launch_conv(const float* x, const float* w_prep, float* y, int b, int
   const int cblocks = (cout + 31) / 32;
   if (static_cast<long long>(b) * cblocks > 65535) return ADV_EINVAL;
   const bool plain = stride == 1 && epi.tap_mask == kAllTaps && epi.class_channels == 0;
+  // the LDS-staged kernels' fetch plan holds 32-bit element offsets inside one batch element and loads 4 floats at a time:
+  // w >= 4, cin*d*h*w and 27*cin*cout_pad below 2^31 - anything else takes the scalar-staging kernel
+  const bool fits = w >= 4 && static_cast<long long>(cin) * d * h * w < (1LL << 31) && 27LL * cin * cblocks * 32 < (1LL << 31);
   const bool narrow_ok = getenv("ADV_CONV_NO_NARROW") == nullptr;  // test hook: the padded matrix kernel instead
   if (cin < kCK) {  // 1..3 input channels (the adjoint of a layer with 1..3 outputs): vector-ALU kernel, HBM-bound on the result
     if (!plain) return ADV_EINVAL;
@@ -589,7 +632,7 @@ static int launch_conv(const float* x, const float* w_prep, float* y, int b, int
       hipLaunchKernelGGL((conv3d_k3_narrow_in<3>), grid, dim3(256), 0, st, x, w_prep, y, cout, cblocks * 32, d, h, w, voxels, epi);
     return adv_internal_finish_launch();
   }
-  if (plain && cout <= 8 && narrow_ok && (reinterpret_cast<uintptr_t>(x) & 3) == 0) {
+  if (plain && fits && cout <= 8 && narrow_ok && (reinterpret_cast<uintptr_t>(x) & 3) == 0) {
     const dim3 grid(tiles_w * tiles_h, (d + 1) / 2, b);
     const int co_t = cout == 1 ? 1 : (cout <= 4 ? 4 : 8);
     const size_t lds = 2 * static_cast<size_t>(Geo<2>::kSX + 27 * kFC * co_t) * sizeof(float);
@@ -603,7 +646,7 @@ static int launch_conv(const float* x, const float* w_prep, float* y, int b, int
   }
   // the main kernel takes every width (rows that are not 16-byte aligned are loaded as dword-aligned float4);
   // ADV_CONV_GENERIC=1 forces the scalar-staging kernel (kept as the reference implementation of the tiling)
-  const bool fast = stride == 1 && (reinterpret_cast<uintptr_t>(w_prep) & 15) == 0 && (reinterpret_cast<uintptr_t>(x) & 3) == 0 &&
+  const bool fast = stride == 1 && fits && (reinterpret_cast<uintptr_t>(w_prep) & 15) == 0 && (reinterpret_cast<uintptr_t>(x) & 3) == 0 &&
                     getenv("ADV_CONV_GENERIC") == nullptr;
   // tile depth 2 (4 waves) and 4 (8 waves, one workgroup per CU) measured the same within 1-2 % (profiles/r01_conv3d_mfma.jsonl)
   if (fast) {
