@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 #include "adv_internal.h"
 #include "advengine.h"
@@ -69,7 +70,17 @@ __device__ __forceinline__ Bin bin_of(const float* roi, float scale, int ph, int
   return b;
 }
 
-// one lane per output element (r, c, ph, pw); the bin index is fastest, so a wave reads neighbouring samples
+// one lane per output element (r, c, ph, pw); the bin index is fastest, so a wave reads neighbouring samples.
+// The kernel is bound by the texture addresser's gather rate (16 single-dword gathers per output, each wave-load touching a
+// dozen rows), not by arithmetic or HBM - two restructurings that remove the redundant tap arithmetic were measured and
+// dropped: (a) one workgroup per (roi, 32 channels) with the roi's window and a tap table in LDS: bit-identical, 0.25 ms
+// against 0.10 ms for 512 rois x 256 channels x 7x7 bins (windows of ~30 x 30 pixels: staging costs more than the L1/L2 hits
+// it saves); (b) one lane per (roi, bin) with the taps in registers, streaming over 32 channels: 0.112 ms against 0.098
+// (profiles/r02_roi_fwd_lds_attempt.jsonl, r02_roi_fwd_regs_attempt.jsonl).  PAIR: the two taps of a row are neighbours
+// (x_high = x_low + 1, or the same pixel at the right edge) - one dword-aligned 8-byte load instead of two gathers.
+typedef float f32x2_u __attribute__((ext_vector_type(2), aligned(4)));
+
+template <bool PAIR>
 __global__ __launch_bounds__(kBlock) void roi_align_fwd(const float* __restrict__ feat, const float* __restrict__ rois,
                                                         float* __restrict__ out, int C, int H, int W, long long total, int PH,
                                                         int PW, float scale, int sampling_ratio) {
@@ -89,8 +100,17 @@ __global__ __launch_bounds__(kBlock) void roi_align_fwd(const float* __restrict_
         const Taps t = taps_at(H, W, y, x);
         float v = 0.0f;
         if (t.valid) {
-          const float v1 = plane[t.y_low * W + t.x_low], v2 = plane[t.y_low * W + t.x_high];
-          const float v3 = plane[t.y_high * W + t.x_low], v4 = plane[t.y_high * W + t.x_high];
+          float v1, v2, v3, v4;
+          if (PAIR) {  // W >= 2 (host-checked): columns xs, xs + 1 cover x_low and x_high and never leave the row
+            const int xs = t.x_low < W - 1 ? t.x_low : W - 2;
+            const f32x2_u lo = *reinterpret_cast<const f32x2_u*>(plane + t.y_low * W + xs);
+            const f32x2_u hi = *reinterpret_cast<const f32x2_u*>(plane + t.y_high * W + xs);
+            v1 = t.x_low == xs ? lo.x : lo.y, v2 = t.x_high == xs ? lo.x : lo.y;
+            v3 = t.x_low == xs ? hi.x : hi.y, v4 = t.x_high == xs ? hi.x : hi.y;
+          } else {
+            v1 = plane[t.y_low * W + t.x_low], v2 = plane[t.y_low * W + t.x_high];
+            v3 = plane[t.y_high * W + t.x_low], v4 = plane[t.y_high * W + t.x_high];
+          }
           v = t.w1 * v1 + t.w2 * v2 + t.w3 * v3 + t.w4 * v4;
         }
         acc += v;
@@ -317,8 +337,12 @@ int adv_roi_align_fwd_f32(const float* feat, const float* rois, float* out, int 
   if (rc != ADV_OK) return rc;
   if (r == 0) return ADV_OK;
   const long long total = static_cast<long long>(r) * c * ph * pw;
-  hipLaunchKernelGGL(roi_align_fwd, dim3(grid_for(total)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), feat, rois, out, c, h, w,
-                     total, ph, pw, spatial_scale, sampling_ratio);
+  if (w >= 2 && getenv("ADV_ROI_FWD_DIRECT") == nullptr)
+    hipLaunchKernelGGL(roi_align_fwd<true>, dim3(grid_for(total)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), feat, rois, out, c, h, w,
+                       total, ph, pw, spatial_scale, sampling_ratio);
+  else  // a one-column map, or ADV_ROI_FWD_DIRECT=1 (test hook): four single-dword gathers per sample
+    hipLaunchKernelGGL(roi_align_fwd<false>, dim3(grid_for(total)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), feat, rois, out, c, h, w,
+                       total, ph, pw, spatial_scale, sampling_ratio);
   return finish();
 }
 

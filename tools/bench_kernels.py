@@ -162,9 +162,32 @@ def conv_narrow(dev):
                           frac_of_8TBps=round(nbytes / ms / 1e6 / 8000, 3), torch_miopen_ms=round(ms_t, 3))))
 
 
+def roi(dev):
+    """RoIAlign forward at the Stereo R-CNN shapes (600x1987 image, 256-channel FPN levels, 7x7 / 14x14 bins, 2x2 samples):
+    paired 8-byte tap loads against four single gathers per sample"""
+    import os
+    import numpy as np
+    rs = np.random.RandomState(0)
+    for name, stride, pooled, n in (("P2 box head", 4, 7, 512), ("P3 box head", 8, 7, 512), ("P4 box head", 16, 7, 512), ("P2 keypoint head", 4, 14, 128)):
+        h, w = (600 + stride - 1) // stride, (1987 + stride - 1) // stride
+        feat = torch.randn((1, 256, h, w), device=dev)
+        side = rs.uniform(7, 28, n) * stride                                  # what the FPN level assignment sends to a level
+        x1, y1 = rs.uniform(0, 1987 - side), rs.uniform(0, 600 - side)
+        rois = torch.tensor(np.stack([np.zeros(n), x1, y1, x1 + side, y1 + side * rs.uniform(0.5, 1.0, n)], 1).astype(np.float32), device=dev)
+        ms = timeit(lambda: ops.roi_align(feat, rois, pooled, 1.0 / stride, 2), reps=20)
+        os.environ["ADV_ROI_FWD_DIRECT"] = "1"
+        ms_d = timeit(lambda: ops.roi_align(feat, rois, pooled, 1.0 / stride, 2), reps=20)
+        del os.environ["ADV_ROI_FWD_DIRECT"]
+        print(json.dumps(dict(kernel="roi_align_fwd<paired loads> %s: %d rois x 256 ch on %dx%d, %dx%d bins" % (name, n, h, w, pooled, pooled), ms=round(ms, 4),
+                              single_gathers_ms=round(ms_d, 4), speedup=round(ms_d / ms, 2))))
+
+
 def main():
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
+    if "--roi" in sys.argv:
+        roi(dev)
+        return
     if "--conv-narrow" in sys.argv:
         conv_narrow(dev)
         return
