@@ -21,7 +21,7 @@ ADV_ELAUNCH = -5
 ADV_SPACE_AFFINE = 0
 ADV_SPACE_IDENTITY = 1
 ADV_SPACE_AFFINE_RCP = 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class AdvSpace(ctypes.Structure):
@@ -86,10 +86,17 @@ SIGNATURES = {
     "adv_conv3d_k3_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "adv_conv3d_k3_ex_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32), _I, _I3, _I3, _I3, _P],
     "adv_space_to_depth2_f32": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "adv_depth_regress_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "adv_depth_regress_bwd_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "adv_grid_sample3d_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "adv_grid_sample3d_plan_f32": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "adv_grid_sample3d_bwd_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "adv_sigmoid_focal_loss_f32": [_P, _P, _P, _P, _L, _I, _F, _F, _P],
 }
 _OTHER = {
     "adv_abi_version": ([], _I),
     "adv_roi_align_bwd_workspace_ints": ([_I, _I, _I, _I], ctypes.c_int64),
+    "adv_grid_sample3d_plan_bytes": ([_I, _I, _I, _I, _I, _I, _I], ctypes.c_int64),
     "adv_last_hip_error": ([], _I),
     "adv_strerror": ([_I], ctypes.c_char_p),
     "adv_space_dsgn": ([_SP], None),

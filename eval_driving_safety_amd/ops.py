@@ -864,3 +864,139 @@ def dense_align(calib, scale, im_left, im_right, boxes, kpts, poses):
     succ = torch.isfinite(cost) & (z > 0)
     disp = torch.where(succ, (f * bl) / z, torch.zeros_like(z))
     return succ.to(torch.int32), disp
+
+
+# --------------------------------------------------------------------------------------------
+# after the 3D convolutions (csrc/volume.hip): fused depth regression, grid_sample on 5-D volumes, sigmoid focal loss
+def depth_regress(cost, depth_values, out_size, align_corners=False, with_stats=False):
+    """cost [B,D,h,w], depth_values [Do] -> depth [B,H,W] = sum_k softmax_k(trilinear_upsample(cost, (Do,H,W)))[k] * depth_values[k],
+    without ever writing the up-sampled volume.  with_stats: also the per-pixel softmax (max, sum) [B,2,H,W] the backward needs."""
+    ci, zv = _feat(cost, "cost"), _feat(depth_values, "depth_values")
+    if ci.dim() != 4 or zv.dim() != 1 or len(out_size) != 3 or zv.shape[0] != int(out_size[0]):
+        raise ValueError("cost must be [B,D,h,w], out_size (Do,H,W) and depth_values [Do]")
+    b, d, h, w = ci.shape
+    do, ho, wo = (int(v) for v in out_size)
+    depth = torch.empty((b, ho, wo), dtype=torch.float32, device=ci.device)
+    stats = torch.empty((b, 2, ho, wo), dtype=torch.float32, device=ci.device) if with_stats else None
+    with _on(ci):
+        _lib.call("adv_depth_regress_f32", _ptr(ci), _ptr(zv), _ptr(depth), None if stats is None else _ptr(stats), b, d, h, w, do, ho, wo,
+                  int(bool(align_corners)), _stream(ci))
+    return (depth, stats) if with_stats else depth
+
+
+def depth_regress_bwd(cost, depth_values, depth, stats, grad_depth, align_corners=False):
+    ci, zv, dp, st, g = (_feat(cost, "cost"), _feat(depth_values, "depth_values"), _feat(depth, "depth"), _feat(stats, "stats"),
+                         _feat(grad_depth, "grad_depth"))
+    b, d, h, w = ci.shape
+    _, ho, wo = dp.shape
+    if tuple(st.shape) != (b, 2, ho, wo) or tuple(g.shape) != (b, ho, wo):
+        raise ValueError("stats must be [B,2,H,W] and grad_depth [B,H,W]")
+    work = torch.empty((b, d, ho, wo), dtype=torch.float32, device=ci.device)
+    gc = torch.empty_like(ci)
+    with _on(ci):
+        _lib.call("adv_depth_regress_bwd_f32", _ptr(ci), _ptr(zv), _ptr(dp), _ptr(st), _ptr(g), _ptr(work), _ptr(gc), b, d, h, w, int(zv.shape[0]),
+                  ho, wo, int(bool(align_corners)), _stream(ci))
+    return gc
+
+
+class DepthRegress(torch.autograd.Function):
+    """depth = DepthRegress.apply(cost [B,D,h,w], depth_values [Do], (Do,H,W), align_corners); gradient w.r.t. cost only"""
+
+    @staticmethod
+    def forward(ctx, cost, depth_values, out_size, align_corners=False):
+        cost = cost.contiguous()
+        depth, stats = depth_regress(cost, depth_values, out_size, align_corners, with_stats=True)
+        ctx.save_for_backward(cost, depth_values, depth, stats)
+        ctx.align = bool(align_corners)
+        return depth
+
+    @staticmethod
+    def backward(ctx, grad_depth):
+        cost, zv, depth, stats = ctx.saved_tensors
+        return depth_regress_bwd(cost, zv, depth, stats, grad_depth.contiguous(), ctx.align), None, None, None
+
+
+def grid_sample3d(vol, grid, align_corners=False):
+    """torch.nn.functional.grid_sample(vol [B,C,D,H,W], grid [B,Z,Y,X,3], bilinear, zeros) - the same bits as torch on the CPU"""
+    vi, gi = _feat(vol, "vol"), _feat(grid, "grid")
+    if vi.dim() != 5 or gi.dim() != 5 or gi.shape[0] != vi.shape[0] or gi.shape[4] != 3:
+        raise ValueError("vol must be [B,C,D,H,W] and grid [B,Z,Y,X,3]")
+    b, c, d, h, w = vi.shape
+    zo, yo, xo = gi.shape[1:4]
+    out = torch.empty((b, c, zo, yo, xo), dtype=torch.float32, device=vi.device)
+    with _on(vi):
+        _lib.call("adv_grid_sample3d_f32", _ptr(vi), _ptr(gi), _ptr(out), b, c, d, h, w, zo, yo, xo, int(bool(align_corners)), _stream(vi))
+    return out
+
+
+class GridSamplePlan:
+    """The backward's gather plan for one grid (build once per calibration): for every cell of the volume the sorted list of
+    (output voxel, weight) that sample it."""
+
+    def __init__(self, grid, vol_dims, align_corners=False):
+        gi = _feat(grid, "grid")
+        b, zo, yo, xo, _ = gi.shape
+        d, h, w = (int(v) for v in vol_dims)
+        nbytes = int(_lib.load().adv_grid_sample3d_plan_bytes(b, d, h, w, zo, yo, xo))
+        if nbytes <= 0:
+            raise ValueError("grid / volume too large for a 32-bit plan")
+        self.buf = torch.empty((nbytes // 4,), dtype=torch.int32, device=gi.device)
+        self.dims, self.out_dims, self.batch, self.align = (d, h, w), (zo, yo, xo), b, bool(align_corners)
+        with _on(gi):
+            _lib.call("adv_grid_sample3d_plan_f32", _ptr(gi), _ptr(self.buf), b, d, h, w, zo, yo, xo, int(self.align), _stream(gi))
+
+
+def grid_sample3d_bwd(grad_out, plan):
+    g = _feat(grad_out, "grad_out")
+    b, c = g.shape[:2]
+    if g.dim() != 5 or b != plan.batch or tuple(g.shape[2:]) != tuple(plan.out_dims):
+        raise ValueError("grad_out must be [B,C,Z,Y,X] of the plan's grid")
+    d, h, w = plan.dims
+    zo, yo, xo = plan.out_dims
+    gv = torch.empty((b, c, d, h, w), dtype=torch.float32, device=g.device)
+    with _on(g):
+        _lib.call("adv_grid_sample3d_bwd_f32", _ptr(g), _ptr(plan.buf), _ptr(gv), b, c, d, h, w, zo, yo, xo, _stream(g))
+    return gv
+
+
+class GridSample3d(torch.autograd.Function):
+    """out = GridSample3d.apply(vol, grid, plan): gradient w.r.t. vol only (the grid is a function of the calibration), as a
+    deterministic gather over ``plan = GridSamplePlan(grid, vol.shape[2:], align_corners)``"""
+
+    @staticmethod
+    def forward(ctx, vol, grid, plan):
+        ctx.plan = plan
+        return grid_sample3d(vol.contiguous(), grid, plan.align)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        return grid_sample3d_bwd(grad_out.contiguous(), ctx.plan), None, None
+
+
+def sigmoid_focal_loss(logits, targets, gamma=2.0, alpha=0.25, want_grad=False):
+    """logits [N,K], targets int32 [N] (0 = background, c = class c, < 0 = ignored) -> per-element loss [N,K] (and d loss / d logit)"""
+    li = _feat(logits, "logits")
+    if li.dim() != 2 or not (isinstance(targets, torch.Tensor) and targets.is_cuda and targets.dtype == torch.int32 and targets.is_contiguous()
+                             and tuple(targets.shape) == (li.shape[0],)):
+        raise ValueError("logits must be [N,K] float32 and targets [N] int32, contiguous, on the GPU")
+    loss = torch.empty_like(li)
+    grad = torch.empty_like(li) if want_grad else None
+    with _on(li):
+        _lib.call("adv_sigmoid_focal_loss_f32", _ptr(li), _ptr(targets), _ptr(loss), None if grad is None else _ptr(grad), int(li.shape[0]),
+                  int(li.shape[1]), float(gamma), float(alpha), _stream(li))
+    return (loss, grad) if want_grad else loss
+
+
+class SigmoidFocalLoss(torch.autograd.Function):
+    """sum of the per-element focal losses (the reduction the FCOS-style heads use before dividing by the positive count)"""
+
+    @staticmethod
+    def forward(ctx, logits, targets, gamma=2.0, alpha=0.25):
+        loss, grad = sigmoid_focal_loss(logits.contiguous(), targets, gamma, alpha, want_grad=True)
+        ctx.save_for_backward(grad)
+        return loss.sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None, None

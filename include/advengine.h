@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ADV_ABI_VERSION 3
+#define ADV_ABI_VERSION 4
 #define ADV_API __attribute__((visibility("default"))) /* the library is built with -fvisibility=hidden */
 #define ADV_CHANNELS 3
 
@@ -306,6 +306,50 @@ ADV_API int adv_conv3d_k3_ex_f32(const float* x, const float* w_prep, const floa
 /* xs [b, 8c, ceil(d/2), ceil(h/2), ceil(w/2)]:  xs[b, p*c + ch, jd, jh, jw] = x[b, ch, 2jd+pd, 2jh+ph, 2jw+pw], p = (pd*2+ph)*2+pw,
  *     zero beyond the input.  HBM-bound permute (one pass); xs is caller-owned workspace. */
 ADV_API int adv_space_to_depth2_f32(const float* x, float* xs, int b, int c, int d, int h, int w, adv_stream_t stream);
+
+/* ---- after the 3D convolutions: what a plane-sweep detector does with its cost volume (upstream DSGN code reached through
+ *      attack/DSGN/pgd_attack.py:308 "outputs = model(...)" and :324 "RPN3DLoss"; SURVEY 2.2 lists them as native ops the
+ *      build must supply: trilinear upsample, grid_sample PSV -> 3D geometric volume, sigmoid focal loss).  UNPINNED against
+ *      DSGN itself (not in the reference tree); pinned against torch's own operators (F.interpolate + softmax, F.grid_sample)
+ *      on the CPU and against the oracle. */
+
+/* depth_out [b,h_out,w_out] = sum_k softmax_k(U)[k] * depth_values[k],  U = trilinear up-sampling of cost [b,d,h,w] to
+ *     [d_out,h_out,w_out] (torch.nn.functional.interpolate(mode="trilinear", align_corners)): the depth-regression head of a
+ *     cost-volume network, FUSED - U and its softmax are never written (368 MB per image at the DSGN size); a lane owns one
+ *     output pixel and streams over the planes.  depth_values DEVICE [d_out].  stats_out [b,2,h_out,w_out] (nullable): the
+ *     per-pixel softmax maximum and denominator, which the backward reads.  exp is the device's: 1e-5 relative parity. */
+ADV_API int adv_depth_regress_f32(const float* cost, const float* depth_values, float* depth_out, float* stats_out, int b, int d,
+                                  int h, int w, int d_out, int h_out, int w_out, int align_corners, adv_stream_t stream);
+
+/* grad_cost [b,d,h,w] from grad_depth [b,h_out,w_out].  Two atomic-free stages: per pixel the depth-axis adjoint into
+ *     workspace [b,d,h_out,w_out] floats (caller-owned), then the bilinear adjoint as a gather per cost cell (rows, then
+ *     columns, ascending): deterministic float32. */
+ADV_API int adv_depth_regress_bwd_f32(const float* cost, const float* depth_values, const float* depth, const float* stats,
+                                      const float* grad_depth, float* workspace, float* grad_cost, int b, int d, int h, int w,
+                                      int d_out, int h_out, int w_out, int align_corners, adv_stream_t stream);
+
+/* out [b,c,zo,yo,xo] = torch.nn.functional.grid_sample(vol [b,c,d,h,w], grid [b,zo,yo,xo,3], mode="bilinear",
+ *     padding_mode="zeros", align_corners): aten's grid_sampler_3d arithmetic (corner order, weight products, skipped
+ *     out-of-range corners) - bit-identical to torch on the CPU.  grid[...,0] indexes w, 1 h, 2 d, in [-1,1]. */
+ADV_API int adv_grid_sample3d_f32(const float* vol, const float* grid, float* out, int b, int c, int d, int h, int w, int zo, int yo,
+                                  int xo, int align_corners, adv_stream_t stream);
+
+/* The gradient w.r.t. vol as a deterministic GATHER.  adv_grid_sample3d_plan_f32 builds, once per grid (the grid depends on
+ *     the camera calibration only), for every cell of vol the list of (output voxel, weight) that sample it, sorted by output
+ *     voxel, into plan (DEVICE, adv_grid_sample3d_plan_bytes bytes, caller-owned; 0 = arguments out of range).
+ *     adv_grid_sample3d_bwd_f32 then sums grad_out * weight over each list in list order: no float atomics, the same bits on
+ *     every run (torch's backward scatters with atomicAdd). */
+ADV_API int64_t adv_grid_sample3d_plan_bytes(int b, int d, int h, int w, int zo, int yo, int xo);
+ADV_API int adv_grid_sample3d_plan_f32(const float* grid, void* plan, int b, int d, int h, int w, int zo, int yo, int xo,
+                                       int align_corners, adv_stream_t stream);
+ADV_API int adv_grid_sample3d_bwd_f32(const float* grad_out, const void* plan, float* grad_vol, int b, int c, int d, int h, int w,
+                                      int zo, int yo, int xo, adv_stream_t stream);
+
+/* Sigmoid focal loss, element-wise (maskrcnn-benchmark SigmoidFocalLoss semantics: the classification term of an FCOS-style
+ *     head).  logits [n,k]; targets DEVICE int32 [n]: 0 = background, c in 1..k = class (column c-1), < 0 = ignored.
+ *     loss_out / grad_out [n,k] (either may be NULL): per-element loss and its derivative w.r.t. the logit. */
+ADV_API int adv_sigmoid_focal_loss_f32(const float* logits, const int32_t* targets, float* loss_out, float* grad_out, int64_t n,
+                                       int k, float gamma, float alpha, adv_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -494,3 +494,155 @@ def nms(boxes, thresh):
             iou = inter / (area[i] + area[i + 1:] - inter)
             removed[i + 1:] |= iou > F32(thresh)
     return np.array(keep, dtype=np.int64)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# csrc/volume.hip: fused depth regression, grid_sample on 5-D volumes, sigmoid focal loss.  The ops are upstream DSGN /
+# maskrcnn-benchmark code (reached at attack/DSGN/pgd_attack.py:308,324), NOT in the reference tree: these restate the
+# KERNELS' arithmetic in float32 and are themselves checked against torch's F.interpolate/softmax, F.grid_sample and an
+# autograd formulation of the focal loss in tests/test_volume.py (CPU).
+def _lin_scale(n_in, n_out, align):
+    if align:
+        return np.float32(n_in - 1) / np.float32(n_out - 1) if n_out > 1 else np.float32(0)
+    return np.float32(n_in) / np.float32(n_out)
+
+
+def _lin_taps(n_in, n_out, align):
+    """torch's linear source index per output index: (i0, i1, l0, l1) as arrays, float32 arithmetic"""
+    sc = _lin_scale(n_in, n_out, align)
+    dst = np.arange(n_out, dtype=np.float32)
+    src = sc * dst if align else np.maximum(sc * (dst + np.float32(0.5)) - np.float32(0.5), np.float32(0))
+    src = src.astype(np.float32)
+    i0 = np.minimum(src.astype(np.int64), n_in - 1)
+    i1 = i0 + (i0 < n_in - 1)
+    l1 = np.clip(src - i0.astype(np.float32), 0, 1).astype(np.float32)
+    return i0, i1, (np.float32(1) - l1).astype(np.float32), l1
+
+
+def trilinear_upsample(cost, out_size, align=False):
+    """[B,D,h,w] -> [B,Do,H,W] in the kernel's nesting (w innermost, then h, then d), float32"""
+    cost = np.asarray(cost, np.float32)
+    do, ho, wo = out_size
+    x0, x1, a0, a1 = _lin_taps(cost.shape[3], wo, align)
+    v = a0 * cost[..., x0] + a1 * cost[..., x1]
+    y0, y1, b0, b1 = _lin_taps(cost.shape[2], ho, align)
+    v = b0[:, None] * v[:, :, y0, :] + b1[:, None] * v[:, :, y1, :]
+    d0, d1, c0, c1 = _lin_taps(cost.shape[1], do, align)
+    return (c0[:, None, None] * v[:, d0] + c1[:, None, None] * v[:, d1]).astype(np.float32)
+
+
+def depth_regress(cost, depth_values, out_size, align=False):
+    """-> depth [B,H,W], stats [B,2,H,W] (softmax max and denominator); plane-ordered float32 sums as the kernel"""
+    up = trilinear_upsample(cost, out_size, align)
+    zv = np.asarray(depth_values, np.float32)
+    m = up.max(axis=1)
+    s = np.zeros_like(m)
+    e = np.zeros_like(m)
+    for k in range(up.shape[1]):
+        p = np.exp(up[:, k] - m).astype(np.float32)
+        s = (s + p).astype(np.float32)
+        e = (e + p * zv[k]).astype(np.float32)
+    return (e / s).astype(np.float32), np.stack([m, s], 1)
+
+
+def depth_regress_bwd(cost, depth_values, grad_depth, out_size, align=False):
+    """float64 gradient of depth_regress w.r.t. cost (the kernel's float32 result is compared with a tolerance)"""
+    cost = np.asarray(cost, np.float64)
+    do, ho, wo = out_size
+    taps = [_lin_taps(cost.shape[1], do, align), _lin_taps(cost.shape[2], ho, align), _lin_taps(cost.shape[3], wo, align)]
+    mats = []
+    for (i0, i1, l0, l1), n_in in zip(taps, cost.shape[1:]):
+        m = np.zeros((len(i0), n_in))
+        m[np.arange(len(i0)), i0] += l0
+        m[np.arange(len(i0)), i1] += l1
+        mats.append(m)
+    up = np.einsum("kd,yh,xw,bdhw->bkyx", mats[0], mats[1], mats[2], cost)
+    p = np.exp(up - up.max(1, keepdims=True))
+    p /= p.sum(1, keepdims=True)
+    zv = np.asarray(depth_values, np.float64)[None, :, None, None]
+    depth = (p * zv).sum(1, keepdims=True)
+    gup = np.asarray(grad_depth, np.float64)[:, None] * p * (zv - depth)
+    return np.einsum("kd,yh,xw,bkyx->bdhw", mats[0], mats[1], mats[2], gup)
+
+
+def _gs_corners(grid, dims, align):
+    """aten grid_sampler_3d: per output voxel the eight (cell offset or -1, weight), float32"""
+    d, h, w = dims
+    g = np.asarray(grid, np.float32)
+
+    def unnorm(c, size):
+        if align:
+            return ((c + np.float32(1)) / np.float32(2)) * np.float32(size - 1)
+        return ((c + np.float32(1)) * np.float32(size) - np.float32(1)) / np.float32(2)
+
+    ix, iy, iz = unnorm(g[..., 0], w), unnorm(g[..., 1], h), unnorm(g[..., 2], d)
+    fx, fy, fz = np.floor(ix), np.floor(iy), np.floor(iz)
+    ax, bx = fx + 1 - ix, ix - fx
+    ay, by = fy + 1 - iy, iy - fy
+    az, bz = fz + 1 - iz, iz - fz
+    offs, wgts = [], []
+    for k in range(8):
+        xx = fx + (k & 1)
+        yy = fy + ((k >> 1) & 1)
+        zz = fz + ((k >> 2) & 1)
+        wk = ((bx if k & 1 else ax) * (by if k & 2 else ay)).astype(np.float32) * (bz if k & 4 else az)
+        ok = (xx >= 0) & (xx <= w - 1) & (yy >= 0) & (yy <= h - 1) & (zz >= 0) & (zz <= d - 1)
+        off = np.where(ok, (np.where(ok, zz, 0) * h + np.where(ok, yy, 0)) * w + np.where(ok, xx, 0), -1).astype(np.int64)
+        offs.append(off)
+        wgts.append(wk.astype(np.float32))
+    return offs, wgts
+
+
+def grid_sample3d(vol, grid, align=False):
+    """vol [B,C,D,H,W], grid [B,Z,Y,X,3] -> [B,C,Z,Y,X]; corners added in aten's order, float32"""
+    vol = np.asarray(vol, np.float32)
+    b, c = vol.shape[:2]
+    offs, wgts = _gs_corners(grid, vol.shape[2:], align)
+    flat = vol.reshape(b, c, -1)
+    out = np.zeros((b, c) + offs[0].shape[1:], np.float32)
+    for k in range(8):
+        for i in range(b):
+            ok = offs[k][i] >= 0
+            val = flat[i][:, np.where(ok, offs[k][i], 0)] * wgts[k][i][None]
+            out[i] = np.where(ok[None], (out[i] + val).astype(np.float32), out[i])
+    return out
+
+
+def grid_sample3d_bwd(grad_out, grid, vol_dims, align=False):
+    """gradient w.r.t. vol in the gather kernel's order: per cell, contributions by ascending output voxel, float32"""
+    go = np.asarray(grad_out, np.float32)
+    b, c = go.shape[:2]
+    d, h, w = vol_dims
+    offs, wgts = _gs_corners(grid, vol_dims, align)
+    gv = np.zeros((b, c, d * h * w), np.float32)
+    gof = go.reshape(b, c, -1)
+    for i in range(b):
+        cell = np.stack([o[i].reshape(-1) for o in offs], 1)            # [N,8]
+        wk = np.stack([x[i].reshape(-1) for x in wgts], 1)
+        n = cell.shape[0]
+        vox = np.repeat(np.arange(n), 8)
+        cell, wk = cell.reshape(-1), wk.reshape(-1)
+        keep = cell >= 0
+        cell, wk, vox = cell[keep], wk[keep], vox[keep]
+        order = np.lexsort((vox, cell))                                 # by cell, then by output voxel
+        cell, wk, vox = cell[order], wk[order], vox[order]
+        rank = np.arange(len(cell)) - np.searchsorted(cell, cell, side="left")
+        for r in range(int(rank.max()) + 1 if len(rank) else 0):        # r-th entry of every list: one vectorised float32 add
+            sel = rank == r
+            gv[i][:, cell[sel]] = (gv[i][:, cell[sel]] + gof[i][:, vox[sel]] * wk[sel][None]).astype(np.float32)
+    return gv.reshape(b, c, d, h, w)
+
+
+def sigmoid_focal_loss(logits, targets, gamma=2.0, alpha=0.25):
+    """-> (loss [N,K], dloss/dlogit [N,K]), float64 (the kernel's float32 is compared with a tolerance)"""
+    x = np.asarray(logits, np.float64)
+    t = np.asarray(targets).reshape(-1, 1)
+    cls = np.arange(1, x.shape[1] + 1)[None]
+    p = 1 / (1 + np.exp(-x))
+    lp = np.minimum(x, 0) - np.log1p(np.exp(-np.abs(x)))
+    lq = np.minimum(-x, 0) - np.log1p(np.exp(-np.abs(x)))
+    pos, neg = t == cls, (t >= 0) & (t != cls)
+    loss = np.where(pos, -alpha * (1 - p) ** gamma * lp, 0) + np.where(neg, -(1 - alpha) * p ** gamma * lq, 0)
+    grad = np.where(pos, alpha * (1 - p) ** gamma * (gamma * p * lp - (1 - p)), 0) + \
+        np.where(neg, (1 - alpha) * p ** gamma * (p - gamma * (1 - p) * lq), 0)
+    return loss, grad
