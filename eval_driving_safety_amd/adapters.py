@@ -90,11 +90,18 @@ class PsvStereoAdapter:
       hourglass=True   a 3D hourglass as plane-sweep detectors use it: 64->32, 32->32, then 32->64 stride 2, 64->64,
                        64->64 stride 2, 64->64, transposed 64->64 (+ skip), transposed 64->32 (+ skip), 32->1;
                        every layer but the last carries a bias (a folded batch-norm) and a fused ReLU
-    It is NOT DSGN (no 3DGV, no detection head, no trained weights): detection parity is unpinned by construction; it
-    exists so that "20-step PGD through a plane-sweep network" can be measured end to end on this hardware."""
+      dsgn_head=True   the rest of the DSGN graph shape on libadvengine's kernels: depth = fused trilinear
+                       up-sampling + softmax over 192 planes + expectation (ops.DepthRegress); plane-sweep features weighted by
+                       the plane probabilities are resampled into a 3D geometric volume on a 0.2 m world grid
+                       (ops.GridSample3d, [B,32,192,20,304]), one 3D convolution, height folded into channels -> bird's-eye-view
+                       2D convolutions -> per-anchor classification / box / centerness maps; the objective becomes
+                       depth smooth-L1 + (sigmoid focal + smooth-L1 + BCE) as attack/DSGN/pgd_attack.py:310-336 adds them.
+    It is NOT DSGN (random weights, simplified heads, no trained parameters): detection parity is unpinned by construction; it
+    exists so that "20-step PGD through a plane-sweep detector" can be measured end to end on this hardware."""
 
     def __init__(self, device, seed=0, channels=32, planes=48, min_depth=2.0, depth_step=0.8, fu=721.5377,
-                 baseline=0.54, downsample=4, mid=32, mfma_conv=True, interp=True, hourglass=False):
+                 baseline=0.54, downsample=4, mid=32, mfma_conv=True, interp=True, hourglass=False, dsgn_head=False,
+                 cu=609.5593, cv=172.854, image_hw=(384, 1248)):
         from . import ops
         self.ops = ops
         gen = torch.Generator().manual_seed(seed)
@@ -139,6 +146,115 @@ class PsvStereoAdapter:
                            "u1": (ops.conv_transpose3d_k3_s2_prep(self.hg["u1"]), S2(self.hg["u1"])),
                            "u2": (ops.conv_transpose3d_k3_s2_prep(self.hg["u2"]), S2(self.hg["u2"]))}
 
+        self.dsgn_head = dsgn_head
+        if dsgn_head:
+            self._init_dsgn_head(w, gen, min_depth, depth_step, cu, cv, image_hw)
+
+    # -- the DSGN-shaped detection branch ------------------------------------------------------------------------
+    VOXEL, X_RANGE, Y_RANGE, ANCHORS = 0.2, (-30.4, 30.4), (-1.0, 3.0), 2
+
+    def _init_dsgn_head(self, w, gen, min_depth, depth_step, cu, cv, image_hw):
+        ops, dev, mid = self.ops, self.device, self.mid
+        planes = self.depth.shape[0]
+        up = self.downsample * planes
+        # depth of up-sampled plane k: the source coordinate of torch's linear interpolation (align_corners=False), unclamped
+        src = (torch.arange(up, dtype=torch.float32) + 0.5) / self.downsample - 0.5
+        self.depth_up = (min_depth + depth_step * src).to(dev).contiguous()
+        self.up_size = (up, image_hw[0], image_hw[1])
+        # world grid of the 3D geometric volume -> where each voxel centre lands in the plane-sweep volume (x: feature column,
+        # y: feature row, z: depth plane), normalised for grid_sample(align_corners=True)
+        v = self.VOXEL
+        zs = min_depth + v * (torch.arange(int(round(depth_step * planes / v)), dtype=torch.float32) + 0.5)
+        ys = self.Y_RANGE[0] + v * (torch.arange(int(round((self.Y_RANGE[1] - self.Y_RANGE[0]) / v)), dtype=torch.float32) + 0.5)
+        xs = self.X_RANGE[0] + v * (torch.arange(int(round((self.X_RANGE[1] - self.X_RANGE[0]) / v)), dtype=torch.float32) + 0.5)
+        Z, Y, X = torch.meshgrid(zs, ys, xs, indexing="ij")
+        fh, fw = image_hw[0] // self.downsample, image_hw[1] // self.downsample
+        col = (self.fu * X / Z + cu) / self.downsample
+        row = (self.fu * Y / Z + cv) / self.downsample
+        pl = (Z - min_depth) / depth_step
+        grid = torch.stack([col / (fw - 1) * 2 - 1, row / (fh - 1) * 2 - 1, pl / (planes - 1) * 2 - 1], dim=-1)
+        self.gv_grid = grid[None].to(dev).contiguous()                   # [1,Zg,Yg,Xg,3]: one calibration for the whole batch
+        self.gv_dims = (planes, fh, fw)
+        self._gv_plans = {}
+        ypool = 4
+        self.ypool = ypool
+        bev_in = mid * (len(ys) // ypool)
+        self.g3 = w(mid, mid, 3, 3, 3)
+        self.gb3 = (torch.randn(mid, generator=gen) * 0.05).to(dev)
+        if self.mfma_conv:
+            self.gp3, self.gp3t = ops.conv3d_k3_prep(self.g3), ops.conv3d_k3_prep(self.g3, transpose=True)
+        a = self.ANCHORS
+        self.bev1, self.bev2 = w(64, bev_in, 3, 3), w(64, 64, 3, 3)
+        self.head_cls, self.head_reg, self.head_ctr = w(a, 64, 3, 3), w(a * 7, 64, 3, 3), w(a, 64, 3, 3)
+        self.cls_bias = float(-torch.log(torch.tensor(99.0)))            # the usual focal-loss prior: p = 0.01
+
+    def _gv(self, b):
+        """grid [b,Zg,Yg,Xg,3] and its backward plan (built once per batch size: the calibration is fixed)"""
+        if b not in self._gv_plans:
+            grid = self.gv_grid.expand(b, -1, -1, -1, -1).contiguous()
+            self._gv_plans[b] = (grid, self.ops.GridSamplePlan(grid, self.gv_dims, align_corners=True))
+        return self._gv_plans[b]
+
+    def detection_maps(self, feat_vol, cost):
+        """plane-sweep feature volume [B,32,D,h,w] + plane scores [B,D,h,w] -> (cls [B,A,Z,X], reg [B,7A,Z,X], ctr [B,A,Z,X])"""
+        ops = self.ops
+        prob = torch.softmax(cost, dim=1)
+        grid, plan = self._gv(feat_vol.shape[0])
+        gv = ops.GridSample3d.apply((feat_vol * prob[:, None]).contiguous(), grid, plan)          # [B,32,Zg,Yg,Xg]
+        if self.mfma_conv:
+            gv = ops.Conv3dK3.apply(gv, self.gp3, self.gp3t, self.mid, None, self.gb3, True)
+        else:
+            gv = F.relu(F.conv3d(gv, self.g3, self.gb3, padding=1))
+        b, c, zg, yg, xg = gv.shape
+        bev = F.avg_pool3d(gv, (1, self.ypool, 1)).permute(0, 1, 3, 2, 4).reshape(b, c * (yg // self.ypool), zg, xg)
+        bev = F.relu(F.conv2d(bev, self.bev1, padding=1))
+        bev = F.relu(F.conv2d(bev, self.bev2, padding=1))
+        return (F.conv2d(bev, self.head_cls, padding=1) + self.cls_bias, F.conv2d(bev, self.head_reg, padding=1),
+                F.conv2d(bev, self.head_ctr, padding=1))
+
+    def detection_targets(self, boxes, zg, xg):
+        """boxes [[x, z, l, w, ry], ...] per image (metres) -> (cls targets int32 [B*Z*X*A], reg targets [B,7A,Z,X], ctr [B,A,Z,X])"""
+        v, a = self.VOXEL, self.ANCHORS
+        b = len(boxes)
+        cls = torch.zeros((b, zg, xg, a), dtype=torch.int32)
+        reg = torch.zeros((b, a * 7, zg, xg))
+        ctr = torch.zeros((b, a, zg, xg))
+        zc = float(self.depth[0]) + v * (torch.arange(zg, dtype=torch.float32) + 0.5)
+        xc = self.X_RANGE[0] + v * (torch.arange(xg, dtype=torch.float32) + 0.5)
+        for i, bl in enumerate(boxes):
+            for (x, z, l, wd, ry) in bl:
+                inz, inx = (zc - z).abs() <= wd / 2, (xc - x).abs() <= l / 2
+                m = inz[:, None] & inx[None, :]
+                if not bool(m.any()):
+                    continue
+                k = 0 if abs(ry) < 0.785 else 1                                   # anchor = nearest of the two orientations
+                cls[i, :, :, k][m] = 1
+                dz, dx = (z - zc)[:, None].expand(zg, xg), (x - xc)[None, :].expand(zg, xg)
+                vals = [dx, dz, torch.full_like(dx, l), torch.full_like(dx, wd), torch.full_like(dx, 1.5), torch.full_like(dx, 1.0),
+                        torch.full_like(dx, ry)]
+                for j, val in enumerate(vals):
+                    reg[i, k * 7 + j][m] = val[m]
+                ctr[i, k][m] = (1 - (dz.abs() / (wd / 2)).clamp(max=1))[m] * (1 - (dx.abs() / (l / 2)).clamp(max=1))[m]
+        dev = self.device
+        return cls.reshape(-1).contiguous().to(dev), reg.to(dev), ctr.to(dev)
+
+    def detection_loss(self, maps, targets):
+        """sigmoid focal / N_pos + smooth-L1 on the positives + BCE centerness on the positives (the three RPN3DLoss terms)"""
+        cls, reg, ctr = maps
+        tcls, treg, tctr = targets
+        b, a, zg, xg = cls.shape
+        logits = cls.permute(0, 2, 3, 1).reshape(-1, 1).contiguous()                       # [B*Z*X*A, 1]: one class ("Car")
+        npos = max(1, int((tcls > 0).sum().item()))
+        l_cls = self.ops.SigmoidFocalLoss.apply(logits, tcls, 2.0, 0.25) / npos
+        pos = (tcls > 0).view(b, zg, xg, a).permute(0, 3, 1, 2)                            # [B,A,Z,X]
+        posr = pos.repeat_interleave(7, dim=1)
+        if bool(pos.any()):
+            l_reg = F.smooth_l1_loss(reg[posr], treg[posr], reduction="sum") / npos
+            l_ctr = F.binary_cross_entropy_with_logits(ctr[pos], tctr[pos], reduction="sum") / npos
+        else:
+            l_reg = l_ctr = cls.sum() * 0
+        return l_cls + l_reg + l_ctr
+
     def shifts(self, b):
         disp = self.fu * self.baseline / self.depth / self.downsample       # feature-pixel disparity per plane
         if self.interp:
@@ -150,17 +266,21 @@ class PsvStereoAdapter:
         f = F.relu(F.conv2d(f, self.f2, stride=2, padding=1))
         return F.conv2d(f, self.f3, padding=1)
 
-    def _volume_net(self, cost):
-        """cost volume [B,64,D,h,w] -> per-plane scores [B,D,h,w]"""
+    def _volume_net(self, cost, with_features=False):
+        """cost volume [B,64,D,h,w] -> per-plane scores [B,D,h,w] (and the last feature volume [B,32,D,h,w])"""
+        score, feat = self._volume_net_impl(cost)
+        return (score, feat) if with_features else score
+
+    def _volume_net_impl(self, cost):
         ops = self.ops
         if not self.hourglass:
             if self.mfma_conv:
                 v = ops.Conv3dK3.apply(cost, self.p1, self.p1t, self.mid, None, None, True)
                 v = ops.Conv3dK3.apply(v, self.p2, self.p2t, self.mid, None, None, True)
-                return ops.Conv3dK3.apply(v, self.p3, self.p3t, 1).squeeze(1)
+                return ops.Conv3dK3.apply(v, self.p3, self.p3t, 1).squeeze(1), v
             v = F.relu(F.conv3d(cost, self.c1, padding=1))
             v = F.relu(F.conv3d(v, self.c2, padding=1))
-            return F.conv3d(v, self.c3, padding=1).squeeze(1)
+            return F.conv3d(v, self.c3, padding=1).squeeze(1), v
         g, hb, m2 = self.hg, self.hb, 2 * self.mid
         if self.mfma_conv:
             hp = self.hp
@@ -174,7 +294,7 @@ class PsvStereoAdapter:
             u1 = F.relu(u1 + s1)
             u2 = ops.ConvTranspose3dK3S2.apply(u1, hp["u2"][0], hp["u2"][1], self.mid, hb["u2"], False)
             u2 = F.relu(u2 + s0)
-            return ops.Conv3dK3.apply(u2, self.p3, self.p3t, 1).squeeze(1)
+            return ops.Conv3dK3.apply(u2, self.p3, self.p3t, 1).squeeze(1), u2
         s0 = F.relu(F.conv3d(cost, self.c1, self.b1, padding=1))
         s0 = F.relu(F.conv3d(s0, self.c2, self.b2, padding=1))
         s1 = F.relu(F.conv3d(s0, g["d1"], hb["d1"], stride=2, padding=1))
@@ -183,7 +303,7 @@ class PsvStereoAdapter:
         s2 = F.relu(F.conv3d(s2, g["m2"], hb["m2"], padding=1))
         u1 = F.relu(F.conv_transpose3d(s2, g["u1"], hb["u1"], stride=2, padding=1, output_padding=1) + s1)
         u2 = F.relu(F.conv_transpose3d(u1, g["u2"], hb["u2"], stride=2, padding=1, output_padding=1) + s0)
-        return F.conv3d(u2, self.c3, padding=1).squeeze(1)
+        return F.conv3d(u2, self.c3, padding=1).squeeze(1), u2
 
     def plane_prob(self, imgL, imgR):
         fl, fr = self.features(imgL), self.features(imgR)
@@ -245,23 +365,48 @@ class PsvStereoAdapter:
         return results
 
     def synthetic_extra(self, batch, seed=1):
-        """a sparse synthetic depth map per pair (5 % of the pixels, 2 .. 40.4 m) for runs without a dataset"""
+        """a sparse synthetic depth map per pair (5 % of the pixels, 2 .. 40.4 m) for runs without a dataset; with the
+        detection head also 1-4 car boxes per pair [x, z, l, w, ry] in metres"""
         import types
         b, hh, ww = len(batch), batch.imgL.shape[2], batch.imgL.shape[3]
         gen = torch.Generator().manual_seed(seed)
         gt = torch.rand((b, hh, ww), generator=gen) * 38.4 + 2.0
         gt = torch.where(torch.rand((b, hh, ww), generator=gen) < 0.05, gt, torch.zeros(()))
-        return types.SimpleNamespace(disp_true=gt.to(self.device))
+        extra = types.SimpleNamespace(disp_true=gt.to(self.device))
+        if self.dsgn_head:
+            boxes = []
+            for _ in range(b):
+                n = int(torch.randint(1, 5, (1,), generator=gen))
+                r = torch.rand((n, 5), generator=gen)
+                boxes.append([(float(-20 + 40 * q[0]), float(6 + 30 * q[1]), 3.9, 1.6, float(-1.57 + 3.14 * q[4])) for q in r])
+            extra.boxes = boxes
+        return extra
+
+    def forward_all(self, imgL, imgR):
+        """-> (depth [B,H,W], detection maps or None): the whole DSGN-shaped graph"""
+        fl, fr = self.features(imgL), self.features(imgR)
+        build = self.ops.PsvBuildLerp if self.interp else self.ops.PsvBuild
+        cost = build.apply(fl.contiguous(), fr.contiguous(), self.shifts(imgL.shape[0]))
+        score, feat = self._volume_net(cost, with_features=True)
+        depth = self.ops.DepthRegress.apply(score.contiguous(), self.depth_up, self.up_size, False)
+        return depth, self.detection_maps(feat, score)
 
     def loss_and_grad(self, x, extra):
         """extra.disp_true [B,H,W] sparse metric depth (0 = no measurement); mask as pgd_attack.py:269"""
         h = _LeafGrad(x)
         with h as leaf:
             imgL, imgR = split_eyes(leaf)
-            pred = self.depth_pred(imgL, imgR)
             gt = extra.disp_true
             mask = (gt > float(self.depth[0])) & (gt <= float(self.depth[-1]) + 0.8)
-            loss = F.smooth_l1_loss(pred[mask], gt[mask], reduction="mean")
+            if self.dsgn_head:      # pgd_attack.py:310-336: depth term + the detection head's three terms
+                pred, maps = self.forward_all(imgL, imgR)
+                key = id(extra)
+                if getattr(self, "_tgt_key", None) != key:     # targets depend on the labels only: once per batch, not per PGD step
+                    self._tgt, self._tgt_key = self.detection_targets(extra.boxes, maps[0].shape[2], maps[0].shape[3]), key
+                loss = F.smooth_l1_loss(pred[mask], gt[mask], reduction="mean") + self.detection_loss(maps, self._tgt)
+            else:
+                pred = self.depth_pred(imgL, imgR)
+                loss = F.smooth_l1_loss(pred[mask], gt[mask], reduction="mean")
             loss.backward()
             return loss.detach(), h.take()
 

@@ -1,0 +1,69 @@
+"""adapters.PsvStereoAdapter(dsgn_head=True): the DSGN-shaped graph on libadvengine's kernels - fused depth
+regression, plane-sweep -> 3D geometric volume resampling, 3D convolution, bird's-eye-view heads, focal loss - against the same
+graph written with torch's own operators (F.interpolate + softmax, F.grid_sample, F.conv3d, an autograd focal loss)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+
+def _torch_reference_loss(net, x, extra, targets):
+    b = x.shape[0] // 2
+    imgL, imgR = x[:b], x[b:]
+    fl, fr = net.features(imgL), net.features(imgR)
+    cost = net.ops.PsvBuildLerp.apply(fl.contiguous(), fr.contiguous(), net.shifts(b))
+    mfma, net.mfma_conv = net.mfma_conv, False
+    try:
+        score, feat = net._volume_net(cost, with_features=True)
+        up = F.interpolate(score[:, None], size=net.up_size, mode="trilinear", align_corners=False)[:, 0]
+        depth = (torch.softmax(up, 1) * net.depth_up.view(1, -1, 1, 1)).sum(1)
+        prob = torch.softmax(score, dim=1)
+        grid = net.gv_grid.expand(b, -1, -1, -1, -1)
+        gv = F.grid_sample(feat * prob[:, None], grid, mode="bilinear", padding_mode="zeros", align_corners=True)
+        gv = F.relu(F.conv3d(gv, net.g3, net.gb3, padding=1))
+    finally:
+        net.mfma_conv = mfma
+    bb, c, zg, yg, xg = gv.shape
+    bev = F.avg_pool3d(gv, (1, net.ypool, 1)).permute(0, 1, 3, 2, 4).reshape(bb, c * (yg // net.ypool), zg, xg)
+    bev = F.relu(F.conv2d(F.relu(F.conv2d(bev, net.bev1, padding=1)), net.bev2, padding=1))
+    cls = F.conv2d(bev, net.head_cls, padding=1) + net.cls_bias
+    reg, ctr = F.conv2d(bev, net.head_reg, padding=1), F.conv2d(bev, net.head_ctr, padding=1)
+    tcls, treg, tctr = targets
+    logits = cls.permute(0, 2, 3, 1).reshape(-1)
+    t = tcls.float()
+    p = torch.sigmoid(logits)
+    focal = -(t * 0.25 * (1 - p) ** 2 * F.logsigmoid(logits) + (1 - t) * 0.75 * p ** 2 * F.logsigmoid(-logits)).sum()
+    npos = max(1, int((tcls > 0).sum()))
+    pos = (tcls > 0).view(bb, zg, xg, -1).permute(0, 3, 1, 2)
+    posr = pos.repeat_interleave(7, dim=1)
+    det = focal / npos + F.smooth_l1_loss(reg[posr], treg[posr], reduction="sum") / npos + \
+        F.binary_cross_entropy_with_logits(ctr[pos], tctr[pos], reduction="sum") / npos
+    gt = extra.disp_true
+    mask = (gt > float(net.depth[0])) & (gt <= float(net.depth[-1]) + 0.8)
+    return F.smooth_l1_loss(depth[mask], gt[mask], reduction="mean") + det
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hourglass", [False, True])
+def test_dsgn_shaped_graph_matches_torch_operators(hourglass):
+    from eval_driving_safety_amd import adapters, data
+    dev = torch.device("cuda", 0)
+    hw = (96, 160)
+    net = adapters.PsvStereoAdapter(dev, seed=3, hourglass=hourglass, dsgn_head=True, image_hw=hw, cu=80.0, cv=44.0, fu=180.0)
+    gen = torch.Generator().manual_seed(11)
+    left = torch.randn((2, 3) + hw, generator=gen)
+    batch = data.StereoBatch(left, torch.roll(left, shifts=-6, dims=3) + 0.05 * torch.randn((2, 3) + hw, generator=gen), ["000000", "000001"], None)
+    extra = net.synthetic_extra(batch, seed=2)
+    x = torch.cat([batch.imgL, batch.imgR]).to(dev)
+    loss, grad = net.loss_and_grad(x, extra)
+    assert torch.isfinite(loss) and torch.isfinite(grad).all() and float(grad.abs().max()) > 0
+    loss2, grad2 = net.loss_and_grad(x, extra)
+    assert float(loss2) == float(loss) and torch.equal(grad, grad2), "the whole graph is reproducible bit for bit"
+    xr = x.clone().requires_grad_(True)
+    ref = _torch_reference_loss(net, xr, extra, net._tgt)
+    ref.backward()
+    assert abs(float(ref) - float(loss)) <= 2e-4 * max(1.0, abs(float(ref)))
+    scale = float(xr.grad.abs().max())
+    assert float((xr.grad - grad).abs().max()) <= 5e-3 * scale        # float32 through ~15 layers, two summation orders
+    # the attack direction is what the PGD step consumes: the signs agree wherever the gradient is not at rounding level
+    big = xr.grad.abs() > 1e-2 * scale
+    assert float((torch.sign(xr.grad[big]) == torch.sign(grad[big])).float().mean()) > 0.999

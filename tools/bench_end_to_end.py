@@ -16,15 +16,17 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from eval_driving_safety_amd import adapters, attacks, data  # noqa: E402
 
 
-def measure(pairs=1, iters=20, reps=2, warm_iters=None, mfma_conv=True, hourglass=False):
+def measure(pairs=1, iters=20, reps=2, warm_iters=None, mfma_conv=True, hourglass=False, dsgn_head=False):
     """-> dict; the first (untimed) attack absorbs MIOpen's solver search"""
     dev = torch.device("cuda", torch.cuda.current_device())
-    net = adapters.PsvStereoAdapter(dev, seed=0, mfma_conv=mfma_conv, hourglass=hourglass)
+    net = adapters.PsvStereoAdapter(dev, seed=0, mfma_conv=mfma_conv, hourglass=hourglass, dsgn_head=dsgn_head)
     batch = next(iter(data.SyntheticStereo(pairs, "dsgn", batch=pairs, seed=0)))
     gen = torch.Generator().manual_seed(1)
     gt = torch.rand((pairs, 384, 1248), generator=gen) * 38.4 + 2.0
     gt = torch.where(torch.rand((pairs, 384, 1248), generator=gen) < 0.05, gt, torch.zeros(()))
     batch.extra = types.SimpleNamespace(disp_true=gt.to(dev))
+    if dsgn_head:
+        batch.extra.boxes = net.synthetic_extra(batch, seed=1).boxes
     warm = attacks.PgdAttack("dsgn", 1 / 255, 0.03, warm_iters if warm_iters else iters, save=False, device=dev)
     warm.run_batch(batch, net)
     torch.cuda.synchronize()
@@ -69,8 +71,13 @@ def measure(pairs=1, iters=20, reps=2, warm_iters=None, mfma_conv=True, hourglas
         "convs": ("libadvengine float32-MFMA conv3d (all 3D layers, forward and adjoint; the 32->1 score layer on the narrow vector-ALU kernels)" if mfma_conv else "torch / MIOpen"),
         "volume_net": ("3D hourglass: 64->32, 32->32, 32->64 /2, 64->64, 64->64 /2, 64->64, transposed 64->64 + skip, transposed 64->32 + skip, 32->1"
                        if hourglass else "three convolutions 64->32->32->1"),
+        "head": ("DSGN-shaped: fused trilinear-upsample+softmax+expectation depth over 192 planes (ops.DepthRegress), plane-sweep features x "
+                 "plane probability -> grid_sample into a [B,32,192,20,304] 3D geometric volume (ops.GridSample3d, deterministic gather "
+                 "backward), conv3d, bird's-eye-view 2D convolutions, focal + smooth-L1 + BCE detection loss" if dsgn_head
+                 else "soft-argmin depth at 1/4 resolution + bilinear up-sampling, smooth-L1"),
         "note": "NOT the headline metric and NOT DSGN: 2D features -> HIP plane-sweep volume [B,64,48,96,312] (fractional disparities) -> "
-                "3D convolutions -> soft-argmin depth -> smooth-L1; dtype f32; cost volume + convolutions + PGD step by libadvengine.so"}
+                "3D convolutions -> depth (and detection) head -> loss; dtype f32; cost volume + convolutions + head kernels + PGD step by "
+                "libadvengine.so"}
 
 
 def main():
@@ -80,9 +87,10 @@ def main():
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--miopen", action="store_true", help="route the wide convolutions through torch / MIOpen instead")
     ap.add_argument("--hourglass", action="store_true", help="the 3D-hourglass volume network instead of three convolutions")
+    ap.add_argument("--dsgn-head", action="store_true", help="fused depth regression + 3D geometric volume + bird's-eye-view detection head")
     args = ap.parse_args()
     torch.cuda.set_device(0)
-    print(json.dumps(measure(args.pairs, args.iters, args.reps, mfma_conv=not args.miopen, hourglass=args.hourglass)))
+    print(json.dumps(measure(args.pairs, args.iters, args.reps, mfma_conv=not args.miopen, hourglass=args.hourglass, dsgn_head=args.dsgn_head)))
 
 
 if __name__ == "__main__":

@@ -182,9 +182,73 @@ def roi(dev):
                               single_gathers_ms=round(ms_d, 4), speedup=round(ms_d / ms, 2))))
 
 
+def volume(dev):
+    """csrc/volume.hip at the DSGN sizes, against torch's unfused operators"""
+    import torch.nn.functional as F
+    D, h, w = 48, 96, 312
+    up = (192, 384, 1248)
+    cost = torch.randn((1, D, h, w), device=dev)
+    zv = torch.linspace(2.0, 40.4, 192, device=dev)
+    g = torch.randn((1, 384, 1248), device=dev)
+    ms = timeit(lambda: ops.depth_regress(cost, zv, up, False, with_stats=True), reps=10)
+    depth, stats = ops.depth_regress(cost, zv, up, False, with_stats=True)
+    ms_b = timeit(lambda: ops.depth_regress_bwd(cost, zv, depth, stats, g, False), reps=10)
+
+    def torch_fwd():
+        u = F.interpolate(cost[:, None], size=up, mode="trilinear", align_corners=False)[:, 0]
+        return (torch.softmax(u, 1) * zv.view(1, -1, 1, 1)).sum(1)
+
+    ms_t = timeit(torch_fwd, reps=5)
+    cr = cost.clone().requires_grad_(True)
+
+    def torch_fb():
+        u = F.interpolate(cr[:, None], size=up, mode="trilinear", align_corners=False)[:, 0]
+        ((torch.softmax(u, 1) * zv.view(1, -1, 1, 1)).sum(1) * g).sum().backward()
+
+    ms_tb = timeit(torch_fb, reps=5)
+    print(json.dumps(dict(kernel="depth_regress fused [1,48,96,312] -> 192 planes -> [1,384,1248]", fwd_ms=round(ms, 4), bwd_ms=round(ms_b, 4),
+                          torch_unfused_fwd_ms=round(ms_t, 3), torch_unfused_fwd_bwd_ms=round(ms_tb, 3),
+                          speedup_fwd=round(ms_t / ms, 1), speedup_fwd_bwd=round(ms_tb / (ms + ms_b), 1))))
+    C, zo, yo, xo = 32, 192, 20, 304
+    vol = torch.randn((1, C, D, h, w), device=dev)
+    net_grid = adapters_grid(dev)
+    out_bytes = C * zo * yo * xo * 4
+    ms = timeit(lambda: ops.grid_sample3d(vol, net_grid, True), reps=10)
+    F.grid_sample(vol, net_grid, mode="bilinear", padding_mode="zeros", align_corners=True)
+    ms_t = timeit(lambda: F.grid_sample(vol, net_grid, mode="bilinear", padding_mode="zeros", align_corners=True), reps=10)
+    t0 = timeit(lambda: ops.GridSamplePlan(net_grid, (D, h, w), True), reps=3, warm=1)
+    plan = ops.GridSamplePlan(net_grid, (D, h, w), True)
+    go = torch.randn((1, C, zo, yo, xo), device=dev)
+    ms_b = timeit(lambda: ops.grid_sample3d_bwd(go, plan), reps=10)
+    vr = vol.clone().requires_grad_(True)
+
+    def torch_gs_fb():
+        F.grid_sample(vr, net_grid, mode="bilinear", padding_mode="zeros", align_corners=True).backward(go)
+
+    ms_tb = timeit(torch_gs_fb, reps=5)
+    print(json.dumps(dict(kernel="grid_sample3d [1,32,48,96,312] -> [1,32,192,20,304] (DSGN PSV -> 3DGV)", fwd_ms=round(ms, 4),
+                          fwd_GBps=round((out_bytes + vol.numel() * 4) / ms / 1e6, 1), torch_fwd_ms=round(ms_t, 4), bwd_gather_ms=round(ms_b, 4),
+                          torch_fwd_bwd_ms=round(ms_tb, 4), plan_build_ms_once_per_calibration=round(t0, 3),
+                          plan_MB=round(plan.buf.numel() * 4 / 1e6, 1))))
+    n = 2 * 192 * 304
+    x = torch.randn((n, 1), device=dev)
+    t = (torch.rand(n, device=dev) < 0.01).to(torch.int32)
+    ms = timeit(lambda: ops.sigmoid_focal_loss(x, t, 2.0, 0.25, want_grad=True), reps=20)
+    print(json.dumps(dict(kernel="sigmoid_focal_loss fwd+grad on %d logits" % n, ms=round(ms, 4))))
+
+
+def adapters_grid(dev):
+    from eval_driving_safety_amd import adapters
+    net = adapters.PsvStereoAdapter(dev, seed=0, dsgn_head=True, mfma_conv=False)
+    return net.gv_grid
+
+
 def main():
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
+    if "--volume" in sys.argv:
+        volume(dev)
+        return
     if "--roi" in sys.argv:
         roi(dev)
         return
