@@ -331,8 +331,9 @@ class PsvStereoAdapter:
         (score + box regression per cell) -> the ``topk`` cells by score -> greedy NMS on their bird's-eye-view footprints
         (``ops.nms``, deterministic) -> 3D boxes and their projected 2D boxes.  Random weights: the boxes mean nothing, the
         PIPELINE (attacked images -> detector -> label files -> scenario conversion) is what this exercises."""
-        import math
         b = x.shape[0] // 2
+        if self.dsgn_head:
+            return self._detect_bev(x, topk, nms_thresh, cu, cv)
         with torch.no_grad():
             prob = self.plane_prob(x[:b], x[b:])
             w1, w2 = self._bev_weights()
@@ -361,6 +362,42 @@ class PsvStereoAdapter:
                     vs = [(cy_ + sy * h_ / 2) * self.fu / cz_ + cv for sy in (-1, 1)]
                     bbox = [min(us), min(vs), max(us), max(vs)]
                     dets.append((2, bbox, float(score[top][k]), [cx_, cy_, cz_], (h_, w_, l_, float(ry[k]))))
+                results.append(dets)
+        return results
+
+    def _detect_bev(self, x, topk, nms_thresh, cu, cv):
+        """the DSGN-shaped head's detections: score = sigmoid(cls) * sigmoid(centerness) per (anchor, BEV cell) -> top-k ->
+        box decode (cell centre + regressed offsets / size / height / angle) -> deterministic NMS on the BEV footprints"""
+        b = x.shape[0] // 2
+        v = self.VOXEL
+        with torch.no_grad():
+            _, (cls, reg, ctr) = self.forward_all(x[:b], x[b:])
+            a, zg, xg = cls.shape[1:]
+            score_map = torch.sigmoid(cls) * torch.sigmoid(ctr)
+            results = []
+            for i in range(b):
+                score = score_map[i].reshape(-1)
+                top = torch.argsort(score, descending=True, stable=True)[:topk]
+                k = torch.div(top, zg * xg, rounding_mode="floor")
+                zi = torch.div(top % (zg * xg), xg, rounding_mode="floor")
+                xi = top % xg
+                r = reg[i].view(a, 7, zg, xg)[k, :, zi, xi]                                   # [K,7]: dx dz l w h y ry
+                xc = self.X_RANGE[0] + v * (xi.float() + 0.5) + r[:, 0]
+                z = float(self.depth[0]) + v * (zi.float() + 0.5) + r[:, 1]
+                z = z.clamp(min=1.0)
+                ll, ww, hh = 3.9 + torch.tanh(r[:, 2]), 1.6 + 0.3 * torch.tanh(r[:, 3]), 1.5 + 0.3 * torch.tanh(r[:, 4])
+                yc = 1.0 + 0.5 * torch.tanh(r[:, 5])
+                ry = torch.where(k == 0, torch.zeros_like(z), torch.full_like(z, 1.5708)) + 0.785 * torch.tanh(r[:, 6])
+                foot = torch.stack([xc - ll / 2, z - ww / 2, xc + ll / 2, z + ww / 2], 1) * 10.0      # decimetres, as in detect()
+                sc = score[top].contiguous()
+                keep = self.ops.nms(foot.contiguous(), sc, nms_thresh)
+                dets = []
+                for j in keep.tolist():
+                    cx_, cy_, cz_ = float(xc[j]), float(yc[j]), float(z[j])
+                    h_, w_, l_ = float(hh[j]), float(ww[j]), float(ll[j])
+                    us = [(cx_ + sx * l_ / 2) * self.fu / cz_ + cu for sx in (-1, 1)]
+                    vs = [(cy_ + sy * h_ / 2) * self.fu / cz_ + cv for sy in (-1, 1)]
+                    dets.append((2, [min(us), min(vs), max(us), max(vs)], float(sc[j]), [cx_, cy_, cz_], (h_, w_, l_, float(ry[j]))))
                 results.append(dets)
         return results
 
@@ -400,7 +437,7 @@ class PsvStereoAdapter:
             mask = (gt > float(self.depth[0])) & (gt <= float(self.depth[-1]) + 0.8)
             if self.dsgn_head:      # pgd_attack.py:310-336: depth term + the detection head's three terms
                 pred, maps = self.forward_all(imgL, imgR)
-                key = id(extra)
+                key = (id(extra), id(extra.boxes))
                 if getattr(self, "_tgt_key", None) != key:     # targets depend on the labels only: once per batch, not per PGD step
                     self._tgt, self._tgt_key = self.detection_targets(extra.boxes, maps[0].shape[2], maps[0].shape[3]), key
                 loss = F.smooth_l1_loss(pred[mask], gt[mask], reduction="mean") + self.detection_loss(maps, self._tgt)
@@ -411,7 +448,12 @@ class PsvStereoAdapter:
             return loss.detach(), h.take()
 
     def inject_fake_target(self, extra, centers_l, centers_r, radius):
-        pass
+        """attack/DSGN/patch_attack.py:336-354 for the detection head: every ground-truth box is dropped and ONE fake car is
+        put where the reference puts it - box3d (h, w, l, x, y, z, theta) = (1.65, 1.67, 3.64, -0.78, 1.98, 29.11, -1.60)"""
+        if self.dsgn_head and hasattr(extra, "boxes"):
+            from . import patchgeom
+            h, w, l, x, y, z, th = patchgeom.DSGN_FAKE_BOX3D
+            extra.boxes = [[(float(x), float(z), float(l), float(w), float(th))] for _ in extra.boxes]
 
 
 class DsgnAdapter:

@@ -35,7 +35,7 @@ def main(argv=None):
         if args.model == "toy":
             adapter, factory = adapters.ToyStereoAdapter(dev, seed=args.seed), base
         else:
-            adapter = adapters.PsvStereoAdapter(dev, seed=args.seed, hourglass=True)
+            adapter = adapters.PsvStereoAdapter(dev, seed=args.seed, hourglass=True, dsgn_head=True)
             factory = lambda: _common.WithExtra(base(), adapter.synthetic_extra)
     else:
         rt = _common.upstream_or_exit(lambda: upstream.DsgnRuntime(args, dev, attack=True))

@@ -34,7 +34,7 @@ def main(argv=None):
         if args.model == "toy":
             adapter = adapters.ToyStereoAdapter(dev, seed=args.seed)
         else:   # plane-sweep volume (HIP) -> 3D hourglass on the float32 matrix cores -> depth loss; synthetic sparse depth
-            adapter = adapters.PsvStereoAdapter(dev, seed=args.seed, hourglass=True)
+            adapter = adapters.PsvStereoAdapter(dev, seed=args.seed, hourglass=True, dsgn_head=True)
             loader = _common.WithExtra(loader, adapter.synthetic_extra)
     else:
         rt = _common.upstream_or_exit(lambda: upstream.DsgnRuntime(args, dev, attack=True))
