@@ -295,12 +295,41 @@ __device__ __forceinline__ void stage_commit(const Stage<TD>& st, const Plan<TD>
   }
 }
 
+// Tiles of the launch, linearised: (row tile, column tile) fastest, then the depth pair, then (batch element, block of 32 output
+// channels).  PERSISTENT workgroups walk them: gridDim.x = min(tiles, 2 per CU), workgroup i takes a contiguous share of the
+// tile range of "its" XCD (workgroups are dealt to the eight XCDs round-robin, so i % 8 is the XCD and each XCD's private L2 sees
+// neighbouring tiles - which share halo rows and weights - at about the same time), and the software pipeline runs ACROSS tiles:
+// the last stage of a tile fetches the first stage of the next one, so a workgroup pays the plan, the first global round trip and
+// the launch itself once, not once per tile.
+struct TileGrid {
+  int tiles_w, tiles_hw, nd, cblocks;
+  long long ntiles;
+};
+
+struct TilePos {
+  int w0, h0, d0, b, cob;
+};
+
+template <int TD>
+__device__ __forceinline__ TilePos tile_at(const TileGrid& tg, long long t) {
+  TilePos p;
+  const int xy = static_cast<int>(t % tg.tiles_hw);
+  t /= tg.tiles_hw;
+  p.d0 = static_cast<int>(t % tg.nd) * TD;
+  const int z = static_cast<int>(t / tg.nd);
+  p.w0 = (xy % tg.tiles_w) * kTW;
+  p.h0 = (xy / tg.tiles_w) * kTH;
+  p.b = z / tg.cblocks;
+  p.cob = z - p.b * tg.cblocks;
+  return p;
+}
+
 // MASKED = false: every tap, no branch in the unrolled tap loop (the ordinary convolution: operand reads run ahead of the
 // MFMAs); MASKED = true: taps are skipped by epi.tap_mask (one parity class of a transposed convolution).
 template <int TD, bool MASKED>
 __global__ __launch_bounds__(128 * TD, 2) void conv3d_k3_mfma(const float* __restrict__ x, const float* __restrict__ wp,
                                                               float* __restrict__ y, int Cin, int Cout, int cout_pad, int D, int H, int W,
-                                                              int tiles_w, int cblocks, Epi epi) {
+                                                              TileGrid tg, Epi epi) {
   using G = Geo<TD>;
   // before which (kd,kh) group of the tap loop the next stage is written to the other LDS buffer - in the shadow of this
   // stage's MFMAs instead of after them (measured: 64->32 1.468 -> 1.437 ms, 32->64 1.395 -> 1.32 ms at 6; the masked
@@ -309,106 +338,133 @@ __global__ __launch_bounds__(128 * TD, 2) void conv3d_k3_mfma(const float* __res
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l32 = lane & 31;
-  const int wt = blockIdx.x % tiles_w, ht = blockIdx.x / tiles_w;
-  const int w0 = wt * kTW, h0 = ht * kTH, d0 = blockIdx.y * TD;
-  const int b = blockIdx.z / cblocks, cob = blockIdx.z - b * cblocks;
-  const long long plane = static_cast<long long>(H) * W;
-  const long long vol = plane * D;
+  const int plane = H * W, vol = plane * D;  // < 2^31 (host-checked)
 
-  f32x16 acc[kNB];
-#pragma unroll
-  for (int i = 0; i < kNB; ++i)
-#pragma unroll
-    for (int v = 0; v < 16; ++v) acc[i][v] = 0.0f;
+  // this workgroup's tiles: t = first + k * step for k < count
+  long long first, step;
+  int count;
+  if ((gridDim.x & 7) == 0 && tg.ntiles >= 8) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per = gridDim.x >> 3;
+    const long long share = (tg.ntiles + 7) / 8, lo = xcd * share;
+    const long long mine = lo + share <= tg.ntiles ? share : (tg.ntiles > lo ? tg.ntiles - lo : 0);
+    first = lo + slot, step = per;
+    count = slot < mine ? static_cast<int>((mine - slot + per - 1) / per) : 0;
+  } else {
+    first = blockIdx.x, step = gridDim.x;
+    count = blockIdx.x < tg.ntiles ? static_cast<int>((tg.ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x) : 0;
+  }
+  if (count == 0) return;
 
   // two LDS stages: while the waves run the MFMAs of stage `cur`, the next chunk travels global -> registers ->
   // the other stage; ONE barrier per chunk
   Stage<TD> st;
   Plan<TD> pl;
-  make_plan<TD>(pl, tid, Cin, cout_pad, D, H, W, d0, h0, w0, static_cast<int>(plane), static_cast<int>(vol));
-  const float* xb = x + static_cast<long long>(b) * Cin * vol;
-  const float* wb = wp + cob * 32;
+  TilePos tp = tile_at<TD>(tg, first);
+  make_plan<TD>(pl, tid, Cin, cout_pad, D, H, W, tp.d0, tp.h0, tp.w0, plane, vol);
+  const float* xb = x + static_cast<long long>(tp.b) * Cin * vol;
+  const float* wb = wp + tp.cob * 32;
   stage_fetch<TD>(st, pl, xb, wb);
   stage_commit<TD>(st, pl, lds, lds + G::kSX, tid);
   __syncthreads();
   int cur = 0;
-  for (int c0 = 0; c0 < Cin; c0 += kFC) {
-    // no branch in the loop body: the last stage re-fetches ITSELF into the idle buffer (harmless), so that the loads, the
-    // commit's selects and LDS stores and the MFMAs are one basic block the scheduler can interleave
-    const int cn = c0 + kFC < Cin ? c0 + kFC : c0;
-    const float* sxc = lds + cur * G::kStageFloats;
-    const float* swc = sxc + G::kSX;
-    stage_fetch<TD>(st, pl, xb + cn * vol, wb + static_cast<long long>(cn) * cout_pad);
-    // the loads are issued HERE, a hundred MFMAs before the commit that consumes them: without the fence the scheduler sinks them
-    // next to their use and every wave sits in s_waitcnt vmcnt for a global-memory round trip per stage (PMC: 20 % of the wave
-    // cycles parked, 10 % without the fetch)
-    __builtin_amdgcn_sched_barrier(0);
-    const unsigned mask = MASKED ? chunk_mask(epi, c0) : kAllTaps;
+  for (int k = 0; k < count; ++k) {
+    f32x16 acc[kNB];
 #pragma unroll
-    for (int t9 = 0; t9 < 9; ++t9) {  // (kd, kh); fully unrolled so that LDS operand reads run ahead of their MFMAs
-      const int kd = t9 / 3, kh = t9 - kd * 3;
-      if (t9 == kCommitAt) {  // the next stage goes to the OTHER buffer in the shadow of this stage's MFMAs
-        float* nx = lds + (cur ^ 1) * G::kStageFloats;
-        stage_commit<TD>(st, pl, nx, nx + G::kSX, tid);
+    for (int i = 0; i < kNB; ++i)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[i][v] = 0.0f;
+    const TilePos cp = tp;  // the tile being accumulated (its results are stored after the stage loop)
+    for (int c0 = 0; c0 < Cin; c0 += kFC) {
+      // what the idle buffer receives during this stage: the tile's next stage; on its last stage the FIRST stage of the
+      // workgroup's next tile (new plan); on the very last stage of the workgroup the stage itself again (harmless) - so that the
+      // body below has no branch and the loads, the commit's selects and LDS stores and the MFMAs are one basic block
+      int cn = c0 + kFC;
+      if (cn >= Cin) {
+        if (k + 1 < count) {
+          tp = tile_at<TD>(tg, first + (k + 1) * step);
+          make_plan<TD>(pl, tid, Cin, cout_pad, D, H, W, tp.d0, tp.h0, tp.w0, plane, vol);
+          xb = x + static_cast<long long>(tp.b) * Cin * vol;
+          wb = wp + tp.cob * 32;
+          cn = 0;
+        } else {
+          cn = c0;
+        }
       }
+      const float* sxc = lds + cur * G::kStageFloats;
+      const float* swc = sxc + G::kSX;
+      stage_fetch<TD>(st, pl, xb + static_cast<long long>(cn) * vol, wb + static_cast<long long>(cn) * cout_pad);
+      // the loads are issued HERE, a hundred MFMAs before the commit that consumes them: without the fence the scheduler sinks
+      // them next to their use and every wave sits in s_waitcnt vmcnt for a global-memory round trip per stage (PMC: 20 % of
+      // the wave cycles parked, 10 % without the fetch)
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned mask = MASKED ? chunk_mask(epi, c0) : kAllTaps;
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        const int tap = t9 * 3 + kw;
-        if (MASKED && !((mask >> tap) & 1u)) continue;  // scalar branch, parity-class convolutions only
+      for (int t9 = 0; t9 < 9; ++t9) {  // (kd, kh); fully unrolled so that LDS operand reads run ahead of their MFMAs
+        const int kd = t9 / 3, kh = t9 - kd * 3;
+        if (t9 == kCommitAt) {  // the next stage goes to the OTHER buffer in the shadow of this stage's MFMAs
+          float* nx = lds + (cur ^ 1) * G::kStageFloats;
+          stage_commit<TD>(st, pl, nx, nx + G::kSX, tid);
+        }
 #pragma unroll
-        for (int kk = 0; kk < kFC / 2; ++kk) {
-          const int c = 2 * kk + half;
-          const float a = swc[(tap * kFC + c) * 32 + l32];
+        for (int kw = 0; kw < 3; ++kw) {
+          const int tap = t9 * 3 + kw;
+          if (MASKED && !((mask >> tap) & 1u)) continue;  // scalar branch, parity-class convolutions only
 #pragma unroll
-          for (int i = 0; i < kNB; ++i) {
-            const int row = wave * kNB + i;
-            const int td = row / kTH, th = row - td * kTH;
-            const float bv = sxc[((c * (TD + 2) + td + kd) * (kTH + 2) + th + kh) * kP + l32 + kw + 3];
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[i], 0, 0, 0);
+          for (int kk = 0; kk < kFC / 2; ++kk) {
+            const int c = 2 * kk + half;
+            const float a = swc[(tap * kFC + c) * 32 + l32];
+#pragma unroll
+            for (int i = 0; i < kNB; ++i) {
+              const int row = wave * kNB + i;
+              const int td = row / kTH, th = row - td * kTH;
+              const float bv = sxc[((c * (TD + 2) + td + kd) * (kTH + 2) + th + kh) * kP + l32 + kw + 3];
+              acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[i], 0, 0, 0);
+            }
           }
         }
       }
+      __syncthreads();
+      cur ^= 1;
     }
-    __syncthreads();
-    cur ^= 1;
-  }
-  // ---- epilogue: accumulator register v of lane l is D[cout = 8*(v/4) + 4*(l/32) + v%4][voxel = l%32].  The bias values of the
-  // lane's 16 channels are fetched once, the lattice position once per row; a store is then an add, a max and a pointer step.
-  const int co0 = cob * 32 + 4 * half;
-  const bool has_bias = epi.bias != nullptr;
-  float bz[16];
+    // ---- epilogue of tile cp: accumulator register v of lane l is D[cout = 8*(v/4) + 4*(l/32) + v%4][voxel = l%32].  The bias
+    // values of the lane's 16 channels are fetched once, the lattice position once per row; a store is then an add, a max and
+    // a pointer step.
+    const int co0 = cp.cob * 32 + 4 * half;
+    const bool has_bias = epi.bias != nullptr;
+    float bz[16];
 #pragma unroll
-  for (int v = 0; v < 16; ++v) {
-    const int co = co0 + 8 * (v >> 2) + (v & 3);
-    bz[v] = (has_bias && co < Cout) ? epi.bias[co] : 0.0f;
-  }
-  const int gw = w0 + l32, zw = gw * epi.sw + epi.fw;
-  const long long ovol = static_cast<long long>(epi.od) * epi.oh * epi.ow;
-  float* yb = y + (static_cast<long long>(b) * Cout + co0) * ovol;
+    for (int v = 0; v < 16; ++v) {
+      const int co = co0 + 8 * (v >> 2) + (v & 3);
+      bz[v] = (has_bias && co < Cout) ? epi.bias[co] : 0.0f;
+    }
+    const int gw = cp.w0 + l32, zw = gw * epi.sw + epi.fw;
+    const long long ovol = static_cast<long long>(epi.od) * epi.oh * epi.ow;
+    float* yb = y + (static_cast<long long>(cp.b) * Cout + co0) * ovol;
 #pragma unroll
-  for (int i = 0; i < kNB; ++i) {
-    const int row = wave * kNB + i;
-    const int td = row / kTH, th = row - td * kTH;
-    const int gd = d0 + td, gh = h0 + th;
-    const int zd = gd * epi.sd + epi.fd, zh = gh * epi.sh + epi.fh;
-    if (gd >= D || gh >= H || gw >= W || zd >= epi.od || zh >= epi.oh || zw >= epi.ow) continue;
-    float* yr = yb + (static_cast<long long>(zd) * epi.oh + zh) * epi.ow + zw;
-    if (cob * 32 + 32 <= Cout) {  // workgroup-uniform: all 32 output channels of the block exist - no per-store predicate
+    for (int i = 0; i < kNB; ++i) {
+      const int row = wave * kNB + i;
+      const int td = row / kTH, th = row - td * kTH;
+      const int gd = cp.d0 + td, gh = cp.h0 + th;
+      const int zd = gd * epi.sd + epi.fd, zh = gh * epi.sh + epi.fh;
+      if (gd >= D || gh >= H || gw >= W || zd >= epi.od || zh >= epi.oh || zw >= epi.ow) continue;
+      float* yr = yb + (static_cast<long long>(zd) * epi.oh + zh) * epi.ow + zw;
+      if (cp.cob * 32 + 32 <= Cout) {  // workgroup-uniform: all 32 output channels of the block exist - no per-store predicate
 #pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        float r = acc[i][v];
-        if (has_bias) r = r + bz[v];
-        if (epi.relu) r = r > 0.0f ? r : 0.0f;
-        yr[(8 * (v >> 2) + (v & 3)) * ovol] = r;
-      }
-    } else {
+        for (int v = 0; v < 16; ++v) {
+          float r = acc[i][v];
+          if (has_bias) r = r + bz[v];
+          if (epi.relu) r = r > 0.0f ? r : 0.0f;
+          yr[(8 * (v >> 2) + (v & 3)) * ovol] = r;
+        }
+      } else {
 #pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        const int cr = 8 * (v >> 2) + (v & 3);
-        float r = acc[i][v];
-        if (has_bias) r = r + bz[v];
-        if (epi.relu) r = r > 0.0f ? r : 0.0f;
-        if (co0 + cr < Cout) yr[cr * ovol] = r;
+        for (int v = 0; v < 16; ++v) {
+          const int cr = 8 * (v >> 2) + (v & 3);
+          float r = acc[i][v];
+          if (has_bias) r = r + bz[v];
+          if (epi.relu) r = r > 0.0f ? r : 0.0f;
+          if (co0 + cr < Cout) yr[cr * ovol] = r;
+        }
       }
     }
   }
@@ -641,6 +697,16 @@ int adv_conv3d_k3_prep_weights_f32(const float* w, float* w_prep, int cout, int 
   return adv_internal_finish_launch();
 }
 
+static int cu_count() {  // compute units of the current device (256 on MI355X); queried once per thread
+  static thread_local int cached = 0;
+  if (cached == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+    cached = n;
+  }
+  return cached;
+}
+
 static int launch_conv(const float* x, const float* w_prep, float* y, int b, int cin, int cout, int d, int h, int w, int stride,
                        const Epi& epi, hipStream_t st) {
   // (d, h, w) = input dims; the tile grid runs over the convolution's own output grid gd x gh x gw
@@ -683,14 +749,20 @@ static int launch_conv(const float* x, const float* w_prep, float* y, int b, int
                     getenv("ADV_CONV_GENERIC") == nullptr;
   // tile depth 2 (4 waves) and 4 (8 waves, one workgroup per CU) measured the same within 1-2 % (profiles/r01_conv3d_mfma.jsonl)
   if (fast) {
-    const dim3 grid(tiles_w * tiles_h, (d + 1) / 2, b * cblocks);
+    TileGrid tg;
+    tg.tiles_w = tiles_w, tg.tiles_hw = tiles_w * tiles_h, tg.nd = (d + 1) / 2, tg.cblocks = cblocks;
+    tg.ntiles = static_cast<long long>(tg.tiles_hw) * tg.nd * b * cblocks;
+    // persistent workgroups: two per CU (the LDS budget), a multiple of 8 so that each XCD walks its own contiguous tile range;
+    // ADV_CONV_ONE_TILE_PER_WG=1 launches one workgroup per tile instead (test hook / A-B)
+    long long wgs = 2LL * cu_count();
+    if (getenv("ADV_CONV_ONE_TILE_PER_WG") != nullptr || tg.ntiles < wgs) wgs = tg.ntiles;
+    if (wgs > 0x7fffffffLL) return ADV_EINVAL;
+    const dim3 grid(static_cast<unsigned>(wgs));
     const size_t lds = 2 * static_cast<size_t>(Geo<2>::kStageFloats) * sizeof(float);
     if (epi.tap_mask == kAllTaps && epi.class_channels == 0)
-      hipLaunchKernelGGL((conv3d_k3_mfma<2, false>), grid, dim3(Geo<2>::kThreads), lds, st, x, w_prep, y, cin, cout, cblocks * 32, d, h, w,
-                         tiles_w, cblocks, epi);
+      hipLaunchKernelGGL((conv3d_k3_mfma<2, false>), grid, dim3(Geo<2>::kThreads), lds, st, x, w_prep, y, cin, cout, cblocks * 32, d, h, w, tg, epi);
     else
-      hipLaunchKernelGGL((conv3d_k3_mfma<2, true>), grid, dim3(Geo<2>::kThreads), lds, st, x, w_prep, y, cin, cout, cblocks * 32, d, h, w,
-                         tiles_w, cblocks, epi);
+      hipLaunchKernelGGL((conv3d_k3_mfma<2, true>), grid, dim3(Geo<2>::kThreads), lds, st, x, w_prep, y, cin, cout, cblocks * 32, d, h, w, tg, epi);
   } else if (stride == 1) {
     const dim3 grid(tiles_w * tiles_h, (gd + kTD - 1) / kTD, b * cblocks);
     hipLaunchKernelGGL((conv3d_k3_mfma_generic<1>), grid, dim3(256), static_cast<size_t>(GenGeo<1>::kSX + kSW) * sizeof(float), st, x, w_prep, y,
