@@ -80,6 +80,40 @@ def measure(pairs=1, iters=20, reps=2, warm_iters=None, mfma_conv=True, hourglas
                 "libadvengine.so"}
 
 
+def measure_srcnn(pairs=1, iters=20, reps=2):
+    """20-step PGD in the Stereo R-CNN pixel space through surrogates.StereoRcnnShaped (siamese backbone + FPN, stereo RPN, ops.nms,
+    pyramid ops.RoIAlign 7x7 / 14x14 with the deterministic gather backward, six uncertainty-weighted losses) at 600x1987"""
+    from eval_driving_safety_amd import surrogates
+    dev = torch.device("cuda", torch.cuda.current_device())
+    model = surrogates.StereoRcnnShaped(seed=0).to(dev).eval()
+    net = adapters.StereoRcnnAdapter(model, torch.zeros(6, device=dev))
+    batch = next(iter(data.SyntheticStereo(pairs, "srcnn", batch=pairs, seed=0)))
+    batch.extra = surrogates.synthetic_srcnn_extra(batch, dev)
+    warm = attacks.PgdAttack("srcnn", 1.0, 0.03, 3, save=False, device=dev)
+    warm.run_batch(batch, net)
+    torch.cuda.synchronize()
+    atk = attacks.PgdAttack("srcnn", 1.0, 0.03, iters, save=False, device=dev)
+    x = torch.cat([batch.imgL, batch.imgR]).to(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        net.loss_and_grad(x, batch.extra)
+    e1.record()
+    torch.cuda.synchronize()
+    model_ms = e0.elapsed_time(e1) / 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        atk.run_batch(batch, net)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    first, last = float(atk.last_losses[0]), float(atk.last_losses[-1])
+    return {"metric": "end-to-end stereo-pairs/s, %d-step PGD through a Stereo R-CNN-shaped detector (surrogate, random weights), 600x1987" % iters,
+            "value": pairs / dt, "unit": "stereo-pairs/s", "pairs": pairs, "iters": iters, "s_per_attack": dt, "detector_fwd_bwd_ms": model_ms,
+            "loss_first_iter": first, "loss_last_iter": last, "loss_rose": last > first,
+            "note": "NOT the headline metric and NOT Stereo R-CNN: plain-convolution pyramid (torch / MIOpen) + stereo RPN + ops.nms + pyramid "
+                    "ops.RoIAlign (paired-load forward, atomic-free gather backward) + the six losses of stereo_rcnn.py; PGD step by libadvengine.so"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--pairs", type=int, default=1)
@@ -88,8 +122,12 @@ def main():
     ap.add_argument("--miopen", action="store_true", help="route the wide convolutions through torch / MIOpen instead")
     ap.add_argument("--hourglass", action="store_true", help="the 3D-hourglass volume network instead of three convolutions")
     ap.add_argument("--dsgn-head", action="store_true", help="fused depth regression + 3D geometric volume + bird's-eye-view detection head")
+    ap.add_argument("--srcnn", action="store_true", help="the Stereo R-CNN-shaped surrogate at 600x1987 instead")
     args = ap.parse_args()
     torch.cuda.set_device(0)
+    if args.srcnn:
+        print(json.dumps(measure_srcnn(args.pairs, args.iters, args.reps)))
+        return
     print(json.dumps(measure(args.pairs, args.iters, args.reps, mfma_conv=not args.miopen, hourglass=args.hourglass, dsgn_head=args.dsgn_head)))
 
 
