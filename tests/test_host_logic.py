@@ -76,6 +76,21 @@ def test_argument_errors_without_a_gpu():
     assert lib.adv_patch_paste_f32(p, p, 4, 4, 4, 2, 2, 1, None) == _lib.ADV_EINVAL      # d != 2r+1
     lib.adv_space_srcnn(ctypes.byref(s))
     assert lib.adv_denormalize_f32(p, p, 1, 2, 2, ctypes.byref(s), None) == _lib.ADV_EINVAL
+    # the detector-side entry points validate before launching too
+    assert lib.adv_conv3d_k3_f32(p, p, p, 1, 6, 8, 2, 2, 4, 0, None) == _lib.ADV_EINVAL               # Cin neither 1..3 nor a multiple of 4
+    assert lib.adv_conv3d_k3_f32(p, None, p, 1, 4, 8, 2, 2, 4, 0, None) == _lib.ADV_EINVAL
+    assert lib.adv_depth_regress_f32(None, p, p, None, 1, 2, 2, 2, 4, 4, 4, 0, None) == _lib.ADV_EINVAL
+    assert lib.adv_depth_regress_f32(p, p, p, None, 1, 2, 2, 2, 0, 4, 4, 0, None) == _lib.ADV_EINVAL
+    assert lib.adv_depth_regress_f32(odd, p, p, None, 1, 2, 2, 2, 4, 4, 4, 0, None) == _lib.ADV_EALIGN
+    assert lib.adv_depth_regress_bwd_f32(p, p, p, p, p, None, p, 1, 2, 2, 2, 4, 4, 4, 0, None) == _lib.ADV_EINVAL   # no workspace
+    assert lib.adv_grid_sample3d_f32(p, None, p, 1, 1, 2, 2, 2, 2, 2, 2, 0, None) == _lib.ADV_EINVAL
+    assert lib.adv_grid_sample3d_plan_bytes(1, 2, 3, 4, 5, 6, 7) == 4 * ((24 + 1) + 24 + 2 + 2 * 8 * 210)
+    assert lib.adv_grid_sample3d_plan_bytes(1, 2048, 2048, 2048, 2, 2, 2) == 0                          # beyond a 32-bit plan
+    assert lib.adv_grid_sample3d_plan_f32(p, None, 1, 2, 2, 2, 2, 2, 2, 0, None) == _lib.ADV_EINVAL
+    assert lib.adv_grid_sample3d_bwd_f32(p, p, p, 1, 0, 2, 2, 2, 2, 2, 2, None) == _lib.ADV_EINVAL
+    assert lib.adv_sigmoid_focal_loss_f32(p, p, None, None, 4, 1, 2.0, 0.25, None) == _lib.ADV_EINVAL   # nothing to write
+    assert lib.adv_sigmoid_focal_loss_f32(p, p, p, None, 0, 1, 2.0, 0.25, None) == _lib.ADV_OK          # empty input: nothing to do
+    assert lib.adv_roi_align_fwd_f32(p, p, p, 1, 1, 2, 2, 0, 2, 2, 0.25, 2, None) == _lib.ADV_OK        # zero rois
 
 
 def test_ops_refuse_cpu_tensors():
