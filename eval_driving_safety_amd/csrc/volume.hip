@@ -278,6 +278,7 @@ __global__ __launch_bounds__(kBlock) void grid_sample3d_fwd(const float* __restr
   const long long ivol = static_cast<long long>(D) * H * W;
   const float* vp = vol + static_cast<long long>(b) * C * ivol;
   float* op = out + static_cast<long long>(b) * C * ovol + o;
+  // (pairing the two x-neighbours of a corner pair into one 8-byte load, which helps RoIAlign's forward, measured 0.148 vs 0.140 ms here: dropped)
   for (int c = 0; c < C; ++c, vp += ivol, op += ovol) {
     float acc = 0.0f;
 #pragma unroll
@@ -422,7 +423,7 @@ __global__ __launch_bounds__(kBlock) void plan_sort(PlanView pv, long long cells
 
 // grad_vol[b,c,cell] = sum over the cell's list, in list order, of grad_out[b,c,voxel] * weight.  One lane per cell (x fastest),
 // kGsChan channels at a time so that a list entry is read once per channel block.
-constexpr int kGsChan = 8;
+constexpr int kGsChan = 16;  // measured at the DSGN size: 8 -> 0.603 ms, 16 -> 0.541 ms, 32 -> 0.657 ms
 
 __global__ __launch_bounds__(kBlock) void grid_sample3d_bwd(const float* __restrict__ gout, PlanView pv, float* __restrict__ gvol, int C,
                                                             long long ivol, long long ovol) {
