@@ -234,7 +234,7 @@ class PgdBench:
 
     def attack(self, ev0=None, ev1=None):
         ops, sp = self.ops, self.sp
-        if not self.affine:
+        if not self.affine and not self.use_index:
             self.clean.copy_(self.x0)        # explicit clone of the clean pair (Stereo R-CNN pgd_attack.py:122-123, quirk Q6)
             ops.export_u8(self.x0, sp, self.crop, out=self.u8)
         elif self.use_index:                 # denormalize + per-image verified 8-bit index + iterate-0 export, one pass
@@ -245,7 +245,7 @@ class PgdBench:
             ops.export_u8(self.x0, sp, self.crop, out=self.u8)
         if ev0 is not None:
             ev0.record()
-        kw = {"clean_index": self.cidx} if (self.affine and self.use_index) else {}
+        kw = {"clean_index": self.cidx} if self.use_index else {}
         cur, nxt = self.x0, self.a
         for _ in range(N_ITER):
             ops.pgd_step(cur, self.grad, self.clean, sp, ALPHA, EPS, out=nxt, u8_out=self.u8, crop=self.crop, **kw)
@@ -332,7 +332,7 @@ def main():
         x0, valid = kitti_like_input(torch, ops, sp, args.pairs, dev, gen, padded=not args.unpadded)
     grad = torch.randn((n_img, 3, H, W), device=dev, generator=gen)
     crop = (CROP_H, CROP_W)
-    use_index = (not srcnn) and (not args.no_clean_index)
+    use_index = not args.no_clean_index
     main_b = PgdBench(torch, ops, sp, x0, grad, valid, crop, use_index, (not args.alternate), affine=not srcnn)
     elapsed, kern_ms = main_b.timed(args.steps, args.warmup, fence)
     if use_dist:
@@ -361,7 +361,7 @@ def main():
         del fb
 
     if rank == 0:
-        kern_name = ("pgd_step_shifted<IDENTITY>" if srcnn else ("pgd_step_vec4_idx<U8_ROWS_DWORD>" if n_indexed else "pgd_step_vec4<AFFINE,U8_ROWS_DWORD>"))
+        kern_name = (("pgd_step_shifted<IDENTITY,IDX>" if n_indexed else "pgd_step_shifted<IDENTITY>") if srcnn else ("pgd_step_vec4_idx<U8_ROWS_DWORD>" if n_indexed else "pgd_step_vec4<AFFINE,U8_ROWS_DWORD>"))
         traffic, traffic_src = (None, None) if srcnn else pmc_traffic(args.pairs, "pgd_step_vec4_idx<1>" if n_indexed else "pgd_step_vec4<0, 1>")
         out = {
             "metric": "KITTI stereo-pairs/sec for 20-step PGD on %s (perturbation path; detector fwd+bwd is the caller's)"
@@ -468,7 +468,7 @@ def main():
         dist.destroy_process_group()
 
 
-def srcnn_object(torch, ops, dev, fence, pairs=64, steps=3):
+def srcnn_object(torch, ops, dev, fence, pairs=64, steps=3, use_index=True):
     """BASELINE configs[2] beside the headline: 20-step PGD in the Stereo R-CNN pixel space (attack/Stereo-RCNN/
     pgd_attack.py:177-243) on 600x1987 pairs, alpha 1.0, eps 0.03*255, 8-bit export of every iterate."""
     global ALPHA, EPS
@@ -481,16 +481,30 @@ def srcnn_object(torch, ops, dev, fence, pairs=64, steps=3):
     keep = (ALPHA, EPS)
     ALPHA, EPS = 1.0, 255 * 0.03
     try:
-        b = PgdBench(torch, ops, sp, x0, grad, (SR_H, SR_W), (SR_H, SR_W), False, False, affine=False)
+        b = PgdBench(torch, ops, sp, x0, grad, None, (SR_H, SR_W), use_index, True, affine=False)
         elapsed, kern_ms = b.timed(steps, 1, fence)
+        verified = sum(b.cidx.verified()) if b.cidx is not None else 0
+        fl = None
+        if use_index:                        # the all-float32 kernel beside it, as the headline does
+            bf = PgdBench(torch, ops, sp, x0, grad, None, (SR_H, SR_W), False, True, affine=False)
+            el_f, k_f = bf.timed(steps, 1, fence)
+            fl = {"value": pairs * steps / el_f, "unit": "stereo-pairs/s", "kernel": "pgd_step_shifted<IDENTITY>", "avg_launch_ms": k_f}
     finally:
         ALPHA, EPS = keep
     alg = n_img * (16 * 3 * SR_H * SR_W + 3 * SR_H * SR_W)
-    return {"metric": "stereo-pairs/s, 20-step PGD in the Stereo R-CNN pixel space (perturbation path)", "value": pairs * steps / elapsed,
-            "unit": "stereo-pairs/s", "pairs": pairs, "steps": steps, "ms_per_step": 1e3 * elapsed / steps,
-            "roofline": {"bound": "hbm", "kernel": "pgd_step_shifted<IDENTITY>", "achieved": alg / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": alg / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": kern_ms,
-                         "algorithmic_bytes_per_launch": alg}}
+    moved = alg - (3 * verified * 3 * SR_H * SR_W if use_index else 0)
+    out = {"metric": "stereo-pairs/s, 20-step PGD in the Stereo R-CNN pixel space (perturbation path)", "value": pairs * steps / elapsed,
+           "unit": "stereo-pairs/s", "pairs": pairs, "steps": steps, "ms_per_step": 1e3 * elapsed / steps,
+           "roofline": {"bound": "hbm", "kernel": "pgd_step_shifted<IDENTITY%s>" % (",IDX" if use_index else ""),
+                        "achieved": alg / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": alg / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": kern_ms,
+                        "algorithmic_bytes_per_launch": alg, "bytes_moved_per_launch_by_design": moved,
+                        "hbm_utilisation_by_design_bytes": moved / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "clean_image_read_as": ("uint8 index for %d of %d images (verified per image on the device)" % (verified, n_img)
+                                                if use_index else "float32")}}
+    if fl is not None:
+        out["float_path"] = fl
+    return out
 
 
 if __name__ == "__main__":

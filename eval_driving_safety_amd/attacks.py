@@ -134,8 +134,8 @@ class PgdAttack:
         #  padding beyond each image's own (h, w) is part of what is verified.)
         cidx = None
         want0 = self._wanted(0)                      # iterate 0 = the un-attacked pair, :279-294
-        if sp.affine and getattr(ops, "can_index_clean", lambda *_: False)(x, sp):
-            valid = None if batch.sizes is None else [(s[1], s[0]) for s in batch.sizes] * 2     # both eyes
+        if getattr(ops, "can_index_clean", lambda *_: False)(x, sp):
+            valid = None if (batch.sizes is None or not sp.affine) else [(s[1], s[0]) for s in batch.sizes] * 2     # both eyes
             clean, cidx = ops.denormalize_indexed(x, sp, valid=valid, u8_out=exporter.next_buffer() if want0 else None,
                                                   crop=(rows, cols) if want0 else None)
         else:

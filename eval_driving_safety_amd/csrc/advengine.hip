@@ -276,14 +276,29 @@ constexpr int kLutSize = 3 * 256;
 
 struct IdxK {  // by-value kernel argument: the device side of adv_clean_index_t
   uint32_t* idx;         // [n,3,hw4] words of 4 index bytes
-  int* ok;               // [n]
-  float* lut;            // [3*256]
+  int* ok;               // [n]: bit 0 = table A reproduces the image, bit 1 = table B does (identity spaces only)
+  float* lut;            // [2][3*256]: table A, table B
   const int* valid_hw;   // [n,2] or nullptr
   int vh, vw;
 };
 
-__global__ __launch_bounds__(256) void clean_lut_kernel(float* lut, SpaceK sp) {
-  for (int e = threadIdx.x; e < kLutSize; e += 256) lut[e] = clean_from_index(e & 255, sp.scale[e >> 8], sp.shift[e >> 8]);
+// AFFINE: one table (B repeats A).  IDENTITY (pixel value minus a per-channel mean, Stereo R-CNN): the loader's subtraction may
+// have run in float32 (x = float(v) - float(mean)) or in float64 rounded once (numpy's `im -= pixel_means` with float64 means:
+// x = float(double(v) - mean)) - the two differ in the last bit for many v, so both tables are kept and every image is
+// verified against each; export_add[c] carries the mean as a double.
+__global__ __launch_bounds__(256) void clean_lut_kernel(float* lut, SpaceK sp, int identity) {
+  for (int e = threadIdx.x; e < kLutSize; e += 256) {
+    const int c = e >> 8, v = e & 255;
+    float a, b;
+    if (identity) {
+      a = static_cast<float>(v) - static_cast<float>(sp.export_add[c]);
+      b = static_cast<float>(static_cast<double>(v) - sp.export_add[c]);
+    } else {
+      a = b = clean_from_index(v, sp.scale[c], sp.shift[c]);
+    }
+    lut[e] = a;
+    lut[kLutSize + e] = b;
+  }
 }
 
 __device__ __forceinline__ void stage_lut(float* lds, const float* __restrict__ lut_g) {
@@ -396,6 +411,43 @@ __global__ __launch_bounds__(kWave) void clean_index_build_vec4(const v4f* x, v4
   }
 }
 
+// The index of an IDENTITY-space batch (Stereo R-CNN: x = 8-bit pixel - mean_c, attack/Stereo-RCNN/pgd_attack.py:122-123 clones it
+// as the clean pair): v = rint(x + mean_c), verified against both tables; no padding rule (the whole frame is image), any row
+// length (hw % 4 == 0 is all the float4 path needs).  clean_out = x when the caller wants a separate copy.
+__global__ __launch_bounds__(kWave) void clean_index_build_identity(const v4f* x, v4f* clean, IdxK ik, long long n_img, int hw4, SpaceK sp,
+                                                                    int copy) {
+  __shared__ float lut[2 * kLutSize];
+  for (int k = threadIdx.x; k < 2 * kLutSize / 4; k += kWave) reinterpret_cast<v4f*>(lut)[k] = reinterpret_cast<const v4f*>(ik.lut)[k];
+  __syncthreads();
+  const int stride = gridDim.x * kWave;
+  for (long long img = blockIdx.y; img < n_img; img += gridDim.y) {
+    const long long plane0 = img * 3LL * hw4;
+    bool bad_a = false, bad_b = false;
+    for (int q = blockIdx.x * kWave + threadIdx.x; q < hw4; q += stride) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const long long i = plane0 + static_cast<long long>(c) * hw4 + q;
+        const v4f X = ld_stream(x + i);
+        const float mean = static_cast<float>(sp.export_add[c]);
+        uint32_t word = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float r = rintf(X[j] + mean);
+          r = r < 0.0f ? 0.0f : (r > 255.0f ? 255.0f : r);
+          const uint32_t v = (r == r) ? static_cast<uint32_t>(r) : 0u;
+          bad_a |= __float_as_uint(lut[c * 256 + v]) != __float_as_uint(X[j]);
+          bad_b |= __float_as_uint(lut[kLutSize + c * 256 + v]) != __float_as_uint(X[j]);
+          word |= v << (8 * j);
+        }
+        if (copy) st_stream(clean + i, X);
+        __builtin_nontemporal_store(word, ik.idx + i);
+      }
+    }
+    const int clear = (__any(bad_a) ? 1 : 0) | (__any(bad_b) ? 2 : 0);
+    if (clear != 0 && (threadIdx.x & 63) == 0) atomicAnd(ik.ok + img, ~clear);
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // K1/K2 for planes that are NOT a whole number of 128-byte cache lines (Stereo R-CNN: 600 x 1987 floats
 // = 37 256.25 lines).  There the three channel planes of an image start at different offsets within a
@@ -449,15 +501,26 @@ __device__ __forceinline__ void store_channel_bytes(uint32_t word, int c, long l
   }
 }
 
-template <int KIND, int U8>
+// IDX: images whose clean-image index was verified (ik.ok[img] != 0) read one index word per pixel group and look the four clean
+// values up in an LDS copy of the table instead of loading a float4 of `cl` (13 instead of 16 bytes per element); the table is
+// staged once per workgroup, which walks two images (grid.y = n/2; measured optimum, see step_indexed_identity).
+template <int KIND, int U8, bool IDX = false>
 __global__ __launch_bounds__(kShiftBlock) void pgd_step_shifted(const v4f* x, const v4f* __restrict__ g,
                                                                 const v4f* __restrict__ cl, v4f* xo, long long n_img, int hw4,
-                                                                int w, int base_f4, SpaceK sp, float alpha, float eps, U8Dst u8) {
+                                                                int w, int base_f4, SpaceK sp, float alpha, float eps, U8Dst u8,
+                                                                IdxK ik = IdxK{nullptr, nullptr, nullptr, nullptr, 0, 0}) {
   constexpr bool kExchange = (U8 == U8_ROWS_DWORD || U8 == U8_FLAT_DWORD);
   __shared__ uint32_t words[kExchange ? 3 : 1][kExchange ? kShiftTile : 1];
+  __shared__ float lut[IDX ? 2 * kLutSize : 4];
   const int j = threadIdx.x;
+  if (IDX) {
+    for (int k = j; k < 2 * kLutSize / 4; k += kShiftBlock) reinterpret_cast<v4f*>(lut)[k] = reinterpret_cast<const v4f*>(ik.lut)[k];
+    __syncthreads();
+  }
   for (long long img = blockIdx.y; img < n_img; img += gridDim.y) {
     const long long plane0 = img * 3LL * hw4;
+    const int sel = IDX ? ik.ok[img] : 0;                                   // uniform: scalar load
+    const float* tb = lut + ((sel & 1) ? 0 : kLutSize);
     int m[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) m[c] = static_cast<int>((base_f4 + plane0 + static_cast<long long>(c) * hw4) & 7);
@@ -466,6 +529,7 @@ __global__ __launch_bounds__(kShiftBlock) void pgd_step_shifted(const v4f* x, co
     const int common_lo = tile - m_min, common_hi = min(tile - m_max + kShiftTile, hw4);  // groups all 3 channels cover here
     // all loads first (3 channels x kShiftUnroll groups x 3 arrays in flight per lane), then the arithmetic
     v4f X[kShiftUnroll][3], G[kShiftUnroll][3], C[kShiftUnroll][3];
+    uint32_t I[kShiftUnroll][3];
 #pragma unroll
     for (int u = 0; u < kShiftUnroll; ++u) {
 #pragma unroll
@@ -475,7 +539,10 @@ __global__ __launch_bounds__(kShiftBlock) void pgd_step_shifted(const v4f* x, co
           const long long i = plane0 + static_cast<long long>(c) * hw4 + q;
           X[u][c] = ld_stream(x + i);
           G[u][c] = ld_stream(g + i);
-          C[u][c] = ld_stream(cl + i);
+          if (IDX && sel != 0)
+            I[u][c] = __builtin_nontemporal_load(ik.idx + i);
+          else
+            C[u][c] = ld_stream(cl + i);
         }
       }
     }
@@ -487,6 +554,10 @@ __global__ __launch_bounds__(kShiftBlock) void pgd_step_shifted(const v4f* x, co
         if (q >= 0 && q < hw4) {
           const long long i = plane0 + static_cast<long long>(c) * hw4 + q;
           v4f O;
+          if (IDX && sel != 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) C[u][c][k] = tb[c * 256 + ((I[u][c] >> (8 * k)) & 0xffu)];
+          }
 #pragma unroll
           for (int k = 0; k < 4; ++k)
             O[k] = pgd_elem<KIND>(X[u][c][k], G[u][c][k], C[u][c][k], sp.scale[c], sp.shift[c], sp.lo[c], sp.hi[c], alpha, eps, sp.rcp[c], sp.use_rcp);
@@ -894,6 +965,50 @@ int launch_pgd(const float* x, const float* g, const float* cl, float* xo, long 
   return finish_launch();
 }
 
+// a13 with the indexed clean image, in the line-aligned kernel (planes that are not whole cache lines - the Stereo R-CNN frame);
+// every other layout steps through the float32 kernels, which give the same bits.  Images per workgroup (= per staged copy of
+// the table), 128 images of 600 x 1987, in place + export: 1 -> 1.17 ms, 2 -> 1.08, 4 -> 1.14, 8 -> 1.17, 16 -> 1.28; all-float32
+// kernel 1.28-1.30 (profiles/r02_srcnn_index_sweep.log).
+constexpr long long kIdxImagesPerWorkgroup = 2;
+
+inline int step_indexed_identity(const float* x, const float* g, const float* cl, const IdxK& ik, float* xo, uint8_t* u8, long long n, int h,
+                                 int w, const adv_space_t* space, float alpha, float eps, int crop_h, int crop_w, long long rs, long long is,
+                                 hipStream_t st) {
+  const SpaceK sp = to_kernel_space(space);
+  const long long hw = static_cast<long long>(h) * w;
+  const bool vec = (hw % 4 == 0) && aligned(x, 16) && aligned(g, 16) && aligned(cl, 16) && aligned(xo, 16);
+  const uintptr_t res = reinterpret_cast<uintptr_t>(x) & 127;
+  const bool same_residue = (reinterpret_cast<uintptr_t>(g) & 127) == res && (reinterpret_cast<uintptr_t>(cl) & 127) == res &&
+                            (reinterpret_cast<uintptr_t>(xo) & 127) == res;
+  const bool shifted = vec && same_residue && (((hw / 4) & 7) != 0 || res != 0);
+  if (!shifted || n < kIdxImagesPerWorkgroup)
+    return launch_pgd<ADV_SPACE_IDENTITY>(x, g, cl, xo, n, h, w, sp, alpha, eps, u8, crop_h, crop_w, rs, is, st);
+  U8Plan plan;
+  const int rc = plan_u8(u8, h, w, crop_h, crop_w, rs, is, vec, &plan);
+  if (rc != ADV_OK) return rc;
+  const int hw4 = static_cast<int>(hw / 4);
+  const int tiles = (hw4 + 7 + kShiftTile - 1) / kShiftTile;
+  long long gy = (n + kIdxImagesPerWorkgroup - 1) / kIdxImagesPerWorkgroup;
+  if (gy > 65535) gy = 65535;
+  const dim3 grid(tiles, static_cast<unsigned>(gy), 1);
+  const int base_f4 = static_cast<int>(res / 16);
+  const v4f* x4 = reinterpret_cast<const v4f*>(x);
+  const v4f* g4 = reinterpret_cast<const v4f*>(g);
+  const v4f* c4 = reinterpret_cast<const v4f*>(cl);
+  v4f* o4 = reinterpret_cast<v4f*>(xo);
+#define ADV_LAUNCH_SHIFTED_IDX(MODE)                                                                                                          \
+  hipLaunchKernelGGL((pgd_step_shifted<ADV_SPACE_IDENTITY, MODE, true>), grid, dim3(kShiftBlock), 0, st, x4, g4, c4, o4, n, hw4, w, base_f4, sp, \
+                     alpha, eps, plan.dst, ik)
+  switch (plan.mode) {
+    case U8_NONE: ADV_LAUNCH_SHIFTED_IDX(U8_NONE); break;
+    case U8_ROWS_DWORD: ADV_LAUNCH_SHIFTED_IDX(U8_ROWS_DWORD); break;
+    case U8_FLAT_DWORD: ADV_LAUNCH_SHIFTED_IDX(U8_FLAT_DWORD); break;
+    default: ADV_LAUNCH_SHIFTED_IDX(U8_BYTES); break;
+  }
+#undef ADV_LAUNCH_SHIFTED_IDX
+  return finish_launch();
+}
+
 inline Lim3 make_lim(const float* lo, const float* hi) {
   Lim3 l;
   l.on = (lo != nullptr && hi != nullptr) ? 1 : 0;
@@ -1046,18 +1161,30 @@ int adv_clean_index_build_f32(const float* x, float* clean_out, const adv_clean_
   if (rc != ADV_OK) return rc;
   rc = check_space(space);
   if (rc != ADV_OK) return rc;
-  if (!is_affine(space)) return ADV_EINVAL;
   IdxK ik;
   rc = check_clean_index(ci, h, w, &ik);
   if (rc != ADV_OK) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const SpaceK sp = to_kernel_space(space);
+  if (!is_affine(space)) {
+    // identity space (Stereo R-CNN): the whole frame is image, rows of any length; clean_out = x (may alias it)
+    if (ci->valid_hw != nullptr || ci->valid_h != h || ci->valid_w != w) return ADV_EINVAL;
+    if ((static_cast<long long>(h) * w) % 4 != 0 || !aligned(x, 16) || !aligned(clean_out, 16)) return ADV_EALIGN;
+    if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ci->ok), 3, static_cast<size_t>(n), st) != hipSuccess) return ADV_ELAUNCH;
+    hipLaunchKernelGGL(clean_lut_kernel, dim3(1), dim3(256), 0, st, ci->lut, sp, 1);
+    const int hw4i = static_cast<int>(static_cast<long long>(h) * w / 4);
+    hipLaunchKernelGGL(clean_index_build_identity, wave_grid(hw4i, n, 4), dim3(kWave), 0, st, reinterpret_cast<const v4f*>(x),
+                       reinterpret_cast<v4f*>(clean_out), ik, static_cast<long long>(n), hw4i, sp, clean_out != x ? 1 : 0);
+    rc = finish_launch();
+    if (rc != ADV_OK || u8_out == nullptr) return rc;
+    return adv_export_u8_f32(x, u8_out, n, h, w, space, crop_h, crop_w, u8_row_stride, u8_image_stride, stream);  // iterate 0
+  }
   if (w % 4 != 0 || !aligned(x, 16) || !aligned(clean_out, 16)) return ADV_EALIGN;
   U8Plan plan;
   rc = plan_u8(u8_out, h, w, crop_h, crop_w, u8_row_stride, u8_image_stride, true, &plan, false);
   if (rc != ADV_OK) return rc;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  const SpaceK sp = to_kernel_space(space);
   if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ci->ok), 1, static_cast<size_t>(n), st) != hipSuccess) return ADV_ELAUNCH;
-  hipLaunchKernelGGL(clean_lut_kernel, dim3(1), dim3(256), 0, st, ci->lut, sp);
+  hipLaunchKernelGGL(clean_lut_kernel, dim3(1), dim3(256), 0, st, ci->lut, sp, 0);
   const int hw4 = static_cast<int>(static_cast<long long>(h) * w / 4);
   const dim3 grid = wave_grid(hw4, n, 1);
   const v4f* x4 = reinterpret_cast<const v4f*>(x);
@@ -1081,10 +1208,12 @@ int adv_pgd_step_indexed_f32(const float* x, const float* grad, const float* cle
   if (rc != ADV_OK) return rc;
   rc = check_space(space);
   if (rc != ADV_OK) return rc;
-  if (!(eps >= 0.0f) || !is_affine(space)) return ADV_EINVAL;
+  if (!(eps >= 0.0f)) return ADV_EINVAL;
   IdxK ik;
   rc = check_clean_index(ci, h, w, &ik);
   if (rc != ADV_OK) return rc;
+  if (!is_affine(space)) return step_indexed_identity(x, grad, clean, ik, x_out, u8_out, n, h, w, space, alpha, eps, crop_h, crop_w, u8_row_stride,
+                                                       u8_image_stride, static_cast<hipStream_t>(stream));
   if (w % 4 != 0 || !aligned(x, 16) || !aligned(grad, 16) || !aligned(clean, 16) || !aligned(x_out, 16)) return ADV_EALIGN;
   U8Plan plan;
   rc = plan_u8(u8_out, h, w, crop_h, crop_w, u8_row_stride, u8_image_stride, true, &plan, false);

@@ -134,8 +134,8 @@ def normalize(x, space, out=None):
 
 class CleanIndex:
     """The clean image of an attack held as one byte per element (adv_clean_index_t): ``index`` uint8 [N,3,H,W],
-    ``ok`` int32 [N] (1 = every element of that image verified on the device; read by the kernels, never by the
-    host on the attack path), ``lut`` float32 [3,256], ``valid`` = (valid_h, valid_w) for the whole batch or an
+    ``ok`` int32 [N] (non-zero = every element of that image verified on the device; read by the kernels, never by the
+    host on the attack path), ``lut`` float32 [2,3,256] (two candidate tables, see include/advengine.h), ``valid`` = (valid_h, valid_w) for the whole batch or an
     int32 device tensor [N,2] with one such pair per image: outside that corner the loader's zero padding is
     expected (clean == shift_c)."""
 
@@ -158,8 +158,11 @@ class CleanIndex:
 
 
 def can_index_clean(x, space):
+    """affine spaces (DSGN): rows of whole pixel groups; identity spaces (Stereo R-CNN): planes of whole pixel groups"""
     xi = x if x.dim() == 4 else x.unsqueeze(0)
-    return space.affine and xi.shape[3] % 4 == 0 and x.data_ptr() % 16 == 0
+    if x.data_ptr() % 16 != 0:
+        return False
+    return xi.shape[3] % 4 == 0 if space.affine else (xi.shape[2] * xi.shape[3]) % 4 == 0
 
 
 def _valid_arg(valid, n, h, w, device):
@@ -187,7 +190,8 @@ def _valid_arg(valid, n, h, w, device):
 
 
 def denormalize_indexed(x, space, out=None, reuse=None, valid=None, u8_out=None, crop=None):
-    """``denormalize`` plus the 8-bit index of the result: returns (clean, CleanIndex).  Pass the CleanIndex to
+    """``denormalize`` (identity spaces: a copy of ``x``, the clean pair of attack/Stereo-RCNN/pgd_attack.py:122-123) plus the
+    8-bit index of the result: returns (clean, CleanIndex).  Pass the CleanIndex to
     ``pgd_step(..., clean_index=...)``: every step then reads 1 byte instead of 4 for the clean image of every image
     whose device-side check succeeded (images that came from 8-bit pixels via ToTensor + Normalize, zero-padded
     beyond ``valid`` = (valid_h, valid_w) or one such pair per image), with identical results.
@@ -203,7 +207,7 @@ def denormalize_indexed(x, space, out=None, reuse=None, valid=None, u8_out=None,
     else:
         ci = CleanIndex(torch.empty((n, 3, h, w), dtype=torch.uint8, device=x.device),
                         torch.empty((n,), dtype=torch.int32, device=x.device),
-                        torch.empty((3, 256), dtype=torch.float32, device=x.device), valid)
+                        torch.empty((2, 3, 256), dtype=torch.float32, device=x.device), valid)
     u8p, crop_h, crop_w, rs, is_ = _u8_args(u8_out, n, h, w, crop)
     with _on(x):
         _lib.call("adv_clean_index_build_f32", _ptr(xi), _ptr(oi), ci.ref(), u8p, n, h, w, space.ref(), crop_h, crop_w, rs, is_,

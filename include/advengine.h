@@ -109,11 +109,16 @@ ADV_API int adv_pgd_step_f32(const float* x, const float* grad, const float* cle
  *     stems from 8-bit pixels v through
  *         t = v/255;  x0 = (t - shift)/scale;  clean = x0*scale + shift        (float32: ToTensor, Normalize, denormalize)
  *     zero-padded IN NORMALISED SPACE to the network size, so that outside the image's valid_h x valid_w corner the clean
- *     value is exactly shift_c.  All pointers are DEVICE memory owned by the caller; nothing here is read by the host. */
+ *     value is exactly shift_c.  IDENTITY spaces (Stereo R-CNN: x0 = v - mean_c, the clean pair is a clone of x0,
+ *     attack/Stereo-RCNN/pgd_attack.py:122-123): v = rint(x0 + mean_c), two candidate tables - the subtraction in float32,
+ *     A_c[v] = float(v) - float(mean_c), or in float64 rounded once, B_c[v] = float(double(v) - mean_c) (numpy's
+ *     `im -= pixel_means`), mean_c = export_add[c]; the whole frame is image (valid = (h, w)), rows of any length.
+ *     All pointers are DEVICE memory owned by the caller; nothing here is read by the host. */
 typedef struct adv_clean_index {
   uint8_t* index;          /* [n,3,h,w]  v = rint(clean*255) inside the valid corner, 0 outside                       */
-  int32_t* ok;             /* [n]        1 = every element of image i verified bit for bit, 0 = read its float clean  */
-  float* lut;              /* [3*256]    T_c[v] = the chain above applied to v (16-byte aligned)                      */
+  int32_t* ok;             /* [n]        != 0: every element of image i verified bit for bit (bit 0: table A, bit 1:
+                                          table B); 0 = the steps read its float clean image                           */
+  float* lut;              /* [2][3*256] table A, table B (AFFINE: both = the chain above applied to v); 16-byte aligned */
   const int32_t* valid_hw; /* [n,2] = (valid_h, valid_w) per image, or NULL: the two fields below for every image     */
   int32_t valid_h, valid_w;
 } adv_clean_index_t;
@@ -122,7 +127,9 @@ typedef struct adv_clean_index {
  *     ok[i] = 1 iff for every element of image i   clean == T_c[index]  (inside the valid corner)
  *                                                 clean == shift_c     (outside it)            BIT FOR BIT.
  *     u8_out (nullable) receives the 8-bit export of x (= iterate 0, attack/DSGN/pgd_attack.py:279-294) exactly as
- *     adv_export_u8_f32 would write it.  Requires w % 4 == 0 and 16-byte aligned images.  AFFINE spaces only. */
+ *     adv_export_u8_f32 would write it.  AFFINE spaces: requires w % 4 == 0 and 16-byte aligned images.
+ *     IDENTITY spaces: clean_out = x (may be the same pointer), requires h*w % 4 == 0, 16-byte aligned images and
+ *     ci->valid = (h, w); ok[i] = 1 or 3 (table A), 2 (table B only) or 0. */
 ADV_API int adv_clean_index_build_f32(const float* x, float* clean_out, const adv_clean_index_t* ci, uint8_t* u8_out,
                                       int64_t n, int h, int w, const adv_space_t* space, int crop_h, int crop_w,
                                       int64_t u8_row_stride, int64_t u8_image_stride, adv_stream_t stream);
@@ -130,7 +137,9 @@ ADV_API int adv_clean_index_build_f32(const float* x, float* clean_out, const ad
 /* a3 with the indexed clean image: identical results to adv_pgd_step_f32.  Images with ok[i] != 0 (read on the device,
  *     no host round trip) are stepped reading the 1-byte index and an LDS copy of the table instead of the float32
  *     `clean` (13 instead of 16 bytes per element, no division); the others read `clean` as usual, in the same launch.
- *     Same requirements as adv_clean_index_build_f32, which must have filled *ci for this batch. */
+ *     Same requirements as adv_clean_index_build_f32, which must have filled *ci for this batch.  IDENTITY spaces use the
+ *     index in the line-aligned kernel (planes that are not whole cache lines: the 600 x 1987 Stereo R-CNN frame, two
+ *     images or more); other layouts step through adv_pgd_step_f32's kernels - the same bits either way. */
 ADV_API int adv_pgd_step_indexed_f32(const float* x, const float* grad, const float* clean, const adv_clean_index_t* ci,
                                      float* x_out, uint8_t* u8_out, int64_t n, int h, int w, const adv_space_t* space,
                                      float alpha, float eps, int crop_h, int crop_w, int64_t u8_row_stride,

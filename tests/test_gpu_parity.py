@@ -527,7 +527,9 @@ def test_indexed_clean_image_path(name, golden, golden_index, ops):
         want_index[:, :, valid[0]:, :] = 0
         want_index[:, :, :, valid[1]:] = 0
     same_bits(host(ci.index).astype(np.float32), want_index, "index = round(clean*255) inside the valid corner, 0 outside")
-    lut = host(ci.lut)
+    assert tuple(ci.lut.shape) == (2, 3, 256)
+    same_bits(host(ci.lut)[1], host(ci.lut)[0], "affine spaces: one table, stored twice")
+    lut = host(ci.lut)[0]
     for c in range(3):      # the table is the ToTensor -> Normalize -> denormalize chain of every 8-bit level
         v = np.arange(256, dtype=np.float32) / np.float32(255)
         t = (v - np.float32(synth.DSGN_MEAN[c])) / np.float32(synth.DSGN_STD[c])
@@ -616,6 +618,60 @@ def test_srcnn_shape_in_place_with_export(shape, ops):
                 same_bits(host(u8)[i], O.srcnn_export_u8(want[i]), "dense export, image %d step %d" % (i, k))
         same_bits(host(x), want, "in-place iterate %d" % k)
     same_bits(host(ops.export_u8(x, sp)), np.stack([O.srcnn_export_u8(want[i]) for i in range(n)]), "stand-alone dense export")
+
+
+@pytest.mark.parametrize("shape", [(24, 51), (600, 1987), (12, 36)])
+def test_srcnn_indexed_clean_image_equals_float_path_and_oracle(shape, ops):
+    """Stereo R-CNN pixel space with the clean pair held as a verified 8-bit index: images whose loader subtracted the means in
+    float32 (table A), in float64 rounded once (numpy's ``im -= pixel_means``: table B), and one image that is no 8-bit image
+    (falls back to its float clean copy) - in one launch, in place, export fused, bit-identical to the oracle."""
+    h, w = shape
+    sp = ops.Space.srcnn()
+    n = 10 if h < 600 else 8
+    imgs = []
+    for i in range(n):
+        a = synth.srcnn_meansub(70 + i, h, w)                              # float32 arithmetic
+        if i % 3 == 1:                                                     # float64 arithmetic, rounded once
+            u8 = synth.u8_image(70 + i, h, w).transpose(2, 0, 1).astype(np.float64)
+            a = (u8 - np.array(O.SRCNN_PIXEL_MEANS, np.float64).reshape(3, 1, 1)).astype(np.float32)[None]
+        imgs.append(a)
+    imgs[4] = imgs[4] * np.float32(0.999)                                  # not from 8-bit pixels
+    x0 = np.concatenate(imgs)
+    a_only = synth.srcnn_meansub(71, h, w)
+    u8 = synth.u8_image(71, h, w).transpose(2, 0, 1).astype(np.float64)
+    b_form = (u8 - np.array(O.SRCNN_PIXEL_MEANS, np.float64).reshape(3, 1, 1)).astype(np.float32)[None]
+    assert a_only.tobytes() != b_form.tobytes(), "the two loader formulas must differ for this test to mean anything"
+    g = synth.gradient(77, x0.shape, 1.0)
+    x = dev(x0)
+    assert ops.can_index_clean(x, sp)
+    u8o = ops.alloc_u8(n, h, w, x.device)
+    clean, cidx = ops.denormalize_indexed(x, sp, u8_out=u8o)
+    same_bits(host(clean), x0, "clean pair = clone of x")
+    flags = cidx.ok.cpu().tolist()
+    for i in range(n):
+        if i == 4:
+            assert flags[i] == 0, "image 4 is not 8-bit derived"
+        elif i % 3 == 1:
+            assert flags[i] in (2, 3) and flags[i] & 2, "float64-subtracted image must match table B (image %d: %d)" % (i, flags[i])
+        else:
+            assert flags[i] & 1, "float32-subtracted image must match table A (image %d: %d)" % (i, flags[i])
+        same_bits(host(u8o)[i], O.srcnn_export_u8(x0[i]), "iterate-0 export, image %d" % i)
+    want = x0
+    xf = dev(x0)
+    cf = xf.clone()
+    for k in range(3):
+        want = O.pgd_step_meansub255(want, g, x0, 1.0, 7.65)
+        ops.pgd_step(x, dev(g), clean, sp, 1.0, 7.65, out=x, u8_out=u8o, clean_index=cidx)
+        ops.pgd_step(xf, dev(g), cf, sp, 1.0, 7.65, out=xf)
+        same_bits(host(x), want, "indexed iterate %d vs oracle" % k)
+        assert torch.equal(x, xf), "indexed vs float path, iterate %d" % k
+        for i in (0, 1, 4, n - 1):
+            same_bits(host(u8o)[i], O.srcnn_export_u8(want[i]), "export, image %d step %d" % (i, k))
+    # an odd, small batch (the last workgroup row holds one image)
+    x2 = dev(x0[:3])
+    c2, ci2 = ops.denormalize_indexed(x2, sp)
+    ops.pgd_step(x2, dev(g[:3]), c2, sp, 1.0, 7.65, out=x2, clean_index=ci2)
+    same_bits(host(x2), O.pgd_step_meansub255(x0[:3], g[:3], x0[:3], 1.0, 7.65), "small batch through the indexed entry point")
 
 
 def test_indexed_equals_float_path_at_bench_scale(ops):
