@@ -502,6 +502,19 @@ def srcnn_object(torch, ops, dev, fence, pairs=64, steps=3, use_index=True):
                         "hbm_utilisation_by_design_bytes": moved / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "clean_image_read_as": ("uint8 index for %d of %d images (verified per image on the device)" % (verified, n_img)
                                                 if use_index else "float32")}}
+    # recorded PMC bytes of this object's kernel (the profile runs the default bench, i.e. this object at 64 pairs)
+    try:
+        import glob
+        path = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm*.json")), reverse=True)[0]
+        with open(path) as f:
+            kern = json.load(f)["kernels"]
+        key = "pgd_step_shifted<1, 3, true>" if (use_index and verified) else "pgd_step_shifted<1, 3, false>"
+        traffic = kern[key]["hbm_bytes_per_launch"] * pairs / 64
+        out["roofline"]["traffic"] = traffic
+        out["roofline"]["traffic_source"] = os.path.basename(path)
+        out["roofline"]["hbm_utilisation"] = traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    except Exception:
+        out["roofline"]["traffic"] = None
     if fl is not None:
         out["float_path"] = fl
     return out

@@ -14,7 +14,7 @@ import os
 import sys
 from collections import defaultdict
 
-OURS = ("clean_index_build_vec4", "clean_lut_kernel", "pgd_step_shifted", "pgd_step_vec4", "pgd_step_scalar", "affine_vec4", "affine_scalar", "export_u8_vec4", "export_u8_scalar",
+OURS = ("clean_index_build_identity", "clean_index_build_vec4", "clean_lut_kernel", "pgd_step_shifted", "pgd_step_vec4", "pgd_step_scalar", "affine_vec4", "affine_scalar", "export_u8_vec4", "export_u8_scalar",
         "patch_paste_kernel", "patch_delta_kernel", "patch_apply_kernel", "disc_mask_kernel", "psv_")
 
 
