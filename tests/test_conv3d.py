@@ -91,6 +91,34 @@ def test_hip_conv3d_single_output_channel_with_torch_adjoint():
     assert float((xm.grad - xr.grad).abs().max()) <= 1e-4 * float(xr.grad.abs().max())
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("masked", [False, True])
+def test_hip_persistent_tile_walk_equals_one_workgroup_per_tile(masked, monkeypatch):
+    """more tiles than resident workgroups: every workgroup walks several tiles with the stage pipeline running across them
+    (XCD-contiguous shares) - the same bits as one workgroup per tile, and as the oracle on a slab"""
+    from eval_driving_safety_amd import ops
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(11)
+    x = torch.randn((2, 8, 27, 60, 300), device=dev, generator=gen)          # 10 x 8 x 14 tiles x 2 batch x 2 blocks = 4480 workgroup-tiles
+    wt = torch.randn((40, 8, 3, 3, 3), device=dev, generator=gen) * 0.1
+    bias = torch.linspace(-0.2, 0.3, 40, device=dev)
+    wp = ops.conv3d_k3_prep(wt)
+    mask = 0b101010101010101010101010101 if masked else ops.ALL_TAPS
+
+    def run():
+        return ops._conv3d_ex(x, wp, 40, 1, True, bias, mask)
+
+    y = run()
+    monkeypatch.setenv("ADV_CONV_ONE_TILE_PER_WG", "1")
+    assert torch.equal(run(), y)
+    monkeypatch.delenv("ADV_CONV_ONE_TILE_PER_WG")
+    want = C.conv3d_k3_ex(x[1:, :, 20:27].cpu().numpy(), wt.cpu().numpy(), bias=bias.cpu().numpy(), relu=True, tap_mask=mask)
+    got = ops._conv3d_ex(x[1:, :, 20:27].contiguous(), wp, 40, 1, True, bias, mask)
+    assert got.cpu().numpy().tobytes() == want.tobytes()
+    # the interior depth planes of the slab do not see its artificial borders: they must equal the full run
+    assert torch.equal(got[:, :, 1:6], y[1:, :, 21:26])
+
+
 NARROW = [(1, 32, 1, 6, 24, 40), (2, 8, 1, 3, 9, 33), (1, 12, 3, 4, 8, 78), (1, 8, 8, 5, 10, 45), (1, 16, 5, 2, 17, 36), (1, 4, 2, 1, 1, 1)]
 
 
