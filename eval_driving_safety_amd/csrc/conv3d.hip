@@ -36,6 +36,12 @@ struct Epi {
   int od, oh, ow;     // output tensor dims
   int sd, sh, sw;     // output lattice stride
   int fd, fh, fw;     // output lattice offset
+  // nclass > 0: ONE launch computes nclass masked convolutions of the same input - class k with its own weights, tap mask and
+  // output lattice offset (the eight output parity classes of a transposed convolution); tap_mask / fd,fh,fw are then unused
+  int nclass;
+  const float* cls_wp[8];
+  unsigned cls_mask[8];
+  int cls_off[8][3];
 };
 
 constexpr unsigned kAllTaps = (1u << 27) - 1u;
@@ -302,17 +308,24 @@ __device__ __forceinline__ void stage_commit(const Stage<TD>& st, const Plan<TD>
 // the last stage of a tile fetches the first stage of the next one, so a workgroup pays the plan, the first global round trip and
 // the launch itself once, not once per tile.
 struct TileGrid {
-  int tiles_w, tiles_hw, nd, cblocks;
+  int tiles_w, tiles_hw, nd, cblocks, nclass;
   long long ntiles;
 };
 
 struct TilePos {
-  int w0, h0, d0, b, cob;
+  int w0, h0, d0, b, cob, cls;
 };
 
 template <int TD>
 __device__ __forceinline__ TilePos tile_at(const TileGrid& tg, long long t) {
   TilePos p;
+  p.cls = 0;
+  if (tg.nclass > 0) {
+    // the class is the fastest index, rotated every 64 tiles: a workgroup walks tiles first + k*step with step a multiple of 8,
+    // and must not end up with one class only (a class with eight taps costs eight times a class with one)
+    p.cls = static_cast<int>((t % tg.nclass + t / 64) % tg.nclass);
+    t /= tg.nclass;
+  }
   const int xy = static_cast<int>(t % tg.tiles_hw);
   t /= tg.tiles_hw;
   p.d0 = static_cast<int>(t % tg.nd) * TD;
@@ -362,7 +375,7 @@ __global__ __launch_bounds__(128 * TD, 2) void conv3d_k3_mfma(const float* __res
   TilePos tp = tile_at<TD>(tg, first);
   make_plan<TD>(pl, tid, Cin, cout_pad, D, H, W, tp.d0, tp.h0, tp.w0, plane, vol);
   const float* xb = x + static_cast<long long>(tp.b) * Cin * vol;
-  const float* wb = wp + tp.cob * 32;
+  const float* wb = ((MASKED && epi.nclass > 0) ? epi.cls_wp[tp.cls] : wp) + tp.cob * 32;
   stage_fetch<TD>(st, pl, xb, wb);
   stage_commit<TD>(st, pl, lds, lds + G::kSX, tid);
   __syncthreads();
@@ -384,7 +397,7 @@ __global__ __launch_bounds__(128 * TD, 2) void conv3d_k3_mfma(const float* __res
           tp = tile_at<TD>(tg, first + (k + 1) * step);
           make_plan<TD>(pl, tid, Cin, cout_pad, D, H, W, tp.d0, tp.h0, tp.w0, plane, vol);
           xb = x + static_cast<long long>(tp.b) * Cin * vol;
-          wb = wp + tp.cob * 32;
+          wb = ((MASKED && epi.nclass > 0) ? epi.cls_wp[tp.cls] : wp) + tp.cob * 32;
           cn = 0;
         } else {
           cn = c0;
@@ -397,7 +410,7 @@ __global__ __launch_bounds__(128 * TD, 2) void conv3d_k3_mfma(const float* __res
       // them next to their use and every wave sits in s_waitcnt vmcnt for a global-memory round trip per stage (PMC: 20 % of
       // the wave cycles parked, 10 % without the fetch)
       __builtin_amdgcn_sched_barrier(0);
-      const unsigned mask = MASKED ? chunk_mask(epi, c0) : kAllTaps;
+      const unsigned mask = MASKED ? (epi.nclass > 0 ? epi.cls_mask[cp.cls] : chunk_mask(epi, c0)) : kAllTaps;
 #pragma unroll
       for (int t9 = 0; t9 < 9; ++t9) {  // (kd, kh); fully unrolled so that LDS operand reads run ahead of their MFMAs
         const int kd = t9 / 3, kh = t9 - kd * 3;
@@ -437,7 +450,10 @@ __global__ __launch_bounds__(128 * TD, 2) void conv3d_k3_mfma(const float* __res
       const int co = co0 + 8 * (v >> 2) + (v & 3);
       bz[v] = (has_bias && co < Cout) ? epi.bias[co] : 0.0f;
     }
-    const int gw = cp.w0 + l32, zw = gw * epi.sw + epi.fw;
+    const bool by_class = MASKED && epi.nclass > 0;
+    const int fd = by_class ? epi.cls_off[cp.cls][0] : epi.fd, fh = by_class ? epi.cls_off[cp.cls][1] : epi.fh;
+    const int fw = by_class ? epi.cls_off[cp.cls][2] : epi.fw;
+    const int gw = cp.w0 + l32, zw = gw * epi.sw + fw;
     const long long ovol = static_cast<long long>(epi.od) * epi.oh * epi.ow;
     float* yb = y + (static_cast<long long>(cp.b) * Cout + co0) * ovol;
 #pragma unroll
@@ -445,7 +461,7 @@ __global__ __launch_bounds__(128 * TD, 2) void conv3d_k3_mfma(const float* __res
       const int row = wave * kNB + i;
       const int td = row / kTH, th = row - td * kTH;
       const int gd = cp.d0 + td, gh = cp.h0 + th;
-      const int zd = gd * epi.sd + epi.fd, zh = gh * epi.sh + epi.fh;
+      const int zd = gd * epi.sd + fd, zh = gh * epi.sh + fh;
       if (gd >= D || gh >= H || gw >= W || zd >= epi.od || zh >= epi.oh || zw >= epi.ow) continue;
       float* yr = yb + (static_cast<long long>(zd) * epi.oh + zh) * epi.ow + zw;
       if (cp.cob * 32 + 32 <= Cout) {  // workgroup-uniform: all 32 output channels of the block exist - no per-store predicate
@@ -750,8 +766,8 @@ static int launch_conv(const float* x, const float* w_prep, float* y, int b, int
   // tile depth 2 (4 waves) and 4 (8 waves, one workgroup per CU) measured the same within 1-2 % (profiles/r01_conv3d_mfma.jsonl)
   if (fast) {
     TileGrid tg;
-    tg.tiles_w = tiles_w, tg.tiles_hw = tiles_w * tiles_h, tg.nd = (d + 1) / 2, tg.cblocks = cblocks;
-    tg.ntiles = static_cast<long long>(tg.tiles_hw) * tg.nd * b * cblocks;
+    tg.tiles_w = tiles_w, tg.tiles_hw = tiles_w * tiles_h, tg.nd = (d + 1) / 2, tg.cblocks = cblocks, tg.nclass = epi.nclass;
+    tg.ntiles = static_cast<long long>(tg.tiles_hw) * tg.nd * b * cblocks * (epi.nclass > 0 ? epi.nclass : 1);
     // persistent workgroups: two per CU (the LDS budget), a multiple of 8 so that each XCD walks its own contiguous tile range;
     // ADV_CONV_ONE_TILE_PER_WG=1 launches one workgroup per tile instead (test hook / A-B)
     long long wgs = 2LL * cu_count();
@@ -759,7 +775,7 @@ static int launch_conv(const float* x, const float* w_prep, float* y, int b, int
     if (wgs > 0x7fffffffLL) return ADV_EINVAL;
     const dim3 grid(static_cast<unsigned>(wgs));
     const size_t lds = 2 * static_cast<size_t>(Geo<2>::kStageFloats) * sizeof(float);
-    if (epi.tap_mask == kAllTaps && epi.class_channels == 0)
+    if (epi.tap_mask == kAllTaps && epi.class_channels == 0 && epi.nclass == 0)
       hipLaunchKernelGGL((conv3d_k3_mfma<2, false>), grid, dim3(Geo<2>::kThreads), lds, st, x, w_prep, y, cin, cout, cblocks * 32, d, h, w, tg, epi);
     else
       hipLaunchKernelGGL((conv3d_k3_mfma<2, true>), grid, dim3(Geo<2>::kThreads), lds, st, x, w_prep, y, cin, cout, cblocks * 32, d, h, w, tg, epi);
@@ -824,6 +840,36 @@ int adv_conv3d_k3_ex_f32(const float* x, const float* w_prep, const float* bias,
     epi.fd = out_offset[0], epi.fh = out_offset[1], epi.fw = out_offset[2];
   }
   return launch_conv(x, w_prep, y, b, cin, cout, d, h, w, stride, epi, static_cast<hipStream_t>(stream));
+}
+
+int adv_conv_transpose3d_k3_s2_f32(const float* x, const float* const* w_prep_classes, const uint32_t* tap_masks, const float* bias, float* y,
+                                   int b, int cin, int cout, int d, int h, int w, int relu, adv_stream_t stream) {
+  if (!x || !w_prep_classes || !tap_masks || !y || b < 1 || cin < kCK || cin % kCK != 0 || cout < 1 || d < 1 || h < 1 || w < 1) return ADV_EINVAL;
+  for (int k = 0; k < 8; ++k)
+    if (w_prep_classes[k] == nullptr || (tap_masks[k] & ~kAllTaps) || tap_masks[k] == 0) return ADV_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  Epi epi{bias, relu, tap_masks[0], {0, 0, 0, 0, 0, 0, 0, 0}, 0, 2 * d, 2 * h, 2 * w, 2, 2, 2, 0, 0, 0};
+  const int cblocks = (cout + 31) / 32;
+  const bool fits = w >= 4 && static_cast<long long>(cin) * d * h * w < (1LL << 31) && 27LL * cin * cblocks * 32 < (1LL << 31);
+  bool aligned_w = (reinterpret_cast<uintptr_t>(x) & 3) == 0;
+  for (int k = 0; k < 8; ++k) aligned_w = aligned_w && (reinterpret_cast<uintptr_t>(w_prep_classes[k]) & 15) == 0;
+  if (fits && aligned_w && getenv("ADV_CONV_GENERIC") == nullptr && getenv("ADV_CONV_CLASS_LAUNCHES") == nullptr) {
+    epi.nclass = 8;   // one launch: the class is a tile index (launch_conv's persistent masked kernel)
+    for (int k = 0; k < 8; ++k) {
+      epi.cls_wp[k] = w_prep_classes[k];
+      epi.cls_mask[k] = tap_masks[k];
+      epi.cls_off[k][0] = (k >> 2) & 1, epi.cls_off[k][1] = (k >> 1) & 1, epi.cls_off[k][2] = k & 1;
+    }
+    epi.tap_mask = 0;  // never the all-taps kernel
+    return launch_conv(x, w_prep_classes[0], y, b, cin, cout, d, h, w, 1, epi, st);
+  }
+  for (int k = 0; k < 8; ++k) {  // eight masked launches: the same bits (ADV_CONV_CLASS_LAUNCHES=1: test hook / A-B)
+    epi.tap_mask = tap_masks[k];
+    epi.fd = (k >> 2) & 1, epi.fh = (k >> 1) & 1, epi.fw = k & 1;
+    const int rc = launch_conv(x, w_prep_classes[k], y, b, cin, cout, d, h, w, 1, epi, st);
+    if (rc != ADV_OK) return rc;
+  }
+  return ADV_OK;
 }
 
 }  // extern "C"

@@ -688,13 +688,22 @@ def conv_transpose3d_k3_s2_prep(weight_t):
 
 
 def conv_transpose3d_k3_s2(x, classes, cout, relu=False, bias=None):
-    """conv_transpose3d(x [B,Cin,D,H,W], kernel 3, stride 2, padding 1, output_padding 1) -> [B,cout,2D,2H,2W]: eight
-    masked-tap launches of the stride-1 MFMA kernel, each writing one parity class of the output."""
+    """conv_transpose3d(x [B,Cin,D,H,W], kernel 3, stride 2, padding 1, output_padding 1) -> [B,cout,2D,2H,2W]: the eight
+    output parity classes (1-8 taps each) as ONE launch of the persistent masked MFMA kernel, the class being a tile index."""
     xi = _feat(x, "x")
-    b, _, d, h, w = xi.shape
+    b, cin, d, h, w = xi.shape
+    if len(classes) != 8 or [tuple(c[2]) for c in classes] != [(k >> 2 & 1, k >> 1 & 1, k & 1) for k in range(8)]:
+        raise ValueError("classes must be the eight (w_prep, tap_mask, (pd,ph,pw)) of conv_transpose3d_k3_s2_prep, in its order")
+    if bias is not None:
+        bias = _feat(bias, "bias")
+        if tuple(bias.shape) != (cout,):
+            raise ValueError("bias must be [cout]")
     out = torch.empty((b, cout, 2 * d, 2 * h, 2 * w), dtype=torch.float32, device=xi.device)
-    for w_prep, mask, off in classes:
-        _conv3d_ex(xi, w_prep, cout, 1, relu, bias, mask, out, (2, 2, 2), off)
+    wps = (ctypes.c_void_p * 8)(*[_feat(c[0], "w_prep").data_ptr() for c in classes])
+    masks = (ctypes.c_uint32 * 8)(*[int(c[1]) for c in classes])
+    with _on(xi):
+        _lib.call("adv_conv_transpose3d_k3_s2_f32", _ptr(xi), wps, masks, None if bias is None else _ptr(bias), _ptr(out), b, cin, cout, d, h, w,
+                  int(relu), _stream(xi))
     return out
 
 

@@ -312,6 +312,16 @@ ADV_API int adv_conv3d_k3_ex_f32(const float* x, const float* w_prep, const floa
                                  int class_channels, const int32_t* out_dims, const int32_t* out_stride,
                                  const int32_t* out_offset, adv_stream_t stream);
 
+/* y [b,cout,2d,2h,2w] = conv_transpose3d(x [b,cin,d,h,w], kernel 3, stride 2, padding 1, output_padding 1) (+ bias, + ReLU) in ONE
+ *     launch: the eight output parity classes k = (pd*2+ph)*2+pw as one tile index of the persistent masked kernel, class k with
+ *     its own prepared weights w_prep_classes[k] (HOST array of 8 DEVICE pointers) and tap mask tap_masks[k] (HOST uint32[8]) -
+ *     ops.conv_transpose3d_k3_s2_prep builds both.  The classes' tiles (1 to 8 taps each) are interleaved over the workgroups,
+ *     so the launch fills the GPU where eight separate launches of 0.7 rounds each did not.  Same bits as eight
+ *     adv_conv3d_k3_ex_f32 calls with out_stride 2 / out_offset (pd,ph,pw). */
+ADV_API int adv_conv_transpose3d_k3_s2_f32(const float* x, const float* const* w_prep_classes, const uint32_t* tap_masks,
+                                           const float* bias, float* y, int b, int cin, int cout, int d, int h, int w, int relu,
+                                           adv_stream_t stream);
+
 /* xs [b, 8c, ceil(d/2), ceil(h/2), ceil(w/2)]:  xs[b, p*c + ch, jd, jh, jw] = x[b, ch, 2jd+pd, 2jh+ph, 2jw+pw], p = (pd*2+ph)*2+pw,
  *     zero beyond the input.  HBM-bound permute (one pass); xs is caller-owned workspace. */
 ADV_API int adv_space_to_depth2_f32(const float* x, float* xs, int b, int c, int d, int h, int w, adv_stream_t stream);
