@@ -176,10 +176,10 @@ constexpr int kFSW = 27 * kFC * 32;  // weights per stage (floats)
 constexpr int kWF4 = kFSW / 4;       // 864 float4
 
 // compile-time geometry of the main kernel for a tile depth TD (waves = 2*TD, 4 rows of 32 voxels per wave)
-template <int TD>
+template <int TD, int TH = 8>
 struct Geo {
   static constexpr int kThreads = 128 * TD;
-  static constexpr int kRows = kFC * (TD + 2) * (kTH + 2);                          // tile rows per stage
+  static constexpr int kRows = kFC * (TD + 2) * (TH + 2);                          // tile rows per stage
   static constexpr int kRowsPerPass = kThreads / 8;
   static constexpr int kXPass = (kRows + kRowsPerPass - 1) / kRowsPerPass;          // float4 per lane
   static constexpr int kHaloPerLane = (2 * kRows + kThreads - 1) / kThreads;
@@ -188,11 +188,11 @@ struct Geo {
   static constexpr int kStageFloats = kSX + kFSW;                                   // one LDS stage; two are resident
 };
 
-template <int TD>
+template <int TD, int TH = 8>
 struct Stage {
-  v4f xi[Geo<TD>::kXPass];
-  float xh[Geo<TD>::kHaloPerLane];
-  v4f wv[Geo<TD>::kWPass];
+  v4f xi[Geo<TD, TH>::kXPass];
+  float xh[Geo<TD, TH>::kHaloPerLane];
+  v4f wv[Geo<TD, TH>::kWPass];
 };
 
 // What a lane fetches for every stage, worked out ONCE per tile: only the channel base moves from stage to stage, so the
@@ -205,27 +205,27 @@ struct Stage {
 //   xk/xok  2 bits / 1 bit per pass: the shift, and "not padding"
 //   ho/hok  the same for the two halo columns (one float each); lanes beyond 2*kRows park their value in an unused pad column
 //   wo[p]   element offset of the lane's weight float4 relative to wp + c0*cout_pad + cob*32
-template <int TD>
+template <int TD, int TH = 8>
 struct Plan {
-  int xo[Geo<TD>::kXPass];
-  int ho[Geo<TD>::kHaloPerLane];
-  int wo[Geo<TD>::kWPass];
+  int xo[Geo<TD, TH>::kXPass];
+  int ho[Geo<TD, TH>::kHaloPerLane];
+  int wo[Geo<TD, TH>::kWPass];
   unsigned xk, xok, hok;
 };
 
-template <int TD, bool WEIGHTS = true>
-__device__ __forceinline__ void make_plan(Plan<TD>& pl, int tid, int Cin, int cout_pad, int D, int H, int W, int d0, int h0, int w0,
+template <int TD, bool WEIGHTS = true, int TH = 8>
+__device__ __forceinline__ void make_plan(Plan<TD, TH>& pl, int tid, int Cin, int cout_pad, int D, int H, int W, int d0, int h0, int w0,
                                           int plane, int vol) {
-  using G = Geo<TD>;
+  using G = Geo<TD, TH>;
   static_assert(G::kRows % G::kRowsPerPass == 0, "every pass of the interior fetch is full");
-  constexpr int kPerC = (TD + 2) * (kTH + 2);
+  constexpr int kPerC = (TD + 2) * (TH + 2);
   const int j = tid & 7, r0 = tid >> 3;
   pl.xk = 0, pl.xok = 0, pl.hok = 0;
 #pragma unroll
   for (int p = 0; p < G::kXPass; ++p) {
     const int row = p * G::kRowsPerPass + r0;
     const int c = row / kPerC, rem = row - c * kPerC;
-    const int dd = rem / (kTH + 2), hh = rem - dd * (kTH + 2);
+    const int dd = rem / (TH + 2), hh = rem - dd * (TH + 2);
     const int gd = d0 + dd - 1, gh = h0 + hh - 1, gw = w0 + 4 * j;
     const bool ok = gd >= 0 && gd < D && gh >= 0 && gh < H && gw < W;
     const int gws = gw + 3 < W ? gw : W - 4;
@@ -239,7 +239,7 @@ __device__ __forceinline__ void make_plan(Plan<TD>& pl, int tid, int Cin, int co
     const bool real = s < 2 * G::kRows;
     const int row = (real ? s : s - 2 * G::kRows) >> 1, side = s & 1;
     const int c = row / kPerC, rem = row - c * kPerC;
-    const int dd = rem / (kTH + 2), hh = rem - dd * (kTH + 2);
+    const int dd = rem / (TH + 2), hh = rem - dd * (TH + 2);
     const int gd = d0 + dd - 1, gh = h0 + hh - 1, gw = side ? w0 + kTW : w0 - 1;
     const bool ok = real && gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W;
     pl.ho[p] = ok ? c * vol + gd * plane + gh * W + gw : 0;
@@ -255,9 +255,9 @@ __device__ __forceinline__ void make_plan(Plan<TD>& pl, int tid, int Cin, int co
   }
 }
 
-template <int TD, bool WEIGHTS = true>
-__device__ __forceinline__ void stage_fetch(Stage<TD>& st, const Plan<TD>& pl, const float* __restrict__ xc, const float* __restrict__ wc) {
-  using G = Geo<TD>;
+template <int TD, bool WEIGHTS = true, int TH = 8>
+__device__ __forceinline__ void stage_fetch(Stage<TD, TH>& st, const Plan<TD, TH>& pl, const float* __restrict__ xc, const float* __restrict__ wc) {
+  using G = Geo<TD, TH>;
 #pragma unroll
   for (int p = 0; p < G::kXPass; ++p) st.xi[p] = *reinterpret_cast<const v4f_u*>(xc + pl.xo[p]);  // dword-aligned float4 (any W)
 #pragma unroll
@@ -267,9 +267,9 @@ __device__ __forceinline__ void stage_fetch(Stage<TD>& st, const Plan<TD>& pl, c
   for (int p = 0; p < G::kWPass; ++p) st.wv[p] = *reinterpret_cast<const v4f*>(wc + pl.wo[p]);
 }
 
-template <int TD, bool WEIGHTS = true>
-__device__ __forceinline__ void stage_commit(const Stage<TD>& st, const Plan<TD>& pl, float* sx, float* sw, int tid) {
-  using G = Geo<TD>;
+template <int TD, bool WEIGHTS = true, int TH = 8>
+__device__ __forceinline__ void stage_commit(const Stage<TD, TH>& st, const Plan<TD, TH>& pl, float* sx, float* sw, int tid) {
+  using G = Geo<TD, TH>;
   const int j = tid & 7, r0 = tid >> 3;
 #pragma unroll
   for (int p = 0; p < G::kXPass; ++p) {
@@ -316,7 +316,7 @@ struct TilePos {
   int w0, h0, d0, b, cob, cls;
 };
 
-template <int TD>
+template <int TD, int TH = 8>
 __device__ __forceinline__ TilePos tile_at(const TileGrid& tg, long long t) {
   TilePos p;
   p.cls = 0;
@@ -331,7 +331,7 @@ __device__ __forceinline__ TilePos tile_at(const TileGrid& tg, long long t) {
   p.d0 = static_cast<int>(t % tg.nd) * TD;
   const int z = static_cast<int>(t / tg.nd);
   p.w0 = (xy % tg.tiles_w) * kTW;
-  p.h0 = (xy / tg.tiles_w) * kTH;
+  p.h0 = (xy / tg.tiles_w) * TH;
   p.b = z / tg.cblocks;
   p.cob = z - p.b * tg.cblocks;
   return p;
@@ -339,15 +339,16 @@ __device__ __forceinline__ TilePos tile_at(const TileGrid& tg, long long t) {
 
 // MASKED = false: every tap, no branch in the unrolled tap loop (the ordinary convolution: operand reads run ahead of the
 // MFMAs); MASKED = true: taps are skipped by epi.tap_mask (one parity class of a transposed convolution).
-template <int TD, bool MASKED>
+template <int TD, bool MASKED, int TH = 8>
 __global__ __launch_bounds__(128 * TD, 2) void conv3d_k3_mfma(const float* __restrict__ x, const float* __restrict__ wp,
                                                               float* __restrict__ y, int Cin, int Cout, int cout_pad, int D, int H, int W,
                                                               TileGrid tg, Epi epi) {
-  using G = Geo<TD>;
+  using G = Geo<TD, TH>;
   // before which (kd,kh) group of the tap loop the next stage is written to the other LDS buffer - in the shadow of this
   // stage's MFMAs instead of after them (measured: 64->32 1.468 -> 1.437 ms, 32->64 1.395 -> 1.32 ms at 6; the masked
   // classes, with fewer MFMAs per stage, 0.60 -> 0.55 ms at 3; profiles/r02_conv3d_staging.jsonl)
   constexpr int kCommitAt = MASKED ? 3 : 6;
+  constexpr int NB = TD * TH / 4;  // rows of 32 voxels per wave
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l32 = lane & 31;
@@ -370,20 +371,20 @@ __global__ __launch_bounds__(128 * TD, 2) void conv3d_k3_mfma(const float* __res
 
   // two LDS stages: while the waves run the MFMAs of stage `cur`, the next chunk travels global -> registers ->
   // the other stage; ONE barrier per chunk
-  Stage<TD> st;
-  Plan<TD> pl;
-  TilePos tp = tile_at<TD>(tg, first);
-  make_plan<TD>(pl, tid, Cin, cout_pad, D, H, W, tp.d0, tp.h0, tp.w0, plane, vol);
+  Stage<TD, TH> st;
+  Plan<TD, TH> pl;
+  TilePos tp = tile_at<TD, TH>(tg, first);
+  make_plan<TD, true, TH>(pl, tid, Cin, cout_pad, D, H, W, tp.d0, tp.h0, tp.w0, plane, vol);
   const float* xb = x + static_cast<long long>(tp.b) * Cin * vol;
   const float* wb = ((MASKED && epi.nclass > 0) ? epi.cls_wp[tp.cls] : wp) + tp.cob * 32;
-  stage_fetch<TD>(st, pl, xb, wb);
-  stage_commit<TD>(st, pl, lds, lds + G::kSX, tid);
+  stage_fetch<TD, true, TH>(st, pl, xb, wb);
+  stage_commit<TD, true, TH>(st, pl, lds, lds + G::kSX, tid);
   __syncthreads();
   int cur = 0;
   for (int k = 0; k < count; ++k) {
-    f32x16 acc[kNB];
+    f32x16 acc[NB];
 #pragma unroll
-    for (int i = 0; i < kNB; ++i)
+    for (int i = 0; i < NB; ++i)
 #pragma unroll
       for (int v = 0; v < 16; ++v) acc[i][v] = 0.0f;
     const TilePos cp = tp;  // the tile being accumulated (its results are stored after the stage loop)
@@ -394,8 +395,8 @@ __global__ __launch_bounds__(128 * TD, 2) void conv3d_k3_mfma(const float* __res
       int cn = c0 + kFC;
       if (cn >= Cin) {
         if (k + 1 < count) {
-          tp = tile_at<TD>(tg, first + (k + 1) * step);
-          make_plan<TD>(pl, tid, Cin, cout_pad, D, H, W, tp.d0, tp.h0, tp.w0, plane, vol);
+          tp = tile_at<TD, TH>(tg, first + (k + 1) * step);
+          make_plan<TD, true, TH>(pl, tid, Cin, cout_pad, D, H, W, tp.d0, tp.h0, tp.w0, plane, vol);
           xb = x + static_cast<long long>(tp.b) * Cin * vol;
           wb = ((MASKED && epi.nclass > 0) ? epi.cls_wp[tp.cls] : wp) + tp.cob * 32;
           cn = 0;
@@ -405,7 +406,7 @@ __global__ __launch_bounds__(128 * TD, 2) void conv3d_k3_mfma(const float* __res
       }
       const float* sxc = lds + cur * G::kStageFloats;
       const float* swc = sxc + G::kSX;
-      stage_fetch<TD>(st, pl, xb + static_cast<long long>(cn) * vol, wb + static_cast<long long>(cn) * cout_pad);
+      stage_fetch<TD, true, TH>(st, pl, xb + static_cast<long long>(cn) * vol, wb + static_cast<long long>(cn) * cout_pad);
       // the loads are issued HERE, a hundred MFMAs before the commit that consumes them: without the fence the scheduler sinks
       // them next to their use and every wave sits in s_waitcnt vmcnt for a global-memory round trip per stage (PMC: 20 % of
       // the wave cycles parked, 10 % without the fetch)
@@ -416,7 +417,7 @@ __global__ __launch_bounds__(128 * TD, 2) void conv3d_k3_mfma(const float* __res
         const int kd = t9 / 3, kh = t9 - kd * 3;
         if (t9 == kCommitAt) {  // the next stage goes to the OTHER buffer in the shadow of this stage's MFMAs
           float* nx = lds + (cur ^ 1) * G::kStageFloats;
-          stage_commit<TD>(st, pl, nx, nx + G::kSX, tid);
+          stage_commit<TD, true, TH>(st, pl, nx, nx + G::kSX, tid);
         }
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
@@ -427,10 +428,10 @@ __global__ __launch_bounds__(128 * TD, 2) void conv3d_k3_mfma(const float* __res
             const int c = 2 * kk + half;
             const float a = swc[(tap * kFC + c) * 32 + l32];
 #pragma unroll
-            for (int i = 0; i < kNB; ++i) {
-              const int row = wave * kNB + i;
-              const int td = row / kTH, th = row - td * kTH;
-              const float bv = sxc[((c * (TD + 2) + td + kd) * (kTH + 2) + th + kh) * kP + l32 + kw + 3];
+            for (int i = 0; i < NB; ++i) {
+              const int row = wave * NB + i;
+              const int td = row / TH, th = row - td * TH;
+              const float bv = sxc[((c * (TD + 2) + td + kd) * (TH + 2) + th + kh) * kP + l32 + kw + 3];
               acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[i], 0, 0, 0);
             }
           }
@@ -457,9 +458,9 @@ __global__ __launch_bounds__(128 * TD, 2) void conv3d_k3_mfma(const float* __res
     const long long ovol = static_cast<long long>(epi.od) * epi.oh * epi.ow;
     float* yb = y + (static_cast<long long>(cp.b) * Cout + co0) * ovol;
 #pragma unroll
-    for (int i = 0; i < kNB; ++i) {
-      const int row = wave * kNB + i;
-      const int td = row / kTH, th = row - td * kTH;
+    for (int i = 0; i < NB; ++i) {
+      const int row = wave * NB + i;
+      const int td = row / TH, th = row - td * TH;
       const int gd = cp.d0 + td, gh = cp.h0 + th;
       const int zd = gd * epi.sd + fd, zh = gh * epi.sh + fh;
       if (gd >= D || gh >= H || gw >= W || zd >= epi.od || zh >= epi.oh || zw >= epi.ow) continue;
@@ -765,20 +766,43 @@ static int launch_conv(const float* x, const float* w_prep, float* y, int b, int
                     getenv("ADV_CONV_GENERIC") == nullptr;
   // tile depth 2 (4 waves) and 4 (8 waves, one workgroup per CU) measured the same within 1-2 % (profiles/r01_conv3d_mfma.jsonl)
   if (fast) {
-    TileGrid tg;
-    tg.tiles_w = tiles_w, tg.tiles_hw = tiles_w * tiles_h, tg.nd = (d + 1) / 2, tg.cblocks = cblocks, tg.nclass = epi.nclass;
-    tg.ntiles = static_cast<long long>(tg.tiles_hw) * tg.nd * b * cblocks * (epi.nclass > 0 ? epi.nclass : 1);
     // persistent workgroups: two per CU (the LDS budget), a multiple of 8 so that each XCD walks its own contiguous tile range;
     // ADV_CONV_ONE_TILE_PER_WG=1 launches one workgroup per tile instead (test hook / A-B)
-    long long wgs = 2LL * cu_count();
+    const long long slots = 2LL * cu_count();
+    const long long per_row_tile = static_cast<long long>(tiles_w) * ((d + 1) / 2) * b * cblocks * (epi.nclass > 0 ? epi.nclass : 1);
+    // Tile height 8 (2 x 8 x 32 voxels, 4 rows per wave) or 4 (2 x 4 x 32, 2 rows per wave).  The half- and quarter-resolution
+    // layers of an hourglass have 0.2-1.4 rounds of 8-row tiles for the resident workgroups; a 4-row tile costs 0.51 of an 8-row
+    // one with all taps (measured at full resolution: 5760 tiles in 1.462 ms vs 2880 in 1.43) and ~0.75 with masked taps
+    // (staging-dominated), and fills the tail - pick whichever needs less time by that estimate (ADV_CONV_TH=4|8 forces one:
+    // test hook / A-B).  Same bits either way.
+    const bool all_taps = epi.tap_mask == kAllTaps && epi.class_channels == 0 && epi.nclass == 0;
+    const long long n8 = per_row_tile * ((h + 7) / 8), n4 = per_row_tile * ((h + 3) / 4);
+    const double t8 = static_cast<double>((n8 + slots - 1) / slots);
+    const double t4 = (all_taps ? 0.52 : 0.75) * static_cast<double>((n4 + slots - 1) / slots);
+    bool th4 = t4 < t8;
+    if (const char* e = getenv("ADV_CONV_TH")) th4 = e[0] == '4';
+    TileGrid tg;
+    tg.tiles_w = tiles_w, tg.tiles_hw = tiles_w * (th4 ? (h + 3) / 4 : (h + 7) / 8), tg.nd = (d + 1) / 2, tg.cblocks = cblocks;
+    tg.nclass = epi.nclass;
+    tg.ntiles = th4 ? n4 : n8;
+    long long wgs = slots;
     if (getenv("ADV_CONV_ONE_TILE_PER_WG") != nullptr || tg.ntiles < wgs) wgs = tg.ntiles;
     if (wgs > 0x7fffffffLL) return ADV_EINVAL;
     const dim3 grid(static_cast<unsigned>(wgs));
-    const size_t lds = 2 * static_cast<size_t>(Geo<2>::kStageFloats) * sizeof(float);
-    if (epi.tap_mask == kAllTaps && epi.class_channels == 0 && epi.nclass == 0)
-      hipLaunchKernelGGL((conv3d_k3_mfma<2, false>), grid, dim3(Geo<2>::kThreads), lds, st, x, w_prep, y, cin, cout, cblocks * 32, d, h, w, tg, epi);
-    else
-      hipLaunchKernelGGL((conv3d_k3_mfma<2, true>), grid, dim3(Geo<2>::kThreads), lds, st, x, w_prep, y, cin, cout, cblocks * 32, d, h, w, tg, epi);
+    const int cpad = cblocks * 32;
+    if (!th4) {
+      const size_t lds = 2 * static_cast<size_t>(Geo<2, 8>::kStageFloats) * sizeof(float);
+      if (all_taps)
+        hipLaunchKernelGGL((conv3d_k3_mfma<2, false, 8>), grid, dim3(256), lds, st, x, w_prep, y, cin, cout, cpad, d, h, w, tg, epi);
+      else
+        hipLaunchKernelGGL((conv3d_k3_mfma<2, true, 8>), grid, dim3(256), lds, st, x, w_prep, y, cin, cout, cpad, d, h, w, tg, epi);
+    } else {
+      const size_t lds = 2 * static_cast<size_t>(Geo<2, 4>::kStageFloats) * sizeof(float);
+      if (all_taps)
+        hipLaunchKernelGGL((conv3d_k3_mfma<2, false, 4>), grid, dim3(256), lds, st, x, w_prep, y, cin, cout, cpad, d, h, w, tg, epi);
+      else
+        hipLaunchKernelGGL((conv3d_k3_mfma<2, true, 4>), grid, dim3(256), lds, st, x, w_prep, y, cin, cout, cpad, d, h, w, tg, epi);
+    }
   } else if (stride == 1) {
     const dim3 grid(tiles_w * tiles_h, (gd + kTD - 1) / kTD, b * cblocks);
     hipLaunchKernelGGL((conv3d_k3_mfma_generic<1>), grid, dim3(256), static_cast<size_t>(GenGeo<1>::kSX + kSW) * sizeof(float), st, x, w_prep, y,
