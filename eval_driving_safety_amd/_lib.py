@@ -93,6 +93,7 @@ SIGNATURES = {
     "adv_grid_sample3d_plan_f32": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "adv_grid_sample3d_bwd_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "adv_sigmoid_focal_loss_f32": [_P, _P, _P, _P, _L, _I, _F, _F, _P],
+    "adv_relu_backward_f32": [_P, _P, _P, _L, _P],
 }
 _OTHER = {
     "adv_abi_version": ([], _I),

@@ -449,6 +449,22 @@ __global__ __launch_bounds__(kBlock) void grid_sample3d_bwd(const float* __restr
     if (c0 + j < C) __builtin_nontemporal_store(acc[j], op + j * ivol);
 }
 
+// ---- the backward of a fused ReLU: out = y > 0 ? grad : 0 (torch's threshold_backward), one pass instead of a compare and a
+//      multiply; the convolutions' autograd wrappers apply it to the incoming gradient before the adjoint convolution.
+__global__ __launch_bounds__(kBlock) void relu_backward_kernel(const float* __restrict__ grad, const float* __restrict__ y, float* __restrict__ out,
+                                                               long long n4, long long n) {
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  const long long stride = static_cast<long long>(gridDim.x) * kBlock;
+  for (long long i = blockIdx.x * static_cast<long long>(kBlock) + threadIdx.x; i < n4; i += stride) {
+    const v4 g = __builtin_nontemporal_load(reinterpret_cast<const v4*>(grad) + i);
+    const v4 v = __builtin_nontemporal_load(reinterpret_cast<const v4*>(y) + i);
+    v4 o;
+    o.x = v.x > 0.0f ? g.x : 0.0f, o.y = v.y > 0.0f ? g.y : 0.0f, o.z = v.z > 0.0f ? g.z : 0.0f, o.w = v.w > 0.0f ? g.w : 0.0f;
+    __builtin_nontemporal_store(o, reinterpret_cast<v4*>(out) + i);
+  }
+  for (long long i = 4 * n4 + blockIdx.x * static_cast<long long>(kBlock) + threadIdx.x; i < n; i += stride) out[i] = y[i] > 0.0f ? grad[i] : 0.0f;
+}
+
 inline bool aligned4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3u) == 0; }
 
 }  // namespace
@@ -543,6 +559,20 @@ int adv_grid_sample3d_bwd_f32(const float* grad_out, const void* plan, float* gr
   const PlanView pv = plan_view(const_cast<void*>(plan), b * ivol, 8 * b * ovol);
   hipLaunchKernelGGL(grid_sample3d_bwd, dim3(static_cast<unsigned>((ivol + kBlock - 1) / kBlock), (c + kGsChan - 1) / kGsChan, b), dim3(kBlock), 0,
                      static_cast<hipStream_t>(stream), grad_out, pv, grad_vol, c, ivol, ovol);
+  return adv_internal_finish_launch();
+}
+
+int adv_relu_backward_f32(const float* grad, const float* y, float* out, int64_t n, adv_stream_t stream) {
+  if (!grad || !y || !out || n < 0) return ADV_EINVAL;
+  if (n == 0) return ADV_OK;
+  if (!aligned4(grad) || !aligned4(y) || !aligned4(out)) return ADV_EALIGN;
+  const bool vec = ((reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0;
+  const long long n4 = vec ? n / 4 : 0;
+  long long blocks = ((vec ? n4 : n) + kBlock - 1) / kBlock;
+  if (blocks > 65535LL * 16) blocks = 65535LL * 16;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(relu_backward_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), grad, y, out, n4,
+                     static_cast<long long>(n));
   return adv_internal_finish_launch();
 }
 

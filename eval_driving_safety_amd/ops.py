@@ -707,6 +707,19 @@ def conv_transpose3d_k3_s2(x, classes, cout, relu=False, bias=None):
     return out
 
 
+def relu_backward(grad, y):
+    """grad where y > 0 else 0 (threshold_backward), one pass; ``y`` is the output of the fused-ReLU convolution"""
+    g, yy = _feat(grad.contiguous(), "grad"), _feat(y, "y")
+    if g.shape != yy.shape:
+        raise ValueError("grad and y must have the same shape")
+    out = torch.empty_like(g)
+    if g.numel() == 0:
+        return out
+    with _on(g):
+        _lib.call("adv_relu_backward_f32", _ptr(g), _ptr(yy), _ptr(out), g.numel(), _stream(g))
+    return out
+
+
 class Conv3dK3(torch.autograd.Function):
     """y = [relu](conv3d(x, weight) [+ bias]); gradient flows to x only (the attacks differentiate w.r.t. the images, the
     detector's weights are constants), through the same kernel family with the transposed / flipped weights (cout a
@@ -726,7 +739,7 @@ class Conv3dK3(torch.autograd.Function):
     def backward(ctx, grad_y):
         w, y = ctx.saved_tensors
         if ctx.relu:
-            grad_y = grad_y * (y > 0)
+            grad_y = relu_backward(grad_y, y)
         if ctx.has_t:
             return conv3d_k3(grad_y.contiguous(), w, ctx.xshape[1]), None, None, None, None, None, None
         return torch.nn.grad.conv3d_input(ctx.xshape, w, grad_y, padding=1), None, None, None, None, None, None
@@ -746,7 +759,7 @@ class Conv3dK3S2(torch.autograd.Function):
     def backward(ctx, grad_y):
         (y,) = ctx.saved_tensors
         if ctx.relu:
-            grad_y = grad_y * (y > 0)
+            grad_y = relu_backward(grad_y, y)
         g = conv_transpose3d_k3_s2(grad_y.contiguous(), ctx.classes_t, ctx.xshape[1])
         d, h, w = ctx.xshape[2:]
         if tuple(g.shape[2:]) != (d, h, w):
@@ -769,7 +782,7 @@ class ConvTranspose3dK3S2(torch.autograd.Function):
     def backward(ctx, grad_y):
         (y,) = ctx.saved_tensors
         if ctx.relu:
-            grad_y = grad_y * (y > 0)
+            grad_y = relu_backward(grad_y, y)
         return conv3d_k3_s2(grad_y.contiguous(), ctx.w_prep_fwd, ctx.cin), None, None, None, None, None
 
 

@@ -370,6 +370,9 @@ ADV_API int adv_grid_sample3d_bwd_f32(const float* grad_out, const void* plan, f
 ADV_API int adv_sigmoid_focal_loss_f32(const float* logits, const int32_t* targets, float* loss_out, float* grad_out, int64_t n,
                                        int k, float gamma, float alpha, adv_stream_t stream);
 
+/* out[i] = y[i] > 0 ? grad[i] : 0  (the backward of a ReLU fused into a convolution's epilogue; out may alias grad). */
+ADV_API int adv_relu_backward_f32(const float* grad, const float* y, float* out, int64_t n, adv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

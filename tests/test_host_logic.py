@@ -474,7 +474,7 @@ def test_ops_surface_is_complete():
              "Conv3dK3", "Conv3dK3S2", "ConvTranspose3dK3S2",
              "dense_align_cost", "dense_align_argmin", "dense_align_search", "box_depth_offsets", "dense_align",
              "depth_regress", "depth_regress_bwd", "DepthRegress", "grid_sample3d", "GridSamplePlan", "grid_sample3d_bwd", "GridSample3d",
-             "sigmoid_focal_loss", "SigmoidFocalLoss"]
+             "sigmoid_focal_loss", "SigmoidFocalLoss", "relu_backward"]
     missing = [n for n in names if not hasattr(ops, n)]
     assert not missing, missing
     # and every exported C symbol is reachable from some operator

@@ -157,3 +157,19 @@ def test_hip_sigmoid_focal_loss():
     txr = tx.clone().requires_grad_(True)
     ops.SigmoidFocalLoss.apply(txr, tt, 2.0, 0.25).backward()
     np.testing.assert_allclose(txr.grad.cpu().numpy(), wg, rtol=2e-5, atol=1e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [0, 1, 5, 4096, 100003])
+def test_hip_relu_backward(n):
+    from eval_driving_safety_amd import ops
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(n)
+    g = torch.randn((n,), device=dev, generator=gen)
+    y = torch.relu(torch.randn((n,), device=dev, generator=gen))
+    if n > 3:
+        y[1], g[1] = 0.0, float("inf")           # threshold_backward semantics: a dead unit passes nothing, not inf * 0
+    want = torch.where(y > 0, g, torch.zeros_like(g))
+    assert torch.equal(ops.relu_backward(g, y), want)
+    if n > 8:                                    # a view that is only 4-byte aligned takes the scalar path
+        assert torch.equal(ops.relu_backward(g[1:], y[1:].contiguous()), want[1:])
