@@ -663,7 +663,10 @@ __global__ __launch_bounds__(256, CI == 1 ? 4 : 2) void conv3d_k3_narrow_in(cons
 // so the strided layers of an hourglass run on the tuned stride-1 kernel.  HBM-bound permute, writes coalesced.
 __global__ __launch_bounds__(256) void space_to_depth2(const float* __restrict__ x, float* __restrict__ xs, int B, int C, int D, int H, int W,
                                                        int D2, int H2, int W2) {
-  const long long total = static_cast<long long>(B) * 8 * C * D2 * H2 * W2;
+  // one lane per (b, c, pd, ph, jd, jh, jw): it reads the x-pair (2jw, 2jw+1) of input row (2jd+pd, 2jh+ph) - consecutive lanes read
+  // consecutive pairs, whole cache lines - and writes one float to each of the two sub-volumes pw = 0, 1 (both coalesced)
+  const long long total = static_cast<long long>(B) * C * 4 * D2 * H2 * W2;
+  const long long sub = static_cast<long long>(D2) * H2 * W2;
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += gridDim.x * 256LL) {
     const int jw = static_cast<int>(i % W2);
     long long t = i / W2;
@@ -671,12 +674,28 @@ __global__ __launch_bounds__(256) void space_to_depth2(const float* __restrict__
     t /= H2;
     const int jd = static_cast<int>(t % D2);
     t /= D2;
+    const int q = static_cast<int>(t % 4);   // (pd, ph)
+    t /= 4;
     const int c = static_cast<int>(t % C);
-    t /= C;
-    const int p = static_cast<int>(t % 8);
-    const long long b = t / 8;
-    const int gd = 2 * jd + (p >> 2), gh = 2 * jh + ((p >> 1) & 1), gw = 2 * jw + (p & 1);
-    xs[i] = (gd < D && gh < H && gw < W) ? x[((b * C + c) * D + gd) * (static_cast<long long>(H) * W) + static_cast<long long>(gh) * W + gw] : 0.0f;
+    const long long b = t / C;
+    const int gd = 2 * jd + (q >> 1), gh = 2 * jh + (q & 1), gw = 2 * jw;
+    float v0 = 0.0f, v1 = 0.0f;
+    if (gd < D && gh < H) {
+      const float* src = x + ((b * C + c) * D + gd) * (static_cast<long long>(H) * W) + static_cast<long long>(gh) * W + gw;
+      if (gw + 1 < W) {
+        if ((reinterpret_cast<uintptr_t>(src) & 7u) == 0) {
+          const float2 v = *reinterpret_cast<const float2*>(src);
+          v0 = v.x, v1 = v.y;
+        } else {
+          v0 = src[0], v1 = src[1];
+        }
+      } else if (gw < W) {
+        v0 = src[0];
+      }
+    }
+    float* dst = xs + ((b * 8 + 2 * q) * C + c) * sub + (static_cast<long long>(jd) * H2 + jh) * W2 + jw;  // sub-volume p = 2q + pw
+    dst[0] = v0;
+    dst[static_cast<long long>(C) * sub] = v1;
   }
 }
 
@@ -832,7 +851,7 @@ int adv_conv3d_k3_f32(const float* x, const float* w_prep, float* y, int b, int 
 int adv_space_to_depth2_f32(const float* x, float* xs, int b, int c, int d, int h, int w, adv_stream_t stream) {
   if (!x || !xs || b < 1 || c < 1 || d < 1 || h < 1 || w < 1) return ADV_EINVAL;
   const int d2 = (d + 1) / 2, h2 = (h + 1) / 2, w2 = (w + 1) / 2;
-  const long long total = static_cast<long long>(b) * 8 * c * d2 * h2 * w2;
+  const long long total = static_cast<long long>(b) * 4 * c * d2 * h2 * w2;   // one lane per pair of output elements
   long long blocks = (total + 255) / 256;
   if (blocks > (1 << 20)) blocks = 1 << 20;
   hipLaunchKernelGGL(space_to_depth2, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, static_cast<hipStream_t>(stream), x, xs, b, c, d, h, w, d2,
