@@ -301,6 +301,86 @@ __device__ __forceinline__ void stage_commit(const Stage<TD, TH>& st, const Plan
   }
 }
 
+// ---- staging by LDS-DMA (global_load_lds_dwordx4: global memory -> LDS with no register in between), W % 4 == 0.
+// An LDS row of the input tile is 40 floats = the 40 floats [w0-4, w0+36) of the global row (the halo columns w0-1 and w0+32 sit at
+// LDS columns 3 and 36, exactly where the register path puts them), so a stage's input tile is kRows*10 float4 that are contiguous
+// in LDS, and its weights 27*4*8 float4 likewise: one wave-instruction moves 64 consecutive float4 (1 KiB), the lanes supplying
+// their own global addresses.  Groups that lie outside the volume (zero padding in d/h, columns < 0 or >= W - whole groups,
+// because W and w0 are multiples of 4) read a 16-byte zero page instead.  No staging registers, no selects, no ds_write.
+__device__ __attribute__((aligned(16))) const float g_zero16[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+
+__device__ __forceinline__ void glds16(const float* src, float* lds_piece) {  // lane l's 16 bytes land at lds_piece + 4*l floats
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_global_load_lds(src, lds_piece, 16, 0, 0);
+#else
+  (void)src, (void)lds_piece;
+#endif
+}
+
+template <int TD, int TH>
+struct DmaGeo {
+  using G = Geo<TD, TH>;
+  static_assert((G::kRows * 10) % 64 == 0, "the input tile is a whole number of 1 KiB pieces");
+  static constexpr int kXInstr = G::kRows * 10 / 64;            // 25 (TH = 8) / 15 (TH = 4) wave-instructions
+  static constexpr int kWInstr = (kWF4 + 63) / 64;              // 14, the last one half used (its tail lands in the pad below)
+  static constexpr int kWaves = G::kThreads / 64;
+  static constexpr int kXPer = (kXInstr + kWaves - 1) / kWaves; // pieces a wave may own
+  static constexpr int kWPer = (kWInstr + kWaves - 1) / kWaves;
+  static constexpr int kStageFloats = G::kSX + kWInstr * 256;   // weights area rounded up to whole pieces
+};
+
+template <int TD, int TH>
+struct DmaPlan {   // per lane: element offsets of its float4 of every piece its wave owns; -1 = the zero page
+  int xo[DmaGeo<TD, TH>::kXPer];
+  int wo[DmaGeo<TD, TH>::kWPer];
+};
+
+template <int TD, int TH>
+__device__ __forceinline__ void make_dma_plan(DmaPlan<TD, TH>& pl, int tid, int Cin, int cout_pad, int D, int H, int W, int d0, int h0, int w0,
+                                              int plane, int vol) {
+  using DG = DmaGeo<TD, TH>;
+  constexpr int kPerC = (TD + 2) * (TH + 2);
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int p = 0; p < DG::kXPer; ++p) {
+    const int q = 64 * (wave + DG::kWaves * p) + lane;   // float4 index inside the tile (pieces beyond kXInstr are never issued)
+    const int row = q / 10, j = q - row * 10;
+    const int c = row / kPerC, rem = row - c * kPerC;
+    const int dd = rem / (TH + 2), hh = rem - dd * (TH + 2);
+    const int gd = d0 + dd - 1, gh = h0 + hh - 1, gw = w0 - 4 + 4 * j;
+    const bool ok = gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw + 3 < W;
+    pl.xo[p] = ok ? c * vol + gd * plane + gh * W + gw : -1;
+  }
+#pragma unroll
+  for (int p = 0; p < DG::kWPer; ++p) {
+    const int f = 64 * (wave + DG::kWaves * p) + lane;
+    const int n4 = f & 7, c = (f >> 3) & (kFC - 1), tap = f / (8 * kFC);
+    pl.wo[p] = f < kWF4 ? (tap * Cin + c) * cout_pad + 4 * n4 : -1;
+  }
+}
+
+template <int TD, int TH>
+__device__ __forceinline__ void dma_issue(const DmaPlan<TD, TH>& pl, const float* __restrict__ xc, const float* __restrict__ wc, float* stage,
+                                          int wave) {
+  using DG = DmaGeo<TD, TH>;
+#pragma unroll
+  for (int p = 0; p < DG::kXPer; ++p) {
+    const int k = wave + DG::kWaves * p;   // wave-uniform
+    if (k < DG::kXInstr) {
+      const float* src = pl.xo[p] >= 0 ? xc + pl.xo[p] : g_zero16;
+      glds16(src, stage + k * 256);
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < DG::kWPer; ++p) {
+    const int k = wave + DG::kWaves * p;
+    if (k < DG::kWInstr) {
+      const float* src = pl.wo[p] >= 0 ? wc + pl.wo[p] : g_zero16;
+      glds16(src, stage + DG::G::kSX + k * 256);
+    }
+  }
+}
+
 // Tiles of the launch, linearised: (row tile, column tile) fastest, then the depth pair, then (batch element, block of 32 output
 // channels).  PERSISTENT workgroups walk them: gridDim.x = min(tiles, 2 per CU), workgroup i takes a contiguous share of the
 // tile range of "its" XCD (workgroups are dealt to the eight XCDs round-robin, so i % 8 is the XCD and each XCD's private L2 sees
@@ -339,7 +419,7 @@ __device__ __forceinline__ TilePos tile_at(const TileGrid& tg, long long t) {
 
 // MASKED = false: every tap, no branch in the unrolled tap loop (the ordinary convolution: operand reads run ahead of the
 // MFMAs); MASKED = true: taps are skipped by epi.tap_mask (one parity class of a transposed convolution).
-template <int TD, bool MASKED, int TH = 8>
+template <int TD, bool MASKED, int TH = 8, bool DMA = false>
 __global__ __launch_bounds__(128 * TD, 2) void conv3d_k3_mfma(const float* __restrict__ x, const float* __restrict__ wp,
                                                               float* __restrict__ y, int Cin, int Cout, int cout_pad, int D, int H, int W,
                                                               TileGrid tg, Epi epi) {
@@ -371,15 +451,24 @@ __global__ __launch_bounds__(128 * TD, 2) void conv3d_k3_mfma(const float* __res
 
   // two LDS stages: while the waves run the MFMAs of stage `cur`, the next chunk travels global -> registers ->
   // the other stage; ONE barrier per chunk
+  constexpr int kStage = DMA ? DmaGeo<TD, TH>::kStageFloats : G::kStageFloats;
   Stage<TD, TH> st;
   Plan<TD, TH> pl;
+  DmaPlan<TD, TH> dpl;
   TilePos tp = tile_at<TD, TH>(tg, first);
-  make_plan<TD, true, TH>(pl, tid, Cin, cout_pad, D, H, W, tp.d0, tp.h0, tp.w0, plane, vol);
+  if (DMA)
+    make_dma_plan<TD, TH>(dpl, tid, Cin, cout_pad, D, H, W, tp.d0, tp.h0, tp.w0, plane, vol);
+  else
+    make_plan<TD, true, TH>(pl, tid, Cin, cout_pad, D, H, W, tp.d0, tp.h0, tp.w0, plane, vol);
   const float* xb = x + static_cast<long long>(tp.b) * Cin * vol;
   const float* wb = ((MASKED && epi.nclass > 0) ? epi.cls_wp[tp.cls] : wp) + tp.cob * 32;
-  stage_fetch<TD, true, TH>(st, pl, xb, wb);
-  stage_commit<TD, true, TH>(st, pl, lds, lds + G::kSX, tid);
-  __syncthreads();
+  if (DMA) {
+    dma_issue<TD, TH>(dpl, xb, wb, lds, wave);
+  } else {
+    stage_fetch<TD, true, TH>(st, pl, xb, wb);
+    stage_commit<TD, true, TH>(st, pl, lds, lds + G::kSX, tid);
+  }
+  __syncthreads();   // (waits for the DMA too: the compiler drains vmcnt before a barrier)
   int cur = 0;
   for (int k = 0; k < count; ++k) {
     f32x16 acc[NB];
@@ -396,7 +485,10 @@ __global__ __launch_bounds__(128 * TD, 2) void conv3d_k3_mfma(const float* __res
       if (cn >= Cin) {
         if (k + 1 < count) {
           tp = tile_at<TD, TH>(tg, first + (k + 1) * step);
-          make_plan<TD, true, TH>(pl, tid, Cin, cout_pad, D, H, W, tp.d0, tp.h0, tp.w0, plane, vol);
+          if (DMA)
+            make_dma_plan<TD, TH>(dpl, tid, Cin, cout_pad, D, H, W, tp.d0, tp.h0, tp.w0, plane, vol);
+          else
+            make_plan<TD, true, TH>(pl, tid, Cin, cout_pad, D, H, W, tp.d0, tp.h0, tp.w0, plane, vol);
           xb = x + static_cast<long long>(tp.b) * Cin * vol;
           wb = ((MASKED && epi.nclass > 0) ? epi.cls_wp[tp.cls] : wp) + tp.cob * 32;
           cn = 0;
@@ -404,9 +496,12 @@ __global__ __launch_bounds__(128 * TD, 2) void conv3d_k3_mfma(const float* __res
           cn = c0;
         }
       }
-      const float* sxc = lds + cur * G::kStageFloats;
+      const float* sxc = lds + cur * kStage;
       const float* swc = sxc + G::kSX;
-      stage_fetch<TD, true, TH>(st, pl, xb + static_cast<long long>(cn) * vol, wb + static_cast<long long>(cn) * cout_pad);
+      if (DMA)   // straight into the idle buffer; complete before the barrier that ends this stage
+        dma_issue<TD, TH>(dpl, xb + static_cast<long long>(cn) * vol, wb + static_cast<long long>(cn) * cout_pad, lds + (cur ^ 1) * kStage, wave);
+      else
+        stage_fetch<TD, true, TH>(st, pl, xb + static_cast<long long>(cn) * vol, wb + static_cast<long long>(cn) * cout_pad);
       // the loads are issued HERE, a hundred MFMAs before the commit that consumes them: without the fence the scheduler sinks
       // them next to their use and every wave sits in s_waitcnt vmcnt for a global-memory round trip per stage (PMC: 20 % of
       // the wave cycles parked, 10 % without the fetch)
@@ -415,8 +510,8 @@ __global__ __launch_bounds__(128 * TD, 2) void conv3d_k3_mfma(const float* __res
 #pragma unroll
       for (int t9 = 0; t9 < 9; ++t9) {  // (kd, kh); fully unrolled so that LDS operand reads run ahead of their MFMAs
         const int kd = t9 / 3, kh = t9 - kd * 3;
-        if (t9 == kCommitAt) {  // the next stage goes to the OTHER buffer in the shadow of this stage's MFMAs
-          float* nx = lds + (cur ^ 1) * G::kStageFloats;
+        if (!DMA && t9 == kCommitAt) {  // the next stage goes to the OTHER buffer in the shadow of this stage's MFMAs
+          float* nx = lds + (cur ^ 1) * kStage;
           stage_commit<TD, true, TH>(st, pl, nx, nx + G::kSX, tid);
         }
 #pragma unroll
@@ -809,19 +904,25 @@ static int launch_conv(const float* x, const float* w_prep, float* y, int b, int
     if (wgs > 0x7fffffffLL) return ADV_EINVAL;
     const dim3 grid(static_cast<unsigned>(wgs));
     const int cpad = cblocks * 32;
+    // staging by LDS-DMA needs whole float4 groups inside the rows: w % 4 == 0 and a 16-byte aligned x (ADV_CONV_NO_DMA=1: the
+    // register-staged path instead - test hook / A-B; same bits)
+    const bool dma = w % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && getenv("ADV_CONV_NO_DMA") == nullptr;
+#define ADV_LAUNCH_MFMA(MASKED_, TH_, DMA_)                                                                                                   \
+  do {                                                                                                                                        \
+    const size_t lds_ = 2 * sizeof(float) * static_cast<size_t>(DMA_ ? DmaGeo<2, TH_>::kStageFloats : Geo<2, TH_>::kStageFloats);               \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_k3_mfma<2, MASKED_, TH_, DMA_>), hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                            static_cast<int>(lds_)) != hipSuccess)                                                                            \
+      return ADV_ELAUNCH;                                                                                                                     \
+    hipLaunchKernelGGL((conv3d_k3_mfma<2, MASKED_, TH_, DMA_>), grid, dim3(256), lds_, st, x, w_prep, y, cin, cout, cpad, d, h, w, tg, epi);    \
+  } while (0)
     if (!th4) {
-      const size_t lds = 2 * static_cast<size_t>(Geo<2, 8>::kStageFloats) * sizeof(float);
-      if (all_taps)
-        hipLaunchKernelGGL((conv3d_k3_mfma<2, false, 8>), grid, dim3(256), lds, st, x, w_prep, y, cin, cout, cpad, d, h, w, tg, epi);
-      else
-        hipLaunchKernelGGL((conv3d_k3_mfma<2, true, 8>), grid, dim3(256), lds, st, x, w_prep, y, cin, cout, cpad, d, h, w, tg, epi);
+      if (all_taps) { if (dma) ADV_LAUNCH_MFMA(false, 8, true); else ADV_LAUNCH_MFMA(false, 8, false); }
+      else          { if (dma) ADV_LAUNCH_MFMA(true, 8, true); else ADV_LAUNCH_MFMA(true, 8, false); }
     } else {
-      const size_t lds = 2 * static_cast<size_t>(Geo<2, 4>::kStageFloats) * sizeof(float);
-      if (all_taps)
-        hipLaunchKernelGGL((conv3d_k3_mfma<2, false, 4>), grid, dim3(256), lds, st, x, w_prep, y, cin, cout, cpad, d, h, w, tg, epi);
-      else
-        hipLaunchKernelGGL((conv3d_k3_mfma<2, true, 4>), grid, dim3(256), lds, st, x, w_prep, y, cin, cout, cpad, d, h, w, tg, epi);
+      if (all_taps) { if (dma) ADV_LAUNCH_MFMA(false, 4, true); else ADV_LAUNCH_MFMA(false, 4, false); }
+      else          { if (dma) ADV_LAUNCH_MFMA(true, 4, true); else ADV_LAUNCH_MFMA(true, 4, false); }
     }
+#undef ADV_LAUNCH_MFMA
   } else if (stride == 1) {
     const dim3 grid(tiles_w * tiles_h, (gd + kTD - 1) / kTD, b * cblocks);
     hipLaunchKernelGGL((conv3d_k3_mfma_generic<1>), grid, dim3(256), static_cast<size_t>(GenGeo<1>::kSX + kSW) * sizeof(float), st, x, w_prep, y,
