@@ -63,7 +63,7 @@ def measure(pairs=1, iters=20, reps=2, warm_iters=None, mfma_conv=True, hourglas
         flops = 2.0 * 64 * 32 * 27 * pairs * 48 * 96 * 312
         mfma = {"bound": "mfma", "kernel": "conv3d_k3_mfma<2> 64->32 on [%d,64,48,96,312]" % pairs, "achieved": flops / ms / 1e9,
                 "peak": 157.3, "unit": "TFLOP/s", "frac": flops / ms / 1e9 / 157.3, "avg_launch_ms": ms,
-                "note": "float32 matrix peak (MI355X_MICROARCH.md); PMC: MFMA pipe 73 % busy (profiles/r01_conv3d_mfma_pmc.json)"}
+                "note": "float32 matrix peak (MI355X_MICROARCH.md); where the rest goes: profiles/r02_conv3d_where_the_time_goes.md (tile-count tail 6 %, staging issue 9 %, epilogue 2-6 %, width padding 2.5 %)"}
         del xv
     return {
         "metric": "end-to-end stereo-pairs/s, %d-step PGD through a DSGN-shaped plane-sweep depth net (surrogate, random weights)" % iters,
