@@ -417,6 +417,7 @@ def main():
                 out["end_to_end_hourglass"] = bench_end_to_end.measure(pairs=1, iters=N_ITER, reps=2, hourglass=True)
                 out["end_to_end_dsgn_shaped"] = bench_end_to_end.measure(pairs=1, iters=N_ITER, reps=2, hourglass=True, dsgn_head=True)
                 out["end_to_end_srcnn_shaped"] = bench_end_to_end.measure_srcnn(pairs=1, iters=N_ITER, reps=2)
+                out["end_to_end_patch"] = bench_end_to_end.measure_patch(pairs=8, iters=2, reps=2)
             except Exception as e:
                 out["end_to_end"] = {"error": repr(e)}
             torch.cuda.empty_cache()

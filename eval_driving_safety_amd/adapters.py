@@ -437,8 +437,8 @@ class PsvStereoAdapter:
             mask = (gt > float(self.depth[0])) & (gt <= float(self.depth[-1]) + 0.8)
             if self.dsgn_head:      # pgd_attack.py:310-336: depth term + the detection head's three terms
                 pred, maps = self.forward_all(imgL, imgR)
-                key = (id(extra), id(extra.boxes))
-                if getattr(self, "_tgt_key", None) != key:     # targets depend on the labels only: once per batch, not per PGD step
+                key = (tuple(maps[0].shape), tuple(tuple(tuple(float(v) for v in bx) for bx in img) for img in extra.boxes))
+                if getattr(self, "_tgt_key", None) != key:     # targets depend on the labels only: once per label set, not per step
                     self._tgt, self._tgt_key = self.detection_targets(extra.boxes, maps[0].shape[2], maps[0].shape[3]), key
                 loss = F.smooth_l1_loss(pred[mask], gt[mask], reduction="mean") + self.detection_loss(maps, self._tgt)
             else:

@@ -116,6 +116,47 @@ def measure_srcnn(pairs=1, iters=20, reps=2):
                     "ops.RoIAlign (paired-load forward, atomic-free gather backward) + the six losses of stereo_rcnn.py; PGD step by libadvengine.so"}
 
 
+def measure_patch(pairs=8, iters=2, reps=2):
+    """BASELINE configs[3] end to end: the universal round patch (ratio 0.2605 -> D = 101) trained through the DSGN-shaped graph -
+    per pair and inner iteration: paste in both eyes (K3), detector forward + backward towards the fake target, windowed gradient
+    sum + clamp + patch update (K4); batch 1, world 1 = the reference's own sequence (attack/DSGN/patch_attack.py:367-430)"""
+    import tempfile
+    dev = torch.device("cuda", torch.cuda.current_device())
+    net = adapters.PsvStereoAdapter(dev, seed=0, hourglass=True, dsgn_head=True)
+    import contextlib
+    import io
+    batches = []                                   # the pairs are generated once, outside the timed region (host-side synthesis)
+    for b in data.SyntheticStereo(pairs, "dsgn", batch=1, seed=3):
+        b.extra = net.synthetic_extra(b, seed=1)
+        batches.append(b)
+
+    def fresh():                                   # the trainer pastes in place: every epoch starts from clean copies
+        out = []
+        for b in batches:
+            c = data.StereoBatch(b.imgL.clone(), b.imgR.clone(), list(b.names), b.sizes)
+            c.extra = types.SimpleNamespace(disp_true=b.extra.disp_true, boxes=[list(v) for v in b.extra.boxes])
+            out.append(c)
+        return out
+
+    with tempfile.TemporaryDirectory() as tmp, contextlib.redirect_stdout(io.StringIO()):
+        trainer = attacks.PatchTrainer("dsgn", 0.2605, 8 / 255, iters, 1, out_root=tmp, seed=0, device=dev)
+        warm = fresh()
+        trainer.train(lambda: warm, net)           # warm: kernels loaded, MIOpen solvers found
+        epochs = [fresh() for _ in range(reps)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for e in epochs:
+            trainer.train(lambda: e, net)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+    return {"metric": "end-to-end stereo-pairs/s, universal-patch training (D = %d, %d inner iterations per pair) through the DSGN-shaped graph "
+                      "(surrogate, random weights)" % (trainer.patch_dim, iters),
+            "value": pairs / dt, "unit": "stereo-pairs/s", "pairs": pairs, "inner_iters": iters, "s_per_epoch_of_%d_pairs" % pairs: dt,
+            "ms_per_inner_iteration": 1e3 * dt / (pairs * iters), "patch_abs_max": float(trainer.patch.abs().max()),
+            "note": "NOT the headline metric and NOT DSGN; pairs pre-generated on the host, the per-epoch patch.npy write included; paste / update "
+                    "kernels and every 3D operator by libadvengine.so"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--pairs", type=int, default=1)
@@ -124,11 +165,15 @@ def main():
     ap.add_argument("--miopen", action="store_true", help="route the wide convolutions through torch / MIOpen instead")
     ap.add_argument("--hourglass", action="store_true", help="the 3D-hourglass volume network instead of three convolutions")
     ap.add_argument("--dsgn-head", action="store_true", help="fused depth regression + 3D geometric volume + bird's-eye-view detection head")
+    ap.add_argument("--patch", action="store_true", help="universal-patch training through the DSGN-shaped graph instead")
     ap.add_argument("--srcnn", action="store_true", help="the Stereo R-CNN-shaped surrogate at 600x1987 instead")
     args = ap.parse_args()
     torch.cuda.set_device(0)
     if args.srcnn:
         print(json.dumps(measure_srcnn(args.pairs, args.iters, args.reps)))
+        return
+    if args.patch:
+        print(json.dumps(measure_patch(max(args.pairs, 4), 2, args.reps)))
         return
     print(json.dumps(measure(args.pairs, args.iters, args.reps, mfma_conv=not args.miopen, hourglass=args.hourglass, dsgn_head=args.dsgn_head)))
 
