@@ -119,6 +119,35 @@ def test_hip_persistent_tile_walk_equals_one_workgroup_per_tile(masked, monkeypa
     assert torch.equal(got[:, :, 1:6], y[1:, :, 21:26])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("switch", ["ADV_CONV_NO_DMA=1", "ADV_CONV_TH=4", "ADV_CONV_TH=8", "ADV_CONV_GENERIC=1", "ADV_CONV_CLASS_LAUNCHES=1"])
+def test_hip_alternative_code_paths_give_the_same_bits(switch, monkeypatch):
+    """register-staged vs LDS-DMA stages, both tile heights, the scalar-staging kernel, eight launches vs one for the transposed
+    convolution: identical results on plain, masked, strided and transposed layers (W % 4 == 0 and != 0)"""
+    from eval_driving_safety_amd import ops
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(21)
+    results = []
+    for rnd in range(2):
+        if rnd == 1:
+            k, v = switch.split("=")
+            monkeypatch.setenv(k, v)
+        out = []
+        for w in (40, 38):
+            g = torch.Generator(device=dev).manual_seed(100 + w)
+            x = torch.randn((2, 8, 6, 20, w), device=dev, generator=g)
+            wt = torch.randn((40, 8, 3, 3, 3), device=dev, generator=g) * 0.1
+            bias = torch.linspace(-0.1, 0.2, 40, device=dev)
+            out.append(ops.conv3d_k3(x, ops.conv3d_k3_prep(wt), 40, relu=True, bias=bias))
+            out.append(ops._conv3d_ex(x, ops.conv3d_k3_prep(wt), 40, 1, False, None, 0b000111000101010000111000101))
+            out.append(ops.conv3d_k3_s2(x, ops.conv3d_k3_s2_prep(wt), 40, relu=True, bias=bias))
+            wtt = torch.randn((8, 24, 3, 3, 3), device=dev, generator=g) * 0.1
+            out.append(ops.conv_transpose3d_k3_s2(x, ops.conv_transpose3d_k3_s2_prep(wtt), 24, bias=bias[:24]))
+        results.append(out)
+    for a, b in zip(*results):
+        assert torch.equal(a, b)
+
+
 NARROW = [(1, 32, 1, 6, 24, 40), (2, 8, 1, 3, 9, 33), (1, 12, 3, 4, 8, 78), (1, 8, 8, 5, 10, 45), (1, 16, 5, 2, 17, 36), (1, 4, 2, 1, 1, 1)]
 
 
