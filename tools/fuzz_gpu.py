@@ -1,0 +1,131 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep on the GPU (not part of the test-suite: run by hand / by gpurun).  Random shapes through the HIP
+kernels against the oracle, bit for bit: convolution (plain / bias+ReLU / masked / strided / transposed, every alternative code path),
+grid_sample3d forward + gather backward, RoIAlign forward + backward, cost volume, PGD steps with and without the 8-bit index.
+usage: python tools/fuzz_gpu.py [--cases 150] [--seed 0]"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+from eval_driving_safety_amd import ops  # noqa: E402
+from oracle import oracle_c as C  # noqa: E402
+from oracle import oracle_np as O  # noqa: E402
+import synth  # noqa: E402
+
+
+def same(a, b, what):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else a
+    if a.tobytes() != np.ascontiguousarray(b).tobytes():
+        bad = int((a.view(np.uint32) != np.ascontiguousarray(b).view(np.uint32)).sum()) if a.shape == b.shape else -1
+        raise AssertionError("%s: %d elements differ" % (what, bad))
+
+
+def conv_case(rs, dev, big=False):
+    b = int(rs.randint(1, 3))
+    cin = 4 * int(rs.randint(1, 5))
+    cout = int(rs.choice([1, 3, 8, 12, 32, 33, 40, 64]))
+    d, h = int(rs.randint(1, 9)), int(rs.randint(1, 30))
+    w = int(rs.choice([4, 8, 31, 32, 33, 36, 40, 64, 78, 100]))
+    if big:      # more tiles than resident workgroups: the persistent walk with several tiles per workgroup
+        cin, cout = 4 * int(rs.randint(1, 3)), int(rs.choice([32, 40, 64]))
+        d, h, w = int(rs.randint(20, 40)), int(rs.randint(40, 80)), int(rs.choice([156, 160, 200, 310, 312]))
+    x = rs.randn(b, cin, d, h, w).astype(np.float32)
+    wt = (rs.randn(cout, cin, 3, 3, 3) * 0.1).astype(np.float32)
+    bias = rs.randn(cout).astype(np.float32) if rs.rand() < 0.5 else None
+    relu = bool(rs.rand() < 0.5)
+    mask = int(rs.randint(1, 1 << 27)) if rs.rand() < 0.4 else (1 << 27) - 1
+    sw = rs.choice(["", "ADV_CONV_NO_DMA", "ADV_CONV_TH4", "ADV_CONV_TH8", "ADV_CONV_ONE_TILE_PER_WG", "ADV_CONV_GENERIC"])
+    env = {"ADV_CONV_TH4": ("ADV_CONV_TH", "4"), "ADV_CONV_TH8": ("ADV_CONV_TH", "8")}.get(sw, (sw, "1") if sw else None)
+    if env:
+        os.environ[env[0]] = env[1]
+    try:
+        tx, tw = torch.tensor(x, device=dev), torch.tensor(wt, device=dev)
+        tb = None if bias is None else torch.tensor(bias, device=dev)
+        y = ops._conv3d_ex(tx, ops.conv3d_k3_prep(tw), cout, 1, relu, tb, mask)
+        same(y, C.conv3d_k3_ex(x, wt, bias=bias, relu=relu, tap_mask=mask), "conv %s" % ((b, cin, cout, d, h, w, relu, hex(mask), sw),))
+        if rs.rand() < 0.4:
+            ys = ops.conv3d_k3_s2(tx, ops.conv3d_k3_s2_prep(tw), cout, relu=relu, bias=tb)
+            same(ys, C.conv3d_k3_s2(x, wt, bias=bias, relu=relu), "strided conv %s" % ((b, cin, cout, d, h, w, sw),))
+        if rs.rand() < 0.4:
+            wtt = (rs.randn(cin, cout, 3, 3, 3) * 0.1).astype(np.float32)
+            yt = ops.conv_transpose3d_k3_s2(tx, ops.conv_transpose3d_k3_s2_prep(torch.tensor(wtt, device=dev)), cout, relu=relu, bias=tb)
+            same(yt, C.conv_transpose3d_k3_s2(x, wtt, bias=bias, relu=relu), "transposed conv %s" % ((b, cin, cout, d, h, w, sw),))
+    finally:
+        if env:
+            del os.environ[env[0]]
+
+
+def grid_case(rs, dev):
+    b, c = int(rs.randint(1, 3)), int(rs.randint(1, 20))
+    dims = tuple(int(v) for v in rs.randint(1, 12, 3))
+    out = tuple(int(v) for v in rs.randint(1, 12, 3))
+    align = bool(rs.rand() < 0.5)
+    vol = rs.randn(b, c, *dims).astype(np.float32)
+    grid = (rs.rand(b, *out, 3) * 2.6 - 1.3).astype(np.float32)
+    tv, tg = torch.tensor(vol, device=dev), torch.tensor(grid, device=dev)
+    same(ops.grid_sample3d(tv, tg, align), O.grid_sample3d(vol, grid, align), "grid_sample3d %s" % ((b, c, dims, out, align),))
+    g = rs.randn(b, c, *out).astype(np.float32)
+    plan = ops.GridSamplePlan(tg, dims, align)
+    same(ops.grid_sample3d_bwd(torch.tensor(g, device=dev), plan), O.grid_sample3d_bwd(g, grid, dims, align), "grid_sample3d bwd %s" % ((b, c, dims, out, align),))
+
+
+def pgd_case(rs, dev):
+    n = int(rs.randint(1, 7))
+    if rs.rand() < 0.5:
+        h, w = int(rs.randint(2, 20)), 4 * int(rs.randint(1, 20))
+        vh, vw = int(rs.randint(1, h + 1)), int(rs.randint(1, w + 1))
+        sp = ops.Space.dsgn()
+        x0 = np.concatenate([synth.dsgn_padded(int(rs.randint(1 << 20)), vh, vw, h, w) for _ in range(n)])
+        step, alpha, eps, valid = O.pgd_step_norm01, 1 / 255, 0.03, (vh, vw)
+        clean_np = O.denormalize(x0)
+    else:
+        h = int(rs.randint(2, 20))
+        w = int(rs.randint(3, 60))
+        if (h * w) % 4:
+            h *= 4
+        sp = ops.Space.srcnn()
+        x0 = np.concatenate([synth.srcnn_meansub(int(rs.randint(1 << 20)), h, w) for _ in range(n)])
+        step, alpha, eps, valid = O.pgd_step_meansub255, 1.0, 7.65, None
+        clean_np = x0
+    if rs.rand() < 0.3:
+        x0[0] = x0[0] * np.float32(0.9993)                        # one image that is not 8-bit derived
+        clean_np = O.denormalize(x0) if sp.affine else x0
+    g = synth.gradient(int(rs.randint(1 << 20)), x0.shape, 1.0)
+    x = torch.tensor(x0, device=dev)
+    clean, ci = ops.denormalize_indexed(x, sp, valid=valid)
+    want = x0
+    for _ in range(2):
+        want = step(want, g, clean_np, alpha, eps)
+        ops.pgd_step(x, torch.tensor(g, device=dev), clean, sp, alpha, eps, out=x, clean_index=ci)
+    same(x, want, "pgd %s" % ((n, h, w, sp.affine),))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=150)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--big", type=int, default=0, help="additional convolution cases with thousands of tiles")
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    rs = np.random.RandomState(args.seed)
+    kinds = [conv_case] * 5 + [grid_case] * 2 + [pgd_case] * 3
+    counts = {}
+    for i in range(args.cases):
+        fn = kinds[int(rs.randint(len(kinds)))]
+        fn(rs, dev)
+        counts[fn.__name__] = counts.get(fn.__name__, 0) + 1
+    for i in range(args.big):
+        conv_case(rs, dev, big=True)
+        counts["conv_case(big)"] = counts.get("conv_case(big)", 0) + 1
+    torch.cuda.synchronize()
+    print("fuzz ok: %s (seed %d)" % (", ".join("%s x%d" % kv for kv in sorted(counts.items())), args.seed))
+
+
+if __name__ == "__main__":
+    main()
