@@ -66,6 +66,7 @@ SIGNATURES = {
     "adv_pgd_step_f32": [_P, _P, _P, _P, _P, _L, _I, _I, _SP, _F, _F, _I, _I, _L, _L, _P],
     "adv_export_u8_f32": [_P, _P, _L, _I, _I, _SP, _I, _I, _L, _L, _P],
     "adv_clean_index_build_f32": [_P, _P, _CI, _P, _L, _I, _I, _SP, _I, _I, _L, _L, _P],
+    "adv_import_u8_f32": [_P, _L, _L, _P, _P, _CI, _I, _I, _L, _I, _I, _SP, _P],
     "adv_pgd_step_indexed_f32": [_P, _P, _P, _CI, _P, _P, _L, _I, _I, _SP, _F, _F, _I, _I, _L, _L, _P],
     "adv_disc_mask_f32": [_P, _I, _I, _I, _I, _I, _P],
     "adv_patch_paste_f32": [_P, _P, _I, _I, _I, _I, _I, _I, _P],

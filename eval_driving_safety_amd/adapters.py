@@ -405,7 +405,8 @@ class PsvStereoAdapter:
         """a sparse synthetic depth map per pair (5 % of the pixels, 2 .. 40.4 m) for runs without a dataset; with the
         detection head also 1-4 car boxes per pair [x, z, l, w, ry] in metres"""
         import types
-        b, hh, ww = len(batch), batch.imgL.shape[2], batch.imgL.shape[3]
+        b = len(batch)
+        hh, ww = batch.pad_to if getattr(batch, "pad_to", None) else (batch.imgL.shape[2], batch.imgL.shape[3])
         gen = torch.Generator().manual_seed(seed)
         gt = torch.rand((b, hh, ww), generator=gen) * 38.4 + 2.0
         gt = torch.where(torch.rand((b, hh, ww), generator=gen) < 0.05, gt, torch.zeros(()))

@@ -59,11 +59,15 @@ class StereoBatch:
     """What a loader hands to the drivers (the reference's BatchCollator dict, attack/DSGN/pgd_attack.py:103-126,
     reduced to what the loop itself touches).  imgL/imgR: float32 [B,3,H,W] in the detector's input space;
     names: file stem per pair; sizes: (w, h) of the original image per pair or None; extra: opaque, handed to
-    the model adapter (calibration, targets, depth map ...)."""
+    the model adapter (calibration, targets, depth map ...).  A loader may instead hand over the raw 8-bit RGB pixels,
+    uint8 [B,h,w,3] with ``pad_to`` = the network frame: the DSGN transform then runs on the device (ops.import_u8)."""
 
-    def __init__(self, imgL, imgR, names, sizes=None, extra=None):
-        assert imgL.shape == imgR.shape and imgL.dim() == 4 and imgL.shape[1] == 3
-        self.imgL, self.imgR, self.names, self.sizes, self.extra = imgL, imgR, list(names), sizes, extra
+    def __init__(self, imgL, imgR, names, sizes=None, extra=None, pad_to=None):
+        if imgL.dtype == torch.uint8:      # raw 8-bit pixels [B,h,w,3] for the device-side loader transform; pad_to = network (H, W)
+            assert imgL.shape == imgR.shape and imgL.dim() == 4 and imgL.shape[3] == 3 and pad_to is not None
+        else:
+            assert imgL.shape == imgR.shape and imgL.dim() == 4 and imgL.shape[1] == 3
+        self.imgL, self.imgR, self.names, self.sizes, self.extra, self.pad_to = imgL, imgR, list(names), sizes, extra, pad_to
 
     def __len__(self):
         return self.imgL.shape[0]
@@ -123,7 +127,19 @@ class PgdAttack:
         """Attack B stereo pairs; returns the final stacked iterate [2B,3,H,W] (device)."""
         ops, sp = self.ops, self.space
         dev = self.device if self.device is not None else batch.imgL.device
-        x = _stack_on_device(batch, dev)
+        imported = None
+        if batch.imgL.dtype == torch.uint8:
+            # 8-bit HWC pixels from the loader (data.KittiFolder(as_u8=True)): ToTensor + Normalize + zero padding run on the device,
+            # and the clean image and its index come with them (ops.import_u8) - a quarter of the upload, no host conversion
+            b2 = len(batch)
+            u8 = torch.empty((2 * b2,) + tuple(batch.imgL.shape[1:]), dtype=torch.uint8, device=dev)    # no concatenation on the host:
+            u8[:b2].copy_(batch.imgL, non_blocking=batch.imgL.is_pinned())                               # reading page-locked memory
+            u8[b2:].copy_(batch.imgR, non_blocking=batch.imgR.is_pinned())                               # back on the CPU is slow
+            valid = None if batch.sizes is None else [(s[1], s[0]) for s in batch.sizes] * 2
+            imported = ops.import_u8(u8, sp, batch.pad_to, valid=valid)
+            x = imported[0]
+        else:
+            x = _stack_on_device(batch, dev)
         n, _, h, w = x.shape
         rows = h if batch.sizes is None else max(s[1] for s in batch.sizes)
         cols = w if batch.sizes is None else max(s[0] for s in batch.sizes)
@@ -134,7 +150,11 @@ class PgdAttack:
         #  padding beyond each image's own (h, w) is part of what is verified.)
         cidx = None
         want0 = self._wanted(0)                      # iterate 0 = the un-attacked pair, :279-294
-        if getattr(ops, "can_index_clean", lambda *_: False)(x, sp):
+        if imported is not None:
+            _, clean, cidx = imported
+            if want0:
+                ops.export_u8(x, sp, (rows, cols), out=exporter.next_buffer())
+        elif getattr(ops, "can_index_clean", lambda *_: False)(x, sp):
             valid = None if (batch.sizes is None or not sp.affine) else [(s[1], s[0]) for s in batch.sizes] * 2     # both eyes
             clean, cidx = ops.denormalize_indexed(x, sp, valid=valid, u8_out=exporter.next_buffer() if want0 else None,
                                                   crop=(rows, cols) if want0 else None)

@@ -411,6 +411,58 @@ __global__ __launch_bounds__(kWave) void clean_index_build_vec4(const v4f* x, v4
   }
 }
 
+// The loader's work on the device (the inverse of the 8-bit export): 8-bit RGB pixels, HWC, -> what the DSGN loader hands over,
+// x = ((v/255) - shift)/scale zero-padded in normalised space to the network frame (ToTensor, Normalize, pad: true float32
+// divisions, as torch computes them on the CPU), and with it - for free, by construction instead of by verification - the attack's
+// clean image clean = x*scale + shift and its 8-bit index (the pixels themselves).  One quarter of the PCIe bytes of a float
+// upload and no conversion on the host.  A lane owns 4 pixels: 12 source bytes, three float4 per output array.
+template <bool ALIGNED>
+__global__ __launch_bounds__(kWave) void import_u8_vec4(const uint8_t* __restrict__ u8, long long row_stride, long long image_stride, v4f* x,
+                                                        v4f* clean, IdxK ik, long long n_img, int hw4, int w, SpaceK sp) {
+  const int stride = gridDim.x * kWave;
+  for (long long img = blockIdx.y; img < n_img; img += gridDim.y) {
+    const int vh = ik.valid_hw ? ik.valid_hw[2 * img] : ik.vh;
+    const int vw = ik.valid_hw ? ik.valid_hw[2 * img + 1] : ik.vw;
+    const long long plane0 = img * 3LL * hw4;
+    for (int q = blockIdx.x * kWave + threadIdx.x; q < hw4; q += stride) {
+      const int p = q * 4;  // w % 4 == 0: the 4 pixels of a group share their row
+      const int row = p / w;
+      const int col = p - row * w;
+      uint32_t b[3] = {0u, 0u, 0u};  // 12 bytes: p0c0 p0c1 p0c2 p1c0 | p1c1 p1c2 p2c0 p2c1 | p2c2 p3c0 p3c1 p3c2
+      if (row < vh && col < vw) {
+        const uint8_t* src = u8 + img * image_stride + row * row_stride + col * 3LL;
+        if (ALIGNED && col + 3 < vw) {
+          const v3u t = *reinterpret_cast<const v3u*>(src);
+          b[0] = t[0], b[1] = t[1], b[2] = t[2];
+        } else {
+          const int nb = 3 * ((vw - col) < 4 ? (vw - col) : 4);
+          for (int k = 0; k < nb; ++k) b[k >> 2] |= static_cast<uint32_t>(src[k]) << (8 * (k & 3));
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        v4f X, C;
+        uint32_t word = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int k = 3 * j + c;
+          const uint32_t v = (b[k >> 2] >> (8 * (k & 3))) & 0xffu;
+          const bool inside = row < vh && col + j < vw;
+          float t = static_cast<float>(v) / 255.0f;
+          t = (t - sp.shift[c]) / sp.scale[c];
+          X[j] = inside ? t : 0.0f;
+          C[j] = inside ? t * sp.scale[c] + sp.shift[c] : sp.shift[c];
+          word |= (inside ? v : 0u) << (8 * j);
+        }
+        const long long i = plane0 + static_cast<long long>(c) * hw4 + q;
+        st_stream(x + i, X);
+        if (clean != nullptr) st_stream(clean + i, C);
+        if (ik.idx != nullptr) __builtin_nontemporal_store(word, ik.idx + i);
+      }
+    }
+  }
+}
+
 // The index of an IDENTITY-space batch (Stereo R-CNN: x = 8-bit pixel - mean_c, attack/Stereo-RCNN/pgd_attack.py:122-123 clones it
 // as the clean pair): v = rint(x + mean_c), verified against both tables; no padding rule (the whole frame is image), any row
 // length (hw % 4 == 0 is all the float4 path needs).  clean_out = x when the caller wants a separate copy.
@@ -1196,6 +1248,43 @@ int adv_clean_index_build_f32(const float* x, float* clean_out, const adv_clean_
     hipLaunchKernelGGL((clean_index_build_vec4<U8_ROWS_DWORD>), grid, dim3(kWave), 0, st, x4, c4, ik, nn, hw4, w, sp, plan.dst);
   else
     hipLaunchKernelGGL((clean_index_build_vec4<U8_BYTES>), grid, dim3(kWave), 0, st, x4, c4, ik, nn, hw4, w, sp, plan.dst);
+  return finish_launch();
+}
+
+int adv_import_u8_f32(const uint8_t* u8_hwc, int64_t u8_row_stride, int64_t u8_image_stride, float* x_out, float* clean_out,
+                      const adv_clean_index_t* ci, int valid_h, int valid_w, int64_t n, int h, int w, const adv_space_t* space,
+                      adv_stream_t stream) {
+  if (u8_hwc == nullptr || x_out == nullptr || n < 1 || h < 1 || w < 1 || static_cast<long long>(h) * w > kMaxPlane) return ADV_EINVAL;
+  int rc = check_space(space);
+  if (rc != ADV_OK) return rc;
+  if (!is_affine(space) || space->kind == ADV_SPACE_AFFINE_RCP) return ADV_EINVAL;   // the loader runs on the CPU: true divisions
+  if (w % 4 != 0 || !aligned(x_out, 16) || (clean_out && !aligned(clean_out, 16))) return ADV_EALIGN;
+  IdxK ik{nullptr, nullptr, nullptr, nullptr, valid_h, valid_w};
+  if (ci != nullptr) {
+    rc = check_clean_index(ci, h, w, &ik);
+    if (rc != ADV_OK) return rc;
+  } else if (valid_h < 0 || valid_h > h || valid_w < 0 || valid_w > w) {
+    return ADV_EINVAL;
+  }
+  // every image's rows must lie inside its own buffer: valid_h rows of at least 3*valid_w bytes (per-image sizes are device data:
+  // the caller guarantees them against the strides it passes)
+  if (u8_row_stride < 3LL * (ci && ci->valid_hw ? 1 : ik.vw) || u8_image_stride < 0) return ADV_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const SpaceK sp = to_kernel_space(space);
+  if (ci != nullptr) {
+    if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ci->ok), 1, static_cast<size_t>(n), st) != hipSuccess) return ADV_ELAUNCH;
+    hipLaunchKernelGGL(clean_lut_kernel, dim3(1), dim3(256), 0, st, ci->lut, sp, 0);
+  }
+  const int hw4 = static_cast<int>(static_cast<long long>(h) * w / 4);
+  const dim3 grid = wave_grid(hw4, n, 2);
+  const bool al = aligned(u8_hwc, 4) && u8_row_stride % 4 == 0 && u8_image_stride % 4 == 0;
+  v4f* x4 = reinterpret_cast<v4f*>(x_out);
+  v4f* c4 = reinterpret_cast<v4f*>(clean_out);
+  const long long nn = n;
+  if (al)
+    hipLaunchKernelGGL((import_u8_vec4<true>), grid, dim3(kWave), 0, st, u8_hwc, u8_row_stride, u8_image_stride, x4, c4, ik, nn, hw4, w, sp);
+  else
+    hipLaunchKernelGGL((import_u8_vec4<false>), grid, dim3(kWave), 0, st, u8_hwc, u8_row_stride, u8_image_stride, x4, c4, ik, nn, hw4, w, sp);
   return finish_launch();
 }
 

@@ -81,11 +81,14 @@ class KittiFolder:
     not block - the counterpart of the reference's 12 DataLoader worker processes (attack/DSGN/pgd_attack.py:79,130-133);
     ``workers=0`` decodes synchronously on the attack thread (the reference's ``--debug`` setting)."""
 
-    def __init__(self, data_path, split_file, batch=1, workers=0, prefetch=2, pin=None):
+    def __init__(self, data_path, split_file, batch=1, workers=0, prefetch=2, pin=None, as_u8=False, pad_to=(384, 1248)):
         with open(split_file) as f:
             self.ids = [l.strip() for l in f if l.strip()]
         self.root, self.batch, self.workers, self.prefetch = data_path, batch, int(workers), max(1, int(prefetch))
         self.pin = torch.cuda.is_available() if pin is None else pin
+        # as_u8: hand over the decoded 8-bit pixels [B,h,w,3]; ToTensor / Normalize / zero padding then run on the device
+        # (ops.import_u8, same bits as dsgn_transform) - a quarter of the upload and no float conversion on the decode threads
+        self.as_u8, self.pad_to = bool(as_u8), tuple(pad_to)
 
     def __len__(self):
         return (len(self.ids) + self.batch - 1) // self.batch
@@ -94,11 +97,20 @@ class KittiFolder:
         from PIL import Image
         with Image.open(os.path.join(self.root, eye, name + ".png")) as im:
             a = np.array(im.convert("RGB"))
+        if self.as_u8:      # already in the common buffer shape (the network frame), so that a batch is a plain stack
+            buf = np.zeros((self.pad_to[0], self.pad_to[1], 3), np.uint8)
+            buf[:a.shape[0], :a.shape[1]] = a[:self.pad_to[0], :self.pad_to[1]]
+            return torch.from_numpy(buf), (a.shape[1], a.shape[0])
         u8 = torch.from_numpy(np.ascontiguousarray(a.transpose(2, 0, 1)))
-        return dsgn_transform(u8), (u8.shape[2], u8.shape[1])
+        return dsgn_transform(u8, self.pad_to), (u8.shape[2], u8.shape[1])
 
     def _assemble(self, names, eyes):
         """eyes: [(tensor, size)] in the order L0, R0, L1, R1 ..."""
+        if self.as_u8:      # images of slightly different sizes share one buffer shape, the (w, h) of each travels in ``sizes``
+            ls, rs = torch.stack([e[0] for e in eyes[0::2]]), torch.stack([e[0] for e in eyes[1::2]])
+            if self.pin:
+                ls, rs = ls.pin_memory(), rs.pin_memory()
+            return StereoBatch(ls, rs, list(names), [e[1] for e in eyes[0::2]], pad_to=self.pad_to)
         ls, rs = torch.stack([e[0] for e in eyes[0::2]]), torch.stack([e[0] for e in eyes[1::2]])
         if self.pin:
             ls, rs = ls.pin_memory(), rs.pin_memory()

@@ -215,6 +215,39 @@ def denormalize_indexed(x, space, out=None, reuse=None, valid=None, u8_out=None,
     return out, ci
 
 
+def import_u8(u8, space, pad_to, valid=None, want_clean=True, want_index=True):
+    """The loader's transform on the device: ``u8`` uint8 [N,h,w,3] RGB pixels (CUDA) -> (x [N,3,H,W] normalised and zero-padded to
+    ``pad_to`` = (H, W) as data.dsgn_transform does on the host - the same bits -, clean or None, CleanIndex or None).  ``valid``: the
+    (h_i, w_i) of every image inside the uint8 buffer (default: the whole buffer).  The clean image and its 8-bit index come for free,
+    by construction (no verification pass): pass them to ``pgd_step(..., clean_index=...)``."""
+    if not (isinstance(u8, torch.Tensor) and u8.is_cuda and u8.dtype == torch.uint8 and u8.dim() == 4 and u8.shape[3] == 3 and u8.is_contiguous()):
+        raise TypeError("u8 must be a contiguous CUDA uint8 tensor [N,h,w,3]")
+    if not space.affine:
+        raise ValueError("import_u8 implements the DSGN loader (affine pixel space)")
+    n, hb, wb, _ = u8.shape
+    H, W = int(pad_to[0]), int(pad_to[1])
+    if valid is None:
+        valid = (hb, wb)
+    if not isinstance(valid, torch.Tensor):      # checked on the host before anything is uploaded (a device tensor is trusted)
+        sizes = [tuple(valid)] if not isinstance(valid[0], (tuple, list)) else [tuple(v) for v in valid]
+        if any(v[0] > hb or v[1] > wb for v in sizes):
+            raise ValueError("a valid corner exceeds the uint8 buffer %s" % ((hb, wb),))
+    valid = _valid_arg(valid, n, H, W, u8.device)
+    x = torch.empty((n, 3, H, W), dtype=torch.float32, device=u8.device)
+    clean = torch.empty_like(x) if want_clean else None
+    ci = None
+    if want_index:
+        ci = CleanIndex(torch.empty((n, 3, H, W), dtype=torch.uint8, device=u8.device), torch.empty((n,), dtype=torch.int32, device=u8.device),
+                        torch.empty((2, 3, 256), dtype=torch.float32, device=u8.device), valid)
+    vh, vw = (0, 0) if isinstance(valid, torch.Tensor) else valid
+    if ci is None and isinstance(valid, torch.Tensor):
+        raise ValueError("per-image sizes need want_index=True (they travel in the CleanIndex)")
+    with _on(u8):
+        _lib.call("adv_import_u8_f32", _ptr(u8), u8.stride(1), u8.stride(0), _ptr(x), None if clean is None else _ptr(clean),
+                  None if ci is None else ci.ref(), int(vh), int(vw), n, H, W, space.ref(), _stream(u8))
+    return x, clean, ci
+
+
 def alloc_u8(n, crop_h, w, device):
     """Export buffer with whole (uncropped-width) rows: [n, crop_h, w, 3] uint8."""
     return torch.empty((n, crop_h, w, 3), dtype=torch.uint8, device=device)

@@ -134,6 +134,18 @@ ADV_API int adv_clean_index_build_f32(const float* x, float* clean_out, const ad
                                       int64_t n, int h, int w, const adv_space_t* space, int crop_h, int crop_w,
                                       int64_t u8_row_stride, int64_t u8_image_stride, adv_stream_t stream);
 
+/* The loader's work on the device (upstream DSGN test-time transform: ToTensor, ImageNet Normalize, zero padding to the network
+ *     frame - the values the attack scripts receive as imgL / imgR, attack/DSGN/pgd_attack.py:262-263):
+ *         x_out [n,3,h,w] = ((v/255) - shift)/scale inside image i's valid_h x valid_w corner, 0 outside      (true float32 divisions)
+ *     from 8-bit RGB pixels u8_hwc (byte (row, col, c) of image i at u8_hwc + i*u8_image_stride + row*u8_row_stride + 3*col + c; DEVICE),
+ *     and optionally, in the same pass: clean_out = x_out*scale + shift (shift outside the corner) = what adv_denormalize_f32 would
+ *     give, and *ci filled as adv_clean_index_build_f32 would fill it - by construction, ok[i] = 1, no verification pass (the
+ *     index IS the pixels).  The valid corner comes from ci (per image or common) or, with ci == NULL, from valid_h / valid_w.
+ *     A quarter of the PCIe bytes of a float upload and no conversion on the host.  AFFINE spaces; w % 4 == 0. */
+ADV_API int adv_import_u8_f32(const uint8_t* u8_hwc, int64_t u8_row_stride, int64_t u8_image_stride, float* x_out, float* clean_out,
+                              const adv_clean_index_t* ci, int valid_h, int valid_w, int64_t n, int h, int w,
+                              const adv_space_t* space, adv_stream_t stream);
+
 /* a3 with the indexed clean image: identical results to adv_pgd_step_f32.  Images with ok[i] != 0 (read on the device,
  *     no host round trip) are stepped reading the 1-byte index and an LDS copy of the table instead of the float32
  *     `clean` (13 instead of 16 bytes per element, no division); the others read `clean` as usual, in the same launch.

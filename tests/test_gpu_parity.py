@@ -674,6 +674,47 @@ def test_srcnn_indexed_clean_image_equals_float_path_and_oracle(shape, ops):
     same_bits(host(x2), O.pgd_step_meansub255(x0[:3], g[:3], x0[:3], 1.0, 7.65), "small batch through the indexed entry point")
 
 
+@pytest.mark.parametrize("aligned_rows", [True, False])
+def test_import_u8_equals_the_host_loader_transform(aligned_rows, ops):
+    """ops.import_u8 (ToTensor + Normalize + zero padding on the device, from 8-bit HWC pixels) against data.dsgn_transform on the
+    host: the same bits for x; clean = denormalize(x); the index is the pixels; images of different sizes in one buffer; then two
+    indexed PGD steps equal the float path started from the host-transformed input"""
+    from eval_driving_safety_amd import data
+    sp = ops.Space.dsgn()
+    H, W = 24, 40
+    sizes = [(21, 37), (24, 40), (19, 33)] if aligned_rows else [(21, 35), (20, 38), (21, 38)]
+    hb, wb = max(s[0] for s in sizes), max(s[1] for s in sizes)
+    if aligned_rows:
+        wb = (wb + 3) // 4 * 4                       # rows of the uint8 buffer 4-byte aligned: the 12-byte load path
+    rs = np.random.RandomState(5)
+    u8 = np.zeros((3, hb, wb, 3), np.uint8)
+    want = []
+    for i, (h, w) in enumerate(sizes):
+        img = rs.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        u8[i, :h, :w] = img
+        want.append(data.dsgn_transform(torch.from_numpy(np.ascontiguousarray(img.transpose(2, 0, 1))), (H, W)).numpy())
+    want = np.stack(want)
+    x, clean, ci = ops.import_u8(dev(u8), sp, (H, W), valid=sizes)
+    same_bits(host(x), want, "x = the host loader's transform")
+    same_bits(host(clean), O.denormalize(want), "clean = denormalize(x)")
+    assert ci.verified() == [True, True, True]
+    idx = host(ci.index)
+    for i, (h, w) in enumerate(sizes):
+        assert np.array_equal(idx[i, :, :h, :w], u8[i, :h, :w].transpose(2, 0, 1)) and not idx[i, :, h:, :].any() and not idx[i, :, :, w:].any()
+    _, ci2 = ops.denormalize_indexed(dev(want), sp, valid=sizes)        # the verified build agrees with the by-construction one
+    assert torch.equal(ci2.index, ci.index) and ci2.verified() == [True, True, True]
+    g = synth.gradient(9, want.shape, 1.0)
+    xs, ref = x.clone(), want
+    for _ in range(2):
+        ops.pgd_step(xs, dev(g), clean, sp, 1 / 255, 0.03, out=xs, clean_index=ci)
+        ref = O.pgd_step_norm01(ref, g, O.denormalize(want), 1 / 255, 0.03)
+    same_bits(host(xs), ref, "two indexed steps from the imported batch")
+    # a common size and no index: the plain transform
+    x1, c1, none = ops.import_u8(dev(u8[:1, :sizes[0][0], :]).contiguous(), sp, (H, W), valid=(sizes[0][0], sizes[0][1]), want_clean=False, want_index=False)
+    assert c1 is None and none is None
+    same_bits(host(x1), want[:1], "import without clean image / index")
+
+
 def test_indexed_equals_float_path_at_bench_scale(ops):
     """BASELINE configs[1] at the bench's own scale: 256 zero-padded KITTI-shaped pairs (512 images) built exactly as bench.py
     builds them; the indexed kernel and the all-float32 kernel (itself pinned by the golden vectors) must agree on every

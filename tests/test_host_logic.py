@@ -466,7 +466,7 @@ def test_depth_statistics_match_the_reference(golden_index):
 def test_ops_surface_is_complete():
     """every host-side operator the drivers, CLIs and INTEGRATION.md name is there (importing ops needs no GPU)"""
     from eval_driving_safety_amd import ops
-    names = ["Space", "denormalize", "normalize", "CleanIndex", "can_index_clean", "denormalize_indexed", "alloc_u8", "pgd_step", "export_u8",
+    names = ["Space", "denormalize", "normalize", "CleanIndex", "can_index_clean", "denormalize_indexed", "import_u8", "alloc_u8", "pgd_step", "export_u8",
              "disc_mask", "patch_paste", "patch_paste_batch", "patch_update", "patch_delta_batch", "patch_apply",
              "psv_build", "psv_build_bwd", "PsvBuild", "psv_build_lerp", "psv_build_lerp_bwd", "PsvBuildLerp",
              "roi_align", "roi_align_bwd", "RoIAlign", "nms",

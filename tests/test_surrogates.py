@@ -120,6 +120,33 @@ def test_shaped_detectors_through_the_clis(tmp_path):
     assert a.shape == (375, 1242, 3) and 1 <= np.abs(a.astype(int) - b.astype(int)).max() <= 3
 
 
+def test_device_import_gives_the_same_png_files(tmp_path):
+    """cli.dsgn_pgd_attack on a PNG folder with --device_import (8-bit upload, loader transform on the GPU) writes byte-identical
+    attacked PNGs to the host-transform run"""
+    from PIL import Image
+    import synth
+    data_dir = tmp_path / "kitti"
+    for eye in ("image_2", "image_3"):
+        os.makedirs(str(data_dir / eye))
+    for i, (name, (h, w)) in enumerate((("000001", (375, 1242)), ("000002", (370, 1224)))):
+        left = synth.u8_image(90 + i, h, w)
+        Image.fromarray(left).save(str(data_dir / "image_2" / (name + ".png")))
+        Image.fromarray(np.roll(left, -17, axis=1)).save(str(data_dir / "image_3" / (name + ".png")))
+    (data_dir / "val.txt").write_text("000001\n000002\n")
+    common = ["--model", "toy", "--data_path", str(data_dir), "--split_file", str(data_dir / "val.txt"), "-btest", "2", "-d", "0", "--iter", "3",
+              "--eps", "0.03"]
+    for tag, extra in (("host", []), ("dev", ["--device_import"])):
+        out = tmp_path / tag
+        os.makedirs(str(out))
+        _run("dsgn_pgd_attack", common + ["--out_root", str(out)] + extra, str(out))
+    for k in (0, 3):
+        for eye in ("image_2", "image_3"):
+            for name in ("000001", "000002"):
+                a = np.array(Image.open(str(tmp_path / "host" / ("dsgn_pgd_iters_%d" % k) / eye / (name + ".png"))))
+                b = np.array(Image.open(str(tmp_path / "dev" / ("dsgn_pgd_iters_%d" % k) / eye / (name + ".png"))))
+                assert a.shape == b.shape and np.array_equal(a, b), (k, eye, name)
+
+
 def test_own_pipeline_attack_detect_labels_scenario(tmp_path):
     """no upstream checkout anywhere: PNG folder -> dsgn_pgd_attack --model shaped -> dsgn_predict_and_save_pgd --model shaped on
     the clean and on the attacked folder -> KITTI label files -> the consumer's parse (evaluation/convert_scenarios.py rules)"""

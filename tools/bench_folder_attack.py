@@ -33,9 +33,9 @@ def main():
         with open(os.path.join(root, "val.txt"), "w") as f:
             f.write("\n".join("%06d" % i for i in range(n)) + "\n")
         toy = adapters.ToyStereoAdapter(dev, seed=1)
-        for workers, save in ((0, True), (12, True), (12, False)):
-            out = os.path.join(root, "out_%d_%d" % (workers, save))
-            loader = data.KittiFolder(root, os.path.join(root, "val.txt"), batch, workers=workers)
+        for workers, save, as_u8 in ((0, True, False), (12, True, False), (12, True, True), (12, False, False), (12, False, True)):
+            out = os.path.join(root, "out_%d_%d_%d" % (workers, save, as_u8))
+            loader = data.KittiFolder(root, os.path.join(root, "val.txt"), batch, workers=workers, as_u8=as_u8)
             atk = attacks.PgdAttack("dsgn", 1 / 255, 0.03, iters, out_root=out, save=save, device=dev)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -43,7 +43,8 @@ def main():
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             print(json.dumps({"path": "KittiFolder(PNG) -> PgdAttack(toy detector, %d steps, batch %d) -> %s" % (iters, batch, "PNG folders of every iterate" if save else "no files"),
-                              "decode_threads": workers, "pairs": done, "pairs_per_s": round(done / dt, 2), "seconds": round(dt, 2),
+                              "decode_threads": workers, "loader_transform": "on the device from 8-bit pixels (ops.import_u8)" if as_u8 else "on the host (float upload)",
+                              "pairs": done, "pairs_per_s": round(done / dt, 2), "seconds": round(dt, 2),
                               "png_files_written": (iters + 1) * 2 * done if save else 0}), flush=True)
 
 
