@@ -41,6 +41,18 @@ class _LeafGrad:
         return g.detach()
 
 
+def _freeze(model):
+    """The attacks differentiate w.r.t. the images only (attack/DSGN/pgd_attack.py:300-336 read ``imgL.grad`` / ``imgR.grad``; the
+    detector stays in eval mode, its weights are constants), but the reference leaves ``requires_grad`` on, so every ``backward``
+    also computes every weight gradient and throws it away - a third of the detector step for the Stereo R-CNN-shaped network
+    (profiles/r02_end_to_end_srcnn_shaped.json).  Switching it off changes no image gradient (``freeze=False`` keeps the
+    reference's behaviour)."""
+    params = getattr(model, "parameters", None)
+    if callable(params):
+        for p in params():
+            p.requires_grad_(False)
+
+
 class ToyStereoAdapter:
     """Fixed-seed two-layer siamese feature net + a 4-plane correlation 'cost volume' + smooth-L1 to a
     synthetic target.  NOT a detector - a deterministic differentiable stand-in with the same call shape,
@@ -465,8 +477,10 @@ class DsgnAdapter:
 
     DISP_WEIGHTS = [0.5, 0.7, 1.0]          # :313
 
-    def __init__(self, model, cfg, rpn3d_loss_cls):
+    def __init__(self, model, cfg, rpn3d_loss_cls, freeze=True):
         self.model, self.cfg, self.rpn3d_loss_cls = model, cfg, rpn3d_loss_cls
+        if freeze:
+            _freeze(model)
 
     def loss_and_grad(self, x, extra):
         cfg = self.cfg
@@ -504,8 +518,10 @@ class StereoRcnnAdapter:
     files of the reference (losses computed in eval mode).  ``extra``: im_info, gt_boxes_left/right/merge,
     gt_dim_orien, gt_kpts, num_boxes; ``uncert`` = the six learned log-variances from the checkpoint (:97)."""
 
-    def __init__(self, model, uncert):
+    def __init__(self, model, uncert, freeze=True):
         self.model, self.uncert = model, uncert
+        if freeze:
+            _freeze(model)
 
     def loss_and_grad(self, x, extra):
         u = self.uncert

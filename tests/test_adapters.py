@@ -58,7 +58,11 @@ def test_dsgn_adapter_objective_and_gradient():
     want.backward()
     assert torch.allclose(loss, want.detach(), rtol=1e-6, atol=1e-6)
     assert torch.allclose(grad, xr.grad, rtol=1e-5, atol=1e-7)
-    assert model.w.grad is not None                      # model.zero_grad() ran before backward, grads now present
+    assert model.w.grad is None                          # the detector's weights are constants: no weight gradients by default
+    model2 = _FakeDsgn()
+    loss2, grad2 = adapters.DsgnAdapter(model2, cfg, _FakeRpnLoss, freeze=False).loss_and_grad(x, extra)
+    assert model2.w.grad is not None                     # freeze=False: the reference's behaviour (model.zero_grad(), then backward)
+    assert torch.equal(grad2, grad) and torch.equal(loss2, loss)      # the image gradient does not depend on it
 
 
 class _FakeSrcnn(torch.nn.Module):
