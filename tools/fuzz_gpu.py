@@ -75,6 +75,40 @@ def grid_case(rs, dev):
     same(ops.grid_sample3d_bwd(torch.tensor(g, device=dev), plan), O.grid_sample3d_bwd(g, grid, dims, align), "grid_sample3d bwd %s" % ((b, c, dims, out, align),))
 
 
+def roi_case(rs, dev):
+    b, c = int(rs.randint(1, 3)), int(rs.randint(1, 40))
+    h, w = int(rs.randint(2, 40)), int(rs.randint(2, 60))
+    n = int(rs.randint(1, 30))
+    scale = float(rs.choice([0.25, 0.125, 0.0625]))
+    pooled = (int(rs.randint(1, 8)), int(rs.randint(1, 8)))
+    sr = int(rs.choice([0, 1, 2, 3]))
+    feat = rs.randn(b, c, h, w).astype(np.float32)
+    x1, y1 = rs.rand(n) * w / scale * 0.9 - 5, rs.rand(n) * h / scale * 0.9 - 5
+    rois = np.stack([rs.randint(0, b, n), x1, y1, x1 + rs.rand(n) * w / scale * 0.6 + 1, y1 + rs.rand(n) * h / scale * 0.6 + 1], 1).astype(np.float32)
+    tf, tr = torch.tensor(feat, device=dev), torch.tensor(rois, device=dev)
+    same(ops.roi_align(tf, tr, pooled, scale, sr), O.roi_align(feat, rois, pooled, scale, sr), "roi_align %s" % ((b, c, h, w, n, pooled, scale, sr),))
+    g = rs.randn(n, c, *pooled).astype(np.float32)
+    same(ops.roi_align_bwd(torch.tensor(g, device=dev), tr, feat.shape, scale, sr), O.roi_align_bwd_ordered(g, rois, feat.shape, scale, sr),
+         "roi_align bwd %s" % ((b, c, h, w, n, pooled, scale, sr),))
+
+
+def depth_case(rs, dev):
+    b, d, h, w = int(rs.randint(1, 3)), int(rs.randint(1, 10)), int(rs.randint(1, 12)), int(rs.randint(1, 14))
+    out = (int(rs.randint(1, 30)), int(rs.randint(1, 30)), int(rs.randint(1, 40)))
+    align = bool(rs.rand() < 0.5)
+    cost = (rs.randn(b, d, h, w) * 2).astype(np.float32)
+    zv = np.sort(rs.rand(out[0]) * 40 + 2).astype(np.float32)
+    tc, tz = torch.tensor(cost, device=dev), torch.tensor(zv, device=dev)
+    depth, stats = ops.depth_regress(tc, tz, out, align, with_stats=True)
+    want, _ = O.depth_regress(cost, zv, out, align)
+    np.testing.assert_allclose(depth.cpu().numpy(), want, rtol=2e-5, atol=1e-3, err_msg="depth_regress %s" % ((b, d, h, w, out, align),))
+    g = rs.randn(*want.shape).astype(np.float32)
+    gc = ops.depth_regress_bwd(tc, tz, depth, stats, torch.tensor(g, device=dev), align)
+    ref = O.depth_regress_bwd(cost, zv, g, out, align)
+    np.testing.assert_allclose(gc.cpu().numpy(), ref, rtol=2e-4, atol=2e-4 * max(1.0, float(np.abs(ref).max())),
+                               err_msg="depth_regress bwd %s" % ((b, d, h, w, out, align),))
+
+
 def pgd_case(rs, dev):
     n = int(rs.randint(1, 7))
     if rs.rand() < 0.5:
@@ -114,7 +148,7 @@ def main():
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     rs = np.random.RandomState(args.seed)
-    kinds = [conv_case] * 5 + [grid_case] * 2 + [pgd_case] * 3
+    kinds = [conv_case] * 5 + [grid_case] * 2 + [pgd_case] * 3 + [roi_case] * 2 + [depth_case] * 2
     counts = {}
     for i in range(args.cases):
         fn = kinds[int(rs.randint(len(kinds)))]
