@@ -15,8 +15,12 @@
  *   - no global state; safe to call from several host threads on different streams;
  *   - returns 0 or a negative ADV_E* code; nothing is launched when an error is
  *     returned;  adv_last_hip_error() gives the hipError_t behind ADV_ELAUNCH;
- *   - results are bit-identical to the reference's torch-CPU arithmetic (float32,
- *     every operation rounded separately, true division, NaN-propagating clamp).
+ *   - the entry points that replace reference code (a1-a13, a5) are bit-identical to the reference's torch-CPU
+ *     arithmetic (float32, every operation rounded separately, true division, NaN-propagating clamp); the detector-side
+ *     operators further down (upstream code, not in the reference tree) state their own contract: bit-identical to torch's
+ *     CPU operator or to the oracle's fixed summation order where no transcendental is involved, 1e-5 relative otherwise;
+ *   - the convolution entry points read the device's CU count once per host thread and set a kernel attribute per launch
+ *     (host-side calls, nothing allocated, nothing synchronised).
  */
 #ifndef ADVENGINE_H
 #define ADVENGINE_H
