@@ -1005,7 +1005,9 @@ class GridSamplePlan:
             _lib.call("adv_grid_sample3d_plan_f32", _ptr(gi), _ptr(self.buf), b, d, h, w, zo, yo, xo, int(self.align), _stream(gi))
 
 
-def grid_sample3d_bwd(grad_out, plan):
+def grid_sample3d_bwd(grad_out, plan, channels_last=True):
+    """gradient w.r.t. the sampled volume; ``channels_last``: through a channels-last copy of grad_out (one run of C floats per list
+    entry instead of C cache lines) - the same bits, less HBM traffic"""
     g = _feat(grad_out, "grad_out")
     b, c = g.shape[:2]
     if g.dim() != 5 or b != plan.batch or tuple(g.shape[2:]) != tuple(plan.out_dims):
@@ -1014,7 +1016,11 @@ def grid_sample3d_bwd(grad_out, plan):
     zo, yo, xo = plan.out_dims
     gv = torch.empty((b, c, d, h, w), dtype=torch.float32, device=g.device)
     with _on(g):
-        _lib.call("adv_grid_sample3d_bwd_f32", _ptr(g), _ptr(plan.buf), _ptr(gv), b, c, d, h, w, zo, yo, xo, _stream(g))
+        if channels_last:
+            work = torch.empty((int(_lib.load().adv_grid_sample3d_bwd_workspace_floats(b, c, zo, yo, xo)),), dtype=torch.float32, device=g.device)
+            _lib.call("adv_grid_sample3d_bwd_ws_f32", _ptr(g), _ptr(plan.buf), _ptr(gv), _ptr(work), b, c, d, h, w, zo, yo, xo, _stream(g))
+        else:
+            _lib.call("adv_grid_sample3d_bwd_f32", _ptr(g), _ptr(plan.buf), _ptr(gv), b, c, d, h, w, zo, yo, xo, _stream(g))
     return gv
 
 

@@ -380,6 +380,13 @@ ADV_API int adv_grid_sample3d_plan_f32(const float* grid, void* plan, int b, int
 ADV_API int adv_grid_sample3d_bwd_f32(const float* grad_out, const void* plan, float* grad_vol, int b, int c, int d, int h, int w,
                                       int zo, int yo, int xo, adv_stream_t stream);
 
+/* The same gradient through a channels-last copy of grad_out in workspace (DEVICE, adv_grid_sample3d_bwd_workspace_floats floats,
+ *     caller-owned): a list entry then reads ONE run of c floats instead of c cache lines (PMC at the DSGN size: 3.0 GB fetched per
+ *     launch by the function above for a 149 MB gradient volume).  Same bits.  workspace == NULL falls back to the function above. */
+ADV_API int64_t adv_grid_sample3d_bwd_workspace_floats(int b, int c, int zo, int yo, int xo);
+ADV_API int adv_grid_sample3d_bwd_ws_f32(const float* grad_out, const void* plan, float* grad_vol, float* workspace, int b, int c, int d,
+                                         int h, int w, int zo, int yo, int xo, adv_stream_t stream);
+
 /* Sigmoid focal loss, element-wise (maskrcnn-benchmark SigmoidFocalLoss semantics: the classification term of an FCOS-style
  *     head).  logits [n,k]; targets DEVICE int32 [n]: 0 = background, c in 1..k = class (column c-1), < 0 = ignored.
  *     loss_out / grad_out [n,k] (either may be NULL): per-element loss and its derivative w.r.t. the logit. */

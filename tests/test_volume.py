@@ -42,7 +42,7 @@ def _grid(rs, b, zo, yo, xo, spread=1.15):
     return (rs.rand(b, zo, yo, xo, 3) * 2 * spread - spread).astype(np.float32)      # some samples leave the volume
 
 
-GS_CASES = [dict(b=1, c=3, dims=(4, 5, 6), out=(3, 4, 5), align=False), dict(b=2, c=2, dims=(3, 7, 5), out=(6, 2, 9), align=True),
+GS_CASES = [dict(b=2, c=70, dims=(3, 4, 5), out=(4, 3, 6), align=False), dict(b=1, c=3, dims=(4, 5, 6), out=(3, 4, 5), align=False), dict(b=2, c=2, dims=(3, 7, 5), out=(6, 2, 9), align=True),
             dict(b=1, c=5, dims=(1, 1, 1), out=(2, 2, 2), align=False), dict(b=1, c=1, dims=(6, 4, 9), out=(5, 5, 5), align=False)]
 
 
@@ -131,6 +131,7 @@ def test_hip_grid_sample3d_bit_exact_and_deterministic_backward(cfg):
     plan = ops.GridSamplePlan(tg, cfg["dims"], cfg["align"])
     gv = ops.grid_sample3d_bwd(torch.tensor(g, device=dev), plan)
     assert gv.cpu().numpy().tobytes() == O.grid_sample3d_bwd(g, grid, cfg["dims"], cfg["align"]).tobytes(), "backward differs from the ordered oracle"
+    assert torch.equal(ops.grid_sample3d_bwd(torch.tensor(g, device=dev), plan, channels_last=False), gv), "NCDHW gather vs channels-last gather"
     plan2 = ops.GridSamplePlan(tg, cfg["dims"], cfg["align"])                       # the plan itself is reproducible
     assert torch.equal(plan.buf[:int(np.prod(cfg["dims"])) * cfg["b"] + 1], plan2.buf[:int(np.prod(cfg["dims"])) * cfg["b"] + 1])
     assert torch.equal(ops.grid_sample3d_bwd(torch.tensor(g, device=dev), plan2), gv)

@@ -220,6 +220,7 @@ def volume(dev):
     plan = ops.GridSamplePlan(net_grid, (D, h, w), True)
     go = torch.randn((1, C, zo, yo, xo), device=dev)
     ms_b = timeit(lambda: ops.grid_sample3d_bwd(go, plan), reps=10)
+    ms_b_nc = timeit(lambda: ops.grid_sample3d_bwd(go, plan, channels_last=False), reps=10)
     vr = vol.clone().requires_grad_(True)
 
     def torch_gs_fb():
@@ -227,7 +228,7 @@ def volume(dev):
 
     ms_tb = timeit(torch_gs_fb, reps=5)
     print(json.dumps(dict(kernel="grid_sample3d [1,32,48,96,312] -> [1,32,192,20,304] (DSGN PSV -> 3DGV)", fwd_ms=round(ms, 4),
-                          fwd_GBps=round((out_bytes + vol.numel() * 4) / ms / 1e6, 1), torch_fwd_ms=round(ms_t, 4), bwd_gather_ms=round(ms_b, 4),
+                          fwd_GBps=round((out_bytes + vol.numel() * 4) / ms / 1e6, 1), torch_fwd_ms=round(ms_t, 4), bwd_gather_ms=round(ms_b, 4), bwd_gather_ncdhw_ms=round(ms_b_nc, 4),
                           torch_fwd_bwd_ms=round(ms_tb, 4), plan_build_ms_once_per_calibration=round(t0, 3),
                           plan_MB=round(plan.buf.numel() * 4 / 1e6, 1))))
     n = 2 * 192 * 304
