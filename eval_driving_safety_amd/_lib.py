@@ -21,7 +21,7 @@ ADV_ELAUNCH = -5
 ADV_SPACE_AFFINE = 0
 ADV_SPACE_IDENTITY = 1
 ADV_SPACE_AFFINE_RCP = 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class AdvSpace(ctypes.Structure):
@@ -85,8 +85,8 @@ SIGNATURES = {
     "adv_dense_align_argmin_f32": [_P, _I, _I, _P, _F, _P, _P, _P],
     "adv_conv3d_k3_prep_weights_f32": [_P, _P, _I, _I, _I, _P],
     "adv_conv3d_k3_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
-    "adv_conv3d_k3_ex_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32), _I, _I3, _I3, _I3, _P],
-    "adv_conv_transpose3d_k3_s2_f32": [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint32), _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "adv_conv3d_k3_ex_f32": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32), _I, _I3, _I3, _I3, _P],
+    "adv_conv_transpose3d_k3_s2_f32": [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint32), _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "adv_space_to_depth2_f32": [_P, _P, _I, _I, _I, _I, _I, _P],
     "adv_depth_regress_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "adv_depth_regress_bwd_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],

@@ -302,10 +302,8 @@ class PsvStereoAdapter:
             s1 = ops.Conv3dK3.apply(s1, hp["m1"][0], hp["m1"][1], m2, None, hb["m1"], True)
             s2 = ops.Conv3dK3S2.apply(s1, hp["d2"][0], hp["d2"][1], m2, hb["d2"], True)
             s2 = ops.Conv3dK3.apply(s2, hp["m2"][0], hp["m2"][1], m2, None, hb["m2"], True)
-            u1 = ops.ConvTranspose3dK3S2.apply(s2, hp["u1"][0], hp["u1"][1], m2, hb["u1"], False)
-            u1 = F.relu(u1 + s1)
-            u2 = ops.ConvTranspose3dK3S2.apply(u1, hp["u2"][0], hp["u2"][1], self.mid, hb["u2"], False)
-            u2 = F.relu(u2 + s0)
+            u1 = ops.ConvTranspose3dK3S2.apply(s2, hp["u1"][0], hp["u1"][1], m2, hb["u1"], True, s1)       # relu(up(s2) + bias + s1): one launch
+            u2 = ops.ConvTranspose3dK3S2.apply(u1, hp["u2"][0], hp["u2"][1], self.mid, hb["u2"], True, s0)
             return ops.Conv3dK3.apply(u2, self.p3, self.p3t, 1).squeeze(1), u2
         s0 = F.relu(F.conv3d(cost, self.c1, self.b1, padding=1))
         s0 = F.relu(F.conv3d(s0, self.c2, self.b2, padding=1))

@@ -42,6 +42,8 @@ struct Epi {
   const float* cls_wp[8];
   unsigned cls_mask[8];
   int cls_off[8][3];
+  // added to every result after the bias and before the ReLU: a tensor laid out like y (an hourglass's skip connection); may be y itself
+  const float* residual;
 };
 
 constexpr unsigned kAllTaps = (1u << 27) - 1u;
@@ -50,12 +52,14 @@ __device__ __forceinline__ unsigned chunk_mask(const Epi& e, int c0) {
   return e.class_channels > 0 ? e.class_masks[c0 / e.class_channels] : e.tap_mask;
 }
 
-__device__ __forceinline__ void epi_store(const Epi& e, float* __restrict__ y, long long b, int Cout, int co, int gd, int gh, int gw, float r) {
+__device__ __forceinline__ void epi_store(const Epi& e, float* y, long long b, int Cout, int co, int gd, int gh, int gw, float r) {
   const int zd = gd * e.sd + e.fd, zh = gh * e.sh + e.fh, zw = gw * e.sw + e.fw;
   if (zd >= e.od || zh >= e.oh || zw >= e.ow) return;
   if (e.bias) r = r + e.bias[co];
+  const long long at = ((b * Cout + co) * e.od + zd) * (static_cast<long long>(e.oh) * e.ow) + static_cast<long long>(zh) * e.ow + zw;
+  if (e.residual) r = r + e.residual[at];
   if (e.relu) r = r > 0.0f ? r : 0.0f;
-  y[((b * Cout + co) * e.od + zd) * (static_cast<long long>(e.oh) * e.ow) + static_cast<long long>(zh) * e.ow + zw] = r;
+  y[at] = r;
 }
 
 constexpr int kCK = 4;    // input channels per LDS stage (both kernels: one accumulation order)
@@ -552,6 +556,8 @@ __global__ __launch_bounds__(128 * TD, 2) void conv3d_k3_mfma(const float* __res
     const int gw = cp.w0 + l32, zw = gw * epi.sw + fw;
     const long long ovol = static_cast<long long>(epi.od) * epi.oh * epi.ow;
     float* yb = y + (static_cast<long long>(cp.b) * Cout + co0) * ovol;
+    const bool has_res = epi.residual != nullptr;
+    const float* rb = epi.residual + (static_cast<long long>(cp.b) * Cout + co0) * ovol;
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int row = wave * NB + i;
@@ -559,8 +565,24 @@ __global__ __launch_bounds__(128 * TD, 2) void conv3d_k3_mfma(const float* __res
       const int gd = cp.d0 + td, gh = cp.h0 + th;
       const int zd = gd * epi.sd + fd, zh = gh * epi.sh + fh;
       if (gd >= D || gh >= H || gw >= W || zd >= epi.od || zh >= epi.oh || zw >= epi.ow) continue;
-      float* yr = yb + (static_cast<long long>(zd) * epi.oh + zh) * epi.ow + zw;
+      const long long at = (static_cast<long long>(zd) * epi.oh + zh) * epi.ow + zw;
+      float* yr = yb + at;
       if (cp.cob * 32 + 32 <= Cout) {  // workgroup-uniform: all 32 output channels of the block exist - no per-store predicate
+        if (has_res) {                 // the skip connection's 16 values of this row first (loads in flight together), then the stores
+          const float* rr = rb + at;
+          float sk[16];
+#pragma unroll
+          for (int v = 0; v < 16; ++v) sk[v] = __builtin_nontemporal_load(rr + (8 * (v >> 2) + (v & 3)) * ovol);
+#pragma unroll
+          for (int v = 0; v < 16; ++v) {
+            float r = acc[i][v];
+            if (has_bias) r = r + bz[v];
+            r = r + sk[v];
+            if (epi.relu) r = r > 0.0f ? r : 0.0f;
+            yr[(8 * (v >> 2) + (v & 3)) * ovol] = r;
+          }
+          continue;
+        }
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
           float r = acc[i][v];
@@ -574,6 +596,7 @@ __global__ __launch_bounds__(128 * TD, 2) void conv3d_k3_mfma(const float* __res
           const int cr = 8 * (v >> 2) + (v & 3);
           float r = acc[i][v];
           if (has_bias) r = r + bz[v];
+          if (has_res && co0 + cr < Cout) r = r + rb[at + cr * ovol];
           if (epi.relu) r = r > 0.0f ? r : 0.0f;
           if (co0 + cr < Cout) yr[cr * ovol] = r;
         }
@@ -960,14 +983,15 @@ int adv_space_to_depth2_f32(const float* x, float* xs, int b, int c, int d, int 
   return adv_internal_finish_launch();
 }
 
-int adv_conv3d_k3_ex_f32(const float* x, const float* w_prep, const float* bias, float* y, int b, int cin, int cout, int d, int h, int w,
+int adv_conv3d_k3_ex_f32(const float* x, const float* w_prep, const float* bias, const float* residual, float* y, int b, int cin, int cout, int d, int h, int w,
                          int stride, int relu, uint32_t tap_mask, const uint32_t* class_masks, int class_channels, const int32_t* out_dims,
                          const int32_t* out_stride, const int32_t* out_offset, adv_stream_t stream) {
   if (!x || !w_prep || !y || b < 1 || cin < 1 || cout < 1 || d < 1 || h < 1 || w < 1) return ADV_EINVAL;
   if ((cin % kCK != 0 && cin > kCK) || (stride != 1 && stride != 2) || (tap_mask & ~kAllTaps)) return ADV_EINVAL;
-  if ((out_dims == nullptr) != (out_stride == nullptr) || (out_dims == nullptr) != (out_offset == nullptr)) return ADV_EINVAL;
+  if ((out_dims == nullptr) != (out_stride == nullptr) || (out_dims == nullptr) != (out_offset == nullptr) || residual == y) return ADV_EINVAL;
   const int gd = stride == 2 ? (d + 1) / 2 : d, gh = stride == 2 ? (h + 1) / 2 : h, gw = stride == 2 ? (w + 1) / 2 : w;
   Epi epi{bias, relu, tap_mask, {0, 0, 0, 0, 0, 0, 0, 0}, 0, gd, gh, gw, 1, 1, 1, 0, 0, 0};
+  epi.residual = residual;
   if (class_masks != nullptr) {
     if (class_channels < kCK || class_channels % kCK != 0 || cin != 8 * class_channels) return ADV_EINVAL;
     for (int k = 0; k < 8; ++k) {
@@ -986,13 +1010,16 @@ int adv_conv3d_k3_ex_f32(const float* x, const float* w_prep, const float* bias,
   return launch_conv(x, w_prep, y, b, cin, cout, d, h, w, stride, epi, static_cast<hipStream_t>(stream));
 }
 
-int adv_conv_transpose3d_k3_s2_f32(const float* x, const float* const* w_prep_classes, const uint32_t* tap_masks, const float* bias, float* y,
+int adv_conv_transpose3d_k3_s2_f32(const float* x, const float* const* w_prep_classes, const uint32_t* tap_masks, const float* bias,
+                                   const float* residual, float* y,
                                    int b, int cin, int cout, int d, int h, int w, int relu, adv_stream_t stream) {
-  if (!x || !w_prep_classes || !tap_masks || !y || b < 1 || cin < kCK || cin % kCK != 0 || cout < 1 || d < 1 || h < 1 || w < 1) return ADV_EINVAL;
+  if (!x || !w_prep_classes || !tap_masks || !y || residual == y || b < 1 || cin < kCK || cin % kCK != 0 || cout < 1 || d < 1 || h < 1 || w < 1)
+    return ADV_EINVAL;
   for (int k = 0; k < 8; ++k)
     if (w_prep_classes[k] == nullptr || (tap_masks[k] & ~kAllTaps) || tap_masks[k] == 0) return ADV_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
   Epi epi{bias, relu, tap_masks[0], {0, 0, 0, 0, 0, 0, 0, 0}, 0, 2 * d, 2 * h, 2 * w, 2, 2, 2, 0, 0, 0};
+  epi.residual = residual;
   const int cblocks = (cout + 31) / 32;
   const bool fits = w >= 4 && static_cast<long long>(cin) * d * h * w < (1LL << 31) && 27LL * cin * cblocks * 32 < (1LL << 31);
   bool aligned_w = (reinterpret_cast<uintptr_t>(x) & 3) == 0;

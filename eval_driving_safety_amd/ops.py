@@ -608,8 +608,17 @@ def _i3(v):
     return None if v is None else (ctypes.c_int32 * 3)(*[int(a) for a in v])
 
 
+def _residual(residual, out):
+    if residual is None:
+        return None
+    r = _feat(residual, "residual")
+    if r.shape != out.shape or r.data_ptr() == out.data_ptr():
+        raise ValueError("residual must have the result's shape %s and must not be the result" % (tuple(out.shape),))
+    return _ptr(r)
+
+
 def _conv3d_ex(x, w_prep, cout, stride=1, relu=False, bias=None, tap_mask=ALL_TAPS, out=None, out_stride=None, out_offset=None,
-               class_masks=None):
+               class_masks=None, residual=None):
     xi, wp = _feat(x, "x"), _feat(w_prep, "w_prep")
     if xi.dim() != 5 or wp.dim() != 3 or wp.shape[0] != 27 or wp.shape[1] != xi.shape[1] or wp.shape[2] < cout:
         raise ValueError("x must be [B,Cin,D,H,W] and w_prep [27,Cin,>=cout]")
@@ -629,16 +638,18 @@ def _conv3d_ex(x, w_prep, cout, stride=1, relu=False, bias=None, tap_mask=ALL_TA
         dims = tuple(out.shape[2:])
     cm = None if class_masks is None else (ctypes.c_uint32 * 8)(*[int(m) for m in class_masks])
     with _on(xi):
-        _lib.call("adv_conv3d_k3_ex_f32", _ptr(xi), _ptr(wp), None if bias is None else _ptr(bias), _ptr(out), b, cin, cout, d, h, w, int(stride),
+        _lib.call("adv_conv3d_k3_ex_f32", _ptr(xi), _ptr(wp), None if bias is None else _ptr(bias), _residual(residual, out), _ptr(out), b, cin,
+                  cout, d, h, w, int(stride),
                   int(relu), int(tap_mask), cm, 0 if cm is None else cin // 8, _i3(dims), _i3(out_stride if dims else None),
                   _i3(out_offset if dims else None), _stream(xi))
     return out
 
 
-def conv3d_k3(x, w_prep, cout, relu=False, bias=None):
-    """conv3d(x [B,Cin,D,H,W], stride 1, padding 1) (+ bias [cout]) (+ ReLU) with prepared weights -> [B,cout,D,H,W]"""
-    if bias is not None:
-        return _conv3d_ex(x, w_prep, cout, 1, relu, bias)
+def conv3d_k3(x, w_prep, cout, relu=False, bias=None, residual=None):
+    """conv3d(x [B,Cin,D,H,W], stride 1, padding 1) (+ bias [cout]) (+ residual [B,cout,D,H,W]) (+ ReLU) with prepared weights
+    -> [B,cout,D,H,W]"""
+    if bias is not None or residual is not None:
+        return _conv3d_ex(x, w_prep, cout, 1, relu, bias, residual=residual)
     xi, wp = _feat(x, "x"), _feat(w_prep, "w_prep")
     if xi.dim() != 5 or wp.dim() != 3 or wp.shape[0] != 27 or wp.shape[1] != xi.shape[1] or wp.shape[2] < cout:
         raise ValueError("x must be [B,Cin,D,H,W] and w_prep [27,Cin,>=cout]")
@@ -720,9 +731,10 @@ def conv_transpose3d_k3_s2_prep(weight_t):
     return out
 
 
-def conv_transpose3d_k3_s2(x, classes, cout, relu=False, bias=None):
+def conv_transpose3d_k3_s2(x, classes, cout, relu=False, bias=None, residual=None):
     """conv_transpose3d(x [B,Cin,D,H,W], kernel 3, stride 2, padding 1, output_padding 1) -> [B,cout,2D,2H,2W]: the eight
-    output parity classes (1-8 taps each) as ONE launch of the persistent masked MFMA kernel, the class being a tile index."""
+    output parity classes (1-8 taps each) as ONE launch of the persistent masked MFMA kernel, the class being a tile index.
+    ``residual`` [B,cout,2D,2H,2W] (a skip connection) is added in the epilogue, after the bias and before the ReLU."""
     xi = _feat(x, "x")
     b, cin, d, h, w = xi.shape
     if len(classes) != 8 or [tuple(c[2]) for c in classes] != [(k >> 2 & 1, k >> 1 & 1, k & 1) for k in range(8)]:
@@ -735,8 +747,8 @@ def conv_transpose3d_k3_s2(x, classes, cout, relu=False, bias=None):
     wps = (ctypes.c_void_p * 8)(*[_feat(c[0], "w_prep").data_ptr() for c in classes])
     masks = (ctypes.c_uint32 * 8)(*[int(c[1]) for c in classes])
     with _on(xi):
-        _lib.call("adv_conv_transpose3d_k3_s2_f32", _ptr(xi), wps, masks, None if bias is None else _ptr(bias), _ptr(out), b, cin, cout, d, h, w,
-                  int(relu), _stream(xi))
+        _lib.call("adv_conv_transpose3d_k3_s2_f32", _ptr(xi), wps, masks, None if bias is None else _ptr(bias), _residual(residual, out),
+                  _ptr(out), b, cin, cout, d, h, w, int(relu), _stream(xi))
     return out
 
 
@@ -758,13 +770,14 @@ class Conv3dK3(torch.autograd.Function):
     detector's weights are constants), through the same kernel family with the transposed / flipped weights (cout a
     multiple of 4 -> the matrix kernel, cout 1..3 -> the narrow vector-ALU kernel).  Any other cout: pass
     ``w_prep_t=None`` and the original ``weight``: the backward then uses torch's conv3d_input.  With ``relu`` the
-    activation is fused into the forward's epilogue and its mask is applied to the incoming gradient."""
+    activation is fused into the forward's epilogue and its mask is applied to the incoming gradient; ``residual`` (a skip
+    connection, [B,cout,D,H,W]) is added in the same epilogue and receives that gradient unchanged."""
 
     @staticmethod
-    def forward(ctx, x, w_prep, w_prep_t, cout, weight=None, bias=None, relu=False):
-        ctx.has_t, ctx.relu = w_prep_t is not None, bool(relu)
+    def forward(ctx, x, w_prep, w_prep_t, cout, weight=None, bias=None, relu=False, residual=None):
+        ctx.has_t, ctx.relu, ctx.has_res = w_prep_t is not None, bool(relu), residual is not None
         ctx.xshape = tuple(x.shape)
-        y = conv3d_k3(x.contiguous(), w_prep, cout, relu=relu, bias=bias)
+        y = conv3d_k3(x.contiguous(), w_prep, cout, relu=relu, bias=bias, residual=None if residual is None else residual.contiguous())
         ctx.save_for_backward(w_prep_t if ctx.has_t else weight, y if relu else None)
         return y
 
@@ -773,9 +786,11 @@ class Conv3dK3(torch.autograd.Function):
         w, y = ctx.saved_tensors
         if ctx.relu:
             grad_y = relu_backward(grad_y, y)
+        gres = grad_y if ctx.has_res else None      # the skip connection receives the (masked) gradient as it is
         if ctx.has_t:
-            return conv3d_k3(grad_y.contiguous(), w, ctx.xshape[1]), None, None, None, None, None, None
-        return torch.nn.grad.conv3d_input(ctx.xshape, w, grad_y, padding=1), None, None, None, None, None, None
+            return conv3d_k3(grad_y.contiguous(), w, ctx.xshape[1]), None, None, None, None, None, None, gres
+        return torch.nn.grad.conv3d_input(ctx.xshape, w, grad_y, padding=1), None, None, None, None, None, None, gres
+
 
 class Conv3dK3S2(torch.autograd.Function):
     """y = conv3d(x, weight, stride 2, padding 1); the gradient w.r.t. x is the transposed convolution of grad_y with the
@@ -805,9 +820,9 @@ class ConvTranspose3dK3S2(torch.autograd.Function):
     convolution of grad_y with weight_t read as [out = Cin, in = Cout] (``w_prep_fwd = conv3d_k3_s2_prep(weight_t)``)."""
 
     @staticmethod
-    def forward(ctx, x, classes, w_prep_fwd, cout, bias=None, relu=False):
-        ctx.w_prep_fwd, ctx.cin, ctx.relu = w_prep_fwd, x.shape[1], bool(relu)
-        y = conv_transpose3d_k3_s2(x.contiguous(), classes, cout, relu=relu, bias=bias)
+    def forward(ctx, x, classes, w_prep_fwd, cout, bias=None, relu=False, residual=None):
+        ctx.w_prep_fwd, ctx.cin, ctx.relu, ctx.has_res = w_prep_fwd, x.shape[1], bool(relu), residual is not None
+        y = conv_transpose3d_k3_s2(x.contiguous(), classes, cout, relu=relu, bias=bias, residual=None if residual is None else residual.contiguous())
         ctx.save_for_backward(y if relu else None)
         return y
 
@@ -816,7 +831,8 @@ class ConvTranspose3dK3S2(torch.autograd.Function):
         (y,) = ctx.saved_tensors
         if ctx.relu:
             grad_y = relu_backward(grad_y, y)
-        return conv3d_k3_s2(grad_y.contiguous(), ctx.w_prep_fwd, ctx.cin), None, None, None, None, None
+        return (conv3d_k3_s2(grad_y.contiguous(), ctx.w_prep_fwd, ctx.cin), None, None, None, None, None,
+                grad_y if ctx.has_res else None)        # the skip connection receives the (masked) gradient as it is
 
 
 # --------------------------------------------------------------------------------------------

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ADV_ABI_VERSION 4
+#define ADV_ABI_VERSION 5
 #define ADV_API __attribute__((visibility("default"))) /* the library is built with -fvisibility=hidden */
 #define ADV_CHANNELS 3
 
@@ -311,6 +311,9 @@ ADV_API int adv_conv3d_k3_f32(const float* x, const float* w_prep, float* y, int
 
 /* The same kernel family with what a plane-sweep detector's 3D hourglass needs around the plain convolution:
  *     bias       DEVICE [cout] or NULL, added after the accumulation (a folded batch-norm shift; its scale goes into the weights)
+ *     residual   DEVICE tensor laid out like y (same dims, read where the result is written) or NULL: added after the bias and
+ *                before the ReLU - an hourglass's skip connection, y = relu(conv(x) + bias + skip), without a pass of its own.
+ *                Must not be y itself (-EINVAL).  Same float operations in the same order as conv, add, add, max done apart.
  *     stride     1, or 2 = the strided 3x3x3 convolution (padding 1): output grid ceil(d/2) x ceil(h/2) x ceil(w/2)
  *     tap_mask   bit t set = tap t = kd*9 + kh*3 + kw takes part (0x7ffffff = all)
  *     out_dims / out_stride / out_offset (HOST int32[3] each, or all NULL): result voxel i of the convolution's own grid is
@@ -323,20 +326,21 @@ ADV_API int adv_conv3d_k3_f32(const float* x, const float* w_prep, float* y, int
  *                class_masks[k] instead of tap_mask (cin must be 8*class_channels).  With adv_space_to_depth2_f32 this is the
  *                FAST strided convolution: conv(x, stride 2) == conv(space_to_depth2(x), stride 1) where parity sub-volume p
  *                keeps only the taps its parity allows (27 taps over the eight sub-volumes), on the tuned stride-1 kernel. */
-ADV_API int adv_conv3d_k3_ex_f32(const float* x, const float* w_prep, const float* bias, float* y, int b, int cin, int cout,
-                                 int d, int h, int w, int stride, int relu, uint32_t tap_mask, const uint32_t* class_masks,
+ADV_API int adv_conv3d_k3_ex_f32(const float* x, const float* w_prep, const float* bias, const float* residual, float* y, int b,
+                                 int cin, int cout, int d, int h, int w, int stride, int relu, uint32_t tap_mask, const uint32_t* class_masks,
                                  int class_channels, const int32_t* out_dims, const int32_t* out_stride,
                                  const int32_t* out_offset, adv_stream_t stream);
 
-/* y [b,cout,2d,2h,2w] = conv_transpose3d(x [b,cin,d,h,w], kernel 3, stride 2, padding 1, output_padding 1) (+ bias, + ReLU) in ONE
+/* y [b,cout,2d,2h,2w] = conv_transpose3d(x [b,cin,d,h,w], kernel 3, stride 2, padding 1, output_padding 1) (+ bias, + residual
+ *     [b,cout,2d,2h,2w] or NULL, + ReLU - as in adv_conv3d_k3_ex_f32) in ONE
  *     launch: the eight output parity classes k = (pd*2+ph)*2+pw as one tile index of the persistent masked kernel, class k with
  *     its own prepared weights w_prep_classes[k] (HOST array of 8 DEVICE pointers) and tap mask tap_masks[k] (HOST uint32[8]) -
  *     ops.conv_transpose3d_k3_s2_prep builds both.  The classes' tiles (1 to 8 taps each) are interleaved over the workgroups,
  *     so the launch fills the GPU where eight separate launches of 0.7 rounds each did not.  Same bits as eight
  *     adv_conv3d_k3_ex_f32 calls with out_stride 2 / out_offset (pd,ph,pw). */
 ADV_API int adv_conv_transpose3d_k3_s2_f32(const float* x, const float* const* w_prep_classes, const uint32_t* tap_masks,
-                                           const float* bias, float* y, int b, int cin, int cout, int d, int h, int w, int relu,
-                                           adv_stream_t stream);
+                                           const float* bias, const float* residual, float* y, int b, int cin, int cout, int d,
+                                           int h, int w, int relu, adv_stream_t stream);
 
 /* xs [b, 8c, ceil(d/2), ceil(h/2), ceil(w/2)]:  xs[b, p*c + ch, jd, jh, jw] = x[b, ch, 2jd+pd, 2jh+ph, 2jw+pw], p = (pd*2+ph)*2+pw,
  *     zero beyond the input.  HBM-bound permute (one pass); xs is caller-owned workspace. */

@@ -286,3 +286,73 @@ def test_hip_hourglass_autograd_vs_torch():
     assert tuple(up.shape) == tuple(ref.shape) == (1, 32, 12, 24, 80)
     assert float((up - ref).abs().max()) <= 1e-4 * float(ref.detach().abs().max())
     assert float((xm.grad - xr.grad).abs().max()) <= 1e-4 * float(xr.grad.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", HG_SHAPES + [(1, 32, 1, 3, 8, 36), (1, 2, 32, 3, 8, 36)])
+def test_hip_residual_epilogue_equals_conv_then_add_then_relu(shape, monkeypatch):
+    """y = relu(conv(x) + bias + skip) in the epilogue (an hourglass's skip connection): the same float operations in the same
+    order as the convolution followed by a separate add and max - on the matrix kernel (all-taps, masked / transposed, every
+    staging variant) and on the narrow vector-ALU kernels - and equal to the oracle's convolution plus a numpy add."""
+    from eval_driving_safety_amd import ops
+    b, cin, cout, d, h, w = shape
+    x, wt = _case(*shape, seed=sum(shape) + 1)
+    rs = np.random.RandomState(17)
+    bias = rs.randn(cout).astype(np.float32)
+    skip = rs.randn(b, cout, d, h, w).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    tx, tw, tb, ts = (torch.tensor(a, device=dev) for a in (x, wt, bias, skip))
+    wp = ops.conv3d_k3_prep(tw)
+    want = np.maximum(C.conv3d_k3_ex(x, wt, bias=bias) + skip, np.float32(0))
+    for env in ({}, {"ADV_CONV_NO_DMA": "1"}, {"ADV_CONV_GENERIC": "1"}, {"ADV_CONV_NO_NARROW": "1"}):
+        for k in ("ADV_CONV_NO_DMA", "ADV_CONV_GENERIC", "ADV_CONV_NO_NARROW"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        got = ops.conv3d_k3(tx, wp, cout, relu=True, bias=tb, residual=ts)
+        assert got.cpu().numpy().tobytes() == want.tobytes(), env
+        assert torch.equal(got, F.relu(ops.conv3d_k3(tx, wp, cout, bias=tb) + ts)), env
+        assert torch.equal(ops.conv3d_k3(tx, wp, cout, residual=ts), ops.conv3d_k3(tx, wp, cout) + ts), env      # no bias, no relu
+    for k in ("ADV_CONV_NO_DMA", "ADV_CONV_GENERIC", "ADV_CONV_NO_NARROW"):
+        monkeypatch.delenv(k, raising=False)
+    if cin % 4 == 0:
+        w_t = (rs.randn(cin, cout, 3, 3, 3) * 0.1).astype(np.float32)
+        classes = ops.conv_transpose3d_k3_s2_prep(torch.tensor(w_t, device=dev))
+        skip2 = torch.tensor(rs.randn(b, cout, 2 * d, 2 * h, 2 * w).astype(np.float32), device=dev)
+        for env in ({}, {"ADV_CONV_CLASS_LAUNCHES": "1"}):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            got = ops.conv_transpose3d_k3_s2(tx, classes, cout, bias=tb, relu=True, residual=skip2)
+            want_t = np.maximum(C.conv_transpose3d_k3_s2(x, w_t, bias=bias) + skip2.cpu().numpy(), np.float32(0))
+            assert got.cpu().numpy().tobytes() == want_t.tobytes(), ("transposed", env)
+        monkeypatch.delenv("ADV_CONV_CLASS_LAUNCHES", raising=False)
+    with pytest.raises(ValueError):
+        ops.conv3d_k3(tx, wp, cout, residual=ts[:, :, :-1].contiguous())
+
+
+@pytest.mark.gpu
+def test_hip_skip_connection_autograd_vs_torch():
+    """relu(up(x) + bias + skip) as ONE autograd function: the value equals the separate add / relu bit for bit, and both x and the
+    skip tensor receive torch's gradients (the skip's gradient is the masked incoming gradient itself)"""
+    from eval_driving_safety_amd import ops
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(5)
+    x = torch.randn((1, 64, 6, 12, 40), device=dev, generator=gen)
+    skip = torch.randn((1, 32, 12, 24, 80), device=dev, generator=gen)
+    wu = torch.randn((64, 32, 3, 3, 3), device=dev, generator=gen) * 0.05
+    bu = torch.randn((32,), device=dev, generator=gen)
+    wc = torch.randn((32, 32, 3, 3, 3), device=dev, generator=gen) * 0.05
+    g = torch.randn(skip.shape, device=dev, generator=gen)
+    xr, sr = x.clone().requires_grad_(True), skip.clone().requires_grad_(True)
+    ref = F.relu(F.conv_transpose3d(xr, wu, bu, stride=2, padding=1, output_padding=1) + sr)
+    ref2 = F.relu(F.conv3d(ref, wc, padding=1) + sr)
+    ref2.backward(g)
+    xm, sm = x.clone().requires_grad_(True), skip.clone().requires_grad_(True)
+    cls, fwd = ops.conv_transpose3d_k3_s2_prep(wu), ops.conv3d_k3_s2_prep(wu)
+    up = ops.ConvTranspose3dK3S2.apply(xm, cls, fwd, 32, bu, True, sm)
+    assert torch.equal(up, F.relu(ops.conv_transpose3d_k3_s2(x, cls, 32, bias=bu) + skip))
+    out = ops.Conv3dK3.apply(up, ops.conv3d_k3_prep(wc), ops.conv3d_k3_prep(wc, transpose=True), 32, None, None, True, sm)  # weight, bias, relu, residual
+    out.backward(g)
+    assert float((out - ref2).abs().max()) <= 1e-4 * float(ref2.detach().abs().max())
+    assert float((xm.grad - xr.grad).abs().max()) <= 1e-4 * float(xr.grad.abs().max())
+    assert float((sm.grad - sr.grad).abs().max()) <= 1e-4 * float(sr.grad.abs().max())

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "libadvengine.so lacks %s" % name
     assert sorted(_lib.EXPORTED) == declared, "ctypes binding and header disagree"
-    assert lib.adv_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.adv_abi_version() == _lib.ABI_VERSION == 5
     assert lib.adv_strerror(-22) == b"invalid argument"
 
 
@@ -44,7 +44,7 @@ def test_header_is_valid_c99(tmp_path):
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
                     "-L", lib_dir, "-l:libadvengine.so", "-Wl,-rpath," + lib_dir], check=True)
     out = subprocess.run([str(exe)], stdout=subprocess.PIPE, text=True)
-    assert out.returncode == 0 and out.stdout.split() == ["4", "0", "0.229"]
+    assert out.returncode == 0 and out.stdout.split() == ["5", "0", "0.229"]
 
 
 def test_space_constants_are_the_reference_constants():
@@ -79,6 +79,9 @@ def test_argument_errors_without_a_gpu():
     # the detector-side entry points validate before launching too
     assert lib.adv_conv3d_k3_f32(p, p, p, 1, 6, 8, 2, 2, 4, 0, None) == _lib.ADV_EINVAL               # Cin neither 1..3 nor a multiple of 4
     assert lib.adv_conv3d_k3_f32(p, None, p, 1, 4, 8, 2, 2, 4, 0, None) == _lib.ADV_EINVAL
+    q = ctypes.c_void_p(0x2000)
+    assert lib.adv_conv3d_k3_ex_f32(p, p, None, q, q, 1, 4, 8, 2, 2, 4, 1, 0, (1 << 27) - 1, None, 0, None, None, None, None) == _lib.ADV_EINVAL  # residual is y
+    assert lib.adv_conv3d_k3_ex_f32(p, p, None, None, q, 1, 4, 8, 2, 2, 4, 3, 0, (1 << 27) - 1, None, 0, None, None, None, None) == _lib.ADV_EINVAL  # stride 3
     assert lib.adv_depth_regress_f32(None, p, p, None, 1, 2, 2, 2, 4, 4, 4, 0, None) == _lib.ADV_EINVAL
     assert lib.adv_depth_regress_f32(p, p, p, None, 1, 2, 2, 2, 0, 4, 4, 0, None) == _lib.ADV_EINVAL
     assert lib.adv_depth_regress_f32(odd, p, p, None, 1, 2, 2, 2, 4, 4, 4, 0, None) == _lib.ADV_EALIGN
