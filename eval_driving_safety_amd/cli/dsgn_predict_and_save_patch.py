@@ -9,7 +9,7 @@ from . import _common, _dsgn_detect, upstream
 
 def build_parser():
     parser = argparse.ArgumentParser(description="Patch attack predict and save")
-    _common.add_scaffolding(parser, loadmodel="./outputs/temp/DSGN_car_pretrained/finetune_53.tar", btest=1, devices="0")
+    _common.add_scaffolding(parser, loadmodel="./outputs/temp/DSGN_car_pretrained/finetune_53.tar", btest=1, devices=0)
     _common.add_detect_flags(parser)
     parser.add_argument("--ratio", dest="ratio", type=float, default=0.2)
     parser.add_argument("--epochs", dest="epochs", type=int, default=80)

@@ -33,8 +33,9 @@ def _need(module, what):
 def resolve_devices(devices, mem_info):
     """``--devices`` as the DSGN scripts read it (attack/DSGN/pgd_attack.py:58-65): empty -> the GPU with the least
     memory in use; ``a-b`` -> the inclusive range (a missing end = first / last GPU).  Returns the comma-separated
-    string the scripts export as CUDA_VISIBLE_DEVICES (:82)."""
-    if not devices and devices != 0:
+    string the scripts export as CUDA_VISIBLE_DEVICES (:82).  The detect-under-patch script's default is the INTEGER 0
+    (predict_and_save_patch.py:52), which ``if not args.devices`` (:70) also sends to the least-used GPU; "-d 0" is GPU 0."""
+    if not devices:
         devices = str(int(np.argmin(mem_info())))
     devices = str(devices)
     if "-" in devices:

@@ -447,6 +447,32 @@ def scenario_case(label_text):
 
 
 # --------------------------------------------------------------------------- main
+def cli_flags_case():
+    """the command-line surface of the eight attack / detect scripts: per script, every
+    ``add_argument`` call's option strings, default VALUE (the default expression evaluated), type and action - data read off
+    the reference's own parser set-up, for tests/test_host_logic.py to hold this package's CLIs against"""
+    out = {}
+    for model in ("DSGN", "Stereo-RCNN"):
+        for script in ("pgd_attack", "patch_attack", "predict_and_save_pgd", "predict_and_save_patch"):
+            rel = "attack/%s/%s.py" % (model, script)
+            tree, _ = _parse(rel)
+            flags = []
+            for n in ast.walk(tree):
+                if not (isinstance(n, ast.Call) and isinstance(n.func, ast.Attribute) and n.func.attr == "add_argument"):
+                    continue
+                entry = {"options": [a.value for a in n.args if isinstance(a, ast.Constant)], "lineno": n.lineno}
+                for k in n.keywords:
+                    if k.arg == "default":
+                        entry["default"] = eval(compile(ast.Expression(k.value), rel, "eval"), {})
+                    elif k.arg == "type":
+                        entry["type"] = ast.unparse(k.value)
+                    elif k.arg in ("action", "dest"):
+                        entry[k.arg] = ast.literal_eval(k.value)
+                flags.append(entry)
+            out[rel] = sorted(flags, key=lambda e: e["lineno"])
+    return out
+
+
 def save_npz(name, arrays):
     path = os.path.join(HERE, name)
     np.savez_compressed(path, **arrays)
@@ -511,6 +537,7 @@ def main():
     index["label"] = label_case()
     index["scenario"] = scenario_case(index["label"]["text"])
     index["depth_stats"] = depth_stats_case()
+    index["cli_flags"] = cli_flags_case()
     with open(os.path.join(HERE, "index.json"), "w") as f:
         json.dump(index, f, indent=1, sort_keys=True)
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE)

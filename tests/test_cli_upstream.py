@@ -67,7 +67,8 @@ def test_devices_flag_as_the_reference_reads_it():
     assert upstream.resolve_devices("-2", mem) == "0,1,2"
     assert upstream.resolve_devices("1-", mem) == "1,2,3"
     assert upstream.resolve_devices("0,3", mem) == "0,3"
-    assert upstream.resolve_devices(0, mem) == "0"                     # predict_and_save_patch.py:52 default is the int 0
+    assert upstream.resolve_devices(0, mem) == "1"                     # predict_and_save_patch.py:52 default is the int 0: falsy at :70 -> least-used GPU
+    assert upstream.resolve_devices("0", mem) == "0"                   # an explicit "-d 0" is GPU 0
 
 
 def _dsgn_args(tmp, **kw):

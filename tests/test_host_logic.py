@@ -484,3 +484,38 @@ def test_ops_surface_is_complete():
     src = open(ops.__file__).read()
     unused = [s for s in _lib.SIGNATURES if s not in src]
     assert not unused, unused
+
+
+# ------------------------------------------------------------------------------------ command-line surface
+CLI_COUNTERPARTS = {
+    "attack/DSGN/pgd_attack.py": "dsgn_pgd_attack", "attack/DSGN/patch_attack.py": "dsgn_patch_attack",
+    "attack/DSGN/predict_and_save_pgd.py": "dsgn_predict_and_save_pgd", "attack/DSGN/predict_and_save_patch.py": "dsgn_predict_and_save_patch",
+    "attack/Stereo-RCNN/pgd_attack.py": "srcnn_pgd_attack", "attack/Stereo-RCNN/patch_attack.py": "srcnn_patch_attack",
+    "attack/Stereo-RCNN/predict_and_save_pgd.py": "srcnn_predict_and_save_pgd",
+    "attack/Stereo-RCNN/predict_and_save_patch.py": "srcnn_predict_and_save_patch",
+}
+
+
+@pytest.mark.parametrize("rel", sorted(CLI_COUNTERPARTS))
+def test_cli_accepts_every_reference_flag_with_the_reference_default(rel, golden_index):
+    """every add_argument of the reference script (option strings, default value, type, store_true) - read off the reference's
+    parser set-up by tests/golden/make_golden.py - exists in the counterpart's parser with the same meaning"""
+    import importlib
+    want = golden_index["cli_flags"][rel]
+    parser = importlib.import_module("eval_driving_safety_amd.cli." + CLI_COUNTERPARTS[rel]).build_parser()
+    by_opt = {o: a for a in parser._actions for o in a.option_strings}
+    assert want, rel
+    for flag in want:
+        acts = {id(by_opt[o]): by_opt[o] for o in flag["options"] if o in by_opt}
+        assert len(acts) == 1 and all(o in by_opt for o in flag["options"]), (rel, flag["options"])
+        (act,) = acts.values()
+        if flag.get("action") == "store_true":
+            assert type(act).__name__ == "_StoreTrueAction" and act.default is False, (rel, flag)
+            continue
+        assert act.default == flag.get("default"), (rel, flag, act.default)
+        if "type" in flag:
+            assert act.type is not None and act.type.__name__ == flag["type"], (rel, flag)
+        if "dest" in flag:
+            assert act.dest == flag["dest"], (rel, flag)
+    # and the defaults parse: the reference's no-argument invocation is accepted as it stands
+    parser.parse_args([])
