@@ -356,3 +356,32 @@ def test_hip_skip_connection_autograd_vs_torch():
     assert float((out - ref2).abs().max()) <= 1e-4 * float(ref2.detach().abs().max())
     assert float((xm.grad - xr.grad).abs().max()) <= 1e-4 * float(xr.grad.abs().max())
     assert float((sm.grad - sr.grad).abs().max()) <= 1e-4 * float(sr.grad.abs().max())
+
+
+@pytest.mark.gpu
+def test_hip_conv3d_batch_beyond_2_31_elements_equals_per_item_launches():
+    """maximum sizes: a batch whose input has 2.2e9 elements (8.8 GB; every item fits 32-bit offsets, the batch does not) in one
+    launch equals the items convolved one by one - forward with bias + ReLU, and the masked / transposed kernel."""
+    from eval_driving_safety_amd import ops
+    if torch.cuda.mem_get_info(0)[0] < 60 * 2 ** 30:
+        pytest.skip("needs 60 GB of free device memory")
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(12)
+    b, cin, cout, d, h, w = 6, 64, 32, 48, 96, 1248
+    assert b * cin * d * h * w > 2 ** 31
+    x = torch.empty((b, cin, d, h, w), device=dev)
+    for i in range(b):
+        x[i].normal_(generator=gen)
+    wt = torch.randn((cout, cin, 3, 3, 3), device=dev, generator=gen) * 0.05
+    bias = torch.randn((cout,), device=dev, generator=gen)
+    wp = ops.conv3d_k3_prep(wt)
+    y = ops.conv3d_k3(x, wp, cout, relu=True, bias=bias)
+    for i in range(b):
+        assert torch.equal(y[i:i + 1], ops.conv3d_k3(x[i:i + 1], wp, cout, relu=True, bias=bias)), i
+    del y
+    xs = x[:, :, :24, :48, :624].contiguous()                       # transposed: output [6,32,48,96,1248] = 1.1e9, eight classes
+    w_t = torch.randn((cin, cout, 3, 3, 3), device=dev, generator=gen) * 0.05
+    classes = ops.conv_transpose3d_k3_s2_prep(w_t)
+    up = ops.conv_transpose3d_k3_s2(xs, classes, cout, bias=bias)
+    for i in (0, b - 1):
+        assert torch.equal(up[i:i + 1], ops.conv_transpose3d_k3_s2(xs[i:i + 1], classes, cout, bias=bias)), i

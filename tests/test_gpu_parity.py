@@ -794,3 +794,79 @@ def test_gpu_reference_numerics_match_torch_on_this_gpu(ops):
         assert float((cur_c - cur_t).abs().max()) <= 2e-6                        # a few ulp: the iterate feeds back
     assert differs, "the CPU-path and GPU-path re-normalisations should not be identical functions"
     assert torch.equal(ops.normalize(clean, sp_gpu), normalize(clean_t))
+
+
+@pytest.mark.gpu
+def test_pgd_step_beyond_2_31_elements_per_stream(ops):
+    """maximum sizes: ONE launch over 1500 KITTI-shaped images - 2.16e9 elements (8.6 GB) per stream, so element offsets pass 2^31
+    and byte offsets 2^33 - gives the bytes of the same work done in launches of 500 images whose offsets all fit 32 bits, on
+    the all-float32 kernel and on the indexed-clean-image kernel, 8-bit export included; the LAST image (beyond every 32-bit
+    boundary) also equals the oracle.  Skipped when the device has less than 80 GB free."""
+    free, _ = torch.cuda.mem_get_info(0)
+    if free < 80 * 2 ** 30:
+        pytest.skip("needs 80 GB of free device memory")
+    sp = ops.Space.dsgn()
+    n, h, w, ch, cw = 1500, 384, 1248, 375, 1242
+    assert n * 3 * h * w > 2 ** 31
+    d = torch.device("cuda", 0)
+    gen = torch.Generator(device=d).manual_seed(77)
+    u = torch.randint(0, 256, (n, ch, cw, 3), device=d, generator=gen, dtype=torch.uint8)
+    x, clean, ci = ops.import_u8(u, sp, (h, w))      # the loader's transform on the device (itself one launch beyond 2^31 elements)
+    del u
+    g = torch.empty_like(x)
+    for i in range(0, n, 100):
+        g[i:i + 100].normal_(generator=gen)
+    assert torch.equal(ops.denormalize_indexed(x[-2:], sp, valid=(ch, cw))[0], clean[-2:])       # the import's clean image, re-derived
+    alpha, eps = 1.0 / 255, 0.03
+    for index in (None, ci):
+        full = torch.empty_like(x)
+        u8_full = ops.alloc_u8(n, ch, w, d)
+        ops.pgd_step(x, g, clean, sp, alpha, eps, out=full, u8_out=u8_full, crop=(ch, cw), clean_index=index)
+        for i in range(0, n, 500):
+            s = slice(i, i + 500)
+            sub = None if index is None else ops.denormalize_indexed(x[s], sp, valid=(ch, cw))[1]
+            part = torch.empty_like(x[s])
+            u8_part = ops.alloc_u8(500, ch, w, d)
+            ops.pgd_step(x[s], g[s], clean[s], sp, alpha, eps, out=part, u8_out=u8_part, crop=(ch, cw), clean_index=sub)
+            assert torch.equal(part, full[s]), (index is not None, i)
+            assert torch.equal(u8_part[:, :, :cw], u8_full[s][:, :, :cw]), (index is not None, i)
+            del part, u8_part, sub
+        want = O.pgd_step_norm01(host(x[-1:]), host(g[-1:]), host(clean[-1:]), alpha, eps)
+        same_bits(host(full[-1:]), want, "last image vs oracle")
+        del full, u8_full
+
+
+@pytest.mark.gpu
+def test_srcnn_pgd_step_beyond_2_31_elements_per_stream(ops):
+    """the same maximum-size check in the Stereo R-CNN pixel space (600x1987, identity space, in place, export fused): 604 images =
+    2.16e9 elements per stream in ONE launch against launches of 151 images, float and indexed clean image; last image vs oracle."""
+    free, _ = torch.cuda.mem_get_info(0)
+    if free < 80 * 2 ** 30:
+        pytest.skip("needs 80 GB of free device memory")
+    sp = ops.Space.srcnn()
+    n, h, w = 604, 600, 1987
+    assert n * 3 * h * w > 2 ** 31
+    d = torch.device("cuda", 0)
+    gen = torch.Generator(device=d).manual_seed(78)
+    means = torch.tensor(O.SRCNN_PIXEL_MEANS, dtype=torch.float32, device=d).view(1, 3, 1, 1)
+    x0 = torch.empty((n, 3, h, w), dtype=torch.float32, device=d)
+    g = torch.empty_like(x0)
+    for i in range(0, n, 151):
+        x0[i:i + 151] = torch.randint(0, 256, (151, 3, h, w), device=d, generator=gen, dtype=torch.uint8).float() - means   # float32 subtraction
+        g[i:i + 151].normal_(generator=gen)
+    clean, ci = ops.denormalize_indexed(x0, sp)
+    assert all(ci.verified())
+    for index in (None, ci):
+        full = x0.clone()
+        u8_full = ops.alloc_u8(n, h, w, d)
+        ops.pgd_step(full, g, clean, sp, 1.0, 7.65, out=full, u8_out=u8_full, clean_index=index)
+        for i in range(0, n, 151):
+            s = slice(i, i + 151)
+            part = x0[s].clone()
+            u8_part = ops.alloc_u8(151, h, w, d)
+            sub_clean, sub = ops.denormalize_indexed(part, sp)
+            ops.pgd_step(part, g[s], sub_clean, sp, 1.0, 7.65, out=part, u8_out=u8_part, clean_index=None if index is None else sub)
+            assert torch.equal(part, full[s]) and torch.equal(u8_part, u8_full[s]), (index is not None, i)
+            del part, u8_part, sub_clean, sub
+        same_bits(host(full[-1:]), O.pgd_step_meansub255(host(x0[-1:]), host(g[-1:]), host(x0[-1:]), 1.0, 7.65), "last image vs oracle")
+        del full, u8_full
