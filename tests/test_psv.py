@@ -164,3 +164,30 @@ def test_hip_psv_lerp_matches_oracle(shape):
     tl2, tr2 = tl.clone().requires_grad_(True), tr.clone().requires_grad_(True)
     (ops.PsvBuildLerp.apply(tl2, tr2, ts) * torch.tensor(g, device=dev)).sum().backward()
     assert tl2.grad.cpu().numpy().tobytes() == wl.tobytes() and tr2.grad.cpu().numpy().tobytes() == wr.tobytes()
+
+
+@pytest.mark.gpu
+def test_hip_psv_batch_beyond_2_31_elements_equals_per_item_launches():
+    """maximum sizes: a batch of 24 DSGN-shaped cost volumes (2.2e9 elements, 8.8 GB) built and back-propagated in one launch
+    each equals the items done one by one - integer-shift and interpolating variants"""
+    from eval_driving_safety_amd import ops
+    if torch.cuda.mem_get_info(0)[0] < 60 * 2 ** 30:
+        pytest.skip("needs 60 GB of free device memory")
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(21)
+    b, c, d, h, w = 24, 32, 48, 96, 312
+    assert b * 2 * c * d * h * w > 2 ** 31
+    left = torch.randn((b, c, h, w), device=dev, generator=gen)
+    right = torch.randn((b, c, h, w), device=dev, generator=gen)
+    shift_i = torch.randint(0, 60, (b, d), device=dev, generator=gen, dtype=torch.int32)
+    shift_f = torch.rand((b, d), device=dev, generator=gen) * 60.0
+    for build, bwd, shift in ((ops.psv_build, ops.psv_build_bwd, shift_i), (ops.psv_build_lerp, ops.psv_build_lerp_bwd, shift_f)):
+        cost = build(left, right, shift)
+        gl, gr = bwd(cost, shift)                       # the volume itself as the incoming gradient
+        for i in (0, 11, b - 1):
+            s = slice(i, i + 1)
+            one = build(left[s].contiguous(), right[s].contiguous(), shift[s].contiguous())
+            assert torch.equal(one, cost[s]), i
+            gl1, gr1 = bwd(one, shift[s].contiguous())
+            assert torch.equal(gl1, gl[s]) and torch.equal(gr1, gr[s]), i
+        del cost, gl, gr

@@ -143,6 +143,32 @@ def test_hip_grid_sample3d_bit_exact_and_deterministic_backward(cfg):
 
 
 @pytest.mark.gpu
+def test_hip_grid_sample3d_beyond_2_31_elements_equals_channel_chunks():
+    """maximum sizes: a volume of 2.3e9 elements (element offsets beyond 32 bits) sampled in one launch, and its backward (both
+    gather variants), equal the same work done on channel chunks whose offsets fit"""
+    from eval_driving_safety_amd import ops
+    if torch.cuda.mem_get_info(0)[0] < 60 * 2 ** 30:
+        pytest.skip("needs 60 GB of free device memory")
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(3)
+    b, c, dims, out = 2, 800, (48, 96, 312), (96, 10, 152)
+    assert b * c * dims[0] * dims[1] * dims[2] > 2 ** 31
+    vol = torch.empty((b, c) + dims, device=dev)
+    for i in range(b):
+        vol[i].normal_(generator=gen)
+    grid = torch.rand((b,) + out + (3,), device=dev, generator=gen) * 2.2 - 1.1
+    got = ops.grid_sample3d(vol, grid, True)
+    plan = ops.GridSamplePlan(grid, dims, True)
+    g = torch.randn(got.shape, device=dev, generator=gen)
+    gv = ops.grid_sample3d_bwd(g, plan)
+    assert torch.equal(ops.grid_sample3d_bwd(g, plan, channels_last=False), gv)
+    for lo in (0, 400):
+        ch = slice(lo, lo + 400)
+        assert torch.equal(got[:, ch], ops.grid_sample3d(vol[:, ch].contiguous(), grid, True)), lo
+        assert torch.equal(gv[:, ch], ops.grid_sample3d_bwd(g[:, ch].contiguous(), plan)), lo
+
+
+@pytest.mark.gpu
 def test_hip_sigmoid_focal_loss():
     from eval_driving_safety_amd import ops
     rs = np.random.RandomState(5)
