@@ -10,27 +10,27 @@ from . import upstream
 def add_scaffolding(parser, loadmodel=None, btest=None, devices=None):
     """flags shared by the DSGN scripts (attack/DSGN/pgd_attack.py:35-51; the detect-under-patch script changes three
     defaults, predict_and_save_patch.py:40,51-52)"""
-    parser.add_argument("-cfg", "--cfg", "--config", default=None, help="config path")
-    parser.add_argument("--data_path", default="./data/kitti/training", help="select model")
-    parser.add_argument("--loadmodel", default=loadmodel, help="loading model")
-    parser.add_argument("--seed", type=int, default=1, metavar="S", help="random seed (default: 1)")
-    parser.add_argument("--split_file", default="./data/kitti/val.txt", help="split file")
-    parser.add_argument("--btest", "-btest", type=int, default=btest)
-    parser.add_argument("--devices", "-d", type=str, default=devices)
-    parser.add_argument("--tag", "-t", type=str, default="")
-    parser.add_argument("--debug", action="store_true", default=False, help="debug mode")
-    parser.add_argument("--debugnum", default=None, type=int, help="debug mode")
+    parser.add_argument("-cfg", "--cfg", "--config", default=None, help="YAML configuration of the upstream DSGN checkout (default: the one stored beside --loadmodel)")
+    parser.add_argument("--data_path", default="./data/kitti/training", help="KITTI object folder holding image_2 / image_3 / calib / label_2 / velodyne")
+    parser.add_argument("--loadmodel", default=loadmodel, help="checkpoint of the detector to attack (.tar written by the upstream trainer)")
+    parser.add_argument("--seed", type=int, default=1, metavar="S", help="seed of torch's generators")
+    parser.add_argument("--split_file", default="./data/kitti/val.txt", help="text file with one KITTI frame index per line")
+    parser.add_argument("--btest", "-btest", type=int, default=btest, help="stereo pairs per batch (default: one per listed device)")
+    parser.add_argument("--devices", "-d", type=str, default=devices, help="GPU id, list a,b or range a-b; empty: the least-used GPU (one process drives one GPU)")
+    parser.add_argument("--tag", "-t", type=str, default="", help="suffix of the result folder name")
+    parser.add_argument("--debug", action="store_true", default=False, help="stop after --debugnum frames and read the data in the main process")
+    parser.add_argument("--debugnum", default=None, type=int, help="how many frames a --debug run handles (the scripts differ by one, see DESIGN.md Q15)")
     add_engine_flags(parser)
 
 
 def add_detect_flags(parser):
     """flags the two DSGN detect scripts add (attack/DSGN/predict_and_save_pgd.py:45-56)"""
-    parser.add_argument("--save_path", type=str, default="./outputs/result", metavar="S", help="path to save the predict")
-    parser.add_argument("--save_lidar", action="store_true", help="if true, save the numpy file, not the png file")
-    parser.add_argument("--save_depth_map", action="store_true", help="if true, save the numpy file, not the png file")
-    parser.add_argument("--train", "-train", action="store_true", default=False, help="test on train set")
-    parser.add_argument("--save_feat_map", action="store_true", help="will save feature maps")
-    parser.add_argument("--save_feat_path", type=str, default="", help="path to save feature maps")
+    parser.add_argument("--save_path", type=str, default="./outputs/result", metavar="S", help="folder for the KITTI-format detection files")
+    parser.add_argument("--save_lidar", action="store_true", help="also store the pseudo-lidar point cloud of every frame (.npy)")
+    parser.add_argument("--save_depth_map", action="store_true", help="also store the predicted depth map of every frame (.npy)")
+    parser.add_argument("--train", "-train", action="store_true", default=False, help="read the training split instead of the validation split")
+    parser.add_argument("--save_feat_map", action="store_true", help="also dump the detector's intermediate feature maps")
+    parser.add_argument("--save_feat_path", type=str, default="", help="folder for --save_feat_map")
 
 
 def add_engine_flags(parser):

@@ -19,7 +19,7 @@ def build_parser():
     p.add_argument("--save_dir", default="model/")
     p.add_argument("--checkpoint", default=None, help="validate: default model/pretrained_model/cnn_20.pth (validate.py:37)")
     p.add_argument("--imagenet_weights", default=None, help="torchvision state dict of the backbone (pretrained=True of Model.py:19; no network here)")
-    p.add_argument("--epochs", type=int, default=None)
+    p.add_argument("--epochs", type=int, default=None, help="passes over the split")
     p.add_argument("--device", default=None)
     return p
 

@@ -10,12 +10,12 @@ from ..dist import Comm
 
 
 def build_parser():
-    parser = argparse.ArgumentParser(description="Patch attack")
+    parser = argparse.ArgumentParser(description="Train a universal adversarial patch against DSGN (MI355X engine; counterpart of attack/DSGN/patch_attack.py)")
     _common.add_scaffolding(parser)
-    parser.add_argument("--iter", type=int, default=2, help="iteration number of patch attack")
-    parser.add_argument("--eps", type=float, default=(8.0 / 255))
-    parser.add_argument("--epochs", type=int, default=80)
-    parser.add_argument("--ratio", type=float, default=0.2)
+    parser.add_argument("--iter", type=int, default=2, help="inner updates of the patch per frame")
+    parser.add_argument("--eps", type=float, default=(8.0 / 255), help="L-infinity budget (DSGN: fraction of the [0,1] range; Stereo R-CNN: multiplied by 255)")
+    parser.add_argument("--epochs", type=int, default=80, help="passes over the split")
+    parser.add_argument("--ratio", type=float, default=0.2, help="patch diameter as a fraction of the image height")
     return parser
 
 

@@ -10,11 +10,11 @@ from ..dist import Comm
 
 
 def build_parser():
-    parser = argparse.ArgumentParser(description="PGD attack")
+    parser = argparse.ArgumentParser(description="PGD / FGSM perturbation of KITTI stereo pairs against DSGN (MI355X engine; counterpart of attack/DSGN/pgd_attack.py)")
     _common.add_scaffolding(parser)
-    parser.add_argument("--iter", type=int, default=4, help="iteration number of pgd attack")
-    parser.add_argument("--alpha", type=float, default=(1.0 / 255))
-    parser.add_argument("--eps", type=float, default=0.3)
+    parser.add_argument("--iter", type=int, default=4, help="number of PGD steps (1 = FGSM)")
+    parser.add_argument("--alpha", type=float, default=(1.0 / 255), help="step size per iteration (in the model's pixel units: 1/255 of the [0,1] range for DSGN, grey levels for Stereo R-CNN)")
+    parser.add_argument("--eps", type=float, default=0.3, help="L-infinity budget (DSGN: fraction of the [0,1] range; Stereo R-CNN: multiplied by 255)")
     return parser
 
 

@@ -8,14 +8,14 @@ from . import _common, _dsgn_detect, upstream
 
 
 def build_parser():
-    parser = argparse.ArgumentParser(description="Patch attack predict and save")
+    parser = argparse.ArgumentParser(description="Run DSGN on frames carrying a trained patch and write KITTI label files (counterpart of attack/DSGN/predict_and_save_patch.py)")
     _common.add_scaffolding(parser, loadmodel="./outputs/temp/DSGN_car_pretrained/finetune_53.tar", btest=1, devices=0)
     _common.add_detect_flags(parser)
-    parser.add_argument("--ratio", dest="ratio", type=float, default=0.2)
-    parser.add_argument("--epochs", dest="epochs", type=int, default=80)
-    parser.add_argument("--patch_dir", dest="patch_dir", type=str, help="path to folder that save all trained patches")
+    parser.add_argument("--ratio", dest="ratio", type=float, default=0.2, help="patch diameter as a fraction of the image height")
+    parser.add_argument("--epochs", dest="epochs", type=int, default=80, help="passes over the split")
+    parser.add_argument("--patch_dir", dest="patch_dir", type=str, help="folder holding the trained patches (<model>_patch_ratio_<r>/epoch<k>/patch.npy)")
     parser.add_argument("--atk_mode", dest="atk_mode", type=str, default="random",
-                        help="four patch attack modes(random, sp_left, sp_straight, sp_right)")
+                        help="where the patch is pasted: random | sp_left | sp_straight | sp_right (column bands of the image)")
     return parser
 
 

@@ -8,11 +8,11 @@ from . import _common, _dsgn_detect, upstream
 
 
 def build_parser():
-    parser = argparse.ArgumentParser(description="Perturbation attack predict and save")
+    parser = argparse.ArgumentParser(description="Run DSGN on a folder of PGD iterates and write KITTI label files (counterpart of attack/DSGN/predict_and_save_pgd.py)")
     _common.add_scaffolding(parser)
     _common.add_detect_flags(parser)
-    parser.add_argument("--iter", type=int, help="iteration number of pgd attack")
-    parser.add_argument("--alpha", type=float, help="iteration number of pgd attack")
+    parser.add_argument("--iter", type=int, help="which iterate folder (<model>_pgd_iters_<k>) to run the detector on")
+    parser.add_argument("--alpha", type=float, help="step size the attacked folder was made with (part of the folder name only)")
     return parser
 
 

@@ -8,14 +8,14 @@ from ..dist import Comm
 
 
 def build_parser():
-    parser = argparse.ArgumentParser(description="Attack the Stereo R-CNN network")
-    parser.add_argument("--iter", type=int, default=2, help="iteration number of pgd attack")
-    parser.add_argument("--eps", dest="eps", type=float, default=0.1)
-    parser.add_argument("--epochs", dest="epochs", type=int, default=40)
-    parser.add_argument("--ratio", dest="ratio", type=float, default=0.1)
-    parser.add_argument("--debug", action="store_true", default=False, help="debug mode")
-    parser.add_argument("--debugnum", default=None, type=int, help="debug mode")
-    parser.add_argument("--seed", type=int, default=3, help="seed of the toy stand-in (upstream: cfg.RNG_SEED)")
+    parser = argparse.ArgumentParser(description="Train a universal adversarial patch against Stereo R-CNN (counterpart of attack/Stereo-RCNN/patch_attack.py)")
+    parser.add_argument("--iter", type=int, default=2, help="inner updates of the patch per frame")
+    parser.add_argument("--eps", dest="eps", type=float, default=0.1, help="L-infinity budget (DSGN: fraction of the [0,1] range; Stereo R-CNN: multiplied by 255)")
+    parser.add_argument("--epochs", dest="epochs", type=int, default=40, help="passes over the split")
+    parser.add_argument("--ratio", dest="ratio", type=float, default=0.1, help="patch diameter as a fraction of the image height")
+    parser.add_argument("--debug", action="store_true", default=False, help="stop after --debugnum frames and read the data in the main process")
+    parser.add_argument("--debugnum", default=None, type=int, help="how many frames a --debug run handles (the scripts differ by one, see DESIGN.md Q15)")
+    parser.add_argument("--seed", type=int, default=3, help="seed of torch's generators")
     parser.add_argument("--devices", "-d", type=str, default="0", help="GPU index (the reference always uses the current device)")
     _common.add_engine_flags(parser)
     return parser

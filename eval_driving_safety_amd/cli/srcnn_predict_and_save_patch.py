@@ -6,16 +6,16 @@ from . import _common, _srcnn_detect, upstream
 
 
 def build_parser():
-    parser = argparse.ArgumentParser(description="Attack the Stereo R-CNN network")
-    parser.add_argument("--debug", action="store_true", default=False, help="debug mode")
-    parser.add_argument("--debugnum", default=None, type=int, help="debug mode")
-    parser.add_argument("--ratio", dest="ratio", type=float, default=0.1)
-    parser.add_argument("--epochs", dest="epochs", type=int, default=40)
-    parser.add_argument("--patch_dir", dest="patch_dir", type=str, help="path to folder that save all trained patches")
+    parser = argparse.ArgumentParser(description="Run Stereo R-CNN on frames carrying a trained patch and write its result files (counterpart of attack/Stereo-RCNN/predict_and_save_patch.py)")
+    parser.add_argument("--debug", action="store_true", default=False, help="stop after --debugnum frames and read the data in the main process")
+    parser.add_argument("--debugnum", default=None, type=int, help="how many frames a --debug run handles (the scripts differ by one, see DESIGN.md Q15)")
+    parser.add_argument("--ratio", dest="ratio", type=float, default=0.1, help="patch diameter as a fraction of the image height")
+    parser.add_argument("--epochs", dest="epochs", type=int, default=40, help="passes over the split")
+    parser.add_argument("--patch_dir", dest="patch_dir", type=str, help="folder holding the trained patches (<model>_patch_ratio_<r>/epoch<k>/patch.npy)")
     parser.add_argument("--atk_mode", dest="atk_mode", type=str, default="random",
-                        help="four patch attack modes(random, sp_left, sp_straight, sp_right)")
-    parser.add_argument("--save_feat_map", action="store_true", help="will save feature maps")
-    parser.add_argument("--save_feat_path", type=str, default="", help="path to save feature maps")
+                        help="where the patch is pasted: random | sp_left | sp_straight | sp_right (column bands of the image)")
+    parser.add_argument("--save_feat_map", action="store_true", help="also dump the detector's intermediate feature maps")
+    parser.add_argument("--save_feat_path", type=str, default="", help="folder for --save_feat_map")
     parser.add_argument("--devices", "-d", type=str, default="0", help="GPU index (the reference always uses the current device)")
     _common.add_engine_flags(parser)
     return parser

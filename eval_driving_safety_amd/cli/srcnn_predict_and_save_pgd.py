@@ -6,11 +6,11 @@ from . import _common, _srcnn_detect, upstream
 
 
 def build_parser():
-    parser = argparse.ArgumentParser(description="Attack the Stereo R-CNN network")
-    parser.add_argument("--iter", dest="iter", help="iteration number of pgd attack", type=int, default=1)
-    parser.add_argument("--alpha", dest="alpha", help="iteration number of pgd attack", type=float, default=1)
-    parser.add_argument("--save_feat_map", action="store_true", help="will save feature maps")
-    parser.add_argument("--save_feat_path", type=str, default="", help="path to save feature maps")
+    parser = argparse.ArgumentParser(description="Run Stereo R-CNN on a folder of PGD iterates and write its result files (counterpart of attack/Stereo-RCNN/predict_and_save_pgd.py)")
+    parser.add_argument("--iter", dest="iter", help="which iterate folder (<model>_pgd_iters_<k>) to run the detector on", type=int, default=1)
+    parser.add_argument("--alpha", dest="alpha", help="step size the attacked folder was made with (part of the folder name only)", type=float, default=1)
+    parser.add_argument("--save_feat_map", action="store_true", help="also dump the detector's intermediate feature maps")
+    parser.add_argument("--save_feat_path", type=str, default="", help="folder for --save_feat_map")
     parser.add_argument("--devices", "-d", type=str, default="0", help="GPU index (the reference always uses the current device)")
     _common.add_engine_flags(parser)
     return parser
