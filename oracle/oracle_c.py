@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_PATH = os.path.join(_HERE, "_build", "liboracle.so")
+_PATH = os.environ.get("ADV_ORACLE_LIB") or os.path.join(_HERE, "_build", "liboracle.so")     # ADV_ORACLE_LIB: the sanitizer build (Makefile)
 if not os.path.exists(_PATH):
     raise ImportError("oracle/_build/liboracle.so not built (make -C oracle)")
 _lib = ctypes.CDLL(_PATH)
