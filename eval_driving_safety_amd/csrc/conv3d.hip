@@ -607,6 +607,152 @@ __global__ __launch_bounds__(128 * TD, 2) void conv3d_k3_mfma(const float* __res
 
 
 // ---------------------------------------------------------------------------------------------------------------
+// Transposed convolution (kernel 3, stride 2, padding 1, output_padding 1) with ALL EIGHT output parity classes per tile.
+// The class-as-tile-index launch above stages an input tile once per class and uses it for that class's 1-8 taps; here a
+// workgroup stages the tile ONCE per 4-channel stage and runs all 27 kernel taps on it, each into the accumulator of the
+// class it belongs to (per axis: kernel tap 1 -> even outputs from input offset 0; tap 2 -> odd outputs from offset 0; tap 0 ->
+// odd outputs from offset +1) - 2.3x fewer staged floats per MFMA.  Tile = 1 x kTT x 32 INPUT voxels (a wave per row) -> a
+// 2 x 2*kTT x 64 block of outputs x 32 channels; eight 32x32 accumulators per wave (128 VGPRs); the input tile needs a halo on
+// the high side only.  Staging by LDS-DMA (W % 4 == 0), two stages.  A class's accumulation order is the one of its masked
+// convolution (stage, input offset in lexicographic order = its taps in ascending order, channel pair), so the result has the
+// same bits as the class launches and the oracle.  The weights are read from the eight per-class prepared tensors the entry
+// point already takes: kernel tap k of class c sits at tap t(k) of cls_wp[c].
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kTT = 4;                                   // input rows per tile = waves per workgroup
+constexpr int kTRows = kFC * 2 * (kTT + 1);              // tile rows per stage: 4 channels x 2 planes x 5 rows
+constexpr int kTXF4 = kTRows * 10;                       // 400 float4
+constexpr int kTXInstr = (kTXF4 + 63) / 64;              // 7 wave-instructions (the last one partly pad)
+constexpr int kTSX = kTXInstr * 256;                     // floats reserved for the input tile
+constexpr int kTWInstr = (kWF4 + 63) / 64;               // 14
+constexpr int kTStage = kTSX + kTWInstr * 256;           // 5376 floats = 21 KiB per stage
+constexpr int kTXPer = (kTXInstr + kTT - 1) / kTT, kTWPer = (kTWInstr + kTT - 1) / kTT;
+
+__device__ __forceinline__ constexpr int tp_off(int a) { return a == 2 ? 1 : 0; }     // input offset of per-axis choice a
+__device__ __forceinline__ constexpr int tp_par(int a) { return a == 0 ? 0 : 1; }     // output parity
+__device__ __forceinline__ constexpr int tp_tap(int a) { return a == 2 ? 2 : 1; }     // tap of the CLASS convolution (offset + 1)
+
+__global__ __launch_bounds__(64 * kTT, 2) void convt3d_k3_s2_mfma(const float* __restrict__ x, float* __restrict__ y, int Cin, int Cout,
+                                                                  int cout_pad, int D, int H, int W, int tiles_w, int tiles_h, int cblocks,
+                                                                  Epi epi) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l32 = lane & 31;
+  const int plane = H * W, vol = plane * D;
+  int t = blockIdx.x;
+  const int w0 = (t % tiles_w) * kTW;
+  t /= tiles_w;
+  const int h0 = (t % tiles_h) * kTT;
+  t /= tiles_h;
+  const int d0 = t % D;
+  t /= D;
+  const int b = t / cblocks, cob = t - b * cblocks;
+  const float* xb = x + static_cast<long long>(b) * Cin * vol;
+
+  // what this lane moves per stage: float4 q = 64*k + lane of piece k (pieces wave, wave + 4, ...)
+  int xo[kTXPer];
+  const float* wsrc[kTWPer];
+#pragma unroll
+  for (int p = 0; p < kTXPer; ++p) {
+    const int q = 64 * (wave + kTT * p) + lane;
+    const int row = q / 10, j = q - row * 10;
+    const int c = row / (2 * (kTT + 1)), rem = row - c * 2 * (kTT + 1);
+    const int dd = rem / (kTT + 1), hh = rem - dd * (kTT + 1);
+    const int gd = d0 + dd, gh = h0 + hh, gw = w0 - 4 + 4 * j;
+    const bool ok = q < kTXF4 && j > 0 && gd < D && gh < H && gw + 3 < W;          // j = 0 (columns left of the tile) is never read
+    xo[p] = ok ? c * vol + gd * plane + gh * W + gw : -1;
+  }
+#pragma unroll
+  for (int p = 0; p < kTWPer; ++p) {
+    const int f = 64 * (wave + kTT * p) + lane;
+    const int n4 = f & 7, c = (f >> 3) & (kFC - 1), slot = f / (8 * kFC);           // slot = (ad*3 + ah)*3 + aw
+    const int ad = slot / 9, ah = (slot / 3) % 3, aw = slot % 3;
+    const int cls = (tp_par(ad) * 2 + tp_par(ah)) * 2 + tp_par(aw), tap = (tp_tap(ad) * 3 + tp_tap(ah)) * 3 + tp_tap(aw);
+    const float* base = epi.cls_wp[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) base = cls == k ? epi.cls_wp[k] : base;
+    wsrc[p] = f < kWF4 ? base + (static_cast<long long>(tap) * Cin + c) * cout_pad + cob * 32 + 4 * n4 : nullptr;
+  }
+  auto issue = [&](int c0, float* stage) {
+#pragma unroll
+    for (int p = 0; p < kTXPer; ++p) {
+      const int k = wave + kTT * p;
+      if (k < kTXInstr) glds16(xo[p] >= 0 ? xb + static_cast<long long>(c0) * vol + xo[p] : g_zero16, stage + k * 256);
+    }
+#pragma unroll
+    for (int p = 0; p < kTWPer; ++p) {
+      const int k = wave + kTT * p;
+      if (k < kTWInstr) glds16(wsrc[p] ? wsrc[p] + static_cast<long long>(c0) * cout_pad : g_zero16, stage + kTSX + k * 256);
+    }
+  };
+
+  f32x16 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[i][v] = 0.0f;
+  issue(0, lds);
+  __syncthreads();
+  int cur = 0;
+  for (int c0 = 0; c0 < Cin; c0 += kFC) {
+    const int cn = c0 + kFC < Cin ? c0 + kFC : c0;      // the last stage fetches itself again (harmless): no branch in the body
+    issue(cn, lds + (cur ^ 1) * kTStage);
+    __builtin_amdgcn_sched_barrier(0);
+    const float* sxc = lds + cur * kTStage;
+    const float* swc = sxc + kTSX;
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {                       // input offset (od, oh, ow), lexicographic
+      const int od = o >> 2, oh = (o >> 1) & 1, ow = o & 1;
+#pragma unroll
+      for (int kk = 0; kk < kFC / 2; ++kk) {
+        const int c = 2 * kk + half;
+        const float bv = sxc[((c * 2 + od) * (kTT + 1) + wave + oh) * kP + 4 + l32 + ow];
+#pragma unroll
+        for (int slot = 0; slot < 27; ++slot) {         // the kernel taps that read this offset: one per class they feed
+          const int ad = slot / 9, ah = (slot / 3) % 3, aw = slot % 3;
+          if (tp_off(ad) != od || tp_off(ah) != oh || tp_off(aw) != ow) continue;
+          const int cls = (tp_par(ad) * 2 + tp_par(ah)) * 2 + tp_par(aw);
+          const float a = swc[(slot * kFC + c) * 32 + l32];
+          acc[cls] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[cls], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue: accumulator register v of lane l is D[cout = 8*(v/4) + 4*(l/32) + v%4][input voxel l%32]; the classes pw = 0 / 1
+  // of an output row are neighbours in memory: one 8-byte store per lane, 256 contiguous bytes per half-wave
+  const int gh = h0 + wave, gw = w0 + l32;
+  if (gh >= H || gw >= W) return;
+  const int co0 = cob * 32 + 4 * half;
+  const long long ovol = static_cast<long long>(epi.od) * epi.oh * epi.ow;
+  typedef float v2f __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int pd = 0; pd < 2; ++pd)
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph) {
+      const long long at = (static_cast<long long>(b) * Cout + co0) * ovol + (static_cast<long long>(2 * d0 + pd) * epi.oh + 2 * gh + ph) * epi.ow + 2 * gw;
+      const int c0i = (pd * 2 + ph) * 2;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int cr = 8 * (v >> 2) + (v & 3);
+        if (co0 + cr >= Cout) continue;
+        v2f r = {acc[c0i][v], acc[c0i + 1][v]};
+        if (epi.bias) {
+          const float bz = epi.bias[co0 + cr];
+          r.x = r.x + bz, r.y = r.y + bz;
+        }
+        if (epi.residual) {
+          const v2f sk = *reinterpret_cast<const v2f*>(epi.residual + at + cr * ovol);
+          r.x = r.x + sk.x, r.y = r.y + sk.y;
+        }
+        if (epi.relu) r.x = r.x > 0.0f ? r.x : 0.0f, r.y = r.y > 0.0f ? r.y : 0.0f;
+        *reinterpret_cast<v2f*>(y + at + cr * ovol) = r;
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Narrow layers on the vector ALUs.  The matrix kernel pads the output channels to 32 rows, so the LAST layer of a
 // cost-volume network (32 -> 1: per-plane scores) would spend 31/32 of its MFMA work on zeros, and its adjoint (1 -> 32,
 // Cin = 1) has K = 27: both are cheaper as plain fmaf chains.  Same accumulation order as the matrix kernel and the oracle
@@ -1025,6 +1171,17 @@ int adv_conv_transpose3d_k3_s2_f32(const float* x, const float* const* w_prep_cl
   bool aligned_w = (reinterpret_cast<uintptr_t>(x) & 3) == 0;
   for (int k = 0; k < 8; ++k) aligned_w = aligned_w && (reinterpret_cast<uintptr_t>(w_prep_classes[k]) & 15) == 0;
   if (fits && aligned_w && getenv("ADV_CONV_GENERIC") == nullptr && getenv("ADV_CONV_CLASS_LAUNCHES") == nullptr) {
+    const int tiles_w = (w + kTW - 1) / kTW, tiles_h = (h + kTT - 1) / kTT;
+    const long long ntiles = static_cast<long long>(tiles_w) * tiles_h * d * b * cblocks;
+    const bool all_classes = w % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 7) == 0 &&
+                             (reinterpret_cast<uintptr_t>(residual) & 7) == 0 && ntiles < (1LL << 31) && getenv("ADV_CONV_T_CLASS_TILES") == nullptr;
+    if (all_classes) {   // every class from one staging of the input tile (convt3d_k3_s2_mfma)
+      for (int k = 0; k < 8; ++k) epi.cls_wp[k] = w_prep_classes[k];
+      const size_t lds = 2 * sizeof(float) * static_cast<size_t>(kTStage);
+      hipLaunchKernelGGL(convt3d_k3_s2_mfma, dim3(static_cast<unsigned>(ntiles)), dim3(64 * kTT), lds, st, x, y, cin, cout, cblocks * 32, d, h, w,
+                         tiles_w, tiles_h, cblocks, epi);
+      return adv_internal_finish_launch();
+    }
     epi.nclass = 8;   // one launch: the class is a tile index (launch_conv's persistent masked kernel)
     for (int k = 0; k < 8; ++k) {
       epi.cls_wp[k] = w_prep_classes[k];

@@ -120,10 +120,10 @@ def test_hip_persistent_tile_walk_equals_one_workgroup_per_tile(masked, monkeypa
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("switch", ["ADV_CONV_NO_DMA=1", "ADV_CONV_TH=4", "ADV_CONV_TH=8", "ADV_CONV_GENERIC=1", "ADV_CONV_CLASS_LAUNCHES=1"])
+@pytest.mark.parametrize("switch", ["ADV_CONV_NO_DMA=1", "ADV_CONV_TH=4", "ADV_CONV_TH=8", "ADV_CONV_GENERIC=1", "ADV_CONV_CLASS_LAUNCHES=1", "ADV_CONV_T_CLASS_TILES=1"])
 def test_hip_alternative_code_paths_give_the_same_bits(switch, monkeypatch):
-    """register-staged vs LDS-DMA stages, both tile heights, the scalar-staging kernel, eight launches vs one for the transposed
-    convolution: identical results on plain, masked, strided and transposed layers (W % 4 == 0 and != 0)"""
+    """register-staged vs LDS-DMA stages, both tile heights, the scalar-staging kernel, for the transposed convolution eight
+    launches / the class as a tile index / all classes per tile: identical results on plain, masked, strided and transposed layers (W % 4 == 0 and != 0)"""
     from eval_driving_safety_amd import ops
     dev = torch.device("cuda", 0)
     gen = torch.Generator(device=dev).manual_seed(21)
@@ -319,13 +319,16 @@ def test_hip_residual_epilogue_equals_conv_then_add_then_relu(shape, monkeypatch
         w_t = (rs.randn(cin, cout, 3, 3, 3) * 0.1).astype(np.float32)
         classes = ops.conv_transpose3d_k3_s2_prep(torch.tensor(w_t, device=dev))
         skip2 = torch.tensor(rs.randn(b, cout, 2 * d, 2 * h, 2 * w).astype(np.float32), device=dev)
-        for env in ({}, {"ADV_CONV_CLASS_LAUNCHES": "1"}):
+        for env in ({}, {"ADV_CONV_T_CLASS_TILES": "1"}, {"ADV_CONV_CLASS_LAUNCHES": "1"}):
+            for k in ("ADV_CONV_T_CLASS_TILES", "ADV_CONV_CLASS_LAUNCHES"):
+                monkeypatch.delenv(k, raising=False)
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
             got = ops.conv_transpose3d_k3_s2(tx, classes, cout, bias=tb, relu=True, residual=skip2)
             want_t = np.maximum(C.conv_transpose3d_k3_s2(x, w_t, bias=bias) + skip2.cpu().numpy(), np.float32(0))
             assert got.cpu().numpy().tobytes() == want_t.tobytes(), ("transposed", env)
-        monkeypatch.delenv("ADV_CONV_CLASS_LAUNCHES", raising=False)
+        for k in ("ADV_CONV_T_CLASS_TILES", "ADV_CONV_CLASS_LAUNCHES"):
+            monkeypatch.delenv(k, raising=False)
     with pytest.raises(ValueError):
         ops.conv3d_k3(tx, wp, cout, residual=ts[:, :, :-1].contiguous())
 

@@ -40,22 +40,33 @@ def conv_case(rs, dev, big=False):
     bias = rs.randn(cout).astype(np.float32) if rs.rand() < 0.5 else None
     relu = bool(rs.rand() < 0.5)
     mask = int(rs.randint(1, 1 << 27)) if rs.rand() < 0.4 else (1 << 27) - 1
-    sw = rs.choice(["", "ADV_CONV_NO_DMA", "ADV_CONV_TH4", "ADV_CONV_TH8", "ADV_CONV_ONE_TILE_PER_WG", "ADV_CONV_GENERIC"])
+    sw = rs.choice(["", "", "ADV_CONV_NO_DMA", "ADV_CONV_TH4", "ADV_CONV_TH8", "ADV_CONV_ONE_TILE_PER_WG", "ADV_CONV_GENERIC", "ADV_CONV_T_CLASS_TILES",
+                    "ADV_CONV_CLASS_LAUNCHES"])
+    skip = bool(rs.rand() < 0.4)
     env = {"ADV_CONV_TH4": ("ADV_CONV_TH", "4"), "ADV_CONV_TH8": ("ADV_CONV_TH", "8")}.get(sw, (sw, "1") if sw else None)
     if env:
         os.environ[env[0]] = env[1]
     try:
         tx, tw = torch.tensor(x, device=dev), torch.tensor(wt, device=dev)
         tb = None if bias is None else torch.tensor(bias, device=dev)
-        y = ops._conv3d_ex(tx, ops.conv3d_k3_prep(tw), cout, 1, relu, tb, mask)
-        same(y, C.conv3d_k3_ex(x, wt, bias=bias, relu=relu, tap_mask=mask), "conv %s" % ((b, cin, cout, d, h, w, relu, hex(mask), sw),))
+        def plus_skip(conv, sk):        # the epilogue's order: accumulate, + bias, + skip, max
+            if sk is None:
+                return conv(relu)
+            r = conv(False) + sk
+            return np.maximum(r, np.float32(0)) if relu else r
+        sk = rs.randn(b, cout, d, h, w).astype(np.float32) if skip else None
+        y = ops._conv3d_ex(tx, ops.conv3d_k3_prep(tw), cout, 1, relu, tb, mask, residual=None if sk is None else torch.tensor(sk, device=dev))
+        same(y, plus_skip(lambda r: C.conv3d_k3_ex(x, wt, bias=bias, relu=r, tap_mask=mask), sk),
+             "conv %s" % ((b, cin, cout, d, h, w, relu, hex(mask), sw, skip),))
         if rs.rand() < 0.4:
             ys = ops.conv3d_k3_s2(tx, ops.conv3d_k3_s2_prep(tw), cout, relu=relu, bias=tb)
             same(ys, C.conv3d_k3_s2(x, wt, bias=bias, relu=relu), "strided conv %s" % ((b, cin, cout, d, h, w, sw),))
         if rs.rand() < 0.4:
             wtt = (rs.randn(cin, cout, 3, 3, 3) * 0.1).astype(np.float32)
-            yt = ops.conv_transpose3d_k3_s2(tx, ops.conv_transpose3d_k3_s2_prep(torch.tensor(wtt, device=dev)), cout, relu=relu, bias=tb)
-            same(yt, C.conv_transpose3d_k3_s2(x, wtt, bias=bias, relu=relu), "transposed conv %s" % ((b, cin, cout, d, h, w, sw),))
+            sk2 = rs.randn(b, cout, 2 * d, 2 * h, 2 * w).astype(np.float32) if skip else None
+            yt = ops.conv_transpose3d_k3_s2(tx, ops.conv_transpose3d_k3_s2_prep(torch.tensor(wtt, device=dev)), cout, relu=relu, bias=tb,
+                                            residual=None if sk2 is None else torch.tensor(sk2, device=dev))
+            same(yt, plus_skip(lambda r: C.conv_transpose3d_k3_s2(x, wtt, bias=bias, relu=r), sk2), "transposed conv %s" % ((b, cin, cout, d, h, w, sw, skip),))
     finally:
         if env:
             del os.environ[env[0]]
