@@ -618,22 +618,28 @@ __global__ __launch_bounds__(128 * TD, 2) void conv3d_k3_mfma(const float* __res
 // same bits as the class launches and the oracle.  The weights are read from the eight per-class prepared tensors the entry
 // point already takes: kernel tap k of class c sits at tap t(k) of cls_wp[c].
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kTT = 4;                                   // input rows per tile = waves per workgroup
-constexpr int kTRows = kFC * 2 * (kTT + 1);              // tile rows per stage: 4 channels x 2 planes x 5 rows
-constexpr int kTXF4 = kTRows * 10;                       // 400 float4
-constexpr int kTXInstr = (kTXF4 + 63) / 64;              // 7 wave-instructions (the last one partly pad)
-constexpr int kTSX = kTXInstr * 256;                     // floats reserved for the input tile
-constexpr int kTWInstr = (kWF4 + 63) / 64;               // 14
-constexpr int kTStage = kTSX + kTWInstr * 256;           // 5376 floats = 21 KiB per stage
-constexpr int kTXPer = (kTXInstr + kTT - 1) / kTT, kTWPer = (kTWInstr + kTT - 1) / kTT;
+template <int TT>                                         // TT = input rows per tile = waves per workgroup
+struct TGeo {
+  static constexpr int kRows = kFC * 2 * (TT + 1);       // tile rows per stage: 4 channels x 2 planes x (TT + 1) rows
+  static constexpr int kXF4 = kRows * 10;                // 400 float4 (TT = 4)
+  static constexpr int kXInstr = (kXF4 + 63) / 64;       // 7 wave-instructions (the last one partly pad)
+  static constexpr int kSX = kXInstr * 256;              // floats reserved for the input tile
+  static constexpr int kWInstr = (kWF4 + 63) / 64;       // 14
+  static constexpr int kStage = kSX + kWInstr * 256;     // 5376 floats = 21 KiB per stage (TT = 4)
+  static constexpr int kXPer = (kXInstr + TT - 1) / TT, kWPer = (kWInstr + TT - 1) / TT;
+};
 
 __device__ __forceinline__ constexpr int tp_off(int a) { return a == 2 ? 1 : 0; }     // input offset of per-axis choice a
 __device__ __forceinline__ constexpr int tp_par(int a) { return a == 0 ? 0 : 1; }     // output parity
 __device__ __forceinline__ constexpr int tp_tap(int a) { return a == 2 ? 2 : 1; }     // tap of the CLASS convolution (offset + 1)
 
-__global__ __launch_bounds__(64 * kTT, 2) void convt3d_k3_s2_mfma(const float* __restrict__ x, float* __restrict__ y, int Cin, int Cout,
+template <int kTT>
+__global__ __launch_bounds__(64 * kTT, kTT == 4 ? 2 : 1) void convt3d_k3_s2_mfma(const float* __restrict__ x, float* __restrict__ y, int Cin, int Cout,
                                                                   int cout_pad, int D, int H, int W, int tiles_w, int tiles_h, int cblocks,
                                                                   Epi epi) {
+  using TG = TGeo<kTT>;
+  constexpr int kTXPer = TG::kXPer, kTWPer = TG::kWPer, kTXF4 = TG::kXF4, kTXInstr = TG::kXInstr, kTWInstr = TG::kWInstr, kTSX = TG::kSX,
+                kTStage = TG::kStage;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l32 = lane & 31;
@@ -1171,14 +1177,15 @@ int adv_conv_transpose3d_k3_s2_f32(const float* x, const float* const* w_prep_cl
   bool aligned_w = (reinterpret_cast<uintptr_t>(x) & 3) == 0;
   for (int k = 0; k < 8; ++k) aligned_w = aligned_w && (reinterpret_cast<uintptr_t>(w_prep_classes[k]) & 15) == 0;
   if (fits && aligned_w && getenv("ADV_CONV_GENERIC") == nullptr && getenv("ADV_CONV_CLASS_LAUNCHES") == nullptr) {
-    const int tiles_w = (w + kTW - 1) / kTW, tiles_h = (h + kTT - 1) / kTT;
+    constexpr int tt = 4;   // rows (= waves) per tile; 8 rows / 512 threads / one workgroup per CU measured the same (0.200-0.204 against 0.205-0.207 ms)
+    const int tiles_w = (w + kTW - 1) / kTW, tiles_h = (h + tt - 1) / tt;
     const long long ntiles = static_cast<long long>(tiles_w) * tiles_h * d * b * cblocks;
     const bool all_classes = w % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 7) == 0 &&
                              (reinterpret_cast<uintptr_t>(residual) & 7) == 0 && ntiles < (1LL << 31) && getenv("ADV_CONV_T_CLASS_TILES") == nullptr;
     if (all_classes) {   // every class from one staging of the input tile (convt3d_k3_s2_mfma)
       for (int k = 0; k < 8; ++k) epi.cls_wp[k] = w_prep_classes[k];
-      const size_t lds = 2 * sizeof(float) * static_cast<size_t>(kTStage);
-      hipLaunchKernelGGL(convt3d_k3_s2_mfma, dim3(static_cast<unsigned>(ntiles)), dim3(64 * kTT), lds, st, x, y, cin, cout, cblocks * 32, d, h, w,
+      const size_t lds = 2 * sizeof(float) * static_cast<size_t>(TGeo<tt>::kStage);
+      hipLaunchKernelGGL(convt3d_k3_s2_mfma<tt>, dim3(static_cast<unsigned>(ntiles)), dim3(64 * tt), lds, st, x, y, cin, cout, cblocks * 32, d, h, w,
                          tiles_w, tiles_h, cblocks, epi);
       return adv_internal_finish_launch();
     }
