@@ -733,27 +733,53 @@ __global__ __launch_bounds__(64 * kTT, kTT == 4 ? 2 : 1) void convt3d_k3_s2_mfma
   const int co0 = cob * 32 + 4 * half;
   const long long ovol = static_cast<long long>(epi.od) * epi.oh * epi.ow;
   typedef float v2f __attribute__((ext_vector_type(2)));
+  if (epi.bias == nullptr && epi.residual == nullptr) {      // the adjoint of a strided convolution: nothing to fetch
+#pragma unroll
+    for (int pd = 0; pd < 2; ++pd)
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph) {
+        float* yr = y + (static_cast<long long>(b) * Cout + co0) * ovol + (static_cast<long long>(2 * d0 + pd) * epi.oh + 2 * gh + ph) * epi.ow + 2 * gw;
+        const int c0i = (pd * 2 + ph) * 2;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int cr = 8 * (v >> 2) + (v & 3);
+          if (co0 + cr >= Cout) continue;
+          v2f r = {acc[c0i][v], acc[c0i + 1][v]};
+          if (epi.relu) r.x = r.x > 0.0f ? r.x : 0.0f, r.y = r.y > 0.0f ? r.y : 0.0f;
+          *reinterpret_cast<v2f*>(yr + cr * ovol) = r;
+        }
+      }
+    return;
+  }
+  float bz[16];      // the lane's 16 bias values, fetched once (a load inside the store loop would be a round trip per store)
+#pragma unroll
+  for (int v = 0; v < 16; ++v) {
+    const int co = co0 + 8 * (v >> 2) + (v & 3);
+    bz[v] = (epi.bias != nullptr && co < Cout) ? epi.bias[co] : 0.0f;
+  }
+  const bool has_bias = epi.bias != nullptr, has_res = epi.residual != nullptr;
 #pragma unroll
   for (int pd = 0; pd < 2; ++pd)
 #pragma unroll
     for (int ph = 0; ph < 2; ++ph) {
       const long long at = (static_cast<long long>(b) * Cout + co0) * ovol + (static_cast<long long>(2 * d0 + pd) * epi.oh + 2 * gh + ph) * epi.ow + 2 * gw;
       const int c0i = (pd * 2 + ph) * 2;
+      v2f sk[16];    // the skip connection's values of this output row, all in flight before the first store
+      if (has_res) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int cr = 8 * (v >> 2) + (v & 3);
+          sk[v] = co0 + cr < Cout ? __builtin_nontemporal_load(reinterpret_cast<const v2f*>(epi.residual + at + cr * ovol)) : (v2f){0.0f, 0.0f};
+        }
+      }
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
         const int cr = 8 * (v >> 2) + (v & 3);
-        if (co0 + cr >= Cout) continue;
         v2f r = {acc[c0i][v], acc[c0i + 1][v]};
-        if (epi.bias) {
-          const float bz = epi.bias[co0 + cr];
-          r.x = r.x + bz, r.y = r.y + bz;
-        }
-        if (epi.residual) {
-          const v2f sk = *reinterpret_cast<const v2f*>(epi.residual + at + cr * ovol);
-          r.x = r.x + sk.x, r.y = r.y + sk.y;
-        }
+        if (has_bias) r.x = r.x + bz[v], r.y = r.y + bz[v];
+        if (has_res) r.x = r.x + sk[v].x, r.y = r.y + sk[v].y;
         if (epi.relu) r.x = r.x > 0.0f ? r.x : 0.0f, r.y = r.y > 0.0f ? r.y : 0.0f;
-        *reinterpret_cast<v2f*>(y + at + cr * ovol) = r;
+        if (co0 + cr < Cout) *reinterpret_cast<v2f*>(y + at + cr * ovol) = r;
       }
     }
 }

@@ -135,6 +135,11 @@ def conv(dev):
     print(json.dumps(dict(kernel="conv_transpose3d_k3 stride 2 (8 masked classes), 64->32 on [1,64,%d,%d,%d]" % (D // 2, H // 2, W // 2), ms=round(ms, 3),
                           TFLOPs=round(flops / ms / 1e9, 1), frac_of_157TF=round(flops / ms / 1e9 / 157.3, 3), torch_miopen_ms=round(ms_t, 3),
                           speedup_vs_miopen=round(ms_t / ms, 2))))
+    bias, skip = torch.randn((32,), device=dev), torch.randn((1, 32, D, H, W), device=dev)      # the hourglass's up layer: relu(up(x) + bias + skip)
+    ms = timeit(lambda: ops.conv_transpose3d_k3_s2(xs, classes, 32, relu=True, bias=bias, residual=skip), reps=10)
+    ms_t = timeit(lambda: F.relu(F.conv_transpose3d(xs, wu, bias, stride=2, padding=1, output_padding=1) + skip), reps=10)
+    print(json.dumps(dict(kernel="conv_transpose3d_k3 stride 2 + bias + skip connection + ReLU in the epilogue, 64->32 on [1,64,%d,%d,%d]" % (D // 2, H // 2, W // 2),
+                          ms=round(ms, 3), TFLOPs=round(flops / ms / 1e9, 1), torch_miopen_plus_add_relu_ms=round(ms_t, 3), speedup=round(ms_t / ms, 2))))
 
 
 def conv_narrow(dev):
