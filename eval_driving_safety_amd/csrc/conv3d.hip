@@ -785,6 +785,130 @@ __global__ __launch_bounds__(64 * kTT, kTT == 4 ? 2 : 1) void convt3d_k3_s2_mfma
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Strided convolution (kernel 3, stride 2, padding 1) DIRECTLY on the input, for layers with more than 32 output channels.
+// The space-to-depth route above runs 8 x Cin/4 short stages per tile (1-8 taps each) and every stage waits for its own round
+// trip; here a stage is TWO input channels of the raw input tile - 3 planes x 9 rows x 72 columns for a 1 x 4 x 32 tile of
+// outputs - and all 27 taps run on it for BOTH blocks of 32 output channels (54 MFMAs per wave and stage, as in the transposed
+// kernel), the operand of output voxel w being read at LDS column 2w + kw: a stride-2 ds_read (2-way bank conflict, the LDS
+// has the time).  No permuted copy of the input, no workspace.  Stages of two channels change the ACCUMULATION ORDER to
+// (channel pair, tap, channel) - the oracle takes the stage size as a parameter; results differ from the 4-channel order in
+// the last bits only (ops.conv3d_k3_s2_stage_channels tells which one a call uses).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kSC = 2;                                    // input channels per stage
+constexpr int kSRow = 72;                                 // LDS row = global columns [2*w0 - 4, 2*w0 + 68)
+constexpr int kSTH = 4;                                   // output rows per tile = waves
+constexpr int kSRows = kSC * 3 * (2 * kSTH + 1);          // 54 tile rows per stage
+constexpr int kSXF4 = kSRows * (kSRow / 4);               // 972 float4
+constexpr int kSXInstr = (kSXF4 + 63) / 64;               // 16 wave-instructions
+constexpr int kSSX = kSXInstr * 256;
+constexpr int kSWF4 = 27 * kSC * 16;                      // weights of a stage: 27 taps x 2 channels x 64 output channels = 864 float4
+constexpr int kSWInstr = (kSWF4 + 63) / 64;               // 14
+constexpr int kSStage = kSSX + kSWInstr * 256;            // 7680 floats = 30 KiB; two stages resident
+constexpr int kSXPer = (kSXInstr + 3) / 4, kSWPer = (kSWInstr + 3) / 4;
+
+__global__ __launch_bounds__(256, 2) void conv3d_k3_s2_mfma(const float* __restrict__ x, const float* __restrict__ wp, float* __restrict__ y,
+                                                            int Cin, int Cout, int cout_pad, int D, int H, int W, int gD, int gH, int gW,
+                                                            int tiles_w, int tiles_h, int cpairs, Epi epi) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l32 = lane & 31;
+  const int plane = H * W, vol = plane * D;
+  int t = blockIdx.x;
+  const int w0 = (t % tiles_w) * kTW;
+  t /= tiles_w;
+  const int h0 = (t % tiles_h) * kSTH;
+  t /= tiles_h;
+  const int d0 = t % gD;
+  t /= gD;
+  const int b = t / cpairs, cp = t - b * cpairs;
+  const float* xb = x + static_cast<long long>(b) * Cin * vol;
+
+  int xo[kSXPer], wo[kSWPer];
+#pragma unroll
+  for (int p = 0; p < kSXPer; ++p) {
+    const int q = 64 * (wave + 4 * p) + lane;
+    const int row = q / 18, j = q - row * 18;
+    const int c = row / 27, rem = row - c * 27;
+    const int kd = rem / 9, r9 = rem - kd * 9;
+    const int gd = 2 * d0 + kd - 1, gh = 2 * h0 + r9 - 1, gw = 2 * w0 - 4 + 4 * j;
+    const bool ok = q < kSXF4 && j < 17 && gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw + 3 < W;   // columns 68..71 are never read
+    xo[p] = ok ? c * vol + gd * plane + gh * W + gw : -1;
+  }
+#pragma unroll
+  for (int p = 0; p < kSWPer; ++p) {
+    const int f = 64 * (wave + 4 * p) + lane;
+    const int n4 = f & 15, c = (f >> 4) & 1, tap = f >> 5;
+    const int co = cp * 64 + 4 * n4;
+    wo[p] = (f < kSWF4 && co < cout_pad) ? (tap * Cin + c) * cout_pad + co : -1;
+  }
+  auto issue = [&](int c0, float* stage) {
+#pragma unroll
+    for (int p = 0; p < kSXPer; ++p) {
+      const int k = wave + 4 * p;
+      if (k < kSXInstr) glds16(xo[p] >= 0 ? xb + static_cast<long long>(c0) * vol + xo[p] : g_zero16, stage + k * 256);
+    }
+#pragma unroll
+    for (int p = 0; p < kSWPer; ++p) {
+      const int k = wave + 4 * p;
+      if (k < kSWInstr) glds16(wo[p] >= 0 ? wp + static_cast<long long>(c0) * cout_pad + wo[p] : g_zero16, stage + kSSX + k * 256);
+    }
+  };
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[i][v] = 0.0f;
+  issue(0, lds);
+  __syncthreads();
+  int cur = 0;
+  for (int c0 = 0; c0 < Cin; c0 += kSC) {
+    const int cn = c0 + kSC < Cin ? c0 + kSC : c0;
+    issue(cn, lds + (cur ^ 1) * kSStage);
+    __builtin_amdgcn_sched_barrier(0);
+    const float* sxc = lds + cur * kSStage;
+    const float* swc = sxc + kSSX;
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) {
+      const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+      const float bv = sxc[((half * 3 + kd) * (2 * kSTH + 1) + 2 * wave + kh) * kSRow + 3 + 2 * l32 + kw];
+      const float a0 = swc[(tap * kSC + half) * 64 + l32], a1 = swc[(tap * kSC + half) * 64 + 32 + l32];
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[1], 0, 0, 0);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  const int gh = h0 + wave, gw = w0 + l32;
+  if (gh >= gH || gw >= gW) return;
+  const long long ovol = static_cast<long long>(gD) * gH * gW;
+  const bool has_bias = epi.bias != nullptr, has_res = epi.residual != nullptr;
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    const int co0 = cp * 64 + cb * 32 + 4 * half;
+    if (cp * 64 + cb * 32 >= Cout) break;
+    const long long at = (static_cast<long long>(b) * Cout + co0) * ovol + (static_cast<long long>(d0) * gH + gh) * gW + gw;
+    float bz[16], sk[16];
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int cr = 8 * (v >> 2) + (v & 3);
+      bz[v] = (has_bias && co0 + cr < Cout) ? epi.bias[co0 + cr] : 0.0f;
+      sk[v] = (has_res && co0 + cr < Cout) ? __builtin_nontemporal_load(epi.residual + at + cr * ovol) : 0.0f;
+    }
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int cr = 8 * (v >> 2) + (v & 3);
+      float r = acc[cb][v];
+      if (has_bias) r = r + bz[v];
+      if (has_res) r = r + sk[v];
+      if (epi.relu) r = r > 0.0f ? r : 0.0f;
+      if (co0 + cr < Cout) y[at + cr * ovol] = r;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Narrow layers on the vector ALUs.  The matrix kernel pads the output channels to 32 rows, so the LAST layer of a
 // cost-volume network (32 -> 1: per-plane scores) would spend 31/32 of its MFMA work on zeros, and its adjoint (1 -> 32,
 // Cin = 1) has K = 27: both are cheaper as plain fmaf chains.  Same accumulation order as the matrix kernel and the oracle
@@ -1039,6 +1163,14 @@ static int cu_count() {  // compute units of the current device (256 on MI355X);
   return cached;
 }
 
+// the direct strided kernel (two-channel stages): more than 32 output channels, rows of whole 16-byte groups, the convolution's own
+// output grid, every tap.  adv_conv3d_k3_s2_stage_channels reports the choice (it fixes the accumulation order).
+static bool conv3d_k3_s2_direct(int cout, int w, const float* x, const Epi& epi) {
+  return cout > 32 && w % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && epi.tap_mask == kAllTaps && epi.class_channels == 0 &&
+         epi.nclass == 0 && epi.sd == 1 && epi.sh == 1 && epi.sw == 1 && epi.fd == 0 && epi.fh == 0 && epi.fw == 0 &&
+         getenv("ADV_CONV_GENERIC") == nullptr && getenv("ADV_CONV_S2_GENERIC") == nullptr;
+}
+
 static int launch_conv(const float* x, const float* w_prep, float* y, int b, int cin, int cout, int d, int h, int w, int stride,
                        const Epi& epi, hipStream_t st) {
   // (d, h, w) = input dims; the tile grid runs over the convolution's own output grid gd x gh x gw
@@ -1074,6 +1206,16 @@ static int launch_conv(const float* x, const float* w_prep, float* y, int b, int
     else
       hipLaunchKernelGGL((conv3d_k3_narrow_out<8>), grid, dim3(256), lds, st, x, w_prep, y, cin, cout, cblocks * 32, d, h, w, tiles_w, epi);
     return adv_internal_finish_launch();
+  }
+  if (stride == 2 && conv3d_k3_s2_direct(cout, w, x, epi) && fits && (reinterpret_cast<uintptr_t>(w_prep) & 15) == 0 && epi.od == gd &&
+      epi.oh == gh && epi.ow == gw) {
+    const int tw = (gw + kTW - 1) / kTW, th = (gh + kSTH - 1) / kSTH, cpairs = (cblocks + 1) / 2;
+    const long long ntiles = static_cast<long long>(tw) * th * gd * b * cpairs;
+    if (ntiles < (1LL << 31)) {
+      hipLaunchKernelGGL(conv3d_k3_s2_mfma, dim3(static_cast<unsigned>(ntiles)), dim3(256), 2 * sizeof(float) * static_cast<size_t>(kSStage), st, x,
+                         w_prep, y, cin, cout, cblocks * 32, d, h, w, gd, gh, gw, tw, th, cpairs, epi);
+      return adv_internal_finish_launch();
+    }
   }
   // the main kernel takes every width (rows that are not 16-byte aligned are loaded as dword-aligned float4);
   // ADV_CONV_GENERIC=1 forces the scalar-staging kernel (kept as the reference implementation of the tiling)
@@ -1148,6 +1290,11 @@ int adv_conv3d_k3_f32(const float* x, const float* w_prep, float* y, int b, int 
   if (cin % kCK != 0 && cin > kCK) return ADV_EINVAL;
   const Epi epi{nullptr, relu, kAllTaps, {0, 0, 0, 0, 0, 0, 0, 0}, 0, d, h, w, 1, 1, 1, 0, 0, 0};
   return launch_conv(x, w_prep, y, b, cin, cout, d, h, w, 1, epi, static_cast<hipStream_t>(stream));
+}
+
+int adv_conv3d_k3_s2_stage_channels(const float* x, int cout, int w) {
+  Epi plain{nullptr, 0, kAllTaps, {0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0, 0, 1, 1, 1, 0, 0, 0};
+  return conv3d_k3_s2_direct(cout, w, x, plain) && w >= 4 ? kSC : kCK;
 }
 
 int adv_space_to_depth2_f32(const float* x, float* xs, int b, int c, int d, int h, int w, adv_stream_t stream) {

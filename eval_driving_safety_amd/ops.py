@@ -674,7 +674,8 @@ def space_to_depth2(x, out=None):
 
 
 def conv3d_k3_s2_prep(weight):
-    """[Cout,Cin,3,3,3] -> (w_prep over the 8*Cin space-to-depth channels, the eight class tap masks).
+    """[Cout,Cin,3,3,3] -> (w_prep over the 8*Cin space-to-depth channels, the eight class tap masks, the plain w_prep for the
+    direct route).
     out[o] = W0 x[2o-1] + W1 x[2o] + W2 x[2o+1] per axis = W1 e[o] + W0 odd[o-1] + W2 odd[o] with e[j] = x[2j], odd[j] = x[2j+1]:
     the even sub-volume uses tap index 1 (offset 0) with kernel element 1; the odd one tap 0 (offset -1) with element 0 and
     tap 1 with element 2."""
@@ -693,17 +694,35 @@ def conv3d_k3_s2_prep(weight):
                     w8[:, p * cin:(p + 1) * cin, td, th, tw] = wt[:, :, kd, kh, kw]
                     mask |= 1 << (td * 9 + th * 3 + tw)
         masks.append(mask)
-    return conv3d_k3_prep(w8), tuple(masks)
+    return conv3d_k3_prep(w8), tuple(masks), conv3d_k3_prep(wt)
 
 
-def conv3d_k3_s2(x, prep, cout, relu=False, bias=None):
+def conv3d_k3_s2_stage_channels(x, cout):
+    """2 or 4: the input channels per stage (= the float32 accumulation order) ``conv3d_k3_s2(x, conv3d_k3_prep(w), cout)`` will use -
+    2 is the direct strided matrix kernel (cout > 32, W % 4 == 0), 4 the scalar-staging kernel; the oracle takes it as ``chunk``"""
+    xi = _feat(x, "x")
+    return int(_lib.load().adv_conv3d_k3_s2_stage_channels(_ptr(xi), int(cout), int(xi.shape[4])))
+
+
+def conv3d_k3_s2(x, prep, cout, relu=False, bias=None, route="auto"):
     """the strided 3x3x3 convolution of an hourglass: stride 2, padding 1 -> [B,cout,ceil(D/2),ceil(H/2),ceil(W/2)].
-    ``prep`` = ``conv3d_k3_s2_prep(weight)``: space-to-depth + the tuned stride-1 MFMA kernel with per-class tap masks (no
-    wasted matrix work).  A plain ``conv3d_k3_prep(weight)`` tensor is accepted too and takes the direct strided kernel
-    (no workspace, slower)."""
+    ``prep`` = ``conv3d_k3_s2_prep(weight)`` holds the weights for both routes:
+      "direct"  the strided matrix kernel on the raw input (more than 32 output channels, W % 4 == 0: two-channel stages, no
+                permuted copy - the fastest route; otherwise the scalar-staging kernel, slow);
+      "s2d"     space-to-depth + the stride-1 MFMA kernel with per-class tap masks (any shape; no wasted matrix work);
+      "auto"    direct where the matrix kernel takes it, else s2d.
+    The routes accumulate in different orders (last-bit differences; each is bit-exact against the oracle run its way).
+    A plain ``conv3d_k3_prep(weight)`` tensor is accepted too (direct only)."""
     if isinstance(prep, torch.Tensor):
         return _conv3d_ex(x, prep, cout, 2, relu, bias)
-    w_prep8, masks = prep
+    w_prep8, masks = prep[0], prep[1]
+    plain = prep[2] if len(prep) > 2 else None
+    if route not in ("auto", "direct", "s2d"):
+        raise ValueError("route must be auto, direct or s2d")
+    if plain is not None and (route == "direct" or (route == "auto" and conv3d_k3_s2_stage_channels(x, cout) == 2)):
+        return _conv3d_ex(x, plain, cout, 2, relu, bias)
+    if route == "direct":
+        raise ValueError("this prep holds no weights for the direct route")
     return _conv3d_ex(space_to_depth2(x), w_prep8, cout, 1, relu, bias, class_masks=masks)
 
 

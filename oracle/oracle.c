@@ -297,7 +297,7 @@ void orc_dense_align_cost(const float* left, const float* right, int h, int w, i
  * class_masks[c / class_channels] (the parity sub-volumes of a space-to-depth input).  Upstream detector op: unpinned. */
 void orc_conv3d_k3_ex(const float* x, const float* w, const float* bias, float* y, int B, int cin, int cout, int D, int H, int W,
                       int stride, int relu, unsigned tap_mask, const int* odims, const int* ostride, const int* ooff,
-                      const unsigned* class_masks, int class_channels) {
+                      const unsigned* class_masks, int class_channels, int chunk) {
   const int gD = stride == 2 ? (D + 1) / 2 : D, gH = stride == 2 ? (H + 1) / 2 : H, gW = stride == 2 ? (W + 1) / 2 : W;
   const long plane = (long)H * W, vol = plane * D;
   const long oplane = (long)odims[1] * odims[2], ovol = oplane * odims[0];
@@ -310,14 +310,14 @@ void orc_conv3d_k3_ex(const float* x, const float* w, const float* bias, float* 
             const int zd = d * ostride[0] + ooff[0], zh = h * ostride[1] + ooff[1], zw = ww * ostride[2] + ooff[2];
             if (zd >= odims[0] || zh >= odims[1] || zw >= odims[2]) continue;
             float acc = 0.0f;
-            for (int c0 = 0; c0 < cin; c0 += 4)
+            for (int c0 = 0; c0 < cin; c0 += chunk)     /* chunk = input channels per LDS stage of the kernel (4; 2 in the direct strided kernel) */
               for (int tap = 0; tap < 27; ++tap) {
                 const unsigned mask = class_channels > 0 ? class_masks[c0 / class_channels] : tap_mask;
                 if (!((mask >> tap) & 1u)) continue;
                 const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
                 const int gd = stride * d + kd - 1, gh = stride * h + kh - 1, gw = stride * ww + kw - 1;
                 const int in = gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W;
-                for (int c = c0; c < c0 + 4 && c < cin; ++c) {
+                for (int c = c0; c < c0 + chunk && c < cin; ++c) {
                   const float xv = in ? x[((long)b * cin + c) * vol + gd * plane + (long)gh * W + gw] : 0.0f;
                   acc = fmaf(w[((long)co * cin + c) * 27 + tap], xv, acc);
                 }

@@ -31,7 +31,7 @@ _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 _lib.orc_dense_align_cost.argtypes = [_fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _i32p, _fp, ctypes.c_int, _fp, ctypes.c_float,
                                       ctypes.c_float, ctypes.c_int, _fp]
 _lib.orc_dense_align_cost.restype = None
-_lib.orc_conv3d_k3_ex.argtypes = [_fp, _fp, ctypes.c_void_p, _fp] + [ctypes.c_int] * 8 + [ctypes.c_uint, _i32p, _i32p, _i32p, ctypes.c_void_p, ctypes.c_int]
+_lib.orc_conv3d_k3_ex.argtypes = [_fp, _fp, ctypes.c_void_p, _fp] + [ctypes.c_int] * 8 + [ctypes.c_uint, _i32p, _i32p, _i32p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
 _lib.orc_conv3d_k3_ex.restype = None
 for _f in ("orc_denormalize", "orc_normalize", "orc_pgd_step_norm01", "orc_pgd_step_meansub255", "orc_tensor2im_u8",
            "orc_patch_paste", "orc_patch_update"):
@@ -168,8 +168,10 @@ def dense_align_argmin(cost, z_center, step):
 
 
 def conv3d_k3_ex(x, w, bias=None, stride=1, relu=False, tap_mask=(1 << 27) - 1, out=None, out_stride=(1, 1, 1), out_offset=(0, 0, 0),
-                 class_masks=None):
-    """csrc/conv3d.hip's extended entry point: x [B,Cin,D,H,W], w [Cout,Cin,3,3,3] (ordinary conv layout)"""
+                 class_masks=None, chunk=4):
+    """csrc/conv3d.hip's extended entry point: x [B,Cin,D,H,W], w [Cout,Cin,3,3,3] (ordinary conv layout); ``chunk`` = input
+    channels per stage of the kernel being checked (the accumulation order is stage, tap, channel: 4 everywhere except the direct
+    strided matrix kernel, which stages 2 - ops.conv3d_k3_s2_stage_channels)"""
     x = np.ascontiguousarray(x, dtype=np.float32)
     w = np.ascontiguousarray(w, dtype=np.float32)
     cout, cin = w.shape[:2]
@@ -182,7 +184,7 @@ def conv3d_k3_ex(x, w, bias=None, stride=1, relu=False, tap_mask=(1 << 27) - 1, 
     cm = None if class_masks is None else np.array(class_masks, np.uint32)
     _lib.orc_conv3d_k3_ex(x, w, bp, out, b, cin, cout, d, h, ww, int(stride), int(relu), int(tap_mask),
                           np.array(out.shape[2:], np.int32), np.array(out_stride, np.int32), np.array(out_offset, np.int32),
-                          None if cm is None else cm.ctypes.data_as(ctypes.c_void_p), 0 if cm is None else cin // 8)
+                          None if cm is None else cm.ctypes.data_as(ctypes.c_void_p), 0 if cm is None else cin // 8, int(chunk))
     return out
 
 

@@ -140,7 +140,7 @@ def test_hip_alternative_code_paths_give_the_same_bits(switch, monkeypatch):
             bias = torch.linspace(-0.1, 0.2, 40, device=dev)
             out.append(ops.conv3d_k3(x, ops.conv3d_k3_prep(wt), 40, relu=True, bias=bias))
             out.append(ops._conv3d_ex(x, ops.conv3d_k3_prep(wt), 40, 1, False, None, 0b000111000101010000111000101))
-            out.append(ops.conv3d_k3_s2(x, ops.conv3d_k3_s2_prep(wt), 40, relu=True, bias=bias))
+            out.append(ops.conv3d_k3_s2(x, ops.conv3d_k3_s2_prep(wt), 40, relu=True, bias=bias, route="s2d"))
             wtt = torch.randn((8, 24, 3, 3, 3), device=dev, generator=g) * 0.1
             out.append(ops.conv_transpose3d_k3_s2(x, ops.conv_transpose3d_k3_s2_prep(wtt), 24, bias=bias[:24]))
         results.append(out)
@@ -245,15 +245,17 @@ def test_hip_hourglass_layers_bit_exact_vs_oracle(shape):
     assert got.cpu().numpy().tobytes() == C.conv3d_k3_ex(x, wt, bias=bias, relu=True).tobytes(), "bias + relu"
     # stride 2: the direct strided kernel, and space-to-depth + the stride-1 kernel with per-class tap masks
     got = ops.conv3d_k3_s2(tx, wp, cout, bias=tb)
-    want = C.conv3d_k3_ex(x, wt, bias=bias, stride=2)
+    want = C.conv3d_k3_ex(x, wt, bias=bias, stride=2, chunk=ops.conv3d_k3_s2_stage_channels(tx, cout))
     assert got.cpu().numpy().tobytes() == want.tobytes(), "stride 2 (direct)"
     ref = F.conv3d(tx, tw, tb, stride=2, padding=1)
     assert float((got - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
     assert ops.space_to_depth2(tx).cpu().numpy().tobytes() == C.space_to_depth2(x).tobytes(), "space to depth"
     s2 = ops.conv3d_k3_s2_prep(tw)
     assert sorted(bin(m).count("1") for m in s2[1]) == [1, 2, 2, 2, 4, 4, 4, 8]
-    got = ops.conv3d_k3_s2(tx, s2, cout, bias=tb, relu=True)
+    got = ops.conv3d_k3_s2(tx, s2, cout, bias=tb, relu=True, route="s2d")
     assert got.cpu().numpy().tobytes() == C.conv3d_k3_s2(x, wt, bias=bias, relu=True).tobytes(), "stride 2 (space-to-depth)"
+    auto = ops.conv3d_k3_s2(tx, s2, cout, bias=tb, relu=True)           # direct where the strided matrix kernel takes the shape
+    assert torch.equal(auto, ops.conv3d_k3_s2(tx, wp, cout, bias=tb, relu=True) if ops.conv3d_k3_s2_stage_channels(tx, cout) == 2 else got)
     assert float((got - F.relu(ref)).abs().max()) <= 1e-4 * float(ref.abs().max())
     # transposed convolution: eight masked-tap launches of the stride-1 kernel
     w_t = (rs.randn(cin, cout, 3, 3, 3) * 0.1).astype(np.float32)
@@ -388,3 +390,37 @@ def test_hip_conv3d_batch_beyond_2_31_elements_equals_per_item_launches():
     up = ops.conv_transpose3d_k3_s2(xs, classes, cout, bias=bias)
     for i in (0, b - 1):
         assert torch.equal(up[i:i + 1], ops.conv_transpose3d_k3_s2(xs[i:i + 1], classes, cout, bias=bias)), i
+
+
+S2_DIRECT = [(1, 8, 33, 3, 9, 40), (2, 12, 64, 5, 7, 36), (1, 32, 64, 6, 16, 44), (1, 4, 96, 4, 10, 132), (1, 12, 40, 1, 1, 4), (1, 16, 72, 7, 33, 64)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", S2_DIRECT)
+def test_hip_direct_strided_kernel_bit_exact_vs_oracle(shape, monkeypatch):
+    """the direct strided matrix kernel (more than 32 output channels, W % 4 == 0; stages of TWO input channels, operands read from
+    LDS at stride 2) against the oracle run with the same stage size - odd and even dims, 2 and 3 blocks of output channels, an odd
+    channel-pair count, bias / skip connection / ReLU - and within 1e-4 of torch; ADV_CONV_S2_GENERIC=1 sends the same call to the
+    scalar-staging kernel, whose stage is 4 channels"""
+    from eval_driving_safety_amd import ops
+    b, cin, cout, d, h, w = shape
+    x, wt = _case(*shape, seed=sum(shape) + 3)
+    rs = np.random.RandomState(23)
+    bias = rs.randn(cout).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    tx, tw, tb = torch.tensor(x, device=dev), torch.tensor(wt, device=dev), torch.tensor(bias, device=dev)
+    wp = ops.conv3d_k3_prep(tw)
+    assert ops.conv3d_k3_s2_stage_channels(tx, cout) == 2
+    assert ops.conv3d_k3_s2_stage_channels(tx, 32) == 4 and ops.conv3d_k3_s2_stage_channels(tx[..., :w - 1].contiguous(), cout) == 4
+    got = ops.conv3d_k3_s2(tx, wp, cout, bias=tb, relu=True)
+    assert got.cpu().numpy().tobytes() == C.conv3d_k3_ex(x, wt, bias=bias, stride=2, relu=True, chunk=2).tobytes(), "direct strided, bias + relu"
+    ref = F.relu(F.conv3d(tx, tw, tb, stride=2, padding=1))
+    assert float((got - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
+    plain = ops.conv3d_k3_s2(tx, wp, cout)
+    assert plain.cpu().numpy().tobytes() == C.conv3d_k3_ex(x, wt, stride=2, chunk=2).tobytes(), "direct strided, plain"
+    skip = torch.tensor(rs.randn(*plain.shape).astype(np.float32), device=dev)
+    assert torch.equal(ops._conv3d_ex(tx, wp, cout, 2, True, tb, residual=skip), F.relu(ops.conv3d_k3_s2(tx, wp, cout, bias=tb) + skip))
+    monkeypatch.setenv("ADV_CONV_S2_GENERIC", "1")
+    assert ops.conv3d_k3_s2_stage_channels(tx, cout) == 4
+    slow = ops.conv3d_k3_s2(tx, wp, cout, bias=tb, relu=True)
+    assert slow.cpu().numpy().tobytes() == C.conv3d_k3_ex(x, wt, bias=bias, stride=2, relu=True, chunk=4).tobytes(), "scalar-staging strided kernel"

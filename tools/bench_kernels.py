@@ -116,10 +116,16 @@ def conv(dev):
     wd = torch.randn((64, 32, 3, 3, 3), device=dev) * 0.05
     wp = ops.conv3d_k3_s2_prep(wd)
     flops = 2.0 * 32 * 64 * 27 * (D // 2) * (H // 2) * (W // 2)
-    ms_direct = timeit(lambda: ops.conv3d_k3_s2(x, ops.conv3d_k3_prep(wd), 64), reps=5)
+    wplain = ops.conv3d_k3_prep(wd)
+    ms_direct = timeit(lambda: ops.conv3d_k3_s2(x, wplain, 64), reps=10)
+    os.environ["ADV_CONV_S2_GENERIC"] = "1"
+    ms_generic = timeit(lambda: ops.conv3d_k3_s2(x, wplain, 64), reps=3)
+    del os.environ["ADV_CONV_S2_GENERIC"]
     ms_s2d = timeit(lambda: ops.space_to_depth2(x), reps=10)
     print(json.dumps(dict(kernel="space_to_depth2 [1,32,%d,%d,%d]" % (D, H, W), ms=round(ms_s2d, 3), GBps=round(2 * x.numel() * 4 / ms_s2d / 1e6, 1),
-                          direct_strided_kernel_ms=round(ms_direct, 3))))
+                          scalar_staging_strided_kernel_ms=round(ms_generic, 3))))
+    print(json.dumps(dict(kernel="conv3d_k3 stride 2 DIRECT (two-channel stages, stride-2 LDS operand reads; conv3d_k3_s2_mfma), 32->64 on [1,32,%d,%d,%d]" % (D, H, W),
+                          ms=round(ms_direct, 3), TFLOPs=round(flops / ms_direct / 1e9, 1), frac_of_157TF=round(flops / ms_direct / 1e9 / 157.3, 3))))
     ms = timeit(lambda: ops.conv3d_k3_s2(x, wp, 64), reps=10)
     F.conv3d(x, wd, stride=2, padding=1)
     ms_t = timeit(lambda: F.conv3d(x, wd, stride=2, padding=1), reps=10)

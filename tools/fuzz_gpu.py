@@ -59,8 +59,11 @@ def conv_case(rs, dev, big=False):
         same(y, plus_skip(lambda r: C.conv3d_k3_ex(x, wt, bias=bias, relu=r, tap_mask=mask), sk),
              "conv %s" % ((b, cin, cout, d, h, w, relu, hex(mask), sw, skip),))
         if rs.rand() < 0.4:
-            ys = ops.conv3d_k3_s2(tx, ops.conv3d_k3_s2_prep(tw), cout, relu=relu, bias=tb)
+            ys = ops.conv3d_k3_s2(tx, ops.conv3d_k3_s2_prep(tw), cout, relu=relu, bias=tb, route="s2d")
             same(ys, C.conv3d_k3_s2(x, wt, bias=bias, relu=relu), "strided conv %s" % ((b, cin, cout, d, h, w, sw),))
+            yd = ops.conv3d_k3_s2(tx, ops.conv3d_k3_prep(tw), cout, relu=relu, bias=tb)       # direct: matrix kernel (2-channel stages) or scalar staging (4)
+            same(yd, C.conv3d_k3_ex(x, wt, bias=bias, stride=2, relu=relu, chunk=ops.conv3d_k3_s2_stage_channels(tx, cout)),
+                 "direct strided conv %s" % ((b, cin, cout, d, h, w, sw),))
         if rs.rand() < 0.4:
             wtt = (rs.randn(cin, cout, 3, 3, 3) * 0.1).astype(np.float32)
             sk2 = rs.randn(b, cout, 2 * d, 2 * h, 2 * w).astype(np.float32) if skip else None
