@@ -390,6 +390,13 @@ def test_hip_conv3d_batch_beyond_2_31_elements_equals_per_item_launches():
     up = ops.conv_transpose3d_k3_s2(xs, classes, cout, bias=bias)
     for i in (0, b - 1):
         assert torch.equal(up[i:i + 1], ops.conv_transpose3d_k3_s2(xs[i:i + 1], classes, cout, bias=bias)), i
+    del up, xs
+    wd = torch.randn((64, cin, 3, 3, 3), device=dev, generator=gen) * 0.05            # strided, direct matrix kernel: 64 -> 64
+    wpd = ops.conv3d_k3_prep(wd)
+    assert ops.conv3d_k3_s2_stage_channels(x, 64) == 2
+    down = ops.conv3d_k3_s2(x, wpd, 64, relu=True)
+    for i in (0, b - 1):
+        assert torch.equal(down[i:i + 1], ops.conv3d_k3_s2(x[i:i + 1], wpd, 64, relu=True)), i
 
 
 S2_DIRECT = [(1, 8, 33, 3, 9, 40), (2, 12, 64, 5, 7, 36), (1, 32, 64, 6, 16, 44), (1, 4, 96, 4, 10, 132), (1, 12, 40, 1, 1, 4), (1, 16, 72, 7, 33, 64)]
