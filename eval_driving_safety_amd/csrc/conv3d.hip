@@ -785,30 +785,41 @@ __global__ __launch_bounds__(64 * kTT, kTT == 4 ? 2 : 1) void convt3d_k3_s2_mfma
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Strided convolution (kernel 3, stride 2, padding 1) DIRECTLY on the input, for layers with more than 32 output channels.
+// Strided convolution (kernel 3, stride 2, padding 1) DIRECTLY on the input.
 // The space-to-depth route above runs 8 x Cin/4 short stages per tile (1-8 taps each) and every stage waits for its own round
 // trip; here a stage is TWO input channels of the raw input tile - 3 planes x 9 rows x 72 columns for a 1 x 4 x 32 tile of
-// outputs - and all 27 taps run on it for BOTH blocks of 32 output channels (54 MFMAs per wave and stage, as in the transposed
-// kernel), the operand of output voxel w being read at LDS column 2w + kw: a stride-2 ds_read (2-way bank conflict, the LDS
+// outputs - and all 27 taps run on it for BOTH blocks of 32 output channels (with 32 channels or fewer: for two output rows per
+// wave of a 1 x 8 x 32 tile): 54 MFMAs per wave and stage, as in the transposed kernel, the operand of output voxel w being read at
+// LDS column 2w + kw: a stride-2 ds_read (2-way bank conflict, the LDS
 // has the time).  No permuted copy of the input, no workspace.  Stages of two channels change the ACCUMULATION ORDER to
 // (channel pair, tap, channel) - the oracle takes the stage size as a parameter; results differ from the 4-channel order in
 // the last bits only (ops.conv3d_k3_s2_stage_channels tells which one a call uses).
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kSC = 2;                                    // input channels per stage
 constexpr int kSRow = 72;                                 // LDS row = global columns [2*w0 - 4, 2*w0 + 68)
-constexpr int kSTH = 4;                                   // output rows per tile = waves
-constexpr int kSRows = kSC * 3 * (2 * kSTH + 1);          // 54 tile rows per stage
-constexpr int kSXF4 = kSRows * (kSRow / 4);               // 972 float4
-constexpr int kSXInstr = (kSXF4 + 63) / 64;               // 16 wave-instructions
-constexpr int kSSX = kSXInstr * 256;
-constexpr int kSWF4 = 27 * kSC * 16;                      // weights of a stage: 27 taps x 2 channels x 64 output channels = 864 float4
-constexpr int kSWInstr = (kSWF4 + 63) / 64;               // 14
-constexpr int kSStage = kSSX + kSWInstr * 256;            // 7680 floats = 30 KiB; two stages resident
-constexpr int kSXPer = (kSXInstr + 3) / 4, kSWPer = (kSWInstr + 3) / 4;
+// CB = blocks of 32 output channels per workgroup: 2 (cout > 32: a wave owns one output row, both blocks) or 1 (a wave owns two output
+// rows of the one block) - either way two accumulators and 54 MFMAs per wave and stage
+template <int CB>
+struct SGeo {
+  static constexpr int kRW = 3 - CB;                      // output rows per wave
+  static constexpr int kTH = 4 * kRW;                     // output rows per tile (four waves)
+  static constexpr int kRowsIn = 2 * kTH + 1;             // input rows per plane of the tile
+  static constexpr int kRows = kSC * 3 * kRowsIn;
+  static constexpr int kXF4 = kRows * (kSRow / 4);        // 972 (CB = 2) / 1836 float4
+  static constexpr int kXInstr = (kXF4 + 63) / 64;
+  static constexpr int kSX = kXInstr * 256;
+  static constexpr int kWF4 = 27 * kSC * 8 * CB;          // weights of a stage: 27 taps x 2 channels x 32*CB output channels
+  static constexpr int kWInstr = (kWF4 + 63) / 64;
+  static constexpr int kStage = kSX + kWInstr * 256;      // 30 KiB (CB = 2) / 36 KiB per stage; two stages resident
+  static constexpr int kXPer = (kXInstr + 3) / 4, kWPer = (kWInstr + 3) / 4;
+};
 
+template <int CB>
 __global__ __launch_bounds__(256, 2) void conv3d_k3_s2_mfma(const float* __restrict__ x, const float* __restrict__ wp, float* __restrict__ y,
                                                             int Cin, int Cout, int cout_pad, int D, int H, int W, int gD, int gH, int gW,
-                                                            int tiles_w, int tiles_h, int cpairs, Epi epi) {
+                                                            int tiles_w, int tiles_h, int cgroups, Epi epi) {
+  using SG = SGeo<CB>;
+  constexpr int kRW = SG::kRW, kRowsIn = SG::kRowsIn, kCO = 32 * CB;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l32 = lane & 31;
@@ -816,41 +827,41 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_s2_mfma(const float* __restr
   int t = blockIdx.x;
   const int w0 = (t % tiles_w) * kTW;
   t /= tiles_w;
-  const int h0 = (t % tiles_h) * kSTH;
+  const int h0 = (t % tiles_h) * SG::kTH;
   t /= tiles_h;
   const int d0 = t % gD;
   t /= gD;
-  const int b = t / cpairs, cp = t - b * cpairs;
+  const int b = t / cgroups, cp = t - b * cgroups;
   const float* xb = x + static_cast<long long>(b) * Cin * vol;
 
-  int xo[kSXPer], wo[kSWPer];
+  int xo[SG::kXPer], wo[SG::kWPer];
 #pragma unroll
-  for (int p = 0; p < kSXPer; ++p) {
+  for (int p = 0; p < SG::kXPer; ++p) {
     const int q = 64 * (wave + 4 * p) + lane;
     const int row = q / 18, j = q - row * 18;
-    const int c = row / 27, rem = row - c * 27;
-    const int kd = rem / 9, r9 = rem - kd * 9;
+    const int c = row / (3 * kRowsIn), rem = row - c * 3 * kRowsIn;
+    const int kd = rem / kRowsIn, r9 = rem - kd * kRowsIn;
     const int gd = 2 * d0 + kd - 1, gh = 2 * h0 + r9 - 1, gw = 2 * w0 - 4 + 4 * j;
-    const bool ok = q < kSXF4 && j < 17 && gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw + 3 < W;   // columns 68..71 are never read
+    const bool ok = q < SG::kXF4 && j < 17 && gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw + 3 < W;   // columns 68..71 are never read
     xo[p] = ok ? c * vol + gd * plane + gh * W + gw : -1;
   }
 #pragma unroll
-  for (int p = 0; p < kSWPer; ++p) {
+  for (int p = 0; p < SG::kWPer; ++p) {
     const int f = 64 * (wave + 4 * p) + lane;
-    const int n4 = f & 15, c = (f >> 4) & 1, tap = f >> 5;
-    const int co = cp * 64 + 4 * n4;
-    wo[p] = (f < kSWF4 && co < cout_pad) ? (tap * Cin + c) * cout_pad + co : -1;
+    const int n4 = f % (8 * CB), c = (f / (8 * CB)) & 1, tap = f / (16 * CB);
+    const int co = cp * kCO + 4 * n4;
+    wo[p] = (f < SG::kWF4 && co < cout_pad) ? (tap * Cin + c) * cout_pad + co : -1;
   }
   auto issue = [&](int c0, float* stage) {
 #pragma unroll
-    for (int p = 0; p < kSXPer; ++p) {
+    for (int p = 0; p < SG::kXPer; ++p) {
       const int k = wave + 4 * p;
-      if (k < kSXInstr) glds16(xo[p] >= 0 ? xb + static_cast<long long>(c0) * vol + xo[p] : g_zero16, stage + k * 256);
+      if (k < SG::kXInstr) glds16(xo[p] >= 0 ? xb + static_cast<long long>(c0) * vol + xo[p] : g_zero16, stage + k * 256);
     }
 #pragma unroll
-    for (int p = 0; p < kSWPer; ++p) {
+    for (int p = 0; p < SG::kWPer; ++p) {
       const int k = wave + 4 * p;
-      if (k < kSWInstr) glds16(wo[p] >= 0 ? wp + static_cast<long long>(c0) * cout_pad + wo[p] : g_zero16, stage + kSSX + k * 256);
+      if (k < SG::kWInstr) glds16(wo[p] >= 0 ? wp + static_cast<long long>(c0) * cout_pad + wo[p] : g_zero16, stage + SG::kSX + k * 256);
     }
   };
 
@@ -864,30 +875,35 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_s2_mfma(const float* __restr
   int cur = 0;
   for (int c0 = 0; c0 < Cin; c0 += kSC) {
     const int cn = c0 + kSC < Cin ? c0 + kSC : c0;
-    issue(cn, lds + (cur ^ 1) * kSStage);
+    issue(cn, lds + (cur ^ 1) * SG::kStage);
     __builtin_amdgcn_sched_barrier(0);
-    const float* sxc = lds + cur * kSStage;
-    const float* swc = sxc + kSSX;
+    const float* sxc = lds + cur * SG::kStage;
+    const float* swc = sxc + SG::kSX;
 #pragma unroll
     for (int tap = 0; tap < 27; ++tap) {
       const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-      const float bv = sxc[((half * 3 + kd) * (2 * kSTH + 1) + 2 * wave + kh) * kSRow + 3 + 2 * l32 + kw];
-      const float a0 = swc[(tap * kSC + half) * 64 + l32], a1 = swc[(tap * kSC + half) * 64 + 32 + l32];
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[1], 0, 0, 0);
+      float a[CB], bv[kRW];
+#pragma unroll
+      for (int r = 0; r < kRW; ++r) bv[r] = sxc[((half * 3 + kd) * kRowsIn + 2 * (wave * kRW + r) + kh) * kSRow + 3 + 2 * l32 + kw];
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) a[cb] = swc[(tap * kSC + half) * kCO + cb * 32 + l32];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[CB == 2 ? i : 0], bv[CB == 2 ? 0 : i], acc[i], 0, 0, 0);
     }
     __syncthreads();
     cur ^= 1;
   }
 
-  const int gh = h0 + wave, gw = w0 + l32;
-  if (gh >= gH || gw >= gW) return;
+  const int gw = w0 + l32;
+  if (gw >= gW) return;
   const long long ovol = static_cast<long long>(gD) * gH * gW;
   const bool has_bias = epi.bias != nullptr, has_res = epi.residual != nullptr;
 #pragma unroll
-  for (int cb = 0; cb < 2; ++cb) {
-    const int co0 = cp * 64 + cb * 32 + 4 * half;
-    if (cp * 64 + cb * 32 >= Cout) break;
+  for (int i = 0; i < 2; ++i) {
+    const int cb = CB == 2 ? i : 0, r = CB == 2 ? 0 : i;
+    const int gh = h0 + wave * kRW + r;
+    const int co0 = cp * kCO + cb * 32 + 4 * half;
+    if (gh >= gH || cp * kCO + cb * 32 >= Cout) continue;
     const long long at = (static_cast<long long>(b) * Cout + co0) * ovol + (static_cast<long long>(d0) * gH + gh) * gW + gw;
     float bz[16], sk[16];
 #pragma unroll
@@ -899,11 +915,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_s2_mfma(const float* __restr
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
       const int cr = 8 * (v >> 2) + (v & 3);
-      float r = acc[cb][v];
-      if (has_bias) r = r + bz[v];
-      if (has_res) r = r + sk[v];
-      if (epi.relu) r = r > 0.0f ? r : 0.0f;
-      if (co0 + cr < Cout) y[at + cr * ovol] = r;
+      float rv = acc[i][v];
+      if (has_bias) rv = rv + bz[v];
+      if (has_res) rv = rv + sk[v];
+      if (epi.relu) rv = rv > 0.0f ? rv : 0.0f;
+      if (co0 + cr < Cout) y[at + cr * ovol] = rv;
     }
   }
 }
@@ -1163,10 +1179,10 @@ static int cu_count() {  // compute units of the current device (256 on MI355X);
   return cached;
 }
 
-// the direct strided kernel (two-channel stages): more than 32 output channels, rows of whole 16-byte groups, the convolution's own
+// the direct strided kernel (two-channel stages): rows of whole 16-byte groups, the convolution's own
 // output grid, every tap.  adv_conv3d_k3_s2_stage_channels reports the choice (it fixes the accumulation order).
 static bool conv3d_k3_s2_direct(int cout, int w, const float* x, const Epi& epi) {
-  return cout > 32 && w % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && epi.tap_mask == kAllTaps && epi.class_channels == 0 &&
+  return cout >= 1 && w % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && epi.tap_mask == kAllTaps && epi.class_channels == 0 &&
          epi.nclass == 0 && epi.sd == 1 && epi.sh == 1 && epi.sw == 1 && epi.fd == 0 && epi.fh == 0 && epi.fw == 0 &&
          getenv("ADV_CONV_GENERIC") == nullptr && getenv("ADV_CONV_S2_GENERIC") == nullptr;
 }
@@ -1209,11 +1225,22 @@ static int launch_conv(const float* x, const float* w_prep, float* y, int b, int
   }
   if (stride == 2 && conv3d_k3_s2_direct(cout, w, x, epi) && fits && (reinterpret_cast<uintptr_t>(w_prep) & 15) == 0 && epi.od == gd &&
       epi.oh == gh && epi.ow == gw) {
-    const int tw = (gw + kTW - 1) / kTW, th = (gh + kSTH - 1) / kSTH, cpairs = (cblocks + 1) / 2;
-    const long long ntiles = static_cast<long long>(tw) * th * gd * b * cpairs;
+    const bool two = cout > 32;   // both 32-channel blocks of a pair per workgroup, or two rows per wave of the one block
+    const int tw = (gw + kTW - 1) / kTW, th = two ? (gh + SGeo<2>::kTH - 1) / SGeo<2>::kTH : (gh + SGeo<1>::kTH - 1) / SGeo<1>::kTH;
+    const int cgroups = two ? (cblocks + 1) / 2 : cblocks;
+    const long long ntiles = static_cast<long long>(tw) * th * gd * b * cgroups;
     if (ntiles < (1LL << 31)) {
-      hipLaunchKernelGGL(conv3d_k3_s2_mfma, dim3(static_cast<unsigned>(ntiles)), dim3(256), 2 * sizeof(float) * static_cast<size_t>(kSStage), st, x,
-                         w_prep, y, cin, cout, cblocks * 32, d, h, w, gd, gh, gw, tw, th, cpairs, epi);
+      if (two) {
+        hipLaunchKernelGGL(conv3d_k3_s2_mfma<2>, dim3(static_cast<unsigned>(ntiles)), dim3(256), 2 * sizeof(float) * static_cast<size_t>(SGeo<2>::kStage),
+                           st, x, w_prep, y, cin, cout, cblocks * 32, d, h, w, gd, gh, gw, tw, th, cgroups, epi);
+      } else {
+        const size_t lds = 2 * sizeof(float) * static_cast<size_t>(SGeo<1>::kStage);   // 72 KiB: beyond the default dynamic-LDS limit
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_k3_s2_mfma<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                static_cast<int>(lds)) != hipSuccess)
+          return ADV_ELAUNCH;
+        hipLaunchKernelGGL(conv3d_k3_s2_mfma<1>, dim3(static_cast<unsigned>(ntiles)), dim3(256), lds, st, x, w_prep, y, cin, cout, cblocks * 32, d, h, w,
+                           gd, gh, gw, tw, th, cgroups, epi);
+      }
       return adv_internal_finish_launch();
     }
   }

@@ -699,7 +699,7 @@ def conv3d_k3_s2_prep(weight):
 
 def conv3d_k3_s2_stage_channels(x, cout):
     """2 or 4: the input channels per stage (= the float32 accumulation order) ``conv3d_k3_s2(x, conv3d_k3_prep(w), cout)`` will use -
-    2 is the direct strided matrix kernel (cout > 32, W % 4 == 0), 4 the scalar-staging kernel; the oracle takes it as ``chunk``"""
+    2 is the direct strided matrix kernel (W % 4 == 0, 16-byte aligned x), 4 the scalar-staging kernel; the oracle takes it as ``chunk``"""
     xi = _feat(x, "x")
     return int(_lib.load().adv_conv3d_k3_s2_stage_channels(_ptr(xi), int(cout), int(xi.shape[4])))
 
@@ -707,8 +707,8 @@ def conv3d_k3_s2_stage_channels(x, cout):
 def conv3d_k3_s2(x, prep, cout, relu=False, bias=None, route="auto"):
     """the strided 3x3x3 convolution of an hourglass: stride 2, padding 1 -> [B,cout,ceil(D/2),ceil(H/2),ceil(W/2)].
     ``prep`` = ``conv3d_k3_s2_prep(weight)`` holds the weights for both routes:
-      "direct"  the strided matrix kernel on the raw input (more than 32 output channels, W % 4 == 0: two-channel stages, no
-                permuted copy - the fastest route; otherwise the scalar-staging kernel, slow);
+      "direct"  the strided matrix kernel on the raw input (W % 4 == 0: two-channel stages, no permuted copy - the fastest
+                route; otherwise the scalar-staging kernel, slow);
       "s2d"     space-to-depth + the stride-1 MFMA kernel with per-class tap masks (any shape; no wasted matrix work);
       "auto"    direct where the matrix kernel takes it, else s2d.
     The routes accumulate in different orders (last-bit differences; each is bit-exact against the oracle run its way).

@@ -315,7 +315,7 @@ ADV_API int adv_conv3d_k3_f32(const float* x, const float* w_prep, float* y, int
  *                before the ReLU - an hourglass's skip connection, y = relu(conv(x) + bias + skip), without a pass of its own.
  *                Must not be y itself (-EINVAL).  Same float operations in the same order as conv, add, add, max done apart.
  *     stride     1, or 2 = the strided 3x3x3 convolution (padding 1): output grid ceil(d/2) x ceil(h/2) x ceil(w/2)
- *                (cout > 32, w % 4 == 0, x and w_prep 16-byte aligned, no masks / lattice: the direct strided matrix kernel, 0.52 of the
+ *                (w % 4 == 0, x and w_prep 16-byte aligned, no masks / lattice: the direct strided matrix kernel, 0.52 of the
  *                float32 matrix peak on 32 -> 64 at the cost-volume size; otherwise a scalar-staging kernel, or the space-to-depth route below)
  *     tap_mask   bit t set = tap t = kd*9 + kh*3 + kw takes part (0x7ffffff = all)
  *     out_dims / out_stride / out_offset (HOST int32[3] each, or all NULL): result voxel i of the convolution's own grid is
@@ -347,7 +347,7 @@ ADV_API int adv_conv_transpose3d_k3_s2_f32(const float* x, const float* const* w
 
 /* How many input channels a STAGE of the plain strided convolution (adv_conv3d_k3_ex_f32, stride 2, every tap, own output grid,
  *     16-byte aligned w_prep) holds for this input pointer, output-channel count and width - the float32 accumulation order is
- *     (stage, tap, channel within the stage): 2 = the direct strided matrix kernel (cout > 32, w % 4 == 0, x 16-byte aligned: 54 MFMAs
+ *     (stage, tap, channel within the stage): 2 = the direct strided matrix kernel (w % 4 == 0, x 16-byte aligned: 54 MFMAs
  *     per wave and stage on the raw input tile, operands read from LDS at stride 2, no permuted copy), 4 = the scalar-staging kernel.
  *     Host-side, no launch.  Results of the two orders differ in the last bits only; the oracle takes the stage size as a parameter. */
 ADV_API int adv_conv3d_k3_s2_stage_channels(const float* x, int cout, int w);
