@@ -269,12 +269,45 @@ class PgdBench:
         return elapsed, kern_ms
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as a CHILD
+    `python -m torch.distributed.run --nproc-per-node N bench.py ...` (this parent has not imported torch.cuda or touched a
+    GPU, and it never replaces itself: it waits for the child), relay rank 0's single JSON line and exit with the child's
+    status (the ranks' watchdog exit code 3 included)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), ADV_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    proc = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, text=True)
+    lines = []
+    for line in proc.stdout:
+        if line.startswith("{"):
+            lines.append(line.rstrip("\n"))
+        else:
+            sys.stderr.write(line)
+    rc = proc.wait()
+    if lines:
+        print(lines[-1], flush=True)
+    elif rc == 0:
+        print("bench.py: the %d-rank child exited 0 without a JSON line" % args.gpus, file=sys.stderr)
+        rc = 4
+    sys.exit(rc)
+
+
 def main():
     args = parse()
     global H, W, CROP_H, CROP_W, ALPHA, EPS
     if args.torch_cpu_baseline:
         print(json.dumps(torch_cpu_baseline()), flush=True)
         return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:      # launched plainly: become the launcher (before anything touches a GPU)
+        self_launch(args)
     srcnn = args.workload == "srcnn"
     if srcnn:   # attack/Stereo-RCNN/pgd_attack.py: network scale 600x1987, no crop (quirk Q14), alpha 1.0, eps = 255*0.03 (:57)
         H, W, CROP_H, CROP_W, ALPHA, EPS = SR_H, SR_W, SR_H, SR_W, 1.0, 255 * 0.03
@@ -286,6 +319,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:         # a launcher that started a different number of ranks: refuse rather than mislabel the line
+        if rank == 0:
+            print("bench.py: --gpus %d but the launcher set WORLD_SIZE=%d; start it plainly (`python bench.py --gpus %d` launches its own "
+                  "ranks) or with --nproc-per-node %d" % (args.gpus, world, args.gpus, args.gpus), file=sys.stderr)
+        sys.exit(2)
     # ADV_BENCH_FORCE_DIST=1: take the distributed code path (process group, barriers, MAX-reduce, patch all-reduce probe) even
     # with WORLD_SIZE=1, so that the RCCL branch can be exercised on a single-GPU box
     use_dist = world > 1 or os.environ.get("ADV_BENCH_FORCE_DIST") == "1"
@@ -306,8 +344,6 @@ def main():
             dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
-    if world != args.gpus and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
     dev = torch.device("cuda", torch.cuda.current_device())
 
     from eval_driving_safety_amd import ops   # raises if libadvengine.so is not built
@@ -335,10 +371,13 @@ def main():
     use_index = not args.no_clean_index
     main_b = PgdBench(torch, ops, sp, x0, grad, valid, crop, use_index, (not args.alternate), affine=not srcnn)
     elapsed, kern_ms = main_b.timed(args.steps, args.warmup, fence)
-    if use_dist:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    per_rank = None
+    if use_dist:                   # MAX over ranks is the job's time; every rank's own clock is kept for the line (min/max pairs/s)
+        t = torch.zeros((dist.get_world_size(), 2), device=dev, dtype=torch.float64)     # own row filled, SUM = a gather (one
+        t[dist.get_rank(), 0], t[dist.get_rank(), 1] = elapsed, kern_ms                      # collective both backends support)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        per_rank = [(float(v[0]), float(v[1])) for v in t.cpu()]
+        elapsed = max(v[0] for v in per_rank)
 
     elems = 3 * H * W
     alg_bytes = n_img * (16 * elems + 3 * CROP_H * CROP_W)     # 16 B/elt + the 8-bit export
@@ -369,6 +408,10 @@ def main():
             "value": world * args.pairs * args.steps / elapsed,
             "unit": "stereo-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "rccl_world": dist.get_world_size() if use_dist else 1,       # what the process group itself says, not what --gpus asked for
+            "backend": (dist.get_backend() if use_dist else "none (single process)"),
+            "launched_by": ("bench.py itself (child torch.distributed.run)" if os.environ.get("ADV_BENCH_SELF_LAUNCHED") == "1"
+                            else ("an outer launcher" if "TORCHELASTIC_RUN_ID" in os.environ or world > 1 else "plain python")),
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
@@ -393,6 +436,10 @@ def main():
                          # `traffic` bytes - less when the clean image is read as bytes - so the HBM itself is this busy:
                          "hbm_utilisation": (traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None},
         }
+        if per_rank is not None:
+            rates = [args.pairs * args.steps / e for e, _ in per_rank]
+            out["per_rank"] = {"pairs_per_s_min": min(rates), "pairs_per_s_max": max(rates), "pairs_per_s": rates,
+                               "kernel_avg_launch_ms": [k for _, k in per_rank]}
         if float_path is not None:
             out["float_path"] = float_path
     else:

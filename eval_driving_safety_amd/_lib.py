@@ -13,6 +13,8 @@ import torch  # noqa: F401  (see module docstring)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # ADVENGINE_LIB: tuning builds of the same library (tools/); the default is the in-tree build next to this file
 LIB_PATH = os.environ.get("ADVENGINE_LIB") or os.path.join(_HERE, "libadvengine.so")
+# the -DADV_TEST_HOOKS build of the same sources (route switches read from the environment): tests/ and tools/ only, via using()
+HOOKS_LIB_PATH = os.path.join(_HERE, "libadvengine_hooks.so")
 
 ADV_OK = 0
 ADV_EINVAL = -22
@@ -100,6 +102,7 @@ SIGNATURES = {
 }
 _OTHER = {
     "adv_abi_version": ([], _I),
+    "adv_build_has_test_hooks": ([], _I),
     "adv_roi_align_bwd_workspace_ints": ([_I, _I, _I, _I], ctypes.c_int64),
     "adv_grid_sample3d_plan_bytes": ([_I, _I, _I, _I, _I, _I, _I], ctypes.c_int64),
     "adv_grid_sample3d_bwd_workspace_floats": ([_I, _I, _I, _I, _I], ctypes.c_int64),
@@ -114,17 +117,13 @@ EXPORTED = sorted(list(SIGNATURES) + list(_OTHER))
 _lib = None
 
 
-def load():
-    """Open libadvengine.so (once).  Raises if it has not been built - there is no fallback."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def _open(path):
+    if not os.path.exists(path):
         raise ImportError(
-            "libadvengine.so is missing at %s - build it with `python -c 'import __graft_entry__ as g; "
+            "%s is missing at %s - build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` or `make -C eval_driving_safety_amd/csrc` (needs hipcc, targets gfx950). "
-            "This package has no CPU / PyTorch fallback." % LIB_PATH)
-    lib = ctypes.CDLL(LIB_PATH)
+            "This package has no CPU / PyTorch fallback." % (os.path.basename(path), path))
+    lib = ctypes.CDLL(path)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
@@ -135,9 +134,35 @@ def load():
         fn.restype = restype
     got = lib.adv_abi_version()
     if got != ABI_VERSION:
-        raise ImportError("libadvengine.so ABI %d, binding expects %d - rebuild" % (got, ABI_VERSION))
-    _lib = lib
+        raise ImportError("%s ABI %d, binding expects %d - rebuild" % (os.path.basename(path), got, ABI_VERSION))
     return lib
+
+
+def load():
+    """Open libadvengine.so (once).  Raises if it has not been built - there is no fallback."""
+    global _lib
+    if _lib is None:
+        _lib = _open(LIB_PATH)
+    return _lib
+
+
+class using:
+    """``with _lib.using(_lib.HOOKS_LIB_PATH): ...`` - route every call inside the block to another build of the library (the
+    -DADV_TEST_HOOKS one, whose ADV_* switches the A/B tests and tools/ flip).  Test / tuning infrastructure: nothing in the
+    package enters it, and the shipped library reads no environment variable (adv_build_has_test_hooks() == 0)."""
+
+    def __init__(self, path):
+        self.path = path
+
+    def __enter__(self):
+        global _lib
+        load()
+        self.prev, _lib = _lib, _open(self.path)
+        return _lib
+
+    def __exit__(self, *a):
+        global _lib
+        _lib = self.prev
 
 
 def check(name, code):

@@ -1088,6 +1088,14 @@ extern "C" {
 
 int adv_abi_version(void) { return ADV_ABI_VERSION; }
 
+int adv_build_has_test_hooks(void) {
+#ifdef ADV_TEST_HOOKS
+  return 1;
+#else
+  return 0;
+#endif
+}
+
 int adv_last_hip_error(void) { return g_last_hip_error; }
 
 const char* adv_strerror(int code) {

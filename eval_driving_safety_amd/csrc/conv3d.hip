@@ -1184,7 +1184,7 @@ static int cu_count() {  // compute units of the current device (256 on MI355X);
 static bool conv3d_k3_s2_direct(int cout, int w, const float* x, const Epi& epi) {
   return cout >= 1 && w % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && epi.tap_mask == kAllTaps && epi.class_channels == 0 &&
          epi.nclass == 0 && epi.sd == 1 && epi.sh == 1 && epi.sw == 1 && epi.fd == 0 && epi.fh == 0 && epi.fw == 0 &&
-         getenv("ADV_CONV_GENERIC") == nullptr && getenv("ADV_CONV_S2_GENERIC") == nullptr;
+         !adv_hook("ADV_CONV_GENERIC") && !adv_hook("ADV_CONV_S2_GENERIC");
 }
 
 static int launch_conv(const float* x, const float* w_prep, float* y, int b, int cin, int cout, int d, int h, int w, int stride,
@@ -1198,7 +1198,7 @@ static int launch_conv(const float* x, const float* w_prep, float* y, int b, int
   // the LDS-staged kernels' fetch plan holds 32-bit element offsets inside one batch element and loads 4 floats at a time:
   // w >= 4, cin*d*h*w and 27*cin*cout_pad below 2^31 - anything else takes the scalar-staging kernel
   const bool fits = w >= 4 && static_cast<long long>(cin) * d * h * w < (1LL << 31) && 27LL * cin * cblocks * 32 < (1LL << 31);
-  const bool narrow_ok = getenv("ADV_CONV_NO_NARROW") == nullptr;  // test hook: the padded matrix kernel instead
+  const bool narrow_ok = !adv_hook("ADV_CONV_NO_NARROW");  // test hook: the padded matrix kernel instead
   if (cin < kCK) {  // 1..3 input channels (the adjoint of a layer with 1..3 outputs): vector-ALU kernel, HBM-bound on the result
     if (!plain) return ADV_EINVAL;
     const long long voxels = static_cast<long long>(d) * h * w;
@@ -1235,9 +1235,7 @@ static int launch_conv(const float* x, const float* w_prep, float* y, int b, int
                            st, x, w_prep, y, cin, cout, cblocks * 32, d, h, w, gd, gh, gw, tw, th, cgroups, epi);
       } else {
         const size_t lds = 2 * sizeof(float) * static_cast<size_t>(SGeo<1>::kStage);   // 72 KiB: beyond the default dynamic-LDS limit
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_k3_s2_mfma<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                static_cast<int>(lds)) != hipSuccess)
-          return ADV_ELAUNCH;
+        if (!adv_internal_lds_limit<conv3d_k3_s2_mfma<1>>(lds)) return ADV_ELAUNCH;
         hipLaunchKernelGGL(conv3d_k3_s2_mfma<1>, dim3(static_cast<unsigned>(ntiles)), dim3(256), lds, st, x, w_prep, y, cin, cout, cblocks * 32, d, h, w,
                            gd, gh, gw, tw, th, cgroups, epi);
       }
@@ -1247,7 +1245,7 @@ static int launch_conv(const float* x, const float* w_prep, float* y, int b, int
   // the main kernel takes every width (rows that are not 16-byte aligned are loaded as dword-aligned float4);
   // ADV_CONV_GENERIC=1 forces the scalar-staging kernel (kept as the reference implementation of the tiling)
   const bool fast = stride == 1 && fits && (reinterpret_cast<uintptr_t>(w_prep) & 15) == 0 && (reinterpret_cast<uintptr_t>(x) & 3) == 0 &&
-                    getenv("ADV_CONV_GENERIC") == nullptr;
+                    !adv_hook("ADV_CONV_GENERIC");
   // tile depth 2 (4 waves) and 4 (8 waves, one workgroup per CU) measured the same within 1-2 % (profiles/r01_conv3d_mfma.jsonl)
   if (fast) {
     // persistent workgroups: two per CU (the LDS budget), a multiple of 8 so that each XCD walks its own contiguous tile range;
@@ -1264,25 +1262,23 @@ static int launch_conv(const float* x, const float* w_prep, float* y, int b, int
     const double t8 = static_cast<double>((n8 + slots - 1) / slots);
     const double t4 = (all_taps ? 0.52 : 0.75) * static_cast<double>((n4 + slots - 1) / slots);
     bool th4 = t4 < t8;
-    if (const char* e = getenv("ADV_CONV_TH")) th4 = e[0] == '4';
+    if (const char* e = adv_hook_value("ADV_CONV_TH")) th4 = e[0] == '4';
     TileGrid tg;
     tg.tiles_w = tiles_w, tg.tiles_hw = tiles_w * (th4 ? (h + 3) / 4 : (h + 7) / 8), tg.nd = (d + 1) / 2, tg.cblocks = cblocks;
     tg.nclass = epi.nclass;
     tg.ntiles = th4 ? n4 : n8;
     long long wgs = slots;
-    if (getenv("ADV_CONV_ONE_TILE_PER_WG") != nullptr || tg.ntiles < wgs) wgs = tg.ntiles;
+    if (adv_hook("ADV_CONV_ONE_TILE_PER_WG") || tg.ntiles < wgs) wgs = tg.ntiles;
     if (wgs > 0x7fffffffLL) return ADV_EINVAL;
     const dim3 grid(static_cast<unsigned>(wgs));
     const int cpad = cblocks * 32;
     // staging by LDS-DMA needs whole float4 groups inside the rows: w % 4 == 0 and a 16-byte aligned x (ADV_CONV_NO_DMA=1: the
     // register-staged path instead - test hook / A-B; same bits)
-    const bool dma = w % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && getenv("ADV_CONV_NO_DMA") == nullptr;
+    const bool dma = w % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && !adv_hook("ADV_CONV_NO_DMA");
 #define ADV_LAUNCH_MFMA(MASKED_, TH_, DMA_)                                                                                                   \
   do {                                                                                                                                        \
     const size_t lds_ = 2 * sizeof(float) * static_cast<size_t>(DMA_ ? DmaGeo<2, TH_>::kStageFloats : Geo<2, TH_>::kStageFloats);               \
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_k3_mfma<2, MASKED_, TH_, DMA_>), hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                            static_cast<int>(lds_)) != hipSuccess)                                                                            \
-      return ADV_ELAUNCH;                                                                                                                     \
+    if (!adv_internal_lds_limit<conv3d_k3_mfma<2, MASKED_, TH_, DMA_>>(lds_)) return ADV_ELAUNCH;                                               \
     hipLaunchKernelGGL((conv3d_k3_mfma<2, MASKED_, TH_, DMA_>), grid, dim3(256), lds_, st, x, w_prep, y, cin, cout, cpad, d, h, w, tg, epi);    \
   } while (0)
     if (!th4) {
@@ -1300,11 +1296,8 @@ static int launch_conv(const float* x, const float* w_prep, float* y, int b, int
   } else {
     const dim3 grid(tiles_w * tiles_h, (gd + kTD - 1) / kTD, b * cblocks);
     const size_t lds = static_cast<size_t>(GenGeo<2>::kSX + kSW) * sizeof(float);
-    // more than 64 KiB of dynamic LDS needs the attribute; set on every call (idempotent, a host-side table write) so that
-    // the library keeps no state of its own
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_k3_mfma_generic<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            static_cast<int>(lds)) != hipSuccess)
-      return ADV_ELAUNCH;
+    // more than 64 KiB of dynamic LDS needs the attribute (raised once per kernel and device: adv_internal.h)
+    if (!adv_internal_lds_limit<conv3d_k3_mfma_generic<2>>(lds)) return ADV_ELAUNCH;
     hipLaunchKernelGGL((conv3d_k3_mfma_generic<2>), grid, dim3(256), lds, st, x, w_prep, y, cin, cout, cblocks * 32, gd, gh, gw, d, h, w,
                        tiles_w, cblocks, epi);
   }
@@ -1376,12 +1369,12 @@ int adv_conv_transpose3d_k3_s2_f32(const float* x, const float* const* w_prep_cl
   const bool fits = w >= 4 && static_cast<long long>(cin) * d * h * w < (1LL << 31) && 27LL * cin * cblocks * 32 < (1LL << 31);
   bool aligned_w = (reinterpret_cast<uintptr_t>(x) & 3) == 0;
   for (int k = 0; k < 8; ++k) aligned_w = aligned_w && (reinterpret_cast<uintptr_t>(w_prep_classes[k]) & 15) == 0;
-  if (fits && aligned_w && getenv("ADV_CONV_GENERIC") == nullptr && getenv("ADV_CONV_CLASS_LAUNCHES") == nullptr) {
+  if (fits && aligned_w && !adv_hook("ADV_CONV_GENERIC") && !adv_hook("ADV_CONV_CLASS_LAUNCHES")) {
     constexpr int tt = 4;   // rows (= waves) per tile; 8 rows / 512 threads / one workgroup per CU measured the same (0.200-0.204 against 0.205-0.207 ms)
     const int tiles_w = (w + kTW - 1) / kTW, tiles_h = (h + tt - 1) / tt;
     const long long ntiles = static_cast<long long>(tiles_w) * tiles_h * d * b * cblocks;
     const bool all_classes = w % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 7) == 0 &&
-                             (reinterpret_cast<uintptr_t>(residual) & 7) == 0 && ntiles < (1LL << 31) && getenv("ADV_CONV_T_CLASS_TILES") == nullptr;
+                             (reinterpret_cast<uintptr_t>(residual) & 7) == 0 && ntiles < (1LL << 31) && !adv_hook("ADV_CONV_T_CLASS_TILES");
     if (all_classes) {   // every class from one staging of the input tile (convt3d_k3_s2_mfma)
       for (int k = 0; k < 8; ++k) epi.cls_wp[k] = w_prep_classes[k];
       const size_t lds = 2 * sizeof(float) * static_cast<size_t>(TGeo<tt>::kStage);

@@ -337,7 +337,7 @@ int adv_roi_align_fwd_f32(const float* feat, const float* rois, float* out, int 
   if (rc != ADV_OK) return rc;
   if (r == 0) return ADV_OK;
   const long long total = static_cast<long long>(r) * c * ph * pw;
-  if (w >= 2 && getenv("ADV_ROI_FWD_DIRECT") == nullptr)
+  if (w >= 2 && !adv_hook("ADV_ROI_FWD_DIRECT"))
     hipLaunchKernelGGL(roi_align_fwd<true>, dim3(grid_for(total)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), feat, rois, out, c, h, w,
                        total, ph, pw, spatial_scale, sampling_ratio);
   else  // a one-column map, or ADV_ROI_FWD_DIRECT=1 (test hook): four single-dword gathers per sample

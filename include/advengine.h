@@ -19,8 +19,8 @@
  *     arithmetic (float32, every operation rounded separately, true division, NaN-propagating clamp); the detector-side
  *     operators further down (upstream code, not in the reference tree) state their own contract: bit-identical to torch's
  *     CPU operator or to the oracle's fixed summation order where no transcendental is involved, 1e-5 relative otherwise;
- *   - the convolution entry points read the device's CU count once per host thread and set a kernel attribute per launch
- *     (host-side calls, nothing allocated, nothing synchronised).
+ *   - the convolution entry points read the device's CU count once per host thread and raise the kernels' dynamic-LDS limit once
+ *     per process (host-side calls outside any capture, nothing allocated, nothing synchronised); no environment variable is read.
  */
 #ifndef ADVENGINE_H
 #define ADVENGINE_H
@@ -73,6 +73,10 @@ ADV_API void adv_space_dsgn_gpu_reference(adv_space_t* s); /* the same constants
 ADV_API void adv_space_srcnn(adv_space_t* s); /* range [-m_c, 255-m_c], m = (102.9801,115.9465,122.7717) */
 
 ADV_API int adv_abi_version(void);
+/* 0 for the shipped library: no entry point reads the environment, kernel selection depends on the arguments alone.  1 for the
+ * -DADV_TEST_HOOKS build (libadvengine_hooks.so, opened by tests/ and tools/ only), whose convolution / RoIAlign entry points read
+ * the ADV_* route switches of DESIGN.md 5 at each launch. */
+ADV_API int adv_build_has_test_hooks(void);
 ADV_API const char* adv_strerror(int code);
 ADV_API int adv_last_hip_error(void); /* thread-local */
 

@@ -15,7 +15,8 @@ for p in (ROOT, GOLDEN):
 def pytest_sessionstart(session):
     """A fresh checkout has no built artefacts (they are git-ignored): build them once, so that the suite does
     not depend on somebody having called __graft_entry__.build() first.  hipcc cross-compiles without a GPU."""
-    need = [os.path.join(ROOT, "eval_driving_safety_amd", "libadvengine.so"), os.path.join(ROOT, "oracle", "_build", "liboracle.so")]
+    need = [os.path.join(ROOT, "eval_driving_safety_amd", "libadvengine.so"), os.path.join(ROOT, "eval_driving_safety_amd", "libadvengine_hooks.so"),
+            os.path.join(ROOT, "oracle", "_build", "liboracle.so")]
     if all(os.path.exists(p) for p in need):
         return
     try:
@@ -27,6 +28,26 @@ def pytest_sessionstart(session):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture
+def route(monkeypatch):
+    """``with route(ADV_CONV_NO_DMA="1"): ...`` - inside the block the calls go to libadvengine_hooks.so (the -DADV_TEST_HOOKS build of
+    the same sources) with the given route switches in the environment; outside it to the shipped library, which reads none."""
+    import contextlib
+
+    @contextlib.contextmanager
+    def cm(**env):
+        from eval_driving_safety_amd import _lib
+        with monkeypatch.context() as m, _lib.using(_lib.HOOKS_LIB_PATH) as lib:
+            assert lib.adv_build_has_test_hooks() == 1
+            for k in [k for k in os.environ if k.startswith("ADV_CONV_") or k.startswith("ADV_ROI_")]:
+                m.delenv(k)
+            for k, v in env.items():
+                m.setenv(k, v)
+            yield
+
+    return cm
 
 
 @pytest.fixture(scope="session")

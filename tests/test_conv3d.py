@@ -93,7 +93,7 @@ def test_hip_conv3d_single_output_channel_with_torch_adjoint():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("masked", [False, True])
-def test_hip_persistent_tile_walk_equals_one_workgroup_per_tile(masked, monkeypatch):
+def test_hip_persistent_tile_walk_equals_one_workgroup_per_tile(masked, route):
     """more tiles than resident workgroups: every workgroup walks several tiles with the stage pipeline running across them
     (XCD-contiguous shares) - the same bits as one workgroup per tile, and as the oracle on a slab"""
     from eval_driving_safety_amd import ops
@@ -109,9 +109,8 @@ def test_hip_persistent_tile_walk_equals_one_workgroup_per_tile(masked, monkeypa
         return ops._conv3d_ex(x, wp, 40, 1, True, bias, mask)
 
     y = run()
-    monkeypatch.setenv("ADV_CONV_ONE_TILE_PER_WG", "1")
-    assert torch.equal(run(), y)
-    monkeypatch.delenv("ADV_CONV_ONE_TILE_PER_WG")
+    with route(ADV_CONV_ONE_TILE_PER_WG="1"):
+        assert torch.equal(run(), y)
     want = C.conv3d_k3_ex(x[1:, :, 20:27].cpu().numpy(), wt.cpu().numpy(), bias=bias.cpu().numpy(), relu=True, tap_mask=mask)
     got = ops._conv3d_ex(x[1:, :, 20:27].contiguous(), wp, 40, 1, True, bias, mask)
     assert got.cpu().numpy().tobytes() == want.tobytes()
@@ -121,17 +120,15 @@ def test_hip_persistent_tile_walk_equals_one_workgroup_per_tile(masked, monkeypa
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("switch", ["ADV_CONV_NO_DMA=1", "ADV_CONV_TH=4", "ADV_CONV_TH=8", "ADV_CONV_GENERIC=1", "ADV_CONV_CLASS_LAUNCHES=1", "ADV_CONV_T_CLASS_TILES=1"])
-def test_hip_alternative_code_paths_give_the_same_bits(switch, monkeypatch):
+def test_hip_alternative_code_paths_give_the_same_bits(switch, route):
     """register-staged vs LDS-DMA stages, both tile heights, the scalar-staging kernel, for the transposed convolution eight
     launches / the class as a tile index / all classes per tile: identical results on plain, masked, strided and transposed layers (W % 4 == 0 and != 0)"""
     from eval_driving_safety_amd import ops
     dev = torch.device("cuda", 0)
     gen = torch.Generator(device=dev).manual_seed(21)
     results = []
-    for rnd in range(2):
-        if rnd == 1:
-            k, v = switch.split("=")
-            monkeypatch.setenv(k, v)
+
+    def layers():
         out = []
         for w in (40, 38):
             g = torch.Generator(device=dev).manual_seed(100 + w)
@@ -143,7 +140,11 @@ def test_hip_alternative_code_paths_give_the_same_bits(switch, monkeypatch):
             out.append(ops.conv3d_k3_s2(x, ops.conv3d_k3_s2_prep(wt), 40, relu=True, bias=bias, route="s2d"))
             wtt = torch.randn((8, 24, 3, 3, 3), device=dev, generator=g) * 0.1
             out.append(ops.conv_transpose3d_k3_s2(x, ops.conv_transpose3d_k3_s2_prep(wtt), 24, bias=bias[:24]))
-        results.append(out)
+        return out
+
+    results.append(layers())                     # the shipped library
+    with route(**dict([switch.split("=")])):     # the hooks build with the switch set
+        results.append(layers())
     for a, b in zip(*results):
         assert torch.equal(a, b)
 
@@ -153,7 +154,7 @@ NARROW = [(1, 32, 1, 6, 24, 40), (2, 8, 1, 3, 9, 33), (1, 12, 3, 4, 8, 78), (1, 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", NARROW)
-def test_hip_narrow_layers_bit_exact_vs_oracle_and_vs_padded_matrix_kernel(shape, monkeypatch):
+def test_hip_narrow_layers_bit_exact_vs_oracle_and_vs_padded_matrix_kernel(shape, route):
     """Cout <= 8 runs on the vector ALUs (narrow_out), its adjoint with 1..3 input channels too (narrow_in): the same bits as the
     oracle's fmaf chain AND as the matrix kernel that pads the channels to 32 rows (ADV_CONV_NO_NARROW=1)."""
     from eval_driving_safety_amd import ops
@@ -168,9 +169,8 @@ def test_hip_narrow_layers_bit_exact_vs_oracle_and_vs_padded_matrix_kernel(shape
     want = C.conv3d_k3(x, wt)
     assert y.cpu().numpy().tobytes() == want.tobytes(), "narrow forward vs oracle"
     assert yb.cpu().numpy().tobytes() == C.conv3d_k3_ex(x, wt, bias=bias.cpu().numpy(), relu=True).tobytes(), "bias + relu"
-    monkeypatch.setenv("ADV_CONV_NO_NARROW", "1")
-    assert torch.equal(ops.conv3d_k3(tx, wp, cout), y), "narrow forward vs the padded matrix kernel"
-    monkeypatch.delenv("ADV_CONV_NO_NARROW")
+    with route(ADV_CONV_NO_NARROW="1"):
+        assert torch.equal(ops.conv3d_k3(tx, wp, cout), y), "narrow forward vs the padded matrix kernel"
     if cout < 4:
         g = np.random.RandomState(5).randn(*want.shape).astype(np.float32)
         wpt = ops.conv3d_k3_prep(tw, transpose=True)
@@ -292,7 +292,7 @@ def test_hip_hourglass_autograd_vs_torch():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", HG_SHAPES + [(1, 32, 1, 3, 8, 36), (1, 2, 32, 3, 8, 36)])
-def test_hip_residual_epilogue_equals_conv_then_add_then_relu(shape, monkeypatch):
+def test_hip_residual_epilogue_equals_conv_then_add_then_relu(shape, route):
     """y = relu(conv(x) + bias + skip) in the epilogue (an hourglass's skip connection): the same float operations in the same
     order as the convolution followed by a separate add and max - on the matrix kernel (all-taps, masked / transposed, every
     staging variant) and on the narrow vector-ALU kernels - and equal to the oracle's convolution plus a numpy add."""
@@ -306,31 +306,22 @@ def test_hip_residual_epilogue_equals_conv_then_add_then_relu(shape, monkeypatch
     tx, tw, tb, ts = (torch.tensor(a, device=dev) for a in (x, wt, bias, skip))
     wp = ops.conv3d_k3_prep(tw)
     want = np.maximum(C.conv3d_k3_ex(x, wt, bias=bias) + skip, np.float32(0))
+    import contextlib
     for env in ({}, {"ADV_CONV_NO_DMA": "1"}, {"ADV_CONV_GENERIC": "1"}, {"ADV_CONV_NO_NARROW": "1"}):
-        for k in ("ADV_CONV_NO_DMA", "ADV_CONV_GENERIC", "ADV_CONV_NO_NARROW"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        got = ops.conv3d_k3(tx, wp, cout, relu=True, bias=tb, residual=ts)
-        assert got.cpu().numpy().tobytes() == want.tobytes(), env
-        assert torch.equal(got, F.relu(ops.conv3d_k3(tx, wp, cout, bias=tb) + ts)), env
-        assert torch.equal(ops.conv3d_k3(tx, wp, cout, residual=ts), ops.conv3d_k3(tx, wp, cout) + ts), env      # no bias, no relu
-    for k in ("ADV_CONV_NO_DMA", "ADV_CONV_GENERIC", "ADV_CONV_NO_NARROW"):
-        monkeypatch.delenv(k, raising=False)
+        with (route(**env) if env else contextlib.nullcontext()):        # {}: the shipped library
+            got = ops.conv3d_k3(tx, wp, cout, relu=True, bias=tb, residual=ts)
+            assert got.cpu().numpy().tobytes() == want.tobytes(), env
+            assert torch.equal(got, F.relu(ops.conv3d_k3(tx, wp, cout, bias=tb) + ts)), env
+            assert torch.equal(ops.conv3d_k3(tx, wp, cout, residual=ts), ops.conv3d_k3(tx, wp, cout) + ts), env      # no bias, no relu
     if cin % 4 == 0:
         w_t = (rs.randn(cin, cout, 3, 3, 3) * 0.1).astype(np.float32)
         classes = ops.conv_transpose3d_k3_s2_prep(torch.tensor(w_t, device=dev))
         skip2 = torch.tensor(rs.randn(b, cout, 2 * d, 2 * h, 2 * w).astype(np.float32), device=dev)
         for env in ({}, {"ADV_CONV_T_CLASS_TILES": "1"}, {"ADV_CONV_CLASS_LAUNCHES": "1"}):
-            for k in ("ADV_CONV_T_CLASS_TILES", "ADV_CONV_CLASS_LAUNCHES"):
-                monkeypatch.delenv(k, raising=False)
-            for k, v in env.items():
-                monkeypatch.setenv(k, v)
-            got = ops.conv_transpose3d_k3_s2(tx, classes, cout, bias=tb, relu=True, residual=skip2)
-            want_t = np.maximum(C.conv_transpose3d_k3_s2(x, w_t, bias=bias) + skip2.cpu().numpy(), np.float32(0))
-            assert got.cpu().numpy().tobytes() == want_t.tobytes(), ("transposed", env)
-        for k in ("ADV_CONV_T_CLASS_TILES", "ADV_CONV_CLASS_LAUNCHES"):
-            monkeypatch.delenv(k, raising=False)
+            with (route(**env) if env else contextlib.nullcontext()):
+                got = ops.conv_transpose3d_k3_s2(tx, classes, cout, bias=tb, relu=True, residual=skip2)
+                want_t = np.maximum(C.conv_transpose3d_k3_s2(x, w_t, bias=bias) + skip2.cpu().numpy(), np.float32(0))
+                assert got.cpu().numpy().tobytes() == want_t.tobytes(), ("transposed", env)
     with pytest.raises(ValueError):
         ops.conv3d_k3(tx, wp, cout, residual=ts[:, :, :-1].contiguous())
 
@@ -404,7 +395,7 @@ S2_DIRECT = [(1, 8, 33, 3, 9, 40), (2, 8, 32, 5, 19, 36), (1, 16, 5, 4, 8, 72), 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", S2_DIRECT)
-def test_hip_direct_strided_kernel_bit_exact_vs_oracle(shape, monkeypatch):
+def test_hip_direct_strided_kernel_bit_exact_vs_oracle(shape, route):
     """the direct strided matrix kernel (W % 4 == 0; stages of TWO input channels, operands read from LDS at stride 2; more than 32
     output channels: two channel blocks per workgroup, else two rows per wave) against the oracle run with the same stage size - odd
     and even dims, 1 to 3 blocks of output channels, bias / skip connection / ReLU - and within 1e-4 of torch; ADV_CONV_S2_GENERIC=1 sends the same call to the
@@ -427,7 +418,7 @@ def test_hip_direct_strided_kernel_bit_exact_vs_oracle(shape, monkeypatch):
     assert plain.cpu().numpy().tobytes() == C.conv3d_k3_ex(x, wt, stride=2, chunk=2).tobytes(), "direct strided, plain"
     skip = torch.tensor(rs.randn(*plain.shape).astype(np.float32), device=dev)
     assert torch.equal(ops._conv3d_ex(tx, wp, cout, 2, True, tb, residual=skip), F.relu(ops.conv3d_k3_s2(tx, wp, cout, bias=tb) + skip))
-    monkeypatch.setenv("ADV_CONV_S2_GENERIC", "1")
-    assert ops.conv3d_k3_s2_stage_channels(tx, cout) == 4
-    slow = ops.conv3d_k3_s2(tx, wp, cout, bias=tb, relu=True)
-    assert slow.cpu().numpy().tobytes() == C.conv3d_k3_ex(x, wt, bias=bias, stride=2, relu=True, chunk=4).tobytes(), "scalar-staging strided kernel"
+    with route(ADV_CONV_S2_GENERIC="1"):
+        assert ops.conv3d_k3_s2_stage_channels(tx, cout) == 4
+        slow = ops.conv3d_k3_s2(tx, wp, cout, bias=tb, relu=True)
+        assert slow.cpu().numpy().tobytes() == C.conv3d_k3_ex(x, wt, bias=bias, stride=2, relu=True, chunk=4).tobytes(), "scalar-staging strided kernel"

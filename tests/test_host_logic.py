@@ -32,6 +32,21 @@ def test_library_exports_every_declared_symbol():
     assert lib.adv_strerror(-22) == b"invalid argument"
 
 
+def test_shipped_library_reads_no_environment_variable():
+    """include/advengine.h: "no environment variable is read" - the A/B route switches exist in the -DADV_TEST_HOOKS build only"""
+    import subprocess
+    assert _lib.load().adv_build_has_test_hooks() == 0
+    with _lib.using(_lib.HOOKS_LIB_PATH) as hooks:
+        assert hooks.adv_build_has_test_hooks() == 1
+    assert _lib.load().adv_build_has_test_hooks() == 0, "using() must restore the shipped library"
+    undefined = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], stdout=subprocess.PIPE, text=True, check=True).stdout
+    assert "getenv" not in undefined, "libadvengine.so imports getenv"
+    assert "getenv" in subprocess.run(["nm", "-D", "--undefined-only", _lib.HOOKS_LIB_PATH], stdout=subprocess.PIPE, text=True, check=True).stdout
+    for name in os.listdir(os.path.join(ROOT, "eval_driving_safety_amd")):        # nothing in the package opens the hooks build
+        if name.endswith(".py") and name != "_lib.py":
+            assert "HOOKS_LIB_PATH" not in open(os.path.join(ROOT, "eval_driving_safety_amd", name)).read(), name
+
+
 def test_header_is_valid_c99(tmp_path):
     """the boundary is a C ABI: the header must compile as plain C, and a C program must link against the library"""
     import subprocess

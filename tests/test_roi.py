@@ -55,7 +55,7 @@ def test_oracle_nms_small_cases():
     dict(b=1, c=7, h=30, w=41, n=11, pooled=(5, 3), scale=1 / 16.0, sr=1),
     dict(b=1, c=6, h=30, w=41, n=11, pooled=4, scale=1 / 16.0, sr=3),         # a grid the register kernel is not built for
 ])
-def test_hip_roi_align(cfg, monkeypatch):
+def test_hip_roi_align(cfg, route):
     from eval_driving_safety_amd import ops
     rs = np.random.RandomState(cfg["h"] + cfg["n"])
     feat = rs.randn(cfg["b"], cfg["c"], cfg["h"], cfg["w"]).astype(np.float32)
@@ -65,9 +65,8 @@ def test_hip_roi_align(cfg, monkeypatch):
     out = ops.roi_align(tf, tr, cfg["pooled"], cfg["scale"], cfg["sr"])
     want = O.roi_align(feat, rois, cfg["pooled"], cfg["scale"], cfg["sr"])
     assert out.cpu().numpy().tobytes() == want.tobytes(), "forward not bit-exact"
-    monkeypatch.setenv("ADV_ROI_FWD_DIRECT", "1")       # four single gathers per sample: the same bits as the paired loads
-    assert torch.equal(ops.roi_align(tf, tr, cfg["pooled"], cfg["scale"], cfg["sr"]), out)
-    monkeypatch.delenv("ADV_ROI_FWD_DIRECT")
+    with route(ADV_ROI_FWD_DIRECT="1"):                # four single gathers per sample: the same bits as the paired loads
+        assert torch.equal(ops.roi_align(tf, tr, cfg["pooled"], cfg["scale"], cfg["sr"]), out)
     g = rs.randn(*want.shape).astype(np.float32)
     gf = ops.roi_align_bwd(torch.tensor(g, device=dev), tr, feat.shape, cfg["scale"], cfg["sr"])
     wf = O.roi_align_bwd(g, rois, feat.shape, cfg["scale"], cfg["sr"])

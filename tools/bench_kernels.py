@@ -12,6 +12,24 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from eval_driving_safety_amd import ops  # noqa: E402
 
 
+
+import contextlib
+
+
+@contextlib.contextmanager
+def hooks_route(**env):
+    """A/B routes live in the -DADV_TEST_HOOKS build only (libadvengine_hooks.so): inside the block the calls go there, with the
+    switches in the environment; the shipped library reads none"""
+    import os
+    from eval_driving_safety_amd import _lib
+    with _lib.using(_lib.HOOKS_LIB_PATH):
+        os.environ.update(env)
+        try:
+            yield
+        finally:
+            for k in env:
+                del os.environ[k]
+
 def timeit(fn, reps=20, warm=3):
     for _ in range(warm):
         fn()
@@ -118,9 +136,8 @@ def conv(dev):
     flops = 2.0 * 32 * 64 * 27 * (D // 2) * (H // 2) * (W // 2)
     wplain = ops.conv3d_k3_prep(wd)
     ms_direct = timeit(lambda: ops.conv3d_k3_s2(x, wplain, 64), reps=10)
-    os.environ["ADV_CONV_S2_GENERIC"] = "1"
-    ms_generic = timeit(lambda: ops.conv3d_k3_s2(x, wplain, 64), reps=3)
-    del os.environ["ADV_CONV_S2_GENERIC"]
+    with hooks_route(ADV_CONV_S2_GENERIC="1"):
+        ms_generic = timeit(lambda: ops.conv3d_k3_s2(x, wplain, 64), reps=3)
     ms_s2d = timeit(lambda: ops.space_to_depth2(x), reps=10)
     print(json.dumps(dict(kernel="space_to_depth2 [1,32,%d,%d,%d]" % (D, H, W), ms=round(ms_s2d, 3), GBps=round(2 * x.numel() * 4 / ms_s2d / 1e6, 1),
                           scalar_staging_strided_kernel_ms=round(ms_generic, 3))))
@@ -157,9 +174,8 @@ def conv_narrow(dev):
     wt = torch.randn((1, 32, 3, 3, 3), device=dev) * 0.05
     wp, wpt = ops.conv3d_k3_prep(wt), ops.conv3d_k3_prep(wt, transpose=True)
     ms = timeit(lambda: ops.conv3d_k3(x, wp, 1), reps=10)
-    os.environ["ADV_CONV_NO_NARROW"] = "1"
-    ms_pad = timeit(lambda: ops.conv3d_k3(x, wp, 1), reps=10)
-    del os.environ["ADV_CONV_NO_NARROW"]
+    with hooks_route(ADV_CONV_NO_NARROW="1"):
+        ms_pad = timeit(lambda: ops.conv3d_k3(x, wp, 1), reps=10)
     F.conv3d(x, wt, padding=1)
     ms_t = timeit(lambda: F.conv3d(x, wt, padding=1), reps=10)
     nbytes = x.numel() * 4 + D * H * W * 4
@@ -186,9 +202,8 @@ def roi(dev):
         x1, y1 = rs.uniform(0, 1987 - side), rs.uniform(0, 600 - side)
         rois = torch.tensor(np.stack([np.zeros(n), x1, y1, x1 + side, y1 + side * rs.uniform(0.5, 1.0, n)], 1).astype(np.float32), device=dev)
         ms = timeit(lambda: ops.roi_align(feat, rois, pooled, 1.0 / stride, 2), reps=20)
-        os.environ["ADV_ROI_FWD_DIRECT"] = "1"
-        ms_d = timeit(lambda: ops.roi_align(feat, rois, pooled, 1.0 / stride, 2), reps=20)
-        del os.environ["ADV_ROI_FWD_DIRECT"]
+        with hooks_route(ADV_ROI_FWD_DIRECT="1"):
+            ms_d = timeit(lambda: ops.roi_align(feat, rois, pooled, 1.0 / stride, 2), reps=20)
         print(json.dumps(dict(kernel="roi_align_fwd<paired loads> %s: %d rois x 256 ch on %dx%d, %dx%d bins" % (name, n, h, w, pooled, pooled), ms=round(ms, 4),
                               single_gathers_ms=round(ms_d, 4), speedup=round(ms_d / ms, 2))))
 

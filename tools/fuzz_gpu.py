@@ -44,9 +44,13 @@ def conv_case(rs, dev, big=False):
                     "ADV_CONV_CLASS_LAUNCHES"])
     skip = bool(rs.rand() < 0.4)
     env = {"ADV_CONV_TH4": ("ADV_CONV_TH", "4"), "ADV_CONV_TH8": ("ADV_CONV_TH", "8")}.get(sw, (sw, "1") if sw else None)
-    if env:
-        os.environ[env[0]] = env[1]
-    try:
+    import contextlib
+    from eval_driving_safety_amd import _lib
+    with contextlib.ExitStack() as stack:        # a switched case runs on the -DADV_TEST_HOOKS build, an unswitched one on the shipped library
+        if env:
+            stack.enter_context(_lib.using(_lib.HOOKS_LIB_PATH))
+            os.environ[env[0]] = env[1]
+            stack.callback(os.environ.pop, env[0])
         tx, tw = torch.tensor(x, device=dev), torch.tensor(wt, device=dev)
         tb = None if bias is None else torch.tensor(bias, device=dev)
         def plus_skip(conv, sk):        # the epilogue's order: accumulate, + bias, + skip, max
@@ -70,9 +74,6 @@ def conv_case(rs, dev, big=False):
             yt = ops.conv_transpose3d_k3_s2(tx, ops.conv_transpose3d_k3_s2_prep(torch.tensor(wtt, device=dev)), cout, relu=relu, bias=tb,
                                             residual=None if sk2 is None else torch.tensor(sk2, device=dev))
             same(yt, plus_skip(lambda r: C.conv_transpose3d_k3_s2(x, wtt, bias=bias, relu=r), sk2), "transposed conv %s" % ((b, cin, cout, d, h, w, sw, skip),))
-    finally:
-        if env:
-            del os.environ[env[0]]
 
 
 def grid_case(rs, dev):
