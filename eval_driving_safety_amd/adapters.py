@@ -248,21 +248,26 @@ class PsvStereoAdapter:
                     reg[i, k * 7 + j][m] = val[m]
                 ctr[i, k][m] = (1 - (dz.abs() / (wd / 2)).clamp(max=1))[m] * (1 - (dx.abs() / (l / 2)).clamp(max=1))[m]
         dev = self.device
-        return cls.reshape(-1).contiguous().to(dev), reg.to(dev), ctr.to(dev)
+        # The labels do not change over the N iterations of an attack: everything the loss needs from them is computed HERE, once -
+        # the number of positives as a Python int, the positives as flat index lists, the targets already gathered - so that an
+        # iteration reads nothing back from the device (no .item(), no bool(tensor), no boolean-mask indexing = nonzero + D2H).
+        pos = (cls > 0).permute(0, 3, 1, 2).contiguous()                                      # [B,A,Z,X]
+        posr = pos.repeat_interleave(7, dim=1)
+        pos_idx, posr_idx = torch.nonzero(pos.reshape(-1)).view(-1), torch.nonzero(posr.reshape(-1)).view(-1)
+        return {"cls": cls.reshape(-1).contiguous().to(dev), "npos": max(1, int(pos_idx.numel())), "any": bool(pos_idx.numel() > 0),
+                "pos_idx": pos_idx.to(dev), "posr_idx": posr_idx.to(dev),
+                "reg_pos": reg.reshape(-1)[posr_idx].to(dev), "ctr_pos": ctr.reshape(-1)[pos_idx].to(dev)}
 
     def detection_loss(self, maps, targets):
         """sigmoid focal / N_pos + smooth-L1 on the positives + BCE centerness on the positives (the three RPN3DLoss terms)"""
         cls, reg, ctr = maps
-        tcls, treg, tctr = targets
-        b, a, zg, xg = cls.shape
+        t = targets
         logits = cls.permute(0, 2, 3, 1).reshape(-1, 1).contiguous()                       # [B*Z*X*A, 1]: one class ("Car")
-        npos = max(1, int((tcls > 0).sum().item()))
-        l_cls = self.ops.SigmoidFocalLoss.apply(logits, tcls, 2.0, 0.25) / npos
-        pos = (tcls > 0).view(b, zg, xg, a).permute(0, 3, 1, 2)                            # [B,A,Z,X]
-        posr = pos.repeat_interleave(7, dim=1)
-        if bool(pos.any()):
-            l_reg = F.smooth_l1_loss(reg[posr], treg[posr], reduction="sum") / npos
-            l_ctr = F.binary_cross_entropy_with_logits(ctr[pos], tctr[pos], reduction="sum") / npos
+        npos = t["npos"]
+        l_cls = self.ops.SigmoidFocalLoss.apply(logits, t["cls"], 2.0, 0.25) / npos
+        if t["any"]:                                                                       # host-side facts of the label set: no sync
+            l_reg = F.smooth_l1_loss(reg.reshape(-1).index_select(0, t["posr_idx"]), t["reg_pos"], reduction="sum") / npos
+            l_ctr = F.binary_cross_entropy_with_logits(ctr.reshape(-1).index_select(0, t["pos_idx"]), t["ctr_pos"], reduction="sum") / npos
         else:
             l_reg = l_ctr = cls.sum() * 0
         return l_cls + l_reg + l_ctr
@@ -439,22 +444,32 @@ class PsvStereoAdapter:
         depth = self.ops.DepthRegress.apply(score.contiguous(), self.depth_up, self.up_size, False)
         return depth, self.detection_maps(feat, score)
 
+    def _depth_targets(self, gt):
+        """the valid-depth mask of pgd_attack.py:269 as a flat index list + the depths it selects, computed once per ground-truth
+        tensor (it does not change over the iterations of an attack): an iteration then gathers by index, with no nonzero / D2H"""
+        key = (gt.data_ptr(), tuple(gt.shape), gt._version)
+        if getattr(self, "_gt_key", None) != key:
+            lo, hi = float(self.depth[0]), float(self.depth[-1]) + 0.8
+            mask = (gt > lo) & (gt <= hi)
+            idx = torch.nonzero(mask.reshape(-1)).view(-1)
+            self._gt_cache, self._gt_key = (idx, gt.reshape(-1).index_select(0, idx)), key
+        return self._gt_cache
+
     def loss_and_grad(self, x, extra):
         """extra.disp_true [B,H,W] sparse metric depth (0 = no measurement); mask as pgd_attack.py:269"""
         h = _LeafGrad(x)
         with h as leaf:
             imgL, imgR = split_eyes(leaf)
-            gt = extra.disp_true
-            mask = (gt > float(self.depth[0])) & (gt <= float(self.depth[-1]) + 0.8)
+            gt_idx, gt_sel = self._depth_targets(extra.disp_true)
             if self.dsgn_head:      # pgd_attack.py:310-336: depth term + the detection head's three terms
                 pred, maps = self.forward_all(imgL, imgR)
                 key = (tuple(maps[0].shape), tuple(tuple(tuple(float(v) for v in bx) for bx in img) for img in extra.boxes))
                 if getattr(self, "_tgt_key", None) != key:     # targets depend on the labels only: once per label set, not per step
                     self._tgt, self._tgt_key = self.detection_targets(extra.boxes, maps[0].shape[2], maps[0].shape[3]), key
-                loss = F.smooth_l1_loss(pred[mask], gt[mask], reduction="mean") + self.detection_loss(maps, self._tgt)
+                loss = F.smooth_l1_loss(pred.reshape(-1).index_select(0, gt_idx), gt_sel, reduction="mean") + self.detection_loss(maps, self._tgt)
             else:
                 pred = self.depth_pred(imgL, imgR)
-                loss = F.smooth_l1_loss(pred[mask], gt[mask], reduction="mean")
+                loss = F.smooth_l1_loss(pred.reshape(-1).index_select(0, gt_idx), gt_sel, reduction="mean")
             loss.backward()
             return loss.detach(), h.take()
 

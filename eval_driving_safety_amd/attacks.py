@@ -136,7 +136,9 @@ class PgdAttack:
             u8[:b2].copy_(batch.imgL, non_blocking=batch.imgL.is_pinned())                               # reading page-locked memory
             u8[b2:].copy_(batch.imgR, non_blocking=batch.imgR.is_pinned())                               # back on the CPU is slow
             valid = None if batch.sizes is None else [(s[1], s[0]) for s in batch.sizes] * 2
-            imported = ops.import_u8(u8, sp, batch.pad_to, valid=valid)
+            # the loader's arithmetic is true divisions whichever way the steps re-normalise: import with the plain DSGN space
+            # (adv_import_u8_f32 takes no AFFINE_RCP space), keep ``sp`` (possibly the reference-on-GPU space) for the steps
+            imported = ops.import_u8(u8, ops.Space.dsgn() if sp.affine else sp, batch.pad_to, valid=valid)
             x = imported[0]
         else:
             x = _stack_on_device(batch, dev)

@@ -47,9 +47,6 @@ def add_engine_flags(parser):
     g.add_argument("--reference_on_gpu", action="store_true",
                    help="DSGN PGD: re-normalise as torch's GPU kernels do (multiply by the reciprocal) - bit-identical to a GPU run of "
                         "the reference script; default: bit-identical to its CPU run")
-    g.add_argument("--device_import", action="store_true",
-                   help="DSGN PGD on a PNG folder: upload the decoded 8-bit pixels and run ToTensor / Normalize / zero padding on the GPU "
-                        "(same bits as the host transform; a quarter of the upload, the clean image and its index for free)")
     g.add_argument("--loader_workers", type=int, default=None,
                    help="decode threads of the folder reader (default: the reference's 12, attack/DSGN/pgd_attack.py:79; 0 with --debug)")
 

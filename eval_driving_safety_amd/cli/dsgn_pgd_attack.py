@@ -30,7 +30,7 @@ def main(argv=None):
         batch = args.btest if args.btest else 1
         workers = args.loader_workers if args.loader_workers is not None else (0 if args.debug else 12)
         loader = data.SyntheticStereo(args.synthetic, "dsgn", batch, seed=args.seed) if args.synthetic \
-            else data.KittiFolder(args.data_path, args.split_file, batch, workers=workers, as_u8=args.device_import)
+            else data.KittiFolder(args.data_path, args.split_file, batch, workers=workers)
         if args.model == "toy":
             adapter = adapters.ToyStereoAdapter(dev, seed=args.seed)
         else:   # plane-sweep volume (HIP) -> 3D hourglass on the float32 matrix cores -> depth loss; synthetic sparse depth

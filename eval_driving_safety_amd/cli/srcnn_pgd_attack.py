@@ -11,7 +11,8 @@ def build_parser():
     parser = argparse.ArgumentParser(description="PGD / FGSM perturbation of KITTI stereo pairs against Stereo R-CNN (counterpart of attack/Stereo-RCNN/pgd_attack.py)")
     parser.add_argument("--iter", type=int, default=4, help="number of PGD steps (1 = FGSM)")
     parser.add_argument("--alpha", default=1.0, type=float, help="step size per iteration (in the model's pixel units: 1/255 of the [0,1] range for DSGN, grey levels for Stereo R-CNN)")
-    parser.add_argument("--eps", default=0.3, type=float)                  # scaled by 255 (:57, help="L-infinity budget (DSGN: fraction of the [0,1] range; Stereo R-CNN: multiplied by 255)")
+    parser.add_argument("--eps", default=0.3, type=float,                  # scaled by 255 (:57)
+                        help="L-infinity budget (DSGN: fraction of the [0,1] range; Stereo R-CNN: multiplied by 255)")
     parser.add_argument("--debug", action="store_true", default=False, help="stop after --debugnum frames and read the data in the main process")
     parser.add_argument("--debugnum", default=None, type=int, help="how many frames a --debug run handles (the scripts differ by one, see DESIGN.md Q15)")
     parser.add_argument("--seed", type=int, default=3, help="seed of torch's generators")

@@ -7,6 +7,7 @@ Nothing upstream is vendored here: ``dsgn.*`` / ``env_utils`` (DSGN) and ``model
 restates.  The tests drive these builders with stand-in packages of the same names (tests/fake_upstream/)."""
 import importlib
 import os
+import re
 import types
 
 import numpy as np
@@ -47,9 +48,20 @@ def resolve_devices(devices, mem_info):
 
 
 def used_memory_per_gpu():
-    """stand-in for upstream ``env_utils.mem_info`` when it is absent: bytes in use per visible GPU"""
+    """stand-in for upstream ``env_utils.mem_info`` when it is absent: bytes in use per visible GPU.  Read from the driver's sysfs
+    counters (``mem_info_vram_used`` of the amdgpu render nodes) so that choosing a GPU does not create a HIP context on every
+    one of them; only where those files are not readable does it fall back to ``torch.cuda.mem_get_info``."""
+    import glob
+    n = torch.cuda.device_count()                   # counts devices without initialising them
+    files = sorted(glob.glob("/sys/class/drm/card*/device/mem_info_vram_used"),
+                   key=lambda p: int(re.search(r"card(\d+)", p).group(1)))
+    if len(files) == n and not (os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES")):
+        try:
+            return [int(open(p).read()) for p in files]
+        except (OSError, ValueError):
+            pass
     out = []
-    for i in range(torch.cuda.device_count()):
+    for i in range(n):
         free, total = torch.cuda.mem_get_info(i)
         out.append(total - free)
     return out
@@ -61,7 +73,10 @@ def pick_device(devices, mem_info=None):
     if not torch.cuda.is_available():
         raise SystemExit("no ROCm device: this engine has no CPU path")
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        index = 0 if os.environ.get("ADV_SHARE_GPU") == "1" else int(os.environ.get("LOCAL_RANK", "0"))   # ADV_SHARE_GPU: 1-GPU test boxes
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        ids = [int(v) for v in resolve_devices(devices, mem_info or used_memory_per_gpu).split(",")] if devices else []
+        # an explicit --devices list (a-b or a,b,c) is indexed by LOCAL_RANK; without one rank k drives GPU k
+        index = 0 if os.environ.get("ADV_SHARE_GPU") == "1" else (ids[local] if local < len(ids) and len(ids) > 1 else local)   # ADV_SHARE_GPU: 1-GPU test boxes
         resolved = str(index)
     else:
         resolved = resolve_devices(devices, mem_info or used_memory_per_gpu)

@@ -99,7 +99,8 @@ class KittiFolder:
             a = np.array(im.convert("RGB"))
         if self.as_u8:      # already in the common buffer shape (the network frame), so that a batch is a plain stack
             buf = np.zeros((self.pad_to[0], self.pad_to[1], 3), np.uint8)
-            buf[:a.shape[0], :a.shape[1]] = a[:self.pad_to[0], :self.pad_to[1]]
+            a = a[:self.pad_to[0], :self.pad_to[1]]         # an oversize frame is clipped to the network frame, and so is its reported size
+            buf[:a.shape[0], :a.shape[1]] = a
             return torch.from_numpy(buf), (a.shape[1], a.shape[0])
         u8 = torch.from_numpy(np.ascontiguousarray(a.transpose(2, 0, 1)))
         return dsgn_transform(u8, self.pad_to), (u8.shape[2], u8.shape[1])

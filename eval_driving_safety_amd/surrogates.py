@@ -103,6 +103,22 @@ class StereoRcnnShaped(nn.Module):
             p[i] = up + self.lat[i](feats[i])
         return [self.smooth[i](p[i]) for i in range(4)]
 
+    def pyramid_pair(self, im_left, im_right):
+        """both eyes through the shared backbone (stereo_rcnn.py:157-187 runs them one after the other)"""
+        return self.pyramid(im_left), self.pyramid(im_right)
+
+    def rpn_features(self, feat_l, feat_r):
+        """stereo_rpn.py:73-80: the shared 3x3 convolution on each eye, concatenated left | right"""
+        return torch.cat([F.relu(self.rpn_conv(feat_l)), F.relu(self.rpn_conv(feat_r))], 1)
+
+    def head_to_tail(self, pooled):
+        return F.relu(self.fc(pooled.flatten(1)))
+
+    def kpts_logits(self, feat14):
+        """[R,C,14,14] -> [R,6,28]: 4 keypoint types + left border + right border over the 28 horizontal bins"""
+        k = self.kpts_class(F.relu(self.kpts_conv(feat14)))
+        return F.interpolate(k, size=(14, self.GRID), mode="bilinear", align_corners=False).mean(2)
+
     def anchors(self, level_idx, h, w, device):
         stride = 4 * 2 ** level_idx
         size = 8.0 * stride
@@ -135,11 +151,11 @@ class StereoRcnnShaped(nn.Module):
         nms = self._nms or ops.nms
         dev = im_left.device
         H, W = float(im_info[0][0]), float(im_info[0][1])
-        fl, fr = self.pyramid(im_left), self.pyramid(im_right)
-        # ---- stereo RPN on every level
+        fl, fr = self.pyramid_pair(im_left, im_right)
+        # ---- stereo RPN on every level (the pyramid may carry levels beyond P5 for the RPN only, stereo_rcnn.py:169,189-193)
         scores, deltas, anchors = [], [], []
-        for i in range(4):
-            both = torch.cat([F.relu(self.rpn_conv(fl[i])), F.relu(self.rpn_conv(fr[i]))], 1)
+        for i in range(len(fl)):
+            both = self.rpn_features(fl[i], fr[i])
             s, d = self.rpn_cls(both), self.rpn_reg(both)
             scores.append(s.permute(0, 2, 3, 1).reshape(-1))
             deltas.append(d.permute(0, 2, 3, 1).reshape(-1, 6))
@@ -174,6 +190,10 @@ class StereoRcnnShaped(nn.Module):
             left, right = left[keep], right[keep]
             if n_gt > 0:                  # the ground truth joins the proposals, as in the proposal-target layer (stereo_rcnn.py:201-204)
                 left, right = torch.cat([gt_l, left]), torch.cat([gt_r, right])
+            rpi = getattr(self, "rois_per_image", None)
+            if rpi:                       # the proposal-target layer hands on exactly cfg.TRAIN.BATCH_SIZE rois, sampled with replacement
+                idx = torch.arange(rpi, device=dev) % left.shape[0]
+                left, right = left[idx], right[idx]
             zeros = left.new_zeros((left.shape[0], 1))
             rois_l, rois_r = torch.cat([zeros, left], 1), torch.cat([zeros, right], 1)
             if n_gt > 0:
@@ -184,12 +204,11 @@ class StereoRcnnShaped(nn.Module):
                 arg = torch.zeros(left.shape[0], dtype=torch.long, device=dev)
                 rois_label = torch.zeros(left.shape[0], dtype=torch.long, device=dev)
         # ---- box / dimension heads on the concatenated left|right 7x7 features, keypoint head on the left 14x14 feature
-        pooled = torch.cat([self.pyramid_roi_feat(fl, rois_l, im_info, 7), self.pyramid_roi_feat(fr, rois_r, im_info, 7)], 1)
-        top = F.relu(self.fc(pooled.flatten(1)))
+        pooled = torch.cat([self.pyramid_roi_feat(fl[:4], rois_l, im_info, 7), self.pyramid_roi_feat(fr[:4], rois_r, im_info, 7)], 1)
+        top = self.head_to_tail(pooled)
         cls_score, bbox_pred, dim_pred = self.cls_score(top), self.bbox_pred(top), self.dim_orien_pred(top)
         cls_prob = F.softmax(cls_score, 1)
-        k = self.kpts_class(F.relu(self.kpts_conv(self.pyramid_roi_feat(fl, rois_l, im_info, 14))))
-        k = F.interpolate(k, size=(14, self.GRID), mode="bilinear", align_corners=False).mean(2)      # [R, 6, 28]
+        k = self.kpts_logits(self.pyramid_roi_feat(fl[:4], rois_l, im_info, 14))                      # [R, 6, 28]
         kpts_prob = F.softmax(k[:, :4].reshape(k.shape[0], -1), 1)
         left_prob, right_prob = F.softmax(k[:, 4], 1), F.softmax(k[:, 5], 1)
         # ---- RCNN losses (computed in eval mode, as the reference's substitute files do)
@@ -230,3 +249,162 @@ def synthetic_srcnn_extra(batch, device, max_boxes=30):
     kpts[:, 0] = torch.tensor([900.0, 1.0, 0.0, 830.0, 1090.0, 0.0], device=device)
     return types.SimpleNamespace(im_info=torch.tensor([[600.0, 1987.0, 1.6]], device=device), gt_boxes_left=left, gt_boxes_right=right,
                                  gt_boxes_merge=left.clone(), gt_dim_orien=dim_orien, gt_kpts=kpts, num_boxes=torch.tensor([1], device=device))
+
+
+# ----------------------------------------------------------------------------------------------------------------------------
+# The same detector with the upstream LAYER LIST: ResNet-101 + FPN + stereo RPN + RoI heads (attack/Stereo-RCNN/pgd_attack.py:89-90
+# builds ``resnet(imdb.classes, 101)``; stereo_rcnn.py:157-187 names the stages and their channel counts).  Random weights, frozen
+# batch-norms folded into the convolutions (the attack runs the detector in eval mode, where a BatchNorm2d is a per-channel affine
+# map): what it is for is an honest FLOP count and an end-to-end time for BASELINE configs[2] - not detections.
+class FoldedConv(nn.Module):
+    """conv2d + folded eval-mode batch-norm (= a bias) [+ residual] [+ ReLU].  ``impl`` picks who computes it:
+    "miopen" = torch's operator (MIOpen / rocBLAS on ROCm), "hip" = this package's float32-MFMA kernels (ops.Conv2d) where one
+    exists for the layer's shape, MIOpen otherwise.  ``flops`` accumulates 2 * MACs of every forward call (FLOP accounting)."""
+    impl = "miopen"
+    trace = None          # a list: every forward call appends (cin, cout, k, stride, padding, batch, h, w) - tools/bench_conv2d_layers.py
+
+    def __init__(self, cin, cout, k, stride=1, padding=0, gen=None, gain=1.0):
+        super().__init__()
+        w = torch.randn((cout, cin, k, k), generator=gen) * (gain * (2.0 / (cin * k * k)) ** 0.5)
+        self.weight = nn.Parameter(w, requires_grad=False)
+        self.bias = nn.Parameter(torch.randn((cout,), generator=gen) * 0.02, requires_grad=False)
+        self.stride, self.padding, self.k = stride, padding, k
+        self.flops = 0
+        self._prep = None
+
+    def forward(self, x, relu=False, residual=None):
+        ho = (x.shape[2] + 2 * self.padding - self.k) // self.stride + 1
+        wo = (x.shape[3] + 2 * self.padding - self.k) // self.stride + 1
+        self.flops += 2 * x.shape[0] * self.weight.shape[0] * self.weight.shape[1] * self.k * self.k * ho * wo
+        if FoldedConv.trace is not None:
+            FoldedConv.trace.append((self.weight.shape[1], self.weight.shape[0], self.k, self.stride, self.padding, x.shape[0], x.shape[2], x.shape[3]))
+        if FoldedConv.impl == "hip":
+            from . import ops
+            if ops.conv2d_supported(x, self.weight, self.stride, self.padding):
+                if self._prep is None or self._prep.device != x.device:
+                    self._prep = ops.Conv2dPrep(self.weight, self.stride, self.padding)
+                return ops.Conv2d.apply(x, self._prep, self.bias, residual, relu)
+        y = F.conv2d(x, self.weight, self.bias, self.stride, self.padding)
+        if residual is not None:
+            y = y + residual
+        return F.relu(y) if relu else y
+
+
+class _FoldedBottleneck(nn.Module):
+    """1x1 (stride here, as the upstream resnet.py of the fpn.pytorch family places it [UPSTREAM-UNVERIFIED]) -> 3x3 -> 1x1 (x4),
+    identity or a strided 1x1 projection on the skip path; batch-norms folded"""
+
+    def __init__(self, cin, width, stride, gen):
+        super().__init__()
+        self.conv1 = FoldedConv(cin, width, 1, stride=stride, gen=gen)
+        self.conv2 = FoldedConv(width, width, 3, padding=1, gen=gen)
+        self.conv3 = FoldedConv(width, 4 * width, 1, gen=gen, gain=0.3)          # a small last scale keeps 33 residual sums bounded
+        self.down = FoldedConv(cin, 4 * width, 1, stride=stride, gen=gen) if (stride != 1 or cin != 4 * width) else None
+
+    def forward(self, x):
+        idt = x if self.down is None else self.down(x)
+        y = self.conv2(self.conv1(x, relu=True), relu=True)
+        return self.conv3(y, relu=True, residual=idt)
+
+
+class StereoRcnnR101(StereoRcnnShaped):
+    """ResNet-101-FPN Stereo R-CNN SHAPE: stem 7x7/2 + max-pool, bottleneck stacks [3, 4, 23, 3] (C2..C5 = 256/512/1024/2048 channels
+    at strides 4/8/16/32), FPN top-down path with 256-channel laterals and 3x3 smoothing (P2..P5) and P6 = stride-2 subsampling of P5
+    for the RPN (stereo_rcnn.py:39,157-171), stereo RPN 3x3 256->512 per eye -> 1x1 on the 1024-channel concatenation (stereo_rpn.py:32-40),
+    RoIAlign 7x7 on both eyes -> 512-channel concatenation -> 7x7 convolution to 2048 + 1x1 (the ``_head_to_tail`` of the fpn.pytorch
+    family [UPSTREAM-UNVERIFIED widths]) -> class / 6-d box / 5-d dimension+orientation; RoIAlign 14x14 on the left eye -> six 3x3
+    convolutions + a 2x2 stride-2 transposed convolution to 28x28 -> 1x1 to 6 maps summed over the rows (stereo_rcnn.py:262-266).
+    ``rois_per_image``: what the proposal-target layer samples [cfg.TRAIN.BATCH_SIZE, UPSTREAM-UNVERIFIED: 512 assumed]; the
+    proposals of this network are padded / cut to exactly that many, as the upstream sampler does with replacement."""
+    BLOCKS = (3, 4, 23, 3)
+
+    def __init__(self, classes=("__background__", "Car"), num_layers=101, pretrained=False, seed=0, post_nms=300, pre_nms=2000,
+                 rois_per_image=512, roi_align=None, nms=None, blocks=None):
+        nn.Module.__init__(self)
+        self.classes, self.n_classes = classes, len(classes)
+        self.post_nms, self.pre_nms, self.rois_per_image = post_nms, pre_nms, rois_per_image
+        self._roi_align, self._nms = roi_align, nms
+        g = torch.Generator().manual_seed(seed)
+        self.stem = FoldedConv(3, 64, 7, stride=2, padding=3, gen=g)
+        cin = 64
+        for i, (width, n, stride) in enumerate(zip((64, 128, 256, 512), blocks or self.BLOCKS, (1, 2, 2, 2)), start=1):
+            mods = []
+            for b in range(n):
+                mods.append(_FoldedBottleneck(cin, width, stride if b == 0 else 1, g))
+                cin = 4 * width
+            setattr(self, "layer%d" % i, nn.Sequential(*mods))
+        c = 256
+        self.top = FoldedConv(2048, c, 1, gen=g)                                  # RCNN_toplayer
+        self.lat = nn.ModuleList(FoldedConv(ci, c, 1, gen=g) for ci in (1024, 512, 256))       # RCNN_latlayer1..3 (C4, C3, C2)
+        self.smooth = nn.ModuleList(FoldedConv(c, c, 3, padding=1, gen=g) for _ in range(3))   # RCNN_smooth1..3 (P4, P3, P2)
+        a = len(self.ANCHOR_RATIOS)
+        self.rpn_conv = FoldedConv(c, 512, 3, padding=1, gen=g)
+        self.rpn_cls = FoldedConv(1024, a, 1, gen=g, gain=0.05)
+        self.rpn_reg = FoldedConv(1024, 6 * a, 1, gen=g, gain=0.05)
+        self.top7 = FoldedConv(2 * c, 2048, 7, gen=g)                             # RCNN_top: 7x7 "fully connected" convolution on the pooled grid
+        self.top1 = FoldedConv(2048, 2048, 1, gen=g)
+        self.cls_score = nn.Linear(2048, self.n_classes)
+        self.bbox_pred = nn.Linear(2048, 6 * self.n_classes)
+        self.dim_orien_pred = nn.Linear(2048, 5 * self.n_classes)
+        self.kpts_convs = nn.ModuleList(FoldedConv(c, c, 3, padding=1, gen=g) for _ in range(6))
+        self.kpts_up = nn.ConvTranspose2d(c, c, 2, stride=2)
+        self.kpts_class = FoldedConv(c, 6, 1, gen=g, gain=0.1)
+        with torch.no_grad():
+            for m in (self.cls_score, self.bbox_pred, self.dim_orien_pred, self.kpts_up):
+                m.weight.copy_(torch.randn(m.weight.shape, generator=g) * (1.0 / m.weight[0].numel()) ** 0.5)
+                m.bias.zero_()
+        for p in self.parameters():
+            p.requires_grad_(False)                                               # the attack differentiates w.r.t. the images only
+
+    # -- FLOP accounting -------------------------------------------------------------------------------------------------
+    def reset_flops(self):
+        for m in self.modules():
+            if isinstance(m, FoldedConv):
+                m.flops = 0
+        self._extra_flops = 0
+
+    def flops_by_class(self):
+        """{layer class: forward FLOPs (2 x MACs) since reset_flops()}; the backward w.r.t. the input costs the same again per layer"""
+        out = {}
+        for name, m in self.named_modules():
+            if isinstance(m, FoldedConv) and m.flops:
+                key = "%dx%d s%d" % (m.k, m.k, m.stride)
+                out[key] = out.get(key, 0) + m.flops
+        out["linear + transposed 2x2"] = getattr(self, "_extra_flops", 0)
+        return out
+
+    # -- backbone + pyramid: both eyes as one batch of two ------------------------------------------------------------------
+    def pyramid(self, im):
+        x = F.max_pool2d(self.stem(im, relu=True), 3, stride=2, padding=1)
+        c2 = self.layer1(x)
+        c3 = self.layer2(c2)
+        c4 = self.layer3(c3)
+        c5 = self.layer4(c4)
+        p5 = self.top(c5)
+        p = [None, None, None, p5]
+        for i, (lat, feat) in enumerate(zip(self.lat, (c4, c3, c2))):            # _upsample_add then smooth (stereo_rcnn.py:164-169)
+            lvl = 2 - i
+            up = F.interpolate(p[lvl + 1], size=feat.shape[2:], mode="bilinear", align_corners=False)
+            p[lvl] = self.smooth[i](lat(feat, residual=up))
+        p6 = p5[:, :, ::2, ::2]                                                   # nn.MaxPool2d(1, stride=2) (stereo_rcnn.py:39,170)
+        return p + [p6]
+
+    def pyramid_pair(self, im_left, im_right):
+        feats = self.pyramid(torch.cat([im_left, im_right], 0) / 64.0)
+        b = im_left.shape[0]
+        return [f[:b] for f in feats], [f[b:] for f in feats]
+
+    def rpn_features(self, feat_l, feat_r):
+        return torch.cat([self.rpn_conv(feat_l, relu=True), self.rpn_conv(feat_r, relu=True)], 1)
+
+    def head_to_tail(self, pooled):
+        self._extra_flops = getattr(self, "_extra_flops", 0) + 2 * pooled.shape[0] * 2048 * 13 * self.n_classes
+        return self.top1(self.top7(pooled, relu=True), relu=True).flatten(1)
+
+    def kpts_logits(self, feat14):
+        x = feat14
+        for conv in self.kpts_convs:
+            x = conv(x, relu=True)
+        self._extra_flops = getattr(self, "_extra_flops", 0) + 2 * x.shape[0] * 256 * 256 * 4 * 14 * 14
+        x = F.relu(self.kpts_up(x))                                               # [R,256,28,28]
+        return self.kpts_class(x).sum(2)                                          # [R,6,28]  (stereo_rcnn.py:264-266)

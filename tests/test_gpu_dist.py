@@ -44,6 +44,23 @@ def test_bench_two_ranks_on_one_gpu():
     assert "cpu_baseline" not in d                                                                              # rank 0 at N = 1 only
 
 
+def test_bench_launches_its_own_ranks_when_started_plainly():
+    """`python bench.py --gpus 2` with NO launcher around it (the way the driver starts --gpus 1): the parent starts the two ranks as a
+    child torch.distributed.run, relays rank 0's one JSON line and its exit status; the line says what the process group says"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4", ADV_BENCH_SHARE_GPU="1", ADV_BENCH_BACKEND="gloo")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--pairs", "8"], cwd=ROOT,
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_world"] == 2 and d["backend"] == "gloo" and d["launched_by"].startswith("bench.py itself")
+    assert len(d["per_rank"]["pairs_per_s"]) == 2 and d["per_rank"]["pairs_per_s_min"] <= d["per_rank"]["pairs_per_s_max"]
+    assert abs(d["value"] - 2 * d["per_rank"]["pairs_per_s_min"]) < 1e-6 * d["value"]          # whole job = all pairs / the slowest rank's time
+    assert d["patch_allreduce"]["correct"] is True and d["patch_allreduce"]["avg_us"] > 0
+
+
 @pytest.mark.parametrize("average", [False, True])
 def test_patch_trainer_two_ranks_hip_ops_real_comm(tmp_path, average):
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))

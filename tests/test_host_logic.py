@@ -536,3 +536,24 @@ def test_cli_accepts_every_reference_flag_with_the_reference_default(rel, golden
             assert act.dest == flag["dest"], (rel, flag)
     # and the defaults parse: the reference's no-argument invocation is accepted as it stands
     parser.parse_args([])
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    """a launcher that started 2 ranks for `--gpus 4` must not produce a line labelled n_gpus 2: exit 2 before any GPU call"""
+    import subprocess
+    import sys
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         text=True, timeout=300)
+    assert out.returncode == 2 and "WORLD_SIZE=2" in out.stderr and not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_parent_relays_the_childs_failure():
+    """no GPU here: the self-launched ranks fail, and the parent must exit non-zero without printing a JSON line"""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(PYTHONPATH=ROOT, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--pairs", "2"], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")]

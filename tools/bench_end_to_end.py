@@ -83,6 +83,58 @@ def measure(pairs=1, iters=20, reps=2, warm_iters=None, mfma_conv=True, hourglas
                 "libadvengine.so"}
 
 
+def measure_srcnn_r101(pairs=1, iters=20, reps=1, rois=512, impl="miopen"):
+    """BASELINE configs[2] with the upstream LAYER LIST (surrogates.StereoRcnnR101: ResNet-101 [3,4,23,3] + FPN P2-P6 + stereo RPN + RoI
+    heads, random weights, batch-norms folded): 20-step PGD at 600x1987, exact FLOPs per detector step from the layer list, the
+    whole-step rate against the float32 matrix peak.  ``impl``: "miopen" = every 2D convolution through torch (MIOpen / rocBLAS),
+    "hip" = libadvengine's float32-MFMA kernels where one exists for the shape."""
+    from eval_driving_safety_amd import surrogates
+    dev = torch.device("cuda", torch.cuda.current_device())
+    surrogates.FoldedConv.impl = impl
+    try:
+        model = surrogates.StereoRcnnR101(seed=0, rois_per_image=rois).to(dev).eval()
+        net = adapters.StereoRcnnAdapter(model, torch.zeros(6, device=dev))
+        batch = next(iter(data.SyntheticStereo(pairs, "srcnn", batch=pairs, seed=0)))
+        batch.extra = surrogates.synthetic_srcnn_extra(batch, dev)
+        x = torch.cat([batch.imgL, batch.imgR]).to(dev)
+        for _ in range(2):                       # MIOpen's solver search, kernel loads
+            net.loss_and_grad(x, batch.extra)
+        torch.cuda.synchronize()
+        model.reset_flops()
+        net.loss_and_grad(x, batch.extra)
+        by_class = model.flops_by_class()
+        fwd = float(sum(by_class.values()))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            net.loss_and_grad(x, batch.extra)
+        e1.record()
+        torch.cuda.synchronize()
+        model_ms = e0.elapsed_time(e1) / 5
+        atk = attacks.PgdAttack("srcnn", 1.0, 0.03, iters, save=False, device=dev)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            atk.run_batch(batch, net)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        peak = torch.cuda.max_memory_allocated() / 2 ** 30
+    finally:
+        surrogates.FoldedConv.impl = "miopen"
+    step = 2.0 * fwd                               # forward + backward w.r.t. the input: every layer's adjoint costs its forward
+    first, last = float(atk.last_losses[0]), float(atk.last_losses[-1])
+    return {"metric": "end-to-end stereo-pairs/s, %d-step PGD through a ResNet-101-FPN Stereo R-CNN-shaped detector (upstream layer list, random weights), 600x1987" % iters,
+            "value": pairs / dt, "unit": "stereo-pairs/s", "pairs": pairs, "iters": iters, "s_per_attack": dt, "detector_fwd_bwd_ms": model_ms,
+            "flops_per_step": step, "flops_fwd_by_layer_class": {k: v for k, v in by_class.items()},
+            "roofline": {"bound": "mfma", "what": "WHOLE detector step (forward + input-gradient backward, every kernel incl. RoIAlign, NMS, "
+                                                   "losses, element-wise) against the float32 matrix peak",
+                         "achieved": step / model_ms / 1e9, "peak": 157.3, "unit": "TFLOP/s", "frac": step / model_ms / 1e9 / 157.3},
+            "convolutions": impl, "rois_per_image": rois, "peak_hbm_gib": peak,
+            "loss_first_iter": first, "loss_last_iter": last, "loss_rose": last > first,
+            "note": "NOT the headline metric and NOT Stereo R-CNN's weights: bottleneck stacks [3,4,23,3] with the stride on the first 1x1, "
+                    "256-channel FPN P2-P6, stereo RPN 3x3 256->512 on both eyes, RoIAlign 7x7 (both eyes) / 14x14 (left) by libadvengine with "
+                    "the deterministic gather backward, ops.nms, six losses; rois_per_image is an assumption (cfg.TRAIN.BATCH_SIZE, upstream)"}
+
+
 def measure_srcnn(pairs=1, iters=20, reps=2):
     """20-step PGD in the Stereo R-CNN pixel space through surrogates.StereoRcnnShaped (siamese backbone + FPN, stereo RPN, ops.nms,
     pyramid ops.RoIAlign 7x7 / 14x14 with the deterministic gather backward, six uncertainty-weighted losses) at 600x1987"""
@@ -168,8 +220,14 @@ def main():
     ap.add_argument("--dsgn-head", action="store_true", help="fused depth regression + 3D geometric volume + bird's-eye-view detection head")
     ap.add_argument("--patch", action="store_true", help="universal-patch training through the DSGN-shaped graph instead")
     ap.add_argument("--srcnn", action="store_true", help="the Stereo R-CNN-shaped surrogate at 600x1987 instead")
+    ap.add_argument("--r101", action="store_true", help="the ResNet-101-FPN Stereo R-CNN-shaped detector (upstream layer list) at 600x1987")
+    ap.add_argument("--rois", type=int, default=512)
+    ap.add_argument("--hip2d", action="store_true", help="--r101: libadvengine's 2D convolution kernels where one exists")
     args = ap.parse_args()
     torch.cuda.set_device(0)
+    if args.r101:
+        print(json.dumps(measure_srcnn_r101(args.pairs, args.iters, args.reps, args.rois, "hip" if args.hip2d else "miopen")))
+        return
     if args.srcnn:
         print(json.dumps(measure_srcnn(args.pairs, args.iters, args.reps)))
         return
