@@ -1,0 +1,270 @@
+// 2D convolutions of the detectors' backbones on the gfx950 float32 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// 1x1 / stride 1 - a plain GEMM per image:  Y_b[co][p] = sum_ci W[co][ci] * X_b[ci][p],  p = h*W + w  (NCHW: X_b is a
+// row-major [Cin][P] matrix as it stands, so no im2col and no transposition):
+//   A operand = one weight per lane (row = output channel = lane & 31, k = lane >> 5), B operand = one input value per lane
+//   (k = lane >> 5, column = pixel = lane & 31); every accumulator register holds 32 consecutive pixels of one output channel,
+//   so the epilogue's loads (skip connection, mask) and stores are 128-byte runs.
+//   A 256-thread workgroup owns BM output channels x BN pixels; per stage of kKC = 16 input channels the X rows [16][BN] and the
+//   weight rows [16][BM] (prepared layout [Cin'][Cout']: a stage is 16 contiguous rows) go global -> registers -> LDS while the
+//   MFMAs of the previous stage run (two LDS buffers, one barrier per stage).  Rows of X are dword-aligned only (P is odd for
+//   most feature maps), hence register staging with dword-aligned float4 loads rather than LDS-DMA.
+//   Four tile shapes (128x256 ... 64x64); the host picks the one that needs the fewest "MFMA rounds" for the layer's size.
+//   Accumulation order: ci ascending, one fmaf per product starting from 0 (the MFMA is a k-ordered fmaf chain), then
+//   + bias, + residual, ReLU, mask - the C oracle restates it bit for bit.
+//   The backward w.r.t. the input is the same kernel on W^T (adv_conv2d_1x1_prep_weights_f32(transpose = 1)); `mask` (the layer's
+//   own input, a ReLU output) turns its result into the gradient w.r.t. the previous layer's PRE-activation in the epilogue.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "adv_internal.h"
+#include "advengine.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef v4f v4f_u __attribute__((aligned(4)));  // a float4 the compiler may not assume 16-byte aligned
+
+constexpr int kKC = 16;  // input channels per LDS stage
+
+struct Epi2 {
+  const float* bias;      // [M] or null
+  const float* residual;  // laid out like y, or null: added after the bias, before the ReLU
+  const float* mask;      // laid out like y, or null: result = mask > 0 ? result : 0, applied last
+  int relu;
+};
+
+template <int WM, int WN, int TM, int TN>
+struct GemmGeo {
+  static_assert(WM * WN == 4, "four waves");
+  static constexpr int kBM = WM * TM * 32, kBN = WN * TN * 32;
+  static constexpr int kXF4 = kKC * kBN / 4 / 256, kWF4 = kKC * kBM / 4 / 256;   // float4 per thread and stage
+  static_assert(kXF4 >= 1 && kWF4 >= 1, "tile too small for 256 loader threads");
+  static constexpr int kStage = kKC * (kBN + kBM);                               // floats per LDS buffer
+};
+
+// x [B][K][P], wp [Kpad][mpad] (zero padded), y [B][M][P].  One workgroup per (m tile, n tile, image); the linear block index is
+// remapped so that each XCD (blocks i, i+8, ... share one) walks a contiguous range of the tile order - m fastest, so the m tiles
+// that re-read one X tile sit in the same L2.
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256, 2) void conv2d_1x1_mfma(const float* __restrict__ x, const float* __restrict__ wp, float* __restrict__ y, int K, int M,
+                                                       int mpad, long long P, int tiles_m, int tiles_n, long long ntiles, Epi2 epi) {
+  using G = GemmGeo<WM, WN, TM, TN>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l32 = lane & 31;
+  const int wm = wave / WN, wn = wave % WN;
+
+  long long t = blockIdx.x;
+  {
+    const long long base = ntiles >> 3, rem = ntiles & 7, xcd = t & 7, j = t >> 3;
+    t = xcd * base + (xcd < rem ? xcd : rem) + j;
+  }
+  const int mt = static_cast<int>(t % tiles_m);
+  const long long r = t / tiles_m;
+  const int nt = static_cast<int>(r % tiles_n);
+  const long long b = r / tiles_n;
+  const int m0 = mt * G::kBM;
+  const long long n0 = static_cast<long long>(nt) * G::kBN;
+  const long long KP = static_cast<long long>(K) * P;
+  const float* xb = x + b * KP;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[i][jn][v] = 0.0f;
+
+  v4f rx[G::kXF4], rw[G::kWF4];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < G::kXF4; ++i) {
+      const int f = tid + 256 * i, row = f / (G::kBN / 4), c4 = f % (G::kBN / 4);
+      const long long off = static_cast<long long>(k0 + row) * P + n0 + c4 * 4;
+      v4f v = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (k0 + row < K) {
+        if (off + 4 <= KP) {
+          v = *reinterpret_cast<const v4f_u*>(xb + off);   // may run past the row's end into the next row: those columns are never stored
+        } else {                                          // the image's last floats: element by element
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (off + e < KP) v[e] = xb[off + e];
+        }
+      }
+      rx[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < G::kWF4; ++i) {
+      const int f = tid + 256 * i, row = f / (G::kBM / 4), c4 = f % (G::kBM / 4);
+      rw[i] = *reinterpret_cast<const v4f*>(wp + static_cast<long long>(k0 + row) * mpad + m0 + c4 * 4);
+    }
+  };
+  auto commit = [&](int buf) {
+    float* sx = lds + buf * G::kStage;
+    float* sw = sx + kKC * G::kBN;
+#pragma unroll
+    for (int i = 0; i < G::kXF4; ++i) {
+      const int f = tid + 256 * i;
+      *reinterpret_cast<v4f*>(sx + 4 * f) = rx[i];     // [row][BN] row-major == float4 index f
+    }
+#pragma unroll
+    for (int i = 0; i < G::kWF4; ++i) {
+      const int f = tid + 256 * i;
+      *reinterpret_cast<v4f*>(sw + 4 * f) = rw[i];
+    }
+  };
+
+  const int nstage = (K + kKC - 1) / kKC;
+  fetch(0);
+  commit(0);
+  __syncthreads();
+  for (int s = 0; s < nstage; ++s) {
+    const bool more = s + 1 < nstage;
+    if (more) fetch((s + 1) * kKC);
+    const float* sx = lds + (s & 1) * G::kStage;
+    const float* sw = sx + kKC * G::kBN;
+#pragma unroll
+    for (int kk = 0; kk < kKC; kk += 2) {
+      float a[TM], bv[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = sw[(kk + half) * G::kBM + (wm * TM + i) * 32 + l32];
+#pragma unroll
+      for (int jn = 0; jn < TN; ++jn) bv[jn] = sx[(kk + half) * G::kBN + (wn * TN + jn) * 32 + l32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bv[jn], acc[i][jn], 0, 0, 0);
+    }
+    if (more) commit((s + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: register v of a 32x32 accumulator = output channel (v & 3) + 8 * (v >> 2) + 4 * half, pixel = lane & 31
+  const long long MP = static_cast<long long>(M) * P;
+  float* yb = y + b * MP;
+  const float* resb = epi.residual ? epi.residual + b * MP : nullptr;
+  const float* maskb = epi.mask ? epi.mask + b * MP : nullptr;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn) {
+      const long long p = n0 + (wn * TN + jn) * 32 + l32;
+      const int cbase = m0 + (wm * TM + i) * 32 + 4 * half;
+      if (p >= P) continue;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int co = cbase + (v & 3) + 8 * (v >> 2);
+        if (co >= M) continue;
+        const long long at = static_cast<long long>(co) * P + p;
+        float rv = acc[i][jn][v];
+        if (epi.bias) rv = rv + epi.bias[co];
+        if (resb) rv = rv + __builtin_nontemporal_load(resb + at);
+        if (epi.relu) rv = rv > 0.0f ? rv : 0.0f;
+        if (maskb) rv = __builtin_nontemporal_load(maskb + at) > 0.0f ? rv : 0.0f;
+        yb[at] = rv;
+      }
+    }
+  }
+}
+
+__global__ void conv2d_1x1_prep_kernel(const float* __restrict__ w, float* __restrict__ out, int cout, int cin, int transpose, int kpad, int mpad) {
+  // forward:  out[k = ci][m = co] = w[co][ci];   transpose (backward w.r.t. the input): out[k = co][m = ci] = w[co][ci]
+  const long long n = static_cast<long long>(kpad) * mpad;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += 256LL * gridDim.x) {
+    const int k = static_cast<int>(i / mpad), m = static_cast<int>(i % mpad);
+    const int co = transpose ? k : m, ci = transpose ? m : k;
+    out[i] = (co < cout && ci < cin) ? w[static_cast<long long>(co) * cin + ci] : 0.0f;
+  }
+}
+
+int round_up(int v, int q) { return (v + q - 1) / q * q; }
+
+int cu_count() {  // compute units of the current device (256 on MI355X); queried once per host thread
+  static thread_local int cached = 0;
+  if (cached == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+    cached = n;
+  }
+  return cached;
+}
+
+template <int WM, int WN, int TM, int TN>
+int launch_1x1(const float* x, const float* wp, float* y, int b, int K, int M, int mpad, long long P, const Epi2& epi, hipStream_t st) {
+  using G = GemmGeo<WM, WN, TM, TN>;
+  const int tiles_m = (M + G::kBM - 1) / G::kBM;
+  const long long tiles_n = (P + G::kBN - 1) / G::kBN;
+  const long long ntiles = static_cast<long long>(tiles_m) * tiles_n * b;
+  if (tiles_n > 0x7fffffffLL || ntiles > 0x7fffffffLL) return ADV_EINVAL;
+  const size_t lds = 2 * sizeof(float) * static_cast<size_t>(G::kStage);
+  if (lds > 64 * 1024 && !adv_internal_lds_limit<conv2d_1x1_mfma<WM, WN, TM, TN>>(lds)) return ADV_ELAUNCH;
+  hipLaunchKernelGGL((conv2d_1x1_mfma<WM, WN, TM, TN>), dim3(static_cast<unsigned>(ntiles)), dim3(256), lds, st, x, wp, y, K, M, mpad, P, tiles_m,
+                     static_cast<int>(tiles_n), ntiles, epi);
+  return adv_internal_finish_launch();
+}
+
+// which tile shape: 0 = 128x256, 1 = 128x128, 2 = 64x128, 3 = 64x64 (output channels x pixels).  One wave's work is TM*TN
+// accumulators over K; the matrix pipes run the waves of a SIMD one after another, so a launch takes about
+// ceil(waves / SIMDs) * TM*TN / efficiency(shape) - bigger tiles reuse more per staged byte, smaller ones fill the chip.
+int pick_1x1_tile(int b, int M, long long P, int simds) {
+  static const int bm[4] = {128, 128, 64, 64}, bn[4] = {256, 128, 128, 64}, work[4] = {8, 4, 2, 1};
+  static const double eff[4] = {1.0, 0.92, 0.8, 0.62};
+  int best = 0;
+  double best_t = 1e300;
+  for (int c = 0; c < 4; ++c) {
+    const double waves = 4.0 * ((M + bm[c] - 1) / bm[c]) * static_cast<double>((P + bn[c] - 1) / bn[c]) * b;
+    const double rounds = static_cast<double>(static_cast<long long>((waves + simds - 1) / simds));
+    const double tcost = rounds * work[c] / eff[c];
+    if (tcost < best_t) best_t = tcost, best = c;
+  }
+  return best;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t adv_conv2d_1x1_prep_floats(int cout, int cin, int transpose) {
+  if (cout < 1 || cin < 1) return ADV_EINVAL;
+  const int k = transpose ? cout : cin, m = transpose ? cin : cout;
+  return static_cast<int64_t>(round_up(k, kKC)) * round_up(m, 128);
+}
+
+int adv_conv2d_1x1_prep_weights_f32(const float* w, float* w_prep, int cout, int cin, int transpose, adv_stream_t stream) {
+  if (!w || !w_prep || cout < 1 || cin < 1) return ADV_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(w) & 3) || (reinterpret_cast<uintptr_t>(w_prep) & 15)) return ADV_EALIGN;
+  const int k = transpose ? cout : cin, m = transpose ? cin : cout;
+  const int kpad = round_up(k, kKC), mpad = round_up(m, 128);
+  const long long n = static_cast<long long>(kpad) * mpad;
+  const unsigned blocks = static_cast<unsigned>(n / 256 + 1 < 4096 ? n / 256 + 1 : 4096);
+  hipLaunchKernelGGL(conv2d_1x1_prep_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), w, w_prep, cout, cin, transpose ? 1 : 0,
+                     kpad, mpad);
+  return adv_internal_finish_launch();
+}
+
+int adv_conv2d_1x1_f32(const float* x, const float* w_prep, const float* bias, const float* residual, const float* mask, float* y, int b, int cin,
+                       int cout, int64_t pixels, int relu, int tile, adv_stream_t stream) {
+  if (!x || !w_prep || !y || b < 1 || cin < 1 || cout < 1 || pixels < 1 || tile < -1 || tile > 3) return ADV_EINVAL;
+  if (static_cast<long long>(cin) * pixels < 4) return ADV_EINVAL;
+  if (residual == y || mask == y || x == y) return ADV_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(x) & 3) || (reinterpret_cast<uintptr_t>(y) & 3) || (reinterpret_cast<uintptr_t>(w_prep) & 15) ||
+      (residual && (reinterpret_cast<uintptr_t>(residual) & 3)) || (mask && (reinterpret_cast<uintptr_t>(mask) & 3)) ||
+      (bias && (reinterpret_cast<uintptr_t>(bias) & 3)))
+    return ADV_EALIGN;
+  Epi2 epi{bias, residual, mask, relu ? 1 : 0};
+  const int mpad = round_up(cout, 128);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int c = tile >= 0 ? tile : pick_1x1_tile(b, cout, pixels, 4 * cu_count());
+  switch (c) {
+    case 0: return launch_1x1<2, 2, 2, 4>(x, w_prep, y, b, cin, cout, mpad, pixels, epi, st);
+    case 1: return launch_1x1<2, 2, 2, 2>(x, w_prep, y, b, cin, cout, mpad, pixels, epi, st);
+    case 2: return launch_1x1<2, 2, 1, 2>(x, w_prep, y, b, cin, cout, mpad, pixels, epi, st);
+    default: return launch_1x1<2, 2, 1, 1>(x, w_prep, y, b, cin, cout, mpad, pixels, epi, st);
+  }
+}
+
+}  // extern "C"

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(kBlock) void roi_align_fwd(const float* __restrict_
 // The candidate ranges are a two-sample-wide superset of the samples that can touch the pixel; every candidate is tested
 // with the forward's own tap arithmetic (taps_at), so membership is exact whatever the float rounding of the range.
 constexpr int kTileY = 8, kTileX = 32;  // 256 lanes: one pixel each, x fastest (coalesced stores)
-constexpr int kChanBlock = 8;
+constexpr int kChanBlock = 8;   // most channels a lane carries; fewer on small maps (see roi_align_bwd_gather)
 
 struct Axis1 {  // one sample coordinate against one pixel coordinate
   float w_low, w_high;  // weight when the sample's low / high tap is this pixel (0 otherwise)
@@ -203,57 +203,157 @@ __device__ __forceinline__ void cand_range(float start, float step, int n_sample
   *k_hi = min(n_samples - 1, static_cast<int>(ceilf(b)) + 2);
 }
 
-__global__ __launch_bounds__(kBlock) void roi_align_bwd_gather(const float* __restrict__ gout, const float* __restrict__ rois,
-                                                               const int* __restrict__ lists, float* __restrict__ gfeat, int C, int H, int W,
-                                                               int R, int tiles_y, int tiles_x, int PH, int PW, float scale,
-                                                               int sampling_ratio) {
-  const int tile = blockIdx.x, img = blockIdx.z;
-  const int c0 = blockIdx.y * kChanBlock;
-  const int py = (tile / tiles_x) * kTileY + static_cast<int>(threadIdx.x) / kTileX;
-  const int px = (tile % tiles_x) * kTileX + static_cast<int>(threadIdx.x) % kTileX;
-  const bool inside = py < H && px < W;
-  const int* list = lists + (static_cast<long long>(img) * tiles_y * tiles_x + tile) * (R + 1);
-  const int n_list = list[0];
-  float acc[kChanBlock];
+// one roi's contributions to this lane's pixel, classified by the lane itself (the round-2 formulation: every lane tests its
+// candidate rows x candidate columns) - the path of a lane whose row or column list does not fit the shared LDS lists
+template <int CB>
+__device__ __forceinline__ void roi_direct(float (&acc)[CB], const Bin& b, const float* __restrict__ gout, int r, int C, int c0, int H, int W, int PH,
+                                           int PW, int py, int px) {
+  const float count = static_cast<float>(b.grid_h * b.grid_w);
+  int ky_lo, ky_hi, kx_lo, kx_hi;
+  cand_range(b.start_h, b.bin_h / static_cast<float>(b.grid_h), PH * b.grid_h, py, H, &ky_lo, &ky_hi);
+  cand_range(b.start_w, b.bin_w / static_cast<float>(b.grid_w), PW * b.grid_w, px, W, &kx_lo, &kx_hi);
+  for (int ky = ky_lo; ky <= ky_hi; ++ky) {
+    const int ph = ky / b.grid_h, iy = ky - ph * b.grid_h;
+    const float y = b.start_h + static_cast<float>(ph) * b.bin_h + (static_cast<float>(iy) + 0.5f) * b.bin_h / static_cast<float>(b.grid_h);
+    const Axis1 ay = axis_taps(H, y, py);
+    if (!ay.valid || !(ay.hit_low || ay.hit_high)) continue;
+    for (int kx = kx_lo; kx <= kx_hi; ++kx) {
+      const int pw = kx / b.grid_w, ix = kx - pw * b.grid_w;
+      const float x = b.start_w + static_cast<float>(pw) * b.bin_w + (static_cast<float>(ix) + 0.5f) * b.bin_w / static_cast<float>(b.grid_w);
+      const Axis1 ax = axis_taps(W, x, px);
+      if (!ax.valid || !(ax.hit_low || ax.hit_high)) continue;
+      // taps 1..4 of this sample = (y_low,x_low) (y_low,x_high) (y_high,x_low) (y_high,x_high), in that order
+      const float w1 = ay.w_low * ax.w_low, w2 = ay.w_low * ax.w_high, w3 = ay.w_high * ax.w_low, w4 = ay.w_high * ax.w_high;
+      const float* g = gout + ((static_cast<long long>(r) * C + c0) * PH + ph) * PW + pw;
 #pragma unroll
-  for (int c = 0; c < kChanBlock; ++c) acc[c] = 0.0f;
-  for (int li = 0; li < n_list; ++li) {
-    const int r = list[1 + li];  // uniform over the workgroup
-    const Bin b = bin_of(rois + static_cast<long long>(r) * 5, scale, PH, PW, sampling_ratio);
-    const float count = static_cast<float>(b.grid_h * b.grid_w);
-    int ky_lo, ky_hi, kx_lo, kx_hi;
-    cand_range(b.start_h, b.bin_h / static_cast<float>(b.grid_h), PH * b.grid_h, py, H, &ky_lo, &ky_hi);
-    cand_range(b.start_w, b.bin_w / static_cast<float>(b.grid_w), PW * b.grid_w, px, W, &kx_lo, &kx_hi);
-    if (!inside) ky_hi = ky_lo - 1;
-    for (int ky = ky_lo; ky <= ky_hi; ++ky) {
-      const int ph = ky / b.grid_h, iy = ky - ph * b.grid_h;
-      const float y = b.start_h + static_cast<float>(ph) * b.bin_h + (static_cast<float>(iy) + 0.5f) * b.bin_h / static_cast<float>(b.grid_h);
-      const Axis1 ay = axis_taps(H, y, py);
-      if (!ay.valid || !(ay.hit_low || ay.hit_high)) continue;
-      for (int kx = kx_lo; kx <= kx_hi; ++kx) {
-        const int pw = kx / b.grid_w, ix = kx - pw * b.grid_w;
-        const float x = b.start_w + static_cast<float>(pw) * b.bin_w + (static_cast<float>(ix) + 0.5f) * b.bin_w / static_cast<float>(b.grid_w);
-        const Axis1 ax = axis_taps(W, x, px);
-        if (!ax.valid || !(ax.hit_low || ax.hit_high)) continue;
-        // taps 1..4 of this sample = (y_low,x_low) (y_low,x_high) (y_high,x_low) (y_high,x_high), in that order
-        const float w1 = ay.w_low * ax.w_low, w2 = ay.w_low * ax.w_high, w3 = ay.w_high * ax.w_low, w4 = ay.w_high * ax.w_high;
-        const float* g = gout + ((static_cast<long long>(r) * C + c0) * PH + ph) * PW + pw;
-#pragma unroll
-        for (int c = 0; c < kChanBlock; ++c) {
-          if (c0 + c < C) {
-            const float gv = g[static_cast<long long>(c) * PH * PW];
-            if (ay.hit_low && ax.hit_low) acc[c] = acc[c] + gv * w1 / count;
-            if (ay.hit_low && ax.hit_high) acc[c] = acc[c] + gv * w2 / count;
-            if (ay.hit_high && ax.hit_low) acc[c] = acc[c] + gv * w3 / count;
-            if (ay.hit_high && ax.hit_high) acc[c] = acc[c] + gv * w4 / count;
-          }
+      for (int c = 0; c < CB; ++c) {
+        if (c0 + c < C) {
+          const float gv = g[static_cast<long long>(c) * PH * PW];
+          if (ay.hit_low && ax.hit_low) acc[c] = acc[c] + gv * w1 / count;
+          if (ay.hit_low && ax.hit_high) acc[c] = acc[c] + gv * w2 / count;
+          if (ay.hit_high && ax.hit_low) acc[c] = acc[c] + gv * w3 / count;
+          if (ay.hit_high && ax.hit_high) acc[c] = acc[c] + gv * w4 / count;
         }
       }
     }
   }
+}
+
+// <round 3> The classification is SEPARABLE and depends on the pixel's row or column only - 8 + 32 distinct problems per roi for
+// the 256 lanes of a tile, which round 2's kernel solved 256 times each (and the column one again for every candidate row).  Now
+// a batch of kRoiBatch rois is classified COOPERATIVELY: lane (roi k of the batch, axis pixel a) walks that pixel's candidate
+// samples once and leaves, in LDS, the ascending list of the samples that touch it (bin index, which tap, both 1-D weights);
+// after one barrier every lane runs its row list x its column list - the same contributions in the same order (roi, sample
+// row, sample column, tap 1..4) with the same float operations, so the bits are those of the direct formulation and of the
+// oracle.  Lists hold kListCap entries (a sample step is bin / ceil(bin) in (0.5, 1] pixels: 2-4 samples touch a pixel per axis);
+// a longer one (rois smaller than their pooled grid) sends that lane to roi_direct for that roi.  CB channels per lane: 8 on
+// large maps, fewer on the small pyramid levels, where 6-20 tiles x C/8 channel blocks left most of the chip idle behind a few
+// hundred-roi lists (profiles/r03_r101_kernel_stats.csv: 9.9 ms per call before, 69 of the 157 ms of the R101-shaped step).
+constexpr int kRoiBatch = 6;   // 6 x (8 rows + 32 columns) = 240 classifying lanes
+constexpr int kListCap = 6;
+
+struct AxisList {
+  int n;                       // samples that touch the pixel (may exceed kListCap: then the entries are not used)
+  int bin[kListCap];           // ph / pw of the sample
+  float w_low[kListCap], w_high[kListCap];
+  unsigned char hit[kListCap];  // bit 0: the sample's low tap is this pixel, bit 1: its high tap
+};
+
+template <int CB>
+__global__ __launch_bounds__(kBlock) void roi_align_bwd_gather(const float* __restrict__ gout, const float* __restrict__ rois,
+                                                               const int* __restrict__ lists, float* __restrict__ gfeat, int C, int H, int W,
+                                                               int R, int tiles_y, int tiles_x, int PH, int PW, float scale,
+                                                               int sampling_ratio) {
+  __shared__ AxisList s_list[kRoiBatch][kTileY + kTileX];
+  __shared__ Bin s_bin[kRoiBatch];
+  const int tile = blockIdx.x, img = blockIdx.z;
+  const int c0 = blockIdx.y * CB;
+  const int tid = static_cast<int>(threadIdx.x);
+  const int ty0 = (tile / tiles_x) * kTileY, tx0 = (tile % tiles_x) * kTileX;
+  const int ly = tid / kTileX, lx = tid % kTileX;
+  const int py = ty0 + ly, px = tx0 + lx;
+  const bool inside = py < H && px < W;
+  const int* list = lists + (static_cast<long long>(img) * tiles_y * tiles_x + tile) * (R + 1);
+  const int n_list = list[0];
+  float acc[CB];
+#pragma unroll
+  for (int c = 0; c < CB; ++c) acc[c] = 0.0f;
+  // classifying role of this lane: roi `cb` of the batch, axis pixel `ca` (0..7 = the tile's rows, 8..39 = its columns)
+  const int cb = tid / (kTileY + kTileX), ca = tid % (kTileY + kTileX);
+  for (int l0 = 0; l0 < n_list; l0 += kRoiBatch) {
+    const int nb = min(kRoiBatch, n_list - l0);
+    if (cb < nb) {
+      const int r = list[1 + l0 + cb];
+      const Bin b = bin_of(rois + static_cast<long long>(r) * 5, scale, PH, PW, sampling_ratio);
+      if (ca == 0) s_bin[cb] = b;
+      const bool is_y = ca < kTileY;
+      const int pixel = is_y ? ty0 + ca : tx0 + (ca - kTileY), size = is_y ? H : W;
+      const float start = is_y ? b.start_h : b.start_w, bin = is_y ? b.bin_h : b.bin_w;
+      const int grid = is_y ? b.grid_h : b.grid_w, pooled = is_y ? PH : PW;
+      AxisList& out = s_list[cb][ca];
+      int n = 0;
+      if (pixel < size) {
+        int k_lo, k_hi;
+        cand_range(start, bin / static_cast<float>(grid), pooled * grid, pixel, size, &k_lo, &k_hi);
+        for (int k = k_lo; k <= k_hi; ++k) {
+          const int pb = k / grid, ik = k - pb * grid;
+          const float v = start + static_cast<float>(pb) * bin + (static_cast<float>(ik) + 0.5f) * bin / static_cast<float>(grid);
+          const Axis1 a = axis_taps(size, v, pixel);
+          if (!a.valid || !(a.hit_low || a.hit_high)) continue;
+          if (n < kListCap) {
+            out.bin[n] = pb;
+            out.w_low[n] = a.w_low;
+            out.w_high[n] = a.w_high;
+            out.hit[n] = static_cast<unsigned char>((a.hit_low ? 1 : 0) | (a.hit_high ? 2 : 0));
+          }
+          ++n;
+        }
+      }
+      out.n = n;
+    }
+    __syncthreads();
+    if (inside) {
+      for (int k = 0; k < nb; ++k) {
+        const AxisList& yl = s_list[k][ly];
+        const AxisList& xl = s_list[k][kTileY + lx];
+        const int ny = yl.n, nx = xl.n;
+        if (ny == 0 || nx == 0) continue;
+        const int r = list[1 + l0 + k];
+        const Bin& b = s_bin[k];
+        if (ny > kListCap || nx > kListCap) {
+          roi_direct<CB>(acc, b, gout, r, C, c0, H, W, PH, PW, py, px);
+          continue;
+        }
+        const float count = static_cast<float>(b.grid_h * b.grid_w);
+        for (int iy = 0; iy < ny; ++iy) {
+          const int ph = yl.bin[iy];
+          const float ywl = yl.w_low[iy], ywh = yl.w_high[iy];
+          const bool yl_hit = yl.hit[iy] & 1, yh_hit = yl.hit[iy] & 2;
+          for (int ix = 0; ix < nx; ++ix) {
+            const int pw = xl.bin[ix];
+            const float xwl = xl.w_low[ix], xwh = xl.w_high[ix];
+            const bool xl_hit = xl.hit[ix] & 1, xh_hit = xl.hit[ix] & 2;
+            const float w1 = ywl * xwl, w2 = ywl * xwh, w3 = ywh * xwl, w4 = ywh * xwh;
+            const float* g = gout + ((static_cast<long long>(r) * C + c0) * PH + ph) * PW + pw;
+#pragma unroll
+            for (int c = 0; c < CB; ++c) {
+              if (c0 + c < C) {
+                const float gv = g[static_cast<long long>(c) * PH * PW];
+                if (yl_hit && xl_hit) acc[c] = acc[c] + gv * w1 / count;
+                if (yl_hit && xh_hit) acc[c] = acc[c] + gv * w2 / count;
+                if (yh_hit && xl_hit) acc[c] = acc[c] + gv * w3 / count;
+                if (yh_hit && xh_hit) acc[c] = acc[c] + gv * w4 / count;
+              }
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
   if (inside) {
 #pragma unroll
-    for (int c = 0; c < kChanBlock; ++c)
+    for (int c = 0; c < CB; ++c)
       if (c0 + c < C) gfeat[((static_cast<long long>(img) * C + c0 + c) * H + py) * W + px] = acc[c];
   }
 }
@@ -363,8 +463,19 @@ int adv_roi_align_bwd_f32(const float* grad_out, const float* rois, float* grad_
   // every element of grad_feat is written by its owning lane (zeros where no roi reaches): no memset needed
   hipLaunchKernelGGL(roi_tile_lists, dim3(tiles_y * tiles_x, b), dim3(64), 0, st, rois, r, h, w, tiles_y, tiles_x, ph, pw, spatial_scale,
                      sampling_ratio, reinterpret_cast<int*>(workspace));
-  hipLaunchKernelGGL(roi_align_bwd_gather, dim3(tiles_y * tiles_x, (c + kChanBlock - 1) / kChanBlock, b), dim3(kBlock), 0, st, grad_out, rois,
-                     reinterpret_cast<const int*>(workspace), grad_feat, c, h, w, r, tiles_y, tiles_x, ph, pw, spatial_scale, sampling_ratio);
+  // channels per lane: as many as still leave ~8 workgroups per compute unit (the small pyramid levels have 6-20 tiles)
+  const long long tiles = static_cast<long long>(tiles_y) * tiles_x * b;
+  int cb = kChanBlock;
+  while (cb > 1 && tiles * ((c + cb - 1) / cb) < 2048) cb >>= 1;
+  if (adv_hook("ADV_ROI_BWD_CB8")) cb = kChanBlock;
+#define ADV_LAUNCH_ROI_BWD(CB_)                                                                                                             \
+  hipLaunchKernelGGL(roi_align_bwd_gather<CB_>, dim3(tiles_y * tiles_x, (c + CB_ - 1) / CB_, b), dim3(kBlock), 0, st, grad_out, rois,          \
+                     reinterpret_cast<const int*>(workspace), grad_feat, c, h, w, r, tiles_y, tiles_x, ph, pw, spatial_scale, sampling_ratio)
+  if (cb == 8) ADV_LAUNCH_ROI_BWD(8);
+  else if (cb == 4) ADV_LAUNCH_ROI_BWD(4);
+  else if (cb == 2) ADV_LAUNCH_ROI_BWD(2);
+  else ADV_LAUNCH_ROI_BWD(1);
+#undef ADV_LAUNCH_ROI_BWD
   return finish();
 }
 

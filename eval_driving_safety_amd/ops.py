@@ -855,6 +855,93 @@ class ConvTranspose3dK3S2(torch.autograd.Function):
 
 
 # --------------------------------------------------------------------------------------------
+# 2D convolutions of the detectors' backbones on the float32 matrix cores (csrc/conv2d.hip)
+def conv2d_supported(x, weight, stride=1, padding=0):
+    """does libadvengine have a kernel for this layer?  (1x1 / stride 1 / no padding so far: the class MIOpen runs at 0.40 of the
+    float32 matrix peak on the ResNet-101-FPN step, profiles/r03_conv2d_layers_miopen.jsonl; 3x3 and strided layers stay on MIOpen)"""
+    k = weight.shape[2]
+    return (x.is_cuda and x.dtype == torch.float32 and weight.dim() == 4 and k == 1 and weight.shape[3] == 1 and stride == 1 and padding == 0
+            and weight.shape[1] * x.shape[2] * x.shape[3] >= 4)
+
+
+class Conv2dPrep:
+    """the weights of one layer in the kernels' layout, for the forward and for the backward w.r.t. the input - prepared once (the
+    attacks never change the weights)"""
+
+    def __init__(self, weight, stride=1, padding=0):
+        wt = _feat(weight.detach().contiguous(), "weight")
+        if wt.dim() != 4 or wt.shape[2] != 1 or wt.shape[3] != 1 or stride != 1 or padding != 0:
+            raise ValueError("only 1x1 / stride 1 / padding 0 layers have a kernel here")
+        self.cout, self.cin, self.k, self.stride, self.padding = int(wt.shape[0]), int(wt.shape[1]), 1, 1, 0
+        self.device = wt.device
+        self.fwd, self.bwd = self._prep(wt, False), self._prep(wt, True)
+
+    def _prep(self, wt, transpose):
+        n = int(_lib.load().adv_conv2d_1x1_prep_floats(self.cout, self.cin, int(transpose)))
+        out = torch.empty((n,), dtype=torch.float32, device=wt.device)
+        with _on(wt):
+            _lib.call("adv_conv2d_1x1_prep_weights_f32", _ptr(wt), _ptr(out), self.cout, self.cin, int(transpose), _stream(wt))
+        return out
+
+
+def _like(t, out, name):
+    if t is None:
+        return None
+    t = _feat(t, name)
+    if t.shape != out.shape or t.data_ptr() == out.data_ptr():
+        raise ValueError("%s must have the result's shape %s and must not be the result" % (name, tuple(out.shape)))
+    return _ptr(t)
+
+
+def _conv2d_1x1(x, w_prep, cin, cout, bias, residual, relu, mask, tile):
+    xi = _feat(x, "x")
+    if xi.dim() != 4 or xi.shape[1] != cin:
+        raise ValueError("x must be [B,%d,H,W]" % cin)
+    b, _, h, w = xi.shape
+    y = torch.empty((b, cout, h, w), dtype=torch.float32, device=xi.device)
+    if bias is not None:
+        bias = _feat(bias, "bias")
+        if tuple(bias.shape) != (cout,):
+            raise ValueError("bias must be [cout]")
+    with _on(xi):
+        _lib.call("adv_conv2d_1x1_f32", _ptr(xi), _ptr(w_prep), None if bias is None else _ptr(bias), _like(residual, y, "residual"),
+                  _like(mask, y, "mask"), _ptr(y), b, cin, cout, h * w, int(bool(relu)), int(tile), _stream(xi))
+    return y
+
+
+def conv2d(x, prep, bias=None, residual=None, relu=False, mask=None, tile=-1):
+    """conv2d(x [B,Cin,H,W], prep) (+ bias [Cout]) (+ residual [B,Cout,H,W]) (ReLU) (zeroed where mask <= 0) -> [B,Cout,H,W]"""
+    return _conv2d_1x1(x, prep.fwd, prep.cin, prep.cout, bias, residual, relu, mask, tile)
+
+
+def conv2d_dgrad(grad, prep, hw=None, residual=None, mask=None, tile=-1):
+    """the backward w.r.t. the input of the same layer: grad [B,Cout,H,W] -> [B,Cin,H,W] (+ residual: a gradient arriving over a
+    skip path) (zeroed where mask <= 0: with mask = the layer's own input, a ReLU output, this is the gradient w.r.t. the previous
+    layer's pre-activation)"""
+    return _conv2d_1x1(grad, prep.bwd, prep.cout, prep.cin, None, residual, False, mask, tile)
+
+
+class Conv2d(torch.autograd.Function):
+    """y = [relu](conv2d(x, prep) [+ bias] [+ residual]); gradients flow to x and to the residual only (the detector's weights are
+    constants in an attack).  With ``relu`` the incoming gradient is masked with y > 0 first (ops.relu_backward)."""
+
+    @staticmethod
+    def forward(ctx, x, prep, bias=None, residual=None, relu=False):
+        ctx.prep, ctx.relu, ctx.has_res = prep, bool(relu), residual is not None
+        y = conv2d(x.contiguous(), prep, bias, None if residual is None else residual.contiguous(), relu)
+        ctx.save_for_backward(y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        (y,) = ctx.saved_tensors
+        g = grad_y.contiguous()
+        if ctx.relu:
+            g = relu_backward(g, y)
+        return conv2d_dgrad(g, ctx.prep), None, None, (g if ctx.has_res else None), None
+
+
+# --------------------------------------------------------------------------------------------
 # dense photometric box alignment (attack/Stereo-RCNN/predict_and_save_pgd.py:381; upstream op, published algorithm)
 def dense_align_cost(left, right, roi, dz, z_center, fb, step, k, out=None):
     """cost [n,k] of k candidate depths around z_center per object (adv_dense_align_cost_f32).  left/right [3,H,W],

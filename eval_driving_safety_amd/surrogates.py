@@ -278,6 +278,13 @@ class FoldedConv(nn.Module):
         self.flops += 2 * x.shape[0] * self.weight.shape[0] * self.weight.shape[1] * self.k * self.k * ho * wo
         if FoldedConv.trace is not None:
             FoldedConv.trace.append((self.weight.shape[1], self.weight.shape[0], self.k, self.stride, self.padding, x.shape[0], x.shape[2], x.shape[3]))
+        if ho == 1 and wo == 1 and self.padding == 0 and self.k == x.shape[2] == x.shape[3]:
+            # the kernel covers the whole map (the RoI head's 7x7 "fully connected" convolution, and the 1x1 behind it): one GEMM over
+            # the rois.  (MIOpen's backward-data for [512,512,7,7] x [2048,512,7,7] takes 24 ms - 2 TFLOP/s; the GEMM 0.6 ms.)
+            y = F.linear(x.flatten(1), self.weight.flatten(1), self.bias)
+            if residual is not None:
+                y = y + residual.flatten(1)
+            return (F.relu(y) if relu else y)[:, :, None, None]
         if FoldedConv.impl == "hip":
             from . import ops
             if ops.conv2d_supported(x, self.weight, self.stride, self.padding):

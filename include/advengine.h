@@ -411,6 +411,30 @@ ADV_API int adv_grid_sample3d_bwd_ws_f32(const float* grad_out, const void* plan
 ADV_API int adv_sigmoid_focal_loss_f32(const float* logits, const int32_t* targets, float* loss_out, float* grad_out, int64_t n,
                                        int k, float gamma, float alpha, adv_stream_t stream);
 
+/* ---- 2D convolutions of the detectors' backbones on the matrix cores (float32 MFMA).  Upstream code reached through
+ *      attack/Stereo-RCNN/pgd_attack.py:156 (ResNet-101-FPN: attack/Stereo-RCNN/stereo_rcnn.py:157-187) and attack/DSGN/pgd_attack.py:308
+ *      (DSGN's 2D feature extractor and bird's-eye-view head); semantics = torch.nn.functional.conv2d; bit-exact against the
+ *      oracle's ci-ordered fmaf chain, within 1e-4 relative of torch's float32 result. */
+
+/* 1x1 / stride 1 convolution = one GEMM per image, Y_b [cout][pixels] = W [cout][cin] . X_b [cin][pixels] (NCHW as it stands).
+ *     w_prep   from adv_conv2d_1x1_prep_weights_f32: [cin'][cout'] zero padded to multiples of 16 x 128
+ *              (adv_conv2d_1x1_prep_floats floats).  transpose = 1 prepares W^T: the SAME entry point then computes the backward
+ *              w.r.t. the input - call it with x = grad_out, cin = the layer's cout, cout = the layer's cin.
+ *     bias     DEVICE [cout] or NULL (a folded batch-norm shift), added after the accumulation;
+ *     residual DEVICE tensor laid out like y or NULL, added after the bias (a bottleneck's skip connection; in a backward the
+ *              gradient arriving over the skip path);
+ *     relu     != 0: max(., 0) after that;
+ *     mask     DEVICE tensor laid out like y or NULL: the result is zeroed where mask <= 0, last of all.  In a backward call with
+ *              mask = the layer's own input (a ReLU output) the result is the gradient w.r.t. the previous layer's PRE-activation:
+ *              no separate ReLU-backward pass over the tensor;
+ *     tile     -1 = pick by size; 0..3 force 128x256 / 128x128 / 64x128 / 64x64 (output channels x pixels per workgroup) - the
+ *              result does not depend on it (one fmaf chain per output element, ci ascending).
+ *     x, y, residual, mask need 4-byte alignment only (rows of odd length are the rule: 150 x 497, 38 x 125 ...). */
+ADV_API int64_t adv_conv2d_1x1_prep_floats(int cout, int cin, int transpose);
+ADV_API int adv_conv2d_1x1_prep_weights_f32(const float* w, float* w_prep, int cout, int cin, int transpose, adv_stream_t stream);
+ADV_API int adv_conv2d_1x1_f32(const float* x, const float* w_prep, const float* bias, const float* residual, const float* mask,
+                               float* y, int b, int cin, int cout, int64_t pixels, int relu, int tile, adv_stream_t stream);
+
 /* out[i] = y[i] > 0 ? grad[i] : 0  (the backward of a ReLU fused into a convolution's epilogue; out may alias grad). */
 ADV_API int adv_relu_backward_f32(const float* grad, const float* y, float* out, int64_t n, adv_stream_t stream);
 

@@ -327,3 +327,44 @@ void orc_conv3d_k3_ex(const float* x, const float* w, const float* bias, float* 
             y[((long)b * cout + co) * ovol + zd * oplane + (long)zh * odims[2] + zw] = acc;
           }
 }
+
+
+/* csrc/conv2d.hip: torch.nn.functional.conv2d (k x k, stride s, zero padding p) in the kernels' accumulation order - chunks of
+ * `chunk` input channels, taps ascending inside a chunk, channels ascending inside a tap, ONE fmaf per product starting from 0
+ * (the float32 MFMA is a k-ordered fmaf chain) - then + bias, + residual, ReLU, and last the mask (result kept where mask > 0).
+ * For a 1x1 kernel the order is simply "input channel ascending" whatever the chunk.
+ * transpose != 0 (stride 1 only): the backward w.r.t. the input - x is grad_out [B,cout,H,W], y is grad_in [B,cin,H,W], the
+ * weights are read transposed and flipped, exactly what the kernel does with its prepared W^T.
+ * Upstream detector code (ResNet-101-FPN of Stereo R-CNN, DSGN's 2D extractor): unpinned; torch's conv2d is the semantics. */
+void orc_conv2d(const float* x, const float* w, const float* bias, const float* residual, const float* mask, float* y, int B, int cin,
+                int cout, int H, int W, int k, int stride, int pad, int relu, int transpose, int chunk) {
+  const int kk = k * k;
+  const int M = transpose ? cin : cout, Kc = transpose ? cout : cin;
+  const int p = transpose ? k - 1 - pad : pad;
+  const int Ho = transpose ? H : (H + 2 * pad - k) / stride + 1, Wo = transpose ? W : (W + 2 * pad - k) / stride + 1;
+  const int s = transpose ? 1 : stride;
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int b = 0; b < B; ++b)
+    for (int m = 0; m < M; ++m)
+      for (int h = 0; h < Ho; ++h)
+        for (int ww = 0; ww < Wo; ++ww) {
+          float acc = 0.0f;
+          for (int c0 = 0; c0 < Kc; c0 += chunk)
+            for (int tap = 0; tap < kk; ++tap) {
+              const int kh = tap / k, kw = tap % k;
+              const int gh = s * h + kh - p, gw = s * ww + kw - p;
+              const int in = gh >= 0 && gh < H && gw >= 0 && gw < W;
+              for (int c = c0; c < c0 + chunk && c < Kc; ++c) {
+                const float wv = transpose ? w[((long)c * cin + m) * kk + (kk - 1 - tap)] : w[((long)m * cin + c) * kk + tap];
+                const float xv = in ? x[((long)b * Kc + c) * H * W + (long)gh * W + gw] : 0.0f;
+                acc = fmaf(wv, xv, acc);
+              }
+            }
+          const long at = (((long)b * M + m) * Ho + h) * Wo + ww;
+          if (bias) acc = acc + bias[m];
+          if (residual) acc = acc + residual[at];
+          if (relu) acc = acc > 0.0f ? acc : 0.0f;
+          if (mask) acc = mask[at] > 0.0f ? acc : 0.0f;
+          y[at] = acc;
+        }
+}

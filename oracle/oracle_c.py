@@ -33,6 +33,8 @@ _lib.orc_dense_align_cost.argtypes = [_fp, _fp, ctypes.c_int, ctypes.c_int, ctyp
 _lib.orc_dense_align_cost.restype = None
 _lib.orc_conv3d_k3_ex.argtypes = [_fp, _fp, ctypes.c_void_p, _fp] + [ctypes.c_int] * 8 + [ctypes.c_uint, _i32p, _i32p, _i32p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
 _lib.orc_conv3d_k3_ex.restype = None
+_lib.orc_conv2d.argtypes = [_fp, _fp, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _fp] + [ctypes.c_int] * 11
+_lib.orc_conv2d.restype = None
 for _f in ("orc_denormalize", "orc_normalize", "orc_pgd_step_norm01", "orc_pgd_step_meansub255", "orc_tensor2im_u8",
            "orc_patch_paste", "orc_patch_update"):
     getattr(_lib, _f).restype = None
@@ -186,6 +188,29 @@ def conv3d_k3_ex(x, w, bias=None, stride=1, relu=False, tap_mask=(1 << 27) - 1, 
                           np.array(out.shape[2:], np.int32), np.array(out_stride, np.int32), np.array(out_offset, np.int32),
                           None if cm is None else cm.ctypes.data_as(ctypes.c_void_p), 0 if cm is None else cin // 8, int(chunk))
     return out
+
+
+def conv2d(x, w, bias=None, residual=None, mask=None, stride=1, padding=0, relu=False, transpose=False, chunk=16):
+    """csrc/conv2d.hip in its accumulation order: x [B,Cin,H,W], w [Cout,Cin,k,k] -> conv2d (+ bias, + residual, ReLU, mask);
+    transpose=True: x is grad_out [B,Cout,H,W] -> the gradient w.r.t. the input [B,Cin,H,W] (stride 1)"""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    cout, cin, k = w.shape[0], w.shape[1], w.shape[2]
+    b, c, h, ww = x.shape
+    assert c == (cout if transpose else cin) and w.shape[3] == k and (stride == 1 or not transpose)
+    ho, wo = (h, ww) if transpose else ((h + 2 * padding - k) // stride + 1, (ww + 2 * padding - k) // stride + 1)
+    y = np.empty((b, cin if transpose else cout, ho, wo), np.float32)
+
+    def opt(a, shape):
+        if a is None:
+            return None, None
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        assert a.shape == shape, (a.shape, shape)
+        return a, a.ctypes.data_as(ctypes.c_void_p)
+
+    keep = [opt(bias, (y.shape[1],)), opt(residual, y.shape), opt(mask, y.shape)]
+    _lib.orc_conv2d(x, w, keep[0][1], keep[1][1], keep[2][1], y, b, cin, cout, h, ww, k, int(stride), int(padding), int(relu), int(transpose), int(chunk))
+    return y
 
 
 def space_to_depth2(x):

@@ -1,0 +1,127 @@
+"""csrc/conv2d.hip (2D convolutions of the detectors' backbones on the float32 matrix cores) against the oracle's fmaf chain (bit
+for bit) and against torch's conv2d (1e-4).  The layers are upstream detector code (ResNet-101-FPN of Stereo R-CNN reached at
+attack/Stereo-RCNN/pgd_attack.py:156, DSGN's 2D networks at attack/DSGN/pgd_attack.py:308): unpinned against upstream; what is
+pinned is this package's arithmetic (oracle) and the operator's semantics (torch)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import oracle_c as C
+
+
+def _case(b, cin, cout, h, w, k=1, seed=0):
+    rs = np.random.RandomState(seed)
+    return rs.randn(b, cin, h, w).astype(np.float32), (rs.randn(cout, cin, k, k) * (1.0 / (cin * k * k)) ** 0.5).astype(np.float32), rs
+
+
+# (B, Cin, Cout, H, W): odd row lengths (the rule for feature maps), channel counts that are not multiples of the stage / tile,
+# fewer pixels than a tile, the R101 shapes at reduced size
+ONE = [(1, 16, 32, 5, 7), (2, 24, 18, 19, 63), (1, 3, 70, 9, 11), (2, 64, 256, 13, 41), (1, 256, 64, 10, 33), (1, 40, 3, 38, 125),
+       (3, 130, 129, 7, 9), (1, 4, 1, 1, 1), (1, 1, 5, 2, 2), (1, 1024, 18, 6, 10)]
+
+
+@pytest.mark.parametrize("shape", ONE[:6])
+def test_oracle_conv2d_matches_torch(shape):
+    b, cin, cout, h, w = shape
+    x, wt, rs = _case(*shape, seed=sum(shape))
+    bias = rs.randn(cout).astype(np.float32)
+    for k, pad, stride in ((1, 0, 1), (3, 1, 1), (3, 1, 2), (1, 0, 2)):
+        wk = (rs.randn(cout, cin, k, k) * (1.0 / (cin * k * k)) ** 0.5).astype(np.float32)
+        got = C.conv2d(x, wk, bias, stride=stride, padding=pad, relu=True)
+        ref = F.relu(F.conv2d(torch.tensor(x), torch.tensor(wk), torch.tensor(bias), stride, pad)).numpy()
+        assert got.shape == ref.shape and np.abs(got - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+        if stride == 1:
+            g = rs.randn(*ref.shape).astype(np.float32)
+            gx = C.conv2d(g, wk, padding=pad, transpose=True)
+            refg = torch.nn.grad.conv2d_input(x.shape, torch.tensor(wk), torch.tensor(g), padding=pad).numpy()
+            assert np.abs(gx - refg).max() <= 1e-5 * max(1.0, np.abs(refg).max())
+
+
+def test_oracle_conv2d_epilogue_order():
+    """+ bias, + residual, ReLU, then the mask - each a separate float32 operation"""
+    x, wt, rs = _case(1, 8, 5, 4, 6, seed=3)
+    bias, res, mask = rs.randn(5).astype(np.float32), rs.randn(1, 5, 4, 6).astype(np.float32), rs.randn(1, 5, 4, 6).astype(np.float32)
+    plain = C.conv2d(x, wt)
+    want = np.maximum(plain + bias[None, :, None, None] + res, np.float32(0)) * (mask > 0)
+    assert C.conv2d(x, wt, bias, res, mask, relu=True).tobytes() == (want + np.float32(0)).astype(np.float32).tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ONE)
+def test_hip_conv2d_1x1_bit_exact_vs_oracle_every_tile_shape(shape):
+    from eval_driving_safety_amd import ops
+    b, cin, cout, h, w = shape
+    x, wt, rs = _case(*shape, seed=sum(shape) + 1)
+    bias = rs.randn(cout).astype(np.float32)
+    res = rs.randn(b, cout, h, w).astype(np.float32)
+    mask = rs.randn(b, cout, h, w).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    tx, tw, tb, tr, tm = (torch.tensor(a, device=dev) for a in (x, wt, bias, res, mask))
+    assert ops.conv2d_supported(tx, tw, 1, 0) or cin * h * w < 4
+    if cin * h * w < 4:
+        with pytest.raises(Exception):
+            ops.conv2d(tx, ops.Conv2dPrep(tw))
+        return
+    prep = ops.Conv2dPrep(tw)
+    want_plain = C.conv2d(x, wt)
+    want_full = C.conv2d(x, wt, bias, res, mask, relu=True)
+    for tile in (-1, 0, 1, 2, 3):
+        assert ops.conv2d(tx, prep, tile=tile).cpu().numpy().tobytes() == want_plain.tobytes(), ("plain", tile)
+        assert ops.conv2d(tx, prep, tb, tr, True, tm, tile=tile).cpu().numpy().tobytes() == want_full.tobytes(), ("bias + residual + relu + mask", tile)
+    ref = F.conv2d(tx, tw, tb)
+    got = ops.conv2d(tx, prep, tb)
+    assert float((got - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
+    # the backward w.r.t. the input: the same kernel on W^T, with the skip-path gradient and the ReLU mask of the layer's input fused
+    g = rs.randn(b, cout, h, w).astype(np.float32)
+    gres = rs.randn(b, cin, h, w).astype(np.float32)
+    tg, tgr = torch.tensor(g, device=dev), torch.tensor(gres, device=dev)
+    assert ops.conv2d_dgrad(tg, prep).cpu().numpy().tobytes() == C.conv2d(g, wt, transpose=True).tobytes()
+    want_b = C.conv2d(g, wt, residual=gres, mask=x, transpose=True)
+    for tile in (-1, 3):
+        assert ops.conv2d_dgrad(tg, prep, residual=tgr, mask=tx, tile=tile).cpu().numpy().tobytes() == want_b.tobytes(), tile
+    refg = torch.nn.grad.conv2d_input(x.shape, tw, tg)
+    assert float((ops.conv2d_dgrad(tg, prep) - refg).abs().max()) <= 1e-4 * max(1.0, float(refg.abs().max()))
+
+
+@pytest.mark.gpu
+def test_hip_conv2d_autograd_matches_torch():
+    """ops.Conv2d inside autograd: relu(conv + bias + skip) forward, gradients to x and to the skip tensor"""
+    from eval_driving_safety_amd import ops
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(5)
+    x = torch.randn((2, 64, 19, 63), device=dev, generator=gen, requires_grad=True)
+    skip = torch.randn((2, 256, 19, 63), device=dev, generator=gen, requires_grad=True)
+    wt = torch.randn((256, 64, 1, 1), device=dev, generator=gen) * 0.1
+    bias = torch.randn((256,), device=dev, generator=gen)
+    prep = ops.Conv2dPrep(wt)
+    y = ops.Conv2d.apply(x, prep, bias, skip, True)
+    ref = F.relu(F.conv2d(x, wt, bias) + skip)
+    assert float((y - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+    gy = torch.randn(y.shape, device=dev, generator=gen)
+    gx, gs = torch.autograd.grad(y, (x, skip), gy)
+    rx, rsk = torch.autograd.grad(ref, (x, skip), gy)
+    assert float((gx - rx).abs().max()) <= 1e-4 * float(rx.abs().max())
+    assert torch.equal(gs * (ref > 0), rsk * (y > 0)) or float((gs - rsk).abs().max()) <= 1e-6
+
+
+@pytest.mark.gpu
+def test_hip_conv2d_r101_layer_shapes_full_size():
+    """the 1x1 layers of the ResNet-101-FPN step at their real size (600x1987 -> 150x497 ... 19x63, both eyes): a sampled set of output
+    elements against the oracle's chain (the full oracle would take minutes), the whole tensor within 1e-4 of torch"""
+    from eval_driving_safety_amd import ops
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(9)
+    for cin, cout, h, w in ((256, 64, 150, 497), (64, 256, 150, 497), (512, 128, 75, 249), (1024, 256, 38, 125), (256, 1024, 38, 125), (2048, 512, 19, 63)):
+        x = torch.randn((2, cin, h, w), device=dev, generator=gen)
+        wt = torch.randn((cout, cin, 1, 1), device=dev, generator=gen) * (1.0 / cin) ** 0.5
+        bias = torch.randn((cout,), device=dev, generator=gen)
+        y = ops.conv2d(x, ops.Conv2dPrep(wt), bias, relu=True)
+        ref = F.relu(F.conv2d(x, wt, bias))
+        assert float((y - ref).abs().max()) <= 1e-4 * float(ref.abs().max()), (cin, cout, h, w)
+        # sampled pixels: last pixel of the plane, tile borders, a few in the middle
+        ps = sorted({0, 31, 32, 255, 256, h * w - 1, h * w - 2, h * w // 2, h * w // 3 + 7})
+        xs = x.reshape(2, cin, h * w)[:, :, ps].cpu().numpy().reshape(2, cin, 1, len(ps))
+        want = C.conv2d(xs, wt.cpu().numpy(), bias.cpu().numpy(), relu=True)
+        got = y.reshape(2, cout, h * w)[:, :, ps].cpu().numpy().reshape(2, cout, 1, len(ps))
+        assert got.tobytes() == want.tobytes(), (cin, cout, h, w)

@@ -76,6 +76,8 @@ def test_hip_roi_align(cfg, route):
     assert gf.cpu().numpy().tobytes() == O.roi_align_bwd_ordered(g, rois, feat.shape, cfg["scale"], cfg["sr"]).tobytes(), "backward not bit-exact"
     again = ops.roi_align_bwd(torch.tensor(g, device=dev), tr, feat.shape, cfg["scale"], cfg["sr"])
     assert torch.equal(gf, again)
+    with route(ADV_ROI_BWD_CB8="1"):                   # eight channels per lane whatever the map size (small maps take fewer): same bits
+        assert torch.equal(ops.roi_align_bwd(torch.tensor(g, device=dev), tr, feat.shape, cfg["scale"], cfg["sr"]), gf)
     # autograd wrapper
     tf2 = tf.clone().requires_grad_(True)
     o2 = ops.RoIAlign.apply(tf2, tr, cfg["pooled"], cfg["scale"], cfg["sr"])
