@@ -556,3 +556,262 @@ class StereoRcnnAdapter:
         extra.num_boxes.data = torch.tensor(1)                                                   # patch_attack.py:188
         patchgeom.inject_fake_target_srcnn(extra.gt_boxes_left, extra.gt_boxes_right, extra.gt_boxes_merge,
                                            centers_l[0], centers_r[0], radius)
+
+
+class _BilinearUp(torch.autograd.Function):
+    """F.interpolate(x, size, mode="bilinear", align_corners=False) with a DETERMINISTIC backward: torch's backward of the bilinear
+    up-sampling scatters with atomicAdd (listed under torch.use_deterministic_algorithms), which would make the whole attack gradient
+    differ from run to run in its last bits.  The up-sampling is linear and separable, up = A_h . x . A_w^T, so its adjoint is
+    A_h^T . g . A_w - two small matrix products in a fixed order (the interpolation matrices are read off F.interpolate itself)."""
+
+    @staticmethod
+    def _matrix(n_in, n_out, device):
+        eye = torch.eye(n_in, device=device).view(1, n_in, n_in, 1)
+        return F.interpolate(eye, size=(n_out, 1), mode="bilinear", align_corners=False)[0, :, :, 0].t().contiguous()     # [n_out, n_in]
+
+    @staticmethod
+    def forward(ctx, x, size):
+        ctx.in_hw = tuple(x.shape[2:])
+        ctx.size = tuple(size)
+        return F.interpolate(x, size=size, mode="bilinear", align_corners=False)
+
+    @staticmethod
+    def backward(ctx, g):
+        (h, w), (ho, wo) = ctx.in_hw, ctx.size
+        ah, aw = _BilinearUp._matrix(h, ho, g.device), _BilinearUp._matrix(w, wo, g.device)
+        return torch.matmul(ah.t(), torch.matmul(g.contiguous(), aw)), None
+
+
+class DsgnShapedAdapter(PsvStereoAdapter):
+    """The DSGN-SHAPED graph with SURVEY App. B's LAYER LIST (all of it [UPSTREAM-UNVERIFIED]: DSGN's source is not in the reference
+    tree - these are the published PSMNet / DSGN structures, random weights, batch-norms folded into biases):
+      2D extractor (per eye, shared)  3 x conv3x3 32 (first stride 2) - 3 residual blocks 32 @1/2 - 16 blocks 64 @1/4 (first stride 2) -
+                                      3 blocks 128 - 3 blocks 128 dilation 2 - four average-pool branches (64/32/16/8) -> 1x1 32 -> up -
+                                      concat 320 -> conv3x3 128 -> conv1x1 32                                    (torch / MIOpen)
+      plane-sweep volume              [B,64,48,H/4,W/4], fractional disparities                                 (csrc/psv.hip)
+      dres0 / dres1                   64->32, 32->32 | 32->32, 32->32 (+ skip)                                  (csrc/conv3d.hip, float32 MFMA)
+      3D hourglass                    32->64 /2, 64->64, 64->64 /2, 64->64, up 64->64 (+ skip), up 64->32 (+ skip)
+      classif                         32->32, 32->1 -> fused trilinear up-sampling + softmax + expectation      (csrc/volume.hip)
+      3D geometric volume             features x plane probability -> grid_sample -> [B,32,192,20,304]          (csrc/volume.hip)
+      3DGV stack                      32->64, 3D hourglass 64->128 /2, 128, 128 /2, 128, up 128 (+ skip), up 64 (+ skip)
+      bird's-eye view                 height pooled 20 -> 5 and folded into channels (320) -> conv3x3 128 -> 2D hourglass
+                                      (128->256 /2, 256, 256 /2, 256, up 256 (+ skip), up 128 (+ skip))       (torch / MIOpen)
+      heads                           two towers of 4 x conv3x3 128 -> class / box (7 per anchor) / centerness maps
+    ``flops_fwd`` accumulates 2 x MACs of every convolution of a forward pass; a detector step (forward + backward w.r.t. the images)
+    costs twice that.  ``torch_ops=True`` computes the same graph with torch's own operators (the parity reference of the tests)."""
+
+    def __init__(self, device, seed=0, planes=48, image_hw=(384, 1248), fu=721.5377, cu=609.5593, cv=172.854, mfma_conv=True, torch_ops=False):
+        super().__init__(device, seed=seed, channels=32, planes=planes, mid=32, mfma_conv=mfma_conv and not torch_ops, interp=True,
+                         hourglass=False, dsgn_head=True, fu=fu, cu=cu, cv=cv, image_hw=image_hw)
+        self.torch_ops = bool(torch_ops)
+        self.flops_fwd = 0
+        gen = torch.Generator().manual_seed(seed + 1000)
+        dev = device
+
+        def conv(cout, cin, *k, gain=1.0):
+            fan = cin
+            for v in k:
+                fan *= v
+            return (torch.randn(cout, cin, *k, generator=gen) * (gain * (2.0 / fan) ** 0.5)).to(dev), (torch.randn(cout, generator=gen) * 0.02).to(dev)
+
+        # ---- 2D extractor: name -> (weight, bias, stride, padding, dilation)
+        w2 = {}
+
+        def add2(name, cout, cin, k, stride=1, dilation=1, gain=1.0):
+            w, b = conv(cout, cin, k, k, gain=gain)
+            w2[name] = (w, b, stride, dilation * (k // 2), dilation)
+
+        add2("f0a", 32, 3, 3, stride=2)
+        add2("f0b", 32, 32, 3)
+        add2("f0c", 32, 32, 3)
+        self.blocks = []                                   # (prefix, has projection)
+        cin = 32
+        for li, (width, n, stride, dil) in enumerate(((32, 3, 1, 1), (64, 16, 2, 1), (128, 3, 1, 1), (128, 3, 1, 2)), start=1):
+            for i in range(n):
+                pre = "l%d.%d" % (li, i)
+                s = stride if i == 0 else 1
+                add2(pre + ".a", width, cin, 3, stride=s, dilation=dil)
+                add2(pre + ".b", width, width, 3, dilation=dil, gain=0.3)
+                proj = s != 1 or cin != width
+                if proj:
+                    add2(pre + ".p", width, cin, 1, stride=s)
+                self.blocks.append((pre, proj, li))
+                cin = width
+        for k in (64, 32, 16, 8):
+            add2("spp%d" % k, 32, 128, 1)
+        add2("last_a", 128, 320, 3)
+        add2("last_b", 32, 128, 1, gain=0.15)
+        # ---- bird's-eye view + heads
+        add2("bev_a", 128, 320, 3)
+        add2("bh1", 256, 128, 3, stride=2)
+        add2("bh2", 256, 256, 3)
+        add2("bh3", 256, 256, 3, stride=2)
+        add2("bh4", 256, 256, 3)
+        for t in ("ct", "rt"):
+            for i in range(4):
+                add2("%s%d" % (t, i), 128, 128, 3)
+        a = self.ANCHORS
+        add2("head_cls", a, 128, 3, gain=0.1)
+        add2("head_reg", 7 * a, 128, 3, gain=0.1)
+        add2("head_ctr", a, 128, 3, gain=0.1)
+        self.w2 = w2
+        self.wt2 = {"bh5": conv(256, 256, 3, 3), "bh6": conv(256, 128, 3, 3)}      # ConvTranspose2d layout [in, out, 3, 3]; bias [in]-shaped draw reused below
+        self.wt2 = {k: (w, (torch.randn(w.shape[1], generator=gen) * 0.02).to(dev)) for k, (w, _) in self.wt2.items()}
+        # ---- 3D layers: name -> dict(kind, weight, bias, cout, prepared weights)
+        ops = self.ops
+        self.w3 = {}
+
+        def add3(name, kind, cout, cin, gain=1.0):
+            if kind == "t2":                               # ConvTranspose3d layout [in, out, 3,3,3]
+                w, _ = conv(cin, cout, 3, 3, 3, gain=gain)
+                b = (torch.randn(cout, generator=gen) * 0.02).to(dev)
+            else:
+                w, b = conv(cout, cin, 3, 3, 3, gain=gain)
+            e = {"kind": kind, "w": w, "b": b, "cout": cout, "cin": cin}
+            if self.mfma_conv:
+                if kind == "s1":
+                    e["p"], e["pt"] = ops.conv3d_k3_prep(w), ops.conv3d_k3_prep(w, transpose=True)
+                elif kind == "s2":
+                    e["p"], e["pt"] = ops.conv3d_k3_s2_prep(w), ops.conv_transpose3d_k3_s2_prep(w)
+                else:
+                    e["p"], e["pt"] = ops.conv_transpose3d_k3_s2_prep(w), ops.conv3d_k3_s2_prep(w)
+            self.w3[name] = e
+
+        for name, kind, cout, cin, gain in (("dres0a", "s1", 32, 64, 1), ("dres0b", "s1", 32, 32, 1), ("dres1a", "s1", 32, 32, 1), ("dres1b", "s1", 32, 32, 0.3),
+                                            ("hg1", "s2", 64, 32, 1), ("hg2", "s1", 64, 64, 1), ("hg3", "s2", 64, 64, 1), ("hg4", "s1", 64, 64, 1),
+                                            ("hg5", "t2", 64, 64, 0.5), ("hg6", "t2", 32, 64, 0.5), ("cls_a", "s1", 32, 32, 1), ("cls_b", "s1", 1, 32, 1),
+                                            ("gv1", "s1", 64, 32, 1), ("gh1", "s2", 128, 64, 1), ("gh2", "s1", 128, 128, 1), ("gh3", "s2", 128, 128, 1),
+                                            ("gh4", "s1", 128, 128, 1), ("gh5", "t2", 128, 128, 0.5), ("gh6", "t2", 64, 128, 0.5)):
+            add3(name, kind, cout, cin, gain)
+
+    # -- layer helpers (each counts its forward FLOPs) -------------------------------------------------------------------
+    def _c2(self, x, name, relu=False, residual=None):
+        w, b, s, p, d = self.w2[name]
+        y = F.conv2d(x, w, b, s, p, d)
+        self.flops_fwd += 2 * y.numel() * w.shape[1] * w.shape[2] * w.shape[3]
+        if residual is not None:
+            y = y + residual
+        return F.relu(y) if relu else y
+
+    def _ct2(self, x, name, relu=False, residual=None):
+        w, b = self.wt2[name]
+        y = F.conv_transpose2d(x, w, b, stride=2, padding=1, output_padding=1)
+        self.flops_fwd += 2 * x.numel() * w.shape[1] * 9
+        if residual is not None:
+            y = y + residual
+        return F.relu(y) if relu else y
+
+    def _c3(self, x, name, relu=False, residual=None):
+        e, ops = self.w3[name], self.ops
+        kind, w, b, cout = e["kind"], e["w"], e["b"], e["cout"]
+        if kind == "t2":
+            self.flops_fwd += 2 * x.numel() * cout * 27
+        if self.mfma_conv:
+            if kind == "s1":
+                if cout < 4:                                   # the 32 -> 1 score layer: the narrow kernels, no bias
+                    y = ops.Conv3dK3.apply(x, e["p"], e["pt"], cout)
+                    y = y + b.view(1, -1, 1, 1, 1)
+                else:
+                    y = ops.Conv3dK3.apply(x, e["p"], e["pt"], cout, None, b, relu, residual)
+            elif kind == "s2":
+                y = ops.Conv3dK3S2.apply(x, e["p"], e["pt"], cout, b, relu)
+            else:
+                y = ops.ConvTranspose3dK3S2.apply(x, e["p"], e["pt"], cout, b, relu, residual)
+        else:
+            if kind == "t2":
+                y = F.conv_transpose3d(x, w, b, stride=2, padding=1, output_padding=1)
+            else:
+                y = F.conv3d(x, w, b, stride=2 if kind == "s2" else 1, padding=1)
+            if residual is not None:
+                y = y + residual
+            if relu:
+                y = F.relu(y)
+        if kind != "t2":
+            self.flops_fwd += 2 * y.numel() * e["cin"] * 27
+        return y
+
+    # -- the graph ----------------------------------------------------------------------------------------------------------
+    def features(self, img):
+        x = self._c2(self._c2(self._c2(img, "f0a", True), "f0b", True), "f0c", True)
+        outs = {}
+        for pre, proj, li in self.blocks:
+            idt = self._c2(x, pre + ".p") if proj else x
+            x = self._c2(self._c2(x, pre + ".a", True), pre + ".b", residual=idt)         # PSMNet's BasicBlock: no ReLU after the sum
+            outs[li] = x
+        l2, l4 = outs[2], outs[4]
+        branches = []
+        for k in (64, 32, 16, 8):
+            kh, kw = min(k, l4.shape[2]), min(k, l4.shape[3])
+            br = self._c2(F.avg_pool2d(l4, (kh, kw), stride=(kh, kw)), "spp%d" % k, True)
+            branches.append(_BilinearUp.apply(br, tuple(l4.shape[2:])))
+        cat = torch.cat([l2, l4] + branches, 1)
+        return self._c2(self._c2(cat, "last_a", True), "last_b")
+
+    def _volume_net_impl(self, cost):
+        c0 = self._c3(self._c3(cost, "dres0a", True), "dres0b", True)
+        c0 = self._c3(self._c3(c0, "dres1a", True), "dres1b", False, c0)
+        pre = self._c3(self._c3(c0, "hg1", True), "hg2", True)
+        h = self._c3(self._c3(pre, "hg3", True), "hg4", True)
+        post = self._c3(h, "hg5", True, pre)
+        out = self._c3(post, "hg6", False, c0)
+        score = self._c3(self._c3(out, "cls_a", True), "cls_b")
+        return score.squeeze(1), out
+
+    def detection_maps(self, feat_vol, cost):
+        ops = self.ops
+        prob = torch.softmax(cost, dim=1)
+        b = feat_vol.shape[0]
+        vol = (feat_vol * prob[:, None]).contiguous()
+        if self.torch_ops:
+            gv = F.grid_sample(vol, self.gv_grid.expand(b, -1, -1, -1, -1), mode="bilinear", padding_mode="zeros", align_corners=True)
+        else:
+            grid, plan = self._gv(b)
+            gv = ops.GridSample3d.apply(vol, grid, plan)                                                  # [B,32,Zg,Yg,Xg]
+        g1 = self._c3(gv, "gv1", True)
+        pre = self._c3(self._c3(g1, "gh1", True), "gh2", True)
+        h = self._c3(self._c3(pre, "gh3", True), "gh4", True)
+        post = self._c3(h, "gh5", True, pre)
+        g = self._c3(post, "gh6", True, g1)
+        bb, c, zg, yg, xg = g.shape
+        bev = F.avg_pool3d(g, (1, self.ypool, 1)).permute(0, 1, 3, 2, 4).reshape(bb, c * (yg // self.ypool), zg, xg)
+        b0 = self._c2(bev, "bev_a", True)
+        pre2 = self._c2(self._c2(b0, "bh1", True), "bh2", True)
+        h2 = self._c2(self._c2(pre2, "bh3", True), "bh4", True)
+        post2 = self._ct2(h2, "bh5", True, pre2)
+        x = self._ct2(post2, "bh6", True, b0)
+        ct = rt = x
+        for i in range(4):
+            ct, rt = self._c2(ct, "ct%d" % i, True), self._c2(rt, "rt%d" % i, True)
+        return self._c2(ct, "head_cls") + self.cls_bias, self._c2(rt, "head_reg"), self._c2(rt, "head_ctr")
+
+    def forward_all(self, imgL, imgR):
+        b = imgL.shape[0]
+        f = self.features(torch.cat([imgL, imgR], 0))                      # both eyes through the shared extractor as one batch
+        fl, fr = f[:b].contiguous(), f[b:].contiguous()
+        cost = self.ops.PsvBuildLerp.apply(fl, fr, self.shifts(b))
+        score, feat = self._volume_net_impl(cost)
+        if self.torch_ops:
+            up = F.interpolate(score[:, None], size=self.up_size, mode="trilinear", align_corners=False)[:, 0]
+            depth = (torch.softmax(up, 1) * self.depth_up.view(1, -1, 1, 1)).sum(1)
+        else:
+            depth = self.ops.DepthRegress.apply(score.contiguous(), self.depth_up, self.up_size, False)
+        return depth, self.detection_maps(feat, score)
+
+    def detection_loss(self, maps, targets):
+        if not self.torch_ops:
+            return super().detection_loss(maps, targets)
+        cls, reg, ctr = maps
+        t = targets
+        logits = cls.permute(0, 2, 3, 1).reshape(-1)
+        tt = t["cls"].float()
+        p = torch.sigmoid(logits)
+        focal = -(tt * 0.25 * (1 - p) ** 2 * F.logsigmoid(logits) + (1 - tt) * 0.75 * p ** 2 * F.logsigmoid(-logits)).sum()
+        npos = t["npos"]
+        return focal / npos + F.smooth_l1_loss(reg.reshape(-1).index_select(0, t["posr_idx"]), t["reg_pos"], reduction="sum") / npos + \
+            F.binary_cross_entropy_with_logits(ctr.reshape(-1).index_select(0, t["pos_idx"]), t["ctr_pos"], reduction="sum") / npos
+
+    def flops_per_step(self, x, extra):
+        """2 x MACs of every convolution of ONE detector step (forward + backward w.r.t. the images = 2 x the forward count)"""
+        self.flops_fwd = 0
+        self.loss_and_grad(x, extra)
+        return 2 * self.flops_fwd

@@ -86,7 +86,7 @@ class PgdAttack:
     """
 
     def __init__(self, model_kind, alpha, eps, iters, out_root=".", save=True, save_every=1, writer_workers=None,
-                 ops=None, device=None, in_place=True, reference_on_gpu=False):
+                 ops=None, device=None, in_place=True, reference_on_gpu=False, graph=False):
         if writer_workers is None:                   # PNG (zlib) encoding is the I/O wall: 42 files per pair at N = 20
             writer_workers = min(16, max(4, (os.cpu_count() or 8) // 4))
         self.ops = ops if ops is not None else _default_ops()
@@ -103,6 +103,11 @@ class PgdAttack:
         self.alpha, self.iters = float(alpha), int(iters)
         self.out_root, self.save, self.save_every = out_root, save, max(1, int(save_every))
         self.device, self.in_place = device, in_place
+        # graph=True: ONE iteration - detector forward + loss + backward + the fused PGD step (+ its 8-bit export) - is captured in a
+        # hipGraph (torch's stream capture) and replayed ``iters`` times: one launch per iteration instead of ~10^3.  Needs a detector
+        # without host read-backs or data-dependent shapes (adapters.PsvStereoAdapter / DsgnShapedAdapter; not the proposal-based
+        # Stereo R-CNN graphs); same bits as the eager loop (tests/test_gpu_drivers.py).
+        self.graph = bool(graph)
         self.writer = pixelio.PngWriter(writer_workers, bgr=(model_kind == "srcnn")) if save else None
 
     # -- file surface --------------------------------------------------------------------------
@@ -173,6 +178,12 @@ class PgdAttack:
         # ``in_place=False`` keeps the previous iterate intact for callers that want it.
         pingpong = not self.in_place
         spare = torch.empty_like(x) if pingpong else None
+        if self.graph and self.iters > 0:
+            x = self._run_graph(x, clean, cidx, adapter, batch, exporter, rows, cols, losses)
+            if exporter is not None:
+                exporter.close()
+            self.last_losses = losses
+            return x
         for k in range(self.iters):
             loss, grad = adapter.loss_and_grad(x, batch.extra)           # detector fwd + loss + bwd (:305-336)
             losses.append(loss)
@@ -190,6 +201,40 @@ class PgdAttack:
             exporter.close()
         self.last_losses = losses
         return x
+
+    def _run_graph(self, x, clean, cidx, adapter, batch, exporter, rows, cols, losses):
+        """capture one iteration on the real buffers, replay it ``iters`` times; the iterate is updated in place"""
+        ops, sp = self.ops, self.space
+        any_export = exporter is not None and any(self._wanted(k + 1) for k in range(self.iters))
+        u8 = ops.alloc_u8(x.shape[0], rows, x.shape[3], x.device) if any_export else None
+        kw = {"clean_index": cidx} if cidx is not None else {}
+
+        def iteration():
+            loss, grad = adapter.loss_and_grad(x, batch.extra)
+            ops.pgd_step(x, grad.contiguous(), clean, sp, self.alpha, self.eps, out=x, u8_out=u8, crop=(rows, cols) if u8 is not None else None, **kw)
+            return loss
+
+        keep = x.clone()
+        side = torch.cuda.Stream(device=x.device)
+        side.wait_stream(torch.cuda.current_stream(x.device))
+        with torch.cuda.stream(side):                       # warm-up outside the capture (solver searches, lazily built plans, LDS limits)
+            for _ in range(2):
+                iteration()
+        torch.cuda.current_stream(x.device).wait_stream(side)
+        x.copy_(keep)
+        del keep
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            loss_buf = iteration().detach().reshape(()).clone()
+        x_now = x
+        for k in range(self.iters):
+            g.replay()
+            losses.append(loss_buf.clone())
+            if self._wanted(k + 1):
+                exporter.next_buffer().copy_(u8)
+                exporter.submit(self._fan_out(k + 1, batch))
+        self.last_graph = g
+        return x_now
 
     def run(self, loader, adapter, comm=None, debugnum=None):
         """Iterate a loader; with a Comm of world > 1 every rank takes the batches i % world == rank

@@ -249,7 +249,6 @@ int adv_conv2d_1x1_prep_weights_f32(const float* w, float* w_prep, int cout, int
 int adv_conv2d_1x1_f32(const float* x, const float* w_prep, const float* bias, const float* residual, const float* mask, float* y, int b, int cin,
                        int cout, int64_t pixels, int relu, int tile, adv_stream_t stream) {
   if (!x || !w_prep || !y || b < 1 || cin < 1 || cout < 1 || pixels < 1 || tile < -1 || tile > 3) return ADV_EINVAL;
-  if (static_cast<long long>(cin) * pixels < 4) return ADV_EINVAL;
   if (residual == y || mask == y || x == y) return ADV_EINVAL;
   if ((reinterpret_cast<uintptr_t>(x) & 3) || (reinterpret_cast<uintptr_t>(y) & 3) || (reinterpret_cast<uintptr_t>(w_prep) & 15) ||
       (residual && (reinterpret_cast<uintptr_t>(residual) & 3)) || (mask && (reinterpret_cast<uintptr_t>(mask) & 3)) ||

@@ -585,6 +585,22 @@ def nms(boxes, scores, thresh):
     return keep[:int(count.item())]
 
 
+def nms_padded(boxes, scores, thresh):
+    """the same suppression with NO host read-back (capturable in a hipGraph): -> keep [N] int64 whose first ``count`` entries are the
+    kept indices (the rest is -1), count [1] int32 on the device"""
+    bx = _feat(boxes, "boxes")
+    if bx.dim() != 2 or bx.shape[1] != 4:
+        raise ValueError("boxes must be [N,4]")
+    n = bx.shape[0]
+    keep = torch.full((max(n, 1),), -1, dtype=torch.int64, device=bx.device)
+    count = torch.zeros((1,), dtype=torch.int32, device=bx.device)
+    if n:
+        work = torch.empty((max(1, n * ((n + 63) // 64)),), dtype=torch.int64, device=bx.device)
+        with _on(bx):
+            _lib.call("adv_nms_f32", _ptr(bx), n, float(thresh), _ptr(keep), _ptr(count), _ptr(work), _stream(bx))
+    return keep, count
+
+
 # --------------------------------------------------------------------------------------------
 # dense 3x3x3 convolution on the float32 matrix cores (the contraction applied to the K7 cost volume)
 def conv3d_k3_prep(weight, transpose=False):
@@ -860,8 +876,7 @@ def conv2d_supported(x, weight, stride=1, padding=0):
     """does libadvengine have a kernel for this layer?  (1x1 / stride 1 / no padding so far: the class MIOpen runs at 0.40 of the
     float32 matrix peak on the ResNet-101-FPN step, profiles/r03_conv2d_layers_miopen.jsonl; 3x3 and strided layers stay on MIOpen)"""
     k = weight.shape[2]
-    return (x.is_cuda and x.dtype == torch.float32 and weight.dim() == 4 and k == 1 and weight.shape[3] == 1 and stride == 1 and padding == 0
-            and weight.shape[1] * x.shape[2] * x.shape[3] >= 4)
+    return x.is_cuda and x.dtype == torch.float32 and weight.dim() == 4 and k == 1 and weight.shape[3] == 1 and stride == 1 and padding == 0
 
 
 class Conv2dPrep:

@@ -58,11 +58,7 @@ def test_hip_conv2d_1x1_bit_exact_vs_oracle_every_tile_shape(shape):
     mask = rs.randn(b, cout, h, w).astype(np.float32)
     dev = torch.device("cuda", 0)
     tx, tw, tb, tr, tm = (torch.tensor(a, device=dev) for a in (x, wt, bias, res, mask))
-    assert ops.conv2d_supported(tx, tw, 1, 0) or cin * h * w < 4
-    if cin * h * w < 4:
-        with pytest.raises(Exception):
-            ops.conv2d(tx, ops.Conv2dPrep(tw))
-        return
+    assert ops.conv2d_supported(tx, tw, 1, 0)
     prep = ops.Conv2dPrep(tw)
     want_plain = C.conv2d(x, wt)
     want_full = C.conv2d(x, wt, bias, res, mask, relu=True)

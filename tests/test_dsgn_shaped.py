@@ -27,16 +27,14 @@ def _torch_reference_loss(net, x, extra, targets):
     bev = F.relu(F.conv2d(F.relu(F.conv2d(bev, net.bev1, padding=1)), net.bev2, padding=1))
     cls = F.conv2d(bev, net.head_cls, padding=1) + net.cls_bias
     reg, ctr = F.conv2d(bev, net.head_reg, padding=1), F.conv2d(bev, net.head_ctr, padding=1)
-    tcls, treg, tctr = targets
+    tcls = targets["cls"]
     logits = cls.permute(0, 2, 3, 1).reshape(-1)
     t = tcls.float()
     p = torch.sigmoid(logits)
     focal = -(t * 0.25 * (1 - p) ** 2 * F.logsigmoid(logits) + (1 - t) * 0.75 * p ** 2 * F.logsigmoid(-logits)).sum()
-    npos = max(1, int((tcls > 0).sum()))
-    pos = (tcls > 0).view(bb, zg, xg, -1).permute(0, 3, 1, 2)
-    posr = pos.repeat_interleave(7, dim=1)
-    det = focal / npos + F.smooth_l1_loss(reg[posr], treg[posr], reduction="sum") / npos + \
-        F.binary_cross_entropy_with_logits(ctr[pos], tctr[pos], reduction="sum") / npos
+    npos = targets["npos"]
+    det = focal / npos + F.smooth_l1_loss(reg.reshape(-1)[targets["posr_idx"]], targets["reg_pos"], reduction="sum") / npos + \
+        F.binary_cross_entropy_with_logits(ctr.reshape(-1)[targets["pos_idx"]], targets["ctr_pos"], reduction="sum") / npos
     gt = extra.disp_true
     mask = (gt > float(net.depth[0])) & (gt <= float(net.depth[-1]) + 0.8)
     return F.smooth_l1_loss(depth[mask], gt[mask], reduction="mean") + det
@@ -87,3 +85,32 @@ def test_dsgn_shaped_detections_are_deterministic_and_well_formed():
         assert scores == sorted(scores, reverse=True)                      # NMS keeps score order
         for cls_id, bbox, score, centre, (h, w, l, ry) in dets:
             assert cls_id == 2 and 0 < score < 1 and bbox[0] < bbox[2] and bbox[1] < bbox[3] and centre[2] >= 1.0 and h > 0 and w > 0 and l > 0
+
+
+@pytest.mark.gpu
+def test_dsgn_layer_list_graph_matches_torch_operators():
+    """adapters.DsgnShapedAdapter (SURVEY App. B's layer list: PSMNet-style extractor, dres0/dres1 + 3D hourglass, 64-channel 3DGV stack +
+    3D hourglass, bird's-eye-view 2D hourglass, head towers) on libadvengine's kernels against the same graph, same weights, computed
+    with torch's own operators; the FLOP count of a step is a property of the layer list, not of who computes it"""
+    from eval_driving_safety_amd import adapters, data
+    dev = torch.device("cuda", 0)
+    hw = (96, 160)
+    kw = dict(seed=3, image_hw=hw, cu=80.0, cv=44.0, fu=180.0)
+    net, ref = adapters.DsgnShapedAdapter(dev, **kw), adapters.DsgnShapedAdapter(dev, torch_ops=True, **kw)
+    gen = torch.Generator().manual_seed(11)
+    left = torch.randn((1, 3) + hw, generator=gen)
+    batch = data.StereoBatch(left, torch.roll(left, shifts=-6, dims=3) + 0.05 * torch.randn((1, 3) + hw, generator=gen), ["000000"], None)
+    extra = net.synthetic_extra(batch, seed=2)
+    x = torch.cat([batch.imgL, batch.imgR]).to(dev)
+    loss, grad = net.loss_and_grad(x, extra)
+    assert torch.isfinite(loss) and torch.isfinite(grad).all() and float(grad.abs().max()) > 0
+    loss2, grad2 = net.loss_and_grad(x, extra)
+    assert float(loss2) == float(loss) and torch.equal(grad, grad2), "the whole graph is reproducible bit for bit"
+    loss_r, grad_r = ref.loss_and_grad(x.clone(), extra)
+    assert abs(float(loss_r) - float(loss)) <= 5e-4 * max(1.0, abs(float(loss_r)))
+    scale = float(grad_r.abs().max())
+    assert float((grad_r - grad).abs().max()) <= 2e-2 * scale          # float32 through ~90 layers, two summation orders
+    big = grad_r.abs() > 2e-2 * scale
+    assert float((torch.sign(grad_r[big]) == torch.sign(grad[big])).float().mean()) > 0.995
+    f = net.flops_per_step(x, extra)
+    assert f == ref.flops_per_step(x.clone(), extra) and f > 5e11      # the 3DGV stack alone is ~0.9 TFLOP per step at any image size

@@ -227,3 +227,83 @@ def test_surrogate_detector_gradients_agree_between_mfma_and_miopen_convs():
     atk = attacks.PgdAttack("dsgn", 1 / 255, 0.03, 3, save=False, device=dev)
     atk.run_batch(batch, adapters.PsvStereoAdapter(dev, seed=0))
     assert float(atk.last_losses[-1]) > float(atk.last_losses[0])
+
+
+@pytest.mark.parametrize("detector", ["toy", "dsgn_shaped", "dsgn_layer_list"])
+def test_pgd_iteration_captured_in_a_hip_graph_equals_the_eager_loop(tmp_path, detector):
+    """PgdAttack(graph=True): ONE iteration - detector forward + loss + backward + adv_pgd_step_indexed_f32 with its 8-bit export -
+    captured with torch's stream capture and replayed N times, against the eager loop: the same final iterate, the same losses, the
+    same PNG files, bit for bit.  The DSGN-shaped detectors put every convolution / cost-volume / depth-regression / grid-sample /
+    focal-loss entry point of libadvengine (forward and backward) inside the capture."""
+    from eval_driving_safety_amd import adapters, attacks, data
+    dev = torch.device("cuda", 0)
+    if detector == "toy":
+        batch = next(iter(data.SyntheticStereo(2, "dsgn", batch=2, seed=5)))
+        make = lambda: adapters.ToyStereoAdapter(dev, seed=1)                                  # noqa: E731
+    else:
+        hw = (96, 160)
+        gen = torch.Generator().manual_seed(11)
+        left = torch.randn((1, 3) + hw, generator=gen)
+        batch = data.StereoBatch(left, torch.roll(left, shifts=-6, dims=3) + 0.05 * torch.randn((1, 3) + hw, generator=gen), ["000000"], None)
+        kw = dict(seed=3, image_hw=hw, cu=80.0, cv=44.0, fu=180.0)
+        if detector == "dsgn_shaped":
+            make = lambda: adapters.PsvStereoAdapter(dev, hourglass=True, dsgn_head=True, **kw)  # noqa: E731
+        else:
+            make = lambda: adapters.DsgnShapedAdapter(dev, **kw)                                # noqa: E731
+        batch.extra = make().synthetic_extra(batch, seed=2)
+    n = 5
+    outs = {}
+    for mode in ("eager", "graph"):
+        root = tmp_path / mode
+        atk = attacks.PgdAttack("dsgn", 1 / 255, 0.03, n, out_root=str(root), device=dev, graph=(mode == "graph"), save=(detector == "toy"))
+        x = atk.run_batch(data.StereoBatch(batch.imgL.clone(), batch.imgR.clone(), batch.names, batch.sizes, batch.extra), make())
+        atk.close()
+        outs[mode] = (x.clone(), [float(v) for v in atk.last_losses])
+    assert torch.equal(outs["eager"][0], outs["graph"][0]), "iterate after %d captured iterations" % n
+    assert outs["eager"][1] == outs["graph"][1] and len(outs["graph"][1]) == n
+    if detector == "toy":
+        for k in range(n + 1):
+            for eye in ("image_2", "image_3"):
+                for name in batch.names:
+                    a = open(str(tmp_path / "eager" / ("dsgn_pgd_iters_%d" % k) / eye / (name + ".png")), "rb").read()
+                    b = open(str(tmp_path / "graph" / ("dsgn_pgd_iters_%d" % k) / eye / (name + ".png")), "rb").read()
+                    assert a == b, (k, eye, name)
+
+
+def test_roi_path_and_2d_convolution_entry_points_are_capturable():
+    """include/advengine.h: "enqueue-only ... safe to capture in a hipGraph" for the entry points the DSGN-shaped capture does not
+    reach: RoIAlign forward / backward (tile lists + gather), NMS (its memset included), dense alignment, the 1x1 convolution GEMM"""
+    from eval_driving_safety_amd import ops
+    dev = torch.device("cuda", 0)
+    rs = np.random.RandomState(3)
+    feat = torch.tensor(rs.randn(1, 16, 38, 125).astype(np.float32), device=dev)
+    rois = torch.tensor(np.float32([[0, 40, 30, 400, 300], [0, 900, 100, 1500, 500], [0, 0, 0, 1986, 599], [0, 5, 5, 9, 9]]), device=dev)
+    boxes = torch.tensor(np.float32([[0, 0, 10, 10], [1, 1, 11, 11], [20, 20, 30, 30], [0, 0, 10, 10], [21, 21, 29, 29]]), device=dev)
+    scores = torch.tensor(np.float32([0.9, 0.8, 0.7, 0.6, 0.5]), device=dev)
+    g = torch.tensor(rs.randn(4, 16, 7, 7).astype(np.float32), device=dev)
+    x2 = torch.tensor(rs.randn(2, 24, 19, 63).astype(np.float32), device=dev)
+    prep = ops.Conv2dPrep(torch.tensor((rs.randn(40, 24, 1, 1) * 0.2).astype(np.float32), device=dev))
+
+    def work():
+        out = ops.roi_align(feat, rois, 7, 1 / 16.0, 0)
+        gf = ops.roi_align_bwd(g, rois, feat.shape, 1 / 16.0, 0)
+        keep, count = ops.nms_padded(boxes, scores, 0.5)
+        y = ops.conv2d(x2, prep, relu=True)
+        gx = ops.conv2d_dgrad(y, prep, mask=x2)
+        return out, gf, keep, count, y, gx
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        want = [t.clone() for t in work()]
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        got = work()
+    for t in got:
+        t.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    for a, b in zip(want, got):
+        assert torch.equal(a, b)
+    assert got[2][:int(got[3])].tolist() == [0, 2]

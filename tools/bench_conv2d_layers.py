@@ -57,6 +57,8 @@ def main():
     ap.add_argument("--rois", type=int, default=512)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--hip", action="store_true", help="also time libadvengine's kernels where one exists for the shape")
+    ap.add_argument("--sweep", action="store_true", help="--hip: time every tile shape of the 1x1 kernel")
+    ap.add_argument("--only", default="", help="only layer classes whose name starts with this (e.g. '1x1 s1')")
     ap.add_argument("--min-gflop", type=float, default=0.0, help="skip shapes below this many GFLOP per call")
     args = ap.parse_args()
     torch.cuda.set_device(0)
@@ -69,7 +71,7 @@ def main():
     for (cin, cout, k, s, p, b, h, w), n in sorted(counts.items(), key=lambda kv: -kv[1] * kv[0][0] * kv[0][1] * kv[0][2] ** 2 * kv[0][6] * kv[0][7] / kv[0][3] ** 2):
         ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
         flops = 2.0 * b * cin * cout * k * k * ho * wo
-        if flops < args.min_gflop * 1e9:
+        if flops < args.min_gflop * 1e9 or not ("%dx%d s%d" % (k, k, s)).startswith(args.only):
             continue
         x = torch.randn((b, cin, h, w), device=dev)
         wt = torch.randn((cout, cin, k, k), device=dev) * 0.05
@@ -87,6 +89,9 @@ def main():
             ms_hb = timeit(lambda: ops.conv2d_dgrad(g, prep, (h, w)), args.reps)
             row.update({"hip_fwd_ms": round(ms_hf, 4), "hip_dgrad_ms": round(ms_hb, 4), "hip_fwd_tflops": round(flops / ms_hf / 1e9, 1),
                         "hip_dgrad_tflops": round(flops / ms_hb / 1e9, 1)})
+            if args.sweep:      # every tile shape, forward and backward: what the host's choice should have been
+                row["hip_fwd_ms_by_tile"] = [round(timeit(lambda t=t: ops.conv2d(x, prep, bias, tile=t), args.reps), 4) for t in range(4)]
+                row["hip_dgrad_ms_by_tile"] = [round(timeit(lambda t=t: ops.conv2d_dgrad(g, prep, (h, w), tile=t), args.reps), 4) for t in range(4)]
         rows.append(row)
         print(json.dumps(row), flush=True)
         del x, wt, y, g

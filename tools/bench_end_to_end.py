@@ -83,6 +83,46 @@ def measure(pairs=1, iters=20, reps=2, warm_iters=None, mfma_conv=True, hourglas
                 "libadvengine.so"}
 
 
+def measure_dsgn_full(pairs=1, iters=20, reps=1):
+    """BASELINE configs[1] end to end through the DSGN-shaped graph with SURVEY App. B's layer list (adapters.DsgnShapedAdapter: PSMNet-style
+    2D extractor, plane-sweep volume, dres0/dres1 + 3D hourglass, fused depth regression, 3D geometric volume + 64-channel stack + 3D
+    hourglass, bird's-eye-view 2D hourglass, head towers): exact FLOPs per detector step from the layer list and the WHOLE step
+    against the float32 matrix peak - at ``pairs`` stereo pairs per step (the reference runs 1; 288 GB hold more)."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    net = adapters.DsgnShapedAdapter(dev, seed=0)
+    batch = next(iter(data.SyntheticStereo(pairs, "dsgn", batch=pairs, seed=0)))
+    batch.extra = net.synthetic_extra(batch, seed=1)
+    x = torch.cat([batch.imgL, batch.imgR]).to(dev)
+    for _ in range(2):
+        net.loss_and_grad(x, batch.extra)
+    torch.cuda.synchronize()
+    step = float(net.flops_per_step(x, batch.extra))
+    n = 5
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        net.loss_and_grad(x, batch.extra)
+    e1.record()
+    torch.cuda.synchronize()
+    model_ms = e0.elapsed_time(e1) / n
+    atk = attacks.PgdAttack("dsgn", 1 / 255, 0.03, iters, save=False, device=dev)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        atk.run_batch(batch, net)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    first, last = float(atk.last_losses[0]), float(atk.last_losses[-1])
+    return {"metric": "end-to-end stereo-pairs/s, %d-step PGD through the DSGN-shaped graph with SURVEY App. B's layer list (surrogate, random weights)" % iters,
+            "value": pairs / dt, "unit": "stereo-pairs/s", "pairs": pairs, "iters": iters, "s_per_attack": dt, "detector_fwd_bwd_ms": model_ms,
+            "flops_per_step": step, "flops_per_step_per_pair": step / pairs,
+            "roofline": {"bound": "mfma", "what": "WHOLE detector step (forward + input-gradient backward; 2D convolutions by MIOpen, everything 3D by "
+                                                   "libadvengine, element-wise and loss kernels included) against the float32 matrix peak",
+                         "achieved": step / model_ms / 1e9, "peak": 157.3, "unit": "TFLOP/s", "frac": step / model_ms / 1e9 / 157.3},
+            "mfma_frac_step": step / model_ms / 1e9 / 157.3, "peak_hbm_gib": torch.cuda.max_memory_allocated() / 2 ** 30,
+            "loss_first_iter": first, "loss_last_iter": last, "loss_rose": last > first,
+            "note": "NOT the headline metric and NOT DSGN's weights; layer list [UPSTREAM-UNVERIFIED] from the published PSMNet / DSGN structures"}
+
+
 def measure_srcnn_r101(pairs=1, iters=20, reps=1, rois=512, impl="miopen"):
     """BASELINE configs[2] with the upstream LAYER LIST (surrogates.StereoRcnnR101: ResNet-101 [3,4,23,3] + FPN P2-P6 + stereo RPN + RoI
     heads, random weights, batch-norms folded): 20-step PGD at 600x1987, exact FLOPs per detector step from the layer list, the
@@ -221,10 +261,14 @@ def main():
     ap.add_argument("--patch", action="store_true", help="universal-patch training through the DSGN-shaped graph instead")
     ap.add_argument("--srcnn", action="store_true", help="the Stereo R-CNN-shaped surrogate at 600x1987 instead")
     ap.add_argument("--r101", action="store_true", help="the ResNet-101-FPN Stereo R-CNN-shaped detector (upstream layer list) at 600x1987")
+    ap.add_argument("--full", action="store_true", help="the DSGN-shaped graph with SURVEY App. B's layer list (adapters.DsgnShapedAdapter)")
     ap.add_argument("--rois", type=int, default=512)
     ap.add_argument("--hip2d", action="store_true", help="--r101: libadvengine's 2D convolution kernels where one exists")
     args = ap.parse_args()
     torch.cuda.set_device(0)
+    if args.full:
+        print(json.dumps(measure_dsgn_full(args.pairs, args.iters, args.reps)))
+        return
     if args.r101:
         print(json.dumps(measure_srcnn_r101(args.pairs, args.iters, args.reps, args.rois, "hip" if args.hip2d else "miopen")))
         return
