@@ -460,13 +460,20 @@ def main():
             try:
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 import bench_end_to_end
-                out["end_to_end"] = bench_end_to_end.measure(pairs=1, iters=N_ITER, reps=3)
-                out["end_to_end_hourglass"] = bench_end_to_end.measure(pairs=1, iters=N_ITER, reps=2, hourglass=True)
-                out["end_to_end_dsgn_shaped"] = bench_end_to_end.measure(pairs=1, iters=N_ITER, reps=2, hourglass=True, dsgn_head=True)
-                out["end_to_end_srcnn_shaped"] = bench_end_to_end.measure_srcnn(pairs=1, iters=N_ITER, reps=2)
-                out["end_to_end_patch"] = bench_end_to_end.measure_patch(pairs=8, iters=2, reps=2)
+                # BASELINE configs[1] end to end: the DSGN-shaped graph with SURVEY App. B's layer list, exact FLOPs per step, the WHOLE
+                # step against the float32 matrix peak - at the reference's 1 pair per step and at 4 (288 GB hold far more)
+                out["end_to_end_dsgn_shaped"] = bench_end_to_end.measure_dsgn_full(pairs=1, iters=N_ITER, reps=1)
+                out["end_to_end_dsgn_shaped"]["batch_of_4_pairs"] = bench_end_to_end.measure_dsgn_full(pairs=4, iters=N_ITER, reps=1)
+                try:    # the same loop with one iteration captured in a hipGraph (launch gaps of ~10^3 kernels per step)
+                    out["end_to_end_dsgn_shaped"]["hip_graph"] = bench_end_to_end.measure_dsgn_full(pairs=1, iters=N_ITER, reps=1, graph=True)
+                except Exception as e:
+                    out["end_to_end_dsgn_shaped"]["hip_graph"] = {"error": repr(e)}
+                # BASELINE configs[2] end to end: ResNet-101-FPN Stereo R-CNN-shaped detector at 600x1987
+                out["end_to_end_srcnn_shaped"] = bench_end_to_end.measure_srcnn_r101(pairs=1, iters=N_ITER, reps=1)
+                # BASELINE configs[3]: universal-patch training through the DSGN-shaped graph
+                out["end_to_end_patch"] = bench_end_to_end.measure_patch(pairs=4, iters=2, reps=1)
             except Exception as e:
-                out["end_to_end"] = {"error": repr(e)}
+                out["end_to_end_error"] = repr(e)
             torch.cuda.empty_cache()
         if not args.no_cpu_baseline and not srcnn:
             out["cpu_baseline"] = cpu_baseline(args.cpu_pairs)

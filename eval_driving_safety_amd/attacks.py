@@ -86,9 +86,9 @@ class PgdAttack:
     """
 
     def __init__(self, model_kind, alpha, eps, iters, out_root=".", save=True, save_every=1, writer_workers=None,
-                 ops=None, device=None, in_place=True, reference_on_gpu=False, graph=False):
-        if writer_workers is None:                   # PNG (zlib) encoding is the I/O wall: 42 files per pair at N = 20
-            writer_workers = min(16, max(4, (os.cpu_count() or 8) // 4))
+                 ops=None, device=None, in_place=True, reference_on_gpu=False, graph=False, png_compress_level=1):
+        if writer_workers is None:                   # PNG (zlib) encoding is the I/O wall: 42 files per pair at N = 20; zlib releases
+            writer_workers = min(96, max(4, (os.cpu_count() or 8) // 2))     # the GIL, so the pool scales with the host's cores
         self.ops = ops if ops is not None else _default_ops()
         self.kind = model_kind
         if model_kind == "dsgn":
@@ -108,7 +108,7 @@ class PgdAttack:
         # without host read-backs or data-dependent shapes (adapters.PsvStereoAdapter / DsgnShapedAdapter; not the proposal-based
         # Stereo R-CNN graphs); same bits as the eager loop (tests/test_gpu_drivers.py).
         self.graph = bool(graph)
-        self.writer = pixelio.PngWriter(writer_workers, bgr=(model_kind == "srcnn")) if save else None
+        self.writer = pixelio.PngWriter(writer_workers, bgr=(model_kind == "srcnn"), compress_level=png_compress_level) if save else None
 
     # -- file surface --------------------------------------------------------------------------
     def _wanted(self, k):

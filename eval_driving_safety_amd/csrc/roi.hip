@@ -250,7 +250,7 @@ __device__ __forceinline__ void roi_direct(float (&acc)[CB], const Bin& b, const
 // large maps, fewer on the small pyramid levels, where 6-20 tiles x C/8 channel blocks left most of the chip idle behind a few
 // hundred-roi lists (profiles/r03_r101_kernel_stats.csv: 9.9 ms per call before, 69 of the 157 ms of the R101-shaped step).
 constexpr int kRoiBatch = 6;   // 6 x (8 rows + 32 columns) = 240 classifying lanes
-constexpr int kListCap = 6;
+constexpr int kListCap = 8;
 
 struct AxisList {
   int n;                       // samples that touch the pixel (may exceed kListCap: then the entries are not used)

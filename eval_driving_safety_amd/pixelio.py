@@ -14,10 +14,13 @@ def iter_dir(prefix, k, eye):
     return os.path.join("%s_pgd_iters_%d" % (prefix, k), "image_2" if eye == 0 else "image_3")
 
 
-def _encode_png(path, hwc_u8, bgr):
+def _encode_png(path, hwc_u8, bgr, compress_level=1):
+    """compress_level: zlib's effort.  The reference writes with PIL's default (6, attack/DSGN/pgd_attack.py:193); the DECODED pixels
+    are the same at every level - only the file size and the encode time change (level 1: ~3x faster, ~15 % larger on KITTI-like
+    content; tools/bench_folder_attack.py) - and the encode is the wall of the folder path (42 files per pair at N = 20)."""
     from PIL import Image
     a = hwc_u8[:, :, ::-1] if bgr else hwc_u8      # cv2.imwrite stores a BGR array as an RGB file
-    Image.fromarray(np.ascontiguousarray(a)).save(path)
+    Image.fromarray(np.ascontiguousarray(a)).save(path, compress_level=compress_level)
 
 
 class PngWriter:
@@ -25,9 +28,9 @@ class PngWriter:
     waits.  (The reference encodes synchronously inside the loop, attack/DSGN/pgd_attack.py:357-374:
     40 PNGs per pair for N=20.)"""
 
-    def __init__(self, workers=4, bgr=False):
-        self.q = queue.Queue(maxsize=256)
-        self.bgr = bgr
+    def __init__(self, workers=4, bgr=False, compress_level=1):
+        self.q = queue.Queue(maxsize=max(256, 8 * workers))
+        self.bgr, self.compress_level = bgr, int(compress_level)
         self.err = None
         self.threads = [threading.Thread(target=self._run, daemon=True) for _ in range(max(1, workers))]
         for t in self.threads:
@@ -41,7 +44,7 @@ class PngWriter:
             try:
                 path, arr = item
                 os.makedirs(os.path.dirname(path), exist_ok=True)
-                _encode_png(path, arr, self.bgr)
+                _encode_png(path, arr, self.bgr, self.compress_level)
             except Exception as e:      # surfaced by close()
                 self.err = e
 

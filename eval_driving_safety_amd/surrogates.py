@@ -111,6 +111,9 @@ class StereoRcnnShaped(nn.Module):
         """stereo_rpn.py:73-80: the shared 3x3 convolution on each eye, concatenated left | right"""
         return torch.cat([F.relu(self.rpn_conv(feat_l)), F.relu(self.rpn_conv(feat_r))], 1)
 
+    def rpn_deltas(self, both):
+        return self.rpn_reg(both)
+
     def head_to_tail(self, pooled):
         return F.relu(self.fc(pooled.flatten(1)))
 
@@ -156,7 +159,7 @@ class StereoRcnnShaped(nn.Module):
         scores, deltas, anchors = [], [], []
         for i in range(len(fl)):
             both = self.rpn_features(fl[i], fr[i])
-            s, d = self.rpn_cls(both), self.rpn_reg(both)
+            s, d = self.rpn_cls(both), self.rpn_deltas(both)
             scores.append(s.permute(0, 2, 3, 1).reshape(-1))
             deltas.append(d.permute(0, 2, 3, 1).reshape(-1, 6))
             anchors.append(self.anchors(i, s.shape[2], s.shape[3], dev))
@@ -186,7 +189,14 @@ class StereoRcnnShaped(nn.Module):
             for b in (left, right):
                 b[:, 0::2].clamp_(0, W - 1)
                 b[:, 1::2].clamp_(0, H - 1)
-            keep = nms(left.contiguous(), scores[order].contiguous(), 0.7)[:self.post_nms]
+            sc = scores[order]
+            min_size = getattr(self, "rpn_min_size", 0.0)
+            if min_size > 0:              # the proposal layer drops boxes under RPN_MIN_SIZE x the image scale [UPSTREAM-UNVERIFIED value]
+                big = ((left[:, 2] - left[:, 0] + 1 >= min_size) & (left[:, 3] - left[:, 1] + 1 >= min_size) &
+                       (right[:, 2] - right[:, 0] + 1 >= min_size))
+                if bool(big.any()):
+                    left, right, sc = left[big], right[big], sc[big]
+            keep = nms(left.contiguous(), sc.contiguous(), 0.7)[:self.post_nms]
             left, right = left[keep], right[keep]
             if n_gt > 0:                  # the ground truth joins the proposals, as in the proposal-target layer (stereo_rcnn.py:201-204)
                 left, right = torch.cat([gt_l, left]), torch.cat([gt_r, right])
@@ -330,6 +340,7 @@ class StereoRcnnR101(StereoRcnnShaped):
         nn.Module.__init__(self)
         self.classes, self.n_classes = classes, len(classes)
         self.post_nms, self.pre_nms, self.rois_per_image = post_nms, pre_nms, rois_per_image
+        self.rpn_min_size = 8 * 1.6            # cfg.TRAIN.RPN_MIN_SIZE x im_info scale [UPSTREAM-UNVERIFIED]
         self._roi_align, self._nms = roi_align, nms
         g = torch.Generator().manual_seed(seed)
         self.stem = FoldedConv(3, 64, 7, stride=2, padding=3, gen=g)
@@ -403,6 +414,11 @@ class StereoRcnnR101(StereoRcnnShaped):
 
     def rpn_features(self, feat_l, feat_r):
         return torch.cat([self.rpn_conv(feat_l, relu=True), self.rpn_conv(feat_r, relu=True)], 1)
+
+    def rpn_deltas(self, both):
+        # a trained RPN regresses small corrections of its anchors; random weights would give slivers a fraction of a pixel wide
+        # (0.2-4 px at P2 in the first version: a degenerate workload for RoIAlign) - bound them to what a trained network emits
+        return 0.5 * torch.tanh(self.rpn_reg(both))
 
     def head_to_tail(self, pooled):
         self._extra_flops = getattr(self, "_extra_flops", 0) + 2 * pooled.shape[0] * 2048 * 13 * self.n_classes

@@ -83,7 +83,7 @@ def measure(pairs=1, iters=20, reps=2, warm_iters=None, mfma_conv=True, hourglas
                 "libadvengine.so"}
 
 
-def measure_dsgn_full(pairs=1, iters=20, reps=1):
+def measure_dsgn_full(pairs=1, iters=20, reps=1, graph=False):
     """BASELINE configs[1] end to end through the DSGN-shaped graph with SURVEY App. B's layer list (adapters.DsgnShapedAdapter: PSMNet-style
     2D extractor, plane-sweep volume, dres0/dres1 + 3D hourglass, fused depth regression, 3D geometric volume + 64-channel stack + 3D
     hourglass, bird's-eye-view 2D hourglass, head towers): exact FLOPs per detector step from the layer list and the WHOLE step
@@ -105,13 +105,31 @@ def measure_dsgn_full(pairs=1, iters=20, reps=1):
     e1.record()
     torch.cuda.synchronize()
     model_ms = e0.elapsed_time(e1) / n
-    atk = attacks.PgdAttack("dsgn", 1 / 255, 0.03, iters, save=False, device=dev)
+    atk = attacks.PgdAttack("dsgn", 1 / 255, 0.03, iters, save=False, device=dev, graph=graph)
+    if graph:                                      # the capture itself (2 warm-up iterations + instantiate) is paid once per batch shape
+        atk.run_batch(batch, net)
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):
         atk.run_batch(batch, net)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     first, last = float(atk.last_losses[0]), float(atk.last_losses[-1])
+    if graph:       # what the eager loop loses between kernels: the replayed iteration against the eager detector step + PGD step
+        g = atk.last_graph
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        replay_ms = e0.elapsed_time(e1) / n
+        return {"metric": "the same %d-step attack with ONE iteration (detector forward + backward + fused PGD step) captured in a hipGraph" % iters,
+                "value": pairs / dt, "unit": "stereo-pairs/s", "pairs": pairs, "iters": iters, "s_per_attack_incl_capture": dt,
+                "graph_replay_ms_per_iteration": replay_ms, "eager_detector_fwd_bwd_ms": model_ms,
+                "launch_gap_share_of_eager_step": max(0.0, 1.0 - replay_ms / model_ms),
+                "note": "s_per_attack includes the per-batch capture (2 eager warm-up iterations + graph instantiation); replay vs eager is the launch-gap share"}
     return {"metric": "end-to-end stereo-pairs/s, %d-step PGD through the DSGN-shaped graph with SURVEY App. B's layer list (surrogate, random weights)" % iters,
             "value": pairs / dt, "unit": "stereo-pairs/s", "pairs": pairs, "iters": iters, "s_per_attack": dt, "detector_fwd_bwd_ms": model_ms,
             "flops_per_step": step, "flops_per_step_per_pair": step / pairs,
@@ -215,7 +233,7 @@ def measure_patch(pairs=8, iters=2, reps=2):
     sum + clamp + patch update (K4); batch 1, world 1 = the reference's own sequence (attack/DSGN/patch_attack.py:367-430)"""
     import tempfile
     dev = torch.device("cuda", torch.cuda.current_device())
-    net = adapters.PsvStereoAdapter(dev, seed=0, hourglass=True, dsgn_head=True)
+    net = adapters.DsgnShapedAdapter(dev, seed=0)
     import contextlib
     import io
     batches = []                                   # the pairs are generated once, outside the timed region (host-side synthesis)
@@ -262,12 +280,13 @@ def main():
     ap.add_argument("--srcnn", action="store_true", help="the Stereo R-CNN-shaped surrogate at 600x1987 instead")
     ap.add_argument("--r101", action="store_true", help="the ResNet-101-FPN Stereo R-CNN-shaped detector (upstream layer list) at 600x1987")
     ap.add_argument("--full", action="store_true", help="the DSGN-shaped graph with SURVEY App. B's layer list (adapters.DsgnShapedAdapter)")
+    ap.add_argument("--graph", action="store_true", help="--full: one PGD iteration captured in a hipGraph")
     ap.add_argument("--rois", type=int, default=512)
     ap.add_argument("--hip2d", action="store_true", help="--r101: libadvengine's 2D convolution kernels where one exists")
     args = ap.parse_args()
     torch.cuda.set_device(0)
     if args.full:
-        print(json.dumps(measure_dsgn_full(args.pairs, args.iters, args.reps)))
+        print(json.dumps(measure_dsgn_full(args.pairs, args.iters, args.reps, graph=args.graph)))
         return
     if args.r101:
         print(json.dumps(measure_srcnn_r101(args.pairs, args.iters, args.reps, args.rois, "hip" if args.hip2d else "miopen")))

@@ -20,7 +20,7 @@ from eval_driving_safety_amd import adapters, attacks, data  # noqa: E402
 def main():
     from PIL import Image
     import synth
-    n, batch, iters = int(os.environ.get("PAIRS", "48")), 4, 4
+    n, batch, iters = int(os.environ.get("PAIRS", "48")), 4, int(os.environ.get("ITERS", "4"))
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     with tempfile.TemporaryDirectory() as root:
@@ -33,17 +33,20 @@ def main():
         with open(os.path.join(root, "val.txt"), "w") as f:
             f.write("\n".join("%06d" % i for i in range(n)) + "\n")
         toy = adapters.ToyStereoAdapter(dev, seed=1)
-        for workers, save, as_u8 in ((0, True, False), (12, True, False), (12, True, True), (12, False, False), (12, False, True)):
-            out = os.path.join(root, "out_%d_%d_%d" % (workers, save, as_u8))
+        for workers, save, as_u8, level, pool in ((0, True, False, 6, 16), (12, True, False, 6, 16), (12, True, False, 6, None), (12, True, False, 1, None),
+                                                  (12, True, False, 0, None), (12, False, False, 1, None), (12, False, True, 1, None)):
+            out = os.path.join(root, "out_%d_%d_%d_%d_%s" % (workers, save, as_u8, level, pool))
             loader = data.KittiFolder(root, os.path.join(root, "val.txt"), batch, workers=workers, as_u8=as_u8)
-            atk = attacks.PgdAttack("dsgn", 1 / 255, 0.03, iters, out_root=out, save=save, device=dev)
+            atk = attacks.PgdAttack("dsgn", 1 / 255, 0.03, iters, out_root=out, save=save, device=dev, png_compress_level=level, writer_workers=pool)
+            atk_threads = atk.writer.threads if atk.writer is not None else []
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             done = atk.run(loader, toy)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             print(json.dumps({"path": "KittiFolder(PNG) -> PgdAttack(toy detector, %d steps, batch %d) -> %s" % (iters, batch, "PNG folders of every iterate" if save else "no files"),
-                              "decode_threads": workers, "loader_transform": "on the device from 8-bit pixels (ops.import_u8)" if as_u8 else "on the host (float upload)",
+                              "decode_threads": workers, "png_compress_level": level if save else None,
+                              "png_writer_threads": (len(atk_threads) if save else 0), "host_cores": os.cpu_count(), "loader_transform": "on the device from 8-bit pixels (ops.import_u8)" if as_u8 else "on the host (float upload)",
                               "pairs": done, "pairs_per_s": round(done / dt, 2), "seconds": round(dt, 2),
                               "png_files_written": (iters + 1) * 2 * done if save else 0}), flush=True)
 
