@@ -740,9 +740,20 @@ class DsgnShapedAdapter(PsvStereoAdapter):
             outs[li] = x
         l2, l4 = outs[2], outs[4]
         branches = []
+        pooled = {}
+        if l4.shape[2] >= 64 and l4.shape[3] >= 64:
+            # the four pooling windows nest (8 | 16 | 32 | 64, same origin, floor): pool 8x8 once and halve three times - torch's avg_pool2d
+            # with a 64 x 64 window has four output columns' worth of threads summing 4096 elements each (0.6 ms a call at 96 x 312)
+            pooled[8] = F.avg_pool2d(l4, 8)
+            for k in (16, 32, 64):
+                pooled[k] = F.avg_pool2d(pooled[k // 2], 2)
         for k in (64, 32, 16, 8):
-            kh, kw = min(k, l4.shape[2]), min(k, l4.shape[3])
-            br = self._c2(F.avg_pool2d(l4, (kh, kw), stride=(kh, kw)), "spp%d" % k, True)
+            if k in pooled:
+                p = pooled[k]
+            else:
+                kh, kw = min(k, l4.shape[2]), min(k, l4.shape[3])
+                p = F.avg_pool2d(l4, (kh, kw), stride=(kh, kw))
+            br = self._c2(p, "spp%d" % k, True)
             branches.append(_BilinearUp.apply(br, tuple(l4.shape[2:])))
         cat = torch.cat([l2, l4] + branches, 1)
         return self._c2(self._c2(cat, "last_a", True), "last_b")
