@@ -226,6 +226,185 @@ int pick_1x1_tile(int b, int M, long long P, int simds) {
   return best;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / padding = dilation (1 or 2): implicit GEMM  D[co][pixel] += W[co][ci][tap] * X[ci][pixel + tap offset], the 2D
+// sibling of csrc/conv3d.hip's main kernel.  A workgroup (4 waves) owns TH output rows x 32 columns x CO output channels; wave v
+// owns RW of the rows for all CO / 32 channel blocks (RW * CO / 32 = 4 accumulators per wave).  Per stage of kC3 = 8 input
+// channels the input tile with its halo ([8][TH + 2 dil][40 floats]: columns w0 - 4 .. w0 + 35, every tap is a shift of the LDS
+// column) and the weights [9][8][CO] are fetched global -> registers while the MFMAs of the previous stage run, then committed to
+// the other LDS buffer (one barrier per stage).  A lane's fetch plan (element offsets, which float4 groups lie inside the image) is
+// computed once per tile.  Order of accumulation: stage, tap, channel pair - orc_conv2d(chunk = 8) restates it bit for bit.
+constexpr int kC3 = 8;
+constexpr int kLW = 40;   // LDS row: 4 halo columns left, 32 outputs, 4 right
+
+template <int RW, int CBK, int DIL>   // rows per wave, 32-channel blocks per workgroup, dilation
+struct Geo3 {
+  static constexpr int kTH = 4 * RW, kCO = 32 * CBK;
+  static constexpr int kRows = kTH + 2 * DIL;
+  static constexpr int kSX = kC3 * kRows * kLW, kSW = 9 * kC3 * kCO;       // floats per stage
+  static constexpr int kXN = kC3 * kRows * (kLW / 4), kWN = 9 * kC3 * (kCO / 4);
+  static constexpr int kXSlots = (kXN + 255) / 256, kWSlots = (kWN + 255) / 256;   // float4 fetches per thread and stage
+};
+
+template <int RW, int CBK, int DIL>
+__global__ __launch_bounds__(256, 2) void conv2d_3x3_mfma(const float* __restrict__ x, const float* __restrict__ wp, float* __restrict__ y, int Cin,
+                                                          int Cout, int cinpad, int copad, int H, int W, int tiles_w, Epi2 epi) {
+  using G = Geo3<RW, CBK, DIL>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l32 = lane & 31;
+  const int wt = blockIdx.x % tiles_w, ht = blockIdx.x / tiles_w;
+  const int w0 = wt * 32, h0 = ht * G::kTH, co0 = blockIdx.y * G::kCO;
+  const long long b = blockIdx.z;
+  const long long HW = static_cast<long long>(H) * W;
+  const float* xb = x + b * Cin * HW;
+
+  f32x16 acc[CBK][RW];
+#pragma unroll
+  for (int i = 0; i < CBK; ++i)
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[i][r][v] = 0.0f;
+
+  // fetch plan, once per tile: slot s = tid + 256 i -> (channel c, tile row r, float4 group j)
+  long long xoff[G::kXSlots];
+  int xkind[G::kXSlots], xc[G::kXSlots];   // kind 0: zeros, 1: one dword-aligned float4, 2: element by element (the image's edge)
+#pragma unroll
+  for (int i = 0; i < G::kXSlots; ++i) {
+    const int sidx = tid + 256 * i;
+    const int j = sidx % (kLW / 4), r = (sidx / (kLW / 4)) % G::kRows, c = sidx / ((kLW / 4) * G::kRows);
+    const int gh = h0 - DIL + r, gw = w0 - 4 + 4 * j;
+    xkind[i] = 0, xoff[i] = 0, xc[i] = c;
+    if (sidx < G::kXN && gh >= 0 && gh < H && gw + 3 >= 0 && gw < W) {
+      xoff[i] = static_cast<long long>(c) * HW + static_cast<long long>(gh) * W + gw;
+      xkind[i] = (gw >= 0 && gw + 3 < W) ? 1 : 2;
+    }
+  }
+  v4f rx[G::kXSlots], rw[G::kWSlots];
+  auto fetch = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < G::kXSlots; ++i) {
+      v4f v = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (xkind[i] != 0 && c0 + xc[i] < Cin) {
+        const float* src = xb + static_cast<long long>(c0) * HW + xoff[i];
+        if (xkind[i] == 1) {
+          v = *reinterpret_cast<const v4f_u*>(src);
+        } else {
+          const int gw = w0 - 4 + 4 * ((tid + 256 * i) % (kLW / 4));
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (gw + e >= 0 && gw + e < W) v[e] = src[e];
+        }
+      }
+      rx[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < G::kWSlots; ++i) {
+      const int sidx = tid + 256 * i;
+      const int q = sidx % (G::kCO / 4), k = (sidx / (G::kCO / 4)) % kC3, tap = sidx / ((G::kCO / 4) * kC3);
+      v4f v = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (sidx < G::kWN) v = *reinterpret_cast<const v4f*>(wp + (static_cast<long long>(tap) * cinpad + c0 + k) * copad + co0 + 4 * q);
+      rw[i] = v;
+    }
+  };
+  auto commit = [&](int buf) {
+    float* sx = lds + buf * (G::kSX + G::kSW);
+    float* sw = sx + G::kSX;
+#pragma unroll
+    for (int i = 0; i < G::kXSlots; ++i) {
+      const int sidx = tid + 256 * i;
+      if (sidx < G::kXN) *reinterpret_cast<v4f*>(sx + 4 * sidx) = rx[i];   // [c][r][40] row-major == float4 index sidx
+    }
+#pragma unroll
+    for (int i = 0; i < G::kWSlots; ++i) {
+      const int sidx = tid + 256 * i;
+      if (sidx < G::kWN) *reinterpret_cast<v4f*>(sw + 4 * sidx) = rw[i];   // [tap][k][CO]
+    }
+  };
+
+  const int nstage = (Cin + kC3 - 1) / kC3;
+  fetch(0);
+  commit(0);
+  __syncthreads();
+  for (int st = 0; st < nstage; ++st) {
+    const bool more = st + 1 < nstage;
+    if (more) fetch((st + 1) * kC3);
+    const float* sx = lds + (st & 1) * (G::kSX + G::kSW);
+    const float* sw = sx + G::kSX;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int kh = tap / 3, kw = tap % 3;
+#pragma unroll
+      for (int kk = 0; kk < kC3; kk += 2) {
+        float a[CBK], bv[RW];
+#pragma unroll
+        for (int i = 0; i < CBK; ++i) a[i] = sw[(tap * kC3 + kk + half) * G::kCO + i * 32 + l32];
+#pragma unroll
+        for (int r = 0; r < RW; ++r) bv[r] = sx[((kk + half) * G::kRows + wave * RW + r + DIL * kh) * kLW + 4 + DIL * (kw - 1) + l32];
+#pragma unroll
+        for (int i = 0; i < CBK; ++i)
+#pragma unroll
+          for (int r = 0; r < RW; ++r) acc[i][r] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bv[r], acc[i][r], 0, 0, 0);
+      }
+    }
+    if (more) commit((st + 1) & 1);
+    __syncthreads();
+  }
+
+  const long long MP = static_cast<long long>(Cout) * HW;
+  float* yb = y + b * MP;
+  const float* resb = epi.residual ? epi.residual + b * MP : nullptr;
+  const float* maskb = epi.mask ? epi.mask + b * MP : nullptr;
+  const int gw = w0 + l32;
+  if (gw >= W) return;
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int gh = h0 + wave * RW + r;
+    if (gh >= H) continue;
+#pragma unroll
+    for (int i = 0; i < CBK; ++i) {
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int co = co0 + i * 32 + 4 * half + (v & 3) + 8 * (v >> 2);
+        if (co >= Cout) continue;
+        const long long at = static_cast<long long>(co) * HW + static_cast<long long>(gh) * W + gw;
+        float rv = acc[i][r][v];
+        if (epi.bias) rv = rv + epi.bias[co];
+        if (resb) rv = rv + __builtin_nontemporal_load(resb + at);
+        if (epi.relu) rv = rv > 0.0f ? rv : 0.0f;
+        if (maskb) rv = __builtin_nontemporal_load(maskb + at) > 0.0f ? rv : 0.0f;
+        yb[at] = rv;
+      }
+    }
+  }
+}
+
+__global__ void conv2d_3x3_prep_kernel(const float* __restrict__ w, float* __restrict__ out, int cout, int cin, int transpose, int kpad, int mpad) {
+  // forward:  out[tap][k = ci][m = co] = w[co][ci][tap];  transpose (backward w.r.t. the input): out[tap][k = co][m = ci] = w[co][ci][8 - tap]
+  const long long n = 9LL * kpad * mpad;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += 256LL * gridDim.x) {
+    const int m = static_cast<int>(i % mpad), k = static_cast<int>((i / mpad) % kpad), tap = static_cast<int>(i / (static_cast<long long>(mpad) * kpad));
+    const int co = transpose ? k : m, ci = transpose ? m : k, t = transpose ? 8 - tap : tap;
+    out[i] = (co < cout && ci < cin) ? w[(static_cast<long long>(co) * cin + ci) * 9 + t] : 0.0f;
+  }
+}
+
+template <int RW, int CBK, int DIL>
+int launch_3x3(const float* x, const float* wp, float* y, int b, int cin, int cout, int cinpad, int copad, int h, int w, const Epi2& epi, hipStream_t st) {
+  using G = Geo3<RW, CBK, DIL>;
+  const int tiles_w = (w + 31) / 32, tiles_h = (h + G::kTH - 1) / G::kTH;
+  const long long tiles = static_cast<long long>(tiles_w) * tiles_h;
+  const int cgroups = (cout + G::kCO - 1) / G::kCO;
+  if (tiles > 0x7fffffffLL || cgroups > 65535 || b > 65535) return ADV_EINVAL;
+  const size_t lds = 2 * sizeof(float) * static_cast<size_t>(G::kSX + G::kSW);
+  if (lds > 64 * 1024 && !adv_internal_lds_limit<conv2d_3x3_mfma<RW, CBK, DIL>>(lds)) return ADV_ELAUNCH;
+  hipLaunchKernelGGL((conv2d_3x3_mfma<RW, CBK, DIL>), dim3(static_cast<unsigned>(tiles), cgroups, b), dim3(256), lds, st, x, wp, y, cin, cout, cinpad, copad,
+                     h, w, tiles_w, epi);
+  return adv_internal_finish_launch();
+}
+
 }  // namespace
 
 extern "C" {
@@ -266,6 +445,47 @@ int adv_conv2d_1x1_f32(const float* x, const float* w_prep, const float* bias, c
     case 2: return launch_1x1<2, 2, 1, 2>(x, w_prep, y, b, cin, cout, mpad, pixels, epi, st);
     default: return launch_1x1<2, 2, 1, 1>(x, w_prep, y, b, cin, cout, mpad, pixels, epi, st);
   }
+}
+
+int64_t adv_conv2d_3x3_prep_floats(int cout, int cin, int transpose) {
+  if (cout < 1 || cin < 1) return ADV_EINVAL;
+  const int k = transpose ? cout : cin, m = transpose ? cin : cout;
+  return 9LL * round_up(k, kC3) * round_up(m, 64);
+}
+
+int adv_conv2d_3x3_prep_weights_f32(const float* w, float* w_prep, int cout, int cin, int transpose, adv_stream_t stream) {
+  if (!w || !w_prep || cout < 1 || cin < 1) return ADV_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(w) & 3) || (reinterpret_cast<uintptr_t>(w_prep) & 15)) return ADV_EALIGN;
+  const int k = transpose ? cout : cin, m = transpose ? cin : cout;
+  const int kpad = round_up(k, kC3), mpad = round_up(m, 64);
+  const long long n = 9LL * kpad * mpad;
+  const unsigned blocks = static_cast<unsigned>(n / 256 + 1 < 4096 ? n / 256 + 1 : 4096);
+  hipLaunchKernelGGL(conv2d_3x3_prep_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), w, w_prep, cout, cin, transpose ? 1 : 0,
+                     kpad, mpad);
+  return adv_internal_finish_launch();
+}
+
+int adv_conv2d_3x3_f32(const float* x, const float* w_prep, const float* bias, const float* residual, const float* mask, float* y, int b, int cin,
+                       int cout, int h, int w, int dilation, int relu, int tile, adv_stream_t stream) {
+  if (!x || !w_prep || !y || b < 1 || cin < 1 || cout < 1 || h < 1 || w < 1 || (dilation != 1 && dilation != 2) || tile < -1 || tile > 1)
+    return ADV_EINVAL;
+  if (residual == y || mask == y || x == y) return ADV_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(x) & 3) || (reinterpret_cast<uintptr_t>(y) & 3) || (reinterpret_cast<uintptr_t>(w_prep) & 15) ||
+      (residual && (reinterpret_cast<uintptr_t>(residual) & 3)) || (mask && (reinterpret_cast<uintptr_t>(mask) & 3)) ||
+      (bias && (reinterpret_cast<uintptr_t>(bias) & 3)))
+    return ADV_EALIGN;
+  Epi2 epi{bias, residual, mask, relu ? 1 : 0};
+  const int cinpad = round_up(cin, kC3), copad = round_up(cout, 64);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  // tile 0: 8 rows x 32 columns x 64 channels (two rows and two channel blocks per wave); tile 1: 16 rows x 32 columns x 32 channels
+  // (four rows of one channel block per wave) - for layers of 32 output channels or fewer, where tile 0 would compute a zero block
+  const int t = tile >= 0 ? tile : (cout <= 32 ? 1 : 0);
+  if (t == 0) {
+    if (dilation == 1) return launch_3x3<2, 2, 1>(x, w_prep, y, b, cin, cout, cinpad, copad, h, w, epi, st);
+    return launch_3x3<2, 2, 2>(x, w_prep, y, b, cin, cout, cinpad, copad, h, w, epi, st);
+  }
+  if (dilation == 1) return launch_3x3<4, 1, 1>(x, w_prep, y, b, cin, cout, cinpad, copad, h, w, epi, st);
+  return launch_3x3<4, 1, 2>(x, w_prep, y, b, cin, cout, cinpad, copad, h, w, epi, st);
 }
 
 }  // extern "C"

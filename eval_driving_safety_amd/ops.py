@@ -872,30 +872,35 @@ class ConvTranspose3dK3S2(torch.autograd.Function):
 
 # --------------------------------------------------------------------------------------------
 # 2D convolutions of the detectors' backbones on the float32 matrix cores (csrc/conv2d.hip)
-def conv2d_supported(x, weight, stride=1, padding=0):
-    """does libadvengine have a kernel for this layer?  (1x1 / stride 1 / no padding so far: the class MIOpen runs at 0.40 of the
-    float32 matrix peak on the ResNet-101-FPN step, profiles/r03_conv2d_layers_miopen.jsonl; 3x3 and strided layers stay on MIOpen)"""
+def conv2d_supported(x, weight, stride=1, padding=0, dilation=1):
+    """does libadvengine have a kernel for this layer?  1x1 / stride 1 / no padding (a GEMM per image) and 3x3 / stride 1 /
+    padding = dilation in (1, 2); strided layers and other kernel sizes stay on MIOpen"""
+    if not (x.is_cuda and x.dtype == torch.float32 and weight.dim() == 4 and weight.shape[2] == weight.shape[3] and stride == 1):
+        return False
     k = weight.shape[2]
-    return x.is_cuda and x.dtype == torch.float32 and weight.dim() == 4 and k == 1 and weight.shape[3] == 1 and stride == 1 and padding == 0
+    return (k == 1 and padding == 0 and dilation == 1) or (k == 3 and dilation in (1, 2) and padding == dilation)
 
 
 class Conv2dPrep:
     """the weights of one layer in the kernels' layout, for the forward and for the backward w.r.t. the input - prepared once (the
     attacks never change the weights)"""
 
-    def __init__(self, weight, stride=1, padding=0):
+    def __init__(self, weight, stride=1, padding=0, dilation=1):
         wt = _feat(weight.detach().contiguous(), "weight")
-        if wt.dim() != 4 or wt.shape[2] != 1 or wt.shape[3] != 1 or stride != 1 or padding != 0:
-            raise ValueError("only 1x1 / stride 1 / padding 0 layers have a kernel here")
-        self.cout, self.cin, self.k, self.stride, self.padding = int(wt.shape[0]), int(wt.shape[1]), 1, 1, 0
+        if wt.dim() != 4 or wt.shape[2] != wt.shape[3] or stride != 1:
+            raise ValueError("weight must be [Cout,Cin,k,k], stride 1")
+        self.cout, self.cin, self.k, self.stride, self.padding, self.dilation = int(wt.shape[0]), int(wt.shape[1]), int(wt.shape[2]), 1, int(padding), int(dilation)
+        if not ((self.k == 1 and padding == 0 and dilation == 1) or (self.k == 3 and dilation in (1, 2) and padding == dilation)):
+            raise ValueError("only 1x1 / padding 0 and 3x3 / padding = dilation in (1, 2) layers have a kernel here")
         self.device = wt.device
         self.fwd, self.bwd = self._prep(wt, False), self._prep(wt, True)
 
     def _prep(self, wt, transpose):
-        n = int(_lib.load().adv_conv2d_1x1_prep_floats(self.cout, self.cin, int(transpose)))
+        kind = "1x1" if self.k == 1 else "3x3"
+        n = int(getattr(_lib.load(), "adv_conv2d_%s_prep_floats" % kind)(self.cout, self.cin, int(transpose)))
         out = torch.empty((n,), dtype=torch.float32, device=wt.device)
         with _on(wt):
-            _lib.call("adv_conv2d_1x1_prep_weights_f32", _ptr(wt), _ptr(out), self.cout, self.cin, int(transpose), _stream(wt))
+            _lib.call("adv_conv2d_%s_prep_weights_f32" % kind, _ptr(wt), _ptr(out), self.cout, self.cin, int(transpose), _stream(wt))
         return out
 
 
@@ -908,7 +913,7 @@ def _like(t, out, name):
     return _ptr(t)
 
 
-def _conv2d_1x1(x, w_prep, cin, cout, bias, residual, relu, mask, tile):
+def _conv2d_call(x, prep, w_prep, cin, cout, bias, residual, relu, mask, tile):
     xi = _feat(x, "x")
     if xi.dim() != 4 or xi.shape[1] != cin:
         raise ValueError("x must be [B,%d,H,W]" % cin)
@@ -918,22 +923,27 @@ def _conv2d_1x1(x, w_prep, cin, cout, bias, residual, relu, mask, tile):
         bias = _feat(bias, "bias")
         if tuple(bias.shape) != (cout,):
             raise ValueError("bias must be [cout]")
+    bp = None if bias is None else _ptr(bias)
     with _on(xi):
-        _lib.call("adv_conv2d_1x1_f32", _ptr(xi), _ptr(w_prep), None if bias is None else _ptr(bias), _like(residual, y, "residual"),
-                  _like(mask, y, "mask"), _ptr(y), b, cin, cout, h * w, int(bool(relu)), int(tile), _stream(xi))
+        if prep.k == 1:
+            _lib.call("adv_conv2d_1x1_f32", _ptr(xi), _ptr(w_prep), bp, _like(residual, y, "residual"), _like(mask, y, "mask"), _ptr(y), b, cin, cout,
+                      h * w, int(bool(relu)), int(tile), _stream(xi))
+        else:
+            _lib.call("adv_conv2d_3x3_f32", _ptr(xi), _ptr(w_prep), bp, _like(residual, y, "residual"), _like(mask, y, "mask"), _ptr(y), b, cin, cout,
+                      h, w, prep.dilation, int(bool(relu)), int(min(tile, 1)), _stream(xi))
     return y
 
 
 def conv2d(x, prep, bias=None, residual=None, relu=False, mask=None, tile=-1):
     """conv2d(x [B,Cin,H,W], prep) (+ bias [Cout]) (+ residual [B,Cout,H,W]) (ReLU) (zeroed where mask <= 0) -> [B,Cout,H,W]"""
-    return _conv2d_1x1(x, prep.fwd, prep.cin, prep.cout, bias, residual, relu, mask, tile)
+    return _conv2d_call(x, prep, prep.fwd, prep.cin, prep.cout, bias, residual, relu, mask, tile)
 
 
 def conv2d_dgrad(grad, prep, hw=None, residual=None, mask=None, tile=-1):
     """the backward w.r.t. the input of the same layer: grad [B,Cout,H,W] -> [B,Cin,H,W] (+ residual: a gradient arriving over a
     skip path) (zeroed where mask <= 0: with mask = the layer's own input, a ReLU output, this is the gradient w.r.t. the previous
     layer's pre-activation)"""
-    return _conv2d_1x1(grad, prep.bwd, prep.cout, prep.cin, None, residual, False, mask, tile)
+    return _conv2d_call(grad, prep, prep.bwd, prep.cout, prep.cin, None, residual, False, mask, tile)
 
 
 class Conv2d(torch.autograd.Function):

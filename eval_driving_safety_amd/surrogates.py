@@ -271,6 +271,7 @@ class FoldedConv(nn.Module):
     "miopen" = torch's operator (MIOpen / rocBLAS on ROCm), "hip" = this package's float32-MFMA kernels (ops.Conv2d) where one
     exists for the layer's shape, MIOpen otherwise.  ``flops`` accumulates 2 * MACs of every forward call (FLOP accounting)."""
     impl = "miopen"
+    hip_kernels = None    # impl == "hip": None = every layer libadvengine has a kernel for, or a set of kernel sizes, e.g. {1} / {3}
     trace = None          # a list: every forward call appends (cin, cout, k, stride, padding, batch, h, w) - tools/bench_conv2d_layers.py
 
     def __init__(self, cin, cout, k, stride=1, padding=0, gen=None, gain=1.0):
@@ -297,7 +298,7 @@ class FoldedConv(nn.Module):
             return (F.relu(y) if relu else y)[:, :, None, None]
         if FoldedConv.impl == "hip":
             from . import ops
-            if ops.conv2d_supported(x, self.weight, self.stride, self.padding):
+            if ops.conv2d_supported(x, self.weight, self.stride, self.padding) and (FoldedConv.hip_kernels is None or self.k in FoldedConv.hip_kernels):
                 if self._prep is None or self._prep.device != x.device:
                     self._prep = ops.Conv2dPrep(self.weight, self.stride, self.padding)
                 return ops.Conv2d.apply(x, self._prep, self.bias, residual, relu)

@@ -435,6 +435,18 @@ ADV_API int adv_conv2d_1x1_prep_weights_f32(const float* w, float* w_prep, int c
 ADV_API int adv_conv2d_1x1_f32(const float* x, const float* w_prep, const float* bias, const float* residual, const float* mask,
                                float* y, int b, int cin, int cout, int64_t pixels, int relu, int tile, adv_stream_t stream);
 
+/* 3x3 / stride 1 / padding = dilation (1 or 2) convolution - the residual blocks, FPN smoothing, RPN and head towers of the detectors.
+ *     Implicit GEMM on v_mfma_f32_32x32x2_f32: a workgroup owns 8 rows x 32 columns x 64 output channels (or 16 x 32 x 32 for
+ *     layers of 32 channels or fewer); per stage of 8 input channels the input tile with its halo and the weights [9][8][64] are
+ *     staged in LDS; accumulation order (stage of 8 channels, tap ascending, channel ascending), one fmaf per product.
+ *     w_prep from adv_conv2d_3x3_prep_weights_f32 ([9][cin'][cout'], zero padded to multiples of 8 x 64); transpose = 1 prepares the
+ *     flipped W^T: the same entry point then computes the backward w.r.t. the input (x = grad_out, cin <-> cout swapped).
+ *     bias / residual / relu / mask: as adv_conv2d_1x1_f32.  tile: -1 = by cout, 0 = 8x32x64, 1 = 16x32x32 (same result). */
+ADV_API int64_t adv_conv2d_3x3_prep_floats(int cout, int cin, int transpose);
+ADV_API int adv_conv2d_3x3_prep_weights_f32(const float* w, float* w_prep, int cout, int cin, int transpose, adv_stream_t stream);
+ADV_API int adv_conv2d_3x3_f32(const float* x, const float* w_prep, const float* bias, const float* residual, const float* mask,
+                               float* y, int b, int cin, int cout, int h, int w, int dilation, int relu, int tile, adv_stream_t stream);
+
 /* out[i] = y[i] > 0 ? grad[i] : 0  (the backward of a ReLU fused into a convolution's epilogue; out may alias grad). */
 ADV_API int adv_relu_backward_f32(const float* grad, const float* y, float* out, int64_t n, adv_stream_t stream);
 

@@ -333,15 +333,15 @@ void orc_conv3d_k3_ex(const float* x, const float* w, const float* bias, float* 
  * `chunk` input channels, taps ascending inside a chunk, channels ascending inside a tap, ONE fmaf per product starting from 0
  * (the float32 MFMA is a k-ordered fmaf chain) - then + bias, + residual, ReLU, and last the mask (result kept where mask > 0).
  * For a 1x1 kernel the order is simply "input channel ascending" whatever the chunk.
- * transpose != 0 (stride 1 only): the backward w.r.t. the input - x is grad_out [B,cout,H,W], y is grad_in [B,cin,H,W], the
+ * dil = dilation of the taps.  transpose != 0 (stride 1 only): the backward w.r.t. the input - x is grad_out [B,cout,H,W], y is grad_in [B,cin,H,W], the
  * weights are read transposed and flipped, exactly what the kernel does with its prepared W^T.
  * Upstream detector code (ResNet-101-FPN of Stereo R-CNN, DSGN's 2D extractor): unpinned; torch's conv2d is the semantics. */
 void orc_conv2d(const float* x, const float* w, const float* bias, const float* residual, const float* mask, float* y, int B, int cin,
-                int cout, int H, int W, int k, int stride, int pad, int relu, int transpose, int chunk) {
+                int cout, int H, int W, int k, int stride, int pad, int dil, int relu, int transpose, int chunk) {
   const int kk = k * k;
   const int M = transpose ? cin : cout, Kc = transpose ? cout : cin;
-  const int p = transpose ? k - 1 - pad : pad;
-  const int Ho = transpose ? H : (H + 2 * pad - k) / stride + 1, Wo = transpose ? W : (W + 2 * pad - k) / stride + 1;
+  const int p = transpose ? dil * (k - 1) - pad : pad;
+  const int Ho = transpose ? H : (H + 2 * pad - dil * (k - 1) - 1) / stride + 1, Wo = transpose ? W : (W + 2 * pad - dil * (k - 1) - 1) / stride + 1;
   const int s = transpose ? 1 : stride;
 #pragma omp parallel for collapse(2) schedule(static)
   for (int b = 0; b < B; ++b)
@@ -352,7 +352,7 @@ void orc_conv2d(const float* x, const float* w, const float* bias, const float* 
           for (int c0 = 0; c0 < Kc; c0 += chunk)
             for (int tap = 0; tap < kk; ++tap) {
               const int kh = tap / k, kw = tap % k;
-              const int gh = s * h + kh - p, gw = s * ww + kw - p;
+              const int gh = s * h + dil * kh - p, gw = s * ww + dil * kw - p;
               const int in = gh >= 0 && gh < H && gw >= 0 && gw < W;
               for (int c = c0; c < c0 + chunk && c < Kc; ++c) {
                 const float wv = transpose ? w[((long)c * cin + m) * kk + (kk - 1 - tap)] : w[((long)m * cin + c) * kk + tap];

@@ -33,7 +33,7 @@ _lib.orc_dense_align_cost.argtypes = [_fp, _fp, ctypes.c_int, ctypes.c_int, ctyp
 _lib.orc_dense_align_cost.restype = None
 _lib.orc_conv3d_k3_ex.argtypes = [_fp, _fp, ctypes.c_void_p, _fp] + [ctypes.c_int] * 8 + [ctypes.c_uint, _i32p, _i32p, _i32p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
 _lib.orc_conv3d_k3_ex.restype = None
-_lib.orc_conv2d.argtypes = [_fp, _fp, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _fp] + [ctypes.c_int] * 11
+_lib.orc_conv2d.argtypes = [_fp, _fp, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _fp] + [ctypes.c_int] * 12
 _lib.orc_conv2d.restype = None
 for _f in ("orc_denormalize", "orc_normalize", "orc_pgd_step_norm01", "orc_pgd_step_meansub255", "orc_tensor2im_u8",
            "orc_patch_paste", "orc_patch_update"):
@@ -190,7 +190,7 @@ def conv3d_k3_ex(x, w, bias=None, stride=1, relu=False, tap_mask=(1 << 27) - 1, 
     return out
 
 
-def conv2d(x, w, bias=None, residual=None, mask=None, stride=1, padding=0, relu=False, transpose=False, chunk=16):
+def conv2d(x, w, bias=None, residual=None, mask=None, stride=1, padding=0, relu=False, transpose=False, chunk=16, dilation=1):
     """csrc/conv2d.hip in its accumulation order: x [B,Cin,H,W], w [Cout,Cin,k,k] -> conv2d (+ bias, + residual, ReLU, mask);
     transpose=True: x is grad_out [B,Cout,H,W] -> the gradient w.r.t. the input [B,Cin,H,W] (stride 1)"""
     x = np.ascontiguousarray(x, dtype=np.float32)
@@ -198,7 +198,7 @@ def conv2d(x, w, bias=None, residual=None, mask=None, stride=1, padding=0, relu=
     cout, cin, k = w.shape[0], w.shape[1], w.shape[2]
     b, c, h, ww = x.shape
     assert c == (cout if transpose else cin) and w.shape[3] == k and (stride == 1 or not transpose)
-    ho, wo = (h, ww) if transpose else ((h + 2 * padding - k) // stride + 1, (ww + 2 * padding - k) // stride + 1)
+    ho, wo = (h, ww) if transpose else ((h + 2 * padding - dilation * (k - 1) - 1) // stride + 1, (ww + 2 * padding - dilation * (k - 1) - 1) // stride + 1)
     y = np.empty((b, cin if transpose else cout, ho, wo), np.float32)
 
     def opt(a, shape):
@@ -209,7 +209,8 @@ def conv2d(x, w, bias=None, residual=None, mask=None, stride=1, padding=0, relu=
         return a, a.ctypes.data_as(ctypes.c_void_p)
 
     keep = [opt(bias, (y.shape[1],)), opt(residual, y.shape), opt(mask, y.shape)]
-    _lib.orc_conv2d(x, w, keep[0][1], keep[1][1], keep[2][1], y, b, cin, cout, h, ww, k, int(stride), int(padding), int(relu), int(transpose), int(chunk))
+    _lib.orc_conv2d(x, w, keep[0][1], keep[1][1], keep[2][1], y, b, cin, cout, h, ww, k, int(stride), int(padding), int(dilation), int(relu),
+                    int(transpose), int(chunk))
     return y
 
 

@@ -26,15 +26,15 @@ def test_oracle_conv2d_matches_torch(shape):
     b, cin, cout, h, w = shape
     x, wt, rs = _case(*shape, seed=sum(shape))
     bias = rs.randn(cout).astype(np.float32)
-    for k, pad, stride in ((1, 0, 1), (3, 1, 1), (3, 1, 2), (1, 0, 2)):
+    for k, pad, stride, dil in ((1, 0, 1, 1), (3, 1, 1, 1), (3, 1, 2, 1), (1, 0, 2, 1), (3, 2, 1, 2)):
         wk = (rs.randn(cout, cin, k, k) * (1.0 / (cin * k * k)) ** 0.5).astype(np.float32)
-        got = C.conv2d(x, wk, bias, stride=stride, padding=pad, relu=True)
-        ref = F.relu(F.conv2d(torch.tensor(x), torch.tensor(wk), torch.tensor(bias), stride, pad)).numpy()
+        got = C.conv2d(x, wk, bias, stride=stride, padding=pad, relu=True, dilation=dil, chunk=8)
+        ref = F.relu(F.conv2d(torch.tensor(x), torch.tensor(wk), torch.tensor(bias), stride, pad, dil)).numpy()
         assert got.shape == ref.shape and np.abs(got - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
         if stride == 1:
             g = rs.randn(*ref.shape).astype(np.float32)
-            gx = C.conv2d(g, wk, padding=pad, transpose=True)
-            refg = torch.nn.grad.conv2d_input(x.shape, torch.tensor(wk), torch.tensor(g), padding=pad).numpy()
+            gx = C.conv2d(g, wk, padding=pad, transpose=True, dilation=dil, chunk=8)
+            refg = torch.nn.grad.conv2d_input(x.shape, torch.tensor(wk), torch.tensor(g), padding=pad, dilation=dil).numpy()
             assert np.abs(gx - refg).max() <= 1e-5 * max(1.0, np.abs(refg).max())
 
 
@@ -121,3 +121,69 @@ def test_hip_conv2d_r101_layer_shapes_full_size():
         want = C.conv2d(xs, wt.cpu().numpy(), bias.cpu().numpy(), relu=True)
         got = y.reshape(2, cout, h * w)[:, :, ps].cpu().numpy().reshape(2, cout, 1, len(ps))
         assert got.tobytes() == want.tobytes(), (cin, cout, h, w)
+
+
+# (B, Cin, Cout, H, W, dilation): channel counts around the 8-channel stage and the 32 / 64-channel tiles, rows / columns around the
+# 8 / 16 x 32 tile, rows shorter than a float4, PSMNet's dilated blocks, the detectors' layer shapes at reduced size
+THREE = [(1, 8, 64, 8, 32, 1), (2, 3, 32, 19, 63, 1), (1, 32, 32, 24, 40, 1), (1, 64, 64, 13, 41, 1), (2, 12, 70, 9, 33, 1), (1, 128, 128, 10, 37, 2),
+         (1, 5, 7, 3, 2, 1), (1, 16, 130, 17, 65, 2), (1, 256, 18, 6, 10, 1), (1, 9, 9, 1, 1, 1)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", THREE)
+def test_hip_conv2d_3x3_bit_exact_vs_oracle_both_tiles(shape):
+    from eval_driving_safety_amd import ops
+    b, cin, cout, h, w, dil = shape
+    x, wt, rs = _case(b, cin, cout, h, w, k=3, seed=sum(shape) + 2)
+    bias = rs.randn(cout).astype(np.float32)
+    res = rs.randn(b, cout, h, w).astype(np.float32)
+    mask = rs.randn(b, cout, h, w).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    tx, tw, tb, tr, tm = (torch.tensor(a, device=dev) for a in (x, wt, bias, res, mask))
+    assert ops.conv2d_supported(tx, tw, 1, dil, dil)
+    prep = ops.Conv2dPrep(tw, 1, dil, dil)
+    want_plain = C.conv2d(x, wt, padding=dil, dilation=dil, chunk=8)
+    want_full = C.conv2d(x, wt, bias, res, mask, padding=dil, dilation=dil, relu=True, chunk=8)
+    for tile in (-1, 0, 1):
+        assert ops.conv2d(tx, prep, tile=tile).cpu().numpy().tobytes() == want_plain.tobytes(), ("plain", tile)
+        assert ops.conv2d(tx, prep, tb, tr, True, tm, tile=tile).cpu().numpy().tobytes() == want_full.tobytes(), ("bias + residual + relu + mask", tile)
+    ref = F.conv2d(tx, tw, tb, 1, dil, dil)
+    got = ops.conv2d(tx, prep, tb)
+    assert float((got - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
+    g = rs.randn(b, cout, h, w).astype(np.float32)
+    gres = rs.randn(b, cin, h, w).astype(np.float32)
+    tg, tgr = torch.tensor(g, device=dev), torch.tensor(gres, device=dev)
+    assert ops.conv2d_dgrad(tg, prep).cpu().numpy().tobytes() == C.conv2d(g, wt, padding=dil, dilation=dil, transpose=True, chunk=8).tobytes()
+    want_b = C.conv2d(g, wt, residual=gres, mask=x, padding=dil, dilation=dil, transpose=True, chunk=8)
+    for tile in (0, 1):
+        assert ops.conv2d_dgrad(tg, prep, residual=tgr, mask=tx, tile=tile).cpu().numpy().tobytes() == want_b.tobytes(), tile
+    refg = torch.nn.grad.conv2d_input(x.shape, tw, tg, padding=dil, dilation=dil)
+    assert float((ops.conv2d_dgrad(tg, prep) - refg).abs().max()) <= 1e-4 * max(1.0, float(refg.abs().max()))
+
+
+@pytest.mark.gpu
+def test_hip_conv2d_3x3_layer_shapes_full_size():
+    """3x3 layers of the two detectors at their real size: the whole tensor within 1e-4 of torch, sampled windows bit-exact vs the oracle"""
+    from eval_driving_safety_amd import ops
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(13)
+    for cin, cout, h, w, dil in ((64, 64, 150, 497, 1), (256, 256, 38, 125, 1), (32, 32, 192, 624, 1), (128, 128, 96, 312, 2), (256, 512, 75, 249, 1)):
+        x = torch.randn((2, cin, h, w), device=dev, generator=gen)
+        wt = torch.randn((cout, cin, 3, 3), device=dev, generator=gen) * (1.0 / (9 * cin)) ** 0.5
+        bias = torch.randn((cout,), device=dev, generator=gen)
+        y = ops.conv2d(x, ops.Conv2dPrep(wt, 1, dil, dil), bias, relu=True)
+        ref = F.relu(F.conv2d(x, wt, bias, 1, dil, dil))
+        assert float((y - ref).abs().max()) <= 1e-4 * float(ref.abs().max()), (cin, cout, h, w)
+        # a window at the bottom-right corner (image edge, partial tile) and one in the interior: the oracle on the window + halo
+        for (r0, c0) in ((h - 6, w - 9), (h // 2, w // 2 - 3)):
+            hal = 2 * dil
+            rs_, re_, cs_, ce_ = max(0, r0 - hal), min(h, r0 + 6 + hal), max(0, c0 - hal), min(w, c0 + 9 + hal)
+            sub = x[:1, :, rs_:re_, cs_:ce_].cpu().numpy()
+            want = C.conv2d(sub, wt.cpu().numpy(), bias.cpu().numpy(), padding=dil, dilation=dil, relu=True, chunk=8)
+            # rows / columns of the window that do not touch the crop's artificial border (true image borders are real zero padding)
+            a0 = 0 if rs_ == 0 else dil
+            a1 = want.shape[2] if re_ == h else want.shape[2] - dil
+            b0 = 0 if cs_ == 0 else dil
+            b1 = want.shape[3] if ce_ == w else want.shape[3] - dil
+            got = y[:1, :, rs_ + a0:rs_ + a1, cs_ + b0:cs_ + b1].cpu().numpy()
+            assert got.tobytes() == np.ascontiguousarray(want[:, :, a0:a1, b0:b1]).tobytes(), (cin, cout, h, w, r0, c0)

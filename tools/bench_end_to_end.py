@@ -83,13 +83,13 @@ def measure(pairs=1, iters=20, reps=2, warm_iters=None, mfma_conv=True, hourglas
                 "libadvengine.so"}
 
 
-def measure_dsgn_full(pairs=1, iters=20, reps=1, graph=False):
+def measure_dsgn_full(pairs=1, iters=20, reps=1, graph=False, hip2d=True):
     """BASELINE configs[1] end to end through the DSGN-shaped graph with SURVEY App. B's layer list (adapters.DsgnShapedAdapter: PSMNet-style
     2D extractor, plane-sweep volume, dres0/dres1 + 3D hourglass, fused depth regression, 3D geometric volume + 64-channel stack + 3D
     hourglass, bird's-eye-view 2D hourglass, head towers): exact FLOPs per detector step from the layer list and the WHOLE step
     against the float32 matrix peak - at ``pairs`` stereo pairs per step (the reference runs 1; 288 GB hold more)."""
     dev = torch.device("cuda", torch.cuda.current_device())
-    net = adapters.DsgnShapedAdapter(dev, seed=0)
+    net = adapters.DsgnShapedAdapter(dev, seed=0, hip2d=hip2d)
     batch = next(iter(data.SyntheticStereo(pairs, "dsgn", batch=pairs, seed=0)))
     batch.extra = net.synthetic_extra(batch, seed=1)
     x = torch.cat([batch.imgL, batch.imgR]).to(dev)
@@ -136,6 +136,8 @@ def measure_dsgn_full(pairs=1, iters=20, reps=1, graph=False):
             "roofline": {"bound": "mfma", "what": "WHOLE detector step (forward + input-gradient backward; 2D convolutions by MIOpen, everything 3D by "
                                                    "libadvengine, element-wise and loss kernels included) against the float32 matrix peak",
                          "achieved": step / model_ms / 1e9, "peak": 157.3, "unit": "TFLOP/s", "frac": step / model_ms / 1e9 / 157.3},
+            "convolutions_2d": ("libadvengine float32-MFMA kernels for the 1x1 and 3x3 stride-1 layers (bias / skip / ReLU in the epilogue), MIOpen for "
+                                "the strided and transposed ones" if hip2d else "torch / MIOpen"),
             "mfma_frac_step": step / model_ms / 1e9 / 157.3, "peak_hbm_gib": torch.cuda.max_memory_allocated() / 2 ** 30,
             "loss_first_iter": first, "loss_last_iter": last, "loss_rose": last > first,
             "note": "NOT the headline metric and NOT DSGN's weights; layer list [UPSTREAM-UNVERIFIED] from the published PSMNet / DSGN structures"}
@@ -286,7 +288,7 @@ def main():
     args = ap.parse_args()
     torch.cuda.set_device(0)
     if args.full:
-        print(json.dumps(measure_dsgn_full(args.pairs, args.iters, args.reps, graph=args.graph)))
+        print(json.dumps(measure_dsgn_full(args.pairs, args.iters, args.reps, graph=args.graph, hip2d=not args.miopen)))
         return
     if args.r101:
         print(json.dumps(measure_srcnn_r101(args.pairs, args.iters, args.reps, args.rois, "hip" if args.hip2d else "miopen")))
