@@ -601,12 +601,12 @@ class DsgnShapedAdapter(PsvStereoAdapter):
     costs twice that.  ``torch_ops=True`` computes the same graph with torch's own operators (the parity reference of the tests)."""
 
     def __init__(self, device, seed=0, planes=48, image_hw=(384, 1248), fu=721.5377, cu=609.5593, cv=172.854, mfma_conv=True, torch_ops=False,
-                 hip2d=True):
+                 hip2d="auto"):
         super().__init__(device, seed=seed, channels=32, planes=planes, mid=32, mfma_conv=mfma_conv and not torch_ops, interp=True,
                          hourglass=False, dsgn_head=True, fu=fu, cu=cu, cv=cv, image_hw=image_hw)
         self.torch_ops = bool(torch_ops)
         # hip2d: the 1x1 and 3x3 stride-1 2D layers (extractor, bird's-eye view, heads) on csrc/conv2d.hip; False: torch / MIOpen
-        self.hip2d, self._p2 = bool(hip2d), {}
+        self.hip2d, self._p2 = hip2d, {}                   # True: always, "auto": where it measures faster than MIOpen, False: never
         self.flops_fwd = 0
         gen = torch.Generator().manual_seed(seed + 1000)
         dev = device
@@ -694,7 +694,10 @@ class DsgnShapedAdapter(PsvStereoAdapter):
             # libadvengine's float32-MFMA 2D kernels: bias, skip connection and ReLU in the epilogue (no element-wise passes)
             if name not in self._p2:
                 self._p2[name] = self.ops.Conv2dPrep(w, s, p, d)
-            y = self.ops.Conv2d.apply(x, self._p2[name], b, residual, relu)
+            if self.hip2d == "auto":       # per layer shape and direction, whichever of {libadvengine, MIOpen} measured faster
+                y = self.ops.Conv2dAuto.apply(x, self._p2[name], w, b, residual, relu)
+            else:
+                y = self.ops.Conv2d.apply(x, self._p2[name], b, residual, relu)
             self.flops_fwd += 2 * y.numel() * w.shape[1] * w.shape[2] * w.shape[3]
             return y
         y = F.conv2d(x, w, b, s, p, d)

@@ -331,24 +331,36 @@ __device__ __forceinline__ void roi_bwd_body(AxisList (*s_list)[kTileY + kTileX]
         const int cnt = b.grid_h * b.grid_w;
         const float count = static_cast<float>(cnt), inv = 1.0f / count;
         const bool pow2 = (cnt & (cnt - 1)) == 0;
-        for (int iy = 0; iy < ny; ++iy) {
-          const int ph = yl.bin[iy];
-          const float ywl = yl.w_low[iy], ywh = yl.w_high[iy];
-          const bool yl_hit = yl.hit[iy] & 1, yh_hit = yl.hit[iy] & 2;
-          for (int ix = 0; ix < nx; ++ix) {
-            const int pw = xl.bin[ix];
-            const float xwl = xl.w_low[ix], xwh = xl.w_high[ix];
-            const bool xl_hit = xl.hit[ix] & 1, xh_hit = xl.hit[ix] & 2;
-            const float w1 = ywl * xwl, w2 = ywl * xwh, w3 = ywh * xwl, w4 = ywh * xwh;
-            const float* g = gout + ((static_cast<long long>(r) * C + c0) * PH + ph) * PW + pw;
+        // The samples of this roi that touch the pixel, row-major (sample row, then sample column): FOUR at a time - their gathers are
+        // issued together and only then consumed in order.  One sample per trip left every trip waiting a full L2 round trip for its
+        // own gathers (one wave per SIMD on a hot tile, nothing else to run): 20 k cycles per roi on a tile that 500 clustered rois reach.
+        const int ns = ny * nx;
+        const long long cstride = static_cast<long long>(PH) * PW;
+        const float* gbase = gout + (static_cast<long long>(r) * C + c0) * cstride;
+        for (int s0 = 0; s0 < ns; s0 += 4) {
+          float gv[4][CB], w1[4], w2[4], w3[4], w4[4];
+          unsigned hitbits[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int sidx = min(s0 + u, ns - 1);
+            const int iy = sidx / nx, ix = sidx - iy * nx;
+            const float ywl = yl.w_low[iy], ywh = yl.w_high[iy], xwl = xl.w_low[ix], xwh = xl.w_high[ix];
+            w1[u] = ywl * xwl, w2[u] = ywl * xwh, w3[u] = ywh * xwl, w4[u] = ywh * xwh;
+            hitbits[u] = (s0 + u < ns) ? (static_cast<unsigned>(yl.hit[iy]) | (static_cast<unsigned>(xl.hit[ix]) << 2)) : 0u;
+            const float* g = gbase + static_cast<long long>(yl.bin[iy]) * PW + xl.bin[ix];
+#pragma unroll
+            for (int c = 0; c < CB; ++c) gv[u][c] = (c0 + c < C) ? g[c * cstride] : 0.0f;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const bool yl_hit = hitbits[u] & 1u, yh_hit = hitbits[u] & 2u, xl_hit = hitbits[u] & 4u, xh_hit = hitbits[u] & 8u;
 #pragma unroll
             for (int c = 0; c < CB; ++c) {
               if (c0 + c < C) {
-                const float gv = g[static_cast<long long>(c) * PH * PW];
-                if (yl_hit && xl_hit) acc[c] = acc[c] + over_count(gv * w1, count, inv, pow2);
-                if (yl_hit && xh_hit) acc[c] = acc[c] + over_count(gv * w2, count, inv, pow2);
-                if (yh_hit && xl_hit) acc[c] = acc[c] + over_count(gv * w3, count, inv, pow2);
-                if (yh_hit && xh_hit) acc[c] = acc[c] + over_count(gv * w4, count, inv, pow2);
+                if (yl_hit && xl_hit) acc[c] = acc[c] + over_count(gv[u][c] * w1[u], count, inv, pow2);
+                if (yl_hit && xh_hit) acc[c] = acc[c] + over_count(gv[u][c] * w2[u], count, inv, pow2);
+                if (yh_hit && xl_hit) acc[c] = acc[c] + over_count(gv[u][c] * w3[u], count, inv, pow2);
+                if (yh_hit && xh_hit) acc[c] = acc[c] + over_count(gv[u][c] * w4[u], count, inv, pow2);
               }
             }
           }
@@ -373,29 +385,6 @@ __global__ __launch_bounds__(kBlock) void roi_align_bwd_gather(const float* __re
   __shared__ Bin s_bin[kRoiBatch];
   roi_bwd_body<CB>(s_list, s_bin, static_cast<int>(blockIdx.y) * CB, gout, rois, lists, gfeat, C, H, W, R, tiles_y, tiles_x, PH, PW, scale,
                    sampling_ratio);
-}
-
-// Large maps: eight channels per lane amortise the per-roi classification - unless a tile's list is LONG (proposals cluster on the
-// objects; the proposal-target layer samples with replacement, so rois repeat): every lane of the tile then walks hundreds of
-// rois, one wave per SIMD with nothing to hide its gathers behind, while the rest of the chip idles (512 clustered rois on P2:
-// 6.5 ms against 0.7 ms for the same number spread out).  The grid has one workgroup per (tile, channel); for a short list only
-// every eighth workgroup works (eight channels, the others leave at once), for a long one all eight do, one channel each - eight
-// times the waves on the hot tiles, an eighth of the gathers per lane.  The sum per (pixel, channel) is the same chain either way.
-constexpr int kLongList = 24;
-__global__ __launch_bounds__(kBlock) void roi_align_bwd_gather_split(const float* __restrict__ gout, const float* __restrict__ rois,
-                                                                     const int* __restrict__ lists, float* __restrict__ gfeat, int C, int H, int W,
-                                                                     int R, int tiles_y, int tiles_x, int PH, int PW, float scale,
-                                                                     int sampling_ratio) {
-  __shared__ AxisList s_list[kRoiBatch][kTileY + kTileX];
-  __shared__ Bin s_bin[kRoiBatch];
-  const int n_list = lists[(static_cast<long long>(blockIdx.z) * tiles_y * tiles_x + blockIdx.x) * (R + 1)];
-  const int cy = static_cast<int>(blockIdx.y);
-  if (n_list <= kLongList) {
-    if (cy & 7) return;
-    roi_bwd_body<8>(s_list, s_bin, cy, gout, rois, lists, gfeat, C, H, W, R, tiles_y, tiles_x, PH, PW, scale, sampling_ratio);
-  } else {
-    if (cy < C) roi_bwd_body<1>(s_list, s_bin, cy, gout, rois, lists, gfeat, C, H, W, R, tiles_y, tiles_x, PH, PW, scale, sampling_ratio);
-  }
 }
 
 // ---- NMS: wave64 suppression masks.  Block (row tile i, col tile j), 64 lanes: lane l owns box 64*i + l and
@@ -511,10 +500,7 @@ int adv_roi_align_bwd_f32(const float* grad_out, const float* rois, float* grad_
 #define ADV_LAUNCH_ROI_BWD(CB_)                                                                                                             \
   hipLaunchKernelGGL(roi_align_bwd_gather<CB_>, dim3(tiles_y * tiles_x, (c + CB_ - 1) / CB_, b), dim3(kBlock), 0, st, grad_out, rois,          \
                      reinterpret_cast<const int*>(workspace), grad_feat, c, h, w, r, tiles_y, tiles_x, ph, pw, spatial_scale, sampling_ratio)
-  if (cb == 8 && !adv_hook("ADV_ROI_BWD_CB8") && (c + 7) / 8 * 8 <= 65535)
-    hipLaunchKernelGGL(roi_align_bwd_gather_split, dim3(tiles_y * tiles_x, (c + 7) / 8 * 8, b), dim3(kBlock), 0, st, grad_out, rois,
-                       reinterpret_cast<const int*>(workspace), grad_feat, c, h, w, r, tiles_y, tiles_x, ph, pw, spatial_scale, sampling_ratio);
-  else if (cb == 8) ADV_LAUNCH_ROI_BWD(8);
+  if (cb == 8) ADV_LAUNCH_ROI_BWD(8);
   else if (cb == 4) ADV_LAUNCH_ROI_BWD(4);
   else if (cb == 2) ADV_LAUNCH_ROI_BWD(2);
   else ADV_LAUNCH_ROI_BWD(1);

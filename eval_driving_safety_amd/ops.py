@@ -10,6 +10,7 @@ torch is plumbing here (device memory + streams); all arithmetic is in the HIP l
 import ctypes
 
 import torch
+import torch.nn.functional as F
 
 from . import _lib
 from ._lib import AdvSpace
@@ -964,6 +965,93 @@ class Conv2d(torch.autograd.Function):
         if ctx.relu:
             g = relu_backward(g, y)
         return conv2d_dgrad(g, ctx.prep), None, None, (g if ctx.has_res else None), None
+
+
+class _Conv2dChoice:
+    """Per layer shape: who computes the forward and who the backward w.r.t. the input - this package's kernel (epilogue fused) or
+    torch's operator (MIOpen / rocBLAS + separate element-wise kernels).  Decided by MEASUREMENT the first time a shape is seen (three
+    timed calls each, HIP events on the current stream - what MIOpen's own solver search does for its candidates), then cached for the
+    process.  The float32 MFMA kernels win on large maps and on the memory-bound 1x1 layers, where the fused epilogue saves as many
+    bytes as the convolution moves; MIOpen's Winograd wins on small maps at one pair per step (profiles/r03_conv2d_layers_ab.jsonl)."""
+    cache = {}
+    enabled = True
+
+    @staticmethod
+    def _time(fn):
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1)
+
+    @classmethod
+    def get(cls, key, hip_fn, torch_fn):
+        c = cls.cache.get(key)
+        if c is None:
+            if torch.cuda.is_current_stream_capturing():
+                return True                      # cannot time inside a capture: this package's kernel
+            c = cls._time(hip_fn) <= cls._time(torch_fn)
+            cls.cache[key] = c
+        return c
+
+
+class Conv2dAuto(torch.autograd.Function):
+    """y = [relu](conv2d(x) [+ bias] [+ residual]) and its backward w.r.t. x and the residual, each direction computed by whichever of
+    {csrc/conv2d.hip, torch} measured faster for this layer shape (see _Conv2dChoice).  ``prep`` = Conv2dPrep of the layer, ``weight``
+    the original tensor for torch's side."""
+
+    @staticmethod
+    def forward(ctx, x, prep, weight, bias=None, residual=None, relu=False):
+        x = x.contiguous()
+        res = None if residual is None else residual.contiguous()
+        pad, dil = prep.padding, prep.dilation
+        key = ("f", prep.k, prep.cin, prep.cout, dil, tuple(x.shape), res is not None, bool(relu))
+
+        def by_torch():
+            y = F.conv2d(x, weight, bias, 1, pad, dil)
+            if res is not None:
+                y = y + res
+            return F.relu(y) if relu else y
+
+        use = _Conv2dChoice.get(key, lambda: conv2d(x, prep, bias, res, relu), by_torch)
+        y = conv2d(x, prep, bias, res, relu) if use else by_torch()
+        ctx.prep, ctx.relu, ctx.has_res, ctx.xshape = prep, bool(relu), res is not None, tuple(x.shape)
+        ctx.save_for_backward(weight, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        weight, y = ctx.saved_tensors
+        prep = ctx.prep
+        g = grad_y.contiguous()
+        if ctx.relu:
+            g = relu_backward(g, y)
+        key = ("b", prep.k, prep.cin, prep.cout, prep.dilation, ctx.xshape)
+
+        def by_torch():
+            return torch.ops.aten.convolution_backward(g, _shape_only(ctx.xshape, g), weight, None,
+                                                       [1, 1], [prep.padding, prep.padding], [prep.dilation, prep.dilation], False, [0, 0], 1,
+                                                       [True, False, False])[0]
+
+        use = _Conv2dChoice.get(key, lambda: conv2d_dgrad(g, prep), by_torch)
+        gx = conv2d_dgrad(g, prep) if use else by_torch()
+        return gx, None, None, None, (g if ctx.has_res else None), None
+
+
+_SHAPE_DUMMY = {}
+
+
+def _shape_only(shape, like):
+    """convolution_backward wants the input TENSOR although the gradient w.r.t. the input reads only its shape: one cached dummy per shape"""
+    key = (tuple(shape), like.device)
+    t = _SHAPE_DUMMY.get(key)
+    if t is None:
+        t = torch.empty(shape, dtype=torch.float32, device=like.device)
+        _SHAPE_DUMMY[key] = t
+    return t
 
 
 # --------------------------------------------------------------------------------------------

@@ -269,7 +269,8 @@ def synthetic_srcnn_extra(batch, device, max_boxes=30):
 class FoldedConv(nn.Module):
     """conv2d + folded eval-mode batch-norm (= a bias) [+ residual] [+ ReLU].  ``impl`` picks who computes it:
     "miopen" = torch's operator (MIOpen / rocBLAS on ROCm), "hip" = this package's float32-MFMA kernels (ops.Conv2d) where one
-    exists for the layer's shape, MIOpen otherwise.  ``flops`` accumulates 2 * MACs of every forward call (FLOP accounting)."""
+    exists for the layer's shape, MIOpen otherwise, "auto" = per layer shape and direction whichever of the two measured faster
+    (ops.Conv2dAuto).  ``flops`` accumulates 2 * MACs of every forward call (FLOP accounting)."""
     impl = "miopen"
     hip_kernels = None    # impl == "hip": None = every layer libadvengine has a kernel for, or a set of kernel sizes, e.g. {1} / {3}
     trace = None          # a list: every forward call appends (cin, cout, k, stride, padding, batch, h, w) - tools/bench_conv2d_layers.py
@@ -296,11 +297,13 @@ class FoldedConv(nn.Module):
             if residual is not None:
                 y = y + residual.flatten(1)
             return (F.relu(y) if relu else y)[:, :, None, None]
-        if FoldedConv.impl == "hip":
+        if FoldedConv.impl in ("hip", "auto"):
             from . import ops
             if ops.conv2d_supported(x, self.weight, self.stride, self.padding) and (FoldedConv.hip_kernels is None or self.k in FoldedConv.hip_kernels):
                 if self._prep is None or self._prep.device != x.device:
                     self._prep = ops.Conv2dPrep(self.weight, self.stride, self.padding)
+                if FoldedConv.impl == "auto":      # per layer shape and direction, whichever of {libadvengine, MIOpen} measured faster
+                    return ops.Conv2dAuto.apply(x, self._prep, self.weight, self.bias, residual, relu)
                 return ops.Conv2d.apply(x, self._prep, self.bias, residual, relu)
         y = F.conv2d(x, self.weight, self.bias, self.stride, self.padding)
         if residual is not None:

@@ -83,7 +83,14 @@ def measure(pairs=1, iters=20, reps=2, warm_iters=None, mfma_conv=True, hourglas
                 "libadvengine.so"}
 
 
-def measure_dsgn_full(pairs=1, iters=20, reps=1, graph=False, hip2d=True):
+def _choice_summary():
+    from eval_driving_safety_amd import ops
+    c = ops._Conv2dChoice.cache
+    return {"forward": "%d of %d layer shapes" % (sum(1 for k, v in c.items() if k[0] == "f" and v), sum(1 for k in c if k[0] == "f")),
+            "backward": "%d of %d layer shapes" % (sum(1 for k, v in c.items() if k[0] == "b" and v), sum(1 for k in c if k[0] == "b"))}
+
+
+def measure_dsgn_full(pairs=1, iters=20, reps=1, graph=False, hip2d="auto"):
     """BASELINE configs[1] end to end through the DSGN-shaped graph with SURVEY App. B's layer list (adapters.DsgnShapedAdapter: PSMNet-style
     2D extractor, plane-sweep volume, dres0/dres1 + 3D hourglass, fused depth regression, 3D geometric volume + 64-channel stack + 3D
     hourglass, bird's-eye-view 2D hourglass, head towers): exact FLOPs per detector step from the layer list and the WHOLE step
@@ -136,14 +143,16 @@ def measure_dsgn_full(pairs=1, iters=20, reps=1, graph=False, hip2d=True):
             "roofline": {"bound": "mfma", "what": "WHOLE detector step (forward + input-gradient backward; 2D convolutions by MIOpen, everything 3D by "
                                                    "libadvengine, element-wise and loss kernels included) against the float32 matrix peak",
                          "achieved": step / model_ms / 1e9, "peak": 157.3, "unit": "TFLOP/s", "frac": step / model_ms / 1e9 / 157.3},
-            "convolutions_2d": ("libadvengine float32-MFMA kernels for the 1x1 and 3x3 stride-1 layers (bias / skip / ReLU in the epilogue), MIOpen for "
-                                "the strided and transposed ones" if hip2d else "torch / MIOpen"),
+            "convolutions_2d": {"auto": "per layer shape and direction whichever of {libadvengine float32-MFMA 1x1 / 3x3 kernel with fused epilogue, "
+                                        "MIOpen} measured faster at first use", True: "libadvengine for every 1x1 / 3x3 stride-1 layer",
+                                False: "torch / MIOpen"}[hip2d],
+            "layers_2d_on_libadvengine": _choice_summary(),
             "mfma_frac_step": step / model_ms / 1e9 / 157.3, "peak_hbm_gib": torch.cuda.max_memory_allocated() / 2 ** 30,
             "loss_first_iter": first, "loss_last_iter": last, "loss_rose": last > first,
             "note": "NOT the headline metric and NOT DSGN's weights; layer list [UPSTREAM-UNVERIFIED] from the published PSMNet / DSGN structures"}
 
 
-def measure_srcnn_r101(pairs=1, iters=20, reps=1, rois=512, impl="miopen"):
+def measure_srcnn_r101(pairs=1, iters=20, reps=1, rois=512, impl="auto"):
     """BASELINE configs[2] with the upstream LAYER LIST (surrogates.StereoRcnnR101: ResNet-101 [3,4,23,3] + FPN P2-P6 + stereo RPN + RoI
     heads, random weights, batch-norms folded): 20-step PGD at 600x1987, exact FLOPs per detector step from the layer list, the
     whole-step rate against the float32 matrix peak.  ``impl``: "miopen" = every 2D convolution through torch (MIOpen / rocBLAS),
@@ -188,7 +197,7 @@ def measure_srcnn_r101(pairs=1, iters=20, reps=1, rois=512, impl="miopen"):
             "roofline": {"bound": "mfma", "what": "WHOLE detector step (forward + input-gradient backward, every kernel incl. RoIAlign, NMS, "
                                                    "losses, element-wise) against the float32 matrix peak",
                          "achieved": step / model_ms / 1e9, "peak": 157.3, "unit": "TFLOP/s", "frac": step / model_ms / 1e9 / 157.3},
-            "convolutions": impl, "rois_per_image": rois, "peak_hbm_gib": peak,
+            "convolutions": impl, "layers_2d_on_libadvengine": _choice_summary(), "rois_per_image": rois, "peak_hbm_gib": peak,
             "loss_first_iter": first, "loss_last_iter": last, "loss_rose": last > first,
             "note": "NOT the headline metric and NOT Stereo R-CNN's weights: bottleneck stacks [3,4,23,3] with the stride on the first 1x1, "
                     "256-channel FPN P2-P6, stereo RPN 3x3 256->512 on both eyes, RoIAlign 7x7 (both eyes) / 14x14 (left) by libadvengine with "
@@ -288,10 +297,10 @@ def main():
     args = ap.parse_args()
     torch.cuda.set_device(0)
     if args.full:
-        print(json.dumps(measure_dsgn_full(args.pairs, args.iters, args.reps, graph=args.graph, hip2d=not args.miopen)))
+        print(json.dumps(measure_dsgn_full(args.pairs, args.iters, args.reps, graph=args.graph, hip2d=(False if args.miopen else (True if args.hip2d else "auto")))))
         return
     if args.r101:
-        print(json.dumps(measure_srcnn_r101(args.pairs, args.iters, args.reps, args.rois, "hip" if args.hip2d else "miopen")))
+        print(json.dumps(measure_srcnn_r101(args.pairs, args.iters, args.reps, args.rois, "hip" if args.hip2d else ("miopen" if args.miopen else "auto"))))
         return
     if args.srcnn:
         print(json.dumps(measure_srcnn(args.pairs, args.iters, args.reps)))
