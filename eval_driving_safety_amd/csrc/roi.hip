@@ -4,6 +4,8 @@
 // and wave64-wide suppression masks for NMS.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include <cstdint>
 #include <cstdlib>
 
@@ -261,16 +263,21 @@ constexpr int kRoiBatch = 6;   // 6 x (8 rows + 32 columns) = 240 classifying la
 constexpr int kListCap = 8;
 
 struct AxisList {
-  int n;                       // samples that touch the pixel (may exceed kListCap: then the entries are not used)
-  int bin[kListCap];           // ph / pw of the sample
-  float w_low[kListCap], w_high[kListCap];
-  unsigned char hit[kListCap];  // bit 0: the sample's low tap is this pixel, bit 1: its high tap
+  int n;                       // tap hits on the pixel (may exceed kListCap: then the entries are not used)
+  int bin[kListCap];           // ph / pw of the sample the tap belongs to
+  float w[kListCap];           // the tap's 1-D weight: hy / hx for a sample's low tap, ly / lx for its high tap
 };
+// One entry per TAP that lands on the pixel, in the order (sample ascending; low tap before high tap).  A sample whose low AND high
+// tap are the same pixel (clamped at the map's last row / column, where the high tap's weight is exactly 0) gives two entries.  A
+// pixel's contributions are then (row entry) x (column entry), one multiply-add each and no conditions: the same products
+// hy*hx, hy*lx, ly*hx, ly*lx as the forward's four taps, summed in the order (roi, row entry, column entry) - which is the order
+// (roi, sample row, sample column, tap 1..4) except that the ZERO terms of a clamped sample come later; adding an exact zero
+// at another position of the chain does not change a float32 sum, so the oracle's ordered sum is reproduced bit for bit.
 
 template <int CB>
 __device__ __forceinline__ void roi_bwd_body(AxisList (*s_list)[kTileY + kTileX], Bin* s_bin, int c0, const float* __restrict__ gout,
                                              const float* __restrict__ rois, const int* __restrict__ lists, float* __restrict__ gfeat, int C, int H, int W,
-                                             int R, int tiles_y, int tiles_x, int PH, int PW, float scale, int sampling_ratio) {
+                                             int R, int tiles_y, int tiles_x, int PH, int PW, float scale, int sampling_ratio, int dbg) {
   const int tile = blockIdx.x, img = blockIdx.z;
   const int tid = static_cast<int>(threadIdx.x);
   const int ty0 = (tile / tiles_x) * kTileY, tx0 = (tile % tiles_x) * kTileX;
@@ -286,7 +293,7 @@ __device__ __forceinline__ void roi_bwd_body(AxisList (*s_list)[kTileY + kTileX]
   const int cb = tid / (kTileY + kTileX), ca = tid % (kTileY + kTileX);
   for (int l0 = 0; l0 < n_list; l0 += kRoiBatch) {
     const int nb = min(kRoiBatch, n_list - l0);
-    if (cb < nb) {
+    if (cb < nb && !(dbg & 2)) {
       const int r = list[1 + l0 + cb];
       const Bin b = bin_of(rois + static_cast<long long>(r) * 5, scale, PH, PW, sampling_ratio);
       if (ca == 0) s_bin[cb] = b;
@@ -304,19 +311,20 @@ __device__ __forceinline__ void roi_bwd_body(AxisList (*s_list)[kTileY + kTileX]
           const float v = start + static_cast<float>(pb) * bin + (static_cast<float>(ik) + 0.5f) * bin / static_cast<float>(grid);
           const Axis1 a = axis_taps(size, v, pixel);
           if (!a.valid || !(a.hit_low || a.hit_high)) continue;
-          if (n < kListCap) {
-            out.bin[n] = pb;
-            out.w_low[n] = a.w_low;
-            out.w_high[n] = a.w_high;
-            out.hit[n] = static_cast<unsigned char>((a.hit_low ? 1 : 0) | (a.hit_high ? 2 : 0));
+          if (a.hit_low) {
+            if (n < kListCap) out.bin[n] = pb, out.w[n] = a.w_low;
+            ++n;
           }
-          ++n;
+          if (a.hit_high) {
+            if (n < kListCap) out.bin[n] = pb, out.w[n] = a.w_high;
+            ++n;
+          }
         }
       }
       out.n = n;
     }
     __syncthreads();
-    if (inside) {
+    if (inside && !(dbg & 1)) {
       for (int k = 0; k < nb; ++k) {
         const AxisList& yl = s_list[k][ly];
         const AxisList& xl = s_list[k][kTileY + lx];
@@ -337,34 +345,33 @@ __device__ __forceinline__ void roi_bwd_body(AxisList (*s_list)[kTileY + kTileX]
         const int ns = ny * nx;
         const long long cstride = static_cast<long long>(PH) * PW;
         const float* gbase = gout + (static_cast<long long>(r) * C + c0) * cstride;
+        // two copies of the loop, chosen per roi (uniform): with `v * inv` only, or with the IEEE division only - left as a select the
+        // compiler evaluated BOTH for each of the 32 contributions of a sample (12 instructions of division each)
+        auto samples = [&](auto pow2_c) {
+        constexpr bool kPow2 = decltype(pow2_c)::value;
         for (int s0 = 0; s0 < ns; s0 += 4) {
-          float gv[4][CB], w1[4], w2[4], w3[4], w4[4];
-          unsigned hitbits[4];
+          float gv[4][CB], wgt[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const int sidx = min(s0 + u, ns - 1);
             const int iy = sidx / nx, ix = sidx - iy * nx;
-            const float ywl = yl.w_low[iy], ywh = yl.w_high[iy], xwl = xl.w_low[ix], xwh = xl.w_high[ix];
-            w1[u] = ywl * xwl, w2[u] = ywl * xwh, w3[u] = ywh * xwl, w4[u] = ywh * xwh;
-            hitbits[u] = (s0 + u < ns) ? (static_cast<unsigned>(yl.hit[iy]) | (static_cast<unsigned>(xl.hit[ix]) << 2)) : 0u;
+            wgt[u] = yl.w[iy] * xl.w[ix];
             const float* g = gbase + static_cast<long long>(yl.bin[iy]) * PW + xl.bin[ix];
 #pragma unroll
             for (int c = 0; c < CB; ++c) gv[u][c] = (c0 + c < C) ? g[c * cstride] : 0.0f;
           }
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
-            const bool yl_hit = hitbits[u] & 1u, yh_hit = hitbits[u] & 2u, xl_hit = hitbits[u] & 4u, xh_hit = hitbits[u] & 8u;
+            if (s0 + u < ns) {
 #pragma unroll
-            for (int c = 0; c < CB; ++c) {
-              if (c0 + c < C) {
-                if (yl_hit && xl_hit) acc[c] = acc[c] + over_count(gv[u][c] * w1[u], count, inv, pow2);
-                if (yl_hit && xh_hit) acc[c] = acc[c] + over_count(gv[u][c] * w2[u], count, inv, pow2);
-                if (yh_hit && xl_hit) acc[c] = acc[c] + over_count(gv[u][c] * w3[u], count, inv, pow2);
-                if (yh_hit && xh_hit) acc[c] = acc[c] + over_count(gv[u][c] * w4[u], count, inv, pow2);
-              }
+              for (int c = 0; c < CB; ++c)
+                if (c0 + c < C) acc[c] = acc[c] + over_count(gv[u][c] * wgt[u], count, inv, kPow2);
             }
           }
         }
+        };
+        if (pow2) samples(std::true_type{});
+        else samples(std::false_type{});
       }
     }
     __syncthreads();
@@ -380,11 +387,11 @@ template <int CB>
 __global__ __launch_bounds__(kBlock) void roi_align_bwd_gather(const float* __restrict__ gout, const float* __restrict__ rois,
                                                                const int* __restrict__ lists, float* __restrict__ gfeat, int C, int H, int W,
                                                                int R, int tiles_y, int tiles_x, int PH, int PW, float scale,
-                                                               int sampling_ratio) {
+                                                               int sampling_ratio, int dbg) {
   __shared__ AxisList s_list[kRoiBatch][kTileY + kTileX];
   __shared__ Bin s_bin[kRoiBatch];
   roi_bwd_body<CB>(s_list, s_bin, static_cast<int>(blockIdx.y) * CB, gout, rois, lists, gfeat, C, H, W, R, tiles_y, tiles_x, PH, PW, scale,
-                   sampling_ratio);
+                   sampling_ratio, dbg);
 }
 
 // ---- NMS: wave64 suppression masks.  Block (row tile i, col tile j), 64 lanes: lane l owns box 64*i + l and
@@ -494,12 +501,14 @@ int adv_roi_align_bwd_f32(const float* grad_out, const float* rois, float* grad_
                      sampling_ratio, reinterpret_cast<int*>(workspace));
   // channels per lane: as many as still leave ~8 workgroups per compute unit (the small pyramid levels have 6-20 tiles)
   const long long tiles = static_cast<long long>(tiles_y) * tiles_x * b;
+  const char* dbg_s = adv_hook_value("ADV_ROI_DBG");
+  const int dbg = dbg_s ? dbg_s[0] - '0' : 0;
   int cb = kChanBlock;
   while (cb > 1 && tiles * ((c + cb - 1) / cb) < 2048) cb >>= 1;
   if (adv_hook("ADV_ROI_BWD_CB8")) cb = kChanBlock;
 #define ADV_LAUNCH_ROI_BWD(CB_)                                                                                                             \
   hipLaunchKernelGGL(roi_align_bwd_gather<CB_>, dim3(tiles_y * tiles_x, (c + CB_ - 1) / CB_, b), dim3(kBlock), 0, st, grad_out, rois,          \
-                     reinterpret_cast<const int*>(workspace), grad_feat, c, h, w, r, tiles_y, tiles_x, ph, pw, spatial_scale, sampling_ratio)
+                     reinterpret_cast<const int*>(workspace), grad_feat, c, h, w, r, tiles_y, tiles_x, ph, pw, spatial_scale, sampling_ratio, dbg)
   if (cb == 8) ADV_LAUNCH_ROI_BWD(8);
   else if (cb == 4) ADV_LAUNCH_ROI_BWD(4);
   else if (cb == 2) ADV_LAUNCH_ROI_BWD(2);
