@@ -405,6 +405,26 @@ int launch_3x3(const float* x, const float* wp, float* y, int b, int cin, int co
   return adv_internal_finish_launch();
 }
 
+
+// The epilogue of a convolution somebody else computed (MIOpen for the layer shapes where it is faster): y = [relu](y + bias[c] +
+// residual) in ONE pass over the tensor, in place - torch runs it as up to three element-wise kernels (bias broadcast, skip add,
+// clamp), each a full read + write.  The same float operations in the same order as the fused epilogues above.
+__global__ __launch_bounds__(256) void bias_act_kernel(float* __restrict__ y, const float* __restrict__ bias, const float* __restrict__ residual, int C,
+                                                       long long hw, int relu) {
+  const long long plane = blockIdx.y;                       // b * C + c
+  const float bv = bias ? bias[plane % C] : 0.0f;
+  float* yp = y + plane * hw;
+  const float* rp = residual ? residual + plane * hw : nullptr;
+  const long long stride = static_cast<long long>(gridDim.x) * 256;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < hw; i += stride) {
+    float v = yp[i];
+    if (bias) v = v + bv;
+    if (rp) v = v + rp[i];
+    if (relu) v = v > 0.0f ? v : 0.0f;
+    yp[i] = v;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -486,6 +506,17 @@ int adv_conv2d_3x3_f32(const float* x, const float* w_prep, const float* bias, c
   }
   if (dilation == 1) return launch_3x3<4, 1, 1>(x, w_prep, y, b, cin, cout, cinpad, copad, h, w, epi, st);
   return launch_3x3<4, 1, 2>(x, w_prep, y, b, cin, cout, cinpad, copad, h, w, epi, st);
+}
+
+int adv_bias_act_f32(float* y, const float* bias, const float* residual, int64_t planes, int c, int64_t hw, int relu, adv_stream_t stream) {
+  if (!y || planes < 1 || c < 1 || hw < 1 || planes > 0x7fffffffLL || residual == y) return ADV_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(y) & 3) || (bias && (reinterpret_cast<uintptr_t>(bias) & 3)) || (residual && (reinterpret_cast<uintptr_t>(residual) & 3)))
+    return ADV_EALIGN;
+  if (planes > 65535) return ADV_EINVAL;
+  const unsigned gx = static_cast<unsigned>((hw + 1023) / 1024 < 1 ? 1 : ((hw + 1023) / 1024 > 4096 ? 4096 : (hw + 1023) / 1024));
+  hipLaunchKernelGGL(bias_act_kernel, dim3(gx, static_cast<unsigned>(planes)), dim3(256), 0, static_cast<hipStream_t>(stream), y, bias, residual, c,
+                     static_cast<long long>(hw), relu ? 1 : 0);
+  return adv_internal_finish_launch();
 }
 
 }  // extern "C"

@@ -967,6 +967,29 @@ class Conv2d(torch.autograd.Function):
         return conv2d_dgrad(g, ctx.prep), None, None, (g if ctx.has_res else None), None
 
 
+def bias_act_(y, bias=None, residual=None, relu=False):
+    """y <- [relu](y + bias[c] + residual) in place, one pass (the epilogue of a convolution another library computed)"""
+    yi = _feat(y, "y")
+    if yi.dim() < 2:
+        raise ValueError("y must be [B,C,...]")
+    b, c = yi.shape[0], yi.shape[1]
+    hw = yi.numel() // max(1, b * c)
+    if yi.numel() == 0 or (bias is None and residual is None and not relu):
+        return yi
+    if b * c > 65535:                     # beyond the launch's plane index: torch's own operators
+        if bias is not None:
+            yi += bias.view(1, -1, *([1] * (yi.dim() - 2)))
+        if residual is not None:
+            yi += residual
+        return yi.relu_() if relu else yi
+    if bias is not None:
+        bias = _feat(bias, "bias")
+    with _on(yi):
+        _lib.call("adv_bias_act_f32", _ptr(yi), None if bias is None else _ptr(bias), _like(residual, yi, "residual"), b * c, c, hw, int(bool(relu)),
+                  _stream(yi))
+    return yi
+
+
 class _Conv2dChoice:
     """Per layer shape: who computes the forward and who the backward w.r.t. the input - this package's kernel (epilogue fused) or
     torch's operator (MIOpen / rocBLAS + separate element-wise kernels).  Decided by MEASUREMENT the first time a shape is seen (three
@@ -1010,11 +1033,8 @@ class Conv2dAuto(torch.autograd.Function):
         pad, dil = prep.padding, prep.dilation
         key = ("f", prep.k, prep.cin, prep.cout, dil, tuple(x.shape), res is not None, bool(relu))
 
-        def by_torch():
-            y = F.conv2d(x, weight, bias, 1, pad, dil)
-            if res is not None:
-                y = y + res
-            return F.relu(y) if relu else y
+        def by_torch():                  # MIOpen's convolution + ONE element-wise pass (bias, skip connection, ReLU)
+            return bias_act_(F.conv2d(x, weight, None, 1, pad, dil), bias, res, relu)
 
         use = _Conv2dChoice.get(key, lambda: conv2d(x, prep, bias, res, relu), by_torch)
         y = conv2d(x, prep, bias, res, relu) if use else by_torch()

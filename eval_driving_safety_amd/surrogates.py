@@ -412,9 +412,26 @@ class StereoRcnnR101(StereoRcnnShaped):
         return p + [p6]
 
     def pyramid_pair(self, im_left, im_right):
-        feats = self.pyramid(torch.cat([im_left, im_right], 0) / 64.0)
+        both = torch.cat([im_left, im_right], 0) / 64.0
+        feats = self._graphed_pyramid(both) if self.use_graph and both.is_cuda else self.pyramid(both)
         b = im_left.shape[0]
         return [f[:b] for f in feats], [f[b:] for f in feats]
+
+    # The backbone + FPN is the STATIC part of the step (no data-dependent shape, no host read-back): ~640 kernel launches forward and
+    # as many backward, each behind ~25 us of Python / autograd dispatch - at one pair per step the GPU waits for the interpreter
+    # (91 ms of kernels in a 135 ms step, profiles/r03_r101_kernel_stats.csv).  ``use_graph``: its forward and its backward are
+    # captured once per input shape as two hipGraphs (torch.cuda.make_graphed_callables) and replayed; the proposal stage and the
+    # RoI heads, whose shapes depend on the data, stay eager.  Same kernels, same order, same bits.
+    use_graph = False
+
+    def _graphed_pyramid(self, both):
+        key = (tuple(both.shape), both.device)
+        cache = self.__dict__.setdefault("_pyramid_graphs", {})
+        if key not in cache:
+            sample = torch.zeros_like(both).requires_grad_(True)
+            self.pyramid(sample.detach())                       # solver searches / lazily prepared weights outside any capture
+            cache[key] = torch.cuda.make_graphed_callables(lambda t: tuple(self.pyramid(t)), (sample,))
+        return list(cache[key](both))
 
     def rpn_features(self, feat_l, feat_r):
         return torch.cat([self.rpn_conv(feat_l, relu=True), self.rpn_conv(feat_r, relu=True)], 1)

@@ -447,6 +447,11 @@ ADV_API int adv_conv2d_3x3_prep_weights_f32(const float* w, float* w_prep, int c
 ADV_API int adv_conv2d_3x3_f32(const float* x, const float* w_prep, const float* bias, const float* residual, const float* mask,
                                float* y, int b, int cin, int cout, int h, int w, int dilation, int relu, int tile, adv_stream_t stream);
 
+/* y [planes = b*c][hw] <- [relu](y + bias[plane % c] + residual), in place, one pass: the epilogue of a convolution computed by another
+ *     library (bias / residual NULL = skipped; residual laid out like y, must not be y).  planes <= 65535. */
+ADV_API int adv_bias_act_f32(float* y, const float* bias, const float* residual, int64_t planes, int c, int64_t hw, int relu,
+                             adv_stream_t stream);
+
 /* out[i] = y[i] > 0 ? grad[i] : 0  (the backward of a ReLU fused into a convolution's epilogue; out may alias grad). */
 ADV_API int adv_relu_backward_f32(const float* grad, const float* y, float* out, int64_t n, adv_stream_t stream);
 

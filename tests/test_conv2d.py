@@ -187,3 +187,20 @@ def test_hip_conv2d_3x3_layer_shapes_full_size():
             b1 = want.shape[3] if ce_ == w else want.shape[3] - dil
             got = y[:1, :, rs_ + a0:rs_ + a1, cs_ + b0:cs_ + b1].cpu().numpy()
             assert got.tobytes() == np.ascontiguousarray(want[:, :, a0:a1, b0:b1]).tobytes(), (cin, cout, h, w, r0, c0)
+
+
+@pytest.mark.gpu
+def test_hip_bias_act_equals_the_three_torch_kernels():
+    """adv_bias_act_f32: y <- relu(y + bias + residual) in one pass, bit-equal to torch's add, add, relu done apart"""
+    from eval_driving_safety_amd import ops
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(2)
+    for shape in ((2, 5, 7, 9), (1, 64, 150, 497), (3, 7, 1, 1), (1, 3, 4, 5, 6)):
+        y = torch.randn(shape, device=dev, generator=gen)
+        bias = torch.randn((shape[1],), device=dev, generator=gen)
+        res = torch.randn(shape, device=dev, generator=gen)
+        bshape = (1, -1) + (1,) * (len(shape) - 2)
+        assert torch.equal(ops.bias_act_(y.clone(), bias, res, True), torch.relu(y + bias.view(bshape) + res))
+        assert torch.equal(ops.bias_act_(y.clone(), bias, None, False), y + bias.view(bshape))
+        assert torch.equal(ops.bias_act_(y.clone(), None, res, True), torch.relu(y + res))
+        assert torch.equal(ops.bias_act_(y.clone(), None, None, True), torch.relu(y))

@@ -83,8 +83,11 @@ def measure(pairs=1, iters=20, reps=2, warm_iters=None, mfma_conv=True, hourglas
                 "libadvengine.so"}
 
 
-def _choice_summary():
+def _choice_summary(fresh=False):
     from eval_driving_safety_amd import ops
+    if fresh:                                   # a new leg: its own decisions (shapes differ between the detectors anyway)
+        ops._Conv2dChoice.cache.clear()
+        return None
     c = ops._Conv2dChoice.cache
     return {"forward": "%d of %d layer shapes" % (sum(1 for k, v in c.items() if k[0] == "f" and v), sum(1 for k in c if k[0] == "f")),
             "backward": "%d of %d layer shapes" % (sum(1 for k, v in c.items() if k[0] == "b" and v), sum(1 for k in c if k[0] == "b"))}
@@ -96,6 +99,7 @@ def measure_dsgn_full(pairs=1, iters=20, reps=1, graph=False, hip2d="auto"):
     hourglass, bird's-eye-view 2D hourglass, head towers): exact FLOPs per detector step from the layer list and the WHOLE step
     against the float32 matrix peak - at ``pairs`` stereo pairs per step (the reference runs 1; 288 GB hold more)."""
     dev = torch.device("cuda", torch.cuda.current_device())
+    _choice_summary(fresh=True)
     net = adapters.DsgnShapedAdapter(dev, seed=0, hip2d=hip2d)
     batch = next(iter(data.SyntheticStereo(pairs, "dsgn", batch=pairs, seed=0)))
     batch.extra = net.synthetic_extra(batch, seed=1)
@@ -140,8 +144,8 @@ def measure_dsgn_full(pairs=1, iters=20, reps=1, graph=False, hip2d="auto"):
     return {"metric": "end-to-end stereo-pairs/s, %d-step PGD through the DSGN-shaped graph with SURVEY App. B's layer list (surrogate, random weights)" % iters,
             "value": pairs / dt, "unit": "stereo-pairs/s", "pairs": pairs, "iters": iters, "s_per_attack": dt, "detector_fwd_bwd_ms": model_ms,
             "flops_per_step": step, "flops_per_step_per_pair": step / pairs,
-            "roofline": {"bound": "mfma", "what": "WHOLE detector step (forward + input-gradient backward; 2D convolutions by MIOpen, everything 3D by "
-                                                   "libadvengine, element-wise and loss kernels included) against the float32 matrix peak",
+            "roofline": {"bound": "mfma", "what": "WHOLE detector step (forward + input-gradient backward; everything 3D by libadvengine, 2D layers by "
+                                                   "libadvengine or MIOpen as measured, element-wise and loss kernels included) against the float32 matrix peak",
                          "achieved": step / model_ms / 1e9, "peak": 157.3, "unit": "TFLOP/s", "frac": step / model_ms / 1e9 / 157.3},
             "convolutions_2d": {"auto": "per layer shape and direction whichever of {libadvengine float32-MFMA 1x1 / 3x3 kernel with fused epilogue, "
                                         "MIOpen} measured faster at first use", True: "libadvengine for every 1x1 / 3x3 stride-1 layer",
@@ -152,7 +156,7 @@ def measure_dsgn_full(pairs=1, iters=20, reps=1, graph=False, hip2d="auto"):
             "note": "NOT the headline metric and NOT DSGN's weights; layer list [UPSTREAM-UNVERIFIED] from the published PSMNet / DSGN structures"}
 
 
-def measure_srcnn_r101(pairs=1, iters=20, reps=1, rois=512, impl="auto"):
+def measure_srcnn_r101(pairs=1, iters=20, reps=1, rois=512, impl="auto", graph_backbone=True):
     """BASELINE configs[2] with the upstream LAYER LIST (surrogates.StereoRcnnR101: ResNet-101 [3,4,23,3] + FPN P2-P6 + stereo RPN + RoI
     heads, random weights, batch-norms folded): 20-step PGD at 600x1987, exact FLOPs per detector step from the layer list, the
     whole-step rate against the float32 matrix peak.  ``impl``: "miopen" = every 2D convolution through torch (MIOpen / rocBLAS),
@@ -160,6 +164,7 @@ def measure_srcnn_r101(pairs=1, iters=20, reps=1, rois=512, impl="auto"):
     from eval_driving_safety_amd import surrogates
     dev = torch.device("cuda", torch.cuda.current_device())
     surrogates.FoldedConv.impl = impl
+    _choice_summary(fresh=True)
     try:
         model = surrogates.StereoRcnnR101(seed=0, rois_per_image=rois).to(dev).eval()
         net = adapters.StereoRcnnAdapter(model, torch.zeros(6, device=dev))
@@ -170,9 +175,20 @@ def measure_srcnn_r101(pairs=1, iters=20, reps=1, rois=512, impl="auto"):
             net.loss_and_grad(x, batch.extra)
         torch.cuda.synchronize()
         model.reset_flops()
-        net.loss_and_grad(x, batch.extra)
+        net.loss_and_grad(x, batch.extra)        # the FLOP count comes from the eager graph (a replayed hipGraph runs no Python)
         by_class = model.flops_by_class()
         fwd = float(sum(by_class.values()))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            net.loss_and_grad(x, batch.extra)
+        e1.record()
+        torch.cuda.synchronize()
+        eager_ms = e0.elapsed_time(e1) / 3
+        model.use_graph = graph_backbone
+        if graph_backbone:
+            net.loss_and_grad(x, batch.extra)    # captures the backbone's forward and backward graphs for this shape
+            torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(5):
@@ -197,7 +213,8 @@ def measure_srcnn_r101(pairs=1, iters=20, reps=1, rois=512, impl="auto"):
             "roofline": {"bound": "mfma", "what": "WHOLE detector step (forward + input-gradient backward, every kernel incl. RoIAlign, NMS, "
                                                    "losses, element-wise) against the float32 matrix peak",
                          "achieved": step / model_ms / 1e9, "peak": 157.3, "unit": "TFLOP/s", "frac": step / model_ms / 1e9 / 157.3},
-            "convolutions": impl, "layers_2d_on_libadvengine": _choice_summary(), "rois_per_image": rois, "peak_hbm_gib": peak,
+            "convolutions": impl, "layers_2d_on_libadvengine": _choice_summary(), "rois_per_image": rois,
+            "backbone_in_hip_graphs": bool(graph_backbone), "detector_fwd_bwd_ms_all_eager": eager_ms, "peak_hbm_gib": peak,
             "loss_first_iter": first, "loss_last_iter": last, "loss_rose": last > first,
             "note": "NOT the headline metric and NOT Stereo R-CNN's weights: bottleneck stacks [3,4,23,3] with the stride on the first 1x1, "
                     "256-channel FPN P2-P6, stereo RPN 3x3 256->512 on both eyes, RoIAlign 7x7 (both eyes) / 14x14 (left) by libadvengine with "
@@ -292,6 +309,7 @@ def main():
     ap.add_argument("--r101", action="store_true", help="the ResNet-101-FPN Stereo R-CNN-shaped detector (upstream layer list) at 600x1987")
     ap.add_argument("--full", action="store_true", help="the DSGN-shaped graph with SURVEY App. B's layer list (adapters.DsgnShapedAdapter)")
     ap.add_argument("--graph", action="store_true", help="--full: one PGD iteration captured in a hipGraph")
+    ap.add_argument("--eager", action="store_true", help="--r101: do not capture the backbone + FPN in hipGraphs")
     ap.add_argument("--rois", type=int, default=512)
     ap.add_argument("--hip2d", action="store_true", help="--r101: libadvengine's 2D convolution kernels where one exists")
     args = ap.parse_args()
@@ -300,7 +318,7 @@ def main():
         print(json.dumps(measure_dsgn_full(args.pairs, args.iters, args.reps, graph=args.graph, hip2d=(False if args.miopen else (True if args.hip2d else "auto")))))
         return
     if args.r101:
-        print(json.dumps(measure_srcnn_r101(args.pairs, args.iters, args.reps, args.rois, "hip" if args.hip2d else ("miopen" if args.miopen else "auto"))))
+        print(json.dumps(measure_srcnn_r101(args.pairs, args.iters, args.reps, args.rois, "hip" if args.hip2d else ("miopen" if args.miopen else "auto"), graph_backbone=not args.eager)))
         return
     if args.srcnn:
         print(json.dumps(measure_srcnn(args.pairs, args.iters, args.reps)))
