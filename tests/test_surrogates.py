@@ -182,3 +182,32 @@ def test_own_pipeline_attack_detect_labels_scenario(tmp_path):
         assert len(label) >= 1 and all(item[0] == "Car" and 2.0 <= item[6][2] <= 41.0 for item in label)
         obstacles = pixelio.scenario_obstacles(label)
         assert len(obstacles) == len(label) and all(o["length"] > 3.0 and o["width"] > 1.0 for o in obstacles)
+
+
+def test_r101_backbone_in_hip_graphs_gives_the_same_loss_and_gradient():
+    """StereoRcnnR101.use_graph: the backbone + FPN forward and backward replayed from two hipGraphs (torch.cuda.make_graphed_callables)
+    - the same kernels in the same order as the eager step, so the same loss and image gradient"""
+    from eval_driving_safety_amd import adapters, surrogates
+    dev = torch.device("cuda", 0)
+    model = surrogates.StereoRcnnR101(seed=2, rois_per_image=32, blocks=(1, 1, 2, 1)).to(dev).eval()
+    gen = torch.Generator().manual_seed(4)
+    x = (torch.randn((2, 3, 160, 320), generator=gen) * 40).to(dev)
+    left = torch.zeros((1, 30, 5), device=dev)
+    left[:, 0] = torch.tensor([100.0, 50.0, 220.0, 120.0, 1.0], device=dev)
+    right = left.clone()
+    right[:, 0, 0] -= 10
+    right[:, 0, 2] -= 10
+    do = torch.zeros((1, 30, 5), device=dev)
+    kp = torch.zeros((1, 30, 6), device=dev)
+    kp[:, 0] = torch.tensor([150.0, 1, 0, 110, 210, 0], device=dev)
+    import types
+    extra = types.SimpleNamespace(im_info=torch.tensor([[160.0, 320.0, 1.0]], device=dev), gt_boxes_left=left, gt_boxes_right=right,
+                                  gt_boxes_merge=left.clone(), gt_dim_orien=do, gt_kpts=kp, num_boxes=torch.tensor([1], device=dev))
+    net = adapters.StereoRcnnAdapter(model, torch.zeros(6, device=dev))
+    net.loss_and_grad(x.clone(), extra)                       # warm-up: solver searches
+    loss_e, grad_e = net.loss_and_grad(x.clone(), extra)
+    model.use_graph = True
+    net.loss_and_grad(x.clone(), extra)                       # captures
+    loss_g, grad_g = net.loss_and_grad(x.clone(), extra)
+    assert float(loss_g) == float(loss_e) or abs(float(loss_g) - float(loss_e)) <= 1e-5 * abs(float(loss_e))
+    assert float((grad_g - grad_e).abs().max()) <= 1e-4 * float(grad_e.abs().max())

@@ -156,7 +156,7 @@ def measure_dsgn_full(pairs=1, iters=20, reps=1, graph=False, hip2d="auto"):
             "note": "NOT the headline metric and NOT DSGN's weights; layer list [UPSTREAM-UNVERIFIED] from the published PSMNet / DSGN structures"}
 
 
-def measure_srcnn_r101(pairs=1, iters=20, reps=1, rois=512, impl="auto", graph_backbone=True):
+def measure_srcnn_r101(pairs=1, iters=20, reps=1, rois=512, impl="auto", graph_backbone=False):
     """BASELINE configs[2] with the upstream LAYER LIST (surrogates.StereoRcnnR101: ResNet-101 [3,4,23,3] + FPN P2-P6 + stereo RPN + RoI
     heads, random weights, batch-norms folded): 20-step PGD at 600x1987, exact FLOPs per detector step from the layer list, the
     whole-step rate against the float32 matrix peak.  ``impl``: "miopen" = every 2D convolution through torch (MIOpen / rocBLAS),
@@ -308,8 +308,7 @@ def main():
     ap.add_argument("--srcnn", action="store_true", help="the Stereo R-CNN-shaped surrogate at 600x1987 instead")
     ap.add_argument("--r101", action="store_true", help="the ResNet-101-FPN Stereo R-CNN-shaped detector (upstream layer list) at 600x1987")
     ap.add_argument("--full", action="store_true", help="the DSGN-shaped graph with SURVEY App. B's layer list (adapters.DsgnShapedAdapter)")
-    ap.add_argument("--graph", action="store_true", help="--full: one PGD iteration captured in a hipGraph")
-    ap.add_argument("--eager", action="store_true", help="--r101: do not capture the backbone + FPN in hipGraphs")
+    ap.add_argument("--graph", action="store_true", help="--full: one PGD iteration captured in a hipGraph; --r101: the backbone + FPN forward / backward as hipGraphs")
     ap.add_argument("--rois", type=int, default=512)
     ap.add_argument("--hip2d", action="store_true", help="--r101: libadvengine's 2D convolution kernels where one exists")
     args = ap.parse_args()
@@ -318,7 +317,7 @@ def main():
         print(json.dumps(measure_dsgn_full(args.pairs, args.iters, args.reps, graph=args.graph, hip2d=(False if args.miopen else (True if args.hip2d else "auto")))))
         return
     if args.r101:
-        print(json.dumps(measure_srcnn_r101(args.pairs, args.iters, args.reps, args.rois, "hip" if args.hip2d else ("miopen" if args.miopen else "auto"), graph_backbone=not args.eager)))
+        print(json.dumps(measure_srcnn_r101(args.pairs, args.iters, args.reps, args.rois, "hip" if args.hip2d else ("miopen" if args.miopen else "auto"), graph_backbone=args.graph)))
         return
     if args.srcnn:
         print(json.dumps(measure_srcnn(args.pairs, args.iters, args.reps)))
