@@ -897,11 +897,12 @@ class Conv2dPrep:
         self.fwd, self.bwd = self._prep(wt, False), self._prep(wt, True)
 
     def _prep(self, wt, transpose):
-        kind = "1x1" if self.k == 1 else "3x3"
-        n = int(getattr(_lib.load(), "adv_conv2d_%s_prep_floats" % kind)(self.cout, self.cin, int(transpose)))
+        floats, prep = {1: ("adv_conv2d_1x1_prep_floats", "adv_conv2d_1x1_prep_weights_f32"),
+                        3: ("adv_conv2d_3x3_prep_floats", "adv_conv2d_3x3_prep_weights_f32")}[self.k]
+        n = int(getattr(_lib.load(), floats)(self.cout, self.cin, int(transpose)))
         out = torch.empty((n,), dtype=torch.float32, device=wt.device)
         with _on(wt):
-            _lib.call("adv_conv2d_%s_prep_weights_f32" % kind, _ptr(wt), _ptr(out), self.cout, self.cin, int(transpose), _stream(wt))
+            _lib.call(prep, _ptr(wt), _ptr(out), self.cout, self.cin, int(transpose), _stream(wt))
         return out
 
 

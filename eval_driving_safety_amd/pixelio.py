@@ -14,13 +14,35 @@ def iter_dir(prefix, k, eye):
     return os.path.join("%s_pgd_iters_%d" % (prefix, k), "image_2" if eye == 0 else "image_3")
 
 
+def _png_chunk(tag, data):
+    import struct
+    import zlib
+    return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(data, zlib.crc32(tag)) & 0xFFFFFFFF)
+
+
 def _encode_png(path, hwc_u8, bgr, compress_level=1):
-    """compress_level: zlib's effort.  The reference writes with PIL's default (6, attack/DSGN/pgd_attack.py:193); the DECODED pixels
-    are the same at every level - only the file size and the encode time change (level 1: ~3x faster, ~15 % larger on KITTI-like
-    content; tools/bench_folder_attack.py) - and the encode is the wall of the folder path (42 files per pair at N = 20)."""
-    from PIL import Image
+    """An 8-bit RGB PNG written directly: signature, IHDR, one IDAT = zlib(scanlines, each behind a filter byte), IEND.
+    The reference writes through PIL (attack/DSGN/pgd_attack.py:193); any PNG reader (PIL, cv2, skimage - what the reference's
+    predict_and_save_* scripts use) decodes the SAME pixels from this file - only size and encode time depend on the filter and the
+    zlib level.  Why not PIL here: its encoder keeps the interpreter lock while it deflates, so a pool of writer threads does not
+    scale (96 threads on a 256-thread host: 5.8 pairs/s against 6.1 with 16, profiles/r03_folder_attack.jsonl); numpy's
+    subtraction and zlib.compress / crc32 release it.  Filter 1 ("Sub": each byte minus the byte one pixel to its left, modulo 256)
+    keeps smooth image content compressible at level 1."""
+    import struct
+    import zlib
     a = hwc_u8[:, :, ::-1] if bgr else hwc_u8      # cv2.imwrite stores a BGR array as an RGB file
-    Image.fromarray(np.ascontiguousarray(a)).save(path, compress_level=compress_level)
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    h, w, c = a.shape
+    assert c == 3
+    flat = a.reshape(h, 3 * w)
+    raw = np.empty((h, 1 + 3 * w), np.uint8)
+    raw[:, 0] = 1                                   # filter type Sub
+    raw[:, 1:4] = flat[:, :3]
+    np.subtract(flat[:, 3:], flat[:, :-3], out=raw[:, 4:])          # uint8 arithmetic wraps modulo 256, as the filter is defined
+    data = zlib.compress(raw.tobytes(), int(compress_level))
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + _png_chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)) + _png_chunk(b"IDAT", data) +
+                _png_chunk(b"IEND", b""))
 
 
 class PngWriter:

@@ -494,7 +494,8 @@ def test_ops_surface_is_complete():
              "Conv3dK3", "Conv3dK3S2", "ConvTranspose3dK3S2",
              "dense_align_cost", "dense_align_argmin", "dense_align_search", "box_depth_offsets", "dense_align",
              "depth_regress", "depth_regress_bwd", "DepthRegress", "grid_sample3d", "GridSamplePlan", "grid_sample3d_bwd", "GridSample3d",
-             "sigmoid_focal_loss", "SigmoidFocalLoss", "relu_backward"]
+             "sigmoid_focal_loss", "SigmoidFocalLoss", "relu_backward",
+             "conv2d_supported", "Conv2dPrep", "conv2d", "conv2d_dgrad", "Conv2d", "Conv2dAuto", "bias_act_", "nms_padded"]
     missing = [n for n in names if not hasattr(ops, n)]
     assert not missing, missing
     # and every exported C symbol is reachable from some operator
