@@ -688,8 +688,12 @@ class DsgnShapedAdapter(PsvStereoAdapter):
             add3(name, kind, cout, cin, gain)
 
     # -- layer helpers (each counts its forward FLOPs) -------------------------------------------------------------------
+    trace2d = None        # a list: every 2D convolution call appends (cin, cout, k, stride, padding, dilation, batch, h, w) - tools/bench_conv2d_layers.py
+
     def _c2(self, x, name, relu=False, residual=None):
         w, b, s, p, d = self.w2[name]
+        if DsgnShapedAdapter.trace2d is not None:
+            DsgnShapedAdapter.trace2d.append((w.shape[1], w.shape[0], w.shape[2], s, p, d, x.shape[0], x.shape[2], x.shape[3]))
         if self.hip2d and not self.torch_ops and self.ops.conv2d_supported(x, w, s, p, d):
             # libadvengine's float32-MFMA 2D kernels: bias, skip connection and ReLU in the epilogue (no element-wise passes)
             if name not in self._p2:

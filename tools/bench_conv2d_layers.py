@@ -39,6 +39,25 @@ def layer_list(rois, dev):
     return counts
 
 
+def layer_list_dsgn(pairs, dev):
+    """the 2D convolutions of one forward of the DSGN-shaped graph (adapters.DsgnShapedAdapter) at ``pairs`` stereo pairs -> {shape: calls}"""
+    from eval_driving_safety_amd import adapters, data
+    net = adapters.DsgnShapedAdapter(dev, seed=0, hip2d=False)
+    batch = next(iter(data.SyntheticStereo(pairs, "dsgn", batch=pairs, seed=0)))
+    x = torch.cat([batch.imgL, batch.imgR]).to(dev)
+    adapters.DsgnShapedAdapter.trace2d = []
+    with torch.no_grad():
+        net.forward_all(x[:pairs], x[pairs:])
+    trace, adapters.DsgnShapedAdapter.trace2d = adapters.DsgnShapedAdapter.trace2d, None
+    counts = {}
+    for (cin, cout, k, s, p, d, b, h, w) in trace:
+        key = (cin, cout, k, s, p, b, h, w, d)
+        counts[key] = counts.get(key, 0) + 1
+    del net
+    torch.cuda.empty_cache()
+    return counts
+
+
 def timeit(fn, reps):
     for _ in range(2):
         fn()
@@ -57,34 +76,36 @@ def main():
     ap.add_argument("--rois", type=int, default=512)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--hip", action="store_true", help="also time libadvengine's kernels where one exists for the shape")
+    ap.add_argument("--dsgn", action="store_true", help="the 2D layers of the DSGN-shaped graph instead of the R101 Stereo R-CNN-shaped one")
+    ap.add_argument("--pairs", type=int, default=1, help="--dsgn: stereo pairs per step")
     ap.add_argument("--sweep", action="store_true", help="--hip: time every tile shape of the 1x1 kernel")
     ap.add_argument("--only", default="", help="only layer classes whose name starts with this (e.g. '1x1 s1')")
     ap.add_argument("--min-gflop", type=float, default=0.0, help="skip shapes below this many GFLOP per call")
     args = ap.parse_args()
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
-    counts = layer_list(args.rois, dev)
+    counts = layer_list_dsgn(args.pairs, dev) if args.dsgn else {k + (1,): v for k, v in layer_list(args.rois, dev).items()}
     ops = None
     if args.hip:
         from eval_driving_safety_amd import ops
     rows = []
-    for (cin, cout, k, s, p, b, h, w), n in sorted(counts.items(), key=lambda kv: -kv[1] * kv[0][0] * kv[0][1] * kv[0][2] ** 2 * kv[0][6] * kv[0][7] / kv[0][3] ** 2):
-        ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+    for (cin, cout, k, s, p, b, h, w, dil), n in sorted(counts.items(), key=lambda kv: -kv[1] * kv[0][0] * kv[0][1] * kv[0][2] ** 2 * kv[0][5] * kv[0][6] * kv[0][7] / kv[0][3] ** 2):
+        ho, wo = (h + 2 * p - dil * (k - 1) - 1) // s + 1, (w + 2 * p - dil * (k - 1) - 1) // s + 1
         flops = 2.0 * b * cin * cout * k * k * ho * wo
         if flops < args.min_gflop * 1e9 or not ("%dx%d s%d" % (k, k, s)).startswith(args.only):
             continue
         x = torch.randn((b, cin, h, w), device=dev)
         wt = torch.randn((cout, cin, k, k), device=dev) * 0.05
         bias = torch.randn((cout,), device=dev)
-        y = F.conv2d(x, wt, bias, s, p)
+        y = F.conv2d(x, wt, bias, s, p, dil)
         g = torch.randn_like(y)
-        ms_f = timeit(lambda: F.conv2d(x, wt, bias, s, p), args.reps)
-        ms_b = timeit(lambda: torch.ops.aten.convolution_backward(g, x, wt, None, [s, s], [p, p], [1, 1], False, [0, 0], 1, [True, False, False]), args.reps)
-        row = {"layer": "%dx%d s%d %d->%d on [%d,%d,%d,%d]" % (k, k, s, cin, cout, b, cin, h, w), "class": "%dx%d s%d" % (k, k, s), "calls_per_forward": n,
+        ms_f = timeit(lambda: F.conv2d(x, wt, bias, s, p, dil), args.reps)
+        ms_b = timeit(lambda: torch.ops.aten.convolution_backward(g, x, wt, None, [s, s], [p, p], [dil, dil], False, [0, 0], 1, [True, False, False]), args.reps)
+        row = {"layer": "%dx%d s%d%s %d->%d on [%d,%d,%d,%d]" % (k, k, s, " dil2" if dil == 2 else "", cin, cout, b, cin, h, w), "class": "%dx%d s%d" % (k, k, s), "calls_per_forward": n,
                "gflop_per_call": round(flops / 1e9, 3), "miopen_fwd_ms": round(ms_f, 4), "miopen_dgrad_ms": round(ms_b, 4),
                "miopen_fwd_tflops": round(flops / ms_f / 1e9, 1), "miopen_dgrad_tflops": round(flops / ms_b / 1e9, 1)}
-        if ops is not None and ops.conv2d_supported(x, wt, s, p):
-            prep = ops.Conv2dPrep(wt, s, p)
+        if ops is not None and ops.conv2d_supported(x, wt, s, p, dil):
+            prep = ops.Conv2dPrep(wt, s, p, dil)
             ms_hf = timeit(lambda: ops.conv2d(x, prep, bias), args.reps)
             ms_hb = timeit(lambda: ops.conv2d_dgrad(g, prep, (h, w)), args.reps)
             row.update({"hip_fwd_ms": round(ms_hf, 4), "hip_dgrad_ms": round(ms_hb, 4), "hip_fwd_tflops": round(flops / ms_hf / 1e9, 1),
@@ -111,7 +132,8 @@ def main():
                           "miopen_tflops": round(c["gflop"] / c["miopen_ms"], 1), "miopen_frac_of_157TF": round(c["gflop"] / c["miopen_ms"] / PEAK, 3),
                           "share_of_conv_time": round(c["miopen_ms"] / tot_ms, 3), "best_of_both_ms": round(c["best_ms"], 3),
                           "best_tflops": round(c["gflop"] / c["best_ms"], 1)}), flush=True)
-    print(json.dumps({"summary": "all 2D convolutions of one R101-FPN Stereo R-CNN-shaped forward + input-gradient backward, 600x1987, both eyes, %d rois" % args.rois,
+    print(json.dumps({"summary": ("all 2D convolutions (transposed ones excepted) of one DSGN-shaped forward + input-gradient backward, %d pair(s)" % args.pairs) if args.dsgn else
+                      "all 2D convolutions of one R101-FPN Stereo R-CNN-shaped forward + input-gradient backward, 600x1987, both eyes, %d rois" % args.rois,
                       "gflop": round(tot_gf, 1), "miopen_ms": round(tot_ms, 2), "miopen_tflops": round(tot_gf / tot_ms, 1),
                       "miopen_frac_of_157TF": round(tot_gf / tot_ms / PEAK, 3), "best_of_both_ms": round(tot_best, 2),
                       "best_frac_of_157TF": round(tot_gf / tot_best / PEAK, 3)}), flush=True)

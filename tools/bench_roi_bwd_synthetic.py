@@ -1,5 +1,5 @@
 import sys, json, torch, numpy as np
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from eval_driving_safety_amd import ops
 dev = torch.device("cuda", 0)
 def t(fn, reps=5):
