@@ -182,7 +182,7 @@ constexpr int kWF4 = kFSW / 4;       // 864 float4
 // compile-time geometry of the main kernel for a tile depth TD (waves = 2*TD, 4 rows of 32 voxels per wave)
 template <int TD, int TH = 8>
 struct Geo {
-  static constexpr int kThreads = 128 * TD;
+  static constexpr int kThreads = 256;                                              // four waves, whatever the tile shape
   static constexpr int kRows = kFC * (TD + 2) * (TH + 2);                          // tile rows per stage
   static constexpr int kRowsPerPass = kThreads / 8;
   static constexpr int kXPass = (kRows + kRowsPerPass - 1) / kRowsPerPass;          // float4 per lane
@@ -324,13 +324,14 @@ __device__ __forceinline__ void glds16(const float* src, float* lds_piece) {  //
 template <int TD, int TH>
 struct DmaGeo {
   using G = Geo<TD, TH>;
-  static_assert((G::kRows * 10) % 64 == 0, "the input tile is a whole number of 1 KiB pieces");
-  static constexpr int kXInstr = G::kRows * 10 / 64;            // 25 (TH = 8) / 15 (TH = 4) wave-instructions
+  static constexpr int kXF4 = G::kRows * 10;                    // float4 of the input tile
+  static constexpr int kXInstr = (kXF4 + 63) / 64;              // 25 (2x8 rows) / 15 (2x4) / 23 (4x4: the last piece half used) wave-instructions
+  static constexpr int kSXp = kXInstr * 256;                    // input area rounded up to whole 1 KiB pieces (= G::kSX for the 2-deep tiles)
   static constexpr int kWInstr = (kWF4 + 63) / 64;              // 14, the last one half used (its tail lands in the pad below)
   static constexpr int kWaves = G::kThreads / 64;
   static constexpr int kXPer = (kXInstr + kWaves - 1) / kWaves; // pieces a wave may own
   static constexpr int kWPer = (kWInstr + kWaves - 1) / kWaves;
-  static constexpr int kStageFloats = G::kSX + kWInstr * 256;   // weights area rounded up to whole pieces
+  static constexpr int kStageFloats = kSXp + kWInstr * 256;     // weights area rounded up to whole pieces
 };
 
 template <int TD, int TH>
@@ -352,7 +353,7 @@ __device__ __forceinline__ void make_dma_plan(DmaPlan<TD, TH>& pl, int tid, int 
     const int c = row / kPerC, rem = row - c * kPerC;
     const int dd = rem / (TH + 2), hh = rem - dd * (TH + 2);
     const int gd = d0 + dd - 1, gh = h0 + hh - 1, gw = w0 - 4 + 4 * j;
-    const bool ok = gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw + 3 < W;
+    const bool ok = q < DG::kXF4 && gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw + 3 < W;
     pl.xo[p] = ok ? c * vol + gd * plane + gh * W + gw : -1;
   }
 #pragma unroll
@@ -380,7 +381,7 @@ __device__ __forceinline__ void dma_issue(const DmaPlan<TD, TH>& pl, const float
     const int k = wave + DG::kWaves * p;
     if (k < DG::kWInstr) {
       const float* src = pl.wo[p] >= 0 ? wc + pl.wo[p] : g_zero16;
-      glds16(src, stage + DG::G::kSX + k * 256);
+      glds16(src, stage + DG::kSXp + k * 256);
     }
   }
 }
@@ -424,7 +425,7 @@ __device__ __forceinline__ TilePos tile_at(const TileGrid& tg, long long t) {
 // MASKED = false: every tap, no branch in the unrolled tap loop (the ordinary convolution: operand reads run ahead of the
 // MFMAs); MASKED = true: taps are skipped by epi.tap_mask (one parity class of a transposed convolution).
 template <int TD, bool MASKED, int TH = 8, bool DMA = false>
-__global__ __launch_bounds__(128 * TD, 2) void conv3d_k3_mfma(const float* __restrict__ x, const float* __restrict__ wp,
+__global__ __launch_bounds__(256, 2) void conv3d_k3_mfma(const float* __restrict__ x, const float* __restrict__ wp,
                                                               float* __restrict__ y, int Cin, int Cout, int cout_pad, int D, int H, int W,
                                                               TileGrid tg, Epi epi) {
   using G = Geo<TD, TH>;
@@ -432,7 +433,8 @@ __global__ __launch_bounds__(128 * TD, 2) void conv3d_k3_mfma(const float* __res
   // stage's MFMAs instead of after them (measured: 64->32 1.468 -> 1.437 ms, 32->64 1.395 -> 1.32 ms at 6; the masked
   // classes, with fewer MFMAs per stage, 0.60 -> 0.55 ms at 3; profiles/r02_conv3d_staging.jsonl)
   constexpr int kCommitAt = MASKED ? 3 : 6;
-  constexpr int NB = TD * TH / 4;  // rows of 32 voxels per wave
+  constexpr int NB = TD * TH / 4;  // rows of 32 voxels per wave (four waves)
+  constexpr int kSXo = DMA ? DmaGeo<TD, TH>::kSXp : G::kSX;   // where a stage's weights start
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l32 = lane & 31;
@@ -456,21 +458,23 @@ __global__ __launch_bounds__(128 * TD, 2) void conv3d_k3_mfma(const float* __res
   // two LDS stages: while the waves run the MFMAs of stage `cur`, the next chunk travels global -> registers ->
   // the other stage; ONE barrier per chunk
   constexpr int kStage = DMA ? DmaGeo<TD, TH>::kStageFloats : G::kStageFloats;
-  Stage<TD, TH> st;
-  Plan<TD, TH> pl;
+  // (the register-staged path exists for the 2-deep tiles only: TDr keeps its templates instantiable when DMA is the path taken)
+  constexpr int TDr = DMA ? 2 : TD;
+  Stage<TDr, TH> st;
+  Plan<TDr, TH> pl;
   DmaPlan<TD, TH> dpl;
   TilePos tp = tile_at<TD, TH>(tg, first);
-  if (DMA)
+  if constexpr (DMA)
     make_dma_plan<TD, TH>(dpl, tid, Cin, cout_pad, D, H, W, tp.d0, tp.h0, tp.w0, plane, vol);
   else
-    make_plan<TD, true, TH>(pl, tid, Cin, cout_pad, D, H, W, tp.d0, tp.h0, tp.w0, plane, vol);
+    make_plan<TDr, true, TH>(pl, tid, Cin, cout_pad, D, H, W, tp.d0, tp.h0, tp.w0, plane, vol);
   const float* xb = x + static_cast<long long>(tp.b) * Cin * vol;
   const float* wb = ((MASKED && epi.nclass > 0) ? epi.cls_wp[tp.cls] : wp) + tp.cob * 32;
-  if (DMA) {
+  if constexpr (DMA) {
     dma_issue<TD, TH>(dpl, xb, wb, lds, wave);
   } else {
-    stage_fetch<TD, true, TH>(st, pl, xb, wb);
-    stage_commit<TD, true, TH>(st, pl, lds, lds + G::kSX, tid);
+    stage_fetch<TDr, true, TH>(st, pl, xb, wb);
+    stage_commit<TDr, true, TH>(st, pl, lds, lds + G::kSX, tid);
   }
   __syncthreads();   // (waits for the DMA too: the compiler drains vmcnt before a barrier)
   int cur = 0;
@@ -489,10 +493,10 @@ __global__ __launch_bounds__(128 * TD, 2) void conv3d_k3_mfma(const float* __res
       if (cn >= Cin) {
         if (k + 1 < count) {
           tp = tile_at<TD, TH>(tg, first + (k + 1) * step);
-          if (DMA)
+          if constexpr (DMA)
             make_dma_plan<TD, TH>(dpl, tid, Cin, cout_pad, D, H, W, tp.d0, tp.h0, tp.w0, plane, vol);
           else
-            make_plan<TD, true, TH>(pl, tid, Cin, cout_pad, D, H, W, tp.d0, tp.h0, tp.w0, plane, vol);
+            make_plan<TDr, true, TH>(pl, tid, Cin, cout_pad, D, H, W, tp.d0, tp.h0, tp.w0, plane, vol);
           xb = x + static_cast<long long>(tp.b) * Cin * vol;
           wb = ((MASKED && epi.nclass > 0) ? epi.cls_wp[tp.cls] : wp) + tp.cob * 32;
           cn = 0;
@@ -501,11 +505,11 @@ __global__ __launch_bounds__(128 * TD, 2) void conv3d_k3_mfma(const float* __res
         }
       }
       const float* sxc = lds + cur * kStage;
-      const float* swc = sxc + G::kSX;
-      if (DMA)   // straight into the idle buffer; complete before the barrier that ends this stage
+      const float* swc = sxc + kSXo;
+      if constexpr (DMA)   // straight into the idle buffer; complete before the barrier that ends this stage
         dma_issue<TD, TH>(dpl, xb + static_cast<long long>(cn) * vol, wb + static_cast<long long>(cn) * cout_pad, lds + (cur ^ 1) * kStage, wave);
       else
-        stage_fetch<TD, true, TH>(st, pl, xb + static_cast<long long>(cn) * vol, wb + static_cast<long long>(cn) * cout_pad);
+        stage_fetch<TDr, true, TH>(st, pl, xb + static_cast<long long>(cn) * vol, wb + static_cast<long long>(cn) * cout_pad);
       // the loads are issued HERE, a hundred MFMAs before the commit that consumes them: without the fence the scheduler sinks
       // them next to their use and every wave sits in s_waitcnt vmcnt for a global-memory round trip per stage (PMC: 20 % of
       // the wave cycles parked, 10 % without the fetch)
@@ -514,9 +518,11 @@ __global__ __launch_bounds__(128 * TD, 2) void conv3d_k3_mfma(const float* __res
 #pragma unroll
       for (int t9 = 0; t9 < 9; ++t9) {  // (kd, kh); fully unrolled so that LDS operand reads run ahead of their MFMAs
         const int kd = t9 / 3, kh = t9 - kd * 3;
-        if (!DMA && t9 == kCommitAt) {  // the next stage goes to the OTHER buffer in the shadow of this stage's MFMAs
-          float* nx = lds + (cur ^ 1) * kStage;
-          stage_commit<TD, true, TH>(st, pl, nx, nx + G::kSX, tid);
+        if constexpr (!DMA) {
+          if (t9 == kCommitAt) {  // the next stage goes to the OTHER buffer in the shadow of this stage's MFMAs
+            float* nx = lds + (cur ^ 1) * kStage;
+            stage_commit<TDr, true, TH>(st, pl, nx, nx + G::kSX, tid);
+          }
         }
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
@@ -1261,32 +1267,42 @@ static int launch_conv(const float* x, const float* w_prep, float* y, int b, int
     const long long n8 = per_row_tile * ((h + 7) / 8), n4 = per_row_tile * ((h + 3) / 4);
     const double t8 = static_cast<double>((n8 + slots - 1) / slots);
     const double t4 = (all_taps ? 0.52 : 0.75) * static_cast<double>((n4 + slots - 1) / slots);
-    bool th4 = t4 < t8;
-    if (const char* e = adv_hook_value("ADV_CONV_TH")) th4 = e[0] == '4';
+    // staging by LDS-DMA needs whole float4 groups inside the rows: w % 4 == 0 and a 16-byte aligned x (ADV_CONV_NO_DMA=1: the
+    // register-staged path instead - test hook / A-B; same bits)
+    const bool dma = w % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && !adv_hook("ADV_CONV_NO_DMA");
+    // <round 3> a third shape, 4 planes x 4 rows x 32 (the same 512 voxels as 2 x 8 x 32, 36 instead of 40 staged rows per channel):
+    // for volumes whose height is a multiple of 4 but not of 8 - the 3D geometric volume's 20 / 10 rows, where 8-row tiles compute
+    // 17-37 % padding and 4-row tiles stage half the voxels per tile (0.51 of peak on 32->64 at [192,20,304], 0.63 on 128->128 at
+    // [96,10,152]: profiles/r03_conv3d_layers.jsonl).  All taps + LDS-DMA only.  ADV_CONV_TH=44 forces it.
+    const long long n44 = static_cast<long long>(tiles_w) * ((d + 3) / 4) * b * cblocks * ((h + 3) / 4);
+    const double t44 = (all_taps && dma) ? 0.98 * static_cast<double>((n44 + slots - 1) / slots) : 1e300;
+    int tsel = t4 < t8 ? 4 : 8;
+    if (t44 < (tsel == 4 ? t4 : t8)) tsel = 44;
+    if (const char* e = adv_hook_value("ADV_CONV_TH")) tsel = (e[0] == '4' && e[1] == '4' && all_taps && dma) ? 44 : (e[0] == '4' ? 4 : 8);
+    const bool th4 = tsel == 4;
     TileGrid tg;
-    tg.tiles_w = tiles_w, tg.tiles_hw = tiles_w * (th4 ? (h + 3) / 4 : (h + 7) / 8), tg.nd = (d + 1) / 2, tg.cblocks = cblocks;
+    tg.tiles_w = tiles_w, tg.tiles_hw = tiles_w * (tsel == 8 ? (h + 7) / 8 : (h + 3) / 4), tg.nd = tsel == 44 ? (d + 3) / 4 : (d + 1) / 2, tg.cblocks = cblocks;
     tg.nclass = epi.nclass;
-    tg.ntiles = th4 ? n4 : n8;
+    tg.ntiles = tsel == 44 ? n44 : (th4 ? n4 : n8);
     long long wgs = slots;
     if (adv_hook("ADV_CONV_ONE_TILE_PER_WG") || tg.ntiles < wgs) wgs = tg.ntiles;
     if (wgs > 0x7fffffffLL) return ADV_EINVAL;
     const dim3 grid(static_cast<unsigned>(wgs));
     const int cpad = cblocks * 32;
-    // staging by LDS-DMA needs whole float4 groups inside the rows: w % 4 == 0 and a 16-byte aligned x (ADV_CONV_NO_DMA=1: the
-    // register-staged path instead - test hook / A-B; same bits)
-    const bool dma = w % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && !adv_hook("ADV_CONV_NO_DMA");
-#define ADV_LAUNCH_MFMA(MASKED_, TH_, DMA_)                                                                                                   \
+#define ADV_LAUNCH_MFMA(TD_, MASKED_, TH_, DMA_)                                                                                              \
   do {                                                                                                                                        \
-    const size_t lds_ = 2 * sizeof(float) * static_cast<size_t>(DMA_ ? DmaGeo<2, TH_>::kStageFloats : Geo<2, TH_>::kStageFloats);               \
-    if (!adv_internal_lds_limit<conv3d_k3_mfma<2, MASKED_, TH_, DMA_>>(lds_)) return ADV_ELAUNCH;                                               \
-    hipLaunchKernelGGL((conv3d_k3_mfma<2, MASKED_, TH_, DMA_>), grid, dim3(256), lds_, st, x, w_prep, y, cin, cout, cpad, d, h, w, tg, epi);    \
+    const size_t lds_ = 2 * sizeof(float) * static_cast<size_t>(DMA_ ? DmaGeo<TD_, TH_>::kStageFloats : Geo<2, TH_>::kStageFloats);             \
+    if (!adv_internal_lds_limit<conv3d_k3_mfma<TD_, MASKED_, TH_, DMA_>>(lds_)) return ADV_ELAUNCH;                                             \
+    hipLaunchKernelGGL((conv3d_k3_mfma<TD_, MASKED_, TH_, DMA_>), grid, dim3(256), lds_, st, x, w_prep, y, cin, cout, cpad, d, h, w, tg, epi);  \
   } while (0)
-    if (!th4) {
-      if (all_taps) { if (dma) ADV_LAUNCH_MFMA(false, 8, true); else ADV_LAUNCH_MFMA(false, 8, false); }
-      else          { if (dma) ADV_LAUNCH_MFMA(true, 8, true); else ADV_LAUNCH_MFMA(true, 8, false); }
+    if (tsel == 44) {
+      ADV_LAUNCH_MFMA(4, false, 4, true);
+    } else if (!th4) {
+      if (all_taps) { if (dma) ADV_LAUNCH_MFMA(2, false, 8, true); else ADV_LAUNCH_MFMA(2, false, 8, false); }
+      else          { if (dma) ADV_LAUNCH_MFMA(2, true, 8, true); else ADV_LAUNCH_MFMA(2, true, 8, false); }
     } else {
-      if (all_taps) { if (dma) ADV_LAUNCH_MFMA(false, 4, true); else ADV_LAUNCH_MFMA(false, 4, false); }
-      else          { if (dma) ADV_LAUNCH_MFMA(true, 4, true); else ADV_LAUNCH_MFMA(true, 4, false); }
+      if (all_taps) { if (dma) ADV_LAUNCH_MFMA(2, false, 4, true); else ADV_LAUNCH_MFMA(2, false, 4, false); }
+      else          { if (dma) ADV_LAUNCH_MFMA(2, true, 4, true); else ADV_LAUNCH_MFMA(2, true, 4, false); }
     }
 #undef ADV_LAUNCH_MFMA
   } else if (stride == 1) {

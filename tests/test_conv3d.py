@@ -119,7 +119,7 @@ def test_hip_persistent_tile_walk_equals_one_workgroup_per_tile(masked, route):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("switch", ["ADV_CONV_NO_DMA=1", "ADV_CONV_TH=4", "ADV_CONV_TH=8", "ADV_CONV_GENERIC=1", "ADV_CONV_CLASS_LAUNCHES=1", "ADV_CONV_T_CLASS_TILES=1"])
+@pytest.mark.parametrize("switch", ["ADV_CONV_NO_DMA=1", "ADV_CONV_TH=4", "ADV_CONV_TH=8", "ADV_CONV_TH=44", "ADV_CONV_GENERIC=1", "ADV_CONV_CLASS_LAUNCHES=1", "ADV_CONV_T_CLASS_TILES=1"])
 def test_hip_alternative_code_paths_give_the_same_bits(switch, route):
     """register-staged vs LDS-DMA stages, both tile heights, the scalar-staging kernel, for the transposed convolution eight
     launches / the class as a tile index / all classes per tile: identical results on plain, masked, strided and transposed layers (W % 4 == 0 and != 0)"""

@@ -40,10 +40,10 @@ def conv_case(rs, dev, big=False):
     bias = rs.randn(cout).astype(np.float32) if rs.rand() < 0.5 else None
     relu = bool(rs.rand() < 0.5)
     mask = int(rs.randint(1, 1 << 27)) if rs.rand() < 0.4 else (1 << 27) - 1
-    sw = rs.choice(["", "", "ADV_CONV_NO_DMA", "ADV_CONV_TH4", "ADV_CONV_TH8", "ADV_CONV_ONE_TILE_PER_WG", "ADV_CONV_GENERIC", "ADV_CONV_T_CLASS_TILES",
+    sw = rs.choice(["", "", "ADV_CONV_NO_DMA", "ADV_CONV_TH4", "ADV_CONV_TH8", "ADV_CONV_TH44", "ADV_CONV_ONE_TILE_PER_WG", "ADV_CONV_GENERIC", "ADV_CONV_T_CLASS_TILES",
                     "ADV_CONV_CLASS_LAUNCHES"])
     skip = bool(rs.rand() < 0.4)
-    env = {"ADV_CONV_TH4": ("ADV_CONV_TH", "4"), "ADV_CONV_TH8": ("ADV_CONV_TH", "8")}.get(sw, (sw, "1") if sw else None)
+    env = {"ADV_CONV_TH4": ("ADV_CONV_TH", "4"), "ADV_CONV_TH8": ("ADV_CONV_TH", "8"), "ADV_CONV_TH44": ("ADV_CONV_TH", "44")}.get(sw, (sw, "1") if sw else None)
     import contextlib
     from eval_driving_safety_amd import _lib
     with contextlib.ExitStack() as stack:        # a switched case runs on the -DADV_TEST_HOOKS build, an unswitched one on the shipped library
