@@ -76,6 +76,34 @@ def conv_case(rs, dev, big=False):
             same(yt, plus_skip(lambda r: C.conv_transpose3d_k3_s2(x, wtt, bias=bias, relu=r), sk2), "transposed conv %s" % ((b, cin, cout, d, h, w, sw, skip),))
 
 
+def conv2d_case(rs, dev):
+    """csrc/conv2d.hip: 1x1 and 3x3 (dilation 1 / 2) layers of random shape, every tile shape, random epilogue (bias, skip connection,
+    ReLU, mask), forward and backward w.r.t. the input, against the oracle's fmaf chain bit for bit"""
+    k = int(rs.choice([1, 3]))
+    dil = int(rs.choice([1, 2])) if k == 3 else 1
+    b = int(rs.randint(1, 4))
+    cin, cout = int(rs.choice([1, 3, 8, 13, 16, 24, 64, 130])), int(rs.choice([1, 6, 18, 32, 33, 64, 70, 128]))
+    h, w = int(rs.randint(1, 40)), int(rs.choice([1, 2, 5, 31, 32, 33, 41, 63, 64, 97]))
+    x = rs.randn(b, cin, h, w).astype(np.float32)
+    wt = (rs.randn(cout, cin, k, k) * (1.0 / (cin * k * k)) ** 0.5).astype(np.float32)
+    bias = rs.randn(cout).astype(np.float32) if rs.rand() < 0.6 else None
+    res = rs.randn(b, cout, h, w).astype(np.float32) if rs.rand() < 0.5 else None
+    mask = rs.randn(b, cout, h, w).astype(np.float32) if rs.rand() < 0.3 else None
+    relu = bool(rs.rand() < 0.5)
+    pad = dil if k == 3 else 0
+    chunk = 8 if k == 3 else 16
+    tile = int(rs.randint(-1, 4 if k == 1 else 2))
+    t = lambda a: None if a is None else torch.tensor(a, device=dev)       # noqa: E731
+    prep = ops.Conv2dPrep(t(wt), 1, pad, dil)
+    y = ops.conv2d(t(x), prep, t(bias), t(res), relu, t(mask), tile=tile)
+    same(y, C.conv2d(x, wt, bias, res, mask, padding=pad, dilation=dil, relu=relu, chunk=chunk), "conv2d %s" % ((k, dil, b, cin, cout, h, w, relu, tile),))
+    g = rs.randn(b, cout, h, w).astype(np.float32)
+    gres = rs.randn(b, cin, h, w).astype(np.float32) if rs.rand() < 0.5 else None
+    gmask = x if rs.rand() < 0.5 else None
+    gx = ops.conv2d_dgrad(t(g), prep, residual=t(gres), mask=t(gmask), tile=tile)
+    same(gx, C.conv2d(g, wt, residual=gres, mask=gmask, padding=pad, dilation=dil, transpose=True, chunk=chunk), "conv2d dgrad %s" % ((k, dil, b, cin, cout, h, w, tile),))
+
+
 def grid_case(rs, dev):
     b, c = int(rs.randint(1, 3)), int(rs.randint(1, 20))
     dims = tuple(int(v) for v in rs.randint(1, 12, 3))
@@ -163,7 +191,7 @@ def main():
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     rs = np.random.RandomState(args.seed)
-    kinds = [conv_case] * 5 + [grid_case] * 2 + [pgd_case] * 3 + [roi_case] * 2 + [depth_case] * 2
+    kinds = [conv_case] * 5 + [conv2d_case] * 4 + [grid_case] * 2 + [pgd_case] * 3 + [roi_case] * 3 + [depth_case] * 2
     counts = {}
     for i in range(args.cases):
         fn = kinds[int(rs.randint(len(kinds)))]
