@@ -805,12 +805,18 @@ constexpr int kSC = 2;                                    // input channels per 
 constexpr int kSRow = 72;                                 // LDS row = global columns [2*w0 - 4, 2*w0 + 68)
 // CB = blocks of 32 output channels per workgroup: 2 (cout > 32: a wave owns one output row, both blocks) or 1 (a wave owns two output
 // rows of the one block) - either way two accumulators and 54 MFMAs per wave and stage
-template <int CB>
+// <round 3> PD = output depth planes per workgroup.  A stage of the PD = 1 tile moves 30 KiB (3 input planes + 27 x 2 x 64 weights) for
+// 54 MFMAs per wave - 8.9 bytes per cycle and workgroup, i.e. the kernel is bound by global -> LDS staging (two workgroups per CU ask for
+// more than the ~10 B/clk/CU the path delivers), not by its 2-way LDS conflicts.  PD = 2 stages 5 input planes for 2 output planes and
+// the same weights: 40 KiB for 108 MFMAs per wave, 5.8 bytes per cycle.  Only with two channel blocks per workgroup (cout > 32), where
+// two 40 KiB stages x two workgroups are exactly the CU's 160 KiB, and only where the halved tile count still fills the chip.
+template <int CB, int PD = 1>
 struct SGeo {
   static constexpr int kRW = 3 - CB;                      // output rows per wave
   static constexpr int kTH = 4 * kRW;                     // output rows per tile (four waves)
   static constexpr int kRowsIn = 2 * kTH + 1;             // input rows per plane of the tile
-  static constexpr int kRows = kSC * 3 * kRowsIn;
+  static constexpr int kPlanes = 2 * PD + 1;              // input planes of the tile
+  static constexpr int kRows = kSC * kPlanes * kRowsIn;
   static constexpr int kXF4 = kRows * (kSRow / 4);        // 972 (CB = 2) / 1836 float4
   static constexpr int kXInstr = (kXF4 + 63) / 64;
   static constexpr int kSX = kXInstr * 256;
@@ -820,12 +826,13 @@ struct SGeo {
   static constexpr int kXPer = (kXInstr + 3) / 4, kWPer = (kWInstr + 3) / 4;
 };
 
-template <int CB>
+template <int CB, int PD = 1>
 __global__ __launch_bounds__(256, 2) void conv3d_k3_s2_mfma(const float* __restrict__ x, const float* __restrict__ wp, float* __restrict__ y,
                                                             int Cin, int Cout, int cout_pad, int D, int H, int W, int gD, int gH, int gW,
                                                             int tiles_w, int tiles_h, int cgroups, Epi epi) {
-  using SG = SGeo<CB>;
-  constexpr int kRW = SG::kRW, kRowsIn = SG::kRowsIn, kCO = 32 * CB;
+  using SG = SGeo<CB, PD>;
+  constexpr int kRW = SG::kRW, kRowsIn = SG::kRowsIn, kCO = 32 * CB, kPlanes = SG::kPlanes;
+  const int gDt = (gD + PD - 1) / PD;                      // depth tiles
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l32 = lane & 31;
@@ -835,8 +842,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_s2_mfma(const float* __restr
   t /= tiles_w;
   const int h0 = (t % tiles_h) * SG::kTH;
   t /= tiles_h;
-  const int d0 = t % gD;
-  t /= gD;
+  const int d0 = (t % gDt) * PD;                           // first output plane of the tile
+  t /= gDt;
   const int b = t / cgroups, cp = t - b * cgroups;
   const float* xb = x + static_cast<long long>(b) * Cin * vol;
 
@@ -845,7 +852,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_s2_mfma(const float* __restr
   for (int p = 0; p < SG::kXPer; ++p) {
     const int q = 64 * (wave + 4 * p) + lane;
     const int row = q / 18, j = q - row * 18;
-    const int c = row / (3 * kRowsIn), rem = row - c * 3 * kRowsIn;
+    const int c = row / (kPlanes * kRowsIn), rem = row - c * kPlanes * kRowsIn;
     const int kd = rem / kRowsIn, r9 = rem - kd * kRowsIn;
     const int gd = 2 * d0 + kd - 1, gh = 2 * h0 + r9 - 1, gw = 2 * w0 - 4 + 4 * j;
     const bool ok = q < SG::kXF4 && j < 17 && gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw + 3 < W;   // columns 68..71 are never read
@@ -871,11 +878,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_s2_mfma(const float* __restr
     }
   };
 
-  f32x16 acc[2];
+  f32x16 acc[PD][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int pd = 0; pd < PD; ++pd)
 #pragma unroll
-    for (int v = 0; v < 16; ++v) acc[i][v] = 0.0f;
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[pd][i][v] = 0.0f;
   issue(0, lds);
   __syncthreads();
   int cur = 0;
@@ -888,13 +897,19 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_s2_mfma(const float* __restr
 #pragma unroll
     for (int tap = 0; tap < 27; ++tap) {
       const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-      float a[CB], bv[kRW];
-#pragma unroll
-      for (int r = 0; r < kRW; ++r) bv[r] = sxc[((half * 3 + kd) * kRowsIn + 2 * (wave * kRW + r) + kh) * kSRow + 3 + 2 * l32 + kw];
+      float a[CB];
 #pragma unroll
       for (int cb = 0; cb < CB; ++cb) a[cb] = swc[(tap * kSC + half) * kCO + cb * 32 + l32];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[CB == 2 ? i : 0], bv[CB == 2 ? 0 : i], acc[i], 0, 0, 0);
+      for (int pd = 0; pd < PD; ++pd) {
+        float bv[kRW];
+#pragma unroll
+        for (int r = 0; r < kRW; ++r)
+          bv[r] = sxc[((half * kPlanes + 2 * pd + kd) * kRowsIn + 2 * (wave * kRW + r) + kh) * kSRow + 3 + 2 * l32 + kw];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          acc[pd][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[CB == 2 ? i : 0], bv[CB == 2 ? 0 : i], acc[pd][i], 0, 0, 0);
+      }
     }
     __syncthreads();
     cur ^= 1;
@@ -905,12 +920,14 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_s2_mfma(const float* __restr
   const long long ovol = static_cast<long long>(gD) * gH * gW;
   const bool has_bias = epi.bias != nullptr, has_res = epi.residual != nullptr;
 #pragma unroll
+  for (int pd = 0; pd < PD; ++pd)
+#pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int cb = CB == 2 ? i : 0, r = CB == 2 ? 0 : i;
     const int gh = h0 + wave * kRW + r;
     const int co0 = cp * kCO + cb * 32 + 4 * half;
-    if (gh >= gH || cp * kCO + cb * 32 >= Cout) continue;
-    const long long at = (static_cast<long long>(b) * Cout + co0) * ovol + (static_cast<long long>(d0) * gH + gh) * gW + gw;
+    if (gh >= gH || d0 + pd >= gD || cp * kCO + cb * 32 >= Cout) continue;
+    const long long at = (static_cast<long long>(b) * Cout + co0) * ovol + (static_cast<long long>(d0 + pd) * gH + gh) * gW + gw;
     float bz[16], sk[16];
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
@@ -921,7 +938,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_s2_mfma(const float* __restr
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
       const int cr = 8 * (v >> 2) + (v & 3);
-      float rv = acc[i][v];
+      float rv = acc[pd][i][v];
       if (has_bias) rv = rv + bz[v];
       if (has_res) rv = rv + sk[v];
       if (epi.relu) rv = rv > 0.0f ? rv : 0.0f;
@@ -1237,6 +1254,18 @@ static int launch_conv(const float* x, const float* w_prep, float* y, int b, int
     const long long ntiles = static_cast<long long>(tw) * th * gd * b * cgroups;
     if (ntiles < (1LL << 31)) {
       if (two) {
+        // two output planes per workgroup (less staged per MFMA) where half as many tiles still make up more rounds of the resident
+        // workgroups than they cost: rounds(n/2) * 2 * 0.78 < rounds(n)   (ADV_CONV_S2_PD=1|2 forces one - test hook / A-B; same bits)
+        const long long slots2 = 2LL * cu_count(), n2 = static_cast<long long>(tw) * th * ((gd + 1) / 2) * b * cgroups;
+        bool pd2 = 1.56 * static_cast<double>((n2 + slots2 - 1) / slots2) < static_cast<double>((ntiles + slots2 - 1) / slots2);
+        if (const char* e = adv_hook_value("ADV_CONV_S2_PD")) pd2 = e[0] == '2';
+        if (pd2) {
+          const size_t lds2 = 2 * sizeof(float) * static_cast<size_t>(SGeo<2, 2>::kStage);
+          if (!adv_internal_lds_limit<conv3d_k3_s2_mfma<2, 2>>(lds2)) return ADV_ELAUNCH;
+          hipLaunchKernelGGL((conv3d_k3_s2_mfma<2, 2>), dim3(static_cast<unsigned>(n2)), dim3(256), lds2, st, x, w_prep, y, cin, cout, cblocks * 32, d, h, w, gd, gh,
+                             gw, tw, th, cgroups, epi);
+          return adv_internal_finish_launch();
+        }
         hipLaunchKernelGGL(conv3d_k3_s2_mfma<2>, dim3(static_cast<unsigned>(ntiles)), dim3(256), 2 * sizeof(float) * static_cast<size_t>(SGeo<2>::kStage),
                            st, x, w_prep, y, cin, cout, cblocks * 32, d, h, w, gd, gh, gw, tw, th, cgroups, epi);
       } else {

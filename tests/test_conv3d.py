@@ -418,6 +418,10 @@ def test_hip_direct_strided_kernel_bit_exact_vs_oracle(shape, route):
     assert plain.cpu().numpy().tobytes() == C.conv3d_k3_ex(x, wt, stride=2, chunk=2).tobytes(), "direct strided, plain"
     skip = torch.tensor(rs.randn(*plain.shape).astype(np.float32), device=dev)
     assert torch.equal(ops._conv3d_ex(tx, wp, cout, 2, True, tb, residual=skip), F.relu(ops.conv3d_k3_s2(tx, wp, cout, bias=tb) + skip))
+    if cout > 32:     # one or two output depth planes per workgroup (the host picks by the tile count): the same bits
+        for pd in ("1", "2"):
+            with route(ADV_CONV_S2_PD=pd):
+                assert torch.equal(ops.conv3d_k3_s2(tx, wp, cout, bias=tb, relu=True), got), "planes per workgroup: " + pd
     with route(ADV_CONV_S2_GENERIC="1"):
         assert ops.conv3d_k3_s2_stage_channels(tx, cout) == 4
         slow = ops.conv3d_k3_s2(tx, wp, cout, bias=tb, relu=True)
