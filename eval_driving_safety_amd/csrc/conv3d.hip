@@ -1254,10 +1254,13 @@ static int launch_conv(const float* x, const float* w_prep, float* y, int b, int
     const long long ntiles = static_cast<long long>(tw) * th * gd * b * cgroups;
     if (ntiles < (1LL << 31)) {
       if (two) {
-        // two output planes per workgroup (less staged per MFMA) where half as many tiles still make up more rounds of the resident
-        // workgroups than they cost: rounds(n/2) * 2 * 0.78 < rounds(n)   (ADV_CONV_S2_PD=1|2 forces one - test hook / A-B; same bits)
-        const long long slots2 = 2LL * cu_count(), n2 = static_cast<long long>(tw) * th * ((gd + 1) / 2) * b * cgroups;
-        bool pd2 = 1.56 * static_cast<double>((n2 + slots2 - 1) / slots2) < static_cast<double>((ntiles + slots2 - 1) / slots2);
+        // two output planes per workgroup (less staged per MFMA: measured 0.93 of the time per output on 64->128 at [192,20,304]) where
+        // half as many tiles do not cost more rounds than that saves.  Rounds are counted per COMPUTE UNIT, not per resident workgroup:
+        // two co-resident workgroups share the matrix pipes, so 576 tiles take three rounds of 256 CUs, and 288 double tiles two
+        // double-length ones (a first version counted 512 slots and made the 16-GFLOP layers 15 % slower).
+        // (ADV_CONV_S2_PD=1|2 forces one - test hook / A-B; same bits)
+        const long long cus = cu_count(), n2 = static_cast<long long>(tw) * th * ((gd + 1) / 2) * b * cgroups;
+        bool pd2 = 1.86 * static_cast<double>((n2 + cus - 1) / cus) < static_cast<double>((ntiles + cus - 1) / cus);
         if (const char* e = adv_hook_value("ADV_CONV_S2_PD")) pd2 = e[0] == '2';
         if (pd2) {
           const size_t lds2 = 2 * sizeof(float) * static_cast<size_t>(SGeo<2, 2>::kStage);
