@@ -1297,8 +1297,10 @@ static int launch_conv(const float* x, const float* w_prep, float* y, int b, int
     // test hook / A-B).  Same bits either way.
     const bool all_taps = epi.tap_mask == kAllTaps && epi.class_channels == 0 && epi.nclass == 0;
     const long long n8 = per_row_tile * ((h + 7) / 8), n4 = per_row_tile * ((h + 3) / 4);
-    const double t8 = static_cast<double>((n8 + slots - 1) / slots);
-    const double t4 = (all_taps ? 0.52 : 0.75) * static_cast<double>((n4 + slots - 1) / slots);
+    // rounds are counted per compute unit (two co-resident workgroups share its matrix pipes: 288 tiles are two rounds, not one)
+    const long long cus = slots / 2;
+    const double t8 = static_cast<double>((n8 + cus - 1) / cus);
+    const double t4 = (all_taps ? 0.52 : 0.75) * static_cast<double>((n4 + cus - 1) / cus);
     // staging by LDS-DMA needs whole float4 groups inside the rows: w % 4 == 0 and a 16-byte aligned x (ADV_CONV_NO_DMA=1: the
     // register-staged path instead - test hook / A-B; same bits)
     const bool dma = w % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && !adv_hook("ADV_CONV_NO_DMA");
@@ -1307,7 +1309,7 @@ static int launch_conv(const float* x, const float* w_prep, float* y, int b, int
     // 17-37 % padding and 4-row tiles stage half the voxels per tile (0.51 of peak on 32->64 at [192,20,304], 0.63 on 128->128 at
     // [96,10,152]: profiles/r03_conv3d_layers.jsonl).  All taps + LDS-DMA only.  ADV_CONV_TH=44 forces it.
     const long long n44 = static_cast<long long>(tiles_w) * ((d + 3) / 4) * b * cblocks * ((h + 3) / 4);
-    const double t44 = (all_taps && dma) ? 0.98 * static_cast<double>((n44 + slots - 1) / slots) : 1e300;
+    const double t44 = (all_taps && dma) ? 0.98 * static_cast<double>((n44 + cus - 1) / cus) : 1e300;
     int tsel = t4 < t8 ? 4 : 8;
     if (t44 < (tsel == 4 ? t4 : t8)) tsel = 44;
     if (const char* e = adv_hook_value("ADV_CONV_TH")) tsel = (e[0] == '4' && e[1] == '4' && all_taps && dma) ? 44 : (e[0] == '4' ? 4 : 8);
