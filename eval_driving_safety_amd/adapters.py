@@ -690,7 +690,9 @@ class DsgnShapedAdapter(PsvStereoAdapter):
     # -- layer helpers (each counts its forward FLOPs) -------------------------------------------------------------------
     trace2d = None        # a list: every 2D convolution call appends (cin, cout, k, stride, padding, dilation, batch, h, w) - tools/bench_conv2d_layers.py
 
-    def _c2(self, x, name, relu=False, residual=None):
+    def _c2(self, x, name, relu=False, residual=None, chain_in=False):
+        """``relu="consumer"`` / ``chain_in=True``: see ops.Conv2dAuto - a ReLU layer whose ONLY consumer is the next convolution leaves
+        its backward mask to that consumer's dgrad epilogue (no relu_backward pass over the tensor)"""
         w, b, s, p, d = self.w2[name]
         if DsgnShapedAdapter.trace2d is not None:
             DsgnShapedAdapter.trace2d.append((w.shape[1], w.shape[0], w.shape[2], s, p, d, x.shape[0], x.shape[2], x.shape[3]))
@@ -699,16 +701,28 @@ class DsgnShapedAdapter(PsvStereoAdapter):
             if name not in self._p2:
                 self._p2[name] = self.ops.Conv2dPrep(w, s, p, d)
             if self.hip2d == "auto":       # per layer shape and direction, whichever of {libadvengine, MIOpen} measured faster
-                y = self.ops.Conv2dAuto.apply(x, self._p2[name], w, b, residual, relu)
+                y = self.ops.Conv2dAuto.apply(x, self._p2[name], w, b, residual, relu, chain_in)
             else:
+                assert not chain_in and relu != "consumer"
                 y = self.ops.Conv2d.apply(x, self._p2[name], b, residual, relu)
             self.flops_fwd += 2 * y.numel() * w.shape[1] * w.shape[2] * w.shape[3]
             return y
+        assert not chain_in and relu != "consumer", "chained ReLU masks need the Conv2dAuto path on both layers"
         y = F.conv2d(x, w, b, s, p, d)
         self.flops_fwd += 2 * y.numel() * w.shape[1] * w.shape[2] * w.shape[3]
         if residual is not None:
             y = y + residual
         return F.relu(y) if relu else y
+
+    def _chain(self, *names):
+        """can the ReLU masks between these consecutive layers be left to the consumers?  (all of them on the Conv2dAuto path)"""
+        if self.hip2d != "auto" or self.torch_ops:
+            return False
+        for n in names:
+            w, b, s, p, d = self.w2[n]
+            if not (s == 1 and ((w.shape[2] == 1 and p == 0 and d == 1) or (w.shape[2] == 3 and d in (1, 2) and p == d))):
+                return False
+        return True
 
     def _ct2(self, x, name, relu=False, residual=None):
         w, b = self.wt2[name]
@@ -753,7 +767,8 @@ class DsgnShapedAdapter(PsvStereoAdapter):
         outs = {}
         for pre, proj, li in self.blocks:
             idt = self._c2(x, pre + ".p") if proj else x
-            x = self._c2(self._c2(x, pre + ".a", True), pre + ".b", residual=idt)         # PSMNet's BasicBlock: no ReLU after the sum
+            ch = self._chain(pre + ".a", pre + ".b")                                          # a's only consumer is b
+            x = self._c2(self._c2(x, pre + ".a", "consumer" if ch else True), pre + ".b", residual=idt, chain_in=ch)   # PSMNet's BasicBlock: no ReLU after the sum
             outs[li] = x
         l2, l4 = outs[2], outs[4]
         branches = []
@@ -808,9 +823,11 @@ class DsgnShapedAdapter(PsvStereoAdapter):
         post2 = self._ct2(h2, "bh5", True, pre2)
         x = self._ct2(post2, "bh6", True, b0)
         ct = rt = x
-        for i in range(4):
-            ct, rt = self._c2(ct, "ct%d" % i, True), self._c2(rt, "rt%d" % i, True)
-        return self._c2(ct, "head_cls") + self.cls_bias, self._c2(rt, "head_reg"), self._c2(rt, "head_ctr")
+        chain = self._chain("ct0", "ct1", "head_cls")
+        for i in range(4):                      # the class tower is a chain (each layer's only consumer is the next one; ct3 -> head_cls);
+            ct = self._c2(ct, "ct%d" % i, "consumer" if chain else True, chain_in=chain and i > 0)      # x itself feeds both towers: no chain into ct0
+            rt = self._c2(rt, "rt%d" % i, "consumer" if (chain and i < 3) else True, chain_in=chain and i > 0)   # rt3 feeds two heads: it masks itself
+        return self._c2(ct, "head_cls", chain_in=chain) + self.cls_bias, self._c2(rt, "head_reg"), self._c2(rt, "head_ctr")
 
     def forward_all(self, imgL, imgR):
         b = imgL.shape[0]

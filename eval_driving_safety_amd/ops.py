@@ -1025,41 +1025,53 @@ class _Conv2dChoice:
 class Conv2dAuto(torch.autograd.Function):
     """y = [relu](conv2d(x) [+ bias] [+ residual]) and its backward w.r.t. x and the residual, each direction computed by whichever of
     {csrc/conv2d.hip, torch} measured faster for this layer shape (see _Conv2dChoice).  ``prep`` = Conv2dPrep of the layer, ``weight``
-    the original tensor for torch's side."""
+    the original tensor for torch's side.
+
+    The ReLU's backward without a pass of its own, for CHAINS (a -> this layer is a's only consumer):
+      ``mask_input=True``   x is a ReLU output consumed by this layer alone: the gradient returned for x is already multiplied by
+                            (x > 0) - in the dgrad kernel's epilogue when libadvengine computes it - i.e. it is the gradient w.r.t.
+                            the producer's PRE-activation;
+      ``relu="consumer"``   this layer applies the ReLU in its forward but does not mask in its backward: its only consumer was
+                            called with mask_input=True and has done it (y > 0 there is the same mask).
+    The caller vouches for the topology; the result is the same gradient, bit for bit (the mask multiplies the same float once)."""
 
     @staticmethod
-    def forward(ctx, x, prep, weight, bias=None, residual=None, relu=False):
+    def forward(ctx, x, prep, weight, bias=None, residual=None, relu=False, mask_input=False):
         x = x.contiguous()
         res = None if residual is None else residual.contiguous()
         pad, dil = prep.padding, prep.dilation
-        key = ("f", prep.k, prep.cin, prep.cout, dil, tuple(x.shape), res is not None, bool(relu))
+        do_relu = bool(relu)
+        key = ("f", prep.k, prep.cin, prep.cout, dil, tuple(x.shape), res is not None, do_relu)
 
         def by_torch():                  # MIOpen's convolution + ONE element-wise pass (bias, skip connection, ReLU)
-            return bias_act_(F.conv2d(x, weight, None, 1, pad, dil), bias, res, relu)
+            return bias_act_(F.conv2d(x, weight, None, 1, pad, dil), bias, res, do_relu)
 
-        use = _Conv2dChoice.get(key, lambda: conv2d(x, prep, bias, res, relu), by_torch)
-        y = conv2d(x, prep, bias, res, relu) if use else by_torch()
-        ctx.prep, ctx.relu, ctx.has_res, ctx.xshape = prep, bool(relu), res is not None, tuple(x.shape)
-        ctx.save_for_backward(weight, y if relu else None)
+        use = _Conv2dChoice.get(key, lambda: conv2d(x, prep, bias, res, do_relu), by_torch)
+        y = conv2d(x, prep, bias, res, do_relu) if use else by_torch()
+        ctx.prep, ctx.has_res, ctx.xshape = prep, res is not None, tuple(x.shape)
+        ctx.mask_own = do_relu and relu != "consumer"          # mask the incoming gradient with y > 0 here
+        ctx.mask_input = bool(mask_input)
+        ctx.save_for_backward(weight, y if ctx.mask_own else None, x if mask_input else None)
         return y
 
     @staticmethod
     def backward(ctx, grad_y):
-        weight, y = ctx.saved_tensors
+        weight, y, x_in = ctx.saved_tensors
         prep = ctx.prep
         g = grad_y.contiguous()
-        if ctx.relu:
+        if ctx.mask_own:
             g = relu_backward(g, y)
-        key = ("b", prep.k, prep.cin, prep.cout, prep.dilation, ctx.xshape)
+        key = ("b", prep.k, prep.cin, prep.cout, prep.dilation, ctx.xshape, ctx.mask_input)
 
         def by_torch():
-            return torch.ops.aten.convolution_backward(g, _shape_only(ctx.xshape, g), weight, None,
-                                                       [1, 1], [prep.padding, prep.padding], [prep.dilation, prep.dilation], False, [0, 0], 1,
-                                                       [True, False, False])[0]
+            gx = torch.ops.aten.convolution_backward(g, _shape_only(ctx.xshape, g), weight, None, [1, 1], [prep.padding, prep.padding],
+                                                     [prep.dilation, prep.dilation], False, [0, 0], 1, [True, False, False])[0]
+            return relu_backward(gx, x_in) if ctx.mask_input else gx
 
-        use = _Conv2dChoice.get(key, lambda: conv2d_dgrad(g, prep), by_torch)
-        gx = conv2d_dgrad(g, prep) if use else by_torch()
-        return gx, None, None, None, (g if ctx.has_res else None), None
+        hip = lambda: conv2d_dgrad(g, prep, mask=x_in if ctx.mask_input else None)      # noqa: E731
+        use = _Conv2dChoice.get(key, hip, by_torch)
+        gx = hip() if use else by_torch()
+        return gx, None, None, None, (g if ctx.has_res else None), None, None
 
 
 _SHAPE_DUMMY = {}

@@ -284,7 +284,12 @@ class FoldedConv(nn.Module):
         self.flops = 0
         self._prep = None
 
-    def forward(self, x, relu=False, residual=None):
+    def chainable(self):
+        """on the ops.Conv2dAuto path (whose backward can take over the ReLU mask of its producer / leave its own to its consumer)?"""
+        return FoldedConv.impl == "auto" and self.stride == 1 and ((self.k == 1 and self.padding == 0) or (self.k == 3 and self.padding == 1)) and \
+            (FoldedConv.hip_kernels is None or self.k in FoldedConv.hip_kernels)
+
+    def forward(self, x, relu=False, residual=None, chain_in=False):
         ho = (x.shape[2] + 2 * self.padding - self.k) // self.stride + 1
         wo = (x.shape[3] + 2 * self.padding - self.k) // self.stride + 1
         self.flops += 2 * x.shape[0] * self.weight.shape[0] * self.weight.shape[1] * self.k * self.k * ho * wo
@@ -303,8 +308,10 @@ class FoldedConv(nn.Module):
                 if self._prep is None or self._prep.device != x.device:
                     self._prep = ops.Conv2dPrep(self.weight, self.stride, self.padding)
                 if FoldedConv.impl == "auto":      # per layer shape and direction, whichever of {libadvengine, MIOpen} measured faster
-                    return ops.Conv2dAuto.apply(x, self._prep, self.weight, self.bias, residual, relu)
+                    return ops.Conv2dAuto.apply(x, self._prep, self.weight, self.bias, residual, relu, chain_in)
+                assert not chain_in and relu != "consumer"
                 return ops.Conv2d.apply(x, self._prep, self.bias, residual, relu)
+        assert not chain_in and relu != "consumer", "chained ReLU masks need the Conv2dAuto path"
         y = F.conv2d(x, self.weight, self.bias, self.stride, self.padding)
         if residual is not None:
             y = y + residual
@@ -324,8 +331,14 @@ class _FoldedBottleneck(nn.Module):
 
     def forward(self, x):
         idt = x if self.down is None else self.down(x)
-        y = self.conv2(self.conv1(x, relu=True), relu=True)
-        return self.conv3(y, relu=True, residual=idt)
+        # conv1 -> conv2 -> conv3 is a chain (each output has one consumer): the ReLU masks of conv1 and conv2 are applied in the
+        # epilogue of their consumer's backward (ops.Conv2dAuto) instead of in passes of their own; conv3's output feeds the next block
+        # twice (its conv1 and its skip path) and keeps its own mask
+        c12 = x.is_cuda and self.conv1.chainable() and self.conv2.chainable() and x.shape[2] * x.shape[3] > 1
+        c23 = x.is_cuda and self.conv2.chainable() and self.conv3.chainable() and x.shape[2] * x.shape[3] > 1
+        y = self.conv1(x, relu="consumer" if c12 else True)
+        y = self.conv2(y, relu="consumer" if c23 else True, chain_in=c12)
+        return self.conv3(y, relu=True, residual=idt, chain_in=c23)
 
 
 class StereoRcnnR101(StereoRcnnShaped):

@@ -211,3 +211,39 @@ def test_r101_backbone_in_hip_graphs_gives_the_same_loss_and_gradient():
     loss_g, grad_g = net.loss_and_grad(x.clone(), extra)
     assert float(loss_g) == float(loss_e) or abs(float(loss_g) - float(loss_e)) <= 1e-5 * abs(float(loss_e))
     assert float((grad_g - grad_e).abs().max()) <= 1e-4 * float(grad_e.abs().max())
+
+
+def test_r101_step_on_libadvengine_convolutions_matches_miopen():
+    """FoldedConv.impl = "auto" (ops.Conv2dAuto: libadvengine's 1x1 / 3x3 kernels where they measure faster, the ReLU masks of each
+    bottleneck's conv1 / conv2 left to their consumer's dgrad epilogue) and "hip" (always libadvengine) against "miopen" (torch's
+    operators throughout): the same loss and image gradient within float32 summation-order differences"""
+    import types
+    from eval_driving_safety_amd import adapters, surrogates
+    dev = torch.device("cuda", 0)
+    model = surrogates.StereoRcnnR101(seed=5, rois_per_image=32, blocks=(2, 1, 2, 1)).to(dev).eval()
+    gen = torch.Generator().manual_seed(6)
+    x = (torch.randn((2, 3, 192, 352), generator=gen) * 40).to(dev)
+    left = torch.zeros((1, 30, 5), device=dev)
+    left[:, 0] = torch.tensor([100.0, 50.0, 240.0, 140.0, 1.0], device=dev)
+    right = left.clone()
+    right[:, 0, 0] -= 10
+    right[:, 0, 2] -= 10
+    kp = torch.zeros((1, 30, 6), device=dev)
+    kp[:, 0] = torch.tensor([150.0, 1, 0, 110, 230, 0], device=dev)
+    extra = types.SimpleNamespace(im_info=torch.tensor([[192.0, 352.0, 1.0]], device=dev), gt_boxes_left=left, gt_boxes_right=right,
+                                  gt_boxes_merge=left.clone(), gt_dim_orien=torch.zeros((1, 30, 5), device=dev), gt_kpts=kp,
+                                  num_boxes=torch.tensor([1], device=dev))
+    net = adapters.StereoRcnnAdapter(model, torch.zeros(6, device=dev))
+    out = {}
+    try:
+        for impl in ("miopen", "hip", "auto"):
+            surrogates.FoldedConv.impl = impl
+            net.loss_and_grad(x.clone(), extra)
+            out[impl] = net.loss_and_grad(x.clone(), extra)
+    finally:
+        surrogates.FoldedConv.impl = "miopen"
+    ref_loss, ref_grad = out["miopen"]
+    for impl in ("hip", "auto"):
+        loss, grad = out[impl]
+        assert abs(float(loss) - float(ref_loss)) <= 2e-4 * abs(float(ref_loss)), impl
+        assert float((grad - ref_grad).abs().max()) <= 2e-3 * float(ref_grad.abs().max()), impl
