@@ -487,7 +487,7 @@ int adv_conv2d_3x3_prep_weights_f32(const float* w, float* w_prep, int cout, int
 
 int adv_conv2d_3x3_f32(const float* x, const float* w_prep, const float* bias, const float* residual, const float* mask, float* y, int b, int cin,
                        int cout, int h, int w, int dilation, int relu, int tile, adv_stream_t stream) {
-  if (!x || !w_prep || !y || b < 1 || cin < 1 || cout < 1 || h < 1 || w < 1 || (dilation != 1 && dilation != 2) || tile < -1 || tile > 1)
+  if (!x || !w_prep || !y || b < 1 || cin < 1 || cout < 1 || h < 1 || w < 1 || (dilation != 1 && dilation != 2) || tile < -1 || tile > 2)
     return ADV_EINVAL;
   if (residual == y || mask == y || x == y) return ADV_EINVAL;
   if ((reinterpret_cast<uintptr_t>(x) & 3) || (reinterpret_cast<uintptr_t>(y) & 3) || (reinterpret_cast<uintptr_t>(w_prep) & 15) ||
@@ -499,7 +499,19 @@ int adv_conv2d_3x3_f32(const float* x, const float* w_prep, const float* bias, c
   hipStream_t st = static_cast<hipStream_t>(stream);
   // tile 0: 8 rows x 32 columns x 64 channels (two rows and two channel blocks per wave); tile 1: 16 rows x 32 columns x 32 channels
   // (four rows of one channel block per wave) - for layers of 32 output channels or fewer, where tile 0 would compute a zero block
-  const int t = tile >= 0 ? tile : (cout <= 32 ? 1 : 0);
+  // tile 2: 4 rows x 32 columns x 64 channels (one row, two channel blocks per wave) - twice the workgroups of tile 0 for maps that
+  // would leave compute units with one workgroup or none (64 channels at 96 x 312: 240 tiles of 8 rows for 256 CUs; a single
+  // workgroup per CU has one wave per SIMD and nothing to overlap its LDS reads and barriers with)
+  int t = tile;
+  if (t < 0) {
+    t = cout <= 32 ? 1 : 0;
+    const long long n0 = static_cast<long long>((w + 31) / 32) * ((h + 7) / 8) * ((cout + 63) / 64) * b;
+    if (t == 0 && n0 <= cu_count()) t = 2;       // (at 480 tiles the 8-row tile is still the faster one: measured on 128->128 at 96 x 312)
+  }
+  if (t == 2) {
+    if (dilation == 1) return launch_3x3<1, 2, 1>(x, w_prep, y, b, cin, cout, cinpad, copad, h, w, epi, st);
+    return launch_3x3<1, 2, 2>(x, w_prep, y, b, cin, cout, cinpad, copad, h, w, epi, st);
+  }
   if (t == 0) {
     if (dilation == 1) return launch_3x3<2, 2, 1>(x, w_prep, y, b, cin, cout, cinpad, copad, h, w, epi, st);
     return launch_3x3<2, 2, 2>(x, w_prep, y, b, cin, cout, cinpad, copad, h, w, epi, st);

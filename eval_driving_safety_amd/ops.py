@@ -932,7 +932,7 @@ def _conv2d_call(x, prep, w_prep, cin, cout, bias, residual, relu, mask, tile):
                       h * w, int(bool(relu)), int(tile), _stream(xi))
         else:
             _lib.call("adv_conv2d_3x3_f32", _ptr(xi), _ptr(w_prep), bp, _like(residual, y, "residual"), _like(mask, y, "mask"), _ptr(y), b, cin, cout,
-                      h, w, prep.dilation, int(bool(relu)), int(min(tile, 1)), _stream(xi))
+                      h, w, prep.dilation, int(bool(relu)), int(min(tile, 2)), _stream(xi))
     return y
 
 

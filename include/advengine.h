@@ -441,7 +441,8 @@ ADV_API int adv_conv2d_1x1_f32(const float* x, const float* w_prep, const float*
  *     staged in LDS; accumulation order (stage of 8 channels, tap ascending, channel ascending), one fmaf per product.
  *     w_prep from adv_conv2d_3x3_prep_weights_f32 ([9][cin'][cout'], zero padded to multiples of 8 x 64); transpose = 1 prepares the
  *     flipped W^T: the same entry point then computes the backward w.r.t. the input (x = grad_out, cin <-> cout swapped).
- *     bias / residual / relu / mask: as adv_conv2d_1x1_f32.  tile: -1 = by cout, 0 = 8x32x64, 1 = 16x32x32 (same result). */
+ *     bias / residual / relu / mask: as adv_conv2d_1x1_f32.  tile: -1 = by cout and map size, 0 = 8x32x64, 1 = 16x32x32, 2 = 4x32x64 (rows x columns x channels per
+ *     workgroup; same result). */
 ADV_API int64_t adv_conv2d_3x3_prep_floats(int cout, int cin, int transpose);
 ADV_API int adv_conv2d_3x3_prep_weights_f32(const float* w, float* w_prep, int cout, int cin, int transpose, adv_stream_t stream);
 ADV_API int adv_conv2d_3x3_f32(const float* x, const float* w_prep, const float* bias, const float* residual, const float* mask,

@@ -144,7 +144,7 @@ def test_hip_conv2d_3x3_bit_exact_vs_oracle_both_tiles(shape):
     prep = ops.Conv2dPrep(tw, 1, dil, dil)
     want_plain = C.conv2d(x, wt, padding=dil, dilation=dil, chunk=8)
     want_full = C.conv2d(x, wt, bias, res, mask, padding=dil, dilation=dil, relu=True, chunk=8)
-    for tile in (-1, 0, 1):
+    for tile in (-1, 0, 1, 2):
         assert ops.conv2d(tx, prep, tile=tile).cpu().numpy().tobytes() == want_plain.tobytes(), ("plain", tile)
         assert ops.conv2d(tx, prep, tb, tr, True, tm, tile=tile).cpu().numpy().tobytes() == want_full.tobytes(), ("bias + residual + relu + mask", tile)
     ref = F.conv2d(tx, tw, tb, 1, dil, dil)
@@ -155,7 +155,7 @@ def test_hip_conv2d_3x3_bit_exact_vs_oracle_both_tiles(shape):
     tg, tgr = torch.tensor(g, device=dev), torch.tensor(gres, device=dev)
     assert ops.conv2d_dgrad(tg, prep).cpu().numpy().tobytes() == C.conv2d(g, wt, padding=dil, dilation=dil, transpose=True, chunk=8).tobytes()
     want_b = C.conv2d(g, wt, residual=gres, mask=x, padding=dil, dilation=dil, transpose=True, chunk=8)
-    for tile in (0, 1):
+    for tile in (0, 1, 2):
         assert ops.conv2d_dgrad(tg, prep, residual=tgr, mask=tx, tile=tile).cpu().numpy().tobytes() == want_b.tobytes(), tile
     refg = torch.nn.grad.conv2d_input(x.shape, tw, tg, padding=dil, dilation=dil)
     assert float((ops.conv2d_dgrad(tg, prep) - refg).abs().max()) <= 1e-4 * max(1.0, float(refg.abs().max()))
