@@ -732,9 +732,13 @@ class DsgnShapedAdapter(PsvStereoAdapter):
             y = y + residual
         return F.relu(y) if relu else y
 
-    def _c3(self, x, name, relu=False, residual=None):
+    def _c3(self, x, name, relu=False, residual=None, chain_in=False):
+        """``relu="consumer"`` / ``chain_in``: as _c2 - a ReLU layer whose only consumer is a stride-1 layer leaves its backward mask to that
+        consumer's dgrad epilogue (ops.Conv3dK3 mask_input); only on the libadvengine path"""
         e, ops = self.w3[name], self.ops
         kind, w, b, cout = e["kind"], e["w"], e["b"], e["cout"]
+        if not self.mfma_conv:
+            assert not chain_in and relu != "consumer"
         if kind == "t2":
             self.flops_fwd += 2 * x.numel() * cout * 27
         if self.mfma_conv:
@@ -743,7 +747,7 @@ class DsgnShapedAdapter(PsvStereoAdapter):
                     y = ops.Conv3dK3.apply(x, e["p"], e["pt"], cout)
                     y = y + b.view(1, -1, 1, 1, 1)
                 else:
-                    y = ops.Conv3dK3.apply(x, e["p"], e["pt"], cout, None, b, relu, residual)
+                    y = ops.Conv3dK3.apply(x, e["p"], e["pt"], cout, None, b, relu, residual, chain_in)
             elif kind == "s2":
                 y = ops.Conv3dK3S2.apply(x, e["p"], e["pt"], cout, b, relu)
             else:
@@ -791,10 +795,11 @@ class DsgnShapedAdapter(PsvStereoAdapter):
         return self._c2(self._c2(cat, "last_a", True), "last_b")
 
     def _volume_net_impl(self, cost):
-        c0 = self._c3(self._c3(cost, "dres0a", True), "dres0b", True)
-        c0 = self._c3(self._c3(c0, "dres1a", True), "dres1b", False, c0)
-        pre = self._c3(self._c3(c0, "hg1", True), "hg2", True)
-        h = self._c3(self._c3(pre, "hg3", True), "hg4", True)
+        ch = self.mfma_conv                 # chains: a ReLU output with ONE consumer, and that consumer a stride-1 layer on the main kernel
+        c0 = self._c3(self._c3(cost, "dres0a", "consumer" if ch else True), "dres0b", True, chain_in=ch)
+        c0 = self._c3(self._c3(c0, "dres1a", "consumer" if ch else True), "dres1b", False, c0, chain_in=ch)
+        pre = self._c3(self._c3(c0, "hg1", "consumer" if ch else True), "hg2", True, chain_in=ch)
+        h = self._c3(self._c3(pre, "hg3", "consumer" if ch else True), "hg4", True, chain_in=ch)
         post = self._c3(h, "hg5", True, pre)
         out = self._c3(post, "hg6", False, c0)
         score = self._c3(self._c3(out, "cls_a", True), "cls_b")
@@ -810,9 +815,10 @@ class DsgnShapedAdapter(PsvStereoAdapter):
         else:
             grid, plan = self._gv(b)
             gv = ops.GridSample3d.apply(vol, grid, plan)                                                  # [B,32,Zg,Yg,Xg]
+        ch = self.mfma_conv
         g1 = self._c3(gv, "gv1", True)
-        pre = self._c3(self._c3(g1, "gh1", True), "gh2", True)
-        h = self._c3(self._c3(pre, "gh3", True), "gh4", True)
+        pre = self._c3(self._c3(g1, "gh1", "consumer" if ch else True), "gh2", True, chain_in=ch)
+        h = self._c3(self._c3(pre, "gh3", "consumer" if ch else True), "gh4", True, chain_in=ch)
         post = self._c3(h, "gh5", True, pre)
         g = self._c3(post, "gh6", True, g1)
         bb, c, zg, yg, xg = g.shape

@@ -44,6 +44,10 @@ struct Epi {
   int cls_off[8][3];
   // added to every result after the bias and before the ReLU: a tensor laid out like y (an hourglass's skip connection); may be y itself
   const float* residual;
+  // <round 3> a tensor laid out like y, or null: the result is zeroed where mask <= 0, last of all (main stride-1 kernel only).  A backward
+  // call with mask = the layer's own input (a ReLU output with this layer as its only consumer) returns the gradient w.r.t. the
+  // producer's PRE-activation - no relu_backward pass over the volume.
+  const float* mask;
 };
 
 constexpr unsigned kAllTaps = (1u << 27) - 1u;
@@ -562,8 +566,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma(const float* __restrict
     const int gw = cp.w0 + l32, zw = gw * epi.sw + fw;
     const long long ovol = static_cast<long long>(epi.od) * epi.oh * epi.ow;
     float* yb = y + (static_cast<long long>(cp.b) * Cout + co0) * ovol;
-    const bool has_res = epi.residual != nullptr;
+    const bool has_res = epi.residual != nullptr, has_mask = epi.mask != nullptr;
     const float* rb = epi.residual + (static_cast<long long>(cp.b) * Cout + co0) * ovol;
+    const float* mb = epi.mask + (static_cast<long long>(cp.b) * Cout + co0) * ovol;
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int row = wave * NB + i;
@@ -585,7 +590,22 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma(const float* __restrict
             if (has_bias) r = r + bz[v];
             r = r + sk[v];
             if (epi.relu) r = r > 0.0f ? r : 0.0f;
+            if (has_mask) r = mb[at + (8 * (v >> 2) + (v & 3)) * ovol] > 0.0f ? r : 0.0f;
             yr[(8 * (v >> 2) + (v & 3)) * ovol] = r;
+          }
+          continue;
+        }
+        if (has_mask) {                // the layer's own input as a ReLU mask: its 16 values first, then the stores
+          const float* mr = mb + at;
+          float mk[16];
+#pragma unroll
+          for (int v = 0; v < 16; ++v) mk[v] = __builtin_nontemporal_load(mr + (8 * (v >> 2) + (v & 3)) * ovol);
+#pragma unroll
+          for (int v = 0; v < 16; ++v) {
+            float r = acc[i][v];
+            if (has_bias) r = r + bz[v];
+            if (epi.relu) r = r > 0.0f ? r : 0.0f;
+            yr[(8 * (v >> 2) + (v & 3)) * ovol] = mk[v] > 0.0f ? r : 0.0f;
           }
           continue;
         }
@@ -604,6 +624,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma(const float* __restrict
           if (has_bias) r = r + bz[v];
           if (has_res && co0 + cr < Cout) r = r + rb[at + cr * ovol];
           if (epi.relu) r = r > 0.0f ? r : 0.0f;
+          if (has_mask && co0 + cr < Cout) r = mb[at + cr * ovol] > 0.0f ? r : 0.0f;
           if (co0 + cr < Cout) yr[cr * ovol] = r;
         }
       }
@@ -1222,6 +1243,11 @@ static int launch_conv(const float* x, const float* w_prep, float* y, int b, int
   // w >= 4, cin*d*h*w and 27*cin*cout_pad below 2^31 - anything else takes the scalar-staging kernel
   const bool fits = w >= 4 && static_cast<long long>(cin) * d * h * w < (1LL << 31) && 27LL * cin * cblocks * 32 < (1LL << 31);
   const bool narrow_ok = !adv_hook("ADV_CONV_NO_NARROW");  // test hook: the padded matrix kernel instead
+  if (epi.mask != nullptr) {   // only the main stride-1 matrix kernel has the mask epilogue: refuse every other route
+    const bool main_route = stride == 1 && fits && cin >= kCK && !(plain && cout <= 8 && narrow_ok) && (reinterpret_cast<uintptr_t>(w_prep) & 15) == 0 &&
+                            (reinterpret_cast<uintptr_t>(x) & 3) == 0 && !adv_hook("ADV_CONV_GENERIC");
+    if (!main_route) return ADV_EINVAL;
+  }
   if (cin < kCK) {  // 1..3 input channels (the adjoint of a layer with 1..3 outputs): vector-ALU kernel, HBM-bound on the result
     if (!plain) return ADV_EINVAL;
     const long long voxels = static_cast<long long>(d) * h * w;
@@ -1359,6 +1385,16 @@ int adv_conv3d_k3_f32(const float* x, const float* w_prep, float* y, int b, int 
   if (!x || !w_prep || !y || b < 1 || cin < 1 || cout < 1 || d < 1 || h < 1 || w < 1) return ADV_EINVAL;
   if (cin % kCK != 0 && cin > kCK) return ADV_EINVAL;
   const Epi epi{nullptr, relu, kAllTaps, {0, 0, 0, 0, 0, 0, 0, 0}, 0, d, h, w, 1, 1, 1, 0, 0, 0};
+  return launch_conv(x, w_prep, y, b, cin, cout, d, h, w, 1, epi, static_cast<hipStream_t>(stream));
+}
+
+int adv_conv3d_k3_masked_f32(const float* x, const float* w_prep, const float* mask, float* y, int b, int cin, int cout, int d, int h, int w,
+                             adv_stream_t stream) {
+  if (!x || !w_prep || !mask || !y || mask == y || b < 1 || cin < 1 || cout < 1 || d < 1 || h < 1 || w < 1) return ADV_EINVAL;
+  if (cin % kCK != 0) return ADV_EINVAL;
+  if (reinterpret_cast<uintptr_t>(mask) & 3) return ADV_EALIGN;
+  Epi epi{nullptr, 0, kAllTaps, {0, 0, 0, 0, 0, 0, 0, 0}, 0, d, h, w, 1, 1, 1, 0, 0, 0};
+  epi.mask = mask;
   return launch_conv(x, w_prep, y, b, cin, cout, d, h, w, 1, epi, static_cast<hipStream_t>(stream));
 }
 

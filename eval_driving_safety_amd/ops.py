@@ -677,6 +677,24 @@ def conv3d_k3(x, w_prep, cout, relu=False, bias=None, residual=None):
     return y
 
 
+def conv3d_k3_masked(x, w_prep, cout, mask):
+    """conv3d(x, w_prep) zeroed where ``mask`` <= 0 - the backward of a layer whose input (``mask``) is a ReLU output it alone consumes;
+    returns None when the shape is not one the main matrix kernel takes (the caller then masks with relu_backward)"""
+    xi, wp, mk = _feat(x, "x"), _feat(w_prep, "w_prep"), _feat(mask, "mask")
+    b, cin, d, h, w = xi.shape
+    if tuple(mk.shape) != (b, cout, d, h, w):
+        raise ValueError("mask must be [B,cout,D,H,W]")
+    if cin % 4 or cout <= 8:
+        return None
+    y = torch.empty((b, cout, d, h, w), dtype=torch.float32, device=xi.device)
+    with _on(xi):
+        rc = _lib.load().adv_conv3d_k3_masked_f32(_ptr(xi), _ptr(wp), _ptr(mk), _ptr(y), b, cin, cout, d, h, w, _stream(xi))
+    if rc == _lib.ADV_EINVAL:
+        return None
+    _lib.check("adv_conv3d_k3_masked_f32", rc)
+    return y
+
+
 def space_to_depth2(x, out=None):
     """[B,C,D,H,W] -> [B,8C,ceil(D/2),ceil(H/2),ceil(W/2)]: the eight parity sub-volumes side by side in the channel dimension"""
     xi = _feat(x, "x")
@@ -810,22 +828,36 @@ class Conv3dK3(torch.autograd.Function):
     connection, [B,cout,D,H,W]) is added in the same epilogue and receives that gradient unchanged."""
 
     @staticmethod
-    def forward(ctx, x, w_prep, w_prep_t, cout, weight=None, bias=None, relu=False, residual=None):
-        ctx.has_t, ctx.relu, ctx.has_res = w_prep_t is not None, bool(relu), residual is not None
+    def forward(ctx, x, w_prep, w_prep_t, cout, weight=None, bias=None, relu=False, residual=None, mask_input=False):
+        """<round 3> chains, as ops.Conv2dAuto: ``mask_input`` - x is a ReLU output this layer alone consumes, the gradient returned for it
+        is already masked with x > 0 (in the dgrad kernel's epilogue); ``relu="consumer"`` - this layer's ReLU mask is applied by its only
+        consumer's backward, not here."""
+        x = x.contiguous()
+        ctx.has_t, ctx.has_res = w_prep_t is not None, residual is not None
+        ctx.mask_own, ctx.mask_input = bool(relu) and relu != "consumer", bool(mask_input)
         ctx.xshape = tuple(x.shape)
-        y = conv3d_k3(x.contiguous(), w_prep, cout, relu=relu, bias=bias, residual=None if residual is None else residual.contiguous())
-        ctx.save_for_backward(w_prep_t if ctx.has_t else weight, y if relu else None)
+        y = conv3d_k3(x, w_prep, cout, relu=bool(relu), bias=bias, residual=None if residual is None else residual.contiguous())
+        ctx.save_for_backward(w_prep_t if ctx.has_t else weight, y if ctx.mask_own else None, x if mask_input else None)
         return y
 
     @staticmethod
     def backward(ctx, grad_y):
-        w, y = ctx.saved_tensors
-        if ctx.relu:
+        w, y, x_in = ctx.saved_tensors
+        if ctx.mask_own:
             grad_y = relu_backward(grad_y, y)
         gres = grad_y if ctx.has_res else None      # the skip connection receives the (masked) gradient as it is
         if ctx.has_t:
-            return conv3d_k3(grad_y.contiguous(), w, ctx.xshape[1]), None, None, None, None, None, None, gres
-        return torch.nn.grad.conv3d_input(ctx.xshape, w, grad_y, padding=1), None, None, None, None, None, None, gres
+            g = grad_y.contiguous()
+            gx = conv3d_k3_masked(g, w, ctx.xshape[1], x_in) if ctx.mask_input else None
+            if gx is None:
+                gx = conv3d_k3(g, w, ctx.xshape[1])
+                if ctx.mask_input:
+                    gx = relu_backward(gx, x_in)
+        else:
+            gx = torch.nn.grad.conv3d_input(ctx.xshape, w, grad_y, padding=1)
+            if ctx.mask_input:
+                gx = relu_backward(gx, x_in)
+        return gx, None, None, None, None, None, None, gres, None
 
 
 class Conv3dK3S2(torch.autograd.Function):
@@ -834,9 +866,10 @@ class Conv3dK3S2(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w_prep, classes_t, cout, bias=None, relu=False):
-        ctx.classes_t, ctx.xshape, ctx.relu = classes_t, tuple(x.shape), bool(relu)
-        y = conv3d_k3_s2(x.contiguous(), w_prep, cout, relu=relu, bias=bias)
-        ctx.save_for_backward(y if relu else None)
+        ctx.classes_t, ctx.xshape = classes_t, tuple(x.shape)
+        ctx.relu = bool(relu) and relu != "consumer"        # "consumer": the only consumer's backward applies this layer's ReLU mask (Conv3dK3 mask_input)
+        y = conv3d_k3_s2(x.contiguous(), w_prep, cout, relu=bool(relu), bias=bias)
+        ctx.save_for_backward(y if ctx.relu else None)
         return y
 
     @staticmethod

@@ -313,6 +313,14 @@ ADV_API int adv_conv3d_k3_prep_weights_f32(const float* w, float* w_prep, int co
 ADV_API int adv_conv3d_k3_f32(const float* x, const float* w_prep, float* y, int b, int cin, int cout, int d, int h,
                               int w, int relu, adv_stream_t stream);
 
+/* y = conv3d(x, w_prep) zeroed where mask <= 0 (mask laid out like y, must not be y): the backward w.r.t. the input of a layer whose
+ *     input is a ReLU output with that layer as its ONLY consumer - call it with x = grad_out, w_prep = the transposed weights and
+ *     mask = the layer's input, and the result is the gradient w.r.t. the producer's pre-activation: no relu-backward pass over the
+ *     volume.  Main matrix kernel only: cin % 4 == 0, cout > 8, 16-byte aligned w_prep - anything else returns ADV_EINVAL (callers
+ *     then mask with adv_relu_backward_f32). */
+ADV_API int adv_conv3d_k3_masked_f32(const float* x, const float* w_prep, const float* mask, float* y, int b, int cin, int cout, int d,
+                                     int h, int w, adv_stream_t stream);
+
 /* The same kernel family with what a plane-sweep detector's 3D hourglass needs around the plain convolution:
  *     bias       DEVICE [cout] or NULL, added after the accumulation (a folded batch-norm shift; its scale goes into the weights)
  *     residual   DEVICE tensor laid out like y (same dims, read where the result is written) or NULL: added after the bias and

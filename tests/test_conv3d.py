@@ -426,3 +426,33 @@ def test_hip_direct_strided_kernel_bit_exact_vs_oracle(shape, route):
         assert ops.conv3d_k3_s2_stage_channels(tx, cout) == 4
         slow = ops.conv3d_k3_s2(tx, wp, cout, bias=tb, relu=True)
         assert slow.cpu().numpy().tobytes() == C.conv3d_k3_ex(x, wt, bias=bias, stride=2, relu=True, chunk=4).tobytes(), "scalar-staging strided kernel"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 8, 40, 6, 20, 40), (2, 32, 32, 5, 12, 36), (1, 12, 33, 3, 9, 38), (1, 64, 32, 4, 8, 76)])
+def test_hip_masked_dgrad_equals_conv_then_relu_backward(shape):
+    """adv_conv3d_k3_masked_f32: the backward w.r.t. the input with the ReLU mask of that input in the epilogue - bit-equal to the
+    unmasked kernel followed by relu_backward, on every staging route; and ops.Conv3dK3's chain flags give the same gradient as the
+    unchained formulation"""
+    from eval_driving_safety_amd import ops
+    b, cin, cout, d, h, w = shape
+    x, wt = _case(*shape, seed=sum(shape) + 9)
+    dev = torch.device("cuda", 0)
+    tx = torch.relu(torch.tensor(x, device=dev))                                   # a ReLU output: zeros and positives
+    tw = torch.tensor(wt, device=dev)
+    wp, wpt = ops.conv3d_k3_prep(tw), ops.conv3d_k3_prep(tw, transpose=True)
+    g = torch.tensor(np.random.RandomState(3).randn(b, cout, d, h, w).astype(np.float32), device=dev)
+    want = ops.relu_backward(ops.conv3d_k3(g, wpt, cin), tx)
+    got = ops.conv3d_k3_masked(g, wpt, cin, tx)
+    assert got is not None and torch.equal(got, want)
+    # chained pair of layers: y1 = relu(conv(x0)) consumed only by conv2
+    x0 = torch.tensor(np.random.RandomState(4).randn(b, cin, d, h, w).astype(np.float32), device=dev, requires_grad=True)
+    w1 = torch.tensor((np.random.RandomState(5).randn(cin, cin, 3, 3, 3) * 0.1).astype(np.float32), device=dev)
+    p1, p1t = ops.conv3d_k3_prep(w1), ops.conv3d_k3_prep(w1, transpose=True)
+    outs = []
+    for chained in (False, True):
+        y1 = ops.Conv3dK3.apply(x0, p1, p1t, cin, None, None, "consumer" if chained else True)
+        y2 = ops.Conv3dK3.apply(y1, wp, wpt, cout, None, None, False, None, chained)
+        (gx,) = torch.autograd.grad(y2, x0, g)
+        outs.append(gx)
+    assert torch.equal(outs[0], outs[1])
