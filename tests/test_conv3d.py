@@ -444,7 +444,10 @@ def test_hip_masked_dgrad_equals_conv_then_relu_backward(shape):
     g = torch.tensor(np.random.RandomState(3).randn(b, cout, d, h, w).astype(np.float32), device=dev)
     want = ops.relu_backward(ops.conv3d_k3(g, wpt, cin), tx)
     got = ops.conv3d_k3_masked(g, wpt, cin, tx)
-    assert got is not None and torch.equal(got, want)
+    if cin <= 8:      # the backward of a layer with 8 input channels or fewer runs on the narrow vector-ALU kernel, which has no mask epilogue
+        assert got is None
+    else:
+        assert got is not None and torch.equal(got, want)
     # chained pair of layers: y1 = relu(conv(x0)) consumed only by conv2
     x0 = torch.tensor(np.random.RandomState(4).randn(b, cin, d, h, w).astype(np.float32), device=dev, requires_grad=True)
     w1 = torch.tensor((np.random.RandomState(5).randn(cin, cin, 3, 3, 3) * 0.1).astype(np.float32), device=dev)
