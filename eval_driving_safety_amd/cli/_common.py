@@ -35,11 +35,16 @@ def add_detect_flags(parser):
 
 def add_engine_flags(parser):
     g = parser.add_argument_group("engine (not in the reference)")
-    g.add_argument("--model", default="upstream", choices=["upstream", "shaped", "toy"],
+    g.add_argument("--model", default="upstream", choices=["upstream", "layerlist", "shaped", "toy"],
                    help="'upstream' builds the detector from the user's DSGN / Stereo R-CNN checkout exactly as the reference "
-                        "script does; 'shaped' runs a detector-SHAPED network with random weights built on this package's kernels "
-                        "(plane-sweep volume + MFMA 3D hourglass for DSGN; FPN + stereo RPN + RoIAlign heads for Stereo R-CNN); "
-                        "'toy' runs the plumbing with a tiny fixed-seed stand-in")
+                        "script does; 'layerlist' runs a random-weight network with the upstream LAYER LIST on this package's kernels "
+                        "(DSGN: PSMNet-style extractor, plane-sweep volume, dres0/dres1 + 3D hourglass, 3D geometric volume stack, "
+                        "bird's-eye-view hourglass, head towers - adapters.DsgnShapedAdapter; Stereo R-CNN: ResNet-101-FPN, stereo RPN, "
+                        "RoIAlign heads - surrogates.StereoRcnnR101): what the end-to-end numbers of bench.py are measured on; "
+                        "'shaped' a much lighter network of the same structure; 'toy' runs the plumbing with a tiny fixed-seed stand-in")
+    g.add_argument("--graph", action="store_true",
+                   help="PGD scripts: capture one iteration (detector forward + backward + the fused step) in a hipGraph and replay it "
+                        "(detectors without data-dependent shapes: --model toy / shaped / layerlist of the DSGN scripts)")
     g.add_argument("--synthetic", type=int, default=0, metavar="N", help="attack N synthetic pairs instead of the dataset")
     g.add_argument("--out_root", default=".", help="where the *_pgd_iters_k / *_patch_ratio_r / result_* folders go")
     g.add_argument("--save_every", type=int, default=1, help="write every k-th iterate (reference: every one)")

@@ -180,6 +180,7 @@ def run_shaped(args, mode, dev):
     loader = data.SyntheticStereo(args.synthetic, "dsgn", batch, seed=args.seed) if args.synthetic \
         else data.KittiFolder(args.data_path, args.split_file, batch, workers=workers)
     det = DetectUnderAttack("dsgn", mode, label_dir, patch=patch, atk_mode=getattr(args, "atk_mode", "random"), seed=args.pos_seed, device=dev)
-    n = det.run(loader, adapters.PsvStereoAdapter(dev, seed=args.seed, hourglass=True, dsgn_head=True), debugnum=args.debugnum if args.debug else None)
+    net = adapters.DsgnShapedAdapter(dev, seed=args.seed) if args.model == "layerlist" else adapters.PsvStereoAdapter(dev, seed=args.seed, hourglass=True, dsgn_head=True)
+    n = det.run(loader, net, debugnum=args.debugnum if args.debug else None)
     print("wrote %d label files to %s" % (n, label_dir))
     return n, label_dir

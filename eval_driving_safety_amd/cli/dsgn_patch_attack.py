@@ -27,7 +27,7 @@ def main(argv=None):
     comm = Comm.from_env(device=dev)
     torch.manual_seed(args.seed)
     torch.cuda.manual_seed(args.seed)
-    if args.model in ("toy", "shaped"):
+    if args.model in ("toy", "shaped", "layerlist"):
         batch = args.btest if args.btest else 1
         workers = args.loader_workers if args.loader_workers is not None else (0 if args.debug else 12)
         base = (lambda: data.SyntheticStereo(args.synthetic, "dsgn", batch, seed=args.seed)) if args.synthetic \
@@ -35,7 +35,8 @@ def main(argv=None):
         if args.model == "toy":
             adapter, factory = adapters.ToyStereoAdapter(dev, seed=args.seed), base
         else:
-            adapter = adapters.PsvStereoAdapter(dev, seed=args.seed, hourglass=True, dsgn_head=True)
+            adapter = adapters.DsgnShapedAdapter(dev, seed=args.seed) if args.model == "layerlist" else \
+                adapters.PsvStereoAdapter(dev, seed=args.seed, hourglass=True, dsgn_head=True)
             factory = lambda: _common.WithExtra(base(), adapter.synthetic_extra)
     else:
         rt = _common.upstream_or_exit(lambda: upstream.DsgnRuntime(args, dev, attack=True))

@@ -26,7 +26,7 @@ def main(argv=None):
     comm = Comm.from_env(device=dev)
     torch.manual_seed(args.seed)                              # :86-87
     torch.cuda.manual_seed(args.seed)
-    if args.model in ("toy", "shaped"):
+    if args.model in ("toy", "shaped", "layerlist"):
         batch = args.btest if args.btest else 1
         workers = args.loader_workers if args.loader_workers is not None else (0 if args.debug else 12)
         loader = data.SyntheticStereo(args.synthetic, "dsgn", batch, seed=args.seed) if args.synthetic \
@@ -34,14 +34,15 @@ def main(argv=None):
         if args.model == "toy":
             adapter = adapters.ToyStereoAdapter(dev, seed=args.seed)
         else:   # plane-sweep volume (HIP) -> 3D hourglass on the float32 matrix cores -> depth loss; synthetic sparse depth
-            adapter = adapters.PsvStereoAdapter(dev, seed=args.seed, hourglass=True, dsgn_head=True)
+            adapter = adapters.DsgnShapedAdapter(dev, seed=args.seed) if args.model == "layerlist" else \
+                adapters.PsvStereoAdapter(dev, seed=args.seed, hourglass=True, dsgn_head=True)
             loader = _common.WithExtra(loader, adapter.synthetic_extra)
     else:
         rt = _common.upstream_or_exit(lambda: upstream.DsgnRuntime(args, dev, attack=True))
         adapter = adapters.DsgnAdapter(rt.model, rt.cfg, rt.RPN3DLoss)
         loader = upstream.dsgn_attack_loader(rt)
     atk = PgdAttack("dsgn", args.alpha, args.eps, args.iter, out_root=args.out_root, save_every=args.save_every, device=dev,
-                    reference_on_gpu=args.reference_on_gpu)
+                    reference_on_gpu=args.reference_on_gpu, graph=args.graph and args.model != "upstream")
     n = atk.run(loader, adapter, comm, debugnum=args.debugnum if args.debug else None)
     print("rank %d attacked %d stereo pairs" % (comm.rank, n))
     comm.close()

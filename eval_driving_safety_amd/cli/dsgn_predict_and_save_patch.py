@@ -26,7 +26,7 @@ def main(argv=None):
     dev, args.devices_resolved = _common.setup_device(args.devices)
     torch.manual_seed(args.seed)
     torch.cuda.manual_seed(args.seed)
-    if args.model == "shaped":
+    if args.model in ("shaped", "layerlist"):
         return _dsgn_detect.run_shaped(args, "patch", dev)
     rt = _common.upstream_or_exit(lambda: upstream.DsgnRuntime(args, dev, attack=False))
     if args.ratio or args.epochs:                                              # :96-97

@@ -23,7 +23,7 @@ def main(argv=None):
     dev, args.devices_resolved = _common.setup_device(args.devices)
     torch.manual_seed(args.seed)
     torch.cuda.manual_seed(args.seed)
-    if args.model == "shaped":
+    if args.model in ("shaped", "layerlist"):
         return _dsgn_detect.run_shaped(args, "pgd", dev)
     rt = _common.upstream_or_exit(lambda: upstream.DsgnRuntime(args, dev, attack=False))
     if args.alpha and args.iter:                                               # :92-93 (after the debug / _train tags)

@@ -25,7 +25,7 @@ def main(argv=None):
     args = build_parser().parse_args(argv)
     dev, _ = _common.setup_device(args.devices)
     comm = Comm.from_env(device=dev)
-    if args.model in ("toy", "shaped"):
+    if args.model in ("toy", "shaped", "layerlist"):
         if not args.synthetic:
             raise SystemExit("--model %s needs --synthetic N (the Stereo R-CNN roidb loader is upstream code)" % args.model)
         base = lambda: data.SyntheticStereo(args.synthetic, "srcnn", 1, seed=args.seed)
@@ -34,7 +34,12 @@ def main(argv=None):
         else:
             import torch
             from .. import surrogates
-            adapter = adapters.StereoRcnnAdapter(surrogates.StereoRcnnShaped(seed=args.seed).to(dev).eval(), torch.zeros(6, device=dev))
+            if args.model == "layerlist":   # ResNet-101-FPN layer list; 2D convolutions by libadvengine or MIOpen, whichever measures faster
+                surrogates.FoldedConv.impl = "auto"
+                net = surrogates.StereoRcnnR101(seed=args.seed)
+            else:
+                net = surrogates.StereoRcnnShaped(seed=args.seed)
+            adapter = adapters.StereoRcnnAdapter(net.to(dev).eval(), torch.zeros(6, device=dev))
             factory = lambda: _common.WithExtra(base(), lambda b: surrogates.synthetic_srcnn_extra(b, dev))
     else:
         rt = _common.upstream_or_exit(lambda: upstream.SrcnnRuntime(dev, training=True, workers=8))     # :128-129

@@ -26,7 +26,7 @@ def main(argv=None):
     dev, _ = _common.setup_device(args.devices)
     comm = Comm.from_env(device=dev)
     print("Start iteration: ", args.iter)                                   # :59
-    if args.model in ("toy", "shaped"):
+    if args.model in ("toy", "shaped", "layerlist"):
         if not args.synthetic:
             raise SystemExit("--model %s needs --synthetic N (the Stereo R-CNN roidb loader is upstream code)" % args.model)
         loader = data.SyntheticStereo(args.synthetic, "srcnn", 1, seed=args.seed)
@@ -35,7 +35,12 @@ def main(argv=None):
         else:   # FPN + stereo RPN + RoIAlign heads on this package's kernels, random weights, synthetic ground truth
             import torch
             from .. import surrogates
-            adapter = adapters.StereoRcnnAdapter(surrogates.StereoRcnnShaped(seed=args.seed).to(dev).eval(), torch.zeros(6, device=dev))
+            if args.model == "layerlist":   # ResNet-101-FPN layer list; 2D convolutions by libadvengine or MIOpen, whichever measures faster
+                surrogates.FoldedConv.impl = "auto"
+                net = surrogates.StereoRcnnR101(seed=args.seed)
+            else:
+                net = surrogates.StereoRcnnShaped(seed=args.seed)
+            adapter = adapters.StereoRcnnAdapter(net.to(dev).eval(), torch.zeros(6, device=dev))
             loader = _common.WithExtra(loader, lambda b: surrogates.synthetic_srcnn_extra(b, dev))
     else:
         rt = _common.upstream_or_exit(lambda: upstream.SrcnnRuntime(dev, training=True, workers=0))

@@ -250,3 +250,17 @@ def test_r101_step_on_libadvengine_convolutions_matches_miopen():
         assert float((grad - ref_grad).abs().max()) <= 2e-2 * scale, impl          # float32 through ~40 layers, different summation orders
         big = ref_grad.abs() > 2e-2 * scale                                        # what the PGD step consumes: the signs
         assert float((torch.sign(grad[big]) == torch.sign(ref_grad[big])).float().mean()) > 0.995, impl
+
+
+def test_cli_layerlist_models_and_graph_flag(tmp_path):
+    """`--model layerlist`: the attack CLIs on the random-weight networks with the upstream layer lists (what bench.py's end-to-end legs
+    measure) - DSGN with one PGD iteration captured in a hipGraph (`--graph`), Stereo R-CNN's ResNet-101-FPN eagerly"""
+    from PIL import Image
+    out = _run("dsgn_pgd_attack", ["--model", "layerlist", "--graph", "--synthetic", "1", "-btest", "1", "-d", "0", "--iter", "2", "--eps", "0.03"], str(tmp_path))
+    assert "rank 0 attacked 1 stereo pairs" in out
+    a = np.array(Image.open(str(tmp_path / "dsgn_pgd_iters_0" / "image_2" / "000000.png")))
+    b = np.array(Image.open(str(tmp_path / "dsgn_pgd_iters_2" / "image_2" / "000000.png")))
+    assert a.shape == (375, 1242, 3) and 1 <= np.abs(a.astype(int) - b.astype(int)).max() <= 3
+    out = _run("srcnn_pgd_attack", ["--model", "layerlist", "--synthetic", "1", "-d", "0", "--iter", "1", "--eps", "0.03"], str(tmp_path))
+    assert "rank 0 attacked 1 stereo pairs" in out
+    assert np.array(Image.open(str(tmp_path / "stereo_rcnn_pgd_iters_1" / "image_3" / "000000.png"))).shape == (600, 1987, 3)
