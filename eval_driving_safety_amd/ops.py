@@ -1035,14 +1035,17 @@ class _Conv2dChoice:
 
     @staticmethod
     def _time(fn):
-        fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(3):
-            fn()
-        e1.record()
-        e1.synchronize()
-        return e0.elapsed_time(e1)
+        fn()                                     # solver search / first-touch outside the timed calls
+        best = float("inf")
+        for _ in range(2):                       # the better of two groups of three: one noisy group must not decide a layer for the whole run
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                fn()
+            e1.record()
+            e1.synchronize()
+            best = min(best, e0.elapsed_time(e1))
+        return best
 
     @classmethod
     def get(cls, key, hip_fn, torch_fn):
