@@ -928,10 +928,22 @@ class Conv2dPrep:
             raise ValueError("only 1x1 / padding 0 and 3x3 / padding = dilation in (1, 2) layers have a kernel here")
         self.device = wt.device
         self.fwd, self.bwd = self._prep(wt, False), self._prep(wt, True)
+        self.has_wino = self.k == 3 and self.dilation == 1      # Winograd F(2x2,3x3) route (csrc/wino2d.hip): prepared on first use
+        self._wt, self._wino = (wt if self.has_wino else None), {}
 
-    def _prep(self, wt, transpose):
+    def wino(self, transpose):
+        """the layer's transformed weights G g G^T for adv_conv2d_wino_f32 (forward / backward w.r.t. the input), made once"""
+        if not self.has_wino:
+            raise ValueError("the Winograd route needs a 3x3 / dilation 1 layer")
+        t = self._wino.get(bool(transpose))
+        if t is None:
+            t = self._wino[bool(transpose)] = self._prep(self._wt, transpose, "wino")
+        return t
+
+    def _prep(self, wt, transpose, kind=None):
         floats, prep = {1: ("adv_conv2d_1x1_prep_floats", "adv_conv2d_1x1_prep_weights_f32"),
-                        3: ("adv_conv2d_3x3_prep_floats", "adv_conv2d_3x3_prep_weights_f32")}[self.k]
+                        3: ("adv_conv2d_3x3_prep_floats", "adv_conv2d_3x3_prep_weights_f32"),
+                        "wino": ("adv_conv2d_wino_prep_floats", "adv_conv2d_wino_prep_weights_f32")}[kind or self.k]
         n = int(getattr(_lib.load(), floats)(self.cout, self.cin, int(transpose)))
         out = torch.empty((n,), dtype=torch.float32, device=wt.device)
         with _on(wt):
@@ -948,7 +960,7 @@ def _like(t, out, name):
     return _ptr(t)
 
 
-def _conv2d_call(x, prep, w_prep, cin, cout, bias, residual, relu, mask, tile):
+def _conv2d_call(x, prep, w_prep, cin, cout, bias, residual, relu, mask, tile, wino=False):
     xi = _feat(x, "x")
     if xi.dim() != 4 or xi.shape[1] != cin:
         raise ValueError("x must be [B,%d,H,W]" % cin)
@@ -960,7 +972,10 @@ def _conv2d_call(x, prep, w_prep, cin, cout, bias, residual, relu, mask, tile):
             raise ValueError("bias must be [cout]")
     bp = None if bias is None else _ptr(bias)
     with _on(xi):
-        if prep.k == 1:
+        if wino:
+            _lib.call("adv_conv2d_wino_f32", _ptr(xi), _ptr(w_prep), bp, _like(residual, y, "residual"), _like(mask, y, "mask"), _ptr(y), b, cin,
+                      cout, h, w, int(bool(relu)), _stream(xi))
+        elif prep.k == 1:
             _lib.call("adv_conv2d_1x1_f32", _ptr(xi), _ptr(w_prep), bp, _like(residual, y, "residual"), _like(mask, y, "mask"), _ptr(y), b, cin, cout,
                       h * w, int(bool(relu)), int(tile), _stream(xi))
         else:
@@ -969,15 +984,21 @@ def _conv2d_call(x, prep, w_prep, cin, cout, bias, residual, relu, mask, tile):
     return y
 
 
-def conv2d(x, prep, bias=None, residual=None, relu=False, mask=None, tile=-1):
-    """conv2d(x [B,Cin,H,W], prep) (+ bias [Cout]) (+ residual [B,Cout,H,W]) (ReLU) (zeroed where mask <= 0) -> [B,Cout,H,W]"""
+def conv2d(x, prep, bias=None, residual=None, relu=False, mask=None, tile=-1, wino=False):
+    """conv2d(x [B,Cin,H,W], prep) (+ bias [Cout]) (+ residual [B,Cout,H,W]) (ReLU) (zeroed where mask <= 0) -> [B,Cout,H,W].
+    wino=True (3x3 / dilation 1 layers): the Winograd F(2x2,3x3) kernel - 2.25x fewer multiply-adds, its own order of float operations
+    (oracle: conv2d_wino)"""
+    if wino:
+        return _conv2d_call(x, prep, prep.wino(False), prep.cin, prep.cout, bias, residual, relu, mask, tile, True)
     return _conv2d_call(x, prep, prep.fwd, prep.cin, prep.cout, bias, residual, relu, mask, tile)
 
 
-def conv2d_dgrad(grad, prep, hw=None, residual=None, mask=None, tile=-1):
+def conv2d_dgrad(grad, prep, hw=None, residual=None, mask=None, tile=-1, wino=False):
     """the backward w.r.t. the input of the same layer: grad [B,Cout,H,W] -> [B,Cin,H,W] (+ residual: a gradient arriving over a
     skip path) (zeroed where mask <= 0: with mask = the layer's own input, a ReLU output, this is the gradient w.r.t. the previous
     layer's pre-activation)"""
+    if wino:
+        return _conv2d_call(grad, prep, prep.wino(True), prep.cout, prep.cin, None, residual, False, mask, tile, True)
     return _conv2d_call(grad, prep, prep.bwd, prep.cout, prep.cin, None, residual, False, mask, tile)
 
 
@@ -1032,6 +1053,7 @@ class _Conv2dChoice:
     bytes as the convolution moves; MIOpen's Winograd wins on small maps at one pair per step (profiles/r03_conv2d_layers_ab.jsonl)."""
     cache = {}
     enabled = True
+    wino = True          # consider the Winograd route
 
     @staticmethod
     def _time(fn):
@@ -1048,12 +1070,16 @@ class _Conv2dChoice:
         return best
 
     @classmethod
-    def get(cls, key, hip_fn, torch_fn):
+    def get(cls, key, hip_fn, torch_fn, wino_fn=None):
+        """-> "hip" (direct implicit GEMM), "wino" (Winograd on the matrix cores, 3x3 layers) or "" (torch / MIOpen)"""
         c = cls.cache.get(key)
         if c is None:
             if torch.cuda.is_current_stream_capturing():
-                return True                      # cannot time inside a capture: this package's kernel
-            c = cls._time(hip_fn) <= cls._time(torch_fn)
+                return "hip"                     # cannot time inside a capture: this package's kernel
+            t = {"hip": cls._time(hip_fn), "": cls._time(torch_fn)}
+            if wino_fn is not None and cls.wino:
+                t["wino"] = cls._time(wino_fn)
+            c = min(t, key=t.get)
             cls.cache[key] = c
         return c
 
@@ -1082,8 +1108,9 @@ class Conv2dAuto(torch.autograd.Function):
         def by_torch():                  # MIOpen's convolution + ONE element-wise pass (bias, skip connection, ReLU)
             return bias_act_(F.conv2d(x, weight, None, 1, pad, dil), bias, res, do_relu)
 
-        use = _Conv2dChoice.get(key, lambda: conv2d(x, prep, bias, res, do_relu), by_torch)
-        y = conv2d(x, prep, bias, res, do_relu) if use else by_torch()
+        use = _Conv2dChoice.get(key, lambda: conv2d(x, prep, bias, res, do_relu), by_torch,
+                                (lambda: conv2d(x, prep, bias, res, do_relu, wino=True)) if prep.has_wino else None)
+        y = conv2d(x, prep, bias, res, do_relu, wino=(use == "wino")) if use else by_torch()
         ctx.prep, ctx.has_res, ctx.xshape = prep, res is not None, tuple(x.shape)
         ctx.mask_own = do_relu and relu != "consumer"          # mask the incoming gradient with y > 0 here
         ctx.mask_input = bool(mask_input)
@@ -1104,9 +1131,9 @@ class Conv2dAuto(torch.autograd.Function):
                                                      [prep.dilation, prep.dilation], False, [0, 0], 1, [True, False, False])[0]
             return relu_backward(gx, x_in) if ctx.mask_input else gx
 
-        hip = lambda: conv2d_dgrad(g, prep, mask=x_in if ctx.mask_input else None)      # noqa: E731
-        use = _Conv2dChoice.get(key, hip, by_torch)
-        gx = hip() if use else by_torch()
+        hip = lambda wino=False: conv2d_dgrad(g, prep, mask=x_in if ctx.mask_input else None, wino=wino)      # noqa: E731
+        use = _Conv2dChoice.get(key, hip, by_torch, (lambda: hip(True)) if prep.has_wino else None)
+        gx = hip(use == "wino") if use else by_torch()
         return gx, None, None, None, (g if ctx.has_res else None), None, None
 
 

@@ -456,6 +456,17 @@ ADV_API int adv_conv2d_3x3_prep_weights_f32(const float* w, float* w_prep, int c
 ADV_API int adv_conv2d_3x3_f32(const float* x, const float* w_prep, const float* bias, const float* residual, const float* mask,
                                float* y, int b, int cin, int cout, int h, int w, int dilation, int relu, int tile, adv_stream_t stream);
 
+/* The same 3x3 / stride 1 / padding 1 convolution by Winograd F(2x2, 3x3): 2.25x fewer multiply-adds; input transform, the sixteen
+ *     element-wise products (v_mfma_f32_16x16x4_f32, a workgroup owns 8 rows x 32 columns x 64 channels) and output transform in ONE
+ *     kernel.  A different order of float operations than adv_conv2d_3x3_f32 (results agree to float32 rounding, ~1e-6 relative; the
+ *     oracle's orc_conv2d_wino restates this order bit for bit): the caller chooses the route explicitly.
+ *     w_prep from adv_conv2d_wino_prep_weights_f32 ([16][cin'][cout'] = G g G^T per channel pair, zero padded to multiples of 8 x 64);
+ *     transpose = 1: the backward w.r.t. the input.  bias / residual / relu / mask: as adv_conv2d_1x1_f32. */
+ADV_API int64_t adv_conv2d_wino_prep_floats(int cout, int cin, int transpose);
+ADV_API int adv_conv2d_wino_prep_weights_f32(const float* w, float* w_prep, int cout, int cin, int transpose, adv_stream_t stream);
+ADV_API int adv_conv2d_wino_f32(const float* x, const float* w_prep, const float* bias, const float* residual, const float* mask,
+                                float* y, int b, int cin, int cout, int h, int w, int relu, adv_stream_t stream);
+
 /* y [planes = b*c][hw] <- [relu](y + bias[plane % c] + residual), in place, one pass: the epilogue of a convolution computed by another
  *     library (bias / residual NULL = skipped; residual laid out like y, must not be y).  planes <= 65535. */
 ADV_API int adv_bias_act_f32(float* y, const float* bias, const float* residual, int64_t planes, int c, int64_t hw, int relu,

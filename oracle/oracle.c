@@ -11,6 +11,7 @@
  * Citations are relative to /root/reference.
  */
 #include <math.h>
+#include <stdlib.h>
 #include <stdint.h>
 #ifdef _OPENMP
 #include <omp.h>
@@ -336,6 +337,97 @@ void orc_conv3d_k3_ex(const float* x, const float* w, const float* bias, float* 
  * dil = dilation of the taps.  transpose != 0 (stride 1 only): the backward w.r.t. the input - x is grad_out [B,cout,H,W], y is grad_in [B,cin,H,W], the
  * weights are read transposed and flipped, exactly what the kernel does with its prepared W^T.
  * Upstream detector code (ResNet-101-FPN of Stereo R-CNN, DSGN's 2D extractor): unpinned; torch's conv2d is the semantics. */
+/* csrc/wino2d.hip restated: the 3x3 stride-1 pad-1 convolution by Winograd F(2x2, 3x3).  Per 2x2 output block and channel pair the
+ * kernel forms U = G g G^T (once per layer), V = B^T d B (per 4x4 input patch, out-of-image pixels zero), accumulates the 16 products
+ * M[k] = sum_c U[k] V[k] as one fmaf chain per k over ascending channels (the 16x16x4 matrix instruction's order), and writes
+ * Y = A^T M A + bias, + residual, ReLU, mask.  Every addition below is written in the order the kernel performs it. */
+static void wino_u(const float* g, float* u /* 16 */) {
+  float t[4][3];
+  for (int j = 0; j < 3; ++j) {
+    const float g0 = g[j], g1 = g[3 + j], g2 = g[6 + j];
+    t[0][j] = g0;
+    t[1][j] = ((g0 + g1) + g2) * 0.5f;
+    t[2][j] = ((g0 - g1) + g2) * 0.5f;
+    t[3][j] = g2;
+  }
+  for (int i = 0; i < 4; ++i) {
+    u[i * 4 + 0] = t[i][0];
+    u[i * 4 + 1] = ((t[i][0] + t[i][1]) + t[i][2]) * 0.5f;
+    u[i * 4 + 2] = ((t[i][0] - t[i][1]) + t[i][2]) * 0.5f;
+    u[i * 4 + 3] = t[i][2];
+  }
+}
+
+void orc_conv2d_wino(const float* x, const float* w, const float* bias, const float* residual, const float* mask, float* y, int B, int cin,
+                     int cout, int H, int W, int relu, int transpose) {
+  const int M = transpose ? cin : cout, Kc = transpose ? cout : cin;
+  float* U = (float*)malloc(sizeof(float) * 16 * (size_t)M * Kc);   /* [m][c][16] */
+  for (int m = 0; m < M; ++m)
+    for (int c = 0; c < Kc; ++c) {
+      float g[9];
+      for (int t = 0; t < 9; ++t) g[t] = transpose ? w[((long)c * cin + m) * 9 + (8 - t)] : w[((long)m * cin + c) * 9 + t];
+      wino_u(g, U + ((long)m * Kc + c) * 16);
+    }
+  const int PH = (H + 1) / 2, PW = (W + 1) / 2;
+#pragma omp parallel for collapse(2) schedule(static)
+  for (int b = 0; b < B; ++b)
+    for (int ph = 0; ph < PH; ++ph) {
+      float* V = (float*)malloc(sizeof(float) * 16 * (size_t)Kc);
+      for (int pw = 0; pw < PW; ++pw) {
+        for (int c = 0; c < Kc; ++c) {
+          float d[4][4], t[4][4];
+          for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) {
+              const int gh = 2 * ph - 1 + i, gw = 2 * pw - 1 + j;
+              d[i][j] = (gh >= 0 && gh < H && gw >= 0 && gw < W) ? x[((long)b * Kc + c) * H * W + (long)gh * W + gw] : 0.0f;
+            }
+          for (int j = 0; j < 4; ++j) {
+            t[0][j] = d[0][j] - d[2][j];
+            t[1][j] = d[1][j] + d[2][j];
+            t[2][j] = d[2][j] - d[1][j];
+            t[3][j] = d[1][j] - d[3][j];
+          }
+          for (int i = 0; i < 4; ++i) {
+            V[c * 16 + i * 4 + 0] = t[i][0] - t[i][2];
+            V[c * 16 + i * 4 + 1] = t[i][1] + t[i][2];
+            V[c * 16 + i * 4 + 2] = t[i][2] - t[i][1];
+            V[c * 16 + i * 4 + 3] = t[i][1] - t[i][3];
+          }
+        }
+        for (int m = 0; m < M; ++m) {
+          float mm[16], s[2][4], o[2][2];
+          for (int k = 0; k < 16; ++k) {
+            float acc = 0.0f;
+            for (int c = 0; c < Kc; ++c) acc = fmaf(U[((long)m * Kc + c) * 16 + k], V[c * 16 + k], acc);
+            mm[k] = acc;
+          }
+          for (int j = 0; j < 4; ++j) {
+            s[0][j] = (mm[j] + mm[4 + j]) + mm[8 + j];
+            s[1][j] = (mm[4 + j] - mm[8 + j]) - mm[12 + j];
+          }
+          for (int r = 0; r < 2; ++r) {
+            o[r][0] = (s[r][0] + s[r][1]) + s[r][2];
+            o[r][1] = (s[r][1] - s[r][2]) - s[r][3];
+          }
+          for (int r = 0; r < 2; ++r)
+            for (int q = 0; q < 2; ++q) {
+              const int gh = 2 * ph + r, gw = 2 * pw + q;
+              if (gh >= H || gw >= W) continue;
+              const long at = (((long)b * M + m) * H + gh) * W + gw;
+              float acc = o[r][q];
+              if (bias) acc = acc + bias[m];
+              if (residual) acc = acc + residual[at];
+              if (relu) acc = acc > 0.0f ? acc : 0.0f;
+              if (mask) acc = mask[at] > 0.0f ? acc : 0.0f;
+              y[at] = acc;
+            }
+        }
+      }
+      free(V);
+    }
+  free(U);
+}
+
 void orc_conv2d(const float* x, const float* w, const float* bias, const float* residual, const float* mask, float* y, int B, int cin,
                 int cout, int H, int W, int k, int stride, int pad, int dil, int relu, int transpose, int chunk) {
   const int kk = k * k;

@@ -35,6 +35,8 @@ _lib.orc_conv3d_k3_ex.argtypes = [_fp, _fp, ctypes.c_void_p, _fp] + [ctypes.c_in
 _lib.orc_conv3d_k3_ex.restype = None
 _lib.orc_conv2d.argtypes = [_fp, _fp, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _fp] + [ctypes.c_int] * 12
 _lib.orc_conv2d.restype = None
+_lib.orc_conv2d_wino.argtypes = [_fp, _fp, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _fp] + [ctypes.c_int] * 7
+_lib.orc_conv2d_wino.restype = None
 for _f in ("orc_denormalize", "orc_normalize", "orc_pgd_step_norm01", "orc_pgd_step_meansub255", "orc_tensor2im_u8",
            "orc_patch_paste", "orc_patch_update"):
     getattr(_lib, _f).restype = None
@@ -211,6 +213,28 @@ def conv2d(x, w, bias=None, residual=None, mask=None, stride=1, padding=0, relu=
     keep = [opt(bias, (y.shape[1],)), opt(residual, y.shape), opt(mask, y.shape)]
     _lib.orc_conv2d(x, w, keep[0][1], keep[1][1], keep[2][1], y, b, cin, cout, h, ww, k, int(stride), int(padding), int(dilation), int(relu),
                     int(transpose), int(chunk))
+    return y
+
+
+def conv2d_wino(x, w, bias=None, residual=None, mask=None, relu=False, transpose=False):
+    """csrc/wino2d.hip in its order of operations: the 3x3 stride-1 pad-1 convolution by Winograd F(2x2,3x3) (+ bias, + residual, ReLU,
+    mask); transpose=True: x is grad_out -> the gradient w.r.t. the input"""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    cout, cin = w.shape[0], w.shape[1]
+    b, c, h, ww = x.shape
+    assert w.shape[2:] == (3, 3) and c == (cout if transpose else cin)
+    y = np.empty((b, cin if transpose else cout, h, ww), np.float32)
+
+    def opt(a, shape):
+        if a is None:
+            return None, None
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        assert a.shape == shape, (a.shape, shape)
+        return a, a.ctypes.data_as(ctypes.c_void_p)
+
+    keep = [opt(bias, (y.shape[1],)), opt(residual, y.shape), opt(mask, y.shape)]
+    _lib.orc_conv2d_wino(x, w, keep[0][1], keep[1][1], keep[2][1], y, b, cin, cout, h, ww, int(relu), int(transpose))
     return y
 
 

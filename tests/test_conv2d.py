@@ -189,6 +189,86 @@ def test_hip_conv2d_3x3_layer_shapes_full_size():
             assert got.tobytes() == np.ascontiguousarray(want[:, :, a0:a1, b0:b1]).tobytes(), (cin, cout, h, w, r0, c0)
 
 
+def test_oracle_conv2d_wino_matches_torch():
+    """the Winograd restatement (oracle conv2d_wino) is the same operator: within float32 rounding of torch, forward and backward"""
+    for shape in ((1, 5, 7, 9, 11), (2, 8, 16, 8, 32), (1, 3, 4, 1, 1), (1, 17, 9, 5, 2), (1, 64, 20, 13, 41)):
+        b, cin, cout, h, w = shape
+        x, wt, rs = _case(b, cin, cout, h, w, k=3, seed=sum(shape))
+        bias, res = rs.randn(cout).astype(np.float32), rs.randn(b, cout, h, w).astype(np.float32)
+        got = C.conv2d_wino(x, wt, bias, res, relu=True)
+        ref = F.relu(F.conv2d(torch.tensor(x), torch.tensor(wt), torch.tensor(bias), 1, 1) + torch.tensor(res)).numpy()
+        assert np.abs(got - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+        g = rs.randn(b, cout, h, w).astype(np.float32)
+        refg = torch.nn.grad.conv2d_input(x.shape, torch.tensor(wt), torch.tensor(g), padding=1).numpy()
+        assert np.abs(C.conv2d_wino(g, wt, transpose=True) - refg).max() <= 1e-5 * max(1.0, np.abs(refg).max())
+    # the epilogue: + bias, + residual, ReLU, then the mask
+    x, wt, rs = _case(1, 8, 5, 4, 6, k=3, seed=3)
+    bias, res, mask = rs.randn(5).astype(np.float32), rs.randn(1, 5, 4, 6).astype(np.float32), rs.randn(1, 5, 4, 6).astype(np.float32)
+    want = np.maximum(C.conv2d_wino(x, wt) + bias[None, :, None, None] + res, np.float32(0)) * (mask > 0)
+    assert C.conv2d_wino(x, wt, bias, res, mask, relu=True).tobytes() == (want + np.float32(0)).astype(np.float32).tobytes()
+
+
+# (B, Cin, Cout, H, W): channels around the 8-channel stage and the 16 / 64-channel blocks, odd heights and widths (half patches at
+# the edge), maps smaller than a patch, more than one tile in every direction
+WINO = [(1, 8, 64, 8, 32), (2, 3, 32, 19, 63), (1, 32, 32, 24, 40), (1, 64, 64, 13, 41), (2, 12, 70, 9, 33), (1, 5, 7, 3, 2), (1, 256, 18, 6, 10),
+        (1, 9, 9, 1, 1), (1, 17, 130, 17, 65), (3, 16, 16, 2, 2)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", WINO)
+def test_hip_conv2d_wino_bit_exact_vs_oracle(shape):
+    """csrc/wino2d.hip (Winograd F(2x2,3x3), products on v_mfma_f32_16x16x4_f32) == oracle conv2d_wino bit for bit, forward with the full
+    epilogue and backward w.r.t. the input with skip gradient and ReLU mask; and within 1e-4 of torch"""
+    from eval_driving_safety_amd import ops
+    b, cin, cout, h, w = shape
+    x, wt, rs = _case(b, cin, cout, h, w, k=3, seed=sum(shape) + 5)
+    bias = rs.randn(cout).astype(np.float32)
+    res = rs.randn(b, cout, h, w).astype(np.float32)
+    mask = rs.randn(b, cout, h, w).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    tx, tw, tb, tr, tm = (torch.tensor(a, device=dev) for a in (x, wt, bias, res, mask))
+    prep = ops.Conv2dPrep(tw, 1, 1, 1)
+    assert prep.has_wino
+    assert ops.conv2d(tx, prep, wino=True).cpu().numpy().tobytes() == C.conv2d_wino(x, wt).tobytes()
+    assert ops.conv2d(tx, prep, tb, tr, True, tm, wino=True).cpu().numpy().tobytes() == C.conv2d_wino(x, wt, bias, res, mask, relu=True).tobytes()
+    ref = F.conv2d(tx, tw, tb, 1, 1)
+    assert float((ops.conv2d(tx, prep, tb, wino=True) - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
+    g = rs.randn(b, cout, h, w).astype(np.float32)
+    gres = rs.randn(b, cin, h, w).astype(np.float32)
+    tg, tgr = torch.tensor(g, device=dev), torch.tensor(gres, device=dev)
+    assert ops.conv2d_dgrad(tg, prep, wino=True).cpu().numpy().tobytes() == C.conv2d_wino(g, wt, transpose=True).tobytes()
+    assert ops.conv2d_dgrad(tg, prep, residual=tgr, mask=tx, wino=True).cpu().numpy().tobytes() == \
+        C.conv2d_wino(g, wt, residual=gres, mask=x, transpose=True).tobytes()
+    refg = torch.nn.grad.conv2d_input(x.shape, tw, tg, padding=1)
+    assert float((ops.conv2d_dgrad(tg, prep, wino=True) - refg).abs().max()) <= 1e-4 * max(1.0, float(refg.abs().max()))
+
+
+@pytest.mark.gpu
+def test_hip_conv2d_wino_layer_shapes_full_size():
+    """the detectors' 3x3 layers at their real size through the Winograd kernel: the whole tensor within 1e-4 of torch, windows (on the
+    even patch grid) bit-exact vs the oracle"""
+    from eval_driving_safety_amd import ops
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(17)
+    for cin, cout, h, w in ((64, 64, 150, 497), (256, 256, 38, 125), (32, 32, 192, 624), (256, 512, 75, 249)):
+        x = torch.randn((2, cin, h, w), device=dev, generator=gen)
+        wt = torch.randn((cout, cin, 3, 3), device=dev, generator=gen) * (1.0 / (9 * cin)) ** 0.5
+        bias = torch.randn((cout,), device=dev, generator=gen)
+        y = ops.conv2d(x, ops.Conv2dPrep(wt, 1, 1, 1), bias, relu=True, wino=True)
+        ref = F.relu(F.conv2d(x, wt, bias, 1, 1))
+        assert float((y - ref).abs().max()) <= 1e-4 * float(ref.abs().max()), (cin, cout, h, w)
+        for (r0, c0) in (((h - 6) & ~1, (w - 9) & ~1), ((h // 2) & ~1, (w // 2 - 3) & ~1)):
+            rs_, re_, cs_, ce_ = max(0, r0 - 2), min(h, r0 + 6 + 2), max(0, c0 - 2), min(w, c0 + 10 + 2)     # even origins: the same patch grid
+            sub = x[:1, :, rs_:re_, cs_:ce_].cpu().numpy()
+            want = C.conv2d_wino(sub, wt.cpu().numpy(), bias.cpu().numpy(), relu=True)
+            a0 = 0 if rs_ == 0 else 2
+            a1 = want.shape[2] if re_ == h else (want.shape[2] - 2) & ~1
+            b0 = 0 if cs_ == 0 else 2
+            b1 = want.shape[3] if ce_ == w else (want.shape[3] - 2) & ~1
+            got = y[:1, :, rs_ + a0:rs_ + a1, cs_ + b0:cs_ + b1].cpu().numpy()
+            assert got.tobytes() == np.ascontiguousarray(want[:, :, a0:a1, b0:b1]).tobytes(), (cin, cout, h, w, r0, c0)
+
+
 @pytest.mark.gpu
 def test_hip_bias_act_equals_the_three_torch_kernels():
     """adv_bias_act_f32: y <- relu(y + bias + residual) in one pass, bit-equal to torch's add, add, relu done apart"""

@@ -110,6 +110,11 @@ def main():
             ms_hb = timeit(lambda: ops.conv2d_dgrad(g, prep, (h, w)), args.reps)
             row.update({"hip_fwd_ms": round(ms_hf, 4), "hip_dgrad_ms": round(ms_hb, 4), "hip_fwd_tflops": round(flops / ms_hf / 1e9, 1),
                         "hip_dgrad_tflops": round(flops / ms_hb / 1e9, 1)})
+            if prep.has_wino:   # Winograd F(2x2,3x3) on the matrix cores (csrc/wino2d.hip); TFLOP/s in direct-convolution FLOPs, like MIOpen's
+                ms_wf = timeit(lambda: ops.conv2d(x, prep, bias, wino=True), args.reps)
+                ms_wb = timeit(lambda: ops.conv2d_dgrad(g, prep, (h, w), wino=True), args.reps)
+                row.update({"wino_fwd_ms": round(ms_wf, 4), "wino_dgrad_ms": round(ms_wb, 4), "wino_fwd_tflops": round(flops / ms_wf / 1e9, 1),
+                            "wino_dgrad_tflops": round(flops / ms_wb / 1e9, 1)})
             if args.sweep:      # every tile shape, forward and backward: what the host's choice should have been
                 row["hip_fwd_ms_by_tile"] = [round(timeit(lambda t=t: ops.conv2d(x, prep, bias, tile=t), args.reps), 4) for t in range(4)]
                 row["hip_dgrad_ms_by_tile"] = [round(timeit(lambda t=t: ops.conv2d_dgrad(g, prep, (h, w), tile=t), args.reps), 4) for t in range(4)]
@@ -123,7 +128,8 @@ def main():
         c["gflop"] += 2 * n * r["gflop_per_call"]                                  # forward + backward w.r.t. the input
         mi = n * (r["miopen_fwd_ms"] + r["miopen_dgrad_ms"])
         c["miopen_ms"] += mi
-        c["best_ms"] += n * (min(r["miopen_fwd_ms"], r.get("hip_fwd_ms", 1e9)) + min(r["miopen_dgrad_ms"], r.get("hip_dgrad_ms", 1e9)))
+        c["best_ms"] += n * (min(r["miopen_fwd_ms"], r.get("hip_fwd_ms", 1e9), r.get("wino_fwd_ms", 1e9)) +
+                             min(r["miopen_dgrad_ms"], r.get("hip_dgrad_ms", 1e9), r.get("wino_dgrad_ms", 1e9)))
     tot_ms = sum(c["miopen_ms"] for c in classes.values())
     tot_best = sum(c["best_ms"] for c in classes.values())
     tot_gf = sum(c["gflop"] for c in classes.values())
