@@ -106,7 +106,7 @@ SIGNATURES = {
     "adv_conv2d_3x3_prep_weights_f32": [_P, _P, _I, _I, _I, _P],
     "adv_conv2d_3x3_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "adv_conv2d_wino_prep_weights_f32": [_P, _P, _I, _I, _I, _P],
-    "adv_conv2d_wino_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "adv_conv2d_wino_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
 }
 _OTHER = {
     "adv_abi_version": ([], _I),

@@ -974,7 +974,7 @@ def _conv2d_call(x, prep, w_prep, cin, cout, bias, residual, relu, mask, tile, w
     with _on(xi):
         if wino:
             _lib.call("adv_conv2d_wino_f32", _ptr(xi), _ptr(w_prep), bp, _like(residual, y, "residual"), _like(mask, y, "mask"), _ptr(y), b, cin,
-                      cout, h, w, int(bool(relu)), _stream(xi))
+                      cout, h, w, int(bool(relu)), int(min(tile, 1)), _stream(xi))
         elif prep.k == 1:
             _lib.call("adv_conv2d_1x1_f32", _ptr(xi), _ptr(w_prep), bp, _like(residual, y, "residual"), _like(mask, y, "mask"), _ptr(y), b, cin, cout,
                       h * w, int(bool(relu)), int(tile), _stream(xi))

@@ -461,11 +461,12 @@ ADV_API int adv_conv2d_3x3_f32(const float* x, const float* w_prep, const float*
  *     kernel.  A different order of float operations than adv_conv2d_3x3_f32 (results agree to float32 rounding, ~1e-6 relative; the
  *     oracle's orc_conv2d_wino restates this order bit for bit): the caller chooses the route explicitly.
  *     w_prep from adv_conv2d_wino_prep_weights_f32 ([16][cin'][cout'] = G g G^T per channel pair, zero padded to multiples of 8 x 64);
- *     transpose = 1: the backward w.r.t. the input.  bias / residual / relu / mask: as adv_conv2d_1x1_f32. */
+ *     transpose = 1: the backward w.r.t. the input.  bias / residual / relu / mask: as adv_conv2d_1x1_f32.
+ *     tile: -1 = by map size, 0 = 8 x 32 outputs per workgroup, 1 = 16 x 16 (same result). */
 ADV_API int64_t adv_conv2d_wino_prep_floats(int cout, int cin, int transpose);
 ADV_API int adv_conv2d_wino_prep_weights_f32(const float* w, float* w_prep, int cout, int cin, int transpose, adv_stream_t stream);
 ADV_API int adv_conv2d_wino_f32(const float* x, const float* w_prep, const float* bias, const float* residual, const float* mask,
-                                float* y, int b, int cin, int cout, int h, int w, int relu, adv_stream_t stream);
+                                float* y, int b, int cin, int cout, int h, int w, int relu, int tile, adv_stream_t stream);
 
 /* y [planes = b*c][hw] <- [relu](y + bias[plane % c] + residual), in place, one pass: the epilogue of a convolution computed by another
  *     library (bias / residual NULL = skipped; residual laid out like y, must not be y).  planes <= 65535. */
