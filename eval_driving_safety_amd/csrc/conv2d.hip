@@ -50,7 +50,7 @@ struct GemmGeo {
 // that re-read one X tile sit in the same L2.
 template <int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(256, 2) void conv2d_1x1_mfma(const float* __restrict__ x, const float* __restrict__ wp, float* __restrict__ y, int K, int M,
-                                                       int mpad, long long P, int tiles_m, int tiles_n, long long ntiles, Epi2 epi) {
+                                                       int mpad, long long P, int tiles_m, int tiles_n, long long ntiles, long long total, Epi2 epi) {
   using G = GemmGeo<WM, WN, TM, TN>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -69,7 +69,6 @@ __global__ __launch_bounds__(256, 2) void conv2d_1x1_mfma(const float* __restric
   const int m0 = mt * G::kBM;
   const long long n0 = static_cast<long long>(nt) * G::kBN;
   const long long KP = static_cast<long long>(K) * P;
-  const float* xb = x + b * KP;
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -79,23 +78,26 @@ __global__ __launch_bounds__(256, 2) void conv2d_1x1_mfma(const float* __restric
 #pragma unroll
       for (int v = 0; v < 16; ++v) acc[i][jn][v] = 0.0f;
 
+  // The loads are UNCONDITIONAL (a load inside a divergent branch makes the compiler wait for it at the join, i.e. before the matrix
+  // instructions): rows past K load row K - 1, the tensor's last floats load from an address clamped into the tensor; both are put right
+  // (zeros; shifted elements) when the data is committed to LDS after the stage's matrix instructions.
   v4f rx[G::kXF4], rw[G::kWF4];
+  int rxs[G::kXF4];
+  unsigned rxm[G::kXF4];
+  const long long xlast = total - 4;
   auto fetch = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < G::kXF4; ++i) {
       const int f = tid + 256 * i, row = f / (G::kBN / 4), c4 = f % (G::kBN / 4);
-      const long long off = static_cast<long long>(k0 + row) * P + n0 + c4 * 4;
-      v4f v = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (k0 + row < K) {
-        if (off + 4 <= KP) {
-          v = *reinterpret_cast<const v4f_u*>(xb + off);   // may run past the row's end into the next row: those columns are never stored
-        } else {                                          // the image's last floats: element by element
+      const int kr = k0 + row;
+      const long long at = b * KP + static_cast<long long>(kr < K ? kr : K - 1) * P + n0 + c4 * 4;   // may run past the row's end into the
+      const long long cl = at > xlast ? xlast : at;                                                 // next row: those columns are never stored
+      rx[i] = *reinterpret_cast<const v4f_u*>(x + cl);
+      rxs[i] = static_cast<int>(cl - at);
+      unsigned m = 0;
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (off + e < KP) v[e] = xb[off + e];
-        }
-      }
-      rx[i] = v;
+      for (int e = 0; e < 4; ++e) m |= (at + e < total) ? (1u << e) : 0u;
+      rxm[i] = kr < K ? m : 0u;
     }
 #pragma unroll
     for (int i = 0; i < G::kWF4; ++i) {
@@ -109,7 +111,22 @@ __global__ __launch_bounds__(256, 2) void conv2d_1x1_mfma(const float* __restric
 #pragma unroll
     for (int i = 0; i < G::kXF4; ++i) {
       const int f = tid + 256 * i;
-      *reinterpret_cast<v4f*>(sx + 4 * f) = rx[i];     // [row][BN] row-major == float4 index f
+      const v4f t4 = rx[i];
+      const int sh = rxs[i];
+      const unsigned m = rxm[i];
+      v4f v;
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(sh != 0) != 0, 0)) {     // wave-uniform: the tensor's last float4 only
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int k = e - sh;
+          v[e] = k == 0 ? t4[0] : (k == 1 ? t4[1] : (k == 2 ? t4[2] : t4[3]));
+        }
+      } else {
+        v = t4;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (m >> e) & 1u ? v[e] : 0.0f;
+      *reinterpret_cast<v4f*>(sx + 4 * f) = v;         // [row][BN] row-major == float4 index f
     }
 #pragma unroll
     for (int i = 0; i < G::kWF4; ++i) {
@@ -117,14 +134,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_1x1_mfma(const float* __restric
       *reinterpret_cast<v4f*>(sw + 4 * f) = rw[i];
     }
   };
-
-  const int nstage = (K + kKC - 1) / kKC;
-  fetch(0);
-  commit(0);
-  __syncthreads();
-  for (int s = 0; s < nstage; ++s) {
-    const bool more = s + 1 < nstage;
-    if (more) fetch((s + 1) * kKC);
+  auto products = [&](int s) {
     const float* sx = lds + (s & 1) * G::kStage;
     const float* sw = sx + kKC * G::kBN;
 #pragma unroll
@@ -139,9 +149,22 @@ __global__ __launch_bounds__(256, 2) void conv2d_1x1_mfma(const float* __restric
 #pragma unroll
         for (int jn = 0; jn < TN; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bv[jn], acc[i][jn], 0, 0, 0);
     }
-    if (more) commit((s + 1) & 1);
+  };
+
+  // the last stage is peeled off so that a load and the LDS write that consumes it sit in the same straight-line block
+  const int nstage = (K + kKC - 1) / kKC;
+  fetch(0);
+  commit(0);
+  __syncthreads();
+  int s = 0;
+  for (; s + 1 < nstage; ++s) {
+    fetch((s + 1) * kKC);
+    __builtin_amdgcn_sched_barrier(0);     // the loads stay AHEAD of the matrix instructions (the scheduler would sink them to their use)
+    products(s);
+    commit((s + 1) & 1);
     __syncthreads();
   }
+  products(s);
 
   // ---- epilogue: register v of a 32x32 accumulator = output channel (v & 3) + 8 * (v >> 2) + 4 * half, pixel = lane & 31
   const long long MP = static_cast<long long>(M) * P;
@@ -203,7 +226,7 @@ int launch_1x1(const float* x, const float* wp, float* y, int b, int K, int M, i
   const size_t lds = 2 * sizeof(float) * static_cast<size_t>(G::kStage);
   if (lds > 64 * 1024 && !adv_internal_lds_limit<conv2d_1x1_mfma<WM, WN, TM, TN>>(lds)) return ADV_ELAUNCH;
   hipLaunchKernelGGL((conv2d_1x1_mfma<WM, WN, TM, TN>), dim3(static_cast<unsigned>(ntiles)), dim3(256), lds, st, x, wp, y, K, M, mpad, P, tiles_m,
-                     static_cast<int>(tiles_n), ntiles, epi);
+                     static_cast<int>(tiles_n), ntiles, static_cast<long long>(b) * K * P, epi);
   return adv_internal_finish_launch();
 }
 
@@ -249,7 +272,7 @@ struct Geo3 {
 
 template <int RW, int CBK, int DIL>
 __global__ __launch_bounds__(256, 2) void conv2d_3x3_mfma(const float* __restrict__ x, const float* __restrict__ wp, float* __restrict__ y, int Cin,
-                                                          int Cout, int cinpad, int copad, int H, int W, int tiles_w, Epi2 epi) {
+                                                          int Cout, int cinpad, int copad, int H, int W, int tiles_w, long long total, Epi2 epi) {
   using G = Geo3<RW, CBK, DIL>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -258,7 +281,6 @@ __global__ __launch_bounds__(256, 2) void conv2d_3x3_mfma(const float* __restric
   const int w0 = wt * 32, h0 = ht * G::kTH, co0 = blockIdx.y * G::kCO;
   const long long b = blockIdx.z;
   const long long HW = static_cast<long long>(H) * W;
-  const float* xb = x + b * Cin * HW;
 
   f32x16 acc[CBK][RW];
 #pragma unroll
@@ -268,45 +290,45 @@ __global__ __launch_bounds__(256, 2) void conv2d_3x3_mfma(const float* __restric
 #pragma unroll
       for (int v = 0; v < 16; ++v) acc[i][r][v] = 0.0f;
 
-  // fetch plan, once per tile: slot s = tid + 256 i -> (channel c, tile row r, float4 group j)
-  long long xoff[G::kXSlots];
-  int xkind[G::kXSlots], xc[G::kXSlots];   // kind 0: zeros, 1: one dword-aligned float4, 2: element by element (the image's edge)
+  // fetch plan, once per tile: slot s = tid + 256 i -> (channel c, tile row r, float4 group j).  The loads are UNCONDITIONAL (a load
+  // inside a divergent branch makes the compiler wait for it at the join - before the matrix instructions): a slot outside the image
+  // loads from an address clamped into the tensor and is zeroed element by element when it is committed to LDS.
+  long long xflat[G::kXSlots];               // gh * W + gw of the group's first element (may lie outside the row / the image)
+  int xc[G::kXSlots];
+  unsigned xvm[G::kXSlots];                  // bit e: element e of the group is a pixel of the image
 #pragma unroll
   for (int i = 0; i < G::kXSlots; ++i) {
     const int sidx = tid + 256 * i;
     const int j = sidx % (kLW / 4), r = (sidx / (kLW / 4)) % G::kRows, c = sidx / ((kLW / 4) * G::kRows);
     const int gh = h0 - DIL + r, gw = w0 - 4 + 4 * j;
-    xkind[i] = 0, xoff[i] = 0, xc[i] = c;
-    if (sidx < G::kXN && gh >= 0 && gh < H && gw + 3 >= 0 && gw < W) {
-      xoff[i] = static_cast<long long>(c) * HW + static_cast<long long>(gh) * W + gw;
-      xkind[i] = (gw >= 0 && gw + 3 < W) ? 1 : 2;
-    }
+    xc[i] = c < kC3 ? c : kC3 - 1;
+    xflat[i] = static_cast<long long>(gh) * W + gw;
+    unsigned vm = 0;
+    if (sidx < G::kXN && gh >= 0 && gh < H)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) vm |= (gw + e >= 0 && gw + e < W) ? (1u << e) : 0u;
+    xvm[i] = vm;
   }
+  const long long xlast = total - 4;         // the last float4 that lies inside the tensor
   v4f rx[G::kXSlots], rw[G::kWSlots];
+  int rxs[G::kXSlots];                       // how far the clamp moved the load (non-zero only in the tensor's first / last three floats)
+  unsigned rxm[G::kXSlots];
   auto fetch = [&](int c0) {
 #pragma unroll
     for (int i = 0; i < G::kXSlots; ++i) {
-      v4f v = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (xkind[i] != 0 && c0 + xc[i] < Cin) {
-        const float* src = xb + static_cast<long long>(c0) * HW + xoff[i];
-        if (xkind[i] == 1) {
-          v = *reinterpret_cast<const v4f_u*>(src);
-        } else {
-          const int gw = w0 - 4 + 4 * ((tid + 256 * i) % (kLW / 4));
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (gw + e >= 0 && gw + e < W) v[e] = src[e];
-        }
-      }
-      rx[i] = v;
+      const int ch = c0 + xc[i];
+      const long long at = (b * Cin + (ch < Cin ? ch : Cin - 1)) * HW + xflat[i];
+      const long long cl = at < 0 ? 0 : (at > xlast ? xlast : at);
+      rx[i] = *reinterpret_cast<const v4f_u*>(x + cl);
+      rxs[i] = static_cast<int>(cl - at);
+      rxm[i] = ch < Cin ? xvm[i] : 0u;
     }
 #pragma unroll
     for (int i = 0; i < G::kWSlots; ++i) {
-      const int sidx = tid + 256 * i;
+      int sidx = tid + 256 * i;
+      if (sidx >= G::kWN) sidx -= 256;       // idle lanes of the last pass repeat a slot (same data to the same place)
       const int q = sidx % (G::kCO / 4), k = (sidx / (G::kCO / 4)) % kC3, tap = sidx / ((G::kCO / 4) * kC3);
-      v4f v = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (sidx < G::kWN) v = *reinterpret_cast<const v4f*>(wp + (static_cast<long long>(tap) * cinpad + c0 + k) * copad + co0 + 4 * q);
-      rw[i] = v;
+      rw[i] = *reinterpret_cast<const v4f*>(wp + (static_cast<long long>(tap) * cinpad + c0 + k) * copad + co0 + 4 * q);
     }
   };
   auto commit = [&](int buf) {
@@ -315,22 +337,31 @@ __global__ __launch_bounds__(256, 2) void conv2d_3x3_mfma(const float* __restric
 #pragma unroll
     for (int i = 0; i < G::kXSlots; ++i) {
       const int sidx = tid + 256 * i;
-      if (sidx < G::kXN) *reinterpret_cast<v4f*>(sx + 4 * sidx) = rx[i];   // [c][r][40] row-major == float4 index sidx
+      const v4f t = rx[i];
+      const int sh = rxs[i];
+      const unsigned m = rxm[i];
+      v4f v;
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(sh != 0) != 0, 0)) {     // wave-uniform: the tensor's first / last float4 only
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int k = e - sh;
+          v[e] = k == 0 ? t[0] : (k == 1 ? t[1] : (k == 2 ? t[2] : t[3]));
+        }
+      } else {
+        v = t;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (m >> e) & 1u ? v[e] : 0.0f;
+      if (sidx < G::kXN) *reinterpret_cast<v4f*>(sx + 4 * sidx) = v;   // [c][r][40] row-major == float4 index sidx
     }
 #pragma unroll
     for (int i = 0; i < G::kWSlots; ++i) {
-      const int sidx = tid + 256 * i;
-      if (sidx < G::kWN) *reinterpret_cast<v4f*>(sw + 4 * sidx) = rw[i];   // [tap][k][CO]
+      int sidx = tid + 256 * i;
+      if (sidx >= G::kWN) sidx -= 256;
+      *reinterpret_cast<v4f*>(sw + 4 * sidx) = rw[i];   // [tap][k][CO]
     }
   };
-
-  const int nstage = (Cin + kC3 - 1) / kC3;
-  fetch(0);
-  commit(0);
-  __syncthreads();
-  for (int st = 0; st < nstage; ++st) {
-    const bool more = st + 1 < nstage;
-    if (more) fetch((st + 1) * kC3);
+  auto products = [&](int st) {
     const float* sx = lds + (st & 1) * (G::kSX + G::kSW);
     const float* sw = sx + G::kSX;
 #pragma unroll
@@ -349,9 +380,24 @@ __global__ __launch_bounds__(256, 2) void conv2d_3x3_mfma(const float* __restric
           for (int r = 0; r < RW; ++r) acc[i][r] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bv[r], acc[i][r], 0, 0, 0);
       }
     }
-    if (more) commit((st + 1) & 1);
+  };
+
+  // the last stage is peeled off: a load and the LDS write that consumes it always sit in the same straight-line block (with
+  // "if (more) fetch ... if (more) commit" the compiler assumes a path with a load still in flight at the loop's head and waits for
+  // all loads before it reuses the registers)
+  const int nstage = (Cin + kC3 - 1) / kC3;
+  fetch(0);
+  commit(0);
+  __syncthreads();
+  int st = 0;
+  for (; st + 1 < nstage; ++st) {
+    fetch((st + 1) * kC3);
+    __builtin_amdgcn_sched_barrier(0);     // the loads stay AHEAD of the matrix instructions (the scheduler would sink them to their use)
+    products(st);
+    commit((st + 1) & 1);
     __syncthreads();
   }
+  products(st);
 
   const long long MP = static_cast<long long>(Cout) * HW;
   float* yb = y + b * MP;
@@ -401,7 +447,7 @@ int launch_3x3(const float* x, const float* wp, float* y, int b, int cin, int co
   const size_t lds = 2 * sizeof(float) * static_cast<size_t>(G::kSX + G::kSW);
   if (lds > 64 * 1024 && !adv_internal_lds_limit<conv2d_3x3_mfma<RW, CBK, DIL>>(lds)) return ADV_ELAUNCH;
   hipLaunchKernelGGL((conv2d_3x3_mfma<RW, CBK, DIL>), dim3(static_cast<unsigned>(tiles), cgroups, b), dim3(256), lds, st, x, wp, y, cin, cout, cinpad, copad,
-                     h, w, tiles_w, epi);
+                     h, w, tiles_w, static_cast<long long>(b) * cin * h * w, epi);
   return adv_internal_finish_launch();
 }
 
@@ -450,6 +496,7 @@ int adv_conv2d_1x1_prep_weights_f32(const float* w, float* w_prep, int cout, int
 int adv_conv2d_1x1_f32(const float* x, const float* w_prep, const float* bias, const float* residual, const float* mask, float* y, int b, int cin,
                        int cout, int64_t pixels, int relu, int tile, adv_stream_t stream) {
   if (!x || !w_prep || !y || b < 1 || cin < 1 || cout < 1 || pixels < 1 || tile < -1 || tile > 3) return ADV_EINVAL;
+  if (static_cast<long long>(b) * cin * pixels < 4) return ADV_EINVAL;      // the kernels load whole float4s (clamped into the tensor)
   if (residual == y || mask == y || x == y) return ADV_EINVAL;
   if ((reinterpret_cast<uintptr_t>(x) & 3) || (reinterpret_cast<uintptr_t>(y) & 3) || (reinterpret_cast<uintptr_t>(w_prep) & 15) ||
       (residual && (reinterpret_cast<uintptr_t>(residual) & 3)) || (mask && (reinterpret_cast<uintptr_t>(mask) & 3)) ||
@@ -489,6 +536,7 @@ int adv_conv2d_3x3_f32(const float* x, const float* w_prep, const float* bias, c
                        int cout, int h, int w, int dilation, int relu, int tile, adv_stream_t stream) {
   if (!x || !w_prep || !y || b < 1 || cin < 1 || cout < 1 || h < 1 || w < 1 || (dilation != 1 && dilation != 2) || tile < -1 || tile > 2)
     return ADV_EINVAL;
+  if (static_cast<long long>(b) * cin * h * w < 4) return ADV_EINVAL;       // the kernels load whole float4s (clamped into the tensor)
   if (residual == y || mask == y || x == y) return ADV_EINVAL;
   if ((reinterpret_cast<uintptr_t>(x) & 3) || (reinterpret_cast<uintptr_t>(y) & 3) || (reinterpret_cast<uintptr_t>(w_prep) & 15) ||
       (residual && (reinterpret_cast<uintptr_t>(residual) & 3)) || (mask && (reinterpret_cast<uintptr_t>(mask) & 3)) ||

@@ -911,6 +911,8 @@ def conv2d_supported(x, weight, stride=1, padding=0, dilation=1):
     padding = dilation in (1, 2); strided layers and other kernel sizes stay on MIOpen"""
     if not (x.is_cuda and x.dtype == torch.float32 and weight.dim() == 4 and weight.shape[2] == weight.shape[3] and stride == 1):
         return False
+    if x.dim() != 4 or x.numel() < 4 or x.shape[0] * weight.shape[0] * x.shape[2] * x.shape[3] < 4:
+        return False            # the kernels load whole float4s (clamped into the tensor): fewer than four floats are refused
     k = weight.shape[2]
     return (k == 1 and padding == 0 and dilation == 1) or (k == 3 and dilation in (1, 2) and padding == dilation)
 

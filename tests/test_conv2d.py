@@ -18,7 +18,7 @@ def _case(b, cin, cout, h, w, k=1, seed=0):
 # (B, Cin, Cout, H, W): odd row lengths (the rule for feature maps), channel counts that are not multiples of the stage / tile,
 # fewer pixels than a tile, the R101 shapes at reduced size
 ONE = [(1, 16, 32, 5, 7), (2, 24, 18, 19, 63), (1, 3, 70, 9, 11), (2, 64, 256, 13, 41), (1, 256, 64, 10, 33), (1, 40, 3, 38, 125),
-       (3, 130, 129, 7, 9), (1, 4, 1, 1, 1), (1, 1, 5, 2, 2), (1, 1024, 18, 6, 10)]
+       (3, 130, 129, 7, 9), (1, 4, 4, 1, 1), (1, 1, 5, 2, 2), (1, 1024, 18, 6, 10)]
 
 
 @pytest.mark.parametrize("shape", ONE[:6])
@@ -78,6 +78,22 @@ def test_hip_conv2d_1x1_bit_exact_vs_oracle_every_tile_shape(shape):
         assert ops.conv2d_dgrad(tg, prep, residual=tgr, mask=tx, tile=tile).cpu().numpy().tobytes() == want_b.tobytes(), tile
     refg = torch.nn.grad.conv2d_input(x.shape, tw, tg)
     assert float((ops.conv2d_dgrad(tg, prep) - refg).abs().max()) <= 1e-4 * max(1.0, float(refg.abs().max()))
+
+
+@pytest.mark.gpu
+def test_hip_conv2d_refuses_tensors_of_fewer_than_four_floats():
+    """the kernels load whole float4s, clamped into the tensor: a tensor of fewer than four floats has no such address"""
+    from eval_driving_safety_amd import ops, _lib
+    dev = torch.device("cuda", 0)
+    for k, pad in ((1, 0), (3, 1)):
+        x, wt = torch.randn((1, 3, 1, 1), device=dev), torch.randn((5, 3, k, k), device=dev)
+        assert not ops.conv2d_supported(x, wt, 1, pad)
+        prep = ops.Conv2dPrep(wt, 1, pad, 1)
+        for kw in ({}, {"wino": True}) if k == 3 else ({},):
+            with pytest.raises(_lib.AdvEngineError):
+                ops.conv2d(x, prep, **kw)
+    assert ops.conv2d_supported(torch.randn((1, 4, 1, 1), device=dev), torch.randn((4, 4, 1, 1), device=dev), 1, 0)
+    assert not ops.conv2d_supported(torch.randn((1, 4, 1, 1), device=dev), torch.randn((1, 4, 1, 1), device=dev), 1, 0)    # the gradient has one float
 
 
 @pytest.mark.gpu

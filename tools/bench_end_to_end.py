@@ -89,8 +89,10 @@ def _choice_summary(fresh=False):
         ops._Conv2dChoice.cache.clear()
         return None
     c = ops._Conv2dChoice.cache
-    return {"forward": "%d of %d layer shapes" % (sum(1 for k, v in c.items() if k[0] == "f" and v), sum(1 for k in c if k[0] == "f")),
-            "backward": "%d of %d layer shapes" % (sum(1 for k, v in c.items() if k[0] == "b" and v), sum(1 for k in c if k[0] == "b"))}
+    def side(d):
+        own = [v for k, v in c.items() if k[0] == d]
+        return "%d of %d layer shapes (%d of them by the Winograd kernel)" % (sum(1 for v in own if v), len(own), sum(1 for v in own if v == "wino"))
+    return {"forward": side("f"), "backward": side("b")}
 
 
 def measure_dsgn_full(pairs=1, iters=20, reps=1, graph=False, hip2d="auto"):
