@@ -107,6 +107,8 @@ SIGNATURES = {
     "adv_conv2d_3x3_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "adv_conv2d_wino_prep_weights_f32": [_P, _P, _I, _I, _I, _P],
     "adv_conv2d_wino_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "adv_conv3d_wino_prep_weights_f32": [_P, _P, _I, _I, _I, _P],
+    "adv_conv3d_wino_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
 }
 _OTHER = {
     "adv_abi_version": ([], _I),
@@ -117,6 +119,7 @@ _OTHER = {
     "adv_conv2d_1x1_prep_floats": ([_I, _I, _I], ctypes.c_int64),
     "adv_conv2d_3x3_prep_floats": ([_I, _I, _I], ctypes.c_int64),
     "adv_conv2d_wino_prep_floats": ([_I, _I, _I], ctypes.c_int64),
+    "adv_conv3d_wino_prep_floats": ([_I, _I, _I], ctypes.c_int64),
     "adv_last_hip_error": ([], _I),
     "adv_strerror": ([_I], ctypes.c_char_p),
     "adv_space_dsgn": ([_SP], None),

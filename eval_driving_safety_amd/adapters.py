@@ -601,7 +601,8 @@ class DsgnShapedAdapter(PsvStereoAdapter):
     costs twice that.  ``torch_ops=True`` computes the same graph with torch's own operators (the parity reference of the tests)."""
 
     def __init__(self, device, seed=0, planes=48, image_hw=(384, 1248), fu=721.5377, cu=609.5593, cv=172.854, mfma_conv=True, torch_ops=False,
-                 hip2d="auto"):
+                 hip2d="auto", wino3d=True):
+        self.wino3d = bool(wino3d)          # the stride-1 3x3x3 layers may take the Winograd kernel where it measures faster (ops.Conv3dK3 wino=)
         super().__init__(device, seed=seed, channels=32, planes=planes, mid=32, mfma_conv=mfma_conv and not torch_ops, interp=True,
                          hourglass=False, dsgn_head=True, fu=fu, cu=cu, cv=cv, image_hw=image_hw)
         self.torch_ops = bool(torch_ops)
@@ -674,6 +675,7 @@ class DsgnShapedAdapter(PsvStereoAdapter):
             if self.mfma_conv:
                 if kind == "s1":
                     e["p"], e["pt"] = ops.conv3d_k3_prep(w), ops.conv3d_k3_prep(w, transpose=True)
+                    e["wino"] = ops.Conv3dWinoPrep(w) if self.wino3d and cout >= 4 else None      # direct or Winograd: whichever measures faster per shape
                 elif kind == "s2":
                     e["p"], e["pt"] = ops.conv3d_k3_s2_prep(w), ops.conv_transpose3d_k3_s2_prep(w)
                 else:
@@ -747,7 +749,7 @@ class DsgnShapedAdapter(PsvStereoAdapter):
                     y = ops.Conv3dK3.apply(x, e["p"], e["pt"], cout)
                     y = y + b.view(1, -1, 1, 1, 1)
                 else:
-                    y = ops.Conv3dK3.apply(x, e["p"], e["pt"], cout, None, b, relu, residual, chain_in)
+                    y = ops.Conv3dK3.apply(x, e["p"], e["pt"], cout, None, b, relu, residual, chain_in, e["wino"])
             elif kind == "s2":
                 y = ops.Conv3dK3S2.apply(x, e["p"], e["pt"], cout, b, relu)
             else:

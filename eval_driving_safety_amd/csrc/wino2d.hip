@@ -1,23 +1,29 @@
-// 3x3 / stride 1 / pad 1 convolution by Winograd F(2x2, 3x3) with the sixteen element-wise products on the gfx950 float32 matrix
-// cores (v_mfma_f32_16x16x4_f32) - 2.25x fewer multiply-adds than the direct kernel of conv2d.hip, everything in ONE kernel (no
-// transformed tensor ever reaches HBM).
+// 3x3 (x3) / stride 1 / pad 1 convolutions by Winograd F(2x2, 3x3) with the sixteen element-wise products on the gfx950 float32 matrix
+// cores (v_mfma_f32_16x16x4_f32) - 2.25x fewer multiply-adds than the direct kernels of conv2d.hip / conv3d.hip, everything in ONE
+// kernel (no transformed tensor ever reaches HBM).
 //
-//   Y(2x2) = A^T [ sum_c (G g_c G^T) .* (B^T d_c B) ] A      d_c: the 4x4 input patch of channel c around the 2x2 output block
+//   Y(2x2) = A^T [ sum_q (G g_q G^T) .* (B^T d_q B) ] A      d_q: the 4x4 input patch of "channel" q around the 2x2 output block
 //
-// A 512-thread workgroup owns 8 rows x 32 columns of the output (4 x 16 = 64 patches) x 64 output channels.  Per stage of 8 input
-// channels:
-//   1. the input tile [8][10][40] and the transformed weights [16][8][64] go global -> registers -> LDS while the previous stage
-//      computes (two buffers; a lane's fetch plan is computed once per tile, as in the direct kernel);
-//   2. every thread transforms one (channel, patch): 16 LDS reads, 32 additions, 16 LDS writes into V[16][8][64 patches];
-//   3. for each of the 16 transform positions k, a [64 ch_out x 8 ch_in] x [8 ch_in x 64 patches] product: wave w owns channel block
-//      w & 3 (16 channels) and patch rows 2 (w >> 2), 2 (w >> 2) + 1 (two blocks of 16 patches): 2 x 16 accumulators of 4 registers.
-//      A operand = U_k[co = lane & 15][c = lane >> 4], B operand = V_k[c = lane >> 4][patch = lane & 15]; rows of U and V are padded
-//      to 80 floats so that the two 16-lane groups a ds_read serves per cycle fall into different banks.
-//   All 16 values M_k of one (channel, patch) end up in the SAME lane and register index of the 16 accumulators, so the output
-//   transform A^T M A is plain per-lane arithmetic; the epilogue (+ bias, + residual, ReLU, mask) follows it before the store.
+//   2D layers: q = input channel.   3D layers (3x3x3 kernels): the transform is applied in the (H, W) plane only and the depth taps are
+//   part of the contraction, q = (kd, channel): output plane od reads the input planes od - 1, od, od + 1 (a missing plane is skipped:
+//   its terms are exact zeros) - 48 products per 2x2 outputs instead of 108.
 //
-// Order of operations (oracle/oracle.c orc_conv2d_wino restates it bit for bit): the transforms' additions as written below, the
-// accumulation of each M_k one fmaf per input channel in ascending order starting from 0 (the matrix instruction is a k-ordered fmaf
+// A workgroup owns 64 patches (4 x 16 patches = 8 x 32 outputs, or 8 x 8 = 16 x 16 outputs) of one image / output plane and
+//   shape A: 64 output channels, 512 threads, stages of 8 q   (155 KB LDS, one workgroup per CU)
+//   shape B: 32 output channels, 256 threads, stages of 4 q   ( 61 KB LDS, two workgroups per CU) - layers of 32 channels or fewer.
+// Wave w owns channel block w % COB (16 channels) and two blocks of 16 patches: 2 x 16 accumulators of 4 registers; A operand =
+// U_k[co = lane & 15][q = lane >> 4], B operand = V_k[q = lane >> 4][patch = lane & 15].  All 16 values M_k of one (channel, patch) end
+// up in the SAME lane and register index of the 16 accumulators, so the output transform A^T M A is plain per-lane arithmetic; the
+// epilogue (+ bias, + residual, ReLU, mask) follows it before the store.
+//
+// Per stage: the input tile [KC][rows][LW] and the transformed weights U [16][KC][CO] go global -> registers -> LDS, every thread
+// transforms one (q, patch) - 8 LDS reads of two floats, 32 additions, 16 LDS writes into V [16][KC][64] - and the waves run the
+// matrix instructions on the PREVIOUS stage's V and U.  All of that is software-pipelined by hand into one instruction stream (see
+// `products`): one barrier per stage, two buffers of everything.  LDS rows of U and V are not padded: column ^ ((q & 3) << 4) puts
+// the four 16-lane groups of a read (four consecutive q) into different banks.
+//
+// Order of operations (oracle/oracle.c orc_conv2d_wino / orc_conv3d_wino restate it bit for bit): the transforms' additions as written
+// below, the accumulation of each M_k one fmaf per q in ascending order starting from 0 (the matrix instruction is a k-ordered fmaf
 // chain).  The backward w.r.t. the input is the same kernel on the transposed, flipped weights.
 #include <hip/hip_runtime.h>
 
@@ -34,19 +40,24 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef v4f v4f_u __attribute__((aligned(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-constexpr int kWC = 8;       // input channels per stage
-constexpr int kWCO = 64;     // output channels per workgroup
-constexpr int kWStr = 64;    // LDS row of U (64 channels) and V (64 patches); column ^ ((channel & 3) << 4): the four 16-lane groups of a read
-                             // (four consecutive channels) fall into four different sets of 16 banks without padding
-constexpr int kSWw = 16 * kWC * kWStr;             // 8192 floats (U of a stage; V of a stage has the same shape)
-constexpr int kWNw = 16 * kWC * (kWCO / 4);        // 2048 float4 per stage
-constexpr int kWSl = kWNw / 512;
-
-template <int PR, int PC>     // patch rows x patch columns of a workgroup's tile (PR * PC = 64): 4 x 16 (8 x 32 outputs) or 8 x 8 (16 x 16)
+// PR x PC patches per workgroup (4 x 16, 8 x 8, or 5 x 12 for maps of 10 / 20 rows); COB blocks of 16 output channels; KC "channels" per stage
+template <int PR, int PC, int COB, int KC>
 struct WGeo {
-  static_assert(PR * PC == 64, "64 patches per workgroup");
-  static constexpr int kRows = 2 * PR + 2, kLW = 2 * PC + 8;     // input rows; LDS row: column = gw - (w0 - 5), so a patch row starts on an even column
-  static constexpr int kSX = kWC * kRows * kLW, kXN = kSX / 4, kXSl = (kXN + 511) / 512;
+  static_assert(PR * PC <= 64 && PR * PC > 48, "up to 64 patches per workgroup (5 x 12 leaves four idle)");
+  static_assert(KC * 64 == COB * 128, "one (q, patch) of the input transform per thread");
+  static constexpr int kNT = COB * 128;                            // threads: COB channel blocks x 2 patch halves, one wave each
+  static constexpr int kCO = 16 * COB;
+  static constexpr int kRows = 2 * PR + 2, kLW = 2 * PC + 8;       // input rows; LDS row: column = gw - (w0 - 5), so a patch row starts on an even column
+  static constexpr int kSX = KC * kRows * kLW, kXN = kSX / 4, kXSl = (kXN + kNT - 1) / kNT;
+  static constexpr int kSW = 16 * KC * kCO, kWN = kSW / 4, kWSl = kWN / kNT;
+  static constexpr int kSV = 16 * KC * 64;
+  static constexpr int kSteps = (KC / 4) * 16;                     // pairs of matrix instructions per stage
+  // where a stage's side work sits among the steps: loads first, then the next stage's input transform, the LDS commits last
+  static constexpr int kLoadW = kXSl, kRead = kXSl + kWSl, kComp = kRead + 4 + (kSteps == 32 ? 2 : 0), kWrite = kComp + (kSteps == 32 ? 2 : 1);
+  static constexpr int kWritesPerStep = kSteps == 32 ? 2 : 4;
+  static constexpr int kCommitX = kSteps - kXSl - kWSl - (kSteps == 32 ? 2 : 0), kCommitW = kCommitX + kXSl;
+  static_assert(kWrite + 16 / kWritesPerStep <= kCommitX + 1, "the schedule fits");
+  static constexpr size_t kLds = 2 * sizeof(float) * (kSX + kSW + kSV);
 };
 
 struct EpiW {
@@ -56,19 +67,24 @@ struct EpiW {
   int relu;
 };
 
-template <int PR, int PC, bool DBG>
-__global__ __launch_bounds__(512, 1) void conv2d_3x3_wino(const float* __restrict__ x, const float* __restrict__ wp, float* __restrict__ y, int Cin,
-                                                         int Cout, int cinpad, int copad, int H, int W, int tiles_w, long long total, EpiW epi, int dbg_arg) {
-  using G = WGeo<PR, PC>;
+// Cin, Cout: channels; cinpad / copad: the prepared weights' padding; D: planes (1 for a 2D layer); DEPTH: 3x3x3 kernel
+template <int PR, int PC, int COB, int KC, bool DEPTH, bool DBG>
+__global__ __launch_bounds__(COB * 128, COB == 4 ? 1 : 2) void conv_wino(const float* __restrict__ x, const float* __restrict__ wp, float* __restrict__ y,
+                                                                          int Cin, int Cout, int cinpad, int copad, int D, int H, int W, int tiles_w,
+                                                                          long long total, EpiW epi, int dbg_arg) {
+  using G = WGeo<PR, PC, COB, KC>;
+  constexpr int NT = G::kNT;
   const int dbg = DBG ? dbg_arg : 0;      // phase ablation for timing: compiled in only for the -DADV_TEST_HOOKS build's probe
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, k4 = lane >> 4;
-  const int cob = wave & 3, hf = wave >> 2;
+  const int cob = wave % COB, hf = wave / COB;
   const int wt = blockIdx.x % tiles_w, ht = blockIdx.x / tiles_w;
-  const int w0 = wt * 2 * PC, h0 = ht * 2 * PR, co0 = blockIdx.y * kWCO;
-  const long long b = blockIdx.z;
+  const int w0 = wt * 2 * PC, h0 = ht * 2 * PR, co0 = blockIdx.y * G::kCO;
+  const long long b = DEPTH ? blockIdx.z / D : blockIdx.z;
+  const int od = DEPTH ? static_cast<int>(blockIdx.z % D) : 0;
   const long long HW = static_cast<long long>(H) * W;
+  const long long DHW = HW * D;
 
   v4f acc[2][16];
 #pragma unroll
@@ -76,7 +92,7 @@ __global__ __launch_bounds__(512, 1) void conv2d_3x3_wino(const float* __restric
 #pragma unroll
     for (int k = 0; k < 16; ++k) acc[i][k] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
 
-  // fetch plan of the input tile, once per tile: slot = tid + 512 i -> (channel c, tile row r, float4 group j).  The loads themselves are
+  // fetch plan of the input tile, once per tile: slot = tid + NT i -> (channel c, tile row r, float4 group j).  The loads themselves are
   // UNCONDITIONAL (no divergent branch around a load: the compiler would have to wait for it at the join, i.e. before the matrix
   // instructions): a slot that lies outside the image loads from a clamped address and is zeroed, element by element, when it is committed
   // to LDS after the stage's matrix instructions.
@@ -85,10 +101,10 @@ __global__ __launch_bounds__(512, 1) void conv2d_3x3_wino(const float* __restric
   unsigned xvm[G::kXSl];                     // bit e: element e of the group is a pixel of the image
 #pragma unroll
   for (int i = 0; i < G::kXSl; ++i) {
-    const int sidx = tid + 512 * i;
+    const int sidx = tid + NT * i;
     const int j = sidx % (G::kLW / 4), r = (sidx / (G::kLW / 4)) % G::kRows, c = sidx / ((G::kLW / 4) * G::kRows);
     const int gh = h0 - 1 + r, gw = w0 - 5 + 4 * j;
-    xc[i] = c < kWC ? c : kWC - 1;
+    xc[i] = c < KC ? c : KC - 1;
     xflat[i] = static_cast<long long>(gh) * W + gw;
     unsigned vm = 0;
     if (sidx < G::kXN && gh >= 0 && gh < H)
@@ -97,31 +113,34 @@ __global__ __launch_bounds__(512, 1) void conv2d_3x3_wino(const float* __restric
     xvm[i] = vm;
   }
   const long long xlast = total - 4;         // the last float4 that lies inside the tensor
-  v4f rx[G::kXSl], rw[kWSl];
+  v4f rx[G::kXSl], rw[G::kWSl];
   int rxs[G::kXSl];                          // how far the clamp moved the load (non-zero only in the tensor's first / last three floats)
   unsigned rxm[G::kXSl];
   // Everything below is written per slot / per row so that a stage's side work (global loads of the stages ahead, the input transform
   // of the next stage, the LDS commits) can be placed BETWEEN the matrix instructions of the current stage, one piece per step.
-  auto fetch_x1 = [&](int i, int c0) {
-    const int ch = c0 + xc[i];
-    const long long at = (b * Cin + (ch < Cin ? ch : Cin - 1)) * HW + xflat[i];
+  // q0 = the stage's first "channel": 2D: the channel itself; 3D: q = kd * cinpad + c, input plane od + kd - 1
+  auto fetch_x1 = [&](int i, int q0) {
+    const int kd = DEPTH ? q0 / cinpad : 0;
+    const int ch = (DEPTH ? q0 - kd * cinpad : q0) + xc[i];
+    const long long at = ((b * Cin + (ch < Cin ? ch : Cin - 1)) * D + (DEPTH ? od + kd - 1 : 0)) * HW + xflat[i];
     const long long cl = at < 0 ? 0 : (at > xlast ? xlast : at);
     rx[i] = *reinterpret_cast<const v4f_u*>(x + cl);
     rxs[i] = static_cast<int>(cl - at);
     rxm[i] = ch < Cin ? xvm[i] : 0u;
   };
-  auto fetch_w1 = [&](int i, int c0) {
-    const int sidx = tid + 512 * i;
-    const int q = sidx % (kWCO / 4), row = sidx / (kWCO / 4);      // row = k * 8 + c
-    const int k = row / kWC, c = row % kWC;
-    rw[i] = *reinterpret_cast<const v4f*>(wp + (static_cast<long long>(k) * cinpad + c0 + c) * copad + co0 + 4 * q);
+  const int wrows = DEPTH ? 3 * cinpad : cinpad;       // rows of U per transform position
+  auto fetch_w1 = [&](int i, int q0) {
+    const int sidx = tid + NT * i;
+    const int q = sidx % (G::kCO / 4), row = sidx / (G::kCO / 4);      // row = k * KC + c
+    const int k = row / KC, c = row % KC;
+    rw[i] = *reinterpret_cast<const v4f*>(wp + (static_cast<long long>(k) * wrows + q0 + c) * copad + co0 + 4 * q);
   };
-  float* const sxb = lds;                               // [2][8][rows][LW]   input tiles
-  float* const swb = lds + 2 * G::kSX;                   // [2][16][8][64]     U = G g G^T of the stage's channels
-  float* const svb = swb + 2 * kSWw;                     // [2][16][8][64]     V = B^T d B of the stage's channels, 64 patches
+  float* const sxb = lds;                               // [2][KC][rows][LW]   input tiles
+  float* const swb = lds + 2 * G::kSX;                   // [2][16][KC][CO]     U = G g G^T of the stage
+  float* const svb = swb + 2 * G::kSW;                   // [2][16][KC][64]     V = B^T d B of the stage, 64 patches
   auto commit_x1 = [&](int i, int buf) {
     float* sx = sxb + buf * G::kSX;
-    const int sidx = tid + 512 * i;
+    const int sidx = tid + NT * i;
     const v4f t = rx[i];
     const int sh = rxs[i];
     const unsigned m = rxm[i];
@@ -139,16 +158,21 @@ __global__ __launch_bounds__(512, 1) void conv2d_3x3_wino(const float* __restric
     for (int e = 0; e < 4; ++e) v[e] = (m >> e) & 1u ? v[e] : 0.0f;
     if (sidx < G::kXN) *reinterpret_cast<v4f*>(sx + 4 * sidx) = v;
   };
+  // U rows are CO floats, unpadded; a read's four 16-lane groups (q = 0..3 of a step) must hit different banks: 64-float rows are
+  // rotated by 16 (q & 3); 32-float rows alternate between the two halves of a 64-bank line by themselves, so q = 1, 2 swap their halves
+  // (distinct modulo 32 within each half-wave and modulo 64 across the wave)
+  auto uswz = [](int q) { return (G::kCO == 64 ? (q & 3) : ((q ^ (q >> 1)) & 1)) << 4; };
   auto commit_w1 = [&](int i, int buf) {
-    float* sw = swb + buf * kSWw;
-    const int sidx = tid + 512 * i;
-    const int q = sidx % (kWCO / 4), row = sidx / (kWCO / 4);
-    *reinterpret_cast<v4f*>(sw + row * kWStr + ((4 * q) ^ ((row & 3) << 4))) = rw[i];
+    float* sw = swb + buf * G::kSW;
+    const int sidx = tid + NT * i;
+    const int q = sidx % (G::kCO / 4), row = sidx / (G::kCO / 4);
+    *reinterpret_cast<v4f*>(sw + row * G::kCO + ((4 * q) ^ uswz(row % KC))) = rw[i];
   };
-  // the input transform: thread -> (channel tid >> 6, patch tid & 63); 8 LDS reads of two floats, 32 additions, 16 LDS writes
+  // the input transform: thread -> (q = tid >> 6, patch = tid & 63)
   const int tc = tid >> 6, tp = tid & 63;
-  const int toff = (tc * G::kRows + 2 * (tp / PC)) * G::kLW + 2 * (tp % PC) + 4;
-  const int voff = tc * kWStr + (tp ^ ((tc & 3) << 4));
+  const int tpc = tp < PR * PC ? tp : PR * PC - 1;      // idle patches (5 x 12 tile) repeat the last one
+  const int toff = (tc * G::kRows + 2 * (tpc / PC)) * G::kLW + 2 * (tpc % PC) + 4;
+  const int voff = tc * 64 + (tp ^ ((tc & 3) << 4));
   float td[4][4], tv[16];
   auto tr_read = [&](int i, int buf) {
     const float* dp = sxb + buf * G::kSX + toff + i * G::kLW;
@@ -172,23 +196,26 @@ __global__ __launch_bounds__(512, 1) void conv2d_3x3_wino(const float* __restric
       tv[i * 4 + 3] = t[i][1] - t[i][3];
     }
   };
-  auto tr_write = [&](int k, int buf) { svb[buf * kSWw + voff + k * kWC * kWStr] = tv[k]; };
+  auto tr_write = [&](int k, int buf) { svb[buf * G::kSV + voff + k * KC * 64] = tv[k]; };
 
-  // operands of the matrix instructions: A = U_k[co = lane & 15][c = lane >> 4], B = V_k[c = lane >> 4][patch = lane & 15]
-  const int aoff = k4 * kWStr + ((cob * 16 + i16) ^ (k4 << 4));
-  const int boff0 = k4 * kWStr + (((2 * hf) * 16 + i16) ^ (k4 << 4)), boff1 = k4 * kWStr + (((2 * hf + 1) * 16 + i16) ^ (k4 << 4));
+  // operands of the matrix instructions: A = U_k[co = lane & 15][q = lane >> 4], B = V_k[q = lane >> 4][patch = lane & 15]
+  const int aoff = k4 * G::kCO + ((cob * 16 + i16) ^ uswz(k4));
+  const int boff0 = k4 * 64 + (((2 * hf) * 16 + i16) ^ (k4 << 4)), boff1 = k4 * 64 + (((2 * hf + 1) * 16 + i16) ^ (k4 << 4));
 
-  const int nstage = (Cin + kWC - 1) / kWC;
+  // the stages: 2D: q = 0, KC, ... < cinpad; 3D: the depth taps whose input plane exists (a contiguous range of q)
+  const int q_lo = DEPTH ? (od == 0 ? cinpad : 0) : 0;
+  const int q_hi = DEPTH ? (od == D - 1 ? 2 * cinpad : 3 * cinpad) : cinpad;
+  const int nstage = (q_hi - q_lo) / KC;
 #pragma unroll
-  for (int i = 0; i < G::kXSl; ++i) fetch_x1(i, 0);
+  for (int i = 0; i < G::kXSl; ++i) fetch_x1(i, q_lo);
 #pragma unroll
-  for (int i = 0; i < kWSl; ++i) fetch_w1(i, 0);
+  for (int i = 0; i < G::kWSl; ++i) fetch_w1(i, q_lo);
 #pragma unroll
   for (int i = 0; i < G::kXSl; ++i) commit_x1(i, 0);
 #pragma unroll
-  for (int i = 0; i < kWSl; ++i) commit_w1(i, 0);
+  for (int i = 0; i < G::kWSl; ++i) commit_w1(i, 0);
 #pragma unroll
-  for (int i = 0; i < G::kXSl; ++i) fetch_x1(i, nstage > 1 ? kWC : 0);
+  for (int i = 0; i < G::kXSl; ++i) fetch_x1(i, nstage > 1 ? q_lo + KC : q_lo);
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < 4; ++i) tr_read(i, 0);
@@ -199,40 +226,40 @@ __global__ __launch_bounds__(512, 1) void conv2d_3x3_wino(const float* __restric
   for (int i = 0; i < G::kXSl; ++i) commit_x1(i, 1);
   __syncthreads();
 
-  // Stage st: 32 steps (channel group cs = t >> 4, transform position k = t & 15) of two matrix instructions each on V / U of stage st.
+  // Stage st: kSteps steps (q group cs = t >> 4, transform position k = t & 15) of two matrix instructions each on V / U of stage st.
   // The operands of step t + 4 are read from LDS before step t issues.  Between the steps, one piece each: the global loads of the
-  // inputs of stage st + 2 and the weights of stage st + 1 (steps 0..5), the input transform of stage st + 1 (LDS reads at steps 6..9,
-  // the additions at 12, LDS writes at 14..21) and the commits of the loaded data to LDS (steps 24..29) - all of them touch buffers the
-  // current stage's products do not read.  The scheduler may not move anything across a step (sched_barrier): it would hoist all reads
-  // and spill.  ONE barrier per stage.
+  // inputs of stage st + 2 and the weights of stage st + 1, the input transform of stage st + 1 (LDS reads, the additions, LDS writes)
+  // and the commits of the loaded data to LDS - all of them touch buffers the current stage's products do not read.  The scheduler may
+  // not move anything across a step (sched_barrier): it would hoist all reads and spill.  ONE barrier per stage.
   auto products = [&](int st, auto fx_tag, auto fw_tag) {
     constexpr bool FX = decltype(fx_tag)::value, FW = decltype(fw_tag)::value;
-    constexpr int kAhead = 4;
-    float ra[32], rb0[32], rb1[32];
-    const float* ap = swb + (st & 1) * kSWw + aoff;
-    const float* bp = svb + (st & 1) * kSWw;
+    constexpr int kAhead = 4, NS = G::kSteps;
+    float ra[NS], rb0[NS], rb1[NS];
+    const float* ap = swb + (st & 1) * G::kSW + aoff;
+    const float* bp = svb + (st & 1) * G::kSV;
     auto load = [&](int t) {
-      const int row = ((t & 15) * kWC + (t >> 4) * 4) * kWStr;
-      ra[t] = ap[row];
-      rb0[t] = bp[row + boff0];
-      rb1[t] = bp[row + boff1];
+      const int row = (t & 15) * KC + (t >> 4) * 4;
+      ra[t] = ap[row * G::kCO];
+      rb0[t] = bp[row * 64 + boff0];
+      rb1[t] = bp[row * 64 + boff1];
     };
     const int nb = (st + 1) & 1;       // the buffers of stage st + 1 (V, U) - and of stage st + 2's inputs: st & 1
+    const int q1 = q_lo + (st + 1) * KC;
 #pragma unroll
     for (int t = 0; t < kAhead; ++t) load(t);
 #pragma unroll
-    for (int t = 0; t < 32; ++t) {
-      if (t + kAhead < 32) load(t + kAhead);
-      if (FX && t < G::kXSl && !(dbg & 4)) fetch_x1(t, (st + 2) * kWC);
-      if (FW && t >= 2 && t < 2 + kWSl && !(dbg & 4)) fetch_w1(t - 2, (st + 1) * kWC);
-      if (FW && t >= 6 && t < 10 && !(dbg & 1)) tr_read(t - 6, nb);
-      if (FW && t == 12 && !(dbg & 1)) tr_compute();
-      if (FW && t >= 14 && t < 22 && !(dbg & 1)) {
-        tr_write(2 * (t - 14), nb);
-        tr_write(2 * (t - 14) + 1, nb);
+    for (int t = 0; t < NS; ++t) {
+      if (t + kAhead < NS) load(t + kAhead);
+      if (FX && t < G::kXSl && !(dbg & 4)) fetch_x1(t, q1 + KC);
+      if (FW && t >= G::kLoadW && t < G::kLoadW + G::kWSl && !(dbg & 4)) fetch_w1(t - G::kLoadW, q1);
+      if (FW && t >= G::kRead && t < G::kRead + 4 && !(dbg & 1)) tr_read(t - G::kRead, nb);
+      if (FW && t == G::kComp && !(dbg & 1)) tr_compute();
+      if (FW && t >= G::kWrite && t < G::kWrite + 16 / G::kWritesPerStep && !(dbg & 1)) {
+#pragma unroll
+        for (int u = 0; u < G::kWritesPerStep; ++u) tr_write(G::kWritesPerStep * (t - G::kWrite) + u, nb);
       }
-      if (FX && t >= 24 && t < 24 + G::kXSl && !(dbg & 8)) commit_x1(t - 24, st & 1);
-      if (FW && t >= 26 && t < 26 + kWSl && !(dbg & 8)) commit_w1(t - 26, nb);
+      if (FX && t >= G::kCommitX && t < G::kCommitX + G::kXSl && !(dbg & 8)) commit_x1(t - G::kCommitX, st & 1);
+      if (FW && t >= G::kCommitW && t < G::kCommitW + G::kWSl && !(dbg & 8)) commit_w1(t - G::kCommitW, nb);
       if (!(dbg & 2)) {
         acc[0][t & 15] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[t], rb0[t], acc[0][t & 15], 0, 0, 0);
         acc[1][t & 15] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[t], rb1[t], acc[1][t & 15], 0, 0, 0);
@@ -255,15 +282,16 @@ __global__ __launch_bounds__(512, 1) void conv2d_3x3_wino(const float* __restric
   }
   products(st, std::false_type{}, std::false_type{});
 
-  const long long MP = static_cast<long long>(Cout) * HW;
-  float* yb = y + b * MP;
-  const float* resb = epi.residual ? epi.residual + b * MP : nullptr;
-  const float* maskb = epi.mask ? epi.mask + b * MP : nullptr;
+  const long long MP = static_cast<long long>(Cout) * DHW;
+  const long long plane0 = static_cast<long long>(od) * HW;
+  float* yb = y + b * MP + plane0;
+  const float* resb = epi.residual ? epi.residual + b * MP + plane0 : nullptr;
+  const float* maskb = epi.mask ? epi.mask + b * MP + plane0 : nullptr;
 #pragma unroll
   for (int blk = 0; blk < 2; ++blk) {
     const int t = (2 * hf + blk) * 16 + i16;
     const int gh = h0 + 2 * (t / PC), gw = w0 + 2 * (t % PC);
-    if (gh >= H || gw >= W) continue;
+    if (t >= PR * PC || gh >= H || gw >= W) continue;
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
       const int co = co0 + cob * 16 + 4 * k4 + reg;
@@ -283,7 +311,7 @@ __global__ __launch_bounds__(512, 1) void conv2d_3x3_wino(const float* __restric
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         if (gh + r >= H) continue;
-        const long long at = static_cast<long long>(co) * HW + static_cast<long long>(gh + r) * W + gw;
+        const long long at = static_cast<long long>(co) * DHW + static_cast<long long>(gh + r) * W + gw;
         const bool two = gw + 1 < W;
         float v0 = o[r][0], v1 = o[r][1];
         if (epi.bias) v0 = v0 + bv, v1 = v1 + bv;
@@ -303,39 +331,77 @@ __global__ __launch_bounds__(512, 1) void conv2d_3x3_wino(const float* __restric
   }
 }
 
-template <int PR, int PC>
-int launch_wino(const float* x, const float* wp, float* y, int b, int cin, int cout, int cinpad, int copad, int h, int w, const EpiW& epi, hipStream_t st) {
-  using G = WGeo<PR, PC>;
+template <int PR, int PC, int COB, int KC, bool DEPTH>
+int launch_wino(const float* x, const float* wp, float* y, int b, int cin, int cout, int cinpad, int copad, int d, int h, int w, const EpiW& epi,
+                hipStream_t st) {
+  using G = WGeo<PR, PC, COB, KC>;
   const int tiles_w = (w + 2 * PC - 1) / (2 * PC), tiles_h = (h + 2 * PR - 1) / (2 * PR);
   const long long tiles = static_cast<long long>(tiles_w) * tiles_h;
-  const int cgroups = (cout + kWCO - 1) / kWCO;
-  if (tiles > 0x7fffffffLL || cgroups > 65535 || b > 65535) return ADV_EINVAL;
-  const size_t lds = 2 * sizeof(float) * static_cast<size_t>(G::kSX + 2 * kSWw);
-  const long long total = static_cast<long long>(b) * cin * h * w;
-  const dim3 grid(static_cast<unsigned>(tiles), cgroups, b);
+  const int cgroups = (cout + G::kCO - 1) / G::kCO;
+  const long long gz = static_cast<long long>(b) * d;
+  if (tiles > 0x7fffffffLL || cgroups > 65535 || gz > 65535) return ADV_EINVAL;
+  const long long total = static_cast<long long>(b) * cin * d * h * w;
+  const dim3 grid(static_cast<unsigned>(tiles), cgroups, static_cast<unsigned>(gz));
 #ifdef ADV_TEST_HOOKS
   if (const char* dbg_s = adv_hook_value("ADV_WINO_DBG")) {      // phase ablation for timing (results are wrong)
-    if (!adv_internal_lds_limit<conv2d_3x3_wino<PR, PC, true>>(lds)) return ADV_ELAUNCH;
-    hipLaunchKernelGGL((conv2d_3x3_wino<PR, PC, true>), grid, dim3(512), lds, st, x, wp, y, cin, cout, cinpad, copad, h, w, tiles_w, total, epi,
-                       std::atoi(dbg_s));
+    if (!adv_internal_lds_limit<conv_wino<PR, PC, COB, KC, DEPTH, true>>(G::kLds)) return ADV_ELAUNCH;
+    hipLaunchKernelGGL((conv_wino<PR, PC, COB, KC, DEPTH, true>), grid, dim3(G::kNT), G::kLds, st, x, wp, y, cin, cout, cinpad, copad, d, h, w, tiles_w,
+                       total, epi, std::atoi(dbg_s));
     return adv_internal_finish_launch();
   }
 #endif
-  if (!adv_internal_lds_limit<conv2d_3x3_wino<PR, PC, false>>(lds)) return ADV_ELAUNCH;
-  hipLaunchKernelGGL((conv2d_3x3_wino<PR, PC, false>), grid, dim3(512), lds, st, x, wp, y, cin, cout, cinpad, copad, h, w, tiles_w, total, epi, 0);
+  if (!adv_internal_lds_limit<conv_wino<PR, PC, COB, KC, DEPTH, false>>(G::kLds)) return ADV_ELAUNCH;
+  hipLaunchKernelGGL((conv_wino<PR, PC, COB, KC, DEPTH, false>), grid, dim3(G::kNT), G::kLds, st, x, wp, y, cin, cout, cinpad, copad, d, h, w, tiles_w,
+                     total, epi, 0);
   return adv_internal_finish_launch();
 }
 
-// U = G g G^T for every (output, input) channel pair, laid out [k = 4 i + j][c' ][m'] (zero rows / columns of padding).
-// forward: m = co, c = ci, g = w[co][ci];  transpose (backward w.r.t. the input): m = ci, c = co, g = w[co][ci] rotated by 180 degrees
-__global__ void conv2d_wino_prep_kernel(const float* __restrict__ w, float* __restrict__ out, int cout, int cin, int transpose, int kpad, int mpad) {
-  const long long n = static_cast<long long>(kpad) * mpad;
+template <bool DEPTH>
+int launch_wino_tile(int t, const float* x, const float* wp, float* y, int b, int cin, int cout, int cinpad, int copad, int d, int h, int w,
+                     const EpiW& epi, hipStream_t st) {
+  switch (t) {
+    case 0: return launch_wino<4, 16, 4, 8, DEPTH>(x, wp, y, b, cin, cout, cinpad, copad, d, h, w, epi, st);
+    case 1: return launch_wino<8, 8, 4, 8, DEPTH>(x, wp, y, b, cin, cout, cinpad, copad, d, h, w, epi, st);
+    case 2: return launch_wino<4, 16, 2, 4, DEPTH>(x, wp, y, b, cin, cout, cinpad, copad, d, h, w, epi, st);
+    case 3: return launch_wino<8, 8, 2, 4, DEPTH>(x, wp, y, b, cin, cout, cinpad, copad, d, h, w, epi, st);
+    case 4: return launch_wino<5, 12, 4, 8, DEPTH>(x, wp, y, b, cin, cout, cinpad, copad, d, h, w, epi, st);
+    default: return launch_wino<5, 12, 2, 4, DEPTH>(x, wp, y, b, cin, cout, cinpad, copad, d, h, w, epi, st);
+  }
+}
+
+// tile: 0 = 8 x 32 outputs x 64 channels, 1 = 16 x 16 x 64, 2 = 8 x 32 x 32 channels, 3 = 16 x 16 x 32, 4 = 10 x 24 x 64, 5 = 10 x 24 x 32
+int pick_wino_tile(int cout, int h, int w) {
+  // 8 x 32 outputs per workgroup (128-byte store runs) unless another shape needs clearly fewer workgroups for the map: 16 x 16 for the
+  // 14 x 14 maps of the box heads (one tile instead of two per image), 10 x 24 for the bird's-eye volumes of 10 / 20 rows;
+  // 32-channel workgroups where 64 would compute a zero block
+  auto tiles = [&](int th, int tw) { return static_cast<long long>((h + th - 1) / th) * ((w + tw - 1) / tw); };
+  const long long t0 = tiles(8, 32) * 10, t1 = tiles(16, 16) * 12, t2 = tiles(10, 24) * 11;      // x 1.2, x 1.1: the handicaps of the other shapes
+  const int shape = (t1 < t0 && t1 <= t2) ? 1 : (t2 < t0 ? 4 : 0);
+  const int narrow = ((cout + 31) / 32) % 2 == 1 ? (shape == 4 ? 1 : 2) : 0;      // an odd number of 32-channel blocks
+  return shape + narrow;
+}
+
+int check_wino_args(const float* x, const float* w_prep, const float* bias, const float* residual, const float* mask, const float* y) {
+  if (residual == y || mask == y || x == y) return ADV_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(x) & 3) || (reinterpret_cast<uintptr_t>(y) & 3) || (reinterpret_cast<uintptr_t>(w_prep) & 15) ||
+      (residual && (reinterpret_cast<uintptr_t>(residual) & 3)) || (mask && (reinterpret_cast<uintptr_t>(mask) & 3)) ||
+      (bias && (reinterpret_cast<uintptr_t>(bias) & 3)))
+    return ADV_EALIGN;
+  return ADV_OK;
+}
+
+// U = G g G^T for every (output, input) channel pair (and depth tap), laid out [k = 4 i + j][kd][c'][m'] (zero rows / columns of
+// padding).  forward: m = co, c = ci, g = w[co][ci][kd];  transpose (backward w.r.t. the input): m = ci, c = co, g = w[co][ci] with all
+// its taps reversed (2 - kd, and the 3x3 slice rotated by 180 degrees).  taps = 1: a 2D layer's [Cout][Cin][3][3] weights.
+__global__ void conv_wino_prep_kernel(const float* __restrict__ w, float* __restrict__ out, int cout, int cin, int taps, int transpose, int kpad,
+                                      int mpad) {
+  const long long n = static_cast<long long>(taps) * kpad * mpad;
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += 256LL * gridDim.x) {
-    const int m = static_cast<int>(i % mpad), c = static_cast<int>(i / mpad);
+    const int m = static_cast<int>(i % mpad), c = static_cast<int>((i / mpad) % kpad), kd = static_cast<int>(i / (static_cast<long long>(mpad) * kpad));
     const int co = transpose ? c : m, ci = transpose ? m : c;
     float u[16];
     if (co < cout && ci < cin) {
-      const float* gp = w + (static_cast<long long>(co) * cin + ci) * 9;
+      const float* gp = w + ((static_cast<long long>(co) * cin + ci) * taps + (transpose ? taps - 1 - kd : kd)) * 9;
       float g[9], t[4][3];
 #pragma unroll
       for (int q = 0; q < 9; ++q) g[q] = gp[transpose ? 8 - q : q];
@@ -365,6 +431,17 @@ __global__ void conv2d_wino_prep_kernel(const float* __restrict__ w, float* __re
 
 int round_up_w(int v, int q) { return (v + q - 1) / q * q; }
 
+int prep_wino(const float* w, float* w_prep, int cout, int cin, int taps, int transpose, hipStream_t st) {
+  if (!w || !w_prep || cout < 1 || cin < 1) return ADV_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(w) & 3) || (reinterpret_cast<uintptr_t>(w_prep) & 15)) return ADV_EALIGN;
+  const int k = transpose ? cout : cin, m = transpose ? cin : cout;
+  const int kpad = round_up_w(k, 8), mpad = round_up_w(m, 64);
+  const long long n = static_cast<long long>(taps) * kpad * mpad;
+  const unsigned blocks = static_cast<unsigned>(n / 256 + 1 < 4096 ? n / 256 + 1 : 4096);
+  hipLaunchKernelGGL(conv_wino_prep_kernel, dim3(blocks), dim3(256), 0, st, w, w_prep, cout, cin, taps, transpose ? 1 : 0, kpad, mpad);
+  return adv_internal_finish_launch();
+}
+
 }  // namespace
 
 extern "C" {
@@ -372,39 +449,41 @@ extern "C" {
 int64_t adv_conv2d_wino_prep_floats(int cout, int cin, int transpose) {
   if (cout < 1 || cin < 1) return ADV_EINVAL;
   const int k = transpose ? cout : cin, m = transpose ? cin : cout;
-  return 16LL * round_up_w(k, kWC) * round_up_w(m, kWCO);
+  return 16LL * round_up_w(k, 8) * round_up_w(m, 64);
 }
 
 int adv_conv2d_wino_prep_weights_f32(const float* w, float* w_prep, int cout, int cin, int transpose, adv_stream_t stream) {
-  if (!w || !w_prep || cout < 1 || cin < 1) return ADV_EINVAL;
-  if ((reinterpret_cast<uintptr_t>(w) & 3) || (reinterpret_cast<uintptr_t>(w_prep) & 15)) return ADV_EALIGN;
-  const int k = transpose ? cout : cin, m = transpose ? cin : cout;
-  const int kpad = round_up_w(k, kWC), mpad = round_up_w(m, kWCO);
-  const long long n = static_cast<long long>(kpad) * mpad;
-  const unsigned blocks = static_cast<unsigned>(n / 256 + 1 < 4096 ? n / 256 + 1 : 4096);
-  hipLaunchKernelGGL(conv2d_wino_prep_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), w, w_prep, cout, cin, transpose ? 1 : 0,
-                     kpad, mpad);
-  return adv_internal_finish_launch();
+  return prep_wino(w, w_prep, cout, cin, 1, transpose, static_cast<hipStream_t>(stream));
 }
 
 int adv_conv2d_wino_f32(const float* x, const float* w_prep, const float* bias, const float* residual, const float* mask, float* y, int b, int cin,
                         int cout, int h, int w, int relu, int tile, adv_stream_t stream) {
-  if (!x || !w_prep || !y || b < 1 || cin < 1 || cout < 1 || h < 1 || w < 1 || tile < -1 || tile > 1) return ADV_EINVAL;
+  if (!x || !w_prep || !y || b < 1 || cin < 1 || cout < 1 || h < 1 || w < 1 || tile < -1 || tile > 5) return ADV_EINVAL;
   if (static_cast<long long>(b) * cin * h * w < 4) return ADV_EINVAL;      // the kernel loads whole float4s (clamped into the tensor)
-  if (residual == y || mask == y || x == y) return ADV_EINVAL;
-  if ((reinterpret_cast<uintptr_t>(x) & 3) || (reinterpret_cast<uintptr_t>(y) & 3) || (reinterpret_cast<uintptr_t>(w_prep) & 15) ||
-      (residual && (reinterpret_cast<uintptr_t>(residual) & 3)) || (mask && (reinterpret_cast<uintptr_t>(mask) & 3)) ||
-      (bias && (reinterpret_cast<uintptr_t>(bias) & 3)))
-    return ADV_EALIGN;
-  EpiW epi{bias, residual, mask, relu ? 1 : 0};
-  const int cinpad = round_up_w(cin, kWC), copad = round_up_w(cout, kWCO);
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  // 8 x 32 outputs per workgroup (128-byte store runs), or 16 x 16 where that wastes fewer patches (the 14 x 14 maps of the box heads:
-  // one tile instead of two per image)
-  auto waste = [&](int th, int tw) { return static_cast<long long>((h + th - 1) / th) * ((w + tw - 1) / tw); };
-  const int t = tile >= 0 ? tile : (waste(16, 16) * 10 < waste(8, 32) * 8 ? 1 : 0);
-  if (t == 1) return launch_wino<8, 8>(x, w_prep, y, b, cin, cout, cinpad, copad, h, w, epi, st);
-  return launch_wino<4, 16>(x, w_prep, y, b, cin, cout, cinpad, copad, h, w, epi, st);
+  if (const int rc = check_wino_args(x, w_prep, bias, residual, mask, y)) return rc;
+  const EpiW epi{bias, residual, mask, relu ? 1 : 0};
+  return launch_wino_tile<false>(tile >= 0 ? tile : pick_wino_tile(cout, h, w), x, w_prep, y, b, cin, cout, round_up_w(cin, 8), round_up_w(cout, 64), 1,
+                                 h, w, epi, static_cast<hipStream_t>(stream));
+}
+
+int64_t adv_conv3d_wino_prep_floats(int cout, int cin, int transpose) {
+  if (cout < 1 || cin < 1) return ADV_EINVAL;
+  const int k = transpose ? cout : cin, m = transpose ? cin : cout;
+  return 48LL * round_up_w(k, 8) * round_up_w(m, 64);
+}
+
+int adv_conv3d_wino_prep_weights_f32(const float* w, float* w_prep, int cout, int cin, int transpose, adv_stream_t stream) {
+  return prep_wino(w, w_prep, cout, cin, 3, transpose, static_cast<hipStream_t>(stream));
+}
+
+int adv_conv3d_wino_f32(const float* x, const float* w_prep, const float* bias, const float* residual, const float* mask, float* y, int b, int cin,
+                        int cout, int d, int h, int w, int relu, int tile, adv_stream_t stream) {
+  if (!x || !w_prep || !y || b < 1 || cin < 1 || cout < 1 || d < 1 || h < 1 || w < 1 || tile < -1 || tile > 5) return ADV_EINVAL;
+  if (static_cast<long long>(b) * cin * d * h * w < 4) return ADV_EINVAL;
+  if (const int rc = check_wino_args(x, w_prep, bias, residual, mask, y)) return rc;
+  const EpiW epi{bias, residual, mask, relu ? 1 : 0};
+  return launch_wino_tile<true>(tile >= 0 ? tile : pick_wino_tile(cout, h, w), x, w_prep, y, b, cin, cout, round_up_w(cin, 8), round_up_w(cout, 64), d,
+                                h, w, epi, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -695,6 +695,54 @@ def conv3d_k3_masked(x, w_prep, cout, mask):
     return y
 
 
+class Conv3dWinoPrep:
+    """a 3x3x3 / stride 1 layer's weights transformed for the Winograd kernel (csrc/wino2d.hip, adv_conv3d_wino_f32): G g G^T per channel
+    pair and depth tap, for the forward and for the backward w.r.t. the input; each made on first use, once"""
+
+    def __init__(self, weight):
+        wt = _feat(weight.detach().contiguous(), "weight")
+        if wt.dim() != 5 or tuple(wt.shape[2:]) != (3, 3, 3):
+            raise ValueError("weight must be [Cout,Cin,3,3,3]")
+        self.cout, self.cin, self._wt, self._u = int(wt.shape[0]), int(wt.shape[1]), wt, {}
+
+    def u(self, transpose):
+        t = self._u.get(bool(transpose))
+        if t is None:
+            n = int(_lib.load().adv_conv3d_wino_prep_floats(self.cout, self.cin, int(transpose)))
+            t = torch.empty((n,), dtype=torch.float32, device=self._wt.device)
+            with _on(self._wt):
+                _lib.call("adv_conv3d_wino_prep_weights_f32", _ptr(self._wt), _ptr(t), self.cout, self.cin, int(transpose), _stream(self._wt))
+            self._u[bool(transpose)] = t
+        return t
+
+
+def _conv3d_wino_call(x, u, cin, cout, bias, residual, relu, mask, tile):
+    xi = _feat(x, "x")
+    if xi.dim() != 5 or xi.shape[1] != cin:
+        raise ValueError("x must be [B,%d,D,H,W]" % cin)
+    b, _, d, h, w = xi.shape
+    y = torch.empty((b, cout, d, h, w), dtype=torch.float32, device=xi.device)
+    if bias is not None:
+        bias = _feat(bias, "bias")
+        if tuple(bias.shape) != (cout,):
+            raise ValueError("bias must be [cout]")
+    with _on(xi):
+        _lib.call("adv_conv3d_wino_f32", _ptr(xi), _ptr(u), None if bias is None else _ptr(bias), _like(residual, y, "residual"), _like(mask, y, "mask"),
+                  _ptr(y), b, cin, cout, d, h, w, int(bool(relu)), int(tile), _stream(xi))
+    return y
+
+
+def conv3d_wino(x, prep, bias=None, residual=None, relu=False, mask=None, tile=-1):
+    """conv3d(x [B,Cin,D,H,W], 3x3x3, stride 1, padding 1) (+ bias) (+ residual) (ReLU) (zeroed where mask <= 0) by the Winograd kernel:
+    2.25x fewer multiply-adds than conv3d_k3, its own order of float operations (oracle: conv3d_wino)"""
+    return _conv3d_wino_call(x, prep.u(False), prep.cin, prep.cout, bias, residual, relu, mask, tile)
+
+
+def conv3d_wino_dgrad(grad, prep, residual=None, mask=None, tile=-1):
+    """the backward w.r.t. the input of the same layer: grad [B,Cout,D,H,W] -> [B,Cin,D,H,W] (+ residual) (zeroed where mask <= 0)"""
+    return _conv3d_wino_call(grad, prep.u(True), prep.cout, prep.cin, None, residual, False, mask, tile)
+
+
 def space_to_depth2(x, out=None):
     """[B,C,D,H,W] -> [B,8C,ceil(D/2),ceil(H/2),ceil(W/2)]: the eight parity sub-volumes side by side in the channel dimension"""
     xi = _feat(x, "x")
@@ -828,15 +876,24 @@ class Conv3dK3(torch.autograd.Function):
     connection, [B,cout,D,H,W]) is added in the same epilogue and receives that gradient unchanged."""
 
     @staticmethod
-    def forward(ctx, x, w_prep, w_prep_t, cout, weight=None, bias=None, relu=False, residual=None, mask_input=False):
+    def forward(ctx, x, w_prep, w_prep_t, cout, weight=None, bias=None, relu=False, residual=None, mask_input=False, wino=None):
         """<round 3> chains, as ops.Conv2dAuto: ``mask_input`` - x is a ReLU output this layer alone consumes, the gradient returned for it
         is already masked with x > 0 (in the dgrad kernel's epilogue); ``relu="consumer"`` - this layer's ReLU mask is applied by its only
-        consumer's backward, not here."""
+        consumer's backward, not here.
+        ``wino`` (a Conv3dWinoPrep of the same weights): each direction is computed by the direct kernel or by the Winograd kernel
+        (csrc/wino2d.hip: 2.25x fewer multiply-adds, same epilogues), whichever measured faster for the layer shape at first use."""
         x = x.contiguous()
         ctx.has_t, ctx.has_res = w_prep_t is not None, residual is not None
         ctx.mask_own, ctx.mask_input = bool(relu) and relu != "consumer", bool(mask_input)
-        ctx.xshape = tuple(x.shape)
-        y = conv3d_k3(x, w_prep, cout, relu=bool(relu), bias=bias, residual=None if residual is None else residual.contiguous())
+        ctx.xshape, ctx.wino = tuple(x.shape), wino
+        res = None if residual is None else residual.contiguous()
+        direct = lambda: conv3d_k3(x, w_prep, cout, relu=bool(relu), bias=bias, residual=res)       # noqa: E731
+        if wino is not None and cout >= 4:
+            by_wino = lambda: conv3d_wino(x, wino, bias, res, bool(relu))                            # noqa: E731
+            key = ("f3", x.shape[1], cout, tuple(x.shape), res is not None, bool(relu))
+            y = by_wino() if _Conv2dChoice.pick(key, {"direct": direct, "wino": by_wino}) == "wino" else direct()
+        else:
+            y = direct()
         ctx.save_for_backward(w_prep_t if ctx.has_t else weight, y if ctx.mask_own else None, x if mask_input else None)
         return y
 
@@ -848,16 +905,26 @@ class Conv3dK3(torch.autograd.Function):
         gres = grad_y if ctx.has_res else None      # the skip connection receives the (masked) gradient as it is
         if ctx.has_t:
             g = grad_y.contiguous()
-            gx = conv3d_k3_masked(g, w, ctx.xshape[1], x_in) if ctx.mask_input else None
-            if gx is None:
-                gx = conv3d_k3(g, w, ctx.xshape[1])
-                if ctx.mask_input:
-                    gx = relu_backward(gx, x_in)
+
+            def direct():
+                gx = conv3d_k3_masked(g, w, ctx.xshape[1], x_in) if ctx.mask_input else None
+                if gx is None:
+                    gx = conv3d_k3(g, w, ctx.xshape[1])
+                    if ctx.mask_input:
+                        gx = relu_backward(gx, x_in)
+                return gx
+
+            if ctx.wino is not None and ctx.xshape[1] >= 4:
+                by_wino = lambda: conv3d_wino_dgrad(g, ctx.wino, mask=x_in if ctx.mask_input else None)      # noqa: E731
+                key = ("b3", ctx.xshape[1], g.shape[1], ctx.xshape, ctx.mask_input)
+                gx = by_wino() if _Conv2dChoice.pick(key, {"direct": direct, "wino": by_wino}) == "wino" else direct()
+            else:
+                gx = direct()
         else:
             gx = torch.nn.grad.conv3d_input(ctx.xshape, w, grad_y, padding=1)
             if ctx.mask_input:
                 gx = relu_backward(gx, x_in)
-        return gx, None, None, None, None, None, None, gres, None
+        return gx, None, None, None, None, None, None, gres, None, None
 
 
 class Conv3dK3S2(torch.autograd.Function):
@@ -976,7 +1043,7 @@ def _conv2d_call(x, prep, w_prep, cin, cout, bias, residual, relu, mask, tile, w
     with _on(xi):
         if wino:
             _lib.call("adv_conv2d_wino_f32", _ptr(xi), _ptr(w_prep), bp, _like(residual, y, "residual"), _like(mask, y, "mask"), _ptr(y), b, cin,
-                      cout, h, w, int(bool(relu)), int(min(tile, 1)), _stream(xi))
+                      cout, h, w, int(bool(relu)), int(tile), _stream(xi))
         elif prep.k == 1:
             _lib.call("adv_conv2d_1x1_f32", _ptr(xi), _ptr(w_prep), bp, _like(residual, y, "residual"), _like(mask, y, "mask"), _ptr(y), b, cin, cout,
                       h * w, int(bool(relu)), int(tile), _stream(xi))
@@ -1070,6 +1137,17 @@ class _Conv2dChoice:
             e1.synchronize()
             best = min(best, e0.elapsed_time(e1))
         return best
+
+    @classmethod
+    def pick(cls, key, fns):
+        """the name of the fastest of ``fns`` (name -> callable) for this key; timed once, cached; inside a stream capture: the first name"""
+        c = cls.cache.get(key)
+        if c is None:
+            if torch.cuda.is_current_stream_capturing():
+                return next(iter(fns))
+            t = {name: cls._time(fn) for name, fn in fns.items()}
+            c = cls.cache[key] = min(t, key=t.get)
+        return c
 
     @classmethod
     def get(cls, key, hip_fn, torch_fn, wino_fn=None):

@@ -462,11 +462,23 @@ ADV_API int adv_conv2d_3x3_f32(const float* x, const float* w_prep, const float*
  *     oracle's orc_conv2d_wino restates this order bit for bit): the caller chooses the route explicitly.
  *     w_prep from adv_conv2d_wino_prep_weights_f32 ([16][cin'][cout'] = G g G^T per channel pair, zero padded to multiples of 8 x 64);
  *     transpose = 1: the backward w.r.t. the input.  bias / residual / relu / mask: as adv_conv2d_1x1_f32.
- *     tile: -1 = by map size, 0 = 8 x 32 outputs per workgroup, 1 = 16 x 16 (same result). */
+ *     tile: -1 = by map size and cout, 0 = 8 x 32 outputs x 64 channels per workgroup, 1 = 16 x 16 x 64, 2 = 8 x 32 x 32 channels (256
+ *     threads, two workgroups per CU), 3 = 16 x 16 x 32, 4 = 10 x 24 x 64, 5 = 10 x 24 x 32 (same result).  Tensors of fewer than four floats: ADV_EINVAL. */
 ADV_API int64_t adv_conv2d_wino_prep_floats(int cout, int cin, int transpose);
 ADV_API int adv_conv2d_wino_prep_weights_f32(const float* w, float* w_prep, int cout, int cin, int transpose, adv_stream_t stream);
 ADV_API int adv_conv2d_wino_f32(const float* x, const float* w_prep, const float* bias, const float* residual, const float* mask,
                                 float* y, int b, int cin, int cout, int h, int w, int relu, int tile, adv_stream_t stream);
+
+/* 3x3x3 / stride 1 / padding 1 convolution (the cost-volume and hourglass layers) by the same Winograd kernel: the transform is applied
+ *     in the (H, W) plane, the three depth taps are part of the contraction (output plane od reads input planes od - 1, od, od + 1; a
+ *     plane outside the volume is skipped) - 48 multiply-adds per 2 x 2 outputs instead of 108.  x [B,cin,D,H,W], y [B,cout,D,H,W];
+ *     w_prep from adv_conv3d_wino_prep_weights_f32 (w [cout][cin][3][3][3] -> [16][3][cin'][cout'], padded to multiples of 8 x 64;
+ *     transpose = 1: all taps reversed, the backward w.r.t. the input).  Its own order of float operations (oracle: orc_conv3d_wino);
+ *     agrees with adv_conv3d_k3_f32 to float32 rounding.  bias / residual / relu / mask / tile: as adv_conv2d_wino_f32.  b * d <= 65535. */
+ADV_API int64_t adv_conv3d_wino_prep_floats(int cout, int cin, int transpose);
+ADV_API int adv_conv3d_wino_prep_weights_f32(const float* w, float* w_prep, int cout, int cin, int transpose, adv_stream_t stream);
+ADV_API int adv_conv3d_wino_f32(const float* x, const float* w_prep, const float* bias, const float* residual, const float* mask,
+                                float* y, int b, int cin, int cout, int d, int h, int w, int relu, int tile, adv_stream_t stream);
 
 /* y [planes = b*c][hw] <- [relu](y + bias[plane % c] + residual), in place, one pass: the epilogue of a convolution computed by another
  *     library (bias / residual NULL = skipped; residual laid out like y, must not be y).  planes <= 65535. */

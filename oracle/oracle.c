@@ -428,6 +428,95 @@ void orc_conv2d_wino(const float* x, const float* w, const float* bias, const fl
   free(U);
 }
 
+/* csrc/wino2d.hip, 3x3x3 layers: the Winograd transform in the (H, W) plane, the depth taps inside the contraction.  Output plane od of
+ * channel m: M[k] = one fmaf chain over q = (kd, c) - kd ascending (a tap whose input plane od + kd - 1 does not exist is skipped),
+ * then c ascending - of U[kd][m][c][k] * V[c][plane][k]; output transform and epilogue as orc_conv2d_wino.
+ * x [B,Kc,D,H,W], w [cout][cin][3][3][3]; transpose: x is grad_out, all taps reversed, the roles of cin / cout swapped. */
+void orc_conv3d_wino(const float* x, const float* w, const float* bias, const float* residual, const float* mask, float* y, int B, int cin,
+                     int cout, int D, int H, int W, int relu, int transpose) {
+  const int M = transpose ? cin : cout, Kc = transpose ? cout : cin;
+  float* U = (float*)malloc(sizeof(float) * 48 * (size_t)M * Kc);   /* [kd][m][c][16] */
+  for (int kd = 0; kd < 3; ++kd)
+    for (int m = 0; m < M; ++m)
+      for (int c = 0; c < Kc; ++c) {
+        float g[9];
+        for (int t = 0; t < 9; ++t)
+          g[t] = transpose ? w[(((long)c * cin + m) * 3 + (2 - kd)) * 9 + (8 - t)] : w[(((long)m * cin + c) * 3 + kd) * 9 + t];
+        wino_u(g, U + (((long)kd * M + m) * Kc + c) * 16);
+      }
+  const int PH = (H + 1) / 2, PW = (W + 1) / 2;
+  const long HW = (long)H * W;
+#pragma omp parallel for collapse(3) schedule(static)
+  for (int b = 0; b < B; ++b)
+    for (int od = 0; od < D; ++od)
+      for (int ph = 0; ph < PH; ++ph) {
+        float* V = (float*)malloc(sizeof(float) * 48 * (size_t)Kc);   /* [kd][c][16] */
+        for (int pw = 0; pw < PW; ++pw) {
+          for (int kd = 0; kd < 3; ++kd) {
+            const int pl = od + kd - 1;
+            if (pl < 0 || pl >= D) continue;
+            for (int c = 0; c < Kc; ++c) {
+              float d[4][4], t[4][4];
+              float* v = V + ((long)kd * Kc + c) * 16;
+              for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 4; ++j) {
+                  const int gh = 2 * ph - 1 + i, gw = 2 * pw - 1 + j;
+                  d[i][j] = (gh >= 0 && gh < H && gw >= 0 && gw < W) ? x[(((long)b * Kc + c) * D + pl) * HW + (long)gh * W + gw] : 0.0f;
+                }
+              for (int j = 0; j < 4; ++j) {
+                t[0][j] = d[0][j] - d[2][j];
+                t[1][j] = d[1][j] + d[2][j];
+                t[2][j] = d[2][j] - d[1][j];
+                t[3][j] = d[1][j] - d[3][j];
+              }
+              for (int i = 0; i < 4; ++i) {
+                v[i * 4 + 0] = t[i][0] - t[i][2];
+                v[i * 4 + 1] = t[i][1] + t[i][2];
+                v[i * 4 + 2] = t[i][2] - t[i][1];
+                v[i * 4 + 3] = t[i][1] - t[i][3];
+              }
+            }
+          }
+          for (int m = 0; m < M; ++m) {
+            float mm[16], s[2][4], o[2][2];
+            for (int k = 0; k < 16; ++k) {
+              float acc = 0.0f;
+              for (int kd = 0; kd < 3; ++kd) {
+                const int pl = od + kd - 1;
+                if (pl < 0 || pl >= D) continue;
+                const float* u = U + (((long)kd * M + m) * Kc) * 16;
+                const float* v = V + ((long)kd * Kc) * 16;
+                for (int c = 0; c < Kc; ++c) acc = fmaf(u[c * 16 + k], v[c * 16 + k], acc);
+              }
+              mm[k] = acc;
+            }
+            for (int j = 0; j < 4; ++j) {
+              s[0][j] = (mm[j] + mm[4 + j]) + mm[8 + j];
+              s[1][j] = (mm[4 + j] - mm[8 + j]) - mm[12 + j];
+            }
+            for (int r = 0; r < 2; ++r) {
+              o[r][0] = (s[r][0] + s[r][1]) + s[r][2];
+              o[r][1] = (s[r][1] - s[r][2]) - s[r][3];
+            }
+            for (int r = 0; r < 2; ++r)
+              for (int q = 0; q < 2; ++q) {
+                const int gh = 2 * ph + r, gw = 2 * pw + q;
+                if (gh >= H || gw >= W) continue;
+                const long at = (((long)b * M + m) * D + od) * HW + (long)gh * W + gw;
+                float acc = o[r][q];
+                if (bias) acc = acc + bias[m];
+                if (residual) acc = acc + residual[at];
+                if (relu) acc = acc > 0.0f ? acc : 0.0f;
+                if (mask) acc = mask[at] > 0.0f ? acc : 0.0f;
+                y[at] = acc;
+              }
+          }
+        }
+        free(V);
+      }
+  free(U);
+}
+
 void orc_conv2d(const float* x, const float* w, const float* bias, const float* residual, const float* mask, float* y, int B, int cin,
                 int cout, int H, int W, int k, int stride, int pad, int dil, int relu, int transpose, int chunk) {
   const int kk = k * k;

@@ -37,6 +37,8 @@ _lib.orc_conv2d.argtypes = [_fp, _fp, ctypes.c_void_p, ctypes.c_void_p, ctypes.c
 _lib.orc_conv2d.restype = None
 _lib.orc_conv2d_wino.argtypes = [_fp, _fp, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _fp] + [ctypes.c_int] * 7
 _lib.orc_conv2d_wino.restype = None
+_lib.orc_conv3d_wino.argtypes = [_fp, _fp, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _fp] + [ctypes.c_int] * 8
+_lib.orc_conv3d_wino.restype = None
 for _f in ("orc_denormalize", "orc_normalize", "orc_pgd_step_norm01", "orc_pgd_step_meansub255", "orc_tensor2im_u8",
            "orc_patch_paste", "orc_patch_update"):
     getattr(_lib, _f).restype = None
@@ -235,6 +237,29 @@ def conv2d_wino(x, w, bias=None, residual=None, mask=None, relu=False, transpose
 
     keep = [opt(bias, (y.shape[1],)), opt(residual, y.shape), opt(mask, y.shape)]
     _lib.orc_conv2d_wino(x, w, keep[0][1], keep[1][1], keep[2][1], y, b, cin, cout, h, ww, int(relu), int(transpose))
+    return y
+
+
+def conv3d_wino(x, w, bias=None, residual=None, mask=None, relu=False, transpose=False):
+    """csrc/wino2d.hip on a 3x3x3 layer in its order of operations (Winograd F(2x2,3x3) in the (H, W) plane, the depth taps inside the
+    contraction): x [B,Cin,D,H,W], w [Cout,Cin,3,3,3] -> [B,Cout,D,H,W] (+ bias, + residual, ReLU, mask); transpose=True: x is grad_out
+    -> the gradient w.r.t. the input"""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    cout, cin = w.shape[0], w.shape[1]
+    b, c, d, h, ww = x.shape
+    assert w.shape[2:] == (3, 3, 3) and c == (cout if transpose else cin)
+    y = np.empty((b, cin if transpose else cout, d, h, ww), np.float32)
+
+    def opt(a, shape):
+        if a is None:
+            return None, None
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        assert a.shape == shape, (a.shape, shape)
+        return a, a.ctypes.data_as(ctypes.c_void_p)
+
+    keep = [opt(bias, (y.shape[1],)), opt(residual, y.shape), opt(mask, y.shape)]
+    _lib.orc_conv3d_wino(x, w, keep[0][1], keep[1][1], keep[2][1], y, b, cin, cout, d, h, ww, int(relu), int(transpose))
     return y
 
 

@@ -459,3 +459,78 @@ def test_hip_masked_dgrad_equals_conv_then_relu_backward(shape):
         (gx,) = torch.autograd.grad(y2, x0, g)
         outs.append(gx)
     assert torch.equal(outs[0], outs[1])
+
+
+# ---- the Winograd route (csrc/wino2d.hip on 3x3x3 layers: transform in the (H, W) plane, depth taps inside the contraction) ----
+def test_oracle_conv3d_wino_matches_torch():
+    import torch.nn.functional as F
+    from oracle import oracle_c as C
+    rs = np.random.RandomState(5)
+    for (b, cin, cout, d, h, w) in ((1, 5, 7, 3, 9, 11), (2, 8, 16, 4, 8, 32), (1, 3, 4, 1, 1, 1), (1, 6, 9, 2, 5, 2)):
+        x = rs.randn(b, cin, d, h, w).astype(np.float32)
+        wt = (rs.randn(cout, cin, 3, 3, 3) * (1.0 / (27 * cin)) ** 0.5).astype(np.float32)
+        bias, res = rs.randn(cout).astype(np.float32), rs.randn(b, cout, d, h, w).astype(np.float32)
+        ref = F.relu(F.conv3d(torch.tensor(x), torch.tensor(wt), torch.tensor(bias), padding=1) + torch.tensor(res)).numpy()
+        assert np.abs(C.conv3d_wino(x, wt, bias, res, relu=True) - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+        g = rs.randn(b, cout, d, h, w).astype(np.float32)
+        refg = torch.nn.grad.conv3d_input(x.shape, torch.tensor(wt), torch.tensor(g), padding=1).numpy()
+        assert np.abs(C.conv3d_wino(g, wt, transpose=True) - refg).max() <= 1e-5 * max(1.0, np.abs(refg).max())
+    x = rs.randn(1, 4, 2, 4, 6).astype(np.float32)
+    wt = (rs.randn(5, 4, 3, 3, 3) * 0.1).astype(np.float32)
+    bias, res, mask = rs.randn(5).astype(np.float32), rs.randn(1, 5, 2, 4, 6).astype(np.float32), rs.randn(1, 5, 2, 4, 6).astype(np.float32)
+    want = np.maximum(C.conv3d_wino(x, wt) + bias[None, :, None, None, None] + res, np.float32(0)) * (mask > 0)
+    assert C.conv3d_wino(x, wt, bias, res, mask, relu=True).tobytes() == (want + np.float32(0)).astype(np.float32).tobytes()
+
+
+# (B, Cin, Cout, D, H, W): channels around the 4 / 8-channel stages and the 16 / 32 / 64-channel blocks, one plane (no depth neighbours),
+# two planes (every plane at a border), odd heights and widths, more than one tile in every direction
+WINO3 = [(1, 8, 32, 3, 8, 32), (2, 3, 32, 2, 19, 63), (1, 32, 32, 4, 9, 40), (1, 64, 64, 3, 13, 41), (1, 12, 70, 1, 9, 33), (1, 5, 7, 5, 3, 2),
+         (1, 9, 9, 2, 1, 1), (1, 17, 40, 3, 17, 65)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", WINO3)
+def test_hip_conv3d_wino_bit_exact_vs_oracle(shape):
+    from oracle import oracle_c as C
+    from eval_driving_safety_amd import ops
+    b, cin, cout, d, h, w = shape
+    rs = np.random.RandomState(sum(shape) + 9)
+    x = rs.randn(b, cin, d, h, w).astype(np.float32)
+    wt = (rs.randn(cout, cin, 3, 3, 3) * (1.0 / (27 * cin)) ** 0.5).astype(np.float32)
+    bias = rs.randn(cout).astype(np.float32)
+    res, mask = rs.randn(b, cout, d, h, w).astype(np.float32), rs.randn(b, cout, d, h, w).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    tx, tw, tb, tr, tm = (torch.tensor(a, device=dev) for a in (x, wt, bias, res, mask))
+    prep = ops.Conv3dWinoPrep(tw)
+    want_plain, want_full = C.conv3d_wino(x, wt), C.conv3d_wino(x, wt, bias, res, mask, relu=True)
+    for tile in (-1, 0, 1, 2, 3, 4, 5):
+        assert ops.conv3d_wino(tx, prep, tile=tile).cpu().numpy().tobytes() == want_plain.tobytes(), tile
+        assert ops.conv3d_wino(tx, prep, tb, tr, True, tm, tile=tile).cpu().numpy().tobytes() == want_full.tobytes(), tile
+    ref = torch.nn.functional.conv3d(tx, tw, tb, padding=1)
+    assert float((ops.conv3d_wino(tx, prep, tb) - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max()))
+    g, gres = rs.randn(b, cout, d, h, w).astype(np.float32), rs.randn(b, cin, d, h, w).astype(np.float32)
+    tg, tgr = torch.tensor(g, device=dev), torch.tensor(gres, device=dev)
+    assert ops.conv3d_wino_dgrad(tg, prep).cpu().numpy().tobytes() == C.conv3d_wino(g, wt, transpose=True).tobytes()
+    want_b = C.conv3d_wino(g, wt, residual=gres, mask=x, transpose=True)
+    for tile in (0, 1, 2, 3, 4, 5):
+        assert ops.conv3d_wino_dgrad(tg, prep, residual=tgr, mask=tx, tile=tile).cpu().numpy().tobytes() == want_b.tobytes(), tile
+    refg = torch.nn.grad.conv3d_input(x.shape, tw, tg, padding=1)
+    assert float((ops.conv3d_wino_dgrad(tg, prep) - refg).abs().max()) <= 1e-4 * max(1.0, float(refg.abs().max()))
+
+
+@pytest.mark.gpu
+def test_hip_conv3d_wino_layer_shapes_full_size_agree_with_the_direct_kernel():
+    """the cost-volume layers at their real size: Winograd route vs the direct float32-MFMA kernel (different order of operations, same
+    operator): within 1e-4 of each other, forward and backward"""
+    from eval_driving_safety_amd import ops
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(21)
+    for cin, cout, dims in ((32, 32, (48, 96, 312)), (64, 32, (24, 96, 312)), (64, 64, (24, 48, 156)), (128, 128, (24, 10, 152))):
+        x = torch.randn((1, cin) + dims, device=dev, generator=gen)
+        wt = torch.randn((cout, cin, 3, 3, 3), device=dev, generator=gen) * (1.0 / (27 * cin)) ** 0.5
+        prep = ops.Conv3dWinoPrep(wt)
+        y, ref = ops.conv3d_wino(x, prep, relu=True), ops.conv3d_k3(x, ops.conv3d_k3_prep(wt), cout, relu=True)
+        assert float((y - ref).abs().max()) <= 1e-4 * float(ref.abs().max()), (cin, cout, dims)
+        g = torch.randn_like(ref)
+        gx, refg = ops.conv3d_wino_dgrad(g, prep), ops.conv3d_k3(g, ops.conv3d_k3_prep(wt, transpose=True), cin)
+        assert float((gx - refg).abs().max()) <= 1e-4 * float(refg.abs().max()), (cin, cout, dims)
