@@ -213,6 +213,8 @@ __device__ __forceinline__ float over_count(float v, float count, float inv, boo
 
 // one roi's contributions to this lane's pixel, classified by the lane itself (the round-2 formulation: every lane tests its
 // candidate rows x candidate columns) - the path of a lane whose row or column list does not fit the shared LDS lists
+__host__ __device__ __forceinline__ int cpad(int c) { return (c + 7) & ~7; }     // channels of the channel-last copy: zero padded to 8
+
 template <int CB>
 __device__ __forceinline__ void roi_direct(float (&acc)[CB], const Bin& b, const float* __restrict__ gout, int r, int C, int c0, int H, int W, int PH,
                                            int PW, int py, int px) {
@@ -234,11 +236,11 @@ __device__ __forceinline__ void roi_direct(float (&acc)[CB], const Bin& b, const
       if (!ax.valid || !(ax.hit_low || ax.hit_high)) continue;
       // taps 1..4 of this sample = (y_low,x_low) (y_low,x_high) (y_high,x_low) (y_high,x_high), in that order
       const float w1 = ay.w_low * ax.w_low, w2 = ay.w_low * ax.w_high, w3 = ay.w_high * ax.w_low, w4 = ay.w_high * ax.w_high;
-      const float* g = gout + ((static_cast<long long>(r) * C + c0) * PH + ph) * PW + pw;
+      const float* g = gout + ((static_cast<long long>(r) * PH + ph) * PW + pw) * cpad(C) + c0;      // channel-last copy of grad_out
 #pragma unroll
       for (int c = 0; c < CB; ++c) {
         if (c0 + c < C) {
-          const float gv = g[static_cast<long long>(c) * PH * PW];
+          const float gv = g[c];
           if (ay.hit_low && ax.hit_low) acc[c] = acc[c] + over_count(gv * w1, count, inv, pow2);
           if (ay.hit_low && ax.hit_high) acc[c] = acc[c] + over_count(gv * w2, count, inv, pow2);
           if (ay.hit_high && ax.hit_low) acc[c] = acc[c] + over_count(gv * w3, count, inv, pow2);
@@ -260,7 +262,7 @@ __device__ __forceinline__ void roi_direct(float (&acc)[CB], const Bin& b, const
 // large maps, fewer on the small pyramid levels, where 6-20 tiles x C/8 channel blocks left most of the chip idle behind a few
 // hundred-roi lists (profiles/r03_r101_kernel_stats.csv: 9.9 ms per call before, 69 of the 157 ms of the R101-shaped step).
 constexpr int kRoiBatch = 6;   // 6 x (8 rows + 32 columns) = 240 classifying lanes
-constexpr int kListCap = 8;
+constexpr int kListCap = 16;  // taps on one pixel per axis: 2 * pooled / roi_size + 1 - 16 covers a 14-bin grid on rois from 2 pixels up (8 sent the narrow proposals to roi_direct: 10x slower)
 
 struct AxisList {
   int n;                       // tap hits on the pixel (may exceed kListCap: then the entries are not used)
@@ -343,8 +345,8 @@ __device__ __forceinline__ void roi_bwd_body(AxisList (*s_list)[kTileY + kTileX]
         // issued together and only then consumed in order.  One sample per trip left every trip waiting a full L2 round trip for its
         // own gathers (one wave per SIMD on a hot tile, nothing else to run): 20 k cycles per roi on a tile that 500 clustered rois reach.
         const int ns = ny * nx;
-        const long long cstride = static_cast<long long>(PH) * PW;
-        const float* gbase = gout + (static_cast<long long>(r) * C + c0) * cstride;
+        const int cp = cpad(C);
+        const float* gbase = gout + static_cast<long long>(r) * PH * PW * cp + c0;      // channel-last copy: a lane's CB channels are ONE load
         // two copies of the loop, chosen per roi (uniform): with `v * inv` only, or with the IEEE division only - left as a select the
         // compiler evaluated BOTH for each of the 32 contributions of a sample (12 instructions of division each)
         auto samples = [&](auto pow2_c) {
@@ -356,9 +358,17 @@ __device__ __forceinline__ void roi_bwd_body(AxisList (*s_list)[kTileY + kTileX]
             const int sidx = min(s0 + u, ns - 1);
             const int iy = sidx / nx, ix = sidx - iy * nx;
             wgt[u] = yl.w[iy] * xl.w[ix];
-            const float* g = gbase + static_cast<long long>(yl.bin[iy]) * PW + xl.bin[ix];
+            const float* g = gbase + (static_cast<long long>(yl.bin[iy]) * PW + xl.bin[ix]) * cp;
+            if constexpr (CB % 4 == 0) {
 #pragma unroll
-            for (int c = 0; c < CB; ++c) gv[u][c] = (c0 + c < C) ? g[c * cstride] : 0.0f;
+              for (int q = 0; q < CB / 4; ++q) {
+                const float4 v4 = *reinterpret_cast<const float4*>(g + 4 * q);
+                gv[u][4 * q] = v4.x, gv[u][4 * q + 1] = v4.y, gv[u][4 * q + 2] = v4.z, gv[u][4 * q + 3] = v4.w;
+              }
+            } else {
+#pragma unroll
+              for (int c = 0; c < CB; ++c) gv[u][c] = g[c];      // (the padding channels hold zeros)
+            }
           }
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
@@ -383,6 +393,24 @@ __device__ __forceinline__ void roi_bwd_body(AxisList (*s_list)[kTileY + kTileX]
   }
 }
 
+// grad_out [R][C][S = PH*PW] -> channel-last [R][S][C'] (C' = C padded to 8 with zeros): the gather reads a lane's block of channels of
+// one bin as one 16 / 32-byte load instead of CB loads S floats apart.  One workgroup per (roi, 32 channels): 32 x S contiguous floats in,
+// S rows of 32 floats out.
+__global__ __launch_bounds__(kBlock) void roi_gout_channel_last(const float* __restrict__ gout, float* __restrict__ out, int C, int S) {
+  extern __shared__ float s_t[];                 // [32][S + 1]
+  const int r = blockIdx.x, c0 = blockIdx.y * 32, cp = cpad(C);
+  const int nc = min(32, C - c0);
+  const float* src = gout + (static_cast<long long>(r) * C + c0) * S;
+  for (int i = threadIdx.x; i < nc * S; i += kBlock) s_t[(i / S) * (S + 1) + i % S] = src[i];
+  __syncthreads();
+  float* dst = out + static_cast<long long>(r) * S * cp + c0;
+  const int ncp = min(32, cp - c0);              // the zero padding belongs to the last block
+  for (int i = threadIdx.x; i < S * 32; i += kBlock) {
+    const int sidx = i / 32, c = i % 32;
+    if (c < ncp) dst[static_cast<long long>(sidx) * cp + c] = c < nc ? s_t[c * (S + 1) + sidx] : 0.0f;
+  }
+}
+
 template <int CB>
 __global__ __launch_bounds__(kBlock) void roi_align_bwd_gather(const float* __restrict__ gout, const float* __restrict__ rois,
                                                                const int* __restrict__ lists, float* __restrict__ gfeat, int C, int H, int W,
@@ -392,6 +420,193 @@ __global__ __launch_bounds__(kBlock) void roi_align_bwd_gather(const float* __re
   __shared__ Bin s_bin[kRoiBatch];
   roi_bwd_body<CB>(s_list, s_bin, static_cast<int>(blockIdx.y) * CB, gout, rois, lists, gfeat, C, H, W, R, tiles_y, tiles_x, PH, PW, scale,
                    sampling_ratio, dbg);
+}
+
+// <round 3, second formulation> The gather above keeps a pixel's accumulators in the registers of the lane that owns the pixel: for the
+// narrow proposals a detector really produces (4 x 13 pixels at the pyramid level) a roi touches ~10 of a wave's 64 pixels and the
+// wave runs the whole sample loop at 15 % lane utilisation, once per block of 8 channels (and classifies the roi again for each of
+// the 32 channel blocks).  Here the tile's accumulators live in LDS, [256 pixels][32 channels], and the lanes are handed WORK ITEMS
+// = (pixel the roi touches, channel): a half-wave owns one pixel, its 32 lanes the 32 channels - every lane busy, the 32 channels of
+// a bin one 128-byte load from the channel-last copy of grad_out, the classification once per 32 channels.  Rois are taken in list
+// order with a barrier between them, an item adds its roi's samples to the pixel in (row entry, column entry) order: the same float
+// operations in the same order as the register formulation and the oracle.
+constexpr int kLdsBatch = 4;
+constexpr int kStageBins = 196;     // grad_out blocks of up to 14 x 14 bins are staged in LDS (two buffers); larger grids gather from global memory
+
+// STAGE: the roi's block of grad_out - [PH*PW bins][32 channels] of the channel-last copy, 6 KB for 7 x 7 bins, 25 KB for 14 x 14 - is
+// copied into LDS by all 256 lanes at once (one round of coalesced 16-byte loads) while the PREVIOUS roi's items are being summed, and
+// the sample loops read LDS.  Gathering straight from global memory left each half-wave waiting a full L2 round trip per four
+// samples with only 8 pixels in flight per workgroup: 25-35 us per roi on the tile's serial chain (profiles/r03_roi_bwd.jsonl).
+template <bool STAGE, int kAccChan>     // kAccChan channels per workgroup: a roi's items are (touched pixel, channel), 256 / kAccChan pixels at a time
+__global__ __launch_bounds__(kBlock) void roi_align_bwd_lds(const float* __restrict__ gcl, const float* __restrict__ rois,
+                                                            const int* __restrict__ lists, float* __restrict__ gfeat, int C, int H, int W, int R,
+                                                            int tiles_y, int tiles_x, int PH, int PW, float scale, int sampling_ratio, int dbg) {
+  __shared__ AxisList s_list[kLdsBatch][kTileY + kTileX];
+  __shared__ Bin s_bin[kLdsBatch];
+  __shared__ int s_rect[kLdsBatch][4];            // first touched row, rows, first touched column, columns (tile-local)
+  constexpr int kAccStride = kAccChan + 1;
+  __shared__ float s_acc[kTileY * kTileX * kAccStride];
+  extern __shared__ __attribute__((aligned(16))) float s_g[];     // STAGE: [2][PH*PW][kAccChan]
+  const int tile = blockIdx.x, img = blockIdx.z, c0 = blockIdx.y * kAccChan;
+  const int tid = static_cast<int>(threadIdx.x);
+  const int ty0 = (tile / tiles_x) * kTileY, tx0 = (tile % tiles_x) * kTileX;
+  const int* list = lists + (static_cast<long long>(img) * tiles_y * tiles_x + tile) * (R + 1);
+  const int n_list = list[0];
+  for (int i = tid; i < kTileY * kTileX * kAccStride; i += kBlock) s_acc[i] = 0.0f;
+  const int cb = tid / (kTileY + kTileX), ca = tid % (kTileY + kTileX);
+  const int cp = cpad(C);
+  const int lane_c = tid % kAccChan;              // this lane's channel of an item
+  const bool chan_ok = c0 + lane_c < C;
+  const int bins = PH * PW, nf4 = bins * (kAccChan / 4);
+  constexpr int kStageSlots = (kStageBins * (kAccChan / 4) + kBlock - 1) / kBlock;   // float4 per lane of a staged block (7)
+  float4 stage[kStageSlots];
+  // (c0 + 32 <= cp always: cp is a multiple of 8 and the block's channels beyond C are zero padding or, past cp, never loaded)
+  auto stage_load = [&](int r) {
+#pragma unroll
+    for (int i = 0; i < kStageSlots; ++i) {
+      const int f = tid + kBlock * i, bin = f / (kAccChan / 4), q = f % (kAccChan / 4);
+      stage[i] = (f < nf4 && c0 + 4 * q < cp) ? *reinterpret_cast<const float4*>(gcl + (static_cast<long long>(r) * bins + bin) * cp + c0 + 4 * q)
+                                               : float4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+  };
+  auto stage_store = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < kStageSlots; ++i) {
+      const int f = tid + kBlock * i;
+      if (f < nf4) *reinterpret_cast<float4*>(s_g + buf * bins * kAccChan + 4 * f) = stage[i];
+    }
+  };
+  for (int l0 = 0; l0 < n_list; l0 += kLdsBatch) {
+    const int nb = min(kLdsBatch, n_list - l0);
+    __syncthreads();                              // the previous batch's lists are no longer read (and the zeroing above is done)
+    if (STAGE) stage_load(list[1 + l0]);          // the batch's first roi: its block travels while the lanes classify
+    if (cb < nb) {                                // classification: as in roi_bwd_body
+      const int r = list[1 + l0 + cb];
+      const Bin b = bin_of(rois + static_cast<long long>(r) * 5, scale, PH, PW, sampling_ratio);
+      if (ca == 0) s_bin[cb] = b;
+      const bool is_y = ca < kTileY;
+      const int pixel = is_y ? ty0 + ca : tx0 + (ca - kTileY), size = is_y ? H : W;
+      const float start = is_y ? b.start_h : b.start_w, bin = is_y ? b.bin_h : b.bin_w;
+      const int grid = is_y ? b.grid_h : b.grid_w, pooled = is_y ? PH : PW;
+      AxisList& out = s_list[cb][ca];
+      int n = 0;
+      if (pixel < size && !(dbg & 2)) {
+        int k_lo, k_hi;
+        cand_range(start, bin / static_cast<float>(grid), pooled * grid, pixel, size, &k_lo, &k_hi);
+        for (int k = k_lo; k <= k_hi; ++k) {
+          const int pb = k / grid, ik = k - pb * grid;
+          const float v = start + static_cast<float>(pb) * bin + (static_cast<float>(ik) + 0.5f) * bin / static_cast<float>(grid);
+          const Axis1 a = axis_taps(size, v, pixel);
+          if (!a.valid || !(a.hit_low || a.hit_high)) continue;
+          if (a.hit_low) {
+            if (n < kListCap) out.bin[n] = pb, out.w[n] = a.w_low;
+            ++n;
+          }
+          if (a.hit_high) {
+            if (n < kListCap) out.bin[n] = pb, out.w[n] = a.w_high;
+            ++n;
+          }
+        }
+      }
+      out.n = n;
+    }
+    if (STAGE) stage_store(0);
+    __syncthreads();
+    if (tid < nb) {                               // the rectangle of tile pixels roi `tid` of the batch touches
+      int y_lo = kTileY, y_hi = -1, x_lo = kTileX, x_hi = -1;
+      for (int i = 0; i < kTileY; ++i)
+        if (s_list[tid][i].n > 0) y_lo = min(y_lo, i), y_hi = i;
+      for (int i = 0; i < kTileX; ++i)
+        if (s_list[tid][kTileY + i].n > 0) x_lo = min(x_lo, i), x_hi = i;
+      s_rect[tid][0] = y_lo, s_rect[tid][1] = y_hi - y_lo + 1, s_rect[tid][2] = x_lo, s_rect[tid][3] = x_hi - x_lo + 1;
+    }
+    __syncthreads();
+    for (int k = 0; k < nb; ++k) {
+      const int rows = s_rect[k][1], cols = s_rect[k][3];
+      if (STAGE && k + 1 < nb) stage_load(list[1 + l0 + k + 1]);       // the next roi's block, into registers
+      if (rows > 0 && cols > 0 && !(dbg & 1)) {
+        const int y_lo = s_rect[k][0], x_lo = s_rect[k][2];
+        const int r = list[1 + l0 + k];
+        const Bin& b = s_bin[k];
+        const int cnt = b.grid_h * b.grid_w;
+        const float count = static_cast<float>(cnt), inv = 1.0f / count;
+        const bool pow2 = (cnt & (cnt - 1)) == 0;
+        const float* gbase = gcl + static_cast<long long>(r) * bins * cp + c0 + lane_c;
+        const float* sbase = s_g + (k & 1) * bins * kAccChan + lane_c;
+        for (int p = tid / kAccChan; p < rows * cols; p += kBlock / kAccChan) {   // 256 / kAccChan pixels at a time
+          const int ly = y_lo + p / cols, lx = x_lo + p % cols;
+          const AxisList& yl = s_list[k][ly];
+          const AxisList& xl = s_list[k][kTileY + lx];
+          const int ny = yl.n, nx = xl.n;
+          if (ny == 0 || nx == 0 || !chan_ok) continue;
+          float* slot = s_acc + (ly * kTileX + lx) * kAccStride + lane_c;
+          float acc = *slot;
+          if (ny > kListCap || nx > kListCap) {                           // more taps than the lists hold: classify per sample
+            float one[1] = {acc};
+            roi_direct<1>(one, b, gcl, r, C, c0 + lane_c, H, W, PH, PW, ty0 + ly, tx0 + lx);
+            *slot = one[0];
+            continue;
+          }
+          const int ns = ny * nx;
+          auto samples = [&](auto pow2_c) {
+            constexpr bool kPow2 = decltype(pow2_c)::value;
+            if (STAGE) {                                                  // LDS is close: plain nested loops, no index arithmetic
+              // the column entries once per item, in registers (every row of samples reuses them); then four LDS reads in flight per
+              // step and four ordered additions - a plain loop made every sample wait for two dependent LDS round trips
+              int xb[kListCap];
+              float xw[kListCap];
+#pragma unroll
+              for (int i = 0; i < kListCap; ++i) {
+                xb[i] = i < nx ? xl.bin[i] * kAccChan : 0;
+                xw[i] = i < nx ? xl.w[i] : 0.0f;
+              }
+              for (int iy = 0; iy < ny; ++iy) {
+                const float wy = yl.w[iy];
+                const float* row = sbase + yl.bin[iy] * PW * kAccChan;
+#pragma unroll
+                for (int i0 = 0; i0 < kListCap; i0 += 4) {
+                  if (i0 >= nx) break;
+                  float gv[4];
+#pragma unroll
+                  for (int u = 0; u < 4; ++u) gv[u] = row[xb[i0 + u]];
+#pragma unroll
+                  for (int u = 0; u < 4; ++u)
+                    if (i0 + u < nx) acc = acc + over_count(gv[u] * (wy * xw[i0 + u]), count, inv, kPow2);
+                }
+              }
+              return;
+            }
+            for (int s0 = 0; s0 < ns; s0 += 4) {                          // four gathers in flight, consumed in order
+              float gv[4], wgt[4];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                const int sidx = min(s0 + u, ns - 1);
+                const int iy = sidx / nx, ix = sidx - iy * nx;
+                wgt[u] = yl.w[iy] * xl.w[ix];
+                const int bin = yl.bin[iy] * PW + xl.bin[ix];
+                gv[u] = STAGE ? sbase[bin * kAccChan] : gbase[static_cast<long long>(bin) * cp];
+              }
+#pragma unroll
+              for (int u = 0; u < 4; ++u)
+                if (s0 + u < ns) acc = acc + over_count(gv[u] * wgt[u], count, inv, kPow2);
+            }
+          };
+          if (dbg & 4) {
+          } else if (pow2) samples(std::true_type{});
+          else samples(std::false_type{});
+          *slot = acc;
+        }
+      }
+      if (STAGE && k + 1 < nb) stage_store((k + 1) & 1);              // (buffer (k + 1) & 1 was last read by roi k - 1: a barrier ago)
+      __syncthreads();                            // the next roi may touch the same pixels through other lanes
+    }
+  }
+  __syncthreads();
+  const int py = ty0 + tid / kTileX, px = tx0 + tid % kTileX;
+  if (py < H && px < W) {
+    for (int c = 0; c < kAccChan && c0 + c < C; ++c)
+      gfeat[((static_cast<long long>(img) * C + c0 + c) * H + py) * W + px] = s_acc[tid * kAccStride + c];
+  }
 }
 
 // ---- NMS: wave64 suppression masks.  Block (row tile i, col tile j), 64 lanes: lane l owns box 64*i + l and
@@ -482,10 +697,11 @@ int adv_roi_align_fwd_f32(const float* feat, const float* rois, float* out, int 
   return finish();
 }
 
-int64_t adv_roi_align_bwd_workspace_ints(int b, int h, int w, int r) {
-  if (b < 1 || h < 1 || w < 1 || r < 0) return 0;
+int64_t adv_roi_align_bwd_workspace_ints(int b, int c, int h, int w, int r, int ph, int pw) {
+  if (b < 1 || c < 1 || h < 1 || w < 1 || r < 0 || ph < 1 || pw < 1) return 0;
   const long long tiles = static_cast<long long>((h + kTileY - 1) / kTileY) * ((w + kTileX - 1) / kTileX);
-  return static_cast<int64_t>(b) * tiles * (r + 1);
+  const long long lists = (static_cast<long long>(b) * tiles * (r + 1) + 3) & ~3LL;
+  return lists + static_cast<long long>(ph) * pw * r * cpad(c);            // + the channel-last copy of grad_out
 }
 
 int adv_roi_align_bwd_f32(const float* grad_out, const float* rois, float* grad_feat, int b, int c, int h, int w, int r, int ph,
@@ -496,6 +712,10 @@ int adv_roi_align_bwd_f32(const float* grad_out, const float* rois, float* grad_
   if (!aligned4(workspace)) return ADV_EALIGN;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int tiles_y = (h + kTileY - 1) / kTileY, tiles_x = (w + kTileX - 1) / kTileX;
+  if (static_cast<long long>(ph) * pw > 1500) return ADV_EINVAL;      // the transposing kernel stages 32 x ph*pw floats in LDS
+  float* gcl = reinterpret_cast<float*>(workspace) + ((static_cast<long long>(b) * tiles_y * tiles_x * (r + 1) + 3) & ~3LL);
+  if (r > 0)
+    hipLaunchKernelGGL(roi_gout_channel_last, dim3(r, (c + 31) / 32), dim3(kBlock), sizeof(float) * 32 * (ph * pw + 1), st, grad_out, gcl, c, ph * pw);
   // every element of grad_feat is written by its owning lane (zeros where no roi reaches): no memset needed
   hipLaunchKernelGGL(roi_tile_lists, dim3(tiles_y * tiles_x, b), dim3(64), 0, st, rois, r, h, w, tiles_y, tiles_x, ph, pw, spatial_scale,
                      sampling_ratio, reinterpret_cast<int*>(workspace));
@@ -503,11 +723,36 @@ int adv_roi_align_bwd_f32(const float* grad_out, const float* rois, float* grad_
   const long long tiles = static_cast<long long>(tiles_y) * tiles_x * b;
   const char* dbg_s = adv_hook_value("ADV_ROI_DBG");
   const int dbg = dbg_s ? dbg_s[0] - '0' : 0;
+  if (!adv_hook("ADV_ROI_BWD_REGS")) {            // the shipped route: accumulators in LDS, lanes = (touched pixel, channel)
+    const char* dbg2_s = adv_hook_value("ADV_ROI_DBG");
+    const int dbg = dbg2_s ? dbg2_s[0] - '0' : 0;
+    const char* ac_s = adv_hook_value("ADV_ROI_ACC_CHAN");
+    const int ac = ac_s ? std::atoi(ac_s) : 16;      // 16 channels per workgroup: the fastest of 8 / 16 / 32 on the R101-shaped proposals (profiles/r03_roi_bwd.jsonl)
+    const bool stage = ph * pw <= kStageBins && !adv_hook("ADV_ROI_BWD_NO_STAGE");
+#define ADV_LAUNCH_ROI_LDS(AC_)                                                                                                               \
+  do {                                                                                                                                        \
+    const dim3 grid(tiles_y * tiles_x, (c + AC_ - 1) / AC_, b);                                                                               \
+    if (stage) {                                                                                                                              \
+      const size_t dyn = 2 * sizeof(float) * static_cast<size_t>(ph) * pw * AC_;                                                              \
+      if (!adv_internal_lds_limit<roi_align_bwd_lds<true, AC_>>(2 * sizeof(float) * kStageBins * AC_)) return ADV_ELAUNCH;                    \
+      hipLaunchKernelGGL((roi_align_bwd_lds<true, AC_>), grid, dim3(kBlock), dyn, st, gcl, rois, reinterpret_cast<const int*>(workspace),     \
+                         grad_feat, c, h, w, r, tiles_y, tiles_x, ph, pw, spatial_scale, sampling_ratio, dbg);                                \
+    } else {                                                                                                                                  \
+      hipLaunchKernelGGL((roi_align_bwd_lds<false, AC_>), grid, dim3(kBlock), 0, st, gcl, rois, reinterpret_cast<const int*>(workspace),      \
+                         grad_feat, c, h, w, r, tiles_y, tiles_x, ph, pw, spatial_scale, sampling_ratio, dbg);                                \
+    }                                                                                                                                         \
+  } while (0)
+    if (ac == 32) ADV_LAUNCH_ROI_LDS(32);
+    else if (ac == 16) ADV_LAUNCH_ROI_LDS(16);
+    else ADV_LAUNCH_ROI_LDS(8);
+#undef ADV_LAUNCH_ROI_LDS
+    return finish();
+  }
   int cb = kChanBlock;
   while (cb > 1 && tiles * ((c + cb - 1) / cb) < 2048) cb >>= 1;
   if (adv_hook("ADV_ROI_BWD_CB8")) cb = kChanBlock;
 #define ADV_LAUNCH_ROI_BWD(CB_)                                                                                                             \
-  hipLaunchKernelGGL(roi_align_bwd_gather<CB_>, dim3(tiles_y * tiles_x, (c + CB_ - 1) / CB_, b), dim3(kBlock), 0, st, grad_out, rois,          \
+  hipLaunchKernelGGL(roi_align_bwd_gather<CB_>, dim3(tiles_y * tiles_x, (c + CB_ - 1) / CB_, b), dim3(kBlock), 0, st, gcl, rois,                \
                      reinterpret_cast<const int*>(workspace), grad_feat, c, h, w, r, tiles_y, tiles_x, ph, pw, spatial_scale, sampling_ratio, dbg)
   if (cb == 8) ADV_LAUNCH_ROI_BWD(8);
   else if (cb == 4) ADV_LAUNCH_ROI_BWD(4);

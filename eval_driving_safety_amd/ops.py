@@ -547,7 +547,7 @@ def roi_align_bwd(grad_out, rois, feat_shape, spatial_scale, sampling_ratio=0):
     if g.dim() != 4 or g.shape[0] != r.shape[0] or g.shape[1] != c:
         raise ValueError("grad_out must be [R,C,PH,PW]")
     gf = torch.empty((b, c, h, w), dtype=torch.float32, device=g.device)
-    work = torch.empty((max(1, int(_lib.load().adv_roi_align_bwd_workspace_ints(b, h, w, r.shape[0]))),), dtype=torch.int32, device=g.device)
+    work = torch.empty((max(1, int(_lib.load().adv_roi_align_bwd_workspace_ints(b, c, h, w, r.shape[0], g.shape[2], g.shape[3]))),), dtype=torch.int32, device=g.device)
     with _on(g):
         _lib.call("adv_roi_align_bwd_f32", _ptr(g), _ptr(r), _ptr(gf), b, c, h, w, r.shape[0], g.shape[2], g.shape[3],
                   float(spatial_scale), int(sampling_ratio), _ptr(work), _stream(g))

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ADV_ABI_VERSION 5
+#define ADV_ABI_VERSION 6
 #define ADV_API __attribute__((visibility("default"))) /* the library is built with -fvisibility=hidden */
 #define ADV_CHANNELS 3
 
@@ -262,9 +262,10 @@ ADV_API int adv_roi_align_fwd_f32(const float* feat, const float* rois, float* o
 /* RoIAlign backward, deterministic: every element of grad_feat [B,C,H,W] is written (no memset needed) as the float32 sum,
  *     in ONE fixed order - roi index, sample row, sample column, tap 1..4 - of the contributions
  *     grad_out[r,c,ph,pw] * weight / count of the samples whose bilinear taps touch it.  No float atomics: two runs give
- *     the same bits, and the result equals the oracle's ordered sum bit for bit.  workspace: DEVICE int32,
- *     adv_roi_align_bwd_workspace_ints(b, h, w, r) elements (per 8 x 32-pixel tile the ascending list of rois that reach it). */
-ADV_API int64_t adv_roi_align_bwd_workspace_ints(int b, int h, int w, int r);
+ *     the same bits, and the result equals the oracle's ordered sum bit for bit.  workspace: DEVICE,
+ *     adv_roi_align_bwd_workspace_ints(b, c, h, w, r, ph, pw) 4-byte elements (per 8 x 32-pixel tile the ascending list of rois that
+ *     reach it; a channel-last copy of grad_out, whose 32 channels of one bin are one coalesced load).  ph * pw <= 1500. */
+ADV_API int64_t adv_roi_align_bwd_workspace_ints(int b, int c, int h, int w, int r, int ph, int pw);
 ADV_API int adv_roi_align_bwd_f32(const float* grad_out, const float* rois, float* grad_feat, int b, int c, int h, int w,
                           int r, int ph, int pw, float spatial_scale, int sampling_ratio, int32_t* workspace,
                           adv_stream_t stream);

@@ -37,7 +37,7 @@ def _base(name):
 
 def test_current_profiles_contain_the_kernels_the_library_launches():
     lib = _kernels_in_library()
-    assert {"pgd_step_vec4_idx", "conv3d_k3_mfma", "conv2d_3x3_mfma", "conv2d_1x1_mfma", "roi_align_bwd_gather"} <= lib
+    assert {"pgd_step_vec4_idx", "conv3d_k3_mfma", "conv2d_3x3_mfma", "conv2d_1x1_mfma", "conv_wino", "roi_align_bwd_lds"} <= lib
     table = _current_profiles()
     assert len(table) >= 4
     for fname, families in table.items():

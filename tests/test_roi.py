@@ -54,6 +54,8 @@ def test_oracle_nms_small_cases():
     dict(b=2, c=33, h=19, w=63, n=30, pooled=14, scale=1 / 32.0, sr=2),       # FPN P5: rois as large as the map
     dict(b=1, c=7, h=30, w=41, n=11, pooled=(5, 3), scale=1 / 16.0, sr=1),
     dict(b=1, c=6, h=30, w=41, n=11, pooled=4, scale=1 / 16.0, sr=3),         # a grid the register kernel is not built for
+    dict(b=2, c=9, h=19, w=40, n=150, pooled=3, scale=1 / 16.0, sr=2),        # many rois on few tiles: long per-tile lists
+    dict(b=1, c=3, h=10, w=33, n=65, pooled=2, scale=1 / 8.0, sr=0),          # lists longer than one batch
 ])
 def test_hip_roi_align(cfg, route):
     from eval_driving_safety_amd import ops
@@ -76,7 +78,13 @@ def test_hip_roi_align(cfg, route):
     assert gf.cpu().numpy().tobytes() == O.roi_align_bwd_ordered(g, rois, feat.shape, cfg["scale"], cfg["sr"]).tobytes(), "backward not bit-exact"
     again = ops.roi_align_bwd(torch.tensor(g, device=dev), tr, feat.shape, cfg["scale"], cfg["sr"])
     assert torch.equal(gf, again)
-    with route(ADV_ROI_BWD_CB8="1"):                   # eight channels per lane whatever the map size (small maps take fewer): same bits
+    # the register formulation (a lane owns a pixel; the shipped route keeps the accumulators in LDS and hands the lanes work items), with
+    # the map-size-dependent and with eight channels per lane: the same bits
+    with route(ADV_ROI_BWD_NO_STAGE="1"):              # grad_out gathered from global memory instead of the LDS-staged block
+        assert torch.equal(ops.roi_align_bwd(torch.tensor(g, device=dev), tr, feat.shape, cfg["scale"], cfg["sr"]), gf)
+    with route(ADV_ROI_BWD_REGS="1"):
+        assert torch.equal(ops.roi_align_bwd(torch.tensor(g, device=dev), tr, feat.shape, cfg["scale"], cfg["sr"]), gf)
+    with route(ADV_ROI_BWD_REGS="1", ADV_ROI_BWD_CB8="1"):
         assert torch.equal(ops.roi_align_bwd(torch.tensor(g, device=dev), tr, feat.shape, cfg["scale"], cfg["sr"]), gf)
     # autograd wrapper
     tf2 = tf.clone().requires_grad_(True)
