@@ -178,17 +178,37 @@ __global__ __launch_bounds__(256, 2) void conv2d_1x1_mfma(const float* __restric
       const long long p = n0 + (wn * TN + jn) * 32 + l32;
       const int cbase = m0 + (wm * TM + i) * 32 + 4 * half;
       if (p >= P) continue;
+      // the skip connection and the mask of all sixteen outputs first (unconditional loads: an element past the last channel reads the
+      // tensor's first float and is not stored), the stores after them - a load behind a store to y, or inside a divergent branch, is
+      // waited for on the spot: a memory round trip per element
+      float rv[16], mv[16];
+#pragma unroll
+      for (int v = 0; v < 16; ++v) rv[v] = 0.0f, mv[v] = 1.0f;
+      if (resb) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int co = cbase + (v & 3) + 8 * (v >> 2);
+          rv[v] = __builtin_nontemporal_load(co < M ? resb + static_cast<long long>(co) * P + p : epi.residual);
+        }
+      }
+      if (maskb) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int co = cbase + (v & 3) + 8 * (v >> 2);
+          mv[v] = __builtin_nontemporal_load(co < M ? maskb + static_cast<long long>(co) * P + p : epi.mask);
+        }
+      }
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
         const int co = cbase + (v & 3) + 8 * (v >> 2);
         if (co >= M) continue;
         const long long at = static_cast<long long>(co) * P + p;
-        float rv = acc[i][jn][v];
-        if (epi.bias) rv = rv + epi.bias[co];
-        if (resb) rv = rv + __builtin_nontemporal_load(resb + at);
-        if (epi.relu) rv = rv > 0.0f ? rv : 0.0f;
-        if (maskb) rv = __builtin_nontemporal_load(maskb + at) > 0.0f ? rv : 0.0f;
-        yb[at] = rv;
+        float r = acc[i][jn][v];
+        if (epi.bias) r = r + epi.bias[co];
+        if (resb) r = r + rv[v];
+        if (epi.relu) r = r > 0.0f ? r : 0.0f;
+        if (maskb) r = mv[v] > 0.0f ? r : 0.0f;
+        yb[at] = r;
       }
     }
   }
@@ -411,17 +431,36 @@ __global__ __launch_bounds__(256, 2) void conv2d_3x3_mfma(const float* __restric
     if (gh >= H) continue;
 #pragma unroll
     for (int i = 0; i < CBK; ++i) {
+      const int cbase = co0 + i * 32 + 4 * half;
+      const long long px = static_cast<long long>(gh) * W + gw;
+      float rv[16], mv[16];                       // skip connection and mask of the sixteen outputs first, unconditionally (see the 1x1 kernel)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) rv[v] = 0.0f, mv[v] = 1.0f;
+      if (resb) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int co = cbase + (v & 3) + 8 * (v >> 2);
+          rv[v] = __builtin_nontemporal_load(co < Cout ? resb + static_cast<long long>(co) * HW + px : epi.residual);
+        }
+      }
+      if (maskb) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int co = cbase + (v & 3) + 8 * (v >> 2);
+          mv[v] = __builtin_nontemporal_load(co < Cout ? maskb + static_cast<long long>(co) * HW + px : epi.mask);
+        }
+      }
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
-        const int co = co0 + i * 32 + 4 * half + (v & 3) + 8 * (v >> 2);
+        const int co = cbase + (v & 3) + 8 * (v >> 2);
         if (co >= Cout) continue;
-        const long long at = static_cast<long long>(co) * HW + static_cast<long long>(gh) * W + gw;
-        float rv = acc[i][r][v];
-        if (epi.bias) rv = rv + epi.bias[co];
-        if (resb) rv = rv + __builtin_nontemporal_load(resb + at);
-        if (epi.relu) rv = rv > 0.0f ? rv : 0.0f;
-        if (maskb) rv = __builtin_nontemporal_load(maskb + at) > 0.0f ? rv : 0.0f;
-        yb[at] = rv;
+        const long long at = static_cast<long long>(co) * HW + px;
+        float o = acc[i][r][v];
+        if (epi.bias) o = o + epi.bias[co];
+        if (resb) o = o + rv[v];
+        if (epi.relu) o = o > 0.0f ? o : 0.0f;
+        if (maskb) o = mv[v] > 0.0f ? o : 0.0f;
+        yb[at] = o;
       }
     }
   }

@@ -68,13 +68,14 @@ struct EpiW {
 };
 
 // Cin, Cout: channels; cinpad / copad: the prepared weights' padding; D: planes (1 for a 2D layer); DEPTH: 3x3x3 kernel
-template <int PR, int PC, int COB, int KC, bool DEPTH, bool DBG>
+template <int PR, int PC, int COB, int KC, bool DEPTH, int ABL>
 __global__ __launch_bounds__(COB * 128, COB == 4 ? 1 : 2) void conv_wino(const float* __restrict__ x, const float* __restrict__ wp, float* __restrict__ y,
                                                                           int Cin, int Cout, int cinpad, int copad, int D, int H, int W, int tiles_w,
-                                                                          long long total, EpiW epi, int dbg_arg) {
+                                                                          long long total, EpiW epi) {
   using G = WGeo<PR, PC, COB, KC>;
   constexpr int NT = G::kNT;
-  const int dbg = DBG ? dbg_arg : 0;      // phase ablation for timing: compiled in only for the -DADV_TEST_HOOKS build's probe
+  constexpr int dbg = ABL;                // phase ablation for timing (compile-time, so the schedule of the rest is the shipped one): the
+                                          // -DADV_TEST_HOOKS build's probe instantiates non-zero values, the shipped kernels are ABL = 0
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, k4 = lane >> 4;
@@ -292,6 +293,42 @@ __global__ __launch_bounds__(COB * 128, COB == 4 ? 1 : 2) void conv_wino(const f
     const int t = (2 * hf + blk) * 16 + i16;
     const int gh = h0 + 2 * (t / PC), gw = w0 + 2 * (t % PC);
     if (t >= PR * PC || gh >= H || gw >= W) continue;
+    const bool two = gw + 1 < W, row2 = gh + 1 < H;
+    const long long at0 = static_cast<long long>(co0 + cob * 16 + 4 * k4) * DHW + static_cast<long long>(gh) * W + gw;
+    // the skip connection and the mask of ALL sixteen outputs of this block first, the stores after them: a load placed behind a store
+    // to y may not be moved ahead of it (the pointers could alias), so element-by-element code waits a memory round trip per element
+    float rv[4][2][2], mv[4][2][2];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) rv[reg][r][c] = 0.0f, mv[reg][r][c] = 1.0f;
+    }
+    // (unconditional loads - an element outside the tensor reads the tensor's first float instead and is never stored: a load inside a
+    // divergent branch is awaited at the join)
+    if (resb) {
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            const bool ok = co0 + cob * 16 + 4 * k4 + reg < Cout && (r == 0 || row2) && (c == 0 || two);
+            rv[reg][r][c] = __builtin_nontemporal_load(ok ? resb + (at0 + reg * DHW + r * W + c) : epi.residual);
+          }
+    }
+    if (maskb) {
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            const bool ok = co0 + cob * 16 + 4 * k4 + reg < Cout && (r == 0 || row2) && (c == 0 || two);
+            mv[reg][r][c] = __builtin_nontemporal_load(ok ? maskb + (at0 + reg * DHW + r * W + c) : epi.mask);
+          }
+    }
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
       const int co = co0 + cob * 16 + 4 * k4 + reg;
@@ -310,20 +347,13 @@ __global__ __launch_bounds__(COB * 128, COB == 4 ? 1 : 2) void conv_wino(const f
       const float bv = epi.bias ? epi.bias[co] : 0.0f;
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
-        if (gh + r >= H) continue;
-        const long long at = static_cast<long long>(co) * DHW + static_cast<long long>(gh + r) * W + gw;
-        const bool two = gw + 1 < W;
+        if (r == 1 && !row2) continue;
+        const long long at = at0 + reg * DHW + r * W;
         float v0 = o[r][0], v1 = o[r][1];
         if (epi.bias) v0 = v0 + bv, v1 = v1 + bv;
-        if (resb) {
-          v0 = v0 + __builtin_nontemporal_load(resb + at);
-          if (two) v1 = v1 + __builtin_nontemporal_load(resb + at + 1);
-        }
+        if (resb) v0 = v0 + rv[reg][r][0], v1 = v1 + rv[reg][r][1];
         if (epi.relu) v0 = v0 > 0.0f ? v0 : 0.0f, v1 = v1 > 0.0f ? v1 : 0.0f;
-        if (maskb) {
-          v0 = __builtin_nontemporal_load(maskb + at) > 0.0f ? v0 : 0.0f;
-          if (two) v1 = __builtin_nontemporal_load(maskb + at + 1) > 0.0f ? v1 : 0.0f;
-        }
+        if (maskb) v0 = mv[reg][r][0] > 0.0f ? v0 : 0.0f, v1 = mv[reg][r][1] > 0.0f ? v1 : 0.0f;
         yb[at] = v0;
         if (two) yb[at + 1] = v1;
       }
@@ -343,16 +373,24 @@ int launch_wino(const float* x, const float* wp, float* y, int b, int cin, int c
   const long long total = static_cast<long long>(b) * cin * d * h * w;
   const dim3 grid(static_cast<unsigned>(tiles), cgroups, static_cast<unsigned>(gz));
 #ifdef ADV_TEST_HOOKS
-  if (const char* dbg_s = adv_hook_value("ADV_WINO_DBG")) {      // phase ablation for timing (results are wrong)
-    if (!adv_internal_lds_limit<conv_wino<PR, PC, COB, KC, DEPTH, true>>(G::kLds)) return ADV_ELAUNCH;
-    hipLaunchKernelGGL((conv_wino<PR, PC, COB, KC, DEPTH, true>), grid, dim3(G::kNT), G::kLds, st, x, wp, y, cin, cout, cinpad, copad, d, h, w, tiles_w,
-                       total, epi, std::atoi(dbg_s));
-    return adv_internal_finish_launch();
+  if (const char* dbg_s = adv_hook_value("ADV_WINO_DBG")) {      // phase ablation for timing (results are wrong); the 8 x 32 x 64 2D shape only
+    if constexpr (PR == 4 && PC == 16 && COB == 4 && !DEPTH) {
+      const int abl = std::atoi(dbg_s);
+#define ADV_WINO_ABL(A_)                                                                                                                  \
+  if (abl == A_) {                                                                                                                        \
+    if (!adv_internal_lds_limit<conv_wino<PR, PC, COB, KC, DEPTH, A_>>(G::kLds)) return ADV_ELAUNCH;                                      \
+    hipLaunchKernelGGL((conv_wino<PR, PC, COB, KC, DEPTH, A_>), grid, dim3(G::kNT), G::kLds, st, x, wp, y, cin, cout, cinpad, copad, d, h, w, \
+                       tiles_w, total, epi);                                                                                              \
+    return adv_internal_finish_launch();                                                                                                  \
+  }
+      ADV_WINO_ABL(1) ADV_WINO_ABL(2) ADV_WINO_ABL(4) ADV_WINO_ABL(8) ADV_WINO_ABL(16) ADV_WINO_ABL(3) ADV_WINO_ABL(13) ADV_WINO_ABL(29) ADV_WINO_ABL(31)
+#undef ADV_WINO_ABL
+    }
   }
 #endif
-  if (!adv_internal_lds_limit<conv_wino<PR, PC, COB, KC, DEPTH, false>>(G::kLds)) return ADV_ELAUNCH;
-  hipLaunchKernelGGL((conv_wino<PR, PC, COB, KC, DEPTH, false>), grid, dim3(G::kNT), G::kLds, st, x, wp, y, cin, cout, cinpad, copad, d, h, w, tiles_w,
-                     total, epi, 0);
+  if (!adv_internal_lds_limit<conv_wino<PR, PC, COB, KC, DEPTH, 0>>(G::kLds)) return ADV_ELAUNCH;
+  hipLaunchKernelGGL((conv_wino<PR, PC, COB, KC, DEPTH, 0>), grid, dim3(G::kNT), G::kLds, st, x, wp, y, cin, cout, cinpad, copad, d, h, w, tiles_w,
+                     total, epi);
   return adv_internal_finish_launch();
 }
 
