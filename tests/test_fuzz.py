@@ -20,7 +20,7 @@ def test_random_shapes_against_the_oracle(seed):
     import fuzz_gpu
     dev = torch.device("cuda", 0)
     rs = np.random.RandomState(seed)
-    kinds = [fuzz_gpu.conv_case] * 5 + [fuzz_gpu.conv2d_case] * 4 + [fuzz_gpu.grid_case] * 2 + [fuzz_gpu.pgd_case] * 3 + [fuzz_gpu.roi_case] * 3 + \
+    kinds = [fuzz_gpu.conv_case] * 5 + [fuzz_gpu.conv2d_case] * 4 + [fuzz_gpu.wino3d_case] * 3 + [fuzz_gpu.grid_case] * 2 + [fuzz_gpu.pgd_case] * 3 + [fuzz_gpu.roi_case] * 3 + \
         [fuzz_gpu.depth_case] * 2
     for _ in range(60):
         kinds[int(rs.randint(len(kinds)))](rs, dev)

@@ -105,11 +105,37 @@ def conv2d_case(rs, dev):
     gx = ops.conv2d_dgrad(t(g), prep, residual=t(gres), mask=t(gmask), tile=tile)
     same(gx, C.conv2d(g, wt, residual=gres, mask=gmask, padding=pad, dilation=dil, transpose=True, chunk=chunk), "conv2d dgrad %s" % ((k, dil, b, cin, cout, h, w, tile),))
     if prep.has_wino:       # csrc/wino2d.hip against its own restatement, both tile shapes
-        wtile = int(rs.randint(-1, 2))
+        wtile = int(rs.randint(-1, 6))
         y = ops.conv2d(t(x), prep, t(bias), t(res), relu, t(mask), tile=wtile, wino=True)
         same(y, C.conv2d_wino(x, wt, bias, res, mask, relu=relu), "conv2d wino %s" % ((b, cin, cout, h, w, relu, wtile),))
         gx = ops.conv2d_dgrad(t(g), prep, residual=t(gres), mask=t(gmask), tile=wtile, wino=True)
         same(gx, C.conv2d_wino(g, wt, residual=gres, mask=gmask, transpose=True), "conv2d wino dgrad %s" % ((b, cin, cout, h, w, wtile),))
+
+
+def wino3d_case(rs, dev):
+    """csrc/wino2d.hip on 3x3x3 layers: random shapes (one plane, two planes, odd maps, channels around the stage / block sizes), every
+    workgroup shape, random epilogue, forward and backward w.r.t. the input, against the restatement bit for bit"""
+    b = int(rs.randint(1, 3))
+    cin, cout = int(rs.choice([1, 3, 4, 8, 13, 32, 40, 64])), int(rs.choice([4, 6, 18, 32, 33, 64, 70]))
+    d, h, w = int(rs.randint(1, 5)), int(rs.randint(1, 30)), int(rs.choice([1, 2, 5, 23, 24, 31, 32, 33, 49, 65]))
+    if b * min(cin, cout) * d * h * w < 4:
+        h = 4
+    x = rs.randn(b, cin, d, h, w).astype(np.float32)
+    wt = (rs.randn(cout, cin, 3, 3, 3) * (1.0 / (27 * cin)) ** 0.5).astype(np.float32)
+    bias = rs.randn(cout).astype(np.float32) if rs.rand() < 0.6 else None
+    res = rs.randn(b, cout, d, h, w).astype(np.float32) if rs.rand() < 0.5 else None
+    mask = rs.randn(b, cout, d, h, w).astype(np.float32) if rs.rand() < 0.3 else None
+    relu = bool(rs.rand() < 0.5)
+    tile = int(rs.randint(-1, 6))
+    t = lambda a: None if a is None else torch.tensor(a, device=dev)       # noqa: E731
+    prep = ops.Conv3dWinoPrep(t(wt))
+    same(ops.conv3d_wino(t(x), prep, t(bias), t(res), relu, t(mask), tile=tile), C.conv3d_wino(x, wt, bias, res, mask, relu=relu),
+         "conv3d wino %s" % ((b, cin, cout, d, h, w, relu, tile),))
+    g = rs.randn(b, cout, d, h, w).astype(np.float32)
+    gres = rs.randn(b, cin, d, h, w).astype(np.float32) if rs.rand() < 0.5 else None
+    gmask = x if rs.rand() < 0.5 else None
+    same(ops.conv3d_wino_dgrad(t(g), prep, residual=t(gres), mask=t(gmask), tile=tile), C.conv3d_wino(g, wt, residual=gres, mask=gmask, transpose=True),
+         "conv3d wino dgrad %s" % ((b, cin, cout, d, h, w, tile),))
 
 
 def grid_case(rs, dev):
@@ -199,7 +225,7 @@ def main():
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     rs = np.random.RandomState(args.seed)
-    kinds = [conv_case] * 5 + [conv2d_case] * 4 + [grid_case] * 2 + [pgd_case] * 3 + [roi_case] * 3 + [depth_case] * 2
+    kinds = [conv_case] * 5 + [conv2d_case] * 4 + [wino3d_case] * 3 + [grid_case] * 2 + [pgd_case] * 3 + [roi_case] * 3 + [depth_case] * 2
     counts = {}
     for i in range(args.cases):
         fn = kinds[int(rs.randint(len(kinds)))]
