@@ -114,20 +114,24 @@ __global__ __launch_bounds__(COB * 128, COB == 4 ? 1 : 2) void conv_wino(const f
     xvm[i] = vm;
   }
   const long long xlast = total - 4;         // the last float4 that lies inside the tensor
-  v4f rx[G::kXSl], rw[G::kWSl];
-  int rxs[G::kXSl];                          // how far the clamp moved the load (non-zero only in the tensor's first / last three floats)
-  unsigned rxm[G::kXSl];
+  struct XSet {                              // staging registers of an input tile
+    v4f v[G::kXSl];
+    int s[G::kXSl];                          // how far the clamp moved the load (non-zero only in the tensor's first / last three floats)
+    unsigned m[G::kXSl];
+  };
+  XSet xs;
+  v4f rw[G::kWSl];
   // Everything below is written per slot / per row so that a stage's side work (global loads of the stages ahead, the input transform
   // of the next stage, the LDS commits) can be placed BETWEEN the matrix instructions of the current stage, one piece per step.
   // q0 = the stage's first "channel": 2D: the channel itself; 3D: q = kd * cinpad + c, input plane od + kd - 1
-  auto fetch_x1 = [&](int i, int q0) {
+  auto fetch_x1 = [&](int i, int q0, XSet& set) {
     const int kd = DEPTH ? q0 / cinpad : 0;
     const int ch = (DEPTH ? q0 - kd * cinpad : q0) + xc[i];
     const long long at = ((b * Cin + (ch < Cin ? ch : Cin - 1)) * D + (DEPTH ? od + kd - 1 : 0)) * HW + xflat[i];
     const long long cl = at < 0 ? 0 : (at > xlast ? xlast : at);
-    rx[i] = *reinterpret_cast<const v4f_u*>(x + cl);
-    rxs[i] = static_cast<int>(cl - at);
-    rxm[i] = ch < Cin ? xvm[i] : 0u;
+    set.v[i] = *reinterpret_cast<const v4f_u*>(x + cl);
+    set.s[i] = static_cast<int>(cl - at);
+    set.m[i] = ch < Cin ? xvm[i] : 0u;
   };
   const int wrows = DEPTH ? 3 * cinpad : cinpad;       // rows of U per transform position
   auto fetch_w1 = [&](int i, int q0) {
@@ -139,12 +143,12 @@ __global__ __launch_bounds__(COB * 128, COB == 4 ? 1 : 2) void conv_wino(const f
   float* const sxb = lds;                               // [2][KC][rows][LW]   input tiles
   float* const swb = lds + 2 * G::kSX;                   // [2][16][KC][CO]     U = G g G^T of the stage
   float* const svb = swb + 2 * G::kSW;                   // [2][16][KC][64]     V = B^T d B of the stage, 64 patches
-  auto commit_x1 = [&](int i, int buf) {
+  auto commit_x1 = [&](int i, int buf, const XSet& set) {
     float* sx = sxb + buf * G::kSX;
     const int sidx = tid + NT * i;
-    const v4f t = rx[i];
-    const int sh = rxs[i];
-    const unsigned m = rxm[i];
+    const v4f t = set.v[i];
+    const int sh = set.s[i];
+    const unsigned m = set.m[i];
     v4f v;
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(sh != 0) != 0, 0)) {     // wave-uniform: the tensor's first / last float4 only
 #pragma unroll
@@ -207,25 +211,31 @@ __global__ __launch_bounds__(COB * 128, COB == 4 ? 1 : 2) void conv_wino(const f
   const int q_lo = DEPTH ? (od == 0 ? cinpad : 0) : 0;
   const int q_hi = DEPTH ? (od == D - 1 ? 2 * cinpad : 3 * cinpad) : cinpad;
   const int nstage = (q_hi - q_lo) / KC;
+  {
+    // prologue: the first two input tiles and the first weights are requested TOGETHER (a second, short-lived register set for the
+    // second tile) - one memory round trip before the first products instead of two in a row; with 24 short stages per tile (the
+    // 32-channel 3D layers) or 8 (64-channel 2D layers) the prologue is a fifth to a third of a tile's time
+    XSet xs1;
 #pragma unroll
-  for (int i = 0; i < G::kXSl; ++i) fetch_x1(i, q_lo);
+    for (int i = 0; i < G::kXSl; ++i) fetch_x1(i, q_lo, xs);
 #pragma unroll
-  for (int i = 0; i < G::kWSl; ++i) fetch_w1(i, q_lo);
+    for (int i = 0; i < G::kWSl; ++i) fetch_w1(i, q_lo);
 #pragma unroll
-  for (int i = 0; i < G::kXSl; ++i) commit_x1(i, 0);
+    for (int i = 0; i < G::kXSl; ++i) fetch_x1(i, nstage > 1 ? q_lo + KC : q_lo, xs1);
 #pragma unroll
-  for (int i = 0; i < G::kWSl; ++i) commit_w1(i, 0);
+    for (int i = 0; i < G::kXSl; ++i) commit_x1(i, 0, xs);
 #pragma unroll
-  for (int i = 0; i < G::kXSl; ++i) fetch_x1(i, nstage > 1 ? q_lo + KC : q_lo);
-  __syncthreads();
+    for (int i = 0; i < G::kWSl; ++i) commit_w1(i, 0);
+    __syncthreads();
 #pragma unroll
-  for (int i = 0; i < 4; ++i) tr_read(i, 0);
-  tr_compute();
+    for (int i = 0; i < 4; ++i) tr_read(i, 0);
+    tr_compute();
 #pragma unroll
-  for (int k = 0; k < 16; ++k) tr_write(k, 0);
+    for (int k = 0; k < 16; ++k) tr_write(k, 0);
 #pragma unroll
-  for (int i = 0; i < G::kXSl; ++i) commit_x1(i, 1);
-  __syncthreads();
+    for (int i = 0; i < G::kXSl; ++i) commit_x1(i, 1, xs1);
+    __syncthreads();
+  }
 
   // Stage st: kSteps steps (q group cs = t >> 4, transform position k = t & 15) of two matrix instructions each on V / U of stage st.
   // The operands of step t + 4 are read from LDS before step t issues.  Between the steps, one piece each: the global loads of the
@@ -251,7 +261,7 @@ __global__ __launch_bounds__(COB * 128, COB == 4 ? 1 : 2) void conv_wino(const f
 #pragma unroll
     for (int t = 0; t < NS; ++t) {
       if (t + kAhead < NS) load(t + kAhead);
-      if (FX && t < G::kXSl && !(dbg & 4)) fetch_x1(t, q1 + KC);
+      if (FX && t < G::kXSl && !(dbg & 4)) fetch_x1(t, q1 + KC, xs);
       if (FW && t >= G::kLoadW && t < G::kLoadW + G::kWSl && !(dbg & 4)) fetch_w1(t - G::kLoadW, q1);
       if (FW && t >= G::kRead && t < G::kRead + 4 && !(dbg & 1)) tr_read(t - G::kRead, nb);
       if (FW && t == G::kComp && !(dbg & 1)) tr_compute();
@@ -259,7 +269,7 @@ __global__ __launch_bounds__(COB * 128, COB == 4 ? 1 : 2) void conv_wino(const f
 #pragma unroll
         for (int u = 0; u < G::kWritesPerStep; ++u) tr_write(G::kWritesPerStep * (t - G::kWrite) + u, nb);
       }
-      if (FX && t >= G::kCommitX && t < G::kCommitX + G::kXSl && !(dbg & 8)) commit_x1(t - G::kCommitX, st & 1);
+      if (FX && t >= G::kCommitX && t < G::kCommitX + G::kXSl && !(dbg & 8)) commit_x1(t - G::kCommitX, st & 1, xs);
       if (FW && t >= G::kCommitW && t < G::kCommitW + G::kWSl && !(dbg & 8)) commit_w1(t - G::kCommitW, nb);
       if (!(dbg & 2)) {
         acc[0][t & 15] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[t], rb0[t], acc[0][t & 15], 0, 0, 0);
@@ -288,6 +298,7 @@ __global__ __launch_bounds__(COB * 128, COB == 4 ? 1 : 2) void conv_wino(const f
   float* yb = y + b * MP + plane0;
   const float* resb = epi.residual ? epi.residual + b * MP + plane0 : nullptr;
   const float* maskb = epi.mask ? epi.mask + b * MP + plane0 : nullptr;
+  const bool vec2 = (W & 1) == 0 && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(epi.residual) | reinterpret_cast<uintptr_t>(epi.mask)) & 7) == 0;
 #pragma unroll
   for (int blk = 0; blk < 2; ++blk) {
     const int t = (2 * hf + blk) * 16 + i16;
@@ -296,39 +307,34 @@ __global__ __launch_bounds__(COB * 128, COB == 4 ? 1 : 2) void conv_wino(const f
     const bool two = gw + 1 < W, row2 = gh + 1 < H;
     const long long at0 = static_cast<long long>(co0 + cob * 16 + 4 * k4) * DHW + static_cast<long long>(gh) * W + gw;
     // the skip connection and the mask of ALL sixteen outputs of this block first, the stores after them: a load placed behind a store
-    // to y may not be moved ahead of it (the pointers could alias), so element-by-element code waits a memory round trip per element
+    // to y may not be moved ahead of it (the pointers could alias), so element-by-element code waits a memory round trip per element.
+    // Unconditional loads - an element outside the tensor reads the tensor's first float(s) instead and is never stored: a load inside
+    // a divergent branch is awaited at the join.  vec2: W even and 8-byte aligned tensors - a patch row is one 8-byte access.
     float rv[4][2][2], mv[4][2][2];
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
+    for (int reg = 0; reg < 4; ++reg)
 #pragma unroll
       for (int r = 0; r < 2; ++r)
 #pragma unroll
         for (int c = 0; c < 2; ++c) rv[reg][r][c] = 0.0f, mv[reg][r][c] = 1.0f;
-    }
-    // (unconditional loads - an element outside the tensor reads the tensor's first float instead and is never stored: a load inside a
-    // divergent branch is awaited at the join)
-    if (resb) {
+    auto gather = [&](const float* base, const float* safe, float (&dst)[4][2][2]) {
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg)
 #pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-          for (int c = 0; c < 2; ++c) {
-            const bool ok = co0 + cob * 16 + 4 * k4 + reg < Cout && (r == 0 || row2) && (c == 0 || two);
-            rv[reg][r][c] = __builtin_nontemporal_load(ok ? resb + (at0 + reg * DHW + r * W + c) : epi.residual);
+        for (int r = 0; r < 2; ++r) {
+          const bool rok = co0 + cob * 16 + 4 * k4 + reg < Cout && (r == 0 || row2);
+          const float* p = base + (at0 + reg * DHW + r * W);
+          if (vec2) {
+            const v2f v = __builtin_nontemporal_load(reinterpret_cast<const v2f*>(rok ? p : safe));
+            dst[reg][r][0] = v[0], dst[reg][r][1] = v[1];
+          } else {
+            dst[reg][r][0] = __builtin_nontemporal_load(rok ? p : safe);
+            dst[reg][r][1] = __builtin_nontemporal_load(rok && two ? p + 1 : safe);
           }
-    }
-    if (maskb) {
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg)
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-          for (int c = 0; c < 2; ++c) {
-            const bool ok = co0 + cob * 16 + 4 * k4 + reg < Cout && (r == 0 || row2) && (c == 0 || two);
-            mv[reg][r][c] = __builtin_nontemporal_load(ok ? maskb + (at0 + reg * DHW + r * W + c) : epi.mask);
-          }
-    }
+        }
+    };
+    if (resb) gather(resb, epi.residual, rv);
+    if (maskb) gather(maskb, epi.mask, mv);
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
       const int co = co0 + cob * 16 + 4 * k4 + reg;
@@ -354,8 +360,12 @@ __global__ __launch_bounds__(COB * 128, COB == 4 ? 1 : 2) void conv_wino(const f
         if (resb) v0 = v0 + rv[reg][r][0], v1 = v1 + rv[reg][r][1];
         if (epi.relu) v0 = v0 > 0.0f ? v0 : 0.0f, v1 = v1 > 0.0f ? v1 : 0.0f;
         if (maskb) v0 = mv[reg][r][0] > 0.0f ? v0 : 0.0f, v1 = mv[reg][r][1] > 0.0f ? v1 : 0.0f;
-        yb[at] = v0;
-        if (two) yb[at + 1] = v1;
+        if (vec2) {
+          *reinterpret_cast<v2f*>(yb + at) = v2f{v0, v1};
+        } else {
+          yb[at] = v0;
+          if (two) yb[at + 1] = v1;
+        }
       }
     }
   }
