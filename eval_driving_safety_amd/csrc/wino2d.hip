@@ -8,7 +8,8 @@
 //   part of the contraction, q = (kd, channel): output plane od reads the input planes od - 1, od, od + 1 (a missing plane is skipped:
 //   its terms are exact zeros) - 48 products per 2x2 outputs instead of 108.
 //
-// A workgroup owns 64 patches (4 x 16 patches = 8 x 32 outputs, or 8 x 8 = 16 x 16 outputs) of one image / output plane and
+// A workgroup owns up to 64 patches (4 x 16 patches = 8 x 32 outputs, 8 x 8 = 16 x 16 outputs, or 5 x 12 = 10 x 24 for maps of 10 / 20 rows)
+// of one image / output plane and
 //   shape A: 64 output channels, 512 threads, stages of 8 q   (155 KB LDS, one workgroup per CU)
 //   shape B: 32 output channels, 256 threads, stages of 4 q   ( 61 KB LDS, two workgroups per CU) - layers of 32 channels or fewer.
 // Wave w owns channel block w % COB (16 channels) and two blocks of 16 patches: 2 x 16 accumulators of 4 registers; A operand =
