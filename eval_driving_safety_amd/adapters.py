@@ -692,10 +692,14 @@ class DsgnShapedAdapter(PsvStereoAdapter):
     # -- layer helpers (each counts its forward FLOPs) -------------------------------------------------------------------
     trace2d = None        # a list: every 2D convolution call appends (cin, cout, k, stride, padding, dilation, batch, h, w) - tools/bench_conv2d_layers.py
 
-    def _c2(self, x, name, relu=False, residual=None, chain_in=False):
+    def _c2(self, x, name, relu=False, residual=None, chain_in=False, undilated=False):
         """``relu="consumer"`` / ``chain_in=True``: see ops.Conv2dAuto - a ReLU layer whose ONLY consumer is the next convolution leaves
-        its backward mask to that consumer's dgrad epilogue (no relu_backward pass over the tensor)"""
+        its backward mask to that consumer's dgrad epilogue (no relu_backward pass over the tensor).  ``undilated``: x holds the four
+        parity sub-images of the layer's input side by side in the batch (_parity_split): the dilation-2 layer is a dilation-1 layer on each"""
         w, b, s, p, d = self.w2[name]
+        if undilated:
+            assert d == 2 and p == 2 and s == 1
+            p, d, name = 1, 1, name + "@parity"
         if DsgnShapedAdapter.trace2d is not None:
             DsgnShapedAdapter.trace2d.append((w.shape[1], w.shape[0], w.shape[2], s, p, d, x.shape[0], x.shape[2], x.shape[3]))
         if self.hip2d and not self.torch_ops and self.ops.conv2d_supported(x, w, s, p, d):
@@ -715,6 +719,17 @@ class DsgnShapedAdapter(PsvStereoAdapter):
         if residual is not None:
             y = y + residual
         return F.relu(y) if relu else y
+
+    @staticmethod
+    def _parity_split(x):
+        """[B,C,H,W] -> [4B,C,H/2,W/2]: sub-image (row parity, column parity) of every map, (b, py, px) in the batch dimension"""
+        b, c, h, w = x.shape
+        return x.view(b, c, h // 2, 2, w // 2, 2).permute(0, 3, 5, 1, 2, 4).reshape(4 * b, c, h // 2, w // 2)
+
+    @staticmethod
+    def _parity_merge(xs, b):
+        _, c, h, w = xs.shape
+        return xs.view(b, 2, 2, c, h, w).permute(0, 3, 4, 1, 5, 2).reshape(b, c, 2 * h, 2 * w)
 
     def _chain(self, *names):
         """can the ReLU masks between these consecutive layers be left to the consumers?  (all of them on the Conv2dAuto path)"""
@@ -771,10 +786,22 @@ class DsgnShapedAdapter(PsvStereoAdapter):
     def features(self, img):
         x = self._c2(self._c2(self._c2(img, "f0a", True), "f0b", True), "f0c", True)
         outs = {}
+        split = 0          # > 0: x is the four parity sub-images of a batch of `split` maps (the dilation-2 blocks run as dilation-1 blocks on them)
         for pre, proj, li in self.blocks:
+            dil2 = self.w2[pre + ".a"][4] == 2 and self.w2[pre + ".b"][4] == 2 and not proj
+            if dil2 and not split and self.hip2d == "auto" and not self.torch_ops and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0:
+                # a dilation-2 3x3 convolution only ever combines pixels of one (row, column) parity: on the four parity sub-images it
+                # is a dilation-1 convolution with the same weights - which has a Winograd kernel (1.7x the dilated direct kernel's rate)
+                split, x = x.shape[0], self._parity_split(x)
+            elif split and not dil2:
+                x, split = self._parity_merge(x, split), 0
             idt = self._c2(x, pre + ".p") if proj else x
             ch = self._chain(pre + ".a", pre + ".b")                                          # a's only consumer is b
-            x = self._c2(self._c2(x, pre + ".a", "consumer" if ch else True), pre + ".b", residual=idt, chain_in=ch)   # PSMNet's BasicBlock: no ReLU after the sum
+            x = self._c2(self._c2(x, pre + ".a", "consumer" if ch else True, undilated=bool(split)), pre + ".b", residual=idt, chain_in=ch,
+                         undilated=bool(split))                                                   # PSMNet's BasicBlock: no ReLU after the sum
+            outs[li] = x
+        if split:
+            x = self._parity_merge(x, split)
             outs[li] = x
         l2, l4 = outs[2], outs[4]
         branches = []
