@@ -692,7 +692,7 @@ class DsgnShapedAdapter(PsvStereoAdapter):
     # -- layer helpers (each counts its forward FLOPs) -------------------------------------------------------------------
     trace2d = None        # a list: every 2D convolution call appends (cin, cout, k, stride, padding, dilation, batch, h, w) - tools/bench_conv2d_layers.py
 
-    def _c2(self, x, name, relu=False, residual=None, chain_in=False, undilated=False):
+    def _c2(self, x, name, relu=False, residual=None, chain_in=False, undilated=False, skip_out=False):
         """``relu="consumer"`` / ``chain_in=True``: see ops.Conv2dAuto - a ReLU layer whose ONLY consumer is the next convolution leaves
         its backward mask to that consumer's dgrad epilogue (no relu_backward pass over the tensor).  ``undilated``: x holds the four
         parity sub-images of the layer's input side by side in the batch (_parity_split): the dilation-2 layer is a dilation-1 layer on each"""
@@ -707,13 +707,16 @@ class DsgnShapedAdapter(PsvStereoAdapter):
             if name not in self._p2:
                 self._p2[name] = self.ops.Conv2dPrep(w, s, p, d)
             if self.hip2d == "auto":       # per layer shape and direction, whichever of {libadvengine, MIOpen} measured faster
-                y = self.ops.Conv2dAuto.apply(x, self._p2[name], w, b, residual, relu, chain_in)
+                y = self.ops.Conv2dAuto.apply(x, self._p2[name], w, b, residual, relu, chain_in, skip_out)
+                if skip_out:
+                    self.flops_fwd += 2 * y[0].numel() * w.shape[1] * w.shape[2] * w.shape[3]
+                    return y
             else:
-                assert not chain_in and relu != "consumer"
+                assert not chain_in and relu != "consumer" and not skip_out
                 y = self.ops.Conv2d.apply(x, self._p2[name], b, residual, relu)
             self.flops_fwd += 2 * y.numel() * w.shape[1] * w.shape[2] * w.shape[3]
             return y
-        assert not chain_in and relu != "consumer", "chained ReLU masks need the Conv2dAuto path on both layers"
+        assert not chain_in and relu != "consumer" and not skip_out, "chained ReLU masks / fused skip gradients need the Conv2dAuto path"
         y = F.conv2d(x, w, b, s, p, d)
         self.flops_fwd += 2 * y.numel() * w.shape[1] * w.shape[2] * w.shape[3]
         if residual is not None:
@@ -795,10 +798,15 @@ class DsgnShapedAdapter(PsvStereoAdapter):
                 split, x = x.shape[0], self._parity_split(x)
             elif split and not dil2:
                 x, split = self._parity_merge(x, split), 0
-            idt = self._c2(x, pre + ".p") if proj else x
             ch = self._chain(pre + ".a", pre + ".b")                                          # a's only consumer is b
-            x = self._c2(self._c2(x, pre + ".a", "consumer" if ch else True, undilated=bool(split)), pre + ".b", residual=idt, chain_in=ch,
-                         undilated=bool(split))                                                   # PSMNet's BasicBlock: no ReLU after the sum
+            if ch and not proj and x.is_cuda:
+                # identity block: layer a hands x on as the skip tensor and its backward adds the skip path's gradient in the dgrad
+                # kernel's epilogue (ops.Conv2dAuto skip_out) - no element-wise addition by the autograd engine
+                t, idt = self._c2(x, pre + ".a", "consumer", undilated=bool(split), skip_out=True)
+            else:
+                idt = self._c2(x, pre + ".p") if proj else x
+                t = self._c2(x, pre + ".a", "consumer" if ch else True, undilated=bool(split))
+            x = self._c2(t, pre + ".b", residual=idt, chain_in=ch, undilated=bool(split))      # PSMNet's BasicBlock: no ReLU after the sum
             outs[li] = x
         if split:
             x = self._parity_merge(x, split)

@@ -1175,10 +1175,16 @@ class Conv2dAuto(torch.autograd.Function):
                             the producer's PRE-activation;
       ``relu="consumer"``   this layer applies the ReLU in its forward but does not mask in its backward: its only consumer was
                             called with mask_input=True and has done it (y > 0 there is the same mask).
-    The caller vouches for the topology; the result is the same gradient, bit for bit (the mask multiplies the same float once)."""
+    The caller vouches for the topology; the result is the same gradient, bit for bit (the mask multiplies the same float once).
+
+    Skip connections without the autograd engine's addition:
+      ``skip_out=True``     returns (y, x_skip) with x_skip an alias of x.  A residual block hands x_skip to its last layer as the
+                            ``residual``; this layer's backward then receives BOTH gradients of x - through its own convolution and over
+                            the skip path - and adds the second in the dgrad kernel's epilogue (before the mask of ``mask_input``, which
+                            then covers both: x may be a ReLU output whose only consumers are this layer and its block's skip path)."""
 
     @staticmethod
-    def forward(ctx, x, prep, weight, bias=None, residual=None, relu=False, mask_input=False):
+    def forward(ctx, x, prep, weight, bias=None, residual=None, relu=False, mask_input=False, skip_out=False):
         x = x.contiguous()
         res = None if residual is None else residual.contiguous()
         pad, dil = prep.padding, prep.dilation
@@ -1195,26 +1201,29 @@ class Conv2dAuto(torch.autograd.Function):
         ctx.mask_own = do_relu and relu != "consumer"          # mask the incoming gradient with y > 0 here
         ctx.mask_input = bool(mask_input)
         ctx.save_for_backward(weight, y if ctx.mask_own else None, x if mask_input else None)
-        return y
+        return (y, x) if skip_out else y
 
     @staticmethod
-    def backward(ctx, grad_y):
+    def backward(ctx, grad_y, grad_skip=None):
         weight, y, x_in = ctx.saved_tensors
         prep = ctx.prep
         g = grad_y.contiguous()
         if ctx.mask_own:
             g = relu_backward(g, y)
-        key = ("b", prep.k, prep.cin, prep.cout, prep.dilation, ctx.xshape, ctx.mask_input)
+        skip = None if grad_skip is None else grad_skip.contiguous()      # the gradient of x over the block's skip path
+        key = ("b", prep.k, prep.cin, prep.cout, prep.dilation, ctx.xshape, ctx.mask_input, skip is not None)
 
         def by_torch():
             gx = torch.ops.aten.convolution_backward(g, _shape_only(ctx.xshape, g), weight, None, [1, 1], [prep.padding, prep.padding],
                                                      [prep.dilation, prep.dilation], False, [0, 0], 1, [True, False, False])[0]
+            if skip is not None:
+                gx = gx + skip
             return relu_backward(gx, x_in) if ctx.mask_input else gx
 
-        hip = lambda wino=False: conv2d_dgrad(g, prep, mask=x_in if ctx.mask_input else None, wino=wino)      # noqa: E731
+        hip = lambda wino=False: conv2d_dgrad(g, prep, residual=skip, mask=x_in if ctx.mask_input else None, wino=wino)      # noqa: E731
         use = _Conv2dChoice.get(key, hip, by_torch, (lambda: hip(True)) if prep.has_wino else None)
         gx = hip(use == "wino") if use else by_torch()
-        return gx, None, None, None, (g if ctx.has_res else None), None, None
+        return gx, None, None, None, (g if ctx.has_res else None), None, None, None
 
 
 _SHAPE_DUMMY = {}

@@ -289,7 +289,7 @@ class FoldedConv(nn.Module):
         return FoldedConv.impl == "auto" and self.stride == 1 and ((self.k == 1 and self.padding == 0) or (self.k == 3 and self.padding == 1)) and \
             (FoldedConv.hip_kernels is None or self.k in FoldedConv.hip_kernels)
 
-    def forward(self, x, relu=False, residual=None, chain_in=False):
+    def forward(self, x, relu=False, residual=None, chain_in=False, skip_out=False):
         ho = (x.shape[2] + 2 * self.padding - self.k) // self.stride + 1
         wo = (x.shape[3] + 2 * self.padding - self.k) // self.stride + 1
         self.flops += 2 * x.shape[0] * self.weight.shape[0] * self.weight.shape[1] * self.k * self.k * ho * wo
@@ -308,10 +308,11 @@ class FoldedConv(nn.Module):
                 if self._prep is None or self._prep.device != x.device:
                     self._prep = ops.Conv2dPrep(self.weight, self.stride, self.padding)
                 if FoldedConv.impl == "auto":      # per layer shape and direction, whichever of {libadvengine, MIOpen} measured faster
-                    return ops.Conv2dAuto.apply(x, self._prep, self.weight, self.bias, residual, relu, chain_in)
+                    return ops.Conv2dAuto.apply(x, self._prep, self.weight, self.bias, residual, relu, chain_in, skip_out)
+                assert not skip_out
                 assert not chain_in and relu != "consumer"
                 return ops.Conv2d.apply(x, self._prep, self.bias, residual, relu)
-        assert not chain_in and relu != "consumer", "chained ReLU masks need the Conv2dAuto path"
+        assert not chain_in and relu != "consumer" and not skip_out, "chained ReLU masks / fused skip gradients need the Conv2dAuto path"
         y = F.conv2d(x, self.weight, self.bias, self.stride, self.padding)
         if residual is not None:
             y = y + residual
@@ -329,16 +330,40 @@ class _FoldedBottleneck(nn.Module):
         self.conv3 = FoldedConv(width, 4 * width, 1, gen=gen, gain=0.3)          # a small last scale keeps 33 residual sums bounded
         self.down = FoldedConv(cin, 4 * width, 1, stride=stride, gen=gen) if (stride != 1 or cin != 4 * width) else None
 
-    def forward(self, x):
-        idt = x if self.down is None else self.down(x)
+    def fuses_input(self, x):
+        """an identity block on the Conv2dAuto path: its first layer's backward takes the skip path's gradient too (ops.Conv2dAuto
+        skip_out) - and, if the producer of x left it to us, x's ReLU mask over the sum of both"""
+        return self.down is None and x.is_cuda and self.conv1.chainable() and self.conv3.chainable() and x.shape[2] * x.shape[3] > 1
+
+    def forward(self, x, mask_x=False, defer_mask=False):
+        """``mask_x``: x is the previous block's ReLU output and that block did not mask its incoming gradient (``defer_mask``): x's only
+        consumers are this block's first layer and skip path, whose gradients meet in conv1's backward"""
         # conv1 -> conv2 -> conv3 is a chain (each output has one consumer): the ReLU masks of conv1 and conv2 are applied in the
         # epilogue of their consumer's backward (ops.Conv2dAuto) instead of in passes of their own; conv3's output feeds the next block
-        # twice (its conv1 and its skip path) and keeps its own mask
+        # twice (its conv1 and its skip path): its mask is applied there if that block fuses its input (defer_mask), else here
         c12 = x.is_cuda and self.conv1.chainable() and self.conv2.chainable() and x.shape[2] * x.shape[3] > 1
         c23 = x.is_cuda and self.conv2.chainable() and self.conv3.chainable() and x.shape[2] * x.shape[3] > 1
-        y = self.conv1(x, relu="consumer" if c12 else True)
+        if self.fuses_input(x):
+            y, idt = self.conv1(x, relu="consumer" if c12 else True, chain_in=mask_x, skip_out=True)
+        else:
+            assert not mask_x
+            idt = x if self.down is None else self.down(x)
+            y = self.conv1(x, relu="consumer" if c12 else True)
         y = self.conv2(y, relu="consumer" if c23 else True, chain_in=c12)
-        return self.conv3(y, relu=True, residual=idt, chain_in=c23)
+        return self.conv3(y, relu="consumer" if defer_mask else True, residual=idt, chain_in=c23)
+
+
+def _run_stage(blocks, x):
+    """the bottlenecks of one stage in sequence; a block's output mask is left to the next block where that one fuses its input"""
+    mask_x = False
+    for i, blk in enumerate(blocks):
+        defer = False
+        if i + 1 < len(blocks) and x.is_cuda and blk.conv3.chainable() and x.shape[2] * x.shape[3] > 16:      # (the next map has more than one pixel)
+            nxt = blocks[i + 1]
+            defer = nxt.down is None and nxt.conv1.chainable() and nxt.conv3.chainable()       # (same map size as this block's output)
+        x = blk(x, mask_x=mask_x, defer_mask=defer)
+        mask_x = defer
+    return x
 
 
 class StereoRcnnR101(StereoRcnnShaped):
@@ -411,10 +436,10 @@ class StereoRcnnR101(StereoRcnnShaped):
     # -- backbone + pyramid: both eyes as one batch of two ------------------------------------------------------------------
     def pyramid(self, im):
         x = F.max_pool2d(self.stem(im, relu=True), 3, stride=2, padding=1)
-        c2 = self.layer1(x)
-        c3 = self.layer2(c2)
-        c4 = self.layer3(c3)
-        c5 = self.layer4(c4)
+        c2 = _run_stage(self.layer1, x)
+        c3 = _run_stage(self.layer2, c2)
+        c4 = _run_stage(self.layer3, c3)
+        c5 = _run_stage(self.layer4, c4)
         p5 = self.top(c5)
         p = [None, None, None, p5]
         for i, (lat, feat) in enumerate(zip(self.lat, (c4, c3, c2))):            # _upsample_add then smooth (stereo_rcnn.py:164-169)

@@ -118,6 +118,41 @@ def test_hip_conv2d_autograd_matches_torch():
 
 
 @pytest.mark.gpu
+def test_conv2d_auto_skip_out_adds_the_skip_gradient_in_the_dgrad_epilogue():
+    """a residual block y = conv_b(relu(conv_a(x))) + x with Conv2dAuto(skip_out=True) on layer a (the skip path's gradient meets the
+    convolution's in a's backward: no addition by the autograd engine) and the chained ReLU mask; x itself a ReLU output whose mask the
+    block applies over both paths - against the same block written with torch's operators"""
+    from eval_driving_safety_amd import ops
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(5)
+    for k, pad in ((3, 1), (1, 0)):
+        pre = torch.randn((2, 24, 17, 38), device=dev, generator=gen, requires_grad=True)
+        wa = torch.randn((24, 24, k, k), device=dev, generator=gen) * 0.1
+        wb = torch.randn((24, 24, k, k), device=dev, generator=gen) * 0.1
+        ba, bb = torch.randn((24,), device=dev, generator=gen), torch.randn((24,), device=dev, generator=gen)
+        go = torch.randn((2, 24, 17, 38), device=dev, generator=gen)
+        x = F.relu(pre)
+        ref = F.conv2d(F.relu(F.conv2d(x, wa, ba, 1, pad)), wb, bb, 1, pad) + x
+        (gref,) = torch.autograd.grad(ref, pre, go)
+        pa, pb = ops.Conv2dPrep(wa, 1, pad, 1), ops.Conv2dPrep(wb, 1, pad, 1)
+        # the producer of x leaves its mask to the block ("consumer"): emulate it with a Function-free clamp whose gradient is the identity
+        class _ReluNoMask(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, t):
+                return t.clamp_min(0)
+
+            @staticmethod
+            def backward(ctx, g):
+                return g
+        x2 = _ReluNoMask.apply(pre)
+        t, skip = ops.Conv2dAuto.apply(x2, pa, wa, ba, None, "consumer", True, True)      # relu left to b; mask_input: x's own mask; skip_out
+        y = ops.Conv2dAuto.apply(t, pb, wb, bb, skip, False, True)                          # + skip; chain_in: the mask of t
+        assert float((y - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+        (got,) = torch.autograd.grad(y, pre, go)
+        assert float((got - gref).abs().max()) <= 1e-4 * float(gref.abs().max()), k
+
+
+@pytest.mark.gpu
 def test_hip_conv2d_r101_layer_shapes_full_size():
     """the 1x1 layers of the ResNet-101-FPN step at their real size (600x1987 -> 150x497 ... 19x63, both eyes): a sampled set of output
     elements against the oracle's chain (the full oracle would take minutes), the whole tensor within 1e-4 of torch"""
