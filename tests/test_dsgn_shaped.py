@@ -122,3 +122,17 @@ def test_dsgn_layer_list_graph_matches_torch_operators():
     assert float((torch.sign(grad_r[big]) == torch.sign(grad[big])).float().mean()) > 0.995
     f = net.flops_per_step(x, extra)
     assert f == ref.flops_per_step(x.clone(), extra) and f > 5e11      # the 3DGV stack alone is ~0.9 TFLOP per step at any image size
+
+
+def test_dilated_convolution_equals_plain_convolution_on_parity_sub_images():
+    """DsgnShapedAdapter runs its dilation-2 blocks as dilation-1 blocks on the four (row, column) parity sub-images: the same values,
+    exactly (the same products summed in the same order), and split / merge are inverse permutations"""
+    import torch.nn.functional as F
+    from eval_driving_safety_amd.adapters import DsgnShapedAdapter as A
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn((2, 5, 8, 12), generator=gen)
+    assert torch.equal(A._parity_merge(A._parity_split(x), 2), x)
+    w = torch.randn((7, 5, 3, 3), generator=gen)
+    ref = F.conv2d(x, w, None, 1, 2, 2)
+    got = A._parity_merge(F.conv2d(A._parity_split(x), w, None, 1, 1, 1), 2)
+    assert torch.equal(got, ref)
