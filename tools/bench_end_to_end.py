@@ -92,7 +92,12 @@ def _choice_summary(fresh=False):
     def side(d):
         own = [v for k, v in c.items() if k[0] == d]
         return "%d of %d layer shapes (%d of them by the Winograd kernel)" % (sum(1 for v in own if v), len(own), sum(1 for v in own if v == "wino"))
-    return {"forward": side("f"), "backward": side("b")}
+    out = {"forward": side("f"), "backward": side("b")}
+    three = {d: [v for k, v in c.items() if k[0] == d] for d in ("f3", "b3")}
+    if three["f3"] or three["b3"]:       # stride-1 3x3x3 layers: direct float32-MFMA kernel or the Winograd kernel
+        out["stride1_3d_layers_on_the_winograd_kernel"] = {"forward": "%d of %d layer shapes" % (sum(v == "wino" for v in three["f3"]), len(three["f3"])),
+                                                            "backward": "%d of %d layer shapes" % (sum(v == "wino" for v in three["b3"]), len(three["b3"]))}
+    return out
 
 
 def measure_dsgn_full(pairs=1, iters=20, reps=1, graph=False, hip2d="auto"):
