@@ -151,11 +151,13 @@ def measure_dsgn_full(pairs=1, iters=20, reps=1, graph=False, hip2d="auto"):
     return {"metric": "end-to-end stereo-pairs/s, %d-step PGD through the DSGN-shaped graph with SURVEY App. B's layer list (surrogate, random weights)" % iters,
             "value": pairs / dt, "unit": "stereo-pairs/s", "pairs": pairs, "iters": iters, "s_per_attack": dt, "detector_fwd_bwd_ms": model_ms,
             "flops_per_step": step, "flops_per_step_per_pair": step / pairs,
-            "roofline": {"bound": "mfma", "what": "WHOLE detector step (forward + input-gradient backward; everything 3D by libadvengine, 2D layers by "
-                                                   "libadvengine or MIOpen as measured, element-wise and loss kernels included) against the float32 matrix peak",
+            "roofline": {"bound": "mfma", "what": "WHOLE detector step (forward + input-gradient backward; everything 3D by libadvengine - stride-1 layers by its direct or its "
+                                                   "Winograd kernel as measured -, 2D layers by libadvengine or MIOpen as measured, element-wise and loss kernels "
+                                                   "included): direct-convolution FLOPs (2 x MACs) against the float32 matrix peak",
                          "achieved": step / model_ms / 1e9, "peak": 157.3, "unit": "TFLOP/s", "frac": step / model_ms / 1e9 / 157.3},
-            "convolutions_2d": {"auto": "per layer shape and direction whichever of {libadvengine float32-MFMA 1x1 / 3x3 kernel with fused epilogue, "
-                                        "MIOpen} measured faster at first use", True: "libadvengine for every 1x1 / 3x3 stride-1 layer",
+            "convolutions_2d": {"auto": "per layer shape and direction whichever of {libadvengine direct float32-MFMA 1x1 / 3x3 kernel, libadvengine Winograd "
+                                        "F(2x2,3x3) kernel on the matrix cores, MIOpen} measured faster at first use - all with fused epilogues; the dilation-2 "
+                                        "blocks run as dilation-1 blocks on the four parity sub-images", True: "libadvengine for every 1x1 / 3x3 stride-1 layer",
                                 False: "torch / MIOpen"}[hip2d],
             "layers_2d_on_libadvengine": _choice_summary(),
             "mfma_frac_step": step / model_ms / 1e9 / 157.3, "peak_hbm_gib": torch.cuda.max_memory_allocated() / 2 ** 30,
