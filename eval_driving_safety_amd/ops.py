@@ -12,7 +12,7 @@ import ctypes
 import torch
 import torch.nn.functional as F
 
-from . import _lib
+from . import _lib, routes
 from ._lib import AdvSpace
 
 _lib.load()  # fail at import time if the HIP library is not built
@@ -1115,53 +1115,24 @@ def bias_act_(y, bias=None, residual=None, relu=False):
 
 
 class _Conv2dChoice:
-    """Per layer shape: who computes the forward and who the backward w.r.t. the input - this package's kernel (epilogue fused) or
-    torch's operator (MIOpen / rocBLAS + separate element-wise kernels).  Decided by MEASUREMENT the first time a shape is seen (three
-    timed calls each, HIP events on the current stream - what MIOpen's own solver search does for its candidates), then cached for the
-    process.  The float32 MFMA kernels win on large maps and on the memory-bound 1x1 layers, where the fused epilogue saves as many
-    bytes as the convolution moves; MIOpen's Winograd wins on small maps at one pair per step (profiles/r03_conv2d_layers_ab.jsonl)."""
-    cache = {}
-    enabled = True
-    wino = True          # consider the Winograd route
+    """Per layer shape and direction: who computes it - this package's direct kernel ("hip"), its Winograd kernel ("wino") or torch's
+    operator ("", MIOpen / rocBLAS + one fused element-wise pass).  The three sum in different float orders, so the choice is part of
+    the result: it comes from the committed table ``routes_gfx950.json`` (routes.py; a fixed rule for shapes the table does not hold),
+    the same in every process and on every rank.  Only ``ADV_ROUTES=measure`` (tools/make_routes.py, the per-layer benches) times the
+    candidates, which is how the table is generated (round 3 timed at first use in every run: results differed run to run)."""
 
     @staticmethod
-    def _time(fn):
-        fn()                                     # solver search / first-touch outside the timed calls
-        best = float("inf")
-        for _ in range(2):                       # the better of two groups of three: one noisy group must not decide a layer for the whole run
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(3):
-                fn()
-            e1.record()
-            e1.synchronize()
-            best = min(best, e0.elapsed_time(e1))
-        return best
+    def pick(key, fns):
+        """the route name for ``key`` among ``fns`` (name -> callable)"""
+        return routes.choose(key, fns)
 
-    @classmethod
-    def pick(cls, key, fns):
-        """the name of the fastest of ``fns`` (name -> callable) for this key; timed once, cached; inside a stream capture: the first name"""
-        c = cls.cache.get(key)
-        if c is None:
-            if torch.cuda.is_current_stream_capturing():
-                return next(iter(fns))
-            t = {name: cls._time(fn) for name, fn in fns.items()}
-            c = cls.cache[key] = min(t, key=t.get)
-        return c
-
-    @classmethod
-    def get(cls, key, hip_fn, torch_fn, wino_fn=None):
+    @staticmethod
+    def get(key, hip_fn, torch_fn, wino_fn=None):
         """-> "hip" (direct implicit GEMM), "wino" (Winograd on the matrix cores, 3x3 layers) or "" (torch / MIOpen)"""
-        c = cls.cache.get(key)
-        if c is None:
-            if torch.cuda.is_current_stream_capturing():
-                return "hip"                     # cannot time inside a capture: this package's kernel
-            t = {"hip": cls._time(hip_fn), "": cls._time(torch_fn)}
-            if wino_fn is not None and cls.wino:
-                t["wino"] = cls._time(wino_fn)
-            c = min(t, key=t.get)
-            cls.cache[key] = c
-        return c
+        fns = {"hip": hip_fn, "": torch_fn}
+        if wino_fn is not None:
+            fns["wino"] = wino_fn
+        return routes.choose(key, fns)
 
 
 class Conv2dAuto(torch.autograd.Function):

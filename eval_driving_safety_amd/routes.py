@@ -1,0 +1,151 @@
+"""Which kernel computes a convolution - a COMMITTED TABLE, not a stopwatch.
+
+Several layers have more than one implementation in libadvengine (direct implicit GEMM, Winograd F(2x2,3x3)) next to torch's
+own operator (MIOpen); they sum in different float orders, so the choice is part of the RESULT: two runs of one attack, or two
+ranks of an image-sharded job, must take the same route for the same layer or their gradients differ in the last bits, the sign
+maps flip somewhere and the adversarial PNGs differ.  Round 3 chose by timing at first use; this module replaces that:
+
+  ADV_ROUTES=table   (default)  ``routes_gfx950.json`` next to this file: "direction|kernel|shape..." -> route, generated on an
+                                MI355X by tools/make_routes.py from per-layer measurements and committed.  A shape the table
+                                does not hold gets the FIXED RULE below - never a timer.
+  ADV_ROUTES=fixed              the fixed rule only (what a table miss gets).
+  ADV_ROUTES=measure            round 3's behaviour (time every candidate the first time a shape is seen, keep the fastest for
+                                the process): for tools/make_routes.py and the per-layer benches, which is how the table is made.
+  ADV_ROUTES=/path/to.json      another table (e.g. one a user generated for their own layer shapes with tools/make_routes.py).
+
+The fixed rule: a layer with a Winograd kernel (3x3 / 3x3x3, stride 1) takes it, everything else this package's direct kernel;
+torch's operator only where the table says so (it won 3 % of the measured layer shapes, all small maps).  ``table_hash()``
+identifies the table in bench lines and output manifests.
+"""
+import hashlib
+import json
+import os
+
+import torch
+
+_DEFAULT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "routes_gfx950.json")
+ROUTES = ("hip", "wino", "", "direct")         # "" = torch's operator (MIOpen / rocBLAS); "direct"/"wino" for the 3D stride-1 layers
+
+_state = {"mode": None, "table": None, "path": None, "measured": {}, "misses": set(), "used": {}}
+
+
+def key_str(key):
+    """a route key (nested tuples of ints / bools / strings) -> the flat string the JSON table is indexed by"""
+    out = []
+    for v in key:
+        if isinstance(v, (tuple, list, torch.Size)):
+            out.append("x".join(str(int(q)) for q in v))
+        elif isinstance(v, bool):
+            out.append("1" if v else "0")
+        else:
+            out.append(str(v))
+    return "|".join(out)
+
+
+def _load(path):
+    with open(path) as f:
+        doc = json.load(f)
+    routes = doc.get("routes", {})
+    bad = {k: v for k, v in routes.items() if v not in ROUTES}
+    if bad:
+        raise ValueError("%s: unknown routes %r" % (path, bad))
+    return routes
+
+
+def configure(mode=None):
+    """(re)read ADV_ROUTES (or take ``mode``): "table" | "fixed" | "measure" | a path"""
+    mode = mode if mode is not None else os.environ.get("ADV_ROUTES", "table")
+    _state["measured"], _state["misses"], _state["used"] = {}, set(), {}
+    if mode in ("fixed", "measure"):
+        _state.update(mode=mode, table={}, path=None)
+    else:
+        path = _DEFAULT if mode == "table" else mode
+        if not os.path.exists(path):
+            if mode != "table":
+                raise FileNotFoundError("ADV_ROUTES=%s: no such route table" % mode)
+            _state.update(mode="table", table={}, path=None)           # no table shipped: everything by the fixed rule
+        else:
+            _state.update(mode="table", table=_load(path), path=path)
+    return _state["mode"]
+
+
+def mode():
+    if _state["mode"] is None:
+        configure()
+    return _state["mode"]
+
+
+def table_hash():
+    """12 hex digits identifying the decisions in force (the table's content, or the mode when there is none)"""
+    m = mode()
+    if m != "table":
+        return m
+    blob = json.dumps(sorted(_state["table"].items()), separators=(",", ":")).encode()
+    return hashlib.sha256(blob).hexdigest()[:12]
+
+
+def fixed_rule(names):
+    """the route of a shape the table does not know: Winograd where the layer has it, else this package's direct kernel"""
+    if "wino" in names:
+        return "wino"
+    return "hip" if "hip" in names else next(iter(names))
+
+
+def _time(fn):
+    fn()                                     # solver search / first touch outside the timed calls
+    best = float("inf")
+    for _ in range(3):                       # the best of three groups of three: one noisy group must not decide a layer
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            fn()
+        e1.record()
+        e1.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    return best
+
+
+def choose(key, fns):
+    """the name of the route for ``key`` among ``fns`` (name -> callable, in order of preference for ties).  Table / fixed rule:
+    no launch, no clock, the same answer in every process.  Measure mode: times each candidate once per key (outside stream
+    captures), remembers the winner - and the timings, for tools/make_routes.py."""
+    m = mode()
+    ks = key_str(key)
+    if m == "measure":
+        got = _state["measured"].get(ks)
+        if got is None:
+            if torch.cuda.is_current_stream_capturing():
+                return fixed_rule(fns)
+            t = {name: _time(fn) for name, fn in fns.items()}
+            got = _state["measured"][ks] = (min(t, key=t.get), t)
+        r = got[0]
+    else:
+        r = _state["table"].get(ks) if m == "table" else None
+        if r is None or r not in fns:
+            if m == "table":
+                _state["misses"].add(ks)
+            r = fixed_rule(fns)
+    _state["used"][ks] = r
+    return r
+
+
+def measured():
+    """measure mode: {key string: (winner, {route: ms of three calls})}"""
+    return dict(_state["measured"])
+
+
+def used():
+    """{key string: route} of every decision this process has asked for"""
+    return dict(_state["used"])
+
+
+def misses():
+    """table mode: the key strings that were looked up and not found (they took the fixed rule)"""
+    return sorted(_state["misses"])
+
+
+def summary():
+    """how many of the decisions of this process so far came from where (for bench lines)"""
+    return {"mode": mode(), "table": os.path.basename(_state["path"]) if _state["path"] else None, "hash": table_hash(),
+            "table_entries": len(_state["table"] or {}), "fixed_rule_lookups": len(_state["misses"]),
+            "measured_shapes": len(_state["measured"])}

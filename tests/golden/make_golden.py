@@ -473,6 +473,49 @@ def cli_flags_case():
     return out
 
 
+def objective_cases():
+    """a4 / a14: the OBJECTIVE statements of the two PGD scripts - attack/DSGN/pgd_attack.py:269-270 (mask), :301-336 (forward call,
+    depth term, RPN3D term, zero_grad, backward) and attack/Stereo-RCNN/pgd_attack.py:153-174 (forward call, the six
+    uncertainty-weighted terms, backward) - executed as they stand around the stand-in detectors of stub_models.py.  Stored: the
+    loss and what ``backward()`` left in the image gradients.  Inputs regenerate from the seeds (synth + torch.Generator)."""
+    import torch.nn.functional as F
+    import stub_models
+    out = {}
+    arrays = {}
+    h, w = 10, 14
+    for name, loss_disp, rpn in (("dsgn_both", True, True), ("dsgn_depth_only", True, False), ("dsgn_rpn_only", False, True)):
+        cfg = types.SimpleNamespace(PlaneSweepVolume=True, loss_disp=loss_disp, RPN3D_ENABLE=rpn, min_depth=2.0, max_depth=40.4, stub_gain=0.7)
+        gen = torch.Generator().manual_seed(41)
+        disp_true = torch.rand((1, h, w), generator=gen) * 50.0
+        targets = (torch.randn((h, w), generator=gen),)
+        ns = {"torch": torch, "F": F, "cfg": cfg, "RPN3DLoss": stub_models.StubRpn3dLoss, "model": stub_models.StubDsgn(5).eval(),
+              "imgL": torch.from_numpy(synth.dsgn_normalised(51, h, w).copy()), "imgR": torch.from_numpy(synth.dsgn_normalised(52, h, w).copy()),
+              "disp_true": disp_true, "targets": targets, "calib": None, "calib_R": None, "ious": 0.3, "labels_map": None,
+              "calibs_fu": torch.tensor([721.5377]), "calibs_baseline": torch.tensor([0.54]),
+              "calibs_Proj": torch.arange(12, dtype=torch.float64).view(1, 3, 4) / 10, "calibs_Proj_R": torch.ones(1, 3, 4, dtype=torch.float64)}
+        exec_lines(DSGN_PGD, 269, 270, ns)            # mask = (disp_true > cfg.min_depth) & (disp_true <= cfg.max_depth); detach_
+        exec_lines(DSGN_PGD, 301, 302, ns)            # loss = 0.; losses = dict()
+        exec_lines(DSGN_PGD, 305, 306, ns)            # requires_grad
+        exec_lines(DSGN_PGD, 308, 336, ns)            # forward, both terms, zero_grad, retain_grad, backward
+        arrays[name + "_gradL"], arrays[name + "_gradR"] = ns["imgL"].grad.numpy().copy(), ns["imgR"].grad.numpy().copy()
+        arrays[name + "_loss"] = ns["loss"].detach().numpy().copy()
+        out[name] = {"h": h, "w": w, "loss_disp": loss_disp, "RPN3D_ENABLE": rpn, "loss": float(ns["loss"]), "mask_count": int(ns["mask"].sum()),
+                     "loss_keys": sorted(ns["losses"].keys())}
+    gen = torch.Generator().manual_seed(43)
+    uncert = torch.randn(6, generator=gen) * 0.4
+    ns = {"torch": torch, "stereoRCNN": stub_models.StubStereoRcnn(6).eval(), "uncert": uncert,
+          "im_left_data": torch.from_numpy(synth.srcnn_meansub(61, h, w).copy()), "im_right_data": torch.from_numpy(synth.srcnn_meansub(62, h, w).copy()),
+          "im_info": torch.tensor([[float(h), float(w), 1.6]]), "gt_boxes_left": torch.full((1, 30, 5), 0.25), "gt_boxes_right": torch.zeros(1, 30, 5),
+          "gt_boxes_merge": torch.zeros(1, 30, 5), "gt_dim_orien": torch.zeros(1, 30, 5), "gt_kpts": torch.zeros(1, 30, 6), "num_boxes": torch.tensor([1])}
+    exec_lines("attack/Stereo-RCNN/pgd_attack.py", 153, 174, ns)
+    arrays["srcnn_gradL"], arrays["srcnn_gradR"] = ns["im_left_data"].grad.numpy().copy(), ns["im_right_data"].grad.numpy().copy()
+    arrays["srcnn_loss"] = ns["loss"].detach().numpy().copy()
+    arrays["srcnn_uncert"] = uncert.numpy().copy()
+    out["srcnn"] = {"h": h, "w": w, "loss": float(ns["loss"])}
+    out["bytes"] = save_npz("objectives.npz", arrays)
+    return out
+
+
 def save_npz(name, arrays):
     path = os.path.join(HERE, name)
     np.savez_compressed(path, **arrays)
@@ -538,6 +581,7 @@ def main():
     index["scenario"] = scenario_case(index["label"]["text"])
     index["depth_stats"] = depth_stats_case()
     index["cli_flags"] = cli_flags_case()
+    index["objectives"] = objective_cases()
     with open(os.path.join(HERE, "index.json"), "w") as f:
         json.dump(index, f, indent=1, sort_keys=True)
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE)

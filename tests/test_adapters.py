@@ -1,96 +1,87 @@
 """The objective glue of the upstream-model adapters (attack/DSGN/pgd_attack.py:300-336 and
-attack/Stereo-RCNN/pgd_attack.py:151-174) exercised with stand-in model objects that have the upstream
-call signatures, and the KITTI folder reader on synthetic PNGs.  CPU only."""
+attack/Stereo-RCNN/pgd_attack.py:151-174) pinned against the reference's own statements, executed by
+tests/golden/make_golden.py around stand-in model objects with the upstream call signatures (tests/golden/stub_models.py), and the KITTI folder reader on synthetic PNGs.  CPU only."""
 import os
 import types
 
 import numpy as np
+import pytest
 import torch
-import torch.nn.functional as F
 
+import stub_models
+import synth
 from eval_driving_safety_amd import adapters, data
 
 
-class _FakeDsgn(torch.nn.Module):
-    """same call signature and output dict as StereoNet (pgd_attack.py:215-222,308)"""
-
-    def __init__(self):
-        super().__init__()
-        self.w = torch.nn.Parameter(torch.tensor(0.5))
-        self.calls = []
-
-    def forward(self, imgL, imgR, fu, baseline, proj, calibs_Proj_R=None):
-        self.calls.append((fu, baseline, proj, calibs_Proj_R))
-        depth = 10 + self.w * (imgL.mean(dim=1) - imgR.mean(dim=1))          # [B,H,W]
-        return {"depth_preds": depth,        # eval mode: a [B,H,W] tensor that the script iterates over (pgd_attack.py:311)
-                 "bbox_cls": imgL.sum(), "bbox_reg": imgR.sum(), "bbox_centerness": imgL.mean()}
+def _same(got, want, what):
+    """bit for bit on the CPU family the fixture was generated on; another SIMD width may round oneDNN's convolutions of the stand-in
+    detector differently - then (and only then) 1e-6 relative, with a warning naming the case"""
+    got = got.detach().numpy() if hasattr(got, "detach") else np.asarray(got)
+    if got.tobytes() == want.tobytes():
+        return
+    import warnings
+    assert got.shape == want.shape and np.allclose(got, want, rtol=1e-6, atol=1e-7 * float(np.abs(want).max())), what
+    warnings.warn("%s: equal to 1e-6 but not bit for bit (different CPU kernels than the fixture's host?)" % what)
 
 
-class _FakeRpnLoss:
-    def __init__(self, cfg):
-        pass
-
-    def __call__(self, cls, reg, ctr, targets, calib, calib_R, ious=None, labels_map=None):
-        total = 0.01 * cls + 0.02 * reg + ctr
-        return total, cls, reg, ctr
-
-
-def test_dsgn_adapter_objective_and_gradient():
-    torch.manual_seed(0)
-    B, H, W = 1, 6, 8
-    x = torch.randn(2 * B, 3, H, W)
-    disp = torch.rand(B, H, W) * 50
-    cfg = types.SimpleNamespace(PlaneSweepVolume=True, loss_disp=True, RPN3D_ENABLE=True, min_depth=2.0, max_depth=40.4)
-    extra = types.SimpleNamespace(calibs_fu=torch.tensor([721.5]), calibs_baseline=torch.tensor([0.54]), calibs_Proj=torch.zeros(1, 3, 4),
-                                  calibs_Proj_R=torch.ones(1, 3, 4), disp_true=disp, targets=None, calib=None, calib_R=None,
-                                  ious=None, labels_map=None)
-    model = _FakeDsgn()
-    ad = adapters.DsgnAdapter(model, cfg, _FakeRpnLoss)
-    loss, grad = ad.loss_and_grad(x, extra)
-    assert model.calls[0][3] is extra.calibs_Proj_R and not x.requires_grad and x.grad is None
-    # the same objective written out directly
-    xr = x.clone().requires_grad_(True)
-    imgL, imgR = xr[:B], xr[B:]
-    depth = 10 + 0.5 * (imgL.mean(dim=1) - imgR.mean(dim=1))
-    mask = (disp > 2.0) & (disp <= 40.4)
-    want = 1.0 * F.smooth_l1_loss(depth[mask[0]][None] if False else depth[0][mask[0]], disp[mask]) \
-        + 0.01 * imgL.sum() + 0.02 * imgR.sum() + imgL.mean()
-    want.backward()
-    assert torch.allclose(loss, want.detach(), rtol=1e-6, atol=1e-6)
-    assert torch.allclose(grad, xr.grad, rtol=1e-5, atol=1e-7)
-    assert model.w.grad is None                          # the detector's weights are constants: no weight gradients by default
-    model2 = _FakeDsgn()
-    loss2, grad2 = adapters.DsgnAdapter(model2, cfg, _FakeRpnLoss, freeze=False).loss_and_grad(x, extra)
-    assert model2.w.grad is not None                     # freeze=False: the reference's behaviour (model.zero_grad(), then backward)
-    assert torch.equal(grad2, grad) and torch.equal(loss2, loss)      # the image gradient does not depend on it
+def _dsgn_inputs(h, w):
+    """the inputs tests/golden/make_golden.py:objective_cases() drew (same seeds, same order of draws)"""
+    gen = torch.Generator().manual_seed(41)
+    disp_true = torch.rand((1, h, w), generator=gen) * 50.0
+    targets = (torch.randn((h, w), generator=gen),)
+    x = torch.from_numpy(np.concatenate([synth.dsgn_normalised(51, h, w), synth.dsgn_normalised(52, h, w)]))
+    extra = types.SimpleNamespace(calibs_fu=torch.tensor([721.5377]), calibs_baseline=torch.tensor([0.54]),
+                                  calibs_Proj=torch.arange(12, dtype=torch.float64).view(1, 3, 4) / 10,
+                                  calibs_Proj_R=torch.ones(1, 3, 4, dtype=torch.float64), disp_true=disp_true, targets=targets,
+                                  calib=None, calib_R=None, ious=0.3, labels_map=None)
+    return x, extra
 
 
-class _FakeSrcnn(torch.nn.Module):
-    """nine inputs -> fifteen outputs, the six losses at positions 8..13 (stereo_rcnn.py:324-326)"""
+@pytest.mark.parametrize("name", ["dsgn_both", "dsgn_depth_only", "dsgn_rpn_only"])
+def test_dsgn_adapter_objective_equals_the_reference_statements(name, golden, golden_index):
+    """a4: adapters.DsgnAdapter around the stand-in detector against what attack/DSGN/pgd_attack.py:269-270,301-336 - EXECUTED by
+    make_golden.py around the same stand-in - left in ``loss`` and ``imgL.grad`` / ``imgR.grad``.  Same torch-CPU operators in the same
+    order: compared bit for bit."""
+    m, g = golden_index["objectives"][name], golden("objectives")
+    x, extra = _dsgn_inputs(m["h"], m["w"])
+    cfg = types.SimpleNamespace(PlaneSweepVolume=True, loss_disp=m["loss_disp"], RPN3D_ENABLE=m["RPN3D_ENABLE"], min_depth=2.0, max_depth=40.4,
+                                stub_gain=0.7)
+    model = stub_models.StubDsgn(5).eval()
+    for freeze in (True, False):                   # freeze=False is the reference's behaviour; the image gradient does not depend on it
+        loss, grad = adapters.DsgnAdapter(model, cfg, stub_models.StubRpn3dLoss, freeze=freeze).loss_and_grad(x, extra)
+        assert not x.requires_grad and x.grad is None
+        _same(loss, g[name + "_loss"], name + " loss")
+        _same(grad[:1], g[name + "_gradL"], name + " left gradient")
+        _same(grad[1:], g[name + "_gradR"], name + " right gradient")
+    assert float(np.abs(g[name + "_gradL"]).sum()) > 0 and float(np.abs(g[name + "_gradR"]).sum()) > 0
 
-    def __init__(self):
-        super().__init__()
-        self.p = torch.nn.Parameter(torch.ones(1))
 
-    def forward(self, l, r, info, gl, gr, gm, gdo, gk, nb):
-        losses = [(l * l).mean(dim=(1, 2, 3)), (r * r).mean(dim=(1, 2, 3)), (l * r).mean(dim=(1, 2, 3)), l.abs().mean(dim=(1, 2, 3)),
-                  r.abs().mean(dim=(1, 2, 3)), (l - r).pow(2).mean(dim=(1, 2, 3))]
-        return tuple([None] * 8 + [v * self.p for v in losses] + [None])
+def test_dsgn_adapter_freezes_the_detector_by_default():
+    x, extra = _dsgn_inputs(10, 14)
+    cfg = types.SimpleNamespace(PlaneSweepVolume=True, loss_disp=True, RPN3D_ENABLE=True, min_depth=2.0, max_depth=40.4, stub_gain=0.7)
+    model = stub_models.StubDsgn(5).eval()
+    adapters.DsgnAdapter(model, cfg, stub_models.StubRpn3dLoss).loss_and_grad(x, extra)
+    assert all(p.grad is None for p in model.parameters())          # the detector's weights are constants: no weight gradients
+    model2 = stub_models.StubDsgn(5).eval()
+    adapters.DsgnAdapter(model2, cfg, stub_models.StubRpn3dLoss, freeze=False).loss_and_grad(x, extra)
+    assert all(p.grad is not None for p in model2.parameters())     # the reference: model.zero_grad(), then backward into them too
 
 
-def test_stereo_rcnn_adapter_uncertainty_weighting():
-    torch.manual_seed(1)
-    x = torch.randn(2, 3, 5, 7)
-    u = torch.tensor([0.1, -0.2, 0.3, 0.0, 0.5, -0.4])
-    extra = types.SimpleNamespace(im_info=None, gt_boxes_left=None, gt_boxes_right=None, gt_boxes_merge=None, gt_dim_orien=None,
-                                  gt_kpts=None, num_boxes=None)
-    loss, grad = adapters.StereoRcnnAdapter(_FakeSrcnn(), u).loss_and_grad(x, extra)
-    xr = x.clone().requires_grad_(True)
-    l, r = xr[:1], xr[1:]
-    terms = [(l * l).mean(), (r * r).mean(), (l * r).mean(), l.abs().mean(), r.abs().mean(), (l - r).pow(2).mean()]
-    want = sum(t * torch.exp(-u[k]) + u[k] for k, t in enumerate(terms))      # pgd_attack.py:165-171
-    want.backward()
-    assert torch.allclose(loss, want.detach(), rtol=1e-6) and torch.allclose(grad, xr.grad, rtol=1e-5, atol=1e-7)
+def test_stereo_rcnn_adapter_objective_equals_the_reference_statements(golden, golden_index):
+    """a14: adapters.StereoRcnnAdapter against attack/Stereo-RCNN/pgd_attack.py:153-174 executed around the same stand-in network:
+    the fifteen outputs unpacked, six ``.mean() * exp(-u_k) + u_k`` terms in the script's order of additions, backward."""
+    m, g = golden_index["objectives"]["srcnn"], golden("objectives")
+    h, w = m["h"], m["w"]
+    x = torch.from_numpy(np.concatenate([synth.srcnn_meansub(61, h, w), synth.srcnn_meansub(62, h, w)]))
+    extra = types.SimpleNamespace(im_info=torch.tensor([[float(h), float(w), 1.6]]), gt_boxes_left=torch.full((1, 30, 5), 0.25),
+                                  gt_boxes_right=torch.zeros(1, 30, 5), gt_boxes_merge=torch.zeros(1, 30, 5), gt_dim_orien=torch.zeros(1, 30, 5),
+                                  gt_kpts=torch.zeros(1, 30, 6), num_boxes=torch.tensor([1]))
+    u = torch.from_numpy(g["srcnn_uncert"].copy())
+    loss, grad = adapters.StereoRcnnAdapter(stub_models.StubStereoRcnn(6).eval(), u).loss_and_grad(x, extra)
+    _same(loss, g["srcnn_loss"], "srcnn loss")
+    _same(grad[:1], g["srcnn_gradL"], "srcnn left gradient")
+    _same(grad[1:], g["srcnn_gradR"], "srcnn right gradient")
+    assert float(np.abs(g["srcnn_gradL"]).sum()) > 0 and float(np.abs(g["srcnn_gradR"]).sum()) > 0
 
 
 def test_toy_adapter_is_deterministic_and_nontrivial():

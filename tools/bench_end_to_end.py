@@ -84,15 +84,18 @@ def measure(pairs=1, iters=20, reps=2, warm_iters=None, mfma_conv=True, hourglas
 
 
 def _choice_summary(fresh=False):
-    from eval_driving_safety_amd import ops
-    if fresh:                                   # a new leg: its own decisions (shapes differ between the detectors anyway)
-        ops._Conv2dChoice.cache.clear()
+    """which kernel computed the convolutions of a leg: the decisions come from routes.py (the committed table by default)"""
+    from eval_driving_safety_amd import routes
+    if fresh:                                   # a new leg: count its own decisions
+        routes._state["used"].clear()
+        routes._state["misses"].clear()
         return None
-    c = ops._Conv2dChoice.cache
+    c = {tuple(k.split("|")): v for k, v in routes.used().items()}
+
     def side(d):
         own = [v for k, v in c.items() if k[0] == d]
         return "%d of %d layer shapes (%d of them by the Winograd kernel)" % (sum(1 for v in own if v), len(own), sum(1 for v in own if v == "wino"))
-    out = {"forward": side("f"), "backward": side("b")}
+    out = {"forward": side("f"), "backward": side("b"), "routes": routes.summary()}
     three = {d: [v for k, v in c.items() if k[0] == d] for d in ("f3", "b3")}
     if three["f3"] or three["b3"]:       # stride-1 3x3x3 layers: direct float32-MFMA kernel or the Winograd kernel
         out["stride1_3d_layers_on_the_winograd_kernel"] = {"forward": "%d of %d layer shapes" % (sum(v == "wino" for v in three["f3"]), len(three["f3"])),
@@ -152,11 +155,11 @@ def measure_dsgn_full(pairs=1, iters=20, reps=1, graph=False, hip2d="auto"):
             "value": pairs / dt, "unit": "stereo-pairs/s", "pairs": pairs, "iters": iters, "s_per_attack": dt, "detector_fwd_bwd_ms": model_ms,
             "flops_per_step": step, "flops_per_step_per_pair": step / pairs,
             "roofline": {"bound": "mfma", "what": "WHOLE detector step (forward + input-gradient backward; everything 3D by libadvengine - stride-1 layers by its direct or its "
-                                                   "Winograd kernel as measured -, 2D layers by libadvengine or MIOpen as measured, element-wise and loss kernels "
+                                                   "Winograd kernel -, 2D layers by libadvengine or MIOpen, each as the committed route table says, element-wise and loss kernels "
                                                    "included): direct-convolution FLOPs (2 x MACs) against the float32 matrix peak",
                          "achieved": step / model_ms / 1e9, "peak": 157.3, "unit": "TFLOP/s", "frac": step / model_ms / 1e9 / 157.3},
             "convolutions_2d": {"auto": "per layer shape and direction whichever of {libadvengine direct float32-MFMA 1x1 / 3x3 kernel, libadvengine Winograd "
-                                        "F(2x2,3x3) kernel on the matrix cores, MIOpen} measured faster at first use - all with fused epilogues; the dilation-2 "
+                                        "F(2x2,3x3) kernel on the matrix cores, MIOpen} the committed route table (routes_gfx950.json) names - all with fused epilogues; the dilation-2 "
                                         "blocks run as dilation-1 blocks on the four parity sub-images", True: "libadvengine for every 1x1 / 3x3 stride-1 layer",
                                 False: "torch / MIOpen"}[hip2d],
             "layers_2d_on_libadvengine": _choice_summary(),
