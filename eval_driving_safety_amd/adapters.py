@@ -58,6 +58,8 @@ class ToyStereoAdapter:
     synthetic target.  NOT a detector - a deterministic differentiable stand-in with the same call shape,
     so that loop-level behaviour can be tested without DSGN / Stereo R-CNN."""
 
+    graph_safe = True
+
     def __init__(self, device, seed=0, channels=8, planes=(0, 4, 8, 16)):
         gen = torch.Generator().manual_seed(seed)
         self.w1 = (torch.randn(channels, 3, 3, 3, generator=gen) * 0.2).to(device)
@@ -110,6 +112,8 @@ class PsvStereoAdapter:
                        depth smooth-L1 + (sigmoid focal + smooth-L1 + BCE) as attack/DSGN/pgd_attack.py:310-336 adds them.
     It is NOT DSGN (random weights, simplified heads, no trained parameters): detection parity is unpinned by construction; it
     exists so that "20-step PGD through a plane-sweep detector" can be measured end to end on this hardware."""
+
+    graph_safe = True       # no host read-back, no data-dependent shape inside loss_and_grad: attacks.PgdAttack(graph=True) may capture it
 
     def __init__(self, device, seed=0, channels=32, planes=48, min_depth=2.0, depth_step=0.8, fu=721.5377,
                  baseline=0.54, downsample=4, mid=32, mfma_conv=True, interp=True, hourglass=False, dsgn_head=False,
@@ -447,12 +451,14 @@ class PsvStereoAdapter:
     def _depth_targets(self, gt):
         """the valid-depth mask of pgd_attack.py:269 as a flat index list + the depths it selects, computed once per ground-truth
         tensor (it does not change over the iterations of an attack): an iteration then gathers by index, with no nonzero / D2H"""
-        key = (gt.data_ptr(), tuple(gt.shape), gt._version)
-        if getattr(self, "_gt_key", None) != key:
+        # keyed on the tensor OBJECT (kept alive here) and its version counter: an address is not an identity - the caching allocator hands
+        # the next batch's ground truth the address of the one just freed, with the same shape and version 0
+        held = getattr(self, "_gt_key", None)
+        if held is None or held[0] is not gt or held[1] != gt._version:
             lo, hi = float(self.depth[0]), float(self.depth[-1]) + 0.8
             mask = (gt > lo) & (gt <= hi)
             idx = torch.nonzero(mask.reshape(-1)).view(-1)
-            self._gt_cache, self._gt_key = (idx, gt.reshape(-1).index_select(0, idx)), key
+            self._gt_cache, self._gt_key = (idx, gt.reshape(-1).index_select(0, idx)), (gt, gt._version)
         return self._gt_cache
 
     def loss_and_grad(self, x, extra):

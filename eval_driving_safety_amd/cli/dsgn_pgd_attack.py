@@ -41,8 +41,11 @@ def main(argv=None):
         rt = _common.upstream_or_exit(lambda: upstream.DsgnRuntime(args, dev, attack=True))
         adapter = adapters.DsgnAdapter(rt.model, rt.cfg, rt.RPN3DLoss)
         loader = upstream.dsgn_attack_loader(rt)
+    if args.graph and not getattr(adapter, "graph_safe", False):
+        raise SystemExit("--graph needs a detector step without host read-backs or data-dependent shapes (--model toy / shaped / layerlist); "
+                         "an upstream DSGN model is not known to be one")
     atk = PgdAttack("dsgn", args.alpha, args.eps, args.iter, out_root=args.out_root, save_every=args.save_every, device=dev,
-                    reference_on_gpu=args.reference_on_gpu, graph=args.graph and args.model != "upstream")
+                    reference_on_gpu=args.reference_on_gpu, graph=args.graph)
     n = atk.run(loader, adapter, comm, debugnum=args.debugnum if args.debug else None)
     print("rank %d attacked %d stereo pairs" % (comm.rank, n))
     comm.close()

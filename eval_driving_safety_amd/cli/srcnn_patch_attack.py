@@ -42,7 +42,7 @@ def main(argv=None):
             adapter = adapters.StereoRcnnAdapter(net.to(dev).eval(), torch.zeros(6, device=dev))
             factory = lambda: _common.WithExtra(base(), lambda b: surrogates.synthetic_srcnn_extra(b, dev))
     else:
-        rt = _common.upstream_or_exit(lambda: upstream.SrcnnRuntime(dev, training=True, workers=8))     # :128-129
+        rt = _common.upstream_or_exit(lambda: upstream.SrcnnRuntime(dev, training=True, workers=8, adopt=args.adopt))     # :128-129
         adapter = adapters.StereoRcnnAdapter(rt.model, rt.uncert)
         factory = lambda: upstream.srcnn_loader(rt)
     trainer = PatchTrainer("srcnn", args.ratio, args.eps, args.iter, args.epochs, out_root=args.out_root,

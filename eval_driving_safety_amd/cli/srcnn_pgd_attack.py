@@ -43,9 +43,11 @@ def main(argv=None):
             adapter = adapters.StereoRcnnAdapter(net.to(dev).eval(), torch.zeros(6, device=dev))
             loader = _common.WithExtra(loader, lambda b: surrogates.synthetic_srcnn_extra(b, dev))
     else:
-        rt = _common.upstream_or_exit(lambda: upstream.SrcnnRuntime(dev, training=True, workers=0))
+        rt = _common.upstream_or_exit(lambda: upstream.SrcnnRuntime(dev, training=True, workers=0, adopt=args.adopt))
         adapter = adapters.StereoRcnnAdapter(rt.model, rt.uncert)
         loader = upstream.srcnn_loader(rt)
+    if args.graph:
+        raise SystemExit("--graph: the Stereo R-CNN detector step has data-dependent shapes (proposals, NMS): it cannot be captured in a hipGraph")
     atk = PgdAttack("srcnn", args.alpha, args.eps, args.iter, out_root=args.out_root, save_every=args.save_every, device=dev)
     # `if args.debug and i >= args.debugnum: break` (:107-108): debugnum - 1 is the last index attacked
     n = atk.run(loader, adapter, comm, debugnum=(args.debugnum - 1) if (args.debug and args.debugnum is not None) else None)

@@ -25,7 +25,7 @@ def main(argv=None):
     args = build_parser().parse_args(argv)
     dev, _ = _common.setup_device(args.devices)
     from .. import ops
-    rt = _common.upstream_or_exit(lambda: upstream.SrcnnRuntime(dev, training=False, workers=0, normalize=False))
+    rt = _common.upstream_or_exit(lambda: upstream.SrcnnRuntime(dev, training=False, workers=0, normalize=False, adopt=args.adopt))
     written, result_dir = _srcnn_detect.run(args, rt, "patch", dev, ops)
     print("wrote %d detections to %s" % (written, result_dir))
 

@@ -20,7 +20,7 @@ def main(argv=None):
     args = build_parser().parse_args(argv)
     dev, _ = _common.setup_device(args.devices)
     from .. import ops
-    rt = _common.upstream_or_exit(lambda: upstream.SrcnnRuntime(dev, training=False, workers=0, normalize=False))      # :78-124
+    rt = _common.upstream_or_exit(lambda: upstream.SrcnnRuntime(dev, training=False, workers=0, normalize=False, adopt=args.adopt))      # :78-124
     written, result_dir = _srcnn_detect.run(args, rt, "pgd", dev, ops)
     print("wrote %d detections to %s" % (written, result_dir))
 

@@ -47,19 +47,45 @@ def resolve_devices(devices, mem_info):
     return devices
 
 
-def used_memory_per_gpu():
-    """stand-in for upstream ``env_utils.mem_info`` when it is absent: bytes in use per visible GPU.  Read from the driver's sysfs
-    counters (``mem_info_vram_used`` of the amdgpu render nodes) so that choosing a GPU does not create a HIP context on every
-    one of them; only where those files are not readable does it fall back to ``torch.cuda.mem_get_info``."""
+def _sysfs_vram_used_by_bus_id():
+    """{PCI bus id "dddd:bb:dd.f" -> bytes in use} from the amdgpu driver's sysfs counters (no HIP context is created)"""
     import glob
+    out = {}
+    for p in glob.glob("/sys/class/drm/card*/device/mem_info_vram_used"):
+        dev_dir = os.path.realpath(os.path.dirname(p))             # .../0000:c1:00.0
+        bus = os.path.basename(dev_dir).lower()
+        if re.fullmatch(r"[0-9a-f]{4}:[0-9a-f]{2}:[0-9a-f]{2}\.[0-9a-f]", bus):
+            try:
+                out[bus] = int(open(p).read())
+            except (OSError, ValueError):
+                pass
+    return out
+
+
+def _hip_bus_id(i):
+    """PCI bus id of HIP device i in sysfs spelling, or None when this torch does not expose it"""
+    props = torch.cuda.get_device_properties(i)
+    bus = getattr(props, "pci_bus_id", None)
+    if bus is None:
+        return None
+    if isinstance(bus, int):                                       # torch exposes domain / bus / device as integers
+        return "%04x:%02x:%02x.0" % (int(getattr(props, "pci_domain_id", 0)), bus, int(getattr(props, "pci_device_id", 0)))
+    return str(bus).lower()
+
+
+def used_memory_per_gpu():
+    """stand-in for upstream ``env_utils.mem_info`` when it is absent: bytes in use per visible HIP device, in HIP's enumeration
+    order.  Read from the driver's sysfs counters matched to the HIP devices BY PCI BUS ID (DRM card numbering need not follow HIP's
+    order - mixed or partitioned GPUs, visibility masks); any device the match cannot place falls back to ``torch.cuda.mem_get_info``
+    for all of them."""
     n = torch.cuda.device_count()                   # counts devices without initialising them
-    files = sorted(glob.glob("/sys/class/drm/card*/device/mem_info_vram_used"),
-                   key=lambda p: int(re.search(r"card(\d+)", p).group(1)))
-    if len(files) == n and not (os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES")):
-        try:
-            return [int(open(p).read()) for p in files]
-        except (OSError, ValueError):
-            pass
+    try:
+        by_bus = _sysfs_vram_used_by_bus_id()
+        ids = [_hip_bus_id(i) for i in range(n)]
+        if n and all(b is not None and b in by_bus for b in ids) and len(set(ids)) == n:
+            return [by_bus[b] for b in ids]
+    except Exception:
+        pass
     out = []
     for i in range(n):
         free, total = torch.cuda.mem_get_info(i)
@@ -84,6 +110,24 @@ def pick_device(devices, mem_info=None):
     print("Using GPU:{}".format(resolved))                                   # pgd_attack.py:81
     torch.cuda.set_device(index)
     return torch.device("cuda", index), resolved
+
+
+# ------------------------------------------------------------------------------------------------ adoption
+def adopt_model(model, mode, dev, first_call=None):
+    """--adopt: the checkout's detector onto libadvengine's convolution kernels with its own weights (adopt.adopt); returns the report"""
+    if mode == "off" or dev.type != "cuda":
+        return None
+    from .. import adopt as _adopt
+    verify = None
+    if mode == "verify":
+        args, kwargs = first_call()
+        verify = _adopt.Call(args, kwargs)
+    rep = _adopt.adopt(model, verify=verify)
+    native = sum(1 for _, what in rep["replaced"] if "torch +" not in what)
+    print("adopted {} convolution modules ({} on libadvengine kernels, {} BatchNorms folded, {} ReLUs fused){}".format(
+        len(rep["replaced"]), native, rep["folded_bn"], rep["fused_relu"],
+        "; {} outputs verified within 1e-4".format(rep["verified_outputs"]) if "verified_outputs" in rep else ""))
+    return rep
 
 
 # ------------------------------------------------------------------------------------------------ DSGN
@@ -166,6 +210,18 @@ class DsgnRuntime:
             print("------------------------------ Load Nothing ---------------------------------")
         print("Number of model parameters: {}".format(sum(p.data.nelement() for p in model.parameters())))
         self.model = model
+        self.adoption = adopt_model(model, getattr(args, "adopt", "on"), dev, self._first_sample_call if getattr(args, "adopt", "on") == "verify" else None)
+
+    def _first_sample_call(self):
+        """the arguments of one forward call on the first sample of the split (for --adopt verify)"""
+        collate = self.torch_loader.collate_fn
+        batch = collate([self.dataset[0]])
+        if self.attack:
+            imgL, imgR, calib, calib_R = batch["imgL"], batch["imgR"], batch["calib"], batch["calib_R"]
+        else:
+            imgL, imgR, calib, calib_R = batch[0], batch[1], batch[3], batch[4]
+        fu, base, proj, proj_r = calib_tensors(calib, calib_R, absolute_baseline=self.attack)
+        return (imgL.float().to(self.dev), imgR.float().to(self.dev), fu, base, proj), {"calibs_Proj_R": proj_r}
 
     # -- the attack scripts' view: StereoBatch + everything the objective needs in ``extra`` -------------------------
     def attack_batches(self):
@@ -235,10 +291,15 @@ MODEL_PTH = "./models_stereo/stereo_rcnn_12_6477.pth"      # hard-coded in all f
 class SrcnnRuntime:
     """roidb + loader + network of one Stereo R-CNN script run"""
 
-    def __init__(self, dev, training, workers=0, model_pth=MODEL_PTH, normalize=None):
+    def __init__(self, dev, training, workers=0, model_pth=MODEL_PTH, normalize=None, adopt="on"):
         """attack/Stereo-RCNN/pgd_attack.py:61-99 (training=True: ground truth prepared, ``uncert`` loaded) and
         predict_and_save_pgd.py:78-124 (training=False, normalize=False)."""
         _need("_init_paths", "_init_paths (upstream Stereo R-CNN)")
+        if dev.type == "cuda":
+            # upstream's model.roi_layers is a compiled CUDA extension: on an MI355X the libadvengine package stands in its place, registered
+            # BEFORE the checkout's model code runs ``from model.roi_layers import ROIAlign`` / ``nms`` (stereo_rcnn.py:18, proposal layer)
+            from .. import upstream_shims
+            upstream_shims.install()
         roidb_mod = _need("roi_data_layer.roidb", "roi_data_layer.roidb")
         loader_mod = _need("roi_data_layer.roibatchLoader", "roi_data_layer.roibatchLoader (the reference's substitute file)")
         self.cfg = cfg = _need("model.utils.config", "model.utils.config").cfg
@@ -258,6 +319,12 @@ class SrcnnRuntime:
         net.to(dev)
         net.eval()
         self.model, self.dev = net, dev
+        self.adoption = adopt_model(net, adopt, dev, self._first_sample_call if adopt == "verify" else None)
+
+    def _first_sample_call(self):
+        data = self.dataset[0]
+        t = [torch.as_tensor(v).unsqueeze(0).to(self.dev) for v in data[:8]]
+        return (t[0].float(), t[1].float(), t[2], t[3], t[4], t[5], t[6], t[7], torch.as_tensor(data[8]).to(self.dev)), {}
 
     def image_name(self, i):
         return self.roidb[i]["img_left"].split("/")[-1].strip()                                           # :120

@@ -709,7 +709,9 @@ int adv_roi_align_bwd_f32(const float* grad_out, const float* rois, float* grad_
   const int rc = check_roi(grad_out, rois, grad_feat, b, c, h, w, r, ph, pw);
   if (rc != ADV_OK) return rc;
   if (workspace == nullptr || b > 65535) return ADV_EINVAL;
-  if (!aligned4(workspace)) return ADV_EALIGN;
+  // the channel-last copy of grad_out inside the workspace is read with 16-byte loads: the lists before it are padded to a multiple of
+  // four ints, so the workspace itself must start on a 16-byte boundary
+  if ((reinterpret_cast<uintptr_t>(workspace) & 15) != 0) return ADV_EALIGN;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int tiles_y = (h + kTileY - 1) / kTileY, tiles_x = (w + kTileX - 1) / kTileX;
   if (static_cast<long long>(ph) * pw > 1500) return ADV_EINVAL;      // the transposing kernel stages 32 x ph*pw floats in LDS

@@ -264,7 +264,9 @@ ADV_API int adv_roi_align_fwd_f32(const float* feat, const float* rois, float* o
  *     grad_out[r,c,ph,pw] * weight / count of the samples whose bilinear taps touch it.  No float atomics: two runs give
  *     the same bits, and the result equals the oracle's ordered sum bit for bit.  workspace: DEVICE,
  *     adv_roi_align_bwd_workspace_ints(b, c, h, w, r, ph, pw) 4-byte elements (per 8 x 32-pixel tile the ascending list of rois that
- *     reach it; a channel-last copy of grad_out, whose 32 channels of one bin are one coalesced load).  ph * pw <= 1500. */
+ *     reach it; a channel-last copy of grad_out, whose 32 channels of one bin are one coalesced load), starting on a 16-BYTE boundary
+ *     (the copy is read with 16-byte loads; ADV_EALIGN otherwise).  ph * pw <= 1500 (the transposing pass stages 32 x ph*pw floats in
+ *     LDS; ADV_EINVAL beyond - the reference's pooled grids are 7 x 7 and 14 x 14). */
 ADV_API int64_t adv_roi_align_bwd_workspace_ints(int b, int c, int h, int w, int r, int ph, int pw);
 ADV_API int adv_roi_align_bwd_f32(const float* grad_out, const float* rois, float* grad_feat, int b, int c, int h, int w,
                           int r, int ph, int pw, float spatial_scale, int sampling_ratio, int32_t* workspace,

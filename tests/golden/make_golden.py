@@ -516,6 +516,45 @@ def objective_cases():
     return out
 
 
+def upstream_call_sites_case():
+    """How the reference's own files USE the upstream operator package ``model.roi_layers`` (a compiled CUDA extension upstream;
+    eval_driving_safety_amd/upstream_shims/roi_layers.py here): names imported, constructor and call arities, keyword names - read
+    off the ASTs, so the shim's signatures are checked against the call sites themselves."""
+    out = {"imports": {}, "calls": {}}
+    files = ["attack/Stereo-RCNN/stereo_rcnn.py", "attack/Stereo-RCNN/pgd_attack.py", "attack/Stereo-RCNN/patch_attack.py",
+             "attack/Stereo-RCNN/predict_and_save_pgd.py", "attack/Stereo-RCNN/predict_and_save_patch.py", "attack/Stereo-RCNN/stereo_rpn.py"]
+    for rel in files:
+        tree, _ = _parse(rel)
+        names = []
+        for node in ast.walk(tree):
+            if isinstance(node, ast.ImportFrom) and node.module == "model.roi_layers":
+                names += [a.name for a in node.names]
+        if names:
+            out["imports"][rel] = sorted(names)
+        # attributes assigned from ROIAlign(...): their later calls are ROIAlign.forward call sites
+        holders = set()
+        for node in ast.walk(tree):
+            if isinstance(node, ast.Assign) and isinstance(node.value, ast.Call) and getattr(node.value.func, "id", None) == "ROIAlign":
+                for t in node.targets:
+                    if isinstance(t, ast.Attribute):
+                        holders.add(t.attr)
+        for node in ast.walk(tree):
+            if not isinstance(node, ast.Call):
+                continue
+            f = node.func
+            what = None
+            if isinstance(f, ast.Name) and f.id in ("ROIAlign", "nms"):
+                what = f.id
+            elif isinstance(f, ast.Attribute) and f.attr in holders:
+                what = "ROIAlign.forward"
+            if what:
+                out["calls"].setdefault(what, []).append({"file": rel, "line": node.lineno, "positional": len(node.args),
+                                                          "keywords": sorted(k.arg for k in node.keywords)})
+    for v in out["calls"].values():
+        v.sort(key=lambda c: (c["file"], c["line"]))
+    return out
+
+
 def save_npz(name, arrays):
     path = os.path.join(HERE, name)
     np.savez_compressed(path, **arrays)
@@ -582,6 +621,7 @@ def main():
     index["depth_stats"] = depth_stats_case()
     index["cli_flags"] = cli_flags_case()
     index["objectives"] = objective_cases()
+    index["upstream_call_sites"] = upstream_call_sites_case()
     with open(os.path.join(HERE, "index.json"), "w") as f:
         json.dump(index, f, indent=1, sort_keys=True)
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE)

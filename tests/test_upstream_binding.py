@@ -1,0 +1,356 @@
+"""The reference's own operator call sites reach the HIP kernels, with the model's real weights:
+
+  * eval_driving_safety_amd/upstream_shims/roi_layers.py stands where the upstream checkout's compiled ``model.roi_layers`` stands -
+    names, constructor and call arities checked against the call sites AST-extracted from the reference (tests/golden/index.json
+    "upstream_call_sites": attack/Stereo-RCNN/stereo_rcnn.py:18,44-45,132-134, predict_and_save_pgd.py:26,300 ...);
+  * ``adopt.adopt(model)`` folds eval-mode BatchNorms and swaps Conv2d / Conv3d / ConvTranspose3d modules for libadvengine-backed ones
+    carrying the same weights: on the stand-in checkouts (tests/fake_upstream: torch-module detectors with the upstream module naming)
+    the adopted network's loss and image gradient stay within 1e-4 of the un-adopted one, and every adopted layer equals the oracle's
+    ordered restatement of its kernel bit for bit.
+CPU: signatures, the import mechanics, BatchNorm folding, the module walk.  GPU (-m gpu): the numbers."""
+import inspect
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from eval_driving_safety_amd import adopt as A
+from eval_driving_safety_amd import upstream_shims
+from eval_driving_safety_amd.upstream_shims import roi_layers as shim
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FAKE = os.path.join(ROOT, "tests", "fake_upstream")
+UPSTREAM_NAMES = ("dsgn", "env_utils", "model", "roi_data_layer", "_init_paths")
+
+
+@pytest.fixture
+def checkout(request):
+    def use(name):
+        path = os.path.join(FAKE, name)
+        sys.path.insert(0, path)
+        request.addfinalizer(lambda: sys.path.remove(path))
+        return path
+    yield use
+    for m in [m for m in sys.modules if m.split(".")[0] in UPSTREAM_NAMES]:
+        del sys.modules[m]
+
+
+# ----------------------------------------------------------------------------------------------- CPU: the shim's surface
+def test_shim_exports_what_the_reference_imports(golden_index):
+    sites = golden_index["upstream_call_sites"]
+    wanted = sorted({n for names in sites["imports"].values() for n in names})
+    assert wanted == ["ROIAlign", "nms"]                      # stereo_rcnn.py:18; the four scripts' ``from model.roi_layers import nms``
+    for n in wanted:
+        assert hasattr(shim, n) and n in shim.__all__
+
+
+def test_shim_signatures_take_the_references_calls(golden_index):
+    calls = golden_index["upstream_call_sites"]["calls"]
+    assert {c["line"] for c in calls["ROIAlign"]} == {44, 45} and {c["line"] for c in calls["ROIAlign.forward"]} == {132, 134}
+    for c in calls["ROIAlign"]:                               # ROIAlign((P, P), 1.0/16.0, 0)
+        assert not c["keywords"]
+        inspect.signature(shim.ROIAlign.__init__).bind(None, *range(c["positional"]))
+    for c in calls["ROIAlign.forward"]:                       # self.RCNN_roi_align(feat_maps[i], rois[idx_l], scale): THREE arguments
+        assert c["positional"] == 3 and not c["keywords"]
+        inspect.signature(shim.ROIAlign.forward).bind(None, *range(c["positional"]))
+    inspect.signature(shim.ROIAlign.forward).bind(None, 0, 1)                      # the two-argument upstream form too
+    for c in calls["nms"]:                                    # nms(cls_boxes_left[order, :], cls_scores[order], cfg.TEST.NMS)
+        assert c["positional"] == 3 and not c["keywords"]
+        inspect.signature(shim.nms).bind(*range(c["positional"]))
+    m = shim.ROIAlign((7, 7), 1.0 / 16.0, 0)
+    assert isinstance(m, nn.Module) and m.output_size == (7, 7) and m.spatial_scale == 1.0 / 16.0 and m.sampling_ratio == 0
+    with pytest.raises(ImportError):
+        exec("from eval_driving_safety_amd.upstream_shims.roi_layers import ROIPool", {})
+
+
+def test_install_puts_the_shim_where_the_checkouts_extension_is(checkout):
+    checkout("srcnn_checkout")
+    import model.roi_layers as theirs                         # the checkout's own package (a compiled extension upstream)
+    assert getattr(theirs, "IS_TORCH_STAND_IN", False)
+    for m in [m for m in sys.modules if m.split(".")[0] == "model"]:
+        del sys.modules[m]
+    assert "model.roi_layers" in upstream_shims.install()
+    from model.roi_layers import ROIAlign, nms
+    import model
+    assert ROIAlign is shim.ROIAlign and nms is shim.nms and model.roi_layers is shim and upstream_shims.installed()
+    from model.stereo_rcnn.resnet import resnet               # the checkout's network code now binds to the shim
+    net = resnet(("__background__", "Car"), 101, pretrained=False)
+    net.create_architecture()
+    assert type(net.RCNN_roi_align) is shim.ROIAlign
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        net.RCNN_roi_align(torch.zeros(1, 2, 8, 8), torch.zeros(1, 5), 0.25)
+
+
+# ----------------------------------------------------------------------------------------------- CPU: folding and the walk
+def _randomise_bn(bn, gen):
+    with torch.no_grad():
+        bn.weight.copy_(1 + 0.3 * torch.randn(bn.weight.shape, generator=gen))
+        bn.bias.copy_(0.2 * torch.randn(bn.bias.shape, generator=gen))
+        bn.running_mean.copy_(0.3 * torch.randn(bn.running_mean.shape, generator=gen))
+        bn.running_var.copy_(0.4 + torch.rand(bn.running_var.shape, generator=gen))
+
+
+@pytest.mark.parametrize("kind", ["conv2d", "conv2d_bias", "conv3d", "convT3d"])
+def test_fold_bn_is_the_same_function(kind):
+    gen = torch.Generator().manual_seed(3)
+    if kind.startswith("conv2d"):
+        conv, bn, x = nn.Conv2d(5, 7, 3, padding=1, bias=kind.endswith("bias")), nn.BatchNorm2d(7), torch.randn(2, 5, 9, 11, generator=gen)
+        run = lambda w, b: F.conv2d(x, w, b, padding=1)                                              # noqa: E731
+    elif kind == "conv3d":
+        conv, bn, x = nn.Conv3d(4, 6, 3, stride=2, padding=1, bias=False), nn.BatchNorm3d(6), torch.randn(1, 4, 6, 7, 8, generator=gen)
+        run = lambda w, b: F.conv3d(x, w, b, stride=2, padding=1)                                    # noqa: E731
+    else:
+        conv, bn, x = nn.ConvTranspose3d(4, 6, 3, stride=2, padding=1, output_padding=1, bias=False), nn.BatchNorm3d(6), torch.randn(1, 4, 3, 4, 5, generator=gen)
+        run = lambda w, b: F.conv_transpose3d(x, w, b, stride=2, padding=1, output_padding=1)        # noqa: E731
+    _randomise_bn(bn, gen)
+    bn.eval()
+    w, b = A.fold_bn(conv.weight, conv.bias, bn, transposed=(kind == "convT3d"))
+    with torch.no_grad():
+        want, got = bn(conv(x)), run(w, b)
+    assert float((want - got).abs().max()) <= 2e-6 * float(want.abs().max())
+    bn.train()
+    with pytest.raises(ValueError, match="training mode"):
+        A.fold_bn(conv.weight, conv.bias, bn)
+
+
+def test_adopt_walks_the_stand_in_stereo_rcnn(checkout):
+    checkout("srcnn_checkout")
+    from model.stereo_rcnn.resnet import resnet
+    net = resnet(("__background__", "Car"), 101, pretrained=False)
+    net.create_architecture()
+    with pytest.raises(ValueError, match="eval mode"):
+        A.adopt(net)
+    net.eval()
+    rep = A.adopt(net)
+    names = dict(rep["replaced"])
+    # layer0: Sequential(conv 7x7/2, bn, relu, maxpool) - folded, ReLU fused, no kernel for the 7x7: torch + one fused epilogue pass
+    assert "torch +" in names["RCNN_layer0.0"] and isinstance(net.RCNN_layer0[1], nn.Identity) and isinstance(net.RCNN_layer0[2], nn.Identity)
+    assert net.RCNN_layer0[0].relu and isinstance(net.RCNN_layer0[3], nn.MaxPool2d)
+    # Bottlenecks: convK / bnK pairs folded by name, the shared ReLU module left alone; downsample = Sequential(conv, bn)
+    b0 = net.RCNN_layer1[0]
+    assert all(isinstance(getattr(b0, "conv%d" % k), A.AdoptedConv2d) and isinstance(getattr(b0, "bn%d" % k), nn.Identity) for k in (1, 2, 3))
+    assert isinstance(b0.relu, nn.ReLU) and not b0.conv2.relu and isinstance(b0.downsample[0], A.AdoptedConv2d) and isinstance(b0.downsample[1], nn.Identity)
+    assert b0.conv1.native and b0.conv2.native and b0.conv2.kind.startswith("conv2d 3x3 s1 d1 4->4")
+    assert not net.RCNN_layer2[0].conv1.native                            # the stride-2 1x1: torch's operator, BatchNorm still folded
+    assert net.RCNN_toplayer.native and net.RCNN_smooth1.native and net.RCNN_smooth1.bias is not None
+    assert rep["folded_bn"] == 1 + 3 * 3 + 2 and rep["fused_relu"] == 1 + 2 and not rep["kept"]
+    assert all(not p.requires_grad for p in net.parameters())
+    assert not any(isinstance(m, (nn.Conv2d, nn.BatchNorm2d)) for m in net.modules())
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        net.RCNN_smooth1(torch.zeros(1, 16, 8, 8))
+
+
+def test_adopt_walks_the_stand_in_dsgn(checkout):
+    checkout("dsgn_checkout")
+    from dsgn.models import StereoNet
+    net = torch.nn.DataParallel(StereoNet(cfg=None)).eval()              # as the scripts wrap it (pgd_attack.py:137)
+    rep = A.adopt(net)
+    kinds = dict(rep["replaced"])
+    assert kinds["module.dres0.0.0"].startswith("conv3d 3x3x3 s1 8->8") and net.module.dres0[0][0].native and not net.module.dres0[0][0].relu
+    assert kinds["module.hg.conv1.0.0"].startswith("conv3d 3x3x3 s2 8->16") and net.module.hg.conv1[0][0].native
+    assert kinds["module.hg.conv5.0"].startswith("conv_transpose3d 3x3x3 s2 16->8") and net.module.hg.conv5[0].native
+    assert isinstance(net.module.hg.conv5[1], nn.Identity)
+    assert kinds["module.classif1.2"].startswith("conv3d 3x3x3 s1 8->1") and net.module.classif1[2].native and net.module.classif1[2].bias is None
+    fe = net.module.feature_extraction
+    assert fe.dilated[0][0].native and fe.dilated[0][0].dilation == (2, 2) and not fe.firstconv[0][0].native      # dilation 2: kernel; stride 2: torch
+    assert fe.lastconv[2].native and fe.lastconv[2].kind.startswith("conv2d 1x1")
+    # convbn(...) is its own Sequential(conv, bn): the ReLU that follows it lives one level up and stays a module
+    assert rep["fused_relu"] == 0 and isinstance(net.module.dres0[1], nn.ReLU)
+    assert rep["folded_bn"] == 5 + 2 + 3 + 1 and not rep["kept"]
+
+
+def test_adopt_verify_catches_a_forward_that_breaks_the_convention():
+    class Odd(nn.Module):                                                # bn1 is NOT applied to conv1's output
+        def __init__(self):
+            super().__init__()
+            self.conv1, self.bn1 = nn.Conv2d(3, 3, 1), nn.BatchNorm2d(3)
+
+        def forward(self, x):
+            return self.conv1(self.bn1(x))
+
+    gen = torch.Generator().manual_seed(0)
+    m = Odd().eval()
+    _randomise_bn(m.bn1, gen)
+
+    class Tracer(A.AdoptedConv2d):                                       # a CPU stand-in for the kernel call, for this test only
+        def forward(self, x):
+            return F.conv2d(x, self.weight, self.bias)
+    old = A._CONVS[nn.Conv2d]
+    A._CONVS[nn.Conv2d] = Tracer
+    try:
+        with pytest.raises(RuntimeError, match="does not\\s+follow the conv->bn conventions"):
+            A.adopt(m, verify=(torch.randn(1, 3, 4, 4, generator=gen),))
+    finally:
+        A._CONVS[nn.Conv2d] = old
+
+
+# ----------------------------------------------------------------------------------------------- GPU
+def _dev():
+    return torch.device("cuda", 0)
+
+
+@pytest.mark.gpu
+def test_shim_roi_align_and_nms_equal_the_checkouts_and_the_oracle(checkout):
+    from oracle import oracle_np as O
+    checkout("srcnn_checkout")
+    import model.roi_layers as theirs
+    dev = _dev()
+    rs = np.random.RandomState(2)
+    feat = rs.randn(2, 6, 24, 40).astype(np.float32)
+    rois = np.array([[0, 10, 20, 200, 150], [1, -30, -10, 90, 400], [0, 300, 100, 480, 310], [1, 5, 5, 9, 9], [0, 100, 50, 620, 380]], np.float32)
+    for size in ((7, 7), (14, 14)):                                      # cfg.POOLING_SIZE and twice that (stereo_rcnn.py:44-45)
+        mine, ref = shim.ROIAlign(size, 1.0 / 16.0, 0), theirs.ROIAlign(size, 1.0 / 16.0, 0)
+        f = torch.tensor(feat, device=dev, requires_grad=True)
+        fr = torch.tensor(feat, requires_grad=True)
+        scale = torch.tensor(24 / 384.0)                                  # the reference passes a tensor: feat.size(2) / im_info[0][0] (:129)
+        y = mine(f, torch.tensor(rois, device=dev), scale)               # three arguments: the per-call scale overrides 1/16
+        yr = ref(fr, torch.tensor(rois), scale)
+        assert y.cpu().numpy().tobytes() == O.roi_align(feat, rois, size, 24 / 384.0, 0).tobytes()
+        assert float((y.cpu() - yr).abs().max()) <= 1e-5
+        g = torch.tensor(rs.randn(*y.shape).astype(np.float32))
+        y.backward(g.to(dev))
+        yr.backward(g)
+        assert f.grad.cpu().numpy().tobytes() == O.roi_align_bwd_ordered(g.numpy(), rois, feat.shape, 24 / 384.0, 0).tobytes()
+        assert float((f.grad.cpu() - fr.grad).abs().max()) <= 1e-5 * max(1.0, float(fr.grad.abs().max()))
+        assert float((mine(f.detach(), torch.tensor(rois, device=dev)).cpu() - theirs.roi_align(fr.detach(), torch.tensor(rois), size, 1.0 / 16.0, 0)).abs().max()) <= 1e-5
+    boxes = (rs.rand(300, 2) * 200).astype(np.float32)
+    boxes = np.concatenate([boxes, boxes + 10 + rs.rand(300, 2).astype(np.float32) * 60], 1)
+    scores = rs.rand(300).astype(np.float32)
+    scores[17] = scores[40]                                              # a tie: the stable sort fixes its order
+    for thresh in (0.3, 0.7):
+        keep = shim.nms(torch.tensor(boxes, device=dev), torch.tensor(scores, device=dev), thresh)
+        want = theirs.nms(torch.tensor(boxes), torch.tensor(scores), thresh)
+        assert keep.dtype == torch.int64 and keep.cpu().tolist() == want.tolist()
+        order = np.argsort(-scores, kind="stable")
+        assert keep.cpu().tolist() == [int(order[k]) for k in O.nms(boxes[order], thresh)]
+    assert shim.nms(torch.zeros(0, 4, device=dev), torch.zeros(0, device=dev), 0.3).numel() == 0
+
+
+def _srcnn_pair(checkout_fn, with_shim):
+    """the stand-in Stereo R-CNN network built either on the checkout's own (plain torch) roi_layers or on the libadvengine shim"""
+    for m in [m for m in sys.modules if m.split(".")[0] in UPSTREAM_NAMES]:
+        del sys.modules[m]
+    if with_shim:
+        upstream_shims.install()
+    from model.stereo_rcnn.resnet import resnet
+    net = resnet(("__background__", "Car"), 101, pretrained=False)
+    net.create_architecture()
+    return net.to(_dev()).eval()
+
+
+@pytest.mark.gpu
+def test_adopted_stand_in_stereo_rcnn_keeps_loss_and_gradient(checkout):
+    from eval_driving_safety_amd import adapters
+    checkout("srcnn_checkout")
+    dev = _dev()
+    from roi_data_layer.roibatchLoader import roibatchLoader
+    data = roibatchLoader([{}], None, None, 1, 2, training=True)[0]
+    t = [torch.as_tensor(v).unsqueeze(0).to(dev) for v in data[:8]]
+    extra = types.SimpleNamespace(im_info=t[2], gt_boxes_left=t[3], gt_boxes_right=t[4], gt_boxes_merge=t[5], gt_dim_orien=t[6], gt_kpts=t[7],
+                                  num_boxes=torch.as_tensor(data[8]).to(dev))
+    x = torch.cat([t[0], t[1]]).float()
+    u = torch.tensor([0.1, -0.2, 0.3, 0.0, 0.5, -0.4], device=dev)
+    ref = _srcnn_pair(checkout, with_shim=False)                         # torch's operators throughout (the checkout as it is)
+    want_loss, want_grad = adapters.StereoRcnnAdapter(ref, u).loss_and_grad(x.clone(), extra)
+    net = _srcnn_pair(checkout, with_shim=True)
+    assert type(net.RCNN_roi_align) is shim.ROIAlign
+    net.load_state_dict(ref.state_dict())                                # "the checkpoint": the same trained weights
+    call = A.Call((t[0].float(), t[1].float(), t[2], t[3], t[4], t[5], t[6], t[7], extra.num_boxes))
+    rep = A.adopt(net, verify=call)
+    assert rep["verified_outputs"] >= 10 and sum("torch +" not in w for _, w in rep["replaced"]) >= 10
+    loss, grad = adapters.StereoRcnnAdapter(net, u).loss_and_grad(x.clone(), extra)
+    assert abs(float(loss) - float(want_loss)) <= 1e-4 * abs(float(want_loss))
+    assert float((grad - want_grad).abs().max()) <= 1e-4 * float(want_grad.abs().max())
+    again = adapters.StereoRcnnAdapter(net, u).loss_and_grad(x.clone(), extra)[1]
+    assert torch.equal(again, grad)                                      # route table + deterministic RoIAlign backward: the same bits
+
+
+@pytest.mark.gpu
+def test_adopted_stand_in_dsgn_keeps_loss_and_gradient(checkout):
+    from eval_driving_safety_amd import adapters
+    checkout("dsgn_checkout")
+    from dsgn.models import StereoNet
+    from dsgn.models.loss3d import RPN3DLoss
+    import synth
+    dev = _dev()
+    h, w = 96, 160
+    x = torch.from_numpy(np.concatenate([synth.dsgn_normalised(71, h, w), synth.dsgn_normalised(72, h, w)])).to(dev)
+    gen = torch.Generator().manual_seed(7)
+    tgt = types.SimpleNamespace(bbox=torch.rand(2, 4, generator=gen).to(dev), box3d=torch.rand(2, 7, generator=gen).to(dev))
+    extra = types.SimpleNamespace(calibs_fu=torch.tensor([721.5377]), calibs_baseline=torch.tensor([0.54]), calibs_Proj=torch.zeros(1, 3, 4),
+                                  calibs_Proj_R=torch.zeros(1, 3, 4), disp_true=(torch.rand(1, h, w, generator=gen) * 45).to(dev), targets=(tgt,),
+                                  calib=None, calib_R=None, ious=None, labels_map=None)
+    cfg = types.SimpleNamespace(PlaneSweepVolume=True, loss_disp=True, RPN3D_ENABLE=True, min_depth=2.0, max_depth=40.4)
+    ref = torch.nn.DataParallel(StereoNet(cfg=None), device_ids=[0]).to(dev).eval()
+    want_loss, want_grad = adapters.DsgnAdapter(ref, cfg, RPN3DLoss).loss_and_grad(x.clone(), extra)
+    net = torch.nn.DataParallel(StereoNet(cfg=None), device_ids=[0]).to(dev).eval()
+    net.load_state_dict(ref.state_dict())
+    rep = A.adopt(net, verify=A.Call((x[:1], x[1:], extra.calibs_fu, extra.calibs_baseline, extra.calibs_Proj), {"calibs_Proj_R": extra.calibs_Proj_R}))
+    assert rep["verified_outputs"] == 4
+    loss, grad = adapters.DsgnAdapter(net, cfg, RPN3DLoss).loss_and_grad(x.clone(), extra)
+    assert abs(float(loss) - float(want_loss)) <= 1e-4 * abs(float(want_loss))
+    assert float((grad - want_grad).abs().max()) <= 1e-4 * float(want_grad.abs().max())
+    assert torch.equal(adapters.DsgnAdapter(net, cfg, RPN3DLoss).loss_and_grad(x.clone(), extra)[1], grad)
+
+
+@pytest.mark.gpu
+def test_every_adopted_layer_equals_its_oracle_bit_for_bit(checkout):
+    """each kernel-backed module of the two adopted stand-in networks, alone, on a seeded input, against the oracle's restatement of the
+    kernel the committed route table sends that shape to (direct implicit GEMM or Winograd), with the FOLDED weights"""
+    from oracle import oracle_c
+    from eval_driving_safety_amd import ops, routes
+    checkout("srcnn_checkout")
+    checkout("dsgn_checkout")
+    from dsgn.models import StereoNet
+    dev = _dev()
+    nets = [_srcnn_pair(checkout, with_shim=True), StereoNet(cfg=None).to(dev).eval()]
+    rs = np.random.RandomState(5)
+    checked = {"conv2d": 0, "conv3d s1": 0, "conv3d s2": 0, "convT3d": 0}
+    for net in nets:
+        A.adopt(net)
+        for name, m in net.named_modules():
+            if not isinstance(m, A._Adopted) or not m.native:
+                continue
+            wt = m.weight.cpu().numpy()
+            bias = None if m.bias is None else m.bias.cpu().numpy()
+            if isinstance(m, A.AdoptedConv2d):
+                x = rs.randn(2, wt.shape[1], 10, 21).astype(np.float32)
+                routes._state["used"].clear()
+                y = m(torch.tensor(x, device=dev)).cpu().numpy()
+                (route,) = set(routes.used().values())
+                k = wt.shape[2]
+                if route == "wino":
+                    want = oracle_c.conv2d_wino(x, wt, bias, relu=m.relu)
+                else:
+                    assert route == "hip", route
+                    want = oracle_c.conv2d(x, wt, bias, padding=m.padding[0], dilation=m.dilation[0], relu=m.relu, chunk=16 if k == 1 else 8)
+                checked["conv2d"] += 1
+            elif isinstance(m, A.AdoptedConv3d):
+                x = rs.randn(1, wt.shape[1], 4, 6, 12).astype(np.float32)
+                routes._state["used"].clear()
+                y = m(torch.tensor(x, device=dev)).cpu().numpy()
+                if m.stride[0] == 2:
+                    chunk = ops.conv3d_k3_s2_stage_channels(torch.tensor(x, device=dev), wt.shape[0])
+                    want = oracle_c.conv3d_k3_ex(x, wt, bias, stride=2, relu=m.relu, chunk=chunk)
+                    checked["conv3d s2"] += 1
+                else:
+                    used = set(routes.used().values())
+                    if used == {"wino"}:
+                        want = oracle_c.conv3d_wino(x, wt, bias, relu=m.relu)
+                    elif wt.shape[0] < 4:
+                        want = oracle_c.conv3d_k3(x, wt)
+                    else:
+                        want = oracle_c.conv3d_k3_ex(x, wt, bias, relu=m.relu)
+                    checked["conv3d s1"] += 1
+            else:
+                x = rs.randn(1, wt.shape[0], 3, 4, 8).astype(np.float32)
+                y = m(torch.tensor(x, device=dev)).cpu().numpy()
+                want = oracle_c.conv_transpose3d_k3_s2(x, wt, bias, relu=m.relu)
+                checked["convT3d"] += 1
+            assert y.tobytes() == want.tobytes(), (name, m.kind, float(np.abs(y - want).max()))
+    assert checked["conv2d"] >= 10 and checked["conv3d s1"] >= 4 and checked["conv3d s2"] >= 1 and checked["convT3d"] >= 1, checked
