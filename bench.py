@@ -488,13 +488,25 @@ def main():
 
         def bail():
             if rank == 0:
-                out["patch_allreduce"] = {"error": "timed out after 120 s"}
+                out["patch_allreduce"] = {"error": "a collective of the N > 1 legs timed out"}
                 print(json.dumps(out), flush=True)
             os._exit(3)
 
-        dog = threading.Timer(120.0, bail)
+        dog = threading.Timer(600.0 if not (args.no_end_to_end or srcnn) else 120.0, bail)
         dog.daemon = True
         dog.start()
+        # N > 1: what the ranks do END TO END - each its own 20-step DSGN-shaped attack (image-sharded, no collective) and a universal-patch
+        # epoch with the delta all-reduced inside the loop (tools/bench_end_to_end.measure_distributed).  Beside `value`, never in it.
+        if not args.no_end_to_end and not srcnn:
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import bench_end_to_end
+                legs = bench_end_to_end.measure_distributed(dist, dev, rank, world, fence, iters=N_ITER)
+            except Exception as e:
+                legs = {"error": repr(e)}
+            if rank == 0:
+                out["distributed_end_to_end"] = legs
+            torch.cuda.empty_cache()
         try:
             d = 101
             delta = torch.full((3, d, d), float(rank + 1), device=dev)
@@ -518,6 +530,9 @@ def main():
         if rank == 0:
             out["patch_allreduce"] = patch_comm
     if rank == 0:
+        from eval_driving_safety_amd import routes
+        # which kernel computes each convolution of the end-to-end legs: the committed table (same in every process and rank)
+        out["routes"] = dict(routes.summary(), unknown_shapes=routes.misses()[:8])
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()

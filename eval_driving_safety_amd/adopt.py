@@ -41,15 +41,12 @@ def fold_bn(weight, bias, bn, transposed=False):
         raise ValueError("BatchNorm in training mode cannot be folded (the attacks run the detector in eval mode)")
     if not bn.track_running_stats or bn.running_mean is None:
         raise ValueError("BatchNorm without running statistics cannot be folded")
-    var, mean = bn.running_var.detach().to(torch.float64), bn.running_mean.detach().to(torch.float64)
-    gamma = bn.weight.detach().to(torch.float64) if bn.affine else torch.ones_like(var)
-    beta = bn.bias.detach().to(torch.float64) if bn.affine else torch.zeros_like(var)
-    s = gamma / torch.sqrt(var + bn.eps)
-    w = weight.detach().to(torch.float64)
-    shape = [1] * w.dim()
-    shape[1 if transposed else 0] = -1
-    b0 = torch.zeros_like(mean) if bias is None else bias.detach().to(torch.float64)
-    return (w * s.view(shape)).to(weight.dtype).contiguous(), ((b0 - mean) * s + beta).to(weight.dtype).contiguous()
+    from .checkpoints import fold_bn_tensors
+    gamma = bn.weight.detach() if bn.affine else torch.ones_like(bn.running_var)
+    beta = bn.bias.detach() if bn.affine else torch.zeros_like(bn.running_var)
+    w, b = fold_bn_tensors(weight.detach(), None if bias is None else bias.detach(), gamma, beta, bn.running_mean.detach(), bn.running_var.detach(),
+                           bn.eps, transposed)
+    return w.to(weight.dtype), b.to(weight.dtype)
 
 
 class Call:

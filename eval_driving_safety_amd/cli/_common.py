@@ -94,3 +94,39 @@ class WithExtra:
 
     def __iter__(self):
         return self._wrap(iter(self.loader))
+
+
+def layerlist_dsgn(dev, args):
+    """--model layerlist of the DSGN scripts: adapters.DsgnShapedAdapter; with ``--loadmodel x.tar`` its layers receive the checkpoint's
+    ``state_dict['state_dict']`` (attack/DSGN/pgd_attack.py:142-145; checkpoints.load_dsgn folds the BatchNorms, checks every shape and
+    raises on anything it cannot place), otherwise the seeded random draw"""
+    import torch
+    from .. import adapters, checkpoints
+    adapter = adapters.DsgnShapedAdapter(dev, seed=args.seed)
+    import os
+    path = getattr(args, "loadmodel", None)
+    if path and os.path.exists(path) and path.endswith("tar"):                # :142 ``args.loadmodel.endswith('tar')``
+        rep = checkpoints.load_dsgn(adapter, torch.load(path, map_location=dev))
+        print("Loaded {} into the layer-list graph ({} layers)".format(path, rep["loaded_layers"]))
+    else:
+        print("------------------------------ Load Nothing ---------------------------------")      # :147
+    return adapter
+
+
+def layerlist_srcnn(dev, args):
+    """--model layerlist of the Stereo R-CNN scripts: surrogates.StereoRcnnR101 on the route table's kernels; when the checkpoint the
+    scripts hard-code (./models_stereo/stereo_rcnn_12_6477.pth, pgd_attack.py:94) exists it is loaded - ``checkpoint['model']`` into the
+    layers, ``checkpoint['uncert']`` returned as the loss weights (:97) -, otherwise seeded random weights and zero log-variances"""
+    import os
+    import torch
+    from .. import checkpoints, surrogates
+    from . import upstream
+    surrogates.FoldedConv.impl = "auto"
+    net = surrogates.StereoRcnnR101(seed=args.seed)
+    uncert = torch.zeros(6, device=dev)
+    if os.path.exists(upstream.MODEL_PTH):
+        rep = checkpoints.load_stereo_rcnn(net, torch.load(upstream.MODEL_PTH, map_location="cpu"))
+        print("Loaded {} into the layer-list graph ({} layers)".format(upstream.MODEL_PTH, rep["loaded_layers"]))
+        if rep["uncert"] is not None:
+            uncert = rep["uncert"].to(dev)
+    return net.to(dev).eval(), uncert

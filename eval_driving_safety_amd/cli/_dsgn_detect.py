@@ -163,6 +163,7 @@ def run_shaped(args, mode, dev):
     folder in, ``<out_root>/kitti_output{tag}/NNNNNN.txt`` out - without an upstream checkout (no depth ground truth, so no
     depth statistics)."""
     from .. import adapters, data
+    from . import _common
     if mode == "pgd" and args.alpha and args.iter:
         args.tag += "_iter{0}_alpha{1}".format(str(args.iter), str(args.alpha))
     if mode == "patch":
@@ -180,7 +181,7 @@ def run_shaped(args, mode, dev):
     loader = data.SyntheticStereo(args.synthetic, "dsgn", batch, seed=args.seed) if args.synthetic \
         else data.KittiFolder(args.data_path, args.split_file, batch, workers=workers)
     det = DetectUnderAttack("dsgn", mode, label_dir, patch=patch, atk_mode=getattr(args, "atk_mode", "random"), seed=args.pos_seed, device=dev)
-    net = adapters.DsgnShapedAdapter(dev, seed=args.seed) if args.model == "layerlist" else adapters.PsvStereoAdapter(dev, seed=args.seed, hourglass=True, dsgn_head=True)
+    net = _common.layerlist_dsgn(dev, args) if args.model == "layerlist" else adapters.PsvStereoAdapter(dev, seed=args.seed, hourglass=True, dsgn_head=True)
     n = det.run(loader, net, debugnum=args.debugnum if args.debug else None)
     print("wrote %d label files to %s" % (n, label_dir))
     return n, label_dir

@@ -35,7 +35,7 @@ def main(argv=None):
         if args.model == "toy":
             adapter, factory = adapters.ToyStereoAdapter(dev, seed=args.seed), base
         else:
-            adapter = adapters.DsgnShapedAdapter(dev, seed=args.seed) if args.model == "layerlist" else \
+            adapter = _common.layerlist_dsgn(dev, args) if args.model == "layerlist" else \
                 adapters.PsvStereoAdapter(dev, seed=args.seed, hourglass=True, dsgn_head=True)
             factory = lambda: _common.WithExtra(base(), adapter.synthetic_extra)
     else:

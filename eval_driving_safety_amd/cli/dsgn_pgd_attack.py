@@ -34,7 +34,7 @@ def main(argv=None):
         if args.model == "toy":
             adapter = adapters.ToyStereoAdapter(dev, seed=args.seed)
         else:   # plane-sweep volume (HIP) -> 3D hourglass on the float32 matrix cores -> depth loss; synthetic sparse depth
-            adapter = adapters.DsgnShapedAdapter(dev, seed=args.seed) if args.model == "layerlist" else \
+            adapter = _common.layerlist_dsgn(dev, args) if args.model == "layerlist" else \
                 adapters.PsvStereoAdapter(dev, seed=args.seed, hourglass=True, dsgn_head=True)
             loader = _common.WithExtra(loader, adapter.synthetic_extra)
     else:

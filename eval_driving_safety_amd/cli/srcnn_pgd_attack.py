@@ -35,12 +35,11 @@ def main(argv=None):
         else:   # FPN + stereo RPN + RoIAlign heads on this package's kernels, random weights, synthetic ground truth
             import torch
             from .. import surrogates
-            if args.model == "layerlist":   # ResNet-101-FPN layer list; 2D convolutions by libadvengine or MIOpen, whichever measures faster
-                surrogates.FoldedConv.impl = "auto"
-                net = surrogates.StereoRcnnR101(seed=args.seed)
+            if args.model == "layerlist":   # ResNet-101-FPN layer list on the route table's kernels; the scripts' checkpoint if it is there
+                net, uncert = _common.layerlist_srcnn(dev, args)
             else:
-                net = surrogates.StereoRcnnShaped(seed=args.seed)
-            adapter = adapters.StereoRcnnAdapter(net.to(dev).eval(), torch.zeros(6, device=dev))
+                net, uncert = surrogates.StereoRcnnShaped(seed=args.seed).to(dev).eval(), torch.zeros(6, device=dev)
+            adapter = adapters.StereoRcnnAdapter(net, uncert)
             loader = _common.WithExtra(loader, lambda b: surrogates.synthetic_srcnn_extra(b, dev))
     else:
         rt = _common.upstream_or_exit(lambda: upstream.SrcnnRuntime(dev, training=True, workers=0, adopt=args.adopt))

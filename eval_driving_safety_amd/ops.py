@@ -891,7 +891,10 @@ class Conv3dK3(torch.autograd.Function):
         if wino is not None and cout >= 4:
             by_wino = lambda: conv3d_wino(x, wino, bias, res, bool(relu))                            # noqa: E731
             key = ("f3", x.shape[1], cout, tuple(x.shape), res is not None, bool(relu))
-            y = by_wino() if _Conv2dChoice.pick(key, {"direct": direct, "wino": by_wino}) == "wino" else direct()
+            took = _Conv2dChoice.pick(key, {"direct": direct, "wino": by_wino}) == "wino"
+            y = by_wino() if took else direct()
+            if took:
+                WINO_DIRECT_EQUIV_FLOPS[0] += 54 * y.numel() * x.shape[1]
         else:
             y = direct()
         ctx.save_for_backward(w_prep_t if ctx.has_t else weight, y if ctx.mask_own else None, x if mask_input else None)
@@ -917,7 +920,10 @@ class Conv3dK3(torch.autograd.Function):
             if ctx.wino is not None and ctx.xshape[1] >= 4:
                 by_wino = lambda: conv3d_wino_dgrad(g, ctx.wino, mask=x_in if ctx.mask_input else None)      # noqa: E731
                 key = ("b3", ctx.xshape[1], g.shape[1], ctx.xshape, ctx.mask_input)
-                gx = by_wino() if _Conv2dChoice.pick(key, {"direct": direct, "wino": by_wino}) == "wino" else direct()
+                took = _Conv2dChoice.pick(key, {"direct": direct, "wino": by_wino}) == "wino"
+                gx = by_wino() if took else direct()
+                if took:
+                    WINO_DIRECT_EQUIV_FLOPS[0] += 54 * gx.numel() * g.shape[1]
             else:
                 gx = direct()
         else:
@@ -1114,6 +1120,12 @@ def bias_act_(y, bias=None, residual=None, relu=False):
     return yi
 
 
+# direct-convolution FLOPs (2 x MACs) of the calls that took a Winograd route since the last reset: such a call EXECUTES 2.25x fewer
+# multiply-adds on the matrix cores than it is credited with (F(2x2,3x3): 16 products per 4 outputs instead of 36) - tools/bench_end_to_end.py
+# turns this into executed FLOPs per step and a matrix-pipe utilisation bound next to the direct-equivalent roofline fraction
+WINO_DIRECT_EQUIV_FLOPS = [0]
+
+
 class _Conv2dChoice:
     """Per layer shape and direction: who computes it - this package's direct kernel ("hip"), its Winograd kernel ("wino") or torch's
     operator ("", MIOpen / rocBLAS + one fused element-wise pass).  The three sum in different float orders, so the choice is part of
@@ -1168,6 +1180,8 @@ class Conv2dAuto(torch.autograd.Function):
         use = _Conv2dChoice.get(key, lambda: conv2d(x, prep, bias, res, do_relu), by_torch,
                                 (lambda: conv2d(x, prep, bias, res, do_relu, wino=True)) if prep.has_wino else None)
         y = conv2d(x, prep, bias, res, do_relu, wino=(use == "wino")) if use else by_torch()
+        if use == "wino":
+            WINO_DIRECT_EQUIV_FLOPS[0] += 18 * y.numel() * prep.cin
         ctx.prep, ctx.has_res, ctx.xshape = prep, res is not None, tuple(x.shape)
         ctx.mask_own = do_relu and relu != "consumer"          # mask the incoming gradient with y > 0 here
         ctx.mask_input = bool(mask_input)
@@ -1194,6 +1208,8 @@ class Conv2dAuto(torch.autograd.Function):
         hip = lambda wino=False: conv2d_dgrad(g, prep, residual=skip, mask=x_in if ctx.mask_input else None, wino=wino)      # noqa: E731
         use = _Conv2dChoice.get(key, hip, by_torch, (lambda: hip(True)) if prep.has_wino else None)
         gx = hip(use == "wino") if use else by_torch()
+        if use == "wino":
+            WINO_DIRECT_EQUIV_FLOPS[0] += 18 * gx.numel() * prep.cout
         return gx, None, None, None, (g if ctx.has_res else None), None, None, None
 
 

@@ -376,6 +376,9 @@ class StereoRcnnR101(StereoRcnnShaped):
     ``rois_per_image``: what the proposal-target layer samples [cfg.TRAIN.BATCH_SIZE, UPSTREAM-UNVERIFIED: 512 assumed]; the
     proposals of this network are padded / cut to exactly that many, as the upstream sampler does with replacement."""
     BLOCKS = (3, 4, 23, 3)
+    # crutches of RANDOM weights, switched off by checkpoints.load_stereo_rcnn: the image (mean-subtracted 0..255 pixels) is scaled down
+    # before the stem, and the RPN's regression output is bounded to what a trained network emits
+    input_scale, bounded_rpn_deltas = 1.0 / 64.0, True
 
     def __init__(self, classes=("__background__", "Car"), num_layers=101, pretrained=False, seed=0, post_nms=300, pre_nms=2000,
                  rois_per_image=512, roi_align=None, nms=None, blocks=None):
@@ -450,7 +453,7 @@ class StereoRcnnR101(StereoRcnnShaped):
         return p + [p6]
 
     def pyramid_pair(self, im_left, im_right):
-        both = torch.cat([im_left, im_right], 0) / 64.0
+        both = torch.cat([im_left, im_right], 0) * self.input_scale
         feats = self._graphed_pyramid(both) if self.use_graph and both.is_cuda else self.pyramid(both)
         b = im_left.shape[0]
         return [f[:b] for f in feats], [f[b:] for f in feats]
@@ -477,7 +480,8 @@ class StereoRcnnR101(StereoRcnnShaped):
     def rpn_deltas(self, both):
         # a trained RPN regresses small corrections of its anchors; random weights would give slivers a fraction of a pixel wide
         # (0.2-4 px at P2 in the first version: a degenerate workload for RoIAlign) - bound them to what a trained network emits
-        return 0.5 * torch.tanh(self.rpn_reg(both))
+        d = self.rpn_reg(both)
+        return 0.5 * torch.tanh(d) if self.bounded_rpn_deltas else d
 
     def head_to_tail(self, pooled):
         self._extra_flops = getattr(self, "_extra_flops", 0) + 2 * pooled.shape[0] * 2048 * 13 * self.n_classes

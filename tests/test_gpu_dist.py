@@ -42,6 +42,16 @@ def test_bench_two_ranks_on_one_gpu():
     assert d["roofline"]["clean_image_read_as"].startswith("uint8 index for 16 of 16")
     assert d["patch_allreduce"]["correct"] is True and d["patch_allreduce"]["avg_us"] > 0
     assert "cpu_baseline" not in d                                                                              # rank 0 at N = 1 only
+    # what the ranks do end to end at N > 1 (beside `value`, never in it): every rank its own DSGN-shaped 20-step attack (image-sharded,
+    # no collective) and a universal-patch epoch with the delta all-reduced inside the loop
+    e = d["distributed_end_to_end"]
+    assert "error" not in e, e
+    a, p = e["image_sharded_attack"], e["universal_patch"]
+    assert e["world"] == 2 and a["value"] > 0 and len(a["per_rank_s_per_attack"]) == 2 and a["loss_rose"] is True
+    assert a["per_rank_pairs_per_s_min"] <= a["per_rank_pairs_per_s_max"] and abs(a["value"] - 2 * a["per_rank_pairs_per_s_min"]) < 1e-6 * a["value"]
+    assert p["pairs"] == 4 and p["value"] > 0 and p["all_reduces_per_rank"] == 4 and p["message_bytes"] == 4 * (3 * 101 * 101 + 1)
+    assert 0 < p["all_reduce_share_of_inner_iteration"] < 1 and len(p["all_reduce_ms_per_inner_iteration"]) == 2 and p["patch_abs_max"] > 0
+    assert d["routes"]["mode"] == "table" and len(d["routes"]["hash"]) == 12 and d["routes"]["fixed_rule_lookups"] == 0
 
 
 def test_bench_launches_its_own_ranks_when_started_plainly():
@@ -49,8 +59,8 @@ def test_bench_launches_its_own_ranks_when_started_plainly():
     child torch.distributed.run, relays rank 0's one JSON line and its exit status; the line says what the process group says"""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4", ADV_BENCH_SHARE_GPU="1", ADV_BENCH_BACKEND="gloo")
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--pairs", "8"], cwd=ROOT,
-                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--pairs", "8",
+                          "--no-end-to-end"], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1

@@ -103,6 +103,16 @@ def _choice_summary(fresh=False):
     return out
 
 
+def _executed(step, wino_equiv, executed, model_ms):
+    """the matrix work the step really EXECUTES: Winograd layers at their 2.25x lower multiply count.  ``roofline.frac`` credits those
+    layers with the direct convolution's FLOPs (algorithmic credit: it can exceed what the pipes did); ``mfma_util`` = executed FLOPs /
+    time / peak is an upper bound of the matrix pipes' busy share over the whole step (padding and the element-wise / loss kernels
+    included in the time); the counters of the individual kernels are in profiles/r04_conv_pmc.json"""
+    return {"executed_flops_per_step": executed, "winograd_share_of_direct_flops": wino_equiv / step if step else 0.0,
+            "mfma_util": executed / model_ms / 1e9 / 157.3,
+            "mfma_util_note": "executed multiply-add FLOPs (Winograd routes at 1/2.25 of their direct count) / step time / 157.3 TFLOP/s"}
+
+
 def measure_dsgn_full(pairs=1, iters=20, reps=1, graph=False, hip2d="auto"):
     """BASELINE configs[1] end to end through the DSGN-shaped graph with SURVEY App. B's layer list (adapters.DsgnShapedAdapter: PSMNet-style
     2D extractor, plane-sweep volume, dres0/dres1 + 3D hourglass, fused depth regression, 3D geometric volume + 64-channel stack + 3D
@@ -117,7 +127,11 @@ def measure_dsgn_full(pairs=1, iters=20, reps=1, graph=False, hip2d="auto"):
     for _ in range(2):
         net.loss_and_grad(x, batch.extra)
     torch.cuda.synchronize()
+    from eval_driving_safety_amd import ops as _ops
+    _ops.WINO_DIRECT_EQUIV_FLOPS[0] = 0
     step = float(net.flops_per_step(x, batch.extra))
+    wino_equiv = float(_ops.WINO_DIRECT_EQUIV_FLOPS[0])       # direct-equivalent FLOPs of the calls that took a Winograd route, one step
+    executed = step - wino_equiv * (1.0 - 1.0 / 2.25)
     n = 5
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -164,6 +178,7 @@ def measure_dsgn_full(pairs=1, iters=20, reps=1, graph=False, hip2d="auto"):
                                 False: "torch / MIOpen"}[hip2d],
             "layers_2d_on_libadvengine": _choice_summary(),
             "mfma_frac_step": step / model_ms / 1e9 / 157.3, "peak_hbm_gib": torch.cuda.max_memory_allocated() / 2 ** 30,
+            **_executed(step, wino_equiv, executed, model_ms),
             "loss_first_iter": first, "loss_last_iter": last, "loss_rose": last > first,
             "note": "NOT the headline metric and NOT DSGN's weights; layer list [UPSTREAM-UNVERIFIED] from the published PSMNet / DSGN structures"}
 
@@ -187,7 +202,10 @@ def measure_srcnn_r101(pairs=1, iters=20, reps=1, rois=512, impl="auto", graph_b
             net.loss_and_grad(x, batch.extra)
         torch.cuda.synchronize()
         model.reset_flops()
+        from eval_driving_safety_amd import ops as _ops
+        _ops.WINO_DIRECT_EQUIV_FLOPS[0] = 0
         net.loss_and_grad(x, batch.extra)        # the FLOP count comes from the eager graph (a replayed hipGraph runs no Python)
+        wino_equiv = float(_ops.WINO_DIRECT_EQUIV_FLOPS[0])
         by_class = model.flops_by_class()
         fwd = float(sum(by_class.values()))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -226,6 +244,7 @@ def measure_srcnn_r101(pairs=1, iters=20, reps=1, rois=512, impl="auto", graph_b
                                                    "losses, element-wise) against the float32 matrix peak",
                          "achieved": step / model_ms / 1e9, "peak": 157.3, "unit": "TFLOP/s", "frac": step / model_ms / 1e9 / 157.3},
             "convolutions": impl, "layers_2d_on_libadvengine": _choice_summary(), "rois_per_image": rois,
+            **_executed(step, wino_equiv, step - wino_equiv * (1.0 - 1.0 / 2.25), model_ms),
             "backbone_in_hip_graphs": bool(graph_backbone), "detector_fwd_bwd_ms_all_eager": eager_ms, "peak_hbm_gib": peak,
             "loss_first_iter": first, "loss_last_iter": last, "loss_rose": last > first,
             "note": "NOT the headline metric and NOT Stereo R-CNN's weights: bottleneck stacks [3,4,23,3] with the stride on the first 1x1, "
@@ -306,6 +325,103 @@ def measure_patch(pairs=8, iters=2, reps=2):
             "ms_per_inner_iteration": 1e3 * dt / (pairs * iters), "patch_abs_max": float(trainer.patch.abs().max()),
             "note": "NOT the headline metric and NOT DSGN; pairs pre-generated on the host, the per-epoch patch.npy write included; paste / update "
                     "kernels and every 3D operator by libadvengine.so"}
+
+
+def measure_distributed(dist, dev, rank, world, fence, iters=20, patch_pairs_per_rank=2):
+    """What the scaling run measures beyond the collective-free perturbation kernel - EVERY rank runs this:
+      image_sharded_attack   the DSGN-shaped 20-step PGD on the rank's OWN stereo pair (SURVEY 8e: pairs shard by image, no collective);
+                             aggregate pairs/s = world pairs / the slowest rank's time, per-rank min / max beside it;
+      universal_patch        one universal-patch epoch (D = 101, 2 inner iterations per pair, BASELINE configs[3]) with the patch delta
+                             all-reduced INSIDE the loop (attacks.PatchTrainer -> Comm.all_reduce_sum_: RCCL over xGMI, gloo in the
+                             1-GPU tests); the all-reduce's share of an inner iteration from device events around the collective.
+    Returns the dict on rank 0, None elsewhere."""
+    import contextlib
+    import io
+    import tempfile
+    from eval_driving_safety_amd.dist import Comm
+
+    def gather(v):                                  # one float per rank -> list (a SUM all-reduce of a one-hot row: both backends do it)
+        t = torch.zeros((world,), dtype=torch.float64, device=dev)
+        t[rank] = v
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return [float(q) for q in t.cpu()]
+
+    net = adapters.DsgnShapedAdapter(dev, seed=0)   # every rank holds the same detector (model replicas only)
+    batch = next(iter(data.SyntheticStereo(1, "dsgn", batch=1, seed=100 + rank)))
+    batch.extra = net.synthetic_extra(batch, seed=1 + rank)
+    x = torch.cat([batch.imgL, batch.imgR]).to(dev)
+    for _ in range(2):
+        net.loss_and_grad(x, batch.extra)
+    atk = attacks.PgdAttack("dsgn", 1 / 255, 0.03, iters, save=False, device=dev)
+    fence()
+    t0 = time.perf_counter()
+    atk.run_batch(batch, net)
+    torch.cuda.synchronize()
+    mine = time.perf_counter() - t0
+    fence()
+    times = gather(mine)
+    sharded = {"metric": "aggregate stereo-pairs/s, %d-step PGD through the DSGN-shaped graph, one pair per rank, image-sharded, no collective" % iters,
+               "value": world / max(times), "unit": "stereo-pairs/s", "per_rank_pairs_per_s_min": 1.0 / max(times), "per_rank_pairs_per_s_max": 1.0 / min(times),
+               "per_rank_s_per_attack": times, "loss_rose": bool(float(atk.last_losses[-1]) > float(atk.last_losses[0]))}
+
+    class TimedComm(Comm):
+        """the production Comm with device events around the exchange (events on the stream the collective is enqueued on)"""
+        spans = []
+
+        def all_reduce_sum_(self, t):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = Comm.all_reduce_sum_(self, t)
+            e1.record()
+            self.spans.append((e0, e1, t.numel()))
+            return out
+
+    comm = TimedComm(rank, world, False)
+    n_pairs = world * patch_pairs_per_rank
+    batches = []                                    # every rank generates the whole round-robin list and owns i % world == rank
+    for b in data.SyntheticStereo(n_pairs, "dsgn", batch=1, seed=3):
+        b.extra = net.synthetic_extra(b, seed=1)
+        batches.append(b)
+
+    def fresh():
+        out = []
+        for b in batches:
+            c = data.StereoBatch(b.imgL.clone(), b.imgR.clone(), list(b.names), b.sizes)
+            c.extra = types.SimpleNamespace(disp_true=b.extra.disp_true, boxes=[list(v) for v in b.extra.boxes])
+            out.append(c)
+        return out
+
+    inner = 2
+    with tempfile.TemporaryDirectory() as tmp, contextlib.redirect_stdout(io.StringIO()):
+        trainer = attacks.PatchTrainer("dsgn", 0.2605, 8 / 255, inner, 1, out_root=tmp, seed=0, comm=comm, device=dev)
+        warm = fresh()
+        trainer.train(lambda: warm, net)
+        epoch = fresh()
+        TimedComm.spans = []
+        fence()
+        t0 = time.perf_counter()
+        trainer.train(lambda: epoch, net)
+        torch.cuda.synchronize()
+        dt_mine = time.perf_counter() - t0
+    fence()
+    delta_spans = [(a, b) for a, b, n in TimedComm.spans if n > 2]         # the [3*D*D + 1] patch exchanges (not the 2-element loss statistics)
+    ar_ms = sum(a.elapsed_time(b) for a, b in delta_spans)
+    dts, ars = gather(dt_mine), gather(ar_ms)
+    dt = max(dts)
+    rounds = patch_pairs_per_rank * inner
+    patch = {"metric": "aggregate stereo-pairs/s, universal-patch training (D = %d, %d inner iterations per pair) through the DSGN-shaped graph, "
+                       "pairs dealt round-robin over the ranks, patch delta all-reduced every inner iteration" % (trainer.patch_dim, inner),
+             "value": n_pairs / dt, "unit": "stereo-pairs/s", "pairs": n_pairs, "per_rank_s_per_epoch": dts,
+             "ms_per_inner_iteration": 1e3 * dt / rounds, "all_reduces_per_rank": len(delta_spans),
+             "all_reduce_ms_per_inner_iteration": [v / max(1, len(delta_spans)) for v in ars],
+             "all_reduce_share_of_inner_iteration": max(ars) / (1e3 * dt), "message_bytes": 4 * (3 * trainer.patch_dim ** 2 + 1),
+             "patch_abs_max": float(trainer.patch.abs().max()),
+             "note": "the share includes what a rank WAITS inside the collective for the slowest rank's detector step (the exchange is the "
+                     "round's only synchronisation point); bench.py's patch_allreduce object times the bare collective"}
+    if rank != 0:
+        return None
+    return {"image_sharded_attack": sharded, "universal_patch": patch, "world": world, "backend": dist.get_backend() if world > 1 or dist.is_initialized() else "none"}
 
 
 def main():
