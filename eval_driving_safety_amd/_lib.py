@@ -23,7 +23,7 @@ ADV_ELAUNCH = -5
 ADV_SPACE_AFFINE = 0
 ADV_SPACE_IDENTITY = 1
 ADV_SPACE_AFFINE_RCP = 2
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class AdvSpace(ctypes.Structure):
@@ -114,6 +114,7 @@ _OTHER = {
     "adv_abi_version": ([], _I),
     "adv_build_has_test_hooks": ([], _I),
     "adv_roi_align_bwd_workspace_ints": ([_I, _I, _I, _I, _I, _I, _I], ctypes.c_int64),
+    "adv_roi_align_bwd_segments": ([_I], _I),
     "adv_grid_sample3d_plan_bytes": ([_I, _I, _I, _I, _I, _I, _I], ctypes.c_int64),
     "adv_grid_sample3d_bwd_workspace_floats": ([_I, _I, _I, _I, _I], ctypes.c_int64),
     "adv_conv2d_1x1_prep_floats": ([_I, _I, _I], ctypes.c_int64),

@@ -96,7 +96,12 @@ class _Adopted(nn.Module):
         return self._prep
 
     def _torch_epilogue(self, y, ops):
-        return ops.bias_act_(y, self.bias, None, self.relu) if (self.bias is not None or self.relu) else y
+        """bias + ReLU behind a convolution torch computed, one fused pass; through ops.BiasAct so that the ReLU has its backward"""
+        if self.bias is None and not self.relu:
+            return y
+        if not y.requires_grad:
+            return ops.bias_act_(y, self.bias, None, self.relu)
+        return ops.BiasAct.apply(y.contiguous(), self.bias, self.relu)
 
 
 class AdoptedConv2d(_Adopted):

@@ -645,39 +645,45 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_mfma(const float* __restrict
 // same bits as the class launches and the oracle.  The weights are read from the eight per-class prepared tensors the entry
 // point already takes: kernel tap k of class c sits at tap t(k) of cls_wp[c].
 // ---------------------------------------------------------------------------------------------------------------
-template <int TT>                                         // TT = input rows per tile = waves per workgroup
+// <round 4> TD = input planes per tile, spread over the waves like the rows: a tile is TD x TT input voxels-rows with TD * TT waves
+// (4 x 1, 2 x 2 or 1 x 4 for the flat hourglass volumes: 5 and 10 rows pad to 8 and 12 in 4-row tiles).  Same footprint per stage
+// (2 planes x 5 rows, 3 x 3, 5 x 2 per channel), same accumulation order per output, same bits.
+template <int TT, int TD = 1>                             // TT = input rows, TD = input planes per tile; TT * TD waves per workgroup
 struct TGeo {
-  static constexpr int kRows = kFC * 2 * (TT + 1);       // tile rows per stage: 4 channels x 2 planes x (TT + 1) rows
+  static constexpr int kNW = TT * TD;                    // waves
+  static constexpr int kRows = kFC * (TD + 1) * (TT + 1);  // tile rows per stage: 4 channels x (TD + 1) planes x (TT + 1) rows
   static constexpr int kXF4 = kRows * 10;                // 400 float4 (TT = 4)
   static constexpr int kXInstr = (kXF4 + 63) / 64;       // 7 wave-instructions (the last one partly pad)
   static constexpr int kSX = kXInstr * 256;              // floats reserved for the input tile
   static constexpr int kWInstr = (kWF4 + 63) / 64;       // 14
   static constexpr int kStage = kSX + kWInstr * 256;     // 5376 floats = 21 KiB per stage (TT = 4)
-  static constexpr int kXPer = (kXInstr + TT - 1) / TT, kWPer = (kWInstr + TT - 1) / TT;
+  static constexpr int kXPer = (kXInstr + kNW - 1) / kNW, kWPer = (kWInstr + kNW - 1) / kNW;
 };
 
 __device__ __forceinline__ constexpr int tp_off(int a) { return a == 2 ? 1 : 0; }     // input offset of per-axis choice a
 __device__ __forceinline__ constexpr int tp_par(int a) { return a == 0 ? 0 : 1; }     // output parity
 __device__ __forceinline__ constexpr int tp_tap(int a) { return a == 2 ? 2 : 1; }     // tap of the CLASS convolution (offset + 1)
 
-template <int kTT>
-__global__ __launch_bounds__(64 * kTT, kTT == 4 ? 2 : 1) void convt3d_k3_s2_mfma(const float* __restrict__ x, float* __restrict__ y, int Cin, int Cout,
+template <int kTT, int kTDt = 1>
+__global__ __launch_bounds__(64 * kTT * kTDt, kTT * kTDt == 4 ? 2 : 1) void convt3d_k3_s2_mfma(const float* __restrict__ x, float* __restrict__ y, int Cin, int Cout,
                                                                   int cout_pad, int D, int H, int W, int tiles_w, int tiles_h, int cblocks,
                                                                   Epi epi) {
-  using TG = TGeo<kTT>;
+  using TG = TGeo<kTT, kTDt>;
   constexpr int kTXPer = TG::kXPer, kTWPer = TG::kWPer, kTXF4 = TG::kXF4, kTXInstr = TG::kXInstr, kTWInstr = TG::kWInstr, kTSX = TG::kSX,
-                kTStage = TG::kStage;
+                kTStage = TG::kStage, kNW = TG::kNW;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wd = wave / kTT, wh = wave % kTT;              // this wave's input plane and row of the tile
   const int half = lane >> 5, l32 = lane & 31;
   const int plane = H * W, vol = plane * D;
+  const int tiles_d = (D + kTDt - 1) / kTDt;
   int t = blockIdx.x;
   const int w0 = (t % tiles_w) * kTW;
   t /= tiles_w;
   const int h0 = (t % tiles_h) * kTT;
   t /= tiles_h;
-  const int d0 = t % D;
-  t /= D;
+  const int d0 = (t % tiles_d) * kTDt;
+  t /= tiles_d;
   const int b = t / cblocks, cob = t - b * cblocks;
   const float* xb = x + static_cast<long long>(b) * Cin * vol;
 
@@ -686,9 +692,9 @@ __global__ __launch_bounds__(64 * kTT, kTT == 4 ? 2 : 1) void convt3d_k3_s2_mfma
   const float* wsrc[kTWPer];
 #pragma unroll
   for (int p = 0; p < kTXPer; ++p) {
-    const int q = 64 * (wave + kTT * p) + lane;
+    const int q = 64 * (wave + kNW * p) + lane;
     const int row = q / 10, j = q - row * 10;
-    const int c = row / (2 * (kTT + 1)), rem = row - c * 2 * (kTT + 1);
+    const int c = row / ((kTDt + 1) * (kTT + 1)), rem = row - c * (kTDt + 1) * (kTT + 1);
     const int dd = rem / (kTT + 1), hh = rem - dd * (kTT + 1);
     const int gd = d0 + dd, gh = h0 + hh, gw = w0 - 4 + 4 * j;
     const bool ok = q < kTXF4 && j > 0 && gd < D && gh < H && gw + 3 < W;          // j = 0 (columns left of the tile) is never read
@@ -696,7 +702,7 @@ __global__ __launch_bounds__(64 * kTT, kTT == 4 ? 2 : 1) void convt3d_k3_s2_mfma
   }
 #pragma unroll
   for (int p = 0; p < kTWPer; ++p) {
-    const int f = 64 * (wave + kTT * p) + lane;
+    const int f = 64 * (wave + kNW * p) + lane;
     const int n4 = f & 7, c = (f >> 3) & (kFC - 1), slot = f / (8 * kFC);           // slot = (ad*3 + ah)*3 + aw
     const int ad = slot / 9, ah = (slot / 3) % 3, aw = slot % 3;
     const int cls = (tp_par(ad) * 2 + tp_par(ah)) * 2 + tp_par(aw), tap = (tp_tap(ad) * 3 + tp_tap(ah)) * 3 + tp_tap(aw);
@@ -708,12 +714,12 @@ __global__ __launch_bounds__(64 * kTT, kTT == 4 ? 2 : 1) void convt3d_k3_s2_mfma
   auto issue = [&](int c0, float* stage) {
 #pragma unroll
     for (int p = 0; p < kTXPer; ++p) {
-      const int k = wave + kTT * p;
+      const int k = wave + kNW * p;
       if (k < kTXInstr) glds16(xo[p] >= 0 ? xb + static_cast<long long>(c0) * vol + xo[p] : g_zero16, stage + k * 256);
     }
 #pragma unroll
     for (int p = 0; p < kTWPer; ++p) {
-      const int k = wave + kTT * p;
+      const int k = wave + kNW * p;
       if (k < kTWInstr) glds16(wsrc[p] ? wsrc[p] + static_cast<long long>(c0) * cout_pad : g_zero16, stage + kTSX + k * 256);
     }
   };
@@ -738,7 +744,7 @@ __global__ __launch_bounds__(64 * kTT, kTT == 4 ? 2 : 1) void convt3d_k3_s2_mfma
 #pragma unroll
       for (int kk = 0; kk < kFC / 2; ++kk) {
         const int c = 2 * kk + half;
-        const float bv = sxc[((c * 2 + od) * (kTT + 1) + wave + oh) * kP + 4 + l32 + ow];
+        const float bv = sxc[((c * (kTDt + 1) + wd + od) * (kTT + 1) + wh + oh) * kP + 4 + l32 + ow];
 #pragma unroll
         for (int slot = 0; slot < 27; ++slot) {         // the kernel taps that read this offset: one per class they feed
           const int ad = slot / 9, ah = (slot / 3) % 3, aw = slot % 3;
@@ -755,8 +761,8 @@ __global__ __launch_bounds__(64 * kTT, kTT == 4 ? 2 : 1) void convt3d_k3_s2_mfma
 
   // ---- epilogue: accumulator register v of lane l is D[cout = 8*(v/4) + 4*(l/32) + v%4][input voxel l%32]; the classes pw = 0 / 1
   // of an output row are neighbours in memory: one 8-byte store per lane, 256 contiguous bytes per half-wave
-  const int gh = h0 + wave, gw = w0 + l32;
-  if (gh >= H || gw >= W) return;
+  const int gh = h0 + wh, gw = w0 + l32, gdi = d0 + wd;
+  if (gh >= H || gw >= W || gdi >= D) return;
   const int co0 = cob * 32 + 4 * half;
   const long long ovol = static_cast<long long>(epi.od) * epi.oh * epi.ow;
   typedef float v2f __attribute__((ext_vector_type(2)));
@@ -765,7 +771,7 @@ __global__ __launch_bounds__(64 * kTT, kTT == 4 ? 2 : 1) void convt3d_k3_s2_mfma
     for (int pd = 0; pd < 2; ++pd)
 #pragma unroll
       for (int ph = 0; ph < 2; ++ph) {
-        float* yr = y + (static_cast<long long>(b) * Cout + co0) * ovol + (static_cast<long long>(2 * d0 + pd) * epi.oh + 2 * gh + ph) * epi.ow + 2 * gw;
+        float* yr = y + (static_cast<long long>(b) * Cout + co0) * ovol + (static_cast<long long>(2 * gdi + pd) * epi.oh + 2 * gh + ph) * epi.ow + 2 * gw;
         const int c0i = (pd * 2 + ph) * 2;
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
@@ -789,7 +795,7 @@ __global__ __launch_bounds__(64 * kTT, kTT == 4 ? 2 : 1) void convt3d_k3_s2_mfma
   for (int pd = 0; pd < 2; ++pd)
 #pragma unroll
     for (int ph = 0; ph < 2; ++ph) {
-      const long long at = (static_cast<long long>(b) * Cout + co0) * ovol + (static_cast<long long>(2 * d0 + pd) * epi.oh + 2 * gh + ph) * epi.ow + 2 * gw;
+      const long long at = (static_cast<long long>(b) * Cout + co0) * ovol + (static_cast<long long>(2 * gdi + pd) * epi.oh + 2 * gh + ph) * epi.ow + 2 * gw;
       const int c0i = (pd * 2 + ph) * 2;
       v2f sk[16];    // the skip connection's values of this output row, all in flight before the first store
       if (has_res) {
@@ -831,12 +837,19 @@ constexpr int kSRow = 72;                                 // LDS row = global co
 // more than the ~10 B/clk/CU the path delivers), not by its 2-way LDS conflicts.  PD = 2 stages 5 input planes for 2 output planes and
 // the same weights: 40 KiB for 108 MFMAs per wave, 5.8 bytes per cycle.  Only with two channel blocks per workgroup (cout > 32), where
 // two 40 KiB stages x two workgroups are exactly the CU's 160 KiB, and only where the halved tile count still fills the chip.
-template <int CB, int PD = 1>
+// <round 4> WD = output depth planes spread over the four WAVES (1, 2 or 4): the tile is WD planes x 4 / WD rows (x kRW rows per wave)
+// instead of 1 x 4.  The hourglass volumes are flat - 10 and 5 output rows at the 3D geometric volume's half and quarter resolution -
+// and a 4-row tile pads them to 12 and 8 (17 % / 38 % of the matrix work on rows that do not exist); 2 x 2 and 4 x 1 tiles cover them
+// with 10 and 5 (6 at 2 x 2).  The staged footprint is the same (3 planes x 9 rows, 5 x 5, 9 x 3 per channel) and so is every output's
+// accumulation order (stage, tap, channel): the same bits whichever tile shape the launch picks.
+template <int CB, int PD = 1, int WD = 1>
 struct SGeo {
   static constexpr int kRW = 3 - CB;                      // output rows per wave
-  static constexpr int kTH = 4 * kRW;                     // output rows per tile (four waves)
+  static constexpr int kWR = 4 / WD;                      // waves along the rows
+  static constexpr int kTH = kWR * kRW;                   // output rows per tile
+  static constexpr int kTDp = PD * WD;                    // output planes per tile
   static constexpr int kRowsIn = 2 * kTH + 1;             // input rows per plane of the tile
-  static constexpr int kPlanes = 2 * PD + 1;              // input planes of the tile
+  static constexpr int kPlanes = 2 * kTDp + 1;            // input planes of the tile
   static constexpr int kRows = kSC * kPlanes * kRowsIn;
   static constexpr int kXF4 = kRows * (kSRow / 4);        // 972 (CB = 2) / 1836 float4
   static constexpr int kXInstr = (kXF4 + 63) / 64;
@@ -847,15 +860,16 @@ struct SGeo {
   static constexpr int kXPer = (kXInstr + 3) / 4, kWPer = (kWInstr + 3) / 4;
 };
 
-template <int CB, int PD = 1>
+template <int CB, int PD = 1, int WD = 1>
 __global__ __launch_bounds__(256, 2) void conv3d_k3_s2_mfma(const float* __restrict__ x, const float* __restrict__ wp, float* __restrict__ y,
                                                             int Cin, int Cout, int cout_pad, int D, int H, int W, int gD, int gH, int gW,
                                                             int tiles_w, int tiles_h, int cgroups, Epi epi) {
-  using SG = SGeo<CB, PD>;
+  using SG = SGeo<CB, PD, WD>;
   constexpr int kRW = SG::kRW, kRowsIn = SG::kRowsIn, kCO = 32 * CB, kPlanes = SG::kPlanes;
-  const int gDt = (gD + PD - 1) / PD;                      // depth tiles
+  const int gDt = (gD + SG::kTDp - 1) / SG::kTDp;          // depth tiles
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wd = wave / SG::kWR, wr = wave % SG::kWR;      // this wave's plane (of WD) and row group (of 4 / WD) of the tile
   const int half = lane >> 5, l32 = lane & 31;
   const int plane = H * W, vol = plane * D;
   int t = blockIdx.x;
@@ -863,7 +877,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_s2_mfma(const float* __restr
   t /= tiles_w;
   const int h0 = (t % tiles_h) * SG::kTH;
   t /= tiles_h;
-  const int d0 = (t % gDt) * PD;                           // first output plane of the tile
+  const int d0 = (t % gDt) * SG::kTDp;                     // first output plane of the tile
   t /= gDt;
   const int b = t / cgroups, cp = t - b * cgroups;
   const float* xb = x + static_cast<long long>(b) * Cin * vol;
@@ -926,7 +940,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_s2_mfma(const float* __restr
         float bv[kRW];
 #pragma unroll
         for (int r = 0; r < kRW; ++r)
-          bv[r] = sxc[((half * kPlanes + 2 * pd + kd) * kRowsIn + 2 * (wave * kRW + r) + kh) * kSRow + 3 + 2 * l32 + kw];
+          bv[r] = sxc[((half * kPlanes + 2 * (wd * PD + pd) + kd) * kRowsIn + 2 * (wr * kRW + r) + kh) * kSRow + 3 + 2 * l32 + kw];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
           acc[pd][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[CB == 2 ? i : 0], bv[CB == 2 ? 0 : i], acc[pd][i], 0, 0, 0);
@@ -945,10 +959,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_s2_mfma(const float* __restr
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int cb = CB == 2 ? i : 0, r = CB == 2 ? 0 : i;
-    const int gh = h0 + wave * kRW + r;
+    const int gh = h0 + wr * kRW + r, gd = d0 + wd * PD + pd;
     const int co0 = cp * kCO + cb * 32 + 4 * half;
-    if (gh >= gH || d0 + pd >= gD || cp * kCO + cb * 32 >= Cout) continue;
-    const long long at = (static_cast<long long>(b) * Cout + co0) * ovol + (static_cast<long long>(d0 + pd) * gH + gh) * gW + gw;
+    if (gh >= gH || gd >= gD || cp * kCO + cb * 32 >= Cout) continue;
+    const long long at = (static_cast<long long>(b) * Cout + co0) * ovol + (static_cast<long long>(gd) * gH + gh) * gW + gw;
     float bz[16], sk[16];
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
@@ -1285,16 +1299,32 @@ static int launch_conv(const float* x, const float* w_prep, float* y, int b, int
         // two co-resident workgroups share the matrix pipes, so 576 tiles take three rounds of 256 CUs, and 288 double tiles two
         // double-length ones (a first version counted 512 slots and made the 16-GFLOP layers 15 % slower).
         // (ADV_CONV_S2_PD=1|2 forces one - test hook / A-B; same bits)
-        const long long cus = cu_count(), n2 = static_cast<long long>(tw) * th * ((gd + 1) / 2) * b * cgroups;
-        bool pd2 = 1.86 * static_cast<double>((n2 + cus - 1) / cus) < static_cast<double>((ntiles + cus - 1) / cus);
-        if (const char* e = adv_hook_value("ADV_CONV_S2_PD")) pd2 = e[0] == '2';
-        if (pd2) {
-          const size_t lds2 = 2 * sizeof(float) * static_cast<size_t>(SGeo<2, 2>::kStage);
-          if (!adv_internal_lds_limit<conv3d_k3_s2_mfma<2, 2>>(lds2)) return ADV_ELAUNCH;
-          hipLaunchKernelGGL((conv3d_k3_s2_mfma<2, 2>), dim3(static_cast<unsigned>(n2)), dim3(256), lds2, st, x, w_prep, y, cin, cout, cblocks * 32, d, h, w, gd, gh,
-                             gw, tw, th, cgroups, epi);
-          return adv_internal_finish_launch();
+        // <round 4> flat volumes: spread the tile's four waves over 2 or 4 output planes where that pads fewer rows (same bits)
+        auto padded = [&](int wdp) { return static_cast<long long>((gh + 4 / wdp - 1) / (4 / wdp)) * (4 / wdp) * ((gd + wdp - 1) / wdp) * wdp; };
+        int wdv = 1;
+        if (padded(2) < padded(wdv)) wdv = 2;
+        if (padded(4) < padded(wdv)) wdv = 4;
+        if (const char* e = adv_hook_value("ADV_CONV_S2_WD")) wdv = e[0] == '4' ? 4 : (e[0] == '2' ? 2 : 1);
+        const int thw = (gh + 4 / wdv - 1) / (4 / wdv);                   // row tiles of the chosen shape
+        const long long cus = cu_count(), n1 = static_cast<long long>(tw) * thw * ((gd + wdv - 1) / wdv) * b * cgroups,
+                        n2 = static_cast<long long>(tw) * thw * ((gd + 2 * wdv - 1) / (2 * wdv)) * b * cgroups;
+        bool pd2 = wdv <= 2 && 1.86 * static_cast<double>((n2 + cus - 1) / cus) < static_cast<double>((n1 + cus - 1) / cus);
+        if (const char* e = adv_hook_value("ADV_CONV_S2_PD")) pd2 = wdv <= 2 && e[0] == '2';
+#define ADV_LAUNCH_S2(PD_, WD_, N_)                                                                                                           \
+  do {                                                                                                                                        \
+    const size_t lds_ = 2 * sizeof(float) * static_cast<size_t>(SGeo<2, PD_, WD_>::kStage);                                                   \
+    if (!adv_internal_lds_limit<conv3d_k3_s2_mfma<2, PD_, WD_>>(lds_)) return ADV_ELAUNCH;                                                    \
+    hipLaunchKernelGGL((conv3d_k3_s2_mfma<2, PD_, WD_>), dim3(static_cast<unsigned>(N_)), dim3(256), lds_, st, x, w_prep, y, cin, cout,       \
+                       cblocks * 32, d, h, w, gd, gh, gw, tw, thw, cgroups, epi);                                                             \
+    return adv_internal_finish_launch();                                                                                                      \
+  } while (0)
+        if (n1 < (1LL << 31)) {
+          if (pd2 && wdv == 1) ADV_LAUNCH_S2(2, 1, n2);
+          if (pd2 && wdv == 2) ADV_LAUNCH_S2(2, 2, n2);
+          if (wdv == 2) ADV_LAUNCH_S2(1, 2, n1);
+          if (wdv == 4) ADV_LAUNCH_S2(1, 4, n1);
         }
+#undef ADV_LAUNCH_S2
         hipLaunchKernelGGL(conv3d_k3_s2_mfma<2>, dim3(static_cast<unsigned>(ntiles)), dim3(256), 2 * sizeof(float) * static_cast<size_t>(SGeo<2>::kStage),
                            st, x, w_prep, y, cin, cout, cblocks * 32, d, h, w, gd, gh, gw, tw, th, cgroups, epi);
       } else {
@@ -1459,10 +1489,29 @@ int adv_conv_transpose3d_k3_s2_f32(const float* x, const float* const* w_prep_cl
     constexpr int tt = 4;   // rows (= waves) per tile; 8 rows / 512 threads / one workgroup per CU measured the same (0.200-0.204 against 0.205-0.207 ms)
     const int tiles_w = (w + kTW - 1) / kTW, tiles_h = (h + tt - 1) / tt;
     const long long ntiles = static_cast<long long>(tiles_w) * tiles_h * d * b * cblocks;
+    // <round 4> flat volumes: 2 x 2 or 4 x 1 (planes x rows) tiles where they pad fewer rows than 1 x 4 (same bits)
+    auto padded = [&](int tdp) { return static_cast<long long>((h + 4 / tdp - 1) / (4 / tdp)) * (4 / tdp) * ((d + tdp - 1) / tdp) * tdp; };
+    int tdv = 1;
+    if (padded(2) < padded(tdv)) tdv = 2;
+    if (padded(4) < padded(tdv)) tdv = 4;
+    if (const char* e = adv_hook_value("ADV_CONV_T_TD")) tdv = e[0] == '4' ? 4 : (e[0] == '2' ? 2 : 1);
     const bool all_classes = w % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 7) == 0 &&
                              (reinterpret_cast<uintptr_t>(residual) & 7) == 0 && ntiles < (1LL << 31) && !adv_hook("ADV_CONV_T_CLASS_TILES");
     if (all_classes) {   // every class from one staging of the input tile (convt3d_k3_s2_mfma)
       for (int k = 0; k < 8; ++k) epi.cls_wp[k] = w_prep_classes[k];
+      if (tdv > 1) {
+        const int th2 = (h + 4 / tdv - 1) / (4 / tdv);
+        const long long nt = static_cast<long long>(tiles_w) * th2 * ((d + tdv - 1) / tdv) * b * cblocks;
+        if (nt < (1LL << 31)) {
+          if (tdv == 2)
+            hipLaunchKernelGGL((convt3d_k3_s2_mfma<2, 2>), dim3(static_cast<unsigned>(nt)), dim3(256), 2 * sizeof(float) * static_cast<size_t>(TGeo<2, 2>::kStage), st, x, y,
+                               cin, cout, cblocks * 32, d, h, w, tiles_w, th2, cblocks, epi);
+          else
+            hipLaunchKernelGGL((convt3d_k3_s2_mfma<1, 4>), dim3(static_cast<unsigned>(nt)), dim3(256), 2 * sizeof(float) * static_cast<size_t>(TGeo<1, 4>::kStage), st, x, y,
+                               cin, cout, cblocks * 32, d, h, w, tiles_w, th2, cblocks, epi);
+          return adv_internal_finish_launch();
+        }
+      }
       const size_t lds = 2 * sizeof(float) * static_cast<size_t>(TGeo<tt>::kStage);
       hipLaunchKernelGGL(convt3d_k3_s2_mfma<tt>, dim3(static_cast<unsigned>(ntiles)), dim3(64 * tt), lds, st, x, y, cin, cout, cblocks * 32, d, h, w,
                          tiles_w, tiles_h, cblocks, epi);

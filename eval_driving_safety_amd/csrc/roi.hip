@@ -17,6 +17,7 @@
 namespace {
 
 constexpr int kBlock = 256;
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 struct Taps {
   int y_low, x_low, y_high, x_high;
@@ -170,16 +171,17 @@ __device__ __forceinline__ void roi_window(float start, float extent, int size, 
 }
 
 __global__ __launch_bounds__(64) void roi_tile_lists(const float* __restrict__ rois, int R, int H, int W, int tiles_y, int tiles_x, int PH,
-                                                     int PW, float scale, int sampling_ratio, int* __restrict__ lists) {
-  // one wave per (tile, image): lists[tile][0] = count, lists[tile][1..] = roi indices ascending
-  const int tile = blockIdx.x, img = blockIdx.y;
+                                                     int PW, float scale, int sampling_ratio, int* __restrict__ lists, int G, int seg_len) {
+  // one wave per (tile, image, roi segment): lists[..][0] = count, lists[..][1..] = the segment's roi indices ascending
+  const int tile = blockIdx.x, img = blockIdx.y / G, seg = blockIdx.y % G;
   const int ty = (tile / tiles_x) * kTileY, tx = (tile % tiles_x) * kTileX;
-  int* out = lists + (static_cast<long long>(img) * tiles_y * tiles_x + tile) * (R + 1);
+  int* out = lists + ((static_cast<long long>(img) * G + seg) * tiles_y * tiles_x + tile) * (R + 1);
   int count = 0;
-  for (int r0 = 0; r0 < R; r0 += 64) {
+  const int r_end = min(R, (seg + 1) * seg_len);
+  for (int r0 = seg * seg_len; r0 < r_end; r0 += 64) {
     const int r = r0 + threadIdx.x;
     bool hit = false;
-    if (r < R) {
+    if (r < r_end) {
       const Bin b = bin_of(rois + static_cast<long long>(r) * 5, scale, PH, PW, sampling_ratio);
       if (b.batch == img) {
         int y_lo, y_hi, x_lo, x_hi;
@@ -437,26 +439,37 @@ constexpr int kStageBins = 196;     // grad_out blocks of up to 14 x 14 bins are
 // copied into LDS by all 256 lanes at once (one round of coalesced 16-byte loads) while the PREVIOUS roi's items are being summed, and
 // the sample loops read LDS.  Gathering straight from global memory left each half-wave waiting a full L2 round trip per four
 // samples with only 8 pixels in flight per workgroup: 25-35 us per roi on the tile's serial chain (profiles/r03_roi_bwd.jsonl).
-template <bool STAGE, int kAccChan>     // kAccChan channels per workgroup: a roi's items are (touched pixel, channel), 256 / kAccChan pixels at a time
+// <round 4> V4 (with STAGE): an item is (touched pixel, FOUR channels) - one 16-byte LDS read per sample instead of four, the sample's
+// weight product and its bin address computed once for the four: the counters put this kernel at 2.8e8 vector instructions per call on
+// 512 proposals, 0 matrix work, issue-bound (profiles/r04_conv_pmc.json) - the per-channel float operations and their order are unchanged.
+template <bool STAGE, int kAccChan, bool V4 = false>     // kAccChan channels per workgroup: a roi's items are (touched pixel, channel), 256 / kAccChan pixels at a time
 __global__ __launch_bounds__(kBlock) void roi_align_bwd_lds(const float* __restrict__ gcl, const float* __restrict__ rois,
                                                             const int* __restrict__ lists, float* __restrict__ gfeat, int C, int H, int W, int R,
-                                                            int tiles_y, int tiles_x, int PH, int PW, float scale, int sampling_ratio, int dbg) {
+                                                            int tiles_y, int tiles_x, int PH, int PW, float scale, int sampling_ratio, int dbg,
+                                                            int G, long long seg_elems) {
   __shared__ AxisList s_list[kLdsBatch][kTileY + kTileX];
   __shared__ Bin s_bin[kLdsBatch];
   __shared__ int s_rect[kLdsBatch][4];            // first touched row, rows, first touched column, columns (tile-local)
-  constexpr int kAccStride = kAccChan + 1;
-  __shared__ float s_acc[kTileY * kTileX * kAccStride];
+  static_assert(!V4 || (STAGE && kAccChan % 4 == 0), "the four-channel items read the staged block");
+  constexpr int kAccStride = V4 ? kAccChan + 4 : kAccChan + 1;      // (V4: 16-byte aligned rows)
+  constexpr int kLanesPerPix = V4 ? kAccChan / 4 : kAccChan;
+  __shared__ __attribute__((aligned(16))) float s_acc[kTileY * kTileX * kAccStride];
   extern __shared__ __attribute__((aligned(16))) float s_g[];     // STAGE: [2][PH*PW][kAccChan]
-  const int tile = blockIdx.x, img = blockIdx.z, c0 = blockIdx.y * kAccChan;
+  // <round 4> G > 1: the rois are split into G segments of consecutive indices and blockIdx.z = image * G + segment sums ITS segment's
+  // rois into its own copy of the map (gfeat + segment * seg_elems); roi_bwd_sum_segments adds the copies in segment order.  A hot tile's
+  // serial chain (hundreds of rois on the few tiles where the proposals cluster, the rest of the chip idle behind them) is cut G-fold.
+  const int tile = blockIdx.x, img = static_cast<int>(blockIdx.z) / G, seg = static_cast<int>(blockIdx.z) % G, c0 = blockIdx.y * kAccChan;
   const int tid = static_cast<int>(threadIdx.x);
   const int ty0 = (tile / tiles_x) * kTileY, tx0 = (tile % tiles_x) * kTileX;
-  const int* list = lists + (static_cast<long long>(img) * tiles_y * tiles_x + tile) * (R + 1);
+  const int* list = lists + ((static_cast<long long>(img) * G + seg) * tiles_y * tiles_x + tile) * (R + 1);
   const int n_list = list[0];
+  if (G > 1 && n_list == 0) return;               // this segment does not reach the tile: its copy is never read there (roi_bwd_sum_segments)
+  gfeat += static_cast<long long>(seg) * seg_elems;
   for (int i = tid; i < kTileY * kTileX * kAccStride; i += kBlock) s_acc[i] = 0.0f;
   const int cb = tid / (kTileY + kTileX), ca = tid % (kTileY + kTileX);
   const int cp = cpad(C);
-  const int lane_c = tid % kAccChan;              // this lane's channel of an item
-  const bool chan_ok = c0 + lane_c < C;
+  const int lane_c = V4 ? 4 * (tid % kLanesPerPix) : tid % kAccChan;     // this lane's (first) channel of an item
+  const bool chan_ok = V4 ? true : c0 + lane_c < C;   // (V4: channels past C are zeros of the staged block - they add nothing and are not written)
   const int bins = PH * PW, nf4 = bins * (kAccChan / 4);
   constexpr int kStageSlots = (kStageBins * (kAccChan / 4) + kBlock - 1) / kBlock;   // float4 per lane of a staged block (7)
   float4 stage[kStageSlots];
@@ -533,13 +546,58 @@ __global__ __launch_bounds__(kBlock) void roi_align_bwd_lds(const float* __restr
         const bool pow2 = (cnt & (cnt - 1)) == 0;
         const float* gbase = gcl + static_cast<long long>(r) * bins * cp + c0 + lane_c;
         const float* sbase = s_g + (k & 1) * bins * kAccChan + lane_c;
-        for (int p = tid / kAccChan; p < rows * cols; p += kBlock / kAccChan) {   // 256 / kAccChan pixels at a time
+        for (int p = tid / kLanesPerPix; p < rows * cols; p += kBlock / kLanesPerPix) {   // 256 / kLanesPerPix pixels at a time
           const int ly = y_lo + p / cols, lx = x_lo + p % cols;
           const AxisList& yl = s_list[k][ly];
           const AxisList& xl = s_list[k][kTileY + lx];
           const int ny = yl.n, nx = xl.n;
           if (ny == 0 || nx == 0 || !chan_ok) continue;
           float* slot = s_acc + (ly * kTileX + lx) * kAccStride + lane_c;
+          if constexpr (V4) {
+            v4f acc4 = *reinterpret_cast<v4f*>(slot);
+            if (ny > kListCap || nx > kListCap) {                         // more taps than the lists hold: classify per sample
+              float four[4] = {acc4.x, acc4.y, acc4.z, acc4.w};
+              roi_direct<4>(four, b, gcl, r, C, c0 + lane_c, H, W, PH, PW, ty0 + ly, tx0 + lx);
+              *reinterpret_cast<v4f*>(slot) = v4f{four[0], four[1], four[2], four[3]};
+              continue;
+            }
+            if (!(dbg & 4)) {
+              auto run4 = [&](auto pow2_c) {
+                constexpr bool kPow2 = decltype(pow2_c)::value;
+                int xb[kListCap];
+                float xw[kListCap];
+#pragma unroll
+                for (int i = 0; i < kListCap; ++i) {
+                  xb[i] = i < nx ? xl.bin[i] * kAccChan : 0;
+                  xw[i] = i < nx ? xl.w[i] : 0.0f;
+                }
+                for (int iy = 0; iy < ny; ++iy) {
+                  const float wy = yl.w[iy];
+                  const float* row = sbase + yl.bin[iy] * PW * kAccChan;
+#pragma unroll
+                  for (int i0 = 0; i0 < kListCap; i0 += 4) {
+                    if (i0 >= nx) break;
+                    v4f gv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) gv[u] = *reinterpret_cast<const v4f*>(row + xb[i0 + u]);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                      if (i0 + u < nx) {
+                        const float wgt = wy * xw[i0 + u];
+                        acc4.x = acc4.x + over_count(gv[u].x * wgt, count, inv, kPow2);
+                        acc4.y = acc4.y + over_count(gv[u].y * wgt, count, inv, kPow2);
+                        acc4.z = acc4.z + over_count(gv[u].z * wgt, count, inv, kPow2);
+                        acc4.w = acc4.w + over_count(gv[u].w * wgt, count, inv, kPow2);
+                      }
+                  }
+                }
+              };
+              if (pow2) run4(std::true_type{});
+              else run4(std::false_type{});
+            }
+            *reinterpret_cast<v4f*>(slot) = acc4;
+            continue;
+          }
           float acc = *slot;
           if (ny > kListCap || nx > kListCap) {                           // more taps than the lists hold: classify per sample
             float one[1] = {acc};
@@ -607,6 +665,22 @@ __global__ __launch_bounds__(kBlock) void roi_align_bwd_lds(const float* __restr
     for (int c = 0; c < kAccChan && c0 + c < C; ++c)
       gfeat[((static_cast<long long>(img) * C + c0 + c) * H + py) * W + px] = s_acc[tid * kAccStride + c];
   }
+}
+
+// gfeat[b,c,y,x] = P_0 + P_1 + ... + P_{G-1} in that order, P_s = segment s's copy where the segment reaches the pixel's tile (its list is
+// not empty) and an exact 0 elsewhere - which leaves a float32 sum unchanged, so the copies of empty (tile, segment) pairs are neither
+// written nor read.  One lane per element, x fastest.
+__global__ __launch_bounds__(kBlock) void roi_bwd_sum_segments(const float* __restrict__ parts, const int* __restrict__ lists, float* __restrict__ gfeat,
+                                                               int C, int H, int W, int R, int tiles_y, int tiles_x, int G, long long seg_elems) {
+  const long long i = static_cast<long long>(blockIdx.x) * kBlock + threadIdx.x;
+  if (i >= seg_elems) return;
+  const int x = static_cast<int>(i % W), y = static_cast<int>((i / W) % H);
+  const int img = static_cast<int>(i / (static_cast<long long>(W) * H * C));
+  const int tile = (y / kTileY) * tiles_x + x / kTileX;
+  float acc = 0.0f;
+  for (int s = 0; s < G; ++s)
+    if (lists[((static_cast<long long>(img) * G + s) * tiles_y * tiles_x + tile) * (R + 1)] > 0) acc = acc + parts[s * seg_elems + i];
+  gfeat[i] = acc;
 }
 
 // ---- NMS: wave64 suppression masks.  Block (row tile i, col tile j), 64 lanes: lane l owns box 64*i + l and
@@ -697,11 +771,22 @@ int adv_roi_align_fwd_f32(const float* feat, const float* rois, float* out, int 
   return finish();
 }
 
+// how many segments of consecutive roi indices the backward sums separately before adding them in segment order (1: one ordered sum).
+// A function of the roi count ALONE - part of the documented float32 order, restated by the oracle (roi_align_bwd_ordered(segments=)).
+int adv_roi_align_bwd_segments(int r) {
+  if (const char* v = adv_hook_value("ADV_ROI_SEGMENTS")) return std::max(1, std::min(8, std::atoi(v)));     // test-hook build only
+  // measured (profiles/r04_roi_bwd.jsonl): on 510 proposals the kernel is bound by its instruction count, not by a tile's serial chain -
+  // eight segments cost 0.25 ms more than one (the extra pass) and gained nothing; segments only where the lists get very long
+  return r <= 1024 ? 1 : std::min(8, (r + 511) / 512);
+}
+
 int64_t adv_roi_align_bwd_workspace_ints(int b, int c, int h, int w, int r, int ph, int pw) {
   if (b < 1 || c < 1 || h < 1 || w < 1 || r < 0 || ph < 1 || pw < 1) return 0;
   const long long tiles = static_cast<long long>((h + kTileY - 1) / kTileY) * ((w + kTileX - 1) / kTileX);
-  const long long lists = (static_cast<long long>(b) * tiles * (r + 1) + 3) & ~3LL;
-  return lists + static_cast<long long>(ph) * pw * r * cpad(c);            // + the channel-last copy of grad_out
+  const int g = adv_roi_align_bwd_segments(r);
+  const long long lists = (static_cast<long long>(b) * g * tiles * (r + 1) + 3) & ~3LL;
+  const long long gcl = (static_cast<long long>(ph) * pw * r * cpad(c) + 3) & ~3LL;            // the channel-last copy of grad_out
+  return lists + gcl + (g > 1 ? static_cast<long long>(g) * b * c * h * w : 0);                // + one copy of the map per segment
 }
 
 int adv_roi_align_bwd_f32(const float* grad_out, const float* rois, float* grad_feat, int b, int c, int h, int w, int r, int ph,
@@ -715,12 +800,18 @@ int adv_roi_align_bwd_f32(const float* grad_out, const float* rois, float* grad_
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int tiles_y = (h + kTileY - 1) / kTileY, tiles_x = (w + kTileX - 1) / kTileX;
   if (static_cast<long long>(ph) * pw > 1500) return ADV_EINVAL;      // the transposing kernel stages 32 x ph*pw floats in LDS
-  float* gcl = reinterpret_cast<float*>(workspace) + ((static_cast<long long>(b) * tiles_y * tiles_x * (r + 1) + 3) & ~3LL);
+  const int G = adv_hook("ADV_ROI_BWD_REGS") ? 1 : adv_roi_align_bwd_segments(r);
+  if (static_cast<long long>(b) * G > 65535) return ADV_EINVAL;
+  const int seg_len = (r + G - 1) / G;
+  const long long seg_elems = static_cast<long long>(b) * c * h * w;
+  float* gcl = reinterpret_cast<float*>(workspace) + ((static_cast<long long>(b) * G * tiles_y * tiles_x * (r + 1) + 3) & ~3LL);
+  float* parts = gcl + ((static_cast<long long>(ph) * pw * r * cpad(c) + 3) & ~3LL);
+  float* dest = G > 1 ? parts : grad_feat;
   if (r > 0)
     hipLaunchKernelGGL(roi_gout_channel_last, dim3(r, (c + 31) / 32), dim3(kBlock), sizeof(float) * 32 * (ph * pw + 1), st, grad_out, gcl, c, ph * pw);
   // every element of grad_feat is written by its owning lane (zeros where no roi reaches): no memset needed
-  hipLaunchKernelGGL(roi_tile_lists, dim3(tiles_y * tiles_x, b), dim3(64), 0, st, rois, r, h, w, tiles_y, tiles_x, ph, pw, spatial_scale,
-                     sampling_ratio, reinterpret_cast<int*>(workspace));
+  hipLaunchKernelGGL(roi_tile_lists, dim3(tiles_y * tiles_x, b * G), dim3(64), 0, st, rois, r, h, w, tiles_y, tiles_x, ph, pw, spatial_scale,
+                     sampling_ratio, reinterpret_cast<int*>(workspace), G, std::max(1, seg_len));
   // channels per lane: as many as still leave ~8 workgroups per compute unit (the small pyramid levels have 6-20 tiles)
   const long long tiles = static_cast<long long>(tiles_y) * tiles_x * b;
   const char* dbg_s = adv_hook_value("ADV_ROI_DBG");
@@ -731,23 +822,33 @@ int adv_roi_align_bwd_f32(const float* grad_out, const float* rois, float* grad_
     const char* ac_s = adv_hook_value("ADV_ROI_ACC_CHAN");
     const int ac = ac_s ? std::atoi(ac_s) : 16;      // 16 channels per workgroup: the fastest of 8 / 16 / 32 on the R101-shaped proposals (profiles/r03_roi_bwd.jsonl)
     const bool stage = ph * pw <= kStageBins && !adv_hook("ADV_ROI_BWD_NO_STAGE");
+    const bool scalar_items = adv_hook("ADV_ROI_BWD_SCALAR_ITEMS");      // test hook: round 3's one-channel items (same bits)
 #define ADV_LAUNCH_ROI_LDS(AC_)                                                                                                               \
   do {                                                                                                                                        \
-    const dim3 grid(tiles_y * tiles_x, (c + AC_ - 1) / AC_, b);                                                                               \
+    const dim3 grid(tiles_y * tiles_x, (c + AC_ - 1) / AC_, b * G);                                                                           \
     if (stage) {                                                                                                                              \
       const size_t dyn = 2 * sizeof(float) * static_cast<size_t>(ph) * pw * AC_;                                                              \
       if (!adv_internal_lds_limit<roi_align_bwd_lds<true, AC_>>(2 * sizeof(float) * kStageBins * AC_)) return ADV_ELAUNCH;                    \
-      hipLaunchKernelGGL((roi_align_bwd_lds<true, AC_>), grid, dim3(kBlock), dyn, st, gcl, rois, reinterpret_cast<const int*>(workspace),     \
-                         grad_feat, c, h, w, r, tiles_y, tiles_x, ph, pw, spatial_scale, sampling_ratio, dbg);                                \
+      if (!adv_internal_lds_limit<roi_align_bwd_lds<true, AC_, true>>(2 * sizeof(float) * kStageBins * AC_)) return ADV_ELAUNCH;              \
+      if (scalar_items)                                                                                                                     \
+        hipLaunchKernelGGL((roi_align_bwd_lds<true, AC_>), grid, dim3(kBlock), dyn, st, gcl, rois, reinterpret_cast<const int*>(workspace),   \
+                           dest, c, h, w, r, tiles_y, tiles_x, ph, pw, spatial_scale, sampling_ratio, dbg, G, seg_elems);                     \
+      else                                                                                                                                  \
+        hipLaunchKernelGGL((roi_align_bwd_lds<true, AC_, true>), grid, dim3(kBlock), dyn, st, gcl, rois,                                      \
+                           reinterpret_cast<const int*>(workspace), dest, c, h, w, r, tiles_y, tiles_x, ph, pw, spatial_scale,                \
+                           sampling_ratio, dbg, G, seg_elems);                                                                                \
     } else {                                                                                                                                  \
       hipLaunchKernelGGL((roi_align_bwd_lds<false, AC_>), grid, dim3(kBlock), 0, st, gcl, rois, reinterpret_cast<const int*>(workspace),      \
-                         grad_feat, c, h, w, r, tiles_y, tiles_x, ph, pw, spatial_scale, sampling_ratio, dbg);                                \
+                         dest, c, h, w, r, tiles_y, tiles_x, ph, pw, spatial_scale, sampling_ratio, dbg, G, seg_elems);                       \
     }                                                                                                                                         \
   } while (0)
     if (ac == 32) ADV_LAUNCH_ROI_LDS(32);
     else if (ac == 16) ADV_LAUNCH_ROI_LDS(16);
     else ADV_LAUNCH_ROI_LDS(8);
 #undef ADV_LAUNCH_ROI_LDS
+    if (G > 1)
+      hipLaunchKernelGGL(roi_bwd_sum_segments, dim3(static_cast<unsigned>((seg_elems + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, parts,
+                         reinterpret_cast<const int*>(workspace), grad_feat, c, h, w, r, tiles_y, tiles_x, G, seg_elems);
     return finish();
   }
   int cb = kChanBlock;

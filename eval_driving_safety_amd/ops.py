@@ -540,6 +540,11 @@ def roi_align(feat, rois, pooled, spatial_scale, sampling_ratio=0):
     return out
 
 
+def roi_align_bwd_segments(n_rois):
+    """into how many segments of consecutive roi indices ``roi_align_bwd`` splits its ordered sum (1 up to 64 rois; include/advengine.h)"""
+    return int(_lib.load().adv_roi_align_bwd_segments(int(n_rois)))
+
+
 def roi_align_bwd(grad_out, rois, feat_shape, spatial_scale, sampling_ratio=0):
     """adjoint of ``roi_align`` w.r.t. the features, summed in a fixed order (bit-reproducible; no atomics)"""
     g, r = _feat(grad_out, "grad_out"), _feat(rois, "rois")
@@ -1118,6 +1123,24 @@ def bias_act_(y, bias=None, residual=None, relu=False):
         _lib.call("adv_bias_act_f32", _ptr(yi), None if bias is None else _ptr(bias), _like(residual, yi, "residual"), b * c, c, hw, int(bool(relu)),
                   _stream(yi))
     return yi
+
+
+class BiasAct(torch.autograd.Function):
+    """``[relu](y + bias[c])`` in place as ONE pass behind a convolution torch computed (adopt.py's layers without a kernel here), with the
+    backward autograd cannot derive from a raw kernel call: the incoming gradient masked with (result > 0) when the ReLU is fused"""
+
+    @staticmethod
+    def forward(ctx, y, bias=None, relu=False):
+        out = bias_act_(y, bias, None, relu)
+        ctx.mark_dirty(y)
+        ctx.relu = bool(relu)
+        ctx.save_for_backward(out if relu else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        (out,) = ctx.saved_tensors
+        return (relu_backward(grad.contiguous(), out) if ctx.relu else grad), None, None
 
 
 # direct-convolution FLOPs (2 x MACs) of the calls that took a Winograd route since the last reset: such a call EXECUTES 2.25x fewer

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ADV_ABI_VERSION 6
+#define ADV_ABI_VERSION 7
 #define ADV_API __attribute__((visibility("default"))) /* the library is built with -fvisibility=hidden */
 #define ADV_CHANNELS 3
 
@@ -262,11 +262,17 @@ ADV_API int adv_roi_align_fwd_f32(const float* feat, const float* rois, float* o
 /* RoIAlign backward, deterministic: every element of grad_feat [B,C,H,W] is written (no memset needed) as the float32 sum,
  *     in ONE fixed order - roi index, sample row, sample column, tap 1..4 - of the contributions
  *     grad_out[r,c,ph,pw] * weight / count of the samples whose bilinear taps touch it.  No float atomics: two runs give
- *     the same bits, and the result equals the oracle's ordered sum bit for bit.  workspace: DEVICE,
+ *     the same bits, and the result equals the oracle's ordered sum bit for bit.
+ *     With more than 1024 rois the roi indices are split into G = adv_roi_align_bwd_segments(r) = min(8, ceil(r / 512)) segments of
+ *     ceil(r / G) consecutive indices; each segment is summed in the order above into its own copy of the map (in the workspace) and the
+ *     copies are added in segment order: grad_feat = ((P_0 + P_1) + ...) + P_{G-1}.  The segments run in parallel, which cuts the serial
+ *     chain of the tiles where the proposals cluster G-fold; the order is a function of r alone (the oracle takes G as a parameter).
+ *     workspace: DEVICE,
  *     adv_roi_align_bwd_workspace_ints(b, c, h, w, r, ph, pw) 4-byte elements (per 8 x 32-pixel tile the ascending list of rois that
- *     reach it; a channel-last copy of grad_out, whose 32 channels of one bin are one coalesced load), starting on a 16-BYTE boundary
+ *     reach it; a channel-last copy of grad_out, whose 32 channels of one bin are one coalesced load; for G > 1 the G copies of the map), starting on a 16-BYTE boundary
  *     (the copy is read with 16-byte loads; ADV_EALIGN otherwise).  ph * pw <= 1500 (the transposing pass stages 32 x ph*pw floats in
  *     LDS; ADV_EINVAL beyond - the reference's pooled grids are 7 x 7 and 14 x 14). */
+ADV_API int adv_roi_align_bwd_segments(int r);
 ADV_API int64_t adv_roi_align_bwd_workspace_ints(int b, int c, int h, int w, int r, int ph, int pw);
 ADV_API int adv_roi_align_bwd_f32(const float* grad_out, const float* rois, float* grad_feat, int b, int c, int h, int w,
                           int r, int ph, int pw, float spatial_scale, int sampling_ratio, int32_t* workspace,

@@ -447,10 +447,21 @@ def roi_align_bwd(grad_out, rois, feat_shape, spatial_scale, sampling_ratio=0):
     return gf.astype(np.float32)
 
 
-def roi_align_bwd_ordered(grad_out, rois, feat_shape, spatial_scale, sampling_ratio=0):
+def roi_align_bwd_ordered(grad_out, rois, feat_shape, spatial_scale, sampling_ratio=0, segments=1):
     """The backward as csrc/roi.hip's gather kernel sums it: float32, contributions added per feature element in the order
-    roi index, sample row (ph, iy), sample column (pw, ix), tap 1..4 - each contribution rounded as (g * w) / count."""
+    roi index, sample row (ph, iy), sample column (pw, ix), tap 1..4 - each contribution rounded as (g * w) / count.
+    ``segments`` = G > 1 (the kernel's rule for more than 1024 rois, include/advengine.h: G = min(8, ceil(R / 512))): the roi indices are cut
+    into G runs of ceil(R / G) consecutive indices, each run summed as above into its own map, the maps added in run order."""
     g, rois = _f32(grad_out), _f32(rois)
+    if segments > 1:
+        n = len(rois)
+        step = (n + segments - 1) // segments
+        total = np.zeros(feat_shape, np.float32)
+        for s in range(segments):
+            lo, hi = s * step, min(n, (s + 1) * step)
+            if lo < hi:
+                total = total + roi_align_bwd_ordered(g[lo:hi], rois[lo:hi], feat_shape, spatial_scale, sampling_ratio)
+        return total
     b, c, h, w = feat_shape
     ph, pw = g.shape[2:]
     gf = np.zeros((b, c, h, w), np.float32)

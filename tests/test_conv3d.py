@@ -226,7 +226,7 @@ def test_oracle_strided_and_transposed_conv_match_torch():
     assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs))
 
 
-HG_SHAPES = [(1, 8, 12, 5, 6, 7), (2, 16, 32, 4, 8, 32), (1, 8, 33, 3, 9, 40), (1, 32, 64, 6, 16, 44)]
+HG_SHAPES = [(1, 8, 12, 5, 6, 7), (2, 16, 32, 4, 8, 32), (1, 8, 33, 3, 9, 40), (1, 32, 64, 6, 16, 44), (1, 16, 32, 7, 5, 36), (1, 8, 40, 6, 10, 40)]
 
 
 @pytest.mark.gpu
@@ -317,7 +317,8 @@ def test_hip_residual_epilogue_equals_conv_then_add_then_relu(shape, route):
         w_t = (rs.randn(cin, cout, 3, 3, 3) * 0.1).astype(np.float32)
         classes = ops.conv_transpose3d_k3_s2_prep(torch.tensor(w_t, device=dev))
         skip2 = torch.tensor(rs.randn(b, cout, 2 * d, 2 * h, 2 * w).astype(np.float32), device=dev)
-        for env in ({}, {"ADV_CONV_T_CLASS_TILES": "1"}, {"ADV_CONV_CLASS_LAUNCHES": "1"}):
+        # (<round 4> ADV_CONV_T_TD: the all-classes kernel's tile as 1 x 4, 2 x 2 or 4 x 1 input planes x rows - the host picks by padding)
+        for env in ({}, {"ADV_CONV_T_CLASS_TILES": "1"}, {"ADV_CONV_CLASS_LAUNCHES": "1"}, {"ADV_CONV_T_TD": "1"}, {"ADV_CONV_T_TD": "2"}, {"ADV_CONV_T_TD": "4"}):
             with (route(**env) if env else contextlib.nullcontext()):
                 got = ops.conv_transpose3d_k3_s2(tx, classes, cout, bias=tb, relu=True, residual=skip2)
                 want_t = np.maximum(C.conv_transpose3d_k3_s2(x, w_t, bias=bias) + skip2.cpu().numpy(), np.float32(0))
@@ -390,7 +391,8 @@ def test_hip_conv3d_batch_beyond_2_31_elements_equals_per_item_launches():
         assert torch.equal(down[i:i + 1], ops.conv3d_k3_s2(x[i:i + 1], wpd, 64, relu=True)), i
 
 
-S2_DIRECT = [(1, 8, 33, 3, 9, 40), (2, 8, 32, 5, 19, 36), (1, 16, 5, 4, 8, 72), (1, 4, 24, 3, 3, 4), (2, 12, 64, 5, 7, 36), (1, 32, 64, 6, 16, 44), (1, 4, 96, 4, 10, 132), (1, 12, 40, 1, 1, 4), (1, 16, 72, 7, 33, 64)]
+S2_DIRECT = [(1, 8, 33, 3, 9, 40), (2, 8, 32, 5, 19, 36), (1, 16, 5, 4, 8, 72), (1, 4, 24, 3, 3, 4), (2, 12, 64, 5, 7, 36), (1, 32, 64, 6, 16, 44), (1, 4, 96, 4, 10, 132), (1, 12, 40, 1, 1, 4), (1, 16, 72, 7, 33, 64),
+             (1, 8, 64, 13, 10, 40), (1, 8, 40, 9, 20, 36)]     # flat volumes: 5 and 10 output rows (the 4 x 1 and 2 x 2 tile shapes by themselves)
 
 
 @pytest.mark.gpu
@@ -422,6 +424,13 @@ def test_hip_direct_strided_kernel_bit_exact_vs_oracle(shape, route):
         for pd in ("1", "2"):
             with route(ADV_CONV_S2_PD=pd):
                 assert torch.equal(ops.conv3d_k3_s2(tx, wp, cout, bias=tb, relu=True), got), "planes per workgroup: " + pd
+        # <round 4> the tile's four waves over 1, 2 or 4 output planes (1 x 4, 2 x 2, 4 x 1 planes x rows; the host picks the shape
+        # that pads the volume least), alone and with two planes per wave: the same bits
+        for wd in ("1", "2", "4"):
+            for pd in ("1", "2"):
+                with route(ADV_CONV_S2_WD=wd, ADV_CONV_S2_PD=pd):
+                    assert torch.equal(ops.conv3d_k3_s2(tx, wp, cout, bias=tb, relu=True), got), "tile %s planes x %d rows, %s planes per wave" % (wd, 4 // int(wd), pd)
+                    assert torch.equal(ops._conv3d_ex(tx, wp, cout, 2, True, tb, residual=skip), F.relu(ops.conv3d_k3_s2(tx, wp, cout, bias=tb) + skip))
     with route(ADV_CONV_S2_GENERIC="1"):
         assert ops.conv3d_k3_s2_stage_channels(tx, cout) == 4
         slow = ops.conv3d_k3_s2(tx, wp, cout, bias=tb, relu=True)

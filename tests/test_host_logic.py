@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "libadvengine.so lacks %s" % name
     assert sorted(_lib.EXPORTED) == declared, "ctypes binding and header disagree"
-    assert lib.adv_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.adv_abi_version() == _lib.ABI_VERSION == 7
     assert lib.adv_strerror(-22) == b"invalid argument"
 
 

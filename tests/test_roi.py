@@ -56,6 +56,7 @@ def test_oracle_nms_small_cases():
     dict(b=1, c=6, h=30, w=41, n=11, pooled=4, scale=1 / 16.0, sr=3),         # a grid the register kernel is not built for
     dict(b=2, c=9, h=19, w=40, n=150, pooled=3, scale=1 / 16.0, sr=2),        # many rois on few tiles: long per-tile lists
     dict(b=1, c=3, h=10, w=33, n=65, pooled=2, scale=1 / 8.0, sr=0),          # lists longer than one batch
+    dict(b=2, c=12, h=38, w=125, n=520, pooled=7, scale=1 / 16.0, sr=0),      # many rois, two images
 ])
 def test_hip_roi_align(cfg, route):
     from eval_driving_safety_amd import ops
@@ -75,17 +76,30 @@ def test_hip_roi_align(cfg, route):
     np.testing.assert_allclose(gf.cpu().numpy(), wf, rtol=2e-5, atol=2e-5)
     # deterministic gather: the float32 sum in the fixed order (roi, sample row, sample column, tap) - bit for bit,
     # and the same bits on a second run (the scatter-with-atomics formulation gives neither)
-    assert gf.cpu().numpy().tobytes() == O.roi_align_bwd_ordered(g, rois, feat.shape, cfg["scale"], cfg["sr"]).tobytes(), "backward not bit-exact"
+    # (more than 64 rois: G = ops.roi_align_bwd_segments(n) runs of consecutive roi indices summed separately, then added in run order)
+    G = ops.roi_align_bwd_segments(cfg["n"])
+    assert G == (1 if cfg["n"] <= 1024 else min(8, (cfg["n"] + 511) // 512)) and ops.roi_align_bwd_segments(1025) == 3
+    assert gf.cpu().numpy().tobytes() == O.roi_align_bwd_ordered(g, rois, feat.shape, cfg["scale"], cfg["sr"], segments=G).tobytes(), "backward not bit-exact"
     again = ops.roi_align_bwd(torch.tensor(g, device=dev), tr, feat.shape, cfg["scale"], cfg["sr"])
     assert torch.equal(gf, again)
+    one = gf
+    if G > 1:                                          # the single ordered sum of the same rois (test hook), for the register routes below
+        with route(ADV_ROI_SEGMENTS="1"):
+            one = ops.roi_align_bwd(torch.tensor(g, device=dev), tr, feat.shape, cfg["scale"], cfg["sr"])
+        assert one.cpu().numpy().tobytes() == O.roi_align_bwd_ordered(g, rois, feat.shape, cfg["scale"], cfg["sr"]).tobytes()
+    with route(ADV_ROI_SEGMENTS="3"):                  # ... and three segments whatever the count: empty (tile, segment) pairs are skipped exactly
+        three = ops.roi_align_bwd(torch.tensor(g, device=dev), tr, feat.shape, cfg["scale"], cfg["sr"])
+    assert three.cpu().numpy().tobytes() == O.roi_align_bwd_ordered(g, rois, feat.shape, cfg["scale"], cfg["sr"], segments=3).tobytes()
     # the register formulation (a lane owns a pixel; the shipped route keeps the accumulators in LDS and hands the lanes work items), with
     # the map-size-dependent and with eight channels per lane: the same bits
+    with route(ADV_ROI_BWD_SCALAR_ITEMS="1"):          # one channel per work item (round 3) instead of four: the same bits
+        assert torch.equal(ops.roi_align_bwd(torch.tensor(g, device=dev), tr, feat.shape, cfg["scale"], cfg["sr"]), gf)
     with route(ADV_ROI_BWD_NO_STAGE="1"):              # grad_out gathered from global memory instead of the LDS-staged block
         assert torch.equal(ops.roi_align_bwd(torch.tensor(g, device=dev), tr, feat.shape, cfg["scale"], cfg["sr"]), gf)
-    with route(ADV_ROI_BWD_REGS="1"):
-        assert torch.equal(ops.roi_align_bwd(torch.tensor(g, device=dev), tr, feat.shape, cfg["scale"], cfg["sr"]), gf)
+    with route(ADV_ROI_BWD_REGS="1"):                  # (always one segment)
+        assert torch.equal(ops.roi_align_bwd(torch.tensor(g, device=dev), tr, feat.shape, cfg["scale"], cfg["sr"]), one)
     with route(ADV_ROI_BWD_REGS="1", ADV_ROI_BWD_CB8="1"):
-        assert torch.equal(ops.roi_align_bwd(torch.tensor(g, device=dev), tr, feat.shape, cfg["scale"], cfg["sr"]), gf)
+        assert torch.equal(ops.roi_align_bwd(torch.tensor(g, device=dev), tr, feat.shape, cfg["scale"], cfg["sr"]), one)
     # autograd wrapper
     tf2 = tf.clone().requires_grad_(True)
     o2 = ops.RoIAlign.apply(tf2, tr, cfg["pooled"], cfg["scale"], cfg["sr"])

@@ -165,7 +165,7 @@ def roi_case(rs, dev):
     tf, tr = torch.tensor(feat, device=dev), torch.tensor(rois, device=dev)
     same(ops.roi_align(tf, tr, pooled, scale, sr), O.roi_align(feat, rois, pooled, scale, sr), "roi_align %s" % ((b, c, h, w, n, pooled, scale, sr),))
     g = rs.randn(n, c, *pooled).astype(np.float32)
-    same(ops.roi_align_bwd(torch.tensor(g, device=dev), tr, feat.shape, scale, sr), O.roi_align_bwd_ordered(g, rois, feat.shape, scale, sr),
+    same(ops.roi_align_bwd(torch.tensor(g, device=dev), tr, feat.shape, scale, sr), O.roi_align_bwd_ordered(g, rois, feat.shape, scale, sr, segments=ops.roi_align_bwd_segments(len(rois))),
          "roi_align bwd %s" % ((b, c, h, w, n, pooled, scale, sr),))
 
 
