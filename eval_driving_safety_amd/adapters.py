@@ -752,8 +752,13 @@ class DsgnShapedAdapter(PsvStereoAdapter):
 
     def _ct2(self, x, name, relu=False, residual=None):
         w, b = self.wt2[name]
-        y = F.conv_transpose2d(x, w, b, stride=2, padding=1, output_padding=1)
         self.flops_fwd += 2 * x.numel() * w.shape[1] * 9
+        if not self.torch_ops and x.is_cuda:
+            # the transposed convolution is MIOpen's; bias + skip connection + ReLU are ONE pass behind it (ops.BiasAct) instead of
+            # torch's add / add / relu and, in the backward, threshold + add: same float operations in the same order
+            y = F.conv_transpose2d(x, w, None, stride=2, padding=1, output_padding=1)
+            return self.ops.BiasAct.apply(y, b, relu, residual)
+        y = F.conv_transpose2d(x, w, b, stride=2, padding=1, output_padding=1)
         if residual is not None:
             y = y + residual
         return F.relu(y) if relu else y
@@ -865,7 +870,10 @@ class DsgnShapedAdapter(PsvStereoAdapter):
         post = self._c3(h, "gh5", True, pre)
         g = self._c3(post, "gh6", True, g1)
         bb, c, zg, yg, xg = g.shape
-        bev = F.avg_pool3d(g, (1, self.ypool, 1)).permute(0, 1, 3, 2, 4).reshape(bb, c * (yg // self.ypool), zg, xg)
+        if self.torch_ops or not g.is_cuda:
+            bev = F.avg_pool3d(g, (1, self.ypool, 1)).permute(0, 1, 3, 2, 4).reshape(bb, c * (yg // self.ypool), zg, xg)
+        else:       # the same values, one pass each way
+            bev = ops.BevFold.apply(g, self.ypool)
         b0 = self._c2(bev, "bev_a", True)
         pre2 = self._c2(self._c2(b0, "bh1", True), "bh2", True)
         h2 = self._c2(self._c2(pre2, "bh3", True), "bh4", True)

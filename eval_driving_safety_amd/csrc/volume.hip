@@ -537,6 +537,42 @@ inline bool aligned4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3
 
 }  // namespace
 
+// ---- bird's-eye-view fold: the 3D geometric volume [B,C,Z,Y,X] -> the 2D head's input [B, C * Y/P, Z, X]: the height is average-pooled by P
+// and what remains of it folded into the channels (DSGN: F.avg_pool3d(v, (1, P, 1)) -> permute(0, 1, 3, 2, 4) -> reshape).  torch makes
+// that a pooling kernel plus a permuting copy (and two more passes backward); it is one HBM-bound pass each way.  out[b, c*Yp + yy, z, x]
+// = ((v[.., P*yy, x] + v[.., P*yy + 1, x]) + ...) / P in that order; rows past Yp * P (floor, as avg_pool3d) are dropped.
+__global__ __launch_bounds__(kBlock) void bev_fold_fwd(const float* __restrict__ v, float* __restrict__ out, int C, int Z, int Y, int X, int P, int Yp,
+                                                       long long total) {
+  for (long long i = static_cast<long long>(blockIdx.x) * kBlock + threadIdx.x; i < total; i += static_cast<long long>(gridDim.x) * kBlock) {
+    const int x = static_cast<int>(i % X);
+    long long r = i / X;
+    const int z = static_cast<int>(r % Z);
+    r /= Z;
+    const int yy = static_cast<int>(r % Yp);
+    r /= Yp;                                          // r = b * C + c
+    const float* src = v + ((r * Z + z) * Y + static_cast<long long>(P) * yy) * X + x;
+    float acc = __builtin_nontemporal_load(src);
+    for (int k = 1; k < P; ++k) acc = acc + __builtin_nontemporal_load(src + static_cast<long long>(k) * X);
+    out[i] = acc / static_cast<float>(P);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void bev_fold_bwd(const float* __restrict__ gout, float* __restrict__ gv, int C, int Z, int Y, int X, int P, int Yp,
+                                                       long long total) {
+  for (long long i = static_cast<long long>(blockIdx.x) * kBlock + threadIdx.x; i < total; i += static_cast<long long>(gridDim.x) * kBlock) {
+    const int x = static_cast<int>(i % X);
+    long long r = i / X;
+    const int y = static_cast<int>(r % Y);
+    r /= Y;
+    const int z = static_cast<int>(r % Z);
+    r /= Z;                                           // r = b * C + c
+    const int yy = y / P;
+    float g = 0.0f;
+    if (yy < Yp) g = gout[((r * Yp + yy) * Z + z) * X + x] / static_cast<float>(P);
+    __builtin_nontemporal_store(g, gv + i);
+  }
+}
+
 extern "C" {
 
 int adv_depth_regress_f32(const float* cost, const float* depth_values, float* depth_out, float* stats_out, int b, int d, int h, int w,
@@ -648,6 +684,28 @@ int adv_grid_sample3d_bwd_ws_f32(const float* grad_out, const void* plan, float*
   hipLaunchKernelGGL(gs_to_channels_last, dim3(static_cast<unsigned>((ovol + 63) / 64), cg, b), dim3(kBlock), 0, st, grad_out, workspace, c, ovol);
   hipLaunchKernelGGL(grid_sample3d_bwd_cl, dim3(static_cast<unsigned>((ivol + kClCells - 1) / kClCells), cg, b), dim3(kBlock), 0, st, workspace, pv,
                      grad_vol, c, ivol, ovol);
+  return adv_internal_finish_launch();
+}
+
+int adv_bev_fold_f32(const float* v, float* out, int b, int c, int z, int y, int x, int pool, adv_stream_t stream) {
+  if (!v || !out || v == out || b < 1 || c < 1 || z < 1 || y < 1 || x < 1 || pool < 1 || pool > y) return ADV_EINVAL;
+  if (!aligned4(v) || !aligned4(out)) return ADV_EALIGN;
+  const int yp = y / pool;
+  const long long total = static_cast<long long>(b) * c * yp * z * x;
+  long long blocks = (total + kBlock - 1) / kBlock;
+  if (blocks > 65535LL * 16) blocks = 65535LL * 16;
+  hipLaunchKernelGGL(bev_fold_fwd, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), v, out, c, z, y, x, pool, yp, total);
+  return adv_internal_finish_launch();
+}
+
+int adv_bev_fold_bwd_f32(const float* grad_out, float* grad_v, int b, int c, int z, int y, int x, int pool, adv_stream_t stream) {
+  if (!grad_out || !grad_v || grad_out == grad_v || b < 1 || c < 1 || z < 1 || y < 1 || x < 1 || pool < 1 || pool > y) return ADV_EINVAL;
+  if (!aligned4(grad_out) || !aligned4(grad_v)) return ADV_EALIGN;
+  const long long total = static_cast<long long>(b) * c * z * y * x;
+  long long blocks = (total + kBlock - 1) / kBlock;
+  if (blocks > 65535LL * 16) blocks = 65535LL * 16;
+  hipLaunchKernelGGL(bev_fold_bwd, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), grad_out, grad_v, c, z, y, x, pool,
+                     y / pool, total);
   return adv_internal_finish_launch();
 }
 

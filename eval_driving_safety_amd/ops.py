@@ -1126,21 +1126,23 @@ def bias_act_(y, bias=None, residual=None, relu=False):
 
 
 class BiasAct(torch.autograd.Function):
-    """``[relu](y + bias[c])`` in place as ONE pass behind a convolution torch computed (adopt.py's layers without a kernel here), with the
-    backward autograd cannot derive from a raw kernel call: the incoming gradient masked with (result > 0) when the ReLU is fused"""
+    """``[relu](y + bias[c] + residual)`` in place as ONE pass behind a convolution torch computed (adopt.py's layers without a kernel here,
+    the bird's-eye view's transposed 2D layers), with the backward autograd cannot derive from a raw kernel call: the incoming gradient
+    masked with (result > 0) when the ReLU is fused; the residual (a skip connection) receives that masked gradient as it is"""
 
     @staticmethod
-    def forward(ctx, y, bias=None, relu=False):
-        out = bias_act_(y, bias, None, relu)
+    def forward(ctx, y, bias=None, relu=False, residual=None):
+        out = bias_act_(y, bias, None if residual is None else residual.contiguous(), relu)
         ctx.mark_dirty(y)
-        ctx.relu = bool(relu)
+        ctx.relu, ctx.has_res = bool(relu), residual is not None
         ctx.save_for_backward(out if relu else None)
         return out
 
     @staticmethod
     def backward(ctx, grad):
         (out,) = ctx.saved_tensors
-        return (relu_backward(grad.contiguous(), out) if ctx.relu else grad), None, None
+        g = relu_backward(grad.contiguous(), out) if ctx.relu else grad
+        return g, None, None, (g if ctx.has_res else None)
 
 
 # direct-convolution FLOPs (2 x MACs) of the calls that took a Winograd route since the last reset: such a call EXECUTES 2.25x fewer
@@ -1466,6 +1468,43 @@ class GridSample3d(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         return grid_sample3d_bwd(grad_out.contiguous(), ctx.plan), None, None
+
+
+def bev_fold(v, pool):
+    """[B,C,Z,Y,X] -> [B, C * (Y // pool), Z, X]: F.avg_pool3d(v, (1, pool, 1)).permute(0, 1, 3, 2, 4).reshape(...) in one pass"""
+    vi = _feat(v, "v")
+    if vi.dim() != 5 or pool < 1 or pool > vi.shape[3]:
+        raise ValueError("v must be [B,C,Z,Y,X] with Y >= pool")
+    b, c, z, y, x = vi.shape
+    out = torch.empty((b, c * (y // pool), z, x), dtype=torch.float32, device=vi.device)
+    with _on(vi):
+        _lib.call("adv_bev_fold_f32", _ptr(vi), _ptr(out), b, c, z, y, x, int(pool), _stream(vi))
+    return out
+
+
+def bev_fold_bwd(grad_out, shape, pool):
+    g = _feat(grad_out, "grad_out")
+    b, c, z, y, x = shape
+    if tuple(g.shape) != (b, c * (y // pool), z, x):
+        raise ValueError("grad_out must be [B, C * (Y // pool), Z, X]")
+    gv = torch.empty(tuple(shape), dtype=torch.float32, device=g.device)
+    with _on(g):
+        _lib.call("adv_bev_fold_bwd_f32", _ptr(g), _ptr(gv), b, c, z, y, x, int(pool), _stream(g))
+    return gv
+
+
+class BevFold(torch.autograd.Function):
+    """the bird's-eye-view fold of the 3D geometric volume (height pooled by ``pool`` and folded into the channels), forward and backward
+    one HBM-bound pass each (csrc/volume.hip) instead of torch's pooling kernel + permuting copy and their two backward passes"""
+
+    @staticmethod
+    def forward(ctx, v, pool):
+        ctx.shape, ctx.pool = tuple(v.shape), int(pool)
+        return bev_fold(v.contiguous(), pool)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        return bev_fold_bwd(grad_out.contiguous(), ctx.shape, ctx.pool), None
 
 
 def sigmoid_focal_loss(logits, targets, gamma=2.0, alpha=0.25, want_grad=False):

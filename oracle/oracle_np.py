@@ -512,6 +512,33 @@ def nms(boxes, thresh):
 # maskrcnn-benchmark code (reached at attack/DSGN/pgd_attack.py:308,324), NOT in the reference tree: these restate the
 # KERNELS' arithmetic in float32 and are themselves checked against torch's F.interpolate/softmax, F.grid_sample and an
 # autograd formulation of the focal loss in tests/test_volume.py (CPU).
+def bev_fold(v, pool):
+    """csrc/volume.hip bev_fold_fwd: [B,C,Z,Y,X] -> [B, C * (Y // pool), Z, X], the float32 sum over ``pool`` consecutive rows in ascending
+    order divided by pool - the values of F.avg_pool3d(v, (1, pool, 1)).permute(0, 1, 3, 2, 4).reshape(...)"""
+    v = _f32(v)
+    b, c, z, y, x = v.shape
+    yp = y // pool
+    out = np.empty((b, c, yp, z, x), np.float32)
+    for yy in range(yp):
+        acc = v[:, :, :, pool * yy, :].copy()
+        for k in range(1, pool):
+            acc = acc + v[:, :, :, pool * yy + k, :]
+        out[:, :, yy] = acc / F32(pool)
+    return out.reshape(b, c * yp, z, x)
+
+
+def bev_fold_bwd(grad_out, shape, pool):
+    g = _f32(grad_out)
+    b, c, z, y, x = shape
+    yp = y // pool
+    gv = np.zeros(shape, np.float32)
+    gg = g.reshape(b, c, yp, z, x) / F32(pool)
+    for yy in range(yp):
+        for k in range(pool):
+            gv[:, :, :, pool * yy + k, :] = gg[:, :, yy]
+    return gv
+
+
 def _lin_scale(n_in, n_out, align):
     if align:
         return np.float32(n_in - 1) / np.float32(n_out - 1) if n_out > 1 else np.float32(0)

@@ -200,3 +200,41 @@ def test_hip_relu_backward(n):
     assert torch.equal(ops.relu_backward(g, y), want)
     if n > 8:                                    # a view that is only 4-byte aligned takes the scalar path
         assert torch.equal(ops.relu_backward(g[1:], y[1:].contiguous()), want[1:])
+
+
+BEV_CASES = [dict(shape=(1, 3, 5, 8, 7), pool=4), dict(shape=(2, 4, 6, 20, 12), pool=4), dict(shape=(1, 2, 3, 7, 9), pool=3), dict(shape=(1, 5, 4, 6, 33), pool=1)]
+
+
+@pytest.mark.parametrize("cfg", BEV_CASES)
+def test_oracle_bev_fold_equals_torch(cfg):
+    """the bird's-eye-view fold is F.avg_pool3d(v, (1, P, 1)) -> permute(0, 1, 3, 2, 4) -> reshape: the same VALUES (a sum of P floats in
+    ascending order, divided by P), and its backward is autograd's"""
+    rs = np.random.RandomState(sum(cfg["shape"]))
+    v = rs.randn(*cfg["shape"]).astype(np.float32)
+    p = cfg["pool"]
+    b, c, z, y, x = cfg["shape"]
+    t = torch.tensor(v, requires_grad=True)
+    ref = F.avg_pool3d(t, (1, p, 1)).permute(0, 1, 3, 2, 4).reshape(b, c * (y // p), z, x)
+    got = O.bev_fold(v, p)
+    assert got.shape == tuple(ref.shape) and np.allclose(got, ref.detach().numpy(), rtol=1e-6, atol=1e-7)
+    g = rs.randn(*got.shape).astype(np.float32)
+    ref.backward(torch.tensor(g))
+    assert np.allclose(O.bev_fold_bwd(g, cfg["shape"], p), t.grad.numpy(), rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", BEV_CASES + [dict(shape=(1, 16, 24, 20, 76), pool=4)])
+def test_hip_bev_fold_fwd_bwd_bit_exact(cfg):
+    from eval_driving_safety_amd import ops
+    dev = torch.device("cuda", 0)
+    rs = np.random.RandomState(sum(cfg["shape"]) + 1)
+    v = rs.randn(*cfg["shape"]).astype(np.float32)
+    p = cfg["pool"]
+    tv = torch.tensor(v, device=dev, requires_grad=True)
+    out = ops.BevFold.apply(tv, p)
+    assert out.detach().cpu().numpy().tobytes() == O.bev_fold(v, p).tobytes()
+    g = rs.randn(*out.shape).astype(np.float32)
+    out.backward(torch.tensor(g, device=dev))
+    assert tv.grad.cpu().numpy().tobytes() == O.bev_fold_bwd(g, cfg["shape"], p).tobytes()
+    with pytest.raises(ValueError):
+        ops.bev_fold(tv.detach(), v.shape[3] + 1)
