@@ -91,6 +91,7 @@ SIGNATURES = {
     "adv_conv3d_k3_s2_stage_channels": [_P, _I, _I],
     "adv_conv3d_k3_ex_f32": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32), _I, _I3, _I3, _I3, _P],
     "adv_conv_transpose3d_k3_s2_f32": [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint32), _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "adv_conv_transpose3d_k3_s2_dgrad_f32": [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint32), _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "adv_space_to_depth2_f32": [_P, _P, _I, _I, _I, _I, _I, _P],
     "adv_depth_regress_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "adv_depth_regress_bwd_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],

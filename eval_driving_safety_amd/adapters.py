@@ -754,22 +754,24 @@ class DsgnShapedAdapter(PsvStereoAdapter):
         w, b = self.wt2[name]
         self.flops_fwd += 2 * x.numel() * w.shape[1] * 9
         if not self.torch_ops and x.is_cuda:
-            # the transposed convolution is MIOpen's; bias + skip connection + ReLU are ONE pass behind it (ops.BiasAct) instead of
-            # torch's add / add / relu and, in the backward, threshold + add: same float operations in the same order
-            y = F.conv_transpose2d(x, w, None, stride=2, padding=1, output_padding=1)
-            return self.ops.BiasAct.apply(y, b, relu, residual)
+            # the transposed convolution (with its bias) is MIOpen's; skip connection + ReLU are ONE pass behind it (ops.BiasAct) instead
+            # of torch's add / relu and, in the backward, threshold + add: same float operations in the same order
+            y = F.conv_transpose2d(x, w, b, stride=2, padding=1, output_padding=1)
+            return self.ops.BiasAct.apply(y, None, relu, residual) if (relu or residual is not None) else y
         y = F.conv_transpose2d(x, w, b, stride=2, padding=1, output_padding=1)
         if residual is not None:
             y = y + residual
         return F.relu(y) if relu else y
 
-    def _c3(self, x, name, relu=False, residual=None, chain_in=False):
+    def _c3(self, x, name, relu=False, residual=None, chain_in=False, skip_out=False):
         """``relu="consumer"`` / ``chain_in``: as _c2 - a ReLU layer whose only consumer is a stride-1 layer leaves its backward mask to that
-        consumer's dgrad epilogue (ops.Conv3dK3 mask_input); only on the libadvengine path"""
+        consumer's dgrad epilogue (ops.Conv3dK3 mask_input); only on the libadvengine path.  <round 4> stride-2 layers take both too, and
+        ``skip_out``: -> (y, x_skip) - see ops.Conv3dK3S2"""
         e, ops = self.w3[name], self.ops
         kind, w, b, cout = e["kind"], e["w"], e["b"], e["cout"]
         if not self.mfma_conv:
-            assert not chain_in and relu != "consumer"
+            assert not chain_in and relu != "consumer" and not skip_out
+        assert not skip_out or kind == "s2"
         if kind == "t2":
             self.flops_fwd += 2 * x.numel() * cout * 27
         if self.mfma_conv:
@@ -780,7 +782,10 @@ class DsgnShapedAdapter(PsvStereoAdapter):
                 else:
                     y = ops.Conv3dK3.apply(x, e["p"], e["pt"], cout, None, b, relu, residual, chain_in, e["wino"])
             elif kind == "s2":
-                y = ops.Conv3dK3S2.apply(x, e["p"], e["pt"], cout, b, relu)
+                y = ops.Conv3dK3S2.apply(x, e["p"], e["pt"], cout, b, relu, chain_in, skip_out)
+                if skip_out:
+                    self.flops_fwd += 2 * y[0].numel() * e["cin"] * 27
+                    return y
             else:
                 y = ops.ConvTranspose3dK3S2.apply(x, e["p"], e["pt"], cout, b, relu, residual)
         else:
@@ -846,10 +851,20 @@ class DsgnShapedAdapter(PsvStereoAdapter):
         ch = self.mfma_conv                 # chains: a ReLU output with ONE consumer, and that consumer a stride-1 layer on the main kernel
         c0 = self._c3(self._c3(cost, "dres0a", "consumer" if ch else True), "dres0b", True, chain_in=ch)
         c0 = self._c3(self._c3(c0, "dres1a", "consumer" if ch else True), "dres1b", False, c0, chain_in=ch)
-        pre = self._c3(self._c3(c0, "hg1", "consumer" if ch else True), "hg2", True, chain_in=ch)
-        h = self._c3(self._c3(pre, "hg3", "consumer" if ch else True), "hg4", True, chain_in=ch)
-        post = self._c3(h, "hg5", True, pre)
-        out = self._c3(post, "hg6", False, c0)
+        if ch:
+            # the tensors a down-sampling layer reads also feed the matching up-sampling layer's skip connection: the down-sampling layer's
+            # backward adds the skip path's gradient (and applies the producer's ReLU mask) in its own launch - ops.Conv3dK3S2 skip_out / mask_input
+            t, c0s = self._c3(c0, "hg1", "consumer", skip_out=True)                          # c0 carries no ReLU
+            pre = self._c3(t, "hg2", "consumer", chain_in=True)                               # hg2's mask: in hg3's backward
+            t, pres = self._c3(pre, "hg3", "consumer", chain_in=True, skip_out=True)
+            h = self._c3(t, "hg4", True, chain_in=True)
+            post = self._c3(h, "hg5", True, pres)
+            out = self._c3(post, "hg6", False, c0s)
+        else:
+            pre = self._c3(self._c3(c0, "hg1", True), "hg2", True)
+            h = self._c3(self._c3(pre, "hg3", True), "hg4", True)
+            post = self._c3(h, "hg5", True, pre)
+            out = self._c3(post, "hg6", False, c0)
         score = self._c3(self._c3(out, "cls_a", True), "cls_b")
         return score.squeeze(1), out
 
@@ -864,11 +879,20 @@ class DsgnShapedAdapter(PsvStereoAdapter):
             grid, plan = self._gv(b)
             gv = ops.GridSample3d.apply(vol, grid, plan)                                                  # [B,32,Zg,Yg,Xg]
         ch = self.mfma_conv
-        g1 = self._c3(gv, "gv1", True)
-        pre = self._c3(self._c3(g1, "gh1", "consumer" if ch else True), "gh2", True, chain_in=ch)
-        h = self._c3(self._c3(pre, "gh3", "consumer" if ch else True), "gh4", True, chain_in=ch)
-        post = self._c3(h, "gh5", True, pre)
-        g = self._c3(post, "gh6", True, g1)
+        if ch:      # as in _volume_net_impl: the skip tensors' gradients and ReLU masks meet in the down-sampling layers' backward launches
+            g1 = self._c3(gv, "gv1", "consumer")
+            t, g1s = self._c3(g1, "gh1", "consumer", chain_in=True, skip_out=True)
+            pre = self._c3(t, "gh2", "consumer", chain_in=True)
+            t, pres = self._c3(pre, "gh3", "consumer", chain_in=True, skip_out=True)
+            h = self._c3(t, "gh4", True, chain_in=True)
+            post = self._c3(h, "gh5", True, pres)
+            g = self._c3(post, "gh6", True, g1s)
+        else:
+            g1 = self._c3(gv, "gv1", True)
+            pre = self._c3(self._c3(g1, "gh1", True), "gh2", True)
+            h = self._c3(self._c3(pre, "gh3", True), "gh4", True)
+            post = self._c3(h, "gh5", True, pre)
+            g = self._c3(post, "gh6", True, g1)
         bb, c, zg, yg, xg = g.shape
         if self.torch_ops or not g.is_cuda:
             bev = F.avg_pool3d(g, (1, self.ypool, 1)).permute(0, 1, 3, 2, 4).reshape(bb, c * (yg // self.ypool), zg, xg)

@@ -766,7 +766,7 @@ __global__ __launch_bounds__(64 * kTT * kTDt, kTT * kTDt == 4 ? 2 : 1) void conv
   const int co0 = cob * 32 + 4 * half;
   const long long ovol = static_cast<long long>(epi.od) * epi.oh * epi.ow;
   typedef float v2f __attribute__((ext_vector_type(2)));
-  if (epi.bias == nullptr && epi.residual == nullptr) {      // the adjoint of a strided convolution: nothing to fetch
+  if (epi.bias == nullptr && epi.residual == nullptr && epi.mask == nullptr) {      // the adjoint of a strided convolution: nothing to fetch
 #pragma unroll
     for (int pd = 0; pd < 2; ++pd)
 #pragma unroll
@@ -790,7 +790,7 @@ __global__ __launch_bounds__(64 * kTT * kTDt, kTT * kTDt == 4 ? 2 : 1) void conv
     const int co = co0 + 8 * (v >> 2) + (v & 3);
     bz[v] = (epi.bias != nullptr && co < Cout) ? epi.bias[co] : 0.0f;
   }
-  const bool has_bias = epi.bias != nullptr, has_res = epi.residual != nullptr;
+  const bool has_bias = epi.bias != nullptr, has_res = epi.residual != nullptr, has_mask = epi.mask != nullptr;
 #pragma unroll
   for (int pd = 0; pd < 2; ++pd)
 #pragma unroll
@@ -805,6 +805,14 @@ __global__ __launch_bounds__(64 * kTT * kTDt, kTT * kTDt == 4 ? 2 : 1) void conv
           sk[v] = co0 + cr < Cout ? __builtin_nontemporal_load(reinterpret_cast<const v2f*>(epi.residual + at + cr * ovol)) : (v2f){0.0f, 0.0f};
         }
       }
+      v2f mk[16];    // <round 4> the mask (a ReLU output laid out like y): the result is zeroed where it is <= 0, last of all
+      if (has_mask) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int cr = 8 * (v >> 2) + (v & 3);
+          mk[v] = co0 + cr < Cout ? __builtin_nontemporal_load(reinterpret_cast<const v2f*>(epi.mask + at + cr * ovol)) : (v2f){1.0f, 1.0f};
+        }
+      }
 #pragma unroll
       for (int v = 0; v < 16; ++v) {
         const int cr = 8 * (v >> 2) + (v & 3);
@@ -812,6 +820,7 @@ __global__ __launch_bounds__(64 * kTT * kTDt, kTT * kTDt == 4 ? 2 : 1) void conv
         if (has_bias) r.x = r.x + bz[v], r.y = r.y + bz[v];
         if (has_res) r.x = r.x + sk[v].x, r.y = r.y + sk[v].y;
         if (epi.relu) r.x = r.x > 0.0f ? r.x : 0.0f, r.y = r.y > 0.0f ? r.y : 0.0f;
+        if (has_mask) r.x = mk[v].x > 0.0f ? r.x : 0.0f, r.y = mk[v].y > 0.0f ? r.y : 0.0f;
         if (co0 + cr < Cout) *reinterpret_cast<v2f*>(y + at + cr * ovol) = r;
       }
     }
@@ -1471,16 +1480,18 @@ int adv_conv3d_k3_ex_f32(const float* x, const float* w_prep, const float* bias,
   return launch_conv(x, w_prep, y, b, cin, cout, d, h, w, stride, epi, static_cast<hipStream_t>(stream));
 }
 
-int adv_conv_transpose3d_k3_s2_f32(const float* x, const float* const* w_prep_classes, const uint32_t* tap_masks, const float* bias,
-                                   const float* residual, float* y,
-                                   int b, int cin, int cout, int d, int h, int w, int relu, adv_stream_t stream) {
-  if (!x || !w_prep_classes || !tap_masks || !y || residual == y || b < 1 || cin < kCK || cin % kCK != 0 || cout < 1 || d < 1 || h < 1 || w < 1)
+// mask != nullptr: only the all-classes kernel applies it (the other routes return ADV_EINVAL: the caller masks in a pass of its own)
+static int convt3d_launch(const float* x, const float* const* w_prep_classes, const uint32_t* tap_masks, const float* bias,
+                          const float* residual, const float* mask, float* y,
+                          int b, int cin, int cout, int d, int h, int w, int relu, adv_stream_t stream) {
+  if (!x || !w_prep_classes || !tap_masks || !y || residual == y || mask == y || b < 1 || cin < kCK || cin % kCK != 0 || cout < 1 || d < 1 || h < 1 || w < 1)
     return ADV_EINVAL;
   for (int k = 0; k < 8; ++k)
     if (w_prep_classes[k] == nullptr || (tap_masks[k] & ~kAllTaps) || tap_masks[k] == 0) return ADV_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
   Epi epi{bias, relu, tap_masks[0], {0, 0, 0, 0, 0, 0, 0, 0}, 0, 2 * d, 2 * h, 2 * w, 2, 2, 2, 0, 0, 0};
   epi.residual = residual;
+  epi.mask = mask;
   const int cblocks = (cout + 31) / 32;
   const bool fits = w >= 4 && static_cast<long long>(cin) * d * h * w < (1LL << 31) && 27LL * cin * cblocks * 32 < (1LL << 31);
   bool aligned_w = (reinterpret_cast<uintptr_t>(x) & 3) == 0;
@@ -1496,7 +1507,9 @@ int adv_conv_transpose3d_k3_s2_f32(const float* x, const float* const* w_prep_cl
     if (padded(4) < padded(tdv)) tdv = 4;
     if (const char* e = adv_hook_value("ADV_CONV_T_TD")) tdv = e[0] == '4' ? 4 : (e[0] == '2' ? 2 : 1);
     const bool all_classes = w % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 7) == 0 &&
-                             (reinterpret_cast<uintptr_t>(residual) & 7) == 0 && ntiles < (1LL << 31) && !adv_hook("ADV_CONV_T_CLASS_TILES");
+                             (reinterpret_cast<uintptr_t>(residual) & 7) == 0 && (reinterpret_cast<uintptr_t>(mask) & 7) == 0 && ntiles < (1LL << 31) &&
+                             !adv_hook("ADV_CONV_T_CLASS_TILES");
+    if (mask != nullptr && !all_classes) return ADV_EINVAL;
     if (all_classes) {   // every class from one staging of the input tile (convt3d_k3_s2_mfma)
       for (int k = 0; k < 8; ++k) epi.cls_wp[k] = w_prep_classes[k];
       if (tdv > 1) {
@@ -1517,6 +1530,7 @@ int adv_conv_transpose3d_k3_s2_f32(const float* x, const float* const* w_prep_cl
                          tiles_w, tiles_h, cblocks, epi);
       return adv_internal_finish_launch();
     }
+    if (mask != nullptr) return ADV_EINVAL;
     epi.nclass = 8;   // one launch: the class is a tile index (launch_conv's persistent masked kernel)
     for (int k = 0; k < 8; ++k) {
       epi.cls_wp[k] = w_prep_classes[k];
@@ -1526,6 +1540,7 @@ int adv_conv_transpose3d_k3_s2_f32(const float* x, const float* const* w_prep_cl
     epi.tap_mask = 0;  // never the all-taps kernel
     return launch_conv(x, w_prep_classes[0], y, b, cin, cout, d, h, w, 1, epi, st);
   }
+  if (mask != nullptr) return ADV_EINVAL;
   for (int k = 0; k < 8; ++k) {  // eight masked launches: the same bits (ADV_CONV_CLASS_LAUNCHES=1: test hook / A-B)
     epi.tap_mask = tap_masks[k];
     epi.fd = (k >> 2) & 1, epi.fh = (k >> 1) & 1, epi.fw = k & 1;
@@ -1533,6 +1548,18 @@ int adv_conv_transpose3d_k3_s2_f32(const float* x, const float* const* w_prep_cl
     if (rc != ADV_OK) return rc;
   }
   return ADV_OK;
+}
+
+int adv_conv_transpose3d_k3_s2_f32(const float* x, const float* const* w_prep_classes, const uint32_t* tap_masks, const float* bias,
+                                   const float* residual, float* y,
+                                   int b, int cin, int cout, int d, int h, int w, int relu, adv_stream_t stream) {
+  return convt3d_launch(x, w_prep_classes, tap_masks, bias, residual, nullptr, y, b, cin, cout, d, h, w, relu, stream);
+}
+
+int adv_conv_transpose3d_k3_s2_dgrad_f32(const float* x, const float* const* w_prep_classes, const uint32_t* tap_masks, const float* residual,
+                                         const float* mask, float* y, int b, int cin, int cout, int d, int h, int w, adv_stream_t stream) {
+  if (mask == nullptr) return ADV_EINVAL;
+  return convt3d_launch(x, w_prep_classes, tap_masks, nullptr, residual, mask, y, b, cin, cout, d, h, w, 0, stream);
 }
 
 }  // extern "C"

@@ -414,19 +414,29 @@ int launch_wino_tile(int t, const float* x, const float* wp, float* y, int b, in
     case 2: return launch_wino<4, 16, 2, 4, DEPTH>(x, wp, y, b, cin, cout, cinpad, copad, d, h, w, epi, st);
     case 3: return launch_wino<8, 8, 2, 4, DEPTH>(x, wp, y, b, cin, cout, cinpad, copad, d, h, w, epi, st);
     case 4: return launch_wino<5, 12, 4, 8, DEPTH>(x, wp, y, b, cin, cout, cinpad, copad, d, h, w, epi, st);
-    default: return launch_wino<5, 12, 2, 4, DEPTH>(x, wp, y, b, cin, cout, cinpad, copad, d, h, w, epi, st);
+    case 5: return launch_wino<5, 12, 2, 4, DEPTH>(x, wp, y, b, cin, cout, cinpad, copad, d, h, w, epi, st);
+    case 6: return launch_wino<3, 20, 4, 8, DEPTH>(x, wp, y, b, cin, cout, cinpad, copad, d, h, w, epi, st);
+    default: return launch_wino<3, 20, 2, 4, DEPTH>(x, wp, y, b, cin, cout, cinpad, copad, d, h, w, epi, st);
   }
 }
 
-// tile: 0 = 8 x 32 outputs x 64 channels, 1 = 16 x 16 x 64, 2 = 8 x 32 x 32 channels, 3 = 16 x 16 x 32, 4 = 10 x 24 x 64, 5 = 10 x 24 x 32
-int pick_wino_tile(int cout, int h, int w) {
+// tile: 0 = 8 x 32 outputs x 64 channels, 1 = 16 x 16 x 64, 2 = 8 x 32 x 32 channels, 3 = 16 x 16 x 32, 4 = 10 x 24 x 64, 5 = 10 x 24 x 32,
+// <round 4> 6 = 6 x 40 x 64, 7 = 6 x 40 x 32 (3 x 20 patches): the 5-row maps of the 3D geometric volume's quarter resolution ([48,5,76]: two
+// tiles of 6 x 40 per plane instead of three of 8 x 32, 1.6x fewer padded outputs) and the 24 x 78 planes of the cost volume's
+int pick_wino_tile(int cout, int h, int w, long long bz) {
   // 8 x 32 outputs per workgroup (128-byte store runs) unless another shape needs clearly fewer workgroups for the map: 16 x 16 for the
   // 14 x 14 maps of the box heads (one tile instead of two per image), 10 x 24 for the bird's-eye volumes of 10 / 20 rows;
   // 32-channel workgroups where 64 would compute a zero block
   auto tiles = [&](int th, int tw) { return static_cast<long long>((h + th - 1) / th) * ((w + tw - 1) / tw); };
-  const long long t0 = tiles(8, 32) * 10, t1 = tiles(16, 16) * 12, t2 = tiles(10, 24) * 11;      // x 1.2, x 1.1: the handicaps of the other shapes
-  const int shape = (t1 < t0 && t1 <= t2) ? 1 : (t2 < t0 ? 4 : 0);
-  const int narrow = ((cout + 31) / 32) % 2 == 1 ? (shape == 4 ? 1 : 2) : 0;      // an odd number of 32-channel blocks
+  const long long t0 = tiles(8, 32) * 10, t1 = tiles(16, 16) * 12, t2 = tiles(10, 24) * 11, t3 = tiles(6, 40) * 11;   // x 1.2, x 1.1: the handicaps of the other shapes
+  int shape = (t1 < t0 && t1 <= t2) ? 1 : (t2 < t0 ? 4 : 0);
+  if (t3 < t0 && t3 < t1 && t3 < t2) shape = 6;
+  int narrow = ((cout + 31) / 32) % 2 == 1 ? ((shape == 4 || shape == 6) ? 1 : 2) : 0;      // an odd number of 32-channel blocks
+  // <round 4> ... and where 64-channel workgroups (one per compute unit) would leave more than half of the chip idle: the 19 x 63 and
+  // 48 x 76 maps at one pair per step (48-96 workgroups).  Two 32-channel workgroups per unit transform every input tile twice, but
+  // they run everywhere: 1.22-1.24x on those layers, slower from ~160 workgroups up (profiles/r04_wino_tiles.jsonl).  Same bits.
+  const long long t = shape == 1 ? tiles(16, 16) : (shape == 4 ? tiles(10, 24) : (shape == 6 ? tiles(6, 40) : tiles(8, 32)));
+  if (narrow == 0 && t * ((cout + 63) / 64) * bz <= 128) narrow = (shape == 4 || shape == 6) ? 1 : 2;
   return shape + narrow;
 }
 
@@ -507,11 +517,11 @@ int adv_conv2d_wino_prep_weights_f32(const float* w, float* w_prep, int cout, in
 
 int adv_conv2d_wino_f32(const float* x, const float* w_prep, const float* bias, const float* residual, const float* mask, float* y, int b, int cin,
                         int cout, int h, int w, int relu, int tile, adv_stream_t stream) {
-  if (!x || !w_prep || !y || b < 1 || cin < 1 || cout < 1 || h < 1 || w < 1 || tile < -1 || tile > 5) return ADV_EINVAL;
+  if (!x || !w_prep || !y || b < 1 || cin < 1 || cout < 1 || h < 1 || w < 1 || tile < -1 || tile > 7) return ADV_EINVAL;
   if (static_cast<long long>(b) * cin * h * w < 4) return ADV_EINVAL;      // the kernel loads whole float4s (clamped into the tensor)
   if (const int rc = check_wino_args(x, w_prep, bias, residual, mask, y)) return rc;
   const EpiW epi{bias, residual, mask, relu ? 1 : 0};
-  return launch_wino_tile<false>(tile >= 0 ? tile : pick_wino_tile(cout, h, w), x, w_prep, y, b, cin, cout, round_up_w(cin, 8), round_up_w(cout, 64), 1,
+  return launch_wino_tile<false>(tile >= 0 ? tile : pick_wino_tile(cout, h, w, b), x, w_prep, y, b, cin, cout, round_up_w(cin, 8), round_up_w(cout, 64), 1,
                                  h, w, epi, static_cast<hipStream_t>(stream));
 }
 
@@ -527,11 +537,11 @@ int adv_conv3d_wino_prep_weights_f32(const float* w, float* w_prep, int cout, in
 
 int adv_conv3d_wino_f32(const float* x, const float* w_prep, const float* bias, const float* residual, const float* mask, float* y, int b, int cin,
                         int cout, int d, int h, int w, int relu, int tile, adv_stream_t stream) {
-  if (!x || !w_prep || !y || b < 1 || cin < 1 || cout < 1 || d < 1 || h < 1 || w < 1 || tile < -1 || tile > 5) return ADV_EINVAL;
+  if (!x || !w_prep || !y || b < 1 || cin < 1 || cout < 1 || d < 1 || h < 1 || w < 1 || tile < -1 || tile > 7) return ADV_EINVAL;
   if (static_cast<long long>(b) * cin * d * h * w < 4) return ADV_EINVAL;
   if (const int rc = check_wino_args(x, w_prep, bias, residual, mask, y)) return rc;
   const EpiW epi{bias, residual, mask, relu ? 1 : 0};
-  return launch_wino_tile<true>(tile >= 0 ? tile : pick_wino_tile(cout, h, w), x, w_prep, y, b, cin, cout, round_up_w(cin, 8), round_up_w(cout, 64), d,
+  return launch_wino_tile<true>(tile >= 0 ? tile : pick_wino_tile(cout, h, w, static_cast<long long>(b) * d), x, w_prep, y, b, cin, cout, round_up_w(cin, 8), round_up_w(cout, 64), d,
                                 h, w, epi, static_cast<hipStream_t>(stream));
 }
 

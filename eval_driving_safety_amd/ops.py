@@ -859,6 +859,26 @@ def conv_transpose3d_k3_s2(x, classes, cout, relu=False, bias=None, residual=Non
     return out
 
 
+def conv_transpose3d_k3_s2_dgrad(grad, classes, cout, residual=None, mask=None):
+    """(conv_transpose3d(grad) + residual) zeroed where mask <= 0, in ONE launch: the backward of a strided 3x3x3 convolution whose input
+    (``mask``, a ReLU output) also feeds a skip path whose gradient is ``residual``.  Returns None where the library has no fused kernel
+    for the shape (W % 4 != 0 ...): the caller then adds / masks in passes of its own."""
+    xi, mk = _feat(grad, "grad"), _feat(mask, "mask")
+    b, cin, d, h, w = xi.shape
+    out = torch.empty((b, cout, 2 * d, 2 * h, 2 * w), dtype=torch.float32, device=xi.device)
+    if tuple(mk.shape) != tuple(out.shape):
+        raise ValueError("mask must be laid out like the result %s" % (tuple(out.shape),))
+    wps = (ctypes.c_void_p * 8)(*[_feat(c[0], "w_prep").data_ptr() for c in classes])
+    masks = (ctypes.c_uint32 * 8)(*[int(c[1]) for c in classes])
+    with _on(xi):
+        rc = _lib.load().adv_conv_transpose3d_k3_s2_dgrad_f32(_ptr(xi), wps, masks, _residual(residual, out), _ptr(mk), _ptr(out), b, cin, cout, d, h, w,
+                                                             _stream(xi))
+    if rc == _lib.ADV_EINVAL:
+        return None
+    _lib.check("adv_conv_transpose3d_k3_s2_dgrad_f32", rc)
+    return out
+
+
 def relu_backward(grad, y):
     """grad where y > 0 else 0 (threshold_backward), one pass; ``y`` is the output of the fused-ReLU convolution"""
     g, yy = _feat(grad.contiguous(), "grad"), _feat(y, "y")
@@ -940,26 +960,47 @@ class Conv3dK3(torch.autograd.Function):
 
 class Conv3dK3S2(torch.autograd.Function):
     """y = conv3d(x, weight, stride 2, padding 1); the gradient w.r.t. x is the transposed convolution of grad_y with the
-    same weights (``classes_t = conv_transpose3d_k3_s2_prep(weight)``), cropped to x's size when a dimension is odd."""
+    same weights (``classes_t = conv_transpose3d_k3_s2_prep(weight)``), cropped to x's size when a dimension is odd.
+
+    <round 4> An hourglass's down-sampling layer reads a tensor that ALSO feeds the matching up-sampling layer's skip connection.  Two
+    flags take the addition of the two gradients and the producer's ReLU mask into this layer's backward launch (as ops.Conv2dAuto's):
+      ``skip_out=True``    returns (y, x_skip), x_skip an alias of x: hand it to the up-sampling layer as its ``residual``; this layer's backward
+                           then receives both gradients of x and adds the skip path's in the transposed kernel's epilogue;
+      ``mask_input=True``  x is a ReLU output whose only consumers are this layer and that skip path, and its producer left the mask to us
+                           (relu="consumer"): the gradient returned is already multiplied by (x > 0).
+    The caller vouches for the topology; same float operations in the same order as autograd's addition and a relu-backward pass."""
 
     @staticmethod
-    def forward(ctx, x, w_prep, classes_t, cout, bias=None, relu=False):
+    def forward(ctx, x, w_prep, classes_t, cout, bias=None, relu=False, mask_input=False, skip_out=False):
         ctx.classes_t, ctx.xshape = classes_t, tuple(x.shape)
         ctx.relu = bool(relu) and relu != "consumer"        # "consumer": the only consumer's backward applies this layer's ReLU mask (Conv3dK3 mask_input)
-        y = conv3d_k3_s2(x.contiguous(), w_prep, cout, relu=bool(relu), bias=bias)
-        ctx.save_for_backward(y if ctx.relu else None)
-        return y
+        ctx.mask_input = bool(mask_input)
+        x = x.contiguous()
+        y = conv3d_k3_s2(x, w_prep, cout, relu=bool(relu), bias=bias)
+        ctx.save_for_backward(y if ctx.relu else None, x if mask_input else None)
+        return (y, x) if skip_out else y
 
     @staticmethod
-    def backward(ctx, grad_y):
-        (y,) = ctx.saved_tensors
+    def backward(ctx, grad_y, grad_skip=None):
+        y, x_in = ctx.saved_tensors
         if ctx.relu:
             grad_y = relu_backward(grad_y, y)
-        g = conv_transpose3d_k3_s2(grad_y.contiguous(), ctx.classes_t, ctx.xshape[1])
         d, h, w = ctx.xshape[2:]
-        if tuple(g.shape[2:]) != (d, h, w):
-            g = g[:, :, :d, :h, :w].contiguous()
-        return g, None, None, None, None, None
+        gy = grad_y.contiguous()
+        even = (2 * gy.shape[2], 2 * gy.shape[3], 2 * gy.shape[4]) == (d, h, w)
+        skip = None if grad_skip is None else grad_skip.contiguous()
+        g = None
+        if even and ctx.mask_input:                         # transposed convolution + skip gradient + mask in one launch
+            g = conv_transpose3d_k3_s2_dgrad(gy, ctx.classes_t, ctx.xshape[1], residual=skip, mask=x_in)
+        if g is None:
+            g = conv_transpose3d_k3_s2(gy, ctx.classes_t, ctx.xshape[1], residual=skip if even else None)
+            if tuple(g.shape[2:]) != (d, h, w):
+                g = g[:, :, :d, :h, :w].contiguous()
+            if skip is not None and not even:
+                g = g + skip
+            if ctx.mask_input:
+                g = relu_backward(g, x_in)
+        return g, None, None, None, None, None, None, None
 
 
 class ConvTranspose3dK3S2(torch.autograd.Function):

@@ -366,6 +366,17 @@ ADV_API int adv_conv_transpose3d_k3_s2_f32(const float* x, const float* const* w
                                            const float* bias, const float* residual, float* y, int b, int cin, int cout, int d,
                                            int h, int w, int relu, adv_stream_t stream);
 
+/* <round 4> The same transposed convolution as the BACKWARD of a strided convolution (kernel 3, stride 2, padding 1) whose input x_in is
+ *     a ReLU output with two consumers - that convolution and one skip path (an hourglass: the layer before a down-sampling layer also feeds
+ *     the matching up-sampling layer's skip connection):  y = (conv_transpose(grad) + residual) zeroed where mask <= 0, with residual = the
+ *     gradient arriving over the skip path (or NULL) and mask = x_in (laid out like y, must not be y) - i.e. the gradient w.r.t. the
+ *     producer's PRE-activation, with neither an addition pass nor a relu-backward pass over the volume.  Same float operations in the same
+ *     order as the three done apart.  Only the all-classes kernel applies the mask (w % 4 == 0, x 16-byte and y / residual / mask 8-byte
+ *     aligned): anything else returns ADV_EINVAL and the caller does the two passes itself. */
+ADV_API int adv_conv_transpose3d_k3_s2_dgrad_f32(const float* x, const float* const* w_prep_classes, const uint32_t* tap_masks,
+                                                 const float* residual, const float* mask, float* y, int b, int cin, int cout, int d,
+                                                 int h, int w, adv_stream_t stream);
+
 /* How many input channels a STAGE of the plain strided convolution (adv_conv3d_k3_ex_f32, stride 2, every tap, own output grid,
  *     16-byte aligned w_prep) holds for this input pointer, output-channel count and width - the float32 accumulation order is
  *     (stage, tap, channel within the stage): 2 = the direct strided matrix kernel (w % 4 == 0, x 16-byte aligned: 54 MFMAs
@@ -479,7 +490,7 @@ ADV_API int adv_conv2d_3x3_f32(const float* x, const float* w_prep, const float*
  *     w_prep from adv_conv2d_wino_prep_weights_f32 ([16][cin'][cout'] = G g G^T per channel pair, zero padded to multiples of 8 x 64);
  *     transpose = 1: the backward w.r.t. the input.  bias / residual / relu / mask: as adv_conv2d_1x1_f32.
  *     tile: -1 = by map size and cout, 0 = 8 x 32 outputs x 64 channels per workgroup, 1 = 16 x 16 x 64, 2 = 8 x 32 x 32 channels (256
- *     threads, two workgroups per CU), 3 = 16 x 16 x 32, 4 = 10 x 24 x 64, 5 = 10 x 24 x 32 (same result).  Tensors of fewer than four floats: ADV_EINVAL. */
+ *     threads, two workgroups per CU), 3 = 16 x 16 x 32, 4 = 10 x 24 x 64, 5 = 10 x 24 x 32, 6 = 6 x 40 x 64, 7 = 6 x 40 x 32 (same result).  Tensors of fewer than four floats: ADV_EINVAL. */
 ADV_API int64_t adv_conv2d_wino_prep_floats(int cout, int cin, int transpose);
 ADV_API int adv_conv2d_wino_prep_weights_f32(const float* w, float* w_prep, int cout, int cin, int transpose, adv_stream_t stream);
 ADV_API int adv_conv2d_wino_f32(const float* x, const float* w_prep, const float* bias, const float* residual, const float* mask,

@@ -281,7 +281,7 @@ def test_hip_conv2d_wino_bit_exact_vs_oracle(shape):
     prep = ops.Conv2dPrep(tw, 1, 1, 1)
     assert prep.has_wino
     want_plain, want_full = C.conv2d_wino(x, wt), C.conv2d_wino(x, wt, bias, res, mask, relu=True)
-    for tile in (-1, 0, 1, 2, 3, 4, 5):  # 8x32 / 16x16 outputs x 64 channels (512 threads), the same x 32 channels (256 threads): one result
+    for tile in (-1, 0, 1, 2, 3, 4, 5, 6, 7):  # 8x32 / 16x16 outputs x 64 channels (512 threads), the same x 32 channels (256 threads): one result
         assert ops.conv2d(tx, prep, wino=True, tile=tile).cpu().numpy().tobytes() == want_plain.tobytes(), tile
         assert ops.conv2d(tx, prep, tb, tr, True, tm, wino=True, tile=tile).cpu().numpy().tobytes() == want_full.tobytes(), tile
     ref = F.conv2d(tx, tw, tb, 1, 1)
@@ -291,7 +291,7 @@ def test_hip_conv2d_wino_bit_exact_vs_oracle(shape):
     tg, tgr = torch.tensor(g, device=dev), torch.tensor(gres, device=dev)
     assert ops.conv2d_dgrad(tg, prep, wino=True).cpu().numpy().tobytes() == C.conv2d_wino(g, wt, transpose=True).tobytes()
     want_b = C.conv2d_wino(g, wt, residual=gres, mask=x, transpose=True)
-    for tile in (0, 1, 2, 3, 4, 5):
+    for tile in (0, 1, 2, 3, 4, 5, 6, 7):
         assert ops.conv2d_dgrad(tg, prep, residual=tgr, mask=tx, wino=True, tile=tile).cpu().numpy().tobytes() == want_b.tobytes(), tile
     refg = torch.nn.grad.conv2d_input(x.shape, tw, tg, padding=1)
     assert float((ops.conv2d_dgrad(tg, prep, wino=True) - refg).abs().max()) <= 1e-4 * max(1.0, float(refg.abs().max()))

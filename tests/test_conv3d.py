@@ -291,6 +291,49 @@ def test_hip_hourglass_autograd_vs_torch():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("w", [40, 38])
+def test_hip_hourglass_skip_and_mask_in_the_down_layers_backward(w):
+    """<round 4> an hourglass whose down-sampling layer's input also feeds the up-sampling layer's skip connection, with the producer's ReLU
+    left to the down-sampling layer's backward (ops.Conv3dK3S2 skip_out / mask_input): the fused backward launch
+    (adv_conv_transpose3d_k3_s2_dgrad_f32: transposed convolution + skip gradient + mask) equals the oracle's transposed convolution, numpy's
+    add and where bit for bit; the graph's values and input gradient equal torch's (1e-4).  w = 38: no fused kernel (W / 2 % 4 != 0), the
+    separate passes - same contract."""
+    from eval_driving_safety_amd import ops
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(4)
+    x = torch.randn((1, 8, 6, 10, w), device=dev, generator=gen)
+    w0 = torch.randn((16, 8, 3, 3, 3), device=dev, generator=gen) * 0.1              # producer: stride 1, ReLU
+    wd = torch.randn((32, 16, 3, 3, 3), device=dev, generator=gen) * 0.05            # down: 16 -> 32
+    wu = torch.randn((32, 16, 3, 3, 3), device=dev, generator=gen) * 0.05            # up (ConvTranspose layout [in = 32, out = 16]) + skip
+    xr = x.clone().requires_grad_(True)
+    a = F.relu(F.conv3d(xr, w0, padding=1))
+    ref = F.relu(F.conv_transpose3d(F.relu(F.conv3d(a, wd, stride=2, padding=1)), wu, stride=2, padding=1, output_padding=1) + a)
+    g = torch.randn(ref.shape, device=dev, generator=gen)
+    ref.backward(g)
+    xm = x.clone().requires_grad_(True)
+    am = ops.Conv3dK3.apply(xm, ops.conv3d_k3_prep(w0), ops.conv3d_k3_prep(w0, transpose=True), 16, None, None, "consumer")
+    down, skip = ops.Conv3dK3S2.apply(am, ops.conv3d_k3_s2_prep(wd), ops.conv_transpose3d_k3_s2_prep(wd), 32, None, True, True, True)
+    up = ops.ConvTranspose3dK3S2.apply(down, ops.conv_transpose3d_k3_s2_prep(wu), ops.conv3d_k3_s2_prep(wu), 16, None, True, skip)
+    up.backward(g)
+    assert float((up - ref).abs().max()) <= 1e-4 * float(ref.detach().abs().max())
+    assert float((xm.grad - xr.grad).abs().max()) <= 1e-4 * float(xr.grad.abs().max())
+    # the fused launch alone against the oracle's pieces
+    gy = torch.randn(down.shape, device=dev, generator=gen)
+    gs = torch.randn(am.shape, device=dev, generator=gen)
+    classes = ops.conv_transpose3d_k3_s2_prep(wd)
+    fused = ops.conv_transpose3d_k3_s2_dgrad(gy, classes, 16, residual=gs, mask=am.detach())
+    wt_t = wd.cpu().numpy()                                                           # conv weight [out = 32, in = 16] read as ConvTranspose [in = 32, out = 16]
+    want = C.conv_transpose3d_k3_s2(gy.cpu().numpy(), wt_t) + gs.cpu().numpy()
+    want = np.where(am.detach().cpu().numpy() > 0, want, np.float32(0)).astype(np.float32)
+    if (w // 2) % 4 == 0:
+        assert fused is not None and fused.cpu().numpy().tobytes() == want.tobytes()
+        assert torch.equal(ops.conv_transpose3d_k3_s2_dgrad(gy, classes, 16, mask=am.detach()),
+                           ops.relu_backward(ops.conv_transpose3d_k3_s2(gy, classes, 16), am.detach()))
+    else:
+        assert fused is None
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("shape", HG_SHAPES + [(1, 32, 1, 3, 8, 36), (1, 2, 32, 3, 8, 36)])
 def test_hip_residual_epilogue_equals_conv_then_add_then_relu(shape, route):
     """y = relu(conv(x) + bias + skip) in the epilogue (an hourglass's skip connection): the same float operations in the same
@@ -512,7 +555,7 @@ def test_hip_conv3d_wino_bit_exact_vs_oracle(shape):
     tx, tw, tb, tr, tm = (torch.tensor(a, device=dev) for a in (x, wt, bias, res, mask))
     prep = ops.Conv3dWinoPrep(tw)
     want_plain, want_full = C.conv3d_wino(x, wt), C.conv3d_wino(x, wt, bias, res, mask, relu=True)
-    for tile in (-1, 0, 1, 2, 3, 4, 5):
+    for tile in (-1, 0, 1, 2, 3, 4, 5, 6, 7):
         assert ops.conv3d_wino(tx, prep, tile=tile).cpu().numpy().tobytes() == want_plain.tobytes(), tile
         assert ops.conv3d_wino(tx, prep, tb, tr, True, tm, tile=tile).cpu().numpy().tobytes() == want_full.tobytes(), tile
     ref = torch.nn.functional.conv3d(tx, tw, tb, padding=1)
@@ -521,7 +564,7 @@ def test_hip_conv3d_wino_bit_exact_vs_oracle(shape):
     tg, tgr = torch.tensor(g, device=dev), torch.tensor(gres, device=dev)
     assert ops.conv3d_wino_dgrad(tg, prep).cpu().numpy().tobytes() == C.conv3d_wino(g, wt, transpose=True).tobytes()
     want_b = C.conv3d_wino(g, wt, residual=gres, mask=x, transpose=True)
-    for tile in (0, 1, 2, 3, 4, 5):
+    for tile in (0, 1, 2, 3, 4, 5, 6, 7):
         assert ops.conv3d_wino_dgrad(tg, prep, residual=tgr, mask=tx, tile=tile).cpu().numpy().tobytes() == want_b.tobytes(), tile
     refg = torch.nn.grad.conv3d_input(x.shape, tw, tg, padding=1)
     assert float((ops.conv3d_wino_dgrad(tg, prep) - refg).abs().max()) <= 1e-4 * max(1.0, float(refg.abs().max()))

@@ -127,6 +127,8 @@ def measure_dsgn_full(pairs=1, iters=20, reps=1, graph=False, hip2d="auto"):
     for _ in range(2):
         net.loss_and_grad(x, batch.extra)
     torch.cuda.synchronize()
+    if os.environ.get("ADV_STOP_AFTER_WARMUP") == "1":      # tools/gpu_profile_step.sh: the warm-up alone (MIOpen's solver search), to be subtracted
+        return {"stopped": "after the warm-up"}
     from eval_driving_safety_amd import ops as _ops
     _ops.WINO_DIRECT_EQUIV_FLOPS[0] = 0
     step = float(net.flops_per_step(x, batch.extra))
@@ -201,6 +203,8 @@ def measure_srcnn_r101(pairs=1, iters=20, reps=1, rois=512, impl="auto", graph_b
         for _ in range(2):                       # MIOpen's solver search, kernel loads
             net.loss_and_grad(x, batch.extra)
         torch.cuda.synchronize()
+        if os.environ.get("ADV_STOP_AFTER_WARMUP") == "1":
+            return {"stopped": "after the warm-up"}
         model.reset_flops()
         from eval_driving_safety_amd import ops as _ops
         _ops.WINO_DIRECT_EQUIV_FLOPS[0] = 0

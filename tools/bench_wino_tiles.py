@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The Winograd kernel's six workgroup shapes (tile 0..5: 8x32 / 16x16 / 10x24 outputs x 64 or 32 output channels) on the 3x3 layer shapes of
+"""The Winograd kernel's eight workgroup shapes (tile 0..7: 8x32 / 16x16 / 10x24 outputs x 64 or 32 output channels) on the 3x3 layer shapes of
 both detector graphs, forward, one JSON line per layer: which shape is fastest where - the evidence behind pick_wino_tile (csrc/wino2d.hip).
 Same bits whatever the shape (tests/test_conv2d.py)."""
 import json
@@ -42,7 +42,7 @@ def main():
         bias = torch.randn((cout,), device=dev, generator=g)
         prep = ops.Conv2dPrep(wt, 1, 1, 1)
         ms = {}
-        for tile in (-1, 0, 1, 2, 3, 4, 5):
+        for tile in (-1, 0, 1, 2, 3, 4, 5, 6, 7):
             ms["auto" if tile < 0 else str(tile)] = round(timed(lambda: ops.conv2d(x, prep, bias, None, True, tile=tile, wino=True)), 4)
         flops = 2.0 * b * cout * cin * 9 * h * w
         best = min((v, k) for k, v in ms.items() if k != "auto")

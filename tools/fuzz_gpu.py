@@ -105,7 +105,7 @@ def conv2d_case(rs, dev):
     gx = ops.conv2d_dgrad(t(g), prep, residual=t(gres), mask=t(gmask), tile=tile)
     same(gx, C.conv2d(g, wt, residual=gres, mask=gmask, padding=pad, dilation=dil, transpose=True, chunk=chunk), "conv2d dgrad %s" % ((k, dil, b, cin, cout, h, w, tile),))
     if prep.has_wino:       # csrc/wino2d.hip against its own restatement, both tile shapes
-        wtile = int(rs.randint(-1, 6))
+        wtile = int(rs.randint(-1, 8))
         y = ops.conv2d(t(x), prep, t(bias), t(res), relu, t(mask), tile=wtile, wino=True)
         same(y, C.conv2d_wino(x, wt, bias, res, mask, relu=relu), "conv2d wino %s" % ((b, cin, cout, h, w, relu, wtile),))
         gx = ops.conv2d_dgrad(t(g), prep, residual=t(gres), mask=t(gmask), tile=wtile, wino=True)
@@ -126,7 +126,7 @@ def wino3d_case(rs, dev):
     res = rs.randn(b, cout, d, h, w).astype(np.float32) if rs.rand() < 0.5 else None
     mask = rs.randn(b, cout, d, h, w).astype(np.float32) if rs.rand() < 0.3 else None
     relu = bool(rs.rand() < 0.5)
-    tile = int(rs.randint(-1, 6))
+    tile = int(rs.randint(-1, 8))
     t = lambda a: None if a is None else torch.tensor(a, device=dev)       # noqa: E731
     prep = ops.Conv3dWinoPrep(t(wt))
     same(ops.conv3d_wino(t(x), prep, t(bias), t(res), relu, t(mask), tile=tile), C.conv3d_wino(x, wt, bias, res, mask, relu=relu),
