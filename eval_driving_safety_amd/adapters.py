@@ -913,8 +913,8 @@ class DsgnShapedAdapter(PsvStereoAdapter):
     def forward_all(self, imgL, imgR):
         b = imgL.shape[0]
         f = self.features(torch.cat([imgL, imgR], 0))                      # both eyes through the shared extractor as one batch
-        fl, fr = f[:b].contiguous(), f[b:].contiguous()
-        cost = self.ops.PsvBuildLerp.apply(fl, fr, self.shifts(b))
+        fl, fr = f.split(b, 0)                                             # one split node (contiguous halves): its backward is one concatenation
+        cost = self.ops.PsvBuildLerp.apply(fl.contiguous(), fr.contiguous(), self.shifts(b))
         score, feat = self._volume_net_impl(cost)
         if self.torch_ops:
             up = F.interpolate(score[:, None], size=self.up_size, mode="trilinear", align_corners=False)[:, 0]

@@ -140,14 +140,22 @@ class StereoRcnnShaped(nn.Module):
         h = rois[:, 4] - rois[:, 2] + 1
         w = rois[:, 3] - rois[:, 1] + 1
         level = torch.round(torch.log(torch.sqrt(h * w) / 224.0) + 4).clamp(2, 5)
-        out = rois.new_zeros((rois.shape[0], feats[0].shape[1], pooled, pooled))
+        # per level the rois it owns, pooled; then ONE gather puts the rows back into roi order - as the reference does (stereo_rcnn.py:123-141:
+        # cat, sort box_to_level, index) instead of a zero tensor and one full-size index_add (a copy of all R x C x P x P floats) per level
+        parts, owners = [], []
         for i, l in enumerate(self.LEVELS):
             idx = torch.nonzero(level == l).view(-1)
             if idx.numel() == 0:
                 continue
             scale = feats[i].shape[2] / float(im_info[0][0])
-            out = out.index_add(0, idx, align(feats[i].contiguous(), rois[idx].contiguous(), pooled, scale))
-        return out
+            parts.append(align(feats[i].contiguous(), rois[idx].contiguous(), pooled, scale))
+            owners.append(idx)
+        if not parts:
+            return rois.new_zeros((rois.shape[0], feats[0].shape[1], pooled, pooled))
+        if len(parts) == 1 and owners[0].numel() == rois.shape[0]:
+            return parts[0]                                        # every roi on one level: already in roi order (nonzero is ascending)
+        order = torch.argsort(torch.cat(owners))                  # the owners are a permutation of 0..R-1: no ties
+        return torch.cat(parts, 0).index_select(0, order)
 
     def forward(self, im_left, im_right, im_info, gt_boxes_left, gt_boxes_right, gt_boxes_merge, gt_dim_orien, gt_kpts, num_boxes):
         from . import ops
@@ -456,7 +464,11 @@ class StereoRcnnR101(StereoRcnnShaped):
         both = torch.cat([im_left, im_right], 0) * self.input_scale
         feats = self._graphed_pyramid(both) if self.use_graph and both.is_cuda else self.pyramid(both)
         b = im_left.shape[0]
-        return [f[:b] for f in feats], [f[b:] for f in feats]
+        # ONE split node per level (its backward concatenates the two eyes' gradients once): ``f[:b]`` / ``f[b:]`` are two slice nodes whose
+        # backward each materialises a zero-filled full-size map per consumer and adds them - at P2 (152 MB) with five consumers that was
+        # ~3 GB of element-wise traffic per step (profiles/r04_r101_step_profile.json: fill + add kernels)
+        halves = [f.split(b, 0) for f in feats]
+        return [h[0] for h in halves], [h[1] for h in halves]
 
     # The backbone + FPN is the STATIC part of the step (no data-dependent shape, no host read-back): ~640 kernel launches forward and
     # as many backward, each behind ~25 us of Python / autograd dispatch - at one pair per step the GPU waits for the interpreter
