@@ -300,6 +300,7 @@ class SrcnnRuntime:
             # BEFORE the checkout's model code runs ``from model.roi_layers import ROIAlign`` / ``nms`` (stereo_rcnn.py:18, proposal layer)
             from .. import upstream_shims
             upstream_shims.install()
+            print("model.roi_layers -> eval_driving_safety_amd.upstream_shims.roi_layers (ROIAlign / nms on csrc/roi.hip)")
         roidb_mod = _need("roi_data_layer.roidb", "roi_data_layer.roidb")
         loader_mod = _need("roi_data_layer.roibatchLoader", "roi_data_layer.roibatchLoader (the reference's substitute file)")
         self.cfg = cfg = _need("model.utils.config", "model.utils.config").cfg

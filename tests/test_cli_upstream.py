@@ -170,6 +170,8 @@ def test_dsgn_clis_on_an_upstream_shaped_checkout(tmp_path):
     # --- pgd_attack.py: debugnum 1 attacks images 0 and 1 (batch_idx * 1 > 1 stops, quirk Q15)
     out = _run("dsgn_pgd_attack", common + ["--iter", "2", "--eps", "0.03"], str(tmp_path), "dsgn_checkout")
     assert "Loaded " + ckpt in out and "Using GPU:0" in out
+    # --adopt on (default): the checkout's StereoNet runs on libadvengine's kernels with the checkpoint's weights (adopt.adopt)
+    assert "adopted 14 convolution modules (12 on libadvengine kernels, 11 BatchNorms folded, 0 ReLUs fused)" in out, out[-1500:]
     for k in range(3):
         for eye in ("image_2", "image_3"):
             assert sorted(os.listdir(str(tmp_path / ("dsgn_pgd_iters_%d" % k) / eye))) == ["000003.png", "000011.png"]
@@ -216,6 +218,8 @@ def test_srcnn_attack_clis_on_an_upstream_shaped_checkout(tmp_path):
     make_srcnn_checkpoint(str(tmp_path / "models_stereo" / "stereo_rcnn_12_6477.pth"))
     out = _run("srcnn_pgd_attack", ["--iter", "2", "--eps", "0.03", "--debug", "--debugnum", "2"], str(tmp_path), "srcnn_checkout")
     assert "Start iteration:  2" in out and "attacked 2 stereo pairs" in out
+    # the checkout's compiled model.roi_layers is replaced by the libadvengine package before its network code is imported, its convolutions adopted
+    assert "model.roi_layers -> eval_driving_safety_amd.upstream_shims.roi_layers" in out and "adopted 17 convolution modules (13 on libadvengine kernels, 12 BatchNorms folded, 3 ReLUs fused)" in out, out[-1500:]
     for k in range(3):
         assert sorted(os.listdir(str(tmp_path / ("stereo_rcnn_pgd_iters_%d" % k) / "image_3"))) == ["000007.png", "000010.png"]
     from PIL import Image
