@@ -420,6 +420,10 @@ class StereoRcnnR101(StereoRcnnShaped):
         self.kpts_convs = nn.ModuleList(FoldedConv(c, c, 3, padding=1, gen=g) for _ in range(6))
         self.kpts_up = nn.ConvTranspose2d(c, c, 2, stride=2)
         self.kpts_class = FoldedConv(c, 6, 1, gen=g, gain=0.1)
+        # the 2x2 / stride-2 transposed convolution computed as a 1x1 convolution to 4 x c channels (kpts_logits): its weights are a
+        # re-layout of kpts_up's, refreshed whenever those change (a checkpoint load)
+        self.kpts_up_1x1 = FoldedConv(c, 4 * c, 1, gen=torch.Generator().manual_seed(0))
+        self._kup_key = None
         with torch.no_grad():
             for m in (self.cls_score, self.bbox_pred, self.dim_orien_pred, self.kpts_up):
                 m.weight.copy_(torch.randn(m.weight.shape, generator=g) * (1.0 / m.weight[0].numel()) ** 0.5)
@@ -500,9 +504,22 @@ class StereoRcnnR101(StereoRcnnShaped):
         return self.top1(self.top7(pooled, relu=True), relu=True).flatten(1)
 
     def kpts_logits(self, feat14):
+        """six 3x3 convolutions -> transposed 2x2 / stride 2 (+ ReLU) to 28 x 28 -> 1x1 to six maps -> summed over the rows (stereo_rcnn.py:262-266).
+        A 2x2 / stride-2 transposed convolution has no overlapping taps: out[r, co, 2i+di, 2j+dj] = sum_ci x[r, ci, i, j] W[ci, co, di, dj] is a
+        1x1 convolution to the 4 x 256 channels (co, di, dj) - ONE GEMM with bias + ReLU in its epilogue on this package's kernel instead of
+        MIOpen's per-image GEMM + col2im loop (~600 launches and 4 ms per step, profiles/r04_r101_step_profile_before_kpts.json) - and the
+        1x1 class layer and the row sum read that tensor through views: channels (co) x "rows" (di, dj, i) x columns j, no pixel shuffle."""
         x = feat14
         for conv in self.kpts_convs:
             x = conv(x, relu=True)
-        self._extra_flops = getattr(self, "_extra_flops", 0) + 2 * x.shape[0] * 256 * 256 * 4 * 14 * 14
-        x = F.relu(self.kpts_up(x))                                               # [R,256,28,28]
-        return self.kpts_class(x).sum(2)                                          # [R,6,28]  (stereo_rcnn.py:264-266)
+        w, b = self.kpts_up.weight, self.kpts_up.bias
+        key = (w.data_ptr(), w._version, b._version, w.device)
+        if self._kup_key != key:
+            with torch.no_grad():
+                self.kpts_up_1x1.weight.copy_(w.permute(1, 2, 3, 0).reshape(4 * w.shape[1], w.shape[0], 1, 1))     # [(co, di, dj), ci]
+                self.kpts_up_1x1.bias.copy_(b.repeat_interleave(4))
+            self.kpts_up_1x1._prep, self._kup_key = None, key
+        r, c, h, wd = x.shape
+        z = self.kpts_up_1x1(x, relu=True)                                        # [R, (co, di, dj), 14, 14] = relu(kpts_up(x)) before the shuffle
+        k = self.kpts_class(z.view(r, c, 4 * h, wd))                              # [R, 6, (di, dj, i), j]
+        return k.view(r, 6, 2, 2, h, wd).sum(dim=(2, 4)).permute(0, 1, 3, 2).reshape(r, 6, 2 * wd)     # rows (i, di) summed; columns 2j + dj
