@@ -66,6 +66,19 @@ def _pair(v):
     return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
 
 
+def _numeric_padding(conv):
+    """``padding="valid"`` / ``"same"`` (stride 1, an even (k - 1) * dilation per axis) as the numbers torch would use; else the string"""
+    p = conv.padding
+    if not isinstance(p, str):
+        return tuple(p)
+    if p == "valid":
+        return tuple(0 for _ in conv.kernel_size)
+    tot = [d * (k - 1) for k, d in zip(conv.kernel_size, conv.dilation)]
+    if p == "same" and all(int(s) == 1 for s in conv.stride) and all(t % 2 == 0 for t in tot):
+        return tuple(t // 2 for t in tot)
+    return p
+
+
 def _same(v):
     """all entries of an int tuple equal -> that int, else None"""
     v = tuple(v) if isinstance(v, (tuple, list)) else (v,)
@@ -109,10 +122,12 @@ class AdoptedConv2d(_Adopted):
 
     def __init__(self, conv, weight, bias, relu=False):
         super().__init__(weight, bias, relu)
-        self.stride, self.padding, self.dilation, self.groups = _pair(conv.stride), _pair(conv.padding), _pair(conv.dilation), conv.groups
+        # (``padding`` may be the string "same" / "valid": such a layer keeps torch's operator, which takes the string as it is)
+        self.stride, self.dilation, self.groups = _pair(conv.stride), _pair(conv.dilation), conv.groups
+        self.padding = _numeric_padding(conv)
         self.padding_mode = conv.padding_mode
         k = tuple(weight.shape[2:])
-        s, p, d = _same(self.stride), _same(self.padding), _same(self.dilation)
+        s, p, d = _same(self.stride), (None if isinstance(self.padding, str) else _same(self.padding)), _same(self.dilation)
         self.native = (self.groups == 1 and self.padding_mode == "zeros" and s == 1 and k[0] == k[1] and
                        ((k[0] == 1 and p == 0 and d == 1) or (k[0] == 3 and d in (1, 2) and p == d)))
         self.kind = "conv2d %dx%d s%s d%s %d->%d%s" % (k[0], k[1], s, d, weight.shape[1] * self.groups, weight.shape[0], "" if self.native else " (torch + fused epilogue)")
@@ -132,10 +147,11 @@ class AdoptedConv3d(_Adopted):
 
     def __init__(self, conv, weight, bias, relu=False):
         super().__init__(weight, bias, relu)
-        self.stride, self.padding, self.dilation, self.groups = tuple(conv.stride), tuple(conv.padding), tuple(conv.dilation), conv.groups
+        self.stride, self.dilation, self.groups = tuple(conv.stride), tuple(conv.dilation), conv.groups
+        self.padding = _numeric_padding(conv)
         cout, cin = weight.shape[:2]
         s = _same(self.stride)
-        self.native = (tuple(weight.shape[2:]) == (3, 3, 3) and self.groups == 1 and _same(self.padding) == 1 and _same(self.dilation) == 1 and
+        self.native = (tuple(weight.shape[2:]) == (3, 3, 3) and self.groups == 1 and not isinstance(self.padding, str) and _same(self.padding) == 1 and _same(self.dilation) == 1 and
                        conv.padding_mode == "zeros" and ((s == 1 and (cin % 4 == 0 or cin < 4) and (cout % 4 == 0 or cout < 4)) or
                                                          (s == 2 and cout % 4 == 0 and cin % 4 == 0)))
         self.kind = "conv3d 3x3x3 s%s %d->%d%s" % (s, cin, cout, "" if self.native else " (torch + fused epilogue)")
