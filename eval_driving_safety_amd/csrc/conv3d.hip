@@ -664,7 +664,10 @@ __device__ __forceinline__ constexpr int tp_off(int a) { return a == 2 ? 1 : 0; 
 __device__ __forceinline__ constexpr int tp_par(int a) { return a == 0 ? 0 : 1; }     // output parity
 __device__ __forceinline__ constexpr int tp_tap(int a) { return a == 2 ? 2 : 1; }     // tap of the CLASS convolution (offset + 1)
 
-template <int kTT, int kTDt = 1>
+// <round 4> DMA = false: the stage goes global -> registers -> LDS (dword-aligned 16-byte loads, the row's last group masked element by
+// element) - any width, any 4-byte aligned input; W = 78 (the cost volume at 1/16 resolution) used to fall back to the class-as-tile-index
+// launch of the stride-1 kernel at 0.22 of the matrix peak.  Same LDS image of the tile, same accumulation order, same bits.
+template <int kTT, int kTDt = 1, bool DMA = true>
 __global__ __launch_bounds__(64 * kTT * kTDt, kTT * kTDt == 4 ? 2 : 1) void convt3d_k3_s2_mfma(const float* __restrict__ x, float* __restrict__ y, int Cin, int Cout,
                                                                   int cout_pad, int D, int H, int W, int tiles_w, int tiles_h, int cblocks,
                                                                   Epi epi) {
@@ -688,7 +691,7 @@ __global__ __launch_bounds__(64 * kTT * kTDt, kTT * kTDt == 4 ? 2 : 1) void conv
   const float* xb = x + static_cast<long long>(b) * Cin * vol;
 
   // what this lane moves per stage: float4 q = 64*k + lane of piece k (pieces wave, wave + 4, ...)
-  int xo[kTXPer];
+  int xo[kTXPer], xn[kTXPer];
   const float* wsrc[kTWPer];
 #pragma unroll
   for (int p = 0; p < kTXPer; ++p) {
@@ -697,8 +700,9 @@ __global__ __launch_bounds__(64 * kTT * kTDt, kTT * kTDt == 4 ? 2 : 1) void conv
     const int c = row / ((kTDt + 1) * (kTT + 1)), rem = row - c * (kTDt + 1) * (kTT + 1);
     const int dd = rem / (kTT + 1), hh = rem - dd * (kTT + 1);
     const int gd = d0 + dd, gh = h0 + hh, gw = w0 - 4 + 4 * j;
-    const bool ok = q < kTXF4 && j > 0 && gd < D && gh < H && gw + 3 < W;          // j = 0 (columns left of the tile) is never read
+    const bool ok = q < kTXF4 && j > 0 && gd < D && gh < H && (DMA ? gw + 3 < W : gw < W);   // j = 0 (columns left of the tile) is never read
     xo[p] = ok ? c * vol + gd * plane + gh * W + gw : -1;
+    xn[p] = ok ? (W - gw < 4 ? W - gw : 4) : 0;                                    // valid floats of the group (register path: the row's end)
   }
 #pragma unroll
   for (int p = 0; p < kTWPer; ++p) {
@@ -724,17 +728,62 @@ __global__ __launch_bounds__(64 * kTT * kTDt, kTT * kTDt == 4 ? 2 : 1) void conv
     }
   };
 
+  typedef float tv4 __attribute__((ext_vector_type(4)));
+  typedef tv4 tv4_u __attribute__((aligned(4)));
+  tv4 rx[kTXPer], rw[kTWPer];                           // DMA = false: a stage's groups on their way to LDS
+  auto fetch = [&](int c0) {
+#pragma unroll
+    for (int p = 0; p < kTXPer; ++p) {
+      tv4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (wave + kNW * p < kTXInstr && xn[p] > 0) {
+        const float* src = xb + static_cast<long long>(c0) * vol + xo[p];
+        if (xn[p] == 4) {
+          v = *reinterpret_cast<const tv4_u*>(src);
+        } else {                                        // the row's last, partial group: its floats one by one, zeros beyond the row
+          v.x = src[0];
+          if (xn[p] > 1) v.y = src[1];
+          if (xn[p] > 2) v.z = src[2];
+        }
+      }
+      rx[p] = v;
+    }
+#pragma unroll
+    for (int p = 0; p < kTWPer; ++p) {
+      tv4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (wave + kNW * p < kTWInstr && wsrc[p]) v = *reinterpret_cast<const tv4*>(wsrc[p] + static_cast<long long>(c0) * cout_pad);
+      rw[p] = v;
+    }
+  };
+  auto commit = [&](float* stage) {
+#pragma unroll
+    for (int p = 0; p < kTXPer; ++p) {
+      const int k = wave + kNW * p;
+      if (k < kTXInstr) *reinterpret_cast<tv4*>(stage + k * 256 + 4 * lane) = rx[p];
+    }
+#pragma unroll
+    for (int p = 0; p < kTWPer; ++p) {
+      const int k = wave + kNW * p;
+      if (k < kTWInstr) *reinterpret_cast<tv4*>(stage + kTSX + k * 256 + 4 * lane) = rw[p];
+    }
+  };
+
   f32x16 acc[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int v = 0; v < 16; ++v) acc[i][v] = 0.0f;
-  issue(0, lds);
+  if constexpr (DMA) {
+    issue(0, lds);
+  } else {
+    fetch(0);
+    commit(lds);
+  }
   __syncthreads();
   int cur = 0;
   for (int c0 = 0; c0 < Cin; c0 += kFC) {
     const int cn = c0 + kFC < Cin ? c0 + kFC : c0;      // the last stage fetches itself again (harmless): no branch in the body
-    issue(cn, lds + (cur ^ 1) * kTStage);
+    if constexpr (DMA) issue(cn, lds + (cur ^ 1) * kTStage);
+    else fetch(cn);
     __builtin_amdgcn_sched_barrier(0);
     const float* sxc = lds + cur * kTStage;
     const float* swc = sxc + kTSX;
@@ -755,6 +804,7 @@ __global__ __launch_bounds__(64 * kTT * kTDt, kTT * kTDt == 4 ? 2 : 1) void conv
         }
       }
     }
+    if constexpr (!DMA) commit(lds + (cur ^ 1) * kTStage);
     __syncthreads();
     cur ^= 1;
   }
@@ -1506,29 +1556,33 @@ static int convt3d_launch(const float* x, const float* const* w_prep_classes, co
     if (padded(2) < padded(tdv)) tdv = 2;
     if (padded(4) < padded(tdv)) tdv = 4;
     if (const char* e = adv_hook_value("ADV_CONV_T_TD")) tdv = e[0] == '4' ? 4 : (e[0] == '2' ? 2 : 1);
-    const bool all_classes = w % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 7) == 0 &&
-                             (reinterpret_cast<uintptr_t>(residual) & 7) == 0 && (reinterpret_cast<uintptr_t>(mask) & 7) == 0 && ntiles < (1LL << 31) &&
-                             !adv_hook("ADV_CONV_T_CLASS_TILES");
+    const bool dma = w % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && !adv_hook("ADV_CONV_T_NO_DMA");     // else: register-staged (any width)
+    const bool all_classes = (reinterpret_cast<uintptr_t>(y) & 7) == 0 && (reinterpret_cast<uintptr_t>(residual) & 7) == 0 &&
+                             (reinterpret_cast<uintptr_t>(mask) & 7) == 0 && ntiles < (1LL << 31) && !adv_hook("ADV_CONV_T_CLASS_TILES");
     if (mask != nullptr && !all_classes) return ADV_EINVAL;
     if (all_classes) {   // every class from one staging of the input tile (convt3d_k3_s2_mfma)
       for (int k = 0; k < 8; ++k) epi.cls_wp[k] = w_prep_classes[k];
+#define ADV_LAUNCH_T2(TT_, TD_, N_, TH_)                                                                                                     \
+  do {                                                                                                                                        \
+    const size_t lds_ = 2 * sizeof(float) * static_cast<size_t>(TGeo<TT_, TD_>::kStage);                                                      \
+    if (dma)                                                                                                                                  \
+      hipLaunchKernelGGL((convt3d_k3_s2_mfma<TT_, TD_, true>), dim3(static_cast<unsigned>(N_)), dim3(256), lds_, st, x, y, cin, cout,         \
+                         cblocks * 32, d, h, w, tiles_w, TH_, cblocks, epi);                                                                  \
+    else                                                                                                                                      \
+      hipLaunchKernelGGL((convt3d_k3_s2_mfma<TT_, TD_, false>), dim3(static_cast<unsigned>(N_)), dim3(256), lds_, st, x, y, cin, cout,        \
+                         cblocks * 32, d, h, w, tiles_w, TH_, cblocks, epi);                                                                  \
+    return adv_internal_finish_launch();                                                                                                      \
+  } while (0)
       if (tdv > 1) {
         const int th2 = (h + 4 / tdv - 1) / (4 / tdv);
         const long long nt = static_cast<long long>(tiles_w) * th2 * ((d + tdv - 1) / tdv) * b * cblocks;
         if (nt < (1LL << 31)) {
-          if (tdv == 2)
-            hipLaunchKernelGGL((convt3d_k3_s2_mfma<2, 2>), dim3(static_cast<unsigned>(nt)), dim3(256), 2 * sizeof(float) * static_cast<size_t>(TGeo<2, 2>::kStage), st, x, y,
-                               cin, cout, cblocks * 32, d, h, w, tiles_w, th2, cblocks, epi);
-          else
-            hipLaunchKernelGGL((convt3d_k3_s2_mfma<1, 4>), dim3(static_cast<unsigned>(nt)), dim3(256), 2 * sizeof(float) * static_cast<size_t>(TGeo<1, 4>::kStage), st, x, y,
-                               cin, cout, cblocks * 32, d, h, w, tiles_w, th2, cblocks, epi);
-          return adv_internal_finish_launch();
+          if (tdv == 2) ADV_LAUNCH_T2(2, 2, nt, th2);
+          ADV_LAUNCH_T2(1, 4, nt, th2);
         }
       }
-      const size_t lds = 2 * sizeof(float) * static_cast<size_t>(TGeo<tt>::kStage);
-      hipLaunchKernelGGL(convt3d_k3_s2_mfma<tt>, dim3(static_cast<unsigned>(ntiles)), dim3(64 * tt), lds, st, x, y, cin, cout, cblocks * 32, d, h, w,
-                         tiles_w, tiles_h, cblocks, epi);
-      return adv_internal_finish_launch();
+      ADV_LAUNCH_T2(4, 1, ntiles, tiles_h);
+#undef ADV_LAUNCH_T2
     }
     if (mask != nullptr) return ADV_EINVAL;
     epi.nclass = 8;   // one launch: the class is a tile index (launch_conv's persistent masked kernel)

@@ -862,7 +862,7 @@ def conv_transpose3d_k3_s2(x, classes, cout, relu=False, bias=None, residual=Non
 def conv_transpose3d_k3_s2_dgrad(grad, classes, cout, residual=None, mask=None):
     """(conv_transpose3d(grad) + residual) zeroed where mask <= 0, in ONE launch: the backward of a strided 3x3x3 convolution whose input
     (``mask``, a ReLU output) also feeds a skip path whose gradient is ``residual``.  Returns None where the library has no fused kernel
-    for the shape (W % 4 != 0 ...): the caller then adds / masks in passes of its own."""
+    for the call (misaligned tensors, W < 4): the caller then adds / masks in passes of its own."""
     xi, mk = _feat(grad, "grad"), _feat(mask, "mask")
     b, cin, d, h, w = xi.shape
     out = torch.empty((b, cout, 2 * d, 2 * h, 2 * w), dtype=torch.float32, device=xi.device)

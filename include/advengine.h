@@ -358,9 +358,10 @@ ADV_API int adv_conv3d_k3_ex_f32(const float* x, const float* w_prep, const floa
  *     [b,cout,2d,2h,2w] or NULL, + ReLU - as in adv_conv3d_k3_ex_f32) in ONE
  *     launch: the eight output parity classes k = (pd*2+ph)*2+pw as one tile index of the persistent masked kernel, class k with
  *     its own prepared weights w_prep_classes[k] (HOST array of 8 DEVICE pointers) and tap mask tap_masks[k] (HOST uint32[8]) -
- *     ops.conv_transpose3d_k3_s2_prep builds both.  With w % 4 == 0 a workgroup stages an input tile once and runs all 27 kernel
+ *     ops.conv_transpose3d_k3_s2_prep builds both.  A workgroup stages an input tile once and runs all 27 kernel
  *     taps on it, each into the accumulator of the class it feeds (0.61 of the float32 matrix peak on 64 -> 32 at the half-resolution
- *     cost-volume size); otherwise the classes' tiles (1 to 8 taps each) are interleaved over the workgroups of one launch.  Same bits
+ *     cost-volume size; LDS-DMA staging with w % 4 == 0 and a 16-byte aligned x, register staging for any other width); with y or
+ *     residual not 8-byte aligned the classes' tiles (1 to 8 taps each) are interleaved over the workgroups of one launch.  Same bits
  *     as eight adv_conv3d_k3_ex_f32 calls with out_stride 2 / out_offset (pd,ph,pw). */
 ADV_API int adv_conv_transpose3d_k3_s2_f32(const float* x, const float* const* w_prep_classes, const uint32_t* tap_masks,
                                            const float* bias, const float* residual, float* y, int b, int cin, int cout, int d,
@@ -371,8 +372,8 @@ ADV_API int adv_conv_transpose3d_k3_s2_f32(const float* x, const float* const* w
  *     the matching up-sampling layer's skip connection):  y = (conv_transpose(grad) + residual) zeroed where mask <= 0, with residual = the
  *     gradient arriving over the skip path (or NULL) and mask = x_in (laid out like y, must not be y) - i.e. the gradient w.r.t. the
  *     producer's PRE-activation, with neither an addition pass nor a relu-backward pass over the volume.  Same float operations in the same
- *     order as the three done apart.  Only the all-classes kernel applies the mask (w % 4 == 0, x 16-byte and y / residual / mask 8-byte
- *     aligned): anything else returns ADV_EINVAL and the caller does the two passes itself. */
+ *     order as the three done apart.  Only the all-classes kernel applies the mask (y / residual / mask 8-byte aligned, w >= 4):
+ *     anything else returns ADV_EINVAL and the caller does the two passes itself. */
 ADV_API int adv_conv_transpose3d_k3_s2_dgrad_f32(const float* x, const float* const* w_prep_classes, const uint32_t* tap_masks,
                                                  const float* residual, const float* mask, float* y, int b, int cin, int cout, int d,
                                                  int h, int w, adv_stream_t stream);

@@ -296,8 +296,8 @@ def test_hip_hourglass_skip_and_mask_in_the_down_layers_backward(w):
     """<round 4> an hourglass whose down-sampling layer's input also feeds the up-sampling layer's skip connection, with the producer's ReLU
     left to the down-sampling layer's backward (ops.Conv3dK3S2 skip_out / mask_input): the fused backward launch
     (adv_conv_transpose3d_k3_s2_dgrad_f32: transposed convolution + skip gradient + mask) equals the oracle's transposed convolution, numpy's
-    add and where bit for bit; the graph's values and input gradient equal torch's (1e-4).  w = 38: no fused kernel (W / 2 % 4 != 0), the
-    separate passes - same contract."""
+    add and where bit for bit; the graph's values and input gradient equal torch's (1e-4).  w = 38: the gradient volume is 19 wide - the
+    register-staged variant of the all-classes kernel (any width), same contract."""
     from eval_driving_safety_amd import ops
     dev = torch.device("cuda", 0)
     gen = torch.Generator(device=dev).manual_seed(4)
@@ -325,12 +325,9 @@ def test_hip_hourglass_skip_and_mask_in_the_down_layers_backward(w):
     wt_t = wd.cpu().numpy()                                                           # conv weight [out = 32, in = 16] read as ConvTranspose [in = 32, out = 16]
     want = C.conv_transpose3d_k3_s2(gy.cpu().numpy(), wt_t) + gs.cpu().numpy()
     want = np.where(am.detach().cpu().numpy() > 0, want, np.float32(0)).astype(np.float32)
-    if (w // 2) % 4 == 0:
-        assert fused is not None and fused.cpu().numpy().tobytes() == want.tobytes()
-        assert torch.equal(ops.conv_transpose3d_k3_s2_dgrad(gy, classes, 16, mask=am.detach()),
-                           ops.relu_backward(ops.conv_transpose3d_k3_s2(gy, classes, 16), am.detach()))
-    else:
-        assert fused is None
+    assert fused is not None and fused.cpu().numpy().tobytes() == want.tobytes()
+    assert torch.equal(ops.conv_transpose3d_k3_s2_dgrad(gy, classes, 16, mask=am.detach()),
+                       ops.relu_backward(ops.conv_transpose3d_k3_s2(gy, classes, 16), am.detach()))
 
 
 @pytest.mark.gpu
@@ -361,7 +358,9 @@ def test_hip_residual_epilogue_equals_conv_then_add_then_relu(shape, route):
         classes = ops.conv_transpose3d_k3_s2_prep(torch.tensor(w_t, device=dev))
         skip2 = torch.tensor(rs.randn(b, cout, 2 * d, 2 * h, 2 * w).astype(np.float32), device=dev)
         # (<round 4> ADV_CONV_T_TD: the all-classes kernel's tile as 1 x 4, 2 x 2 or 4 x 1 input planes x rows - the host picks by padding)
-        for env in ({}, {"ADV_CONV_T_CLASS_TILES": "1"}, {"ADV_CONV_CLASS_LAUNCHES": "1"}, {"ADV_CONV_T_TD": "1"}, {"ADV_CONV_T_TD": "2"}, {"ADV_CONV_T_TD": "4"}):
+        # (ADV_CONV_T_NO_DMA: the register-staged variant - what widths that are not multiples of 4 take - on every shape)
+        for env in ({}, {"ADV_CONV_T_CLASS_TILES": "1"}, {"ADV_CONV_CLASS_LAUNCHES": "1"}, {"ADV_CONV_T_TD": "1"}, {"ADV_CONV_T_TD": "2"}, {"ADV_CONV_T_TD": "4"},
+                    {"ADV_CONV_T_NO_DMA": "1"}, {"ADV_CONV_T_NO_DMA": "1", "ADV_CONV_T_TD": "2"}, {"ADV_CONV_T_NO_DMA": "1", "ADV_CONV_T_TD": "4"}):
             with (route(**env) if env else contextlib.nullcontext()):
                 got = ops.conv_transpose3d_k3_s2(tx, classes, cout, bias=tb, relu=True, residual=skip2)
                 want_t = np.maximum(C.conv_transpose3d_k3_s2(x, w_t, bias=bias) + skip2.cpu().numpy(), np.float32(0))
