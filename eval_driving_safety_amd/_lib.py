@@ -102,7 +102,7 @@ SIGNATURES = {
     "adv_sigmoid_focal_loss_f32": [_P, _P, _P, _P, _L, _I, _F, _F, _P],
     "adv_relu_backward_f32": [_P, _P, _P, _L, _P],
     "adv_bev_fold_f32": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
-    "adv_bev_fold_bwd_f32": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "adv_bev_fold_bwd_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "adv_conv2d_1x1_prep_weights_f32": [_P, _P, _I, _I, _I, _P],
     "adv_conv2d_1x1_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _L, _I, _I, _P],
     "adv_bias_act_f32": [_P, _P, _P, _L, _I, _L, _I, _P],

@@ -886,7 +886,7 @@ class DsgnShapedAdapter(PsvStereoAdapter):
             t, pres = self._c3(pre, "gh3", "consumer", chain_in=True, skip_out=True)
             h = self._c3(t, "gh4", True, chain_in=True)
             post = self._c3(h, "gh5", True, pres)
-            g = self._c3(post, "gh6", True, g1s)
+            g = self._c3(post, "gh6", "consumer", g1s)                     # its only consumer is the bird's-eye-view fold, whose backward masks
         else:
             g1 = self._c3(gv, "gv1", True)
             pre = self._c3(self._c3(g1, "gh1", True), "gh2", True)
@@ -896,8 +896,8 @@ class DsgnShapedAdapter(PsvStereoAdapter):
         bb, c, zg, yg, xg = g.shape
         if self.torch_ops or not g.is_cuda:
             bev = F.avg_pool3d(g, (1, self.ypool, 1)).permute(0, 1, 3, 2, 4).reshape(bb, c * (yg // self.ypool), zg, xg)
-        else:       # the same values, one pass each way
-            bev = ops.BevFold.apply(g, self.ypool)
+        else:       # the same values, one pass each way (and gh6's ReLU backward inside the fold's, where gh6 left it to us)
+            bev = ops.BevFold.apply(g, self.ypool, bool(ch))
         b0 = self._c2(bev, "bev_a", True)
         pre2 = self._c2(self._c2(b0, "bh1", True), "bh2", True)
         h2 = self._c2(self._c2(pre2, "bh3", True), "bh4", True)

@@ -557,8 +557,10 @@ __global__ __launch_bounds__(kBlock) void bev_fold_fwd(const float* __restrict__
   }
 }
 
-__global__ __launch_bounds__(kBlock) void bev_fold_bwd(const float* __restrict__ gout, float* __restrict__ gv, int C, int Z, int Y, int X, int P, int Yp,
-                                                       long long total) {
+// mask (the forward's input v, a ReLU output whose only consumer is this fold; or null): the gradient is zeroed where v <= 0 - the producer's
+// ReLU backward without a pass of its own over the volume
+__global__ __launch_bounds__(kBlock) void bev_fold_bwd(const float* __restrict__ gout, const float* __restrict__ mask, float* __restrict__ gv, int C, int Z,
+                                                       int Y, int X, int P, int Yp, long long total) {
   for (long long i = static_cast<long long>(blockIdx.x) * kBlock + threadIdx.x; i < total; i += static_cast<long long>(gridDim.x) * kBlock) {
     const int x = static_cast<int>(i % X);
     long long r = i / X;
@@ -569,6 +571,7 @@ __global__ __launch_bounds__(kBlock) void bev_fold_bwd(const float* __restrict__
     const int yy = y / P;
     float g = 0.0f;
     if (yy < Yp) g = gout[((r * Yp + yy) * Z + z) * X + x] / static_cast<float>(P);
+    if (mask != nullptr && !(__builtin_nontemporal_load(mask + i) > 0.0f)) g = 0.0f;
     __builtin_nontemporal_store(g, gv + i);
   }
 }
@@ -698,14 +701,14 @@ int adv_bev_fold_f32(const float* v, float* out, int b, int c, int z, int y, int
   return adv_internal_finish_launch();
 }
 
-int adv_bev_fold_bwd_f32(const float* grad_out, float* grad_v, int b, int c, int z, int y, int x, int pool, adv_stream_t stream) {
-  if (!grad_out || !grad_v || grad_out == grad_v || b < 1 || c < 1 || z < 1 || y < 1 || x < 1 || pool < 1 || pool > y) return ADV_EINVAL;
-  if (!aligned4(grad_out) || !aligned4(grad_v)) return ADV_EALIGN;
+int adv_bev_fold_bwd_f32(const float* grad_out, const float* mask, float* grad_v, int b, int c, int z, int y, int x, int pool, adv_stream_t stream) {
+  if (!grad_out || !grad_v || grad_out == grad_v || mask == grad_v || b < 1 || c < 1 || z < 1 || y < 1 || x < 1 || pool < 1 || pool > y) return ADV_EINVAL;
+  if (!aligned4(grad_out) || !aligned4(grad_v) || !aligned4(mask)) return ADV_EALIGN;
   const long long total = static_cast<long long>(b) * c * z * y * x;
   long long blocks = (total + kBlock - 1) / kBlock;
   if (blocks > 65535LL * 16) blocks = 65535LL * 16;
-  hipLaunchKernelGGL(bev_fold_bwd, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), grad_out, grad_v, c, z, y, x, pool,
-                     y / pool, total);
+  hipLaunchKernelGGL(bev_fold_bwd, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), grad_out, mask, grad_v, c, z, y, x,
+                     pool, y / pool, total);
   return adv_internal_finish_launch();
 }
 

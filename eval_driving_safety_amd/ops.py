@@ -1009,9 +1009,11 @@ class ConvTranspose3dK3S2(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, classes, w_prep_fwd, cout, bias=None, relu=False, residual=None):
-        ctx.w_prep_fwd, ctx.cin, ctx.relu, ctx.has_res = w_prep_fwd, x.shape[1], bool(relu), residual is not None
-        y = conv_transpose3d_k3_s2(x.contiguous(), classes, cout, relu=relu, bias=bias, residual=None if residual is None else residual.contiguous())
-        ctx.save_for_backward(y if relu else None)
+        """relu="consumer": the ReLU is applied here, its backward mask by this layer's only consumer (ops.BevFold mask_input)"""
+        ctx.w_prep_fwd, ctx.cin, ctx.has_res = w_prep_fwd, x.shape[1], residual is not None
+        ctx.relu = bool(relu) and relu != "consumer"
+        y = conv_transpose3d_k3_s2(x.contiguous(), classes, cout, relu=bool(relu), bias=bias, residual=None if residual is None else residual.contiguous())
+        ctx.save_for_backward(y if ctx.relu else None)
         return y
 
     @staticmethod
@@ -1523,14 +1525,19 @@ def bev_fold(v, pool):
     return out
 
 
-def bev_fold_bwd(grad_out, shape, pool):
+def bev_fold_bwd(grad_out, shape, pool, mask=None):
+    """the fold's backward; ``mask`` (the forward's input, a ReLU output) zeroes the gradient where it is <= 0"""
     g = _feat(grad_out, "grad_out")
     b, c, z, y, x = shape
     if tuple(g.shape) != (b, c * (y // pool), z, x):
         raise ValueError("grad_out must be [B, C * (Y // pool), Z, X]")
+    if mask is not None:
+        mask = _feat(mask, "mask")
+        if tuple(mask.shape) != tuple(shape):
+            raise ValueError("mask must be laid out like the fold's input")
     gv = torch.empty(tuple(shape), dtype=torch.float32, device=g.device)
     with _on(g):
-        _lib.call("adv_bev_fold_bwd_f32", _ptr(g), _ptr(gv), b, c, z, y, x, int(pool), _stream(g))
+        _lib.call("adv_bev_fold_bwd_f32", _ptr(g), None if mask is None else _ptr(mask), _ptr(gv), b, c, z, y, x, int(pool), _stream(g))
     return gv
 
 
@@ -1539,13 +1546,18 @@ class BevFold(torch.autograd.Function):
     one HBM-bound pass each (csrc/volume.hip) instead of torch's pooling kernel + permuting copy and their two backward passes"""
 
     @staticmethod
-    def forward(ctx, v, pool):
+    def forward(ctx, v, pool, mask_input=False):
+        """``mask_input``: v is a ReLU output this fold alone consumes and its producer left the mask to us (relu="consumer"): the gradient
+        returned is already multiplied by (v > 0)"""
         ctx.shape, ctx.pool = tuple(v.shape), int(pool)
-        return bev_fold(v.contiguous(), pool)
+        v = v.contiguous()
+        ctx.save_for_backward(v if mask_input else None)
+        return bev_fold(v, pool)
 
     @staticmethod
     def backward(ctx, grad_out):
-        return bev_fold_bwd(grad_out.contiguous(), ctx.shape, ctx.pool), None
+        (v,) = ctx.saved_tensors
+        return bev_fold_bwd(grad_out.contiguous(), ctx.shape, ctx.pool, mask=v), None, None
 
 
 def sigmoid_focal_loss(logits, targets, gamma=2.0, alpha=0.25, want_grad=False):

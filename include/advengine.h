@@ -443,9 +443,12 @@ ADV_API int adv_sigmoid_focal_loss_f32(const float* logits, const int32_t* targe
 /* Bird's-eye-view fold (DSGN: F.avg_pool3d(v, (1, pool, 1)).permute(0, 1, 3, 2, 4).reshape(B, C * Y/pool, Z, X), reached at
  *     attack/DSGN/pgd_attack.py:308): v [b,c,z,y,x] -> out [b, c * (y / pool), z, x], out[b, ch*Yp + yy, z, x] = the float32 sum of
  *     v[b, ch, z, pool*yy + k, x] over k ascending, divided by pool (rows past Yp * pool dropped, as avg_pool3d floors).  One pass
- *     instead of a pooling kernel and a permuting copy; _bwd writes every element of grad_v (grad_out / pool, zero in dropped rows). */
+ *     instead of a pooling kernel and a permuting copy; _bwd writes every element of grad_v (grad_out / pool, zero in dropped rows); its
+ *     mask (laid out like v, or NULL) = the forward's input when that is a ReLU output consumed by the fold alone: grad_v is zeroed where
+ *     mask <= 0, i.e. it is the gradient w.r.t. the producer's pre-activation. */
 ADV_API int adv_bev_fold_f32(const float* v, float* out, int b, int c, int z, int y, int x, int pool, adv_stream_t stream);
-ADV_API int adv_bev_fold_bwd_f32(const float* grad_out, float* grad_v, int b, int c, int z, int y, int x, int pool, adv_stream_t stream);
+ADV_API int adv_bev_fold_bwd_f32(const float* grad_out, const float* mask, float* grad_v, int b, int c, int z, int y, int x, int pool,
+                                 adv_stream_t stream);
 
 /* ---- 2D convolutions of the detectors' backbones on the matrix cores (float32 MFMA).  Upstream code reached through
  *      attack/Stereo-RCNN/pgd_attack.py:156 (ResNet-101-FPN: attack/Stereo-RCNN/stereo_rcnn.py:157-187) and attack/DSGN/pgd_attack.py:308

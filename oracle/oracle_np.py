@@ -527,7 +527,9 @@ def bev_fold(v, pool):
     return out.reshape(b, c * yp, z, x)
 
 
-def bev_fold_bwd(grad_out, shape, pool):
+def bev_fold_bwd(grad_out, shape, pool, mask=None):
+    if mask is not None:
+        return np.where(_f32(mask) > 0, bev_fold_bwd(grad_out, shape, pool), F32(0)).astype(np.float32)
     g = _f32(grad_out)
     b, c, z, y, x = shape
     yp = y // pool

@@ -236,5 +236,9 @@ def test_hip_bev_fold_fwd_bwd_bit_exact(cfg):
     g = rs.randn(*out.shape).astype(np.float32)
     out.backward(torch.tensor(g, device=dev))
     assert tv.grad.cpu().numpy().tobytes() == O.bev_fold_bwd(g, cfg["shape"], p).tobytes()
+    # the producer's ReLU mask inside the fold's backward (mask_input): grad where v > 0, zero elsewhere
+    tv2 = torch.tensor(v, device=dev, requires_grad=True)
+    ops.BevFold.apply(tv2, p, True).backward(torch.tensor(g, device=dev))
+    assert tv2.grad.cpu().numpy().tobytes() == O.bev_fold_bwd(g, cfg["shape"], p, mask=v).tobytes()
     with pytest.raises(ValueError):
         ops.bev_fold(tv.detach(), v.shape[3] + 1)
