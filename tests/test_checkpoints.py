@@ -3,7 +3,6 @@ attack/Stereo-RCNN/pgd_attack.py:94-97 into surrogates.StereoRcnnR101 and ``stat
 into adapters.DsgnShapedAdapter.  The upstream-named state dicts are produced by torch modules written HERE with the module names the
 reference's substitute files spell out (stereo_rcnn.py:69-85,157-171; stereo_rpn.py:32-40) - BatchNorms with non-trivial statistics -
 and the loaded graph must compute what that module computes.  CPU."""
-import numpy as np
 import pytest
 import torch
 import torch.nn as nn

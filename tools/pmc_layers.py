@@ -67,8 +67,8 @@ def main():
     for name, c, k, d, h, w in (("hg6", 64, 32, 24, 48, 156), ("gh6", 128, 64, 96, 10, 152), ("hg5", 64, 64, 12, 24, 78), ("gh5", 128, 128, 48, 5, 76)):
         x, wt, bias = rnd(1, c, d, h, w), rnd(c, k, 3, 3, 3) * 0.03, rnd(k)
         cls = ops.conv_transpose3d_k3_s2_prep(wt)
-        # (a width that is not a multiple of 4 - 78 at 1/16 resolution - takes the persistent masked stride-1 kernel, one launch for the eight classes)
-        case("t2 %s %d->%d on [1,%d,%d,%d,%d]" % (name, c, k, c, d, h, w), "convt3d_k3_s2_mfma" if w % 4 == 0 else "conv3d_k3_mfma", 2.0 * k * c * 27 * d * h * w,
+        # (a width that is not a multiple of 4 - 78 at 1/16 resolution - takes the register-staged variant of the same kernel)
+        case("t2 %s %d->%d on [1,%d,%d,%d,%d]" % (name, c, k, c, d, h, w), "convt3d_k3_s2_mfma", 2.0 * k * c * 27 * d * h * w,
              lambda: ops.conv_transpose3d_k3_s2(x, cls, k, relu=True, bias=bias))
     # ---- RoIAlign backward: 512 proposals, 7x7 and 14x14, on a P2-sized map
     rs = torch.Generator().manual_seed(3)
