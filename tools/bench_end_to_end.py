@@ -334,6 +334,7 @@ def measure_patch(pairs=8, iters=2, reps=2):
 def measure_distributed(dist, dev, rank, world, fence, iters=20, patch_pairs_per_rank=2):
     """What the scaling run measures beyond the collective-free perturbation kernel - EVERY rank runs this:
       image_sharded_attack   the DSGN-shaped 20-step PGD on the rank's OWN stereo pair (SURVEY 8e: pairs shard by image, no collective);
+                             every rank times its own attack on its own clock (no barrier inside: the leg holds no collective at all);
                              aggregate pairs/s = world pairs / the slowest rank's time, per-rank min / max beside it;
       universal_patch        one universal-patch epoch (D = 101, 2 inner iterations per pair, BASELINE configs[3]) with the patch delta
                              all-reduced INSIDE the loop (attacks.PatchTrainer -> Comm.all_reduce_sum_: RCCL over xGMI, gloo in the
@@ -351,19 +352,27 @@ def measure_distributed(dist, dev, rank, world, fence, iters=20, patch_pairs_per
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return [float(q) for q in t.cpu()]
 
-    net = adapters.DsgnShapedAdapter(dev, seed=0)   # every rank holds the same detector (model replicas only)
-    batch = next(iter(data.SyntheticStereo(1, "dsgn", batch=1, seed=100 + rank)))
-    batch.extra = net.synthetic_extra(batch, seed=1 + rank)
-    x = torch.cat([batch.imgL, batch.imgR]).to(dev)
-    for _ in range(2):
-        net.loss_and_grad(x, batch.extra)
-    atk = attacks.PgdAttack("dsgn", 1 / 255, 0.03, iters, save=False, device=dev)
-    fence()
-    t0 = time.perf_counter()
-    atk.run_batch(batch, net)
-    torch.cuda.synchronize()
-    mine = time.perf_counter() - t0
-    fence()
+    # Phase A holds NO collective (the attack shards by image and needs none): a rank that fails here fails alone, and the flag exchange
+    # right after it is the first thing every rank reaches - so one rank's exception cannot leave the others waiting inside a collective.
+    ok, why, mine, atk, net = 1.0, None, 0.0, None, None
+    try:
+        net = adapters.DsgnShapedAdapter(dev, seed=0)   # every rank holds the same detector (model replicas only)
+        batch = next(iter(data.SyntheticStereo(1, "dsgn", batch=1, seed=100 + rank)))
+        batch.extra = net.synthetic_extra(batch, seed=1 + rank)
+        x = torch.cat([batch.imgL, batch.imgR]).to(dev)
+        for _ in range(2):
+            net.loss_and_grad(x, batch.extra)
+        atk = attacks.PgdAttack("dsgn", 1 / 255, 0.03, iters, save=False, device=dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        atk.run_batch(batch, net)
+        torch.cuda.synchronize()
+        mine = time.perf_counter() - t0
+    except Exception as e:                              # reported, and the patch leg (which has collectives) is skipped on every rank
+        ok, why = 0.0, repr(e)
+    oks = gather(ok)
+    if min(oks) < 1.0:
+        return {"error": "the image-sharded leg failed on rank(s) %s%s" % ([i for i, v in enumerate(oks) if v < 1.0], ": " + why if why else "")} if rank == 0 else None
     times = gather(mine)
     sharded = {"metric": "aggregate stereo-pairs/s, %d-step PGD through the DSGN-shaped graph, one pair per rank, image-sharded, no collective" % iters,
                "value": world / max(times), "unit": "stereo-pairs/s", "per_rank_pairs_per_s_min": 1.0 / max(times), "per_rank_pairs_per_s_max": 1.0 / min(times),
