@@ -23,7 +23,7 @@ ADV_ELAUNCH = -5
 ADV_SPACE_AFFINE = 0
 ADV_SPACE_IDENTITY = 1
 ADV_SPACE_AFFINE_RCP = 2
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class AdvSpace(ctypes.Structure):
@@ -103,6 +103,8 @@ SIGNATURES = {
     "adv_relu_backward_f32": [_P, _P, _P, _L, _P],
     "adv_bev_fold_f32": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "adv_bev_fold_bwd_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "adv_bilinear_up_f32": [_P, _P, _L, _I, _I, _I, _I, _P],
+    "adv_bilinear_up_bwd_f32": [_P, _P, _L, _I, _I, _I, _I, _P],
     "adv_conv2d_1x1_prep_weights_f32": [_P, _P, _I, _I, _I, _P],
     "adv_conv2d_1x1_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _L, _I, _I, _P],
     "adv_bias_act_f32": [_P, _P, _P, _L, _I, _L, _I, _P],

@@ -570,10 +570,17 @@ class _BilinearUp(torch.autograd.Function):
     differ from run to run in its last bits.  The up-sampling is linear and separable, up = A_h . x . A_w^T, so its adjoint is
     A_h^T . g . A_w - two small matrix products in a fixed order (the interpolation matrices are read off F.interpolate itself)."""
 
+    _matrices = {}
+
     @staticmethod
     def _matrix(n_in, n_out, device):
-        eye = torch.eye(n_in, device=device).view(1, n_in, n_in, 1)
-        return F.interpolate(eye, size=(n_out, 1), mode="bilinear", align_corners=False)[0, :, :, 0].t().contiguous()     # [n_out, n_in]
+        key = (n_in, n_out, device)
+        m = _BilinearUp._matrices.get(key)
+        if m is None:                           # once per (size pair, device): the matrices depend on nothing else
+            eye = torch.eye(n_in, device=device).view(1, n_in, n_in, 1)
+            m = F.interpolate(eye, size=(n_out, 1), mode="bilinear", align_corners=False)[0, :, :, 0].t().contiguous()     # [n_out, n_in]
+            _BilinearUp._matrices[key] = m
+        return m
 
     @staticmethod
     def forward(ctx, x, size):

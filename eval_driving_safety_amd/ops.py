@@ -1513,6 +1513,43 @@ class GridSample3d(torch.autograd.Function):
         return grid_sample3d_bwd(grad_out.contiguous(), ctx.plan), None, None
 
 
+def bilinear_up(x, size):
+    """F.interpolate(x, size, mode="bilinear", align_corners=False) for x [B,C,h,w] (csrc/resize.hip)"""
+    xi = _feat(x, "x")
+    if xi.dim() != 4 or len(size) != 2 or min(size) < 1:
+        raise ValueError("x must be [B,C,h,w] and size (ho, wo)")
+    b, c, h, w = xi.shape
+    out = torch.empty((b, c, int(size[0]), int(size[1])), dtype=torch.float32, device=xi.device)
+    with _on(xi):
+        _lib.call("adv_bilinear_up_f32", _ptr(xi), _ptr(out), b * c, h, w, int(size[0]), int(size[1]), _stream(xi))
+    return out
+
+
+def bilinear_up_bwd(grad_out, in_hw):
+    """the adjoint of bilinear_up as a fixed-order gather: reproducible bit for bit (torch's backward scatters with atomicAdd)"""
+    g = _feat(grad_out, "grad_out")
+    if g.dim() != 4:
+        raise ValueError("grad_out must be [B,C,ho,wo]")
+    b, c, ho, wo = g.shape
+    gin = torch.empty((b, c, int(in_hw[0]), int(in_hw[1])), dtype=torch.float32, device=g.device)
+    with _on(g):
+        _lib.call("adv_bilinear_up_bwd_f32", _ptr(g), _ptr(gin), b * c, int(in_hw[0]), int(in_hw[1]), ho, wo, _stream(g))
+    return gin
+
+
+class BilinearUp(torch.autograd.Function):
+    """the FPN top-down path's up-sampling (attack/Stereo-RCNN/stereo_rcnn.py:92-108) with a deterministic backward"""
+
+    @staticmethod
+    def forward(ctx, x, size):
+        ctx.in_hw = tuple(x.shape[2:])
+        return bilinear_up(x.contiguous(), size)
+
+    @staticmethod
+    def backward(ctx, grad):
+        return bilinear_up_bwd(grad.contiguous(), ctx.in_hw), None
+
+
 def bev_fold(v, pool):
     """[B,C,Z,Y,X] -> [B, C * (Y // pool), Z, X]: F.avg_pool3d(v, (1, pool, 1)).permute(0, 1, 3, 2, 4).reshape(...) in one pass"""
     vi = _feat(v, "v")

@@ -49,6 +49,16 @@ def _decode(src, d):
     return torch.stack([cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w - 1, cy + 0.5 * h - 1], 1)
 
 
+def _bilinear_up(x, size):
+    """F.interpolate(x, size, "bilinear", align_corners=False).  On the GPU torch's BACKWARD of it scatters with atomicAdd, so the attack
+    gradient would differ in its last bits from run to run: ops.BilinearUp (csrc/resize.hip) is the same operator with a fixed-order
+    gather as its backward.  The CPU path keeps torch's own (sequential, deterministic) operator - it is the fixtures' one."""
+    if x.is_cuda:
+        from . import ops
+        return ops.BilinearUp.apply(x, tuple(size))
+    return F.interpolate(x, size=tuple(size), mode="bilinear", align_corners=False)
+
+
 class StereoRcnnShaped(nn.Module):
     LEVELS = (2, 3, 4, 5)                # pyramid levels P2..P5, strides 4..32
     ANCHOR_RATIOS = (0.5, 1.0, 2.0)
@@ -99,8 +109,7 @@ class StereoRcnnShaped(nn.Module):
         p = [None] * 4
         p[3] = self.lat[3](feats[3])
         for i in (2, 1, 0):               # _upsample_add (stereo_rcnn.py:92-108): bilinear to the lateral map's size
-            up = F.interpolate(p[i + 1], size=feats[i].shape[2:], mode="bilinear", align_corners=False)
-            p[i] = up + self.lat[i](feats[i])
+            p[i] = _bilinear_up(p[i + 1], feats[i].shape[2:]) + self.lat[i](feats[i])
         return [self.smooth[i](p[i]) for i in range(4)]
 
     def pyramid_pair(self, im_left, im_right):
@@ -120,7 +129,7 @@ class StereoRcnnShaped(nn.Module):
     def kpts_logits(self, feat14):
         """[R,C,14,14] -> [R,6,28]: 4 keypoint types + left border + right border over the 28 horizontal bins"""
         k = self.kpts_class(F.relu(self.kpts_conv(feat14)))
-        return F.interpolate(k, size=(14, self.GRID), mode="bilinear", align_corners=False).mean(2)
+        return _bilinear_up(k, (14, self.GRID)).mean(2)
 
     def anchors(self, level_idx, h, w, device):
         stride = 4 * 2 ** level_idx
@@ -459,8 +468,7 @@ class StereoRcnnR101(StereoRcnnShaped):
         p = [None, None, None, p5]
         for i, (lat, feat) in enumerate(zip(self.lat, (c4, c3, c2))):            # _upsample_add then smooth (stereo_rcnn.py:164-169)
             lvl = 2 - i
-            up = F.interpolate(p[lvl + 1], size=feat.shape[2:], mode="bilinear", align_corners=False)
-            p[lvl] = self.smooth[i](lat(feat, residual=up))
+            p[lvl] = self.smooth[i](lat(feat, residual=_bilinear_up(p[lvl + 1], feat.shape[2:])))
         p6 = p5[:, :, ::2, ::2]                                                   # nn.MaxPool2d(1, stride=2) (stereo_rcnn.py:39,170)
         return p + [p6]
 

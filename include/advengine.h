@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ADV_ABI_VERSION 7
+#define ADV_ABI_VERSION 8
 #define ADV_API __attribute__((visibility("default"))) /* the library is built with -fvisibility=hidden */
 #define ADV_CHANNELS 3
 
@@ -449,6 +449,14 @@ ADV_API int adv_sigmoid_focal_loss_f32(const float* logits, const int32_t* targe
 ADV_API int adv_bev_fold_f32(const float* v, float* out, int b, int c, int z, int y, int x, int pool, adv_stream_t stream);
 ADV_API int adv_bev_fold_bwd_f32(const float* grad_out, const float* mask, float* grad_v, int b, int c, int z, int y, int x, int pool,
                                  adv_stream_t stream);
+
+/* Bilinear up-sampling of a pyramid level, align_corners = False (the FPN top-down path's _upsample_add,
+ *     attack/Stereo-RCNN/stereo_rcnn.py:92-108: F.upsample(x, size=(H, W), mode='bilinear') + y; also DSGN's pooled feature branches):
+ *     x [nc,h,w] -> out [nc,ho,wo] for any size pair, source coordinate max(fmaf(in / out, o + 0.5, -0.5), 0) in float32.
+ *     _bwd is its adjoint as a GATHER - every grad_in element is a sum in a fixed order (output rows, then columns, ascending; zero
+ *     weights skipped), so the result is reproducible bit for bit, where a scattering backward with atomics is not. */
+ADV_API int adv_bilinear_up_f32(const float* x, float* out, int64_t nc, int h, int w, int ho, int wo, adv_stream_t stream);
+ADV_API int adv_bilinear_up_bwd_f32(const float* grad_out, float* grad_in, int64_t nc, int h, int w, int ho, int wo, adv_stream_t stream);
 
 /* ---- 2D convolutions of the detectors' backbones on the matrix cores (float32 MFMA).  Upstream code reached through
  *      attack/Stereo-RCNN/pgd_attack.py:156 (ResNet-101-FPN: attack/Stereo-RCNN/stereo_rcnn.py:157-187) and attack/DSGN/pgd_attack.py:308

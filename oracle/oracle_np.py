@@ -541,6 +541,62 @@ def bev_fold_bwd(grad_out, shape, pool, mask=None):
     return gv
 
 
+def _up_taps(n_in, n_out):
+    """csrc/resize.hip source_of: per output index (i0, i1, l0, l1) - torch's align_corners=False source coordinate in float32"""
+    sc = np.float32(n_in) / np.float32(n_out)
+    o = np.arange(n_out, dtype=np.float32)
+    # fmaf(scale, o + 0.5, -0.5): the product of two float32 is exact in float64 and so is the sum here (< 2^12, bits down to 2^-37): one rounding
+    src = np.maximum((sc.astype(np.float64) * (o + F32(0.5)).astype(np.float64) - 0.5).astype(np.float32), F32(0)).astype(np.float32)
+    i0 = np.minimum(src.astype(np.int64), n_in - 1)
+    i1 = i0 + (i0 < n_in - 1)
+    l1 = (src - i0.astype(np.float32)).astype(np.float32)
+    return i0, i1, (F32(1) - l1).astype(np.float32), l1
+
+
+def bilinear_up(x, size):
+    """csrc/resize.hip bilinear_up_fwd (F.interpolate(x, size, mode="bilinear", align_corners=False); the FPN's _upsample_add,
+    attack/Stereo-RCNN/stereo_rcnn.py:92-108): x [..., h, w] -> [..., ho, wo], every product and sum rounded on its own"""
+    x = _f32(x)
+    h, w = x.shape[-2:]
+    y0, y1, ly0, ly1 = _up_taps(h, size[0])
+    x0, x1, lx0, lx1 = _up_taps(w, size[1])
+    top = (lx0 * x[..., y0, :][..., x0]).astype(np.float32) + (lx1 * x[..., y0, :][..., x1]).astype(np.float32)
+    bot = (lx0 * x[..., y1, :][..., x0]).astype(np.float32) + (lx1 * x[..., y1, :][..., x1]).astype(np.float32)
+    return ((ly0[:, None] * top).astype(np.float32) + (ly1[:, None] * bot).astype(np.float32)).astype(np.float32)
+
+
+def bilinear_up_bwd(grad_out, in_hw):
+    """csrc/resize.hip bilinear_up_bwd, the adjoint as a gather: grad_in[iy][ix] = the sum over output rows ascending, columns ascending of
+    (wy * wx) * g with w(o, i) = (i0(o) == i ? l0 : 0) + (i1(o) == i ? l1 : 0), zero weights skipped.  Walking the outputs in raster
+    order and adding each to the pixels it reads visits every input pixel's terms in exactly that order."""
+    g = _f32(grad_out)
+    h, w = in_hw
+    ho, wo = g.shape[-2:]
+    lead = g.shape[:-2]
+    gin = np.zeros(lead + (h, w), np.float32)
+
+    def weights(n_in, n_out):
+        i0, i1, l0, l1 = _up_taps(n_in, n_out)
+        out = []
+        for o in range(n_out):
+            if i0[o] == i1[o]:
+                out.append([(int(i0[o]), np.float32(l0[o] + l1[o]))])
+            else:
+                out.append([(int(i0[o]), l0[o]), (int(i1[o]), l1[o])])
+        return out
+    wys, wxs = weights(h, ho), weights(w, wo)
+    for oy in range(ho):
+        for ox in range(wo):
+            for iy, wy in wys[oy]:
+                if wy == 0:
+                    continue
+                for ix, wx in wxs[ox]:
+                    if wx == 0:
+                        continue
+                    gin[..., iy, ix] = gin[..., iy, ix] + (np.float32(wy * wx) * g[..., oy, ox]).astype(np.float32)
+    return gin
+
+
 def _lin_scale(n_in, n_out, align):
     if align:
         return np.float32(n_in - 1) / np.float32(n_out - 1) if n_out > 1 else np.float32(0)

@@ -252,6 +252,47 @@ def test_r101_step_on_libadvengine_convolutions_matches_miopen():
         assert float((torch.sign(grad[big]) == torch.sign(ref_grad[big])).float().mean()) > 0.995, impl
 
 
+def test_r101_step_is_reproducible_bit_for_bit():
+    """the R101 layer-list step twice from the same input: the same bytes.  What makes that hold: RoIAlign's backward is this
+    package's ordered one (no atomics), the FPN / keypoint bilinear up-samplings go through adapters._BilinearUp (torch's own backward
+    scatters with atomicAdd), the level gather is a permutation (one addend per element), and MIOpen is asked for deterministic
+    solvers.  torch.use_deterministic_algorithms(True) makes torch raise on any operator it knows to be order-dependent."""
+    import types
+    from eval_driving_safety_amd import adapters, surrogates
+    dev = torch.device("cuda", 0)
+    model = surrogates.StereoRcnnR101(seed=8, rois_per_image=64, blocks=(1, 1, 2, 1)).to(dev).eval()
+    gen = torch.Generator().manual_seed(9)
+    x = (torch.randn((2, 3, 192, 352), generator=gen) * 40).to(dev)
+    left = torch.zeros((1, 30, 5), device=dev)
+    left[:, 0] = torch.tensor([100.0, 50.0, 240.0, 140.0, 1.0], device=dev)
+    right = left.clone()
+    right[:, 0, 0] -= 10
+    right[:, 0, 2] -= 10
+    kp = torch.zeros((1, 30, 6), device=dev)
+    kp[:, 0] = torch.tensor([150.0, 1, 0, 110, 230, 0], device=dev)
+    extra = types.SimpleNamespace(im_info=torch.tensor([[192.0, 352.0, 1.0]], device=dev), gt_boxes_left=left, gt_boxes_right=right,
+                                  gt_boxes_merge=left.clone(), gt_dim_orien=torch.zeros((1, 30, 5), device=dev), gt_kpts=kp,
+                                  num_boxes=torch.tensor([1], device=dev))
+    net = adapters.StereoRcnnAdapter(model, torch.zeros(6, device=dev))
+    old = os.environ.get("CUBLAS_WORKSPACE_CONFIG")
+    os.environ.setdefault("CUBLAS_WORKSPACE_CONFIG", ":4096:8")
+    try:
+        surrogates.FoldedConv.impl = "auto"
+        torch.use_deterministic_algorithms(True)
+        with torch.backends.cudnn.flags(enabled=True, deterministic=True, benchmark=False):
+            net.loss_and_grad(x.clone(), extra)                   # MIOpen answers a shape's first call with a fallback solver
+            runs = [net.loss_and_grad(x.clone(), extra) for _ in range(3)]
+    finally:
+        torch.use_deterministic_algorithms(False)
+        surrogates.FoldedConv.impl = "miopen"
+        if old is None:
+            os.environ.pop("CUBLAS_WORKSPACE_CONFIG", None)
+    for loss, grad in runs[1:]:
+        assert float(loss) == float(runs[0][0])
+        assert torch.equal(grad, runs[0][1])
+    assert float(runs[0][1].abs().max()) > 0
+
+
 def test_cli_layerlist_models_and_graph_flag(tmp_path):
     """`--model layerlist`: the attack CLIs on the random-weight networks with the upstream layer lists (what bench.py's end-to-end legs
     measure) - DSGN with one PGD iteration captured in a hipGraph (`--graph`), Stereo R-CNN's ResNet-101-FPN eagerly"""
