@@ -213,7 +213,8 @@ def _make(conv, bn, relu):
 
 def adopt(model, fuse_relu=True, fold_named_pairs=True, verify=None, tol=1e-4, freeze=True):
     """Replace, IN PLACE, the convolutions of ``model`` by libadvengine-backed modules carrying the model's own weights (see the module
-    docstring).  -> {"replaced": [(qualified name, what)], "folded_bn": n, "fused_relu": n, "kept": [(name, why)]}."""
+    docstring).  -> {"replaced": [(qualified name, what)], "folded_bn": n, "fused_relu": n, "kept": [(name, why)], "upsample_add": modules whose
+    ``_upsample_add`` now has a deterministic backward}."""
     if model.training:
         raise ValueError("adopt() needs the model in eval mode (BatchNorm statistics are folded)")
     before = None
@@ -268,6 +269,15 @@ def adopt(model, fuse_relu=True, fold_named_pairs=True, verify=None, tol=1e-4, f
             report["kept"].append((name, type(m).__name__ + ": no libadvengine counterpart for this module type here"))
         elif isinstance(m, (nn.BatchNorm2d, nn.BatchNorm3d)):
             report["kept"].append((name, "BatchNorm not next to a convolution by either convention: left as it is"))
+    # the FPN top-down path of the reference's detector class: ``_upsample_add(x, y)`` = F.interpolate(x, size=y's, mode='bilinear',
+    # align_corners=False) + y (attack/Stereo-RCNN/stereo_rcnn.py:91-108).  torch's backward of that up-sampling scatters with atomicAdd -
+    # the image gradient then differs in its last bits from run to run; ops.BilinearUp is the same operator with a fixed-order gather
+    # backward.  Rebound on every module that defines the method (CPU tensors keep torch's operator).
+    report["upsample_add"] = 0
+    for m in model.modules():
+        if callable(getattr(type(m), "_upsample_add", None)):
+            m._upsample_add = _upsample_add
+            report["upsample_add"] += 1
     if freeze:
         for p in model.parameters():
             p.requires_grad_(False)
@@ -284,6 +294,13 @@ def adopt(model, fuse_relu=True, fold_named_pairs=True, verify=None, tol=1e-4, f
                                    "follow the conv->bn conventions adopt() folds by; pass fold_named_pairs=False or adopt sub-modules" % (k, err, scale, tol))
         report["verified_outputs"] = len(after)
     return report
+
+
+def _upsample_add(x, y):
+    if x.is_cuda and x.dtype == torch.float32 and x.dim() == 4:
+        from . import ops
+        return ops.BilinearUp.apply(x, tuple(y.shape[2:])) + y
+    return F.interpolate(x, size=tuple(y.shape[2:]), mode="bilinear", align_corners=False) + y
 
 
 def _q(parent, name):

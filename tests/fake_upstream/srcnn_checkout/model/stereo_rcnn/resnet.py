@@ -69,8 +69,11 @@ class resnet(nn.Module):
         c2 = self.RCNN_layer1(self.RCNN_layer0(im / 64.0))                   # 16 x 1/4
         c3 = self.RCNN_layer2(c2)                                            # 32 x 1/8
         p3 = self.RCNN_toplayer(c3)
-        up = F.interpolate(p3, size=c2.shape[2:], mode="bilinear", align_corners=False) + self.RCNN_latlayer1(c2)
+        up = self._upsample_add(p3, self.RCNN_latlayer1(c2))
         return self.RCNN_smooth1(up)                                         # 16 x 1/4
+
+    def _upsample_add(self, x, y):           # the method name and meaning of the detector class this stands in for (top-down path)
+        return F.interpolate(x, size=y.shape[2:], mode="bilinear", align_corners=False) + y
 
     def forward(self, im_left, im_right, im_info, gt_l, gt_r, gt_m, gt_dim_orien, gt_kpts, num_boxes):
         dev = im_left.device

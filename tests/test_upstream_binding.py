@@ -139,6 +139,10 @@ def test_adopt_walks_the_stand_in_stereo_rcnn(checkout):
     assert not net.RCNN_layer2[0].conv1.native                            # the stride-2 1x1: torch's operator, BatchNorm still folded
     assert net.RCNN_toplayer.native and net.RCNN_smooth1.native and net.RCNN_smooth1.bias is not None
     assert rep["folded_bn"] == 1 + 3 * 3 + 2 and rep["fused_relu"] == 1 + 2 and not rep["kept"]
+    # the top-down path's _upsample_add (attack/Stereo-RCNN/stereo_rcnn.py:91-108) rebound: same values, a fixed-order backward on the GPU
+    assert rep["upsample_add"] == 1 and net._upsample_add is A._upsample_add
+    x, y = torch.randn(1, 2, 3, 5), torch.randn(1, 2, 6, 9)
+    assert torch.equal(net._upsample_add(x, y), torch.nn.functional.interpolate(x, size=(6, 9), mode="bilinear", align_corners=False) + y)
     assert all(not p.requires_grad for p in net.parameters())
     assert not any(isinstance(m, (nn.Conv2d, nn.BatchNorm2d)) for m in net.modules())
     with pytest.raises(RuntimeError, match="no CPU path"):
@@ -262,7 +266,7 @@ def test_adopted_stand_in_stereo_rcnn_keeps_loss_and_gradient(checkout):
     net.load_state_dict(ref.state_dict())                                # "the checkpoint": the same trained weights
     call = A.Call((t[0].float(), t[1].float(), t[2], t[3], t[4], t[5], t[6], t[7], extra.num_boxes))
     rep = A.adopt(net, verify=call)
-    assert rep["verified_outputs"] >= 10 and sum("torch +" not in w for _, w in rep["replaced"]) >= 10
+    assert rep["verified_outputs"] >= 10 and sum("torch +" not in w for _, w in rep["replaced"]) >= 10 and rep["upsample_add"] == 1
     loss, grad = adapters.StereoRcnnAdapter(net, u).loss_and_grad(x.clone(), extra)
     assert abs(float(loss) - float(want_loss)) <= 1e-4 * abs(float(want_loss))
     # Element by element the gradient is within 1e-4 of its magnitude EXCEPT around a handful of discrete decisions: a ReLU whose input is
@@ -282,7 +286,7 @@ def test_adopted_stand_in_stereo_rcnn_keeps_loss_and_gradient(checkout):
           "torch CPU vs torch GPU (same modules): relative L2 %.3g" % (rel_l2, off, q999, float(diff.max()), float((cpu_grad - want_grad).norm() / want_grad.norm())))
     assert q999 <= 1e-4 and off <= 1e-3 and rel_l2 <= 1e-3 and float(diff.max()) <= 0.05, (rel_l2, off, q999, float(diff.max()))
     again = adapters.StereoRcnnAdapter(net, u).loss_and_grad(x.clone(), extra)[1]
-    assert torch.equal(again, grad)                                      # route table + deterministic RoIAlign backward: the same bits
+    assert torch.equal(again, grad)                                      # route table + deterministic RoIAlign / up-sampling backward: the same bits
 
 
 @pytest.mark.gpu

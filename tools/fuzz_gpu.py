@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity sweep on the GPU (not part of the test-suite: run by hand / by gpurun).  Random shapes through the HIP
 kernels against the oracle, bit for bit: convolution (plain / bias+ReLU / masked / strided / transposed, every alternative code path),
-grid_sample3d forward + gather backward, RoIAlign forward + backward, cost volume, PGD steps with and without the 8-bit index.
+grid_sample3d forward + gather backward, bilinear up-sampling + gather adjoint, RoIAlign forward + backward, cost volume, PGD steps with and without the 8-bit index.
 usage: python tools/fuzz_gpu.py [--cases 150] [--seed 0]"""
 import argparse
 import os
@@ -152,6 +152,24 @@ def grid_case(rs, dev):
     same(ops.grid_sample3d_bwd(torch.tensor(g, device=dev), plan), O.grid_sample3d_bwd(g, grid, dims, align), "grid_sample3d bwd %s" % ((b, c, dims, out, align),))
 
 
+def resize_case(rs, dev):
+    """bilinear up-sampling (any size pair, also equal sizes and down-sampling) and its gather adjoint"""
+    lead = (int(rs.randint(1, 3)), int(rs.randint(1, 5)))
+    h, w = int(rs.randint(1, 14)), int(rs.randint(1, 20))
+    mode = int(rs.randint(4))
+    if mode == 0:        # the pyramid's ragged ~2x steps
+        ho, wo = 2 * h - int(rs.randint(2)), 2 * w - int(rs.randint(2))
+    elif mode == 1:      # large ratios: more candidates per axis than the kernel keeps in registers
+        ho, wo = h * int(rs.randint(3, 9)) + int(rs.randint(3)), w * int(rs.randint(3, 7)) + int(rs.randint(3))
+    else:                # anything, down-sampling included
+        ho, wo = int(rs.randint(1, 40)), int(rs.randint(1, 50))
+    ho, wo = max(ho, 1), max(wo, 1)
+    x = rs.randn(*lead, h, w).astype(np.float32)
+    g = rs.randn(*lead, ho, wo).astype(np.float32)
+    same(ops.bilinear_up(torch.tensor(x, device=dev), (ho, wo)), O.bilinear_up(x, (ho, wo)), "bilinear_up %s" % ((lead, h, w, ho, wo),))
+    same(ops.bilinear_up_bwd(torch.tensor(g, device=dev), (h, w)), O.bilinear_up_bwd(g, (h, w)), "bilinear_up bwd %s" % ((lead, h, w, ho, wo),))
+
+
 def roi_case(rs, dev):
     b, c = int(rs.randint(1, 3)), int(rs.randint(1, 40))
     h, w = int(rs.randint(2, 40)), int(rs.randint(2, 60))
@@ -225,7 +243,7 @@ def main():
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     rs = np.random.RandomState(args.seed)
-    kinds = [conv_case] * 5 + [conv2d_case] * 4 + [wino3d_case] * 3 + [grid_case] * 2 + [pgd_case] * 3 + [roi_case] * 3 + [depth_case] * 2
+    kinds = [conv_case] * 5 + [conv2d_case] * 4 + [wino3d_case] * 3 + [grid_case] * 2 + [pgd_case] * 3 + [roi_case] * 3 + [depth_case] * 2 + [resize_case] * 2
     counts = {}
     for i in range(args.cases):
         fn = kinds[int(rs.randint(len(kinds)))]
