@@ -384,8 +384,8 @@ int launch_wino(const float* x, const float* wp, float* y, int b, int cin, int c
   const long long total = static_cast<long long>(b) * cin * d * h * w;
   const dim3 grid(static_cast<unsigned>(tiles), cgroups, static_cast<unsigned>(gz));
 #ifdef ADV_TEST_HOOKS
-  if (const char* dbg_s = adv_hook_value("ADV_WINO_DBG")) {      // phase ablation for timing (results are wrong); the 8 x 32 x 64 2D shape only
-    if constexpr (PR == 4 && PC == 16 && COB == 4 && !DEPTH) {
+  if (const char* dbg_s = adv_hook_value("ADV_WINO_DBG")) {      // phase ablation for timing (results are wrong); the 8 x 32 x 64 2D shape and the 8 x 32 x 32 3D shape
+    if constexpr (PR == 4 && PC == 16 && ((COB == 4 && !DEPTH) || (COB == 2 && DEPTH))) {
       const int abl = std::atoi(dbg_s);
 #define ADV_WINO_ABL(A_)                                                                                                                  \
   if (abl == A_) {                                                                                                                        \

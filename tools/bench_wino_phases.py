@@ -31,5 +31,25 @@ def main():
                               "direct_equiv_tflops": round(flops / ms / 1e9, 1)}), flush=True)
 
 
+def main3d():
+    """the 32 -> 32 layer of the cost-volume network (8 x 32 x 32-channel workgroups, stages of 4 q, three depth taps)"""
+    dev = torch.device("cuda", 0)
+    b, cin, cout, d, h, w = 1, 32, 32, 48, 96, 312
+    x = torch.randn((b, cin, d, h, w), device=dev)
+    wt = torch.randn((cout, cin, 3, 3, 3), device=dev) * 0.05
+    prep = ops.Conv3dWinoPrep(wt)
+    flops = 2.0 * b * cin * cout * 27 * d * h * w
+    for dbg, what in ((0, "full kernel"), (1, "no input transform"), (2, "no matrix instructions"), (4, "no global fetches"), (8, "no LDS commits"),
+                      (16, "no barrier"), (3, "no transform, no matrix instructions"), (13, "only the matrix instructions + barrier"),
+                      (29, "only the matrix instructions"), (31, "empty stage loop (prologue + epilogue)")):
+        with hooks_route(ADV_WINO_DBG=str(dbg)):
+            ms = timeit(lambda: ops.conv3d_wino(x, prep, None, relu=False, tile=2), reps=10)
+        print(json.dumps({"layer": "3D %d->%d on [%d,%d,%d,%d,%d]" % (cin, cout, b, cin, d, h, w), "dbg": dbg, "what": what, "ms": round(ms, 4),
+                          "direct_equiv_tflops": round(flops / ms / 1e9, 1)}), flush=True)
+
+
 if __name__ == "__main__":
+    if "--3d" in sys.argv:
+        main3d()
+        sys.exit(0)
     main()
