@@ -69,7 +69,7 @@ struct EpiW {
 };
 
 // Cin, Cout: channels; cinpad / copad: the prepared weights' padding; D: planes (1 for a 2D layer); DEPTH: 3x3x3 kernel
-template <int PR, int PC, int COB, int KC, bool DEPTH, int ABL>
+template <int PR, int PC, int COB, int KC, bool DEPTH, int ABL, bool DEEP = false>
 __global__ __launch_bounds__(COB * 128, COB == 4 ? 1 : 2) void conv_wino(const float* __restrict__ x, const float* __restrict__ wp, float* __restrict__ y,
                                                                           int Cin, int Cout, int cinpad, int copad, int D, int H, int W, int tiles_w,
                                                                           long long total, EpiW epi) {
@@ -135,11 +135,11 @@ __global__ __launch_bounds__(COB * 128, COB == 4 ? 1 : 2) void conv_wino(const f
     set.m[i] = ch < Cin ? xvm[i] : 0u;
   };
   const int wrows = DEPTH ? 3 * cinpad : cinpad;       // rows of U per transform position
-  auto fetch_w1 = [&](int i, int q0) {
+  auto fetch_w1 = [&](int i, int q0, v4f (&dst)[G::kWSl]) {
     const int sidx = tid + NT * i;
     const int q = sidx % (G::kCO / 4), row = sidx / (G::kCO / 4);      // row = k * KC + c
     const int k = row / KC, c = row % KC;
-    rw[i] = *reinterpret_cast<const v4f*>(wp + (static_cast<long long>(k) * wrows + q0 + c) * copad + co0 + 4 * q);
+    dst[i] = *reinterpret_cast<const v4f*>(wp + (static_cast<long long>(k) * wrows + q0 + c) * copad + co0 + 4 * q);
   };
   float* const sxb = lds;                               // [2][KC][rows][LW]   input tiles
   float* const swb = lds + 2 * G::kSX;                   // [2][16][KC][CO]     U = G g G^T of the stage
@@ -168,11 +168,11 @@ __global__ __launch_bounds__(COB * 128, COB == 4 ? 1 : 2) void conv_wino(const f
   // rotated by 16 (q & 3); 32-float rows alternate between the two halves of a 64-bank line by themselves, so q = 1, 2 swap their halves
   // (distinct modulo 32 within each half-wave and modulo 64 across the wave)
   auto uswz = [](int q) { return (G::kCO == 64 ? (q & 3) : ((q ^ (q >> 1)) & 1)) << 4; };
-  auto commit_w1 = [&](int i, int buf) {
+  auto commit_w1 = [&](int i, int buf, const v4f (&src)[G::kWSl]) {
     float* sw = swb + buf * G::kSW;
     const int sidx = tid + NT * i;
     const int q = sidx % (G::kCO / 4), row = sidx / (G::kCO / 4);
-    *reinterpret_cast<v4f*>(sw + row * G::kCO + ((4 * q) ^ uswz(row % KC))) = rw[i];
+    *reinterpret_cast<v4f*>(sw + row * G::kCO + ((4 * q) ^ uswz(row % KC))) = src[i];
   };
   // the input transform: thread -> (q = tid >> 6, patch = tid & 63)
   const int tc = tid >> 6, tp = tid & 63;
@@ -212,6 +212,18 @@ __global__ __launch_bounds__(COB * 128, COB == 4 ? 1 : 2) void conv_wino(const f
   const int q_lo = DEPTH ? (od == 0 ? cinpad : 0) : 0;
   const int q_hi = DEPTH ? (od == D - 1 ? 2 * cinpad : 3 * cinpad) : cinpad;
   const int nstage = (q_hi - q_lo) / KC;
+  // <round 4> DEEP staging (32-channel workgroups on layers with many stages): a stage of 4 q is 16 steps - ~0.85 us, less than a round
+  // trip to HBM - so a load issued at a stage's start is not always back at its end, where it is committed.  A second set of staging
+  // registers lets every load travel for a whole stage more: stage st requests the inputs of stage st + 3 and the weights of stage st + 2
+  // into one set and commits the other one (requested during stage st - 1).  The stage loop is then UNIFORM - no peeled tail: requests
+  // past the last stage are clamped to it and their commits / transforms fill buffers nobody reads - unrolled by two for the alternation
+  // of the register sets.  Worth 3-8 % from 24 (3D) / 32 (2D) stages up, a loss of as much on short contractions (three stages of wasted
+  // side work per tile): the launch picks (launch_wino).  The 64-channel shape has no registers for a second set.  Same bits.
+  constexpr bool kDeep = DEEP;
+  static_assert(!DEEP || COB == 2, "deep staging: the 32-channel shape only");
+  XSet xsB;
+  v4f rwB[G::kWSl];
+  auto qclamp = [&](int q) { return q < q_hi - KC ? q : q_hi - KC; };
   {
     // prologue: the first two input tiles and the first weights are requested TOGETHER (a second, short-lived register set for the
     // second tile) - one memory round trip before the first products instead of two in a row; with 24 short stages per tile (the
@@ -220,13 +232,19 @@ __global__ __launch_bounds__(COB * 128, COB == 4 ? 1 : 2) void conv_wino(const f
 #pragma unroll
     for (int i = 0; i < G::kXSl; ++i) fetch_x1(i, q_lo, xs);
 #pragma unroll
-    for (int i = 0; i < G::kWSl; ++i) fetch_w1(i, q_lo);
+    for (int i = 0; i < G::kWSl; ++i) fetch_w1(i, q_lo, rw);
 #pragma unroll
     for (int i = 0; i < G::kXSl; ++i) fetch_x1(i, nstage > 1 ? q_lo + KC : q_lo, xs1);
+    if constexpr (kDeep) {       // the second register sets: the input tile of stage 2 and the weights of stage 1 (committed during stage 0)
+#pragma unroll
+      for (int i = 0; i < G::kXSl; ++i) fetch_x1(i, qclamp(q_lo + 2 * KC), xsB);
+#pragma unroll
+      for (int i = 0; i < G::kWSl; ++i) fetch_w1(i, qclamp(q_lo + KC), rwB);
+    }
 #pragma unroll
     for (int i = 0; i < G::kXSl; ++i) commit_x1(i, 0, xs);
 #pragma unroll
-    for (int i = 0; i < G::kWSl; ++i) commit_w1(i, 0);
+    for (int i = 0; i < G::kWSl; ++i) commit_w1(i, 0, rw);
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; ++i) tr_read(i, 0);
@@ -243,7 +261,7 @@ __global__ __launch_bounds__(COB * 128, COB == 4 ? 1 : 2) void conv_wino(const f
   // inputs of stage st + 2 and the weights of stage st + 1, the input transform of stage st + 1 (LDS reads, the additions, LDS writes)
   // and the commits of the loaded data to LDS - all of them touch buffers the current stage's products do not read.  The scheduler may
   // not move anything across a step (sched_barrier): it would hoist all reads and spill.  ONE barrier per stage.
-  auto products = [&](int st, auto fx_tag, auto fw_tag) {
+  auto products = [&](int st, auto fx_tag, auto fw_tag, XSet& fxs, XSet& cxs, v4f (&frw)[G::kWSl], v4f (&crw)[G::kWSl]) {
     constexpr bool FX = decltype(fx_tag)::value, FW = decltype(fw_tag)::value;
     constexpr int kAhead = 4, NS = G::kSteps;
     float ra[NS], rb0[NS], rb1[NS];
@@ -257,21 +275,23 @@ __global__ __launch_bounds__(COB * 128, COB == 4 ? 1 : 2) void conv_wino(const f
     };
     const int nb = (st + 1) & 1;       // the buffers of stage st + 1 (V, U) - and of stage st + 2's inputs: st & 1
     const int q1 = q_lo + (st + 1) * KC;
+    // what this stage requests: the inputs of stage st + 2 and the weights of stage st + 1 - or, deep, one stage further each
+    const int qfx = kDeep ? qclamp(q1 + 2 * KC) : q1 + KC, qfw = kDeep ? qclamp(q1 + KC) : q1;
 #pragma unroll
     for (int t = 0; t < kAhead; ++t) load(t);
 #pragma unroll
     for (int t = 0; t < NS; ++t) {
       if (t + kAhead < NS) load(t + kAhead);
-      if (FX && t < G::kXSl && !(dbg & 4)) fetch_x1(t, q1 + KC, xs);
-      if (FW && t >= G::kLoadW && t < G::kLoadW + G::kWSl && !(dbg & 4)) fetch_w1(t - G::kLoadW, q1);
+      if (FX && t < G::kXSl && !(dbg & 4)) fetch_x1(t, qfx, fxs);
+      if (FW && t >= G::kLoadW && t < G::kLoadW + G::kWSl && !(dbg & 4)) fetch_w1(t - G::kLoadW, qfw, frw);
       if (FW && t >= G::kRead && t < G::kRead + 4 && !(dbg & 1)) tr_read(t - G::kRead, nb);
       if (FW && t == G::kComp && !(dbg & 1)) tr_compute();
       if (FW && t >= G::kWrite && t < G::kWrite + 16 / G::kWritesPerStep && !(dbg & 1)) {
 #pragma unroll
         for (int u = 0; u < G::kWritesPerStep; ++u) tr_write(G::kWritesPerStep * (t - G::kWrite) + u, nb);
       }
-      if (FX && t >= G::kCommitX && t < G::kCommitX + G::kXSl && !(dbg & 8)) commit_x1(t - G::kCommitX, st & 1, xs);
-      if (FW && t >= G::kCommitW && t < G::kCommitW + G::kWSl && !(dbg & 8)) commit_w1(t - G::kCommitW, nb);
+      if (FX && t >= G::kCommitX && t < G::kCommitX + G::kXSl && !(dbg & 8)) commit_x1(t - G::kCommitX, st & 1, cxs);
+      if (FW && t >= G::kCommitW && t < G::kCommitW + G::kWSl && !(dbg & 8)) commit_w1(t - G::kCommitW, nb, crw);
       if (!(dbg & 2)) {
         acc[0][t & 15] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[t], rb0[t], acc[0][t & 15], 0, 0, 0);
         acc[1][t & 15] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[t], rb1[t], acc[1][t & 15], 0, 0, 0);
@@ -283,16 +303,26 @@ __global__ __launch_bounds__(COB * 128, COB == 4 ? 1 : 2) void conv_wino(const f
   // "if (more) fetch ... if (more) commit" the compiler must assume a path on which a load is still in flight at the loop's head and
   // waits for ALL loads (the fresh ones too) before it may reuse the registers - i.e. before the matrix instructions.
   int st = 0;
-  for (; st + 2 < nstage; ++st) {
-    products(st, std::true_type{}, std::true_type{});
-    if (!(dbg & 16)) __syncthreads();
+  if constexpr (kDeep) {
+    for (; st + 1 < nstage; st += 2) {
+      products(st, std::true_type{}, std::true_type{}, xs, xsB, rw, rwB);
+      if (!(dbg & 16)) __syncthreads();
+      products(st + 1, std::true_type{}, std::true_type{}, xsB, xs, rwB, rw);
+      if (!(dbg & 16)) __syncthreads();
+    }
+    if (st < nstage) products(st, std::false_type{}, std::false_type{}, xs, xs, rw, rw);      // an odd count's last stage: products only
+  } else {
+    for (; st + 2 < nstage; ++st) {
+      products(st, std::true_type{}, std::true_type{}, xs, xs, rw, rw);
+      if (!(dbg & 16)) __syncthreads();
+    }
+    if (st + 1 < nstage) {
+      products(st, std::false_type{}, std::true_type{}, xs, xs, rw, rw);
+      __syncthreads();
+      ++st;
+    }
+    products(st, std::false_type{}, std::false_type{}, xs, xs, rw, rw);
   }
-  if (st + 1 < nstage) {
-    products(st, std::false_type{}, std::true_type{});
-    __syncthreads();
-    ++st;
-  }
-  products(st, std::false_type{}, std::false_type{});
 
   const long long MP = static_cast<long long>(Cout) * DHW;
   const long long plane0 = static_cast<long long>(od) * HW;
@@ -399,6 +429,17 @@ int launch_wino(const float* x, const float* wp, float* y, int b, int cin, int c
     }
   }
 #endif
+  if constexpr (COB == 2) {
+    const int stages = (DEPTH ? 3 : 1) * cinpad / KC;       // (interior planes)
+    bool deep = stages >= (DEPTH ? 24 : 32);
+    if (const char* e = adv_hook_value("ADV_WINO_DEEP")) deep = e[0] == '1';      // test hook / A-B; same bits
+    if (deep) {
+      if (!adv_internal_lds_limit<conv_wino<PR, PC, COB, KC, DEPTH, 0, true>>(G::kLds)) return ADV_ELAUNCH;
+      hipLaunchKernelGGL((conv_wino<PR, PC, COB, KC, DEPTH, 0, true>), grid, dim3(G::kNT), G::kLds, st, x, wp, y, cin, cout, cinpad, copad, d, h, w,
+                         tiles_w, total, epi);
+      return adv_internal_finish_launch();
+    }
+  }
   if (!adv_internal_lds_limit<conv_wino<PR, PC, COB, KC, DEPTH, 0>>(G::kLds)) return ADV_ELAUNCH;
   hipLaunchKernelGGL((conv_wino<PR, PC, COB, KC, DEPTH, 0>), grid, dim3(G::kNT), G::kLds, st, x, wp, y, cin, cout, cinpad, copad, d, h, w, tiles_w,
                      total, epi);

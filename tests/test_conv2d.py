@@ -298,6 +298,36 @@ def test_hip_conv2d_wino_bit_exact_vs_oracle(shape):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("deep", ["0", "1"])
+def test_hip_wino_deep_staging_is_the_same_result(deep):
+    """the 32-channel workgroups' two staging schedules (csrc/wino2d.hip DEEP: loads travel a stage longer through a second register set,
+    uniform stage loop with clamped requests past the end) forced either way through the hooks build: the oracle's bytes, 2D and 3D, from
+    two stages per tile up"""
+    import os
+    from eval_driving_safety_amd import _lib, ops
+    dev = torch.device("cuda", 0)
+    with _lib.using(_lib.HOOKS_LIB_PATH):
+        os.environ["ADV_WINO_DEEP"] = deep
+        try:
+            for (b, cin, cout, h, w) in ((1, 5, 7, 9, 33), (2, 12, 40, 8, 32), (1, 40, 32, 13, 41), (1, 136, 18, 6, 10)):
+                x, wt, rs = _case(b, cin, cout, h, w, k=3, seed=sum((b, cin, cout, h, w)) + 11)
+                tx, tw = torch.tensor(x, device=dev), torch.tensor(wt, device=dev)
+                prep = ops.Conv2dPrep(tw, 1, 1, 1)
+                for tile in (2, 3, 5, 7):
+                    assert ops.conv2d(tx, prep, wino=True, tile=tile).cpu().numpy().tobytes() == C.conv2d_wino(x, wt).tobytes(), (cin, tile)
+            rs = np.random.RandomState(3)
+            for (cin, cout, d, h, w) in ((4, 6, 3, 5, 9), (12, 32, 1, 8, 33), (32, 32, 4, 9, 20)):
+                x = rs.randn(1, cin, d, h, w).astype(np.float32)
+                wt = (rs.randn(cout, cin, 3, 3, 3) * 0.1).astype(np.float32)
+                prep = ops.Conv3dWinoPrep(torch.tensor(wt, device=dev))
+                want = C.conv3d_wino(x, wt)
+                for tile in (2, 3, 5, 7):
+                    assert ops.conv3d_wino(torch.tensor(x, device=dev), prep, None, relu=False, tile=tile).cpu().numpy().tobytes() == want.tobytes(), (cin, tile)
+        finally:
+            del os.environ["ADV_WINO_DEEP"]
+
+
+@pytest.mark.gpu
 def test_hip_conv2d_wino_layer_shapes_full_size():
     """the detectors' 3x3 layers at their real size through the Winograd kernel: the whole tensor within 1e-4 of torch, windows (on the
     even patch grid) bit-exact vs the oracle"""
