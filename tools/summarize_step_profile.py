@@ -10,7 +10,7 @@ import json
 import re
 import sys
 
-OURS = re.compile(r"conv_wino|conv2d_\w+_mfma|conv3d_k3\w*|convt3d\w*|roi_\w+|nms_\w+|psv_\w+|pgd_step\w*|affine_\w+|export_u8\w*|patch_\w+|depth_regress\w*|grid_sample3d\w*|"
+OURS = re.compile(r"conv_wino|bilinear_up_\w+|conv2d_\w+_mfma|conv3d_k3\w*|convt3d\w*|roi_\w+|nms_\w+|psv_\w+|pgd_step\w*|affine_\w+|export_u8\w*|patch_\w+|depth_regress\w*|grid_sample3d\w*|"
                   r"gs_to_channels_last|bias_act_kernel|relu_backward_kernel|bev_fold\w*|focal_\w+|space_to_depth2|disc_mask\w*|clean_index\w*|import_u8\w*|dense_align\w*|\w+_prep_kernel|conv3d_k3_prep")
 LIBS = re.compile(r"miopen|Cijk_|igemm_|Col2Im|Im2d2Col|Im2Col|batched_transpose|ck::|_ZN2ck|SubTensorOp|gridwise|MIOpen|Op\dd|transpose_")
 
