@@ -542,6 +542,12 @@ class StereoRcnnAdapter:
         if freeze:
             _freeze(model)
 
+    @property
+    def graph_safe(self):
+        """capturable in a hipGraph (attacks.PgdAttack(graph=True)): only a detector that says so itself - the layer-list surrogates on
+        their static path (surrogates.StereoRcnnShaped.graph_capturable); upstream's proposal layers read back and compact"""
+        return bool(getattr(self.model, "graph_capturable", False))
+
     def loss_and_grad(self, x, extra):
         u = self.uncert
         h = _LeafGrad(x)

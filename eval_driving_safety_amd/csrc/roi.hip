@@ -695,6 +695,12 @@ __device__ __forceinline__ float iou_legacy(const float* a, const float* b) {
   return inter / (sa + sb - inter);
 }
 
+// the mask words start at zero (a kernel rather than hipMemsetAsync: inside a captured hipGraph every node of the suppression is then a
+// kernel node)
+__global__ __launch_bounds__(256) void nms_zero(unsigned long long* __restrict__ p, long long n) {
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += 256LL * gridDim.x) p[i] = 0ull;
+}
+
 __global__ __launch_bounds__(64) void nms_mask(const float* __restrict__ boxes, int n, float thresh, unsigned long long* mask, int col_blocks) {
   const int row = blockIdx.y, col = blockIdx.x;
   if (row > col) return;  // only later (lower-score) boxes can be suppressed by earlier ones
@@ -872,7 +878,11 @@ int adv_nms_f32(const float* boxes, int n, float thresh, int64_t* keep_out, int3
   if (n == 0) return hipMemsetAsync(num_keep_out, 0, sizeof(int32_t), st) == hipSuccess ? ADV_OK : ADV_ELAUNCH;
   const int col_blocks = (n + 63) / 64;
   if (static_cast<size_t>(col_blocks) * 8 > 64 * 1024) return ADV_EINVAL;  // removed[] must fit 64 KiB of LDS: n <= 524288
-  if (hipMemsetAsync(workspace, 0, static_cast<size_t>(n) * col_blocks * sizeof(uint64_t), st) != hipSuccess) return ADV_ELAUNCH;
+  {
+    const long long words = static_cast<long long>(n) * col_blocks;
+    const unsigned zb = static_cast<unsigned>(words / 256 + 1 < 1024 ? words / 256 + 1 : 1024);
+    hipLaunchKernelGGL(nms_zero, dim3(zb), dim3(256), 0, st, reinterpret_cast<unsigned long long*>(workspace), words);
+  }
   hipLaunchKernelGGL(nms_mask, dim3(col_blocks, col_blocks), dim3(64), 0, st, boxes, n, thresh,
                      reinterpret_cast<unsigned long long*>(workspace), col_blocks);
   hipLaunchKernelGGL(nms_scan, dim3(1), dim3(64), static_cast<size_t>(col_blocks) * 8, st,
