@@ -123,6 +123,9 @@ class StereoRcnnShaped(nn.Module):
     def rpn_deltas(self, both):
         return self.rpn_reg(both)
 
+    def rpn_scores(self, both):
+        return self.rpn_cls(both)
+
     def head_to_tail(self, pooled):
         return F.relu(self.fc(pooled.flatten(1)))
 
@@ -237,7 +240,7 @@ class StereoRcnnShaped(nn.Module):
         scores, deltas, anchors = [], [], []
         for i in range(len(fl)):
             both = self.rpn_features(fl[i], fr[i])
-            s, d = self.rpn_cls(both), self.rpn_deltas(both)
+            s, d = self.rpn_scores(both), self.rpn_deltas(both)
             scores.append(s.permute(0, 2, 3, 1).reshape(-1))
             deltas.append(d.permute(0, 2, 3, 1).reshape(-1, 6))
             anchors.append(self.anchors(i, s.shape[2], s.shape[3], dev))
@@ -348,7 +351,7 @@ class StereoRcnnShaped(nn.Module):
         scores, deltas, anchors = [], [], []
         for i in range(len(fl)):
             both = self.rpn_features(fl[i], fr[i])
-            s, d = self.rpn_cls(both), self.rpn_deltas(both)
+            s, d = self.rpn_scores(both), self.rpn_deltas(both)
             scores.append(s.permute(0, 2, 3, 1).reshape(-1))
             deltas.append(d.permute(0, 2, 3, 1).reshape(-1, 6))
             anchors.append(self.anchors(i, s.shape[2], s.shape[3], dev))
@@ -670,13 +673,22 @@ class StereoRcnnR101(StereoRcnnShaped):
             cache[key] = torch.cuda.make_graphed_callables(lambda t: tuple(self.pyramid(t)), (sample,))
         return list(cache[key](both))
 
+    def _rpn_chained(self, x):
+        """the shared 3x3 layer's ReLU mask is applied by its two consumers' backward launches (each masks its own share of the gradient:
+        the mask is linear) instead of a pass of its own over the 512-channel maps"""
+        return x.is_cuda and self.rpn_conv.chainable() and self.rpn_cls.chainable() and self.rpn_reg.chainable()
+
     def rpn_features(self, feat_l, feat_r):
-        return torch.cat([self.rpn_conv(feat_l, relu=True), self.rpn_conv(feat_r, relu=True)], 1)
+        relu = "consumer" if self._rpn_chained(feat_l) else True
+        return torch.cat([self.rpn_conv(feat_l, relu=relu), self.rpn_conv(feat_r, relu=relu)], 1)
+
+    def rpn_scores(self, both):
+        return self.rpn_cls(both, chain_in=self._rpn_chained(both))
 
     def rpn_deltas(self, both):
         # a trained RPN regresses small corrections of its anchors; random weights would give slivers a fraction of a pixel wide
         # (0.2-4 px at P2 in the first version: a degenerate workload for RoIAlign) - bound them to what a trained network emits
-        d = self.rpn_reg(both)
+        d = self.rpn_reg(both, chain_in=self._rpn_chained(both))
         return 0.5 * torch.tanh(d) if self.bounded_rpn_deltas else d
 
     def head_to_tail(self, pooled):
@@ -690,8 +702,11 @@ class StereoRcnnR101(StereoRcnnShaped):
         MIOpen's per-image GEMM + col2im loop (~600 launches and 4 ms per step, profiles/r04_r101_step_profile_before_kpts.json) - and the
         1x1 class layer and the row sum read that tensor through views: channels (co) x "rows" (di, dj, i) x columns j, no pixel shuffle."""
         x = feat14
-        for conv in self.kpts_convs:
-            x = conv(x, relu=True)
+        # the head is a chain (every layer's output has one consumer): each ReLU mask is applied in the epilogue of its consumer's backward
+        # launch instead of a pass of its own - the last of them over the 412 MB tensor behind the transposed convolution
+        chain = bool(x.is_cuda and all(c.chainable() for c in self.kpts_convs) and self.kpts_up_1x1.chainable() and self.kpts_class.chainable())
+        for i, conv in enumerate(self.kpts_convs):
+            x = conv(x, relu="consumer" if chain else True, chain_in=chain and i > 0)
         w, b = self.kpts_up.weight, self.kpts_up.bias
         key = (w.data_ptr(), w._version, b._version, w.device)
         if self._kup_key != key:
@@ -700,6 +715,6 @@ class StereoRcnnR101(StereoRcnnShaped):
                 self.kpts_up_1x1.bias.copy_(b.repeat_interleave(4))
             self.kpts_up_1x1._prep, self._kup_key = None, key
         r, c, h, wd = x.shape
-        z = self.kpts_up_1x1(x, relu=True)                                        # [R, (co, di, dj), 14, 14] = relu(kpts_up(x)) before the shuffle
-        k = self.kpts_class(z.view(r, c, 4 * h, wd))                              # [R, 6, (di, dj, i), j]
+        z = self.kpts_up_1x1(x, relu="consumer" if chain else True, chain_in=chain)      # [R, (co, di, dj), 14, 14] = relu(kpts_up(x)) before the shuffle
+        k = self.kpts_class(z.view(r, c, 4 * h, wd), chain_in=chain)              # [R, 6, (di, dj, i), j]
         return k.view(r, 6, 2, 2, h, wd).sum(dim=(2, 4)).permute(0, 1, 3, 2).reshape(r, 6, 2 * wd)     # rows (i, di) summed; columns 2j + dj
