@@ -93,6 +93,7 @@ __global__ __launch_bounds__(kBlock) void roi_align_fwd(const float* __restrict_
     const int c = static_cast<int>((i / (static_cast<long long>(PW) * PH)) % C);
     const long long r = i / (static_cast<long long>(PW) * PH * C);
     const Bin b = bin_of(rois + r * 5, scale, PH, PW, sampling_ratio);
+    if (b.batch < 0) continue;         // <round 4> a roi with a negative batch index is skipped: its output rows stay as they are
     const float* plane = feat + (static_cast<long long>(b.batch) * C + c) * H * W;
     const float count = static_cast<float>(b.grid_h * b.grid_w);
     float acc = 0.0f;

@@ -526,14 +526,18 @@ class PsvBuild(torch.autograd.Function):
 
 # --------------------------------------------------------------------------------------------
 # Stereo R-CNN RoI path (attack/Stereo-RCNN/stereo_rcnn.py:44-45,132-134; predict_and_save_pgd.py:300)
-def roi_align(feat, rois, pooled, spatial_scale, sampling_ratio=0):
-    """feat [B,C,H,W], rois [R,5] = (batch idx, x1, y1, x2, y2) -> [R,C,PH,PW] (legacy RoIAlign)."""
+def roi_align(feat, rois, pooled, spatial_scale, sampling_ratio=0, out=None):
+    """feat [B,C,H,W], rois [R,5] = (batch idx, x1, y1, x2, y2) -> [R,C,PH,PW] (legacy RoIAlign).  A roi with a NEGATIVE batch index is
+    skipped: its rows of ``out`` (a tensor to write into; default: a new, uninitialised one) stay as they are."""
     f, r = _feat(feat, "feat"), _feat(rois, "rois")
     if f.dim() != 4 or r.dim() != 2 or r.shape[1] != 5:
         raise ValueError("feat must be [B,C,H,W], rois [R,5]")
     b, c, h, w = f.shape
     ph, pw = (pooled, pooled) if isinstance(pooled, int) else pooled
-    out = torch.empty((r.shape[0], c, ph, pw), dtype=torch.float32, device=f.device)
+    if out is None:
+        out = torch.empty((r.shape[0], c, ph, pw), dtype=torch.float32, device=f.device)
+    elif tuple(_feat(out, "out").shape) != (r.shape[0], c, ph, pw):
+        raise ValueError("out must be [R,C,PH,PW]")
     with _on(f):
         _lib.call("adv_roi_align_fwd_f32", _ptr(f), _ptr(r), _ptr(out), b, c, h, w, r.shape[0], ph, pw, float(spatial_scale),
                   int(sampling_ratio), _stream(f))
@@ -571,6 +575,35 @@ class RoIAlign(torch.autograd.Function):
         (rois,) = ctx.saved_tensors
         shape, scale, sr = ctx.meta
         return roi_align_bwd(grad_out.contiguous(), rois, shape, scale, sr), None, None, None, None
+
+
+class PyramidRoIAlign(torch.autograd.Function):
+    """RoI pooling over a feature pyramid (attack/Stereo-RCNN/stereo_rcnn.py:110-141: every roi is pooled from the level its size
+    selects) with shapes known on the host: ``owner`` [R] int64 holds each roi's index into ``feats``; level l pools the whole roi list
+    with the rois it does not own marked skipped (batch index -1) - the forward launches write disjoint rows of ONE output, the backward
+    is the ordered gather per level.  No compaction, no read-back, no element-wise combination of per-level results."""
+
+    @staticmethod
+    def forward(ctx, rois, owner, pooled, scales, sampling_ratio, *feats):
+        r = rois.contiguous()
+        out = torch.empty((r.shape[0], feats[0].shape[1], pooled, pooled), dtype=torch.float32, device=r.device)
+        mine = []
+        minus = torch.full_like(r[:, 0], -1.0)
+        for l, f in enumerate(feats):
+            m = r.clone()
+            m[:, 0] = torch.where(owner == l, r[:, 0], minus)
+            roi_align(f.contiguous(), m, pooled, scales[l], sampling_ratio, out=out)
+            mine.append(m)
+        ctx.save_for_backward(*mine)
+        ctx.meta = ([tuple(f.shape) for f in feats], tuple(scales), sampling_ratio)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        shapes, scales, sr = ctx.meta
+        g = grad_out.contiguous()
+        grads = tuple(roi_align_bwd(g, m, shapes[l], scales[l], sr) if ctx.needs_input_grad[5 + l] else None for l, m in enumerate(ctx.saved_tensors))
+        return (None, None, None, None, None) + grads
 
 
 def nms(boxes, scores, thresh):

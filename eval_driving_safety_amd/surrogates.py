@@ -209,23 +209,14 @@ class StereoRcnnShaped(nn.Module):
         return bool(im.is_cuda and getattr(self, "rois_per_image", None) and self._roi_align is None and self._nms is None and self.static_shapes)
 
     def _pyramid_roi_feat_static(self, feats, rois, height, pooled):
-        """pyramid_roi_feat with shapes known on the host: every level pools ALL rois, those it does not own moved far outside the map
-        (legacy RoIAlign returns exact zeros for samples outside [-1, size] and its backward finds no tile for them), and the four results
-        are added - each roi's row is its owner's values plus three exact zeros."""
+        """pyramid_roi_feat with shapes known on the host (ops.PyramidRoIAlign): every level is handed the whole roi list with the rois it
+        does not own marked skipped, and the four launches fill disjoint rows of one output"""
         from . import ops
         h = rois[:, 4] - rois[:, 2] + 1
         w = rois[:, 3] - rois[:, 1] + 1
         level = torch.round(torch.log(torch.sqrt(h * w) / 224.0) + 4).clamp(2, 5)
-        fars = self.__dict__.setdefault("_far_roi", {})
-        if rois.device not in fars:           # (built once: a host-to-device copy has no place in a captured step)
-            fars[rois.device] = torch.tensor([0.0, -1.0e4, -1.0e4, -1.0e4, -1.0e4], device=rois.device)
-        far = fars[rois.device]
-        out = None
-        for i, l in enumerate(self.LEVELS):
-            mine = torch.where((level == l)[:, None], rois, far[None, :]).contiguous()
-            part = ops.RoIAlign.apply(feats[i].contiguous(), mine, pooled, feats[i].shape[2] / height, 0)
-            out = part if out is None else out + part
-        return out
+        owner = (level - float(self.LEVELS[0])).long()                      # LEVELS = (2, 3, 4, 5): index into feats
+        return ops.PyramidRoIAlign.apply(rois, owner, pooled, tuple(f.shape[2] / height for f in feats), 0, *feats)
 
     def _forward_static(self, im_left, im_right, im_info, gt_boxes_left, gt_boxes_right, gt_dim_orien, gt_kpts, num_boxes):
         """forward() operation for operation where shapes allow, masks and padded index lists where the original compacts (boolean

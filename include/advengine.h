@@ -255,7 +255,9 @@ ADV_API int adv_psv_build_lerp_bwd_f32(const float* grad_cost, const float* shif
 /* RoIAlign forward (legacy, non-"aligned" pixel model): rois [R,5] = (batch index, x1, y1, x2, y2) in image
  *     coordinates, scaled by spatial_scale; sampling_ratio <= 0 -> ceil(roi_size / pooled_size) samples per bin
  *     (the reference constructs ROIAlign(..., 1/16, 0) and passes the FPN level's scale per call);
- *     out [R,C,PH,PW] = mean of the bilinear samples of each bin. */
+ *     out [R,C,PH,PW] = mean of the bilinear samples of each bin.  A roi whose batch index is NEGATIVE is skipped: the forward leaves
+ *     its rows of out untouched, the backward adds nothing for it - one roi list can so be handed to every level of a feature pyramid,
+ *     each level owning some of the rois and all of them writing one output (stereo_rcnn.py:110-141 without compaction). */
 ADV_API int adv_roi_align_fwd_f32(const float* feat, const float* rois, float* out, int b, int c, int h, int w, int r,
                           int ph, int pw, float spatial_scale, int sampling_ratio, adv_stream_t stream);
 

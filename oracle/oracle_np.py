@@ -417,6 +417,8 @@ def roi_align(feat, rois, pooled, spatial_scale, sampling_ratio=0):
     ph, pw = (pooled, pooled) if isinstance(pooled, int) else pooled
     out = np.zeros((rois.shape[0], c, ph, pw), np.float32)
     for r, roi in enumerate(rois):
+        if roi[0] < 0:                 # a negative batch index: the roi is skipped (the kernel leaves its rows untouched; zeros here)
+            continue
         plane = feat[int(roi[0])]
         count = None
         for i, j, count, (valid, yl, xl, yh, xh, w1, w2, w3, w4) in _roi_samples(roi, spatial_scale, ph, pw, sampling_ratio, h, w):
@@ -466,6 +468,8 @@ def roi_align_bwd_ordered(grad_out, rois, feat_shape, spatial_scale, sampling_ra
     ph, pw = g.shape[2:]
     gf = np.zeros((b, c, h, w), np.float32)
     for r, roi in enumerate(rois):
+        if roi[0] < 0:                 # skipped roi (negative batch index): belongs to no image's tile lists
+            continue
         bi, sh, sw, bh, bw, gh, gw = _roi_bins(roi, spatial_scale, ph, pw, sampling_ratio)
         count = F32(gh * gw)
         for i in range(ph):

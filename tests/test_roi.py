@@ -37,6 +37,58 @@ def test_oracle_roi_align_adjoint_and_constant():
     assert np.allclose(O.roi_align(ones, inside, 7, 1 / 16.0), 1.0, atol=1e-6)
 
 
+def test_oracle_skips_rois_with_a_negative_batch_index():
+    rs = np.random.RandomState(4)
+    feat = rs.randn(2, 3, 12, 16).astype(np.float32)
+    rois = _rois(rs, 6, 2, 12 * 16, 16 * 16)
+    skip = rois.copy()
+    skip[[1, 4], 0] = -1
+    out, ref = O.roi_align(feat, skip, 3, 1 / 16.0), O.roi_align(feat, rois, 3, 1 / 16.0)
+    assert not out[[1, 4]].any() and out[[0, 2, 3, 5]].tobytes() == ref[[0, 2, 3, 5]].tobytes()
+    g = rs.randn(*out.shape).astype(np.float32)
+    keep = [0, 2, 3, 5]
+    assert O.roi_align_bwd_ordered(g, skip, feat.shape, 1 / 16.0).tobytes() == O.roi_align_bwd_ordered(g[keep], rois[keep], feat.shape, 1 / 16.0).tobytes()
+
+
+@pytest.mark.gpu
+def test_hip_roi_align_skips_negative_batch_indices_and_pools_a_pyramid():
+    """a roi with a negative batch index: the forward leaves its rows untouched, the backward adds nothing (bit-exact vs the oracle);
+    ops.PyramidRoIAlign (every level handed the whole list, non-owned rois skipped, one output) == pooling each level's own rois apart"""
+    from eval_driving_safety_amd import ops
+    dev = torch.device("cuda", 0)
+    rs = np.random.RandomState(8)
+    feat = rs.randn(2, 5, 20, 28).astype(np.float32)
+    rois = _rois(rs, 9, 2, 20 * 8, 28 * 8)
+    skip = rois.copy()
+    skip[[2, 5, 6], 0] = -1
+    tf, ts = torch.tensor(feat, device=dev), torch.tensor(skip, device=dev)
+    out = torch.full((9, 5, 4, 4), 7.0, device=dev)
+    ops.roi_align(tf, ts, 4, 1 / 8.0, out=out)
+    got = out.cpu().numpy()
+    want = O.roi_align(feat, skip, 4, 1 / 8.0)
+    owned = [0, 1, 3, 4, 7, 8]
+    assert (got[[2, 5, 6]] == 7.0).all() and got[owned].tobytes() == want[owned].tobytes()
+    g = rs.randn(9, 5, 4, 4).astype(np.float32)
+    gb = ops.roi_align_bwd(torch.tensor(g, device=dev), ts, feat.shape, 1 / 8.0).cpu().numpy()
+    assert gb.tobytes() == O.roi_align_bwd_ordered(g, skip, feat.shape, 1 / 8.0).tobytes()
+    # the pyramid: three levels of different size, owners by index
+    feats = [rs.randn(1, 4, 24 >> l, 40 >> l).astype(np.float32) for l in range(3)]
+    prois = _rois(rs, 11, 1, 24 * 4, 40 * 4)
+    owner = rs.randint(0, 3, 11)
+    scales = tuple(0.25 / (1 << l) for l in range(3))
+    tfs = [torch.tensor(f, device=dev, requires_grad=True) for f in feats]
+    pooled = ops.PyramidRoIAlign.apply(torch.tensor(prois, device=dev), torch.tensor(owner, device=dev), 3, scales, 0, *tfs)
+    gp = rs.randn(11, 4, 3, 3).astype(np.float32)
+    pooled.backward(torch.tensor(gp, device=dev))
+    for l in range(3):
+        idx = np.nonzero(owner == l)[0]
+        if len(idx):
+            assert pooled.detach().cpu().numpy()[idx].tobytes() == O.roi_align(feats[l], prois[idx], 3, scales[l]).tobytes(), l
+        masked = prois.copy()
+        masked[owner != l, 0] = -1
+        assert tfs[l].grad.cpu().numpy().tobytes() == O.roi_align_bwd_ordered(gp, masked, feats[l].shape, scales[l]).tobytes(), l
+
+
 def test_oracle_nms_small_cases():
     boxes = np.float32([[0, 0, 10, 10], [1, 1, 11, 11], [20, 20, 30, 30], [0, 0, 10, 10], [21, 21, 29, 29]])
     assert O.nms(boxes, 0.5).tolist() == [0, 2]
