@@ -187,12 +187,13 @@ class StereoRcnnShaped(nn.Module):
         import weakref
         cache = self.__dict__.setdefault("_host_cache", {})
         hit = cache.get(id(t))
-        if hit is not None and hit[0]() is t and hit[1] == (t._version, n):       # the same tensor OBJECT, unmodified (an address alone could be a new tensor's)
+        stamp = (t._version, t.data_ptr(), n)         # in-place writes bump the version, ``t.data = other`` moves the pointer
+        if hit is not None and hit[0]() is t and hit[1] == stamp:                   # the same tensor OBJECT, untouched (an address alone could be a new tensor's)
             return hit[2]
         if len(cache) > 64:
             cache.clear()
         vals = [float(v) for v in t.reshape(-1)[:n].tolist()]
-        cache[id(t)] = (weakref.ref(t), (t._version, n), vals)
+        cache[id(t)] = (weakref.ref(t), stamp, vals)
         return vals
 
     # Whether forward() may take the path without host read-backs (_forward_static): this package's own RoIAlign / NMS and a fixed
