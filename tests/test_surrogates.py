@@ -337,6 +337,24 @@ def test_static_forward_equals_the_compacting_forward():
         assert float((ga - gb).abs().max()) <= 1e-4 * float(ga.abs().max()), n_gt
 
 
+def test_host_value_cache_follows_the_tensor():
+    """StereoRcnnShaped._host_values remembers im_info / num_boxes per tensor object (no read-back per step) - and must notice an in-place
+    write (version) and a ``.data`` swap (pointer), as patch_attack.py:188 does with num_boxes"""
+    from eval_driving_safety_amd import surrogates
+    dev = torch.device("cuda", 0)
+    model = surrogates.StereoRcnnR101(seed=1, rois_per_image=32, blocks=(1, 1, 1, 1)).to(dev).eval()
+    nb = torch.tensor([3], device=dev)
+    assert model._host_values(nb, 1) == [3.0] and model._host_values(nb, 1) is model._host_values(nb, 1)      # cached list object
+    nb.fill_(2)
+    assert model._host_values(nb, 1) == [2.0]
+    nb.data = torch.tensor([5], device=dev)
+    assert model._host_values(nb, 1) == [5.0]
+    nb.data = torch.tensor(1)                                   # the reference's own statement: a CPU scalar from then on
+    assert model._host_values(nb, 1) == [1.0]
+    info = torch.tensor([[600.0, 1987.0, 1.0]], device=dev)
+    assert model._host_values(info, 2) == [600.0, 1987.0]
+
+
 def test_cli_layerlist_models_and_graph_flag(tmp_path):
     """`--model layerlist`: the attack CLIs on the random-weight networks with the upstream layer lists (what bench.py's end-to-end legs
     measure) - DSGN with one PGD iteration captured in a hipGraph (`--graph`), Stereo R-CNN's ResNet-101-FPN eagerly"""
