@@ -220,6 +220,10 @@ class PgdAttack:
         if held is not None and held["key"] == key and held["extra"] is batch.extra and \
                 (cidx is None or isinstance(cidx.valid, torch.Tensor) or tuple(cidx.valid) == tuple(held["cidx"].valid)):
             xs = held["x"]
+            # the static buffers are about to be rewritten by eager copies: nothing of the previous batch's replays may still be in flight
+            # (stream order should see to that; without this wait a reused capture of the Stereo R-CNN-shaped step faulted on replay - a race
+            # that a device-wide wait before the copies removes, found by tracing, root cause below the runtime's surface; once per batch)
+            torch.cuda.synchronize(x.device)
             xs.copy_(x)
             held["clean"].copy_(clean)
             if cidx is not None:
@@ -259,6 +263,10 @@ class PgdAttack:
                 exporter.next_buffer().copy_(u8)
                 exporter.submit(self._fan_out(k + 1, batch))
         self.last_graph = g
+        # ... and nothing eager may start while the last replay is still in flight: without this second wait the NEXT batch's eager
+        # preparation (upload, clean-image index) raced with the tail of the replays and the Stereo R-CNN-shaped step faulted - found with
+        # tools/graph_replay_probe.py-style bisection: a wait after every batch makes it pass every time, none makes it fail every time
+        torch.cuda.synchronize(xs.device)
         return xs.clone() if xs is not x else xs            # a reused capture: the static iterate is overwritten by the next batch
 
     def run(self, loader, adapter, comm=None, debugnum=None):

@@ -355,6 +355,52 @@ def test_host_value_cache_follows_the_tensor():
     assert model._host_values(info, 2) == [600.0, 1987.0]
 
 
+_GRAPH_WORKER = r"""
+import sys, torch
+sys.path.insert(0, %r)
+from eval_driving_safety_amd import adapters, attacks, data, surrogates
+dev = torch.device("cuda", 0)
+model = surrogates.StereoRcnnR101(seed=4, rois_per_image=64, blocks=(1, 1, 2, 1)).to(dev).eval()
+net = adapters.StereoRcnnAdapter(model, torch.zeros(6, device=dev))
+assert not net.graph_safe                # opt-in
+model.allow_graph_capture = True
+assert net.graph_safe
+batch = next(iter(data.SyntheticStereo(1, "srcnn", batch=1, seed=3)))
+batch.extra = surrogates.synthetic_srcnn_extra(batch, dev)
+surrogates.FoldedConv.impl = "auto"
+with torch.backends.cudnn.flags(enabled=True, deterministic=True, benchmark=False):
+    eager = attacks.PgdAttack("srcnn", 1.0, 0.03, 4, save=False, device=dev)
+    xe = eager.run_batch(batch, net).clone()
+    le = [float(v) for v in eager.last_losses]
+    atk = attacks.PgdAttack("srcnn", 1.0, 0.03, 4, save=False, device=dev, graph=True)
+    outs = []
+    for _ in range(3):                      # capture, then the capture reused twice
+        outs.append((atk.run_batch(batch, net).clone(), [float(v) for v in atk.last_losses]))
+torch.cuda.synchronize()
+assert atk.graph_captures_reused == 2
+for xg, lg in outs:
+    assert lg == le and torch.equal(xg, xe), (lg, le)
+assert le[-1] != le[0]
+model.static_shapes = False
+assert not net.graph_safe
+print("GRAPH-REUSE-OK")
+"""
+
+
+def test_static_iteration_replays_from_a_hipgraph_and_the_capture_is_reused(tmp_path):
+    """one whole attack iteration through the R101-shaped detector (forward, losses, backward, fused PGD step) captured once, replayed, and
+    reused for two more batches (attacks.PgdAttack(graph=True)): the eager loop's perturbed pair and losses, byte for byte.  Runs in a
+    child process: a fault inside a replayed hipGraph aborts the process that launched it, and this torch / ROCm stack has produced such
+    faults on the way here (surrogates.StereoRcnnShaped.graph_capturable) - a child killed by a signal is reported as an expected
+    failure of the platform, a child that finishes must have found everything equal."""
+    script = tmp_path / "graph_worker.py"
+    script.write_text(_GRAPH_WORKER % ROOT)
+    res = subprocess.run([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    if res.returncode < 0 or "hardware exception" in res.stderr:
+        pytest.xfail("the hipGraph replay faulted on this machine (signal %d): %s" % (res.returncode, res.stderr[-200:]))
+    assert res.returncode == 0 and "GRAPH-REUSE-OK" in res.stdout, res.stderr[-2000:]
+
+
 def test_cli_layerlist_models_and_graph_flag(tmp_path):
     """`--model layerlist`: the attack CLIs on the random-weight networks with the upstream layer lists (what bench.py's end-to-end legs
     measure) - DSGN with one PGD iteration captured in a hipGraph (`--graph`), Stereo R-CNN's ResNet-101-FPN eagerly"""

@@ -185,7 +185,55 @@ def measure_dsgn_full(pairs=1, iters=20, reps=1, graph=False, hip2d="auto"):
             "note": "NOT the headline metric and NOT DSGN's weights; layer list [UPSTREAM-UNVERIFIED] from the published PSMNet / DSGN structures"}
 
 
-def measure_srcnn_r101(pairs=1, iters=20, reps=1, rois=512, impl="auto", graph_backbone=False):
+def _graph_leg_in_child(pairs, iters, rois, fwd_flops):
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--r101-graph-leg", "--pairs", str(pairs), "--iters", str(iters), "--rois", str(rois)]
+    try:
+        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    except subprocess.TimeoutExpired:
+        return {"error": "the child process did not finish in 900 s"}
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    if res.returncode != 0 or not lines:
+        return {"error": "child process ended with code %d" % res.returncode, "stderr_tail": res.stderr[-300:]}
+    out = json.loads(lines[-1])
+    out["roofline"] = {"bound": "mfma", "what": "ONE replayed iteration - detector forward + backward AND the fused PGD step - against the float32 matrix peak",
+                       "achieved": 2.0 * fwd_flops / out["graph_replay_ms_per_iteration"] / 1e9, "peak": 157.3, "unit": "TFLOP/s",
+                       "frac": 2.0 * fwd_flops / out["graph_replay_ms_per_iteration"] / 1e9 / 157.3}
+    return out
+
+
+def graph_leg_r101(pairs=1, iters=20, rois=512):
+    """the child's side of _graph_leg_in_child: capture, one reused attack (timed), replay timing"""
+    from eval_driving_safety_amd import adapters, attacks, data, surrogates
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    surrogates.FoldedConv.impl = "auto"
+    model = surrogates.StereoRcnnR101(seed=0, rois_per_image=rois).to(dev).eval()
+    model.allow_graph_capture = True              # opt-in: see surrogates.StereoRcnnShaped.allow_graph_capture
+    net = adapters.StereoRcnnAdapter(model, torch.zeros(6, device=dev))
+    batch = next(iter(data.SyntheticStereo(pairs, "srcnn", batch=pairs, seed=0)))
+    batch.extra = surrogates.synthetic_srcnn_extra(batch, dev)
+    atk = attacks.PgdAttack("srcnn", 1.0, 0.03, iters, save=False, device=dev, graph=True)
+    atk.run_batch(batch, net)                     # pays the capture (two eager warm-up iterations + instantiation)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    atk.run_batch(batch, net)                     # the next batch with the same label set: the capture is reused
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    g = atk.last_graph
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return {"metric": "the same %d-step attack with ONE iteration (detector forward + backward + fused PGD step) captured in a hipGraph, capture reused" % iters,
+            "value": pairs / dt, "unit": "stereo-pairs/s", "s_per_attack": dt, "graph_replay_ms_per_iteration": e0.elapsed_time(e1) / 10,
+            "captures_reused": getattr(atk, "graph_captures_reused", 0),
+            "loss_first_iter": float(atk.last_losses[0]), "loss_last_iter": float(atk.last_losses[-1])}
+
+
+def measure_srcnn_r101(pairs=1, iters=20, reps=1, rois=512, impl="auto", graph_backbone=False, graph_leg=True):
     """BASELINE configs[2] with the upstream LAYER LIST (surrogates.StereoRcnnR101: ResNet-101 [3,4,23,3] + FPN P2-P6 + stereo RPN + RoI
     heads, random weights, batch-norms folded): 20-step PGD at 600x1987, exact FLOPs per detector step from the layer list, the
     whole-step rate against the float32 matrix peak.  ``impl``: "miopen" = every 2D convolution through torch (MIOpen / rocBLAS),
@@ -238,30 +286,11 @@ def measure_srcnn_r101(pairs=1, iters=20, reps=1, rois=512, impl="auto", graph_b
         dt = (time.perf_counter() - t0) / reps
         peak = torch.cuda.max_memory_allocated() / 2 ** 30
         hip_graph = None
-        if net.graph_safe:      # the whole iteration (detector forward + backward + fused PGD step) captured once and replayed: no launch gaps at all
-            try:
-                gatk = attacks.PgdAttack("srcnn", 1.0, 0.03, iters, save=False, device=dev, graph=True)
-                gatk.run_batch(batch, net)                     # pays the capture
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                gatk.run_batch(batch, net)
-                torch.cuda.synchronize()
-                gdt = time.perf_counter() - t0
-                g = gatk.last_graph
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(5):
-                    g.replay()
-                e1.record()
-                torch.cuda.synchronize()
-                replay_ms = e0.elapsed_time(e1) / 5
-                hip_graph = {"metric": "the same %d-step attack with ONE iteration (detector forward + backward + fused PGD step) captured in a hipGraph" % iters,
-                             "value": pairs / gdt, "unit": "stereo-pairs/s", "s_per_attack": gdt, "graph_replay_ms_per_iteration": replay_ms,
-                             "launch_gap_share_of_eager_step": max(0.0, 1.0 - replay_ms / model_ms),
-                             "roofline_frac_of_replayed_step": 2.0 * fwd / replay_ms / 1e9 / 157.3,
-                             "loss_first_iter": float(gatk.last_losses[0]), "loss_last_iter": float(gatk.last_losses[-1])}
-            except Exception as e:      # noqa: BLE001 - a measurement leg must not take the others down
-                hip_graph = {"error": repr(e)}
+        if graph_leg and model._static_ok(x):
+            # The whole iteration (detector forward + backward + fused PGD step) captured once, reused for the next batch, replayed: no launch
+            # gaps.  In a CHILD process: a fault inside a replayed graph aborts the process that launched it (this stack has produced such
+            # faults), and this one must still print its line.
+            hip_graph = _graph_leg_in_child(pairs, iters, rois, fwd)
     finally:
         surrogates.FoldedConv.impl = "miopen"
     step = 2.0 * fwd                               # forward + backward w.r.t. the input: every layer's adjoint costs its forward
@@ -476,10 +505,14 @@ def main():
     ap.add_argument("--r101", action="store_true", help="the ResNet-101-FPN Stereo R-CNN-shaped detector (upstream layer list) at 600x1987")
     ap.add_argument("--full", action="store_true", help="the DSGN-shaped graph with SURVEY App. B's layer list (adapters.DsgnShapedAdapter)")
     ap.add_argument("--graph", action="store_true", help="--full: one PGD iteration captured in a hipGraph; --r101: the backbone + FPN forward / backward as hipGraphs")
+    ap.add_argument("--r101-graph-leg", action="store_true", help="(child process of --r101) the captured-iteration measurement alone")
     ap.add_argument("--rois", type=int, default=512)
     ap.add_argument("--hip2d", action="store_true", help="--r101: libadvengine's 2D convolution kernels where one exists")
     args = ap.parse_args()
     torch.cuda.set_device(0)
+    if args.r101_graph_leg:
+        print(json.dumps(graph_leg_r101(args.pairs, args.iters, args.rois)))
+        return
     if args.full:
         print(json.dumps(measure_dsgn_full(args.pairs, args.iters, args.reps, graph=args.graph, hip2d=(False if args.miopen else (True if args.hip2d else "auto")))))
         return
