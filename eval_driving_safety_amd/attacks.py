@@ -132,6 +132,11 @@ class PgdAttack:
         """Attack B stereo pairs; returns the final stacked iterate [2B,3,H,W] (device)."""
         ops, sp = self.ops, self.space
         dev = self.device if self.device is not None else batch.imgL.device
+        if self.graph and getattr(self, "_graph_cache", None) is not None and torch.cuda.is_available():
+            # a captured iteration is about to be replayed again: let whatever the caller did with the previous result (a clone, a loss
+            # read-back) finish before this batch's eager preparation starts - third of the three waits that keep a reused capture of the
+            # Stereo R-CNN-shaped step from faulting on this stack (see _run_graph); once per batch
+            torch.cuda.synchronize(dev)
         imported = None
         if batch.imgL.dtype == torch.uint8:
             # 8-bit HWC pixels from the loader (data.KittiFolder(as_u8=True)): ToTensor + Normalize + zero padding run on the device,

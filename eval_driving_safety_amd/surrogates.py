@@ -204,9 +204,10 @@ class StereoRcnnShaped(nn.Module):
     # can capture it: replays equal the eager loop byte for byte and take 44.6 ms against 47.6 (ResNet-101-FPN, 600 x 1987).  OPT-IN
     # (``allow_graph_capture = True``), because replayed hipGraphs of this step are not dependable on this torch / ROCm stack: found by
     # bisection (profiles/r04_graph_replay_probe.txt) and worked around - a bitwise OR of bool tensors inside the capture faults on replay
-    # (masks are combined arithmetically here), ``pos[idx] = True`` copies a host scalar (index_fill_), eager work overlapping the replays
-    # of a reused capture faults (attacks._run_graph waits before and after a batch) - and still one allocation pattern is left in which
-    # the second batch faults (tests/test_surrogates.py runs it in a child process).  A fault aborts the process: not on by default.
+    # (masks are combined arithmetically here), ``pos[idx] = True`` copies a host scalar (index_fill_), and eager work overlapping the
+    # replays of a reused capture faults - attacks.PgdAttack waits for the device at a batch's entry, before the static buffers are
+    # rewritten and after the last replay; with the three waits every pattern that faulted passes (tests/test_surrogates.py runs the
+    # scenario in a child process).  The root cause lies below the runtime's surface and a fault aborts the process: not on by default.
     allow_graph_capture = False
 
     @property
