@@ -217,8 +217,9 @@ class PgdAttack:
         if not self.in_place:
             raise ValueError("graph=True replays one captured iteration on one buffer: it needs in_place=True")
         if not getattr(adapter, "graph_safe", False):
-            raise ValueError("%s does not declare graph_safe: a detector step with host read-backs or data-dependent shapes (the "
-                             "proposal-based Stereo R-CNN graphs, upstream models) cannot be captured in a hipGraph" % type(adapter).__name__)
+            raise ValueError("%s does not declare graph_safe: a detector step with host read-backs or data-dependent shapes (upstream models; the "
+                             "Stereo R-CNN-shaped surrogates unless their static forward is opted in: allow_graph_capture) cannot be captured in a "
+                             "hipGraph" % type(adapter).__name__)
         any_export = exporter is not None and any(self._wanted(k + 1) for k in range(self.iters))
         key = (id(adapter), tuple(x.shape), x.device, cidx is not None, None if cidx is None else isinstance(cidx.valid, torch.Tensor), any_export, rows, cols)
         held = getattr(self, "_graph_cache", None)
