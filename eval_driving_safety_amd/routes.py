@@ -26,7 +26,7 @@ import torch
 _DEFAULT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "routes_gfx950.json")
 ROUTES = ("hip", "wino", "", "direct")         # "" = torch's operator (MIOpen / rocBLAS); "direct"/"wino" for the 3D stride-1 layers
 
-_state = {"mode": None, "table": None, "path": None, "measured": {}, "misses": set(), "used": {}}
+_state = {"mode": None, "table": None, "path": None, "measured": {}, "misses": set(), "used": {}, "memo": {}}
 
 
 def key_str(key):
@@ -55,7 +55,7 @@ def _load(path):
 def configure(mode=None):
     """(re)read ADV_ROUTES (or take ``mode``): "table" | "fixed" | "measure" | a path"""
     mode = mode if mode is not None else os.environ.get("ADV_ROUTES", "table")
-    _state["measured"], _state["misses"], _state["used"] = {}, set(), {}
+    _state["measured"], _state["misses"], _state["used"], _state["memo"] = {}, set(), {}, {}
     if mode in ("fixed", "measure"):
         _state.update(mode=mode, table={}, path=None)
     else:
@@ -110,6 +110,13 @@ def choose(key, fns):
     no launch, no clock, the same answer in every process.  Measure mode: times each candidate once per key (outside stream
     captures), remembers the winner - and the timings, for tools/make_routes.py."""
     m = mode()
+    if m != "measure":              # the answer is a function of (key, candidates): remembered - the string key costs more than the lookup
+        try:
+            hit = _state["memo"].get((key, tuple(fns)))
+        except TypeError:           # an unhashable key (a list inside): not memoised
+            hit = None
+        if hit is not None:
+            return hit
     ks = key_str(key)
     if m == "measure":
         got = _state["measured"].get(ks)
@@ -126,6 +133,11 @@ def choose(key, fns):
                 _state["misses"].add(ks)
             r = fixed_rule(fns)
     _state["used"][ks] = r
+    if m != "measure":
+        try:
+            _state["memo"][(key, tuple(fns))] = r
+        except TypeError:
+            pass
     return r
 
 
