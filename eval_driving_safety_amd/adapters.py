@@ -548,6 +548,29 @@ class StereoRcnnAdapter:
         their static path (surrogates.StereoRcnnShaped.graph_capturable); upstream's proposal layers read back and compact"""
         return bool(getattr(self.model, "graph_capturable", False))
 
+    _EXTRA_TENSORS = ("im_info", "gt_boxes_left", "gt_boxes_right", "gt_boxes_merge", "gt_dim_orien", "gt_kpts", "num_boxes")
+
+    def graph_extra_signature(self, extra):
+        """what of a label set is a HOST constant of a captured iteration (attacks.PgdAttack(graph=True)): image size, number of boxes,
+        tensor shapes.  Two label sets with the same signature can share a capture - their tensors are copied into the captured ones."""
+        m = self.model
+        if not getattr(m, "graph_capturable", False) or not all(torch.is_tensor(getattr(extra, k, None)) and getattr(extra, k).is_cuda
+                                                                 for k in self._EXTRA_TENSORS):
+            return None
+        return (tuple(m._host_values(extra.im_info, 2)), int(m._host_values(extra.num_boxes, 1)[0])) + \
+            tuple(tuple(getattr(extra, k).shape) for k in self._EXTRA_TENSORS)
+
+    def graph_copy_extra(self, dst, src):
+        for k in self._EXTRA_TENSORS:
+            getattr(dst, k).copy_(getattr(src, k))
+
+    def graph_clone_extra(self, extra):
+        import types
+        out = types.SimpleNamespace(**vars(extra))
+        for k in self._EXTRA_TENSORS:
+            setattr(out, k, getattr(extra, k).clone())
+        return out
+
     def loss_and_grad(self, x, extra):
         u = self.uncert
         h = _LeafGrad(x)

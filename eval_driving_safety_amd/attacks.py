@@ -108,6 +108,7 @@ class PgdAttack:
         # without host read-backs or data-dependent shapes (adapters.PsvStereoAdapter / DsgnShapedAdapter; not the proposal-based
         # Stereo R-CNN graphs); same bits as the eager loop (tests/test_gpu_drivers.py).
         self.graph = bool(graph)
+        self.max_graphs = 4          # captures kept for reuse (graph=True): one per label signature, least recently used dropped
         self.writer = pixelio.PngWriter(writer_workers, bgr=(model_kind == "srcnn"), compress_level=png_compress_level) if save else None
 
     # -- file surface --------------------------------------------------------------------------
@@ -222,9 +223,22 @@ class PgdAttack:
                              "hipGraph" % type(adapter).__name__)
         any_export = exporter is not None and any(self._wanted(k + 1) for k in range(self.iters))
         key = (id(adapter), tuple(x.shape), x.device, cidx is not None, None if cidx is None else isinstance(cidx.valid, torch.Tensor), any_export, rows, cols)
-        held = getattr(self, "_graph_cache", None)
-        if held is not None and held["key"] == key and held["extra"] is batch.extra and \
-                (cidx is None or isinstance(cidx.valid, torch.Tensor) or tuple(cidx.valid) == tuple(held["cidx"].valid)):
+        # another batch's labels fit a capture when they are the same OBJECT - or when the adapter can say so: ``graph_extra_signature``
+        # (everything of the labels that is a host constant of the capture: counts, sizes, shapes) equal, and the label TENSORS copied into
+        # the captured ones (``graph_copy_extra``).  Up to ``max_graphs`` captures are kept (each holds its private memory pool).
+        sig_fn = getattr(adapter, "graph_extra_signature", None)
+        sig = sig_fn(batch.extra) if sig_fn is not None else None
+        pool = self.__dict__.setdefault("_graph_caches", [])
+        held = None
+        for h in pool:
+            if h["key"] == key and (h["extra"] is batch.extra or (sig is not None and h["sig"] == sig)) and \
+                    (cidx is None or isinstance(cidx.valid, torch.Tensor) or tuple(cidx.valid) == tuple(h["cidx"].valid)):
+                held = h
+                break
+        if held is not None:
+            pool.remove(held)
+            pool.append(held)                                # most recently used last
+            self._graph_cache = held
             xs = held["x"]
             # the static buffers are about to be rewritten by eager copies: nothing of the previous batch's replays may still be in flight
             # (stream order should see to that; without this wait a reused capture of the Stereo R-CNN-shaped step faulted on replay - a race
@@ -232,6 +246,8 @@ class PgdAttack:
             torch.cuda.synchronize(x.device)
             xs.copy_(x)
             held["clean"].copy_(clean)
+            if held["extra"] is not batch.extra:
+                adapter.graph_copy_extra(held["extra"], batch.extra)
             if cidx is not None:
                 for name in ("index", "ok", "lut"):
                     getattr(held["cidx"], name).copy_(getattr(cidx, name))
@@ -242,9 +258,11 @@ class PgdAttack:
             xs, cs = x, clean                               # this batch's own buffers become the static ones
             u8 = ops.alloc_u8(x.shape[0], rows, x.shape[3], x.device) if any_export else None
             kw = {"clean_index": cidx} if cidx is not None else {}
+            # labels shared by signature are captured through a private copy (later batches' tensors are copied INTO it: the caller's stay untouched)
+            static_extra = adapter.graph_clone_extra(batch.extra) if sig is not None else batch.extra
 
             def iteration():
-                loss, grad = adapter.loss_and_grad(xs, batch.extra)
+                loss, grad = adapter.loss_and_grad(xs, static_extra)
                 ops.pgd_step(xs, grad.contiguous(), cs, sp, self.alpha, self.eps, out=xs, u8_out=u8, crop=(rows, cols) if u8 is not None else None, **kw)
                 return loss
 
@@ -260,7 +278,10 @@ class PgdAttack:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 loss_buf = iteration().detach().reshape(()).clone()
-            held = self._graph_cache = {"key": key, "extra": batch.extra, "g": g, "x": xs, "clean": cs, "cidx": cidx, "u8": u8, "loss": loss_buf}
+            held = self._graph_cache = {"key": key, "extra": static_extra, "sig": sig, "g": g, "x": xs, "clean": cs, "cidx": cidx, "u8": u8, "loss": loss_buf}
+            pool.append(held)
+            while len(pool) > self.max_graphs:
+                pool.pop(0)                                  # the least recently used capture and its memory pool go
         g, u8, loss_buf = held["g"], held["u8"], held["loss"]
         for k in range(self.iters):
             g.replay()

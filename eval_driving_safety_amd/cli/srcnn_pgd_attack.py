@@ -46,9 +46,10 @@ def main(argv=None):
         adapter = adapters.StereoRcnnAdapter(rt.model, rt.uncert)
         loader = upstream.srcnn_loader(rt)
     if args.graph:
-        raise SystemExit("--graph: a captured Stereo R-CNN iteration is reused only for the label set it was captured with (ground-truth counts and image "
-                         "sizes are host constants of the capture) - per pair of a data set it costs three iterations more than it saves; upstream "
-                         "models read back and compact.  attacks.PgdAttack(graph=True) takes the layer-list surrogates from Python.")
+        raise SystemExit("--graph: not offered for the Stereo R-CNN scripts.  The layer-list surrogates' iteration can be captured from Python "
+                         "(attacks.PgdAttack(graph=True) with surrogates.StereoRcnnShaped.allow_graph_capture, reused across label sets with the "
+                         "same host constants), but with the PNG export running beside the replays it faulted on this torch / ROCm stack; "
+                         "upstream models read back and compact")
     atk = PgdAttack("srcnn", args.alpha, args.eps, args.iter, out_root=args.out_root, save_every=args.save_every, device=dev)
     # `if args.debug and i >= args.debugnum: break` (:107-108): debugnum - 1 is the last index attacked
     n = atk.run(loader, adapter, comm, debugnum=(args.debugnum - 1) if (args.debug and args.debugnum is not None) else None)

@@ -207,7 +207,8 @@ class StereoRcnnShaped(nn.Module):
     # (masks are combined arithmetically here), ``pos[idx] = True`` copies a host scalar (index_fill_), and eager work overlapping the
     # replays of a reused capture faults - attacks.PgdAttack waits for the device at a batch's entry, before the static buffers are
     # rewritten and after the last replay; with the three waits every pattern that faulted passes (tests/test_surrogates.py runs the
-    # scenario in a child process).  The root cause lies below the runtime's surface and a fault aborts the process: not on by default.
+    # scenario in a child process) - except with the PNG export's copies and writer threads running beside the replays (the CLI: it faulted,
+    # so the Stereo R-CNN scripts do not offer --graph).  The root cause lies below the runtime's surface and a fault aborts the process: not on by default.
     allow_graph_capture = False
 
     @property

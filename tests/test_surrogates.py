@@ -376,8 +376,28 @@ with torch.backends.cudnn.flags(enabled=True, deterministic=True, benchmark=Fals
     outs = []
     for _ in range(3):                      # capture, then the capture reused twice
         outs.append((atk.run_batch(batch, net).clone(), [float(v) for v in atk.last_losses]))
+    # another label set with the same host constants (one box, same image size) shares the capture: its tensors are copied into the
+    # captured ones; a label set with two boxes needs a capture of its own
+    import copy
+    b2 = copy.copy(batch)
+    b2.extra = surrogates.synthetic_srcnn_extra(batch, dev)
+    b2.extra.gt_boxes_left[:, 0, :4] += torch.tensor([-60.0, 20.0, -40.0, 30.0], device=dev)
+    b2.extra.gt_boxes_right[:, 0, :4] += torch.tensor([-60.0, 20.0, -40.0, 30.0], device=dev)
+    b2.extra.gt_boxes_merge.copy_(b2.extra.gt_boxes_left)
+    keep_first = batch.extra.gt_boxes_left.clone()
+    x2e, x2g = eager.run_batch(b2, net).clone(), atk.run_batch(b2, net).clone()
+    reused_after_b2 = atk.graph_captures_reused
+    b3 = copy.copy(batch)
+    b3.extra = surrogates.synthetic_srcnn_extra(batch, dev)
+    b3.extra.gt_boxes_left[:, 1] = torch.tensor([200.0, 280.0, 420.0, 400.0, 1.0], device=dev)
+    b3.extra.gt_boxes_right[:, 1] = torch.tensor([170.0, 280.0, 390.0, 400.0, 1.0], device=dev)
+    b3.extra.gt_boxes_merge.copy_(b3.extra.gt_boxes_left)
+    b3.extra.num_boxes.fill_(2)
+    x3e, x3g = eager.run_batch(b3, net).clone(), atk.run_batch(b3, net).clone()
 torch.cuda.synchronize()
-assert atk.graph_captures_reused == 2
+assert reused_after_b2 == 3 and atk.graph_captures_reused == 3 and len(atk._graph_caches) == 2
+assert torch.equal(x2e, x2g) and not torch.equal(x2e, xe) and torch.equal(x3e, x3g)
+assert torch.equal(batch.extra.gt_boxes_left, keep_first)          # the caller's labels were not written to
 for xg, lg in outs:
     assert lg == le and torch.equal(xg, xe), (lg, le)
 assert le[-1] != le[0]
