@@ -116,7 +116,8 @@ def choose(key, fns):
         except TypeError:           # an unhashable key (a list inside): not memoised
             hit = None
         if hit is not None:
-            return hit
+            _state["used"][hit[1]] = hit[0]          # (used() stays the record of every decision asked for)
+            return hit[0]
     ks = key_str(key)
     if m == "measure":
         got = _state["measured"].get(ks)
@@ -135,7 +136,7 @@ def choose(key, fns):
     _state["used"][ks] = r
     if m != "measure":
         try:
-            _state["memo"][(key, tuple(fns))] = r
+            _state["memo"][(key, tuple(fns))] = (r, ks)
         except TypeError:
             pass
     return r
