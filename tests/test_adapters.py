@@ -84,6 +84,31 @@ def test_stereo_rcnn_adapter_objective_equals_the_reference_statements(golden, g
     assert float(np.abs(g["srcnn_gradL"]).sum()) > 0 and float(np.abs(g["srcnn_gradR"]).sum()) > 0
 
 
+def test_stereo_rcnn_adapter_graph_hooks_on_the_host():
+    """what attacks.PgdAttack(graph=True) asks a Stereo R-CNN adapter: capturable only when the detector says so (the layer-list
+    surrogates' static forward, opted in); a label signature only for device tensors of such a detector; clone / copy of the labels"""
+    from eval_driving_safety_amd import surrogates
+    model = surrogates.StereoRcnnR101(seed=0, rois_per_image=16, blocks=(1, 1, 1, 1)).eval()
+    net = adapters.StereoRcnnAdapter(model, torch.zeros(6))
+    assert not net.graph_safe
+    model.allow_graph_capture = True
+    assert net.graph_safe
+    model.static_shapes = False
+    assert not net.graph_safe
+    model.static_shapes = True
+    extra = types.SimpleNamespace(im_info=torch.tensor([[600.0, 1987.0, 1.6]]), gt_boxes_left=torch.zeros(1, 30, 5), gt_boxes_right=torch.zeros(1, 30, 5),
+                                  gt_boxes_merge=torch.zeros(1, 30, 5), gt_dim_orien=torch.zeros(1, 30, 5), gt_kpts=torch.zeros(1, 30, 6),
+                                  num_boxes=torch.tensor([2]), note="kept by reference")
+    assert net.graph_extra_signature(extra) is None                       # CPU labels: no capture to share
+    assert model._host_values(extra.im_info, 2) == [600.0, 1987.0] and model._host_values(extra.num_boxes, 1) == [2.0]
+    twin = net.graph_clone_extra(extra)
+    assert twin.note == "kept by reference" and twin.gt_kpts is not extra.gt_kpts and torch.equal(twin.gt_kpts, extra.gt_kpts)
+    extra.gt_boxes_left[0, 0] = torch.tensor([1.0, 2.0, 3.0, 4.0, 1.0])
+    net.graph_copy_extra(twin, extra)
+    assert torch.equal(twin.gt_boxes_left, extra.gt_boxes_left)
+    assert not adapters.StereoRcnnAdapter(types.SimpleNamespace(), torch.zeros(6), freeze=False).graph_safe       # an upstream-like model says nothing: not capturable
+
+
 def test_toy_adapter_is_deterministic_and_nontrivial():
     a = adapters.ToyStereoAdapter(torch.device("cpu"), seed=3)
     x = torch.randn(2, 3, 32, 48)

@@ -186,9 +186,15 @@ def test_route_table_is_committed_and_well_formed():
     assert routes.choose(("f", 1, 8, 8, 1, (1, 8, 9, 9), False, True), {"hip": boom, "": boom}) == "hip"
     assert routes.choose(("f3", 8, 8, (1, 8, 3, 9, 9), False, True), {"direct": boom, "wino": boom}) == "wino"
     assert len(routes.misses()) == 3
+    # lookups are memoised per (key, candidates) - the answer, the record of decisions (used()) and the candidate set all still count
+    routes._state["used"].clear()
+    assert routes.choose(tup, {"hip": boom, "": boom, "wino": boom}) == "" and routes.used() == {key: ""}
+    assert routes.choose(tup, {"hip": boom, "wino": boom}) == "wino"               # torch not on offer for this call: the fixed rule among the rest
+    assert routes.choose(("f", 3, 8, 8, 1, [1, 8, 9, 9], False, True), {"hip": boom, "": boom, "wino": boom}) == "wino"      # unhashable key: not memoised, still answered
     routes.configure("fixed")
-    assert routes.choose(tup, {"hip": boom, "": boom, "wino": boom}) == "wino" and routes.table_hash() == "fixed"
+    assert routes.choose(tup, {"hip": boom, "": boom, "wino": boom}) == "wino" and routes.table_hash() == "fixed"      # (a new mode forgets the memo)
     routes.configure("table")
+    assert routes.choose(tup, {"hip": boom, "": boom, "wino": boom}) == ""
 
 
 def test_dilated_convolution_equals_plain_convolution_on_parity_sub_images():
