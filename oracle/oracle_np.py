@@ -559,7 +559,8 @@ def _up_taps(n_in, n_out):
 
 def bilinear_up(x, size):
     """csrc/resize.hip bilinear_up_fwd (F.interpolate(x, size, mode="bilinear", align_corners=False); the FPN's _upsample_add,
-    attack/Stereo-RCNN/stereo_rcnn.py:92-108): x [..., h, w] -> [..., ho, wo], every product and sum rounded on its own"""
+    attack/Stereo-RCNN/stereo_rcnn.py:92-108): x [..., h, w] -> [..., ho, wo], every product and sum rounded on its own.  PINNED by
+    tests/golden/upsample_add.npz (the reference's method executed, with its backward: tests/test_resize.py)"""
     x = _f32(x)
     h, w = x.shape[-2:]
     y0, y1, ly0, ly1 = _up_taps(h, size[0])

@@ -41,6 +41,41 @@ def test_oracle_bilinear_up_is_the_adjoint_pair():
     assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), 1.0)
 
 
+def _fixture_cases(golden, golden_index):
+    z = golden("upsample_add")
+    for i, c in enumerate(golden_index["upsample_add"]["cases"]):
+        yield i, tuple(c["in"]), tuple(c["out"]), z
+
+
+def test_oracle_against_the_references_upsample_add(golden, golden_index):
+    """tests/golden/upsample_add.npz: the reference's ``_upsample_add`` (attack/Stereo-RCNN/stereo_rcnn.py:91-108) executed on seeded maps
+    with its backward - the oracle's up-sampling + y and adjoint within float32 rounding of it, and adopt._upsample_add (what adopt()
+    rebinds the method to) equal to it bit for bit on the CPU"""
+    from eval_driving_safety_amd import adopt
+    for i, hw, size, z in _fixture_cases(golden, golden_index):
+        x, y, g = z["x%d" % i], z["y%d" % i], z["g%d" % i]
+        assert x.shape[2:] == hw and y.shape[2:] == size
+        np.testing.assert_allclose(O.bilinear_up(x, size) + y, z["out%d" % i], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(O.bilinear_up_bwd(g, hw), z["grad_x%d" % i], rtol=0, atol=2e-5)
+        t = torch.tensor(x, requires_grad=True)
+        res = adopt._upsample_add(t, torch.tensor(y))
+        res.backward(torch.tensor(g))
+        assert res.detach().numpy().tobytes() == z["out%d" % i].tobytes() and t.grad.numpy().tobytes() == z["grad_x%d" % i].tobytes()
+
+
+@pytest.mark.gpu
+def test_hip_against_the_references_upsample_add(golden, golden_index):
+    """the same fixture through csrc/resize.hip (ops.BilinearUp + y, as adopt() and the surrogates call it on the GPU)"""
+    from eval_driving_safety_amd import adopt
+    dev = torch.device("cuda", 0)
+    for i, hw, size, z in _fixture_cases(golden, golden_index):
+        t = torch.tensor(z["x%d" % i], device=dev, requires_grad=True)
+        res = adopt._upsample_add(t, torch.tensor(z["y%d" % i], device=dev))
+        res.backward(torch.tensor(z["g%d" % i], device=dev))
+        np.testing.assert_allclose(res.detach().cpu().numpy(), z["out%d" % i], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(t.grad.cpu().numpy(), z["grad_x%d" % i], rtol=0, atol=2e-5)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", CASES, ids=_ids)
 def test_hip_bilinear_up_fwd_bwd_bit_exact(case):
