@@ -540,6 +540,39 @@ def upsample_add_case():
     return out
 
 
+def pyramid_roi_case():
+    """RoI pooling over the feature pyramid: the reference's own ``PyramidRoI_Feat`` (attack/Stereo-RCNN/stereo_rcnn.py:110-141) lifted as
+    a function and executed - level per roi, per-level pooling at ``feat.size(2) / im_info[0][0]``, concatenation, sort back into roi
+    order - with the per-level operator held fixed (``RCNN_roi_align`` = the oracle's RoIAlign, 7x7; ``RCNN_roi_kpts_align`` = 14x14).
+    Pins surrogates.pyramid_roi_feat and ops.PyramidRoIAlign (level assignment, scales, row order)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import oracle_np as O
+    ns = exec_lines("attack/Stereo-RCNN/stereo_rcnn.py", 110, 141, {"torch": torch})
+    fn = ns["PyramidRoI_Feat"]
+
+    def pool(p):
+        return lambda feat, rois, scale: torch.from_numpy(O.roi_align(feat.numpy(), rois.numpy(), p, float(scale)))
+    me = types.SimpleNamespace(RCNN_roi_align=pool(7), RCNN_roi_kpts_align=pool(14))
+    gen = torch.Generator().manual_seed(91)
+    im_info = torch.tensor([[600.0, 1000.0, 1.6]])
+    feats = [torch.randn((1, 2, int(np.ceil(600 / s)), int(np.ceil(1000 / s))), generator=gen) for s in (4, 8, 16, 32)]
+    sizes = [18, 30, 47, 60, 90, 130, 140, 200, 230, 330, 380, 520, 45, 300]            # square-ish boxes across the four levels, ragged order
+    rois = []
+    for i, sz in enumerate(sizes):
+        x1, y1 = float(20 + 37 * i), float(10 + 23 * (i % 7))
+        rois.append([0.0, x1, y1, x1 + sz * (1.0 + 0.1 * (i % 3)), y1 + sz * (1.0 - 0.05 * (i % 4))])
+    rois = torch.tensor(rois)
+    arrays = {"rois": rois.numpy().copy(), "im_info": im_info.numpy().copy()}
+    for l, f in enumerate(feats):
+        arrays["feat%d" % l] = f.numpy().copy()
+    arrays["pooled7"] = fn(me, feats, rois, im_info).numpy().copy()
+    arrays["pooled14"] = fn(me, feats, rois, im_info, kpts=True).numpy().copy()
+    h = rois[:, 4] - rois[:, 2] + 1
+    w = rois[:, 3] - rois[:, 1] + 1
+    levels = torch.round(torch.log(torch.sqrt(h * w) / 224.0) + 4).clamp(2, 5)
+    return {"bytes": save_npz("pyramid_roi.npz", arrays), "rois": len(sizes), "levels_used": sorted(set(int(v) for v in levels))}
+
+
 def upstream_call_sites_case():
     """How the reference's own files USE the upstream operator package ``model.roi_layers`` (a compiled CUDA extension upstream;
     eval_driving_safety_amd/upstream_shims/roi_layers.py here): names imported, constructor and call arities, keyword names - read
@@ -647,6 +680,7 @@ def main():
     index["objectives"] = objective_cases()
     index["upstream_call_sites"] = upstream_call_sites_case()
     index["upsample_add"] = upsample_add_case()
+    index["pyramid_roi"] = pyramid_roi_case()
     with open(os.path.join(HERE, "index.json"), "w") as f:
         json.dump(index, f, indent=1, sort_keys=True)
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE)

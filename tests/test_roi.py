@@ -89,6 +89,44 @@ def test_hip_roi_align_skips_negative_batch_indices_and_pools_a_pyramid():
         assert tfs[l].grad.cpu().numpy().tobytes() == O.roi_align_bwd_ordered(gp, masked, feats[l].shape, scales[l]).tobytes(), l
 
 
+def _pyramid_fixture(golden):
+    z = golden("pyramid_roi")
+    return z, [z["feat%d" % l] for l in range(4)]
+
+
+def test_pyramid_roi_pooling_equals_the_references_executed_method(golden, golden_index):
+    """tests/golden/pyramid_roi.npz: the reference's ``PyramidRoI_Feat`` (attack/Stereo-RCNN/stereo_rcnn.py:110-141) executed with the
+    oracle's RoIAlign as the per-level operator - surrogates.pyramid_roi_feat (level per roi, scale per level, rows back in roi order)
+    around the same operator gives the same bytes, for the 7x7 and the 14x14 pooling"""
+    from eval_driving_safety_amd import surrogates
+    assert golden_index["pyramid_roi"]["levels_used"] == [2, 3, 4, 5]
+    z, feats = _pyramid_fixture(golden)
+    model = surrogates.StereoRcnnShaped.__new__(surrogates.StereoRcnnShaped)
+    torch.nn.Module.__init__(model)
+    model._roi_align = lambda f, r, p, s: torch.from_numpy(O.roi_align(f.numpy(), r.numpy(), p, float(s)))
+    tf = [torch.tensor(f) for f in feats]
+    for pooled, key in ((7, "pooled7"), (14, "pooled14")):
+        got = model.pyramid_roi_feat(tf, torch.tensor(z["rois"]), torch.tensor(z["im_info"]), pooled)
+        assert got.numpy().tobytes() == z[key].tobytes(), key
+
+
+@pytest.mark.gpu
+def test_hip_pyramid_roi_align_equals_the_references_executed_method(golden):
+    """the same fixture through ops.PyramidRoIAlign (surrogates._pyramid_roi_feat_static: no compaction, skipped rois, one output) and through
+    the compacting path on ops.RoIAlign: the reference's bytes"""
+    from eval_driving_safety_amd import surrogates
+    dev = torch.device("cuda", 0)
+    z, feats = _pyramid_fixture(golden)
+    model = surrogates.StereoRcnnShaped.__new__(surrogates.StereoRcnnShaped)
+    torch.nn.Module.__init__(model)
+    model._roi_align = None
+    tf = [torch.tensor(f, device=dev) for f in feats]
+    rois, info = torch.tensor(z["rois"], device=dev), torch.tensor(z["im_info"], device=dev)
+    for pooled, key in ((7, "pooled7"), (14, "pooled14")):
+        assert model._pyramid_roi_feat_static(tf, rois, float(z["im_info"][0, 0]), pooled).cpu().numpy().tobytes() == z[key].tobytes(), key
+        assert model.pyramid_roi_feat(tf, rois, info, pooled).cpu().numpy().tobytes() == z[key].tobytes(), key
+
+
 def test_oracle_nms_small_cases():
     boxes = np.float32([[0, 0, 10, 10], [1, 1, 11, 11], [20, 20, 30, 30], [0, 0, 10, 10], [21, 21, 29, 29]])
     assert O.nms(boxes, 0.5).tolist() == [0, 2]
