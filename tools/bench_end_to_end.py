@@ -189,9 +189,9 @@ def _graph_leg_in_child(pairs, iters, rois, fwd_flops):
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--r101-graph-leg", "--pairs", str(pairs), "--iters", str(iters), "--rois", str(rois)]
     try:
-        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)      # (normally ~40 s)
     except subprocess.TimeoutExpired:
-        return {"error": "the child process did not finish in 900 s"}
+        return {"error": "the child process did not finish in 300 s"}
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     if res.returncode != 0 or not lines:
         return {"error": "child process ended with code %d" % res.returncode, "stderr_tail": res.stderr[-300:]}
