@@ -211,10 +211,13 @@ def _make(conv, bn, relu):
     return _CONVS[type(conv)](conv, w, b, relu)
 
 
-def adopt(model, fuse_relu=True, fold_named_pairs=True, verify=None, tol=1e-4, freeze=True):
+def adopt(model, fuse_relu=True, fold_named_pairs=True, verify=None, tol=1e-4, freeze=True, functional=True):
     """Replace, IN PLACE, the convolutions of ``model`` by libadvengine-backed modules carrying the model's own weights (see the module
-    docstring).  -> {"replaced": [(qualified name, what)], "folded_bn": n, "fused_relu": n, "kept": [(name, why)], "upsample_add": modules whose
-    ``_upsample_add`` now has a deterministic backward}."""
+    docstring).  ``functional``: also bind the two functional patterns of a DSGN forward - 5-D ``F.grid_sample`` and the
+    ``F.interpolate(trilinear)`` -> softmax -> depth-weighted sum chain - to ``ops.GridSample3d`` / ``ops.DepthRegress`` by putting a proxy
+    where the defining Python modules hold ``torch.nn.functional`` (adopt_functional.py; ``adopt_functional.unbind()`` undoes it).
+    -> {"replaced": [(qualified name, what)], "folded_bn": n, "fused_relu": n, "kept": [(name, why)], "upsample_add": modules whose
+    ``_upsample_add`` now has a deterministic backward, "functional": [(python module, global name)] rebound}."""
     if model.training:
         raise ValueError("adopt() needs the model in eval mode (BatchNorm statistics are folded)")
     before = None
@@ -278,6 +281,10 @@ def adopt(model, fuse_relu=True, fold_named_pairs=True, verify=None, tol=1e-4, f
         if callable(getattr(type(m), "_upsample_add", None)):
             m._upsample_add = _upsample_add
             report["upsample_add"] += 1
+    report["functional"] = []
+    if functional:
+        from . import adopt_functional
+        report["functional"] = adopt_functional.bind(model)
     if freeze:
         for p in model.parameters():
             p.requires_grad_(False)

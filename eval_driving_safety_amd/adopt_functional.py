@@ -1,0 +1,296 @@
+"""The two FUNCTIONAL patterns of an upstream DSGN ``forward`` that a module walk cannot see (behind
+attack/DSGN/pgd_attack.py:308), bound to libadvengine by ``adopt.adopt(model, functional=True)``:
+
+  1. ``F.grid_sample(volume [B,C,D,H,W], grid [B,Z,Y,X,3])`` - the plane-sweep volume resampled into the 3D geometric volume -
+     -> ``ops.GridSample3d`` (csrc/volume.hip): the same bits as torch's CPU operator forward, a fixed-order GATHER backward instead of
+     torch's atomicAdd scatter (two runs give the same image gradient).  The gather plan is a function of the grid, i.e. of the
+     calibration: it is cached and reused while the grid's VALUES stay the same (one comparison on the device per call).
+
+  2. ``F.interpolate(cost [B,1,D,h,w], (Do,H,W), mode="trilinear")`` -> ``squeeze(1)`` -> ``softmax(dim=1)`` -> ``* depth[None,:,None,None]``
+     -> ``sum(1)`` - the depth regression - -> ``ops.DepthRegress``: ONE kernel each way that never writes the up-sampled volume
+     (Do x H x W = 92 M floats per sample at KITTI size; torch's unfused chain moves it six times forward and back).
+
+How: the checkout's Python modules hold a module-level ``F`` (``import torch.nn.functional as F``).  ``bind(model)`` replaces that global,
+in the modules that DEFINE the model's classes and nowhere else, by a proxy that forwards every attribute to the real package except
+``grid_sample`` and ``interpolate`` / ``upsample``.  Pattern 2 spans several statements, so the proxy's ``interpolate`` returns a LAZY
+tensor (a ``torch.Tensor`` wrapper subclass without storage): ``__torch_function__`` follows the chain squeeze -> softmax -> mul -> sum and
+emits the fused operator at the ``sum``; ANY other use of a lazy value materialises it with torch's own operators first - the adopted
+forward computes what the original computes, fused where the chain is recognised and unfused where it is not (``adopt(verify=...)``
+checks the outputs either way).  CPU tensors and anything else the kernels do not take (other dtypes, other modes, a grid that requires a
+gradient) go to torch's operator untouched.  ``unbind`` restores the globals."""
+import sys
+
+import torch
+import torch.nn.functional as _F
+
+_STATS = {"grid_sample": 0, "grid_plan_built": 0, "depth_regress": 0, "materialised": 0}
+
+
+def stats(reset=False):
+    """how often each pattern fired since the last reset (tests, the adoption report)"""
+    out = dict(_STATS)
+    if reset:
+        for k in _STATS:
+            _STATS[k] = 0
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ pattern 1: 5-D grid_sample
+class _PlanCache:
+    """the last few (grid values -> gather plan) pairs; a hit costs one ``torch.equal`` on the device"""
+
+    def __init__(self, keep=4):
+        self.keep, self.items = keep, []
+
+    def get(self, grid, dims, align):
+        from . import ops
+        key = (tuple(grid.shape), tuple(dims), bool(align), grid.device)
+        for i, (k, g, plan) in enumerate(self.items):
+            if k == key and torch.equal(g, grid):
+                self.items.insert(0, self.items.pop(i))
+                return plan
+        plan = ops.GridSamplePlan(grid, dims, align)
+        _STATS["grid_plan_built"] += 1
+        self.items.insert(0, (key, grid.detach().clone(), plan))
+        del self.items[self.keep:]
+        return plan
+
+
+_plans = _PlanCache()
+
+
+def grid_sample(input, grid, mode="bilinear", padding_mode="zeros", align_corners=None):
+    ok = (isinstance(input, torch.Tensor) and isinstance(grid, torch.Tensor) and type(input) is torch.Tensor and input.dim() == 5 and
+          grid.dim() == 5 and input.is_cuda and grid.is_cuda and input.dtype == torch.float32 and grid.dtype == torch.float32 and
+          mode == "bilinear" and padding_mode == "zeros" and not grid.requires_grad and grid.shape[-1] == 3 and grid.shape[0] == input.shape[0])
+    if not ok:
+        return _F.grid_sample(_plain(input), _plain(grid), mode=mode, padding_mode=padding_mode, align_corners=align_corners)
+    from . import ops
+    align = bool(align_corners)                       # torch's default (None) is align_corners=False
+    g = grid.detach().contiguous()
+    _STATS["grid_sample"] += 1
+    if not (input.requires_grad and torch.is_grad_enabled()):
+        return ops.grid_sample3d(input.contiguous(), g, align)
+    return ops.GridSample3d.apply(input, g, _plans.get(g, input.shape[2:], align))
+
+
+# ------------------------------------------------------------------------------------------------ pattern 2: the depth regression chain
+_UP, _UP4, _PROB, _WEIGHTED = "up", "up4", "prob", "weighted"
+
+
+class LazyDepth(torch.Tensor):
+    """a value of the chain  interpolate(trilinear) -> squeeze(1) -> softmax(1) -> * depth values -> sum(1)  that has not been computed"""
+
+    @staticmethod
+    def __new__(cls, stage, cost4, size, align, shape, zvals=None):
+        t = torch.Tensor._make_wrapper_subclass(cls, tuple(shape), dtype=cost4.dtype, device=cost4.device, requires_grad=False)
+        t._stage, t._cost4, t._size, t._align, t._zvals = stage, cost4, tuple(int(v) for v in size), align, zvals
+        return t
+
+    def _next(self, stage, shape, zvals=None):
+        return LazyDepth(stage, self._cost4, self._size, self._align, shape, self._zvals if zvals is None else zvals)
+
+    def materialise(self):
+        """the value torch's own operators give for this node"""
+        _STATS["materialised"] += 1
+        b, d, h, w = self._cost4.shape
+        v = _F.interpolate(self._cost4.unsqueeze(1), size=self._size, mode="trilinear", align_corners=self._align)
+        if self._stage == _UP:
+            return v
+        v = v.squeeze(1)
+        if self._stage == _UP4:
+            return v
+        v = torch.softmax(v, dim=1)
+        if self._stage == _PROB:
+            return v
+        return v * self._zvals.reshape(1, -1, 1, 1)
+
+    def __repr__(self):
+        return "LazyDepth(%s, cost %s -> %s)" % (self._stage, tuple(self._cost4.shape), self._size)
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        with torch._C.DisableTorchFunctionSubclass():
+            out = _follow(func, args, kwargs)
+            if out is not NotImplemented:
+                return out
+            args = _tree_map(args)
+            kwargs = {k: _tree_map(v) for k, v in kwargs.items()}
+            return func(*args, **kwargs)
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        # a wrapper subclass must define it; everything is answered in __torch_function__, so this is reached only by an ATen call made
+        # with torch functions disabled around it: compute on the materialised values
+        return func(*_tree_map(args), **{k: _tree_map(v) for k, v in (kwargs or {}).items()})
+
+
+def _plain(v):
+    return v.materialise() if isinstance(v, LazyDepth) else v
+
+
+def _tree_map(v):
+    if isinstance(v, LazyDepth):
+        return v.materialise()
+    if isinstance(v, (tuple, list)):
+        return type(v)(_tree_map(q) for q in v)
+    return v
+
+
+def _dim_arg(args, kwargs, pos, default=None):
+    if "dim" in kwargs:
+        return kwargs["dim"]
+    if "axis" in kwargs:
+        return kwargs["axis"]
+    return args[pos] if len(args) > pos else default
+
+
+_NAMES = {}
+
+
+def _name(func):
+    n = _NAMES.get(func)
+    if n is None:
+        n = _NAMES[func] = getattr(func, "__name__", str(func))
+    return n
+
+
+_METADATA = ("size", "dim", "ndimension", "numel", "nelement", "is_floating_point", "is_complex", "element_size", "is_contiguous",
+             "get_device", "__len__", "_is_view", "stride", "storage_offset")
+_META_PROPERTIES = ("shape", "dtype", "device", "requires_grad", "is_cuda", "ndim", "layout", "is_leaf", "is_sparse", "is_quantized", "is_meta",
+                    "names", "is_cpu", "grad_fn", "grad")
+
+
+def _follow(func, args, kwargs):
+    """the next node of the chain, the fused result, plain metadata - or NotImplemented (the caller then materialises)"""
+    self = args[0] if args and isinstance(args[0], LazyDepth) else None
+    name = _name(func)
+    if self is not None and name in _METADATA:
+        return func(*args, **kwargs)
+    if self is not None and name == "__get__":                    # a property: the wrapper's own metadata answers shape / dtype / device ...
+        prop = getattr(getattr(func, "__self__", None), "__name__", "")
+        return func(*args, **kwargs) if prop in _META_PROPERTIES else NotImplemented
+    if self is None:                                              # ``other * lazy``: the lazy operand is second
+        if name in ("mul", "__mul__", "__rmul__", "multiply") and len(args) == 2 and isinstance(args[1], LazyDepth) and not kwargs:
+            return _follow(func, (args[1], args[0]), kwargs)
+        return NotImplemented
+    stage = self._stage
+    if stage == _UP:                                              # [B,1,Do,H,W] -> [B,Do,H,W]
+        if name == "squeeze" and _dim_arg(args, kwargs, 1) in (1, -4):
+            return self._next(_UP4, (self.shape[0],) + tuple(self.shape[2:]))
+        if name == "__getitem__" and len(args) == 2 and isinstance(args[1], tuple) and len(args[1]) == 2 and args[1][0] == slice(None) and args[1][1] == 0:
+            return self._next(_UP4, (self.shape[0],) + tuple(self.shape[2:]))
+        return NotImplemented
+    if stage == _UP4:
+        if name in ("softmax", "_softmax") and _dim_arg(args, kwargs, 1) in (1, -3) and kwargs.get("dtype") is None and len(args) <= 2:
+            return self._next(_PROB, self.shape)
+        if name == "softmax" and len(args) == 4 and args[1] in (1, -3) and args[3] is None:     # F.softmax(input, dim, _stacklevel, dtype)
+            return self._next(_PROB, self.shape)
+        return NotImplemented
+    if stage == _PROB:
+        if name in ("mul", "__mul__", "__rmul__", "multiply") and len(args) == 2 and not kwargs:
+            z = args[1]
+            do = self.shape[1]
+            if (isinstance(z, torch.Tensor) and type(z) is torch.Tensor and z.numel() == do and z.dtype == self.dtype and not z.requires_grad and
+                    z.dim() in (3, 4) and tuple(z.shape[-3:]) == (do, 1, 1) and z.device == self.device):
+                return self._next(_WEIGHTED, self.shape, zvals=z.reshape(-1).contiguous())
+        return NotImplemented
+    if stage == _WEIGHTED:
+        if name == "sum" and _dim_arg(args, kwargs, 1) in (1, -3, (1,), [1]) and kwargs.get("dtype") is None:
+            keep = bool(kwargs.get("keepdim", args[2] if len(args) > 2 else False))
+            depth = _depth_regress(self._cost4, self._zvals, self._size, self._align)
+            return depth.unsqueeze(1) if keep else depth
+        return NotImplemented
+    return NotImplemented
+
+
+_fused = None       # tests put a CPU restatement here; None -> ops.DepthRegress (ROCm tensors) or torch's chain (anything else)
+
+
+def _depth_regress(cost4, zvals, size, align):
+    if _fused is not None:
+        _STATS["depth_regress"] += 1
+        return _fused(cost4, zvals, size, align)
+    if cost4.is_cuda and cost4.dtype == torch.float32:
+        from . import ops
+        _STATS["depth_regress"] += 1
+        return ops.DepthRegress.apply(cost4, zvals, size, align)
+    v = torch.softmax(_F.interpolate(cost4.unsqueeze(1), size=size, mode="trilinear", align_corners=align).squeeze(1), dim=1)
+    return (v * zvals.reshape(1, -1, 1, 1)).sum(1)
+
+
+def interpolate(input, size=None, scale_factor=None, mode="nearest", align_corners=None, **kw):
+    lazy = (isinstance(input, torch.Tensor) and type(input) is torch.Tensor and input.dim() == 5 and input.shape[1] == 1 and mode == "trilinear" and
+            size is not None and scale_factor is None and not kw and input.dtype == torch.float32 and (input.is_cuda or _fused is not None) and
+            not isinstance(size, int) and len(size) == 3)
+    if not lazy:
+        return _F.interpolate(_plain(input), size=size, scale_factor=scale_factor, mode=mode, align_corners=align_corners, **kw)
+    size = tuple(int(v) for v in size)
+    return LazyDepth(_UP, input[:, 0], size, bool(align_corners), (input.shape[0], 1) + size)
+
+
+def upsample(input, size=None, scale_factor=None, mode="nearest", align_corners=None):
+    """``F.upsample`` (the deprecated spelling PSMNet-family code uses) = ``F.interpolate``"""
+    return interpolate(input, size=size, scale_factor=scale_factor, mode=mode, align_corners=align_corners)
+
+
+def softmax(input, dim=None, _stacklevel=3, dtype=None):
+    if isinstance(input, LazyDepth):
+        return torch.softmax(input, dim) if dtype is None else torch.softmax(input, dim, dtype=dtype)
+    return _F.softmax(input, dim=dim, _stacklevel=_stacklevel, dtype=dtype)
+
+
+# ------------------------------------------------------------------------------------------------ the proxy and its binding
+class FunctionalProxy:
+    """stands where a module's global ``F`` (= torch.nn.functional) stands: everything but the patterns above is the real package's"""
+
+    IS_LIBADVENGINE_PROXY = True
+    grid_sample = staticmethod(grid_sample)
+    interpolate = staticmethod(interpolate)
+    upsample = staticmethod(upsample)
+    softmax = staticmethod(softmax)
+
+    def __getattr__(self, name):
+        return getattr(_F, name)
+
+    def __repr__(self):
+        return "<torch.nn.functional behind eval_driving_safety_amd.adopt_functional>"
+
+
+PROXY = FunctionalProxy()
+_bound = {}          # (module name, global name) -> the original object
+
+
+def _defining_modules(model):
+    names = []
+    for m in model.modules():
+        mod = type(m).__module__
+        if mod.split(".")[0] in ("torch", "eval_driving_safety_amd", "builtins") or mod in names:
+            continue
+        names.append(mod)
+    return names
+
+
+def bind(model):
+    """replace the ``torch.nn.functional`` globals of the Python modules that define ``model``'s classes by the proxy -> [(module, global)]"""
+    done = []
+    for mod_name in _defining_modules(model):
+        mod = sys.modules.get(mod_name)
+        if mod is None:
+            continue
+        for gname, val in list(vars(mod).items()):
+            if val is _F:
+                _bound[(mod_name, gname)] = val
+                setattr(mod, gname, PROXY)
+                done.append((mod_name, gname))
+    return done
+
+
+def unbind(which=None):
+    """put the original globals back (all of them, or the (module, global) pairs given)"""
+    for key in list(_bound) if which is None else list(which):
+        mod = sys.modules.get(key[0])
+        if mod is not None and key in _bound:
+            setattr(mod, key[1], _bound[key])
+        _bound.pop(key, None)

@@ -42,12 +42,16 @@ def add_engine_flags(parser):
                         "bird's-eye-view hourglass, head towers - adapters.DsgnShapedAdapter; Stereo R-CNN: ResNet-101-FPN, stereo RPN, "
                         "RoIAlign heads - surrogates.StereoRcnnR101): what the end-to-end numbers of bench.py are measured on; "
                         "'shaped' a much lighter network of the same structure; 'toy' runs the plumbing with a tiny fixed-seed stand-in")
-    g.add_argument("--adopt", default="on", choices=["on", "verify", "off"],
+    g.add_argument("--adopt", default="verify", choices=["on", "verify", "off"],
                    help="--model upstream: put the checkout's detector on libadvengine - fold its eval-mode BatchNorms and replace its "
                         "Conv2d / Conv3d / ConvTranspose3d modules by kernel-backed ones carrying the same weights (adopt.adopt); Stereo R-CNN's "
                         "compiled model.roi_layers is always replaced by the libadvengine one (upstream_shims).  'verify' also runs the first "
                         "sample through the network before and after and stops if any output moved by more than 1e-4 of its magnitude; "
                         "'off' leaves the convolutions to torch / MIOpen")
+    g.add_argument("--shim", action="append", default=[], metavar="MODULE=KEY",
+                   help="--model upstream: additionally register a libadvengine shim (KEY: ext_C = the compiled extension's flat functions, "
+                        "dsgn_layers = DSGN's operator wrappers, roi_layers = Stereo R-CNN's RoI package) under the module name YOUR checkout "
+                        "imports, e.g. --shim dsgn.ops._ext=ext_C; default names: eval_driving_safety_amd/upstream_shims/__init__.py")
     g.add_argument("--graph", action="store_true",
                    help="PGD scripts: capture one iteration (detector forward + backward + the fused step) in a hipGraph and replay it "
                         "(detectors without data-dependent shapes: --model toy / shaped / layerlist of the DSGN scripts)")

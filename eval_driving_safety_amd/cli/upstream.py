@@ -124,8 +124,9 @@ def adopt_model(model, mode, dev, first_call=None):
         verify = _adopt.Call(args, kwargs)
     rep = _adopt.adopt(model, verify=verify)
     native = sum(1 for _, what in rep["replaced"] if "torch +" not in what)
-    print("adopted {} convolution modules ({} on libadvengine kernels, {} BatchNorms folded, {} ReLUs fused){}".format(
+    print("adopted {} convolution modules ({} on libadvengine kernels, {} BatchNorms folded, {} ReLUs fused{}){}".format(
         len(rep["replaced"]), native, rep["folded_bn"], rep["fused_relu"],
+        "; grid_sample / depth regression bound in {}".format(", ".join(sorted({m for m, _ in rep["functional"]}))) if rep.get("functional") else "",
         "; {} outputs verified within 1e-4".format(rep["verified_outputs"]) if "verified_outputs" in rep else ""))
     return rep
 
@@ -171,6 +172,12 @@ class DsgnRuntime:
         """attack=True: the scaffolding of pgd_attack.py / patch_attack.py (:70-147: Experimenter config, is_train=True
         loader with targets, 12 workers unless --debug); attack=False: that of predict_and_save_*.py (:76-175)."""
         env_utils = _need("env_utils", "env_utils (upstream DSGN)")
+        if dev.type == "cuda":
+            # upstream's dsgn._C (cost-volume build, sigmoid focal loss, NMS: CUDA sources) does not exist on an MI355X: libadvengine's
+            # entry points stand in its place, registered BEFORE the checkout's layers run ``from dsgn import _C`` (SURVEY 2.2)
+            from .. import upstream_shims
+            done = upstream_shims.install("dsgn", table=upstream_shims.parse_shim_flags(getattr(args, "shim", None)))
+            print("{} -> eval_driving_safety_amd.upstream_shims (cost volume / focal loss / NMS on csrc/psv.hip, volume.hip, roi.hip)".format(", ".join(done)))
         models = _need("dsgn.models", "dsgn.models (upstream DSGN)")
         ls = _need("dsgn.dataloader.KITTILoader3D", "dsgn.dataloader.KITTILoader3D")
         DA = _need("dsgn.dataloader.KITTILoader_dataset3d", "dsgn.dataloader.KITTILoader_dataset3d")
@@ -299,7 +306,7 @@ class SrcnnRuntime:
             # upstream's model.roi_layers is a compiled CUDA extension: on an MI355X the libadvengine package stands in its place, registered
             # BEFORE the checkout's model code runs ``from model.roi_layers import ROIAlign`` / ``nms`` (stereo_rcnn.py:18, proposal layer)
             from .. import upstream_shims
-            upstream_shims.install()
+            upstream_shims.install("srcnn")
             print("model.roi_layers -> eval_driving_safety_amd.upstream_shims.roi_layers (ROIAlign / nms on csrc/roi.hip)")
         roidb_mod = _need("roi_data_layer.roidb", "roi_data_layer.roidb")
         loader_mod = _need("roi_data_layer.roibatchLoader", "roi_data_layer.roibatchLoader (the reference's substitute file)")

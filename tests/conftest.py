@@ -50,6 +50,25 @@ def route(monkeypatch):
     return cm
 
 
+@pytest.fixture
+def checkout(request):
+    """``checkout("dsgn_checkout", ext="reference")``: put one stand-in checkout on sys.path for the test (DSGN: with the given module at
+    ``dsgn._C``, see tests/_upstream.py) and forget its modules afterwards"""
+    import _upstream
+
+    def use(name, ext="reference"):
+        path = os.path.join(_upstream.FAKE, name)
+        sys.path.insert(0, path)
+        request.addfinalizer(lambda: sys.path.remove(path))
+        if name == "dsgn_checkout":
+            _upstream.bind_dsgn_extension(ext)
+        return path
+    yield use
+    from eval_driving_safety_amd import adopt_functional
+    adopt_functional.unbind()
+    _upstream.forget_upstream()
+
+
 @pytest.fixture(scope="session")
 def golden_index():
     with open(os.path.join(GOLDEN, "index.json")) as f:

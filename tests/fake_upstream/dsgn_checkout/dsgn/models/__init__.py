@@ -1,10 +1,16 @@
 """A small torch-module network with the upstream DSGN ``StereoNet``'s call signature and output dict (attack/DSGN/pgd_attack.py:215-222,308)
 and the PSMNet / DSGN family's building blocks - ``convbn`` / ``convbn_3d`` = Sequential(conv, BatchNorm) helpers, a plane-sweep
-concatenation volume, a 3D hourglass (stride-2 convolution down, transposed convolution up with a skip connection), a 3x3x3 score layer,
-soft-argmin depth.  Not DSGN: a stand-in for the tests, weights seeded, batch-norm statistics non-trivial."""
+concatenation volume built by the checkout's COMPILED operator (``from dsgn.layers import BuildCostVolume`` - importable only where a
+``dsgn._C`` exists), a 3D hourglass (stride-2 convolution down, transposed convolution up with a skip connection), a 3x3x3 score layer,
+depth regression written the PSMNet way (``F.interpolate(trilinear)`` -> ``F.softmax`` -> a ``disparityregression`` module), the plane-sweep
+features resampled into a 3D geometric volume with ``F.grid_sample`` on a grid computed from the projection matrix, a voxel convolution,
+the height axis folded into channels, a bird's-eye-view head.  Not DSGN: a stand-in for the tests, weights seeded, batch-norm statistics
+non-trivial."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from dsgn.layers import BuildCostVolume
 
 
 def convbn(cin, cout, k, stride, pad, dilation):
@@ -39,8 +45,16 @@ class hourglass(nn.Module):
         return F.relu(self.conv5(self.conv2(self.conv1(x))) + x)
 
 
+class disparityregression(nn.Module):
+    def forward(self, x, depth):
+        return torch.sum(x * depth[None, :, None, None], 1)
+
+
 class StereoNet(nn.Module):
-    PLANES = (0, 2, 4, 6, 8, 10, 12, 14)        # feature-pixel disparities of the eight planes
+    DEPTHS = (10.0, 12.5, 15.0, 17.5, 20.0, 22.5, 25.0, 27.5)        # metres: the eight planes of the sweep
+    UP_PLANES = 32                                                     # planes of the up-sampled cost volume (4 x: ``maxdisp / downsample``)
+    VOXELS = (6, 4, 10)                                                # (Z, Y, X) cells of the 3D geometric volume
+    RANGE = ((-8.0, 8.0), (-1.0, 3.0), (10.0, 27.5))                   # metres: X, Y, Z extent of that volume
 
     def __init__(self, cfg=None):
         super().__init__()
@@ -50,7 +64,12 @@ class StereoNet(nn.Module):
         self.dres0 = nn.Sequential(convbn_3d(8, 8, 3, 1, 1), nn.ReLU(inplace=True), convbn_3d(8, 8, 3, 1, 1), nn.ReLU(inplace=True))
         self.hg = hourglass(8)
         self.classif1 = nn.Sequential(convbn_3d(8, 8, 3, 1, 1), nn.ReLU(inplace=True), nn.Conv3d(8, 1, kernel_size=3, padding=1, stride=1, bias=False))
-        self.head = nn.Conv2d(8, 3, 1)
+        self.build_cost = BuildCostVolume()
+        self.dispregression = disparityregression()
+        self.register_buffer("depth", torch.linspace(self.DEPTHS[0], self.DEPTHS[-1], self.UP_PLANES))
+        self.voxel_conv = nn.Sequential(convbn_3d(8, 8, 3, 1, 1), nn.ReLU(inplace=True))
+        self.bev_conv = nn.Sequential(convbn(8 * self.VOXELS[1], 16, 3, 1, 1, 1), nn.ReLU(inplace=True))
+        self.head = nn.Conv2d(16, 3, 1)
         with torch.no_grad():
             for m in self.modules():
                 if isinstance(m, (nn.Conv2d, nn.Conv3d, nn.ConvTranspose3d)):
@@ -63,15 +82,41 @@ class StereoNet(nn.Module):
                     m.running_mean.copy_(0.1 * torch.randn(m.running_mean.shape, generator=g))
                     m.running_var.copy_(0.5 + torch.rand(m.running_var.shape, generator=g))
 
+    def _voxel_grid(self, calibs_Proj, image_hw, dev):
+        """normalised sampling coordinates [B,Z,Y,X,3] = (u, v, plane) of every voxel centre: projected with the left camera matrix, the
+        depth axis linear in metres over the sweep's planes (a function of the calibration only)"""
+        (x0, x1), (y0, y1), (z0, z1) = self.RANGE
+        nz, ny, nx = self.VOXELS
+        zs = z0 + (z1 - z0) * (torch.arange(nz, dtype=torch.float32) + 0.5) / nz
+        ys = y0 + (y1 - y0) * (torch.arange(ny, dtype=torch.float32) + 0.5) / ny
+        xs = x0 + (x1 - x0) * (torch.arange(nx, dtype=torch.float32) + 0.5) / nx
+        zz, yy, xx = torch.meshgrid(zs, ys, xs, indexing="ij")
+        pts = torch.stack([xx, yy, zz, torch.ones_like(xx)], -1)                                     # [Z,Y,X,4]
+        P = torch.as_tensor(calibs_Proj, dtype=torch.float32)                                        # [B,3,4]
+        uvw = torch.einsum("bij,zyxj->bzyxi", P, pts)
+        u, v = uvw[..., 0] / uvw[..., 2], uvw[..., 1] / uvw[..., 2]
+        h, w = image_hw
+        d = (zz - self.DEPTHS[0]) / (self.DEPTHS[-1] - self.DEPTHS[0])
+        grid = torch.stack([2 * u / (w - 1) - 1, 2 * v / (h - 1) - 1, (2 * d - 1).expand_as(u)], -1)
+        return grid.to(dev).contiguous()
+
     def forward(self, imgL, imgR, calibs_fu, calibs_baseline, calibs_Proj, calibs_Proj_R=None):
         assert calibs_Proj_R is not None and len(calibs_fu) == imgL.shape[0]
         fl, fr = self.feature_extraction(imgL), self.feature_extraction(imgR)
-        w = fr.shape[-1]
-        cost = torch.stack([torch.cat([fl, fr if d == 0 else F.pad(fr, (d, 0))[..., :w]], 1) for d in self.PLANES], 2)     # [B,8,D,h,w]
-        score = self.classif1(self.hg(self.dres0(cost)))[:, 0]                                                              # [B,D,h,w]
-        prob = torch.softmax(score, 1)
-        depth = (prob * (10.0 + 2.5 * torch.arange(len(self.PLANES), device=prob.device, dtype=prob.dtype)).view(1, -1, 1, 1)).sum(1, keepdim=True)
-        depth = F.interpolate(depth, size=imgL.shape[2:], mode="bilinear", align_corners=False)
-        out = self.head(torch.cat([fl, fr], dim=1))
+        # per-plane disparity in FEATURE pixels: fu * baseline / depth / 4 (fractional: the operator interpolates)
+        fb = torch.as_tensor(calibs_fu, dtype=torch.float32) * torch.as_tensor(calibs_baseline, dtype=torch.float32).abs()
+        shift = (fb[:, None] / torch.tensor(self.DEPTHS)[None, :] / 4.0).to(fl.device)
+        cost = self.build_cost(fl, fr, shift)                                                                    # [B,8,D,h,w]
+        out = self.hg(self.dres0(cost))
+        score = self.classif1(out)                                                                               # [B,1,D,h,w]
+        score = F.interpolate(score, [self.UP_PLANES, imgL.shape[2], imgL.shape[3]], mode="trilinear", align_corners=False)
+        score = torch.squeeze(score, 1)
+        pred = F.softmax(score, dim=1)
+        depth = self.dispregression(pred, self.depth)                                                            # [B,H,W]
+        grid = self._voxel_grid(calibs_Proj, imgL.shape[2:], out.device)
+        voxel = self.voxel_conv(F.grid_sample(out, grid, align_corners=False))                                   # [B,8,Z,Y,X]
+        b, c, nz, ny, nx = voxel.shape
+        bev = voxel.permute(0, 1, 3, 2, 4).reshape(b, c * ny, nz, nx)
+        head = self.head(self.bev_conv(bev))
         # eval mode: depth_preds is one [B,H,W] tensor that the scripts iterate over the batch dimension
-        return {"depth_preds": depth.squeeze(1), "bbox_cls": out[:, 0], "bbox_reg": out[:, 1], "bbox_centerness": out[:, 2]}
+        return {"depth_preds": depth, "bbox_cls": head[:, 0:1], "bbox_reg": head[:, 1], "bbox_centerness": head[:, 2]}

@@ -1,5 +1,7 @@
 import torch
 
+from dsgn.layers import nms
+
 
 class BoxList:
     def __init__(self, bbox, fields):
@@ -19,6 +21,12 @@ def make_fcos3d_postprocessor(cfg):
             s = torch.sigmoid(bbox_cls[b].mean()).reshape(1)
             x0 = 100.0 + 50.0 * torch.tanh(bbox_reg[b].mean())
             box = torch.stack([x0, x0 * 0 + 120.0, x0 + 80.0, x0 * 0 + 200.0]).reshape(1, 4)
+            # candidates: the box, three jittered copies of lower score (suppressed) - box NMS through the checkout's compiled operator
+            jit = torch.tensor([[0.0, 0, 0, 0], [3, -2, 4, 1], [-5, 4, -3, 2], [6, 6, 5, 7]], device=box.device)
+            cand, cand_s = box + jit, s * torch.tensor([1.0, 0.9, 0.8, 0.7], device=box.device)
+            keep = nms(cand, cand_s, 0.5)
+            assert keep.tolist() == [0], keep
+            box = cand[keep]
             c = torch.tensor([[-1.0, 1.0, 20.0]], device=box.device) + bbox_centerness[b].mean()
             d = torch.tensor([[-0.8, -0.8, -2.0], [0.8, -0.8, -2.0], [0.8, 0.8, -2.0], [-0.8, 0.8, -2.0],
                               [-0.8, -0.8, 2.0], [0.8, -0.8, 2.0], [0.8, 0.8, 2.0], [-0.8, 0.8, 2.0]], device=box.device)

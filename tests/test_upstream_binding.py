@@ -24,20 +24,7 @@ from eval_driving_safety_amd import upstream_shims
 from eval_driving_safety_amd.upstream_shims import roi_layers as shim
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FAKE = os.path.join(ROOT, "tests", "fake_upstream")
-UPSTREAM_NAMES = ("dsgn", "env_utils", "model", "roi_data_layer", "_init_paths")
-
-
-@pytest.fixture
-def checkout(request):
-    def use(name):
-        path = os.path.join(FAKE, name)
-        sys.path.insert(0, path)
-        request.addfinalizer(lambda: sys.path.remove(path))
-        return path
-    yield use
-    for m in [m for m in sys.modules if m.split(".")[0] in UPSTREAM_NAMES]:
-        del sys.modules[m]
+from _upstream import FAKE, UPSTREAM_NAMES, bind_dsgn_extension, forget_upstream
 
 
 # ----------------------------------------------------------------------------------------------- CPU: the shim's surface
@@ -84,6 +71,106 @@ def test_install_puts_the_shim_where_the_checkouts_extension_is(checkout):
     assert type(net.RCNN_roi_align) is shim.ROIAlign
     with pytest.raises(RuntimeError, match="no CPU path"):
         net.RCNN_roi_align(torch.zeros(1, 2, 8, 8), torch.zeros(1, 5), 0.25)
+
+
+def test_registry_puts_the_extension_shim_where_the_dsgn_checkout_imports_it(checkout):
+    """the DSGN half: the stand-in checkout's wrappers do ``from dsgn import _C`` (as upstream's do); ``install("dsgn")`` makes that resolve to
+    upstream_shims.ext_C; the table is data - other module names through ``table=`` / ``--shim``"""
+    from eval_driving_safety_amd.upstream_shims import dsgn_layers, ext_C
+    checkout("dsgn_checkout", ext=None)
+    with pytest.raises(ImportError):
+        import dsgn.layers                                       # noqa: F401  no extension: not importable, like a checkout without a build
+    forget_upstream()
+    assert upstream_shims.install("dsgn") == ["dsgn._C"] and upstream_shims.installed("dsgn._C")
+    import dsgn
+    import dsgn.layers as L
+    from dsgn.models import StereoNet
+    from dsgn.models.loss3d import RPN3DLoss
+    from dsgn.models.inference3d import make_fcos3d_postprocessor      # noqa: F401
+    assert dsgn._C is ext_C and L.BuildCostVolume.__module__ == "dsgn.layers.build_cost_volume"         # the CHECKOUT's wrappers, on the shim
+    their_nms = sys.modules["dsgn.layers.nms"]
+    assert their_nms._C is ext_C and their_nms.nms is ext_C.nms and L.nms is ext_C.nms
+    net = StereoNet(cfg=None)
+    assert type(net.build_cost).__module__ == "dsgn.layers.build_cost_volume" and type(RPN3DLoss(None).cls_loss_func).__module__ == "dsgn.layers.sigmoid_focal_loss"
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        net.build_cost(torch.zeros(1, 2, 4, 8), torch.zeros(1, 2, 4, 8), torch.zeros(1, 3))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        L.SigmoidFocalLoss(2.0, 0.25)(torch.zeros(4, 1), torch.zeros(4, dtype=torch.int32))
+    # every flat function the stand-in's wrappers call exists on the shim with that arity (and on the plain-torch reference)
+    import _upstream
+    ref = _upstream.reference_C()
+    for name in ext_C.__all__:
+        assert callable(getattr(ext_C, name))
+        if hasattr(ref, name):
+            assert list(inspect.signature(getattr(ext_C, name)).parameters) == list(inspect.signature(getattr(ref, name)).parameters), name
+    with pytest.raises(AttributeError, match="no kernel here"):
+        ext_C.roi_pool_forward
+    # one level up, and under a name of the user's choosing
+    forget_upstream()
+    done = upstream_shims.install(["dsgn.layers"], table={"dsgn.ops.ext": "ext_C"})
+    assert done == ["dsgn.layers", "dsgn.ops.ext"] and sys.modules["dsgn.ops.ext"] is ext_C
+    from dsgn.layers import BuildCostVolume, SigmoidFocalLoss, nms
+    assert BuildCostVolume is dsgn_layers.BuildCostVolume and SigmoidFocalLoss is dsgn_layers.SigmoidFocalLoss and nms is shim.nms
+    assert upstream_shims.parse_shim_flags(["a.b=ext_C", "c=dsgn_layers"]) == {"a.b": "ext_C", "c": "dsgn_layers"}
+    with pytest.raises(ValueError):
+        upstream_shims.parse_shim_flags(["a.b=nothing"])
+    with pytest.raises(KeyError, match="no shim is listed"):
+        upstream_shims.install(["their.unknown.module"])
+    del sys.modules["dsgn.ops.ext"]
+
+
+def test_functional_patterns_follow_the_chain_and_fall_back(checkout):
+    """adopt_functional on the CPU with a restatement plugged in as the fused operator: the recognised chain emits ONE fused call, every
+    other use of a lazy value materialises torch's own result, the proxy is the real package for everything else"""
+    from eval_driving_safety_amd import adopt_functional as AF
+    gen = torch.Generator().manual_seed(4)
+    cost = torch.randn(2, 1, 6, 5, 7, generator=gen, requires_grad=True)
+    z = torch.linspace(2.0, 40.0, 12)
+    size = (12, 10, 14)
+
+    def chain(Fm, variant):
+        up = Fm.interpolate(cost, size, mode="trilinear", align_corners=False) if variant != "upsample" else Fm.upsample(cost, size=list(size), mode="trilinear")
+        up = up[:, 0] if variant == "index" else torch.squeeze(up, 1)
+        p = torch.softmax(up, 1) if variant == "torch" else Fm.softmax(up, dim=1)
+        w = z.view(1, -1, 1, 1) * p if variant == "rmul" else p * z[None, :, None, None]
+        return w.sum(dim=1, keepdim=True) if variant == "keepdim" else torch.sum(w, 1)
+
+    calls = []
+
+    def fused(c4, zv, sz, align):
+        calls.append((tuple(c4.shape), tuple(sz), align))
+        return (torch.softmax(F.interpolate(c4.unsqueeze(1), size=sz, mode="trilinear", align_corners=align).squeeze(1), dim=1) * zv.view(1, -1, 1, 1)).sum(1)
+
+    AF._fused = fused
+    try:
+        AF.stats(reset=True)
+        for variant in ("plain", "index", "torch", "rmul", "keepdim", "upsample"):
+            want, got = chain(F, variant), chain(AF.PROXY, variant)
+            assert type(got) is torch.Tensor and torch.equal(want, got), variant
+            assert torch.equal(torch.autograd.grad(got.sum(), cost)[0], torch.autograd.grad(want.sum(), cost)[0])
+        assert len(calls) == 6 and calls[0] == ((2, 6, 5, 7), size, False) and AF.stats()["materialised"] == 0 and AF.stats()["depth_regress"] == 6
+        # any other use: the value torch computes, no fused call
+        up = AF.PROXY.interpolate(cost, size, mode="trilinear")
+        assert isinstance(up, AF.LazyDepth) and tuple(up.shape) == (2, 1) + size and up.dtype == torch.float32 and up.dim() == 5 and up.size(2) == 12
+        ref_up = F.interpolate(cost, size, mode="trilinear")
+        assert torch.equal(up * 2.0, ref_up * 2.0) and torch.equal(up.squeeze(1).max(), ref_up.max())
+        prob = AF.PROXY.softmax(up.squeeze(1), dim=1)
+        assert isinstance(prob, AF.LazyDepth) and torch.equal(prob + 0, torch.softmax(ref_up.squeeze(1), 1))
+        assert torch.equal((prob * z.view(1, -1, 1, 1)).mean(), (torch.softmax(ref_up.squeeze(1), 1) * z.view(1, -1, 1, 1)).mean())
+        assert torch.equal(torch.softmax(up.squeeze(1), 2) + 0, torch.softmax(ref_up.squeeze(1), 2))             # another dim: not the pattern
+        assert torch.equal(torch.sum(prob * torch.ones(2, 12, 10, 14), 1), torch.sum(torch.softmax(ref_up.squeeze(1), 1) * torch.ones(2, 12, 10, 14), 1))
+        assert len(calls) == 6 and AF.stats()["materialised"] >= 6
+        # not the pattern at all: the real functions, untouched results
+        x4 = torch.randn(1, 3, 5, 6, generator=gen)
+        assert torch.equal(AF.PROXY.interpolate(x4, size=(10, 12), mode="bilinear", align_corners=False), F.interpolate(x4, size=(10, 12), mode="bilinear", align_corners=False))
+        assert torch.equal(AF.PROXY.interpolate(cost, scale_factor=2, mode="trilinear"), F.interpolate(cost, scale_factor=2, mode="trilinear"))
+        vol, grid = torch.randn(1, 2, 3, 4, 5, generator=gen), torch.rand(1, 2, 2, 2, 3, generator=gen) * 2 - 1
+        assert torch.equal(AF.PROXY.grid_sample(vol, grid, align_corners=False), F.grid_sample(vol, grid, align_corners=False))      # CPU: torch's operator
+        assert AF.PROXY.relu is F.relu and AF.PROXY.softmax(x4, dim=1).equal(F.softmax(x4, dim=1))
+    finally:
+        AF._fused = None
+    # without a device and without the test's restatement the proxy does not even build a lazy value
+    assert type(AF.PROXY.interpolate(cost, size, mode="trilinear")) is torch.Tensor
 
 
 # ----------------------------------------------------------------------------------------------- CPU: folding and the walk
@@ -165,7 +252,16 @@ def test_adopt_walks_the_stand_in_dsgn(checkout):
     assert fe.lastconv[2].native and fe.lastconv[2].kind.startswith("conv2d 1x1")
     # convbn(...) is its own Sequential(conv, bn): the ReLU that follows it lives one level up and stays a module
     assert rep["fused_relu"] == 0 and isinstance(net.module.dres0[1], nn.ReLU)
-    assert rep["folded_bn"] == 5 + 2 + 3 + 1 and not rep["kept"]
+    assert rep["folded_bn"] == 5 + 2 + 3 + 1 + 2 and not rep["kept"]                # + the voxel and bird's-eye-view layers
+    assert kinds["module.voxel_conv.0.0"].startswith("conv3d 3x3x3 s1 8->8") and kinds["module.bev_conv.0.0"].startswith("conv2d 3x3 s1 d1 32->16")
+    # the functional half: the global ``F`` of the Python module that defines StereoNet now is the proxy (grid_sample / trilinear chain)
+    from eval_driving_safety_amd import adopt_functional as AF
+    import dsgn.models as dm
+    try:
+        assert rep["functional"] == [("dsgn.models", "F")] and dm.F is AF.PROXY and dm.F.relu is F.relu and dm.F.conv2d is F.conv2d
+    finally:
+        AF.unbind()
+    assert dm.F is F
 
 
 def test_adopt_verify_catches_a_forward_that_breaks_the_convention():
@@ -289,32 +385,132 @@ def test_adopted_stand_in_stereo_rcnn_keeps_loss_and_gradient(checkout):
     assert torch.equal(again, grad)                                      # route table + deterministic RoIAlign / up-sampling backward: the same bits
 
 
-@pytest.mark.gpu
-def test_adopted_stand_in_dsgn_keeps_loss_and_gradient(checkout):
-    from eval_driving_safety_amd import adapters
-    checkout("dsgn_checkout")
-    from dsgn.models import StereoNet
-    from dsgn.models.loss3d import RPN3DLoss
+def _dsgn_case(dev, h=96, w=160):
     import synth
-    dev = _dev()
-    h, w = 96, 160
     x = torch.from_numpy(np.concatenate([synth.dsgn_normalised(71, h, w), synth.dsgn_normalised(72, h, w)])).to(dev)
     gen = torch.Generator().manual_seed(7)
     tgt = types.SimpleNamespace(bbox=torch.rand(2, 4, generator=gen).to(dev), box3d=torch.rand(2, 7, generator=gen).to(dev))
-    extra = types.SimpleNamespace(calibs_fu=torch.tensor([721.5377]), calibs_baseline=torch.tensor([0.54]), calibs_Proj=torch.zeros(1, 3, 4),
-                                  calibs_Proj_R=torch.zeros(1, 3, 4), disp_true=(torch.rand(1, h, w, generator=gen) * 45).to(dev), targets=(tgt,),
+    # a KITTI-like left projection matrix scaled to the small frame (the voxel grid of the stand-in projects with it)
+    proj = torch.tensor([[[92.9, 0.0, 78.5, 5.8], [0.0, 92.9, 44.2, 0.03], [0.0, 0.0, 1.0, 0.003]]])
+    extra = types.SimpleNamespace(calibs_fu=torch.tensor([721.5377]), calibs_baseline=torch.tensor([0.54]), calibs_Proj=proj,
+                                  calibs_Proj_R=proj.clone(), disp_true=(torch.rand(1, h, w, generator=gen) * 45).to(dev), targets=(tgt,),
                                   calib=None, calib_R=None, ious=None, labels_map=None)
     cfg = types.SimpleNamespace(PlaneSweepVolume=True, loss_disp=True, RPN3D_ENABLE=True, min_depth=2.0, max_depth=40.4)
+    return x, extra, cfg
+
+
+@pytest.mark.gpu
+def test_adopted_stand_in_dsgn_keeps_loss_and_gradient(checkout):
+    """the DSGN half of the binding, end to end: the stand-in checkout (cost volume / focal loss / NMS imported from ``dsgn.layers`` over
+    ``dsgn._C``; ``F.grid_sample`` and the trilinear-softmax depth regression inline in ``forward``) once on the plain-torch extension,
+    un-adopted, once on libadvengine's shim + adopt(): psv_fwd_plane / psv_bwd_vec4, grid_sample3d_*, depth_regress_*, focal_fwd_bwd and the
+    convolution kernels carry the second run; loss and image gradient within 1e-4, the same bits on every run"""
+    from eval_driving_safety_amd import adapters
+    from eval_driving_safety_amd import adopt_functional as AF
+    dev = _dev()
+    x, extra, cfg = _dsgn_case(dev)
+    checkout("dsgn_checkout", ext="reference")
+    from dsgn.models import StereoNet
+    from dsgn.models.loss3d import RPN3DLoss
     ref = torch.nn.DataParallel(StereoNet(cfg=None), device_ids=[0]).to(dev).eval()
     want_loss, want_grad = adapters.DsgnAdapter(ref, cfg, RPN3DLoss).loss_and_grad(x.clone(), extra)
-    net = torch.nn.DataParallel(StereoNet(cfg=None), device_ids=[0]).to(dev).eval()
-    net.load_state_dict(ref.state_dict())
-    rep = A.adopt(net, verify=A.Call((x[:1], x[1:], extra.calibs_fu, extra.calibs_baseline, extra.calibs_Proj), {"calibs_Proj_R": extra.calibs_Proj_R}))
-    assert rep["verified_outputs"] == 4
-    loss, grad = adapters.DsgnAdapter(net, cfg, RPN3DLoss).loss_and_grad(x.clone(), extra)
-    assert abs(float(loss) - float(want_loss)) <= 1e-4 * abs(float(want_loss))
-    assert float((grad - want_grad).abs().max()) <= 1e-4 * float(want_grad.abs().max())
-    assert torch.equal(adapters.DsgnAdapter(net, cfg, RPN3DLoss).loss_and_grad(x.clone(), extra)[1], grad)
+    state = ref.state_dict()
+    forget_upstream()
+    bind_dsgn_extension("shim")
+    from dsgn.models import StereoNet as ShimNet
+    from dsgn.models.loss3d import RPN3DLoss as ShimLoss
+    import dsgn
+    from eval_driving_safety_amd.upstream_shims import ext_C
+    assert dsgn._C is ext_C and ShimNet is not StereoNet
+    net = torch.nn.DataParallel(ShimNet(cfg=None), device_ids=[0]).to(dev).eval()
+    net.load_state_dict(state)
+    try:
+        rep = A.adopt(net, verify=A.Call((x[:1], x[1:], extra.calibs_fu, extra.calibs_baseline, extra.calibs_Proj), {"calibs_Proj_R": extra.calibs_Proj_R}))
+        assert rep["verified_outputs"] == 4 and rep["functional"] == [("dsgn.models", "F")]
+        AF.stats(reset=True)
+        loss, grad = adapters.DsgnAdapter(net, cfg, ShimLoss).loss_and_grad(x.clone(), extra)
+        st = AF.stats()
+        assert st["grid_sample"] == 1 and st["depth_regress"] == 1 and st["materialised"] == 0, st
+        assert abs(float(loss) - float(want_loss)) <= 1e-4 * abs(float(want_loss))
+        assert float((grad - want_grad).abs().max()) <= 1e-4 * float(want_grad.abs().max())
+        AF.stats(reset=True)
+        assert torch.equal(adapters.DsgnAdapter(net, cfg, ShimLoss).loss_and_grad(x.clone(), extra)[1], grad)
+        assert AF.stats()["grid_plan_built"] == 0                       # the same calibration: the gather plan of the first call is reused
+        # the detect path: no-grad forward + the checkout's post-processor (box NMS through dsgn._C.nms -> adv_nms_f32)
+        from dsgn.models.inference3d import make_fcos3d_postprocessor
+        with torch.no_grad():
+            out = net(x[:1], x[1:], extra.calibs_fu, extra.calibs_baseline, extra.calibs_Proj, calibs_Proj_R=extra.calibs_Proj_R)
+            outr = ref(x[:1], x[1:], extra.calibs_fu, extra.calibs_baseline, extra.calibs_Proj, calibs_Proj_R=extra.calibs_Proj_R)
+        box = make_fcos3d_postprocessor(cfg)(out["bbox_cls"], out["bbox_reg"], out["bbox_centerness"])[0][0]
+        assert tuple(box.bbox.shape) == (1, 4)
+        assert float((out["depth_preds"] - outr["depth_preds"]).abs().max()) <= 1e-4 * float(outr["depth_preds"].abs().max())
+    finally:
+        AF.unbind()
+
+
+@pytest.mark.gpu
+def test_dsgn_extension_shim_ops_equal_their_oracles():
+    """every flat function of upstream_shims.ext_C alone, on seeded inputs: cost volume (integer and fractional disparities) forward and
+    adjoint bit for bit vs oracle_np.psv_build* and equal to the plain-torch stand-in extension within rounding; focal loss within 1e-5 of
+    the float64 oracle (device exp / log); NMS: the oracle's indices; 5-D grid_sample through the proxy: torch's CPU bits forward, the
+    ordered oracle's bits backward; the fused depth regression within 1e-5 of torch's chain"""
+    from oracle import oracle_np as O
+    from eval_driving_safety_amd import adopt_functional as AF
+    from eval_driving_safety_amd.upstream_shims import ext_C
+    import _upstream
+    ref = _upstream.reference_C()
+    dev = _dev()
+    rs = np.random.RandomState(11)
+    left, right = rs.randn(2, 3, 5, 24).astype(np.float32), rs.randn(2, 3, 5, 24).astype(np.float32)
+    g = rs.randn(2, 6, 4, 5, 24).astype(np.float32)
+    for shift, fwd, bwd in ((np.array([[0, 2, 5, 30], [1, 0, 23, 7]], np.int32), O.psv_build, O.psv_build_bwd),
+                            (np.array([[0.0, 2.25, 5.5, 30.0], [1.75, 0.5, 22.9, 7.0]], np.float32), O.psv_build_lerp, O.psv_build_lerp_bwd)):
+        t = lambda a: torch.tensor(a, device=dev)                                                        # noqa: E731
+        cost = ext_C.build_cost_volume_forward(t(left), t(right), t(shift))
+        assert cost.cpu().numpy().tobytes() == fwd(left, right, shift).tobytes()
+        gl, gr = ext_C.build_cost_volume_backward(t(g), t(shift))
+        wl, wr = bwd(g, shift)
+        assert gl.cpu().numpy().tobytes() == wl.tobytes() and gr.cpu().numpy().tobytes() == wr.tobytes()
+        rc = ref.build_cost_volume_forward(torch.tensor(left), torch.tensor(right), torch.tensor(shift))
+        assert float((rc - cost.cpu()).abs().max()) <= 1e-6
+        rl, rr = ref.build_cost_volume_backward(torch.tensor(g), torch.tensor(shift))
+        assert float((rl - gl.cpu()).abs().max()) <= 1e-5 and float((rr - gr.cpu()).abs().max()) <= 1e-5
+        one = ext_C.build_cost_volume_forward(t(left), t(right), t(shift[0]))                           # a [D] shift: shared by the batch
+        assert one[1].cpu().numpy().tobytes() == fwd(left[1:], right[1:], shift[:1]).tobytes()
+    x = (rs.randn(50, 3) * 3).astype(np.float32)
+    tg = rs.randint(-1, 4, size=50).astype(np.int32)
+    wl_, wg_ = O.sigmoid_focal_loss(x, tg, 2.0, 0.25)
+    loss = ext_C.sigmoid_focalloss_forward(torch.tensor(x, device=dev), torch.tensor(tg, device=dev), 3, 2.0, 0.25)
+    dl = rs.rand(50, 3).astype(np.float32)
+    grad = ext_C.sigmoid_focalloss_backward(torch.tensor(x, device=dev), torch.tensor(tg.astype(np.int64), device=dev), torch.tensor(dl, device=dev), 3, 2.0, 0.25)
+    assert np.allclose(loss.cpu().numpy(), wl_, rtol=1e-5, atol=1e-6) and np.allclose(grad.cpu().numpy(), wg_ * dl, rtol=1e-5, atol=1e-6)
+    boxes = (rs.rand(120, 2) * 150).astype(np.float32)
+    boxes = np.concatenate([boxes, boxes + 8 + rs.rand(120, 2).astype(np.float32) * 50], 1)
+    scores = rs.rand(120).astype(np.float32)
+    keep = ext_C.nms(torch.tensor(boxes, device=dev), torch.tensor(scores, device=dev), 0.4)
+    order = np.argsort(-scores, kind="stable")
+    assert keep.cpu().tolist() == [int(order[k]) for k in O.nms(boxes[order], 0.4)] == ref.nms(torch.tensor(boxes), torch.tensor(scores), 0.4).tolist()
+    # the functional patterns on the device
+    vol = rs.randn(1, 4, 5, 6, 9).astype(np.float32)
+    grid = (rs.rand(1, 3, 4, 7, 3) * 2.3 - 1.15).astype(np.float32)
+    tv = torch.tensor(vol, device=dev, requires_grad=True)
+    AF.stats(reset=True)
+    out = AF.PROXY.grid_sample(tv, torch.tensor(grid, device=dev), align_corners=False)
+    assert out.detach().cpu().numpy().tobytes() == F.grid_sample(torch.tensor(vol), torch.tensor(grid), align_corners=False).numpy().tobytes()
+    go = rs.randn(*out.shape).astype(np.float32)
+    out.backward(torch.tensor(go, device=dev))
+    assert tv.grad.cpu().numpy().tobytes() == O.grid_sample3d_bwd(go, grid, (5, 6, 9), False).tobytes()
+    assert AF.stats()["grid_sample"] == 1 and AF.stats()["grid_plan_built"] == 1
+    cost = torch.tensor(rs.randn(1, 1, 6, 7, 9).astype(np.float32), device=dev, requires_grad=True)
+    z = torch.linspace(2.0, 40.0, 12, device=dev)
+
+    def chain(Fm, c):
+        return torch.sum(Fm.softmax(torch.squeeze(Fm.interpolate(c, [12, 14, 18], mode="trilinear", align_corners=False), 1), dim=1) * z[None, :, None, None], 1)
+    want, got = chain(F, cost), chain(AF.PROXY, cost)
+    assert AF.stats()["depth_regress"] == 1 and AF.stats()["materialised"] == 0
+    assert float((want - got).abs().max()) <= 1e-5 * float(want.abs().max())
+    gw, gg = torch.autograd.grad(want.sum(), cost)[0], torch.autograd.grad(got.sum(), cost)[0]
+    assert float((gw - gg).abs().max()) <= 1e-4 * float(gw.abs().max())
 
 
 @pytest.mark.gpu
