@@ -13,6 +13,8 @@ matcher used by the tests, smoke() and the CLI's ``--model toy`` plumbing mode.
 import torch
 import torch.nn.functional as F
 
+from .determinism import deterministic
+
 
 def split_eyes(x):
     b = x.shape[0] // 2
@@ -82,6 +84,7 @@ class ToyStereoAdapter:
         depth = sum(p * prob[:, i] for i, p in enumerate(self.planes))
         return F.smooth_l1_loss(depth / max(self.planes), torch.full_like(depth, self.target))
 
+    @deterministic
     def loss_and_grad(self, x, extra=None):
         h = _LeafGrad(x)
         with h as leaf:
@@ -344,6 +347,7 @@ class PsvStereoAdapter:
             self._bev = (w1, w2)
         return self._bev
 
+    @deterministic
     def detect(self, x, extra=None, topk=24, nms_thresh=0.25, cu=609.5593, cv=172.854):
         """-> per stereo pair a list of (cls, bbox[4], score, center[3], (h, w, l, ry)) for ``DetectUnderAttack`` /
         ``pixelio.write_kitti_labels``.  Plane probabilities -> occupancy over (depth plane, image column) -> a small 2D head
@@ -461,6 +465,7 @@ class PsvStereoAdapter:
             self._gt_cache, self._gt_key = (idx, gt.reshape(-1).index_select(0, idx)), (gt, gt._version)
         return self._gt_cache
 
+    @deterministic
     def loss_and_grad(self, x, extra):
         """extra.disp_true [B,H,W] sparse metric depth (0 = no measurement); mask as pgd_attack.py:269"""
         h = _LeafGrad(x)
@@ -501,6 +506,7 @@ class DsgnAdapter:
         if freeze:
             _freeze(model)
 
+    @deterministic
     def loss_and_grad(self, x, extra):
         cfg = self.cfg
         h = _LeafGrad(x)
@@ -571,6 +577,7 @@ class StereoRcnnAdapter:
             setattr(out, k, getattr(extra, k).clone())
         return out
 
+    @deterministic
     def loss_and_grad(self, x, extra):
         u = self.uncert
         h = _LeafGrad(x)

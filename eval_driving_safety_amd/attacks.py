@@ -17,7 +17,8 @@ import os
 
 import torch
 
-from . import patchgeom, pixelio
+from . import determinism, patchgeom, pixelio
+from .determinism import deterministic
 from .dist import Comm
 
 
@@ -129,8 +130,10 @@ class PgdAttack:
         return fan_out
 
     # -- one batch -----------------------------------------------------------------------------
+    @deterministic
     def run_batch(self, batch, adapter):
-        """Attack B stereo pairs; returns the final stacked iterate [2B,3,H,W] (device)."""
+        """Attack B stereo pairs; returns the final stacked iterate [2B,3,H,W] (device).  Runs under determinism.solvers(), after one
+        throw-away detector step per (detector, shape) (``warm_up``): the iterates are a function of the inputs only."""
         ops, sp = self.ops, self.space
         dev = self.device if self.device is not None else batch.imgL.device
         if self.graph and getattr(self, "_graph_cache", None) is not None and torch.cuda.is_available():
@@ -184,6 +187,8 @@ class PgdAttack:
         # ``in_place=False`` keeps the previous iterate intact for callers that want it.
         pingpong = not self.in_place
         spare = torch.empty_like(x) if pingpong else None
+        if self.iters > 0 and getattr(self, "warm_up", True) and not self.graph:        # (the graph path warms up before its capture)
+            determinism.warm_adapter(adapter, x, batch.extra)
         if self.graph and self.iters > 0:
             x = self._run_graph(x, clean, cidx, adapter, batch, exporter, rows, cols, losses)
             if exporter is not None:
@@ -222,7 +227,10 @@ class PgdAttack:
                              "Stereo R-CNN-shaped surrogates unless their static forward is opted in: allow_graph_capture) cannot be captured in a "
                              "hipGraph" % type(adapter).__name__)
         any_export = exporter is not None and any(self._wanted(k + 1) for k in range(self.iters))
-        key = (id(adapter), tuple(x.shape), x.device, cidx is not None, None if cidx is None else isinstance(cidx.valid, torch.Tensor), any_export, rows, cols)
+        # everything baked into the captured kernels' arguments besides the buffers: shapes, the kind of clean image, the export geometry -
+        # and the step's own constants (alpha, eps, the pixel space); the adapter OBJECT is held by the capture and compared with ``is``
+        key = (tuple(x.shape), x.device, cidx is not None, None if cidx is None else isinstance(cidx.valid, torch.Tensor), any_export, rows, cols,
+               float(self.alpha), float(self.eps), getattr(sp, "name", None))
         # another batch's labels fit a capture when they are the same OBJECT - or when the adapter can say so: ``graph_extra_signature``
         # (everything of the labels that is a host constant of the capture: counts, sizes, shapes) equal, and the label TENSORS copied into
         # the captured ones (``graph_copy_extra``).  Up to ``max_graphs`` captures are kept (each holds its private memory pool).
@@ -231,7 +239,7 @@ class PgdAttack:
         pool = self.__dict__.setdefault("_graph_caches", [])
         held = None
         for h in pool:
-            if h["key"] == key and (h["extra"] is batch.extra or (sig is not None and h["sig"] == sig)) and \
+            if h["adapter"] is adapter and h["key"] == key and (h["extra"] is batch.extra or (sig is not None and h["sig"] == sig)) and \
                     (cidx is None or isinstance(cidx.valid, torch.Tensor) or tuple(cidx.valid) == tuple(h["cidx"].valid)):
                 held = h
                 break
@@ -255,7 +263,18 @@ class PgdAttack:
                     held["cidx"].valid.copy_(cidx.valid)
             self.graph_captures_reused = getattr(self, "graph_captures_reused", 0) + 1
         else:
-            xs, cs = x, clean                               # this batch's own buffers become the static ones
+            # a capture that could only be matched by its ``extra`` OBJECT (no signature) is dead as soon as another batch arrives: free
+            # it - graph, private memory pool, static buffers - BEFORE capturing, so that at most one such capture is ever resident
+            if sig is None:
+                dead = [h for h in pool if h["sig"] is None]
+                if dead:
+                    pool[:] = [h for h in pool if h["sig"] is not None]
+                    if getattr(self, "_graph_cache", None) in dead:
+                        self._graph_cache = None
+                    self.last_graph = None
+                    del dead
+            # PRIVATE static buffers: the caller's tensors are never aliased by a capture, and the result is always a copy (below)
+            xs, cs = x.clone(), clean.clone()
             u8 = ops.alloc_u8(x.shape[0], rows, x.shape[3], x.device) if any_export else None
             kw = {"clean_index": cidx} if cidx is not None else {}
             # labels shared by signature are captured through a private copy (later batches' tensors are copied INTO it: the caller's stay untouched)
@@ -278,7 +297,8 @@ class PgdAttack:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 loss_buf = iteration().detach().reshape(()).clone()
-            held = self._graph_cache = {"key": key, "extra": static_extra, "sig": sig, "g": g, "x": xs, "clean": cs, "cidx": cidx, "u8": u8, "loss": loss_buf}
+            held = self._graph_cache = {"key": key, "adapter": adapter, "extra": static_extra, "sig": sig, "g": g, "x": xs, "clean": cs, "cidx": cidx, "u8": u8,
+                                        "loss": loss_buf}
             pool.append(held)
             while len(pool) > self.max_graphs:
                 pool.pop(0)                                  # the least recently used capture and its memory pool go
@@ -294,7 +314,7 @@ class PgdAttack:
         # preparation (upload, clean-image index) raced with the tail of the replays and the Stereo R-CNN-shaped step faulted - found with
         # tools/graph_replay_probe.py-style bisection: a wait after every batch makes it pass every time, none makes it fail every time
         torch.cuda.synchronize(xs.device)
-        return xs.clone() if xs is not x else xs            # a reused capture: the static iterate is overwritten by the next batch
+        return xs.clone()                                   # always a copy: the static iterate is overwritten by the next batch's replays
 
     def run(self, loader, adapter, comm=None, debugnum=None):
         """Iterate a loader; with a Comm of world > 1 every rank takes the batches i % world == rank
@@ -366,6 +386,7 @@ class PatchTrainer:
         return self.patch
 
     # -- one round: B pairs on this rank against one patch snapshot ----------------------------------
+    @deterministic
     def train_batch(self, batch, adapter, contributes=True):
         ops, r = self.ops, self.radius
         dev = self.patch.device
@@ -382,6 +403,8 @@ class PatchTrainer:
                 self.positions.append((batch.names[i], list(cl[i]), list(cr[i])))
             if hasattr(adapter, "inject_fake_target"):
                 adapter.inject_fake_target(batch.extra, cl, cr, r)       # patch_attack.py:336-354 / :187-207
+            if self.iters > 0 and getattr(self, "warm_up", True):
+                determinism.warm_adapter(adapter, x, batch.extra)        # once per (detector, shape): see determinism.py
             # one small upload per round: paste centres [2b,2] and update windows [b,3] are views of the same buffer
             flat = [v for c in cl for v in (c[0], c[1])] + [v for c in cr for v in (c[0], c[1])] + \
                    [v for l, rr in zip(cl, cr) for v in (l[0], l[1], rr[1])]
@@ -511,6 +534,7 @@ class DetectUnderAttack:
             self.ops.patch_paste_batch(x, self.patch, centers, self.radius)
         return x
 
+    @deterministic
     def run(self, loader, detector, debugnum=None):
         written = 0
         for i, batch in enumerate(loader):

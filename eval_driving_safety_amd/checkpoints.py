@@ -115,7 +115,9 @@ def load_stereo_rcnn(model, checkpoint, keys=None, strict=True):
     keys = keys if keys is not None else stereo_rcnn_keys(tuple(len(getattr(model, "layer%d" % i)) for i in (1, 2, 3, 4)))
     ld = _Loader(state)
     mods = dict(model.named_modules())
-    loaded = 0
+    # STAGED: every tensor is checked and collected first; the model is written to only after the (strict) report has passed, so that a
+    # checkpoint that does not fit leaves the model exactly as it was - random weights WITH their crutches - instead of half loaded
+    staged = []            # (module, weight, bias)
     with torch.no_grad():
         for ours, (cp, bp) in keys.items():
             m = mods.get(ours)
@@ -124,30 +126,28 @@ def load_stereo_rcnn(model, checkpoint, keys=None, strict=True):
                 continue
             got = ld.conv(ours, cp, bp, m.weight.shape, m.bias.shape)
             if got is not None:
-                m.weight.copy_(got[0])
-                m.bias.copy_(got[1])
-                m._prep = None
-                loaded += 1
+                staged.append((m, got[0], got[1]))
         w, b = ld.take("RCNN_rpn.RPN_cls_score.weight"), ld.take("RCNN_rpn.RPN_cls_score.bias")
         a = model.rpn_cls.weight.shape[0]
         if w is None or tuple(w.shape) != (2 * a,) + tuple(model.rpn_cls.weight.shape[1:]):
             ld.problems.append("rpn_cls: RCNN_rpn.RPN_cls_score.weight missing or not [2A, ...]")
         else:
-            model.rpn_cls.weight.copy_(w[a:] - w[:a])
-            model.rpn_cls.bias.copy_((b[a:] - b[:a]) if b is not None else torch.zeros(a))
-            model.rpn_cls._prep = None
-            loaded += 1
+            staged.append((model.rpn_cls, w[a:] - w[:a], (b[a:] - b[:a]) if b is not None else torch.zeros(a)))
         for ours, up in _SRCNN_PLAIN.items():
             m = mods[ours]
             w, b = ld.take(up + ".weight"), ld.take(up + ".bias")
             if w is None or tuple(w.shape) != tuple(m.weight.shape):
                 ld.problems.append("%s: %s.weight missing or %s instead of %s" % (ours, up, None if w is None else tuple(w.shape), tuple(m.weight.shape)))
                 continue
+            staged.append((m, w, b if b is not None else torch.zeros_like(m.bias)))
+        rep = ld.report(len(staged), strict, "load_stereo_rcnn")          # raises (strict) before anything has been written
+        for m, w, b in staged:
             m.weight.copy_(w)
-            m.bias.copy_(b if b is not None else torch.zeros_like(m.bias))
-            loaded += 1
-    rep = ld.report(loaded, strict, "load_stereo_rcnn")
-    model.input_scale, model.bounded_rpn_deltas = 1.0, False
+            m.bias.copy_(b)
+            if hasattr(m, "_prep"):
+                m._prep = None
+    if not rep["problems"]:                  # a partial (non-strict) load keeps the random-weight crutches: half-random RPN deltas still need their bound
+        model.input_scale, model.bounded_rpn_deltas = 1.0, False
     rep["uncert"] = checkpoint.get("uncert") if isinstance(checkpoint, dict) else None
     return rep
 

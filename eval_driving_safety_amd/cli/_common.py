@@ -67,7 +67,9 @@ def add_engine_flags(parser):
 
 
 def setup_device(devices=None, mem_info=None):
-    """-> (torch.device, the resolved --devices string)"""
+    """-> (torch.device, the resolved --devices string); the process asks MIOpen for deterministic solvers from here on (determinism.py)"""
+    from .. import determinism
+    determinism.set_process_defaults()
     return upstream.pick_device(devices, mem_info)
 
 

@@ -1,0 +1,78 @@
+"""Byte-reproducible attacks: what the PRODUCT does about the layers it leaves to torch (README "Reproducibility").
+
+This package's own kernels accumulate in a fixed order and the committed route table (routes_gfx950.json) fixes which kernel a layer
+takes, so their results depend on the inputs only.  Layers still computed by torch - MIOpen convolutions (strided / 7x7 layers, the
+table's "" routes) and rocBLAS products - may take split-K solvers that accumulate with float atomics, and MIOpen answers a shape's
+FIRST call in a process with a fallback solver while it looks for a better one.  Two measures, applied by the attack drivers and the
+adapters themselves (not by the caller, not by the tests):
+
+  ``solvers()`` / ``@deterministic``   every detector step runs under ``torch.backends.cudnn.flags(deterministic=True, benchmark=False)``:
+                                       MIOpen is asked for deterministic solvers only and never times alternatives at run time;
+  ``warm_once(key, fn)``               the drivers run ONE throw-away detector step per (detector, input shape) before the first real one,
+                                       so that iteration 1 of image 1 is computed by the same solvers as every later iteration.
+
+``cli/_common.setup_device`` additionally sets the two flags process-wide for the command-line scripts.  north_star asks for bit-exact
+box indices: a sign flip of one gradient element moves one pixel by 2 alpha, so reproducible gradients are what that rests on."""
+import contextlib
+import functools
+
+import torch
+
+_warmed = set()
+
+
+@contextlib.contextmanager
+def solvers():
+    with torch.backends.cudnn.flags(enabled=True, deterministic=True, benchmark=False):
+        yield
+
+
+def deterministic(fn):
+    """decorator: the call (and the autograd backward it runs - the flags are process-wide, not thread-local) under ``solvers()``"""
+    @functools.wraps(fn)
+    def inner(*args, **kwargs):
+        with torch.backends.cudnn.flags(enabled=True, deterministic=True, benchmark=False):
+            return fn(*args, **kwargs)
+    inner.__wrapped_deterministic__ = True
+    return inner
+
+
+def set_process_defaults():
+    """the same two flags as process-wide defaults (the CLIs); returns the previous (deterministic, benchmark)"""
+    old = (torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark)
+    torch.backends.cudnn.deterministic = True
+    torch.backends.cudnn.benchmark = False
+    return old
+
+
+def warm_once(key, fn):
+    """run ``fn()`` once per ``key`` per process (a throw-away detector step on a new (detector, shape)); True when it ran"""
+    if key in _warmed:
+        return False
+    _warmed.add(key)
+    fn()
+    return True
+
+
+def warm_adapter(adapter, x, extra):
+    """ONE throw-away ``adapter.loss_and_grad(x, extra)`` per (adapter object, input shape, device) on a ROCm tensor: MIOpen's first
+    answer for a shape may come from another solver than its later ones.  ``x`` is not modified.  True when the step ran."""
+    if not (isinstance(x, torch.Tensor) and x.is_cuda):
+        return False
+    seen = getattr(adapter, "_adv_warm_shapes", None)
+    if seen is None:
+        seen = set()
+        try:
+            adapter._adv_warm_shapes = seen
+        except AttributeError:              # an adapter without a __dict__: warm it every time rather than never
+            pass
+    key = (tuple(x.shape), str(x.device))
+    if key in seen:
+        return False
+    seen.add(key)
+    adapter.loss_and_grad(x, extra)
+    return True
+
+
+def forget_warm_ups():
+    _warmed.clear()

@@ -545,7 +545,8 @@ def roi_align(feat, rois, pooled, spatial_scale, sampling_ratio=0, out=None):
 
 
 def roi_align_bwd_segments(n_rois):
-    """into how many segments of consecutive roi indices ``roi_align_bwd`` splits its ordered sum (1 up to 64 rois; include/advengine.h)"""
+    """into how many segments of consecutive roi indices ``roi_align_bwd`` splits its ordered sum: 1 up to 1024 rois, beyond that
+    min(8, ceil(r / 512)) (include/advengine.h)"""
     return int(_lib.load().adv_roi_align_bwd_segments(int(n_rois)))
 
 
@@ -586,7 +587,9 @@ class PyramidRoIAlign(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rois, owner, pooled, scales, sampling_ratio, *feats):
         r = rois.contiguous()
-        out = torch.empty((r.shape[0], feats[0].shape[1], pooled, pooled), dtype=torch.float32, device=r.device)
+        # zeros, not empty: a roi that no level owns (an owner index out of range - NaN / inf boxes from diverged RPN deltas under attack) is
+        # skipped by every launch; its rows must be the same bytes on every run
+        out = torch.zeros((r.shape[0], feats[0].shape[1], pooled, pooled), dtype=torch.float32, device=r.device)
         mine = []
         minus = torch.full_like(r[:, 0], -1.0)
         for l, f in enumerate(feats):

@@ -124,12 +124,17 @@ def test_stereo_rcnn_loader_refuses_a_partial_or_misshapen_checkpoint():
     del sd["RCNN_smooth2.weight"]
     sd["RCNN_layer2.0.conv2.weight"] = torch.zeros(128, 128, 1, 1)
     net = surrogates.StereoRcnnR101(seed=3, blocks=(1, 1, 1, 1)).eval()
+    before = {k: v.clone() for k, v in net.state_dict().items()}
     with pytest.raises(ValueError) as e:
         checkpoints.load_stereo_rcnn(net, {"model": sd})
     msg = str(e.value)
     assert "smooth.1: no RCNN_smooth2.weight" in msg and "layer2.0.conv2" in msg and "RCNN_extra.weight" in msg
-    rep = checkpoints.load_stereo_rcnn(surrogates.StereoRcnnR101(seed=3, blocks=(1, 1, 1, 1)).eval(), {"model": sd}, strict=False)
+    # refused BEFORE anything was written: the model is exactly what it was, random weights with their crutches on
+    assert all(torch.equal(v, before[k]) for k, v in net.state_dict().items()) and net.input_scale == 1.0 / 64.0 and net.bounded_rpn_deltas
+    partial = surrogates.StereoRcnnR101(seed=3, blocks=(1, 1, 1, 1)).eval()
+    rep = checkpoints.load_stereo_rcnn(partial, {"model": sd}, strict=False)
     assert len(rep["problems"]) == 2 and "RCNN_extra.weight" in rep["unused_upstream_keys"]
+    assert partial.input_scale == 1.0 / 64.0 and partial.bounded_rpn_deltas          # a partial load keeps the crutches of the layers still random
     # the full-depth key map names every upstream tensor of a [3, 4, 23, 3] ResNet-101
     assert len(checkpoints.STEREO_RCNN_KEYS) == 1 + 3 * 33 + 4 + 1 + 6 + 2 + 2 + 6 + 1
 

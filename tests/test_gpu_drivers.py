@@ -144,6 +144,34 @@ def test_cli_toy_run_writes_the_reference_layout(tmp_path):
     assert "Average loss for epoch1" in out.stdout
 
 
+@pytest.mark.parametrize("script,prefix", [("dsgn_pgd_attack", "dsgn_pgd_iters_"), ("srcnn_pgd_attack", "stereo_rcnn_pgd_iters_")])
+def test_a_cli_run_twice_in_fresh_processes_writes_the_same_png_bytes(tmp_path, script, prefix):
+    """README "Reproducibility", for the product path: the command-line script, run twice in two fresh processes on the layer-list detector
+    (route table + the layers left to MIOpen under determinism.py's flags and warm-up, set by the drivers - nothing is set here), writes
+    byte-identical attacked images for every iterate.  The first process may populate MIOpen's user caches for the second: the bytes must
+    not depend on that."""
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    digests = []
+    for run in ("a", "b"):
+        root = tmp_path / run
+        cmd = [sys.executable, "-m", "eval_driving_safety_amd.cli." + script, "--model", "layerlist", "--synthetic", "1", "--iter", "3", "--eps", "0.03",
+               "--out_root", str(root)] + (["-btest", "1", "-d", "0"] if script.startswith("dsgn") else [])
+        out = subprocess.run(cmd, env=env, cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+        assert out.returncode == 0, out.stdout[-3000:]
+        files = {}
+        for k in range(4):
+            for eye in ("image_2", "image_3"):
+                d = os.path.join(str(root), prefix + str(k), eye)
+                for name in sorted(os.listdir(d)):
+                    files[(k, eye, name)] = open(os.path.join(d, name), "rb").read()
+        assert len(files) == 8
+        digests.append(files)
+    assert digests[0].keys() == digests[1].keys()
+    differ = [k for k in digests[0] if digests[0][k] != digests[1][k]]
+    assert not differ, differ
+    assert digests[0][(0, "image_2", sorted(n for (k, e, n) in digests[0] if k == 0)[0])] != digests[0][(3, "image_2", sorted(n for (k, e, n) in digests[0] if k == 3)[0])]
+
+
 def test_attack_folders_feed_detect_under_attack(tmp_path):
     """the file contract end to end: PGD folders -> swapped in as image_2/image_3 (attack/DSGN/README.md:30,69) ->
     detect-under-attack -> KITTI label files -> the consumer's parser (evaluation/convert_scenarios.py:52-95)"""
@@ -255,13 +283,12 @@ def test_pgd_iteration_captured_in_a_hip_graph_equals_the_eager_loop(tmp_path, d
     outs = {}
     # (MIOpen may pick split-K solvers that accumulate with atomics for some 2D shapes: two runs of the same eager loop then differ in
     #  the last bits - ask it for deterministic solvers, so that what is compared is the capture, not MIOpen's schedule)
-    with torch.backends.cudnn.flags(enabled=True, deterministic=True, benchmark=False):
-        for mode in ("eager", "graph"):
-            root = tmp_path / mode
-            atk = attacks.PgdAttack("dsgn", 1 / 255, 0.03, n, out_root=str(root), device=dev, graph=(mode == "graph"), save=(detector == "toy"))
-            x = atk.run_batch(data.StereoBatch(batch.imgL.clone(), batch.imgR.clone(), batch.names, batch.sizes, batch.extra), make())
-            atk.close()
-            outs[mode] = (x.clone(), [float(v) for v in atk.last_losses])
+    for mode in ("eager", "graph"):
+        root = tmp_path / mode
+        atk = attacks.PgdAttack("dsgn", 1 / 255, 0.03, n, out_root=str(root), device=dev, graph=(mode == "graph"), save=(detector == "toy"))
+        x = atk.run_batch(data.StereoBatch(batch.imgL.clone(), batch.imgR.clone(), batch.names, batch.sizes, batch.extra), make())
+        atk.close()
+        outs[mode] = (x.clone(), [float(v) for v in atk.last_losses])
     assert torch.equal(outs["eager"][0], outs["graph"][0]), "iterate after %d captured iterations" % n
     assert outs["eager"][1] == outs["graph"][1] and len(outs["graph"][1]) == n
     if detector == "toy":

@@ -87,6 +87,20 @@ def test_hip_roi_align_skips_negative_batch_indices_and_pools_a_pyramid():
         masked = prois.copy()
         masked[owner != l, 0] = -1
         assert tfs[l].grad.cpu().numpy().tobytes() == O.roi_align_bwd_ordered(gp, masked, feats[l].shape, scales[l]).tobytes(), l
+    # a roi that NO level owns (an owner out of range: what .long() makes of a NaN level under a diverged RPN) and a NaN box: their rows are
+    # zeros, on every run - not whatever the allocator handed out
+    bad_owner = owner.copy()
+    bad_owner[[1, 6]] = (7, -3)
+    bad_rois = prois.copy()
+    bad_rois[6, 1:] = np.nan
+    for _ in range(2):
+        junk = torch.full((64, 4, 3, 3), 123.0, device=dev)         # dirty the allocator's free list
+        del junk
+        again = ops.PyramidRoIAlign.apply(torch.tensor(bad_rois, device=dev), torch.tensor(bad_owner, device=dev), 3, scales, 0, *[t.detach() for t in tfs])
+        a = again.cpu().numpy()
+        assert not a[[1, 6]].any() and np.isfinite(a).all()
+        keep = [i for i in range(11) if i not in (1, 6)]
+        assert a[keep].tobytes() == pooled.detach().cpu().numpy()[keep].tobytes()
 
 
 def _pyramid_fixture(golden):

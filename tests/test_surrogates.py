@@ -279,9 +279,8 @@ def test_r101_step_is_reproducible_bit_for_bit():
     try:
         surrogates.FoldedConv.impl = "auto"
         torch.use_deterministic_algorithms(True)
-        with torch.backends.cudnn.flags(enabled=True, deterministic=True, benchmark=False):
-            net.loss_and_grad(x.clone(), extra)                   # MIOpen answers a shape's first call with a fallback solver
-            runs = [net.loss_and_grad(x.clone(), extra) for _ in range(3)]
+        net.loss_and_grad(x.clone(), extra)                   # MIOpen answers a shape's first call with a fallback solver
+        runs = [net.loss_and_grad(x.clone(), extra) for _ in range(3)]
     finally:
         torch.use_deterministic_algorithms(False)
         surrogates.FoldedConv.impl = "miopen"
@@ -319,14 +318,13 @@ def test_static_forward_equals_the_compacting_forward():
         net = adapters.StereoRcnnAdapter(model, torch.tensor([0.1, -0.2, 0.3, 0.0, 0.2, -0.1], device=dev))
         out = {}
         # (MIOpen computes the strided layers: deterministic solvers and a warm-up call, or the two forwards differ in their last bits by themselves)
-        with torch.backends.cudnn.flags(enabled=True, deterministic=True, benchmark=False):
-            net.loss_and_grad(x.clone(), extra)
-            for static in (False, True):
-                model.static_shapes = static
-                assert model._static_ok(x) == static
-                with torch.no_grad():
-                    res = model(x[:1], x[1:], extra.im_info, left, right, left, do, kp, extra.num_boxes)
-                out[static] = (res, net.loss_and_grad(x.clone(), extra))
+        net.loss_and_grad(x.clone(), extra)
+        for static in (False, True):
+            model.static_shapes = static
+            assert model._static_ok(x) == static
+            with torch.no_grad():
+                res = model(x[:1], x[1:], extra.im_info, left, right, left, do, kp, extra.num_boxes)
+            out[static] = (res, net.loss_and_grad(x.clone(), extra))
         model.static_shapes = True
         (ra, (la, ga)), (rb, (lb, gb)) = out[False], out[True]
         assert torch.equal(ra[0], rb[0]) and torch.equal(ra[1], rb[1]) and torch.equal(ra[14], rb[14]), n_gt      # rois left / right, labels
@@ -368,32 +366,31 @@ assert net.graph_safe
 batch = next(iter(data.SyntheticStereo(1, "srcnn", batch=1, seed=3)))
 batch.extra = surrogates.synthetic_srcnn_extra(batch, dev)
 surrogates.FoldedConv.impl = "auto"
-with torch.backends.cudnn.flags(enabled=True, deterministic=True, benchmark=False):
-    eager = attacks.PgdAttack("srcnn", 1.0, 0.03, 4, save=False, device=dev)
-    xe = eager.run_batch(batch, net).clone()
-    le = [float(v) for v in eager.last_losses]
-    atk = attacks.PgdAttack("srcnn", 1.0, 0.03, 4, save=False, device=dev, graph=True)
-    outs = []
-    for _ in range(3):                      # capture, then the capture reused twice
-        outs.append((atk.run_batch(batch, net).clone(), [float(v) for v in atk.last_losses]))
-    # another label set with the same host constants (one box, same image size) shares the capture: its tensors are copied into the
-    # captured ones; a label set with two boxes needs a capture of its own
-    import copy
-    b2 = copy.copy(batch)
-    b2.extra = surrogates.synthetic_srcnn_extra(batch, dev)
-    b2.extra.gt_boxes_left[:, 0, :4] += torch.tensor([-60.0, 20.0, -40.0, 30.0], device=dev)
-    b2.extra.gt_boxes_right[:, 0, :4] += torch.tensor([-60.0, 20.0, -40.0, 30.0], device=dev)
-    b2.extra.gt_boxes_merge.copy_(b2.extra.gt_boxes_left)
-    keep_first = batch.extra.gt_boxes_left.clone()
-    x2e, x2g = eager.run_batch(b2, net).clone(), atk.run_batch(b2, net).clone()
-    reused_after_b2 = atk.graph_captures_reused
-    b3 = copy.copy(batch)
-    b3.extra = surrogates.synthetic_srcnn_extra(batch, dev)
-    b3.extra.gt_boxes_left[:, 1] = torch.tensor([200.0, 280.0, 420.0, 400.0, 1.0], device=dev)
-    b3.extra.gt_boxes_right[:, 1] = torch.tensor([170.0, 280.0, 390.0, 400.0, 1.0], device=dev)
-    b3.extra.gt_boxes_merge.copy_(b3.extra.gt_boxes_left)
-    b3.extra.num_boxes.fill_(2)
-    x3e, x3g = eager.run_batch(b3, net).clone(), atk.run_batch(b3, net).clone()
+eager = attacks.PgdAttack("srcnn", 1.0, 0.03, 4, save=False, device=dev)
+xe = eager.run_batch(batch, net).clone()
+le = [float(v) for v in eager.last_losses]
+atk = attacks.PgdAttack("srcnn", 1.0, 0.03, 4, save=False, device=dev, graph=True)
+outs = []
+for _ in range(3):                      # capture, then the capture reused twice
+    outs.append((atk.run_batch(batch, net).clone(), [float(v) for v in atk.last_losses]))
+# another label set with the same host constants (one box, same image size) shares the capture: its tensors are copied into the
+# captured ones; a label set with two boxes needs a capture of its own
+import copy
+b2 = copy.copy(batch)
+b2.extra = surrogates.synthetic_srcnn_extra(batch, dev)
+b2.extra.gt_boxes_left[:, 0, :4] += torch.tensor([-60.0, 20.0, -40.0, 30.0], device=dev)
+b2.extra.gt_boxes_right[:, 0, :4] += torch.tensor([-60.0, 20.0, -40.0, 30.0], device=dev)
+b2.extra.gt_boxes_merge.copy_(b2.extra.gt_boxes_left)
+keep_first = batch.extra.gt_boxes_left.clone()
+x2e, x2g = eager.run_batch(b2, net).clone(), atk.run_batch(b2, net).clone()
+reused_after_b2 = atk.graph_captures_reused
+b3 = copy.copy(batch)
+b3.extra = surrogates.synthetic_srcnn_extra(batch, dev)
+b3.extra.gt_boxes_left[:, 1] = torch.tensor([200.0, 280.0, 420.0, 400.0, 1.0], device=dev)
+b3.extra.gt_boxes_right[:, 1] = torch.tensor([170.0, 280.0, 390.0, 400.0, 1.0], device=dev)
+b3.extra.gt_boxes_merge.copy_(b3.extra.gt_boxes_left)
+b3.extra.num_boxes.fill_(2)
+x3e, x3g = eager.run_batch(b3, net).clone(), atk.run_batch(b3, net).clone()
 torch.cuda.synchronize()
 assert reused_after_b2 == 3 and atk.graph_captures_reused == 3 and len(atk._graph_caches) == 2
 assert torch.equal(x2e, x2g) and not torch.equal(x2e, xe) and torch.equal(x3e, x3g)
@@ -411,12 +408,13 @@ def test_static_iteration_replays_from_a_hipgraph_and_the_capture_is_reused(tmp_
     """one whole attack iteration through the R101-shaped detector (forward, losses, backward, fused PGD step) captured once, replayed, and
     reused for two more batches (attacks.PgdAttack(graph=True)): the eager loop's perturbed pair and losses, byte for byte.  Runs in a
     child process: a fault inside a replayed hipGraph aborts the process that launched it, and this torch / ROCm stack has produced such
-    faults on the way here (surrogates.StereoRcnnShaped.graph_capturable) - a child killed by a signal is reported as an expected
-    failure of the platform, a child that finishes must have found everything equal."""
+    faults on the way here (surrogates.StereoRcnnShaped.graph_capturable).  A child killed by a signal FAILS the test - a fault could as
+    well be an out-of-bounds access of one of this package's kernels inside the capture - unless ADV_ALLOW_GRAPH_FAULT=1 says the machine is
+    known to fault on replays; a child that finishes must have found everything equal."""
     script = tmp_path / "graph_worker.py"
     script.write_text(_GRAPH_WORKER % ROOT)
     res = subprocess.run([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
-    if res.returncode < 0 or "hardware exception" in res.stderr:
+    if (res.returncode < 0 or "hardware exception" in res.stderr) and os.environ.get("ADV_ALLOW_GRAPH_FAULT") == "1":
         pytest.xfail("the hipGraph replay faulted on this machine (signal %d): %s" % (res.returncode, res.stderr[-200:]))
     assert res.returncode == 0 and "GRAPH-REUSE-OK" in res.stdout, res.stderr[-2000:]
 

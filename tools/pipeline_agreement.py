@@ -49,24 +49,23 @@ def main():
     clean = ops.denormalize(x0, sp)
     xa, xb = x0.clone(), x0.clone()
     steps = []
-    with torch.backends.cudnn.flags(enabled=True, deterministic=True, benchmark=False):
-        for k in range(args.iters):
-            la, ga = net.loss_and_grad(xa, extra)
-            ls, gs = ref.loss_and_grad(xa.clone(), extra)              # torch's operators at libadvengine's iterate
-            sa, ss = torch.sign(ga), torch.sign(gs)
-            scale = float(gs.abs().max())
-            rec = {"step": k + 1, "loss_libadvengine": float(la), "loss_torch_same_iterate": float(ls),
-                   "sign_agreement_all_elements": float((sa == ss).float().mean()),
-                   "sign_flips_between_nonzero": int(((sa * ss) < 0).sum()), "zeros_libadvengine": int((sa == 0).sum()), "zeros_torch": int((ss == 0).sum()),
-                   "elements": ga.numel(), "grad_rel_linf": float((ga - gs).abs().max()) / scale,
-                   "median_abs_grad_over_max": float(gs.abs().median()) / scale}
-            lb, gb = ref.loss_and_grad(xb, extra)                      # the free-running torch path
-            xa = ops.pgd_step(xa, ga.contiguous(), clean, sp, args.alpha, args.eps)
-            xb = ops.pgd_step(xb, gb.contiguous(), clean, sp, args.alpha, args.eps)
-            da, db = ops.denormalize(xa, sp), ops.denormalize(xb, sp)
-            rec.update(free_run_elements_bit_equal=float((xa == xb).float().mean()), free_run_max_abs_diff_01=float((da - db).abs().max()),
-                       free_run_mean_abs_diff_01=float((da - db).abs().mean()), loss_torch_free_run=float(lb))
-            steps.append(rec)
+    for k in range(args.iters):
+        la, ga = net.loss_and_grad(xa, extra)
+        ls, gs = ref.loss_and_grad(xa.clone(), extra)              # torch's operators at libadvengine's iterate
+        sa, ss = torch.sign(ga), torch.sign(gs)
+        scale = float(gs.abs().max())
+        rec = {"step": k + 1, "loss_libadvengine": float(la), "loss_torch_same_iterate": float(ls),
+               "sign_agreement_all_elements": float((sa == ss).float().mean()),
+               "sign_flips_between_nonzero": int(((sa * ss) < 0).sum()), "zeros_libadvengine": int((sa == 0).sum()), "zeros_torch": int((ss == 0).sum()),
+               "elements": ga.numel(), "grad_rel_linf": float((ga - gs).abs().max()) / scale,
+               "median_abs_grad_over_max": float(gs.abs().median()) / scale}
+        lb, gb = ref.loss_and_grad(xb, extra)                      # the free-running torch path
+        xa = ops.pgd_step(xa, ga.contiguous(), clean, sp, args.alpha, args.eps)
+        xb = ops.pgd_step(xb, gb.contiguous(), clean, sp, args.alpha, args.eps)
+        da, db = ops.denormalize(xa, sp), ops.denormalize(xb, sp)
+        rec.update(free_run_elements_bit_equal=float((xa == xb).float().mean()), free_run_max_abs_diff_01=float((da - db).abs().max()),
+                   free_run_mean_abs_diff_01=float((da - db).abs().mean()), loss_torch_free_run=float(lb))
+        steps.append(rec)
     ua, ub = ops.export_u8(xa, sp), ops.export_u8(xb, sp)
     diff = (ua.int() - ub.int()).abs()
     out = {"what": "20-step PGD through adapters.DsgnShapedAdapter: libadvengine (route table %s) vs torch_ops=True (MIOpen / torch float32), same weights and pair" % routes.table_hash(),
