@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--unpadded", action="store_true", help="fill the whole 384x1248 frame with 8-bit pixels (round-1 input; no padding)")
     ap.add_argument("--no-float-path", action="store_true", help="skip the second (all-float32) measurement")
     ap.add_argument("--no-srcnn", action="store_true", help="skip the configs[2] (Stereo R-CNN shape) object")
+    ap.add_argument("--no-delivered", action="store_true", help="skip the leg that delivers every iterate to pinned host memory (PCIe-inclusive figure)")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the (separately reported) surrogate-detector attack")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--torch-cpu-baseline", action="store_true", help="(internal) print the torch-CPU baseline object and exit; touches no GPU")
@@ -269,6 +270,76 @@ class PgdBench:
         return elapsed, kern_ms
 
 
+def export_delivered(torch, ops, sp, x0, grad, valid, crop, fence, pairs, steps=2):
+    """The same resident batch and the same 20-step attack, with every iterate DELIVERED: the reference hands each step's 8-bit images to
+    the host (attack/DSGN/pgd_attack.py:357-374: tensor2im + save_img per step; iterate 0 at :279-294).  Two device export buffers alternate;
+    a side stream copies each one into a ring of two PINNED host buffers as soon as its step kernel has written it (event-fenced both ways:
+    the copy waits for the kernel, the kernel that reuses a buffer waits for its copy), so the D2H of iterate k runs under the kernels of
+    iterates k+1 ....  Reported BESIDE `value`, never in it: with delivery the path is bound by PCIe, not by HBM.  Also measured: the 21
+    copies alone and the kernels alone, so that the share of the kernel time hidden behind the copies can be read off."""
+    dev = x0.device
+    n = x0.shape[0]
+    u8 = [ops.alloc_u8(n, crop[0], x0.shape[3], dev) for _ in range(2)]
+    host = [torch.empty(tuple(u8[0].shape), dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+    clean, cur = torch.empty_like(x0), torch.empty_like(x0)
+    side = torch.cuda.Stream(device=dev)
+    main = torch.cuda.current_stream(dev)
+    ready = [torch.cuda.Event() for _ in range(2)]
+    freed = [torch.cuda.Event() for _ in range(2)]
+    state = {"cidx": None}
+
+    def deliver(slot):
+        ready[slot].record(main)
+        side.wait_event(ready[slot])
+        with torch.cuda.stream(side):
+            host[slot].copy_(u8[slot], non_blocking=True)
+            freed[slot].record(side)
+
+    def attack(copies=True, kernels=True):
+        if kernels:
+            _, state["cidx"] = ops.denormalize_indexed(x0, sp, out=clean, reuse=state["cidx"], valid=valid, u8_out=u8[0], crop=crop)
+        if copies:
+            deliver(0)
+        src = x0
+        for it in range(N_ITER):
+            slot = (it + 1) & 1
+            if copies:
+                main.wait_event(freed[slot])           # the copy that last read this export buffer (recorded before its first use too)
+            if kernels:
+                ops.pgd_step(src, grad, clean, sp, ALPHA, EPS, out=cur, u8_out=u8[slot], crop=crop, clean_index=state["cidx"])
+                src = cur
+            if copies:
+                deliver(slot)
+
+    for e in freed:
+        e.record(side)
+
+    def timed(**kw):
+        attack(**kw)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            attack(**kw)
+        fence()
+        return (time.perf_counter() - t0) / steps
+
+    t_kernels = timed(copies=False)
+    t_copies = timed(kernels=False)
+    t_both = timed()
+    # the delivered bytes are the attack's own: iterate 20 on the host equals the device buffer the last step wrote
+    ok = bool(torch.equal(host[N_ITER & 1], u8[N_ITER & 1].cpu()))
+    nbytes = (N_ITER + 1) * u8[0].numel()
+    hidden = max(0.0, min(1.0, (t_kernels + t_copies - t_both) / t_kernels))
+    return {"metric": "stereo-pairs/s with all 21 8-bit iterates of every pair delivered to pinned host memory (PCIe-inclusive; NOT `value`)",
+            "value": pairs / t_both, "unit": "stereo-pairs/s", "pairs": pairs, "steps": steps,
+            "ms_per_attack": {"kernels_and_copies": 1e3 * t_both, "kernels_alone": 1e3 * t_kernels, "copies_alone": 1e3 * t_copies},
+            "d2h_bytes_per_attack": nbytes, "d2h_GBps": nbytes / t_both / 1e9, "d2h_GBps_copies_alone": nbytes / t_copies / 1e9,
+            "kernel_time_hidden_behind_copies": hidden, "bound": "pcie",
+            "delivered_equals_device": ok,
+            "how": "two alternating device export buffers [2B,375,1248,3] u8, side-stream D2H into a ring of two pinned host buffers, "
+                   "event-fenced both ways; reference: attack/DSGN/pgd_attack.py:357-374 writes every iterate of every pair"}
+
+
 def self_launch(args):
     """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as a CHILD
     `python -m torch.distributed.run --nproc-per-node N bench.py ...` (this parent has not imported torch.cuda or touched a
@@ -444,6 +515,12 @@ def main():
             out["float_path"] = float_path
     else:
         out = None
+
+    if rank == 0 and world == 1 and not srcnn and use_index and not args.no_delivered:
+        try:        # the attack with every iterate handed to the host, as the reference's loop does (beside `value`, never in it)
+            out["export_delivered"] = export_delivered(torch, ops, sp, x0, grad, valid, crop, fence, args.pairs)
+        except Exception as e:
+            out["export_delivered"] = {"error": repr(e)}
     del main_b, x0, grad
     torch.cuda.empty_cache()
 

@@ -28,7 +28,7 @@ def _pairs(n):
     return [(synth.dsgn_normalised(70 + 2 * i, H, W), synth.dsgn_normalised(71 + 2 * i, H, W)) for i in range(n)]
 
 
-def _worker(rank, world, port, out_dir, n_pairs, mode):
+def _worker(rank, world, port, out_dir, n_pairs, mode, average=False):
     for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -48,7 +48,7 @@ def _worker(rank, world, port, out_dir, n_pairs, mode):
                 for i, (l, r) in enumerate(pairs)]
 
     if mode == "patch":
-        tr = attacks.PatchTrainer("dsgn", 0.2, 8 / 255, 2, 1, out_root=out_dir, seed=9, comm=comm, ops=_oracle_ops, device=cpu)
+        tr = attacks.PatchTrainer("dsgn", 0.2, 8 / 255, 2, 1, out_root=out_dir, seed=9, comm=comm, ops=_oracle_ops, device=cpu, average=average)
         patch = tr.train(factory, toy)
         np.save(os.path.join(out_dir, "patch_rank%d.npy" % rank), patch.numpy())
     else:
@@ -59,9 +59,43 @@ def _worker(rank, world, port, out_dir, n_pairs, mode):
     comm.close()
 
 
-def _spawn(tmp_path, n_pairs, mode):
+def _spawn(tmp_path, n_pairs, mode, world=2, average=False):
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path), n_pairs, mode), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), n_pairs, mode, average), nprocs=world, join=True)
+
+
+def _replay_patch_rule(n_pairs, world, average, iters=2):
+    """host replay of the data-parallel patch rule for one epoch: round r gives rank k the pair r * world + k (a rank that has
+    run out contributes a ZERO delta and a zero count); per inner iteration every live pair is evaluated against the same patch snapshot,
+    the clamped deltas are summed in rank order (= the all-reduce(SUM)), ``average`` divides by the number of contributing pairs"""
+    from oracle import oracle_np as O
+    from eval_driving_safety_amd import adapters
+    toy = adapters.ToyStereoAdapter(torch.device("cpu"), seed=4)
+    pairs = _pairs(n_pairs)
+    D, r = O.init_patch_dims(384, 0.2)
+    patch = np.zeros((1, 3, D, D), np.float32)
+    rngs = [random.Random(9 + 7919 * k) for k in range(world)]
+    for rnd in range((n_pairs + world - 1) // world):
+        live = []
+        for rank in range(world):
+            i = rnd * world + rank
+            if i < n_pairs:
+                cl, cr = O.round_mask_centers(rngs[rank], H, W, r)
+                live.append([np.concatenate(pairs[i]).copy(), cl, cr, None])
+        for it in range(iters):
+            total = np.zeros((1, 3, D, D), np.float32)
+            for k, (x, cl, cr, gacc) in enumerate(live):
+                x[0:1] = O.patch_paste(x[0:1], patch, cl[0], cl[1], r)
+                x[1:2] = O.patch_paste(x[1:2], patch, cr[0], cr[1], r)
+                _, g = toy.loss_and_grad(torch.from_numpy(x.copy()))
+                gacc = g.numpy() if gacc is None else gacc + g.numpy()
+                live[k][3] = gacc
+                d = O.patch_delta(gacc[0:1], gacc[1:2], cl[0], cl[1], cr[1], r, 8 / 255)
+                total = d if k == 0 else total + d
+            if average:
+                total = total / np.float32(max(len(live), 1))
+            patch = O.patch_apply_delta(patch, total)
+    return patch
 
 
 @pytest.mark.timeout(600)
@@ -75,29 +109,7 @@ def test_patch_allreduce_rule_world2(tmp_path):
     p1 = np.load(os.path.join(str(tmp_path), "patch_rank1.npy"))
     assert p0.tobytes() == p1.tobytes(), "ranks disagree on the patch"
     # expected: per round, every rank's pair is evaluated against the same snapshot; deltas summed; applied once
-    toy = adapters.ToyStereoAdapter(torch.device("cpu"), seed=4)
-    pairs = _pairs(n_pairs)
-    D, r = O.init_patch_dims(384, 0.2)
-    patch = np.zeros((1, 3, D, D), np.float32)
-    rngs = [random.Random(9 + 7919 * k) for k in range(2)]
-    for rnd in range(2):
-        live = []
-        for rank in range(2):
-            i = rnd * 2 + rank
-            if i < n_pairs:
-                cl, cr = O.round_mask_centers(rngs[rank], H, W, r)
-                live.append([np.concatenate(pairs[i]).copy(), cl, cr, None])
-        for it in range(2):
-            total = np.zeros((1, 3, D, D), np.float32)
-            for k, (x, cl, cr, gacc) in enumerate(live):
-                x[0:1] = O.patch_paste(x[0:1], patch, cl[0], cl[1], r)
-                x[1:2] = O.patch_paste(x[1:2], patch, cr[0], cr[1], r)
-                _, g = toy.loss_and_grad(torch.from_numpy(x.copy()))
-                gacc = g.numpy() if gacc is None else gacc + g.numpy()
-                live[k][3] = gacc
-                d = O.patch_delta(gacc[0:1], gacc[1:2], cl[0], cl[1], cr[1], r, 8 / 255)
-                total = d if k == 0 else total + d
-            patch = O.patch_apply_delta(patch, total)
+    patch = _replay_patch_rule(n_pairs, 2, False)
     assert np.abs(patch).max() > 0
     assert p0.tobytes() == patch.tobytes()
     assert os.path.exists(os.path.join(str(tmp_path), "dsgn_patch_ratio_0.2", "epoch1", "patch.npy"))
@@ -112,3 +124,35 @@ def test_pgd_shards_by_image_world2(tmp_path):
         for folder in ("image_2", "image_3"):
             files = sorted(os.listdir(os.path.join(str(tmp_path), "dsgn_pgd_iters_%d" % k, folder)))
             assert files == ["000000.png", "000001.png", "000002.png"]
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("average", [False, True])
+def test_patch_allreduce_rule_world8_ragged(tmp_path, average):
+    """eight ranks, eleven pairs: the second round has three live ranks and five that contribute zero deltas (and zero counts: with
+    ``average`` the sum is divided by 3, not 8) - all ranks end with the SAME patch bit for bit, and it is the host replay's (bit for
+    bit when the backend adds the eight contributions in rank order, as the replay does; to float32 rounding otherwise)."""
+    import _oracle_ops  # noqa: F401
+    n_pairs, world = 11, 8
+    _spawn(tmp_path, n_pairs, "patch", world=world, average=average)
+    got = [np.load(os.path.join(str(tmp_path), "patch_rank%d.npy" % k)) for k in range(world)]
+    for k in range(1, world):
+        assert got[k].tobytes() == got[0].tobytes(), "rank %d disagrees on the patch" % k
+    want = _replay_patch_rule(n_pairs, world, average)
+    assert np.abs(want).max() > 0
+    if got[0].tobytes() != want.tobytes():
+        # the order in which a ring all-reduce adds eight float32 contributions is the backend's: the values must agree to rounding
+        # (a handful of additions per element), and all ranks among themselves exactly (above)
+        assert np.allclose(got[0], want, rtol=0, atol=4e-7 * max(1.0, float(np.abs(want).max()))), float(np.abs(got[0] - want).max())
+    assert os.path.exists(os.path.join(str(tmp_path), "dsgn_patch_ratio_0.2", "epoch1", "patch.npy"))
+
+
+@pytest.mark.timeout(900)
+def test_pgd_shards_by_image_world8_eleven_images(tmp_path):
+    """8 ranks / 11 images: ranks 0-2 attack two pairs, ranks 3-7 one; no collective; every image's every iterate exists exactly once"""
+    _spawn(tmp_path, 11, "pgd", world=8)
+    done = [int(open(os.path.join(str(tmp_path), "done_rank%d.txt" % k)).read()) for k in range(8)]
+    assert done == [2, 2, 2, 1, 1, 1, 1, 1]
+    for k in (0, 1):
+        for folder in ("image_2", "image_3"):
+            assert sorted(os.listdir(os.path.join(str(tmp_path), "dsgn_pgd_iters_%d" % k, folder))) == ["%06d.png" % i for i in range(11)]

@@ -23,8 +23,8 @@ def _free_port():
     return p
 
 
-def _torchrun(script_and_args, timeout=900, **env):
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+def _torchrun(script_and_args, timeout=900, nproc=2, **env):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port())] + script_and_args
     e = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4", **env)
     return subprocess.run(cmd, cwd=ROOT, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
@@ -52,6 +52,27 @@ def test_bench_two_ranks_on_one_gpu():
     assert p["pairs"] == 4 and p["value"] > 0 and p["all_reduces_per_rank"] == 4 and p["message_bytes"] == 4 * (3 * 101 * 101 + 1)
     assert 0 < p["all_reduce_share_of_inner_iteration"] < 1 and len(p["all_reduce_ms_per_inner_iteration"]) == 2 and p["patch_abs_max"] > 0
     assert d["routes"]["mode"] == "table" and len(d["routes"]["hash"]) == 12 and d["routes"]["fixed_rule_lookups"] == 0
+
+
+def test_bench_eight_ranks_on_one_gpu_under_ten_minutes():
+    """the command the driver runs on an 8-GPU node, `... --nproc-per-node 8 bench.py --gpus 8 --steps K --warmup W`, with the eight ranks
+    sharing cuda:0 (gloo for the collectives: RCCL refuses two ranks per device): one JSON line from rank 0, the process group says 8, one
+    entry per rank, whole-job value = all pairs / the slowest rank's time - and the whole command well inside the driver's budget"""
+    import time
+    t0 = time.perf_counter()
+    out = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--pairs", "4", "--no-end-to-end"], nproc=8,
+                    ADV_BENCH_SHARE_GPU="1", ADV_BENCH_BACKEND="gloo")
+    took = time.perf_counter() - t0
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line, from rank 0"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["rccl_world"] == 8 and d["backend"] == "gloo" and d["scaling"] == "weak" and d["config"]["pairs_per_gpu"] == 4
+    assert len(d["per_rank"]["pairs_per_s"]) == 8 and len(d["per_rank"]["kernel_avg_launch_ms"]) == 8
+    assert abs(d["value"] - 8 * d["per_rank"]["pairs_per_s_min"]) < 1e-6 * d["value"]
+    assert d["config"]["parallelism"] == "image-sharded x8, no collective" and d["patch_allreduce"]["correct"] is True
+    assert "cpu_baseline" not in d and "export_delivered" not in d                                      # rank 0 at N = 1 only
+    assert took < 600, took
 
 
 def test_bench_launches_its_own_ranks_when_started_plainly():
