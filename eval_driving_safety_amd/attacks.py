@@ -17,8 +17,8 @@ import os
 
 import torch
 
-from . import determinism, patchgeom, pixelio
-from .determinism import deterministic
+from . import patchgeom, pixelio
+from .determinism import under_solvers
 from .dist import Comm
 
 
@@ -130,10 +130,10 @@ class PgdAttack:
         return fan_out
 
     # -- one batch -----------------------------------------------------------------------------
-    @deterministic
+    @under_solvers
     def run_batch(self, batch, adapter):
-        """Attack B stereo pairs; returns the final stacked iterate [2B,3,H,W] (device).  Runs under determinism.solvers(), after one
-        throw-away detector step per (detector, shape) (``warm_up``): the iterates are a function of the inputs only."""
+        """Attack B stereo pairs; returns the final stacked iterate [2B,3,H,W] (device).  Runs under determinism.solvers(); this package's
+        adapters warm a new input shape up by themselves (determinism.deterministic): the iterates are a function of the inputs only."""
         ops, sp = self.ops, self.space
         dev = self.device if self.device is not None else batch.imgL.device
         if self.graph and getattr(self, "_graph_cache", None) is not None and torch.cuda.is_available():
@@ -187,8 +187,6 @@ class PgdAttack:
         # ``in_place=False`` keeps the previous iterate intact for callers that want it.
         pingpong = not self.in_place
         spare = torch.empty_like(x) if pingpong else None
-        if self.iters > 0 and getattr(self, "warm_up", True) and not self.graph:        # (the graph path warms up before its capture)
-            determinism.warm_adapter(adapter, x, batch.extra)
         if self.graph and self.iters > 0:
             x = self._run_graph(x, clean, cidx, adapter, batch, exporter, rows, cols, losses)
             if exporter is not None:
@@ -386,7 +384,7 @@ class PatchTrainer:
         return self.patch
 
     # -- one round: B pairs on this rank against one patch snapshot ----------------------------------
-    @deterministic
+    @under_solvers
     def train_batch(self, batch, adapter, contributes=True):
         ops, r = self.ops, self.radius
         dev = self.patch.device
@@ -403,8 +401,6 @@ class PatchTrainer:
                 self.positions.append((batch.names[i], list(cl[i]), list(cr[i])))
             if hasattr(adapter, "inject_fake_target"):
                 adapter.inject_fake_target(batch.extra, cl, cr, r)       # patch_attack.py:336-354 / :187-207
-            if self.iters > 0 and getattr(self, "warm_up", True):
-                determinism.warm_adapter(adapter, x, batch.extra)        # once per (detector, shape): see determinism.py
             # one small upload per round: paste centres [2b,2] and update windows [b,3] are views of the same buffer
             flat = [v for c in cl for v in (c[0], c[1])] + [v for c in cr for v in (c[0], c[1])] + \
                    [v for l, rr in zip(cl, cr) for v in (l[0], l[1], rr[1])]
@@ -534,7 +530,7 @@ class DetectUnderAttack:
             self.ops.patch_paste_batch(x, self.patch, centers, self.radius)
         return x
 
-    @deterministic
+    @under_solvers
     def run(self, loader, detector, debugnum=None):
         written = 0
         for i, batch in enumerate(loader):

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from ..attacks import StereoBatch
-from ..determinism import deterministic
+from ..determinism import under_solvers
 
 
 class UpstreamMissing(ImportError):
@@ -262,7 +262,7 @@ class DsgnRuntime:
                                           calib=calib, calib_R=calib_R, image_sizes=image_sizes, image_indexes=image_indexes)
             yield StereoBatch(imgL.float(), imgR.float(), ["%06d" % i for i in image_indexes], None, extra)
 
-    @deterministic
+    @under_solvers
     def predict(self, x, extra):
         """``test()`` of the scripts (pgd_attack.py:208-226): no-grad forward + FCOS3D post-processing"""
         b = x.shape[0] // 2

@@ -72,7 +72,7 @@ struct EpiW {
 template <int PR, int PC, int COB, int KC, bool DEPTH, int ABL, bool DEEP = false>
 __global__ __launch_bounds__(COB * 128, COB == 4 ? 1 : 2) void conv_wino(const float* __restrict__ x, const float* __restrict__ wp, float* __restrict__ y,
                                                                           int Cin, int Cout, int cinpad, int copad, int D, int H, int W, int tiles_w,
-                                                                          long long total, EpiW epi) {
+                                                                          long long wbytes, EpiW epi) {
   using G = WGeo<PR, PC, COB, KC>;
   constexpr int NT = G::kNT;
   constexpr int dbg = ABL;                // phase ablation for timing (compile-time, so the schedule of the rest is the shipped one): the
@@ -94,52 +94,64 @@ __global__ __launch_bounds__(COB * 128, COB == 4 ? 1 : 2) void conv_wino(const f
 #pragma unroll
     for (int k = 0; k < 16; ++k) acc[i][k] = v4f{0.0f, 0.0f, 0.0f, 0.0f};
 
+  // <round 5> Addressing by BUFFER loads: the per-stage side work of a wave is issued between its matrix instructions, and the counters
+  // (profiles/r04_conv_pmc.json) showed the vector ALU, not the matrix pipe, setting the pace - 80 vector instructions per stage of 32 matrix
+  // instructions, 45 of them 64-bit address arithmetic (quarter-rate 32-bit multiplies among them) and clamps.  Now every slot's byte offset
+  // inside the IMAGE (input) or inside the prepared weights is computed ONCE per tile as a 32-bit number; a stage adds one wave-uniform
+  // offset to it (one v_add per input slot, nothing per weight slot: the scalar offset operand of the instruction), and the hardware's range
+  // check against the image's byte count returns zeros for what lies before the image, behind it, or in a channel >= Cin (padding of the
+  // contraction) - no clamp, no per-stage mask.  Same loads, same bits.
+  //
   // fetch plan of the input tile, once per tile: slot = tid + NT i -> (channel c, tile row r, float4 group j).  The loads themselves are
   // UNCONDITIONAL (no divergent branch around a load: the compiler would have to wait for it at the join, i.e. before the matrix
-  // instructions): a slot that lies outside the image loads from a clamped address and is zeroed, element by element, when it is committed
-  // to LDS after the stage's matrix instructions.
-  long long xflat[G::kXSl];                  // gh * W + gw of the group's first element (may lie outside the row / the image)
-  int xc[G::kXSl];
+  // instructions): a slot that lies outside the image row loads whatever the address holds (or zeros, out of range) and is zeroed, element
+  // by element, when it is committed to LDS after the stage's matrix instructions.
+  const float* const xb = x + b * Cin * DHW;                       // this image (wave-uniform)
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, static_cast<int>(static_cast<unsigned>(Cin * DHW * 4)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rwgt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wp), 0, static_cast<int>(wbytes), 0x00020000);
+  int xvo[G::kXSl];                          // byte offset of the group's first element inside the image, for channel c of a stage at channel 0, plane 0
   unsigned xvm[G::kXSl];                     // bit e: element e of the group is a pixel of the image
 #pragma unroll
   for (int i = 0; i < G::kXSl; ++i) {
     const int sidx = tid + NT * i;
     const int j = sidx % (G::kLW / 4), r = (sidx / (G::kLW / 4)) % G::kRows, c = sidx / ((G::kLW / 4) * G::kRows);
     const int gh = h0 - 1 + r, gw = w0 - 5 + 4 * j;
-    xc[i] = c < KC ? c : KC - 1;
-    xflat[i] = static_cast<long long>(gh) * W + gw;
+    // (32-bit wrap-around is part of the scheme: a negative offset is a huge unsigned one - out of range, zeros - unless the stage's
+    //  offset brings it back inside the image, where it addresses the end of the previous channel: masked)
+    xvo[i] = static_cast<int>(static_cast<unsigned>(c < KC ? c : KC - 1) * static_cast<unsigned>(DHW) * 4u) + (gh * W + gw) * 4;
     unsigned vm = 0;
     if (sidx < G::kXN && gh >= 0 && gh < H)
 #pragma unroll
       for (int e = 0; e < 4; ++e) vm |= (gw + e >= 0 && gw + e < W) ? (1u << e) : 0u;
     xvm[i] = vm;
   }
-  const long long xlast = total - 4;         // the last float4 that lies inside the tensor
   struct XSet {                              // staging registers of an input tile
     v4f v[G::kXSl];
-    int s[G::kXSl];                          // how far the clamp moved the load (non-zero only in the tensor's first / last three floats)
-    unsigned m[G::kXSl];
   };
   XSet xs;
   v4f rw[G::kWSl];
   // Everything below is written per slot / per row so that a stage's side work (global loads of the stages ahead, the input transform
   // of the next stage, the LDS commits) can be placed BETWEEN the matrix instructions of the current stage, one piece per step.
   // q0 = the stage's first "channel": 2D: the channel itself; 3D: q = kd * cinpad + c, input plane od + kd - 1
-  auto fetch_x1 = [&](int i, int q0, XSet& set) {
+  auto stage_off = [&](int q0) -> unsigned {      // wave-uniform: bytes from (channel 0, plane 0) to (the stage's first channel, its plane)
     const int kd = DEPTH ? q0 / cinpad : 0;
-    const int ch = (DEPTH ? q0 - kd * cinpad : q0) + xc[i];
-    const long long at = ((b * Cin + (ch < Cin ? ch : Cin - 1)) * D + (DEPTH ? od + kd - 1 : 0)) * HW + xflat[i];
-    const long long cl = at < 0 ? 0 : (at > xlast ? xlast : at);
-    set.v[i] = *reinterpret_cast<const v4f_u*>(x + cl);
-    set.s[i] = static_cast<int>(cl - at);
-    set.m[i] = ch < Cin ? xvm[i] : 0u;
+    const int ch = DEPTH ? q0 - kd * cinpad : q0;
+    return static_cast<unsigned>((static_cast<long long>(ch) * D + (DEPTH ? od + kd - 1 : 0)) * HW * 4);
+  };
+  auto fetch_x1 = [&](int i, int q0, XSet& set) {
+    set.v[i] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rx, xvo[i] + static_cast<int>(stage_off(q0)), 0, 0));
   };
   const int wrows = DEPTH ? 3 * cinpad : cinpad;       // rows of U per transform position
-  auto fetch_w1 = [&](int i, int q0, v4f (&dst)[G::kWSl]) {
+  int wvo[G::kWSl];                          // byte offset of the slot's float4 in the first stage's rows of U
+#pragma unroll
+  for (int i = 0; i < G::kWSl; ++i) {
     const int sidx = tid + NT * i;
     const int q = sidx % (G::kCO / 4), row = sidx / (G::kCO / 4);      // row = k * KC + c
     const int k = row / KC, c = row % KC;
-    dst[i] = *reinterpret_cast<const v4f*>(wp + (static_cast<long long>(k) * wrows + q0 + c) * copad + co0 + 4 * q);
+    wvo[i] = ((k * wrows + c) * copad + co0 + 4 * q) * 4;
+  }
+  auto fetch_w1 = [&](int i, int q0, v4f (&dst)[G::kWSl]) {
+    dst[i] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rwgt, wvo[i], q0 * copad * 4, 0));
   };
   float* const sxb = lds;                               // [2][KC][rows][LW]   input tiles
   float* const swb = lds + 2 * G::kSX;                   // [2][16][KC][CO]     U = G g G^T of the stage
@@ -147,19 +159,8 @@ __global__ __launch_bounds__(COB * 128, COB == 4 ? 1 : 2) void conv_wino(const f
   auto commit_x1 = [&](int i, int buf, const XSet& set) {
     float* sx = sxb + buf * G::kSX;
     const int sidx = tid + NT * i;
-    const v4f t = set.v[i];
-    const int sh = set.s[i];
-    const unsigned m = set.m[i];
-    v4f v;
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(sh != 0) != 0, 0)) {     // wave-uniform: the tensor's first / last float4 only
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int k = e - sh;
-        v[e] = k == 0 ? t[0] : (k == 1 ? t[1] : (k == 2 ? t[2] : t[3]));
-      }
-    } else {
-      v = t;
-    }
+    v4f v = set.v[i];
+    const unsigned m = xvm[i];
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = (m >> e) & 1u ? v[e] : 0.0f;
     if (sidx < G::kXN) *reinterpret_cast<v4f*>(sx + 4 * sidx) = v;
@@ -240,6 +241,14 @@ __global__ __launch_bounds__(COB * 128, COB == 4 ? 1 : 2) void conv_wino(const f
       for (int i = 0; i < G::kXSl; ++i) fetch_x1(i, qclamp(q_lo + 2 * KC), xsB);
 #pragma unroll
       for (int i = 0; i < G::kWSl; ++i) fetch_w1(i, qclamp(q_lo + KC), rwB);
+    }
+    if (blockIdx.x == 0 && stage_off(q_lo) == 0) {      // wave-uniform: the tile at the image's origin, its first stage at channel 0, plane 0
+      // the float4 that holds columns -1 .. 2 of row 0 starts four bytes BEFORE the image: out of range as a whole (zeros) - its three
+      // pixels are fetched one by one.  (Everywhere else such a group starts in the previous row, channel or plane: inside the image.)
+#pragma unroll
+      for (int i = 0; i < G::kXSl; ++i)
+        if (tid + NT * i == G::kLW / 4 + 1)              // channel 0, tile row 1 (image row 0), group 1 (columns -1 .. 2)
+          xs.v[i] = v4f{0.0f, xb[0], W > 1 ? xb[1] : 0.0f, W > 2 ? xb[2] : 0.0f};
     }
 #pragma unroll
     for (int i = 0; i < G::kXSl; ++i) commit_x1(i, 0, xs);
@@ -411,7 +420,9 @@ int launch_wino(const float* x, const float* wp, float* y, int b, int cin, int c
   const int cgroups = (cout + G::kCO - 1) / G::kCO;
   const long long gz = static_cast<long long>(b) * d;
   if (tiles > 0x7fffffffLL || cgroups > 65535 || gz > 65535) return ADV_EINVAL;
-  const long long total = static_cast<long long>(b) * cin * d * h * w;
+  // the kernel addresses an image and the prepared weights with 32-bit byte offsets (buffer loads): both must stay below 4 GiB
+  const long long wbytes = 16LL * (DEPTH ? 3 : 1) * cinpad * copad * 4;
+  if ((static_cast<long long>(cinpad) + 1) * d * h * w * 4 >= 0xfff00000LL || wbytes >= 0xfff00000LL) return ADV_EINVAL;
   const dim3 grid(static_cast<unsigned>(tiles), cgroups, static_cast<unsigned>(gz));
 #ifdef ADV_TEST_HOOKS
   if (const char* dbg_s = adv_hook_value("ADV_WINO_DBG")) {      // phase ablation for timing (results are wrong); the 8 x 32 x 64 2D shape and the 8 x 32 x 32 3D shape
@@ -421,7 +432,7 @@ int launch_wino(const float* x, const float* wp, float* y, int b, int cin, int c
   if (abl == A_) {                                                                                                                        \
     if (!adv_internal_lds_limit<conv_wino<PR, PC, COB, KC, DEPTH, A_>>(G::kLds)) return ADV_ELAUNCH;                                      \
     hipLaunchKernelGGL((conv_wino<PR, PC, COB, KC, DEPTH, A_>), grid, dim3(G::kNT), G::kLds, st, x, wp, y, cin, cout, cinpad, copad, d, h, w, \
-                       tiles_w, total, epi);                                                                                              \
+                       tiles_w, wbytes, epi);                                                                                              \
     return adv_internal_finish_launch();                                                                                                  \
   }
       ADV_WINO_ABL(1) ADV_WINO_ABL(2) ADV_WINO_ABL(4) ADV_WINO_ABL(8) ADV_WINO_ABL(16) ADV_WINO_ABL(3) ADV_WINO_ABL(13) ADV_WINO_ABL(29) ADV_WINO_ABL(31)
@@ -436,13 +447,13 @@ int launch_wino(const float* x, const float* wp, float* y, int b, int cin, int c
     if (deep) {
       if (!adv_internal_lds_limit<conv_wino<PR, PC, COB, KC, DEPTH, 0, true>>(G::kLds)) return ADV_ELAUNCH;
       hipLaunchKernelGGL((conv_wino<PR, PC, COB, KC, DEPTH, 0, true>), grid, dim3(G::kNT), G::kLds, st, x, wp, y, cin, cout, cinpad, copad, d, h, w,
-                         tiles_w, total, epi);
+                         tiles_w, wbytes, epi);
       return adv_internal_finish_launch();
     }
   }
   if (!adv_internal_lds_limit<conv_wino<PR, PC, COB, KC, DEPTH, 0>>(G::kLds)) return ADV_ELAUNCH;
   hipLaunchKernelGGL((conv_wino<PR, PC, COB, KC, DEPTH, 0>), grid, dim3(G::kNT), G::kLds, st, x, wp, y, cin, cout, cinpad, copad, d, h, w, tiles_w,
-                     total, epi);
+                     wbytes, epi);
   return adv_internal_finish_launch();
 }
 

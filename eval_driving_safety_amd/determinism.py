@@ -8,8 +8,10 @@ adapters themselves (not by the caller, not by the tests):
 
   ``solvers()`` / ``@deterministic``   every detector step runs under ``torch.backends.cudnn.flags(deterministic=True, benchmark=False)``:
                                        MIOpen is asked for deterministic solvers only and never times alternatives at run time;
-  ``warm_once(key, fn)``               the drivers run ONE throw-away detector step per (detector, input shape) before the first real one,
-                                       so that iteration 1 of image 1 is computed by the same solvers as every later iteration.
+  warm-up (inside ``@deterministic``)  the first time an adapter sees an input shape it runs ONE throw-away step before the real one, so that
+                                       iteration 1 of image 1 is computed by the same solvers as every later iteration.  An adapter of
+                                       your own: decorate its ``loss_and_grad`` with ``determinism.deterministic`` (or call
+                                       ``determinism.warm_adapter`` yourself).
 
 ``cli/_common.setup_device`` additionally sets the two flags process-wide for the command-line scripts.  north_star asks for bit-exact
 box indices: a sign flip of one gradient element moves one pixel by 2 alpha, so reproducible gradients are what that rests on."""
@@ -28,12 +30,30 @@ def solvers():
 
 
 def deterministic(fn):
-    """decorator: the call (and the autograd backward it runs - the flags are process-wide, not thread-local) under ``solvers()``"""
+    """decorator for a detector step (``loss_and_grad(self, x, extra)`` / ``detect(self, x, extra)``): the call - and the autograd backward
+    it runs; the flags are process-wide, not thread-local - under ``solvers()``, preceded, the FIRST time this object sees an input of
+    this shape on a ROCm device, by one throw-away call of the same function (the warm-up: MIOpen's first answer for a shape may come from
+    another solver than its later ones).  The caller sees one call and one result either way; ``x`` is not modified by a step."""
+    @functools.wraps(fn)
+    def inner(self, x, *args, **kwargs):
+        with torch.backends.cudnn.flags(enabled=True, deterministic=True, benchmark=False):
+            if isinstance(x, torch.Tensor) and x.is_cuda and not torch.cuda.is_current_stream_capturing():
+                seen = self.__dict__.setdefault("_adv_warm_shapes", set())
+                key = (fn.__name__, tuple(x.shape), str(x.device))
+                if key not in seen:
+                    seen.add(key)
+                    fn(self, x, *args, **kwargs)
+            return fn(self, x, *args, **kwargs)
+    inner.__wrapped_deterministic__ = True
+    return inner
+
+
+def under_solvers(fn):
+    """decorator for a driver entry point (PgdAttack.run_batch, PatchTrainer.train_batch ...): the call under ``solvers()``, no warm-up"""
     @functools.wraps(fn)
     def inner(*args, **kwargs):
         with torch.backends.cudnn.flags(enabled=True, deterministic=True, benchmark=False):
             return fn(*args, **kwargs)
-    inner.__wrapped_deterministic__ = True
     return inner
 
 

@@ -28,6 +28,20 @@ def pytest_sessionstart(session):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: long repeats of coverage the default suite already has; run with --full or ADV_FULL_SUITE=1")
+
+
+def pytest_addoption(parser):
+    parser.addoption("--full", action="store_true", default=False, help="also run the tests marked slow (fuzz repeats, second-opinion comparisons)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if config.getoption("--full") or os.environ.get("ADV_FULL_SUITE") == "1":
+        return
+    skip = pytest.mark.skip(reason="slow: run with --full or ADV_FULL_SUITE=1 (the default -m gpu suite must stay well inside the driver's step limit)")
+    for item in items:
+        if "slow" in item.keywords:
+            item.add_marker(skip)
 
 
 @pytest.fixture

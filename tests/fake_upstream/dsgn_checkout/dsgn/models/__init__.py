@@ -92,7 +92,7 @@ class StereoNet(nn.Module):
         xs = x0 + (x1 - x0) * (torch.arange(nx, dtype=torch.float32) + 0.5) / nx
         zz, yy, xx = torch.meshgrid(zs, ys, xs, indexing="ij")
         pts = torch.stack([xx, yy, zz, torch.ones_like(xx)], -1)                                     # [Z,Y,X,4]
-        P = torch.as_tensor(calibs_Proj, dtype=torch.float32)                                        # [B,3,4]
+        P = torch.as_tensor(calibs_Proj, dtype=torch.float32).cpu()                                  # [B,3,4] (DataParallel may have moved it)
         uvw = torch.einsum("bij,zyxj->bzyxi", P, pts)
         u, v = uvw[..., 0] / uvw[..., 2], uvw[..., 1] / uvw[..., 2]
         h, w = image_hw
@@ -104,8 +104,8 @@ class StereoNet(nn.Module):
         assert calibs_Proj_R is not None and len(calibs_fu) == imgL.shape[0]
         fl, fr = self.feature_extraction(imgL), self.feature_extraction(imgR)
         # per-plane disparity in FEATURE pixels: fu * baseline / depth / 4 (fractional: the operator interpolates)
-        fb = torch.as_tensor(calibs_fu, dtype=torch.float32) * torch.as_tensor(calibs_baseline, dtype=torch.float32).abs()
-        shift = (fb[:, None] / torch.tensor(self.DEPTHS)[None, :] / 4.0).to(fl.device)
+        fb = (torch.as_tensor(calibs_fu, dtype=torch.float32) * torch.as_tensor(calibs_baseline, dtype=torch.float32).abs()).to(fl.device)
+        shift = fb[:, None] / torch.tensor(self.DEPTHS, device=fl.device)[None, :] / 4.0
         cost = self.build_cost(fl, fr, shift)                                                                    # [B,8,D,h,w]
         out = self.hg(self.dres0(cost))
         score = self.classif1(out)                                                                               # [B,1,D,h,w]

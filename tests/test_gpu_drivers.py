@@ -232,6 +232,7 @@ def test_baseline_config1_fgsm_four_pairs(tmp_path):
     assert len(os.listdir(os.path.join(str(tmp_path), "dsgn_pgd_iters_1", "image_2"))) == 4
 
 
+@pytest.mark.slow        # 60 s of MIOpen compilation on a fresh box; tests/test_surrogates.py compares the same two routes on the R101 step
 def test_surrogate_detector_gradients_agree_between_mfma_and_miopen_convs():
     """the DSGN-shaped surrogate with its 3D convolutions on libadvengine's MFMA kernel vs on torch / MIOpen: same
     loss and image gradient up to float32 summation order; and a 3-step attack raises the loss"""
