@@ -50,7 +50,7 @@ struct GemmGeo {
 // that re-read one X tile sit in the same L2.
 template <int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(256, 2) void conv2d_1x1_mfma(const float* __restrict__ x, const float* __restrict__ wp, float* __restrict__ y, int K, int M,
-                                                       int mpad, long long P, int tiles_m, int tiles_n, long long ntiles, long long total, Epi2 epi) {
+                                                       int mpad, long long P, int tiles_m, int tiles_n, long long ntiles, long long wbytes, Epi2 epi) {
   using G = GemmGeo<WM, WN, TM, TN>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -78,61 +78,45 @@ __global__ __launch_bounds__(256, 2) void conv2d_1x1_mfma(const float* __restric
 #pragma unroll
       for (int v = 0; v < 16; ++v) acc[i][jn][v] = 0.0f;
 
-  // The loads are UNCONDITIONAL (a load inside a divergent branch makes the compiler wait for it at the join, i.e. before the matrix
-  // instructions): rows past K load row K - 1, the tensor's last floats load from an address clamped into the tensor; both are put right
-  // (zeros; shifted elements) when the data is committed to LDS after the stage's matrix instructions.
-  v4f rx[G::kXF4], rw[G::kWF4];
-  int rxs[G::kXF4];
-  unsigned rxm[G::kXF4];
-  const long long xlast = total - 4;
-  auto fetch = [&](int k0) {
+  // <round 5> Staging by BUFFER loads, two register sets deep.  The counters (profiles/r04_conv_pmc.json) had this kernel at ten vector
+  // instructions per matrix instruction and 0.38-0.46 matrix-pipe busy: every stage recomputed 64-bit addresses, clamps and element masks,
+  // and a stage is short (16 channels: 8-64 matrix instructions per wave), so a load requested at its start was not back at its end.
+  // Now a slot's byte offset inside the image / the prepared weights is computed ONCE; a stage adds a wave-uniform offset (one v_add per
+  // input slot; the scalar offset operand for the weights) and the hardware's range check returns zeros for rows >= K and behind the
+  // tensor - no clamp, no mask (columns past a row's end read the next row: never stored).  Every load travels a whole stage longer: stage s
+  // requests stage s + 2 into one register set and commits the other (requested during stage s - 1); the loop is uniform, unrolled by two
+  // for the alternation, requests past the last stage are out of range (zeros) and their commits fill a buffer nobody reads.  Same bits.
+  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + b * KP), 0, static_cast<int>(static_cast<unsigned>(KP * 4)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wp), 0, static_cast<int>(static_cast<unsigned>(wbytes)), 0x00020000);
+  int xvo[G::kXF4], wvo[G::kWF4];
 #pragma unroll
-    for (int i = 0; i < G::kXF4; ++i) {
-      const int f = tid + 256 * i, row = f / (G::kBN / 4), c4 = f % (G::kBN / 4);
-      const int kr = k0 + row;
-      const long long at = b * KP + static_cast<long long>(kr < K ? kr : K - 1) * P + n0 + c4 * 4;   // may run past the row's end into the
-      const long long cl = at > xlast ? xlast : at;                                                 // next row: those columns are never stored
-      rx[i] = *reinterpret_cast<const v4f_u*>(x + cl);
-      rxs[i] = static_cast<int>(cl - at);
-      unsigned m = 0;
+  for (int i = 0; i < G::kXF4; ++i) {
+    const int f = tid + 256 * i, row = f / (G::kBN / 4), c4 = f % (G::kBN / 4);
+    xvo[i] = static_cast<int>((static_cast<unsigned>(row) * static_cast<unsigned>(P) + static_cast<unsigned>(n0) + 4u * c4) * 4u);
+  }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) m |= (at + e < total) ? (1u << e) : 0u;
-      rxm[i] = kr < K ? m : 0u;
-    }
-#pragma unroll
-    for (int i = 0; i < G::kWF4; ++i) {
-      const int f = tid + 256 * i, row = f / (G::kBM / 4), c4 = f % (G::kBM / 4);
-      rw[i] = *reinterpret_cast<const v4f*>(wp + static_cast<long long>(k0 + row) * mpad + m0 + c4 * 4);
-    }
+  for (int i = 0; i < G::kWF4; ++i) {
+    const int f = tid + 256 * i, row = f / (G::kBM / 4), c4 = f % (G::kBM / 4);
+    wvo[i] = (row * mpad + m0 + c4 * 4) * 4;
+  }
+  struct Set {
+    v4f x[G::kXF4], w[G::kWF4];
   };
-  auto commit = [&](int buf) {
+  Set sa, sb;
+  auto fetch = [&](int k0, Set& st) {
+    const int xo = static_cast<int>(static_cast<unsigned>(k0) * static_cast<unsigned>(P) * 4u);      // wave-uniform
+#pragma unroll
+    for (int i = 0; i < G::kXF4; ++i) st.x[i] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsx, xvo[i] + xo, 0, 0));
+#pragma unroll
+    for (int i = 0; i < G::kWF4; ++i) st.w[i] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsw, wvo[i], k0 * mpad * 4, 0));
+  };
+  auto commit = [&](int buf, const Set& st) {
     float* sx = lds + buf * G::kStage;
     float* sw = sx + kKC * G::kBN;
 #pragma unroll
-    for (int i = 0; i < G::kXF4; ++i) {
-      const int f = tid + 256 * i;
-      const v4f t4 = rx[i];
-      const int sh = rxs[i];
-      const unsigned m = rxm[i];
-      v4f v;
-      if (__builtin_expect(__builtin_amdgcn_ballot_w64(sh != 0) != 0, 0)) {     // wave-uniform: the tensor's last float4 only
+    for (int i = 0; i < G::kXF4; ++i) *reinterpret_cast<v4f*>(sx + 4 * (tid + 256 * i)) = st.x[i];         // [row][BN] row-major == float4 index
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int k = e - sh;
-          v[e] = k == 0 ? t4[0] : (k == 1 ? t4[1] : (k == 2 ? t4[2] : t4[3]));
-        }
-      } else {
-        v = t4;
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = (m >> e) & 1u ? v[e] : 0.0f;
-      *reinterpret_cast<v4f*>(sx + 4 * f) = v;         // [row][BN] row-major == float4 index f
-    }
-#pragma unroll
-    for (int i = 0; i < G::kWF4; ++i) {
-      const int f = tid + 256 * i;
-      *reinterpret_cast<v4f*>(sw + 4 * f) = rw[i];
-    }
+    for (int i = 0; i < G::kWF4; ++i) *reinterpret_cast<v4f*>(sw + 4 * (tid + 256 * i)) = st.w[i];
   };
   auto products = [&](int s) {
     const float* sx = lds + (s & 1) * G::kStage;
@@ -151,20 +135,24 @@ __global__ __launch_bounds__(256, 2) void conv2d_1x1_mfma(const float* __restric
     }
   };
 
-  // the last stage is peeled off so that a load and the LDS write that consumes it sit in the same straight-line block
   const int nstage = (K + kKC - 1) / kKC;
-  fetch(0);
-  commit(0);
+  fetch(0, sa);
+  fetch(kKC, sb);
+  commit(0, sa);
   __syncthreads();
-  int s = 0;
-  for (; s + 1 < nstage; ++s) {
-    fetch((s + 1) * kKC);
+  auto stage = [&](int s, Set& fs, const Set& cs) {
+    fetch((s + 2) * kKC, fs);
     __builtin_amdgcn_sched_barrier(0);     // the loads stay AHEAD of the matrix instructions (the scheduler would sink them to their use)
     products(s);
-    commit((s + 1) & 1);
+    commit((s + 1) & 1, cs);
     __syncthreads();
+  };
+  int s = 0;
+  for (; s + 1 < nstage; s += 2) {
+    stage(s, sa, sb);
+    stage(s + 1, sb, sa);
   }
-  products(s);
+  if (s < nstage) products(s);
 
   // ---- epilogue: register v of a 32x32 accumulator = output channel (v & 3) + 8 * (v >> 2) + 4 * half, pixel = lane & 31
   const long long MP = static_cast<long long>(M) * P;
@@ -243,10 +231,13 @@ int launch_1x1(const float* x, const float* wp, float* y, int b, int K, int M, i
   const long long tiles_n = (P + G::kBN - 1) / G::kBN;
   const long long ntiles = static_cast<long long>(tiles_m) * tiles_n * b;
   if (tiles_n > 0x7fffffffLL || ntiles > 0x7fffffffLL) return ADV_EINVAL;
+  // an image and the prepared weights are addressed with 32-bit byte offsets (buffer loads): both below 4 GiB
+  const long long wbytes = static_cast<long long>(round_up(K, kKC)) * mpad * 4;
+  if ((static_cast<long long>(K) + kKC) * P * 4 >= 0xfff00000LL || wbytes >= 0xfff00000LL) return ADV_EINVAL;
   const size_t lds = 2 * sizeof(float) * static_cast<size_t>(G::kStage);
   if (lds > 64 * 1024 && !adv_internal_lds_limit<conv2d_1x1_mfma<WM, WN, TM, TN>>(lds)) return ADV_ELAUNCH;
   hipLaunchKernelGGL((conv2d_1x1_mfma<WM, WN, TM, TN>), dim3(static_cast<unsigned>(ntiles)), dim3(256), lds, st, x, wp, y, K, M, mpad, P, tiles_m,
-                     static_cast<int>(tiles_n), ntiles, static_cast<long long>(b) * K * P, epi);
+                     static_cast<int>(tiles_n), ntiles, wbytes, epi);
   return adv_internal_finish_launch();
 }
 

@@ -61,6 +61,8 @@ struct WGeo {
   static constexpr size_t kLds = 2 * sizeof(float) * (kSX + kSW + kSV);
 };
 
+constexpr int kDeep64Stages = 8;      // 64-channel workgroups: deep staging from this many stages per tile up (profiles/r05_wino_deep64.jsonl)
+
 struct EpiW {
   const float* bias;
   const float* residual;
@@ -69,7 +71,7 @@ struct EpiW {
 };
 
 // Cin, Cout: channels; cinpad / copad: the prepared weights' padding; D: planes (1 for a 2D layer); DEPTH: 3x3x3 kernel
-template <int PR, int PC, int COB, int KC, bool DEPTH, int ABL, bool DEEP = false>
+template <int PR, int PC, int COB, int KC, bool DEPTH, int ABL, int DEEP = 0>
 __global__ __launch_bounds__(COB * 128, COB == 4 ? 1 : 2) void conv_wino(const float* __restrict__ x, const float* __restrict__ wp, float* __restrict__ y,
                                                                           int Cin, int Cout, int cinpad, int copad, int D, int H, int W, int tiles_w,
                                                                           long long wbytes, EpiW epi) {
@@ -219,9 +221,10 @@ __global__ __launch_bounds__(COB * 128, COB == 4 ? 1 : 2) void conv_wino(const f
   // into one set and commits the other one (requested during stage st - 1).  The stage loop is then UNIFORM - no peeled tail: requests
   // past the last stage are clamped to it and their commits / transforms fill buffers nobody reads - unrolled by two for the alternation
   // of the register sets.  Worth 3-8 % from 24 (3D) / 32 (2D) stages up, a loss of as much on short contractions (three stages of wasted
-  // side work per tile): the launch picks (launch_wino).  The 64-channel shape has no registers for a second set.  Same bits.
-  constexpr bool kDeep = DEEP;
-  static_assert(!DEEP || COB == 2, "deep staging: the 32-channel shape only");
+  // side work per tile): the launch picks (launch_wino).  Same bits.
+  // <round 5> DEEP = 2: the INPUT tiles only (the 64-channel shape has no registers for a second set of weight registers - with both the
+  // compiler spills 7-16 registers; its weights keep the one-stage trip: they are L2-resident, the input tiles come from HBM)
+  constexpr bool kDeep = DEEP != 0, kDeepW = DEEP == 1;
   XSet xsB;
   v4f rwB[G::kWSl];
   auto qclamp = [&](int q) { return q < q_hi - KC ? q : q_hi - KC; };
@@ -239,8 +242,10 @@ __global__ __launch_bounds__(COB * 128, COB == 4 ? 1 : 2) void conv_wino(const f
     if constexpr (kDeep) {       // the second register sets: the input tile of stage 2 and the weights of stage 1 (committed during stage 0)
 #pragma unroll
       for (int i = 0; i < G::kXSl; ++i) fetch_x1(i, qclamp(q_lo + 2 * KC), xsB);
+      if constexpr (kDeepW) {
 #pragma unroll
-      for (int i = 0; i < G::kWSl; ++i) fetch_w1(i, qclamp(q_lo + KC), rwB);
+        for (int i = 0; i < G::kWSl; ++i) fetch_w1(i, qclamp(q_lo + KC), rwB);
+      }
     }
     if (blockIdx.x == 0 && stage_off(q_lo) == 0) {      // wave-uniform: the tile at the image's origin, its first stage at channel 0, plane 0
       // the float4 that holds columns -1 .. 2 of row 0 starts four bytes BEFORE the image: out of range as a whole (zeros) - its three
@@ -285,14 +290,17 @@ __global__ __launch_bounds__(COB * 128, COB == 4 ? 1 : 2) void conv_wino(const f
     const int nb = (st + 1) & 1;       // the buffers of stage st + 1 (V, U) - and of stage st + 2's inputs: st & 1
     const int q1 = q_lo + (st + 1) * KC;
     // what this stage requests: the inputs of stage st + 2 and the weights of stage st + 1 - or, deep, one stage further each
-    const int qfx = kDeep ? qclamp(q1 + 2 * KC) : q1 + KC, qfw = kDeep ? qclamp(q1 + KC) : q1;
+    const int qfx = kDeep ? qclamp(q1 + 2 * KC) : q1 + KC, qfw = kDeepW ? qclamp(q1 + KC) : (kDeep ? qclamp(q1) : q1);
 #pragma unroll
     for (int t = 0; t < kAhead; ++t) load(t);
 #pragma unroll
     for (int t = 0; t < NS; ++t) {
       if (t + kAhead < NS) load(t + kAhead);
-      if (FX && t < G::kXSl && !(dbg & 4)) fetch_x1(t, qfx, fxs);
-      if (FW && t >= G::kLoadW && t < G::kLoadW + G::kWSl && !(dbg & 4)) fetch_w1(t - G::kLoadW, qfw, frw);
+      // (input-only deep staging: the weights are requested FIRST - they are committed in this very stage, and the memory counter retires
+      //  loads in order: a weight commit would otherwise wait for the stage's input loads too, which are meant to stay in flight)
+      constexpr int kFx0 = DEEP == 2 ? G::kWSl : 0, kFw0 = DEEP == 2 ? 0 : G::kLoadW;
+      if (FX && t >= kFx0 && t < kFx0 + G::kXSl && !(dbg & 4)) fetch_x1(t - kFx0, qfx, fxs);
+      if (FW && t >= kFw0 && t < kFw0 + G::kWSl && !(dbg & 4)) fetch_w1(t - kFw0, qfw, frw);
       if (FW && t >= G::kRead && t < G::kRead + 4 && !(dbg & 1)) tr_read(t - G::kRead, nb);
       if (FW && t == G::kComp && !(dbg & 1)) tr_compute();
       if (FW && t >= G::kWrite && t < G::kWrite + 16 / G::kWritesPerStep && !(dbg & 1)) {
@@ -314,9 +322,15 @@ __global__ __launch_bounds__(COB * 128, COB == 4 ? 1 : 2) void conv_wino(const f
   int st = 0;
   if constexpr (kDeep) {
     for (; st + 1 < nstage; st += 2) {
-      products(st, std::true_type{}, std::true_type{}, xs, xsB, rw, rwB);
-      if (!(dbg & 16)) __syncthreads();
-      products(st + 1, std::true_type{}, std::true_type{}, xsB, xs, rwB, rw);
+      if constexpr (kDeepW) {
+        products(st, std::true_type{}, std::true_type{}, xs, xsB, rw, rwB);
+        if (!(dbg & 16)) __syncthreads();
+        products(st + 1, std::true_type{}, std::true_type{}, xsB, xs, rwB, rw);
+      } else {
+        products(st, std::true_type{}, std::true_type{}, xs, xsB, rw, rw);
+        if (!(dbg & 16)) __syncthreads();
+        products(st + 1, std::true_type{}, std::true_type{}, xsB, xs, rw, rw);
+      }
       if (!(dbg & 16)) __syncthreads();
     }
     if (st < nstage) products(st, std::false_type{}, std::false_type{}, xs, xs, rw, rw);      // an odd count's last stage: products only
@@ -440,13 +454,16 @@ int launch_wino(const float* x, const float* wp, float* y, int b, int cin, int c
     }
   }
 #endif
-  if constexpr (COB == 2) {
+  {
+    // deep staging (a second set of staging registers: every load travels a stage longer): 32-channel workgroups from 24 (3D) / 32 (2D)
+    // stages up (round 4); <round 5> the 64-channel shape too - the buffer-load addressing freed the registers - from ADV_DEEP64 stages up
     const int stages = (DEPTH ? 3 : 1) * cinpad / KC;       // (interior planes)
-    bool deep = stages >= (DEPTH ? 24 : 32);
+    bool deep = COB == 2 ? stages >= (DEPTH ? 24 : 32) : stages >= kDeep64Stages;
     if (const char* e = adv_hook_value("ADV_WINO_DEEP")) deep = e[0] == '1';      // test hook / A-B; same bits
     if (deep) {
-      if (!adv_internal_lds_limit<conv_wino<PR, PC, COB, KC, DEPTH, 0, true>>(G::kLds)) return ADV_ELAUNCH;
-      hipLaunchKernelGGL((conv_wino<PR, PC, COB, KC, DEPTH, 0, true>), grid, dim3(G::kNT), G::kLds, st, x, wp, y, cin, cout, cinpad, copad, d, h, w,
+      constexpr int kMode = COB == 2 ? 1 : 2;      // 32-channel workgroups: inputs and weights; 64-channel: the inputs only
+      if (!adv_internal_lds_limit<conv_wino<PR, PC, COB, KC, DEPTH, 0, kMode>>(G::kLds)) return ADV_ELAUNCH;
+      hipLaunchKernelGGL((conv_wino<PR, PC, COB, KC, DEPTH, 0, kMode>), grid, dim3(G::kNT), G::kLds, st, x, wp, y, cin, cout, cinpad, copad, d, h, w,
                          tiles_w, wbytes, epi);
       return adv_internal_finish_launch();
     }
@@ -488,7 +505,18 @@ int pick_wino_tile(int cout, int h, int w, long long bz) {
   // 48 x 76 maps at one pair per step (48-96 workgroups).  Two 32-channel workgroups per unit transform every input tile twice, but
   // they run everywhere: 1.22-1.24x on those layers, slower from ~160 workgroups up (profiles/r04_wino_tiles.jsonl).  Same bits.
   const long long t = shape == 1 ? tiles(16, 16) : (shape == 4 ? tiles(10, 24) : (shape == 6 ? tiles(6, 40) : tiles(8, 32)));
-  if (narrow == 0 && t * ((cout + 63) / 64) * bz <= 128) narrow = (shape == 4 || shape == 6) ? 1 : 2;
+  // <round 5> the same question as a makespan estimate over the chip's 256 compute units (profiles/r05_wino_tiles.jsonl): 64-channel workgroups
+  // run one per unit, ceil(n64 / 256) rounds; 32-channel workgroups run two per unit at ~7 % more work per output (every input tile is
+  // transformed twice) but their LAST round is finer-grained - up to 256 left-over workgroups sit alone on a unit and finish in half a
+  // round.  The quantisation of a 64-channel launch of 1.25 or 2.5 rounds (the 75 x 249 maps: 320 / 640 workgroups) costs 17-24 %; launches of
+  // many rounds gain nothing from the finer tail and keep the 64-channel shape.  (n64 <= 128 is the round-4 rule: half of the chip idle.)
+  if (narrow == 0) {
+    const long long n64 = t * ((cout + 63) / 64) * bz, n32 = t * ((cout + 31) / 32) * bz;
+    const double t64 = static_cast<double>((n64 + 255) / 256);
+    const long long rem = n32 % 512;
+    const double t32 = 1.07 * (static_cast<double>(n32 / 512) + (rem == 0 ? 0.0 : (rem <= 256 ? 0.5 : 1.0)));
+    if (t32 < t64) narrow = (shape == 4 || shape == 6) ? 1 : 2;
+  }
   return shape + narrow;
 }
 

@@ -429,8 +429,8 @@ def test_adopted_stand_in_dsgn_keeps_loss_and_gradient(checkout):
         assert rep["verified_outputs"] == 4 and rep["functional"] == [("dsgn.models", "F")]
         AF.stats(reset=True)
         loss, grad = adapters.DsgnAdapter(net, cfg, ShimLoss).loss_and_grad(x.clone(), extra)
-        st = AF.stats()
-        assert st["grid_sample"] == 1 and st["depth_regress"] == 1 and st["materialised"] == 0, st
+        st = AF.stats()                               # (a new input shape: the adapter runs its throw-away warm-up step first - two forwards)
+        assert st["grid_sample"] == 2 and st["depth_regress"] == 2 and st["grid_plan_built"] == 1 and st["materialised"] == 0, st
         assert abs(float(loss) - float(want_loss)) <= 1e-4 * abs(float(want_loss))
         assert float((grad - want_grad).abs().max()) <= 1e-4 * float(want_grad.abs().max())
         AF.stats(reset=True)
