@@ -10,7 +10,8 @@ The attacks differentiate w.r.t. the images only; the detector is in eval mode a
     which), ``nn.Conv3d`` 3x3x3 stride 1 / 2 and ``nn.ConvTranspose3d`` 3x3x3 stride 2 on csrc/conv3d.hip (``ops.Conv3dK3``,
     ``ops.Conv3dK3S2``, ``ops.ConvTranspose3dK3S2``); bias (the folded BatchNorm shift) and - where the graph is a plain
     ``nn.Sequential`` conv -> [bn] -> relu - the ReLU run in the kernel's epilogue;
-  * layers without a kernel here (7x7 stems, strided 2D layers, grouped convolutions ...) keep torch's operator but still lose their
+  * a stride-2 1x1 layer (ResNet's down-sampling projections) is a sub-sampling copy + the 1x1 GEMM kernel;
+  * layers without a kernel here (7x7 stems, strided 3x3 layers, grouped convolutions ...) keep torch's operator but still lose their
     BatchNorm (folded) and get bias + ReLU as ONE fused pass (``ops.bias_act_``);
   * gradients flow to the INPUT only: the adopted modules return no weight gradients (``adopt`` switches ``requires_grad`` off on
     what it adopts, as adapters._freeze does for the whole model).
@@ -128,12 +129,17 @@ class AdoptedConv2d(_Adopted):
         self.padding_mode = conv.padding_mode
         k = tuple(weight.shape[2:])
         s, p, d = _same(self.stride), (None if isinstance(self.padding, str) else _same(self.padding)), _same(self.dilation)
-        self.native = (self.groups == 1 and self.padding_mode == "zeros" and s == 1 and k[0] == k[1] and
-                       ((k[0] == 1 and p == 0 and d == 1) or (k[0] == 3 and d in (1, 2) and p == d)))
+        self.subsample = self.groups == 1 and self.padding_mode == "zeros" and s == 2 and k == (1, 1) and p == 0 and d == 1      # strided 1x1: sub-sample + GEMM
+        self.native = self.subsample or (self.groups == 1 and self.padding_mode == "zeros" and s == 1 and k[0] == k[1] and
+                                         ((k[0] == 1 and p == 0 and d == 1) or (k[0] == 3 and d in (1, 2) and p == d)))
         self.kind = "conv2d %dx%d s%s d%s %d->%d%s" % (k[0], k[1], s, d, weight.shape[1] * self.groups, weight.shape[0], "" if self.native else " (torch + fused epilogue)")
 
     def forward(self, x):
         ops = self._ops(x)
+        if self.subsample and x.dtype == torch.float32:
+            x = x[:, :, ::2, ::2].contiguous()          # every other pixel of every other row: what a stride-2 1x1 layer reads
+        elif self.subsample:
+            return self._torch_epilogue(F.conv2d(x, self.weight, None, self.stride, self.padding, self.dilation, self.groups), ops)
         if self.native and ops.conv2d_supported(x, self.weight, 1, self.padding[0], self.dilation[0]):
             prep = self._prepared(lambda: ops.Conv2dPrep(self.weight, 1, self.padding[0], self.dilation[0]))
             return ops.Conv2dAuto.apply(x, prep, self.weight, self.bias, None, self.relu)

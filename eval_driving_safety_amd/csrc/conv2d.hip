@@ -246,9 +246,10 @@ int launch_1x1(const float* x, const float* wp, float* y, int b, int K, int M, i
 // ceil(waves / SIMDs) * TM*TN / efficiency(shape) - bigger tiles reuse more per staged byte, smaller ones fill the chip.
 int pick_1x1_tile(int b, int M, long long P, int simds) {
   static const int bm[4] = {128, 128, 64, 64}, bn[4] = {256, 128, 128, 64}, work[4] = {8, 4, 2, 1};
-  // relative efficiency of a wave's MFMA stream per tile shape, fitted to the sweep of the R101 1x1 layers on MI355X
-  // (profiles/r03_conv2d_1x1_tile_sweep.jsonl): the 128x256 tile (219 VGPRs, two waves per SIMD) is the slowest per FLOP
-  static const double eff[4] = {0.8, 1.08, 0.94, 1.0};
+  // relative efficiency of a wave's MFMA stream per tile shape, fitted to the sweep of the R101 1x1 layers on MI355X (round 5, after the
+  // buffer-load staging: profiles/r05_conv2d_1x1_tile_sweep.jsonl - the small tiles gained most: several workgroups per compute unit
+  // cover each other's prologue and epilogue; 0.07 ms per R101 step over the per-layer optimum, the round-3 fit {0.8, 1.08, 0.94, 1} 0.26)
+  static const double eff[4] = {0.75, 0.88, 0.99, 1.0};
   int best = 0;
   double best_t = 1e300;
   for (int c = 0; c < 4; ++c) {

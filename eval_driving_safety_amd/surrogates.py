@@ -498,9 +498,14 @@ class FoldedConv(nn.Module):
             return (F.relu(y) if relu else y)[:, :, None, None]
         if FoldedConv.impl in ("hip", "auto"):
             from . import ops
-            if ops.conv2d_supported(x, self.weight, self.stride, self.padding) and (FoldedConv.hip_kernels is None or self.k in FoldedConv.hip_kernels):
+            stride = self.stride
+            if self.k == 1 and stride == 2 and self.padding == 0 and x.is_cuda and (FoldedConv.hip_kernels is None or 1 in FoldedConv.hip_kernels):
+                # a strided 1x1 layer reads every other pixel of every other row: sub-sample (one strided copy; its backward scatters into
+                # zeros, deterministically) and run the GEMM kernel on what is left - the layer is this package's, not MIOpen's
+                x, stride = x[:, :, ::2, ::2].contiguous(), 1
+            if ops.conv2d_supported(x, self.weight, stride, self.padding) and (FoldedConv.hip_kernels is None or self.k in FoldedConv.hip_kernels):
                 if self._prep is None or self._prep.device != x.device:
-                    self._prep = ops.Conv2dPrep(self.weight, self.stride, self.padding)
+                    self._prep = ops.Conv2dPrep(self.weight, 1, self.padding)
                 if FoldedConv.impl == "auto":      # per layer shape and direction, whichever of {libadvengine, MIOpen} measured faster
                     return ops.Conv2dAuto.apply(x, self._prep, self.weight, self.bias, residual, relu, chain_in, skip_out)
                 assert not skip_out

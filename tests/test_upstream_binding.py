@@ -223,7 +223,7 @@ def test_adopt_walks_the_stand_in_stereo_rcnn(checkout):
     assert all(isinstance(getattr(b0, "conv%d" % k), A.AdoptedConv2d) and isinstance(getattr(b0, "bn%d" % k), nn.Identity) for k in (1, 2, 3))
     assert isinstance(b0.relu, nn.ReLU) and not b0.conv2.relu and isinstance(b0.downsample[0], A.AdoptedConv2d) and isinstance(b0.downsample[1], nn.Identity)
     assert b0.conv1.native and b0.conv2.native and b0.conv2.kind.startswith("conv2d 3x3 s1 d1 4->4")
-    assert not net.RCNN_layer2[0].conv1.native                            # the stride-2 1x1: torch's operator, BatchNorm still folded
+    assert net.RCNN_layer2[0].conv1.native and net.RCNN_layer2[0].conv1.subsample      # the stride-2 1x1: a sub-sampling copy + the GEMM kernel
     assert net.RCNN_toplayer.native and net.RCNN_smooth1.native and net.RCNN_smooth1.bias is not None
     assert rep["folded_bn"] == 1 + 3 * 3 + 2 and rep["fused_relu"] == 1 + 2 and not rep["kept"]
     # the top-down path's _upsample_add (attack/Stereo-RCNN/stereo_rcnn.py:91-108) rebound: same values, a fixed-order backward on the GPU
@@ -539,11 +539,15 @@ def test_every_adopted_layer_equals_its_oracle_bit_for_bit(checkout):
                 y = m(torch.tensor(x, device=dev)).cpu().numpy()
                 (route,) = set(routes.used().values())
                 k = wt.shape[2]
+                xin = x
+                if m.subsample:                                           # a stride-2 1x1 layer: the GEMM kernel on every other pixel of every other row
+                    x = np.ascontiguousarray(x[:, :, ::2, ::2])
                 if route == "wino":
                     want = oracle_c.conv2d_wino(x, wt, bias, relu=m.relu)
                 else:
                     assert route == "hip", route
                     want = oracle_c.conv2d(x, wt, bias, padding=m.padding[0], dilation=m.dilation[0], relu=m.relu, chunk=16 if k == 1 else 8)
+                x = xin
                 checked["conv2d"] += 1
             elif isinstance(m, A.AdoptedConv3d):
                 x = rs.randn(1, wt.shape[1], 4, 6, 12).astype(np.float32)
