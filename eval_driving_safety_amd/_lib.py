@@ -23,7 +23,7 @@ ADV_ELAUNCH = -5
 ADV_SPACE_AFFINE = 0
 ADV_SPACE_IDENTITY = 1
 ADV_SPACE_AFFINE_RCP = 2
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class AdvSpace(ctypes.Structure):
@@ -114,6 +114,10 @@ SIGNATURES = {
     "adv_conv2d_wino_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "adv_conv3d_wino_prep_weights_f32": [_P, _P, _I, _I, _I, _P],
     "adv_conv3d_wino_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "adv_conv2d_wino4_prep_weights_f32": [_P, _P, _I, _I, _I, _P],
+    "adv_conv2d_wino4_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "adv_conv3d_wino4_prep_weights_f32": [_P, _P, _I, _I, _I, _P],
+    "adv_conv3d_wino4_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
 }
 _OTHER = {
     "adv_abi_version": ([], _I),
@@ -126,6 +130,8 @@ _OTHER = {
     "adv_conv2d_3x3_prep_floats": ([_I, _I, _I], ctypes.c_int64),
     "adv_conv2d_wino_prep_floats": ([_I, _I, _I], ctypes.c_int64),
     "adv_conv3d_wino_prep_floats": ([_I, _I, _I], ctypes.c_int64),
+    "adv_conv2d_wino4_prep_floats": ([_I, _I, _I], ctypes.c_int64),
+    "adv_conv3d_wino4_prep_floats": ([_I, _I, _I], ctypes.c_int64),
     "adv_last_hip_error": ([], _I),
     "adv_strerror": ([_I], ctypes.c_char_p),
     "adv_space_dsgn": ([_SP], None),

@@ -1,0 +1,539 @@
+// 3x3 (x3) / stride 1 / pad 1 convolutions by Winograd F(4x4, 3x3) on the gfx950 float32 matrix cores (v_mfma_f32_32x32x2_f32):
+// 36 element-wise products per 4 x 4 outputs - 4x fewer multiply-adds than the direct kernels, 1.78x fewer than csrc/wino2d.hip's
+// F(2x2, 3x3) - input transform, products, output transform and epilogue in ONE kernel (no transformed tensor reaches HBM).
+//
+//   Y(4x4) = A^T [ sum_q (G g_q G^T) .* (B^T d_q B) ] A      d_q: the 6 x 6 input patch of "channel" q around the 4 x 4 output block
+//   2D layers: q = input channel.   3x3x3 layers: the transform in the (H, W) plane, the depth taps inside the contraction, q = (kd, c).
+//
+// Why the design differs from wino2d.hip.  Thirty-six products of a (channel block) x (patch block) tile need 36 accumulator tiles.  With
+// 16x16 tiles and two waves per SIMD (wino2d's scheme) that is 144 registers per 16 x 16 block and two operand reads per matrix
+// instruction - the LDS, not the matrix pipe, would set the pace.  Here a workgroup is FOUR waves, one per SIMD, each with the whole
+// 512-register file: wave w owns the nine positions k = w, w + 4, ..., w + 32 for ALL 64 output channels x 32 patches of the tile
+// (18 accumulators of 32 x 32 = 288 registers), one B operand shared by the two channel blocks: three LDS reads per two 64-cycle matrix
+// instructions, a quarter of the operand traffic per matrix cycle.  The 36 values of one (channel, patch) then sit in four different waves:
+// after the contraction they are exchanged through LDS (four rounds of 16 channels, 74 KB each) and every thread transforms two
+// (channel, patch) items per round - ~2 us per tile against 60 us of products at 256 channels.
+//
+//   per stage of KC = 4 q:   input tile [4][4 PR + 2][LWP]   global -> registers (buffer loads, two sets deep) -> LDS
+//                            U = G g G^T of the stage [36][4][64]   global -> LDS by LDS-DMA, each wave ITS OWN nine positions (1 KiB each)
+//                            V = B^T d B [36][4][32]   256 threads: two per (q, patch), three of the six rows of V each
+//   one barrier per stage, two buffers of everything, side work woven between the matrix instructions (one wave per SIMD: whatever
+//   stalls the wave stalls the pipe).
+//
+// Order of float operations (oracle/oracle.c orc_conv_wino4 restates it bit for bit): the transforms' expressions as written below
+// (explicit fmaf where a multiply feeds an add), each M_k one fmaf chain over q ascending starting from 0 (the matrix instruction is a
+// k-ordered fmaf chain).  The backward w.r.t. the input is the same kernel on the transposed, flipped weights.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <type_traits>
+
+#include "adv_internal.h"
+#include "advengine.h"
+
+namespace {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+constexpr int kKC = 4;        // "channels" q per stage
+constexpr int kCO = 64;       // output channels per workgroup
+
+// PR x PC = 32 patches of 4 x 4 outputs per workgroup; LWP: floats per LDS row of the input tile (>= 4 PC + 8, padded against bank conflicts)
+template <int PR, int PC, int LWP>
+struct W4Geo {
+  static_assert(PR * PC == 32, "32 patches per workgroup");
+  static constexpr int kRows = 4 * PR + 2, kLW = 4 * PC + 8;      // input rows; loaded columns gw = w0 - 4 .. w0 + 4 PC + 3 (whole aligned float4 groups)
+  static_assert(LWP >= kLW && LWP % 4 == 0, "row pitch");
+  static constexpr int kSX = kKC * kRows * LWP;                   // floats per input-tile buffer
+  static constexpr int kXN = kKC * kRows * (kLW / 4);             // float4 groups per stage
+  static constexpr int kXSl = (kXN + 511) / 512;
+  static constexpr int kSW = 36 * kKC * kCO, kSV = 36 * kKC * 32;
+  static constexpr size_t kLds = 2 * sizeof(float) * (kSX + kSW + kSV);
+  static_assert(kLds >= sizeof(float) * 36 * 16 * 32, "the exchange buffer of the epilogue fits");
+};
+
+struct Epi4 {
+  const float* bias;
+  const float* residual;
+  const float* mask;
+  int relu;
+};
+
+// the six expressions of B^T applied to (d0 .. d5)
+__device__ __forceinline__ void bt6(float d0, float d1, float d2, float d3, float d4, float d5, float (&t)[6]) {
+  t[0] = __builtin_fmaf(4.0f, d0, __builtin_fmaf(-5.0f, d2, d4));
+  t[1] = __builtin_fmaf(-4.0f, d1 + d2, d3 + d4);
+  t[2] = __builtin_fmaf(4.0f, d1 - d2, d4 - d3);
+  t[3] = __builtin_fmaf(2.0f, d3 - d1, d4 - d2);
+  t[4] = __builtin_fmaf(2.0f, d1 - d3, d4 - d2);
+  t[5] = __builtin_fmaf(4.0f, d1, __builtin_fmaf(-5.0f, d3, d5));
+}
+
+// A^T applied to (m0 .. m5) -> four outputs
+__device__ __forceinline__ void at6(float m0, float m1, float m2, float m3, float m4, float m5, float (&y)[4]) {
+  const float a = m1 + m2, b = m1 - m2, c = m3 + m4, e = m3 - m4;
+  y[0] = (m0 + a) + c;
+  y[1] = __builtin_fmaf(2.0f, e, b);
+  y[2] = __builtin_fmaf(4.0f, c, a);
+  y[3] = __builtin_fmaf(8.0f, e, b) + m5;
+}
+
+template <int PR, int PC, int LWP, bool DEPTH>
+__global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x, const float* __restrict__ wp, float* __restrict__ y, int Cin, int Cout,
+                                                     int cinpad, int copad, int D, int H, int W, int tiles_w, long long wbytes, Epi4 epi) {
+  using G = W4Geo<PR, PC, LWP>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l32 = lane & 31, half = lane >> 5;
+  const int wt = blockIdx.x % tiles_w, ht = blockIdx.x / tiles_w;
+  const int w0 = wt * 4 * PC, h0 = ht * 4 * PR, co0 = blockIdx.y * kCO;
+  const long long b = DEPTH ? blockIdx.z / D : blockIdx.z;
+  const int od = DEPTH ? static_cast<int>(blockIdx.z % D) : 0;
+  const long long HW = static_cast<long long>(H) * W;
+  const long long DHW = HW * D;
+
+  float* const sxb = lds;                          // [2][KC][rows][LWP]   input tiles
+  float* const swb = lds + 2 * G::kSX;             // [2][36][KC][64]      U of the stage
+  float* const svb = swb + 2 * G::kSW;             // [2][36][KC][32]      V of the stage
+
+  // ---- addressing: buffer loads, one 32-bit byte offset per slot computed once per tile, the hardware's range check = zero padding
+  const float* const xb = x + b * Cin * DHW;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, static_cast<int>(static_cast<unsigned>(Cin * DHW * 4)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rwgt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wp), 0, static_cast<int>(wbytes), 0x00020000);
+  int xvo[G::kXSl], xls[G::kXSl];
+  unsigned xvm[G::kXSl];
+#pragma unroll
+  for (int i = 0; i < G::kXSl; ++i) {
+    const int sidx = tid + 512 * i;
+    const int j = sidx % (G::kLW / 4), r = (sidx / (G::kLW / 4)) % G::kRows, c = sidx / ((G::kLW / 4) * G::kRows);
+    const int gh = h0 - 1 + r, gw = w0 - 4 + 4 * j;          // groups start on multiples of four columns: none straddles the row's start
+    xvo[i] = static_cast<int>(static_cast<unsigned>(c < kKC ? c : kKC - 1) * static_cast<unsigned>(DHW) * 4u) + (gh * W + gw) * 4;
+    xls[i] = ((c < kKC ? c : kKC - 1) * G::kRows + r) * LWP + 4 * j;
+    unsigned vm = 0;
+    if (sidx < G::kXN && gh >= 0 && gh < H)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) vm |= (gw + e >= 0 && gw + e < W) ? (1u << e) : 0u;
+    xvm[i] = vm | (sidx < G::kXN ? 16u : 0u);                // bit 4: the slot exists
+  }
+  struct XSet {
+    v4f v[G::kXSl];
+  };
+  auto stage_off = [&](int q0) -> unsigned {      // wave-uniform: bytes from (channel 0, plane 0) to (the stage's first channel, its plane)
+    const int kd = DEPTH ? q0 / cinpad : 0;
+    const int ch = DEPTH ? q0 - kd * cinpad : q0;
+    return static_cast<unsigned>((static_cast<long long>(ch) * D + (DEPTH ? od + kd - 1 : 0)) * HW * 4);
+  };
+  auto fetch_x1 = [&](int i, int q0, XSet& set) {
+    set.v[i] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rx, xvo[i] + static_cast<int>(stage_off(q0)), 0, 0));
+  };
+  auto commit_x1 = [&](int i, int buf, const XSet& set) {
+    v4f v = set.v[i];
+    const unsigned m = xvm[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (m >> e) & 1u ? v[e] : 0.0f;
+    if (m & 16u) *reinterpret_cast<v4f*>(sxb + buf * G::kSX + xls[i]) = v;
+  };
+  // The 36 positions are dealt to the eight waves so that the two waves of a SIMD carry nine between them: waves 0-3 (which also compute
+  // the input transform) own four each, k = w + 4 n (positions 0-15); waves 4-7 own five each, k = 12 + w + 4 n (positions 16-35).
+  const int kbase = wave < 4 ? wave : 12 + wave;
+  // weights: a wave stages the positions it multiplies itself: U[k][q0 .. q0 + 3][co0 .. co0 + 63] = 1 KiB, one LDS-DMA instruction
+  // (lane L: row L >> 4, float4 L & 15), straight into the stage buffer - no staging registers, no commit, no other wave involved
+  const int wrows = DEPTH ? 3 * cinpad : cinpad;           // rows of U per transform position
+  const int wvo = ((lane >> 4) * copad + co0 + 4 * (lane & 15)) * 4;
+  auto dma_w1 = [&](int n, int q0, int buf) {
+    const int k = kbase + 4 * n;
+    float* dst = swb + buf * G::kSW + k * (kKC * kCO);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rwgt, (lds_void*)dst, 16, wvo, (k * wrows + q0) * copad * 4, 0, 0);
+  };
+
+  // ---- the input transform (waves 0-3): thread -> (q = pair >> 5, patch = pair & 31), pair = tid & 127; waves 0, 1 compute rows 0-2 of V, waves 2, 3 rows 3-5
+  const int pair = tid & 127, tc = pair >> 5, tp = pair & 31;
+  const int hs = (wave >> 1) & 1;
+  const int toff = (tc * G::kRows + 4 * (tp / PC) + hs) * LWP + 4 * (tp % PC) + 3;     // first needed row: 0 (rows 0-4) or 1 (rows 1-5)
+  const int voff = tc * 32 + tp;
+  float td[5][6], tt[3][6], tv[18];
+  auto tr_read = [&](int i, int buf) {
+    const float* p = sxb + buf * G::kSX + toff + i * LWP;
+    td[i][0] = p[0];
+    const v4f m = *reinterpret_cast<const v4f*>(p + 1);
+    td[i][1] = m[0], td[i][2] = m[1], td[i][3] = m[2], td[i][4] = m[3];
+    td[i][5] = p[5];
+  };
+  auto tr_cols = [&](auto hs_c, int j) {          // column pass, column j: the thread's three rows of T = B^T d
+    constexpr bool kHi = decltype(hs_c)::value;
+    const float e0 = td[0][j], e1 = td[1][j], e2 = td[2][j], e3 = td[3][j], e4 = td[4][j];
+    if constexpr (!kHi) {       // rows 0, 1, 2 from d0 .. d4
+      tt[0][j] = __builtin_fmaf(4.0f, e0, __builtin_fmaf(-5.0f, e2, e4));
+      tt[1][j] = __builtin_fmaf(-4.0f, e1 + e2, e3 + e4);
+      tt[2][j] = __builtin_fmaf(4.0f, e1 - e2, e4 - e3);
+    } else {                    // rows 3, 4, 5 from d1 .. d5 (e0 = d1)
+      tt[0][j] = __builtin_fmaf(2.0f, e2 - e0, e3 - e1);
+      tt[1][j] = __builtin_fmaf(2.0f, e0 - e2, e3 - e1);
+      tt[2][j] = __builtin_fmaf(4.0f, e0, __builtin_fmaf(-5.0f, e2, e4));
+    }
+  };
+  auto tr_row = [&](int i) {                      // row pass of the thread's row i (0 .. 2)
+    float o[6];
+    bt6(tt[i][0], tt[i][1], tt[i][2], tt[i][3], tt[i][4], tt[i][5], o);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) tv[6 * i + j] = o[j];
+  };
+  auto tr_write = [&](int idx, int buf) {
+    const int k = (3 * hs + idx / 6) * 6 + idx % 6;
+    svb[buf * G::kSV + k * (kKC * 32) + voff] = tv[idx];
+  };
+
+  // ---- operands of the matrix instructions: A = U_k[q = 2 kp + half][co = 32 cb + l32], B = V_k[q][patch = l32]
+  const int aoff = (kbase * kKC + half) * kCO + l32, boff = (kbase * kKC + half) * 32 + l32;
+
+  const int q_lo = DEPTH ? (od == 0 ? cinpad : 0) : 0;
+  const int q_hi = DEPTH ? (od == D - 1 ? 2 * cinpad : 3 * cinpad) : cinpad;
+  const int nstage = (q_hi - q_lo) / kKC;
+  auto qclamp = [&](int q) { return q < q_hi - kKC ? q : q_hi - kKC; };
+
+  // epilogue geometry (every thread: one (channel of the round's 16, patch) item per round)
+  const long long MP = static_cast<long long>(Cout) * DHW;
+  const long long plane0 = static_cast<long long>(od) * HW;
+  float* const yb = y + b * MP + plane0;
+  const float* const resb = epi.residual ? epi.residual + b * MP + plane0 : nullptr;
+  const float* const maskb = epi.mask ? epi.mask + b * MP + plane0 : nullptr;
+  const bool vec4 = (W & 3) == 0 && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(epi.residual) | reinterpret_cast<uintptr_t>(epi.mask)) & 15) == 0;
+  const int ep = tid & 31, eg = tid >> 5;
+  const int gh0 = h0 + 4 * (ep / PC), gw0 = w0 + 4 * (ep % PC);
+
+  // body<NP, T, HS>: a wave's whole life after the set-up - NP positions; T: it also computes the input transform (half HS of it)
+  auto body = [&](auto np_c, auto t_c, auto hs_c) __attribute__((always_inline)) {
+    constexpr int NP = decltype(np_c)::value;
+    constexpr bool TR = decltype(t_c)::value;
+    constexpr int NS = 2 * NP;                    // steps per stage: (position n, q pair kp), two matrix instructions each
+    f32x16 acc[NP][2];
+#pragma unroll
+    for (int n = 0; n < NP; ++n)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[n][c][v] = 0.0f;
+    XSet xsA, xsB;
+    {
+      // prologue: the first three input tiles and the first weights are requested together
+      XSet xs0, xs1;
+#pragma unroll
+      for (int i = 0; i < G::kXSl; ++i) fetch_x1(i, q_lo, xs0);
+#pragma unroll
+      for (int n = 0; n < NP; ++n) dma_w1(n, q_lo, 0);
+#pragma unroll
+      for (int i = 0; i < G::kXSl; ++i) fetch_x1(i, qclamp(q_lo + kKC), xs1);
+#pragma unroll
+      for (int i = 0; i < G::kXSl; ++i) fetch_x1(i, qclamp(q_lo + 2 * kKC), xsB);
+#pragma unroll
+      for (int i = 0; i < G::kXSl; ++i) commit_x1(i, 0, xs0);
+#pragma unroll
+      for (int i = 0; i < G::kXSl; ++i) commit_x1(i, 1, xs1);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if constexpr (TR) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) tr_read(i, 0);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) tr_cols(hs_c, j);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) tr_row(i);
+#pragma unroll
+        for (int k = 0; k < 18; ++k) tr_write(k, 0);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    // Stage st: NS steps of two matrix instructions each (the two channel blocks, one B operand) on U / V of stage st.  Woven between
+    // them, one piece per step: the LDS-DMA of the wave's weights of stage st + 1, the loads of the input tile of stage st + 3, the commit
+    // of the input tile of stage st + 2 (requested during stage st - 1) and - waves 0-3, eight steps - the input transform of stage st + 1.
+    // The scheduler may not move anything across a step.  ONE barrier per stage; before it the wave's LDS-DMAs have landed (vmcnt: all
+    // but the stage's own input loads, which are issued after them and travel on).
+    auto stage = [&](int st, XSet& fxs, const XSet& cxs) __attribute__((always_inline)) {
+      constexpr int kAhead = 3;
+      float ra0[NS], ra1[NS], rb[NS];
+      const float* ap = swb + (st & 1) * G::kSW + aoff;
+      const float* bp = svb + (st & 1) * G::kSV + boff;
+      auto load = [&](int t) {
+        const int row = (4 * (t >> 1)) * kKC + 2 * (t & 1);      // (k - kbase) * KC + 2 kp
+        ra0[t] = ap[row * kCO];
+        ra1[t] = ap[row * kCO + 32];
+        rb[t] = bp[row * 32];
+      };
+      const int nb = (st + 1) & 1;
+      const int q1 = qclamp(q_lo + (st + 1) * kKC), q3 = qclamp(q_lo + (st + 3) * kKC);
+#pragma unroll
+      for (int t = 0; t < kAhead; ++t) load(t);
+#pragma unroll
+      for (int t = 0; t < NS; ++t) {
+        if (t + kAhead < NS) load(t + kAhead);
+        if (t < NP) dma_w1(t, q1, nb);
+        if (t >= NP && t < NP + G::kXSl) fetch_x1(t - NP, q3, fxs);
+        if (t >= NS - G::kXSl) commit_x1(t - (NS - G::kXSl), st & 1, cxs);
+        if constexpr (TR) {      // eight steps: rows 0-2 | rows 3-4 | columns 0-2 | columns 3-5 | V rows 0, 1 + first writes | V row 2 + writes | writes | writes
+          if (t == 0) tr_read(0, nb), tr_read(1, nb), tr_read(2, nb);
+          if (t == 1) tr_read(3, nb), tr_read(4, nb);
+          if (t == 2) tr_cols(hs_c, 0), tr_cols(hs_c, 1), tr_cols(hs_c, 2);
+          if (t == 3) tr_cols(hs_c, 3), tr_cols(hs_c, 4), tr_cols(hs_c, 5);
+          if (t == 4) tr_row(0), tr_row(1);
+          if (t == 5) tr_row(2);
+          if (t >= 4) {
+            constexpr int kPer[4] = {3, 5, 5, 5};       // 18 writes over steps 4-7
+            int first = 0;
+#pragma unroll
+            for (int u = 4; u < t; ++u) first += kPer[u - 4];
+#pragma unroll
+            for (int u = 0; u < kPer[t - 4]; ++u) tr_write(first + u, nb);
+          }
+        }
+        acc[t >> 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra0[t], rb[t], acc[t >> 1][0], 0, 0, 0);
+        acc[t >> 1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra1[t], rb[t], acc[t >> 1][1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // the stage's LDS-DMAs have landed (issued before its input loads, which travel on: the counter retires in order), the LDS writes
+      // are done; a plain __syncthreads() would wait for ALL memory operations - the input loads too
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(G::kXSl) : "memory");
+    };
+    {
+      int st = 0;
+      for (; st + 1 < nstage; st += 2) {
+        stage(st, xsA, xsB);
+        stage(st + 1, xsB, xsA);
+      }
+      if (st < nstage) stage(st, xsA, xsB);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // (clamped requests of the last stages: nothing may land later)
+
+    // ---- epilogue: the 36 values M_k of one (channel, patch) sit in eight waves - exchange through LDS, 16 channels per round:
+    // E[k][co16][patch]; register v of a 32 x 32 accumulator = channel (v & 3) + 8 (v >> 2) + 4 half of its block, patch = lane & 31
+    float* const se = lds;
+#pragma unroll
+    for (int round = 0; round < 4; ++round) {               // (unrolled: the accumulator registers are addressed by constants)
+      if (co0 + 16 * round >= Cout) continue;               // (workgroup-uniform) nothing but padding from here on
+      constexpr int kDummy = 0;
+      (void)kDummy;
+#pragma unroll
+      for (int n = 0; n < NP; ++n) {
+        const int k = kbase + 4 * n;
+#pragma unroll
+        for (int v8 = 0; v8 < 8; ++v8) {
+          const int co16 = (v8 & 3) + 8 * (v8 >> 2) + 4 * half;
+          se[(k * 16 + co16) * 32 + l32] = acc[n][round >> 1][8 * (round & 1) + v8];
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      {
+        const int co16 = eg;
+        const int co = co0 + 16 * round + co16;
+        float s[4][6], o[4][4];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          float col[4];
+          at6(se[((0 * 6 + j) * 16 + co16) * 32 + ep], se[((1 * 6 + j) * 16 + co16) * 32 + ep], se[((2 * 6 + j) * 16 + co16) * 32 + ep],
+              se[((3 * 6 + j) * 16 + co16) * 32 + ep], se[((4 * 6 + j) * 16 + co16) * 32 + ep], se[((5 * 6 + j) * 16 + co16) * 32 + ep], col);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[r][j] = col[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) at6(s[r][0], s[r][1], s[r][2], s[r][3], s[r][4], s[r][5], o[r]);
+        if (co < Cout && gh0 < H && gw0 < W) {
+          const float bv = epi.bias ? epi.bias[co] : 0.0f;
+          const long long at0 = static_cast<long long>(co) * DHW + static_cast<long long>(gh0) * W + gw0;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (gh0 + r >= H) continue;
+            const long long at = at0 + static_cast<long long>(r) * W;
+            float rv[4] = {0.0f, 0.0f, 0.0f, 0.0f}, mv[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+            if (vec4) {
+              if (resb) {
+                const v4f t4 = *reinterpret_cast<const v4f*>(resb + at);
+                rv[0] = t4[0], rv[1] = t4[1], rv[2] = t4[2], rv[3] = t4[3];
+              }
+              if (maskb) {
+                const v4f t4 = *reinterpret_cast<const v4f*>(maskb + at);
+                mv[0] = t4[0], mv[1] = t4[1], mv[2] = t4[2], mv[3] = t4[3];
+              }
+            } else {
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                if (gw0 + c >= W) continue;
+                if (resb) rv[c] = resb[at + c];
+                if (maskb) mv[c] = maskb[at + c];
+              }
+            }
+            float res[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              float v = o[r][c];
+              if (epi.bias) v = v + bv;
+              if (resb) v = v + rv[c];
+              if (epi.relu) v = v > 0.0f ? v : 0.0f;
+              if (maskb) v = mv[c] > 0.0f ? v : 0.0f;
+              res[c] = v;
+            }
+            if (vec4) {
+              *reinterpret_cast<v4f*>(yb + at) = v4f{res[0], res[1], res[2], res[3]};
+            } else {
+#pragma unroll
+              for (int c = 0; c < 4; ++c)
+                if (gw0 + c < W) yb[at + c] = res[c];
+            }
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+  };
+  using I4 = std::integral_constant<int, 4>;
+  using I5 = std::integral_constant<int, 5>;
+  if (wave >= 4) body(I5{}, std::false_type{}, std::false_type{});
+  else if (hs) body(I4{}, std::true_type{}, std::true_type{});
+  else body(I4{}, std::true_type{}, std::false_type{});
+}
+
+int round_up4(int v, int q) { return (v + q - 1) / q * q; }
+
+template <int PR, int PC, int LWP, bool DEPTH>
+int launch_wino4(const float* x, const float* wp, float* y, int b, int cin, int cout, int cinpad, int copad, int d, int h, int w, const Epi4& epi,
+                 hipStream_t st) {
+  using G = W4Geo<PR, PC, LWP>;
+  const int tiles_w = (w + 4 * PC - 1) / (4 * PC), tiles_h = (h + 4 * PR - 1) / (4 * PR);
+  const long long tiles = static_cast<long long>(tiles_w) * tiles_h;
+  const int cgroups = (cout + kCO - 1) / kCO;
+  const long long gz = static_cast<long long>(b) * d;
+  if (tiles > 0x7fffffffLL || cgroups > 65535 || gz > 65535) return ADV_EINVAL;
+  const long long wbytes = 36LL * (DEPTH ? 3 : 1) * cinpad * copad * 4;
+  if ((static_cast<long long>(cinpad) + 1) * d * h * w * 4 >= 0xfff00000LL || wbytes >= 0x7ff00000LL) return ADV_EINVAL;
+  const dim3 grid(static_cast<unsigned>(tiles), cgroups, static_cast<unsigned>(gz));
+  if (!adv_internal_lds_limit<conv_wino4<PR, PC, LWP, DEPTH>>(G::kLds)) return ADV_ELAUNCH;
+  hipLaunchKernelGGL((conv_wino4<PR, PC, LWP, DEPTH>), grid, dim3(512), G::kLds, st, x, wp, y, cin, cout, cinpad, copad, d, h, w, tiles_w, wbytes, epi);
+  return adv_internal_finish_launch();
+}
+
+// tile: 0 = 16 x 32 outputs (4 x 8 patches), 1 = 8 x 64 outputs (2 x 16 patches: maps of few rows)
+int pick_wino4_tile(int h, int w) {
+  auto tiles = [&](int th, int tw) { return static_cast<long long>((h + th - 1) / th) * ((w + tw - 1) / tw); };
+  return tiles(8, 64) * 21 < tiles(16, 32) * 20 ? 1 : 0;
+}
+
+template <bool DEPTH>
+int launch_wino4_tile(int t, const float* x, const float* wp, float* y, int b, int cin, int cout, int cinpad, int copad, int d, int h, int w,
+                      const Epi4& epi, hipStream_t st) {
+  switch (t) {
+    case 0: return launch_wino4<4, 8, 40, DEPTH>(x, wp, y, b, cin, cout, cinpad, copad, d, h, w, epi, st);
+    default: return launch_wino4<2, 16, 72, DEPTH>(x, wp, y, b, cin, cout, cinpad, copad, d, h, w, epi, st);
+  }
+}
+
+int check_wino4_args(const float* x, const float* w_prep, const float* bias, const float* residual, const float* mask, const float* y) {
+  if (residual == y || mask == y || x == y) return ADV_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(x) & 3) || (reinterpret_cast<uintptr_t>(y) & 3) || (reinterpret_cast<uintptr_t>(w_prep) & 15) ||
+      (residual && (reinterpret_cast<uintptr_t>(residual) & 3)) || (mask && (reinterpret_cast<uintptr_t>(mask) & 3)) ||
+      (bias && (reinterpret_cast<uintptr_t>(bias) & 3)))
+    return ADV_EALIGN;
+  return ADV_OK;
+}
+
+// U = G g G^T (6 x 6) for every (output, input) channel pair (and depth tap), laid out [k = 6 i + j][kd][c'][m'] (zero rows / columns of
+// padding).  forward: m = co, c = ci, g = w[co][ci][kd];  transpose (backward w.r.t. the input): m = ci, c = co, g = w[co][ci] with all
+// its taps reversed.  taps = 1: a 2D layer's [Cout][Cin][3][3] weights.
+__device__ __forceinline__ void g6(float g0, float g1, float g2, float (&t)[6]) {
+  const float w6 = -1.0f / 6.0f, w24 = 1.0f / 24.0f, w12 = 1.0f / 12.0f, w6p = 1.0f / 6.0f;
+  t[0] = g0 * 0.25f;
+  t[1] = ((g0 + g1) + g2) * w6;
+  t[2] = ((g0 - g1) + g2) * w6;
+  t[3] = __builtin_fmaf(g0, w24, __builtin_fmaf(g1, w12, g2 * w6p));
+  t[4] = __builtin_fmaf(g0, w24, __builtin_fmaf(-g1, w12, g2 * w6p));
+  t[5] = g2;
+}
+
+__global__ void conv_wino4_prep_kernel(const float* __restrict__ w, float* __restrict__ out, int cout, int cin, int taps, int transpose, int kpad,
+                                       int mpad) {
+  const long long n = static_cast<long long>(taps) * kpad * mpad;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += 256LL * gridDim.x) {
+    const int m = static_cast<int>(i % mpad), c = static_cast<int>((i / mpad) % kpad), kd = static_cast<int>(i / (static_cast<long long>(mpad) * kpad));
+    const int co = transpose ? c : m, ci = transpose ? m : c;
+    float u[36];
+    if (co < cout && ci < cin) {
+      const float* gp = w + ((static_cast<long long>(co) * cin + ci) * taps + (transpose ? taps - 1 - kd : kd)) * 9;
+      float g[9], t[6][3];
+#pragma unroll
+      for (int q = 0; q < 9; ++q) g[q] = gp[transpose ? 8 - q : q];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        float col[6];
+        g6(g[j], g[3 + j], g[6 + j], col);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) t[r][j] = col[r];
+      }
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        float row[6];
+        g6(t[r][0], t[r][1], t[r][2], row);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) u[6 * r + j] = row[j];
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 36; ++q) u[q] = 0.0f;
+    }
+#pragma unroll
+    for (int q = 0; q < 36; ++q) out[q * n + i] = u[q];
+  }
+}
+
+int prep_wino4(const float* w, float* w_prep, int cout, int cin, int taps, int transpose, hipStream_t st) {
+  if (!w || !w_prep || cout < 1 || cin < 1) return ADV_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(w) & 3) || (reinterpret_cast<uintptr_t>(w_prep) & 15)) return ADV_EALIGN;
+  const int k = transpose ? cout : cin, m = transpose ? cin : cout;
+  const int kpad = round_up4(k, kKC), mpad = round_up4(m, kCO);
+  const long long n = static_cast<long long>(taps) * kpad * mpad;
+  const unsigned blocks = static_cast<unsigned>(n / 256 + 1 < 4096 ? n / 256 + 1 : 4096);
+  hipLaunchKernelGGL(conv_wino4_prep_kernel, dim3(blocks), dim3(256), 0, st, w, w_prep, cout, cin, taps, transpose ? 1 : 0, kpad, mpad);
+  return adv_internal_finish_launch();
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t adv_conv2d_wino4_prep_floats(int cout, int cin, int transpose) {
+  if (cout < 1 || cin < 1) return ADV_EINVAL;
+  const int k = transpose ? cout : cin, m = transpose ? cin : cout;
+  return 36LL * round_up4(k, kKC) * round_up4(m, kCO);
+}
+
+int adv_conv2d_wino4_prep_weights_f32(const float* w, float* w_prep, int cout, int cin, int transpose, adv_stream_t stream) {
+  return prep_wino4(w, w_prep, cout, cin, 1, transpose, static_cast<hipStream_t>(stream));
+}
+
+int adv_conv2d_wino4_f32(const float* x, const float* w_prep, const float* bias, const float* residual, const float* mask, float* y, int b, int cin,
+                         int cout, int h, int w, int relu, int tile, adv_stream_t stream) {
+  if (!x || !w_prep || !y || b < 1 || cin < 1 || cout < 1 || h < 1 || w < 1 || tile < -1 || tile > 1) return ADV_EINVAL;
+  if (const int rc = check_wino4_args(x, w_prep, bias, residual, mask, y)) return rc;
+  const Epi4 epi{bias, residual, mask, relu ? 1 : 0};
+  return launch_wino4_tile<false>(tile >= 0 ? tile : pick_wino4_tile(h, w), x, w_prep, y, b, cin, cout, round_up4(cin, kKC), round_up4(cout, kCO), 1, h, w,
+                                  epi, static_cast<hipStream_t>(stream));
+}
+
+int64_t adv_conv3d_wino4_prep_floats(int cout, int cin, int transpose) {
+  if (cout < 1 || cin < 1) return ADV_EINVAL;
+  const int k = transpose ? cout : cin, m = transpose ? cin : cout;
+  return 108LL * round_up4(k, kKC) * round_up4(m, kCO);
+}
+
+int adv_conv3d_wino4_prep_weights_f32(const float* w, float* w_prep, int cout, int cin, int transpose, adv_stream_t stream) {
+  return prep_wino4(w, w_prep, cout, cin, 3, transpose, static_cast<hipStream_t>(stream));
+}
+
+int adv_conv3d_wino4_f32(const float* x, const float* w_prep, const float* bias, const float* residual, const float* mask, float* y, int b, int cin,
+                         int cout, int d, int h, int w, int relu, int tile, adv_stream_t stream) {
+  if (!x || !w_prep || !y || b < 1 || cin < 1 || cout < 1 || d < 1 || h < 1 || w < 1 || tile < -1 || tile > 1) return ADV_EINVAL;
+  if (const int rc = check_wino4_args(x, w_prep, bias, residual, mask, y)) return rc;
+  const Epi4 epi{bias, residual, mask, relu ? 1 : 0};
+  return launch_wino4_tile<true>(tile >= 0 ? tile : pick_wino4_tile(h, w), x, w_prep, y, b, cin, cout, round_up4(cin, kKC), round_up4(cout, kCO), d, h, w,
+                                 epi, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

@@ -5,6 +5,7 @@
   roi      RoIAlign forward / ordered backward, pyramid pooling, NMS (csrc/roi.hip)
   conv3d   3x3x3 convolutions on the float32 matrix cores: direct, strided, transposed, Winograd (csrc/conv3d.hip, csrc/wino2d.hip)
   conv2d   2D convolutions on the float32 matrix cores: 1x1, 3x3, Winograd, the route choice; fused bias / ReLU pass (csrc/conv2d.hip, csrc/wino2d.hip)
+  wino4    3x3 / 3x3x3 stride-1 convolutions by Winograd F(4x4,3x3) (csrc/wino4.hip)
   align    dense photometric box alignment (csrc/align.hip)
   volume   after the 3D convolutions: depth regression, 5-D grid sampling, bilinear up-sampling, bird's-eye-view fold, focal loss (csrc/volume.hip, csrc/resize.hip)
 
@@ -18,7 +19,8 @@ from .psv import *       # noqa: F401,F403
 from .roi import *       # noqa: F401,F403
 from .conv3d import *       # noqa: F401,F403
 from .conv2d import *       # noqa: F401,F403
+from .wino4 import *       # noqa: F401,F403
 from .align import *       # noqa: F401,F403
 from .volume import *       # noqa: F401,F403
 
-SOURCES = tuple(__import__("os").path.join(__import__("os").path.dirname(__file__), n + ".py") for n in ("_base", "elementwise", "pixel", "psv", "roi", "conv3d", "conv2d", "align", "volume"))
+SOURCES = tuple(__import__("os").path.join(__import__("os").path.dirname(__file__), n + ".py") for n in ("_base", "elementwise", "pixel", "psv", "roi", "conv3d", "conv2d", "wino4", "align", "volume"))

@@ -30,7 +30,16 @@ class Conv2dPrep:
         self.device = wt.device
         self.fwd, self.bwd = self._prep(wt, False), self._prep(wt, True)
         self.has_wino = self.k == 3 and self.dilation == 1      # Winograd F(2x2,3x3) route (csrc/wino2d.hip): prepared on first use
-        self._wt, self._wino = (wt if self.has_wino else None), {}
+        self._wt, self._wino, self._wino4 = (wt if self.has_wino else None), {}, None
+
+    def wino4(self):
+        """the layer as a ConvWino4Prep (Winograd F(4x4,3x3), csrc/wino4.hip), made on first use"""
+        if not self.has_wino:
+            raise ValueError("the Winograd routes need a 3x3 / dilation 1 layer")
+        if self._wino4 is None:
+            from .wino4 import ConvWino4Prep
+            self._wino4 = ConvWino4Prep(self._wt)
+        return self._wino4
 
     def wino(self, transpose):
         """the layer's transformed weights G g G^T for adv_conv2d_wino_f32 (forward / backward w.r.t. the input), made once"""
@@ -170,6 +179,7 @@ class BiasAct(torch.autograd.Function):
 # multiply-adds on the matrix cores than it is credited with (F(2x2,3x3): 16 products per 4 outputs instead of 36) - tools/bench_end_to_end.py
 # turns this into executed FLOPs per step and a matrix-pipe utilisation bound next to the direct-equivalent roofline fraction
 WINO_DIRECT_EQUIV_FLOPS = [0]
+WINO4_DIRECT_EQUIV_FLOPS = [0]       # the same for the F(4x4,3x3) route (csrc/wino4.hip): 4x fewer multiply-adds than it is credited with
 
 
 class _Conv2dChoice:
@@ -185,11 +195,13 @@ class _Conv2dChoice:
         return routes.choose(key, fns)
 
     @staticmethod
-    def get(key, hip_fn, torch_fn, wino_fn=None):
-        """-> "hip" (direct implicit GEMM), "wino" (Winograd on the matrix cores, 3x3 layers) or "" (torch / MIOpen)"""
+    def get(key, hip_fn, torch_fn, wino_fn=None, wino4_fn=None):
+        """-> "hip" (direct implicit GEMM), "wino" / "wino4" (Winograd F(2x2,3x3) / F(4x4,3x3) on the matrix cores, 3x3 layers) or "" (torch / MIOpen)"""
         fns = {"hip": hip_fn, "": torch_fn}
         if wino_fn is not None:
             fns["wino"] = wino_fn
+        if wino4_fn is not None:
+            fns["wino4"] = wino4_fn
         return routes.choose(key, fns)
 
 
@@ -223,11 +235,17 @@ class Conv2dAuto(torch.autograd.Function):
         def by_torch():                  # MIOpen's convolution + ONE element-wise pass (bias, skip connection, ReLU)
             return bias_act_(F.conv2d(x, weight, None, 1, pad, dil), bias, res, do_relu)
 
+        def by_wino4():
+            from .wino4 import conv_wino4
+            return conv_wino4(x, prep.wino4(), bias, res, do_relu)
+
         use = _Conv2dChoice.get(key, lambda: conv2d(x, prep, bias, res, do_relu), by_torch,
-                                (lambda: conv2d(x, prep, bias, res, do_relu, wino=True)) if prep.has_wino else None)
-        y = conv2d(x, prep, bias, res, do_relu, wino=(use == "wino")) if use else by_torch()
+                                (lambda: conv2d(x, prep, bias, res, do_relu, wino=True)) if prep.has_wino else None, by_wino4 if prep.has_wino else None)
+        y = by_wino4() if use == "wino4" else (conv2d(x, prep, bias, res, do_relu, wino=(use == "wino")) if use else by_torch())
         if use == "wino":
             WINO_DIRECT_EQUIV_FLOPS[0] += 18 * y.numel() * prep.cin
+        elif use == "wino4":
+            WINO4_DIRECT_EQUIV_FLOPS[0] += 18 * y.numel() * prep.cin
         ctx.prep, ctx.has_res, ctx.xshape = prep, res is not None, tuple(x.shape)
         ctx.mask_own = do_relu and relu != "consumer"          # mask the incoming gradient with y > 0 here
         ctx.mask_input = bool(mask_input)
@@ -252,10 +270,17 @@ class Conv2dAuto(torch.autograd.Function):
             return relu_backward(gx, x_in) if ctx.mask_input else gx
 
         hip = lambda wino=False: conv2d_dgrad(g, prep, residual=skip, mask=x_in if ctx.mask_input else None, wino=wino)      # noqa: E731
-        use = _Conv2dChoice.get(key, hip, by_torch, (lambda: hip(True)) if prep.has_wino else None)
-        gx = hip(use == "wino") if use else by_torch()
+
+        def by_wino4():
+            from .wino4 import conv_wino4_dgrad
+            return conv_wino4_dgrad(g, prep.wino4(), residual=skip, mask=x_in if ctx.mask_input else None)
+
+        use = _Conv2dChoice.get(key, hip, by_torch, (lambda: hip(True)) if prep.has_wino else None, by_wino4 if prep.has_wino else None)
+        gx = by_wino4() if use == "wino4" else (hip(use == "wino") if use else by_torch())
         if use == "wino":
             WINO_DIRECT_EQUIV_FLOPS[0] += 18 * gx.numel() * prep.cout
+        elif use == "wino4":
+            WINO4_DIRECT_EQUIV_FLOPS[0] += 18 * gx.numel() * prep.cout
         return gx, None, None, None, (g if ctx.has_res else None), None, None, None
 
 

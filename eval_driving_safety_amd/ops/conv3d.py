@@ -2,7 +2,7 @@
 still gives every name)."""
 from ._base import *       # noqa: F401,F403  (torch, F, ctypes, _lib, routes, Space and the argument helpers)
 from .elementwise import relu_backward
-from .conv2d import WINO_DIRECT_EQUIV_FLOPS, _Conv2dChoice, _like
+from .conv2d import WINO4_DIRECT_EQUIV_FLOPS, WINO_DIRECT_EQUIV_FLOPS, _Conv2dChoice, _like
 
 # --------------------------------------------------------------------------------------------
 # dense 3x3x3 convolution on the float32 matrix cores (the contraction applied to the K7 cost volume)
@@ -105,7 +105,14 @@ class Conv3dWinoPrep:
         wt = _feat(weight.detach().contiguous(), "weight")
         if wt.dim() != 5 or tuple(wt.shape[2:]) != (3, 3, 3):
             raise ValueError("weight must be [Cout,Cin,3,3,3]")
-        self.cout, self.cin, self._wt, self._u = int(wt.shape[0]), int(wt.shape[1]), wt, {}
+        self.cout, self.cin, self._wt, self._u, self._w4 = int(wt.shape[0]), int(wt.shape[1]), wt, {}, None
+
+    def wino4(self):
+        """the same layer as a ConvWino4Prep (Winograd F(4x4,3x3) in the plane, csrc/wino4.hip), made on first use"""
+        if self._w4 is None:
+            from .wino4 import ConvWino4Prep
+            self._w4 = ConvWino4Prep(self._wt)
+        return self._w4
 
     def u(self, transpose):
         t = self._u.get(bool(transpose))
@@ -299,11 +306,18 @@ class Conv3dK3(torch.autograd.Function):
         direct = lambda: conv3d_k3(x, w_prep, cout, relu=bool(relu), bias=bias, residual=res)       # noqa: E731
         if wino is not None and cout >= 4:
             by_wino = lambda: conv3d_wino(x, wino, bias, res, bool(relu))                            # noqa: E731
+
+            def by_wino4():
+                from .wino4 import conv_wino4
+                return conv_wino4(x, wino.wino4(), bias, res, bool(relu))
+
             key = ("f3", x.shape[1], cout, tuple(x.shape), res is not None, bool(relu))
-            took = _Conv2dChoice.pick(key, {"direct": direct, "wino": by_wino}) == "wino"
-            y = by_wino() if took else direct()
-            if took:
+            took = _Conv2dChoice.pick(key, {"direct": direct, "wino": by_wino, "wino4": by_wino4})
+            y = by_wino() if took == "wino" else (by_wino4() if took == "wino4" else direct())
+            if took == "wino":
                 WINO_DIRECT_EQUIV_FLOPS[0] += 54 * y.numel() * x.shape[1]
+            elif took == "wino4":
+                WINO4_DIRECT_EQUIV_FLOPS[0] += 54 * y.numel() * x.shape[1]
         else:
             y = direct()
         ctx.save_for_backward(w_prep_t if ctx.has_t else weight, y if ctx.mask_own else None, x if mask_input else None)
@@ -328,11 +342,18 @@ class Conv3dK3(torch.autograd.Function):
 
             if ctx.wino is not None and ctx.xshape[1] >= 4:
                 by_wino = lambda: conv3d_wino_dgrad(g, ctx.wino, mask=x_in if ctx.mask_input else None)      # noqa: E731
+
+                def by_wino4():
+                    from .wino4 import conv_wino4_dgrad
+                    return conv_wino4_dgrad(g, ctx.wino.wino4(), mask=x_in if ctx.mask_input else None)
+
                 key = ("b3", ctx.xshape[1], g.shape[1], ctx.xshape, ctx.mask_input)
-                took = _Conv2dChoice.pick(key, {"direct": direct, "wino": by_wino}) == "wino"
-                gx = by_wino() if took else direct()
-                if took:
+                took = _Conv2dChoice.pick(key, {"direct": direct, "wino": by_wino, "wino4": by_wino4})
+                gx = by_wino() if took == "wino" else (by_wino4() if took == "wino4" else direct())
+                if took == "wino":
                     WINO_DIRECT_EQUIV_FLOPS[0] += 54 * gx.numel() * g.shape[1]
+                elif took == "wino4":
+                    WINO4_DIRECT_EQUIV_FLOPS[0] += 54 * gx.numel() * g.shape[1]
             else:
                 gx = direct()
         else:

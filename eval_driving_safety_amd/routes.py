@@ -24,7 +24,8 @@ import os
 import torch
 
 _DEFAULT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "routes_gfx950.json")
-ROUTES = ("hip", "wino", "", "direct")         # "" = torch's operator (MIOpen / rocBLAS); "direct"/"wino" for the 3D stride-1 layers
+ROUTES = ("hip", "wino", "wino4", "", "direct")         # "" = torch's operator (MIOpen / rocBLAS); "direct"/"wino"/"wino4" for the 3D stride-1 layers
+                                                         # "wino" = Winograd F(2x2,3x3) (csrc/wino2d.hip), "wino4" = F(4x4,3x3) (csrc/wino4.hip)
 
 _state = {"mode": None, "table": None, "path": None, "measured": {}, "misses": set(), "used": {}, "memo": {}}
 
@@ -85,7 +86,8 @@ def table_hash():
 
 
 def fixed_rule(names):
-    """the route of a shape the table does not know: Winograd where the layer has it, else this package's direct kernel"""
+    """the route of a shape the table does not know: Winograd F(2x2,3x3) where the layer has it (F(4x4,3x3) only where the table measured it
+    faster: it needs large maps), else this package's direct kernel"""
     if "wino" in names:
         return "wino"
     return "hip" if "hip" in names else next(iter(names))

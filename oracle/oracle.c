@@ -549,3 +549,134 @@ void orc_conv2d(const float* x, const float* w, const float* bias, const float* 
           y[at] = acc;
         }
 }
+
+/* ----------------------------------------------------------------------------------------------------------------------------------
+ * csrc/wino4.hip: 3x3 (x3) / stride 1 / pad 1 convolutions by Winograd F(4x4, 3x3) - 36 element-wise products per 16 outputs (the direct
+ * convolution multiplies 144 times, F(2x2,3x3) 64 times).  Restated in the kernel's order of float operations:
+ *   U = G g G^T      wino4_u:   t = G g  (rows: g0/4; -((g0+g1)+g2)/6; -((g0-g1)+g2)/6; g0/24 + g1/12 + g2/6 ...), then the same along the row
+ *   V = B^T d B      wino4_v:   column pass, then row pass, each the six expressions of wino4_b
+ *   M_k              one fmaf chain over q ascending (3D: kd-major, a tap whose input plane does not exist skipped), starting from 0
+ *   Y = A^T M A      wino4_a along the position's first index, then along the second; then bias, residual, ReLU, mask.
+ * UNPINNED against any upstream source (the reference has none): this is the kernel's own restatement; agreement with torch's operator
+ * to float32 rounding is tested separately. */
+static const float kW6 = -1.0f / 6.0f, kW24 = 1.0f / 24.0f, kW12 = 1.0f / 12.0f, kW6p = 1.0f / 6.0f;
+
+static void wino4_g(float g0, float g1, float g2, float* t /* 6 */) {
+  t[0] = g0 * 0.25f;
+  t[1] = ((g0 + g1) + g2) * kW6;
+  t[2] = ((g0 - g1) + g2) * kW6;
+  t[3] = fmaf(g0, kW24, fmaf(g1, kW12, g2 * kW6p));
+  t[4] = fmaf(g0, kW24, fmaf(-g1, kW12, g2 * kW6p));
+  t[5] = g2;
+}
+
+static void wino4_u(const float* g /* 9 */, float* u /* 36 */) {
+  float t[6][3];
+  for (int j = 0; j < 3; ++j) {
+    float col[6];
+    wino4_g(g[j], g[3 + j], g[6 + j], col);
+    for (int i = 0; i < 6; ++i) t[i][j] = col[i];
+  }
+  for (int i = 0; i < 6; ++i) wino4_g(t[i][0], t[i][1], t[i][2], u + 6 * i);
+}
+
+static void wino4_b(const float* d /* 6, stride s */, int s, float* t /* 6 */) {
+  const float d0 = d[0], d1 = d[s], d2 = d[2 * s], d3 = d[3 * s], d4 = d[4 * s], d5 = d[5 * s];
+  t[0] = fmaf(4.0f, d0, fmaf(-5.0f, d2, d4));
+  t[1] = fmaf(-4.0f, d1 + d2, d3 + d4);
+  t[2] = fmaf(4.0f, d1 - d2, d4 - d3);
+  t[3] = fmaf(2.0f, d3 - d1, d4 - d2);
+  t[4] = fmaf(2.0f, d1 - d3, d4 - d2);
+  t[5] = fmaf(4.0f, d1, fmaf(-5.0f, d3, d5));
+}
+
+static void wino4_v(const float d[6][6], float* v /* 36 */) {
+  float t[6][6];
+  for (int j = 0; j < 6; ++j) {
+    float col[6];
+    wino4_b(&d[0][j], 6, col);
+    for (int i = 0; i < 6; ++i) t[i][j] = col[i];
+  }
+  for (int i = 0; i < 6; ++i) wino4_b(&t[i][0], 1, v + 6 * i);
+}
+
+static void wino4_a(float m0, float m1, float m2, float m3, float m4, float m5, float* y /* 4 */) {
+  const float a = m1 + m2, b = m1 - m2, c = m3 + m4, e = m3 - m4;
+  y[0] = (m0 + a) + c;
+  y[1] = fmaf(2.0f, e, b);
+  y[2] = fmaf(4.0f, c, a);
+  y[3] = fmaf(8.0f, e, b) + m5;
+}
+
+/* x [B,Kc,D,H,W], w [cout][cin][taps][3][3] with taps = 3 (a 3x3x3 layer: depth taps inside the contraction) or 1 (a 2D layer, D = 1).
+ * transpose: x is grad_out, all taps reversed, the roles of cin / cout swapped (the backward w.r.t. the input). */
+void orc_conv_wino4(const float* x, const float* w, const float* bias, const float* residual, const float* mask, float* y, int B, int cin,
+                    int cout, int D, int H, int W, int taps, int relu, int transpose) {
+  const int M = transpose ? cin : cout, Kc = transpose ? cout : cin;
+  float* U = (float*)malloc(sizeof(float) * 36 * (size_t)taps * M * Kc);   /* [kd][m][c][36] */
+  for (int kd = 0; kd < taps; ++kd)
+    for (int m = 0; m < M; ++m)
+      for (int c = 0; c < Kc; ++c) {
+        float g[9];
+        for (int t = 0; t < 9; ++t)
+          g[t] = transpose ? w[(((long)c * cin + m) * taps + (taps - 1 - kd)) * 9 + (8 - t)] : w[(((long)m * cin + c) * taps + kd) * 9 + t];
+        wino4_u(g, U + (((long)kd * M + m) * Kc + c) * 36);
+      }
+  const int PH = (H + 3) / 4, PW = (W + 3) / 4;
+  const long HW = (long)H * W;
+#pragma omp parallel for collapse(3) schedule(static)
+  for (int b = 0; b < B; ++b)
+    for (int od = 0; od < D; ++od)
+      for (int ph = 0; ph < PH; ++ph) {
+        float* V = (float*)malloc(sizeof(float) * 36 * (size_t)taps * Kc);   /* [kd][c][36] */
+        for (int pw = 0; pw < PW; ++pw) {
+          for (int kd = 0; kd < taps; ++kd) {
+            const int pl = taps == 3 ? od + kd - 1 : od;
+            if (pl < 0 || pl >= D) continue;
+            for (int c = 0; c < Kc; ++c) {
+              float d[6][6];
+              for (int i = 0; i < 6; ++i)
+                for (int j = 0; j < 6; ++j) {
+                  const int gh = 4 * ph - 1 + i, gw = 4 * pw - 1 + j;
+                  d[i][j] = (gh >= 0 && gh < H && gw >= 0 && gw < W) ? x[(((long)b * Kc + c) * D + pl) * HW + (long)gh * W + gw] : 0.0f;
+                }
+              wino4_v(d, V + ((long)kd * Kc + c) * 36);
+            }
+          }
+          for (int m = 0; m < M; ++m) {
+            float mm[36], s[4][6], o[4][4];
+            for (int k = 0; k < 36; ++k) {
+              float acc = 0.0f;
+              for (int kd = 0; kd < taps; ++kd) {
+                const int pl = taps == 3 ? od + kd - 1 : od;
+                if (pl < 0 || pl >= D) continue;
+                const float* u = U + (((long)kd * M + m) * Kc) * 36;
+                const float* v = V + ((long)kd * Kc) * 36;
+                for (int c = 0; c < Kc; ++c) acc = fmaf(u[c * 36 + k], v[c * 36 + k], acc);
+              }
+              mm[k] = acc;
+            }
+            for (int j = 0; j < 6; ++j) {
+              float col[4];
+              wino4_a(mm[j], mm[6 + j], mm[12 + j], mm[18 + j], mm[24 + j], mm[30 + j], col);
+              for (int r = 0; r < 4; ++r) s[r][j] = col[r];
+            }
+            for (int r = 0; r < 4; ++r) wino4_a(s[r][0], s[r][1], s[r][2], s[r][3], s[r][4], s[r][5], o[r]);
+            for (int r = 0; r < 4; ++r)
+              for (int q = 0; q < 4; ++q) {
+                const int gh = 4 * ph + r, gw = 4 * pw + q;
+                if (gh >= H || gw >= W) continue;
+                const long at = (((long)b * M + m) * D + od) * HW + (long)gh * W + gw;
+                float acc = o[r][q];
+                if (bias) acc = acc + bias[m];
+                if (residual) acc = acc + residual[at];
+                if (relu) acc = acc > 0.0f ? acc : 0.0f;
+                if (mask) acc = mask[at] > 0.0f ? acc : 0.0f;
+                y[at] = acc;
+              }
+          }
+        }
+        free(V);
+      }
+  free(U);
+}

@@ -39,6 +39,8 @@ _lib.orc_conv2d_wino.argtypes = [_fp, _fp, ctypes.c_void_p, ctypes.c_void_p, cty
 _lib.orc_conv2d_wino.restype = None
 _lib.orc_conv3d_wino.argtypes = [_fp, _fp, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _fp] + [ctypes.c_int] * 8
 _lib.orc_conv3d_wino.restype = None
+_lib.orc_conv_wino4.argtypes = [_fp, _fp, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _fp] + [ctypes.c_int] * 9
+_lib.orc_conv_wino4.restype = None
 for _f in ("orc_denormalize", "orc_normalize", "orc_pgd_step_norm01", "orc_pgd_step_meansub255", "orc_tensor2im_u8",
            "orc_patch_paste", "orc_patch_update"):
     getattr(_lib, _f).restype = None
@@ -314,3 +316,27 @@ def conv_transpose3d_k3_s2(x, weight_t, bias=None, relu=False):
                             mask |= 1 << (td * 9 + th * 3 + tw)
                 conv3d_k3_ex(x, wc, bias, 1, relu, mask, out, (2, 2, 2), (pd, ph, pw))
     return out
+
+
+def conv_wino4(x, w, bias=None, residual=None, mask=None, relu=False, transpose=False):
+    """csrc/wino4.hip in its order of operations: Winograd F(4x4,3x3) in the (H, W) plane - x [B,C,H,W] with w [Cout,Cin,3,3], or x
+    [B,C,D,H,W] with w [Cout,Cin,3,3,3] (the depth taps inside the contraction) - + bias, + residual, ReLU, mask; transpose=True: x is
+    grad_out -> the gradient w.r.t. the input"""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    cout, cin = w.shape[0], w.shape[1]
+    three_d = x.ndim == 5
+    assert w.shape[2:] == ((3, 3, 3) if three_d else (3, 3)) and x.shape[1] == (cout if transpose else cin)
+    b, d, h, ww = x.shape[0], (x.shape[2] if three_d else 1), x.shape[-2], x.shape[-1]
+    y = np.empty((b, cin if transpose else cout) + tuple(x.shape[2:]), np.float32)
+
+    def opt(a, shape):
+        if a is None:
+            return None, None
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        assert a.shape == shape, (a.shape, shape)
+        return a, a.ctypes.data_as(ctypes.c_void_p)
+
+    keep = [opt(bias, (y.shape[1],)), opt(residual, y.shape), opt(mask, y.shape)]
+    _lib.orc_conv_wino4(x, w, keep[0][1], keep[1][1], keep[2][1], y, b, cin, cout, d, h, ww, 3 if three_d else 1, int(relu), int(transpose))
+    return y

@@ -542,7 +542,9 @@ def test_every_adopted_layer_equals_its_oracle_bit_for_bit(checkout):
                 xin = x
                 if m.subsample:                                           # a stride-2 1x1 layer: the GEMM kernel on every other pixel of every other row
                     x = np.ascontiguousarray(x[:, :, ::2, ::2])
-                if route == "wino":
+                if route == "wino4":
+                    want = oracle_c.conv_wino4(x, wt, bias, relu=m.relu)
+                elif route == "wino":
                     want = oracle_c.conv2d_wino(x, wt, bias, relu=m.relu)
                 else:
                     assert route == "hip", route
@@ -559,7 +561,9 @@ def test_every_adopted_layer_equals_its_oracle_bit_for_bit(checkout):
                     checked["conv3d s2"] += 1
                 else:
                     used = set(routes.used().values())
-                    if used == {"wino"}:
+                    if used == {"wino4"}:
+                        want = oracle_c.conv_wino4(x, wt, bias, relu=m.relu)
+                    elif used == {"wino"}:
                         want = oracle_c.conv3d_wino(x, wt, bias, relu=m.relu)
                     elif wt.shape[0] < 4:
                         want = oracle_c.conv3d_k3(x, wt)

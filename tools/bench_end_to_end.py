@@ -130,10 +130,11 @@ def measure_dsgn_full(pairs=1, iters=20, reps=1, graph=False, hip2d="auto"):
     if os.environ.get("ADV_STOP_AFTER_WARMUP") == "1":      # tools/gpu_profile_step.sh: the warm-up alone (MIOpen's solver search), to be subtracted
         return {"stopped": "after the warm-up"}
     from eval_driving_safety_amd import ops as _ops
-    _ops.WINO_DIRECT_EQUIV_FLOPS[0] = 0
+    _ops.WINO_DIRECT_EQUIV_FLOPS[0] = _ops.WINO4_DIRECT_EQUIV_FLOPS[0] = 0
     step = float(net.flops_per_step(x, batch.extra))
     wino_equiv = float(_ops.WINO_DIRECT_EQUIV_FLOPS[0])       # direct-equivalent FLOPs of the calls that took a Winograd route, one step
-    executed = step - wino_equiv * (1.0 - 1.0 / 2.25)
+    wino4_equiv = float(_ops.WINO4_DIRECT_EQUIV_FLOPS[0])     # ... and of those that took the F(4x4,3x3) route (4x fewer multiply-adds executed)
+    executed = step - wino_equiv * (1.0 - 1.0 / 2.25) - wino4_equiv * 0.75
     n = 5
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -180,7 +181,7 @@ def measure_dsgn_full(pairs=1, iters=20, reps=1, graph=False, hip2d="auto"):
                                 False: "torch / MIOpen"}[hip2d],
             "layers_2d_on_libadvengine": _choice_summary(),
             "mfma_frac_step": step / model_ms / 1e9 / 157.3, "peak_hbm_gib": torch.cuda.max_memory_allocated() / 2 ** 30,
-            **_executed(step, wino_equiv, executed, model_ms),
+            **_executed(step, wino_equiv + wino4_equiv, executed, model_ms),
             "loss_first_iter": first, "loss_last_iter": last, "loss_rose": last > first,
             "note": "NOT the headline metric and NOT DSGN's weights; layer list [UPSTREAM-UNVERIFIED] from the published PSMNet / DSGN structures"}
 
@@ -255,9 +256,10 @@ def measure_srcnn_r101(pairs=1, iters=20, reps=1, rois=512, impl="auto", graph_b
             return {"stopped": "after the warm-up"}
         model.reset_flops()
         from eval_driving_safety_amd import ops as _ops
-        _ops.WINO_DIRECT_EQUIV_FLOPS[0] = 0
+        _ops.WINO_DIRECT_EQUIV_FLOPS[0] = _ops.WINO4_DIRECT_EQUIV_FLOPS[0] = 0
         net.loss_and_grad(x, batch.extra)        # the FLOP count comes from the eager graph (a replayed hipGraph runs no Python)
         wino_equiv = float(_ops.WINO_DIRECT_EQUIV_FLOPS[0])
+        wino4_equiv = float(_ops.WINO4_DIRECT_EQUIV_FLOPS[0])
         by_class = model.flops_by_class()
         fwd = float(sum(by_class.values()))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -302,7 +304,7 @@ def measure_srcnn_r101(pairs=1, iters=20, reps=1, rois=512, impl="auto", graph_b
                                                    "losses, element-wise) against the float32 matrix peak",
                          "achieved": step / model_ms / 1e9, "peak": 157.3, "unit": "TFLOP/s", "frac": step / model_ms / 1e9 / 157.3},
             "convolutions": impl, "layers_2d_on_libadvengine": _choice_summary(), "rois_per_image": rois,
-            **_executed(step, wino_equiv, step - wino_equiv * (1.0 - 1.0 / 2.25), model_ms),
+            **_executed(step, wino_equiv + wino4_equiv, step - wino_equiv * (1.0 - 1.0 / 2.25) - wino4_equiv * 0.75, model_ms),
             "backbone_in_hip_graphs": bool(graph_backbone), "detector_fwd_bwd_ms_all_eager": eager_ms, "peak_hbm_gib": peak, "hip_graph": hip_graph,
             "host_read_backs_per_step": 0 if model._static_ok(x) else "several (compacting forward)",
             "loss_first_iter": first, "loss_last_iter": last, "loss_rose": last > first,
