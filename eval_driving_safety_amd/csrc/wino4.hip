@@ -38,20 +38,22 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void lds_void;
 
 constexpr int kKC = 4;        // "channels" q per stage
-constexpr int kCO = 64;       // output channels per workgroup
 
-// PR x PC = 32 patches of 4 x 4 outputs per workgroup; LWP: floats per LDS row of the input tile (>= 4 PC + 8, padded against bank conflicts)
-template <int PR, int PC, int LWP>
+// PR x PC patches of 4 x 4 outputs per workgroup, CB blocks of 32 output channels: 32 patches x 64 channels (CB = 2) or 64 patches x 32
+// channels (CB = 1: layers of 32 output channels or an odd number of 32-channel blocks); LWP: floats per LDS row of the input tile
+template <int PR, int PC, int LWP, int CB>
 struct W4Geo {
-  static_assert(PR * PC == 32, "32 patches per workgroup");
+  static constexpr int kPB = 2 / CB, kNP = 32 * kPB, kCO = 32 * CB;   // patch blocks per wave tile, patches and output channels per workgroup
+  static_assert((CB == 1 || CB == 2) && PR * PC == kNP, "32 patches x 64 channels or 64 patches x 32 channels per workgroup");
   static constexpr int kRows = 4 * PR + 2, kLW = 4 * PC + 8;      // input rows; loaded columns gw = w0 - 4 .. w0 + 4 PC + 3 (whole aligned float4 groups)
   static_assert(LWP >= kLW && LWP % 4 == 0, "row pitch");
   static constexpr int kSX = kKC * kRows * LWP;                   // floats per input-tile buffer
   static constexpr int kXN = kKC * kRows * (kLW / 4);             // float4 groups per stage
   static constexpr int kXSl = (kXN + 511) / 512;
-  static constexpr int kSW = 36 * kKC * kCO, kSV = 36 * kKC * 32;
+  static constexpr int kSW = 36 * kKC * kCO, kSV = 36 * kKC * kNP;
+  static constexpr int kPairs = kKC * kNP;                        // (q, patch) pairs of the input transform per stage: two threads each
   static constexpr size_t kLds = 2 * sizeof(float) * (kSX + kSW + kSV);
-  static_assert(kLds >= sizeof(float) * 36 * 16 * 32, "the exchange buffer of the epilogue fits");
+  static_assert(kLds >= sizeof(float) * 36 * 16 * kNP && kLds <= 160 * 1024, "the exchange buffer of the epilogue fits; the CU's LDS holds the workgroup");
 };
 
 struct Epi4 {
@@ -80,24 +82,25 @@ __device__ __forceinline__ void at6(float m0, float m1, float m2, float m3, floa
   y[3] = __builtin_fmaf(8.0f, e, b) + m5;
 }
 
-template <int PR, int PC, int LWP, bool DEPTH>
+template <int PR, int PC, int LWP, int CB, bool DEPTH>
 __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x, const float* __restrict__ wp, float* __restrict__ y, int Cin, int Cout,
                                                      int cinpad, int copad, int D, int H, int W, int tiles_w, long long wbytes, Epi4 epi) {
-  using G = W4Geo<PR, PC, LWP>;
+  using G = W4Geo<PR, PC, LWP, CB>;
+  constexpr int PB = G::kPB, NPT = G::kNP, CO = G::kCO;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l32 = lane & 31, half = lane >> 5;
   const int wt = blockIdx.x % tiles_w, ht = blockIdx.x / tiles_w;
-  const int w0 = wt * 4 * PC, h0 = ht * 4 * PR, co0 = blockIdx.y * kCO;
+  const int w0 = wt * 4 * PC, h0 = ht * 4 * PR, co0 = blockIdx.y * CO;
   const long long b = DEPTH ? blockIdx.z / D : blockIdx.z;
   const int od = DEPTH ? static_cast<int>(blockIdx.z % D) : 0;
   const long long HW = static_cast<long long>(H) * W;
   const long long DHW = HW * D;
 
   float* const sxb = lds;                          // [2][KC][rows][LWP]   input tiles
-  float* const swb = lds + 2 * G::kSX;             // [2][36][KC][64]      U of the stage
-  float* const svb = swb + 2 * G::kSW;             // [2][36][KC][32]      V of the stage
+  float* const swb = lds + 2 * G::kSX;             // [2][36][KC][CO]      U of the stage
+  float* const svb = swb + 2 * G::kSW;             // [2][36][KC][NPT]     V of the stage
 
   // ---- addressing: buffer loads, one 32-bit byte offset per slot computed once per tile, the hardware's range check = zero padding
   const float* const xb = x + b * Cin * DHW;
@@ -136,24 +139,26 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
     for (int e = 0; e < 4; ++e) v[e] = (m >> e) & 1u ? v[e] : 0.0f;
     if (m & 16u) *reinterpret_cast<v4f*>(sxb + buf * G::kSX + xls[i]) = v;
   };
-  // The 36 positions are dealt to the eight waves so that the two waves of a SIMD carry nine between them: waves 0-3 (which also compute
-  // the input transform) own four each, k = w + 4 n (positions 0-15); waves 4-7 own five each, k = 12 + w + 4 n (positions 16-35).
+  // The 36 positions are dealt to the eight waves so that the two waves of a SIMD carry nine between them: waves 0-3 own four each,
+  // k = w + 4 n (positions 0-15); waves 4-7 own five each, k = 12 + w + 4 n (positions 16-35).
   const int kbase = wave < 4 ? wave : 12 + wave;
-  // weights: a wave stages the positions it multiplies itself: U[k][q0 .. q0 + 3][co0 .. co0 + 63] = 1 KiB, one LDS-DMA instruction
-  // (lane L: row L >> 4, float4 L & 15), straight into the stage buffer - no staging registers, no commit, no other wave involved
+  // weights: a wave stages the positions it multiplies itself: U[k][q0 .. q0 + 3][co0 .. co0 + CO - 1] = 1 KiB (CO = 64) or 512 B, one
+  // LDS-DMA instruction (lane L: row L / (CO / 4), float4 L % (CO / 4); the upper half of the wave idle at CO = 32), straight into the
+  // stage buffer - no staging registers, no commit, no other wave involved
   const int wrows = DEPTH ? 3 * cinpad : cinpad;           // rows of U per transform position
-  const int wvo = ((lane >> 4) * copad + co0 + 4 * (lane & 15)) * 4;
+  const int wvo = ((lane / (CO / 4)) * copad + co0 + 4 * (lane % (CO / 4))) * 4;
   auto dma_w1 = [&](int n, int q0, int buf) {
     const int k = kbase + 4 * n;
-    float* dst = swb + buf * G::kSW + k * (kKC * kCO);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rwgt, (lds_void*)dst, 16, wvo, (k * wrows + q0) * copad * 4, 0, 0);
+    float* dst = swb + buf * G::kSW + k * (kKC * CO);
+    if (CB == 2 || lane < 32) __builtin_amdgcn_raw_ptr_buffer_load_lds(rwgt, (lds_void*)dst, 16, wvo, (k * wrows + q0) * copad * 4, 0, 0);
   };
 
-  // ---- the input transform (waves 0-3): thread -> (q = pair >> 5, patch = pair & 31), pair = tid & 127; waves 0, 1 compute rows 0-2 of V, waves 2, 3 rows 3-5
-  const int pair = tid & 127, tc = pair >> 5, tp = pair & 31;
-  const int hs = (wave >> 1) & 1;
+  // ---- the input transform: two threads per (q, patch) pair, three of the six rows of V each (hs = 0: rows 0-2, 1: rows 3-5).
+  // CB = 2 (128 pairs): waves 0, 1 / 2, 3; waves 4-7 do not transform (they carry five positions).  CB = 1 (256 pairs): waves 0-3 / 4-7.
+  const int pair = tid % G::kPairs, tc = pair / NPT, tp = pair % NPT;
+  const int hs = CB == 2 ? (wave >> 1) & 1 : wave >> 2;
   const int toff = (tc * G::kRows + 4 * (tp / PC) + hs) * LWP + 4 * (tp % PC) + 3;     // first needed row: 0 (rows 0-4) or 1 (rows 1-5)
-  const int voff = tc * 32 + tp;
+  const int voff = tc * NPT + tp;
   float td[5][6], tt[3][6], tv[18];
   auto tr_read = [&](int i, int buf) {
     const float* p = sxb + buf * G::kSX + toff + i * LWP;
@@ -183,33 +188,33 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
   };
   auto tr_write = [&](int idx, int buf) {
     const int k = (3 * hs + idx / 6) * 6 + idx % 6;
-    svb[buf * G::kSV + k * (kKC * 32) + voff] = tv[idx];
+    svb[buf * G::kSV + k * (kKC * NPT) + voff] = tv[idx];
   };
 
-  // ---- operands of the matrix instructions: A = U_k[q = 2 kp + half][co = 32 cb + l32], B = V_k[q][patch = l32]
-  const int aoff = (kbase * kKC + half) * kCO + l32, boff = (kbase * kKC + half) * 32 + l32;
+  // ---- operands of the matrix instructions: A = U_k[q = 2 kp + half][co = 32 cb + l32], B = V_k[q][patch = 32 pb + l32]
+  const int aoff = (kbase * kKC + half) * CO + l32, boff = (kbase * kKC + half) * NPT + l32;
 
   const int q_lo = DEPTH ? (od == 0 ? cinpad : 0) : 0;
   const int q_hi = DEPTH ? (od == D - 1 ? 2 * cinpad : 3 * cinpad) : cinpad;
   const int nstage = (q_hi - q_lo) / kKC;
   auto qclamp = [&](int q) { return q < q_hi - kKC ? q : q_hi - kKC; };
 
-  // epilogue geometry (every thread: one (channel of the round's 16, patch) item per round)
+  // epilogue geometry: the exchange rounds hand every thread (channel of the round's 16, patch) items - one at 32 patches, two at 64
   const long long MP = static_cast<long long>(Cout) * DHW;
   const long long plane0 = static_cast<long long>(od) * HW;
   float* const yb = y + b * MP + plane0;
   const float* const resb = epi.residual ? epi.residual + b * MP + plane0 : nullptr;
   const float* const maskb = epi.mask ? epi.mask + b * MP + plane0 : nullptr;
   const bool vec4 = (W & 3) == 0 && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(epi.residual) | reinterpret_cast<uintptr_t>(epi.mask)) & 15) == 0;
-  const int ep = tid & 31, eg = tid >> 5;
+  const int ep = tid % NPT, eg = tid / NPT;               // patch; first channel of the round's 16 (then + 512 / NPT)
   const int gh0 = h0 + 4 * (ep / PC), gw0 = w0 + 4 * (ep % PC);
 
-  // body<NP, T, HS>: a wave's whole life after the set-up - NP positions; T: it also computes the input transform (half HS of it)
+  // body<NP, TR, HS>: a wave's whole life after the set-up - NP positions; TR: it also computes the input transform (half HS of it)
   auto body = [&](auto np_c, auto t_c, auto hs_c) __attribute__((always_inline)) {
     constexpr int NP = decltype(np_c)::value;
     constexpr bool TR = decltype(t_c)::value;
     constexpr int NS = 2 * NP;                    // steps per stage: (position n, q pair kp), two matrix instructions each
-    f32x16 acc[NP][2];
+    f32x16 acc[NP][2];                            // [n][cb] (CB = 2) or [n][pb] (CB = 1)
 #pragma unroll
     for (int n = 0; n < NP; ++n)
 #pragma unroll
@@ -245,21 +250,21 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
       }
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
-    // Stage st: NS steps of two matrix instructions each (the two channel blocks, one B operand) on U / V of stage st.  Woven between
-    // them, one piece per step: the LDS-DMA of the wave's weights of stage st + 1, the loads of the input tile of stage st + 3, the commit
-    // of the input tile of stage st + 2 (requested during stage st - 1) and - waves 0-3, eight steps - the input transform of stage st + 1.
-    // The scheduler may not move anything across a step.  ONE barrier per stage; before it the wave's LDS-DMAs have landed (vmcnt: all
-    // but the stage's own input loads, which are issued after them and travel on).
+    // Stage st: NS steps of two matrix instructions each (two channel blocks sharing the B operand, or two patch blocks sharing the A
+    // operand) on U / V of stage st.  Woven between them, one piece per step: the LDS-DMA of the wave's weights of stage st + 1, the loads
+    // of the input tile of stage st + 3, the commit of the input tile of stage st + 2 (requested during stage st - 1) and - transform
+    // waves, eight steps - the input transform of stage st + 1.  The scheduler may not move anything across a step.  ONE barrier per stage;
+    // before it the wave's LDS-DMAs have landed (vmcnt: all but the stage's own input loads, issued after them, which travel on).
     auto stage = [&](int st, XSet& fxs, const XSet& cxs) __attribute__((always_inline)) {
       constexpr int kAhead = 3;
-      float ra0[NS], ra1[NS], rb[NS];
+      float r0[NS], r1[NS], r2[NS];               // CB = 2: A (block 0), A (block 1), B;  CB = 1: A, B (block 0), B (block 1)
       const float* ap = swb + (st & 1) * G::kSW + aoff;
       const float* bp = svb + (st & 1) * G::kSV + boff;
       auto load = [&](int t) {
         const int row = (4 * (t >> 1)) * kKC + 2 * (t & 1);      // (k - kbase) * KC + 2 kp
-        ra0[t] = ap[row * kCO];
-        ra1[t] = ap[row * kCO + 32];
-        rb[t] = bp[row * 32];
+        r0[t] = ap[row * CO];
+        r1[t] = CB == 2 ? ap[row * CO + 32] : bp[row * NPT];
+        r2[t] = CB == 2 ? bp[row * NPT] : bp[row * NPT + 32];
       };
       const int nb = (st + 1) & 1;
       const int q1 = qclamp(q_lo + (st + 1) * kKC), q3 = qclamp(q_lo + (st + 3) * kKC);
@@ -278,7 +283,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
           if (t == 3) tr_cols(hs_c, 3), tr_cols(hs_c, 4), tr_cols(hs_c, 5);
           if (t == 4) tr_row(0), tr_row(1);
           if (t == 5) tr_row(2);
-          if (t >= 4) {
+          if (t >= 4 && t < 8) {
             constexpr int kPer[4] = {3, 5, 5, 5};       // 18 writes over steps 4-7
             int first = 0;
 #pragma unroll
@@ -287,8 +292,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
             for (int u = 0; u < kPer[t - 4]; ++u) tr_write(first + u, nb);
           }
         }
-        acc[t >> 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra0[t], rb[t], acc[t >> 1][0], 0, 0, 0);
-        acc[t >> 1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra1[t], rb[t], acc[t >> 1][1], 0, 0, 0);
+        if constexpr (CB == 2) {
+          acc[t >> 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(r0[t], r2[t], acc[t >> 1][0], 0, 0, 0);
+          acc[t >> 1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(r1[t], r2[t], acc[t >> 1][1], 0, 0, 0);
+        } else {
+          acc[t >> 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(r0[t], r1[t], acc[t >> 1][0], 0, 0, 0);
+          acc[t >> 1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(r0[t], r2[t], acc[t >> 1][1], 0, 0, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
       // the stage's LDS-DMAs have landed (issued before its input loads, which travel on: the counter retires in order), the LDS writes
@@ -309,29 +319,33 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
     // E[k][co16][patch]; register v of a 32 x 32 accumulator = channel (v & 3) + 8 (v >> 2) + 4 half of its block, patch = lane & 31
     float* const se = lds;
 #pragma unroll
-    for (int round = 0; round < 4; ++round) {               // (unrolled: the accumulator registers are addressed by constants)
+    for (int round = 0; round < 2 * CB; ++round) {          // (unrolled: the accumulator registers are addressed by constants)
       if (co0 + 16 * round >= Cout) continue;               // (workgroup-uniform) nothing but padding from here on
-      constexpr int kDummy = 0;
-      (void)kDummy;
 #pragma unroll
       for (int n = 0; n < NP; ++n) {
         const int k = kbase + 4 * n;
 #pragma unroll
         for (int v8 = 0; v8 < 8; ++v8) {
           const int co16 = (v8 & 3) + 8 * (v8 >> 2) + 4 * half;
-          se[(k * 16 + co16) * 32 + l32] = acc[n][round >> 1][8 * (round & 1) + v8];
+          if constexpr (CB == 2) {
+            se[(k * 16 + co16) * NPT + l32] = acc[n][round >> 1][8 * (round & 1) + v8];
+          } else {
+            se[(k * 16 + co16) * NPT + l32] = acc[n][0][8 * round + v8];
+            se[(k * 16 + co16) * NPT + 32 + l32] = acc[n][1][8 * round + v8];
+          }
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      {
-        const int co16 = eg;
+#pragma unroll
+      for (int item = 0; item < PB; ++item) {
+        const int co16 = eg + (512 / NPT) * item;
         const int co = co0 + 16 * round + co16;
         float s[4][6], o[4][4];
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
           float col[4];
-          at6(se[((0 * 6 + j) * 16 + co16) * 32 + ep], se[((1 * 6 + j) * 16 + co16) * 32 + ep], se[((2 * 6 + j) * 16 + co16) * 32 + ep],
-              se[((3 * 6 + j) * 16 + co16) * 32 + ep], se[((4 * 6 + j) * 16 + co16) * 32 + ep], se[((5 * 6 + j) * 16 + co16) * 32 + ep], col);
+          at6(se[((0 * 6 + j) * 16 + co16) * NPT + ep], se[((1 * 6 + j) * 16 + co16) * NPT + ep], se[((2 * 6 + j) * 16 + co16) * NPT + ep],
+              se[((3 * 6 + j) * 16 + co16) * NPT + ep], se[((4 * 6 + j) * 16 + co16) * NPT + ep], se[((5 * 6 + j) * 16 + co16) * NPT + ep], col);
 #pragma unroll
           for (int r = 0; r < 4; ++r) s[r][j] = col[r];
         }
@@ -387,33 +401,41 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
   };
   using I4 = std::integral_constant<int, 4>;
   using I5 = std::integral_constant<int, 5>;
-  if (wave >= 4) body(I5{}, std::false_type{}, std::false_type{});
-  else if (hs) body(I4{}, std::true_type{}, std::true_type{});
-  else body(I4{}, std::true_type{}, std::false_type{});
+  if constexpr (CB == 2) {
+    if (wave >= 4) body(I5{}, std::false_type{}, std::false_type{});
+    else if (hs) body(I4{}, std::true_type{}, std::true_type{});
+    else body(I4{}, std::true_type{}, std::false_type{});
+  } else {
+    if (wave >= 4) body(I5{}, std::true_type{}, std::true_type{});
+    else body(I4{}, std::true_type{}, std::false_type{});
+  }
 }
 
 int round_up4(int v, int q) { return (v + q - 1) / q * q; }
 
-template <int PR, int PC, int LWP, bool DEPTH>
+template <int PR, int PC, int LWP, int CB, bool DEPTH>
 int launch_wino4(const float* x, const float* wp, float* y, int b, int cin, int cout, int cinpad, int copad, int d, int h, int w, const Epi4& epi,
                  hipStream_t st) {
-  using G = W4Geo<PR, PC, LWP>;
+  using G = W4Geo<PR, PC, LWP, CB>;
   const int tiles_w = (w + 4 * PC - 1) / (4 * PC), tiles_h = (h + 4 * PR - 1) / (4 * PR);
   const long long tiles = static_cast<long long>(tiles_w) * tiles_h;
-  const int cgroups = (cout + kCO - 1) / kCO;
+  const int cgroups = (cout + G::kCO - 1) / G::kCO;
   const long long gz = static_cast<long long>(b) * d;
   if (tiles > 0x7fffffffLL || cgroups > 65535 || gz > 65535) return ADV_EINVAL;
   const long long wbytes = 36LL * (DEPTH ? 3 : 1) * cinpad * copad * 4;
   if ((static_cast<long long>(cinpad) + 1) * d * h * w * 4 >= 0xfff00000LL || wbytes >= 0x7ff00000LL) return ADV_EINVAL;
   const dim3 grid(static_cast<unsigned>(tiles), cgroups, static_cast<unsigned>(gz));
-  if (!adv_internal_lds_limit<conv_wino4<PR, PC, LWP, DEPTH>>(G::kLds)) return ADV_ELAUNCH;
-  hipLaunchKernelGGL((conv_wino4<PR, PC, LWP, DEPTH>), grid, dim3(512), G::kLds, st, x, wp, y, cin, cout, cinpad, copad, d, h, w, tiles_w, wbytes, epi);
+  if (!adv_internal_lds_limit<conv_wino4<PR, PC, LWP, CB, DEPTH>>(G::kLds)) return ADV_ELAUNCH;
+  hipLaunchKernelGGL((conv_wino4<PR, PC, LWP, CB, DEPTH>), grid, dim3(512), G::kLds, st, x, wp, y, cin, cout, cinpad, copad, d, h, w, tiles_w, wbytes, epi);
   return adv_internal_finish_launch();
 }
 
-// tile: 0 = 16 x 32 outputs (4 x 8 patches), 1 = 8 x 64 outputs (2 x 16 patches: maps of few rows)
-int pick_wino4_tile(int h, int w) {
+// tile: 0 = 16 x 32 outputs x 64 channels (4 x 8 patches), 1 = 8 x 64 x 64 (2 x 16 patches: maps of few rows), 2 = 32 x 32 outputs x 32
+// channels (8 x 8 patches), 3 = 16 x 64 x 32 (4 x 16 patches).  The 32-channel shapes where 64 channels would compute a block of padding
+// (an odd number of 32-channel blocks); the flat shapes where they need clearly fewer workgroups for the map.
+int pick_wino4_tile(int cout, int h, int w) {
   auto tiles = [&](int th, int tw) { return static_cast<long long>((h + th - 1) / th) * ((w + tw - 1) / tw); };
+  if (((cout + 31) / 32) % 2 == 1) return tiles(16, 64) * 21 < tiles(32, 32) * 20 ? 3 : 2;
   return tiles(8, 64) * 21 < tiles(16, 32) * 20 ? 1 : 0;
 }
 
@@ -421,8 +443,10 @@ template <bool DEPTH>
 int launch_wino4_tile(int t, const float* x, const float* wp, float* y, int b, int cin, int cout, int cinpad, int copad, int d, int h, int w,
                       const Epi4& epi, hipStream_t st) {
   switch (t) {
-    case 0: return launch_wino4<4, 8, 40, DEPTH>(x, wp, y, b, cin, cout, cinpad, copad, d, h, w, epi, st);
-    default: return launch_wino4<2, 16, 72, DEPTH>(x, wp, y, b, cin, cout, cinpad, copad, d, h, w, epi, st);
+    case 0: return launch_wino4<4, 8, 40, 2, DEPTH>(x, wp, y, b, cin, cout, cinpad, copad, d, h, w, epi, st);
+    case 1: return launch_wino4<2, 16, 80, 2, DEPTH>(x, wp, y, b, cin, cout, cinpad, copad, d, h, w, epi, st);
+    case 2: return launch_wino4<8, 8, 40, 1, DEPTH>(x, wp, y, b, cin, cout, cinpad, copad, d, h, w, epi, st);
+    default: return launch_wino4<4, 16, 80, 1, DEPTH>(x, wp, y, b, cin, cout, cinpad, copad, d, h, w, epi, st);
   }
 }
 
@@ -434,6 +458,8 @@ int check_wino4_args(const float* x, const float* w_prep, const float* bias, con
     return ADV_EALIGN;
   return ADV_OK;
 }
+
+constexpr int kCO = 64;       // the prepared weights are padded to multiples of 64 output channels (both workgroup shapes read them)
 
 // U = G g G^T (6 x 6) for every (output, input) channel pair (and depth tap), laid out [k = 6 i + j][kd][c'][m'] (zero rows / columns of
 // padding).  forward: m = co, c = ci, g = w[co][ci][kd];  transpose (backward w.r.t. the input): m = ci, c = co, g = w[co][ci] with all
@@ -510,10 +536,10 @@ int adv_conv2d_wino4_prep_weights_f32(const float* w, float* w_prep, int cout, i
 
 int adv_conv2d_wino4_f32(const float* x, const float* w_prep, const float* bias, const float* residual, const float* mask, float* y, int b, int cin,
                          int cout, int h, int w, int relu, int tile, adv_stream_t stream) {
-  if (!x || !w_prep || !y || b < 1 || cin < 1 || cout < 1 || h < 1 || w < 1 || tile < -1 || tile > 1) return ADV_EINVAL;
+  if (!x || !w_prep || !y || b < 1 || cin < 1 || cout < 1 || h < 1 || w < 1 || tile < -1 || tile > 3) return ADV_EINVAL;
   if (const int rc = check_wino4_args(x, w_prep, bias, residual, mask, y)) return rc;
   const Epi4 epi{bias, residual, mask, relu ? 1 : 0};
-  return launch_wino4_tile<false>(tile >= 0 ? tile : pick_wino4_tile(h, w), x, w_prep, y, b, cin, cout, round_up4(cin, kKC), round_up4(cout, kCO), 1, h, w,
+  return launch_wino4_tile<false>(tile >= 0 ? tile : pick_wino4_tile(cout, h, w), x, w_prep, y, b, cin, cout, round_up4(cin, kKC), round_up4(cout, kCO), 1, h, w,
                                   epi, static_cast<hipStream_t>(stream));
 }
 
@@ -529,10 +555,10 @@ int adv_conv3d_wino4_prep_weights_f32(const float* w, float* w_prep, int cout, i
 
 int adv_conv3d_wino4_f32(const float* x, const float* w_prep, const float* bias, const float* residual, const float* mask, float* y, int b, int cin,
                          int cout, int d, int h, int w, int relu, int tile, adv_stream_t stream) {
-  if (!x || !w_prep || !y || b < 1 || cin < 1 || cout < 1 || d < 1 || h < 1 || w < 1 || tile < -1 || tile > 1) return ADV_EINVAL;
+  if (!x || !w_prep || !y || b < 1 || cin < 1 || cout < 1 || d < 1 || h < 1 || w < 1 || tile < -1 || tile > 3) return ADV_EINVAL;
   if (const int rc = check_wino4_args(x, w_prep, bias, residual, mask, y)) return rc;
   const Epi4 epi{bias, residual, mask, relu ? 1 : 0};
-  return launch_wino4_tile<true>(tile >= 0 ? tile : pick_wino4_tile(h, w), x, w_prep, y, b, cin, cout, round_up4(cin, kKC), round_up4(cout, kCO), d, h, w,
+  return launch_wino4_tile<true>(tile >= 0 ? tile : pick_wino4_tile(cout, h, w), x, w_prep, y, b, cin, cout, round_up4(cin, kKC), round_up4(cout, kCO), d, h, w,
                                  epi, static_cast<hipStream_t>(stream));
 }
 

@@ -54,7 +54,7 @@ def test_hip_conv2d_wino4_bit_exact_vs_oracle(case):
     mask = (rs.rand(b, cout, h, w) > 0.3).astype(np.float32)
     prep = ops.ConvWino4Prep(torch.tensor(wt, device=dev))
     tx, tb, tr, tm = (torch.tensor(a, device=dev) for a in (x, bias, res, mask))
-    for tile in (0, 1, -1):
+    for tile in (0, 1, 2, 3, -1):
         y = ops.conv_wino4(tx, prep, tile=tile).cpu().numpy()
         want = oracle_c.conv_wino4(x, wt)
         assert y.tobytes() == want.tobytes(), (case, tile, float(np.abs(y - want).max()))
@@ -82,7 +82,7 @@ def test_hip_conv3d_wino4_bit_exact_vs_oracle(case):
     res = rs.randn(b, cout, d, h, w).astype(np.float32)
     prep = ops.ConvWino4Prep(torch.tensor(wt, device=dev))
     tx = torch.tensor(x, device=dev)
-    for tile in (0, 1):
+    for tile in (0, 1, 2, 3):
         y = ops.conv_wino4(tx, prep, torch.tensor(bias, device=dev), torch.tensor(res, device=dev), True, tile=tile).cpu().numpy()
         want = oracle_c.conv_wino4(x, wt, bias, res, relu=True)
         assert y.tobytes() == want.tobytes(), (case, tile, float(np.abs(y - want).max()))

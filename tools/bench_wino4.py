@@ -27,7 +27,7 @@ def main():
         p2, p4 = ops.Conv2dPrep(wt, 1, 1, 1), ops.ConvWino4Prep(wt)
         flops = 2.0 * b * cout * cin * 9 * h * w
         m2 = timed(lambda: ops.conv2d(x, p2, bias, None, True, wino=True))
-        m4 = {t: round(timed(lambda t=t: ops.conv_wino4(x, p4, bias, None, True, tile=t)), 4) for t in (0, 1)}
+        m4 = {t: round(timed(lambda t=t: ops.conv_wino4(x, p4, bias, None, True, tile=t)), 4) for t in (0, 1, 2, 3)}
         err = float((ops.conv_wino4(x, p4, bias, None, True) - ops.conv2d(x, p2, bias, None, True, wino=True)).abs().max())
         print(json.dumps({"layer": "%d->%d on [%d,%d,%d,%d]" % (cin, cout, b, cin, h, w), "wino2_ms": round(m2, 4), "wino4_ms_by_tile": m4,
                           "wino2_tflops": round(flops / m2 / 1e9, 1), "wino4_tflops": round(flops / min(m4.values()) / 1e9, 1),
@@ -38,7 +38,7 @@ def main():
         p2, p4 = ops.Conv3dWinoPrep(wt), ops.ConvWino4Prep(wt)
         flops = 2.0 * cout * cin * 27 * d * h * w
         m2 = timed(lambda: ops.conv3d_wino(x, p2, None, relu=True))
-        m4 = {t: round(timed(lambda t=t: ops.conv_wino4(x, p4, None, None, True, tile=t)), 4) for t in (0, 1)}
+        m4 = {t: round(timed(lambda t=t: ops.conv_wino4(x, p4, None, None, True, tile=t)), 4) for t in (0, 1, 2, 3)}
         print(json.dumps({"layer": "3D %d->%d on [%d,%d,%d]" % (cin, cout, d, h, w), "wino2_ms": round(m2, 4), "wino4_ms_by_tile": m4,
                           "wino2_tflops": round(flops / m2 / 1e9, 1), "wino4_tflops": round(flops / min(m4.values()) / 1e9, 1),
                           "speedup": round(m2 / min(m4.values()), 3)}), flush=True)
