@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 #include <type_traits>
 
 #include "adv_internal.h"
@@ -34,10 +35,12 @@
 namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void lds_void;
 
 constexpr int kKC = 4;        // "channels" q per stage
+constexpr int kTransformWavePositions = 3;      // 64-channel workgroups: positions carried by each of the four transform waves (the others: 9 - this)
 
 // PR x PC patches of 4 x 4 outputs per workgroup, CB blocks of 32 output channels: 32 patches x 64 channels (CB = 2) or 64 patches x 32
 // channels (CB = 1: layers of 32 output channels or an odd number of 32-channel blocks); LWP: floats per LDS row of the input tile
@@ -46,7 +49,7 @@ struct W4Geo {
   static constexpr int kPB = 2 / CB, kNP = 32 * kPB, kCO = 32 * CB;   // patch blocks per wave tile, patches and output channels per workgroup
   static_assert((CB == 1 || CB == 2) && PR * PC == kNP, "32 patches x 64 channels or 64 patches x 32 channels per workgroup");
   static constexpr int kRows = 4 * PR + 2, kLW = 4 * PC + 8;      // input rows; loaded columns gw = w0 - 4 .. w0 + 4 PC + 3 (whole aligned float4 groups)
-  static_assert(LWP >= kLW && LWP % 4 == 0, "row pitch");
+  static_assert(LWP >= kLW + 4 && LWP % 4 == 0, "row pitch (the tile sits one column to the right of the row's start)");
   static constexpr int kSX = kKC * kRows * LWP;                   // floats per input-tile buffer
   static constexpr int kXN = kKC * kRows * (kLW / 4);             // float4 groups per stage
   static constexpr int kXSl = (kXN + 511) / 512;
@@ -82,11 +85,15 @@ __device__ __forceinline__ void at6(float m0, float m1, float m2, float m3, floa
   y[3] = __builtin_fmaf(8.0f, e, b) + m5;
 }
 
-template <int PR, int PC, int LWP, int CB, bool DEPTH>
+// ABL: phase ablation for timing (compile-time, so the schedule of the rest is the shipped one; results are wrong): bit 0 input transform,
+// 1 matrix instructions, 2 input loads, 3 input commits, 4 the stage's wait + barrier, 5 operand reads, 6 weight DMA.
+// The -DADV_TEST_HOOKS build's probe instantiates non-zero values, the shipped kernels are ABL = 0.
+template <int PR, int PC, int LWP, int CB, bool DEPTH, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x, const float* __restrict__ wp, float* __restrict__ y, int Cin, int Cout,
                                                      int cinpad, int copad, int D, int H, int W, int tiles_w, long long wbytes, Epi4 epi) {
   using G = W4Geo<PR, PC, LWP, CB>;
   constexpr int PB = G::kPB, NPT = G::kNP, CO = G::kCO;
+  constexpr int dbg = ABL;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -114,7 +121,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
     const int j = sidx % (G::kLW / 4), r = (sidx / (G::kLW / 4)) % G::kRows, c = sidx / ((G::kLW / 4) * G::kRows);
     const int gh = h0 - 1 + r, gw = w0 - 4 + 4 * j;          // groups start on multiples of four columns: none straddles the row's start
     xvo[i] = static_cast<int>(static_cast<unsigned>(c < kKC ? c : kKC - 1) * static_cast<unsigned>(DHW) * 4u) + (gh * W + gw) * 4;
-    xls[i] = ((c < kKC ? c : kKC - 1) * G::kRows + r) * LWP + 4 * j;
+    xls[i] = ((c < kKC ? c : kKC - 1) * G::kRows + r) * LWP + 4 * j + 1;    // LDS column = gw - (w0 - 5): a patch's six columns start on a multiple of four
     unsigned vm = 0;
     if (sidx < G::kXN && gh >= 0 && gh < H)
 #pragma unroll
@@ -137,11 +144,19 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
     const unsigned m = xvm[i];
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = (m >> e) & 1u ? v[e] : 0.0f;
-    if (m & 16u) *reinterpret_cast<v4f*>(sxb + buf * G::kSX + xls[i]) = v;
+    if (m & 16u) {        // the group lands one column off a 16-byte boundary (so that the transform reads whole aligned pieces): 4 + 8 + 4 bytes
+      float* p = sxb + buf * G::kSX + xls[i];
+      p[0] = v[0];
+      *reinterpret_cast<v2f*>(p + 1) = v2f{v[1], v[2]};
+      p[3] = v[3];
+    }
   };
-  // The 36 positions are dealt to the eight waves so that the two waves of a SIMD carry nine between them: waves 0-3 own four each,
-  // k = w + 4 n (positions 0-15); waves 4-7 own five each, k = 12 + w + 4 n (positions 16-35).
-  const int kbase = wave < 4 ? wave : 12 + wave;
+  // The 36 positions are dealt to the eight waves so that the two waves of a SIMD carry nine between them: waves 0-3 own NT each,
+  // k = w + 4 n; waves 4-7 own 9 - NT each, k = 4 NT + (w - 4) + 4 n.  64-channel workgroups: NT = 3 / 6 - waves 0-3 also compute the whole
+  // input transform, and a wave issues in order: its side work must fit in the shadow of ITS matrix instructions or the pipe waits for it
+  // (4 / 5 measured 4-7 % slower); 32-channel workgroups: every wave transforms, 4 / 5.
+  constexpr int NT = CB == 2 ? kTransformWavePositions : 4;      // positions of a wave 0-3 (waves 4-7: 9 - NT)
+  const int kbase = wave < 4 ? wave : 4 * NT - 4 + wave;
   // weights: a wave stages the positions it multiplies itself: U[k][q0 .. q0 + 3][co0 .. co0 + CO - 1] = 1 KiB (CO = 64) or 512 B, one
   // LDS-DMA instruction (lane L: row L / (CO / 4), float4 L % (CO / 4); the upper half of the wave idle at CO = 32), straight into the
   // stage buffer - no staging registers, no commit, no other wave involved
@@ -157,15 +172,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
   // CB = 2 (128 pairs): waves 0, 1 / 2, 3; waves 4-7 do not transform (they carry five positions).  CB = 1 (256 pairs): waves 0-3 / 4-7.
   const int pair = tid % G::kPairs, tc = pair / NPT, tp = pair % NPT;
   const int hs = CB == 2 ? (wave >> 1) & 1 : wave >> 2;
-  const int toff = (tc * G::kRows + 4 * (tp / PC) + hs) * LWP + 4 * (tp % PC) + 3;     // first needed row: 0 (rows 0-4) or 1 (rows 1-5)
+  const int toff = (tc * G::kRows + 4 * (tp / PC) + hs) * LWP + 4 * (tp % PC) + 4;     // first needed row: 0 (rows 0-4) or 1 (rows 1-5)
   const int voff = tc * NPT + tp;
   float td[5][6], tt[3][6], tv[18];
   auto tr_read = [&](int i, int buf) {
-    const float* p = sxb + buf * G::kSX + toff + i * LWP;
-    td[i][0] = p[0];
-    const v4f m = *reinterpret_cast<const v4f*>(p + 1);
-    td[i][1] = m[0], td[i][2] = m[1], td[i][3] = m[2], td[i][4] = m[3];
-    td[i][5] = p[5];
+    const float* p = sxb + buf * G::kSX + toff + i * LWP;          // six columns: one 16-byte and one 8-byte read, both aligned
+    const v4f m = *reinterpret_cast<const v4f*>(p);
+    const v2f n = *reinterpret_cast<const v2f*>(p + 4);
+    td[i][0] = m[0], td[i][1] = m[1], td[i][2] = m[2], td[i][3] = m[3], td[i][4] = n[0], td[i][5] = n[1];
   };
   auto tr_cols = [&](auto hs_c, int j) {          // column pass, column j: the thread's three rows of T = B^T d
     constexpr bool kHi = decltype(hs_c)::value;
@@ -258,6 +272,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
     auto stage = [&](int st, XSet& fxs, const XSet& cxs) __attribute__((always_inline)) {
       constexpr int kAhead = 3;
       float r0[NS], r1[NS], r2[NS];               // CB = 2: A (block 0), A (block 1), B;  CB = 1: A, B (block 0), B (block 1)
+      if constexpr ((dbg & 32) != 0) {
+#pragma unroll
+        for (int t = 0; t < NS; ++t) r0[t] = r1[t] = r2[t] = static_cast<float>(lane + t);
+      }
       const float* ap = swb + (st & 1) * G::kSW + aoff;
       const float* bp = svb + (st & 1) * G::kSV + boff;
       auto load = [&](int t) {
@@ -269,41 +287,48 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
       const int nb = (st + 1) & 1;
       const int q1 = qclamp(q_lo + (st + 1) * kKC), q3 = qclamp(q_lo + (st + 3) * kKC);
 #pragma unroll
-      for (int t = 0; t < kAhead; ++t) load(t);
+      for (int t = 0; t < kAhead; ++t)
+        if (!(dbg & 32)) load(t);
+      // HALF-steps: exactly one matrix instruction each, the side work in front of it.  A wave issues in order: with both matrix
+      // instructions of a step back to back the second waits out the first's 64 cycles with the wave stalled behind it, so only every
+      // other matrix instruction had side work in its shadow (profiles/r05_wino4_phases.jsonl: the two did not overlap at all).
+      // Schedule (transform waves): rows 0-1 | 2-3 | 4 | columns 0-1 | 2-3 | 4-5 | V row 0 | V row 1 + writes | V row 2 + writes | writes x 3,
+      // the weight DMAs on half-steps 0 .. NP-1, the input loads on 9 .., the commits on the last ones.
 #pragma unroll
-      for (int t = 0; t < NS; ++t) {
-        if (t + kAhead < NS) load(t + kAhead);
-        if (t < NP) dma_w1(t, q1, nb);
-        if (t >= NP && t < NP + G::kXSl) fetch_x1(t - NP, q3, fxs);
-        if (t >= NS - G::kXSl) commit_x1(t - (NS - G::kXSl), st & 1, cxs);
-        if constexpr (TR) {      // eight steps: rows 0-2 | rows 3-4 | columns 0-2 | columns 3-5 | V rows 0, 1 + first writes | V row 2 + writes | writes | writes
-          if (t == 0) tr_read(0, nb), tr_read(1, nb), tr_read(2, nb);
-          if (t == 1) tr_read(3, nb), tr_read(4, nb);
-          if (t == 2) tr_cols(hs_c, 0), tr_cols(hs_c, 1), tr_cols(hs_c, 2);
-          if (t == 3) tr_cols(hs_c, 3), tr_cols(hs_c, 4), tr_cols(hs_c, 5);
-          if (t == 4) tr_row(0), tr_row(1);
-          if (t == 5) tr_row(2);
-          if (t >= 4 && t < 8) {
-            constexpr int kPer[4] = {3, 5, 5, 5};       // 18 writes over steps 4-7
+      for (int h = 0; h < 2 * NS; ++h) {
+        const int t = h >> 1;
+        if ((h & 1) == 0 && t + kAhead < NS && !(dbg & 32)) load(t + kAhead);
+        if (h < NP && !(dbg & 64)) dma_w1(h, q1, nb);
+        if (h >= 9 && h < 9 + G::kXSl && !(dbg & 4)) fetch_x1(h - 9, q3, fxs);
+        if (h >= 2 * NS - 1 - G::kXSl && h < 2 * NS - 1 && !(dbg & 8)) commit_x1(h - (2 * NS - 1 - G::kXSl), st & 1, cxs);
+        if constexpr (TR && !(dbg & 1)) {
+          if (h == 0) tr_read(0, nb), tr_read(1, nb);
+          if (h == 1) tr_read(2, nb), tr_read(3, nb);
+          if (h == 2) tr_read(4, nb);
+          if (h >= 3 && h < 6) tr_cols(hs_c, 2 * (h - 3)), tr_cols(hs_c, 2 * (h - 3) + 1);
+          if (h >= 6 && h < 9) tr_row(h - 6);
+          if (h >= 7 && h < 12) {
+            constexpr int kPer[5] = {3, 3, 4, 4, 4};      // 18 writes over half-steps 7-11 (row i's values exist from half-step 6 + i on)
             int first = 0;
 #pragma unroll
-            for (int u = 4; u < t; ++u) first += kPer[u - 4];
+            for (int u = 7; u < h; ++u) first += kPer[u - 7];
 #pragma unroll
-            for (int u = 0; u < kPer[t - 4]; ++u) tr_write(first + u, nb);
+            for (int u = 0; u < kPer[h - 7]; ++u) tr_write(first + u, nb);
           }
         }
-        if constexpr (CB == 2) {
-          acc[t >> 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(r0[t], r2[t], acc[t >> 1][0], 0, 0, 0);
-          acc[t >> 1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(r1[t], r2[t], acc[t >> 1][1], 0, 0, 0);
+        if constexpr ((dbg & 2) != 0) {
+        } else if constexpr (CB == 2) {
+          if ((h & 1) == 0) acc[t >> 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(r0[t], r2[t], acc[t >> 1][0], 0, 0, 0);
+          else acc[t >> 1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(r1[t], r2[t], acc[t >> 1][1], 0, 0, 0);
         } else {
-          acc[t >> 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(r0[t], r1[t], acc[t >> 1][0], 0, 0, 0);
-          acc[t >> 1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(r0[t], r2[t], acc[t >> 1][1], 0, 0, 0);
+          if ((h & 1) == 0) acc[t >> 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(r0[t], r1[t], acc[t >> 1][0], 0, 0, 0);
+          else acc[t >> 1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(r0[t], r2[t], acc[t >> 1][1], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
       // the stage's LDS-DMAs have landed (issued before its input loads, which travel on: the counter retires in order), the LDS writes
       // are done; a plain __syncthreads() would wait for ALL memory operations - the input loads too
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(G::kXSl) : "memory");
+      if constexpr (!(dbg & 16)) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(G::kXSl) : "memory");
     };
     {
       int st = 0;
@@ -401,10 +426,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
   };
   using I4 = std::integral_constant<int, 4>;
   using I5 = std::integral_constant<int, 5>;
+  using IT = std::integral_constant<int, NT>;
+  using IP = std::integral_constant<int, 9 - NT>;
   if constexpr (CB == 2) {
-    if (wave >= 4) body(I5{}, std::false_type{}, std::false_type{});
-    else if (hs) body(I4{}, std::true_type{}, std::true_type{});
-    else body(I4{}, std::true_type{}, std::false_type{});
+    if (wave >= 4) body(IP{}, std::false_type{}, std::false_type{});
+    else if (hs) body(IT{}, std::true_type{}, std::true_type{});
+    else body(IT{}, std::true_type{}, std::false_type{});
   } else {
     if (wave >= 4) body(I5{}, std::true_type{}, std::true_type{});
     else body(I4{}, std::true_type{}, std::false_type{});
@@ -425,6 +452,22 @@ int launch_wino4(const float* x, const float* wp, float* y, int b, int cin, int 
   const long long wbytes = 36LL * (DEPTH ? 3 : 1) * cinpad * copad * 4;
   if ((static_cast<long long>(cinpad) + 1) * d * h * w * 4 >= 0xfff00000LL || wbytes >= 0x7ff00000LL) return ADV_EINVAL;
   const dim3 grid(static_cast<unsigned>(tiles), cgroups, static_cast<unsigned>(gz));
+#ifdef ADV_TEST_HOOKS
+  if (const char* dbg_s = adv_hook_value("ADV_WINO4_DBG")) {      // phase ablation for timing (results are wrong): the 8 x 64 x 64 2D shape and the 16 x 64 x 32 3D shape
+    if constexpr ((PR == 2 && PC == 16 && CB == 2 && !DEPTH) || (PR == 4 && PC == 16 && CB == 1 && DEPTH)) {
+      const int abl = std::atoi(dbg_s);
+#define ADV_WINO4_ABL(A_)                                                                                                                       \
+  if (abl == A_) {                                                                                                                              \
+    if (!adv_internal_lds_limit<conv_wino4<PR, PC, LWP, CB, DEPTH, A_>>(G::kLds)) return ADV_ELAUNCH;                                           \
+    hipLaunchKernelGGL((conv_wino4<PR, PC, LWP, CB, DEPTH, A_>), grid, dim3(512), G::kLds, st, x, wp, y, cin, cout, cinpad, copad, d, h, w, tiles_w, \
+                       wbytes, epi);                                                                                                            \
+    return adv_internal_finish_launch();                                                                                                        \
+  }
+      ADV_WINO4_ABL(1) ADV_WINO4_ABL(2) ADV_WINO4_ABL(4) ADV_WINO4_ABL(8) ADV_WINO4_ABL(16) ADV_WINO4_ABL(32) ADV_WINO4_ABL(64) ADV_WINO4_ABL(12) ADV_WINO4_ABL(93) ADV_WINO4_ABL(125) ADV_WINO4_ABL(127)
+#undef ADV_WINO4_ABL
+    }
+  }
+#endif
   if (!adv_internal_lds_limit<conv_wino4<PR, PC, LWP, CB, DEPTH>>(G::kLds)) return ADV_ELAUNCH;
   hipLaunchKernelGGL((conv_wino4<PR, PC, LWP, CB, DEPTH>), grid, dim3(512), G::kLds, st, x, wp, y, cin, cout, cinpad, copad, d, h, w, tiles_w, wbytes, epi);
   return adv_internal_finish_launch();
@@ -433,19 +476,24 @@ int launch_wino4(const float* x, const float* wp, float* y, int b, int cin, int 
 // tile: 0 = 16 x 32 outputs x 64 channels (4 x 8 patches), 1 = 8 x 64 x 64 (2 x 16 patches: maps of few rows), 2 = 32 x 32 outputs x 32
 // channels (8 x 8 patches), 3 = 16 x 64 x 32 (4 x 16 patches).  The 32-channel shapes where 64 channels would compute a block of padding
 // (an odd number of 32-channel blocks); the flat shapes where they need clearly fewer workgroups for the map.
-int pick_wino4_tile(int cout, int h, int w) {
-  auto tiles = [&](int th, int tw) { return static_cast<long long>((h + th - 1) / th) * ((w + tw - 1) / tw); };
-  if (((cout + 31) / 32) % 2 == 1) return tiles(16, 64) * 21 < tiles(32, 32) * 20 ? 3 : 2;
-  return tiles(8, 64) * 21 < tiles(16, 32) * 20 ? 1 : 0;
+int pick_wino4_tile(int cout, int h, int w, long long bz) {
+  // every shape is one workgroup per compute unit with the same work: the launch takes ceil(workgroups / 256) rounds; among equal rounds the
+  // shape with fewer workgroups (less padding), then the wide one (8 x 64 / 16 x 64: measured 2-7 % faster on large maps, profiles/r05_wino4_*.jsonl)
+  auto wgs = [&](int th, int tw, int co) { return static_cast<long long>((h + th - 1) / th) * ((w + tw - 1) / tw) * ((cout + co - 1) / co) * bz; };
+  const bool narrow = ((cout + 31) / 32) % 2 == 1;
+  const long long a = narrow ? wgs(32, 32, 32) : wgs(16, 32, 64), b = narrow ? wgs(16, 64, 32) : wgs(8, 64, 64);
+  const long long ra = (a + 255) / 256, rb = (b + 255) / 256;
+  const bool wide = rb < ra || (rb == ra && b <= a);
+  return (narrow ? 2 : 0) + (wide ? 1 : 0);
 }
 
 template <bool DEPTH>
 int launch_wino4_tile(int t, const float* x, const float* wp, float* y, int b, int cin, int cout, int cinpad, int copad, int d, int h, int w,
                       const Epi4& epi, hipStream_t st) {
   switch (t) {
-    case 0: return launch_wino4<4, 8, 40, 2, DEPTH>(x, wp, y, b, cin, cout, cinpad, copad, d, h, w, epi, st);
+    case 0: return launch_wino4<4, 8, 56, 2, DEPTH>(x, wp, y, b, cin, cout, cinpad, copad, d, h, w, epi, st);
     case 1: return launch_wino4<2, 16, 80, 2, DEPTH>(x, wp, y, b, cin, cout, cinpad, copad, d, h, w, epi, st);
-    case 2: return launch_wino4<8, 8, 40, 1, DEPTH>(x, wp, y, b, cin, cout, cinpad, copad, d, h, w, epi, st);
+    case 2: return launch_wino4<8, 8, 44, 1, DEPTH>(x, wp, y, b, cin, cout, cinpad, copad, d, h, w, epi, st);
     default: return launch_wino4<4, 16, 80, 1, DEPTH>(x, wp, y, b, cin, cout, cinpad, copad, d, h, w, epi, st);
   }
 }
@@ -539,7 +587,7 @@ int adv_conv2d_wino4_f32(const float* x, const float* w_prep, const float* bias,
   if (!x || !w_prep || !y || b < 1 || cin < 1 || cout < 1 || h < 1 || w < 1 || tile < -1 || tile > 3) return ADV_EINVAL;
   if (const int rc = check_wino4_args(x, w_prep, bias, residual, mask, y)) return rc;
   const Epi4 epi{bias, residual, mask, relu ? 1 : 0};
-  return launch_wino4_tile<false>(tile >= 0 ? tile : pick_wino4_tile(cout, h, w), x, w_prep, y, b, cin, cout, round_up4(cin, kKC), round_up4(cout, kCO), 1, h, w,
+  return launch_wino4_tile<false>(tile >= 0 ? tile : pick_wino4_tile(cout, h, w, b), x, w_prep, y, b, cin, cout, round_up4(cin, kKC), round_up4(cout, kCO), 1, h, w,
                                   epi, static_cast<hipStream_t>(stream));
 }
 
@@ -558,7 +606,7 @@ int adv_conv3d_wino4_f32(const float* x, const float* w_prep, const float* bias,
   if (!x || !w_prep || !y || b < 1 || cin < 1 || cout < 1 || d < 1 || h < 1 || w < 1 || tile < -1 || tile > 3) return ADV_EINVAL;
   if (const int rc = check_wino4_args(x, w_prep, bias, residual, mask, y)) return rc;
   const Epi4 epi{bias, residual, mask, relu ? 1 : 0};
-  return launch_wino4_tile<true>(tile >= 0 ? tile : pick_wino4_tile(cout, h, w), x, w_prep, y, b, cin, cout, round_up4(cin, kKC), round_up4(cout, kCO), d, h, w,
+  return launch_wino4_tile<true>(tile >= 0 ? tile : pick_wino4_tile(cout, h, w, static_cast<long long>(b) * d), x, w_prep, y, b, cin, cout, round_up4(cin, kKC), round_up4(cout, kCO), d, h, w,
                                  epi, static_cast<hipStream_t>(stream));
 }
 
