@@ -40,7 +40,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void lds_void;
 
 constexpr int kKC = 4;        // "channels" q per stage
-constexpr int kTransformWavePositions = 3;      // 64-channel workgroups: positions carried by each of the four transform waves (the others: 9 - this)
+constexpr int kTransformWavePositions = 4;      // 64-channel workgroups: positions carried by each of the four transform waves (the others: 9 - this)
 
 // PR x PC patches of 4 x 4 outputs per workgroup, CB blocks of 32 output channels: 32 patches x 64 channels (CB = 2) or 64 patches x 32
 // channels (CB = 1: layers of 32 output channels or an odd number of 32-channel blocks); LWP: floats per LDS row of the input tile
@@ -88,9 +88,12 @@ __device__ __forceinline__ void at6(float m0, float m1, float m2, float m3, floa
 // ABL: phase ablation for timing (compile-time, so the schedule of the rest is the shipped one; results are wrong): bit 0 input transform,
 // 1 matrix instructions, 2 input loads, 3 input commits, 4 the stage's wait + barrier, 5 operand reads, 6 weight DMA.
 // The -DADV_TEST_HOOKS build's probe instantiates non-zero values, the shipped kernels are ABL = 0.
-template <int PR, int PC, int LWP, int CB, bool DEPTH, int ABL = 0>
+// PAIR (16 x 32-output tiles of 2D layers on maps of at most 15 x 16 pixels - the RoI heads' 14 x 14 maps): the tile's left and right halves are
+// TWO IMAGES side by side (blockIdx.z = image pair): an image's right zero padding and its neighbour's left one coincide in the LDS tile, so
+// a 14 x 14 map uses 77 % of the tile instead of 38 %.  Needs Cin % 4 == 0 (the range check covers the pair, not one image's channels).
+template <int PR, int PC, int LWP, int CB, bool DEPTH, int ABL = 0, bool PAIR = false>
 __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x, const float* __restrict__ wp, float* __restrict__ y, int Cin, int Cout,
-                                                     int cinpad, int copad, int D, int H, int W, int tiles_w, long long wbytes, Epi4 epi) {
+                                                     int cinpad, int copad, int D, int H, int W, int tiles_w, long long wbytes, int nimg, Epi4 epi) {
   using G = W4Geo<PR, PC, LWP, CB>;
   constexpr int PB = G::kPB, NPT = G::kNP, CO = G::kCO;
   constexpr int dbg = ABL;
@@ -100,7 +103,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
   const int l32 = lane & 31, half = lane >> 5;
   const int wt = blockIdx.x % tiles_w, ht = blockIdx.x / tiles_w;
   const int w0 = wt * 4 * PC, h0 = ht * 4 * PR, co0 = blockIdx.y * CO;
-  const long long b = DEPTH ? blockIdx.z / D : blockIdx.z;
+  static_assert(!PAIR || (!DEPTH && PC == 8), "image pairs: the 16 x 32 tile of a 2D layer");
+  const long long b = DEPTH ? blockIdx.z / D : (PAIR ? 2LL * blockIdx.z : blockIdx.z);      // PAIR: the first image of the pair
   const int od = DEPTH ? static_cast<int>(blockIdx.z % D) : 0;
   const long long HW = static_cast<long long>(H) * W;
   const long long DHW = HW * D;
@@ -111,7 +115,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
 
   // ---- addressing: buffer loads, one 32-bit byte offset per slot computed once per tile, the hardware's range check = zero padding
   const float* const xb = x + b * Cin * DHW;
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, static_cast<int>(static_cast<unsigned>(Cin * DHW * 4)), 0x00020000);
+  const long long ximgs = PAIR ? (b + 1 < nimg ? 2 : 1) : 1;      // images behind the descriptor
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, static_cast<int>(static_cast<unsigned>(ximgs * Cin * DHW * 4)), 0x00020000);
   const __amdgpu_buffer_rsrc_t rwgt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wp), 0, static_cast<int>(wbytes), 0x00020000);
   int xvo[G::kXSl], xls[G::kXSl];
   unsigned xvm[G::kXSl];
@@ -119,8 +124,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
   for (int i = 0; i < G::kXSl; ++i) {
     const int sidx = tid + 512 * i;
     const int j = sidx % (G::kLW / 4), r = (sidx / (G::kLW / 4)) % G::kRows, c = sidx / ((G::kLW / 4) * G::kRows);
-    const int gh = h0 - 1 + r, gw = w0 - 4 + 4 * j;          // groups start on multiples of four columns: none straddles the row's start
-    xvo[i] = static_cast<int>(static_cast<unsigned>(c < kKC ? c : kKC - 1) * static_cast<unsigned>(DHW) * 4u) + (gh * W + gw) * 4;
+    // groups start on multiples of four columns: none straddles the row's start.  PAIR: groups 0-4 are image A's columns -4 .. 15, groups
+    // 5-9 image B's columns 0 .. 19 (LDS column = column + 5 / + 21: B's column -1 is A's column 15 - zero padding for both)
+    const int gh = h0 - 1 + r, gw = PAIR ? (j < 5 ? 4 * j - 4 : 4 * (j - 5)) : w0 - 4 + 4 * j;
+    xvo[i] = static_cast<int>(static_cast<unsigned>(c < kKC ? c : kKC - 1) * static_cast<unsigned>(DHW) * 4u) + (gh * W + gw) * 4 +
+             (PAIR && j >= 5 ? static_cast<int>(static_cast<unsigned>(Cin * DHW) * 4u) : 0);
     xls[i] = ((c < kKC ? c : kKC - 1) * G::kRows + r) * LWP + 4 * j + 1;    // LDS column = gw - (w0 - 5): a patch's six columns start on a multiple of four
     unsigned vm = 0;
     if (sidx < G::kXN && gh >= 0 && gh < H)
@@ -152,9 +160,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
     }
   };
   // The 36 positions are dealt to the eight waves so that the two waves of a SIMD carry nine between them: waves 0-3 own NT each,
-  // k = w + 4 n; waves 4-7 own 9 - NT each, k = 4 NT + (w - 4) + 4 n.  64-channel workgroups: NT = 3 / 6 - waves 0-3 also compute the whole
-  // input transform, and a wave issues in order: its side work must fit in the shadow of ITS matrix instructions or the pipe waits for it
-  // (4 / 5 measured 4-7 % slower); 32-channel workgroups: every wave transforms, 4 / 5.
+  // k = w + 4 n; waves 4-7 own 9 - NT each, k = 4 NT + (w - 4) + 4 n.  NT = 4 / 5 everywhere (64-channel workgroups: waves 0-3 also compute the
+  // whole input transform; giving them three positions and the others six measured 2-5 % slower, profiles/r05_wino4_split36_negative.jsonl).
   constexpr int NT = CB == 2 ? kTransformWavePositions : 4;      // positions of a wave 0-3 (waves 4-7: 9 - NT)
   const int kbase = wave < 4 ? wave : 4 * NT - 4 + wave;
   // weights: a wave stages the positions it multiplies itself: U[k][q0 .. q0 + 3][co0 .. co0 + CO - 1] = 1 KiB (CO = 64) or 512 B, one
@@ -221,7 +228,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
   const float* const maskb = epi.mask ? epi.mask + b * MP + plane0 : nullptr;
   const bool vec4 = (W & 3) == 0 && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(epi.residual) | reinterpret_cast<uintptr_t>(epi.mask)) & 15) == 0;
   const int ep = tid % NPT, eg = tid / NPT;               // patch; first channel of the round's 16 (then + 512 / NPT)
-  const int gh0 = h0 + 4 * (ep / PC), gw0 = w0 + 4 * (ep % PC);
+  const int gh0 = h0 + 4 * (ep / PC), gw0 = PAIR ? 4 * (ep % 4) : w0 + 4 * (ep % PC);
+  const long long eimg = PAIR && (ep % PC) >= 4 ? MP : 0;      // PAIR: the right half of the tile is the pair's second image
+  const bool eok = !PAIR || (ep % PC) < 4 || b + 1 < nimg;
 
   // body<NP, TR, HS>: a wave's whole life after the set-up - NP positions; TR: it also computes the input transform (half HS of it)
   auto body = [&](auto np_c, auto t_c, auto hs_c) __attribute__((always_inline)) {
@@ -376,39 +385,43 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) at6(s[r][0], s[r][1], s[r][2], s[r][3], s[r][4], s[r][5], o[r]);
-        if (co < Cout && gh0 < H && gw0 < W) {
+        if (co < Cout && gh0 < H && gw0 < W && eok) {
           const float bv = epi.bias ? epi.bias[co] : 0.0f;
-          const long long at0 = static_cast<long long>(co) * DHW + static_cast<long long>(gh0) * W + gw0;
+          const long long at0 = eimg + static_cast<long long>(co) * DHW + static_cast<long long>(gh0) * W + gw0;
+          // the skip connection and the mask of all sixteen outputs FIRST, the stores after them: a load placed behind a store to y may
+          // not be moved ahead of it (the pointers could alias) - row by row that was a memory round trip per row (+25 % on the layers with
+          // a residual); unconditional loads (a row / column outside the map reads the tensor's first floats and is never stored)
+          float rv[4][4], mv[4][4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool rok = gh0 + r < H;
+            const long long at = at0 + static_cast<long long>(r) * W;
+            if (vec4) {
+              const v4f tr = resb ? *reinterpret_cast<const v4f*>(rok ? resb + at : epi.residual) : v4f{0.0f, 0.0f, 0.0f, 0.0f};
+              const v4f tm = maskb ? *reinterpret_cast<const v4f*>(rok ? maskb + at : epi.mask) : v4f{1.0f, 1.0f, 1.0f, 1.0f};
+#pragma unroll
+              for (int c = 0; c < 4; ++c) rv[r][c] = tr[c], mv[r][c] = tm[c];
+            } else {
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                const bool ok = rok && gw0 + c < W;
+                rv[r][c] = resb ? (ok ? resb[at + c] : epi.residual[0]) : 0.0f;
+                mv[r][c] = maskb ? (ok ? maskb[at + c] : epi.mask[0]) : 1.0f;
+              }
+            }
+          }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             if (gh0 + r >= H) continue;
             const long long at = at0 + static_cast<long long>(r) * W;
-            float rv[4] = {0.0f, 0.0f, 0.0f, 0.0f}, mv[4] = {1.0f, 1.0f, 1.0f, 1.0f};
-            if (vec4) {
-              if (resb) {
-                const v4f t4 = *reinterpret_cast<const v4f*>(resb + at);
-                rv[0] = t4[0], rv[1] = t4[1], rv[2] = t4[2], rv[3] = t4[3];
-              }
-              if (maskb) {
-                const v4f t4 = *reinterpret_cast<const v4f*>(maskb + at);
-                mv[0] = t4[0], mv[1] = t4[1], mv[2] = t4[2], mv[3] = t4[3];
-              }
-            } else {
-#pragma unroll
-              for (int c = 0; c < 4; ++c) {
-                if (gw0 + c >= W) continue;
-                if (resb) rv[c] = resb[at + c];
-                if (maskb) mv[c] = maskb[at + c];
-              }
-            }
             float res[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
               float v = o[r][c];
               if (epi.bias) v = v + bv;
-              if (resb) v = v + rv[c];
+              if (resb) v = v + rv[r][c];
               if (epi.relu) v = v > 0.0f ? v : 0.0f;
-              if (maskb) v = mv[c] > 0.0f ? v : 0.0f;
+              if (maskb) v = mv[r][c] > 0.0f ? v : 0.0f;
               res[c] = v;
             }
             if (vec4) {
@@ -440,27 +453,28 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
 
 int round_up4(int v, int q) { return (v + q - 1) / q * q; }
 
-template <int PR, int PC, int LWP, int CB, bool DEPTH>
+template <int PR, int PC, int LWP, int CB, bool DEPTH, bool PAIR = false>
 int launch_wino4(const float* x, const float* wp, float* y, int b, int cin, int cout, int cinpad, int copad, int d, int h, int w, const Epi4& epi,
                  hipStream_t st) {
   using G = W4Geo<PR, PC, LWP, CB>;
-  const int tiles_w = (w + 4 * PC - 1) / (4 * PC), tiles_h = (h + 4 * PR - 1) / (4 * PR);
+  if (PAIR && (w > 15 || cin % kKC != 0)) return ADV_EINVAL;
+  const int tiles_w = PAIR ? 1 : (w + 4 * PC - 1) / (4 * PC), tiles_h = (h + 4 * PR - 1) / (4 * PR);
   const long long tiles = static_cast<long long>(tiles_w) * tiles_h;
   const int cgroups = (cout + G::kCO - 1) / G::kCO;
-  const long long gz = static_cast<long long>(b) * d;
+  const long long gz = PAIR ? (static_cast<long long>(b) + 1) / 2 : static_cast<long long>(b) * d;
   if (tiles > 0x7fffffffLL || cgroups > 65535 || gz > 65535) return ADV_EINVAL;
   const long long wbytes = 36LL * (DEPTH ? 3 : 1) * cinpad * copad * 4;
-  if ((static_cast<long long>(cinpad) + 1) * d * h * w * 4 >= 0xfff00000LL || wbytes >= 0x7ff00000LL) return ADV_EINVAL;
+  if ((static_cast<long long>(cinpad) + 1) * d * h * w * 4 * (PAIR ? 2 : 1) >= 0xfff00000LL || wbytes >= 0x7ff00000LL) return ADV_EINVAL;
   const dim3 grid(static_cast<unsigned>(tiles), cgroups, static_cast<unsigned>(gz));
 #ifdef ADV_TEST_HOOKS
   if (const char* dbg_s = adv_hook_value("ADV_WINO4_DBG")) {      // phase ablation for timing (results are wrong): the 8 x 64 x 64 2D shape and the 16 x 64 x 32 3D shape
-    if constexpr ((PR == 2 && PC == 16 && CB == 2 && !DEPTH) || (PR == 4 && PC == 16 && CB == 1 && DEPTH)) {
+    if constexpr (!PAIR && ((PR == 2 && PC == 16 && CB == 2 && !DEPTH) || (PR == 4 && PC == 16 && CB == 1 && DEPTH))) {
       const int abl = std::atoi(dbg_s);
 #define ADV_WINO4_ABL(A_)                                                                                                                       \
   if (abl == A_) {                                                                                                                              \
     if (!adv_internal_lds_limit<conv_wino4<PR, PC, LWP, CB, DEPTH, A_>>(G::kLds)) return ADV_ELAUNCH;                                           \
     hipLaunchKernelGGL((conv_wino4<PR, PC, LWP, CB, DEPTH, A_>), grid, dim3(512), G::kLds, st, x, wp, y, cin, cout, cinpad, copad, d, h, w, tiles_w, \
-                       wbytes, epi);                                                                                                            \
+                       wbytes, b, epi);                                                                                                            \
     return adv_internal_finish_launch();                                                                                                        \
   }
       ADV_WINO4_ABL(1) ADV_WINO4_ABL(2) ADV_WINO4_ABL(4) ADV_WINO4_ABL(8) ADV_WINO4_ABL(16) ADV_WINO4_ABL(32) ADV_WINO4_ABL(64) ADV_WINO4_ABL(12) ADV_WINO4_ABL(93) ADV_WINO4_ABL(125) ADV_WINO4_ABL(127)
@@ -468,19 +482,21 @@ int launch_wino4(const float* x, const float* wp, float* y, int b, int cin, int 
     }
   }
 #endif
-  if (!adv_internal_lds_limit<conv_wino4<PR, PC, LWP, CB, DEPTH>>(G::kLds)) return ADV_ELAUNCH;
-  hipLaunchKernelGGL((conv_wino4<PR, PC, LWP, CB, DEPTH>), grid, dim3(512), G::kLds, st, x, wp, y, cin, cout, cinpad, copad, d, h, w, tiles_w, wbytes, epi);
+  if (!adv_internal_lds_limit<conv_wino4<PR, PC, LWP, CB, DEPTH, 0, PAIR>>(G::kLds)) return ADV_ELAUNCH;
+  hipLaunchKernelGGL((conv_wino4<PR, PC, LWP, CB, DEPTH, 0, PAIR>), grid, dim3(512), G::kLds, st, x, wp, y, cin, cout, cinpad, copad, d, h, w, tiles_w, wbytes,
+                     b, epi);
   return adv_internal_finish_launch();
 }
 
 // tile: 0 = 16 x 32 outputs x 64 channels (4 x 8 patches), 1 = 8 x 64 x 64 (2 x 16 patches: maps of few rows), 2 = 32 x 32 outputs x 32
 // channels (8 x 8 patches), 3 = 16 x 64 x 32 (4 x 16 patches).  The 32-channel shapes where 64 channels would compute a block of padding
 // (an odd number of 32-channel blocks); the flat shapes where they need clearly fewer workgroups for the map.
-int pick_wino4_tile(int cout, int h, int w, long long bz) {
+int pick_wino4_tile(int cout, int h, int w, long long bz, bool pair_ok) {
   // every shape is one workgroup per compute unit with the same work: the launch takes ceil(workgroups / 256) rounds; among equal rounds the
   // shape with fewer workgroups (less padding), then the wide one (8 x 64 / 16 x 64: measured 2-7 % faster on large maps, profiles/r05_wino4_*.jsonl)
   auto wgs = [&](int th, int tw, int co) { return static_cast<long long>((h + th - 1) / th) * ((w + tw - 1) / tw) * ((cout + co - 1) / co) * bz; };
   const bool narrow = ((cout + 31) / 32) % 2 == 1;
+  if (pair_ok && !narrow) return 4;      // maps of at most 15 columns (the RoI heads' 14 x 14): two images per tile
   const long long a = narrow ? wgs(32, 32, 32) : wgs(16, 32, 64), b = narrow ? wgs(16, 64, 32) : wgs(8, 64, 64);
   const long long ra = (a + 255) / 256, rb = (b + 255) / 256;
   const bool wide = rb < ra || (rb == ra && b <= a);
@@ -494,7 +510,10 @@ int launch_wino4_tile(int t, const float* x, const float* wp, float* y, int b, i
     case 0: return launch_wino4<4, 8, 56, 2, DEPTH>(x, wp, y, b, cin, cout, cinpad, copad, d, h, w, epi, st);
     case 1: return launch_wino4<2, 16, 80, 2, DEPTH>(x, wp, y, b, cin, cout, cinpad, copad, d, h, w, epi, st);
     case 2: return launch_wino4<8, 8, 44, 1, DEPTH>(x, wp, y, b, cin, cout, cinpad, copad, d, h, w, epi, st);
-    default: return launch_wino4<4, 16, 80, 1, DEPTH>(x, wp, y, b, cin, cout, cinpad, copad, d, h, w, epi, st);
+    case 3: return launch_wino4<4, 16, 80, 1, DEPTH>(x, wp, y, b, cin, cout, cinpad, copad, d, h, w, epi, st);
+    default:
+      if constexpr (!DEPTH) return launch_wino4<4, 8, 56, 2, false, true>(x, wp, y, b, cin, cout, cinpad, copad, d, h, w, epi, st);
+      return ADV_EINVAL;
   }
 }
 
@@ -584,10 +603,10 @@ int adv_conv2d_wino4_prep_weights_f32(const float* w, float* w_prep, int cout, i
 
 int adv_conv2d_wino4_f32(const float* x, const float* w_prep, const float* bias, const float* residual, const float* mask, float* y, int b, int cin,
                          int cout, int h, int w, int relu, int tile, adv_stream_t stream) {
-  if (!x || !w_prep || !y || b < 1 || cin < 1 || cout < 1 || h < 1 || w < 1 || tile < -1 || tile > 3) return ADV_EINVAL;
+  if (!x || !w_prep || !y || b < 1 || cin < 1 || cout < 1 || h < 1 || w < 1 || tile < -1 || tile > 4) return ADV_EINVAL;
   if (const int rc = check_wino4_args(x, w_prep, bias, residual, mask, y)) return rc;
   const Epi4 epi{bias, residual, mask, relu ? 1 : 0};
-  return launch_wino4_tile<false>(tile >= 0 ? tile : pick_wino4_tile(cout, h, w, b), x, w_prep, y, b, cin, cout, round_up4(cin, kKC), round_up4(cout, kCO), 1, h, w,
+  return launch_wino4_tile<false>(tile >= 0 ? tile : pick_wino4_tile(cout, h, w, b, w <= 15 && cin % kKC == 0 && b >= 2), x, w_prep, y, b, cin, cout, round_up4(cin, kKC), round_up4(cout, kCO), 1, h, w,
                                   epi, static_cast<hipStream_t>(stream));
 }
 
@@ -606,7 +625,7 @@ int adv_conv3d_wino4_f32(const float* x, const float* w_prep, const float* bias,
   if (!x || !w_prep || !y || b < 1 || cin < 1 || cout < 1 || d < 1 || h < 1 || w < 1 || tile < -1 || tile > 3) return ADV_EINVAL;
   if (const int rc = check_wino4_args(x, w_prep, bias, residual, mask, y)) return rc;
   const Epi4 epi{bias, residual, mask, relu ? 1 : 0};
-  return launch_wino4_tile<true>(tile >= 0 ? tile : pick_wino4_tile(cout, h, w, static_cast<long long>(b) * d), x, w_prep, y, b, cin, cout, round_up4(cin, kKC), round_up4(cout, kCO), d, h, w,
+  return launch_wino4_tile<true>(tile >= 0 ? tile : pick_wino4_tile(cout, h, w, static_cast<long long>(b) * d, false), x, w_prep, y, b, cin, cout, round_up4(cin, kKC), round_up4(cout, kCO), d, h, w,
                                  epi, static_cast<hipStream_t>(stream));
 }
 

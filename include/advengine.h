@@ -530,7 +530,7 @@ ADV_API int adv_conv3d_wino_f32(const float* x, const float* w_prep, const float
  *     inside the 1e-4 band) - the caller chooses the route explicitly.
  *     w_prep from adv_conv{2,3}d_wino4_prep_weights_f32 ([36][taps * cin'][cout'] = G g G^T, zero padded to multiples of 4 x 64; transpose
  *     = 1: the backward w.r.t. the input).  bias / residual / relu / mask: as adv_conv2d_1x1_f32.  tile: -1 = by map size and cout, 0 = 16 x 32
- *     outputs x 64 channels per workgroup, 1 = 8 x 64 x 64, 2 = 32 x 32 outputs x 32 channels, 3 = 16 x 64 x 32 (same result).  An image (cin x d x h x w floats) and the prepared weights must stay below 4 GiB / 2 GiB. */
+ *     outputs x 64 channels per workgroup, 1 = 8 x 64 x 64, 2 = 32 x 32 outputs x 32 channels, 3 = 16 x 64 x 32, 4 (2D, w <= 15, cin % 4 == 0) = two images per 16 x 32 tile (same result).  An image (cin x d x h x w floats) and the prepared weights must stay below 4 GiB / 2 GiB. */
 ADV_API int64_t adv_conv2d_wino4_prep_floats(int cout, int cin, int transpose);
 ADV_API int adv_conv2d_wino4_prep_weights_f32(const float* w, float* w_prep, int cout, int cin, int transpose, adv_stream_t stream);
 ADV_API int adv_conv2d_wino4_f32(const float* x, const float* w_prep, const float* bias, const float* residual, const float* mask,

@@ -91,3 +91,29 @@ def test_hip_conv3d_wino4_bit_exact_vs_oracle(case):
     g = rs.randn(b, cout, d, h, w).astype(np.float32)
     gx = ops.conv_wino4_dgrad(torch.tensor(g, device=dev), prep).cpu().numpy()
     assert gx.tobytes() == oracle_c.conv_wino4(g, wt, transpose=True).tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(5, 8, 70, 14, 14), (2, 4, 64, 7, 15), (1, 16, 64, 14, 14), (6, 32, 128, 20, 9)])
+def test_hip_conv2d_wino4_image_pairs_bit_exact_vs_oracle(case):
+    """tile 4: two images side by side in one 16 x 32 tile (maps of at most 15 columns - the RoI heads' 14 x 14 maps), odd batch sizes too;
+    the same bytes as the one-image shapes and as the oracle"""
+    from oracle import oracle_c
+    from eval_driving_safety_amd import ops
+    dev = torch.device("cuda", 0)
+    b, cin, cout, h, w = case
+    rs = np.random.RandomState(cin * 3 + b)
+    x = rs.randn(b, cin, h, w).astype(np.float32)
+    wt = (rs.randn(cout, cin, 3, 3) * 0.2).astype(np.float32)
+    bias = rs.randn(cout).astype(np.float32)
+    res = rs.randn(b, cout, h, w).astype(np.float32)
+    mask = (rs.rand(b, cout, h, w) > 0.3).astype(np.float32)
+    prep = ops.ConvWino4Prep(torch.tensor(wt, device=dev))
+    tx, tb, tr, tm = (torch.tensor(a, device=dev) for a in (x, bias, res, mask))
+    want = oracle_c.conv_wino4(x, wt, bias, res, mask, relu=True)
+    for tile in (4, 0, -1):
+        y = ops.conv_wino4(tx, prep, tb, tr, True, tm, tile=tile).cpu().numpy()
+        assert y.tobytes() == want.tobytes(), (case, tile, float(np.abs(y - want).max()))
+    g = rs.randn(b, cout, h, w).astype(np.float32)
+    gx = ops.conv_wino4_dgrad(torch.tensor(g, device=dev), prep, tile=4 if cout % 4 == 0 else -1).cpu().numpy()      # (pairs need a contraction of whole stages)
+    assert gx.tobytes() == oracle_c.conv_wino4(g, wt, transpose=True).tobytes()

@@ -27,7 +27,8 @@ def main():
         p2, p4 = ops.Conv2dPrep(wt, 1, 1, 1), ops.ConvWino4Prep(wt)
         flops = 2.0 * b * cout * cin * 9 * h * w
         m2 = timed(lambda: ops.conv2d(x, p2, bias, None, True, wino=True))
-        m4 = {t: round(timed(lambda t=t: ops.conv_wino4(x, p4, bias, None, True, tile=t)), 4) for t in (0, 1, 2, 3)}
+        m4 = {t: round(timed(lambda t=t: ops.conv_wino4(x, p4, bias, None, True, tile=t)), 4) for t in ((0, 1, 2, 3) + ((4,) if w <= 15 and b >= 2 else ()))}
+        m4["auto"] = round(timed(lambda: ops.conv_wino4(x, p4, bias, None, True)), 4)
         err = float((ops.conv_wino4(x, p4, bias, None, True) - ops.conv2d(x, p2, bias, None, True, wino=True)).abs().max())
         print(json.dumps({"layer": "%d->%d on [%d,%d,%d,%d]" % (cin, cout, b, cin, h, w), "wino2_ms": round(m2, 4), "wino4_ms_by_tile": m4,
                           "wino2_tflops": round(flops / m2 / 1e9, 1), "wino4_tflops": round(flops / min(m4.values()) / 1e9, 1),
