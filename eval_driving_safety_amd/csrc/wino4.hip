@@ -93,7 +93,7 @@ __device__ __forceinline__ void at6(float m0, float m1, float m2, float m3, floa
 // a 14 x 14 map uses 77 % of the tile instead of 38 %.  Needs Cin % 4 == 0 (the range check covers the pair, not one image's channels).
 template <int PR, int PC, int LWP, int CB, bool DEPTH, int ABL = 0, bool PAIR = false>
 __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x, const float* __restrict__ wp, float* __restrict__ y, int Cin, int Cout,
-                                                     int cinpad, int copad, int D, int H, int W, int tiles_w, long long wbytes, int nimg, Epi4 epi) {
+                                                     int cinpad, int copad, int D, int H, int W, int tiles_w, long long wbytes, int nimg, int flags, Epi4 epi) {
   using G = W4Geo<PR, PC, LWP, CB>;
   constexpr int PB = G::kPB, NPT = G::kNP, CO = G::kCO;
   constexpr int dbg = ABL;
@@ -236,6 +236,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
   auto body = [&](auto np_c, auto t_c, auto hs_c) __attribute__((always_inline)) {
     constexpr int NP = decltype(np_c)::value;
     constexpr bool TR = decltype(t_c)::value;
+    if (CB == 2 && ((TR && (flags & 1)) || (!TR && (flags & 2)))) __builtin_amdgcn_s_setprio(1);      // static priority of one half of the waves (A/B: kWaveFlags)
     constexpr int NS = 2 * NP;                    // steps per stage: (position n, q pair kp), two matrix instructions each
     f32x16 acc[NP][2];                            // [n][cb] (CB = 2) or [n][pb] (CB = 1)
 #pragma unroll
@@ -453,6 +454,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
 
 int round_up4(int v, int q) { return (v + q - 1) / q * q; }
 
+constexpr int kWaveFlags = 0;      // bit 0: the transform waves of a 64-channel workgroup run at priority 1, bit 1: the product waves
+int wave_flags() {
+  if (const char* e = adv_hook_value("ADV_WINO4_FLAGS")) return std::atoi(e);      // test hook / A-B; same bits
+  return kWaveFlags;
+}
+
 template <int PR, int PC, int LWP, int CB, bool DEPTH, bool PAIR = false>
 int launch_wino4(const float* x, const float* wp, float* y, int b, int cin, int cout, int cinpad, int copad, int d, int h, int w, const Epi4& epi,
                  hipStream_t st) {
@@ -474,7 +481,7 @@ int launch_wino4(const float* x, const float* wp, float* y, int b, int cin, int 
   if (abl == A_) {                                                                                                                              \
     if (!adv_internal_lds_limit<conv_wino4<PR, PC, LWP, CB, DEPTH, A_>>(G::kLds)) return ADV_ELAUNCH;                                           \
     hipLaunchKernelGGL((conv_wino4<PR, PC, LWP, CB, DEPTH, A_>), grid, dim3(512), G::kLds, st, x, wp, y, cin, cout, cinpad, copad, d, h, w, tiles_w, \
-                       wbytes, b, epi);                                                                                                            \
+                       wbytes, b, wave_flags(), epi);                                                                                                            \
     return adv_internal_finish_launch();                                                                                                        \
   }
       ADV_WINO4_ABL(1) ADV_WINO4_ABL(2) ADV_WINO4_ABL(4) ADV_WINO4_ABL(8) ADV_WINO4_ABL(16) ADV_WINO4_ABL(32) ADV_WINO4_ABL(64) ADV_WINO4_ABL(12) ADV_WINO4_ABL(93) ADV_WINO4_ABL(125) ADV_WINO4_ABL(127)
@@ -484,7 +491,7 @@ int launch_wino4(const float* x, const float* wp, float* y, int b, int cin, int 
 #endif
   if (!adv_internal_lds_limit<conv_wino4<PR, PC, LWP, CB, DEPTH, 0, PAIR>>(G::kLds)) return ADV_ELAUNCH;
   hipLaunchKernelGGL((conv_wino4<PR, PC, LWP, CB, DEPTH, 0, PAIR>), grid, dim3(512), G::kLds, st, x, wp, y, cin, cout, cinpad, copad, d, h, w, tiles_w, wbytes,
-                     b, epi);
+                     b, wave_flags(), epi);
   return adv_internal_finish_launch();
 }
 
