@@ -684,6 +684,175 @@ __global__ __launch_bounds__(kBlock) void roi_bwd_sum_segments(const float* __re
   gfeat[i] = acc;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// <round 5> third formulation: PER-ROI AXIS TABLES + a wave per pixel.
+// The LDS formulation above classifies every roi again for each (tile, block of 16 channels) and walks a tile's rois one after the other
+// behind two barriers each: on 510 clustered P2 proposals 0.23 ms of classification, 0.36 ms of staging / barriers and 0.66 ms of item and
+// sample loops (profiles/r04_roi_bwd_phases.json).  Here
+//   * roi_axis_tables classifies ONCE per call: for roi r and every row y / column x of the map, the ascending list of the sample taps that
+//     land on that row / column (bin index + 1-D weight: exactly the AxisList entries of the kernels above) - n_tab[r][H + W] counts and
+//     e_tab[r][H + W][kListCap] entries, shared by all channels and all pixels;
+//   * roi_align_bwd_tab gives a pixel to a WAVE (lanes = 64 channels; grad_out's channel-last rows are 256-byte loads).  The wave scans the
+//     tile's roi list 64 rois at a time (lane j: do roi j's row and column lists both hold entries for my pixel? - one ballot), lays the
+//     touching rois' ny x nx entries end to end (wave prefix sum), and its lanes fetch 64 entries of that sequence at once - whichever rois
+//     they belong to - as (weight product, grad_out offset, sample count); the ordered sum then runs over the 64 entries with the loads
+//     eight deep.  No barrier, no LDS accumulators, no serial walk over rois that do not touch the pixel, and a hot pixel's chain is a
+//     stream of independent loads rather than a round trip per roi.
+// Per pixel and channel the additions are (roi ascending; row entry; column entry) - the order of the formulations above and of the
+// oracle's roi_align_bwd_ordered with one segment - with the same float operations (weight product, * 1/count or / count), so the bits
+// are the same.  A roi whose list for the pixel overflows kListCap is summed by roi_direct in its place of the sequence.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kTabPix = 8;       // pixels per workgroup (two per wave): a 32-byte run per channel when the tile is written
+constexpr int kTabChan = 64;     // channels per workgroup = the lanes of a wave
+
+__global__ __launch_bounds__(kBlock) void roi_axis_tables(const float* __restrict__ rois, int B, int H, int W, int PH, int PW, float scale,
+                                                          int sampling_ratio, int* __restrict__ n_tab, int2* __restrict__ e_tab,
+                                                          float* __restrict__ cnt) {
+  const int r = blockIdx.y, a = blockIdx.x * kBlock + static_cast<int>(threadIdx.x);
+  if (a >= H + W) return;
+  const Bin b = bin_of(rois + static_cast<long long>(r) * 5, scale, PH, PW, sampling_ratio);
+  if (a == 0) cnt[r] = static_cast<float>(b.grid_h * b.grid_w);
+  int n = 0;
+  if (b.batch >= 0 && b.batch < B) {               // (a skipped roi - batch index -1 - is on no tile's list either)
+    const bool is_y = a < H;
+    const int pixel = is_y ? a : a - H, size = is_y ? H : W;
+    const float start = is_y ? b.start_h : b.start_w, bin = is_y ? b.bin_h : b.bin_w;
+    const int grid = is_y ? b.grid_h : b.grid_w, pooled = is_y ? PH : PW;
+    int2* out = e_tab + (static_cast<long long>(r) * (H + W) + a) * kListCap;
+    int k_lo, k_hi;
+    cand_range(start, bin / static_cast<float>(grid), pooled * grid, pixel, size, &k_lo, &k_hi);
+    for (int k = k_lo; k <= k_hi; ++k) {           // classification: as in roi_bwd_body
+      const int pb = k / grid, ik = k - pb * grid;
+      const float v = start + static_cast<float>(pb) * bin + (static_cast<float>(ik) + 0.5f) * bin / static_cast<float>(grid);
+      const Axis1 t = axis_taps(size, v, pixel);
+      if (!t.valid || !(t.hit_low || t.hit_high)) continue;
+      if (t.hit_low) {
+        if (n < kListCap) out[n] = int2{pb, __float_as_int(t.w_low)};
+        ++n;
+      }
+      if (t.hit_high) {
+        if (n < kListCap) out[n] = int2{pb, __float_as_int(t.w_high)};
+        ++n;
+      }
+    }
+  }
+  n_tab[static_cast<long long>(r) * (H + W) + a] = n;
+}
+
+__device__ __forceinline__ int lane_read(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ float lane_read(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+__device__ __forceinline__ int lane_fetch(int v, int lane) { return __builtin_amdgcn_ds_bpermute(lane << 2, v); }
+
+__global__ __launch_bounds__(kBlock) void roi_align_bwd_tab(const float* __restrict__ gcl, const float* __restrict__ rois,
+                                                            const int* __restrict__ lists, const int* __restrict__ n_tab,
+                                                            const int2* __restrict__ e_tab, const float* __restrict__ cnt,
+                                                            float* __restrict__ gfeat, int C, int H, int W, int R, int tiles_y, int tiles_x,
+                                                            int groups_x, int PH, int PW, float scale, int sampling_ratio) {
+  __shared__ float s_out[kTabChan][kTabPix + 1];
+  const int img = blockIdx.z, c0 = static_cast<int>(blockIdx.y) * kTabChan;
+  const int gx = static_cast<int>(blockIdx.x) % groups_x, py = static_cast<int>(blockIdx.x) / groups_x;
+  const int px0 = gx * kTabPix;
+  const int tile = (py / kTileY) * tiles_x + px0 / kTileX;
+  const int* list = lists + (static_cast<long long>(img) * tiles_y * tiles_x + tile) * (R + 1);
+  const int n_list = list[0];
+  const int tid = static_cast<int>(threadIdx.x), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cp = cpad(C), chan = c0 + lane, HW = H + W, bins = PH * PW;
+  const bool chan_ok = chan < cp;                  // (channels C .. cp - 1 of the channel-last copy are zeros; beyond cp nothing is read)
+  const float* gl = gcl + (chan_ok ? chan : 0);
+#pragma unroll 1
+  for (int i = 0; i < kTabPix / 4; ++i) {
+    const int lx = wave * (kTabPix / 4) + i, px = px0 + lx;
+    float acc = 0.0f;
+    if (px < W) {
+#pragma unroll 1
+      for (int l0 = 0; l0 < n_list; l0 += 64) {
+        const int r = l0 + lane < n_list ? list[1 + l0 + lane] : -1;
+        int ny = 0, nx = 0;
+        if (r >= 0) {
+          ny = n_tab[static_cast<long long>(r) * HW + py];
+          nx = n_tab[static_cast<long long>(r) * HW + H + px];
+        }
+        const bool touch = ny > 0 && nx > 0;
+        const float count = touch ? cnt[r] : 1.0f;
+        unsigned long long m = __ballot(touch), ov = __ballot(touch && (ny > kListCap || nx > kListCap));
+        while (m) {
+          // the touching rois up to the first one whose lists overflow, as one sequence of entries; then that roi by itself
+          const int jo = ov ? __builtin_ctzll(ov) : 64;
+          const unsigned long long grp = jo < 64 ? (m & ((1ULL << jo) - 1ULL)) : m;
+          if (grp) {
+            const int ns = ((grp >> lane) & 1ULL) ? ny * nx : 0;
+            int incl = ns;                          // inclusive prefix sum over the lanes
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+              const int up = __shfl_up(incl, d, 64);
+              if (lane >= d) incl += up;
+            }
+            const int excl = incl - ns, total = lane_read(incl, 63);
+#pragma unroll 1
+            for (int t0 = 0; t0 < total; t0 += 64) {
+              const int nk = min(64, total - t0);
+              const int t = t0 + min(lane, nk - 1);
+              int j = 0;                            // the lane (= roi of the batch) whose run of entries holds entry t
+#pragma unroll
+              for (int q = 0; q < 63; ++q) j += lane_read(incl, q) <= t ? 1 : 0;
+              const int e = t - lane_fetch(excl, j), nxj = lane_fetch(nx, j), rj = lane_fetch(r, j);
+              const float cj = __int_as_float(lane_fetch(__float_as_int(count), j));
+              const int iy = e / nxj, ix = e - iy * nxj;
+              const long long rb = static_cast<long long>(rj) * HW;
+              const int2 ye = e_tab[(rb + py) * kListCap + iy], xe = e_tab[(rb + H + px) * kListCap + ix];
+              const float wgt = __int_as_float(ye.y) * __int_as_float(xe.y);
+              const int off = (rj * bins + ye.x * PW + xe.x) * cp;
+              const bool p2 = (__float_as_int(cj) & 0x007fffff) == 0;       // the count is a power of two: * (1 / count) is the division
+              const float inv = 1.0f / cj;
+              auto run = [&](auto all_pow2) __attribute__((always_inline)) {
+                constexpr bool kAllPow2 = decltype(all_pow2)::value;
+#pragma unroll 1
+                for (int k = 0; k < nk; k += 8) {
+                  float g[8], w[8], c[8], v[8];
+#pragma unroll
+                  for (int u = 0; u < 8; ++u) {
+                    const int kk = min(k + u, nk - 1);
+                    w[u] = lane_read(wgt, kk);
+                    c[u] = lane_read(cj, kk);
+                    v[u] = lane_read(inv, kk);
+                    g[u] = gl[lane_read(off, kk)];
+                  }
+#pragma unroll
+                  for (int u = 0; u < 8; ++u)
+                    if (k + u < nk) {
+                      const float prod = g[u] * w[u];
+                      if (kAllPow2) acc = acc + prod * v[u];
+                      else acc = acc + (((__float_as_int(c[u]) & 0x007fffff) == 0) ? prod * v[u] : prod / c[u]);
+                    }
+                }
+              };
+              if (__ballot(!p2) == 0ULL) run(std::true_type{});
+              else run(std::false_type{});
+            }
+            m &= ~grp;
+          }
+          if (jo < 64) {
+            const int rj = lane_read(r, jo);
+            const Bin b = bin_of(rois + static_cast<long long>(rj) * 5, scale, PH, PW, sampling_ratio);
+            float one[1] = {acc};
+            roi_direct<1>(one, b, gcl, rj, C, chan, H, W, PH, PW, py, px);
+            acc = one[0];
+            ov &= ov - 1ULL;
+            m &= ~(1ULL << jo);
+          }
+        }
+      }
+    }
+    s_out[lane][lx] = acc;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < kTabChan * kTabPix / kBlock; ++p) {
+    const int ch = tid / kTabPix + p * (kBlock / kTabPix), lx = tid % kTabPix, px = px0 + lx;
+    if (px < W && c0 + ch < C) gfeat[((static_cast<long long>(img) * C + c0 + ch) * H + py) * W + px] = s_out[ch][lx];
+  }
+}
+
 // ---- NMS: wave64 suppression masks.  Block (row tile i, col tile j), 64 lanes: lane l owns box 64*i + l and
 // tests it against the 64 boxes of tile j (staged in LDS); bit k of its mask = IoU(box_l, box_{64j+k}) > thresh.
 __device__ __forceinline__ float iou_legacy(const float* a, const float* b) {
@@ -793,7 +962,9 @@ int64_t adv_roi_align_bwd_workspace_ints(int b, int c, int h, int w, int r, int 
   const int g = adv_roi_align_bwd_segments(r);
   const long long lists = (static_cast<long long>(b) * g * tiles * (r + 1) + 3) & ~3LL;
   const long long gcl = (static_cast<long long>(ph) * pw * r * cpad(c) + 3) & ~3LL;            // the channel-last copy of grad_out
-  return lists + gcl + (g > 1 ? static_cast<long long>(g) * b * c * h * w : 0);                // + one copy of the map per segment
+  // <round 5> one ordered sum (g == 1): the per-roi axis tables - counts [r][h + w], entries [r][h + w][kListCap] x 2 ints, sample counts [r]
+  const long long tabs = g == 1 ? ((static_cast<long long>(r) * (h + w) + 3) & ~3LL) + static_cast<long long>(r) * (h + w) * kListCap * 2 + ((r + 3) & ~3LL) : 0;
+  return lists + gcl + tabs + (g > 1 ? static_cast<long long>(g) * b * c * h * w : 0);         // + one copy of the map per segment
 }
 
 int adv_roi_align_bwd_f32(const float* grad_out, const float* rois, float* grad_feat, int b, int c, int h, int w, int r, int ph,
@@ -821,6 +992,23 @@ int adv_roi_align_bwd_f32(const float* grad_out, const float* rois, float* grad_
                      sampling_ratio, reinterpret_cast<int*>(workspace), G, std::max(1, seg_len));
   // channels per lane: as many as still leave ~8 workgroups per compute unit (the small pyramid levels have 6-20 tiles)
   const long long tiles = static_cast<long long>(tiles_y) * tiles_x * b;
+  // <round 5> the shipped route for one ordered sum: per-roi axis tables + a wave per pixel (ADV_ROI_BWD_LDS=1 or one of the older routes'
+  // own hooks: the formulations below - the same bits)
+  const bool older = adv_hook("ADV_ROI_BWD_LDS") || adv_hook("ADV_ROI_BWD_REGS") || adv_hook("ADV_ROI_BWD_SCALAR_ITEMS") || adv_hook("ADV_ROI_BWD_NO_STAGE") ||
+                     adv_hook("ADV_ROI_ACC_CHAN") || adv_hook("ADV_ROI_DBG");
+  if (G == 1 && !older && static_cast<long long>(r) * ph * pw * cpad(c) < (1LL << 31) && static_cast<long long>(r) * (h + w) * kListCap < (1LL << 31)) {
+    int* n_tab = reinterpret_cast<int*>(parts);
+    int2* e_tab = reinterpret_cast<int2*>(n_tab + ((static_cast<long long>(r) * (h + w) + 3) & ~3LL));
+    float* cnt = reinterpret_cast<float*>(e_tab + static_cast<long long>(r) * (h + w) * kListCap);
+    if (r > 0)
+      hipLaunchKernelGGL(roi_axis_tables, dim3((h + w + kBlock - 1) / kBlock, r), dim3(kBlock), 0, st, rois, b, h, w, ph, pw, spatial_scale, sampling_ratio,
+                         n_tab, e_tab, cnt);
+    const int groups_x = (w + kTabPix - 1) / kTabPix;
+    hipLaunchKernelGGL(roi_align_bwd_tab, dim3(groups_x * h, (c + kTabChan - 1) / kTabChan, b), dim3(kBlock), 0, st, gcl, rois,
+                       reinterpret_cast<const int*>(workspace), n_tab, e_tab, cnt, grad_feat, c, h, w, r, tiles_y, tiles_x, groups_x, ph, pw, spatial_scale,
+                       sampling_ratio);
+    return finish();
+  }
   const char* dbg_s = adv_hook_value("ADV_ROI_DBG");
   const int dbg = dbg_s ? dbg_s[0] - '0' : 0;
   if (!adv_hook("ADV_ROI_BWD_REGS")) {            // the shipped route: accumulators in LDS, lanes = (touched pixel, channel)

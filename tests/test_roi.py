@@ -161,6 +161,7 @@ def test_oracle_nms_small_cases():
     dict(b=2, c=9, h=19, w=40, n=150, pooled=3, scale=1 / 16.0, sr=2),        # many rois on few tiles: long per-tile lists
     dict(b=1, c=3, h=10, w=33, n=65, pooled=2, scale=1 / 8.0, sr=0),          # lists longer than one batch
     dict(b=2, c=12, h=38, w=125, n=520, pooled=7, scale=1 / 16.0, sr=0),      # many rois, two images
+    dict(b=1, c=70, h=24, w=40, n=90, pooled=14, scale=1 / 64.0, sr=2),       # 70 channels: a wave's block of 64 and a partial one (the channel-last copy pads to 72)
 ])
 def test_hip_roi_align(cfg, route):
     from eval_driving_safety_amd import ops
@@ -194,8 +195,10 @@ def test_hip_roi_align(cfg, route):
     with route(ADV_ROI_SEGMENTS="3"):                  # ... and three segments whatever the count: empty (tile, segment) pairs are skipped exactly
         three = ops.roi_align_bwd(torch.tensor(g, device=dev), tr, feat.shape, cfg["scale"], cfg["sr"])
     assert three.cpu().numpy().tobytes() == O.roi_align_bwd_ordered(g, rois, feat.shape, cfg["scale"], cfg["sr"], segments=3).tobytes()
-    # the register formulation (a lane owns a pixel; the shipped route keeps the accumulators in LDS and hands the lanes work items), with
-    # the map-size-dependent and with eight channels per lane: the same bits
+    # the shipped route keeps per-roi axis tables and gives a pixel to a wave (round 5); round 4's (accumulators in LDS, the lanes handed
+    # work items) and round 3's register formulation, with the map-size-dependent and with eight channels per lane: the same bits
+    with route(ADV_ROI_BWD_LDS="1"):
+        assert torch.equal(ops.roi_align_bwd(torch.tensor(g, device=dev), tr, feat.shape, cfg["scale"], cfg["sr"]), gf)
     with route(ADV_ROI_BWD_SCALAR_ITEMS="1"):          # one channel per work item (round 3) instead of four: the same bits
         assert torch.equal(ops.roi_align_bwd(torch.tensor(g, device=dev), tr, feat.shape, cfg["scale"], cfg["sr"]), gf)
     with route(ADV_ROI_BWD_NO_STAGE="1"):              # grad_out gathered from global memory instead of the LDS-staged block

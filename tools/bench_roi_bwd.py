@@ -9,6 +9,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from eval_driving_safety_amd import data, ops, surrogates  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from bench_kernels import hooks_route  # noqa: E402
 
 
 def main():
@@ -33,19 +35,27 @@ def main():
         r = rois[idx].contiguous()
         for pooled in (7, 14):
             g = torch.randn((r.shape[0], 256, pooled, pooled), device=dev)
-            for _ in range(2):
-                ops.roi_align_bwd(g, r, (1, 256, fh, fw), 1.0 / stride, 0)
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(5):
-                ops.roi_align_bwd(g, r, (1, 256, fh, fw), 1.0 / stride, 0)
-            e1.record()
-            torch.cuda.synchronize()
+            def timed():
+                for _ in range(2):
+                    ops.roi_align_bwd(g, r, (1, 256, fh, fw), 1.0 / stride, 0)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(5):
+                    ops.roi_align_bwd(g, r, (1, 256, fh, fw), 1.0 / stride, 0)
+                e1.record()
+                torch.cuda.synchronize()
+                return e0.elapsed_time(e1) / 5
+            ms = timed()
+            with hooks_route(ADV_ROI_BWD_LDS="1"):      # round 4's route: accumulators in LDS, a tile's rois one after the other
+                same = torch.equal(ops.roi_align_bwd(g, r, (1, 256, fh, fw), 1.0 / stride, 0), ops.roi_align_bwd(g, r, (1, 256, fh, fw), 1.0 / stride, 0))
+                lds_ms = timed()
+                older = ops.roi_align_bwd(g, r, (1, 256, fh, fw), 1.0 / stride, 0)
+            same = same and torch.equal(older, ops.roi_align_bwd(g, r, (1, 256, fh, fw), 1.0 / stride, 0))
             print(json.dumps({"level": "P%d" % l, "map": [fh, fw], "pooled": pooled, "rois": int(r.shape[0]),
                               "roi_w_at_level_px_min_mean_max": [round(float(v), 2) for v in ((w[idx] / stride).min(), (w[idx] / stride).mean(), (w[idx] / stride).max())],
                               "roi_h_at_level_px_min_mean_max": [round(float(v), 2) for v in ((h[idx] / stride).min(), (h[idx] / stride).mean(), (h[idx] / stride).max())],
-                              "ms_per_call": round(e0.elapsed_time(e1) / 5, 4)}), flush=True)
+                              "ms_per_call": round(ms, 4), "r04_lds_route_ms": round(lds_ms, 4), "same_bits": bool(same)}), flush=True)
 
 
 if __name__ == "__main__":
