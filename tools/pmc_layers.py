@@ -4,8 +4,8 @@
 (weight preparation and workspace kernels have other names and are filtered by the summariser); the launch order is written to
 ``--manifest`` so that tools/summarize_pmc_layers.py can attribute dispatches to cases.
 
-cases: conv_wino on six 2D shapes and two 3D shapes, conv2d_1x1_mfma, conv2d_3x3_mfma (dilation 2), conv3d_k3_s2_mfma and
-convt3d_k3_s2_mfma on the hourglass shapes, roi_align_bwd_lds on ResNet-101-FPN-like proposals."""
+cases: conv_wino on six 2D shapes and two 3D shapes, conv_wino4 on five 2D and three 3D shapes, conv2d_1x1_mfma, conv2d_3x3_mfma (dilation 2), conv3d_k3_s2_mfma and
+convt3d_k3_s2_mfma on the hourglass shapes, roi_align_bwd_tab on ResNet-101-FPN-like proposals."""
 import argparse
 import json
 import os
@@ -50,6 +50,17 @@ def main():
         p3 = ops.Conv3dWinoPrep(wt)
         p3.u(False)
         case("wino3d %d->%d on [1,%d,%d,%d,%d]" % (c, k, c, d, h, w), "conv_wino", 2.0 * k * c * 27 * d * h * w, lambda: ops.conv3d_wino(x, p3, bias, None, True))
+    # ---- Winograd F(4x4,3x3): 2D (one and two images per tile), 3D
+    for b, c, k, h, w in ((2, 256, 256, 150, 497), (2, 128, 128, 96, 312), (2, 512, 512, 38, 125), (512, 256, 256, 14, 14), (1, 128, 128, 192, 304)):
+        x, wt, bias = rnd(b, c, h, w), rnd(k, c, 3, 3) * 0.05, rnd(k)
+        p4 = ops.ConvWino4Prep(wt)
+        p4.u(False)
+        case("wino4 2d %d->%d on [%d,%d,%d,%d]" % (c, k, b, c, h, w), "conv_wino4", 2.0 * b * k * c * 9 * h * w, lambda: ops.conv_wino4(x, p4, bias, None, True))
+    for c, k, d, h, w in ((128, 128, 96, 10, 152), (64, 64, 24, 48, 156), (32, 32, 48, 96, 312)):
+        x, wt, bias = rnd(1, c, d, h, w), rnd(k, c, 3, 3, 3) * 0.03, rnd(k)
+        p4 = ops.ConvWino4Prep(wt)
+        p4.u(False)
+        case("wino4 3d %d->%d on [1,%d,%d,%d,%d]" % (c, k, c, d, h, w), "conv_wino4", 2.0 * k * c * 27 * d * h * w, lambda: ops.conv_wino4(x, p4, bias, None, True))
     # ---- direct 2D kernels
     for b, c, k, h, w in ((2, 256, 1024, 38, 125), (2, 64, 256, 150, 497), (2, 1024, 256, 38, 125)):
         x, wt, bias = rnd(b, c, h, w), rnd(k, c, 1, 1) * 0.05, rnd(k)
@@ -78,7 +89,7 @@ def main():
     rois = torch.stack([torch.zeros(n), cx - bw / 2, cy - bh / 2, cx + bw / 2, cy + bh / 2], 1).to(dev)
     for pooled in (7, 14):
         go = rnd(n, 256, pooled, pooled)
-        case("roi_bwd 512 rois %dx%d C=256 on [1,256,150,497]" % (pooled, pooled), "roi_align_bwd_lds", 0.0, lambda: ops.roi_align_bwd(go, rois, (1, 256, 150, 497), 0.25, 0))
+        case("roi_bwd 512 rois %dx%d C=256 on [1,256,150,497]" % (pooled, pooled), "roi_align_bwd_tab", 0.0, lambda: ops.roi_align_bwd(go, rois, (1, 256, 150, 497), 0.25, 0))
     os.makedirs(os.path.dirname(os.path.abspath(args.manifest)), exist_ok=True)
     if os.environ.get("PMC_WRITE_MANIFEST", "1") == "1":
         with open(args.manifest, "w") as f:

@@ -12,7 +12,7 @@ import re
 import sys
 from collections import defaultdict
 
-KERNELS = re.compile(r"::(conv_wino|conv2d_1x1_mfma|conv2d_3x3_mfma|conv3d_k3_s2_mfma|convt3d_k3_s2_mfma|conv3d_k3_mfma|roi_align_bwd_lds)<")
+KERNELS = re.compile(r"::(conv_wino4|conv_wino|conv2d_1x1_mfma|conv2d_3x3_mfma|conv3d_k3_s2_mfma|convt3d_k3_s2_mfma|conv3d_k3_mfma|roi_align_bwd_lds)<|::(roi_align_bwd_tab)\(")
 
 
 def dispatches(src, leg, value):
@@ -25,7 +25,7 @@ def dispatches(src, leg, value):
                 continue
             did = int(r["Dispatch_Id"])
             e = rows[did]
-            e[0], e[1] = m.group(1), r["Kernel_Name"]
+            e[0], e[1] = m.group(1) or m.group(2), r["Kernel_Name"]
             if value:
                 e[2] = int(r["Grid_Size"])
                 e[3][r["Counter_Name"]] = e[3].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
@@ -67,7 +67,7 @@ def main():
             row["avg_us"] = ns / 1e3
             if c["direct_flops_per_launch"]:
                 row["direct_equiv_tflops"] = c["direct_flops_per_launch"] / ns / 1e3
-                executed = c["direct_flops_per_launch"] / (2.25 if c["kernel"] == "conv_wino" else 1.0)
+                executed = c["direct_flops_per_launch"] / {"conv_wino": 2.25, "conv_wino4": 4.0}.get(c["kernel"], 1.0)
                 row["executed_tflops"] = executed / ns / 1e3
                 row["executed_over_peak_157.3"] = executed / ns / 1e3 / 157.3
         gui = mean(p1, "GRBM_GUI_ACTIVE")
@@ -91,7 +91,7 @@ def main():
         rows.append(row)
     out = {"source": "tools/gpu_profile_layers.sh over tools/pmc_layers.py (rocprofv3 --pmc, four separate passes, + a kernel trace; the program directly after --)",
            "how": "mfma_pipe_utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8); LDS = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE; "
-                  "hbm bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024; executed = direct FLOPs / 2.25 for the Winograd kernel", "rows": rows}
+                  "hbm bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024; executed = direct FLOPs / 2.25 for the F(2x2,3x3) kernel, / 4 for the F(4x4,3x3) kernel", "rows": rows}
     with open(dst, "w") as fh:
         json.dump(out, fh, indent=1)
     for r in rows:
