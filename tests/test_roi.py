@@ -215,8 +215,8 @@ def test_hip_roi_align(cfg, route):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [0, 1, 5, 64, 65, 300, 2000])
-def test_hip_nms_exact_indices(n):
+@pytest.mark.parametrize("n", [0, 1, 5, 64, 65, 300, 2000, 4001, 6200])      # (6200 boxes: beyond the block scan's LDS image - the per-box scan)
+def test_hip_nms_exact_indices(n, route):
     from eval_driving_safety_amd import ops
     rs = np.random.RandomState(n)
     ctr = rs.rand(n, 2) * 300
@@ -230,3 +230,5 @@ def test_hip_nms_exact_indices(n):
     for thresh in (0.3, 0.5):
         keep = ops.nms(torch.tensor(boxes, device=dev).reshape(n, 4), torch.tensor(scores, device=dev), thresh)
         assert keep.cpu().numpy().tolist() == O.nms(boxes.reshape(n, 4), thresh).tolist(), (n, thresh)
+        with route(ADV_NMS_BOX_SCAN="1"):                    # round 1's scan, one box per step: the same indices
+            assert torch.equal(ops.nms(torch.tensor(boxes, device=dev).reshape(n, 4), torch.tensor(scores, device=dev), thresh), keep)

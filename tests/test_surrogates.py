@@ -252,6 +252,32 @@ def test_r101_step_on_libadvengine_convolutions_matches_miopen():
         assert float((torch.sign(grad[big]) == torch.sign(ref_grad[big])).float().mean()) > 0.995, impl
 
 
+def test_r101_merged_rpn_heads_give_the_separate_layers_outputs():
+    """rpn_heads on the Conv2dAuto path runs the class and the regression layer as one 1x1 layer to 3 + 18 channels: the forward's bits
+    are those of the two layers; the gradient w.r.t. the map agrees to float32 rounding (21 products summed in one chain instead of 3 + 18);
+    a changed weight (checkpoint load) is picked up"""
+    from eval_driving_safety_amd import surrogates
+    dev = torch.device("cuda", 0)
+    model = surrogates.StereoRcnnR101(seed=2, rois_per_image=32, blocks=(1, 1, 1, 1)).to(dev).eval()
+    gen = torch.Generator().manual_seed(1)
+    both = torch.relu(torch.randn((1, 1024, 38, 125), generator=gen)).to(dev).requires_grad_(True)
+    try:
+        surrogates.FoldedConv.impl = "auto"
+        for attempt in range(2):
+            s, d = model.rpn_heads(both)
+            s2, d2 = model.rpn_scores(both), model.rpn_deltas(both)
+            assert torch.equal(s, s2) and torch.equal(d, d2)
+            gs, gd = torch.randn(s.shape, generator=gen).to(dev), torch.randn(d.shape, generator=gen).to(dev)
+            g1, = torch.autograd.grad((s * gs).sum() + (d * gd).sum(), both)
+            g2, = torch.autograd.grad((s2 * gs).sum() + (d2 * gd).sum(), both)
+            assert float((g1 - g2).abs().max()) <= 1e-5 * float(g2.abs().max())
+            with torch.no_grad():
+                model.rpn_reg.weight.mul_(1.5)                  # the merged copy follows (the layer's own prepared weights are dropped by hand,
+            model.rpn_reg._prep = None                          # as checkpoints.load_stereo_rcnn does)
+    finally:
+        surrogates.FoldedConv.impl = "miopen"
+
+
 def test_r101_step_is_reproducible_bit_for_bit():
     """the R101 layer-list step twice from the same input: the same bytes.  What makes that hold: RoIAlign's backward is this
     package's ordered one (no atomics), the FPN / keypoint bilinear up-samplings go through adapters._BilinearUp (torch's own backward
