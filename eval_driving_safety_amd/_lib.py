@@ -23,7 +23,7 @@ ADV_ELAUNCH = -5
 ADV_SPACE_AFFINE = 0
 ADV_SPACE_IDENTITY = 1
 ADV_SPACE_AFFINE_RCP = 2
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class AdvSpace(ctypes.Structure):
@@ -101,6 +101,8 @@ SIGNATURES = {
     "adv_grid_sample3d_bwd_ws_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "adv_sigmoid_focal_loss_f32": [_P, _P, _P, _P, _L, _I, _F, _F, _P],
     "adv_relu_backward_f32": [_P, _P, _P, _L, _P],
+    "adv_stem_pool_fwd_f32": [_P, _P, _P, _P, _L, _I, _I, _I, _P],
+    "adv_stem_pool_bwd_f32": [_P, _P, _P, _L, _I, _I, _P],
     "adv_bev_fold_f32": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "adv_bev_fold_bwd_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "adv_bilinear_up_f32": [_P, _P, _L, _I, _I, _I, _I, _P],

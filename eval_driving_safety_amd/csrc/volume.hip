@@ -533,6 +533,62 @@ __global__ __launch_bounds__(kBlock) void relu_backward_kernel(const float* __re
   for (long long i = 4 * n4 + blockIdx.x * static_cast<long long>(kBlock) + threadIdx.x; i < n; i += stride) out[i] = y[i] > 0.0f ? grad[i] : 0.0f;
 }
 
+// ---- the ResNet stem's tail in one pass each way: y = maxpool(3x3, stride 2, padding 1)(relu(t + bias)) straight from the convolution's
+//      output t, and the gradient w.r.t. t straight from the gradient w.r.t. y.  torch runs a bias pass, a ReLU pass, the pooling, and
+//      backward the pooling's gather (0.25 ms on [2,64,300,994]) and threshold_backward - five passes over a 305 MB tensor per step
+//      (profiles/r05_r101_small_ops.json).  max(relu(v)) = relu(max(v)) and rounding is monotone, so the value is torch's; the window is
+//      scanned row-major and a later element replaces the maximum only if it is greater (or NaN): torch's argmax.  The code byte is the
+//      argmax's position in the window (0..8), or kNoGrad where the maximum is <= 0: relu's backward passes nothing there, so the backward
+//      needs neither t nor y.  A pixel's gradient sums the outputs that chose it in (oy, ox) order, as torch's gather does.
+constexpr unsigned char kNoGrad = 15;
+
+__global__ __launch_bounds__(kBlock) void stem_pool_fwd(const float* __restrict__ t, const float* __restrict__ bias, float* __restrict__ y,
+                                                        unsigned char* __restrict__ code, int C, int H, int W, int OH, int OW, long long total) {
+  const long long stride = static_cast<long long>(gridDim.x) * kBlock;
+  for (long long i = blockIdx.x * static_cast<long long>(kBlock) + threadIdx.x; i < total; i += stride) {
+    const int ox = static_cast<int>(i % OW), oy = static_cast<int>((i / OW) % OH);
+    const long long plane = i / (static_cast<long long>(OW) * OH);
+    const float b = bias ? bias[plane % C] : 0.0f;
+    const float* tp = t + plane * H * W;
+    float m = -__builtin_inff();
+    int arg = -1;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = 2 * oy - 1 + ky;
+      if (iy < 0 || iy >= H) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = 2 * ox - 1 + kx;
+        if (ix < 0 || ix >= W) continue;
+        const float v = tp[static_cast<long long>(iy) * W + ix] + b;
+        if (arg < 0 || v > m || v != v) m = v, arg = ky * 3 + kx;
+      }
+    }
+    const bool pass = m > 0.0f || m != m;
+    y[i] = pass ? m : 0.0f;
+    code[i] = pass ? static_cast<unsigned char>(arg) : kNoGrad;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void stem_pool_bwd(const float* __restrict__ gy, const unsigned char* __restrict__ code, float* __restrict__ gt,
+                                                        int H, int W, int OH, int OW, long long total) {
+  const long long stride = static_cast<long long>(gridDim.x) * kBlock;
+  for (long long i = blockIdx.x * static_cast<long long>(kBlock) + threadIdx.x; i < total; i += stride) {
+    const int x = static_cast<int>(i % W), yy = static_cast<int>((i / W) % H);
+    const long long plane = i / (static_cast<long long>(W) * H);
+    const float* gp = gy + plane * OH * OW;
+    const unsigned char* cp = code + plane * OH * OW;
+    float acc = 0.0f;
+    const int oy_hi = min((yy + 1) / 2, OH - 1), ox_hi = min((x + 1) / 2, OW - 1);
+    for (int oy = yy / 2; oy <= oy_hi; ++oy)
+      for (int ox = x / 2; ox <= ox_hi; ++ox) {
+        const int k = (yy - (2 * oy - 1)) * 3 + (x - (2 * ox - 1));
+        if (cp[oy * OW + ox] == k) acc = acc + gp[oy * OW + ox];
+      }
+    __builtin_nontemporal_store(acc, gt + i);
+  }
+}
+
 inline bool aligned4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3u) == 0; }
 
 }  // namespace
@@ -709,6 +765,32 @@ int adv_bev_fold_bwd_f32(const float* grad_out, const float* mask, float* grad_v
   if (blocks > 65535LL * 16) blocks = 65535LL * 16;
   hipLaunchKernelGGL(bev_fold_bwd, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), grad_out, mask, grad_v, c, z, y, x,
                      pool, y / pool, total);
+  return adv_internal_finish_launch();
+}
+
+int adv_stem_pool_fwd_f32(const float* t, const float* bias, float* y, uint8_t* code, int64_t planes, int c, int h, int w, adv_stream_t stream) {
+  if (!t || !y || !code || planes < 0 || c < 1 || h < 1 || w < 1 || static_cast<const void*>(t) == static_cast<const void*>(y)) return ADV_EINVAL;
+  if (planes == 0) return ADV_OK;
+  if (!aligned4(t) || !aligned4(y) || (bias && !aligned4(bias))) return ADV_EALIGN;
+  const int oh = (h - 1) / 2 + 1, ow = (w - 1) / 2 + 1;
+  const long long total = static_cast<long long>(planes) * oh * ow;
+  long long blocks = (total + kBlock - 1) / kBlock;
+  if (blocks > 65535LL * 16) blocks = 65535LL * 16;
+  hipLaunchKernelGGL(stem_pool_fwd, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), t, bias, y, code, c, h, w, oh, ow,
+                     total);
+  return adv_internal_finish_launch();
+}
+
+int adv_stem_pool_bwd_f32(const float* grad_y, const uint8_t* code, float* grad_t, int64_t planes, int h, int w, adv_stream_t stream) {
+  if (!grad_y || !code || !grad_t || planes < 0 || h < 1 || w < 1 || grad_y == grad_t) return ADV_EINVAL;
+  if (planes == 0) return ADV_OK;
+  if (!aligned4(grad_y) || !aligned4(grad_t)) return ADV_EALIGN;
+  const int oh = (h - 1) / 2 + 1, ow = (w - 1) / 2 + 1;
+  const long long total = static_cast<long long>(planes) * h * w;
+  long long blocks = (total + kBlock - 1) / kBlock;
+  if (blocks > 65535LL * 16) blocks = 65535LL * 16;
+  hipLaunchKernelGGL(stem_pool_bwd, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), grad_y, code, grad_t, h, w, oh, ow,
+                     total);
   return adv_internal_finish_launch();
 }
 

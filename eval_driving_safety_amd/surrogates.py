@@ -645,7 +645,15 @@ class StereoRcnnR101(StereoRcnnShaped):
 
     # -- backbone + pyramid: both eyes as one batch of two ------------------------------------------------------------------
     def pyramid(self, im):
-        x = F.max_pool2d(self.stem(im, relu=True), 3, stride=2, padding=1)
+        if im.is_cuda and FoldedConv.impl in ("hip", "auto"):
+            # bias + ReLU + the 3x3 / stride-2 max-pooling as ONE pass over the 7x7 convolution's output (ops.StemPool, and one pass back)
+            # instead of torch's three forward and two backward passes over the 305 MB map: the same values and the same gradient
+            from . import ops
+            st = self.stem
+            st.flops += 2 * im.shape[0] * st.weight.shape[0] * st.weight.shape[1] * 49 * ((im.shape[2] - 1) // 2 + 1) * ((im.shape[3] - 1) // 2 + 1)
+            x = ops.StemPool.apply(F.conv2d(im, st.weight, None, 2, 3), st.bias)
+        else:
+            x = F.max_pool2d(self.stem(im, relu=True), 3, stride=2, padding=1)
         c2 = _run_stage(self.layer1, x)
         c3 = _run_stage(self.layer2, c2)
         c4 = _run_stage(self.layer3, c3)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ADV_ABI_VERSION 9
+#define ADV_ABI_VERSION 10
 #define ADV_API __attribute__((visibility("default"))) /* the library is built with -fvisibility=hidden */
 #define ADV_CHANNELS 3
 
@@ -544,6 +544,15 @@ ADV_API int adv_conv3d_wino4_f32(const float* x, const float* w_prep, const floa
  *     library (bias / residual NULL = skipped; residual laid out like y, must not be y).  planes <= 65535. */
 ADV_API int adv_bias_act_f32(float* y, const float* bias, const float* residual, int64_t planes, int c, int64_t hw, int relu,
                              adv_stream_t stream);
+
+/* The ResNet stem's tail (replaces relu + nn.MaxPool2d(kernel_size=3, stride=2, padding=1) behind the 7x7 convolution, upstream
+ *     lib/model/stereo_rcnn/resnet.py [UPSTREAM-UNVERIFIED path]; torch: F.max_pool2d(F.relu(t + bias), 3, 2, 1)):
+ *     y [planes][oh][ow] = maxpool(relu(t [planes][h][w] + bias[plane % c])), oh = (h - 1) / 2 + 1, ow likewise; bias NULL = none.
+ *     code [planes][oh][ow] bytes: the argmax's position in the 3x3 window (row-major 0..8, first maximum), 15 where relu passes no gradient.
+ *   _bwd: grad_t [planes][h][w] from grad_y and the code alone (each pixel sums the outputs that chose it, in (oy, ox) order - torch's). */
+ADV_API int adv_stem_pool_fwd_f32(const float* t, const float* bias, float* y, uint8_t* code, int64_t planes, int c, int h, int w,
+                                  adv_stream_t stream);
+ADV_API int adv_stem_pool_bwd_f32(const float* grad_y, const uint8_t* code, float* grad_t, int64_t planes, int h, int w, adv_stream_t stream);
 
 /* out[i] = y[i] > 0 ? grad[i] : 0  (the backward of a ReLU fused into a convolution's epilogue; out may alias grad). */
 ADV_API int adv_relu_backward_f32(const float* grad, const float* y, float* out, int64_t n, adv_stream_t stream);

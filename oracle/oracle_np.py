@@ -747,3 +747,37 @@ def sigmoid_focal_loss(logits, targets, gamma=2.0, alpha=0.25):
     grad = np.where(pos, alpha * (1 - p) ** gamma * (gamma * p * lp - (1 - p)), 0) + \
         np.where(neg, (1 - alpha) * p ** gamma * (p - gamma * (1 - p) * lq), 0)
     return loss, grad
+
+
+def stem_pool(t, bias=None):
+    """y = maxpool(3x3, stride 2, padding 1)(relu(t + bias)) and the code bytes of csrc/volume.hip:stem_pool_fwd - the tail of the ResNet
+    stem (upstream: ``self.relu`` + ``self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)`` behind conv1 / bn1 of the
+    fpn.pytorch-family resnet.py the Stereo R-CNN backbone is built from [UPSTREAM-UNVERIFIED path]).  Window scanned row-major, a later
+    element wins only if greater: torch's argmax; code 15 where the maximum is <= 0 (relu passes no gradient).  Test infrastructure."""
+    t = np.asarray(t, np.float32)
+    b, c, h, w = t.shape
+    v = t if bias is None else (t + np.asarray(bias, np.float32)[None, :, None, None]).astype(np.float32)
+    oh, ow = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    pad = np.full((b, c, 2 * oh + 1, 2 * ow + 1), -np.inf, np.float32)
+    pad[:, :, 1:h + 1, 1:w + 1] = v
+    stack = np.stack([pad[:, :, ky:ky + 2 * oh:2, kx:kx + 2 * ow:2] for ky in range(3) for kx in range(3)], 0)
+    arg = np.argmax(stack, 0)                     # the first maximum in row-major window order
+    m = np.take_along_axis(stack, arg[None], 0)[0]
+    keep = m > 0
+    return np.where(keep, m, np.float32(0)).astype(np.float32), np.where(keep, arg, 15).astype(np.uint8)
+
+
+def stem_pool_bwd(grad_y, code, in_hw):
+    """the gradient w.r.t. t: every pixel sums, in (oy, ox) order, the outputs whose code points at it"""
+    g = np.asarray(grad_y, np.float32)
+    b, c, oh, ow = g.shape
+    h, w = in_hw
+    out = np.zeros((b, c, h + 2, w + 3), np.float32)          # padded by one on the low side (window offset -1), room on the high side
+    for oy in range(oh):                                       # ascending (oy, ox): float32 sums in the kernel's order
+        for ox in range(ow):
+            k = code[:, :, oy, ox]
+            live = k < 9
+            ky, kx = k // 3, k % 3
+            bi, ci = np.nonzero(live)
+            out[bi, ci, 2 * oy + ky[live], 2 * ox + kx[live]] += g[bi, ci, oy, ox]
+    return out[:, :, 1:h + 1, 1:w + 1].copy()

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "libadvengine.so lacks %s" % name
     assert sorted(_lib.EXPORTED) == declared, "ctypes binding and header disagree"
-    assert lib.adv_abi_version() == _lib.ABI_VERSION == 9
+    assert lib.adv_abi_version() == _lib.ABI_VERSION == 10
     assert lib.adv_strerror(-22) == b"invalid argument"
 
 
@@ -59,7 +59,7 @@ def test_header_is_valid_c99(tmp_path):
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
                     "-L", lib_dir, "-l:libadvengine.so", "-Wl,-rpath," + lib_dir], check=True)
     out = subprocess.run([str(exe)], stdout=subprocess.PIPE, text=True)
-    assert out.returncode == 0 and out.stdout.split() == ["9", "0", "0.229"]
+    assert out.returncode == 0 and out.stdout.split() == ["10", "0", "0.229"]
 
 
 def test_space_constants_are_the_reference_constants():
@@ -494,7 +494,7 @@ def test_ops_surface_is_complete():
              "Conv3dK3", "Conv3dK3S2", "ConvTranspose3dK3S2",
              "dense_align_cost", "dense_align_argmin", "dense_align_search", "box_depth_offsets", "dense_align",
              "depth_regress", "depth_regress_bwd", "DepthRegress", "grid_sample3d", "GridSamplePlan", "grid_sample3d_bwd", "GridSample3d",
-             "sigmoid_focal_loss", "SigmoidFocalLoss", "relu_backward",
+             "sigmoid_focal_loss", "SigmoidFocalLoss", "relu_backward", "stem_pool", "stem_pool_bwd", "StemPool", "conv_wino4", "ConvWino4Prep",
              "conv2d_supported", "Conv2dPrep", "conv2d", "conv2d_dgrad", "Conv2d", "Conv2dAuto", "bias_act_", "nms_padded"]
     missing = [n for n in names if not hasattr(ops, n)]
     assert not missing, missing
