@@ -6,19 +6,24 @@
 //   2D layers: q = input channel.   3x3x3 layers: the transform in the (H, W) plane, the depth taps inside the contraction, q = (kd, c).
 //
 // Why the design differs from wino2d.hip.  Thirty-six products of a (channel block) x (patch block) tile need 36 accumulator tiles.  With
-// 16x16 tiles and two waves per SIMD (wino2d's scheme) that is 144 registers per 16 x 16 block and two operand reads per matrix
-// instruction - the LDS, not the matrix pipe, would set the pace.  Here a workgroup is FOUR waves, one per SIMD, each with the whole
-// 512-register file: wave w owns the nine positions k = w, w + 4, ..., w + 32 for ALL 64 output channels x 32 patches of the tile
-// (18 accumulators of 32 x 32 = 288 registers), one B operand shared by the two channel blocks: three LDS reads per two 64-cycle matrix
-// instructions, a quarter of the operand traffic per matrix cycle.  The 36 values of one (channel, patch) then sit in four different waves:
-// after the contraction they are exchanged through LDS (four rounds of 16 channels, 74 KB each) and every thread transforms two
-// (channel, patch) items per round - ~2 us per tile against 60 us of products at 256 channels.
+// 16x16 tiles and wino2d's scheme (every wave all positions of its own block) that is 144 registers per 16 x 16 block and two operand reads
+// per matrix instruction - the LDS, not the matrix pipe, would set the pace.  Here the POSITIONS are dealt to the waves: a workgroup is
+// EIGHT waves (two per SIMD, 256 registers each); with 64 output channels per workgroup (CB = 2) waves 0-3 carry four positions each
+// (k = w + 4 n) and run the input transform, waves 4-7 five each; every wave holds its positions for ALL 64 channels x 32 patches of the
+// tile (8 / 10 accumulators of 32 x 32 = 128 / 160 registers), one B operand shared by the two channel blocks: three LDS reads per two
+// 64-cycle matrix instructions, a quarter of wino2d's operand traffic per matrix cycle.  With 32 output channels (CB = 1) the tile is 32
+// channels x 64 patches and all eight waves transform.  (A first version - four waves, one per SIMD, nine positions = 288 accumulator
+// registers each - kept part of the accumulators in AGPRs and shuffled them around every matrix instruction; two waves per SIMD also give
+// the pipe something to run while the other wave transforms.)  The 36 values of one (channel, patch) sit in eight different waves after
+// the contraction: they are exchanged through LDS in rounds of 16 channels and every thread transforms one or two (channel, patch) items
+// per round (prologue + epilogue: 13 % of a tile at 256 channels, profiles/r05_wino4_phases.jsonl).
 //
 //   per stage of KC = 4 q:   input tile [4][4 PR + 2][LWP]   global -> registers (buffer loads, two sets deep) -> LDS
-//                            U = G g G^T of the stage [36][4][64]   global -> LDS by LDS-DMA, each wave ITS OWN nine positions (1 KiB each)
-//                            V = B^T d B [36][4][32]   256 threads: two per (q, patch), three of the six rows of V each
-//   one barrier per stage, two buffers of everything, side work woven between the matrix instructions (one wave per SIMD: whatever
-//   stalls the wave stalls the pipe).
+//                            U = G g G^T of the stage [36][4][64]   global -> LDS by LDS-DMA, each wave ITS OWN positions (1 KiB per instruction)
+//                            V = B^T d B [36][4][32]   the transform waves: two threads per (q, patch), three of the six rows of V each
+//   one "s_waitcnt; s_barrier" per stage (not __syncthreads(): its fence would drain the loads in flight), two buffers of everything, and
+//   the side work woven between the matrix instructions in half-steps (one matrix instruction per scheduling step).
+//   PAIR: two images of at most 15 columns side by side in one 32-column tile (the RoI heads' 14 x 14 maps).
 //
 // Order of float operations (oracle/oracle.c orc_conv_wino4 restates it bit for bit): the transforms' expressions as written below
 // (explicit fmaf where a multiply feeds an add), each M_k one fmaf chain over q ascending starting from 0 (the matrix instruction is a

@@ -487,9 +487,13 @@ class FoldedConv(nn.Module):
         return FoldedConv.impl == "auto" and self.stride == 1 and ((self.k == 1 and self.padding == 0) or (self.k == 3 and self.padding == 1)) and \
             (FoldedConv.hip_kernels is None or self.k in FoldedConv.hip_kernels)
 
-    def forward(self, x, relu=False, residual=None, chain_in=False, skip_out=False):
-        ho = (x.shape[2] + 2 * self.padding - self.k) // self.stride + 1
-        wo = (x.shape[3] + 2 * self.padding - self.k) // self.stride + 1
+    def forward(self, x, relu=False, residual=None, chain_in=False, skip_out=False, presampled=False):
+        """``presampled``: a strided 1x1 layer handed ``x[:, :, ::s, ::s]`` already (a block's first layer and its projection share one
+        sub-sampled copy - and one scatter of the summed gradient back - instead of one each)"""
+        own_stride = 1 if presampled else self.stride
+        assert not presampled or (self.k == 1 and self.padding == 0)
+        ho = (x.shape[2] + 2 * self.padding - self.k) // own_stride + 1
+        wo = (x.shape[3] + 2 * self.padding - self.k) // own_stride + 1
         self.flops += 2 * x.shape[0] * self.weight.shape[0] * self.weight.shape[1] * self.k * self.k * ho * wo
         if FoldedConv.trace is not None:
             FoldedConv.trace.append((self.weight.shape[1], self.weight.shape[0], self.k, self.stride, self.padding, x.shape[0], x.shape[2], x.shape[3]))
@@ -502,7 +506,7 @@ class FoldedConv(nn.Module):
             return (F.relu(y) if relu else y)[:, :, None, None]
         if FoldedConv.impl in ("hip", "auto"):
             from . import ops
-            stride = self.stride
+            stride = own_stride
             if self.k == 1 and stride == 2 and self.padding == 0 and x.is_cuda and (FoldedConv.hip_kernels is None or 1 in FoldedConv.hip_kernels):
                 # a strided 1x1 layer reads every other pixel of every other row: sub-sample (one strided copy; its backward scatters into
                 # zeros, deterministically) and run the GEMM kernel on what is left - the layer is this package's, not MIOpen's
@@ -516,7 +520,7 @@ class FoldedConv(nn.Module):
                 assert not chain_in and relu != "consumer"
                 return ops.Conv2d.apply(x, self._prep, self.bias, residual, relu)
         assert not chain_in and relu != "consumer" and not skip_out, "chained ReLU masks / fused skip gradients need the Conv2dAuto path"
-        y = F.conv2d(x, self.weight, self.bias, self.stride, self.padding)
+        y = F.conv2d(x, self.weight, self.bias, own_stride, self.padding)
         if residual is not None:
             y = y + residual
         return F.relu(y) if relu else y
@@ -550,8 +554,14 @@ class _FoldedBottleneck(nn.Module):
             y, idt = self.conv1(x, relu="consumer" if c12 else True, chain_in=mask_x, skip_out=True)
         else:
             assert not mask_x
-            idt = x if self.down is None else self.down(x)
-            y = self.conv1(x, relu="consumer" if c12 else True)
+            pre = self.down is not None and self.conv1.stride == 2 and self.down.stride == 2 and x.is_cuda and FoldedConv.impl in ("hip", "auto")
+            if pre:
+                # the stage's first block: its first layer and its projection are both 1x1 / stride 2 on x - ONE sub-sampled copy for the two
+                # (and backward one zero-filled scatter of their summed gradient instead of two and an addition over the full-size map:
+                # 0.3 ms at C2, profiles/r05_r101_small_ops.json)
+                x = x[:, :, ::2, ::2].contiguous()
+            idt = x if self.down is None else self.down(x, presampled=pre)
+            y = self.conv1(x, relu="consumer" if c12 else True, presampled=pre)
         y = self.conv2(y, relu="consumer" if c23 else True, chain_in=c12)
         return self.conv3(y, relu="consumer" if defer_mask else True, residual=idt, chain_in=c23)
 
