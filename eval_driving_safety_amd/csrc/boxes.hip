@@ -1,0 +1,141 @@
+// Box arithmetic of the proposal / target stage of a Stereo R-CNN step, one kernel per chain of torch one-liners (round 5).
+// The reference reaches this code inside the detector call of attack/Stereo-RCNN/pgd_attack.py:156 (upstream lib/model/rpn/
+// bbox_transform.py: bbox_overlaps, bbox_transform, bbox_transform_inv, clip_boxes [UPSTREAM-UNVERIFIED paths]); this package's layer-list
+// graph (surrogates.py) wrote them as ~15 element-wise torch operators each - 3-5 us per launch, a few hundred launches per step.
+// Every kernel evaluates the SAME float32 expressions in the same order as those operators (no contraction: -ffp-contract=off; logf / expf
+// are the device library's, as in torch's kernels), so the results are the operators' bit for bit on the device.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "adv_internal.h"
+#include "advengine.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+struct Box {
+  float x1, y1, x2, y2;
+};
+__device__ __forceinline__ Box load_box(const float* p) {
+  const float4 v = *reinterpret_cast<const float4*>(p);
+  return Box{v.x, v.y, v.z, v.w};
+}
+
+// surrogates._iou: legacy +1 areas
+__device__ __forceinline__ float iou_of(const Box& a, const Box& b) {
+  const float ltx = fmaxf(a.x1, b.x1), lty = fmaxf(a.y1, b.y1), rbx = fminf(a.x2, b.x2), rby = fminf(a.y2, b.y2);
+  const float w = fmaxf(rbx - ltx + 1.0f, 0.0f), h = fmaxf(rby - lty + 1.0f, 0.0f);
+  const float inter = w * h;
+  const float area_a = (a.x2 - a.x1 + 1.0f) * (a.y2 - a.y1 + 1.0f), area_b = (b.x2 - b.x1 + 1.0f) * (b.y2 - b.y1 + 1.0f);
+  return inter / (area_a + area_b - inter);
+}
+
+// one lane per box of ``a``: its IoU with every box of ``b`` (written to iou[N][M] if asked for), the largest and the index of the FIRST largest
+__global__ __launch_bounds__(kBlock) void box_iou_rows(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ iou,
+                                                      float* __restrict__ best, long long* __restrict__ arg, long long n, int m) {
+  const long long i = blockIdx.x * static_cast<long long>(kBlock) + threadIdx.x;
+  if (i >= n) return;
+  const Box bi = load_box(a + 4 * i);
+  float bv = 0.0f;
+  long long bj = 0;
+  for (int j = 0; j < m; ++j) {
+    const float v = iou_of(bi, load_box(b + 4 * j));
+    if (iou) iou[i * m + j] = v;
+    if (j == 0 || v > bv || (v != v && bv == bv)) bv = v, bj = j;      // (torch.max: the first maximum; a NaN wins)
+  }
+  best[i] = bv;
+  arg[i] = bj;
+}
+
+struct Enc {
+  float dx, dy, dw, dh;
+};
+// surrogates._encode
+__device__ __forceinline__ Enc encode(const Box& s, const Box& d) {
+  const float sw = s.x2 - s.x1 + 1.0f, sh = s.y2 - s.y1 + 1.0f;
+  const float sx = s.x1 + 0.5f * sw, sy = s.y1 + 0.5f * sh;
+  const float dw = d.x2 - d.x1 + 1.0f, dh = d.y2 - d.y1 + 1.0f;
+  const float dx = d.x1 + 0.5f * dw, dy = d.y1 + 0.5f * dh;
+  return Enc{(dx - sx) / sw, (dy - sy) / sh, logf(dw / sw), logf(dh / sh)};
+}
+
+// out[i] = (encode(src_i, gt_l[arg_i]), encode(src_r_i, gt_r[arg_i]).dx, .dw): the six regression targets of a stereo box pair (src_r = src for anchors)
+__global__ __launch_bounds__(kBlock) void box_encode6(const float* __restrict__ src, const float* __restrict__ src_r, const float* __restrict__ gt_l, const float* __restrict__ gt_r,
+                                                     const long long* __restrict__ arg, float* __restrict__ out, long long n, int m) {
+  const long long i = blockIdx.x * static_cast<long long>(kBlock) + threadIdx.x;
+  if (i >= n) return;
+  long long j = arg[i];
+  j = j < 0 ? 0 : (j >= m ? m - 1 : j);
+  const Enc l = encode(load_box(src + 4 * i), load_box(gt_l + 4 * j)), r = encode(load_box(src_r + 4 * i), load_box(gt_r + 4 * j));
+  float* o = out + 6 * i;
+  o[0] = l.dx, o[1] = l.dy, o[2] = l.dw, o[3] = l.dh, o[4] = r.dx, o[5] = r.dw;
+}
+
+// surrogates._decode + the clip to the image
+__device__ __forceinline__ Box decode_clip(const Box& s, float d0, float d1, float d2, float d3, float wmax, float hmax) {
+  const float sw = s.x2 - s.x1 + 1.0f, sh = s.y2 - s.y1 + 1.0f;
+  const float sx = s.x1 + 0.5f * sw, sy = s.y1 + 0.5f * sh;
+  const float cx = d0 * sw + sx, cy = d1 * sh + sy;
+  const float w = expf(fminf(d2, 4.0f)) * sw, h = expf(fminf(d3, 4.0f)) * sh;
+  Box o{cx - 0.5f * w, cy - 0.5f * h, cx + 0.5f * w - 1.0f, cy + 0.5f * h - 1.0f};
+  o.x1 = fminf(fmaxf(o.x1, 0.0f), wmax), o.x2 = fminf(fmaxf(o.x2, 0.0f), wmax);
+  o.y1 = fminf(fmaxf(o.y1, 0.0f), hmax), o.y2 = fminf(fmaxf(o.y2, 0.0f), hmax);
+  return o;
+}
+
+// left = decode(a, d[0..3]), right = decode(a, (d4, d1, d5, d3)), both clipped to [0, W-1] x [0, H-1]; big = both wide and the left one high enough
+__global__ __launch_bounds__(kBlock) void box_decode_stereo(const float* __restrict__ anchors, const float* __restrict__ d, float* __restrict__ left,
+                                                           float* __restrict__ right, long long* __restrict__ big, long long n, float wmax, float hmax,
+                                                           float min_size) {
+  const long long i = blockIdx.x * static_cast<long long>(kBlock) + threadIdx.x;
+  if (i >= n) return;
+  const Box s = load_box(anchors + 4 * i);
+  const float* di = d + 6 * i;
+  const Box l = decode_clip(s, di[0], di[1], di[2], di[3], wmax, hmax), r = decode_clip(s, di[4], di[1], di[5], di[3], wmax, hmax);
+  *reinterpret_cast<float4*>(left + 4 * i) = float4{l.x1, l.y1, l.x2, l.y2};
+  *reinterpret_cast<float4*>(right + 4 * i) = float4{r.x1, r.y1, r.x2, r.y2};
+  if (big) big[i] = (l.x2 - l.x1 + 1.0f >= min_size && l.y2 - l.y1 + 1.0f >= min_size && r.x2 - r.x1 + 1.0f >= min_size) ? 1 : 0;
+}
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline bool al8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; }
+inline bool al4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3u) == 0; }
+inline unsigned blocks_for(long long n) { return static_cast<unsigned>((n + kBlock - 1) / kBlock); }
+
+}  // namespace
+
+extern "C" {
+
+int adv_box_iou_rows_f32(const float* a, const float* b, float* iou, float* best, int64_t* arg, int64_t n, int m, adv_stream_t stream) {
+  if (!a || !b || !best || !arg || n < 0 || m < 1 || n > (1LL << 40)) return ADV_EINVAL;
+  if (n == 0) return ADV_OK;
+  if (!al16(a) || !al16(b) || !al4(best) || !al8(arg) || (iou && !al4(iou))) return ADV_EALIGN;
+  hipLaunchKernelGGL(box_iou_rows, dim3(blocks_for(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), a, b, iou, best,
+                     reinterpret_cast<long long*>(arg), static_cast<long long>(n), m);
+  return adv_internal_finish_launch();
+}
+
+int adv_box_encode6_f32(const float* src, const float* src_right, const float* gt_left, const float* gt_right, const int64_t* arg, float* out,
+                        int64_t n, int m, adv_stream_t stream) {
+  if (!src || !gt_left || !gt_right || !arg || !out || n < 0 || m < 1) return ADV_EINVAL;
+  if (n == 0) return ADV_OK;
+  if (!src_right) src_right = src;
+  if (!al16(src) || !al16(src_right) || !al16(gt_left) || !al16(gt_right) || !al8(arg) || !al4(out)) return ADV_EALIGN;
+  hipLaunchKernelGGL(box_encode6, dim3(blocks_for(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), src, src_right, gt_left, gt_right,
+                     reinterpret_cast<const long long*>(arg), out, static_cast<long long>(n), m);
+  return adv_internal_finish_launch();
+}
+
+int adv_box_decode_stereo_f32(const float* anchors, const float* deltas, float* left, float* right, int64_t* big, int64_t n, float width,
+                              float height, float min_size, adv_stream_t stream) {
+  if (!anchors || !deltas || !left || !right || n < 0 || left == right) return ADV_EINVAL;
+  if (n == 0) return ADV_OK;
+  if (!al16(anchors) || !al4(deltas) || !al16(left) || !al16(right) || (big && !al8(big))) return ADV_EALIGN;
+  hipLaunchKernelGGL(box_decode_stereo, dim3(blocks_for(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), anchors, deltas, left, right,
+                     reinterpret_cast<long long*>(big), static_cast<long long>(n), width - 1.0f, height - 1.0f, min_size);
+  return adv_internal_finish_launch();
+}
+
+}  // extern "C"

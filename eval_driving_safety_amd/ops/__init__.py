@@ -22,5 +22,6 @@ from .conv2d import *       # noqa: F401,F403
 from .wino4 import *       # noqa: F401,F403
 from .align import *       # noqa: F401,F403
 from .volume import *       # noqa: F401,F403
+from .boxes import *       # noqa: F401,F403
 
-SOURCES = tuple(__import__("os").path.join(__import__("os").path.dirname(__file__), n + ".py") for n in ("_base", "elementwise", "pixel", "psv", "roi", "conv3d", "conv2d", "wino4", "align", "volume"))
+SOURCES = tuple(__import__("os").path.join(__import__("os").path.dirname(__file__), n + ".py") for n in ("_base", "elementwise", "pixel", "psv", "roi", "conv3d", "conv2d", "wino4", "align", "volume", "boxes"))

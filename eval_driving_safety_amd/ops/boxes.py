@@ -1,0 +1,62 @@
+"""Box arithmetic of the proposal / target stage (csrc/boxes.hip): IoU rows with their maxima, the six stereo regression targets, decoding +
+clipping of stereo proposals - each a chain of ~15 torch one-liners as one launch, the same float32 expressions in the same order.
+Part of the ``ops`` package."""
+from ._base import *       # noqa: F401,F403
+
+
+def _boxes(t, name, cols=4):
+    b = _feat(t.contiguous(), name)
+    if b.dim() != 2 or b.shape[1] != cols:
+        raise ValueError("%s must be [N,%d]" % (name, cols))
+    return b
+
+
+def box_iou_rows(a, b, want_matrix=True):
+    """a [N,4] against b [M,4] (M >= 1), legacy +1 areas -> (iou [N,M] or None, best [N], arg [N] int64: the first maximum of each row)"""
+    aa, bb = _boxes(a, "a"), _boxes(b, "b")
+    n, m = aa.shape[0], bb.shape[0]
+    if m < 1:
+        raise ValueError("b must hold at least one box")
+    iou = torch.empty((n, m), dtype=torch.float32, device=aa.device) if want_matrix else None
+    best = torch.empty((n,), dtype=torch.float32, device=aa.device)
+    arg = torch.empty((n,), dtype=torch.int64, device=aa.device)
+    if n:
+        with _on(aa):
+            _lib.call("adv_box_iou_rows_f32", _ptr(aa), _ptr(bb), None if iou is None else _ptr(iou), _ptr(best), _ptr(arg), n, m, _stream(aa))
+    return iou, best, arg
+
+
+def box_encode6(src, gt_left, gt_right, arg, src_right=None):
+    """[N,6]: (dx, dy, log dw, log dh) from src onto gt_left[arg] and (dx, log dw) from src_right (default: src) onto gt_right[arg]"""
+    s, gl, gr = _boxes(src, "src"), _boxes(gt_left, "gt_left"), _boxes(gt_right, "gt_right")
+    sr = None if src_right is None else _boxes(src_right, "src_right")
+    if sr is not None and sr.shape != s.shape:
+        raise ValueError("src_right must have src's shape")
+    if gl.shape != gr.shape or gl.shape[0] < 1 or arg.dtype != torch.int64 or arg.shape != (s.shape[0],) or arg.device != s.device:
+        raise ValueError("gt_left / gt_right must be [M,4] with M >= 1, arg int64 [N] on src's device")
+    out = torch.empty((s.shape[0], 6), dtype=torch.float32, device=s.device)
+    if s.shape[0]:
+        ar = arg.contiguous()
+        with _on(s):
+            _lib.call("adv_box_encode6_f32", _ptr(s), None if sr is None else _ptr(sr), _ptr(gl), _ptr(gr), _ptr(ar), _ptr(out), s.shape[0], gl.shape[0], _stream(s))
+    return out
+
+
+def box_decode_stereo(anchors, deltas, width, height, min_size=0.0):
+    """-> (left [N,4], right [N,4], big [N] int64): anchors moved by deltas[:, (0,1,2,3)] / deltas[:, (4,1,5,3)], clipped to the image;
+    big = 1 where both widths and the left height reach ``min_size``"""
+    a, d = _boxes(anchors, "anchors"), _boxes(deltas, "deltas", 6)
+    if a.shape[0] != d.shape[0]:
+        raise ValueError("one row of deltas per anchor")
+    n = a.shape[0]
+    left = torch.empty((n, 4), dtype=torch.float32, device=a.device)
+    right = torch.empty((n, 4), dtype=torch.float32, device=a.device)
+    big = torch.empty((n,), dtype=torch.int64, device=a.device)
+    if n:
+        with _on(a):
+            _lib.call("adv_box_decode_stereo_f32", _ptr(a), _ptr(d), _ptr(left), _ptr(right), _ptr(big), n, float(width), float(height), float(min_size),
+                      _stream(a))
+    return left, right, big
+
+
+__all__ = [n for n in dir() if not n.startswith("__")]

@@ -68,14 +68,13 @@ class PyramidRoIAlign(torch.autograd.Function):
         # zeros, not empty: a roi that no level owns (an owner index out of range - NaN / inf boxes from diverged RPN deltas under attack) is
         # skipped by every launch; its rows must be the same bytes on every run
         out = torch.zeros((r.shape[0], feats[0].shape[1], pooled, pooled), dtype=torch.float32, device=r.device)
-        mine = []
-        minus = torch.full_like(r[:, 0], -1.0)
+        # the per-level roi lists in five launches whatever the number of levels (a clone + compare + select + column write per level before)
+        levels = torch.arange(len(feats), device=r.device)[:, None]
+        mine = r.unsqueeze(0).repeat(len(feats), 1, 1)
+        mine[:, :, 0] = torch.where(owner[None, :] == levels, r[None, :, 0], -1.0)
         for l, f in enumerate(feats):
-            m = r.clone()
-            m[:, 0] = torch.where(owner == l, r[:, 0], minus)
-            roi_align(f.contiguous(), m, pooled, scales[l], sampling_ratio, out=out)
-            mine.append(m)
-        ctx.save_for_backward(*mine)
+            roi_align(f.contiguous(), mine[l], pooled, scales[l], sampling_ratio, out=out)
+        ctx.save_for_backward(mine)
         ctx.meta = ([tuple(f.shape) for f in feats], tuple(scales), sampling_ratio)
         return out
 
@@ -83,7 +82,8 @@ class PyramidRoIAlign(torch.autograd.Function):
     def backward(ctx, grad_out):
         shapes, scales, sr = ctx.meta
         g = grad_out.contiguous()
-        grads = tuple(roi_align_bwd(g, m, shapes[l], scales[l], sr) if ctx.needs_input_grad[5 + l] else None for l, m in enumerate(ctx.saved_tensors))
+        mine, = ctx.saved_tensors
+        grads = tuple(roi_align_bwd(g, mine[l], shapes[l], scales[l], sr) if ctx.needs_input_grad[5 + l] else None for l in range(len(shapes)))
         return (None, None, None, None, None) + grads
 
 

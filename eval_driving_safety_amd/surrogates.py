@@ -223,15 +223,20 @@ class StereoRcnnShaped(nn.Module):
     def _static_ok(self, im):
         return bool(im.is_cuda and getattr(self, "rois_per_image", None) and self._roi_align is None and self._nms is None and self.static_shapes)
 
-    def _pyramid_roi_feat_static(self, feats, rois, height, pooled):
+    def _pyramid_roi_feat_static(self, feats, rois, height, pooled, owner=None):
         """pyramid_roi_feat with shapes known on the host (ops.PyramidRoIAlign): every level is handed the whole roi list with the rois it
         does not own marked skipped, and the four launches fill disjoint rows of one output"""
         from . import ops
+        if owner is None:
+            owner = self._roi_owner(rois)
+        return ops.PyramidRoIAlign.apply(rois, owner, pooled, tuple(f.shape[2] / height for f in feats), 0, *feats)
+
+    def _roi_owner(self, rois):
+        """index into the pyramid levels P2..P5 of the level each roi's size selects (stereo_rcnn.py:110-141)"""
         h = rois[:, 4] - rois[:, 2] + 1
         w = rois[:, 3] - rois[:, 1] + 1
         level = torch.round(torch.log(torch.sqrt(h * w) / 224.0) + 4).clamp(2, 5)
-        owner = (level - float(self.LEVELS[0])).long()                      # LEVELS = (2, 3, 4, 5): index into feats
-        return ops.PyramidRoIAlign.apply(rois, owner, pooled, tuple(f.shape[2] / height for f in feats), 0, *feats)
+        return (level - float(self.LEVELS[0])).long()                       # LEVELS = (2, 3, 4, 5): index into feats
 
     def _forward_static(self, im_left, im_right, im_info, gt_boxes_left, gt_boxes_right, gt_dim_orien, gt_kpts, num_boxes):
         """forward() operation for operation where shapes allow, masks and padded index lists where the original compacts (boolean
@@ -257,8 +262,10 @@ class StereoRcnnShaped(nn.Module):
         anchors = self._anchors_cat
         gt_l, gt_r = gt_boxes_left.reshape(-1, 5)[:n_gt, :4], gt_boxes_right.reshape(-1, 5)[:n_gt, :4]
         if n_gt > 0:
-            iou = _iou(anchors, gt_l)
-            best, arg = iou.max(1)
+            gt_l, gt_r = gt_l.contiguous(), gt_r.contiguous()
+            # ops.box_*: each chain of ~15 element-wise one-liners (_iou + max, _encode x 2 + cat, _decode x 2 + clamps) as ONE launch with
+            # the same float32 expressions - the same bits as the torch operators on the device (tests/test_boxes.py)
+            iou, best, arg = ops.box_iou_rows(anchors, gt_l)
             pos, neg = best >= 0.5, best < 0.3
             pos.index_fill_(0, iou.argmax(0), True)              # (pos[idx] = True copies a host scalar to the device: not capturable)
             label = pos.float()
@@ -267,8 +274,7 @@ class StereoRcnnShaped(nn.Module):
             keep = torch.maximum(label, neg.float())
             bce = F.binary_cross_entropy_with_logits(scores, label, reduction="none")
             rpn_loss_cls = ((bce * keep).sum() / keep.sum().clamp(min=1.0)).unsqueeze(0)
-            tl, tr = _encode(anchors, gt_l[arg]), _encode(anchors, gt_r[arg])
-            target = torch.cat([tl, tr[:, 0:1], tr[:, 2:3]], 1)
+            target = ops.box_encode6(anchors, gt_l, gt_r, arg)
             sl1 = F.smooth_l1_loss(deltas, target, reduction="none")
             rpn_loss_box = ((sl1 * label[:, None]).sum() / (6.0 * label.sum()).clamp(min=1.0)).unsqueeze(0)
         else:
@@ -276,20 +282,14 @@ class StereoRcnnShaped(nn.Module):
         with torch.no_grad():
             order = torch.argsort(scores, descending=True)[:self.pre_nms]
             d, a = deltas[order], anchors[order]
-            left = _decode(a, d[:, :4])
-            right = _decode(a, torch.stack([d[:, 4], d[:, 1], d[:, 5], d[:, 3]], 1))
-            for b in (left, right):
-                b[:, 0::2].clamp_(0, W - 1)
-                b[:, 1::2].clamp_(0, H - 1)
+            min_size = getattr(self, "rpn_min_size", 0.0)
+            left, right, big = ops.box_decode_stereo(a, d, W, H, min_size)      # decoded, clipped to the image; big: 1 = big enough
             sc = scores[order]
             n = left.shape[0]
             nvalid = torch.full((), n, dtype=torch.long, device=dev)
-            min_size = getattr(self, "rpn_min_size", 0.0)
             if min_size > 0:
                 # boxes under the minimum size are dropped - here: moved behind the others (a stable partition keeps the score order), where
                 # they can suppress none of them; kept indices below the number of big boxes are then exactly NMS(big boxes only)
-                big = ((left[:, 2] - left[:, 0] + 1 >= min_size).long() * (left[:, 3] - left[:, 1] + 1 >= min_size).long() *
-                       (right[:, 2] - right[:, 0] + 1 >= min_size).long())                       # 1 = big enough
                 nbig = big.sum()
                 perm = torch.argsort(1 - big, stable=True)
                 perm = torch.where(nbig > 0, perm, torch.arange(n, device=dev))               # no box is big: nothing is dropped
@@ -308,17 +308,17 @@ class StereoRcnnShaped(nn.Module):
             zeros = left.new_zeros((left.shape[0], 1))
             rois_l, rois_r = torch.cat([zeros, left], 1), torch.cat([zeros, right], 1)
             if n_gt > 0:
-                iou = _iou(left, gt_l)
-                best, arg = iou.max(1)
+                _, best, arg = ops.box_iou_rows(left, gt_l, want_matrix=False)
                 rois_label = (best >= 0.5).long()
             else:
                 arg = torch.zeros(left.shape[0], dtype=torch.long, device=dev)
                 rois_label = torch.zeros(left.shape[0], dtype=torch.long, device=dev)
-        pooled = torch.cat([self._pyramid_roi_feat_static(fl[:4], rois_l, H, 7), self._pyramid_roi_feat_static(fr[:4], rois_r, H, 7)], 1)
+        owner_l = self._roi_owner(rois_l)                     # (shared by the 7 x 7 and the 14 x 14 pooling of the left rois)
+        pooled = torch.cat([self._pyramid_roi_feat_static(fl[:4], rois_l, H, 7, owner_l), self._pyramid_roi_feat_static(fr[:4], rois_r, H, 7)], 1)
         top = self.head_to_tail(pooled)
         cls_score, bbox_pred, dim_pred = self.cls_score(top), self.bbox_pred(top), self.dim_orien_pred(top)
         cls_prob = F.softmax(cls_score, 1)
-        k = self.kpts_logits(self._pyramid_roi_feat_static(fl[:4], rois_l, H, 14))
+        k = self.kpts_logits(self._pyramid_roi_feat_static(fl[:4], rois_l, H, 14, owner_l))
         kpts_prob = F.softmax(k[:, :4].reshape(k.shape[0], -1), 1)
         left_prob, right_prob = F.softmax(k[:, 4], 1), F.softmax(k[:, 5], 1)
         RCNN_loss_cls = F.cross_entropy(cls_score, rois_label).unsqueeze(0)
@@ -326,8 +326,7 @@ class StereoRcnnShaped(nn.Module):
             fg = (rois_label > 0).float()
             nfg = fg.sum()
             rows = torch.arange(rois_l.shape[0], device=dev)
-            tl, tr = _encode(left, gt_l[arg]), _encode(right, gt_r[arg])
-            target = torch.cat([tl, tr[:, 0:1], tr[:, 2:3]], 1)
+            target = ops.box_encode6(left, gt_l, gt_r, arg, src_right=right)
             pred = bbox_pred.view(-1, self.n_classes, 6)[rows, rois_label]
             RCNN_loss_bbox = ((F.smooth_l1_loss(pred, target, reduction="none") * fg[:, None]).sum() / (6.0 * nfg).clamp(min=1.0)).unsqueeze(0)
             do = gt_dim_orien.reshape(-1, 5)[:n_gt][arg]

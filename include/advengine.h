@@ -554,6 +554,20 @@ ADV_API int adv_stem_pool_fwd_f32(const float* t, const float* bias, float* y, u
                                   adv_stream_t stream);
 ADV_API int adv_stem_pool_bwd_f32(const float* grad_y, const uint8_t* code, float* grad_t, int64_t planes, int h, int w, adv_stream_t stream);
 
+/* Box arithmetic of the proposal / target stage (csrc/boxes.hip; upstream lib/model/rpn/bbox_transform.py: bbox_overlaps, bbox_transform,
+ *   bbox_transform_inv + clip_boxes [UPSTREAM-UNVERIFIED paths], reached inside the detector call of attack/Stereo-RCNN/pgd_attack.py:156).
+ *   Boxes are (x1, y1, x2, y2) rows of four floats, 16-byte aligned; widths are x2 - x1 + 1 (the legacy convention).
+ *   _iou_rows: a [n][4] against b [m][4]: iou [n][m] (NULL = not wanted), best [n] = the row maximum, arg [n] = index of its first occurrence.
+ *   _encode6:  out [n][6] = (dx, dy, log dw, log dh) from src_i onto gt_left[arg_i], then (dx, log dw) from src_right_i (NULL: src_i) onto
+ *              gt_right[arg_i].
+ *   _decode_stereo: left = src moved by deltas [n][6] columns (0,1,2,3), right by (4,1,5,3) (log-sizes clamped at 4), both clipped to
+ *              [0, width-1] x [0, height-1]; big [n] (NULL = not wanted) = 1 where both widths and the left height are >= min_size. */
+ADV_API int adv_box_iou_rows_f32(const float* a, const float* b, float* iou, float* best, int64_t* arg, int64_t n, int m, adv_stream_t stream);
+ADV_API int adv_box_encode6_f32(const float* src, const float* src_right, const float* gt_left, const float* gt_right, const int64_t* arg,
+                                float* out, int64_t n, int m, adv_stream_t stream);
+ADV_API int adv_box_decode_stereo_f32(const float* anchors, const float* deltas, float* left, float* right, int64_t* big, int64_t n, float width,
+                                      float height, float min_size, adv_stream_t stream);
+
 /* out[i] = y[i] > 0 ? grad[i] : 0  (the backward of a ReLU fused into a convolution's epilogue; out may alias grad). */
 ADV_API int adv_relu_backward_f32(const float* grad, const float* y, float* out, int64_t n, adv_stream_t stream);
 

@@ -781,3 +781,42 @@ def stem_pool_bwd(grad_y, code, in_hw):
             bi, ci = np.nonzero(live)
             out[bi, ci, 2 * oy + ky[live], 2 * ox + kx[live]] += g[bi, ci, oy, ox]
     return out[:, :, 1:h + 1, 1:w + 1].copy()
+
+
+def box_iou(a, b):
+    """[N,4] x [M,4] -> [N,M] with the legacy +1 widths (upstream lib/model/rpn/bbox_transform.py:bbox_overlaps [UPSTREAM-UNVERIFIED path];
+    this package: surrogates._iou, csrc/boxes.hip:iou_of), float32 operation by operation.  Test infrastructure."""
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    one, zero = np.float32(1), np.float32(0)
+    lt = np.maximum(a[:, None, :2], b[None, :, :2])
+    rb = np.minimum(a[:, None, 2:], b[None, :, 2:])
+    wh = np.maximum(rb - lt + one, zero)
+    inter = wh[..., 0] * wh[..., 1]
+    area_a = (a[:, 2] - a[:, 0] + one) * (a[:, 3] - a[:, 1] + one)
+    area_b = (b[:, 2] - b[:, 0] + one) * (b[:, 3] - b[:, 1] + one)
+    return (inter / (area_a[:, None] + area_b[None, :] - inter)).astype(np.float32)
+
+
+def box_encode(src, dst):
+    """(dx, dy, log dw, log dh) that move ``src`` onto ``dst`` (bbox_transform; surrogates._encode).  np.log is within an ulp of the device's."""
+    s, d = np.asarray(src, np.float32), np.asarray(dst, np.float32)
+    one, half = np.float32(1), np.float32(0.5)
+    sw, sh = s[:, 2] - s[:, 0] + one, s[:, 3] - s[:, 1] + one
+    sx, sy = s[:, 0] + half * sw, s[:, 1] + half * sh
+    dw, dh = d[:, 2] - d[:, 0] + one, d[:, 3] - d[:, 1] + one
+    dx, dy = d[:, 0] + half * dw, d[:, 1] + half * dh
+    return np.stack([(dx - sx) / sw, (dy - sy) / sh, np.log(dw / sw), np.log(dh / sh)], 1).astype(np.float32)
+
+
+def box_decode_clip(src, d, width, height):
+    """bbox_transform_inv (log-sizes clamped at 4) + clip_boxes (surrogates._decode and the clamps of its caller)"""
+    s, d = np.asarray(src, np.float32), np.asarray(d, np.float32)
+    one, half = np.float32(1), np.float32(0.5)
+    sw, sh = s[:, 2] - s[:, 0] + one, s[:, 3] - s[:, 1] + one
+    sx, sy = s[:, 0] + half * sw, s[:, 1] + half * sh
+    cx, cy = d[:, 0] * sw + sx, d[:, 1] * sh + sy
+    w, h = np.exp(np.minimum(d[:, 2], np.float32(4))) * sw, np.exp(np.minimum(d[:, 3], np.float32(4))) * sh
+    out = np.stack([cx - half * w, cy - half * h, cx + half * w - one, cy + half * h - one], 1).astype(np.float32)
+    out[:, 0::2] = np.clip(out[:, 0::2], 0, np.float32(width - 1))
+    out[:, 1::2] = np.clip(out[:, 1::2], 0, np.float32(height - 1))
+    return out

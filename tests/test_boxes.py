@@ -1,0 +1,78 @@
+"""Box arithmetic of the proposal / target stage (ops.box_*): the oracle against the torch one-liners on the CPU; the kernels against the
+same one-liners ON THE DEVICE (bit for bit - same expressions, the device's logf / expf) and against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle_np as O
+
+
+def _boxes(rs, n, w=1987.0, h=600.0):
+    x1, y1 = rs.rand(n) * w * 0.9, rs.rand(n) * h * 0.9
+    bw, bh = rs.rand(n) * 300 + 1, rs.rand(n) * 200 + 1
+    return np.stack([x1, y1, x1 + bw, y1 + bh], 1).astype(np.float32)
+
+
+def test_oracle_boxes_follow_the_torch_one_liners():
+    from eval_driving_safety_amd import surrogates as S
+    rs = np.random.RandomState(0)
+    a, g = _boxes(rs, 200), _boxes(rs, 7)
+    assert O.box_iou(a, g).tobytes() == S._iou(torch.tensor(a), torch.tensor(g)).numpy().tobytes()
+    arg = rs.randint(0, 7, 200)
+    np.testing.assert_allclose(O.box_encode(a, g[arg]), S._encode(torch.tensor(a), torch.tensor(g[arg])).numpy(), rtol=1e-6, atol=1e-7)
+    d = (rs.randn(200, 4) * 0.5).astype(np.float32)
+    d[0, 2] = 9.0                                          # clamped at 4
+    want = S._decode(torch.tensor(a), torch.tensor(d))
+    want[:, 0::2].clamp_(0, 1987.0 - 1)
+    want[:, 1::2].clamp_(0, 600.0 - 1)
+    np.testing.assert_allclose(O.box_decode_clip(a, d, 1987.0, 600.0), want.numpy(), rtol=1e-6, atol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,m", [(1, 1), (300, 3), (4097, 30)])
+def test_hip_boxes_are_the_one_liners_on_the_device(n, m):
+    from eval_driving_safety_amd import ops, surrogates as S
+    dev = torch.device("cuda", 0)
+    rs = np.random.RandomState(n + m)
+    a, gl = _boxes(rs, n), _boxes(rs, m)
+    gr = gl.copy()
+    gr[:, 0::2] -= (rs.rand(m, 1) * 30).astype(np.float32)
+    if n > 2:
+        a[1] = gl[0]                                       # IoU 1
+        a[2] = a[1]
+    if m > 2:
+        gl[2] = gl[0]                                      # a tie between two ground-truth boxes: the first one wins
+    ta, tl, tr = (torch.tensor(v, device=dev) for v in (a, gl, gr))
+    iou, best, arg = ops.box_iou_rows(ta, tl)
+    want = S._iou(ta, tl)
+    wb, wa = want.max(1)
+    assert torch.equal(iou, want) and torch.equal(best, wb) and torch.equal(arg, wa)
+    assert iou.cpu().numpy().tobytes() == O.box_iou(a, gl).tobytes()
+    none, b2, a2 = ops.box_iou_rows(ta, tl, want_matrix=False)
+    assert none is None and torch.equal(b2, best) and torch.equal(a2, arg)
+    # the six regression targets
+    t6 = ops.box_encode6(ta, tl, tr, arg)
+    el, er = S._encode(ta, tl[arg]), S._encode(ta, tr[arg])
+    assert torch.equal(t6, torch.cat([el, er[:, 0:1], er[:, 2:3]], 1))
+    np.testing.assert_allclose(t6[:, :4].cpu().numpy(), O.box_encode(a, gl[arg.cpu().numpy()]), rtol=2e-6, atol=1e-6)
+    a_r = a.copy()
+    a_r[:, 0::2] -= 7.0                                    # the right boxes of stereo rois: their own source
+    t6r = ops.box_encode6(ta, tl, tr, arg, src_right=torch.tensor(a_r, device=dev))
+    er = S._encode(torch.tensor(a_r, device=dev), tr[arg])
+    assert torch.equal(t6r, torch.cat([el, er[:, 0:1], er[:, 2:3]], 1))
+    # decoding + clipping + the minimum-size flags
+    d = (rs.randn(n, 6) * 0.4).astype(np.float32)
+    d[0, 2] = 11.0
+    td = torch.tensor(d, device=dev)
+    W, H, ms = 1987.0, 600.0, 8 * 1.6
+    left, right, big = ops.box_decode_stereo(ta, td, W, H, ms)
+    wl = S._decode(ta, td[:, :4])
+    wr = S._decode(ta, torch.stack([td[:, 4], td[:, 1], td[:, 5], td[:, 3]], 1))
+    for b in (wl, wr):
+        b[:, 0::2].clamp_(0, W - 1)
+        b[:, 1::2].clamp_(0, H - 1)
+    wbig = ((wl[:, 2] - wl[:, 0] + 1 >= ms).long() * (wl[:, 3] - wl[:, 1] + 1 >= ms).long() * (wr[:, 2] - wr[:, 0] + 1 >= ms).long())
+    assert torch.equal(left, wl) and torch.equal(right, wr) and torch.equal(big, wbig)
+    np.testing.assert_allclose(left.cpu().numpy(), O.box_decode_clip(a, d[:, :4], W, H), rtol=2e-6, atol=2e-3)
+    with pytest.raises(ValueError):
+        ops.box_encode6(ta, tl, tr, arg.int())
