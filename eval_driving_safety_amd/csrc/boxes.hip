@@ -99,6 +99,92 @@ __global__ __launch_bounds__(kBlock) void box_decode_stereo(const float* __restr
   if (big) big[i] = (l.x2 - l.x1 + 1.0f >= min_size && l.y2 - l.y1 + 1.0f >= min_size && r.x2 - r.x1 + 1.0f >= min_size) ? 1 : 0;
 }
 
+// ---- proposal bookkeeping of one image, each a single workgroup (a few thousand boxes at most): what the static forward did with two
+//      sorts, a dozen gathers and concatenations.
+constexpr int kOneBlock = 1024;
+
+// block-wide count of ``flag`` and this thread's exclusive prefix of it (16 waves: ballots + one LDS round)
+__device__ __forceinline__ int block_prefix(bool flag, int* s_wave, int* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long m = __ballot(flag);
+  const int in_wave = __popcll(m & ((1ULL << lane) - 1ULL));
+  __syncthreads();                                   // (s_wave is reused from call to call)
+  if (lane == 0) s_wave[wave] = __popcll(m);
+  __syncthreads();
+  int base = 0, sum = 0;
+  for (int w = 0; w < kOneBlock / 64; ++w) {
+    const int c = s_wave[w];
+    if (w < wave) base += c;
+    sum += c;
+  }
+  *total = sum;
+  return base + in_wave;
+}
+
+// STABLE partition: the boxes with big != 0 first, in order, then the others, in order (= gathering with argsort(1 - big, stable)); nothing
+// moves if no box is big.  nvalid = the number of big boxes (n if none is).
+__global__ __launch_bounds__(kOneBlock) void box_partition_stereo(const float* __restrict__ left, const float* __restrict__ right,
+                                                                  const long long* __restrict__ big, float* __restrict__ out_left,
+                                                                  float* __restrict__ out_right, long long* __restrict__ nvalid, int n) {
+  __shared__ int s_wave[kOneBlock / 64];
+  int nbig = 0;
+  for (int i0 = 0; i0 < n; i0 += kOneBlock) {        // first pass: how many are big
+    int t;
+    const int i = i0 + static_cast<int>(threadIdx.x);
+    block_prefix(i < n && big[i] != 0, s_wave, &t);
+    nbig += t;
+  }
+  int seen_big = 0;
+  for (int i0 = 0; i0 < n; i0 += kOneBlock) {
+    const int i = i0 + static_cast<int>(threadIdx.x);
+    const bool in = i < n, flag = in && big[i] != 0;
+    int t;
+    const int before = block_prefix(flag, s_wave, &t) + seen_big;      // big boxes before box i
+    if (in) {
+      const int dst = nbig == 0 ? i : (flag ? before : nbig + (i - before));
+      *reinterpret_cast<float4*>(out_left + 4LL * dst) = *reinterpret_cast<const float4*>(left + 4LL * i);
+      *reinterpret_cast<float4*>(out_right + 4LL * dst) = *reinterpret_cast<const float4*>(right + 4LL * i);
+    }
+    seen_big += t;
+  }
+  if (threadIdx.x == 0) *nvalid = nbig == 0 ? n : nbig;
+}
+
+// The rois of one image: candidates = (ground truth boxes, then the kept proposals left[keep[j]] for the j with 0 <= keep[j] < nvalid - a
+// prefix of ``keep``), sampled in order with replacement: roi i = candidate i % max(count, 1).  Writes (0, box) rows and the boxes alone.
+__global__ __launch_bounds__(kOneBlock) void box_sample_rois(const long long* __restrict__ keep, int k, const long long* __restrict__ nvalid,
+                                                             const float* __restrict__ left, const float* __restrict__ right,
+                                                             const float* __restrict__ gt_l, const float* __restrict__ gt_r, int n_gt, int R,
+                                                             float* __restrict__ rois_l, float* __restrict__ rois_r, float* __restrict__ out_left,
+                                                             float* __restrict__ out_right) {
+  __shared__ int s_wave[kOneBlock / 64];
+  const long long nv = *nvalid;
+  int nkeep = 0;
+  for (int j0 = 0; j0 < k; j0 += kOneBlock) {
+    const int j = j0 + static_cast<int>(threadIdx.x);
+    int t;
+    block_prefix(j < k && keep[j] >= 0 && keep[j] < nv, s_wave, &t);
+    nkeep += t;
+  }
+  const int total = max(nkeep + n_gt, 1);
+  for (int i = threadIdx.x; i < R; i += kOneBlock) {
+    const int idx = i % total;
+    float4 l, r;
+    if (idx < n_gt) {
+      l = *reinterpret_cast<const float4*>(gt_l + 4LL * idx), r = *reinterpret_cast<const float4*>(gt_r + 4LL * idx);
+    } else {
+      const long long src = max(keep[idx - n_gt], 0LL);
+      l = *reinterpret_cast<const float4*>(left + 4 * src), r = *reinterpret_cast<const float4*>(right + 4 * src);
+    }
+    *reinterpret_cast<float4*>(out_left + 4LL * i) = l;
+    *reinterpret_cast<float4*>(out_right + 4LL * i) = r;
+    float* pl = rois_l + 5LL * i;
+    float* pr = rois_r + 5LL * i;
+    pl[0] = 0.0f, pl[1] = l.x, pl[2] = l.y, pl[3] = l.z, pl[4] = l.w;
+    pr[0] = 0.0f, pr[1] = r.x, pr[2] = r.y, pr[3] = r.z, pr[4] = r.w;
+  }
+}
+
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline bool al8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; }
 inline bool al4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3u) == 0; }
@@ -135,6 +221,28 @@ int adv_box_decode_stereo_f32(const float* anchors, const float* deltas, float* 
   if (!al16(anchors) || !al4(deltas) || !al16(left) || !al16(right) || (big && !al8(big))) return ADV_EALIGN;
   hipLaunchKernelGGL(box_decode_stereo, dim3(blocks_for(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), anchors, deltas, left, right,
                      reinterpret_cast<long long*>(big), static_cast<long long>(n), width - 1.0f, height - 1.0f, min_size);
+  return adv_internal_finish_launch();
+}
+
+int adv_box_partition_stereo_f32(const float* left, const float* right, const int64_t* big, float* out_left, float* out_right, int64_t* nvalid,
+                                 int n, adv_stream_t stream) {
+  if (!left || !right || !big || !out_left || !out_right || !nvalid || n < 1 || left == out_left || right == out_right) return ADV_EINVAL;
+  if (!al16(left) || !al16(right) || !al16(out_left) || !al16(out_right) || !al8(big) || !al8(nvalid)) return ADV_EALIGN;
+  hipLaunchKernelGGL(box_partition_stereo, dim3(1), dim3(kOneBlock), 0, static_cast<hipStream_t>(stream), left, right,
+                     reinterpret_cast<const long long*>(big), out_left, out_right, reinterpret_cast<long long*>(nvalid), n);
+  return adv_internal_finish_launch();
+}
+
+int adv_box_sample_rois_f32(const int64_t* keep, int k, const int64_t* nvalid, const float* left, const float* right, const float* gt_left,
+                            const float* gt_right, int n_gt, int r, float* rois_left, float* rois_right, float* out_left, float* out_right,
+                            adv_stream_t stream) {
+  if (!keep || !nvalid || !left || !right || !rois_left || !rois_right || !out_left || !out_right || k < 1 || n_gt < 0 || r < 1) return ADV_EINVAL;
+  if (n_gt > 0 && (!gt_left || !gt_right)) return ADV_EINVAL;
+  if (!al16(left) || !al16(right) || !al16(out_left) || !al16(out_right) || !al4(rois_left) || !al4(rois_right) || !al8(keep) || !al8(nvalid) ||
+      (n_gt > 0 && (!al16(gt_left) || !al16(gt_right))))
+    return ADV_EALIGN;
+  hipLaunchKernelGGL(box_sample_rois, dim3(1), dim3(kOneBlock), 0, static_cast<hipStream_t>(stream), reinterpret_cast<const long long*>(keep), k,
+                     reinterpret_cast<const long long*>(nvalid), left, right, gt_left, gt_right, n_gt, r, rois_left, rois_right, out_left, out_right);
   return adv_internal_finish_launch();
 }
 

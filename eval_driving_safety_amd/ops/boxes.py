@@ -59,4 +59,42 @@ def box_decode_stereo(anchors, deltas, width, height, min_size=0.0):
     return left, right, big
 
 
+def box_partition_stereo(left, right, big):
+    """stable partition of the box pairs: those with ``big`` != 0 first, in order (what gathering with argsort(1 - big, stable=True) gives);
+    -> (left', right', nvalid [1] int64 = how many are big; all of them - and nothing moved - if none is).  No read-back."""
+    l, r = _boxes(left, "left"), _boxes(right, "right")
+    if r.shape != l.shape or big.dtype != torch.int64 or big.shape != (l.shape[0],) or big.device != l.device or l.shape[0] < 1:
+        raise ValueError("left / right [N,4] (N >= 1), big int64 [N] on their device")
+    ol, orr = torch.empty_like(l), torch.empty_like(r)
+    nvalid = torch.empty((1,), dtype=torch.int64, device=l.device)
+    bg = big.contiguous()
+    with _on(l):
+        _lib.call("adv_box_partition_stereo_f32", _ptr(l), _ptr(r), _ptr(bg), _ptr(ol), _ptr(orr), _ptr(nvalid), l.shape[0], _stream(l))
+    return ol, orr, nvalid
+
+
+def box_sample_rois(keep, nvalid, left, right, gt_left, gt_right, n_rois):
+    """the rois of one image without a read-back: candidates = ground-truth pairs (may be None), then left/right[keep[j]] for the valid
+    entries of the padded list ``keep`` (0 <= keep[j] < nvalid: a prefix), sampled in order with replacement
+    -> (rois_left [R,5], rois_right [R,5], left [R,4], right [R,4])"""
+    l, r = _boxes(left, "left"), _boxes(right, "right")
+    kp = keep.contiguous()
+    if kp.dtype != torch.int64 or kp.dim() != 1 or kp.shape[0] < 1 or nvalid.dtype != torch.int64 or nvalid.numel() != 1:
+        raise ValueError("keep int64 [K >= 1], nvalid int64 [1]")
+    n_gt = 0 if gt_left is None else int(gt_left.shape[0])
+    gl = gr = None
+    if n_gt:
+        gl, gr = _boxes(gt_left, "gt_left"), _boxes(gt_right, "gt_right")
+    R = int(n_rois)
+    rl = torch.empty((R, 5), dtype=torch.float32, device=l.device)
+    rr = torch.empty((R, 5), dtype=torch.float32, device=l.device)
+    ol = torch.empty((R, 4), dtype=torch.float32, device=l.device)
+    orr = torch.empty((R, 4), dtype=torch.float32, device=l.device)
+    nv = nvalid.contiguous()
+    with _on(l):
+        _lib.call("adv_box_sample_rois_f32", _ptr(kp), kp.shape[0], _ptr(nv), _ptr(l), _ptr(r), None if gl is None else _ptr(gl), None if gr is None else _ptr(gr),
+                  n_gt, R, _ptr(rl), _ptr(rr), _ptr(ol), _ptr(orr), _stream(l))
+    return rl, rr, ol, orr
+
+
 __all__ = [n for n in dir() if not n.startswith("__")]

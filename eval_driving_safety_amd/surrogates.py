@@ -286,27 +286,17 @@ class StereoRcnnShaped(nn.Module):
             left, right, big = ops.box_decode_stereo(a, d, W, H, min_size)      # decoded, clipped to the image; big: 1 = big enough
             sc = scores[order]
             n = left.shape[0]
-            nvalid = torch.full((), n, dtype=torch.long, device=dev)
             if min_size > 0:
                 # boxes under the minimum size are dropped - here: moved behind the others (a stable partition keeps the score order), where
                 # they can suppress none of them; kept indices below the number of big boxes are then exactly NMS(big boxes only)
-                nbig = big.sum()
-                perm = torch.argsort(1 - big, stable=True)
-                perm = torch.where(nbig > 0, perm, torch.arange(n, device=dev))               # no box is big: nothing is dropped
-                nvalid = torch.where(nbig > 0, nbig, nvalid)
-                left, right, sc = left[perm], right[perm], sc[perm]
-            keep, _ = ops.nms_padded(left.contiguous(), sc.contiguous(), 0.7)
-            keep = keep[:min(self.post_nms, n)]
-            nkeep = ((keep >= 0).long() * (keep < nvalid).long()).sum()                         # the valid kept boxes are a prefix of the list
-            keep = keep.clamp(min=0)
-            cand_l, cand_r = left[keep], right[keep]
-            if n_gt > 0:                  # the ground truth joins the proposals (stereo_rcnn.py:201-204)
-                cand_l, cand_r = torch.cat([gt_l, cand_l]), torch.cat([gt_r, cand_r])
-            total = (nkeep + n_gt).clamp(min=1)
-            idx = torch.arange(self.rois_per_image, device=dev) % total                        # sampled with replacement, in order
-            left, right = cand_l[idx], cand_r[idx]
-            zeros = left.new_zeros((left.shape[0], 1))
-            rois_l, rois_r = torch.cat([zeros, left], 1), torch.cat([zeros, right], 1)
+                left, right, nvalid = ops.box_partition_stereo(left, right, big)                # (nothing moves if no box is big)
+            else:
+                nvalid = torch.full((1,), n, dtype=torch.long, device=dev)
+            keep, _ = ops.nms_padded(left, sc, 0.7)                                             # (the scores are not read: the order is the boxes')
+            # the ground truth joins the proposals (stereo_rcnn.py:201-204); sampled with replacement, in order: one launch instead of the
+            # gathers / concatenations / index arithmetic of the padded list
+            rois_l, rois_r, left, right = ops.box_sample_rois(keep[:min(self.post_nms, n)], nvalid, left, right, gt_l if n_gt > 0 else None,
+                                                              gt_r if n_gt > 0 else None, self.rois_per_image)
             if n_gt > 0:
                 _, best, arg = ops.box_iou_rows(left, gt_l, want_matrix=False)
                 rois_label = (best >= 0.5).long()

@@ -561,7 +561,18 @@ ADV_API int adv_stem_pool_bwd_f32(const float* grad_y, const uint8_t* code, floa
  *   _encode6:  out [n][6] = (dx, dy, log dw, log dh) from src_i onto gt_left[arg_i], then (dx, log dw) from src_right_i (NULL: src_i) onto
  *              gt_right[arg_i].
  *   _decode_stereo: left = src moved by deltas [n][6] columns (0,1,2,3), right by (4,1,5,3) (log-sizes clamped at 4), both clipped to
- *              [0, width-1] x [0, height-1]; big [n] (NULL = not wanted) = 1 where both widths and the left height are >= min_size. */
+ *              [0, width-1] x [0, height-1]; big [n] (NULL = not wanted) = 1 where both widths and the left height are >= min_size.
+ *   _partition_stereo: STABLE partition of n box pairs: those with big != 0 first (the proposal layer's minimum-size filter without
+ *              compaction: the small ones move behind the others, where NMS lets them suppress nothing); nvalid [1] = how many are big
+ *              (n, and nothing moves, if none is).  One workgroup.
+ *   _sample_rois: the proposal-target layer's sampling with replacement, in order: candidates = the n_gt ground-truth pairs, then
+ *              left/right[keep[j]] for the entries 0 <= keep[j] < nvalid of keep [k] (a prefix: adv_nms_f32's padded list); roi i =
+ *              candidate i % max(count, 1): rois_* [r][5] = (0, box), out_* [r][4] = the boxes.  One workgroup. */
+ADV_API int adv_box_partition_stereo_f32(const float* left, const float* right, const int64_t* big, float* out_left, float* out_right,
+                                         int64_t* nvalid, int n, adv_stream_t stream);
+ADV_API int adv_box_sample_rois_f32(const int64_t* keep, int k, const int64_t* nvalid, const float* left, const float* right,
+                                    const float* gt_left, const float* gt_right, int n_gt, int r, float* rois_left, float* rois_right,
+                                    float* out_left, float* out_right, adv_stream_t stream);
 ADV_API int adv_box_iou_rows_f32(const float* a, const float* b, float* iou, float* best, int64_t* arg, int64_t n, int m, adv_stream_t stream);
 ADV_API int adv_box_encode6_f32(const float* src, const float* src_right, const float* gt_left, const float* gt_right, const int64_t* arg,
                                 float* out, int64_t n, int m, adv_stream_t stream);

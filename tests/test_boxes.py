@@ -76,3 +76,42 @@ def test_hip_boxes_are_the_one_liners_on_the_device(n, m):
     np.testing.assert_allclose(left.cpu().numpy(), O.box_decode_clip(a, d[:, :4], W, H), rtol=2e-6, atol=2e-3)
     with pytest.raises(ValueError):
         ops.box_encode6(ta, tl, tr, arg.int())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,frac_big,n_gt", [(2000, 0.7, 3), (2000, 0.0, 2), (1500, 1.0, 0), (70, 0.3, 1), (1, 1.0, 0)])
+def test_hip_proposal_partition_and_sampling_follow_the_torch_formulation(n, frac_big, n_gt):
+    """the static forward's bookkeeping (stable partition by size, padded NMS list -> rois with the ground truth, sampled with replacement)
+    as two launches against the tensor formulation they replace - gathers only: exact"""
+    from eval_driving_safety_amd import ops
+    dev = torch.device("cuda", 0)
+    rs = np.random.RandomState(n + n_gt)
+    left, right = torch.tensor(_boxes(rs, n), device=dev), torch.tensor(_boxes(rs, n), device=dev)
+    big = torch.tensor((rs.rand(n) < frac_big).astype(np.int64), device=dev)
+    pl, pr, nvalid = ops.box_partition_stereo(left, right, big)
+    nbig = big.sum()
+    perm = torch.argsort(1 - big, stable=True)
+    perm = torch.where(nbig > 0, perm, torch.arange(n, device=dev))
+    assert torch.equal(pl, left[perm]) and torch.equal(pr, right[perm])
+    assert int(nvalid) == (int(nbig) if int(nbig) > 0 else n)
+    # a padded kept list: a prefix of valid indices, then entries beyond nvalid, then -1
+    k = min(300, n)
+    n_ok = min(k, int(rs.randint(0, k + 1)))
+    valid = np.sort(rs.choice(int(nvalid), size=min(n_ok, int(nvalid)), replace=False))
+    tail = np.full(k - len(valid), -1, np.int64)
+    if int(nvalid) < n and len(tail):
+        tail[0] = n - 1                                      # a kept small box: beyond nvalid, not a candidate
+    keep = torch.tensor(np.concatenate([valid, tail]).astype(np.int64), device=dev)
+    gl = torch.tensor(_boxes(rs, n_gt), device=dev) if n_gt else None
+    gr = torch.tensor(_boxes(rs, n_gt), device=dev) if n_gt else None
+    R = 512
+    rl, rr, ol, orr = ops.box_sample_rois(keep, nvalid, pl, pr, gl, gr, R)
+    nkeep = ((keep >= 0).long() * (keep < nvalid).long()).sum()
+    kc = keep.clamp(min=0)
+    cand_l, cand_r = pl[kc], pr[kc]
+    if n_gt:
+        cand_l, cand_r = torch.cat([gl, cand_l]), torch.cat([gr, cand_r])
+    idx = torch.arange(R, device=dev) % (nkeep + n_gt).clamp(min=1)
+    wl, wr = cand_l[idx], cand_r[idx]
+    z = wl.new_zeros((R, 1))
+    assert torch.equal(ol, wl) and torch.equal(orr, wr) and torch.equal(rl, torch.cat([z, wl], 1)) and torch.equal(rr, torch.cat([z, wr], 1))
