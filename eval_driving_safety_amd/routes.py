@@ -85,9 +85,36 @@ def table_hash():
     return hashlib.sha256(blob).hexdigest()[:12]
 
 
-def fixed_rule(names):
-    """the route of a shape the table does not know: Winograd F(2x2,3x3) where the layer has it (F(4x4,3x3) only where the table measured it
-    faster: it needs large maps), else this package's direct kernel"""
+def _wino4_pays(key):
+    """a 3x3 / 3x3x3 stride-1 layer the table does not know: does F(4x4,3x3) pay?  Its workgroup computes 16 x 32 outputs of 64 channels
+    in one plane; it wins where the launch is at least ~0.8 rounds of the chip AND the tiles are mostly real outputs (maps of 5 or 10
+    rows are two thirds padding), F(2x2,3x3) otherwise - fitted to profiles/r05_routes_measured.jsonl (the sign of the measured
+    difference on 162 of the 185 layers measured both ways; summed over all of them the rule is 2 % over the per-layer optimum, always-F(2x2) 18 %).  A function of the key alone: no clock."""
+    try:
+        if key[0] in ("f", "b"):
+            if key[1] != 3:
+                return False
+            out_ch = key[3] if key[0] == "f" else key[2]
+            shape = key[5]
+            planes, h, w = shape[0], shape[2], shape[3]
+        elif key[0] in ("f3", "b3"):
+            out_ch = key[2] if key[0] == "f3" else key[1]
+            shape = key[3]
+            planes, h, w = shape[0] * shape[2], shape[3], shape[4]
+        else:
+            return False
+        tiles = ((h + 15) // 16) * ((w + 31) // 32)
+        wgs = tiles * planes * ((out_ch + 63) // 64)
+        return wgs >= 200 and h * w >= 0.62 * tiles * 512
+    except (TypeError, IndexError, ValueError):
+        return False
+
+
+def fixed_rule(names, key=None):
+    """the route of a shape the table does not know: Winograd where the layer has it - F(4x4,3x3) on large maps (_wino4_pays), F(2x2,3x3)
+    otherwise - else this package's direct kernel"""
+    if "wino4" in names and key is not None and _wino4_pays(key):
+        return "wino4"
     if "wino" in names:
         return "wino"
     return "hip" if "hip" in names else next(iter(names))
@@ -125,7 +152,7 @@ def choose(key, fns):
         got = _state["measured"].get(ks)
         if got is None:
             if torch.cuda.is_current_stream_capturing():
-                return fixed_rule(fns)
+                return fixed_rule(fns, key)
             t = {name: _time(fn) for name, fn in fns.items()}
             got = _state["measured"][ks] = (min(t, key=t.get), t)
         r = got[0]
@@ -134,7 +161,7 @@ def choose(key, fns):
         if r is None or r not in fns:
             if m == "table":
                 _state["misses"].add(ks)
-            r = fixed_rule(fns)
+            r = fixed_rule(fns, key)
     _state["used"][ks] = r
     if m != "measure":
         try:

@@ -191,6 +191,15 @@ def test_route_table_is_committed_and_well_formed():
     assert routes.choose(("f", 3, 8, 8, 1, [1, 8, 9, 9], False, True), {"hip": boom, "": boom, "wino": boom}) == "wino"      # unhashable key: not memoised, still answered
     routes.configure("fixed")
     assert routes.choose(tup, {"hip": boom, "": boom, "wino": boom}) == "wino" and routes.table_hash() == "fixed"      # (a new mode forgets the memo)
+    # a 3x3 layer the table does not know, F(4x4,3x3) on offer: it is taken where its launch fills the chip with mostly real outputs - a
+    # function of the key (no clock), fitted to the measured table (routes._wino4_pays)
+    four = {"hip": boom, "": boom, "wino": boom, "wino4": boom}
+    assert routes.choose(("f", 3, 128, 128, 1, (2, 128, 190, 300), False, True), four) == "wino4"          # 140 tiles x 2 images x 2 channel blocks
+    assert routes.choose(("b", 3, 128, 128, 1, (2, 128, 190, 300), False, False), four) == "wino4"
+    assert routes.choose(("f", 3, 256, 256, 1, (2, 256, 37, 120), False, True), four) == "wino"            # 96 workgroups: a third of the chip
+    assert routes.choose(("f3", 128, 128, (1, 128, 47, 5, 76), False, True), {"direct": boom, "wino": boom, "wino4": boom}) == "wino"     # 5-row planes: padding
+    assert routes.choose(("f3", 32, 32, (1, 32, 47, 96, 312), False, True), {"direct": boom, "wino": boom, "wino4": boom}) == "wino4"
+    assert routes.choose(("f", 1, 128, 128, 1, (2, 128, 190, 300), False, True), {"hip": boom, "": boom}) == "hip"
     routes.configure("table")
     assert routes.choose(tup, {"hip": boom, "": boom, "wino": boom}) == ""
 
