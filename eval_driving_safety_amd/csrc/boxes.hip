@@ -185,6 +185,48 @@ __global__ __launch_bounds__(kOneBlock) void box_sample_rois(const long long* __
   }
 }
 
+// ---- the RPN head's output of one pyramid level, [B][A + 6A][H*W] (A objectness maps, then six regression maps per anchor), into the
+//      proposal stage's lists: scores [(b, pixel, a)] and deltas [(b, pixel, a)][6] (= permute(0, 2, 3, 1).reshape(...) of the two slices),
+//      written at the level's offset of the lists of ALL levels; ``bounded``: deltas = 0.5 * tanh(raw) (surrogates.StereoRcnnR101).  And
+//      back: the gradient w.r.t. the head's output from the gradients of the two lists (tanh's: g * 0.5 * (1 - y * y), torch's order).
+__global__ __launch_bounds__(kBlock) void rpn_pack_fwd(const float* __restrict__ src, float* __restrict__ scores, float* __restrict__ deltas, int A,
+                                                      long long hw, long long total, int bounded) {
+  const long long i = blockIdx.x * static_cast<long long>(kBlock) + threadIdx.x;      // (b, pixel, a)
+  if (i >= total) return;
+  const int a = static_cast<int>(i % A);
+  const long long p = (i / A) % hw, b = i / (A * hw);
+  const float* sp = src + b * 7 * A * hw + p;
+  scores[i] = sp[a * hw];
+  float* d = deltas + 6 * i;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const float raw = sp[(A + a * 6 + j) * hw];
+    d[j] = bounded ? 0.5f * tanhf(raw) : raw;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void rpn_pack_bwd(const float* __restrict__ src, const float* __restrict__ g_scores,
+                                                      const float* __restrict__ g_deltas, float* __restrict__ g_src, int A, long long hw,
+                                                      long long total, int bounded) {
+  const long long i = blockIdx.x * static_cast<long long>(kBlock) + threadIdx.x;
+  if (i >= total) return;
+  const int a = static_cast<int>(i % A);
+  const long long p = (i / A) % hw, b = i / (A * hw);
+  const long long base = b * 7 * A * hw + p;
+  g_src[base + a * hw] = g_scores ? g_scores[i] : 0.0f;
+  const float* g = g_deltas ? g_deltas + 6 * i : nullptr;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const long long at = base + (A + a * 6 + j) * hw;
+    float v = g ? g[j] : 0.0f;
+    if (bounded) {
+      const float y = tanhf(src[at]);
+      v = (v * 0.5f) * fmaf(-y, y, 1.0f);      // torch's tanh_backward kernel, a * (1 - b * b), is built with contraction: 1 - b * b is one fma
+    }
+    g_src[at] = v;
+  }
+}
+
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline bool al8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; }
 inline bool al4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3u) == 0; }
@@ -221,6 +263,25 @@ int adv_box_decode_stereo_f32(const float* anchors, const float* deltas, float* 
   if (!al16(anchors) || !al4(deltas) || !al16(left) || !al16(right) || (big && !al8(big))) return ADV_EALIGN;
   hipLaunchKernelGGL(box_decode_stereo, dim3(blocks_for(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), anchors, deltas, left, right,
                      reinterpret_cast<long long*>(big), static_cast<long long>(n), width - 1.0f, height - 1.0f, min_size);
+  return adv_internal_finish_launch();
+}
+
+int adv_rpn_pack_fwd_f32(const float* head, float* scores, float* deltas, int b, int anchors, int64_t hw, int bounded, adv_stream_t stream) {
+  if (!head || !scores || !deltas || b < 1 || anchors < 1 || hw < 1) return ADV_EINVAL;
+  if (!al4(head) || !al4(scores) || !al4(deltas)) return ADV_EALIGN;
+  const long long total = static_cast<long long>(b) * anchors * hw;
+  hipLaunchKernelGGL(rpn_pack_fwd, dim3(blocks_for(total)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), head, scores, deltas, anchors,
+                     static_cast<long long>(hw), total, bounded ? 1 : 0);
+  return adv_internal_finish_launch();
+}
+
+int adv_rpn_pack_bwd_f32(const float* head, const float* grad_scores, const float* grad_deltas, float* grad_head, int b, int anchors, int64_t hw,
+                         int bounded, adv_stream_t stream) {
+  if (!head || !grad_head || head == grad_head || b < 1 || anchors < 1 || hw < 1) return ADV_EINVAL;
+  if (!al4(head) || !al4(grad_head) || (grad_scores && !al4(grad_scores)) || (grad_deltas && !al4(grad_deltas))) return ADV_EALIGN;
+  const long long total = static_cast<long long>(b) * anchors * hw;
+  hipLaunchKernelGGL(rpn_pack_bwd, dim3(blocks_for(total)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), head, grad_scores, grad_deltas, grad_head,
+                     anchors, static_cast<long long>(hw), total, bounded ? 1 : 0);
   return adv_internal_finish_launch();
 }
 

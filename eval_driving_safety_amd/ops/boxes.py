@@ -97,4 +97,47 @@ def box_sample_rois(keep, nvalid, left, right, gt_left, gt_right, n_rois):
     return rl, rr, ol, orr
 
 
+class RpnHeadPack(torch.autograd.Function):
+    """(scores [N], deltas [N,6]) of ALL pyramid levels from the RPN head's per-level outputs [B, 7A, H_l, W_l] (A objectness maps, then six
+    regression maps per anchor), N = sum_l B * H_l * W_l * A in (level, image, pixel, anchor) order - what the per-level
+    ``permute(0, 2, 3, 1).reshape`` of the two slices and the two concatenations give, with ``bounded`` deltas = 0.5 * tanh(raw): one launch
+    per level each way instead of ~12, the same values and the same gradient (tests/test_boxes.py)"""
+
+    @staticmethod
+    def forward(ctx, anchors, bounded, *heads):
+        hs = [_feat(h.contiguous(), "head") for h in heads]
+        a = int(anchors)
+        if not hs or any(h.dim() != 4 or h.shape[1] != 7 * a for h in hs):
+            raise ValueError("every head output must be [B, 7 * anchors, H, W]")
+        counts = [h.shape[0] * h.shape[2] * h.shape[3] * a for h in hs]
+        n = sum(counts)
+        scores = torch.empty((n,), dtype=torch.float32, device=hs[0].device)
+        deltas = torch.empty((n, 6), dtype=torch.float32, device=hs[0].device)
+        off = 0
+        with _on(hs[0]):
+            for h, c in zip(hs, counts):
+                _lib.call("adv_rpn_pack_fwd_f32", _ptr(h), scores.data_ptr() + 4 * off, deltas.data_ptr() + 24 * off, h.shape[0], a, h.shape[2] * h.shape[3],
+                          int(bool(bounded)), _stream(h))
+                off += c
+        ctx.save_for_backward(*hs)
+        ctx.meta = (a, bool(bounded), counts)
+        return scores, deltas
+
+    @staticmethod
+    def backward(ctx, g_scores, g_deltas):
+        a, bounded, counts = ctx.meta
+        hs = ctx.saved_tensors
+        gs = None if g_scores is None else g_scores.contiguous()
+        gd = None if g_deltas is None else g_deltas.contiguous()
+        outs, off = [], 0
+        with _on(hs[0]):
+            for h, c in zip(hs, counts):
+                g = torch.empty_like(h)
+                _lib.call("adv_rpn_pack_bwd_f32", _ptr(h), None if gs is None else gs.data_ptr() + 4 * off, None if gd is None else gd.data_ptr() + 24 * off,
+                          _ptr(g), h.shape[0], a, h.shape[2] * h.shape[3], int(bounded), _stream(h))
+                outs.append(g)
+                off += c
+        return (None, None) + tuple(outs)
+
+
 __all__ = [n for n in dir() if not n.startswith("__")]

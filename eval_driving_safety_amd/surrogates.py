@@ -249,13 +249,23 @@ class StereoRcnnShaped(nn.Module):
         n_gt = int(self._host_values(num_boxes, 1)[0])
         fl, fr = self.pyramid_pair(im_left, im_right)
         scores, deltas, anchors = [], [], []
+        raw_head = getattr(self, "rpn_head_raw", None)
+        packed = raw_head is not None and fl[0].is_cuda and self._rpn_chained(fl[0])
         for i in range(len(fl)):
             both = self.rpn_features(fl[i], fr[i])
-            s, d = self.rpn_heads(both)
-            scores.append(s.permute(0, 2, 3, 1).reshape(-1))
-            deltas.append(d.permute(0, 2, 3, 1).reshape(-1, 6))
+            if packed:                      # the merged head's output as it is: all levels go through ops.RpnHeadPack below
+                s = raw_head(both)
+                scores.append(s)
+            else:
+                s, d = self.rpn_heads(both)
+                scores.append(s.permute(0, 2, 3, 1).reshape(-1))
+                deltas.append(d.permute(0, 2, 3, 1).reshape(-1, 6))
             anchors.append(self.anchors(i, s.shape[2], s.shape[3], dev))
-        scores, deltas = torch.cat(scores), torch.cat(deltas)
+        if packed:
+            # slices, tanh, permuted copies and concatenations of the five levels (~12 launches per level and as many backward): one per level
+            scores, deltas = ops.RpnHeadPack.apply(len(self.ANCHOR_RATIOS), self.bounded_rpn_deltas, *scores)
+        else:
+            scores, deltas = torch.cat(scores), torch.cat(deltas)
         akey = tuple(a.data_ptr() for a in anchors)
         if getattr(self, "_anchors_cat_key", None) != akey:
             self._anchors_cat, self._anchors_cat_key = torch.cat(anchors), akey
@@ -718,6 +728,12 @@ class StereoRcnnR101(StereoRcnnShaped):
         if not (both.is_cuda and self._rpn_chained(both)):
             return self.rpn_scores(both), self.rpn_deltas(both)
         wc, wr = self.rpn_cls.weight, self.rpn_reg.weight
+        s, d = self.rpn_head_raw(both).split([wc.shape[0], wr.shape[0]], 1)
+        return s, (0.5 * torch.tanh(d) if self.bounded_rpn_deltas else d)
+
+    def rpn_head_raw(self, both):
+        """the merged layer's output [B, 3 + 18, H, W] (objectness maps, then the RAW regression maps); callers on the kernel path only"""
+        wc, wr = self.rpn_cls.weight, self.rpn_reg.weight
         key = (wc.data_ptr(), wc._version, wr.data_ptr(), wr._version, self.rpn_cls.bias._version, self.rpn_reg.bias._version, wc.device)
         if getattr(self, "_rpn_head_key", None) != key:
             head = self.__dict__.get("_rpn_head")
@@ -734,9 +750,9 @@ class StereoRcnnR101(StereoRcnnShaped):
         self.rpn_cls.flops += 2 * both.shape[0] * wc.shape[0] * wc.shape[1] * both.shape[2] * both.shape[3]      # (accounted where the layer list has them)
         self.rpn_reg.flops += 2 * both.shape[0] * wr.shape[0] * wr.shape[1] * both.shape[2] * both.shape[3]
         f0 = head.flops
-        s, d = head(both, chain_in=True).split([wc.shape[0], wr.shape[0]], 1)
+        out = head(both, chain_in=True)
         head.flops = f0
-        return s, (0.5 * torch.tanh(d) if self.bounded_rpn_deltas else d)
+        return out
 
     def head_to_tail(self, pooled):
         self._extra_flops = getattr(self, "_extra_flops", 0) + 2 * pooled.shape[0] * 2048 * 13 * self.n_classes

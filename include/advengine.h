@@ -568,6 +568,13 @@ ADV_API int adv_stem_pool_bwd_f32(const float* grad_y, const uint8_t* code, floa
  *   _sample_rois: the proposal-target layer's sampling with replacement, in order: candidates = the n_gt ground-truth pairs, then
  *              left/right[keep[j]] for the entries 0 <= keep[j] < nvalid of keep [k] (a prefix: adv_nms_f32's padded list); roi i =
  *              candidate i % max(count, 1): rois_* [r][5] = (0, box), out_* [r][4] = the boxes.  One workgroup. */
+/* The RPN head's output of one pyramid level, head [b][7 * anchors][hw] (objectness maps, then six regression maps per anchor:
+ *   stereo_rpn.py:32-40's RPN_cls_score / RPN_bbox_pred side by side), into the proposal stage's lists in (image, pixel, anchor) order:
+ *   scores [b * hw * anchors], deltas [b * hw * anchors][6] (pointers AT this level's offset in the lists of all levels); bounded != 0:
+ *   deltas = 0.5 * tanh(raw).  _bwd: grad_head from the gradients of the two lists (NULL = zero); needs head again for tanh's derivative. */
+ADV_API int adv_rpn_pack_fwd_f32(const float* head, float* scores, float* deltas, int b, int anchors, int64_t hw, int bounded, adv_stream_t stream);
+ADV_API int adv_rpn_pack_bwd_f32(const float* head, const float* grad_scores, const float* grad_deltas, float* grad_head, int b, int anchors,
+                                 int64_t hw, int bounded, adv_stream_t stream);
 ADV_API int adv_box_partition_stereo_f32(const float* left, const float* right, const int64_t* big, float* out_left, float* out_right,
                                          int64_t* nvalid, int n, adv_stream_t stream);
 ADV_API int adv_box_sample_rois_f32(const int64_t* keep, int k, const int64_t* nvalid, const float* left, const float* right,
