@@ -632,6 +632,33 @@ __global__ __launch_bounds__(kBlock) void bev_fold_bwd(const float* __restrict__
   }
 }
 
+// the same, four consecutive x per lane (X % 4 == 0, 16-byte aligned tensors): 16-byte loads and stores - the scalar version moved 0.67 GB in
+// 0.31 ms on the [1,64,192,20,304] volume (2.1 TB/s, profiles/r05_dsgn_small_ops.json)
+__global__ __launch_bounds__(kBlock) void bev_fold_bwd_vec4(const float* __restrict__ gout, const float* __restrict__ mask, float* __restrict__ gv, int C,
+                                                            int Z, int Y, int X4, int P, int Yp, long long total4) {
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  for (long long i = static_cast<long long>(blockIdx.x) * kBlock + threadIdx.x; i < total4; i += static_cast<long long>(gridDim.x) * kBlock) {
+    const int x4 = static_cast<int>(i % X4);
+    long long r = i / X4;
+    const int y = static_cast<int>(r % Y);
+    r /= Y;
+    const int z = static_cast<int>(r % Z);
+    r /= Z;                                           // r = b * C + c
+    const int yy = y / P;
+    v4 g = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (yy < Yp) {
+      g = *(reinterpret_cast<const v4*>(gout) + ((r * Yp + yy) * Z + z) * X4 + x4);
+      const float p = static_cast<float>(P);
+      g.x = g.x / p, g.y = g.y / p, g.z = g.z / p, g.w = g.w / p;
+    }
+    if (mask != nullptr) {
+      const v4 m = __builtin_nontemporal_load(reinterpret_cast<const v4*>(mask) + i);
+      g.x = m.x > 0.0f ? g.x : 0.0f, g.y = m.y > 0.0f ? g.y : 0.0f, g.z = m.z > 0.0f ? g.z : 0.0f, g.w = m.w > 0.0f ? g.w : 0.0f;
+    }
+    __builtin_nontemporal_store(g, reinterpret_cast<v4*>(gv) + i);
+  }
+}
+
 extern "C" {
 
 int adv_depth_regress_f32(const float* cost, const float* depth_values, float* depth_out, float* stats_out, int b, int d, int h, int w,
@@ -761,6 +788,14 @@ int adv_bev_fold_bwd_f32(const float* grad_out, const float* mask, float* grad_v
   if (!grad_out || !grad_v || grad_out == grad_v || mask == grad_v || b < 1 || c < 1 || z < 1 || y < 1 || x < 1 || pool < 1 || pool > y) return ADV_EINVAL;
   if (!aligned4(grad_out) || !aligned4(grad_v) || !aligned4(mask)) return ADV_EALIGN;
   const long long total = static_cast<long long>(b) * c * z * y * x;
+  if (x % 4 == 0 && ((reinterpret_cast<uintptr_t>(grad_out) | reinterpret_cast<uintptr_t>(grad_v) | reinterpret_cast<uintptr_t>(mask)) & 15u) == 0 &&
+      !adv_hook("ADV_BEV_SCALAR")) {
+    long long blocks4 = (total / 4 + kBlock - 1) / kBlock;
+    if (blocks4 > 65535LL * 16) blocks4 = 65535LL * 16;
+    hipLaunchKernelGGL(bev_fold_bwd_vec4, dim3(static_cast<unsigned>(blocks4)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), grad_out, mask, grad_v, c, z,
+                       y, x / 4, pool, y / pool, total / 4);
+    return adv_internal_finish_launch();
+  }
   long long blocks = (total + kBlock - 1) / kBlock;
   if (blocks > 65535LL * 16) blocks = 65535LL * 16;
   hipLaunchKernelGGL(bev_fold_bwd, dim3(static_cast<unsigned>(blocks)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), grad_out, mask, grad_v, c, z, y, x,
