@@ -683,6 +683,7 @@ class StereoRcnnR101(StereoRcnnShaped):
         # backward each materialises a zero-filled full-size map per consumer and adds them - at P2 (152 MB) with five consumers that was
         # ~3 GB of element-wise traffic per step (profiles/r04_r101_step_profile.json: fill + add kernels)
         halves = [f.split(b, 0) for f in feats]
+        self.__dict__["_joint_feats"] = feats if b == 1 else None      # (rpn_features: one pair per step runs both eyes as one batch of two)
         return [h[0] for h in halves], [h[1] for h in halves]
 
     # The backbone + FPN is the STATIC part of the step (no data-dependent shape, no host read-back): ~640 kernel launches forward and
@@ -708,6 +709,15 @@ class StereoRcnnR101(StereoRcnnShaped):
 
     def rpn_features(self, feat_l, feat_r):
         relu = "consumer" if self._rpn_chained(feat_l) else True
+        joint = self.__dict__.get("_joint_feats")
+        if joint is not None and feat_l.is_cuda:
+            # One pair per step: the two eyes are the two images of ONE pyramid tensor [2, C, H, W] (pyramid_pair).  The shared 3x3 layer on
+            # that batch of two gives [2, 512, H, W], whose memory IS the channel concatenation left | right [1, 1024, H, W]: one launch each
+            # way instead of two, and no concatenation (a 305 MB copy at P2, profiles/r05_r101_small_ops.json) - the same values.
+            for f in joint:
+                if f.shape[0] == 2 and f.shape[2:] == feat_l.shape[2:] and f.data_ptr() == feat_l.data_ptr() and feat_r.data_ptr() == f[1].data_ptr():
+                    y = self.rpn_conv(f, relu=relu)
+                    return y.view(1, 2 * y.shape[1], y.shape[2], y.shape[3])
         return torch.cat([self.rpn_conv(feat_l, relu=relu), self.rpn_conv(feat_r, relu=relu)], 1)
 
     def rpn_scores(self, both):
