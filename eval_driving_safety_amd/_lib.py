@@ -104,6 +104,7 @@ SIGNATURES = {
     "adv_box_iou_rows_f32": [_P, _P, _P, _P, _P, _L, _I, _P],
     "adv_box_encode6_f32": [_P, _P, _P, _P, _P, _P, _L, _I, _P],
     "adv_box_decode_stereo_f32": [_P, _P, _P, _P, _P, _L, _F, _F, _F, _P],
+    "adv_objective_chain_f32": [_P, _P, _P, _P, _I, _P],
     "adv_rpn_pack_fwd_f32": [_P, _P, _P, _I, _I, _L, _I, _P],
     "adv_rpn_pack_bwd_f32": [_P, _P, _P, _P, _I, _I, _L, _I, _P],
     "adv_box_partition_stereo_f32": [_P, _P, _P, _P, _P, _P, _I, _P],

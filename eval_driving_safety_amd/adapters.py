@@ -586,9 +586,14 @@ class StereoRcnnAdapter:
             out = self.model(imgL, imgR, extra.im_info, extra.gt_boxes_left, extra.gt_boxes_right,
                              extra.gt_boxes_merge, extra.gt_dim_orien, extra.gt_kpts, extra.num_boxes)   # :156-163
             terms = out[8:14]   # rpn_loss_cls, rpn_loss_box_left_right, RCNN_loss_cls, _bbox, _dim_orien, _kpts
-            loss = 0.
-            for k in range(6):                                                                   # :165-171
-                loss = loss + terms[k].mean() * torch.exp(-u[k]) + u[k]
+            if leaf.is_cuda and u.is_cuda and not u.requires_grad and all(t.numel() == 1 for t in terms):
+                # the same six terms in the same order of float operations as one launch (ops.ObjectiveChain; a one-element mean is the element)
+                from . import ops
+                loss = ops.ObjectiveChain.apply(torch.cat([t.reshape(1) for t in terms]), u)
+            else:
+                loss = 0.
+                for k in range(6):                                                               # :165-171
+                    loss = loss + terms[k].mean() * torch.exp(-u[k]) + u[k]
             self.model.zero_grad()                                                               # :173
             loss.backward()                                                                      # :174
             return loss.detach(), h.take()

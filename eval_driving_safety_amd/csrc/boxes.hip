@@ -227,6 +227,22 @@ __global__ __launch_bounds__(kBlock) void rpn_pack_bwd(const float* __restrict__
   }
 }
 
+// ---- the Stereo R-CNN attack objective (attack/Stereo-RCNN/pgd_attack.py:165-171): loss = sum_k (term_k * exp(-u_k) + u_k), added in the
+//      script's order - ((0 + t0 w0) + u0) + t1 w1 ... - by ONE thread; w_k = exp(-u_k) is kept for the backward (d loss / d term_k = w_k).
+//      The script's six-fold loop is ~45 scalar launches forward and ~30 backward through torch.
+__global__ __launch_bounds__(64) void objective_chain(const float* __restrict__ terms, const float* __restrict__ u, float* __restrict__ loss,
+                                                     float* __restrict__ w, int n) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float acc = 0.0f;
+  for (int k = 0; k < n; ++k) {
+    const float wk = expf(-u[k]);
+    w[k] = wk;
+    acc = acc + terms[k] * wk;
+    acc = acc + u[k];
+  }
+  loss[0] = acc;
+}
+
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline bool al8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; }
 inline bool al4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3u) == 0; }
@@ -263,6 +279,13 @@ int adv_box_decode_stereo_f32(const float* anchors, const float* deltas, float* 
   if (!al16(anchors) || !al4(deltas) || !al16(left) || !al16(right) || (big && !al8(big))) return ADV_EALIGN;
   hipLaunchKernelGGL(box_decode_stereo, dim3(blocks_for(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), anchors, deltas, left, right,
                      reinterpret_cast<long long*>(big), static_cast<long long>(n), width - 1.0f, height - 1.0f, min_size);
+  return adv_internal_finish_launch();
+}
+
+int adv_objective_chain_f32(const float* terms, const float* u, float* loss, float* w, int n, adv_stream_t stream) {
+  if (!terms || !u || !loss || !w || n < 1 || n > 64) return ADV_EINVAL;
+  if (!al4(terms) || !al4(u) || !al4(loss) || !al4(w)) return ADV_EALIGN;
+  hipLaunchKernelGGL(objective_chain, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), terms, u, loss, w, n);
   return adv_internal_finish_launch();
 }
 

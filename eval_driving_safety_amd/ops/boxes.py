@@ -97,6 +97,28 @@ def box_sample_rois(keep, nvalid, left, right, gt_left, gt_right, n_rois):
     return rl, rr, ol, orr
 
 
+class ObjectiveChain(torch.autograd.Function):
+    """sum_k (terms[k] * exp(-u[k]) + u[k]) in the order attack/Stereo-RCNN/pgd_attack.py:165-171 adds it (one launch; the script's loop is
+    ~45 scalar launches and ~30 more backward), differentiable w.r.t. ``terms`` [n]; u [n] is a constant of the attack"""
+
+    @staticmethod
+    def forward(ctx, terms, u):
+        t, uu = _feat(terms.contiguous(), "terms"), _feat(u.detach().contiguous(), "u")
+        if t.dim() != 1 or uu.shape != t.shape or not 1 <= t.shape[0] <= 64:
+            raise ValueError("terms and u must be [n], 1 <= n <= 64")
+        loss = torch.empty((1,), dtype=torch.float32, device=t.device)
+        w = torch.empty_like(t)
+        with _on(t):
+            _lib.call("adv_objective_chain_f32", _ptr(t), _ptr(uu), _ptr(loss), _ptr(w), t.shape[0], _stream(t))
+        ctx.save_for_backward(w)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        w, = ctx.saved_tensors
+        return g * w, None
+
+
 class RpnHeadPack(torch.autograd.Function):
     """(scores [N], deltas [N,6]) of ALL pyramid levels from the RPN head's per-level outputs [B, 7A, H_l, W_l] (A objectness maps, then six
     regression maps per anchor), N = sum_l B * H_l * W_l * A in (level, image, pixel, anchor) order - what the per-level

@@ -568,6 +568,10 @@ ADV_API int adv_stem_pool_bwd_f32(const float* grad_y, const uint8_t* code, floa
  *   _sample_rois: the proposal-target layer's sampling with replacement, in order: candidates = the n_gt ground-truth pairs, then
  *              left/right[keep[j]] for the entries 0 <= keep[j] < nvalid of keep [k] (a prefix: adv_nms_f32's padded list); roi i =
  *              candidate i % max(count, 1): rois_* [r][5] = (0, box), out_* [r][4] = the boxes.  One workgroup. */
+/* The Stereo R-CNN attack objective (attack/Stereo-RCNN/pgd_attack.py:165-171): loss[0] = sum over k < n of (terms[k] * exp(-u[k]) + u[k]),
+ *   added in the script's order (product, then u_k, term after term, starting from 0); w[k] = exp(-u[k]) = d loss / d terms[k].  n <= 64. */
+ADV_API int adv_objective_chain_f32(const float* terms, const float* u, float* loss, float* w, int n, adv_stream_t stream);
+
 /* The RPN head's output of one pyramid level, head [b][7 * anchors][hw] (objectness maps, then six regression maps per anchor:
  *   stereo_rpn.py:32-40's RPN_cls_score / RPN_bbox_pred side by side), into the proposal stage's lists in (image, pixel, anchor) order:
  *   scores [b * hw * anchors], deltas [b * hw * anchors][6] (pointers AT this level's offset in the lists of all levels); bounded != 0:
