@@ -3,7 +3,9 @@
 // bbox_transform.py: bbox_overlaps, bbox_transform, bbox_transform_inv, clip_boxes [UPSTREAM-UNVERIFIED paths]); this package's layer-list
 // graph (surrogates.py) wrote them as ~15 element-wise torch operators each - 3-5 us per launch, a few hundred launches per step.
 // Every kernel evaluates the SAME float32 expressions in the same order as those operators (no contraction: -ffp-contract=off; logf / expf
-// are the device library's, as in torch's kernels), so the results are the operators' bit for bit on the device.
+// are the device library's, as in torch's kernels), so the results are the operators' bit for bit on the device.  Also here: the
+// proposal bookkeeping (stable size partition, roi sampling: single-workgroup kernels, exact), the RPN head's list packing with its backward,
+// and the attack script's six-term objective chain (attack/Stereo-RCNN/pgd_attack.py:165-171) in its own order of additions.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>

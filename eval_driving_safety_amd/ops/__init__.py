@@ -8,6 +8,9 @@
   wino4    3x3 / 3x3x3 stride-1 convolutions by Winograd F(4x4,3x3) (csrc/wino4.hip)
   align    dense photometric box alignment (csrc/align.hip)
   volume   after the 3D convolutions: depth regression, 5-D grid sampling, bilinear up-sampling, bird's-eye-view fold, focal loss (csrc/volume.hip, csrc/resize.hip)
+  boxes    the proposal / target stage of a Stereo R-CNN step: IoU rows, regression targets, decode + clip, size partition, roi sampling,
+           the RPN head's list packing, the attack objective's six-term chain (csrc/boxes.hip)
+  elementwise  ReLU backward, the ResNet stem's bias + ReLU + max-pooling (csrc/volume.hip)
 
 Each function is the counterpart of one inline block of the reference's attack scripts (cited per function) and keeps its argument
 meaning; tensors stay where they are, kernels are enqueued on the caller's current torch stream.  There is no CPU or eager-torch fallback:
