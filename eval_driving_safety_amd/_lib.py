@@ -104,6 +104,8 @@ SIGNATURES = {
     "adv_box_iou_rows_f32": [_P, _P, _P, _P, _P, _L, _I, _P],
     "adv_box_encode6_f32": [_P, _P, _P, _P, _P, _P, _L, _I, _P],
     "adv_box_decode_stereo_f32": [_P, _P, _P, _P, _P, _L, _F, _F, _F, _P],
+    "adv_masked_loss_f32": [_P, _P, _P, _P, _P, _L, _I, _F, _I, _P],
+    "adv_masked_loss_bwd_f32": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
     "adv_objective_chain_f32": [_P, _P, _P, _P, _I, _P],
     "adv_rpn_pack_fwd_f32": [_P, _P, _P, _I, _I, _L, _I, _P],
     "adv_rpn_pack_bwd_f32": [_P, _P, _P, _P, _I, _I, _L, _I, _P],
@@ -134,6 +136,7 @@ _OTHER = {
     "adv_build_has_test_hooks": ([], _I),
     "adv_roi_align_bwd_workspace_ints": ([_I, _I, _I, _I, _I, _I, _I], ctypes.c_int64),
     "adv_roi_align_bwd_segments": ([_I], _I),
+    "adv_masked_loss_workspace_floats": ([], ctypes.c_int64),
     "adv_grid_sample3d_plan_bytes": ([_I, _I, _I, _I, _I, _I, _I], ctypes.c_int64),
     "adv_grid_sample3d_bwd_workspace_floats": ([_I, _I, _I, _I, _I], ctypes.c_int64),
     "adv_conv2d_1x1_prep_floats": ([_I, _I, _I], ctypes.c_int64),

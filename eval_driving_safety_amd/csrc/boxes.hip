@@ -245,6 +245,74 @@ __global__ __launch_bounds__(64) void objective_chain(const float* __restrict__ 
   loss[0] = acc;
 }
 
+// ---- masked-mean losses: loss = sum_i w_i * l(pred_i, target_i) / max(scale * sum_i w_i, 1) with l = smooth-L1 (beta 1) over the K columns of
+//      row i, or binary cross-entropy with logits (K = 1) - the RPN / RCNN loss terms of the layer-list graph, which torch computes with
+//      six or seven launches each (+ four or five backward).  Partial sums per block (a fixed chunk per block, a tree inside it), then one
+//      thread adds the partials in order: deterministic; the VALUE differs from torch's own summation order in the last bits, the GRADIENT
+//      does not depend on that order and is evaluated with torch's expressions in torch's order: bit-equal (tests/test_boxes.py).
+constexpr int kLossBlock = 256, kLossMaxBlocks = 256;
+
+template <bool BCE>
+__device__ __forceinline__ float loss_value(float p, float t) {
+  if (BCE) {                                        // (1 - y) x - log_sigmoid(x),  log_sigmoid(x) = min(x, 0) - log1p(exp(-|x|))
+    const float ls = fminf(p, 0.0f) - log1pf(expf(-fabsf(p)));
+    return (1.0f - t) * p - ls;
+  }
+  const float z = fabsf(p - t);                     // smooth-L1, beta = 1
+  return z < 1.0f ? 0.5f * z * z : z - 0.5f;
+}
+
+template <bool BCE>
+__global__ __launch_bounds__(kLossBlock) void masked_loss_partial(const float* __restrict__ pred, const float* __restrict__ target,
+                                                                 const float* __restrict__ weight, float* __restrict__ partial, long long rows,
+                                                                 int K, long long chunk) {
+  __shared__ float s_l[kLossBlock], s_w[kLossBlock];
+  const long long r0 = blockIdx.x * chunk, r1 = min(rows, r0 + chunk);
+  float sl = 0.0f, sw = 0.0f;
+  for (long long r = r0 + threadIdx.x; r < r1; r += kLossBlock) {
+    const float w = weight[r];
+    sw = sw + w;
+    for (int k = 0; k < K; ++k) sl = sl + loss_value<BCE>(pred[r * K + k], target[r * K + k]) * w;
+  }
+  s_l[threadIdx.x] = sl, s_w[threadIdx.x] = sw;
+  __syncthreads();
+  for (int d = kLossBlock / 2; d > 0; d >>= 1) {
+    if (static_cast<int>(threadIdx.x) < d) s_l[threadIdx.x] = s_l[threadIdx.x] + s_l[threadIdx.x + d], s_w[threadIdx.x] = s_w[threadIdx.x] + s_w[threadIdx.x + d];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[2 * blockIdx.x] = s_l[0], partial[2 * blockIdx.x + 1] = s_w[0];
+}
+
+__global__ void masked_loss_finish(const float* __restrict__ partial, int blocks, float scale, float* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float sl = 0.0f, sw = 0.0f;
+  for (int b = 0; b < blocks; ++b) sl = sl + partial[2 * b], sw = sw + partial[2 * b + 1];
+  const float d = fmaxf(scale * sw, 1.0f);
+  out[0] = sl / d;                                   // the loss
+  out[1] = d;                                        // its denominator, for the backward
+}
+
+// grad_pred = l'(pred, target) * ((g / denominator) * w): torch's smooth_l1_loss_backward (x < -1 ? -go : x > 1 ? go : x * go) and
+// binary_cross_entropy_with_logits backward ((sigmoid(x) - y) * go)
+template <bool BCE>
+__global__ __launch_bounds__(kLossBlock) void masked_loss_bwd(const float* __restrict__ pred, const float* __restrict__ target,
+                                                             const float* __restrict__ weight, const float* __restrict__ out,
+                                                             const float* __restrict__ g, float* __restrict__ grad, long long total, int K) {
+  const long long i = blockIdx.x * static_cast<long long>(kLossBlock) + threadIdx.x;
+  if (i >= total) return;
+  const float go = (g[0] / out[1]) * weight[i / K];
+  const float p = pred[i], t = target[i];
+  float r;
+  if (BCE) {
+    const float sg = 1.0f / (1.0f + expf(-p));
+    r = (sg - t) * go;
+  } else {
+    const float x = p - t;
+    r = x < -1.0f ? -go : (x > 1.0f ? go : x * go);
+  }
+  grad[i] = r;
+}
+
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline bool al8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; }
 inline bool al4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3u) == 0; }
@@ -281,6 +349,41 @@ int adv_box_decode_stereo_f32(const float* anchors, const float* deltas, float* 
   if (!al16(anchors) || !al4(deltas) || !al16(left) || !al16(right) || (big && !al8(big))) return ADV_EALIGN;
   hipLaunchKernelGGL(box_decode_stereo, dim3(blocks_for(n)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), anchors, deltas, left, right,
                      reinterpret_cast<long long*>(big), static_cast<long long>(n), width - 1.0f, height - 1.0f, min_size);
+  return adv_internal_finish_launch();
+}
+
+int64_t adv_masked_loss_workspace_floats(void) { return 2 * kLossMaxBlocks; }
+
+static int masked_loss_blocks(long long rows, long long* chunk) {
+  long long blocks = (rows + 4 * kLossBlock - 1) / (4 * kLossBlock);
+  if (blocks < 1) blocks = 1;
+  if (blocks > kLossMaxBlocks) blocks = kLossMaxBlocks;
+  *chunk = (rows + blocks - 1) / blocks;
+  return static_cast<int>((rows + *chunk - 1) / *chunk);
+}
+
+int adv_masked_loss_f32(const float* pred, const float* target, const float* weight, float* out2, float* workspace, int64_t rows, int k, float scale,
+                        int bce, adv_stream_t stream) {
+  if (!pred || !target || !weight || !out2 || !workspace || rows < 1 || k < 1 || (bce && k != 1)) return ADV_EINVAL;
+  if (!al4(pred) || !al4(target) || !al4(weight) || !al4(out2) || !al4(workspace)) return ADV_EALIGN;
+  long long chunk = 0;
+  const int blocks = masked_loss_blocks(rows, &chunk);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (bce) hipLaunchKernelGGL(masked_loss_partial<true>, dim3(blocks), dim3(kLossBlock), 0, st, pred, target, weight, workspace, static_cast<long long>(rows), k, chunk);
+  else hipLaunchKernelGGL(masked_loss_partial<false>, dim3(blocks), dim3(kLossBlock), 0, st, pred, target, weight, workspace, static_cast<long long>(rows), k, chunk);
+  hipLaunchKernelGGL(masked_loss_finish, dim3(1), dim3(64), 0, st, workspace, blocks, scale, out2);
+  return adv_internal_finish_launch();
+}
+
+int adv_masked_loss_bwd_f32(const float* pred, const float* target, const float* weight, const float* out2, const float* grad_loss, float* grad_pred,
+                            int64_t rows, int k, int bce, adv_stream_t stream) {
+  if (!pred || !target || !weight || !out2 || !grad_loss || !grad_pred || rows < 1 || k < 1 || (bce && k != 1)) return ADV_EINVAL;
+  if (!al4(pred) || !al4(target) || !al4(weight) || !al4(out2) || !al4(grad_loss) || !al4(grad_pred)) return ADV_EALIGN;
+  const long long total = static_cast<long long>(rows) * k;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const unsigned blocks = static_cast<unsigned>((total + kLossBlock - 1) / kLossBlock);
+  if (bce) hipLaunchKernelGGL(masked_loss_bwd<true>, dim3(blocks), dim3(kLossBlock), 0, st, pred, target, weight, out2, grad_loss, grad_pred, total, k);
+  else hipLaunchKernelGGL(masked_loss_bwd<false>, dim3(blocks), dim3(kLossBlock), 0, st, pred, target, weight, out2, grad_loss, grad_pred, total, k);
   return adv_internal_finish_launch();
 }
 

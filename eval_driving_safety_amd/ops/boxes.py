@@ -97,6 +97,50 @@ def box_sample_rois(keep, nvalid, left, right, gt_left, gt_right, n_rois):
     return rl, rr, ol, orr
 
 
+class MaskedLossMean(torch.autograd.Function):
+    """sum_i weight[i] * l(pred[i], target[i]) / max(scale * sum(weight), 1) - l = smooth-L1 (beta 1) summed over the columns of row i, or
+    (``bce``) binary cross-entropy with logits - as two launches forward and one backward (torch: six or seven + four or five).  The
+    gradient w.r.t. ``pred`` is torch's, bit for bit; the value is summed in this kernel's own fixed order (last-bit differences).
+    ``weight`` [N] and ``target`` are constants."""
+
+    @staticmethod
+    def forward(ctx, pred, target, weight, scale, bce):
+        p = _feat(pred.contiguous(), "pred")
+        t = _feat(target.detach().contiguous(), "target")
+        w = _feat(weight.detach().contiguous(), "weight")
+        rows = p.shape[0]
+        k = 1 if p.dim() == 1 else p.shape[1]
+        if p.dim() not in (1, 2) or t.shape != p.shape or w.shape != (rows,) or rows < 1 or (bce and k != 1):
+            raise ValueError("pred / target [N] or [N,K], weight [N]; the cross-entropy form takes [N]")
+        out2 = torch.empty((2,), dtype=torch.float32, device=p.device)
+        work = torch.empty((int(_lib.load().adv_masked_loss_workspace_floats()),), dtype=torch.float32, device=p.device)
+        with _on(p):
+            _lib.call("adv_masked_loss_f32", _ptr(p), _ptr(t), _ptr(w), _ptr(out2), _ptr(work), rows, k, float(scale), int(bool(bce)), _stream(p))
+        ctx.save_for_backward(p, t, w, out2)
+        ctx.meta = (rows, k, bool(bce))
+        return out2[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        p, t, w, out2 = ctx.saved_tensors
+        rows, k, bce = ctx.meta
+        gg = _feat(g.contiguous().reshape(1), "grad")
+        grad = torch.empty_like(p)
+        with _on(p):
+            _lib.call("adv_masked_loss_bwd_f32", _ptr(p), _ptr(t), _ptr(w), _ptr(out2), _ptr(gg), _ptr(grad), rows, k, int(bce), _stream(p))
+        return grad, None, None, None, None
+
+
+def masked_smooth_l1_mean(pred, target, weight, scale):
+    """((smooth_l1(pred, target) * weight[:, None]).sum() / (scale * weight.sum()).clamp(min=1)) as ops.MaskedLossMean"""
+    return MaskedLossMean.apply(pred, target, weight, scale, False)
+
+
+def masked_bce_mean(logits, label, keep):
+    """((bce_with_logits(logits, label) * keep).sum() / keep.sum().clamp(min=1)) as ops.MaskedLossMean"""
+    return MaskedLossMean.apply(logits, label, keep, 1.0, True)
+
+
 class ObjectiveChain(torch.autograd.Function):
     """sum_k (terms[k] * exp(-u[k]) + u[k]) in the order attack/Stereo-RCNN/pgd_attack.py:165-171 adds it (one launch; the script's loop is
     ~45 scalar launches and ~30 more backward), differentiable w.r.t. ``terms`` [n]; u [n] is a constant of the attack"""

@@ -282,11 +282,11 @@ class StereoRcnnShaped(nn.Module):
             # (no bitwise operator on bool tensors anywhere on this path: ``pos | neg`` captured in a hipGraph faults on replay with this
             # torch / ROCm - found by bisection, tools/graph_replay_probe.py - so masks are combined arithmetically)
             keep = torch.maximum(label, neg.float())
-            bce = F.binary_cross_entropy_with_logits(scores, label, reduction="none")
-            rpn_loss_cls = ((bce * keep).sum() / keep.sum().clamp(min=1.0)).unsqueeze(0)
+            # masked means as ops.MaskedLossMean: two launches forward, one backward each (torch: ~7 + ~5); the gradients are torch's bit for
+            # bit, the values are summed in the kernel's own fixed order
+            rpn_loss_cls = ops.masked_bce_mean(scores, label, keep).unsqueeze(0)
             target = ops.box_encode6(anchors, gt_l, gt_r, arg)
-            sl1 = F.smooth_l1_loss(deltas, target, reduction="none")
-            rpn_loss_box = ((sl1 * label[:, None]).sum() / (6.0 * label.sum()).clamp(min=1.0)).unsqueeze(0)
+            rpn_loss_box = ops.masked_smooth_l1_mean(deltas, target, label, 6.0).unsqueeze(0)
         else:
             rpn_loss_cls = rpn_loss_box = scores.sum().unsqueeze(0) * 0
         with torch.no_grad():
@@ -328,10 +328,10 @@ class StereoRcnnShaped(nn.Module):
             rows = torch.arange(rois_l.shape[0], device=dev)
             target = ops.box_encode6(left, gt_l, gt_r, arg, src_right=right)
             pred = bbox_pred.view(-1, self.n_classes, 6)[rows, rois_label]
-            RCNN_loss_bbox = ((F.smooth_l1_loss(pred, target, reduction="none") * fg[:, None]).sum() / (6.0 * nfg).clamp(min=1.0)).unsqueeze(0)
+            RCNN_loss_bbox = ops.masked_smooth_l1_mean(pred, target, fg, 6.0).unsqueeze(0)
             do = gt_dim_orien.reshape(-1, 5)[:n_gt][arg]
             dpred = dim_pred.view(-1, self.n_classes, 5)[rows, rois_label]
-            RCNN_loss_dim_orien = ((F.smooth_l1_loss(dpred, do, reduction="none") * fg[:, None]).sum() / (5.0 * nfg).clamp(min=1.0)).unsqueeze(0)
+            RCNN_loss_dim_orien = ops.masked_smooth_l1_mean(dpred, do, fg, 5.0).unsqueeze(0)
             kp = gt_kpts.reshape(-1, 6)[:n_gt][arg]
             bw = (left[:, 2] - left[:, 0] + 1)
             bins = (((kp[:, 0] - left[:, 0]) / bw) * self.GRID).long().clamp(0, self.GRID - 1)

@@ -568,6 +568,18 @@ ADV_API int adv_stem_pool_bwd_f32(const float* grad_y, const uint8_t* code, floa
  *   _sample_rois: the proposal-target layer's sampling with replacement, in order: candidates = the n_gt ground-truth pairs, then
  *              left/right[keep[j]] for the entries 0 <= keep[j] < nvalid of keep [k] (a prefix: adv_nms_f32's padded list); roi i =
  *              candidate i % max(count, 1): rois_* [r][5] = (0, box), out_* [r][4] = the boxes.  One workgroup. */
+/* Masked-mean loss terms of the detector's proposal / RoI stages (upstream: the smooth-L1 and objectness losses of stereo_rpn.py / stereo_rcnn.py
+ *   [UPSTREAM-UNVERIFIED paths], reached inside the detector call of attack/Stereo-RCNN/pgd_attack.py:156):
+ *   out2[0] = sum_i weight[i] * l(pred[i][:], target[i][:]) / max(scale * sum_i weight[i], 1), out2[1] = that denominator;
+ *   l = smooth-L1 (beta 1) summed over the k columns, or (bce != 0, k == 1) binary cross-entropy with logits (target = the 0 / 1 label).
+ *   workspace: adv_masked_loss_workspace_floats() floats.  Deterministic (fixed chunks, ordered partials).
+ *   _bwd: grad_pred [rows][k] = l' * ((grad_loss[0] / out2[1]) * weight[i]) with torch's backward expressions in torch's order. */
+ADV_API int64_t adv_masked_loss_workspace_floats(void);
+ADV_API int adv_masked_loss_f32(const float* pred, const float* target, const float* weight, float* out2, float* workspace, int64_t rows, int k,
+                                float scale, int bce, adv_stream_t stream);
+ADV_API int adv_masked_loss_bwd_f32(const float* pred, const float* target, const float* weight, const float* out2, const float* grad_loss,
+                                    float* grad_pred, int64_t rows, int k, int bce, adv_stream_t stream);
+
 /* The Stereo R-CNN attack objective (attack/Stereo-RCNN/pgd_attack.py:165-171): loss[0] = sum over k < n of (terms[k] * exp(-u[k]) + u[k]),
  *   added in the script's order (product, then u_k, term after term, starting from 0); w[k] = exp(-u[k]) = d loss / d terms[k].  n <= 64. */
 ADV_API int adv_objective_chain_f32(const float* terms, const float* u, float* loss, float* w, int n, adv_stream_t stream);

@@ -169,3 +169,34 @@ def test_hip_objective_chain_is_the_scripts_loop_on_the_device():
         (want * 1.7).backward()
         for k in range(6):
             assert torch.equal(a[k].grad, b[k].grad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,k,bce", [(5, 6, False), (512, 5, False), (300000, 6, False), (300000, 1, True), (7, 1, True)])
+def test_hip_masked_loss_mean_gradient_is_torchs_and_the_value_agrees(n, k, bce):
+    """ops.MaskedLossMean against the tensor formulation on the device: the gradient w.r.t. the prediction bit for bit (it does not depend on
+    the order of the sum), the value within float32 summation error; an all-zero weight gives 0 / max(0, 1)"""
+    import torch.nn.functional as F
+    from eval_driving_safety_amd import ops
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator().manual_seed(n + k)
+    shape = (n,) if bce else (n, k)
+    pred = (torch.randn(shape, generator=gen) * 2).to(dev).requires_grad_(True)
+    ref = pred.detach().clone().requires_grad_(True)
+    w = (torch.rand((n,), generator=gen) < 0.3).float().to(dev)
+    if bce:
+        target = (torch.rand(shape, generator=gen) < 0.5).float().to(dev)
+        got = ops.masked_bce_mean(pred, target, w)
+        want = (F.binary_cross_entropy_with_logits(ref, target, reduction="none") * w).sum() / w.sum().clamp(min=1.0)
+    else:
+        target = (torch.randn(shape, generator=gen) * 2).to(dev)
+        got = ops.masked_smooth_l1_mean(pred, target, w, float(k))
+        want = (F.smooth_l1_loss(ref, target, reduction="none") * w[:, None]).sum() / (float(k) * w.sum()).clamp(min=1.0)
+    assert got.shape == want.shape and abs(float(got) - float(want)) <= 2e-6 * max(1.0, abs(float(want)))
+    (got * 1.3).backward()
+    (want * 1.3).backward()
+    assert torch.equal(pred.grad, ref.grad)
+    again = ops.MaskedLossMean.apply(pred.detach(), target, w, float(k), bce)
+    assert float(again) == float(got)                       # deterministic
+    zero = ops.MaskedLossMean.apply(pred.detach(), target, torch.zeros_like(w), float(k), bce)
+    assert float(zero) == 0.0

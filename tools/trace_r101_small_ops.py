@@ -47,7 +47,7 @@ def main():
         key = "%s %s" % (name, str(ev.input_shapes)[:150])
         rows[key][0] += ev.count
         rows[key][1] += dt
-    top = sorted(rows.items(), key=lambda kv: -kv[1][1])[:60]
+    top = sorted(rows.items(), key=lambda kv: -kv[1][1])[:int(os.environ.get("ADV_TRACE_TOP", "60"))]
     print(json.dumps({"device_us_total": total, "small_op_us": sum(v[1] for v in rows.values()), "small_op_calls": sum(v[0] for v in rows.values()),
                       "top": [{"op": k, "calls": v[0], "device_us": round(v[1], 1)} for k, v in top]}, indent=1))
 
