@@ -819,7 +819,7 @@ class DsgnShapedAdapter(PsvStereoAdapter):
         kind, w, b, cout = e["kind"], e["w"], e["b"], e["cout"]
         if not self.mfma_conv:
             assert not chain_in and relu != "consumer" and not skip_out
-        assert not skip_out or kind == "s2"
+        assert not skip_out or kind in ("s2", "s1")
         if kind == "t2":
             self.flops_fwd += 2 * x.numel() * cout * 27
         if self.mfma_conv:
@@ -828,7 +828,10 @@ class DsgnShapedAdapter(PsvStereoAdapter):
                     y = ops.Conv3dK3.apply(x, e["p"], e["pt"], cout)
                     y = y + b.view(1, -1, 1, 1, 1)
                 else:
-                    y = ops.Conv3dK3.apply(x, e["p"], e["pt"], cout, None, b, relu, residual, chain_in, e["wino"])
+                    y = ops.Conv3dK3.apply(x, e["p"], e["pt"], cout, None, b, relu, residual, chain_in, e["wino"], skip_out)
+                    if skip_out:
+                        self.flops_fwd += 2 * y[0].numel() * e["cin"] * 27
+                        return y
             elif kind == "s2":
                 y = ops.Conv3dK3S2.apply(x, e["p"], e["pt"], cout, b, relu, chain_in, skip_out)
                 if skip_out:
@@ -851,7 +854,15 @@ class DsgnShapedAdapter(PsvStereoAdapter):
 
     # -- the graph ----------------------------------------------------------------------------------------------------------
     def features(self, img):
-        x = self._c2(self._c2(self._c2(img, "f0a", True), "f0b", True), "f0c", True)
+        # f0a (strided: torch's) -> f0b -> f0c -> the first block: f0b's ReLU mask is left to f0c's backward launch, f0c's to the first block's
+        # first layer (which also takes the skip path's gradient: the mask then covers both) - where all of them are on the Conv2dAuto path
+        first = self.blocks[0][0]
+        bc = self._chain("f0b", "f0c") and img.is_cuda
+        c1 = bc and self._chain("f0c", first + ".a", first + ".b") and not self.blocks[0][1] and img.is_cuda and \
+            not (self.w2[first + ".a"][4] == 2 and self.w2[first + ".b"][4] == 2)
+        x = self._c2(self._c2(img, "f0a", True), "f0b", "consumer" if bc else True)
+        x = self._c2(x, "f0c", "consumer" if c1 else True, chain_in=bc)
+        mask_first = c1
         outs = {}
         split = 0          # > 0: x is the four parity sub-images of a batch of `split` maps (the dilation-2 blocks run as dilation-1 blocks on them)
         for pre, proj, li in self.blocks:
@@ -866,8 +877,10 @@ class DsgnShapedAdapter(PsvStereoAdapter):
             if ch and not proj and x.is_cuda:
                 # identity block: layer a hands x on as the skip tensor and its backward adds the skip path's gradient in the dgrad
                 # kernel's epilogue (ops.Conv2dAuto skip_out) - no element-wise addition by the autograd engine
-                t, idt = self._c2(x, pre + ".a", "consumer", undilated=bool(split), skip_out=True)
+                t, idt = self._c2(x, pre + ".a", "consumer", undilated=bool(split), skip_out=True, chain_in=mask_first)
+                mask_first = False
             else:
+                assert not mask_first, "f0c left its ReLU mask to a block that does not take it"
                 idt = self._c2(x, pre + ".p") if proj else x
                 t = self._c2(x, pre + ".a", "consumer" if ch else True, undilated=bool(split))
             x = self._c2(t, pre + ".b", residual=idt, chain_in=ch, undilated=bool(split))      # PSMNet's BasicBlock: no ReLU after the sum
@@ -893,12 +906,20 @@ class DsgnShapedAdapter(PsvStereoAdapter):
             br = self._c2(p, "spp%d" % k, True)
             branches.append(_BilinearUp.apply(br, tuple(l4.shape[2:])))
         cat = torch.cat([l2, l4] + branches, 1)
-        return self._c2(self._c2(cat, "last_a", True), "last_b")
+        lc = self._chain("last_a", "last_b") and cat.is_cuda
+        return self._c2(self._c2(cat, "last_a", "consumer" if lc else True), "last_b", chain_in=lc)
 
     def _volume_net_impl(self, cost):
         ch = self.mfma_conv                 # chains: a ReLU output with ONE consumer, and that consumer a stride-1 layer on the main kernel
-        c0 = self._c3(self._c3(cost, "dres0a", "consumer" if ch else True), "dres0b", True, chain_in=ch)
-        c0 = self._c3(self._c3(c0, "dres1a", "consumer" if ch else True), "dres1b", False, c0, chain_in=ch)
+        if ch:
+            # dres0b's output feeds dres1a AND dres1's skip connection: dres1a's backward takes both gradients and dres0b's ReLU mask over their
+            # sum in its dgrad launch (ops.Conv3dK3 skip_out + mask_input) - no relu_backward pass and no autograd addition over the 184 MB volume
+            c0 = self._c3(self._c3(cost, "dres0a", "consumer"), "dres0b", "consumer", chain_in=True)
+            t, c0s = self._c3(c0, "dres1a", "consumer", chain_in=True, skip_out=True)
+            c0 = self._c3(t, "dres1b", False, c0s, chain_in=True)
+        else:
+            c0 = self._c3(self._c3(cost, "dres0a", True), "dres0b", True)
+            c0 = self._c3(self._c3(c0, "dres1a", True), "dres1b", False, c0)
         if ch:
             # the tensors a down-sampling layer reads also feed the matching up-sampling layer's skip connection: the down-sampling layer's
             # backward adds the skip path's gradient (and applies the producer's ReLU mask) in its own launch - ops.Conv3dK3S2 skip_out / mask_input

@@ -292,13 +292,17 @@ class Conv3dK3(torch.autograd.Function):
     connection, [B,cout,D,H,W]) is added in the same epilogue and receives that gradient unchanged."""
 
     @staticmethod
-    def forward(ctx, x, w_prep, w_prep_t, cout, weight=None, bias=None, relu=False, residual=None, mask_input=False, wino=None):
+    def forward(ctx, x, w_prep, w_prep_t, cout, weight=None, bias=None, relu=False, residual=None, mask_input=False, wino=None, skip_out=False):
         """<round 3> chains, as ops.Conv2dAuto: ``mask_input`` - x is a ReLU output this layer alone consumes, the gradient returned for it
         is already masked with x > 0 (in the dgrad kernel's epilogue); ``relu="consumer"`` - this layer's ReLU mask is applied by its only
         consumer's backward, not here.
         ``wino`` (a Conv3dWinoPrep of the same weights): each direction is computed by the direct kernel or by the Winograd kernel
-        (csrc/wino2d.hip: 2.25x fewer multiply-adds, same epilogues), whichever measured faster for the layer shape at first use."""
+        (csrc/wino2d.hip: 2.25x fewer multiply-adds, same epilogues), whichever measured faster for the layer shape at first use.
+        <round 5> ``skip_out`` (as ops.Conv2dAuto / Conv3dK3S2): returns (y, x_skip), x_skip an alias of x - a residual block hands it to
+        its last layer as the ``residual``; this layer's backward then receives BOTH gradients of x and adds the skip path's in the dgrad
+        kernel's epilogue, before the mask of ``mask_input`` (which then covers both)."""
         x = x.contiguous()
+        ctx.skip_out = bool(skip_out)
         ctx.has_t, ctx.has_res = w_prep_t is not None, residual is not None
         ctx.mask_own, ctx.mask_input = bool(relu) and relu != "consumer", bool(mask_input)
         ctx.xshape, ctx.wino = tuple(x.shape), wino
@@ -321,18 +325,24 @@ class Conv3dK3(torch.autograd.Function):
         else:
             y = direct()
         ctx.save_for_backward(w_prep_t if ctx.has_t else weight, y if ctx.mask_own else None, x if mask_input else None)
+        if skip_out:
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, grad_y):
+    def backward(ctx, grad_y, grad_skip=None):
         w, y, x_in = ctx.saved_tensors
         if ctx.mask_own:
             grad_y = relu_backward(grad_y, y)
         gres = grad_y if ctx.has_res else None      # the skip connection receives the (masked) gradient as it is
+        skip = grad_skip.contiguous() if (ctx.skip_out and grad_skip is not None) else None
         if ctx.has_t:
             g = grad_y.contiguous()
 
             def direct():
+                if skip is not None:                # the direct kernel's epilogue adds the skip gradient; the mask (if any) is a pass behind it
+                    gx = conv3d_k3(g, w, ctx.xshape[1], residual=skip)
+                    return relu_backward(gx, x_in) if ctx.mask_input else gx
                 gx = conv3d_k3_masked(g, w, ctx.xshape[1], x_in) if ctx.mask_input else None
                 if gx is None:
                     gx = conv3d_k3(g, w, ctx.xshape[1])
@@ -341,11 +351,11 @@ class Conv3dK3(torch.autograd.Function):
                 return gx
 
             if ctx.wino is not None and ctx.xshape[1] >= 4:
-                by_wino = lambda: conv3d_wino_dgrad(g, ctx.wino, mask=x_in if ctx.mask_input else None)      # noqa: E731
+                by_wino = lambda: conv3d_wino_dgrad(g, ctx.wino, residual=skip, mask=x_in if ctx.mask_input else None)      # noqa: E731
 
                 def by_wino4():
                     from .wino4 import conv_wino4_dgrad
-                    return conv_wino4_dgrad(g, ctx.wino.wino4(), mask=x_in if ctx.mask_input else None)
+                    return conv_wino4_dgrad(g, ctx.wino.wino4(), residual=skip, mask=x_in if ctx.mask_input else None)
 
                 key = ("b3", ctx.xshape[1], g.shape[1], ctx.xshape, ctx.mask_input)
                 took = _Conv2dChoice.pick(key, {"direct": direct, "wino": by_wino, "wino4": by_wino4})
@@ -358,9 +368,11 @@ class Conv3dK3(torch.autograd.Function):
                 gx = direct()
         else:
             gx = torch.nn.grad.conv3d_input(ctx.xshape, w, grad_y, padding=1)
+            if skip is not None:
+                gx = gx + skip
             if ctx.mask_input:
                 gx = relu_backward(gx, x_in)
-        return gx, None, None, None, None, None, None, gres, None, None
+        return gx, None, None, None, None, None, None, gres, None, None, None
 
 
 class Conv3dK3S2(torch.autograd.Function):
