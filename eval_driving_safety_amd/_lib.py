@@ -82,6 +82,8 @@ SIGNATURES = {
     "adv_psv_build_lerp_bwd_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "adv_roi_align_fwd_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P],
     "adv_roi_align_bwd_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P, _P],
+    "adv_roi_align_bwd_cl_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P, _P],
+    "adv_roi_gout_channel_last_f32": [_P, _P, _I, _I, _I, _I, _P],
     "adv_nms_f32": [_P, _I, _F, _P, _P, _P, _P],
     "adv_dense_align_cost_f32": [_P, _P, _I, _I, _I, _P, _P, _I, _P, _F, _F, _I, _P, _P],
     "adv_dense_align_argmin_f32": [_P, _I, _I, _P, _F, _P, _P, _P],
@@ -136,6 +138,7 @@ _OTHER = {
     "adv_build_has_test_hooks": ([], _I),
     "adv_roi_align_bwd_workspace_ints": ([_I, _I, _I, _I, _I, _I, _I], ctypes.c_int64),
     "adv_roi_align_bwd_segments": ([_I], _I),
+    "adv_roi_gout_channel_last_floats": ([_I, _I, _I, _I], ctypes.c_int64),
     "adv_masked_loss_workspace_floats": ([], ctypes.c_int64),
     "adv_grid_sample3d_plan_bytes": ([_I, _I, _I, _I, _I, _I, _I], ctypes.c_int64),
     "adv_grid_sample3d_bwd_workspace_floats": ([_I, _I, _I, _I, _I], ctypes.c_int64),

@@ -1033,9 +1033,11 @@ int64_t adv_roi_align_bwd_workspace_ints(int b, int c, int h, int w, int r, int 
   return lists + gcl + tabs + (g > 1 ? static_cast<long long>(g) * b * c * h * w : 0);         // + one copy of the map per segment
 }
 
-int adv_roi_align_bwd_f32(const float* grad_out, const float* rois, float* grad_feat, int b, int c, int h, int w, int r, int ph,
-                          int pw, float spatial_scale, int sampling_ratio, int32_t* workspace, adv_stream_t stream) {
-  const int rc = check_roi(grad_out, rois, grad_feat, b, c, h, w, r, ph, pw);
+// gcl_in != NULL: the channel-last copy of grad_out made by the caller (adv_roi_gout_channel_last_f32) - a pyramid pools ONE roi list from four
+// levels, and the backward of each level reads the same grad_out: transposed once instead of once per level
+static int roi_bwd_impl(const float* grad_out, const float* gcl_in, const float* rois, float* grad_feat, int b, int c, int h, int w, int r, int ph,
+                        int pw, float spatial_scale, int sampling_ratio, int32_t* workspace, adv_stream_t stream) {
+  const int rc = check_roi(gcl_in ? gcl_in : grad_out, rois, grad_feat, b, c, h, w, r, ph, pw);
   if (rc != ADV_OK) return rc;
   if (workspace == nullptr || b > 65535) return ADV_EINVAL;
   // the channel-last copy of grad_out inside the workspace is read with 16-byte loads: the lists before it are padded to a multiple of
@@ -1048,11 +1050,13 @@ int adv_roi_align_bwd_f32(const float* grad_out, const float* rois, float* grad_
   if (static_cast<long long>(b) * G > 65535) return ADV_EINVAL;
   const int seg_len = (r + G - 1) / G;
   const long long seg_elems = static_cast<long long>(b) * c * h * w;
-  float* gcl = reinterpret_cast<float*>(workspace) + ((static_cast<long long>(b) * G * tiles_y * tiles_x * (r + 1) + 3) & ~3LL);
-  float* parts = gcl + ((static_cast<long long>(ph) * pw * r * cpad(c) + 3) & ~3LL);
+  float* gcl_ws = reinterpret_cast<float*>(workspace) + ((static_cast<long long>(b) * G * tiles_y * tiles_x * (r + 1) + 3) & ~3LL);
+  float* parts = gcl_ws + ((static_cast<long long>(ph) * pw * r * cpad(c) + 3) & ~3LL);
   float* dest = G > 1 ? parts : grad_feat;
-  if (r > 0)
-    hipLaunchKernelGGL(roi_gout_channel_last, dim3(r, (c + 31) / 32), dim3(kBlock), sizeof(float) * 32 * (ph * pw + 1), st, grad_out, gcl, c, ph * pw);
+  if (gcl_in && (reinterpret_cast<uintptr_t>(gcl_in) & 15) != 0) return ADV_EALIGN;
+  const float* gcl = gcl_in ? gcl_in : gcl_ws;
+  if (r > 0 && !gcl_in)
+    hipLaunchKernelGGL(roi_gout_channel_last, dim3(r, (c + 31) / 32), dim3(kBlock), sizeof(float) * 32 * (ph * pw + 1), st, grad_out, gcl_ws, c, ph * pw);
   // every element of grad_feat is written by its owning lane (zeros where no roi reaches): no memset needed
   hipLaunchKernelGGL(roi_tile_lists, dim3(tiles_y * tiles_x, b * G), dim3(64), 0, st, rois, r, h, w, tiles_y, tiles_x, ph, pw, spatial_scale,
                      sampling_ratio, reinterpret_cast<int*>(workspace), G, std::max(1, seg_len));
@@ -1124,6 +1128,31 @@ int adv_roi_align_bwd_f32(const float* grad_out, const float* rois, float* grad_
   else ADV_LAUNCH_ROI_BWD(1);
 #undef ADV_LAUNCH_ROI_BWD
   return finish();
+}
+
+int adv_roi_align_bwd_f32(const float* grad_out, const float* rois, float* grad_feat, int b, int c, int h, int w, int r, int ph, int pw,
+                          float spatial_scale, int sampling_ratio, int32_t* workspace, adv_stream_t stream) {
+  return roi_bwd_impl(grad_out, nullptr, rois, grad_feat, b, c, h, w, r, ph, pw, spatial_scale, sampling_ratio, workspace, stream);
+}
+
+int64_t adv_roi_gout_channel_last_floats(int c, int r, int ph, int pw) {
+  if (c < 1 || r < 0 || ph < 1 || pw < 1) return 0;
+  return static_cast<int64_t>(ph) * pw * r * cpad(c);
+}
+
+int adv_roi_gout_channel_last_f32(const float* grad_out, float* gcl, int c, int r, int ph, int pw, adv_stream_t stream) {
+  if (!grad_out || !gcl || c < 1 || r < 0 || ph < 1 || pw < 1 || static_cast<long long>(ph) * pw > 1500) return ADV_EINVAL;
+  if (!aligned4(grad_out) || (reinterpret_cast<uintptr_t>(gcl) & 15) != 0) return ADV_EALIGN;
+  if (r == 0) return ADV_OK;
+  hipLaunchKernelGGL(roi_gout_channel_last, dim3(r, (c + 31) / 32), dim3(kBlock), sizeof(float) * 32 * (ph * pw + 1), static_cast<hipStream_t>(stream),
+                     grad_out, gcl, c, ph * pw);
+  return finish();
+}
+
+int adv_roi_align_bwd_cl_f32(const float* gcl, const float* rois, float* grad_feat, int b, int c, int h, int w, int r, int ph, int pw,
+                             float spatial_scale, int sampling_ratio, int32_t* workspace, adv_stream_t stream) {
+  if (!gcl) return ADV_EINVAL;
+  return roi_bwd_impl(nullptr, gcl, rois, grad_feat, b, c, h, w, r, ph, pw, spatial_scale, sampling_ratio, workspace, stream);
 }
 
 int adv_nms_f32(const float* boxes, int n, float thresh, int64_t* keep_out, int32_t* num_keep_out, uint64_t* workspace,

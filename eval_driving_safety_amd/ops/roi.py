@@ -42,6 +42,35 @@ def roi_align_bwd(grad_out, rois, feat_shape, spatial_scale, sampling_ratio=0):
     return gf
 
 
+def roi_gout_channel_last(grad_out):
+    """grad_out [R,C,PH,PW] -> its channel-last copy (flat, channels padded to 8) for ``roi_align_bwd(..., gcl=)``: made once when several
+    feature maps were pooled with the same roi list"""
+    g = _feat(grad_out, "grad_out")
+    if g.dim() != 4:
+        raise ValueError("grad_out must be [R,C,PH,PW]")
+    r, c, ph, pw = g.shape
+    gcl = torch.empty((max(4, int(_lib.load().adv_roi_gout_channel_last_floats(c, r, ph, pw))),), dtype=torch.float32, device=g.device)
+    if r:
+        with _on(g):
+            _lib.call("adv_roi_gout_channel_last_f32", _ptr(g), _ptr(gcl), c, r, ph, pw, _stream(g))
+    return gcl
+
+
+def roi_align_bwd_cl(gcl, pooled_hw, rois, feat_shape, spatial_scale, sampling_ratio=0):
+    """``roi_align_bwd`` from the channel-last copy of grad_out (``roi_gout_channel_last``): the same bits"""
+    r = _feat(rois, "rois")
+    b, c, h, w = feat_shape
+    ph, pw = pooled_hw
+    if gcl.dtype != torch.float32 or gcl.dim() != 1 or gcl.numel() < int(_lib.load().adv_roi_gout_channel_last_floats(c, r.shape[0], ph, pw)):
+        raise ValueError("gcl is not the channel-last copy of a [R,%d,%d,%d] gradient" % (c, ph, pw))
+    gf = torch.empty((b, c, h, w), dtype=torch.float32, device=gcl.device)
+    work = torch.empty((max(1, int(_lib.load().adv_roi_align_bwd_workspace_ints(b, c, h, w, r.shape[0], ph, pw))),), dtype=torch.int32, device=gcl.device)
+    with _on(gcl):
+        _lib.call("adv_roi_align_bwd_cl_f32", _ptr(gcl), _ptr(r), _ptr(gf), b, c, h, w, r.shape[0], ph, pw, float(spatial_scale), int(sampling_ratio),
+                  _ptr(work), _stream(gcl))
+    return gf
+
+
 class RoIAlign(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feat, rois, pooled, spatial_scale, sampling_ratio):
@@ -83,7 +112,9 @@ class PyramidRoIAlign(torch.autograd.Function):
         shapes, scales, sr = ctx.meta
         g = grad_out.contiguous()
         mine, = ctx.saved_tensors
-        grads = tuple(roi_align_bwd(g, mine[l], shapes[l], scales[l], sr) if ctx.needs_input_grad[5 + l] else None for l in range(len(shapes)))
+        gcl = roi_gout_channel_last(g)                  # one transposition for all levels (each level's launch made its own before)
+        hw = tuple(g.shape[2:])
+        grads = tuple(roi_align_bwd_cl(gcl, hw, mine[l], shapes[l], scales[l], sr) if ctx.needs_input_grad[5 + l] else None for l in range(len(shapes)))
         return (None, None, None, None, None) + grads
 
 

@@ -279,6 +279,13 @@ ADV_API int64_t adv_roi_align_bwd_workspace_ints(int b, int c, int h, int w, int
 ADV_API int adv_roi_align_bwd_f32(const float* grad_out, const float* rois, float* grad_feat, int b, int c, int h, int w,
                           int r, int ph, int pw, float spatial_scale, int sampling_ratio, int32_t* workspace,
                           adv_stream_t stream);
+/* The same backward for SEVERAL feature maps pooled with one roi list (a feature pyramid: stereo_rcnn.py:110-141): grad_out is transposed to
+ *   channel-last once - gcl, adv_roi_gout_channel_last_floats(c, r, ph, pw) floats, 16-byte aligned - and handed to each level's launch
+ *   (_cl: same arguments and workspace as adv_roi_align_bwd_f32 otherwise; the same bits). */
+ADV_API int64_t adv_roi_gout_channel_last_floats(int c, int r, int ph, int pw);
+ADV_API int adv_roi_gout_channel_last_f32(const float* grad_out, float* gcl, int c, int r, int ph, int pw, adv_stream_t stream);
+ADV_API int adv_roi_align_bwd_cl_f32(const float* gcl, const float* rois, float* grad_feat, int b, int c, int h, int w, int r, int ph, int pw,
+                                     float spatial_scale, int sampling_ratio, int32_t* workspace, adv_stream_t stream);
 
 /* Greedy NMS over n boxes [n,4] = (x1,y1,x2,y2) ALREADY SORTED by descending score, legacy "+1" areas,
  *     suppress when IoU > thresh.  keep_out [n] int64 receives the kept indices in order, num_keep_out [1] int32

@@ -207,6 +207,9 @@ def test_hip_roi_align(cfg, route):
         assert torch.equal(ops.roi_align_bwd(torch.tensor(g, device=dev), tr, feat.shape, cfg["scale"], cfg["sr"]), one)
     with route(ADV_ROI_BWD_REGS="1", ADV_ROI_BWD_CB8="1"):
         assert torch.equal(ops.roi_align_bwd(torch.tensor(g, device=dev), tr, feat.shape, cfg["scale"], cfg["sr"]), one)
+    # the channel-last copy of grad_out made by the caller (a pyramid's levels share it): the same bytes
+    gcl = ops.roi_gout_channel_last(torch.tensor(g, device=dev))
+    assert torch.equal(ops.roi_align_bwd_cl(gcl, tuple(g.shape[2:]), tr, feat.shape, cfg["scale"], cfg["sr"]), gf)
     # autograd wrapper
     tf2 = tf.clone().requires_grad_(True)
     o2 = ops.RoIAlign.apply(tf2, tr, cfg["pooled"], cfg["scale"], cfg["sr"])
