@@ -918,28 +918,32 @@ __global__ __launch_bounds__(64) void nms_scan(const unsigned long long* __restr
 // registers - lane l holds row 64k + l's word of the DIAGONAL mask block, and only the boxes still alive are visited - while the other
 // waves copy the NEXT block's 64 mask rows (contiguous in memory) into LDS; then every word of removed[] beyond the block takes the OR of
 // the kept boxes' rows from LDS.  Two barriers per 64 boxes, no global latency on the chain.  Same kept indices in the same order.
-constexpr int kNmsScanThreads = 256;
+constexpr int kNmsScanThreads = 1024;     // one workgroup: wave 0 settles the diagonal block, the other fifteen copy mask rows (one round trip per block)
 __global__ __launch_bounds__(kNmsScanThreads) void nms_scan_blocks(const unsigned long long* __restrict__ mask, int n, int col_blocks, long long* keep,
                                                                    int* num_keep) {
-  extern __shared__ unsigned long long s_nms[];      // removed[col_blocks] | rows[2][64 * col_blocks] | alive
+  extern __shared__ unsigned long long s_nms[];      // removed[col_blocks] | rows[3][64 * col_blocks] | alive
   unsigned long long* removed = s_nms;
   unsigned long long* rows = s_nms + col_blocks;
-  unsigned long long* s_alive = rows + 2 * 64 * col_blocks;
+  unsigned long long* s_alive = rows + 3 * 64 * col_blocks;
   const int tid = static_cast<int>(threadIdx.x), lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int per = 64 * col_blocks;
-  auto stage = [&](int k, int first, int step) {     // rows 64k .. 64k + 63 (zeros beyond n) -> rows[k & 1]
-    unsigned long long* dst = rows + (k & 1) * per;
+  // rows 64k .. 64k + 63 (zeros beyond n) -> rows[k % 3], TWO blocks ahead of their use (a ring of three): a block takes ~1.5 us, a trip to
+  // memory about as long - one block ahead the copy was what every block waited for (3.5 us per block, profiles/r05_r101_kernel_stats.csv)
+  auto stage = [&](int k, int first, int step) {
+    unsigned long long* dst = rows + (k % 3) * per;
     const unsigned long long* src = mask + static_cast<long long>(k) * per;
     const int have = min(64, n - 64 * k) * col_blocks;
-    for (int i = first; i < per; i += step) dst[i] = i < have ? src[i] : 0ULL;
+#pragma unroll 6
+    for (int i = first; i < per; i += step) dst[i] = i < have ? src[i] : 0ULL;      // (unrolled: the thread's loads in flight together)
   };
   for (int j = tid; j < col_blocks; j += kNmsScanThreads) removed[j] = 0ULL;
   stage(0, tid, kNmsScanThreads);
+  if (col_blocks > 1) stage(1, tid, kNmsScanThreads);
   __syncthreads();
   int kept = 0;
   for (int k = 0; k < col_blocks; ++k) {
-    const unsigned long long* cur = rows + (k & 1) * per;
+    const unsigned long long* cur = rows + (k % 3) * per;
     if (wave == 0) {
       const int nb = min(64, n - 64 * k);
       const unsigned long long diag = cur[lane * col_blocks + k];
@@ -958,26 +962,31 @@ __global__ __launch_bounds__(kNmsScanThreads) void nms_scan_blocks(const unsigne
       }
       if ((alive >> lane) & 1ULL) keep[kept + __popcll(alive & ((1ULL << lane) - 1ULL))] = 64LL * k + lane;
       if (lane == 0) *s_alive = alive;
-    } else if (k + 1 < col_blocks) {
-      stage(k + 1, tid - 64, kNmsScanThreads - 64);
+    } else if (k + 2 < col_blocks) {
+      stage(k + 2, tid - 64, kNmsScanThreads - 64);
     }
     __syncthreads();
     const unsigned long long alive = *s_alive;
     kept += __popcll(alive);
-    for (int j = k + 1 + tid; j < col_blocks; j += kNmsScanThreads) {
-      unsigned long long acc = removed[j], bits = alive;
-      while (bits) {
-        const int l = __builtin_ctzll(bits);
-        bits &= bits - 1ULL;
-        acc |= cur[l * col_blocks + j];
+    // every later word of removed[] takes the OR of the kept boxes' rows: eight threads per word, eight rows each with their LDS reads in
+    // flight together, combined by an LDS atomic OR (commutative: the result does not depend on the order) - a thread per word walking the
+    // kept rows one dependent read after the other was 2-3 us of the ~4.4 us a block took
+    for (int item = tid; item < 8 * (col_blocks - k - 1); item += kNmsScanThreads) {
+      const int j = k + 1 + (item >> 3), part = item & 7;
+      unsigned long long acc = 0ULL;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int l = 8 * part + u;
+        const unsigned long long row = cur[l * col_blocks + j];
+        acc |= ((alive >> l) & 1ULL) ? row : 0ULL;
       }
-      removed[j] = acc;
+      if (acc) atomicOr(&removed[j], acc);
     }
     __syncthreads();
   }
   if (tid == 0) *num_keep = kept;
 }
-constexpr int kNmsBlockScanMaxWords = 96;             // col_blocks up to which the block scan's LDS image fits (n <= 6144)
+constexpr int kNmsBlockScanMaxWords = 96;             // col_blocks up to which the block scan's LDS image (three blocks of rows: 148 KB) fits (n <= 6144)
 
 inline int finish() { return adv_internal_finish_launch(); }
 inline bool aligned4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3) == 0; }
@@ -1170,8 +1179,8 @@ int adv_nms_f32(const float* boxes, int n, float thresh, int64_t* keep_out, int3
   hipLaunchKernelGGL(nms_mask, dim3(col_blocks, col_blocks), dim3(64), 0, st, boxes, n, thresh,
                      reinterpret_cast<unsigned long long*>(workspace), col_blocks);
   if (col_blocks <= kNmsBlockScanMaxWords && !adv_hook("ADV_NMS_BOX_SCAN")) {
-    const size_t lds = (static_cast<size_t>(col_blocks) * 129 + 1) * 8;
-    if (!adv_internal_lds_limit<nms_scan_blocks>((static_cast<size_t>(kNmsBlockScanMaxWords) * 129 + 1) * 8)) return ADV_ELAUNCH;
+    const size_t lds = (static_cast<size_t>(col_blocks) * 193 + 1) * 8;
+    if (!adv_internal_lds_limit<nms_scan_blocks>((static_cast<size_t>(kNmsBlockScanMaxWords) * 193 + 1) * 8)) return ADV_ELAUNCH;
     hipLaunchKernelGGL(nms_scan_blocks, dim3(1), dim3(kNmsScanThreads), lds, st, reinterpret_cast<const unsigned long long*>(workspace), n, col_blocks,
                        reinterpret_cast<long long*>(keep_out), reinterpret_cast<int*>(num_keep_out));
     return finish();
