@@ -138,6 +138,58 @@ def wino3d_case(rs, dev):
          "conv3d wino dgrad %s" % ((b, cin, cout, d, h, w, tile),))
 
 
+def wino4_case(rs, dev):
+    """csrc/wino4.hip (Winograd F(4x4,3x3)) on 3x3 and 3x3x3 layers of random shape - odd maps, one-pixel maps, channels around the stage /
+    block sizes, every workgroup shape incl. the two-images-per-tile one, random epilogue - forward and backward w.r.t. the input, against
+    its restatement (oracle.c orc_conv_wino4) bit for bit"""
+    three_d = bool(rs.rand() < 0.4)
+    b = int(rs.randint(1, 4))
+    cin, cout = int(rs.choice([1, 3, 4, 8, 13, 32, 40, 64, 100])), int(rs.choice([1, 4, 6, 18, 32, 33, 64, 70, 128]))
+    d = int(rs.randint(1, 4)) if three_d else 1
+    h, w = int(rs.randint(1, 36)), int(rs.choice([1, 2, 5, 14, 15, 16, 31, 32, 33, 49, 65, 90]))
+    if b * min(cin, cout) * d * h * w < 4:          # (tensors of fewer than four floats are refused)
+        h = 4
+    shape = (b, cin, d, h, w) if three_d else (b, cin, h, w)
+    oshape = (b, cout) + shape[2:]
+    x = rs.randn(*shape).astype(np.float32)
+    wt = (rs.randn(*((cout, cin) + ((3, 3, 3) if three_d else (3, 3)))) * (1.0 / (cin * (27 if three_d else 9))) ** 0.5).astype(np.float32)
+    bias = rs.randn(cout).astype(np.float32) if rs.rand() < 0.6 else None
+    res = rs.randn(*oshape).astype(np.float32) if rs.rand() < 0.5 else None
+    mask = rs.randn(*oshape).astype(np.float32) if rs.rand() < 0.3 else None
+    relu = bool(rs.rand() < 0.5)
+    pair_ok = (not three_d) and w <= 15 and cin % 4 == 0
+    tile = int(rs.choice([-1, 0, 1, 2, 3] + ([4] if pair_ok else [])))
+    t = lambda a: None if a is None else torch.tensor(a, device=dev)       # noqa: E731
+    prep = ops.ConvWino4Prep(t(wt))
+    same(ops.conv_wino4(t(x), prep, t(bias), t(res), relu, t(mask), tile=tile), C.conv_wino4(x, wt, bias, res, mask, relu=relu),
+         "wino4 %s" % ((three_d, b, cin, cout, d, h, w, relu, tile),))
+    g = rs.randn(*oshape).astype(np.float32)
+    gres = rs.randn(*shape).astype(np.float32) if rs.rand() < 0.5 else None
+    gmask = x if rs.rand() < 0.5 else None
+    dtile = tile if not (tile == 4 and cout % 4 != 0) else -1          # (the image-pair shape needs the contraction's channels in fours)
+    same(ops.conv_wino4_dgrad(t(g), prep, residual=t(gres), mask=t(gmask), tile=dtile), C.conv_wino4(g, wt, residual=gres, mask=gmask, transpose=True),
+         "wino4 dgrad %s" % ((three_d, b, cin, cout, d, h, w, dtile),))
+
+
+def boxes_case(rs, dev):
+    """csrc/boxes.hip: IoU rows + maxima and the stable size partition / roi sampling against the oracle / the tensor formulation (exact)"""
+    n, m = int(rs.randint(1, 3000)), int(rs.randint(1, 20))
+    def boxes(k):
+        x1, y1 = rs.rand(k) * 1800, rs.rand(k) * 550
+        return np.stack([x1, y1, x1 + rs.rand(k) * 300 + 1, y1 + rs.rand(k) * 200 + 1], 1).astype(np.float32)
+    a, g = boxes(n), boxes(m)
+    ta, tg = torch.tensor(a, device=dev), torch.tensor(g, device=dev)
+    iou, best, arg = ops.box_iou_rows(ta, tg)
+    want = O.box_iou(a, g)
+    same(iou, want, "box_iou %s" % ((n, m),))
+    assert np.array_equal(arg.cpu().numpy(), want.argmax(1)) and best.cpu().numpy().tobytes() == want.max(1).tobytes(), "box_iou maxima %s" % ((n, m),)
+    right = torch.tensor(boxes(n), device=dev)
+    big = torch.tensor((rs.rand(n) < rs.rand()).astype(np.int64), device=dev)
+    pl, pr, nvalid = ops.box_partition_stereo(ta, right, big)
+    perm = torch.argsort(1 - big, stable=True) if int(big.sum()) > 0 else torch.arange(n, device=dev)
+    assert torch.equal(pl, ta[perm]) and torch.equal(pr, right[perm]) and int(nvalid) == (int(big.sum()) or n), "box_partition %s" % (n,)
+
+
 def grid_case(rs, dev):
     b, c = int(rs.randint(1, 3)), int(rs.randint(1, 20))
     dims = tuple(int(v) for v in rs.randint(1, 12, 3))
@@ -243,7 +295,7 @@ def main():
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     rs = np.random.RandomState(args.seed)
-    kinds = [conv_case] * 5 + [conv2d_case] * 4 + [wino3d_case] * 3 + [grid_case] * 2 + [pgd_case] * 3 + [roi_case] * 3 + [depth_case] * 2 + [resize_case] * 2
+    kinds = [conv_case] * 5 + [conv2d_case] * 4 + [wino3d_case] * 3 + [wino4_case] * 4 + [boxes_case] * 1 + [grid_case] * 2 + [pgd_case] * 3 + [roi_case] * 3 + [depth_case] * 2 + [resize_case] * 2
     counts = {}
     for i in range(args.cases):
         fn = kinds[int(rs.randint(len(kinds)))]
