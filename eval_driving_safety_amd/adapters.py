@@ -825,7 +825,7 @@ class DsgnShapedAdapter(PsvStereoAdapter):
         if self.mfma_conv:
             if kind == "s1":
                 if cout < 4:                                   # the 32 -> 1 score layer: the narrow kernels, no bias
-                    y = ops.Conv3dK3.apply(x, e["p"], e["pt"], cout)
+                    y = ops.Conv3dK3.apply(x, e["p"], e["pt"], cout, None, None, False, None, chain_in)      # (chain_in: its adjoint masks)
                     y = y + b.view(1, -1, 1, 1, 1)
                 else:
                     y = ops.Conv3dK3.apply(x, e["p"], e["pt"], cout, None, b, relu, residual, chain_in, e["wino"], skip_out)
@@ -934,7 +934,8 @@ class DsgnShapedAdapter(PsvStereoAdapter):
             h = self._c3(self._c3(pre, "hg3", True), "hg4", True)
             post = self._c3(h, "hg5", True, pre)
             out = self._c3(post, "hg6", False, c0)
-        score = self._c3(self._c3(out, "cls_a", True), "cls_b")
+        # cls_a's ReLU mask: in cls_b's backward launch (the 1 -> 32 narrow-input kernel's epilogue), not a pass over the 184 MB volume
+        score = self._c3(self._c3(out, "cls_a", "consumer" if ch else True), "cls_b", chain_in=ch)
         return score.squeeze(1), out
 
     def detection_maps(self, feat_vol, cost):

@@ -63,6 +63,7 @@ __device__ __forceinline__ void epi_store(const Epi& e, float* y, long long b, i
   const long long at = ((b * Cout + co) * e.od + zd) * (static_cast<long long>(e.oh) * e.ow) + static_cast<long long>(zh) * e.ow + zw;
   if (e.residual) r = r + e.residual[at];
   if (e.relu) r = r > 0.0f ? r : 0.0f;
+  if (e.mask) r = e.mask[at] > 0.0f ? r : 0.0f;      // <round 5> (the narrow-input kernel's route: the adjoint of a 32 -> 1 score layer behind a ReLU)
   y[at] = r;
 }
 
@@ -1316,7 +1317,7 @@ static int launch_conv(const float* x, const float* w_prep, float* y, int b, int
   // w >= 4, cin*d*h*w and 27*cin*cout_pad below 2^31 - anything else takes the scalar-staging kernel
   const bool fits = w >= 4 && static_cast<long long>(cin) * d * h * w < (1LL << 31) && 27LL * cin * cblocks * 32 < (1LL << 31);
   const bool narrow_ok = !adv_hook("ADV_CONV_NO_NARROW");  // test hook: the padded matrix kernel instead
-  if (epi.mask != nullptr) {   // only the main stride-1 matrix kernel has the mask epilogue: refuse every other route
+  if (epi.mask != nullptr && !(cin < kCK && plain)) {   // the main stride-1 matrix kernel and the narrow-input kernel have the mask epilogue: refuse every other route
     const bool main_route = stride == 1 && fits && cin >= kCK && !(plain && cout <= 8 && narrow_ok) && (reinterpret_cast<uintptr_t>(w_prep) & 15) == 0 &&
                             (reinterpret_cast<uintptr_t>(x) & 3) == 0 && !adv_hook("ADV_CONV_GENERIC");
     if (!main_route) return ADV_EINVAL;
@@ -1480,7 +1481,7 @@ int adv_conv3d_k3_f32(const float* x, const float* w_prep, float* y, int b, int 
 int adv_conv3d_k3_masked_f32(const float* x, const float* w_prep, const float* mask, float* y, int b, int cin, int cout, int d, int h, int w,
                              adv_stream_t stream) {
   if (!x || !w_prep || !mask || !y || mask == y || b < 1 || cin < 1 || cout < 1 || d < 1 || h < 1 || w < 1) return ADV_EINVAL;
-  if (cin % kCK != 0) return ADV_EINVAL;
+  if (cin % kCK != 0 && cin > kCK) return ADV_EINVAL;
   if (reinterpret_cast<uintptr_t>(mask) & 3) return ADV_EALIGN;
   Epi epi{nullptr, 0, kAllTaps, {0, 0, 0, 0, 0, 0, 0, 0}, 0, d, h, w, 1, 1, 1, 0, 0, 0};
   epi.mask = mask;

@@ -86,7 +86,7 @@ def conv3d_k3_masked(x, w_prep, cout, mask):
     b, cin, d, h, w = xi.shape
     if tuple(mk.shape) != (b, cout, d, h, w):
         raise ValueError("mask must be [B,cout,D,H,W]")
-    if cin % 4 or cout <= 8:
+    if cin >= 4 and (cin % 4 or cout <= 8):      # (fewer than four input channels: the narrow-input kernel, which masks too)
         return None
     y = torch.empty((b, cout, d, h, w), dtype=torch.float32, device=xi.device)
     with _on(xi):

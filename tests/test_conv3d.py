@@ -480,7 +480,8 @@ def test_hip_direct_strided_kernel_bit_exact_vs_oracle(shape, route):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(1, 8, 40, 6, 20, 40), (2, 32, 32, 5, 12, 36), (1, 12, 36, 3, 9, 38), (1, 64, 32, 4, 8, 76)])
+@pytest.mark.parametrize("shape", [(1, 8, 40, 6, 20, 40), (2, 32, 32, 5, 12, 36), (1, 12, 36, 3, 9, 38), (1, 64, 32, 4, 8, 76),
+                                   (1, 32, 1, 4, 12, 40), (2, 16, 3, 3, 9, 38)])       # (the last two: the adjoint of a 32 -> 1 / 16 -> 3 layer - the narrow-input kernel)
 def test_hip_masked_dgrad_equals_conv_then_relu_backward(shape):
     """adv_conv3d_k3_masked_f32: the backward w.r.t. the input with the ReLU mask of that input in the epilogue - bit-equal to the
     unmasked kernel followed by relu_backward, on every staging route; and ops.Conv3dK3's chain flags give the same gradient as the
