@@ -41,7 +41,7 @@ def _torch_reference_loss(net, x, extra, targets):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("hourglass", [pytest.param(False, marks=pytest.mark.slow), True])      # (the plain variant - 22 s of solver searches - with --full)
+@pytest.mark.parametrize("hourglass", [False, True])
 def test_dsgn_shaped_graph_matches_torch_operators(hourglass):
     from eval_driving_safety_amd import adapters, data
     dev = torch.device("cuda", 0)
