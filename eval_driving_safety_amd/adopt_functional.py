@@ -23,7 +23,7 @@ import sys
 import torch
 import torch.nn.functional as _F
 
-_STATS = {"grid_sample": 0, "grid_plan_built": 0, "depth_regress": 0, "materialised": 0}
+_STATS = {"grid_sample": 0, "grid_plan_built": 0, "grid_plan_hit_by_identity": 0, "depth_regress": 0, "materialised": 0}
 
 
 def stats(reset=False):
@@ -37,21 +37,37 @@ def stats(reset=False):
 
 # ------------------------------------------------------------------------------------------------ pattern 1: 5-D grid_sample
 class _PlanCache:
-    """the last few (grid values -> gather plan) pairs; a hit costs one ``torch.equal`` on the device"""
+    """the last few (grid values -> gather plan) pairs.  A grid that IS a tensor a plan is known for - same storage (kept alive here, so
+    its address cannot be handed to another tensor), same version counter, same strides: the calibration tensor a model keeps and passes
+    again every step - hits without touching the device (no host read-back: the adopted forward stays capturable in a hipGraph); any
+    other grid of the same geometry costs one ``torch.equal``."""
 
     def __init__(self, keep=4):
         self.keep, self.items = keep, []
 
+    @staticmethod
+    def _ident(grid):
+        return (grid.data_ptr(), grid._version, tuple(grid.stride()))
+
     def get(self, grid, dims, align):
         from . import ops
         key = (tuple(grid.shape), tuple(dims), bool(align), grid.device)
-        for i, (k, g, plan) in enumerate(self.items):
-            if k == key and torch.equal(g, grid):
+        ident = self._ident(grid)
+        for i, (k, g, plan, known) in enumerate(self.items):
+            if k == key and any(self._ident(t) == ident and t.data_ptr() == grid.data_ptr() for t in known):
                 self.items.insert(0, self.items.pop(i))
+                _STATS["grid_plan_hit_by_identity"] += 1
                 return plan
+        if not torch.cuda.is_current_stream_capturing():      # (a read-back is not allowed inside a capture: a plan is built there instead)
+            for i, (k, g, plan, known) in enumerate(self.items):
+                if k == key and torch.equal(g, grid):
+                    known.append(grid)                         # the alias keeps the storage alive: its address stays this tensor's
+                    del known[:-2]
+                    self.items.insert(0, self.items.pop(i))
+                    return plan
         plan = ops.GridSamplePlan(grid, dims, align)
         _STATS["grid_plan_built"] += 1
-        self.items.insert(0, (key, grid.detach().clone(), plan))
+        self.items.insert(0, (key, grid.detach().clone(), plan, [grid]))
         del self.items[self.keep:]
         return plan
 

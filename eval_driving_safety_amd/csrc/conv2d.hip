@@ -103,12 +103,16 @@ __global__ __launch_bounds__(256, 2) void conv2d_1x1_mfma(const float* __restric
     v4f x[G::kXF4], w[G::kWF4];
   };
   Set sa, sb;
+  const int nstage = (K + kKC - 1) / kKC;
   auto fetch = [&](int k0, Set& st) {
     const int xo = static_cast<int>(static_cast<unsigned>(k0) * static_cast<unsigned>(P) * 4u);      // wave-uniform
 #pragma unroll
     for (int i = 0; i < G::kXF4; ++i) st.x[i] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsx, xvo[i] + xo, 0, 0));
+    // (the scalar offset takes no part in the range check: the two look-ahead stages past the last one re-read the last stage - in bounds,
+    // into a register set nobody reads - instead of reaching past the prepared weights)
+    const int kw = k0 < nstage * kKC ? k0 : (nstage - 1) * kKC;
 #pragma unroll
-    for (int i = 0; i < G::kWF4; ++i) st.w[i] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsw, wvo[i], k0 * mpad * 4, 0));
+    for (int i = 0; i < G::kWF4; ++i) st.w[i] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsw, wvo[i], kw * mpad * 4, 0));
   };
   auto commit = [&](int buf, const Set& st) {
     float* sx = lds + buf * G::kStage;
@@ -135,7 +139,6 @@ __global__ __launch_bounds__(256, 2) void conv2d_1x1_mfma(const float* __restric
     }
   };
 
-  const int nstage = (K + kKC - 1) / kKC;
   fetch(0, sa);
   fetch(kKC, sb);
   commit(0, sa);

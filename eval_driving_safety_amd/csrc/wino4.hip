@@ -8,22 +8,35 @@
 // Why the design differs from wino2d.hip.  Thirty-six products of a (channel block) x (patch block) tile need 36 accumulator tiles.  With
 // 16x16 tiles and wino2d's scheme (every wave all positions of its own block) that is 144 registers per 16 x 16 block and two operand reads
 // per matrix instruction - the LDS, not the matrix pipe, would set the pace.  Here the POSITIONS are dealt to the waves: a workgroup is
-// EIGHT waves (two per SIMD, 256 registers each); with 64 output channels per workgroup (CB = 2) waves 0-3 carry four positions each
-// (k = w + 4 n) and run the input transform, waves 4-7 five each; every wave holds its positions for ALL 64 channels x 32 patches of the
-// tile (8 / 10 accumulators of 32 x 32 = 128 / 160 registers), one B operand shared by the two channel blocks: three LDS reads per two
-// 64-cycle matrix instructions, a quarter of wino2d's operand traffic per matrix cycle.  With 32 output channels (CB = 1) the tile is 32
-// channels x 64 patches and all eight waves transform.  (A first version - four waves, one per SIMD, nine positions = 288 accumulator
-// registers each - kept part of the accumulators in AGPRs and shuffled them around every matrix instruction; two waves per SIMD also give
-// the pipe something to run while the other wave transforms.)  The 36 values of one (channel, patch) sit in eight different waves after
-// the contraction: they are exchanged through LDS in rounds of 16 channels and every thread transforms one or two (channel, patch) items
-// per round (prologue + epilogue: 13 % of a tile at 256 channels, profiles/r05_wino4_phases.jsonl).
+// EIGHT waves (two per SIMD, 256 registers each) over a tile of 32 patches x 64 output channels (CB = 2) or 64 patches x 32 channels
+// (CB = 1), and every wave holds its positions for the WHOLE tile in 32 x 32 accumulators.
 //
-//   per stage of KC = 4 q:   input tile [4][4 PR + 2][LWP]   global -> registers (buffer loads, two sets deep) -> LDS
-//                            U = G g G^T of the stage [36][4][64]   global -> LDS by LDS-DMA, each wave ITS OWN positions (1 KiB per instruction)
-//                            V = B^T d B [36][4][32]   the transform waves: two threads per (q, patch), three of the six rows of V each
-//   one "s_waitcnt; s_barrier" per stage (not __syncthreads(): its fence would drain the loads in flight), two buffers of everything, and
-//   the side work woven between the matrix instructions in half-steps (one matrix instruction per scheduling step).
-//   PAIR: two images of at most 15 columns side by side in one 32-column tile (the RoI heads' 14 x 14 maps).
+// <round 6> What the machine does with such a kernel, measured with in-kernel time stamps and two probes (profiles/r06_wino4_stamps*.jsonl,
+// r06_mfma_valu_probe.json, r06_wino4_stagger_negative.*), and what this version does about it:
+//   * a float32 matrix instruction and the OTHER wave's float32 vector instructions do not execute at the same time on a SIMD (matrix waves
+//     alone 0.254 ms, vector waves alone 0.190 ms, together 0.420 ms): the input transform's ~93 vector instructions per thread and stage come
+//     out of the matrix pipe's time whichever wave issues them.  Only LDS, memory and scalar instructions hide behind matrix instructions.
+//     The matrix-pipe counter of this kernel is therefore bounded by matrix / (matrix + vector) cycles = 0.86 (CB = 2) / 0.75 (CB = 1).
+//   * the matrix pipe serves the OLDER wave of a SIMD whenever both are ready, and a wave issues in order: round 5's split (waves 0-3: four
+//     positions and the whole transform, waves 4-7: five positions) left waves 4-7 idle for ~800 of 3 500 cycles per stage at the barrier.
+//     Now every wave is alike: the nine positions of a SIMD's two waves are four whole ones each and the ninth split by channel (patch) block -
+//     NINE accumulators and 18 matrix instructions per four q for every wave - and every thread transforms half a (q, patch) pair per stage
+//     (a stage is 8 q at CB = 2: half the barriers of round 5 per matrix instruction).
+//   * U (the transformed weights) never touches LDS: every wave multiplies its own positions only, so the prepared layout hands each lane its
+//     A operands as one 16-byte buffer load per (position, four q), requested a stage (two at CB = 1) ahead into the registers just consumed:
+//     37 KB per stage less through LDS, no weight DMA to issue or to wait for at the barrier.
+//   * the input tile arrives by LDS-DMA (1 KiB per wave instruction, three buffers, two stages ahead; the range check writes the zero
+//     padding): no staging registers, no per-element masks, no commit stores (round 5's were 75 % of the kernel's LDS bank conflicts).
+//   Tried and dropped: fixed roles in time (waves 0-3 all their matrix instructions first while waves 4-7 do their side work, then the
+//   other way round) - 7 % SLOWER: the side-work wave makes no progress while its partner streams matrix instructions (first bullet).
+//
+//   per stage of KC = 4 CB q:   input tile [KC][4 PR + 2][groups of 4 columns]   global -> LDS by LDS-DMA
+//                               U = G g G^T: global -> registers, each wave its own positions
+//                               V = B^T d B [36][KC][patches]   every thread: half a (q, patch) pair, three of the six rows of V
+//   one "s_waitcnt; s_barrier" per stage (not __syncthreads(): its fence would drain the loads in flight), the side work woven between the
+//   matrix instructions in half-steps (one matrix instruction per scheduling step).  The 36 values of one (channel, patch) sit in eight
+//   waves after the contraction: they are exchanged through LDS in rounds of 16 channels and every thread transforms one or two (channel,
+//   patch) items per round.  PAIR: two images of at most 15 columns side by side in one 32-column tile (the RoI heads' 14 x 14 maps).
 //
 // Order of float operations (oracle/oracle.c orc_conv_wino4 restates it bit for bit): the transforms' expressions as written below
 // (explicit fmaf where a multiply feeds an add), each M_k one fmaf chain over q ascending starting from 0 (the matrix instruction is a
@@ -37,6 +50,16 @@
 #include "adv_internal.h"
 #include "advengine.h"
 
+#ifdef ADV_WINO4_STAMPS
+// diagnostic builds only (tools/build_variant.sh ... -DADV_WINO4_STAMPS; tools/wino4_stamps.py): s_memtime stamps of the stage loop of the first
+// workgroups - [workgroup < 8][wave][stage < 64][5]: stage start, start of half-step (stage % half-steps), last matrix instruction issued,
+// LDS drained, barrier passed.  The stamps go to a buffer of their own and feed nothing.
+__device__ unsigned long long adv_wino4_stamps[8][8][64][5];
+extern "C" __attribute__((visibility("default"))) int adv_debug_wino4_stamps(void* dst, size_t bytes) {
+  return static_cast<int>(hipMemcpyFromSymbol(dst, HIP_SYMBOL(adv_wino4_stamps), bytes < sizeof(adv_wino4_stamps) ? bytes : sizeof(adv_wino4_stamps)));
+}
+#endif
+
 namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -44,24 +67,33 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void lds_void;
 
-constexpr int kKC = 4;        // "channels" q per stage
-constexpr int kTransformWavePositions = 4;      // 64-channel workgroups: positions carried by each of the four transform waves (the others: 9 - this)
+constexpr int kKQ = 4;        // "channels" q per SUB-stage (two matrix-instruction steps of two q each); a stage is CB sub-stages
 
 // PR x PC patches of 4 x 4 outputs per workgroup, CB blocks of 32 output channels: 32 patches x 64 channels (CB = 2) or 64 patches x 32
-// channels (CB = 1: layers of 32 output channels or an odd number of 32-channel blocks); LWP: floats per LDS row of the input tile
-template <int PR, int PC, int LWP, int CB>
+// channels (CB = 1: layers of 32 output channels or an odd number of 32-channel blocks).  A stage covers KC = 4 CB "channels" q, so that the
+// input transform of a stage is 256 (q, patch) pairs for either shape: every one of the 512 threads transforms half a pair per stage.
+template <int PR, int PC, int CB>
 struct W4Geo {
-  static constexpr int kPB = 2 / CB, kNP = 32 * kPB, kCO = 32 * CB;   // patch blocks per wave tile, patches and output channels per workgroup
+  static constexpr int kPB = 2 / CB, kNP = 32 * kPB, kCO = 32 * CB, kKC = kKQ * CB;
   static_assert((CB == 1 || CB == 2) && PR * PC == kNP, "32 patches x 64 channels or 64 patches x 32 channels per workgroup");
-  static constexpr int kRows = 4 * PR + 2, kLW = 4 * PC + 8;      // input rows; loaded columns gw = w0 - 4 .. w0 + 4 PC + 3 (whole aligned float4 groups)
-  static_assert(LWP >= kLW + 4 && LWP % 4 == 0, "row pitch (the tile sits one column to the right of the row's start)");
-  static constexpr int kSX = kKC * kRows * LWP;                   // floats per input-tile buffer
-  static constexpr int kXN = kKC * kRows * (kLW / 4);             // float4 groups per stage
-  static constexpr int kXSl = (kXN + 511) / 512;
-  static constexpr int kSW = 36 * kKC * kCO, kSV = 36 * kKC * kNP;
-  static constexpr int kPairs = kKC * kNP;                        // (q, patch) pairs of the input transform per stage: two threads each
-  static constexpr size_t kLds = 2 * sizeof(float) * (kSX + kSW + kSV);
-  static_assert(kLds >= sizeof(float) * 36 * 16 * kNP && kLds <= 160 * 1024, "the exchange buffer of the epilogue fits; the CU's LDS holds the workgroup");
+  static constexpr int kRows = 4 * PR + 2;                        // input rows h0 - 1 .. h0 + 4 PR
+  // Input tiles arrive by LDS-DMA (16 bytes per lane, 64 consecutive groups of four columns per wave instruction): the LDS image is
+  // [q][row][group], the groups of a row start at column w0 - 4 (whole aligned groups: none straddles the map's left edge; one entirely
+  // outside the map is a lane whose offset fails the range check = zeros).  Groups per row: PC + 2 needed, padded so that the patch rows
+  // read together by the transform fall into different banks (pitch = 8 mod 16 floats at 8 patches per row, 0 mod 16 at 16).
+  static constexpr int kGPR = PC == 16 ? 20 : PC + 2;
+  static_assert(PC == 16 || (PC == 8 && kGPR % 4 == 2), "row pitch against bank conflicts");
+  static constexpr int kPitch = 4 * kGPR;
+  static constexpr int kXN = kKC * kRows * kGPR;                  // groups per stage
+  static constexpr int kPieces = (kXN + 63) / 64;                 // wave instructions per stage (1 KiB each)
+  static constexpr int kXSl = (kPieces + 7) / 8, kXMin = kPieces / 8;      // pieces per wave: at most / at least
+  static constexpr int kSX = kPieces * 256;                       // floats per input-tile buffer
+  static constexpr int kNXB = 3;                                  // input-tile buffers: a tile is requested two stages before the transform reads it
+  static constexpr int kSV = 36 * kKC * kNP;                      // floats per V buffer (two of them)
+  static_assert(kKC * kNP == 256, "one (q, patch) pair per two threads");
+  static constexpr size_t kMain = sizeof(float) * (kNXB * kSX + 2 * kSV), kExch = sizeof(float) * 36 * 16 * kNP;      // stage buffers; the epilogue's exchange buffer
+  static constexpr size_t kLds = kMain > kExch ? kMain : kExch;
+  static_assert(kLds <= 160 * 1024, "the CU's LDS holds the workgroup");
 };
 
 struct Epi4 {
@@ -91,16 +123,16 @@ __device__ __forceinline__ void at6(float m0, float m1, float m2, float m3, floa
 }
 
 // ABL: phase ablation for timing (compile-time, so the schedule of the rest is the shipped one; results are wrong): bit 0 input transform,
-// 1 matrix instructions, 2 input loads, 3 input commits, 4 the stage's wait + barrier, 5 operand reads, 6 weight DMA.
+// 1 matrix instructions, 2 input-tile DMA, 3 the edge fix-up, 4 the stage's wait + barrier, 5 operand reads, 6 weight loads.
 // The -DADV_TEST_HOOKS build's probe instantiates non-zero values, the shipped kernels are ABL = 0.
 // PAIR (16 x 32-output tiles of 2D layers on maps of at most 15 x 16 pixels - the RoI heads' 14 x 14 maps): the tile's left and right halves are
 // TWO IMAGES side by side (blockIdx.z = image pair): an image's right zero padding and its neighbour's left one coincide in the LDS tile, so
-// a 14 x 14 map uses 77 % of the tile instead of 38 %.  Needs Cin % 4 == 0 (the range check covers the pair, not one image's channels).
-template <int PR, int PC, int LWP, int CB, bool DEPTH, int ABL = 0, bool PAIR = false>
+// a 14 x 14 map uses 77 % of the tile instead of 38 %.  Needs Cin % 8 == 0 (the range check covers the pair, not one image's channels).
+template <int PR, int PC, int CB, bool DEPTH, int ABL = 0, bool PAIR = false>
 __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x, const float* __restrict__ wp, float* __restrict__ y, int Cin, int Cout,
                                                      int cinpad, int copad, int D, int H, int W, int tiles_w, long long wbytes, int nimg, int flags, Epi4 epi) {
-  using G = W4Geo<PR, PC, LWP, CB>;
-  constexpr int PB = G::kPB, NPT = G::kNP, CO = G::kCO;
+  using G = W4Geo<PR, PC, CB>;
+  constexpr int PB = G::kPB, NPT = G::kNP, CO = G::kCO, KC = G::kKC, NSUB = CB, NH = 18 * CB;      // NH: matrix instructions (= half-steps) per wave and stage
   constexpr int dbg = ABL;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -114,84 +146,83 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
   const long long HW = static_cast<long long>(H) * W;
   const long long DHW = HW * D;
 
-  float* const sxb = lds;                          // [2][KC][rows][LWP]   input tiles
-  float* const swb = lds + 2 * G::kSX;             // [2][36][KC][CO]      U of the stage
-  float* const svb = swb + 2 * G::kSW;             // [2][36][KC][NPT]     V of the stage
+  float* const sxb = lds;                          // [3][KC][rows][groups][4]   input tiles (+ the pad of the last 1 KiB piece)
+  float* const svb = lds + G::kNXB * G::kSX;       // [2][36][KC][NPT]           V of the stage
 
-  // ---- addressing: buffer loads, one 32-bit byte offset per slot computed once per tile, the hardware's range check = zero padding
+  // ---- input tiles: LDS-DMA, one 32-bit byte offset per piece and lane computed once per tile; the descriptor's base moves with the
+  // stage (scalar arithmetic), the hardware's range check writes the zeros of the padding: a lane outside the map (row, whole group, pad)
+  // carries an offset no descriptor admits.  Left: groups start on multiples of four columns, none straddles column 0.  Right (W % 4 != 0):
+  // the group that straddles column W brings the next row's first columns along - the lane that requested it overwrites them with zeros
+  // when its piece has landed (xfm: the elements to clear; the rare lanes of the right-edge tiles only).
   const float* const xb = x + b * Cin * DHW;
-  const long long ximgs = PAIR ? (b + 1 < nimg ? 2 : 1) : 1;      // images behind the descriptor
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, static_cast<int>(static_cast<unsigned>(ximgs * Cin * DHW * 4)), 0x00020000);
+  const unsigned xtotal = static_cast<unsigned>((PAIR ? (b + 1 < nimg ? 2LL : 1LL) : 1LL) * Cin * DHW * 4);      // bytes behind the descriptor (whole tensor of the image / the pair)
   const __amdgpu_buffer_rsrc_t rwgt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wp), 0, static_cast<int>(wbytes), 0x00020000);
-  int xvo[G::kXSl], xls[G::kXSl];
-  unsigned xvm[G::kXSl];
+  int xvo[G::kXSl];
+  unsigned xfm[G::kXSl];
 #pragma unroll
   for (int i = 0; i < G::kXSl; ++i) {
-    const int sidx = tid + 512 * i;
-    const int j = sidx % (G::kLW / 4), r = (sidx / (G::kLW / 4)) % G::kRows, c = sidx / ((G::kLW / 4) * G::kRows);
-    // groups start on multiples of four columns: none straddles the row's start.  PAIR: groups 0-4 are image A's columns -4 .. 15, groups
-    // 5-9 image B's columns 0 .. 19 (LDS column = column + 5 / + 21: B's column -1 is A's column 15 - zero padding for both)
+    const int sidx = (wave + 8 * i) * 64 + lane;
+    const int j = sidx % G::kGPR, r = (sidx / G::kGPR) % G::kRows, c = sidx / (G::kGPR * G::kRows);
+    // PAIR: groups 0-4 are image A's columns -4 .. 15, groups 5-9 image B's columns 0 .. 19 (B's column -1 is A's column 15: zero for both)
     const int gh = h0 - 1 + r, gw = PAIR ? (j < 5 ? 4 * j - 4 : 4 * (j - 5)) : w0 - 4 + 4 * j;
-    xvo[i] = static_cast<int>(static_cast<unsigned>(c < kKC ? c : kKC - 1) * static_cast<unsigned>(DHW) * 4u) + (gh * W + gw) * 4 +
-             (PAIR && j >= 5 ? static_cast<int>(static_cast<unsigned>(Cin * DHW) * 4u) : 0);
-    xls[i] = ((c < kKC ? c : kKC - 1) * G::kRows + r) * LWP + 4 * j + 1;    // LDS column = gw - (w0 - 5): a patch's six columns start on a multiple of four
-    unsigned vm = 0;
-    if (sidx < G::kXN && gh >= 0 && gh < H)
+    const bool in = wave + 8 * i < G::kPieces && c < KC && j < PC + 2 && gh >= 0 && gh < H && gw >= 0 && gw < W;
+    xvo[i] = in ? static_cast<int>(static_cast<unsigned>(c) * static_cast<unsigned>(DHW) * 4u + static_cast<unsigned>(gh * W + gw) * 4u +
+                                   (PAIR && j >= 5 ? static_cast<unsigned>(Cin * DHW) * 4u : 0u))
+                : static_cast<int>(0xFFFFFF00u);
+    unsigned fm = 0;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) vm |= (gw + e >= 0 && gw + e < W) ? (1u << e) : 0u;
-    xvm[i] = vm | (sidx < G::kXN ? 16u : 0u);                // bit 4: the slot exists
+    for (int e = 1; e < 4; ++e) fm |= (in && gw + e >= W) ? (1u << e) : 0u;
+    xfm[i] = fm;
   }
-  struct XSet {
-    v4f v[G::kXSl];
-  };
-  auto stage_off = [&](int q0) -> unsigned {      // wave-uniform: bytes from (channel 0, plane 0) to (the stage's first channel, its plane)
+  auto stage_off = [&](int q0) -> long long {      // wave-uniform: bytes from (channel 0, plane 0) to (the stage's first channel, its plane)
     const int kd = DEPTH ? q0 / cinpad : 0;
     const int ch = DEPTH ? q0 - kd * cinpad : q0;
-    return static_cast<unsigned>((static_cast<long long>(ch) * D + (DEPTH ? od + kd - 1 : 0)) * HW * 4);
+    return (static_cast<long long>(ch) * D + (DEPTH ? od + kd - 1 : 0)) * HW * 4;
   };
-  auto fetch_x1 = [&](int i, int q0, XSet& set) {
-    set.v[i] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rx, xvo[i] + static_cast<int>(stage_off(q0)), 0, 0));
+  auto dma_x = [&](int i, int q0, int buf) {       // piece wave + 8 i of the tile of the stage that starts at q0 -> input buffer buf
+    const long long so = stage_off(q0);
+    const long long left = static_cast<long long>(xtotal) - so;      // (channels past Cin: nothing left - zeros)
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(xb) + so), 0,
+                                                                         static_cast<int>(static_cast<unsigned>(left > 0 ? left : 0)), 0x00020000);
+    float* dst = sxb + buf * G::kSX + (wave + 8 * i) * 256;
+    const int vo = xvo[i];      // (a copy: the host pass of hipcc cannot compile the array element as this builtin's argument)
+    if (wave + 8 * i < G::kPieces) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)dst, 16, vo, 0, 0, 0);
   };
-  auto commit_x1 = [&](int i, int buf, const XSet& set) {
-    v4f v = set.v[i];
-    const unsigned m = xvm[i];
+  auto fix_x = [&](int i, int buf) {               // the straddling groups of piece wave + 8 i: the columns past the map's right edge -> 0
+    if (xfm[i]) {
+      float* p = sxb + buf * G::kSX + ((wave + 8 * i) * 64 + lane) * 4;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = (m >> e) & 1u ? v[e] : 0.0f;
-    if (m & 16u) {        // the group lands one column off a 16-byte boundary (so that the transform reads whole aligned pieces): 4 + 8 + 4 bytes
-      float* p = sxb + buf * G::kSX + xls[i];
-      p[0] = v[0];
-      *reinterpret_cast<v2f*>(p + 1) = v2f{v[1], v[2]};
-      p[3] = v[3];
+      for (int e = 1; e < 4; ++e)
+        if ((xfm[i] >> e) & 1u) p[e] = 0.0f;
     }
   };
-  // The 36 positions are dealt to the eight waves so that the two waves of a SIMD carry nine between them: waves 0-3 own NT each,
-  // k = w + 4 n; waves 4-7 own 9 - NT each, k = 4 NT + (w - 4) + 4 n.  NT = 4 / 5 everywhere (64-channel workgroups: waves 0-3 also compute the
-  // whole input transform; giving them three positions and the others six measured 2-5 % slower, profiles/r05_wino4_split36_negative.jsonl).
-  constexpr int NT = CB == 2 ? kTransformWavePositions : 4;      // positions of a wave 0-3 (waves 4-7: 9 - NT)
-  const int kbase = wave < 4 ? wave : 4 * NT - 4 + wave;
-  // weights: a wave stages the positions it multiplies itself: U[k][q0 .. q0 + 3][co0 .. co0 + CO - 1] = 1 KiB (CO = 64) or 512 B, one
-  // LDS-DMA instruction (lane L: row L / (CO / 4), float4 L % (CO / 4); the upper half of the wave idle at CO = 32), straight into the
-  // stage buffer - no staging registers, no commit, no other wave involved
-  const int wrows = DEPTH ? 3 * cinpad : cinpad;           // rows of U per transform position
-  const int wvo = ((lane / (CO / 4)) * copad + co0 + 4 * (lane % (CO / 4))) * 4;
-  auto dma_w1 = [&](int n, int q0, int buf) {
-    const int k = kbase + 4 * n;
-    float* dst = swb + buf * G::kSW + k * (kKC * CO);
-    if (CB == 2 || lane < 32) __builtin_amdgcn_raw_ptr_buffer_load_lds(rwgt, (lds_void*)dst, 16, wvo, (k * wrows + q0) * copad * 4, 0, 0);
-  };
 
-  // ---- the input transform: two threads per (q, patch) pair, three of the six rows of V each (hs = 0: rows 0-2, 1: rows 3-5).
-  // CB = 2 (128 pairs): waves 0, 1 / 2, 3; waves 4-7 do not transform (they carry five positions).  CB = 1 (256 pairs): waves 0-3 / 4-7.
-  const int pair = tid % G::kPairs, tc = pair / NPT, tp = pair % NPT;
-  const int hs = CB == 2 ? (wave >> 1) & 1 : wave >> 2;
-  const int toff = (tc * G::kRows + 4 * (tp / PC) + hs) * LWP + 4 * (tp % PC) + 4;     // first needed row: 0 (rows 0-4) or 1 (rows 1-5)
-  const int voff = tc * NPT + tp;
+  // ---- positions.  The two waves of a SIMD (w and w + 4) carry nine of the 36 positions between them, k = sp + 4 j (sp = w & 3): wave w the
+  // positions j = 0 .. 3 whole and block 0 of position 4 (channel block at CB = 2, patch block at CB = 1), wave w + 4 block 1 of position 4 and
+  // j = 5 .. 8 whole: NINE 32 x 32 accumulators and 18 matrix instructions per sub-stage for every wave, and every wave computes its
+  // 1/512th of the input transform - no wave waits at the stage's barrier for a partner with more to do (an earlier version gave four /
+  // five whole positions and the whole transform to waves 0-3: those finished 800 cycles after the others, profiles/r06_wino4_stamps.jsonl).
+  const int sp = wave & 3;
+  // weights: every wave multiplies ITS OWN positions and nobody else reads them, so U never touches LDS: the prepared layout
+  // [k][q / 4][co / 64][lane][cb, kp] hands lane (half, l32) the four A operands of one (position, sub-stage) - q = 4 s + 2 kp + half,
+  // co = 64 g + 32 cb + l32 - as ONE 16-byte buffer load (1 KiB per wave instruction, whole lines); the shared position and 32-channel
+  // workgroups take one block's half (8 bytes).  The wave-uniform part of the address travels in the scalar offset.  Register ring: the load
+  // of (sub-stage + 2, slot) is issued right behind the last matrix instruction of (sub-stage, slot), into the registers that one read.
+  const int wqs = (DEPTH ? 3 * cinpad : cinpad) / kKQ;     // sub-stages of U per transform position
+  const int wg64 = copad / 64;
+  const int wgrp = CB == 2 ? blockIdx.y : blockIdx.y >> 1;
+  const int wvo16 = lane * 16, wcb = CB == 2 ? 0 : 8 * (blockIdx.y & 1);
+
+  // ---- the input transform: two threads per (q, patch) pair, three of the six rows of V each (waves 0-3: rows 0-2, waves 4-7: rows 3-5)
+  const int pair = tid & 255, tc = pair / NPT, tp = pair % NPT;
+  const int toff = (tc * G::kRows + 4 * (tp / PC)) * G::kPitch + 4 * (tp % PC) + 2;     // LDS column of the patch's first column - 1 (8-byte aligned)
   float td[5][6], tt[3][6], tv[18];
-  auto tr_read = [&](int i, int buf) {
-    const float* p = sxb + buf * G::kSX + toff + i * LWP;          // six columns: one 16-byte and one 8-byte read, both aligned
-    const v4f m = *reinterpret_cast<const v4f*>(p);
-    const v2f n = *reinterpret_cast<const v2f*>(p + 4);
-    td[i][0] = m[0], td[i][1] = m[1], td[i][2] = m[2], td[i][3] = m[3], td[i][4] = n[0], td[i][5] = n[1];
+  auto tr_read = [&](int i, const float* tile) {           // six columns at LDS columns 4 p + 3 .. 4 p + 8: 8 + 16 + 8 bytes, all aligned
+    const float* p = tile + i * G::kPitch;
+    const v2f a = *reinterpret_cast<const v2f*>(p);
+    const v4f m = *reinterpret_cast<const v4f*>(p + 2);
+    const v2f n = *reinterpret_cast<const v2f*>(p + 6);
+    td[i][0] = a[1], td[i][1] = m[0], td[i][2] = m[1], td[i][3] = m[2], td[i][4] = m[3], td[i][5] = n[0];
   };
   auto tr_cols = [&](auto hs_c, int j) {          // column pass, column j: the thread's three rows of T = B^T d
     constexpr bool kHi = decltype(hs_c)::value;
@@ -212,18 +243,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
 #pragma unroll
     for (int j = 0; j < 6; ++j) tv[6 * i + j] = o[j];
   };
-  auto tr_write = [&](int idx, int buf) {
-    const int k = (3 * hs + idx / 6) * 6 + idx % 6;
-    svb[buf * G::kSV + k * (kKC * NPT) + voff] = tv[idx];
-  };
-
-  // ---- operands of the matrix instructions: A = U_k[q = 2 kp + half][co = 32 cb + l32], B = V_k[q][patch = 32 pb + l32]
-  const int aoff = (kbase * kKC + half) * CO + l32, boff = (kbase * kKC + half) * NPT + l32;
 
   const int q_lo = DEPTH ? (od == 0 ? cinpad : 0) : 0;
   const int q_hi = DEPTH ? (od == D - 1 ? 2 * cinpad : 3 * cinpad) : cinpad;
-  const int nstage = (q_hi - q_lo) / kKC;
-  auto qclamp = [&](int q) { return q < q_hi - kKC ? q : q_hi - kKC; };
+  const int nstage = (q_hi - q_lo) / KC;
+  auto qclamp = [&](int q) { return q < q_hi - KC ? q : q_hi - KC; };      // (stage starts beyond the last one: the last one again)
 
   // epilogue geometry: the exchange rounds hand every thread (channel of the round's 16, patch) items - one at 32 patches, two at 64
   const long long MP = static_cast<long long>(Cout) * DHW;
@@ -237,121 +261,181 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
   const long long eimg = PAIR && (ep % PC) >= 4 ? MP : 0;      // PAIR: the right half of the tile is the pair's second image
   const bool eok = !PAIR || (ep % PC) < 4 || b + 1 < nimg;
 
-  // body<NP, TR, HS>: a wave's whole life after the set-up - NP positions; TR: it also computes the input transform (half HS of it)
-  auto body = [&](auto np_c, auto t_c, auto hs_c) __attribute__((always_inline)) {
-    constexpr int NP = decltype(np_c)::value;
-    constexpr bool TR = decltype(t_c)::value;
-    if (CB == 2 && ((TR && (flags & 1)) || (!TR && (flags & 2)))) __builtin_amdgcn_s_setprio(1);      // static priority of one half of the waves (A/B: kWaveFlags)
-    constexpr int NS = 2 * NP;                    // steps per stage: (position n, q pair kp), two matrix instructions each
-    f32x16 acc[NP][2];                            // [n][cb] (CB = 2) or [n][pb] (CB = 1)
+  // body<HI>: a wave's whole life after the set-up (HI: waves 4-7)
+  auto body = [&](auto hi_c) __attribute__((always_inline)) {
+    constexpr bool HI = decltype(hi_c)::value;
+    constexpr int JB = HI ? 5 : 0;                // whole positions j = JB + slot (slot 0 .. 3); slot 4 = position 4, block HI
+    if ((!HI && (flags & 1)) || (HI && (flags & 2))) __builtin_amdgcn_s_setprio(1);      // static priority of one half of the waves (A/B: kWaveFlags)
+    f32x16 acc[9];                                // [2 slot + block] for the whole positions, [8] the shared one
 #pragma unroll
-    for (int n = 0; n < NP; ++n)
+    for (int u = 0; u < 9; ++u)
 #pragma unroll
-      for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int v = 0; v < 16; ++v) acc[n][c][v] = 0.0f;
-    XSet xsA, xsB;
+      for (int v = 0; v < 16; ++v) acc[u][v] = 0.0f;
+    auto kpos = [&](int slot) { return sp + 4 * (slot < 4 ? JB + slot : 4); };
+    using WF = std::conditional_t<CB == 2, v4f, v2f>;      // whole position: [cb][kp] or [kp]
+    struct WSet {
+      WF f[NSUB][4];
+      v2f s[NSUB];
+    };
+    WSet wsA, wsB;
+    auto load_w = [&](int sub, int slot, int q0, WSet& set) {      // q0: first q of the sub-stage
+      const int so = ((kpos(slot) * wqs + q0 / kKQ) * wg64 + wgrp) * 1024;      // wave-uniform
+      if (slot < 4) {
+        if constexpr (CB == 2) set.f[sub][slot & 3] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rwgt, wvo16, so, 0));
+        else set.f[sub][slot & 3] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rwgt, wvo16 + wcb, so, 0));
+      } else {
+        set.s[sub] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rwgt, wvo16 + (CB == 2 ? (HI ? 8 : 0) : wcb), so, 0));
+      }
+    };
+    auto tr_write = [&](int idx, float* vdst) {   // vdst: the V buffer + the pair's offset
+      const int k = (3 * (HI ? 1 : 0) + idx / 6) * 6 + idx % 6;
+      vdst[k * 256] = tv[idx];
+    };
     {
-      // prologue: the first three input tiles and the first weights are requested together
-      XSet xs0, xs1;
+      // prologue: the first three input tiles and the weights of the first two sub-stages are requested together
 #pragma unroll
-      for (int i = 0; i < G::kXSl; ++i) fetch_x1(i, q_lo, xs0);
+      for (int t = 0; t < G::kNXB; ++t)
 #pragma unroll
-      for (int n = 0; n < NP; ++n) dma_w1(n, q_lo, 0);
+        for (int i = 0; i < G::kXSl; ++i) dma_x(i, qclamp(q_lo + t * KC), t);
 #pragma unroll
-      for (int i = 0; i < G::kXSl; ++i) fetch_x1(i, qclamp(q_lo + kKC), xs1);
+      for (int s = 0; s < NSUB; ++s)
 #pragma unroll
-      for (int i = 0; i < G::kXSl; ++i) fetch_x1(i, qclamp(q_lo + 2 * kKC), xsB);
+        for (int slot = 0; slot < 5; ++slot) load_w(s, slot, q_lo + kKQ * s, wsA);
+      if constexpr (CB == 1) {
 #pragma unroll
-      for (int i = 0; i < G::kXSl; ++i) commit_x1(i, 0, xs0);
+        for (int slot = 0; slot < 5; ++slot) load_w(0, slot, qclamp(q_lo + KC), wsB);
+      }
+      asm volatile("s_waitcnt vmcnt(10)" ::: "memory");      // the tiles have landed (the weight loads behind them travel on)
 #pragma unroll
-      for (int i = 0; i < G::kXSl; ++i) commit_x1(i, 1, xs1);
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      if constexpr (TR) {
+      for (int i = 0; i < G::kXSl; ++i) fix_x(i, 0), fix_x(i, 1);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      {
+        const float* tile = sxb + toff + (HI ? G::kPitch : 0);
 #pragma unroll
-        for (int i = 0; i < 5; ++i) tr_read(i, 0);
+        for (int i = 0; i < 5; ++i) tr_read(i, tile);
 #pragma unroll
-        for (int j = 0; j < 6; ++j) tr_cols(hs_c, j);
+        for (int j = 0; j < 6; ++j) tr_cols(hi_c, j);
 #pragma unroll
         for (int i = 0; i < 3; ++i) tr_row(i);
 #pragma unroll
-        for (int k = 0; k < 18; ++k) tr_write(k, 0);
+        for (int k = 0; k < 18; ++k) tr_write(k, svb + pair);
       }
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
-    // Stage st: NS steps of two matrix instructions each (two channel blocks sharing the B operand, or two patch blocks sharing the A
-    // operand) on U / V of stage st.  Woven between them, one piece per step: the LDS-DMA of the wave's weights of stage st + 1, the loads
-    // of the input tile of stage st + 3, the commit of the input tile of stage st + 2 (requested during stage st - 1) and - transform
-    // waves, eight steps - the input transform of stage st + 1.  The scheduler may not move anything across a step.  ONE barrier per stage;
-    // before it the wave's LDS-DMAs have landed (vmcnt: all but the stage's own input loads, issued after them, which travel on).
-    auto stage = [&](int st, XSet& fxs, const XSet& cxs) __attribute__((always_inline)) {
-      constexpr int kAhead = 3;
-      float r0[NS], r1[NS], r2[NS];               // CB = 2: A (block 0), A (block 1), B;  CB = 1: A, B (block 0), B (block 1)
+#ifdef ADV_WINO4_STAMPS
+    unsigned long long stamp0 = __builtin_amdgcn_s_memtime();
+    const bool stamped = blockIdx.x < 8 && blockIdx.y == 0 && blockIdx.z == 0;
+#endif
+    // Stage st: NH matrix instructions on U (registers) / V (LDS) of stage st, one per HALF-step, the side work in front of them (a wave
+    // issues in order: side work behind a matrix instruction runs in its 64-cycle shadow).  Woven in, one piece per half-step: the wave's
+    // pieces of the input tile of stage st + 3 (LDS-DMA), its eighteen-step share of the input transform of stage st + 1 (row reads,
+    // columns, rows, writes), a weight load behind the last matrix instruction of every slot.  The scheduler may not move anything across a
+    // half-step.  At the end: the pieces of the tile of stage st + 2 (requested a stage ago) have landed - counted wait, the younger loads
+    // travel on - their right-edge columns are cleared, then ONE barrier behind the wave's LDS writes.
+    int xr = 0;                                   // st % 3: the input buffer of tiles st, st + 3
+    auto stage = [&](int st, WSet& ws) __attribute__((always_inline)) {
+      constexpr int kAhead = 6;                   // B operands: read this many half-steps ahead
+      float bv[NH];
       if constexpr ((dbg & 32) != 0) {
 #pragma unroll
-        for (int t = 0; t < NS; ++t) r0[t] = r1[t] = r2[t] = static_cast<float>(lane + t);
+        for (int h = 0; h < NH; ++h) bv[h] = static_cast<float>(lane + h);
       }
-      const float* ap = swb + (st & 1) * G::kSW + aoff;
-      const float* bp = svb + (st & 1) * G::kSV + boff;
-      auto load = [&](int t) {
-        const int row = (4 * (t >> 1)) * kKC + 2 * (t & 1);      // (k - kbase) * KC + 2 kp
-        r0[t] = ap[row * CO];
-        r1[t] = CB == 2 ? ap[row * CO + 32] : bp[row * NPT];
-        r2[t] = CB == 2 ? bp[row * NPT] : bp[row * NPT + 32];
+#ifdef ADV_WINO4_STAMPS
+      unsigned long long stampx = 0;
+      const int hsel = st % NH;
+#endif
+      const int x1 = xr == 2 ? 0 : xr + 1, x2 = xr == 0 ? 2 : xr - 1;      // (st + 1) % 3, (st + 2) % 3
+      const float* bp = svb + (st & 1) * G::kSV + half * NPT + l32;          // V_k[q = 2 kp + half (+ 4 sub)][patch = 32 pb + l32]
+      float* const vdst = svb + ((st + 1) & 1) * G::kSV + pair;
+      const float* const tile = sxb + x1 * G::kSX + toff + (HI ? G::kPitch : 0);
+      // half-step h = 18 sub + m:  m < 16: slot m / 4, kp = (m / 2) % 2, block m % 2;  m = 16, 17: the shared position, kp = m - 16
+      auto need_b = [](int h) { const int m = h % 18; return CB == 1 || m >= 16 || (m & 1) == 0; };       // does this half-step start a new B operand?
+      auto load_b = [&](int h) {
+        const int sub = h / 18, m = h % 18;
+        const int slot = m < 16 ? m / 4 : 4, kp = m < 16 ? (m >> 1) & 1 : m - 16, blk = m < 16 ? m & 1 : (HI ? 1 : 0);
+        bv[h] = bp[kpos(slot) * 256 + (kKQ * sub + 2 * kp) * NPT + (CB == 1 ? 32 * blk : 0)];
       };
-      const int nb = (st + 1) & 1;
-      const int q1 = qclamp(q_lo + (st + 1) * kKC), q3 = qclamp(q_lo + (st + 3) * kKC);
+      const int qn = CB == 2 ? qclamp(q_lo + (st + 1) * KC) : qclamp(q_lo + (st + 2) * KC);      // the stage whose weights this stage requests
+      const int q3 = qclamp(q_lo + (st + 3) * KC);
 #pragma unroll
-      for (int t = 0; t < kAhead; ++t)
-        if (!(dbg & 32)) load(t);
-      // HALF-steps: exactly one matrix instruction each, the side work in front of it.  A wave issues in order: with both matrix
-      // instructions of a step back to back the second waits out the first's 64 cycles with the wave stalled behind it, so only every
-      // other matrix instruction had side work in its shadow (profiles/r05_wino4_phases.jsonl: the two did not overlap at all).
-      // Schedule (transform waves): rows 0-1 | 2-3 | 4 | columns 0-1 | 2-3 | 4-5 | V row 0 | V row 1 + writes | V row 2 + writes | writes x 3,
-      // the weight DMAs on half-steps 0 .. NP-1, the input loads on 9 .., the commits on the last ones.
+      for (int h = 0; h < kAhead; ++h)
+        if (need_b(h) && !(dbg & 32)) load_b(h);
 #pragma unroll
-      for (int h = 0; h < 2 * NS; ++h) {
-        const int t = h >> 1;
-        if ((h & 1) == 0 && t + kAhead < NS && !(dbg & 32)) load(t + kAhead);
-        if (h < NP && !(dbg & 64)) dma_w1(h, q1, nb);
-        if (h >= 9 && h < 9 + G::kXSl && !(dbg & 4)) fetch_x1(h - 9, q3, fxs);
-        if (h >= 2 * NS - 1 - G::kXSl && h < 2 * NS - 1 && !(dbg & 8)) commit_x1(h - (2 * NS - 1 - G::kXSl), st & 1, cxs);
-        if constexpr (TR && !(dbg & 1)) {
-          if (h == 0) tr_read(0, nb), tr_read(1, nb);
-          if (h == 1) tr_read(2, nb), tr_read(3, nb);
-          if (h == 2) tr_read(4, nb);
-          if (h >= 3 && h < 6) tr_cols(hs_c, 2 * (h - 3)), tr_cols(hs_c, 2 * (h - 3) + 1);
-          if (h >= 6 && h < 9) tr_row(h - 6);
-          if (h >= 7 && h < 12) {
-            constexpr int kPer[5] = {3, 3, 4, 4, 4};      // 18 writes over half-steps 7-11 (row i's values exist from half-step 6 + i on)
-            int first = 0;
+      for (int h = 0; h < NH; ++h) {
+        const int sub = h / 18, m = h % 18;
+#ifdef ADV_WINO4_STAMPS
+        if (h == hsel) stampx = __builtin_amdgcn_s_memtime();
+#endif
+        if (h + kAhead < NH && need_b(h + kAhead) && !(dbg & 32)) load_b(h + kAhead);
+        if (h >= 1 && h < 1 + G::kXSl && !(dbg & 4)) dma_x(h - 1, q3, xr);
+        if constexpr (!(dbg & 1)) {
+          if (h % CB == 0) {                      // transform event e = h / CB (0 .. 17)
+            const int e = h / CB;
+            if (e < 5) tr_read(e, tile);
+            if (e >= 5 && e < 11) tr_cols(hi_c, e - 5);
+            if (e >= 11 && e < 14) tr_row(e - 11);
+            if (e >= 12) {                        // row r's six values exist from event 11 + r on: three writes per event, 12 .. 17
 #pragma unroll
-            for (int u = 7; u < h; ++u) first += kPer[u - 7];
-#pragma unroll
-            for (int u = 0; u < kPer[h - 7]; ++u) tr_write(first + u, nb);
+              for (int u = 0; u < 3; ++u) tr_write(3 * (e - 12) + u, vdst);
+            }
           }
         }
         if constexpr ((dbg & 2) != 0) {
         } else if constexpr (CB == 2) {
-          if ((h & 1) == 0) acc[t >> 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(r0[t], r2[t], acc[t >> 1][0], 0, 0, 0);
-          else acc[t >> 1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(r1[t], r2[t], acc[t >> 1][1], 0, 0, 0);
+          if (m < 16) {
+            const int slot = m / 4, kp = (m >> 1) & 1, cb = m & 1;
+            acc[2 * slot + cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws.f[sub][slot][2 * cb + kp], bv[h & ~1], acc[2 * slot + cb], 0, 0, 0);
+          } else {
+            acc[8] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws.s[sub][m - 16], bv[h], acc[8], 0, 0, 0);
+          }
         } else {
-          if ((h & 1) == 0) acc[t >> 1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(r0[t], r1[t], acc[t >> 1][0], 0, 0, 0);
-          else acc[t >> 1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(r0[t], r2[t], acc[t >> 1][1], 0, 0, 0);
+          if (m < 16) {
+            const int slot = m / 4, kp = (m >> 1) & 1, pb = m & 1;
+            acc[2 * slot + pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws.f[sub][slot][kp], bv[h], acc[2 * slot + pb], 0, 0, 0);
+          } else {
+            acc[8] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws.s[sub][m - 16], bv[h], acc[8], 0, 0, 0);
+          }
+        }
+        if (!(dbg & 64)) {
+          if (m < 16 && (m & 3) == 3) load_w(sub, m / 4, qn + kKQ * sub, ws);
+          if (m == 17) load_w(sub, 4, qn + kKQ * sub, ws);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      // the stage's LDS-DMAs have landed (issued before its input loads, which travel on: the counter retires in order), the LDS writes
-      // are done; a plain __syncthreads() would wait for ALL memory operations - the input loads too
-      if constexpr (!(dbg & 16)) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(G::kXSl) : "memory");
+#ifdef ADV_WINO4_STAMPS
+      const unsigned long long stamp2 = __builtin_amdgcn_s_memtime();
+#endif
+      // the wave's pieces of the tile of stage st + 2 (requested during stage st - 1) have landed: younger than they are at most this
+      // stage's pieces and the weight loads of two stages (a plain __syncthreads() would wait for every load in flight)
+      if constexpr (!(dbg & 16)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::kXMin + 10 * NSUB - 2) : "memory");
+      if constexpr (!(dbg & 8)) {
+#pragma unroll
+        for (int i = 0; i < G::kXSl; ++i) fix_x(i, x2);
+      }
+#ifdef ADV_WINO4_STAMPS
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const unsigned long long stamp3 = __builtin_amdgcn_s_memtime();
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      const unsigned long long stamp4 = __builtin_amdgcn_s_memtime();
+      if (stamped && st < 64 && lane == 0) {
+        unsigned long long* o = adv_wino4_stamps[blockIdx.x][wave][st];
+        o[0] = stamp0, o[1] = stampx, o[2] = stamp2, o[3] = stamp3, o[4] = stamp4;
+      }
+      stamp0 = stamp4;
+#else
+      if constexpr (!(dbg & 16)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+      xr = x1;
     };
-    {
+    if constexpr (CB == 2) {
+      for (int st = 0; st < nstage; ++st) stage(st, wsA);
+    } else {
       int st = 0;
       for (; st + 1 < nstage; st += 2) {
-        stage(st, xsA, xsB);
-        stage(st + 1, xsB, xsA);
+        stage(st, wsA);
+        stage(st + 1, wsB);
       }
-      if (st < nstage) stage(st, xsA, xsB);
+      if (st < nstage) stage(st, wsA);
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // (clamped requests of the last stages: nothing may land later)
 
@@ -362,16 +446,21 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
     for (int round = 0; round < 2 * CB; ++round) {          // (unrolled: the accumulator registers are addressed by constants)
       if (co0 + 16 * round >= Cout) continue;               // (workgroup-uniform) nothing but padding from here on
 #pragma unroll
-      for (int n = 0; n < NP; ++n) {
-        const int k = kbase + 4 * n;
+      for (int slot = 0; slot < 5; ++slot) {
+        const int k = kpos(slot);
 #pragma unroll
         for (int v8 = 0; v8 < 8; ++v8) {
           const int co16 = (v8 & 3) + 8 * (v8 >> 2) + 4 * half;
           if constexpr (CB == 2) {
-            se[(k * 16 + co16) * NPT + l32] = acc[n][round >> 1][8 * (round & 1) + v8];
+            if (slot < 4) se[(k * 16 + co16) * NPT + l32] = acc[2 * (slot & 3) + (round >> 1)][8 * (round & 1) + v8];
+            else if ((round >> 1) == (HI ? 1 : 0)) se[(k * 16 + co16) * NPT + l32] = acc[8][8 * (round & 1) + v8];
           } else {
-            se[(k * 16 + co16) * NPT + l32] = acc[n][0][8 * round + v8];
-            se[(k * 16 + co16) * NPT + 32 + l32] = acc[n][1][8 * round + v8];
+            if (slot < 4) {
+              se[(k * 16 + co16) * NPT + l32] = acc[2 * (slot & 3)][8 * round + v8];
+              se[(k * 16 + co16) * NPT + 32 + l32] = acc[2 * (slot & 3) + 1][8 * round + v8];
+            } else {
+              se[(k * 16 + co16) * NPT + (HI ? 32 : 0) + l32] = acc[8][8 * round + v8];
+            }
           }
         }
       }
@@ -443,18 +532,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
   };
-  using I4 = std::integral_constant<int, 4>;
-  using I5 = std::integral_constant<int, 5>;
-  using IT = std::integral_constant<int, NT>;
-  using IP = std::integral_constant<int, 9 - NT>;
-  if constexpr (CB == 2) {
-    if (wave >= 4) body(IP{}, std::false_type{}, std::false_type{});
-    else if (hs) body(IT{}, std::true_type{}, std::true_type{});
-    else body(IT{}, std::true_type{}, std::false_type{});
-  } else {
-    if (wave >= 4) body(I5{}, std::true_type{}, std::true_type{});
-    else body(I4{}, std::true_type{}, std::false_type{});
-  }
+  if (wave >= 4) body(std::true_type{});
+  else body(std::false_type{});
 }
 
 int round_up4(int v, int q) { return (v + q - 1) / q * q; }
@@ -465,11 +544,13 @@ int wave_flags() {
   return kWaveFlags;
 }
 
-template <int PR, int PC, int LWP, int CB, bool DEPTH, bool PAIR = false>
+constexpr int kKPad = 8;      // the contraction is padded to whole stages of the 64-channel shape (prepared weights and kernel alike)
+
+template <int PR, int PC, int CB, bool DEPTH, bool PAIR = false>
 int launch_wino4(const float* x, const float* wp, float* y, int b, int cin, int cout, int cinpad, int copad, int d, int h, int w, const Epi4& epi,
                  hipStream_t st) {
-  using G = W4Geo<PR, PC, LWP, CB>;
-  if (PAIR && (w > 15 || cin % kKC != 0)) return ADV_EINVAL;
+  using G = W4Geo<PR, PC, CB>;
+  if (PAIR && (w > 15 || cin % kKPad != 0)) return ADV_EINVAL;
   const int tiles_w = PAIR ? 1 : (w + 4 * PC - 1) / (4 * PC), tiles_h = (h + 4 * PR - 1) / (4 * PR);
   const long long tiles = static_cast<long long>(tiles_w) * tiles_h;
   const int cgroups = (cout + G::kCO - 1) / G::kCO;
@@ -484,8 +565,8 @@ int launch_wino4(const float* x, const float* wp, float* y, int b, int cin, int 
       const int abl = std::atoi(dbg_s);
 #define ADV_WINO4_ABL(A_)                                                                                                                       \
   if (abl == A_) {                                                                                                                              \
-    if (!adv_internal_lds_limit<conv_wino4<PR, PC, LWP, CB, DEPTH, A_>>(G::kLds)) return ADV_ELAUNCH;                                           \
-    hipLaunchKernelGGL((conv_wino4<PR, PC, LWP, CB, DEPTH, A_>), grid, dim3(512), G::kLds, st, x, wp, y, cin, cout, cinpad, copad, d, h, w, tiles_w, \
+    if (!adv_internal_lds_limit<conv_wino4<PR, PC, CB, DEPTH, A_>>(G::kLds)) return ADV_ELAUNCH;                                           \
+    hipLaunchKernelGGL((conv_wino4<PR, PC, CB, DEPTH, A_>), grid, dim3(512), G::kLds, st, x, wp, y, cin, cout, cinpad, copad, d, h, w, tiles_w, \
                        wbytes, b, wave_flags(), epi);                                                                                                            \
     return adv_internal_finish_launch();                                                                                                        \
   }
@@ -494,8 +575,8 @@ int launch_wino4(const float* x, const float* wp, float* y, int b, int cin, int 
     }
   }
 #endif
-  if (!adv_internal_lds_limit<conv_wino4<PR, PC, LWP, CB, DEPTH, 0, PAIR>>(G::kLds)) return ADV_ELAUNCH;
-  hipLaunchKernelGGL((conv_wino4<PR, PC, LWP, CB, DEPTH, 0, PAIR>), grid, dim3(512), G::kLds, st, x, wp, y, cin, cout, cinpad, copad, d, h, w, tiles_w, wbytes,
+  if (!adv_internal_lds_limit<conv_wino4<PR, PC, CB, DEPTH, 0, PAIR>>(G::kLds)) return ADV_ELAUNCH;
+  hipLaunchKernelGGL((conv_wino4<PR, PC, CB, DEPTH, 0, PAIR>), grid, dim3(512), G::kLds, st, x, wp, y, cin, cout, cinpad, copad, d, h, w, tiles_w, wbytes,
                      b, wave_flags(), epi);
   return adv_internal_finish_launch();
 }
@@ -519,12 +600,12 @@ template <bool DEPTH>
 int launch_wino4_tile(int t, const float* x, const float* wp, float* y, int b, int cin, int cout, int cinpad, int copad, int d, int h, int w,
                       const Epi4& epi, hipStream_t st) {
   switch (t) {
-    case 0: return launch_wino4<4, 8, 56, 2, DEPTH>(x, wp, y, b, cin, cout, cinpad, copad, d, h, w, epi, st);
-    case 1: return launch_wino4<2, 16, 80, 2, DEPTH>(x, wp, y, b, cin, cout, cinpad, copad, d, h, w, epi, st);
-    case 2: return launch_wino4<8, 8, 44, 1, DEPTH>(x, wp, y, b, cin, cout, cinpad, copad, d, h, w, epi, st);
-    case 3: return launch_wino4<4, 16, 80, 1, DEPTH>(x, wp, y, b, cin, cout, cinpad, copad, d, h, w, epi, st);
+    case 0: return launch_wino4<4, 8, 2, DEPTH>(x, wp, y, b, cin, cout, cinpad, copad, d, h, w, epi, st);
+    case 1: return launch_wino4<2, 16, 2, DEPTH>(x, wp, y, b, cin, cout, cinpad, copad, d, h, w, epi, st);
+    case 2: return launch_wino4<8, 8, 1, DEPTH>(x, wp, y, b, cin, cout, cinpad, copad, d, h, w, epi, st);
+    case 3: return launch_wino4<4, 16, 1, DEPTH>(x, wp, y, b, cin, cout, cinpad, copad, d, h, w, epi, st);
     default:
-      if constexpr (!DEPTH) return launch_wino4<4, 8, 56, 2, false, true>(x, wp, y, b, cin, cout, cinpad, copad, d, h, w, epi, st);
+      if constexpr (!DEPTH) return launch_wino4<4, 8, 2, false, true>(x, wp, y, b, cin, cout, cinpad, copad, d, h, w, epi, st);
       return ADV_EINVAL;
   }
 }
@@ -540,8 +621,8 @@ int check_wino4_args(const float* x, const float* w_prep, const float* bias, con
 
 constexpr int kCO = 64;       // the prepared weights are padded to multiples of 64 output channels (both workgroup shapes read them)
 
-// U = G g G^T (6 x 6) for every (output, input) channel pair (and depth tap), laid out [k = 6 i + j][kd][c'][m'] (zero rows / columns of
-// padding).  forward: m = co, c = ci, g = w[co][ci][kd];  transpose (backward w.r.t. the input): m = ci, c = co, g = w[co][ci] with all
+// U = G g G^T (6 x 6) for every (output, input) channel pair (and depth tap), laid out [k = 6 i + j][(kd, c') / 4][m' / 64][lane][4] as the
+// kernel's waves load it (zero rows / columns of padding).  forward: m = co, c = ci, g = w[co][ci][kd];  transpose (backward w.r.t. the input): m = ci, c = co, g = w[co][ci] with all
 // its taps reversed.  taps = 1: a 2D layer's [Cout][Cin][3][3] weights.
 __device__ __forceinline__ void g6(float g0, float g1, float g2, float (&t)[6]) {
   const float w6 = -1.0f / 6.0f, w24 = 1.0f / 24.0f, w12 = 1.0f / 12.0f, w6p = 1.0f / 6.0f;
@@ -583,8 +664,12 @@ __global__ void conv_wino4_prep_kernel(const float* __restrict__ w, float* __res
 #pragma unroll
       for (int q = 0; q < 36; ++q) u[q] = 0.0f;
     }
+    // element (k, q = kd kpad + c, m) -> [k][q / 4][m / 64][lane = 32 (q & 1) + m % 32][2 (m / 32 % 2) + (q / 2 % 2)]: the float4 of lane
+    // (half, l32) holds the A operands (cb, kp) of the stage's two matrix-instruction steps
+    const int q = kd * kpad + c;
+    const long long at = ((static_cast<long long>(q >> 2) * (mpad >> 6) + (m >> 6)) * 64 + 32 * (q & 1) + (m & 31)) * 4 + 2 * ((m >> 5) & 1) + ((q >> 1) & 1);
 #pragma unroll
-    for (int q = 0; q < 36; ++q) out[q * n + i] = u[q];
+    for (int k = 0; k < 36; ++k) out[k * n + at] = u[k];
   }
 }
 
@@ -592,7 +677,7 @@ int prep_wino4(const float* w, float* w_prep, int cout, int cin, int taps, int t
   if (!w || !w_prep || cout < 1 || cin < 1) return ADV_EINVAL;
   if ((reinterpret_cast<uintptr_t>(w) & 3) || (reinterpret_cast<uintptr_t>(w_prep) & 15)) return ADV_EALIGN;
   const int k = transpose ? cout : cin, m = transpose ? cin : cout;
-  const int kpad = round_up4(k, kKC), mpad = round_up4(m, kCO);
+  const int kpad = round_up4(k, kKPad), mpad = round_up4(m, kCO);
   const long long n = static_cast<long long>(taps) * kpad * mpad;
   const unsigned blocks = static_cast<unsigned>(n / 256 + 1 < 4096 ? n / 256 + 1 : 4096);
   hipLaunchKernelGGL(conv_wino4_prep_kernel, dim3(blocks), dim3(256), 0, st, w, w_prep, cout, cin, taps, transpose ? 1 : 0, kpad, mpad);
@@ -606,7 +691,7 @@ extern "C" {
 int64_t adv_conv2d_wino4_prep_floats(int cout, int cin, int transpose) {
   if (cout < 1 || cin < 1) return ADV_EINVAL;
   const int k = transpose ? cout : cin, m = transpose ? cin : cout;
-  return 36LL * round_up4(k, kKC) * round_up4(m, kCO);
+  return 36LL * round_up4(k, kKPad) * round_up4(m, kCO);
 }
 
 int adv_conv2d_wino4_prep_weights_f32(const float* w, float* w_prep, int cout, int cin, int transpose, adv_stream_t stream) {
@@ -618,14 +703,14 @@ int adv_conv2d_wino4_f32(const float* x, const float* w_prep, const float* bias,
   if (!x || !w_prep || !y || b < 1 || cin < 1 || cout < 1 || h < 1 || w < 1 || tile < -1 || tile > 4) return ADV_EINVAL;
   if (const int rc = check_wino4_args(x, w_prep, bias, residual, mask, y)) return rc;
   const Epi4 epi{bias, residual, mask, relu ? 1 : 0};
-  return launch_wino4_tile<false>(tile >= 0 ? tile : pick_wino4_tile(cout, h, w, b, w <= 15 && cin % kKC == 0 && b >= 2), x, w_prep, y, b, cin, cout, round_up4(cin, kKC), round_up4(cout, kCO), 1, h, w,
+  return launch_wino4_tile<false>(tile >= 0 ? tile : pick_wino4_tile(cout, h, w, b, w <= 15 && cin % kKPad == 0 && b >= 2), x, w_prep, y, b, cin, cout, round_up4(cin, kKPad), round_up4(cout, kCO), 1, h, w,
                                   epi, static_cast<hipStream_t>(stream));
 }
 
 int64_t adv_conv3d_wino4_prep_floats(int cout, int cin, int transpose) {
   if (cout < 1 || cin < 1) return ADV_EINVAL;
   const int k = transpose ? cout : cin, m = transpose ? cin : cout;
-  return 108LL * round_up4(k, kKC) * round_up4(m, kCO);
+  return 108LL * round_up4(k, kKPad) * round_up4(m, kCO);
 }
 
 int adv_conv3d_wino4_prep_weights_f32(const float* w, float* w_prep, int cout, int cin, int transpose, adv_stream_t stream) {
@@ -637,7 +722,7 @@ int adv_conv3d_wino4_f32(const float* x, const float* w_prep, const float* bias,
   if (!x || !w_prep || !y || b < 1 || cin < 1 || cout < 1 || d < 1 || h < 1 || w < 1 || tile < -1 || tile > 3) return ADV_EINVAL;
   if (const int rc = check_wino4_args(x, w_prep, bias, residual, mask, y)) return rc;
   const Epi4 epi{bias, residual, mask, relu ? 1 : 0};
-  return launch_wino4_tile<true>(tile >= 0 ? tile : pick_wino4_tile(cout, h, w, static_cast<long long>(b) * d, false), x, w_prep, y, b, cin, cout, round_up4(cin, kKC), round_up4(cout, kCO), d, h, w,
+  return launch_wino4_tile<true>(tile >= 0 ? tile : pick_wino4_tile(cout, h, w, static_cast<long long>(b) * d, false), x, w_prep, y, b, cin, cout, round_up4(cin, kKPad), round_up4(cout, kCO), d, h, w,
                                  epi, static_cast<hipStream_t>(stream));
 }
 

@@ -23,10 +23,37 @@ import torch
 _warmed = set()
 
 
+def _flags():
+    """deterministic solvers, no run-time search; ``enabled`` stays what the user set (torch's context manager would default it to False)"""
+    return torch.backends.cudnn.flags(enabled=torch.backends.cudnn.enabled, deterministic=True, benchmark=False)
+
+
 @contextlib.contextmanager
 def solvers():
-    with torch.backends.cudnn.flags(enabled=True, deterministic=True, benchmark=False):
+    with _flags():
         yield
+
+
+def _throw_away(step):
+    """run a warm-up step without consuming the caller's random numbers: an upstream detector's forward may sample (proposal targets),
+    and the real step must draw what it would have drawn without the warm-up"""
+    import random
+    py, cpu = random.getstate(), torch.random.get_rng_state()
+    cuda = torch.cuda.get_rng_state_all() if torch.cuda.is_available() else None
+    try:
+        import numpy as np
+        npst = np.random.get_state()
+    except Exception:                             # noqa: BLE001
+        np = npst = None
+    try:
+        step()
+    finally:
+        random.setstate(py)
+        torch.random.set_rng_state(cpu)
+        if cuda is not None:
+            torch.cuda.set_rng_state_all(cuda)
+        if np is not None:
+            np.random.set_state(npst)
 
 
 def deterministic(fn):
@@ -36,13 +63,13 @@ def deterministic(fn):
     another solver than its later ones).  The caller sees one call and one result either way; ``x`` is not modified by a step."""
     @functools.wraps(fn)
     def inner(self, x, *args, **kwargs):
-        with torch.backends.cudnn.flags(enabled=True, deterministic=True, benchmark=False):
+        with _flags():
             if isinstance(x, torch.Tensor) and x.is_cuda and not torch.cuda.is_current_stream_capturing():
                 seen = self.__dict__.setdefault("_adv_warm_shapes", set())
-                key = (fn.__name__, tuple(x.shape), str(x.device))
+                key = (tuple(x.shape), str(x.device))                                # one key format with warm_adapter(): either warms for both
                 if key not in seen:
                     seen.add(key)
-                    fn(self, x, *args, **kwargs)
+                    _throw_away(lambda: fn(self, x, *args, **kwargs))
             return fn(self, x, *args, **kwargs)
     inner.__wrapped_deterministic__ = True
     return inner
@@ -52,7 +79,7 @@ def under_solvers(fn):
     """decorator for a driver entry point (PgdAttack.run_batch, PatchTrainer.train_batch ...): the call under ``solvers()``, no warm-up"""
     @functools.wraps(fn)
     def inner(*args, **kwargs):
-        with torch.backends.cudnn.flags(enabled=True, deterministic=True, benchmark=False):
+        with _flags():
             return fn(*args, **kwargs)
     return inner
 
@@ -90,7 +117,7 @@ def warm_adapter(adapter, x, extra):
     if key in seen:
         return False
     seen.add(key)
-    adapter.loss_and_grad(x, extra)
+    _throw_away(lambda: adapter.loss_and_grad(x, extra))
     return True
 
 

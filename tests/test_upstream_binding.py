@@ -283,7 +283,7 @@ def test_adopt_verify_catches_a_forward_that_breaks_the_convention():
     old = A._CONVS[nn.Conv2d]
     A._CONVS[nn.Conv2d] = Tracer
     try:
-        with pytest.raises(RuntimeError, match="does not\\s+follow the conv->bn conventions"):
+        with pytest.raises(RuntimeError, match="BatchNorm was folded\\s+into a convolution it does not follow"):
             A.adopt(m, verify=(torch.randn(1, 3, 4, 4, generator=gen),))
     finally:
         A._CONVS[nn.Conv2d] = old
@@ -608,3 +608,40 @@ def test_every_adopted_layer_equals_its_oracle_bit_for_bit(checkout):
                 checked["torch + epilogue"] = checked.get("torch + epilogue", 0) + 1
     assert checked["torch + epilogue"] >= 4
     assert checked["conv2d"] >= 10 and checked["conv3d s1"] >= 4 and checked["conv3d s2"] >= 1 and checked["convT3d"] >= 1, checked
+
+
+def test_adopt_verify_gives_a_sampling_forward_the_same_random_numbers_twice_and_leaves_the_generators_alone():
+    """Stereo R-CNN's proposal-target layer samples rois (numpy / torch generators) inside the forward; the two verification
+    runs must see one generator state, or 'before' and 'after' differ whatever adopt() did - and the caller's generators must be where they
+    were, or a verified run is not the run the un-verified script would have made."""
+    import random
+
+    class Sampling(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv1, self.bn1 = nn.Conv2d(3, 4, 1), nn.BatchNorm2d(4)
+
+        def forward(self, x):
+            y = self.bn1(self.conv1(x))
+            pick = torch.randperm(y.shape[1])[:2]                      # torch generator
+            shift = float(np.random.rand()) + random.random()           # numpy and python generators
+            return y[:, pick] + shift
+
+    gen = torch.Generator().manual_seed(3)
+    m = Sampling().eval()
+    _randomise_bn(m.bn1, gen)
+
+    class Tracer(A.AdoptedConv2d):
+        def forward(self, x):
+            return F.conv2d(x, self.weight, self.bias)
+    old = A._CONVS[nn.Conv2d]
+    A._CONVS[nn.Conv2d] = Tracer
+    try:
+        torch.manual_seed(11), np.random.seed(12), random.seed(13)
+        want = (torch.rand(1).item(), float(np.random.rand()), random.random())
+        torch.manual_seed(11), np.random.seed(12), random.seed(13)
+        rep = A.adopt(m, verify=(torch.randn(1, 3, 4, 4, generator=gen),))
+        assert rep["verified_outputs"] == 1 and rep["verified"][0]["share_beyond_tol"] == 0.0
+        assert (torch.rand(1).item(), float(np.random.rand()), random.random()) == want
+    finally:
+        A._CONVS[nn.Conv2d] = old

@@ -48,6 +48,18 @@ def per_case(src, leg, value, manifest):
     return out
 
 
+def kernel_name(full):
+    """'void (anonymous namespace)::conv_wino4<2, 16, 2, false, 0, false>(float const*, ...)' -> 'conv_wino4<2, 16, 2, false, 0, false>'"""
+    name = full.replace("void ", "", 1).replace("(anonymous namespace)::", "")
+    depth = 0
+    for i, ch in enumerate(name):           # cut at the argument list: the first '(' outside the template brackets
+        depth += ch == "<"
+        depth -= ch == ">"
+        if ch == "(" and depth == 0:
+            return name[:i]
+    return name
+
+
 def mean(rows, key):
     v = [r[4][key] for r in rows if key in r[4]]
     return sum(v) / len(v) if v else None
@@ -61,7 +73,7 @@ def main():
     rows = []
     for k, c in enumerate(manifest["cases"]):
         t, p1, p2, f, w = (legs[n][k] for n in ("trace", "pmc1", "pmc2", "fetch", "write"))
-        row = {"case": c["case"], "kernel": (t[0][2] if t else c["kernel"]).split("(")[0].replace("void (anonymous namespace)::", ""), "launches_averaged": len(t)}
+        row = {"case": c["case"], "kernel": kernel_name(t[0][2]) if t else c["kernel"], "launches_averaged": len(t)}
         ns = mean(t, "ns")
         if ns:
             row["avg_us"] = ns / 1e3
@@ -83,6 +95,12 @@ def main():
             row["lds_bank_conflict_over_lds_active"] = mean(p2, "SQ_LDS_BANK_CONFLICT") / mean(p2, "SQ_LDS_IDX_ACTIVE")
             row["lds_active_over_gpu_cycles_per_cu"] = mean(p2, "SQ_LDS_IDX_ACTIVE") / (256.0 * gui2 / 8.0)
             row["valu_instructions"], row["lds_instructions"] = mean(p2, "SQ_INSTS_VALU"), mean(p2, "SQ_INSTS_LDS")
+            if row.get("mfma_instructions") is not None and row["valu_instructions"]:
+                # a float32 matrix instruction and the other wave's vector instructions do not overlap on a SIMD (profiles/r06_mfma_valu_probe.json):
+                # the vector instructions' ~4 cycles each come out of the same budget - what the matrix pipe could reach at most in this kernel
+                other = max(0.0, row["valu_instructions"] - row["mfma_instructions"])
+                row["vector_share_of_simd_cycles"] = 4.0 * other / (1024.0 * gui2 / 8.0)
+                row["matrix_plus_vector_share"] = row.get("mfma_pipe_utilisation", 0.0) + row["vector_share_of_simd_cycles"]
         fs, ws = mean(f, "FETCH_SIZE"), mean(w, "WRITE_SIZE")
         if fs is not None and ws is not None:
             row["hbm_read_bytes"], row["hbm_write_bytes"] = 2 * 1024 * fs, 1024 * ws
@@ -91,6 +109,7 @@ def main():
         rows.append(row)
     out = {"source": "tools/gpu_profile_layers.sh over tools/pmc_layers.py (rocprofv3 --pmc, four separate passes, + a kernel trace; the program directly after --)",
            "how": "mfma_pipe_utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8); LDS = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE; "
+                  "vector_share_of_simd_cycles = 4 x (SQ_INSTS_VALU - SQ_INSTS_VALU_MFMA_F32) / the same SIMD cycles (float32 matrix and vector instructions share a SIMD's datapath on gfx950); "
                   "hbm bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024; executed = direct FLOPs / 2.25 for the F(2x2,3x3) kernel, / 4 for the F(4x4,3x3) kernel", "rows": rows}
     with open(dst, "w") as fh:
         json.dump(out, fh, indent=1)

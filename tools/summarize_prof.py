@@ -32,15 +32,22 @@ def main():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     dst = os.path.join(root, "profiles")
     os.makedirs(dst, exist_ok=True)
-    stats = glob.glob(os.path.join(src, "trace", "**", "*_kernel_stats.csv"), recursive=True)[0]
-    rows = list(csv.DictReader(open(stats)))
-    with open(os.path.join(dst, "%s_kernel_stats.csv" % tag), "w", newline="") as f:
-        w = csv.writer(f)
-        w.writerow(["Kernel", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
-        for r in rows:
-            s = short(r["Name"])
-            w.writerow([s if s else r["Name"][:100], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
-                        r["MinNs"], r["MaxNs"], r["StdDev"]])
+    for leg, suffix in (("trace", ""), ("trace_other", "_other_legs")):      # the headline leg alone; the Stereo R-CNN-shape + delivered-iterates legs
+        found = glob.glob(os.path.join(src, leg, "**", "*_kernel_stats.csv"), recursive=True)
+        if not found:
+            continue
+        rows = list(csv.DictReader(open(found[0])))
+        with open(os.path.join(dst, "%s_kernel_stats%s.csv" % (tag, suffix)), "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["Kernel", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+            for r in rows:
+                s = short(r["Name"])
+                w.writerow([s if s else r["Name"][:100], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
+                            r["MinNs"], r["MaxNs"], r["StdDev"]])
+    line = os.path.join(src, "bench_line_of_the_trace.json")
+    if os.path.exists(line) and os.path.getsize(line):      # the line the traced command itself printed: its roofline belongs to this trace's averages
+        with open(os.path.join(dst, "%s_kernel_stats_bench_line.json" % tag), "w") as f:
+            json.dump(json.loads(open(line).readline()), f, indent=1)
     pmc = defaultdict(lambda: defaultdict(list))
     for leg in ("fetch", "write"):
         for path in glob.glob(os.path.join(src, leg, "**", "*_counter_collection.csv"), recursive=True):
@@ -49,7 +56,7 @@ def main():
                 if s:
                     pmc[s][r["Counter_Name"]].append(float(r["Counter_Value"]))
     out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python3 bench.py --steps 1 "
-                     "--warmup 0 --no-cpu-baseline`", "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 "
+                     "--warmup 0 --no-cpu-baseline --no-end-to-end --no-delivered --no-srcnn`", "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 "
                      "(gfx950: FETCH_SIZE reads half of a wide coalesced stream)", "kernels": {}}
     for k, d in sorted(pmc.items()):
         f = sum(d["FETCH_SIZE"]) / max(1, len(d["FETCH_SIZE"]))

@@ -12,6 +12,21 @@ import sys
 
 OURS = re.compile(r"conv_wino|bilinear_up_\w+|conv2d_\w+_mfma|conv3d_k3\w*|convt3d\w*|roi_\w+|nms_\w+|psv_\w+|pgd_step\w*|affine_\w+|export_u8\w*|patch_\w+|depth_regress\w*|grid_sample3d\w*|"
                   r"gs_to_channels_last|bias_act_kernel|relu_backward_kernel|bev_fold\w*|focal_\w+|space_to_depth2|disc_mask\w*|clean_index\w*|import_u8\w*|dense_align\w*|\w+_prep_kernel|conv3d_k3_prep")
+
+
+def _library_kernels():
+    """the kernel names of the in-tree libadvengine.so (its device stubs): the exact list instead of a pattern that lags behind new kernels"""
+    import os
+    import subprocess
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "eval_driving_safety_amd", "libadvengine.so")
+    try:
+        out = subprocess.run(["nm", "-C", lib], stdout=subprocess.PIPE, text=True, check=True).stdout
+    except Exception:
+        return None
+    names = set(re.findall(r"__device_stub__([A-Za-z0-9_]+)", out))
+    return re.compile(r"(?:^|[\s:])(" + "|".join(sorted(names, key=len, reverse=True)) + r")[<(]") if names else None
+
+
 LIBS = re.compile(r"miopen|Cijk_|igemm_|Col2Im|Im2d2Col|Im2Col|batched_transpose|ck::|_ZN2ck|SubTensorOp|gridwise|MIOpen|Op\dd|transpose_")
 
 
@@ -28,12 +43,13 @@ def main():
                 kept.append(r)
         rows = kept
     cats = {"libadvengine": [], "miopen_rocblas_ck": [], "torch_elementwise_and_copies": [], "miopen_solver_search_one_time": []}
+    exact = _library_kernels()
     for r in rows:
         n = r["Name"]
         t = float(r["TotalDurationNs"])
         if "naive_conv" in n:
             cats["miopen_solver_search_one_time"].append((n, t, int(r["Calls"])))
-        elif OURS.search(n):
+        elif (exact.search(n) if exact else None) or OURS.search(n):
             cats["libadvengine"].append((n, t, int(r["Calls"])))
         elif LIBS.search(n):
             cats["miopen_rocblas_ck"].append((n, t, int(r["Calls"])))

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Timeline of the F(4x4,3x3) kernel's stage loop from in-kernel s_memtime stamps (a -DADV_WINO4_STAMPS build of csrc/wino4.hip:
+tools/build_variant.sh stamps wino4.hip -DADV_WINO4_STAMPS; run with ADVENGINE_LIB=tools/_build/libadv_stamps.so).  Per wave: cycles from the
+stage's start to each half-step (sampled: stage s stamps half-step s % n), to the last matrix instruction, to the LDS drain, to the barrier's release."""
+import ctypes
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from eval_driving_safety_amd import ops, _lib  # noqa: E402
+
+
+def run(name, fn, half_steps, last_stage=60):
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    buf = np.zeros((8, 8, 64, 5), dtype=np.uint64)
+    rc = lib.adv_debug_wino4_stamps(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(buf.nbytes))
+    assert rc == 0, rc
+    s = buf.astype(np.int64)
+    for wave in range(8):
+        ns = half_steps[wave]
+        st = s[:, wave, 4:last_stage, :]                        # steady-state stages of the eight stamped workgroups
+        ok = st[..., 0] > 0
+        if not ok.any():
+            continue
+        total = (st[..., 4] - st[..., 0])[ok]
+        last = (st[..., 2] - st[..., 0])[ok]
+        drain = (st[..., 3] - st[..., 2])[ok]
+        bar = (st[..., 4] - st[..., 3])[ok]
+        prof = {}
+        stages = np.arange(4, last_stage)
+        for h in range(ns):
+            sel = (stages % ns) == h
+            d = (st[:, sel, 1] - st[:, sel, 0])[ok[:, sel]]
+            if d.size:
+                prof[h] = int(np.median(d))
+        print(json.dumps({"case": name, "wave": wave, "stage_cycles_median": int(np.median(total)), "to_last_matrix_issue": int(np.median(last)),
+                          "lds_drain": int(np.median(drain)), "barrier_wait": int(np.median(bar)), "barrier_wait_p90": int(np.percentile(bar, 90)),
+                          "half_step_start": prof}), flush=True)
+
+
+def main():
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    x = torch.randn((2, 256, 150, 497), device=dev)
+    prep = ops.ConvWino4Prep(torch.randn((256, 256, 3, 3), device=dev) * 0.02)
+    for dbg in [int(a) for a in sys.argv[1:]] or [0]:        # phase ablations need the -DADV_TEST_HOOKS build of the stamped library
+        if dbg:
+            os.environ["ADV_WINO4_DBG"] = str(dbg)
+        run("256->256 [2,256,150,497] tile 1 dbg %d" % dbg, lambda: ops.conv_wino4(x, prep, tile=1), [36] * 8, last_stage=31)
+        os.environ.pop("ADV_WINO4_DBG", None)
+    x3 = torch.randn((1, 32, 48, 96, 312), device=dev)
+    p3 = ops.ConvWino4Prep(torch.randn((32, 32, 3, 3, 3), device=dev) * 0.05)
+    run("3D 32->32 [48,96,312] tile 3", lambda: ops.conv_wino4(x3, p3, tile=3), [18] * 8, last_stage=22)
+
+
+if __name__ == "__main__":
+    main()
