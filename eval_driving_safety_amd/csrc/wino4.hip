@@ -174,19 +174,22 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
     for (int e = 1; e < 4; ++e) fm |= (in && gw + e >= W) ? (1u << e) : 0u;
     xfm[i] = fm;
   }
+  unsigned anyfm = 0;
+#pragma unroll
+  for (int i = 0; i < G::kXSl; ++i) anyfm |= xfm[i];
+  const bool wave_fixes = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(anyfm != 0) != 0 ? 1 : 0) != 0;      // any straddling group in this wave's pieces?
   auto stage_off = [&](int q0) -> long long {      // wave-uniform: bytes from (channel 0, plane 0) to (the stage's first channel, its plane)
     const int kd = DEPTH ? q0 / cinpad : 0;
     const int ch = DEPTH ? q0 - kd * cinpad : q0;
     return (static_cast<long long>(ch) * D + (DEPTH ? od + kd - 1 : 0)) * HW * 4;
   };
-  auto dma_x = [&](int i, int q0, int buf) {       // piece wave + 8 i of the tile of the stage that starts at q0 -> input buffer buf
-    const long long so = stage_off(q0);
+  auto dma_x = [&](int i, long long so, int buf) {      // piece wave + 8 i of the tile of the stage so bytes into the image -> input buffer buf
     const long long left = static_cast<long long>(xtotal) - so;      // (channels past Cin: nothing left - zeros)
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(xb) + so), 0,
                                                                          static_cast<int>(static_cast<unsigned>(left > 0 ? left : 0)), 0x00020000);
     float* dst = sxb + buf * G::kSX + (wave + 8 * i) * 256;
     const int vo = xvo[i];      // (a copy: the host pass of hipcc cannot compile the array element as this builtin's argument)
-    if (wave + 8 * i < G::kPieces) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)dst, 16, vo, 0, 0, 0);
+    if (i < G::kXMin || wave + 8 * i < G::kPieces) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)dst, 16, vo, 0, 0, 0);
   };
   auto fix_x = [&](int i, int buf) {               // the straddling groups of piece wave + 8 i: the columns past the map's right edge -> 0
     if (xfm[i]) {
@@ -278,8 +281,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
       v2f s[NSUB];
     };
     WSet wsA, wsB;
-    auto load_w = [&](int sub, int slot, int q0, WSet& set) {      // q0: first q of the sub-stage
-      const int so = ((kpos(slot) * wqs + q0 / kKQ) * wg64 + wgrp) * 1024;      // wave-uniform
+    // byte offset of (position, sub-stage s, the workgroup's channel group): wbase[slot] + s * wstep - one scalar add per load in the loop
+    const int wstep = wg64 * 1024;
+    int wbase[5];
+#pragma unroll
+    for (int slot = 0; slot < 5; ++slot) wbase[slot] = (kpos(slot) * wqs * wg64 + wgrp) * 1024;
+    auto load_w = [&](int sub, int slot, int qoff, WSet& set) {      // qoff: (first q of the sub-stage / 4) * wstep
+      const int so = wbase[slot] + qoff;          // wave-uniform
       if (slot < 4) {
         if constexpr (CB == 2) set.f[sub][slot & 3] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rwgt, wvo16, so, 0));
         else set.f[sub][slot & 3] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rwgt, wvo16 + wcb, so, 0));
@@ -296,14 +304,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
 #pragma unroll
       for (int t = 0; t < G::kNXB; ++t)
 #pragma unroll
-        for (int i = 0; i < G::kXSl; ++i) dma_x(i, qclamp(q_lo + t * KC), t);
+        for (int i = 0; i < G::kXSl; ++i) dma_x(i, stage_off(qclamp(q_lo + t * KC)), t);
 #pragma unroll
       for (int s = 0; s < NSUB; ++s)
 #pragma unroll
-        for (int slot = 0; slot < 5; ++slot) load_w(s, slot, q_lo + kKQ * s, wsA);
+        for (int slot = 0; slot < 5; ++slot) load_w(s, slot, (q_lo / kKQ + s) * wstep, wsA);
       if constexpr (CB == 1) {
 #pragma unroll
-        for (int slot = 0; slot < 5; ++slot) load_w(0, slot, qclamp(q_lo + KC), wsB);
+        for (int slot = 0; slot < 5; ++slot) load_w(0, slot, qclamp(q_lo + KC) / kKQ * wstep, wsB);
       }
       asm volatile("s_waitcnt vmcnt(10)" ::: "memory");      // the tiles have landed (the weight loads behind them travel on)
 #pragma unroll
@@ -333,6 +341,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
     // half-step.  At the end: the pieces of the tile of stage st + 2 (requested a stage ago) have landed - counted wait, the younger loads
     // travel on - their right-edge columns are cleared, then ONE barrier behind the wave's LDS writes.
     int xr = 0;                                   // st % 3: the input buffer of tiles st, st + 3
+    // the tile the next stage requests (stage st: the tile of stage st + 3), kept incrementally: its first q, that q's channel, its byte
+    // offset - a division by the channel count per stage (3x3x3 layers) was ~50 scalar instructions in the issue stream of every wave
+    int xq = qclamp(q_lo + 3 * KC);
+    int xch = DEPTH ? xq % cinpad : xq;
+    long long xso = stage_off(xq);
+    const long long xstep = static_cast<long long>(KC) * D * HW * 4;                                   // KC channels on
+    const long long xwrap = (static_cast<long long>(1) - static_cast<long long>(cinpad - KC) * D) * HW * 4;      // 3x3x3: first channel of the next depth tap
     auto stage = [&](int st, WSet& ws) __attribute__((always_inline)) {
       constexpr int kAhead = 6;                   // B operands: read this many half-steps ahead
       float bv[NH];
@@ -355,8 +370,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
         const int slot = m < 16 ? m / 4 : 4, kp = m < 16 ? (m >> 1) & 1 : m - 16, blk = m < 16 ? m & 1 : (HI ? 1 : 0);
         bv[h] = bp[kpos(slot) * 256 + (kKQ * sub + 2 * kp) * NPT + (CB == 1 ? 32 * blk : 0)];
       };
-      const int qn = CB == 2 ? qclamp(q_lo + (st + 1) * KC) : qclamp(q_lo + (st + 2) * KC);      // the stage whose weights this stage requests
-      const int q3 = qclamp(q_lo + (st + 3) * KC);
+      const int qnoff = (CB == 2 ? qclamp(q_lo + (st + 1) * KC) : qclamp(q_lo + (st + 2) * KC)) / kKQ * wstep;      // the stage whose weights this stage requests
 #pragma unroll
       for (int h = 0; h < kAhead; ++h)
         if (need_b(h) && !(dbg & 32)) load_b(h);
@@ -367,7 +381,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
         if (h == hsel) stampx = __builtin_amdgcn_s_memtime();
 #endif
         if (h + kAhead < NH && need_b(h + kAhead) && !(dbg & 32)) load_b(h + kAhead);
-        if (h >= 1 && h < 1 + G::kXSl && !(dbg & 4)) dma_x(h - 1, q3, xr);
+        if (h >= 1 && h < 1 + G::kXSl && !(dbg & 4)) dma_x(h - 1, xso, xr);
         if constexpr (!(dbg & 1)) {
           if (h % CB == 0) {                      // transform event e = h / CB (0 .. 17)
             const int e = h / CB;
@@ -397,8 +411,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
           }
         }
         if (!(dbg & 64)) {
-          if (m < 16 && (m & 3) == 3) load_w(sub, m / 4, qn + kKQ * sub, ws);
-          if (m == 17) load_w(sub, 4, qn + kKQ * sub, ws);
+          if (m < 16 && (m & 3) == 3) load_w(sub, m / 4, qnoff + sub * wstep, ws);
+          if (m == 17) load_w(sub, 4, qnoff + sub * wstep, ws);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -409,8 +423,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
       // stage's pieces and the weight loads of two stages (a plain __syncthreads() would wait for every load in flight)
       if constexpr (!(dbg & 16)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::kXMin + 10 * NSUB - 2) : "memory");
       if constexpr (!(dbg & 8)) {
+        if (wave_fixes) {
 #pragma unroll
-        for (int i = 0; i < G::kXSl; ++i) fix_x(i, x2);
+          for (int i = 0; i < G::kXSl; ++i) fix_x(i, x2);
+        }
       }
 #ifdef ADV_WINO4_STAMPS
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -426,6 +442,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
       if constexpr (!(dbg & 16)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
       xr = x1;
+      if (xq < q_hi - KC) {                       // the next tile (beyond the last stage: the last one again)
+        xq += KC, xch += KC;
+        if (DEPTH && xch == cinpad) xch = 0, xso += xwrap;
+        else xso += xstep;
+      }
     };
     if constexpr (CB == 2) {
       for (int st = 0; st < nstage; ++st) stage(st, wsA);
