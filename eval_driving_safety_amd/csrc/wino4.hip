@@ -135,6 +135,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
   constexpr int PB = G::kPB, NPT = G::kNP, CO = G::kCO, KC = G::kKC, NSUB = CB, NH = 18 * CB;      // NH: matrix instructions (= half-steps) per wave and stage
   constexpr int dbg = ABL;
   extern __shared__ __attribute__((aligned(16))) float lds[];
+#ifdef ADV_WINO4_STAMPS
+  const unsigned long long stamp_entry = __builtin_amdgcn_s_memtime();
+#endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l32 = lane & 31, half = lane >> 5;
@@ -332,6 +335,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
     }
 #ifdef ADV_WINO4_STAMPS
     unsigned long long stamp0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long stamp_loop_start = stamp0;
     const bool stamped = blockIdx.x < 8 && blockIdx.y == 0 && blockIdx.z == 0;
 #endif
     // Stage st: NH matrix instructions on U (registers) / V (LDS) of stage st, one per HALF-step, the side work in front of them (a wave
@@ -459,6 +463,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
       if (st < nstage) stage(st, wsA);
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // (clamped requests of the last stages: nothing may land later)
+#ifdef ADV_WINO4_STAMPS
+    const unsigned long long stamp_loop_end = __builtin_amdgcn_s_memtime();
+#endif
 
     // ---- epilogue: the 36 values M_k of one (channel, patch) sit in eight waves - exchange through LDS, 16 channels per round:
     // E[k][co16][patch]; register v of a 32 x 32 accumulator = channel (v & 3) + 8 (v >> 2) + 4 half of its block, patch = lane & 31
@@ -552,6 +559,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
       }
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
+#ifdef ADV_WINO4_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the stores have left
+    const unsigned long long stamp_end = __builtin_amdgcn_s_memtime();
+    if (stamped && lane == 0) {                           // [.][.][63]: kernel entry, first stage's start, loop end, kernel end
+      unsigned long long* o = adv_wino4_stamps[blockIdx.x][wave][63];
+      o[0] = stamp_entry, o[1] = stamp_loop_start, o[2] = stamp_loop_end, o[3] = stamp_end, o[4] = 0;
+    }
+#endif
   };
   if (wave >= 4) body(std::true_type{});
   else body(std::false_type{});

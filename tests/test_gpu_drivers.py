@@ -144,8 +144,7 @@ def test_cli_toy_run_writes_the_reference_layout(tmp_path):
     assert "Average loss for epoch1" in out.stdout
 
 
-@pytest.mark.parametrize("script,prefix", [("dsgn_pgd_attack", "dsgn_pgd_iters_"),
-                                           pytest.param("srcnn_pgd_attack", "stereo_rcnn_pgd_iters_", marks=pytest.mark.slow)])      # (36 s: with --full)
+@pytest.mark.parametrize("script,prefix", [("dsgn_pgd_attack", "dsgn_pgd_iters_"), ("srcnn_pgd_attack", "stereo_rcnn_pgd_iters_")])      # (the second: 36 s - the graph that leaves more layers to MIOpen)
 def test_a_cli_run_twice_in_fresh_processes_writes_the_same_png_bytes(tmp_path, script, prefix):
     """README "Reproducibility", for the product path: the command-line script, run twice in two fresh processes on the layer-list detector
     (route table + the layers left to MIOpen under determinism.py's flags and warm-up, set by the drivers - nothing is set here), writes

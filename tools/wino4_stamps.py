@@ -23,6 +23,11 @@ def run(name, fn, half_steps, last_stage=60):
     rc = lib.adv_debug_wino4_stamps(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(buf.nbytes))
     assert rc == 0, rc
     s = buf.astype(np.int64)
+    life = s[:, :, 63, :]                               # kernel entry, first stage's start, loop end, kernel end (after the stores have left)
+    okl = life[..., 0] > 0
+    if okl.any():
+        print(json.dumps({"case": name, "workgroup_life_cycles_median": {"prologue": int(np.median((life[..., 1] - life[..., 0])[okl])),
+                          "stage_loop": int(np.median((life[..., 2] - life[..., 1])[okl])), "epilogue_incl_store_drain": int(np.median((life[..., 3] - life[..., 2])[okl]))}}), flush=True)
     for wave in range(8):
         ns = half_steps[wave]
         st = s[:, wave, 4:last_stage, :]                        # steady-state stages of the eight stamped workgroups
