@@ -530,14 +530,15 @@ ADV_API int adv_conv3d_wino_f32(const float* x, const float* w_prep, const float
 
 /* The same 3x3 / stride 1 / padding 1 convolutions (2D, and 3x3x3 with the depth taps inside the contraction) by Winograd F(4x4, 3x3):
  *     36 element-wise products per 4 x 4 outputs - 4x fewer multiply-adds than the direct kernels, 1.78x fewer than F(2x2, 3x3) - on
- *     v_mfma_f32_32x32x2_f32; a workgroup of eight waves owns 16 x 32 (or 8 x 64) outputs x 64 channels, each wave four or five of the 36
- *     positions, the input transform, products, output transform (positions exchanged through LDS) and epilogue in ONE kernel
+ *     v_mfma_f32_32x32x2_f32; a workgroup of eight waves owns 16 x 32 (or 8 x 64) outputs x 64 channels, each wave nine 32 x 32 accumulators (four
+ *     whole positions of the 36 and one block of a fifth), the input transform, products, output transform (positions exchanged through LDS) and epilogue in ONE kernel
  *     (csrc/wino4.hip).  Its own order of float operations (oracle: orc_conv_wino4, bit for bit); against the direct kernels and torch the
  *     results agree to ~1e-5 of the output's magnitude (the transform's constants reach 8 and 1/24: about ten times F(2x2, 3x3)'s error,
  *     inside the 1e-4 band) - the caller chooses the route explicitly.
- *     w_prep from adv_conv{2,3}d_wino4_prep_weights_f32 ([36][taps * cin'][cout'] = G g G^T, zero padded to multiples of 4 x 64; transpose
+ *     w_prep from adv_conv{2,3}d_wino4_prep_weights_f32 (G g G^T as [36][taps * cin' / 4][cout' / 64][lane][4]: the float4 a lane of the
+ *     kernel loads per position and four input channels; zero padded to multiples of 8 x 64 - an opaque layout, sized by *_prep_floats; transpose
  *     = 1: the backward w.r.t. the input).  bias / residual / relu / mask: as adv_conv2d_1x1_f32.  tile: -1 = by map size and cout, 0 = 16 x 32
- *     outputs x 64 channels per workgroup, 1 = 8 x 64 x 64, 2 = 32 x 32 outputs x 32 channels, 3 = 16 x 64 x 32, 4 (2D, w <= 15, cin % 4 == 0) = two images per 16 x 32 tile (same result).  An image (cin x d x h x w floats) and the prepared weights must stay below 4 GiB / 2 GiB. */
+ *     outputs x 64 channels per workgroup, 1 = 8 x 64 x 64, 2 = 32 x 32 outputs x 32 channels, 3 = 16 x 64 x 32, 4 (2D, w <= 15, cin % 8 == 0) = two images per 16 x 32 tile (same result).  An image (cin x d x h x w floats) and the prepared weights must stay below 4 GiB / 2 GiB. */
 ADV_API int64_t adv_conv2d_wino4_prep_floats(int cout, int cin, int transpose);
 ADV_API int adv_conv2d_wino4_prep_weights_f32(const float* w, float* w_prep, int cout, int cin, int transpose, adv_stream_t stream);
 ADV_API int adv_conv2d_wino4_f32(const float* x, const float* w_prep, const float* bias, const float* residual, const float* mask,

@@ -51,3 +51,24 @@ def test_current_profiles_contain_the_kernels_the_library_launches():
         for n in set(names):
             if n and not n.startswith(THIRD_PARTY) and re.fullmatch(r"[a-z0-9_]+", n):
                 assert n in lib, "%s holds kernel %s, which the current libadvengine.so does not have - a stale profile" % (fname, n)
+
+
+def test_the_headline_trace_reproduces_the_bench_line_the_traced_command_printed():
+    """the rocprofv3 summary committed for the headline leg must give the `roofline.frac` of the bench line - the line the
+    SAME traced command printed is kept beside it (tools/gpu_profile.sh traces the headline leg alone; tools/summarize_prof.py copies both):
+    algorithmic bytes per launch / the trace's average duration of `pgd_step_vec4_idx` / 8 TB/s within 2 % of that line's frac."""
+    import json
+    table = _current_profiles()
+    stats = next(n for n in table if re.fullmatch(r"r\d+_kernel_stats\.csv", n))
+    tag = stats.split("_")[0]
+    line_path = os.path.join(ROOT, "profiles", "%s_kernel_stats_bench_line.json" % tag)
+    assert os.path.exists(line_path), "%s: the bench line of the traced command is missing (tools/summarize_prof.py writes it)" % line_path
+    line = json.load(open(line_path))
+    rows = [r for r in csv.DictReader(open(os.path.join(ROOT, "profiles", stats))) if _base(r["Kernel"]).startswith("pgd_step_vec4_idx")]
+    assert rows, "%s holds no pgd_step_vec4_idx row" % stats
+    row = max(rows, key=lambda r: int(r["Calls"]))
+    avg_s = float(row["AverageNs"]) * 1e-9
+    roof = line["roofline"]
+    frac = roof["algorithmic_bytes_per_launch"] / avg_s / 1e9 / roof["peak"]
+    assert abs(frac - roof["frac"]) <= 0.02 * roof["frac"], (frac, roof["frac"], row)
+    assert float(row["StdDev"]) <= 0.1 * float(row["AverageNs"]), "the trace mixes this kernel with another leg (copy-engine traffic beside it): %r" % row
