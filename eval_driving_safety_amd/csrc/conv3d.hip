@@ -48,6 +48,10 @@ struct Epi {
   // call with mask = the layer's own input (a ReLU output with this layer as its only consumer) returns the gradient w.r.t. the
   // producer's PRE-activation - no relu_backward pass over the volume.
   const float* mask;
+  // <round 6> cls_wp[0..7] as ONE window for buffer addressing (the transposed kernel's weight requests): the lowest of the eight pointers
+  // and the bytes from it to the end of the highest tensor, or null when they do not lie within 2 GiB of each other
+  const float* cls_lo;
+  unsigned cls_span;
 };
 
 constexpr unsigned kAllTaps = (1u << 27) - 1u;
@@ -318,6 +322,21 @@ __device__ __forceinline__ void stage_commit(const Stage<TD, TH>& st, const Plan
 // because W and w0 are multiples of 4) read a 16-byte zero page instead.  No staging registers, no selects, no ds_write.
 __device__ __attribute__((aligned(16))) const float g_zero16[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 
+typedef __attribute__((address_space(3))) void lds_void;
+// the same through a buffer descriptor: lane l's 16 bytes from base + voff (a 32-bit byte offset held in a register for the whole tile; a
+// lane whose offset fails the range check - the marker kNoLane, channels past the last one - writes zeros).  The per-stage part of the
+// address lives in the descriptor's base (scalar arithmetic): NO vector instruction per request.  Why that matters: a workgroup's waves
+// issue their requests while the co-resident workgroup's waves stream matrix instructions, and on gfx950 a vector instruction of one wave
+// and a matrix instruction of the other do not execute together (profiles/r06_mfma_valu_probe.json) - the 64-bit select + add per request
+// of the pointer form made the ten requests of a stage take 4 600 of its 15 000 cycles (profiles/r06_s2_stamps.jsonl).
+constexpr int kNoLane = static_cast<int>(0xFFFFFF00u);
+__device__ __forceinline__ void bdma16(__amdgpu_buffer_rsrc_t r, int voff, float* lds_piece) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)lds_piece, 16, voff, 0, 0, 0);
+#else
+  (void)r, (void)voff, (void)lds_piece;
+#endif
+}
 __device__ __forceinline__ void glds16(const float* src, float* lds_piece) {  // lane l's 16 bytes land at lds_piece + 4*l floats
 #if defined(__HIP_DEVICE_COMPILE__)
   __builtin_amdgcn_global_load_lds(src, lds_piece, 16, 0, 0);
@@ -705,6 +724,9 @@ __global__ __launch_bounds__(64 * kTT * kTDt, kTT * kTDt == 4 ? 2 : 1) void conv
     xo[p] = ok ? c * vol + gd * plane + gh * W + gw : -1;
     xn[p] = ok ? (W - gw < 4 ? W - gw : 4) : 0;                                    // valid floats of the group (register path: the row's end)
   }
+  int xob[kTXPer], wob[kTWPer];                          // DMA: the groups' byte offsets (buffer form of the requests; weights: from epi.cls_lo)
+#pragma unroll
+  for (int p = 0; p < kTXPer; ++p) xob[p] = xo[p] >= 0 ? xo[p] * 4 : kNoLane;
 #pragma unroll
   for (int p = 0; p < kTWPer; ++p) {
     const int f = 64 * (wave + kNW * p) + lane;
@@ -715,17 +737,34 @@ __global__ __launch_bounds__(64 * kTT * kTDt, kTT * kTDt == 4 ? 2 : 1) void conv
 #pragma unroll
     for (int k = 1; k < 8; ++k) base = cls == k ? epi.cls_wp[k] : base;
     wsrc[p] = f < kWF4 ? base + (static_cast<long long>(tap) * Cin + c) * cout_pad + cob * 32 + 4 * n4 : nullptr;
+    wob[p] = (f < kWF4 && epi.cls_lo) ? static_cast<int>((base - epi.cls_lo) * 4 + ((static_cast<long long>(tap) * Cin + c) * cout_pad + cob * 32 + 4 * n4) * 4) : kNoLane;
   }
   auto issue = [&](int c0, float* stage) {
+    // (DMA only: the launch keeps the image below 4 GiB) requests through buffer descriptors whose bases carry the stage's channel offset:
+    // no vector instruction per request (see bdma16); the eight class tensors as one window where the caller allocated them together
+    const long long xoff = static_cast<long long>(c0) * vol * 4;
+    const __amdgpu_buffer_rsrc_t rxd = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(xb) + xoff), 0,
+                                                                          static_cast<int>(static_cast<unsigned>(static_cast<long long>(Cin) * vol * 4 - xoff)), 0x00020000);
 #pragma unroll
     for (int p = 0; p < kTXPer; ++p) {
-      const int k = wave + kNW * p;
-      if (k < kTXInstr) glds16(xo[p] >= 0 ? xb + static_cast<long long>(c0) * vol + xo[p] : g_zero16, stage + k * 256);
+      const int k = wave + kNW * p, vo = xob[p];
+      if (k < kTXInstr) bdma16(rxd, vo, stage + k * 256);
     }
+    if (epi.cls_lo) {
+      const long long woff = static_cast<long long>(c0) * cout_pad * 4;
+      const __amdgpu_buffer_rsrc_t rwd = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(epi.cls_lo) + woff), 0,
+                                                                            static_cast<int>(static_cast<unsigned>(static_cast<long long>(epi.cls_span) - woff)), 0x00020000);
 #pragma unroll
-    for (int p = 0; p < kTWPer; ++p) {
-      const int k = wave + kNW * p;
-      if (k < kTWInstr) glds16(wsrc[p] ? wsrc[p] + static_cast<long long>(c0) * cout_pad : g_zero16, stage + kTSX + k * 256);
+      for (int p = 0; p < kTWPer; ++p) {
+        const int k = wave + kNW * p, vo = wob[p];
+        if (k < kTWInstr) bdma16(rwd, vo, stage + kTSX + k * 256);
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < kTWPer; ++p) {
+        const int k = wave + kNW * p;
+        if (k < kTWInstr) glds16(wsrc[p] ? wsrc[p] + static_cast<long long>(c0) * cout_pad : g_zero16, stage + kTSX + k * 256);
+      }
     }
   };
 
@@ -888,6 +927,14 @@ __global__ __launch_bounds__(64 * kTT * kTDt, kTT * kTDt == 4 ? 2 : 1) void conv
 // (channel pair, tap, channel) - the oracle takes the stage size as a parameter; results differ from the 4-channel order in
 // the last bits only (ops.conv3d_k3_s2_stage_channels tells which one a call uses).
 // ---------------------------------------------------------------------------------------------------------------
+#ifdef ADV_S2_STAMPS
+// diagnostic builds only (tools/build_variant.sh s2stamps conv3d.hip -DADV_S2_STAMPS; tools/s2_stamps.py): s_memtime stamps of the strided kernel's
+// stage loop - [workgroup < 8][wave][stage < 64][4]: stage start, requests issued, last matrix instruction issued, barrier passed
+__device__ unsigned long long adv_s2_stamps[8][4][64][4];
+extern "C" __attribute__((visibility("default"))) int adv_debug_s2_stamps(void* dst, size_t bytes) {
+  return static_cast<int>(hipMemcpyFromSymbol(dst, HIP_SYMBOL(adv_s2_stamps), bytes < sizeof(adv_s2_stamps) ? bytes : sizeof(adv_s2_stamps)));
+}
+#endif
 constexpr int kSC = 2;                                    // input channels per stage
 constexpr int kSRow = 72;                                 // LDS row = global columns [2*w0 - 4, 2*w0 + 68)
 // CB = blocks of 32 output channels per workgroup: 2 (cout > 32: a wave owns one output row, both blocks) or 1 (a wave owns two output
@@ -951,25 +998,32 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_s2_mfma(const float* __restr
     const int kd = rem / kRowsIn, r9 = rem - kd * kRowsIn;
     const int gd = 2 * d0 + kd - 1, gh = 2 * h0 + r9 - 1, gw = 2 * w0 - 4 + 4 * j;
     const bool ok = q < SG::kXF4 && j < 17 && gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw + 3 < W;   // columns 68..71 are never read
-    xo[p] = ok ? c * vol + gd * plane + gh * W + gw : -1;
+    xo[p] = ok ? (c * vol + gd * plane + gh * W + gw) * 4 : kNoLane;            // byte offsets from the stage's first channel (the launch keeps the image below 4 GiB)
   }
 #pragma unroll
   for (int p = 0; p < SG::kWPer; ++p) {
     const int f = 64 * (wave + 4 * p) + lane;
     const int n4 = f % (8 * CB), c = (f / (8 * CB)) & 1, tap = f / (16 * CB);
     const int co = cp * kCO + 4 * n4;
-    wo[p] = (f < SG::kWF4 && co < cout_pad) ? (tap * Cin + c) * cout_pad + co : -1;
+    wo[p] = (f < SG::kWF4 && co < cout_pad) ? ((tap * Cin + c) * cout_pad + co) * 4 : kNoLane;
   }
+  const long long xbytes = static_cast<long long>(Cin) * vol * 4, wbytes = 27LL * Cin * cout_pad * 4;
   auto issue = [&](int c0, float* stage) {
+    // the stage's channel pair moves the descriptors' bases; what is left behind them bounds the range check (a channel past Cin: zeros)
+    const long long xoff = static_cast<long long>(c0) * vol * 4, woff = static_cast<long long>(c0) * cout_pad * 4;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(xb) + xoff), 0,
+                                                                         static_cast<int>(static_cast<unsigned>(xbytes - xoff)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(wp) + woff), 0,
+                                                                         static_cast<int>(static_cast<unsigned>(wbytes - woff)), 0x00020000);
 #pragma unroll
     for (int p = 0; p < SG::kXPer; ++p) {
-      const int k = wave + 4 * p;
-      if (k < SG::kXInstr) glds16(xo[p] >= 0 ? xb + static_cast<long long>(c0) * vol + xo[p] : g_zero16, stage + k * 256);
+      const int k = wave + 4 * p, vo = xo[p];
+      if (k < SG::kXInstr) bdma16(rx, vo, stage + k * 256);
     }
 #pragma unroll
     for (int p = 0; p < SG::kWPer; ++p) {
-      const int k = wave + 4 * p;
-      if (k < SG::kWInstr) glds16(wo[p] >= 0 ? wp + static_cast<long long>(c0) * cout_pad + wo[p] : g_zero16, stage + SG::kSX + k * 256);
+      const int k = wave + 4 * p, vo = wo[p];
+      if (k < SG::kWInstr) bdma16(rw, vo, stage + SG::kSX + k * 256);
     }
   };
 
@@ -985,7 +1039,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_s2_mfma(const float* __restr
   int cur = 0;
   for (int c0 = 0; c0 < Cin; c0 += kSC) {
     const int cn = c0 + kSC < Cin ? c0 + kSC : c0;
+#ifdef ADV_S2_STAMPS
+    const unsigned long long st0 = __builtin_amdgcn_s_memtime();
+#endif
     issue(cn, lds + (cur ^ 1) * SG::kStage);
+#ifdef ADV_S2_STAMPS
+    const unsigned long long st1 = __builtin_amdgcn_s_memtime();
+#endif
     __builtin_amdgcn_sched_barrier(0);
     const float* sxc = lds + cur * SG::kStage;
     const float* swc = sxc + SG::kSX;
@@ -1006,7 +1066,17 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_s2_mfma(const float* __restr
           acc[pd][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[CB == 2 ? i : 0], bv[CB == 2 ? 0 : i], acc[pd][i], 0, 0, 0);
       }
     }
+#ifdef ADV_S2_STAMPS
+    const unsigned long long st2 = __builtin_amdgcn_s_memtime();
+#endif
     __syncthreads();
+#ifdef ADV_S2_STAMPS
+    const unsigned long long st3 = __builtin_amdgcn_s_memtime();
+    if (blockIdx.x < 8 && lane == 0 && c0 / kSC < 64) {
+      unsigned long long* o = adv_s2_stamps[blockIdx.x][wave][c0 / kSC];
+      o[0] = st0, o[1] = st1, o[2] = st2, o[3] = st3;
+    }
+#endif
     cur ^= 1;
   }
 
@@ -1346,7 +1416,8 @@ static int launch_conv(const float* x, const float* w_prep, float* y, int b, int
       hipLaunchKernelGGL((conv3d_k3_narrow_out<8>), grid, dim3(256), lds, st, x, w_prep, y, cin, cout, cblocks * 32, d, h, w, tiles_w, epi);
     return adv_internal_finish_launch();
   }
-  if (stride == 2 && conv3d_k3_s2_direct(cout, w, x, epi) && fits && (reinterpret_cast<uintptr_t>(w_prep) & 15) == 0 && epi.od == gd &&
+  const bool fits32 = static_cast<long long>(cin) * d * h * w * 4 < 0xfff00000LL && 27LL * cin * cblocks * 32 * 4 < 0x7ff00000LL;   // byte offsets in 32 bits
+  if (stride == 2 && conv3d_k3_s2_direct(cout, w, x, epi) && fits && fits32 && (reinterpret_cast<uintptr_t>(w_prep) & 15) == 0 && epi.od == gd &&
       epi.oh == gh && epi.ow == gw) {
     const bool two = cout > 32;   // both 32-channel blocks of a pair per workgroup, or two rows per wave of the one block
     const int tw = (gw + kTW - 1) / kTW, th = two ? (gh + SGeo<2>::kTH - 1) / SGeo<2>::kTH : (gh + SGeo<1>::kTH - 1) / SGeo<1>::kTH;
@@ -1360,16 +1431,36 @@ static int launch_conv(const float* x, const float* w_prep, float* y, int b, int
         // double-length ones (a first version counted 512 slots and made the 16-GFLOP layers 15 % slower).
         // (ADV_CONV_S2_PD=1|2 forces one - test hook / A-B; same bits)
         // <round 4> flat volumes: spread the tile's four waves over 2 or 4 output planes where that pads fewer rows (same bits)
-        auto padded = [&](int wdp) { return static_cast<long long>((gh + 4 / wdp - 1) / (4 / wdp)) * (4 / wdp) * ((gd + wdp - 1) / wdp) * wdp; };
+        // <round 6> tile shape by a makespan estimate instead of by padded volume alone (profiles/r06_s2_t2_tiles.jsonl: the old rule was 3-9 %
+        // off the best shape on three of the four hourglass layers).  Two workgroups share a CU and its matrix pipes: a full "slot round" of
+        // 2 x CUs tiles costs two tile times at ~0.9 (the pair keeps the pipe busy); a last partial round costs the same if some CU still
+        // holds two tiles, and one tile time at ~1 / 0.65 if every CU holds at most one (a lone wave per SIMD cannot hide its operand
+        // reads: 102 cycles per matrix instruction in the stamps, profiles/r06_s2_stamps.jsonl).  A tile's time = its output planes per
+        // wave (PD) + 0.12 of fixed cost.  Ties go to the shape with more planes per tile (measured: never slower).
+        const long long cus = cu_count();
+        auto tiles_of = [&](int wdp, int pdp) {
+          return static_cast<long long>(tw) * ((gh + 4 / wdp - 1) / (4 / wdp)) * ((gd + wdp * pdp - 1) / (wdp * pdp)) * b * cgroups;
+        };
+        auto estimate = [&](int wdp, int pdp) {
+          const long long n = tiles_of(wdp, pdp), full = n / (2 * cus), rest = n - full * 2 * cus;
+          const double t = pdp + 0.12;
+          return static_cast<double>(full) * 2.0 * t * 0.9 + (rest == 0 ? 0.0 : (rest <= cus ? t / 0.65 : 2.0 * t * 0.9));
+        };
         int wdv = 1;
-        if (padded(2) < padded(wdv)) wdv = 2;
-        if (padded(4) < padded(wdv)) wdv = 4;
+        bool pd2 = false;
+        {
+          double best = estimate(1, 1);
+          const int cand[4][2] = {{1, 2}, {2, 1}, {2, 2}, {4, 1}};
+          for (const auto& c : cand) {
+            const double e = estimate(c[0], c[1]);
+            if (e <= best * 1.0001) best = e < best ? e : best, wdv = c[0], pd2 = c[1] == 2;
+          }
+        }
         if (const char* e = adv_hook_value("ADV_CONV_S2_WD")) wdv = e[0] == '4' ? 4 : (e[0] == '2' ? 2 : 1);
         const int thw = (gh + 4 / wdv - 1) / (4 / wdv);                   // row tiles of the chosen shape
-        const long long cus = cu_count(), n1 = static_cast<long long>(tw) * thw * ((gd + wdv - 1) / wdv) * b * cgroups,
-                        n2 = static_cast<long long>(tw) * thw * ((gd + 2 * wdv - 1) / (2 * wdv)) * b * cgroups;
-        bool pd2 = wdv <= 2 && 1.86 * static_cast<double>((n2 + cus - 1) / cus) < static_cast<double>((n1 + cus - 1) / cus);
-        if (const char* e = adv_hook_value("ADV_CONV_S2_PD")) pd2 = wdv <= 2 && e[0] == '2';
+        if (const char* e = adv_hook_value("ADV_CONV_S2_PD")) pd2 = e[0] == '2';
+        pd2 = pd2 && wdv <= 2;
+        const long long n1 = tiles_of(wdv, 1), n2 = tiles_of(wdv, 2);
 #define ADV_LAUNCH_S2(PD_, WD_, N_)                                                                                                           \
   do {                                                                                                                                        \
     const size_t lds_ = 2 * sizeof(float) * static_cast<size_t>(SGeo<2, PD_, WD_>::kStage);                                                   \
@@ -1557,7 +1648,15 @@ static int convt3d_launch(const float* x, const float* const* w_prep_classes, co
     if (padded(2) < padded(tdv)) tdv = 2;
     if (padded(4) < padded(tdv)) tdv = 4;
     if (const char* e = adv_hook_value("ADV_CONV_T_TD")) tdv = e[0] == '4' ? 4 : (e[0] == '2' ? 2 : 1);
-    const bool dma = w % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && !adv_hook("ADV_CONV_T_NO_DMA");     // else: register-staged (any width)
+    const bool dma = w % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && static_cast<long long>(cin) * d * h * w * 4 < 0xfff00000LL &&
+                     !adv_hook("ADV_CONV_T_NO_DMA");     // else: register-staged (any width, any size)
+    {   // the eight class tensors as one window of less than 2 GiB (ops.conv_transpose3d_k3_s2_prep allocates them as one slab)
+      const float *lo = w_prep_classes[0], *hi = w_prep_classes[0];
+      for (int k = 1; k < 8; ++k) lo = w_prep_classes[k] < lo ? w_prep_classes[k] : lo, hi = w_prep_classes[k] > hi ? w_prep_classes[k] : hi;
+      const long long span = (hi - lo) * 4 + 27LL * cin * cblocks * 32 * 4;
+      epi.cls_lo = span < 0x7ff00000LL && !adv_hook("ADV_CONV_T_POINTER_WEIGHTS") ? lo : nullptr;
+      epi.cls_span = epi.cls_lo ? static_cast<unsigned>(span) : 0u;
+    }
     const bool all_classes = (reinterpret_cast<uintptr_t>(y) & 7) == 0 && (reinterpret_cast<uintptr_t>(residual) & 7) == 0 &&
                              (reinterpret_cast<uintptr_t>(mask) & 7) == 0 && ntiles < (1LL << 31) && !adv_hook("ADV_CONV_T_CLASS_TILES");
     if (mask != nullptr && !all_classes) return ADV_EINVAL;

@@ -6,15 +6,20 @@ from .conv2d import WINO4_DIRECT_EQUIV_FLOPS, WINO_DIRECT_EQUIV_FLOPS, _Conv2dCh
 
 # --------------------------------------------------------------------------------------------
 # dense 3x3x3 convolution on the float32 matrix cores (the contraction applied to the K7 cost volume)
-def conv3d_k3_prep(weight, transpose=False):
+def conv3d_k3_prep(weight, transpose=False, out=None):
     """[Cout,Cin,3,3,3] -> the kernel's layout [27, Cin', 32*ceil(Cout'/32)]; transpose=True prepares the adjoint
-    (gradient w.r.t. the input).  Do it once per weight tensor - the attacks never change the weights."""
+    (gradient w.r.t. the input).  Do it once per weight tensor - the attacks never change the weights.  ``out``: a contiguous
+    float32 tensor of that shape to fill (the eight class tensors of a transposed layer share one allocation)."""
     wt = _feat(weight, "weight")
     if wt.dim() != 5 or tuple(wt.shape[2:]) != (3, 3, 3):
         raise ValueError("weight must be [Cout,Cin,3,3,3]")
     cout, cin = wt.shape[:2]
     cin_p, cout_p = (cout, cin) if transpose else (cin, cout)
-    out = torch.empty((27, cin_p, 32 * ((cout_p + 31) // 32)), dtype=torch.float32, device=wt.device)
+    shape = (27, cin_p, 32 * ((cout_p + 31) // 32))
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=wt.device)
+    elif tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous() or out.device != wt.device:
+        raise ValueError("out must be a contiguous float32 tensor of shape %s on the weight's device" % (shape,))
     with _on(wt):
         _lib.call("adv_conv3d_k3_prep_weights_f32", _ptr(wt), _ptr(out), cout, cin, int(transpose), _stream(wt))
     return out
@@ -228,6 +233,9 @@ def conv_transpose3d_k3_s2_prep(weight_t):
         raise ValueError("weight_t must be [Cin,Cout,3,3,3]")
     pairs = {0: ((1, 1),), 1: ((1, 2), (2, 0))}
     out = []
+    # ONE allocation for the eight class tensors: the transposed kernel then requests them through one buffer descriptor (32-bit offsets
+    # from the lowest of the eight pointers - csrc/conv3d.hip; separately allocated tensors still work, through 64-bit pointers)
+    slab = torch.empty((8, 27, wt.shape[0], 32 * ((wt.shape[1] + 31) // 32)), dtype=torch.float32, device=wt.device)
     for pd in (0, 1):
         for ph in (0, 1):
             for pw in (0, 1):
@@ -238,7 +246,7 @@ def conv_transpose3d_k3_s2_prep(weight_t):
                         for tw, kw in pairs[pw]:
                             wc[:, :, td, th, tw] = wt[:, :, kd, kh, kw].t()
                             mask |= 1 << (td * 9 + th * 3 + tw)
-                out.append((conv3d_k3_prep(wc.contiguous()), mask, (pd, ph, pw)))
+                out.append((conv3d_k3_prep(wc.contiguous(), out=slab[len(out)]), mask, (pd, ph, pw)))
     return out
 
 
