@@ -9,7 +9,7 @@
 //   weight rows [16][BM] (prepared layout [Cin'][Cout']: a stage is 16 contiguous rows) go global -> registers -> LDS while the
 //   MFMAs of the previous stage run (two LDS buffers, one barrier per stage).  Rows of X are dword-aligned only (P is odd for
 //   most feature maps), hence register staging with dword-aligned float4 loads rather than LDS-DMA.
-//   Four tile shapes (128x256 ... 64x64); the host picks the one that needs the fewest "MFMA rounds" for the layer's size.
+//   Five tile shapes (128x256 ... 64x64, 64x32 with two waves); the host picks the one that needs the fewest "MFMA rounds" for the layer's size.
 //   Accumulation order: ci ascending, one fmaf per product starting from 0 (the MFMA is a k-ordered fmaf chain), then
 //   + bias, + residual, ReLU, mask - the C oracle restates it bit for bit.
 //   The backward w.r.t. the input is the same kernel on W^T (adv_conv2d_1x1_prep_weights_f32(transpose = 1)); `mask` (the layer's
@@ -38,10 +38,11 @@ struct Epi2 {
 
 template <int WM, int WN, int TM, int TN>
 struct GemmGeo {
-  static_assert(WM * WN == 4, "four waves");
+  static_assert(WM * WN == 4 || WM * WN == 2, "four waves, or two (the 64 x 32 tile)");
+  static constexpr int kT = 64 * WM * WN;                                        // threads
   static constexpr int kBM = WM * TM * 32, kBN = WN * TN * 32;
-  static constexpr int kXF4 = kKC * kBN / 4 / 256, kWF4 = kKC * kBM / 4 / 256;   // float4 per thread and stage
-  static_assert(kXF4 >= 1 && kWF4 >= 1, "tile too small for 256 loader threads");
+  static constexpr int kXF4 = kKC * kBN / 4 / kT, kWF4 = kKC * kBM / 4 / kT;     // float4 per thread and stage
+  static_assert(kXF4 >= 1 && kWF4 >= 1 && kXF4 * 4 * kT == kKC * kBN && kWF4 * 4 * kT == kKC * kBM, "the loader threads cover a stage in whole float4 rounds");
   static constexpr int kStage = kKC * (kBN + kBM);                               // floats per LDS buffer
 };
 
@@ -49,7 +50,7 @@ struct GemmGeo {
 // remapped so that each XCD (blocks i, i+8, ... share one) walks a contiguous range of the tile order - m fastest, so the m tiles
 // that re-read one X tile sit in the same L2.
 template <int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(256, 2) void conv2d_1x1_mfma(const float* __restrict__ x, const float* __restrict__ wp, float* __restrict__ y, int K, int M,
+__global__ __launch_bounds__(64 * WM * WN, 2) void conv2d_1x1_mfma(const float* __restrict__ x, const float* __restrict__ wp, float* __restrict__ y, int K, int M,
                                                        int mpad, long long P, int tiles_m, int tiles_n, long long ntiles, long long wbytes, Epi2 epi) {
   using G = GemmGeo<WM, WN, TM, TN>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -91,12 +92,12 @@ __global__ __launch_bounds__(256, 2) void conv2d_1x1_mfma(const float* __restric
   int xvo[G::kXF4], wvo[G::kWF4];
 #pragma unroll
   for (int i = 0; i < G::kXF4; ++i) {
-    const int f = tid + 256 * i, row = f / (G::kBN / 4), c4 = f % (G::kBN / 4);
+    const int f = tid + G::kT * i, row = f / (G::kBN / 4), c4 = f % (G::kBN / 4);
     xvo[i] = static_cast<int>((static_cast<unsigned>(row) * static_cast<unsigned>(P) + static_cast<unsigned>(n0) + 4u * c4) * 4u);
   }
 #pragma unroll
   for (int i = 0; i < G::kWF4; ++i) {
-    const int f = tid + 256 * i, row = f / (G::kBM / 4), c4 = f % (G::kBM / 4);
+    const int f = tid + G::kT * i, row = f / (G::kBM / 4), c4 = f % (G::kBM / 4);
     wvo[i] = (row * mpad + m0 + c4 * 4) * 4;
   }
   struct Set {
@@ -118,9 +119,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_1x1_mfma(const float* __restric
     float* sx = lds + buf * G::kStage;
     float* sw = sx + kKC * G::kBN;
 #pragma unroll
-    for (int i = 0; i < G::kXF4; ++i) *reinterpret_cast<v4f*>(sx + 4 * (tid + 256 * i)) = st.x[i];         // [row][BN] row-major == float4 index
+    for (int i = 0; i < G::kXF4; ++i) *reinterpret_cast<v4f*>(sx + 4 * (tid + G::kT * i)) = st.x[i];         // [row][BN] row-major == float4 index
 #pragma unroll
-    for (int i = 0; i < G::kWF4; ++i) *reinterpret_cast<v4f*>(sw + 4 * (tid + 256 * i)) = st.w[i];
+    for (int i = 0; i < G::kWF4; ++i) *reinterpret_cast<v4f*>(sw + 4 * (tid + G::kT * i)) = st.w[i];
   };
   auto products = [&](int s) {
     const float* sx = lds + (s & 1) * G::kStage;
@@ -239,24 +240,26 @@ int launch_1x1(const float* x, const float* wp, float* y, int b, int K, int M, i
   if ((static_cast<long long>(K) + kKC) * P * 4 >= 0xfff00000LL || wbytes >= 0xfff00000LL) return ADV_EINVAL;
   const size_t lds = 2 * sizeof(float) * static_cast<size_t>(G::kStage);
   if (lds > 64 * 1024 && !adv_internal_lds_limit<conv2d_1x1_mfma<WM, WN, TM, TN>>(lds)) return ADV_ELAUNCH;
-  hipLaunchKernelGGL((conv2d_1x1_mfma<WM, WN, TM, TN>), dim3(static_cast<unsigned>(ntiles)), dim3(256), lds, st, x, wp, y, K, M, mpad, P, tiles_m,
+  hipLaunchKernelGGL((conv2d_1x1_mfma<WM, WN, TM, TN>), dim3(static_cast<unsigned>(ntiles)), dim3(G::kT), lds, st, x, wp, y, K, M, mpad, P, tiles_m,
                      static_cast<int>(tiles_n), ntiles, wbytes, epi);
   return adv_internal_finish_launch();
 }
 
-// which tile shape: 0 = 128x256, 1 = 128x128, 2 = 64x128, 3 = 64x64 (output channels x pixels).  One wave's work is TM*TN
-// accumulators over K; the matrix pipes run the waves of a SIMD one after another, so a launch takes about
+// which tile shape: 0 = 128x256, 1 = 128x128, 2 = 64x128, 3 = 64x64, 4 = 64x32 (output channels x pixels; 4: two waves).  One wave's work
+// is TM*TN accumulators over K; the matrix pipes run the waves of a SIMD one after another, so a launch takes about
 // ceil(waves / SIMDs) * TM*TN / efficiency(shape) - bigger tiles reuse more per staged byte, smaller ones fill the chip.
 int pick_1x1_tile(int b, int M, long long P, int simds) {
-  static const int bm[4] = {128, 128, 64, 64}, bn[4] = {256, 128, 128, 64}, work[4] = {8, 4, 2, 1};
+  static const int bm[5] = {128, 128, 64, 64, 64}, bn[5] = {256, 128, 128, 64, 32}, work[5] = {8, 4, 2, 1, 1}, wg_waves[5] = {4, 4, 4, 4, 2};
   // relative efficiency of a wave's MFMA stream per tile shape, fitted to the sweep of the R101 1x1 layers on MI355X (round 5, after the
   // buffer-load staging: profiles/r05_conv2d_1x1_tile_sweep.jsonl - the small tiles gained most: several workgroups per compute unit
-  // cover each other's prologue and epilogue; 0.07 ms per R101 step over the per-layer optimum, the round-3 fit {0.8, 1.08, 0.94, 1} 0.26)
-  static const double eff[4] = {0.75, 0.88, 0.99, 1.0};
+  // cover each other's prologue and epilogue; 0.07 ms per R101 step over the per-layer optimum, the round-3 fit {0.8, 1.08, 0.94, 1} 0.26).
+  // <round 6> the 64 x 32 shape (profiles/r06_conv2d_1x1_tile_sweep.jsonl): as fast as 64 x 64 where the pixels fill whole tiles, 7 % faster
+  // on the RoI heads' 14 x 14 maps (196 pixels per image: 7 tiles of 32 instead of 4 of 64) - it wins where it saves more than 5 % of the waves
+  static const double eff[5] = {0.75, 0.88, 0.99, 1.0, 0.95};
   int best = 0;
   double best_t = 1e300;
-  for (int c = 0; c < 4; ++c) {
-    const double waves = 4.0 * ((M + bm[c] - 1) / bm[c]) * static_cast<double>((P + bn[c] - 1) / bn[c]) * b;
+  for (int c = 0; c < 5; ++c) {
+    const double waves = static_cast<double>(wg_waves[c]) * ((M + bm[c] - 1) / bm[c]) * static_cast<double>((P + bn[c] - 1) / bn[c]) * b;
     const double rounds = static_cast<double>(static_cast<long long>((waves + simds - 1) / simds));
     const double tcost = rounds * work[c] / eff[c];
     if (tcost < best_t) best_t = tcost, best = c;
@@ -529,7 +532,7 @@ int adv_conv2d_1x1_prep_weights_f32(const float* w, float* w_prep, int cout, int
 
 int adv_conv2d_1x1_f32(const float* x, const float* w_prep, const float* bias, const float* residual, const float* mask, float* y, int b, int cin,
                        int cout, int64_t pixels, int relu, int tile, adv_stream_t stream) {
-  if (!x || !w_prep || !y || b < 1 || cin < 1 || cout < 1 || pixels < 1 || tile < -1 || tile > 3) return ADV_EINVAL;
+  if (!x || !w_prep || !y || b < 1 || cin < 1 || cout < 1 || pixels < 1 || tile < -1 || tile > 4) return ADV_EINVAL;
   if (static_cast<long long>(b) * cin * pixels < 4) return ADV_EINVAL;      // the kernels load whole float4s (clamped into the tensor)
   if (residual == y || mask == y || x == y) return ADV_EINVAL;
   if ((reinterpret_cast<uintptr_t>(x) & 3) || (reinterpret_cast<uintptr_t>(y) & 3) || (reinterpret_cast<uintptr_t>(w_prep) & 15) ||
@@ -544,6 +547,7 @@ int adv_conv2d_1x1_f32(const float* x, const float* w_prep, const float* bias, c
     case 0: return launch_1x1<2, 2, 2, 4>(x, w_prep, y, b, cin, cout, mpad, pixels, epi, st);
     case 1: return launch_1x1<2, 2, 2, 2>(x, w_prep, y, b, cin, cout, mpad, pixels, epi, st);
     case 2: return launch_1x1<2, 2, 1, 2>(x, w_prep, y, b, cin, cout, mpad, pixels, epi, st);
+    case 4: return launch_1x1<2, 1, 1, 1>(x, w_prep, y, b, cin, cout, mpad, pixels, epi, st);      // 64 x 32, two waves
     default: return launch_1x1<2, 2, 1, 1>(x, w_prep, y, b, cin, cout, mpad, pixels, epi, st);
   }
 }
