@@ -309,6 +309,8 @@ def main():
         line("psv_build_lerp fwd", timeit(lambda: ops.psv_build_lerp(left, right, shift_f, out=cost)), vol + feat, B=B)
         line("psv_build_lerp bwd", timeit(lambda: ops.psv_build_lerp_bwd(g, shift_f)), vol + feat, B=B)
         del cost, g
+    if "--psv" in sys.argv:
+        return
     # ---- affine / export at 512 images
     n = 512
     sp = ops.Space.dsgn()
