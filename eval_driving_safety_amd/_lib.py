@@ -130,6 +130,7 @@ SIGNATURES = {
     "adv_conv3d_wino_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "adv_conv2d_wino4_prep_weights_f32": [_P, _P, _I, _I, _I, _P],
     "adv_conv2d_wino4_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "adv_conv2d_wino4_ksplit_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "adv_conv3d_wino4_prep_weights_f32": [_P, _P, _I, _I, _I, _P],
     "adv_conv3d_wino4_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
 }
@@ -148,6 +149,8 @@ _OTHER = {
     "adv_conv3d_wino_prep_floats": ([_I, _I, _I], ctypes.c_int64),
     "adv_conv2d_wino4_prep_floats": ([_I, _I, _I], ctypes.c_int64),
     "adv_conv3d_wino4_prep_floats": ([_I, _I, _I], ctypes.c_int64),
+    "adv_conv2d_wino4_ksplit_pick": ([_I, _I, _I, _I, _I], _I),
+    "adv_conv2d_wino4_ksplit_chunk": ([_I, _I, _I], _I),
     "adv_last_hip_error": ([], _I),
     "adv_strerror": ([_I], ctypes.c_char_p),
     "adv_space_dsgn": ([_SP], None),

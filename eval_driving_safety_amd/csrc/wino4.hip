@@ -64,6 +64,7 @@ namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4fu __attribute__((ext_vector_type(4), aligned(4)));      // four floats at any float address (global memory takes unaligned 16-byte accesses)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void lds_void;
 
@@ -101,6 +102,7 @@ struct Epi4 {
   const float* residual;
   const float* mask;
   int relu;
+  int ksplit, kchunk;      // 2D layers on small maps: the contraction dealt to ksplit workgroups per tile, kchunk channels each (0 / 1: whole)
 };
 
 // the six expressions of B^T applied to (d0 .. d5)
@@ -144,7 +146,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
   const int wt = blockIdx.x % tiles_w, ht = blockIdx.x / tiles_w;
   const int w0 = wt * 4 * PC, h0 = ht * 4 * PR, co0 = blockIdx.y * CO;
   static_assert(!PAIR || (!DEPTH && PC == 8), "image pairs: the 16 x 32 tile of a 2D layer");
-  const long long b = DEPTH ? blockIdx.z / D : (PAIR ? 2LL * blockIdx.z : blockIdx.z);      // PAIR: the first image of the pair
+  // K-split (2D, one image per tile): blockIdx.z = image * ksplit + part; a part multiplies kchunk input channels and writes its raw
+  // F(4x4,3x3) outputs to plane `part` of a scratch tensor [ksplit][B][Cout][H][W] (y here) - wino4_ksplit_sum adds the planes in order
+  const int ksn = (!DEPTH && !PAIR && epi.ksplit > 1) ? epi.ksplit : 1;
+  const int ks = ksn > 1 ? static_cast<int>(blockIdx.z % ksn) : 0;
+  const long long b = DEPTH ? blockIdx.z / D : (PAIR ? 2LL * blockIdx.z : (ksn > 1 ? blockIdx.z / ksn : blockIdx.z));      // PAIR: the first image of the pair
   const int od = DEPTH ? static_cast<int>(blockIdx.z % D) : 0;
   const long long HW = static_cast<long long>(H) * W;
   const long long DHW = HW * D;
@@ -250,15 +256,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
     for (int j = 0; j < 6; ++j) tv[6 * i + j] = o[j];
   };
 
-  const int q_lo = DEPTH ? (od == 0 ? cinpad : 0) : 0;
-  const int q_hi = DEPTH ? (od == D - 1 ? 2 * cinpad : 3 * cinpad) : cinpad;
+  const int q_lo = DEPTH ? (od == 0 ? cinpad : 0) : ks * epi.kchunk;
+  const int q_hi = DEPTH ? (od == D - 1 ? 2 * cinpad : 3 * cinpad) : (ksn > 1 && q_lo + epi.kchunk < cinpad ? q_lo + epi.kchunk : cinpad);
   const int nstage = (q_hi - q_lo) / KC;
   auto qclamp = [&](int q) { return q < q_hi - KC ? q : q_hi - KC; };      // (stage starts beyond the last one: the last one again)
 
   // epilogue geometry: the exchange rounds hand every thread (channel of the round's 16, patch) items - one at 32 patches, two at 64
   const long long MP = static_cast<long long>(Cout) * DHW;
   const long long plane0 = static_cast<long long>(od) * HW;
-  float* const yb = y + b * MP + plane0;
+  float* const yb = y + (static_cast<long long>(ks) * nimg + b) * MP + plane0;
   const float* const resb = epi.residual ? epi.residual + b * MP + plane0 : nullptr;
   const float* const maskb = epi.mask ? epi.mask + b * MP + plane0 : nullptr;
   const bool vec4 = (W & 3) == 0 && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(epi.residual) | reinterpret_cast<uintptr_t>(epi.mask)) & 15) == 0;
@@ -266,6 +272,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
   const int gh0 = h0 + 4 * (ep / PC), gw0 = PAIR ? 4 * (ep % 4) : w0 + 4 * (ep % PC);
   const long long eimg = PAIR && (ep % PC) >= 4 ? MP : 0;      // PAIR: the right half of the tile is the pair's second image
   const bool eok = !PAIR || (ep % PC) < 4 || b + 1 < nimg;
+  const bool wide = gw0 + 3 < W;      // (per thread) the patch's four columns are inside the map
 
   // body<HI>: a wave's whole life after the set-up (HI: waves 4-7)
   auto body = [&](auto hi_c) __attribute__((always_inline)) {
@@ -470,6 +477,48 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
     // ---- epilogue: the 36 values M_k of one (channel, patch) sit in eight waves - exchange through LDS, 16 channels per round:
     // E[k][co16][patch]; register v of a 32 x 32 accumulator = channel (v & 3) + 8 (v >> 2) + 4 half of its block, patch = lane & 31
     float* const se = lds;
+#ifdef ADV_WINO4_STAMPS
+    unsigned long long est[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // round 0: start, writes issued, barrier passed, transformed, stores issued; then each round's end
+    est[0] = __builtin_amdgcn_s_memtime();
+#endif
+    // every unit's (round, item) bias and the first unit's skip connection / mask are requested HERE, ahead of the exchange: in front of
+    // a round's use they would wait for the round before's stores (vmcnt is in-order) - and a cold bias line alone is ~2 us.
+    // Unconditional loads (a row / column / channel outside the tensor reads its first floats and is never stored)
+    float bvu[2 * CB * PB], rvb[2][4][4], mvb[2][4][4];
+    auto load_rm = [&](int unit, float (&rv)[4][4], float (&mv)[4][4]) {
+      const int co = co0 + 16 * (unit / PB) + eg + (512 / NPT) * (unit % PB);
+      const bool uok = co < Cout && gh0 < H && gw0 < W && eok;
+      const long long at0 = eimg + static_cast<long long>(co) * DHW + static_cast<long long>(gh0) * W + gw0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool rok = uok && gh0 + r < H;
+        const long long at = at0 + static_cast<long long>(r) * W;
+        if (vec4) {
+          const v4f tr = resb ? *reinterpret_cast<const v4f*>(rok ? resb + at : epi.residual) : v4f{0.0f, 0.0f, 0.0f, 0.0f};
+          const v4f tm = maskb ? *reinterpret_cast<const v4f*>(rok ? maskb + at : epi.mask) : v4f{1.0f, 1.0f, 1.0f, 1.0f};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) rv[r][c] = tr[c], mv[r][c] = tm[c];
+        } else if (wide) {      // W % 4 != 0: the rows start at any float - one unaligned 16-byte access where the patch's four columns are in the map
+          const v4fu tr = resb ? *reinterpret_cast<const v4fu*>(rok ? resb + at : epi.residual) : v4fu{0.0f, 0.0f, 0.0f, 0.0f};
+          const v4fu tm = maskb ? *reinterpret_cast<const v4fu*>(rok ? maskb + at : epi.mask) : v4fu{1.0f, 1.0f, 1.0f, 1.0f};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) rv[r][c] = tr[c], mv[r][c] = tm[c];
+        } else {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const bool ok = rok && gw0 + c < W;
+            rv[r][c] = resb ? (ok ? resb[at + c] : epi.residual[0]) : 0.0f;
+            mv[r][c] = maskb ? (ok ? maskb[at + c] : epi.mask[0]) : 1.0f;
+          }
+        }
+      }
+    };
+#pragma unroll
+    for (int u = 0; u < 2 * CB * PB; ++u) {
+      const int co = co0 + 16 * (u / PB) + eg + (512 / NPT) * (u % PB);
+      bvu[u] = epi.bias ? epi.bias[co < Cout ? co : 0] : 0.0f;
+    }
+    if (resb || maskb) load_rm(0, rvb[0], mvb[0]);
 #pragma unroll
     for (int round = 0; round < 2 * CB; ++round) {          // (unrolled: the accumulator registers are addressed by constants)
       if (co0 + 16 * round >= Cout) continue;               // (workgroup-uniform) nothing but padding from here on
@@ -492,11 +541,19 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
           }
         }
       }
+#ifdef ADV_WINO4_STAMPS
+      if (round == 0) est[1] = __builtin_amdgcn_s_memtime();
+#endif
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef ADV_WINO4_STAMPS
+      if (round == 0) est[2] = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
       for (int item = 0; item < PB; ++item) {
         const int co16 = eg + (512 / NPT) * item;
         const int co = co0 + 16 * round + co16;
+        constexpr int kUnits = 2 * CB * PB;
+        const int unit = round * PB + item;      // (a constant after unrolling)
         float s[4][6], o[4][4];
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
@@ -508,31 +565,20 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) at6(s[r][0], s[r][1], s[r][2], s[r][3], s[r][4], s[r][5], o[r]);
+#ifdef ADV_WINO4_STAMPS
+        if (round == 0 && item == 0) {
+          asm volatile("" ::"v"(o[0][0]), "v"(o[3][3]));
+          est[3] = __builtin_amdgcn_s_memtime();
+        }
+#endif
+        // the NEXT unit's skip connection / mask are requested before this unit's stores: vmcnt retires in order and counts stores, a load
+        // behind them waits ~5 000 cycles for their acknowledgement (profiles/r06_wino4_epilogue_stamps.jsonl)
+        if (unit + 1 < kUnits && (resb || maskb)) load_rm(unit + 1, rvb[(unit + 1) & 1], mvb[(unit + 1) & 1]);
         if (co < Cout && gh0 < H && gw0 < W && eok) {
-          const float bv = epi.bias ? epi.bias[co] : 0.0f;
+          const float bv = bvu[unit];
           const long long at0 = eimg + static_cast<long long>(co) * DHW + static_cast<long long>(gh0) * W + gw0;
-          // the skip connection and the mask of all sixteen outputs FIRST, the stores after them: a load placed behind a store to y may
-          // not be moved ahead of it (the pointers could alias) - row by row that was a memory round trip per row (+25 % on the layers with
-          // a residual); unconditional loads (a row / column outside the map reads the tensor's first floats and is never stored)
-          float rv[4][4], mv[4][4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const bool rok = gh0 + r < H;
-            const long long at = at0 + static_cast<long long>(r) * W;
-            if (vec4) {
-              const v4f tr = resb ? *reinterpret_cast<const v4f*>(rok ? resb + at : epi.residual) : v4f{0.0f, 0.0f, 0.0f, 0.0f};
-              const v4f tm = maskb ? *reinterpret_cast<const v4f*>(rok ? maskb + at : epi.mask) : v4f{1.0f, 1.0f, 1.0f, 1.0f};
-#pragma unroll
-              for (int c = 0; c < 4; ++c) rv[r][c] = tr[c], mv[r][c] = tm[c];
-            } else {
-#pragma unroll
-              for (int c = 0; c < 4; ++c) {
-                const bool ok = rok && gw0 + c < W;
-                rv[r][c] = resb ? (ok ? resb[at + c] : epi.residual[0]) : 0.0f;
-                mv[r][c] = maskb ? (ok ? maskb[at + c] : epi.mask[0]) : 1.0f;
-              }
-            }
-          }
+          const auto& rv = rvb[unit & 1];
+          const auto& mv = mvb[unit & 1];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             if (gh0 + r >= H) continue;
@@ -549,6 +595,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
             }
             if (vec4) {
               *reinterpret_cast<v4f*>(yb + at) = v4f{res[0], res[1], res[2], res[3]};
+            } else if (wide) {
+              *reinterpret_cast<v4fu*>(yb + at) = v4fu{res[0], res[1], res[2], res[3]};
             } else {
 #pragma unroll
               for (int c = 0; c < 4; ++c)
@@ -557,9 +605,21 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
           }
         }
       }
+#ifdef ADV_WINO4_STAMPS
+      if (round == 0) est[4] = __builtin_amdgcn_s_memtime();
+#endif
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef ADV_WINO4_STAMPS
+      est[5 + round] = __builtin_amdgcn_s_memtime();
+#endif
     }
 #ifdef ADV_WINO4_STAMPS
+    if (stamped && lane == 0) {
+      unsigned long long* o1 = adv_wino4_stamps[blockIdx.x][wave][61];
+      unsigned long long* o2 = adv_wino4_stamps[blockIdx.x][wave][62];
+#pragma unroll
+      for (int i = 0; i < 5; ++i) o1[i] = est[i], o2[i] = est[5 + i];
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the stores have left
     const unsigned long long stamp_end = __builtin_amdgcn_s_memtime();
     if (stamped && lane == 0) {                           // [.][.][63]: kernel entry, first stage's start, loop end, kernel end
@@ -590,7 +650,8 @@ int launch_wino4(const float* x, const float* wp, float* y, int b, int cin, int 
   const int tiles_w = PAIR ? 1 : (w + 4 * PC - 1) / (4 * PC), tiles_h = (h + 4 * PR - 1) / (4 * PR);
   const long long tiles = static_cast<long long>(tiles_w) * tiles_h;
   const int cgroups = (cout + G::kCO - 1) / G::kCO;
-  const long long gz = PAIR ? (static_cast<long long>(b) + 1) / 2 : static_cast<long long>(b) * d;
+  if (epi.ksplit > 1 && (DEPTH || PAIR)) return ADV_EINVAL;
+  const long long gz = PAIR ? (static_cast<long long>(b) + 1) / 2 : static_cast<long long>(b) * d * (epi.ksplit > 1 ? epi.ksplit : 1);
   if (tiles > 0x7fffffffLL || cgroups > 65535 || gz > 65535) return ADV_EINVAL;
   const long long wbytes = 36LL * (DEPTH ? 3 : 1) * cinpad * copad * 4;
   if ((static_cast<long long>(cinpad) + 1) * d * h * w * 4 * (PAIR ? 2 : 1) >= 0xfff00000LL || wbytes >= 0x7ff00000LL) return ADV_EINVAL;
@@ -644,6 +705,55 @@ int launch_wino4_tile(int t, const float* x, const float* wp, float* y, int b, i
       if constexpr (!DEPTH) return launch_wino4<4, 8, 2, false, true>(x, wp, y, b, cin, cout, cinpad, copad, d, h, w, epi, st);
       return ADV_EINVAL;
   }
+}
+
+// ---- K-split, second pass: y = epilogue(((p0 + p1) + p2) + ...) over the scratch planes the parts wrote (fixed order: reproducible bits)
+template <int V>
+__global__ void wino4_ksplit_sum(const float* __restrict__ part, float* __restrict__ y, long long n, int splits, int cout, long long hw, Epi4 epi) {
+  using vf = std::conditional_t<V == 1, float, v4f>;
+  for (long long i = (blockIdx.x * 256LL + threadIdx.x) * V; i < n; i += 256LL * V * gridDim.x) {
+    vf v = *reinterpret_cast<const vf*>(part + i);
+    for (int s = 1; s < splits; ++s) v = v + *reinterpret_cast<const vf*>(part + s * n + i);
+    const int co = static_cast<int>((i / hw) % cout);
+    const float bv = epi.bias ? epi.bias[co] : 0.0f;
+    vf r, m;
+    if (epi.residual) r = *reinterpret_cast<const vf*>(epi.residual + i);
+    if (epi.mask) m = *reinterpret_cast<const vf*>(epi.mask + i);
+    vf o;
+#pragma unroll
+    for (int c = 0; c < V; ++c) {
+      float t;
+      if constexpr (V == 1) t = v; else t = v[c];
+      if (epi.bias) t = t + bv;
+      if (epi.residual) { if constexpr (V == 1) t = t + r; else t = t + r[c]; }
+      if (epi.relu) t = t > 0.0f ? t : 0.0f;
+      if (epi.mask) { if constexpr (V == 1) t = m > 0.0f ? t : 0.0f; else t = m[c] > 0.0f ? t : 0.0f; }
+      if constexpr (V == 1) o = t; else o[c] = t;
+    }
+    *reinterpret_cast<vf*>(y + i) = o;
+  }
+}
+
+// channels per part: whole stages of the tile's shape (8 channels at 64 output channels per workgroup, 4 at 32), as even as the stages divide
+int ksplit_chunk(int cinpad, int tile, int splits) {
+  const int kc = (tile == 2 || tile == 3) ? 4 : 8;
+  const int nst = cinpad / kc;
+  return (nst + splits - 1) / splits * kc;
+}
+
+// auto rule: the most parts that still give every workgroup a compute unit of its own (one round of at most 256 workgroups with the
+// flatter of the two 64-channel tiles), each part at least 4 stages, at most 8 parts.  Measured on the ResNet-101 stage-4 / 5 layers
+// (profiles/r06_wino4_ksplit.jsonl): a workgroup's fixed cost (first tiles, output transform, stores) is ~12 us of its life - parts that
+// double up on a compute unit cost more than they save, parts that fill idle ones are nearly free.
+int pick_wino4_ksplit(int b, int cin, int cout, int h, int w) {
+  const long long cg = (cout + 63) / 64;
+  const long long t0 = static_cast<long long>((h + 15) / 16) * ((w + 31) / 32) * cg * b, t1 = static_cast<long long>((h + 7) / 8) * ((w + 63) / 64) * cg * b;
+  const long long wgs = t0 < t1 ? t0 : t1;
+  const int nst = round_up4(cin, 8) / 8;
+  int s = wgs > 0 && wgs <= 128 ? static_cast<int>(256 / wgs) : 1;
+  if (s > nst / 4) s = nst / 4;
+  if (s > 8) s = 8;
+  return s < 2 ? 1 : s;
 }
 
 int check_wino4_args(const float* x, const float* w_prep, const float* bias, const float* residual, const float* mask, const float* y) {
@@ -741,6 +851,43 @@ int adv_conv2d_wino4_f32(const float* x, const float* w_prep, const float* bias,
   const Epi4 epi{bias, residual, mask, relu ? 1 : 0};
   return launch_wino4_tile<false>(tile >= 0 ? tile : pick_wino4_tile(cout, h, w, b, w <= 15 && cin % kKPad == 0 && b >= 2), x, w_prep, y, b, cin, cout, round_up4(cin, kKPad), round_up4(cout, kCO), 1, h, w,
                                   epi, static_cast<hipStream_t>(stream));
+}
+
+int adv_conv2d_wino4_ksplit_pick(int b, int cin, int cout, int h, int w) {
+  if (b < 1 || cin < 1 || cout < 1 || h < 1 || w < 1) return ADV_EINVAL;
+  return pick_wino4_ksplit(b, cin, cout, h, w);
+}
+
+int adv_conv2d_wino4_ksplit_chunk(int cin, int tile, int splits) {
+  if (cin < 1 || tile < 0 || tile > 3 || splits < 1) return ADV_EINVAL;
+  return ksplit_chunk(round_up4(cin, kKPad), tile, splits);
+}
+
+int adv_conv2d_wino4_ksplit_f32(const float* x, const float* w_prep, const float* bias, const float* residual, const float* mask, float* y,
+                                float* scratch, int b, int cin, int cout, int h, int w, int relu, int tile, int splits, adv_stream_t stream) {
+  if (!x || !w_prep || !y || !scratch || b < 1 || cin < 1 || cout < 1 || h < 1 || w < 1 || tile < -1 || tile > 3 || splits < 2 || splits > 64) return ADV_EINVAL;
+  if (const int rc = check_wino4_args(x, w_prep, bias, residual, mask, y)) return rc;
+  if ((reinterpret_cast<uintptr_t>(scratch) & 15) || scratch == y || scratch == x) return ADV_EALIGN;
+  const int cinpad = round_up4(cin, kKPad);
+  const int t = tile >= 0 ? tile : pick_wino4_tile(cout, h, w, static_cast<long long>(b) * splits, false);
+  const int chunk = ksplit_chunk(cinpad, t, splits);
+  const int parts = (cinpad + chunk - 1) / chunk;      // (no empty part)
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (parts < 2) {
+    const Epi4 whole{bias, residual, mask, relu ? 1 : 0, 0, 0};
+    return launch_wino4_tile<false>(t, x, w_prep, y, b, cin, cout, cinpad, round_up4(cout, kCO), 1, h, w, whole, st);
+  }
+  const Epi4 raw{nullptr, nullptr, nullptr, 0, parts, chunk};
+  if (const int rc = launch_wino4_tile<false>(t, x, w_prep, scratch, b, cin, cout, cinpad, round_up4(cout, kCO), 1, h, w, raw, st)) return rc;
+  const long long hw = static_cast<long long>(h) * w, n = hw * cout * b;
+  const Epi4 epi{bias, residual, mask, relu ? 1 : 0, 0, 0};
+  const bool v4 = hw % 4 == 0 && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(mask)) & 15) == 0;
+  const long long items = v4 ? n / 4 : n;
+  long long blocks = (items + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (v4) hipLaunchKernelGGL(wino4_ksplit_sum<4>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, scratch, y, n, parts, cout, hw, epi);
+  else hipLaunchKernelGGL(wino4_ksplit_sum<1>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, st, scratch, y, n, parts, cout, hw, epi);
+  return adv_internal_finish_launch();
 }
 
 int64_t adv_conv3d_wino4_prep_floats(int cout, int cin, int transpose) {

@@ -237,7 +237,7 @@ class Conv2dAuto(torch.autograd.Function):
 
         def by_wino4():
             from .wino4 import conv_wino4
-            return conv_wino4(x, prep.wino4(), bias, res, do_relu)
+            return conv_wino4(x, prep.wino4(), bias, res, do_relu, splits=0)       # (small maps: the contraction dealt to several workgroups per tile)
 
         use = _Conv2dChoice.get(key, lambda: conv2d(x, prep, bias, res, do_relu), by_torch,
                                 (lambda: conv2d(x, prep, bias, res, do_relu, wino=True)) if prep.has_wino else None, by_wino4 if prep.has_wino else None)
@@ -273,7 +273,7 @@ class Conv2dAuto(torch.autograd.Function):
 
         def by_wino4():
             from .wino4 import conv_wino4_dgrad
-            return conv_wino4_dgrad(g, prep.wino4(), residual=skip, mask=x_in if ctx.mask_input else None)
+            return conv_wino4_dgrad(g, prep.wino4(), residual=skip, mask=x_in if ctx.mask_input else None, splits=0)
 
         use = _Conv2dChoice.get(key, hip, by_torch, (lambda: hip(True)) if prep.has_wino else None, by_wino4 if prep.has_wino else None)
         gx = by_wino4() if use == "wino4" else (hip(use == "wino") if use else by_torch())

@@ -28,7 +28,7 @@ class ConvWino4Prep:
         return t
 
 
-def _wino4_call(x, u, three_d, cin, cout, bias, residual, relu, mask, tile):
+def _wino4_call(x, u, three_d, cin, cout, bias, residual, relu, mask, tile, splits=1):
     xi = _feat(x, "x")
     if xi.dim() != (5 if three_d else 4) or xi.shape[1] != cin:
         raise ValueError("x must be [B,%d,%sH,W]" % (cin, "D," if three_d else ""))
@@ -45,19 +45,33 @@ def _wino4_call(x, u, three_d, cin, cout, bias, residual, relu, mask, tile):
                       int(bool(relu)), int(tile), _stream(xi))
         else:
             b, _, h, w = xi.shape
+            if splits == 0:      # this library's rule for the layer (1: one workgroup per tile)
+                splits = int(_lib.load().adv_conv2d_wino4_ksplit_pick(b, cin, cout, h, w))
+            if splits > 1:       # the contraction dealt to `splits` workgroups per tile; the parts meet in a scratch tensor (the caching allocator's)
+                scratch = torch.empty((splits,) + tuple(y.shape), dtype=torch.float32, device=xi.device)
+                _lib.call("adv_conv2d_wino4_ksplit_f32", _ptr(xi), _ptr(u), bp, _like(residual, y, "residual"), _like(mask, y, "mask"), _ptr(y), _ptr(scratch),
+                          b, cin, cout, h, w, int(bool(relu)), int(tile), int(splits), _stream(xi))
+                return y
             _lib.call("adv_conv2d_wino4_f32", _ptr(xi), _ptr(u), bp, _like(residual, y, "residual"), _like(mask, y, "mask"), _ptr(y), b, cin, cout, h, w,
                       int(bool(relu)), int(tile), _stream(xi))
     return y
 
 
-def conv_wino4(x, prep, bias=None, residual=None, relu=False, mask=None, tile=-1):
-    """conv(x, 3x3 or 3x3x3, stride 1, padding 1) (+ bias) (+ residual) (ReLU) (zeroed where mask <= 0) by the F(4x4,3x3) kernel"""
-    return _wino4_call(x, prep.u(False), prep.three_d, prep.cin, prep.cout, bias, residual, relu, mask, tile)
+def conv_wino4(x, prep, bias=None, residual=None, relu=False, mask=None, tile=-1, splits=1):
+    """conv(x, 3x3 or 3x3x3, stride 1, padding 1) (+ bias) (+ residual) (ReLU) (zeroed where mask <= 0) by the F(4x4,3x3) kernel.
+    ``splits`` (2D layers): > 1 = the contraction dealt to that many workgroups per tile (small maps; its own - reproducible - order of
+    additions: oracle ``conv_wino4(..., chunk=...)``), 0 = the library's rule for the layer, 1 = one workgroup per tile"""
+    return _wino4_call(x, prep.u(False), prep.three_d, prep.cin, prep.cout, bias, residual, relu, mask, tile, splits)
 
 
-def conv_wino4_dgrad(grad, prep, residual=None, mask=None, tile=-1):
+def conv_wino4_dgrad(grad, prep, residual=None, mask=None, tile=-1, splits=1):
     """the backward w.r.t. the input of the same layer: grad [B,Cout,...] -> [B,Cin,...] (+ residual, masked)"""
-    return _wino4_call(grad, prep.u(True), prep.three_d, prep.cout, prep.cin, None, residual, False, mask, tile)
+    return _wino4_call(grad, prep.u(True), prep.three_d, prep.cout, prep.cin, None, residual, False, mask, tile, splits)
+
+
+def conv_wino4_ksplit_chunk(cin, tile, splits):
+    """input channels per part of a K-split launch (adv_conv2d_wino4_ksplit_chunk): what the oracle needs to restate its order"""
+    return int(_lib.load().adv_conv2d_wino4_ksplit_chunk(int(cin), int(tile), int(splits)))
 
 
 __all__ = [n for n in dir() if not n.startswith("__")]

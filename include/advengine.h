@@ -543,6 +543,19 @@ ADV_API int64_t adv_conv2d_wino4_prep_floats(int cout, int cin, int transpose);
 ADV_API int adv_conv2d_wino4_prep_weights_f32(const float* w, float* w_prep, int cout, int cin, int transpose, adv_stream_t stream);
 ADV_API int adv_conv2d_wino4_f32(const float* x, const float* w_prep, const float* bias, const float* residual, const float* mask,
                                  float* y, int b, int cin, int cout, int h, int w, int relu, int tile, adv_stream_t stream);
+/* The same layer with the contraction dealt to `splits` workgroups per tile ("K-split"), for maps too small to fill the chip with one
+ * workgroup per tile (a 256 -> 256 layer on 2 x 38 x 125 is 80 tiles for 256 compute units): part p multiplies input channels
+ * [p * chunk, (p + 1) * chunk) and writes its raw F(4x4,3x3) outputs to plane p of `scratch` ([splits][b][cout][h][w] floats, 16-byte
+ * aligned, the caller's); a second kernel adds the planes in order ((p0 + p1) + p2 ...), then bias, residual, ReLU, mask as above -
+ * reproducible bits, the oracle's orc_conv_wino4 with `chunk`.  chunk = adv_conv2d_wino4_ksplit_chunk(cin, tile, splits) (whole stages
+ * of the tile: tile must be 0..3 there); adv_conv2d_wino4_ksplit_pick: the number of parts this library would use for the layer
+ * (1: do not split).  tile -1: chosen for b * splits workgroups per tile position (then read the chunk back through the oracle-side
+ * helper with the same rule - tests pass explicit tiles).  No reference counterpart (the reference has no native code). */
+ADV_API int adv_conv2d_wino4_ksplit_pick(int b, int cin, int cout, int h, int w);
+ADV_API int adv_conv2d_wino4_ksplit_chunk(int cin, int tile, int splits);
+ADV_API int adv_conv2d_wino4_ksplit_f32(const float* x, const float* w_prep, const float* bias, const float* residual, const float* mask,
+                                        float* y, float* scratch, int b, int cin, int cout, int h, int w, int relu, int tile, int splits,
+                                        adv_stream_t stream);
 ADV_API int64_t adv_conv3d_wino4_prep_floats(int cout, int cin, int transpose);
 ADV_API int adv_conv3d_wino4_prep_weights_f32(const float* w, float* w_prep, int cout, int cin, int transpose, adv_stream_t stream);
 ADV_API int adv_conv3d_wino4_f32(const float* x, const float* w_prep, const float* bias, const float* residual, const float* mask,

@@ -610,9 +610,25 @@ static void wino4_a(float m0, float m1, float m2, float m3, float m4, float m5, 
 
 /* x [B,Kc,D,H,W], w [cout][cin][taps][3][3] with taps = 3 (a 3x3x3 layer: depth taps inside the contraction) or 1 (a 2D layer, D = 1).
  * transpose: x is grad_out, all taps reversed, the roles of cin / cout swapped (the backward w.r.t. the input). */
+static void orc_conv_wino4_chunked(const float* x, const float* w, const float* bias, const float* residual, const float* mask, float* y, int B, int cin,
+                                   int cout, int D, int H, int W, int taps, int relu, int transpose, int chunk);
+
 void orc_conv_wino4(const float* x, const float* w, const float* bias, const float* residual, const float* mask, float* y, int B, int cin,
                     int cout, int D, int H, int W, int taps, int relu, int transpose) {
+  orc_conv_wino4_chunked(x, w, bias, residual, mask, y, B, cin, cout, D, H, W, taps, relu, transpose, 0);
+}
+
+/* the K-split launch of a 2D layer (adv_conv2d_wino4_ksplit_f32): part p contracts the input channels [p * chunk, (p + 1) * chunk) into its
+ * own F(4x4,3x3) outputs (A^T M A of its partial M); the parts are added in order ((p0 + p1) + p2 ...) before bias / residual / ReLU / mask */
+void orc_conv_wino4_ksplit(const float* x, const float* w, const float* bias, const float* residual, const float* mask, float* y, int B, int cin,
+                           int cout, int H, int W, int relu, int transpose, int chunk) {
+  orc_conv_wino4_chunked(x, w, bias, residual, mask, y, B, cin, cout, 1, H, W, 1, relu, transpose, chunk);
+}
+
+static void orc_conv_wino4_chunked(const float* x, const float* w, const float* bias, const float* residual, const float* mask, float* y, int B, int cin,
+                                   int cout, int D, int H, int W, int taps, int relu, int transpose, int chunk) {
   const int M = transpose ? cin : cout, Kc = transpose ? cout : cin;
+  const int part = (chunk > 0 && taps == 1) ? chunk : Kc;      /* channels per part (whole contraction: one part) */
   float* U = (float*)malloc(sizeof(float) * 36 * (size_t)taps * M * Kc);   /* [kd][m][c][36] */
   for (int kd = 0; kd < taps; ++kd)
     for (int m = 0; m < M; ++m)
@@ -644,24 +660,29 @@ void orc_conv_wino4(const float* x, const float* w, const float* bias, const flo
             }
           }
           for (int m = 0; m < M; ++m) {
-            float mm[36], s[4][6], o[4][4];
-            for (int k = 0; k < 36; ++k) {
-              float acc = 0.0f;
-              for (int kd = 0; kd < taps; ++kd) {
-                const int pl = taps == 3 ? od + kd - 1 : od;
-                if (pl < 0 || pl >= D) continue;
-                const float* u = U + (((long)kd * M + m) * Kc) * 36;
-                const float* v = V + ((long)kd * Kc) * 36;
-                for (int c = 0; c < Kc; ++c) acc = fmaf(u[c * 36 + k], v[c * 36 + k], acc);
+            float mm[36], s[4][6], o[4][4], op[4][4];
+            for (int c0 = 0; c0 < Kc; c0 += part) {
+              const int c1 = c0 + part < Kc ? c0 + part : Kc;
+              for (int k = 0; k < 36; ++k) {
+                float acc = 0.0f;
+                for (int kd = 0; kd < taps; ++kd) {
+                  const int pl = taps == 3 ? od + kd - 1 : od;
+                  if (pl < 0 || pl >= D) continue;
+                  const float* u = U + (((long)kd * M + m) * Kc) * 36;
+                  const float* v = V + ((long)kd * Kc) * 36;
+                  for (int c = c0; c < c1; ++c) acc = fmaf(u[c * 36 + k], v[c * 36 + k], acc);
+                }
+                mm[k] = acc;
               }
-              mm[k] = acc;
+              for (int j = 0; j < 6; ++j) {
+                float col[4];
+                wino4_a(mm[j], mm[6 + j], mm[12 + j], mm[18 + j], mm[24 + j], mm[30 + j], col);
+                for (int r = 0; r < 4; ++r) s[r][j] = col[r];
+              }
+              for (int r = 0; r < 4; ++r) wino4_a(s[r][0], s[r][1], s[r][2], s[r][3], s[r][4], s[r][5], op[r]);
+              for (int r = 0; r < 4; ++r)
+                for (int q = 0; q < 4; ++q) o[r][q] = c0 == 0 ? op[r][q] : o[r][q] + op[r][q];
             }
-            for (int j = 0; j < 6; ++j) {
-              float col[4];
-              wino4_a(mm[j], mm[6 + j], mm[12 + j], mm[18 + j], mm[24 + j], mm[30 + j], col);
-              for (int r = 0; r < 4; ++r) s[r][j] = col[r];
-            }
-            for (int r = 0; r < 4; ++r) wino4_a(s[r][0], s[r][1], s[r][2], s[r][3], s[r][4], s[r][5], o[r]);
             for (int r = 0; r < 4; ++r)
               for (int q = 0; q < 4; ++q) {
                 const int gh = 4 * ph + r, gw = 4 * pw + q;

@@ -41,6 +41,8 @@ _lib.orc_conv3d_wino.argtypes = [_fp, _fp, ctypes.c_void_p, ctypes.c_void_p, cty
 _lib.orc_conv3d_wino.restype = None
 _lib.orc_conv_wino4.argtypes = [_fp, _fp, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _fp] + [ctypes.c_int] * 9
 _lib.orc_conv_wino4.restype = None
+_lib.orc_conv_wino4_ksplit.argtypes = [_fp, _fp, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _fp] + [ctypes.c_int] * 8
+_lib.orc_conv_wino4_ksplit.restype = None
 for _f in ("orc_denormalize", "orc_normalize", "orc_pgd_step_norm01", "orc_pgd_step_meansub255", "orc_tensor2im_u8",
            "orc_patch_paste", "orc_patch_update"):
     getattr(_lib, _f).restype = None
@@ -318,14 +320,16 @@ def conv_transpose3d_k3_s2(x, weight_t, bias=None, relu=False):
     return out
 
 
-def conv_wino4(x, w, bias=None, residual=None, mask=None, relu=False, transpose=False):
+def conv_wino4(x, w, bias=None, residual=None, mask=None, relu=False, transpose=False, chunk=0):
     """csrc/wino4.hip in its order of operations: Winograd F(4x4,3x3) in the (H, W) plane - x [B,C,H,W] with w [Cout,Cin,3,3], or x
     [B,C,D,H,W] with w [Cout,Cin,3,3,3] (the depth taps inside the contraction) - + bias, + residual, ReLU, mask; transpose=True: x is
-    grad_out -> the gradient w.r.t. the input"""
+    grad_out -> the gradient w.r.t. the input.  ``chunk`` > 0 (2D): the K-split launch's order - parts of ``chunk`` input channels,
+    each through its own output transform, added in order"""
     x = np.ascontiguousarray(x, dtype=np.float32)
     w = np.ascontiguousarray(w, dtype=np.float32)
     cout, cin = w.shape[0], w.shape[1]
     three_d = x.ndim == 5
+    assert not (chunk and three_d)
     assert w.shape[2:] == ((3, 3, 3) if three_d else (3, 3)) and x.shape[1] == (cout if transpose else cin)
     b, d, h, ww = x.shape[0], (x.shape[2] if three_d else 1), x.shape[-2], x.shape[-1]
     y = np.empty((b, cin if transpose else cout) + tuple(x.shape[2:]), np.float32)
@@ -338,5 +342,8 @@ def conv_wino4(x, w, bias=None, residual=None, mask=None, relu=False, transpose=
         return a, a.ctypes.data_as(ctypes.c_void_p)
 
     keep = [opt(bias, (y.shape[1],)), opt(residual, y.shape), opt(mask, y.shape)]
+    if chunk:
+        _lib.orc_conv_wino4_ksplit(x, w, keep[0][1], keep[1][1], keep[2][1], y, b, cin, cout, h, ww, int(relu), int(transpose), int(chunk))
+        return y
     _lib.orc_conv_wino4(x, w, keep[0][1], keep[1][1], keep[2][1], y, b, cin, cout, d, h, ww, 3 if three_d else 1, int(relu), int(transpose))
     return y

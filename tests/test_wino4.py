@@ -117,3 +117,43 @@ def test_hip_conv2d_wino4_image_pairs_bit_exact_vs_oracle(case):
     g = rs.randn(b, cout, h, w).astype(np.float32)
     gx = ops.conv_wino4_dgrad(torch.tensor(g, device=dev), prep, tile=4 if cout % 8 == 0 else -1).cpu().numpy()      # (pairs need a contraction of whole stages: 8 channels)
     assert gx.tobytes() == oracle_c.conv_wino4(g, wt, transpose=True).tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(2, 64, 64, 19, 63), (1, 40, 70, 9, 13), (2, 20, 33, 21, 45), (1, 128, 32, 12, 30)])
+def test_hip_conv2d_wino4_ksplit_bit_exact_vs_oracle(case):
+    """the K-split launch (small maps: the contraction dealt to several workgroups per tile, the parts added in order by a second kernel):
+    every tile shape and 2 / 3 / 4 parts against the oracle's restatement of that order, epilogue and backward included; one part too many
+    for the stages (more parts than stages) degenerates to fewer parts, not to empty ones"""
+    from oracle import oracle_c
+    from eval_driving_safety_amd import ops
+    dev = torch.device("cuda", 0)
+    b, cin, cout, h, w = case
+    rs = np.random.RandomState(cin + 5 * w)
+    x = rs.randn(b, cin, h, w).astype(np.float32)
+    wt = (rs.randn(cout, cin, 3, 3) * 0.2).astype(np.float32)
+    bias = rs.randn(cout).astype(np.float32)
+    res = rs.randn(b, cout, h, w).astype(np.float32)
+    mask = (rs.rand(b, cout, h, w) > 0.3).astype(np.float32)
+    prep = ops.ConvWino4Prep(torch.tensor(wt, device=dev))
+    tx, tb, tr, tm = (torch.tensor(a, device=dev) for a in (x, bias, res, mask))
+    ref = F.conv2d(tx, torch.tensor(wt, device=dev), padding=1)
+    for tile in (0, 1, 2, 3):
+        for splits in (2, 3, 4, 40):
+            chunk = ops.conv_wino4_ksplit_chunk(cin, tile, splits)
+            assert chunk % (8 if tile < 2 else 4) == 0 and chunk * splits >= cin
+            y = ops.conv_wino4(tx, prep, tile=tile, splits=splits)
+            want = oracle_c.conv_wino4(x, wt, chunk=chunk)
+            assert y.cpu().numpy().tobytes() == want.tobytes(), (case, tile, splits, chunk)
+            assert float((y - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+        chunk = ops.conv_wino4_ksplit_chunk(cin, tile, 3)
+        y = ops.conv_wino4(tx, prep, tb, tr, True, tm, tile=tile, splits=3).cpu().numpy()
+        assert y.tobytes() == oracle_c.conv_wino4(x, wt, bias, res, mask, relu=True, chunk=chunk).tobytes(), (case, tile)
+    g = rs.randn(b, cout, h, w).astype(np.float32)
+    gres = rs.randn(b, cin, h, w).astype(np.float32)
+    chunk = ops.conv_wino4_ksplit_chunk(cout, 0, 2)
+    gx = ops.conv_wino4_dgrad(torch.tensor(g, device=dev), prep, residual=torch.tensor(gres, device=dev), tile=0, splits=2).cpu().numpy()
+    assert gx.tobytes() == oracle_c.conv_wino4(g, wt, residual=gres, transpose=True, chunk=chunk).tobytes()
+    # the library's own rule (splits=0) gives the bytes of SOME explicit number of parts with the tile it picks; and the same bytes twice
+    a, b2 = ops.conv_wino4(tx, prep, tb, splits=0), ops.conv_wino4(tx, prep, tb, splits=0)
+    assert torch.equal(a, b2) and float((a - ref - tb[None, :, None, None]).abs().max()) <= 1e-4 * float(ref.abs().max())

@@ -20,10 +20,20 @@ for b, cin, cout, h, w in ((2, 256, 256, 150, 497), (2, 128, 128, 96, 312), (2, 
     x = torch.randn((b, cin, h, w), device=dev, generator=g)
     prep = ops.ConvWino4Prep(torch.randn((cout, cin, 3, 3), device=dev, generator=g) * 0.05)
     out["%%d->%%d @[%%d,%%d,%%d]" %% (cin, cout, b, h, w)] = round(min(timed(lambda: ops.conv_wino4(x, prep, None, None, True)) for _ in range(2)), 4)
+    if os.environ.get("WINO4_EPILOGUES"):      # the same layer with the epilogue's loads: bias; bias + skip connection + mask
+        bias, res = torch.randn((cout,), device=dev, generator=g), torch.randn((b, cout, h, w), device=dev, generator=g)
+        out["%%d->%%d @[%%d,%%d,%%d] +bias" %% (cin, cout, b, h, w)] = round(min(timed(lambda: ops.conv_wino4(x, prep, bias, None, True)) for _ in range(2)), 4)
+        out["%%d->%%d @[%%d,%%d,%%d] +bias+skip+mask" %% (cin, cout, b, h, w)] = round(min(timed(lambda: ops.conv_wino4(x, prep, bias, res, True, res)) for _ in range(2)), 4)
+        del bias, res
 for c, d, h, w in ((128, 96, 10, 152), (32, 48, 96, 312), (64, 48, 96, 312)):
     x = torch.randn((1, c, d, h, w), device=dev, generator=g)
     prep = ops.ConvWino4Prep(torch.randn((c, c, 3, 3, 3), device=dev, generator=g) * 0.05)
     out["3D %%d @[%%d,%%d,%%d]" %% (c, d, h, w)] = round(min(timed(lambda: ops.conv_wino4(x, prep, None, None, True)) for _ in range(2)), 4)
+    if os.environ.get("WINO4_EPILOGUES"):
+        bias, res = torch.randn((c,), device=dev, generator=g), torch.randn((1, c, d, h, w), device=dev, generator=g)
+        out["3D %%d @[%%d,%%d,%%d] +bias" %% (c, d, h, w)] = round(min(timed(lambda: ops.conv_wino4(x, prep, bias, None, True)) for _ in range(2)), 4)
+        out["3D %%d @[%%d,%%d,%%d] +bias+skip+mask" %% (c, d, h, w)] = round(min(timed(lambda: ops.conv_wino4(x, prep, bias, res, True, res)) for _ in range(2)), 4)
+        del bias, res
 print(json.dumps(out))
 ''' % (ROOT, ROOT)
 

@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from eval_driving_safety_amd import ops, _lib  # noqa: E402
 
 
-def run(name, fn, half_steps, last_stage=60):
+def run(name, fn, half_steps, last_stage=60, life_only=False):
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for _ in range(3):
         fn()
@@ -28,7 +28,16 @@ def run(name, fn, half_steps, last_stage=60):
     if okl.any():
         print(json.dumps({"case": name, "workgroup_life_cycles_median": {"prologue": int(np.median((life[..., 1] - life[..., 0])[okl])),
                           "stage_loop": int(np.median((life[..., 2] - life[..., 1])[okl])), "epilogue_incl_store_drain": int(np.median((life[..., 3] - life[..., 2])[okl]))}}), flush=True)
-    for wave in range(8):
+    e1, e2 = s[:, :, 61, :], s[:, :, 62, :]          # the epilogue: round 0 in four steps, then every round's end
+    oke = e1[..., 0] > 0
+    if oke.any():
+        med = lambda a: int(np.median(a[oke]))
+        print(json.dumps({"case": name, "epilogue_cycles_median": {
+            "loop_end_to_epilogue_start": med(e1[..., 0] - life[..., 2]), "round0_lds_writes_issued": med(e1[..., 1] - e1[..., 0]), "round0_barrier": med(e1[..., 2] - e1[..., 1]),
+            "round0_reads_and_transform": med(e1[..., 3] - e1[..., 2]), "round0_stores_issued": med(e1[..., 4] - e1[..., 3]), "round0_end_barrier": med(e2[..., 0] - e1[..., 4]),
+            "round1": med(e2[..., 1] - e2[..., 0]), "round2": med(e2[..., 2] - e2[..., 1]), "round3": med(e2[..., 3] - e2[..., 2]),
+            "store_drain": med(life[..., 3] - np.maximum.reduce([e2[..., 0], e2[..., 1], e2[..., 2], e2[..., 3]]))}}), flush=True)
+    for wave in range(0 if not life_only else 8, 8):
         ns = half_steps[wave]
         st = s[:, wave, 4:last_stage, :]                        # steady-state stages of the eight stamped workgroups
         ok = st[..., 0] > 0
@@ -53,6 +62,13 @@ def run(name, fn, half_steps, last_stage=60):
 def main():
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
+    if "--small" in sys.argv:      # a map with fewer tiles than compute units: the workgroup's life, whole and as parts of a K-split launch
+        xs = torch.randn((2, 256, 38, 125), device=dev)
+        ps = ops.ConvWino4Prep(torch.randn((256, 256, 3, 3), device=dev) * 0.02)
+        for tile in (0, 1):
+            for splits in (1, 3):
+                run("256->256 [2,256,38,125] tile %d, %d part(s)" % (tile, splits), lambda: ops.conv_wino4(xs, ps, tile=tile, splits=splits), [36] * 8, life_only=True)
+        return
     x = torch.randn((2, 256, 150, 497), device=dev)
     prep = ops.ConvWino4Prep(torch.randn((256, 256, 3, 3), device=dev) * 0.02)
     for dbg in [int(a) for a in sys.argv[1:]] or [0]:        # phase ablations need the -DADV_TEST_HOOKS build of the stamped library
