@@ -157,7 +157,7 @@ def wino4_case(rs, dev):
     res = rs.randn(*oshape).astype(np.float32) if rs.rand() < 0.5 else None
     mask = rs.randn(*oshape).astype(np.float32) if rs.rand() < 0.3 else None
     relu = bool(rs.rand() < 0.5)
-    pair_ok = (not three_d) and w <= 15 and cin % 4 == 0
+    pair_ok = (not three_d) and w <= 15 and cin % 8 == 0
     tile = int(rs.choice([-1, 0, 1, 2, 3] + ([4] if pair_ok else [])))
     t = lambda a: None if a is None else torch.tensor(a, device=dev)       # noqa: E731
     prep = ops.ConvWino4Prep(t(wt))
@@ -166,9 +166,15 @@ def wino4_case(rs, dev):
     g = rs.randn(*oshape).astype(np.float32)
     gres = rs.randn(*shape).astype(np.float32) if rs.rand() < 0.5 else None
     gmask = x if rs.rand() < 0.5 else None
-    dtile = tile if not (tile == 4 and cout % 4 != 0) else -1          # (the image-pair shape needs the contraction's channels in fours)
+    dtile = tile if not (tile == 4 and cout % 8 != 0) else -1          # (the image-pair shape needs the contraction's channels in whole stages: eights)
     same(ops.conv_wino4_dgrad(t(g), prep, residual=t(gres), mask=t(gmask), tile=dtile), C.conv_wino4(g, wt, residual=gres, mask=gmask, transpose=True),
          "wino4 dgrad %s" % ((three_d, b, cin, cout, d, h, w, dtile),))
+    if not three_d:      # the K-split launch: parts of the contraction on their own workgroups, added in order (its own order: oracle chunk=)
+        ktile, parts = int(rs.choice([0, 1, 2, 3])), int(rs.choice([2, 3, 5]))
+        same(ops.conv_wino4(t(x), prep, t(bias), t(res), relu, t(mask), tile=ktile, splits=parts),
+             C.conv_wino4(x, wt, bias, res, mask, relu=relu, chunk=ops.conv_wino4_ksplit_chunk(cin, ktile, parts)), "wino4 k-split %s" % ((b, cin, cout, h, w, relu, ktile, parts),))
+        same(ops.conv_wino4_dgrad(t(g), prep, residual=t(gres), mask=t(gmask), tile=ktile, splits=parts),
+             C.conv_wino4(g, wt, residual=gres, mask=gmask, transpose=True, chunk=ops.conv_wino4_ksplit_chunk(cout, ktile, parts)), "wino4 k-split dgrad %s" % ((b, cin, cout, h, w, ktile, parts),))
 
 
 def boxes_case(rs, dev):
