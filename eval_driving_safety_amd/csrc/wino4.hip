@@ -309,6 +309,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
       const int k = (3 * (HI ? 1 : 0) + idx / 6) * 6 + idx % 6;
       vdst[k * 256] = tv[idx];
     };
+#ifdef ADV_WINO4_STAMPS
+    unsigned long long pst[5] = {0, 0, 0, 0, 0};      // prologue: set-up done, requests issued, tiles landed, first barrier passed
+    pst[0] = __builtin_amdgcn_s_memtime();
+#endif
     {
       // prologue: the first three input tiles and the weights of the first two sub-stages are requested together
 #pragma unroll
@@ -323,10 +327,19 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
 #pragma unroll
         for (int slot = 0; slot < 5; ++slot) load_w(0, slot, qclamp(q_lo + KC) / kKQ * wstep, wsB);
       }
+#ifdef ADV_WINO4_STAMPS
+      pst[1] = __builtin_amdgcn_s_memtime();
+#endif
       asm volatile("s_waitcnt vmcnt(10)" ::: "memory");      // the tiles have landed (the weight loads behind them travel on)
+#ifdef ADV_WINO4_STAMPS
+      pst[2] = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
       for (int i = 0; i < G::kXSl; ++i) fix_x(i, 0), fix_x(i, 1);
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef ADV_WINO4_STAMPS
+      pst[3] = __builtin_amdgcn_s_memtime();
+#endif
       {
         const float* tile = sxb + toff + (HI ? G::kPitch : 0);
 #pragma unroll
@@ -477,6 +490,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
     // ---- epilogue: the 36 values M_k of one (channel, patch) sit in eight waves - exchange through LDS, 16 channels per round:
     // E[k][co16][patch]; register v of a 32 x 32 accumulator = channel (v & 3) + 8 (v >> 2) + 4 half of its block, patch = lane & 31
     float* const se = lds;
+    auto eat = [&](int k, int co16, int patch) { return (k * 16 + co16) * NPT + patch; };      // E[k][co16][patch]
 #ifdef ADV_WINO4_STAMPS
     unsigned long long est[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // round 0: start, writes issued, barrier passed, transformed, stores issued; then each round's end
     est[0] = __builtin_amdgcn_s_memtime();
@@ -528,15 +542,18 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
 #pragma unroll
         for (int v8 = 0; v8 < 8; ++v8) {
           const int co16 = (v8 & 3) + 8 * (v8 >> 2) + 4 * half;
+          // (a register's two lane halves are channels co16 and co16 + 4, 128 or 256 floats apart; sending one half to the other 32 banks
+          // - row parity flipped / patch column ^ 32 - measured SLOWER: 1 200 -> 1 500 cycles per round of writes, the lane-dependent
+          // address costs more than it saves: profiles/r06_wino4_epilogue_stamps.jsonl)
           if constexpr (CB == 2) {
-            if (slot < 4) se[(k * 16 + co16) * NPT + l32] = acc[2 * (slot & 3) + (round >> 1)][8 * (round & 1) + v8];
-            else if ((round >> 1) == (HI ? 1 : 0)) se[(k * 16 + co16) * NPT + l32] = acc[8][8 * (round & 1) + v8];
+            if (slot < 4) se[eat(k, co16, l32)] = acc[2 * (slot & 3) + (round >> 1)][8 * (round & 1) + v8];
+            else if ((round >> 1) == (HI ? 1 : 0)) se[eat(k, co16, l32)] = acc[8][8 * (round & 1) + v8];
           } else {
             if (slot < 4) {
-              se[(k * 16 + co16) * NPT + l32] = acc[2 * (slot & 3)][8 * round + v8];
-              se[(k * 16 + co16) * NPT + 32 + l32] = acc[2 * (slot & 3) + 1][8 * round + v8];
+              se[eat(k, co16, l32)] = acc[2 * (slot & 3)][8 * round + v8];
+              se[eat(k, co16, 32 + l32)] = acc[2 * (slot & 3) + 1][8 * round + v8];
             } else {
-              se[(k * 16 + co16) * NPT + (HI ? 32 : 0) + l32] = acc[8][8 * round + v8];
+              se[eat(k, co16, (HI ? 32 : 0) + l32)] = acc[8][8 * round + v8];
             }
           }
         }
@@ -558,8 +575,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
           float col[4];
-          at6(se[((0 * 6 + j) * 16 + co16) * NPT + ep], se[((1 * 6 + j) * 16 + co16) * NPT + ep], se[((2 * 6 + j) * 16 + co16) * NPT + ep],
-              se[((3 * 6 + j) * 16 + co16) * NPT + ep], se[((4 * 6 + j) * 16 + co16) * NPT + ep], se[((5 * 6 + j) * 16 + co16) * NPT + ep], col);
+          at6(se[eat(0 * 6 + j, co16, ep)], se[eat(1 * 6 + j, co16, ep)], se[eat(2 * 6 + j, co16, ep)], se[eat(3 * 6 + j, co16, ep)],
+              se[eat(4 * 6 + j, co16, ep)], se[eat(5 * 6 + j, co16, ep)], col);
 #pragma unroll
           for (int r = 0; r < 4; ++r) s[r][j] = col[r];
         }
@@ -617,6 +634,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
     if (stamped && lane == 0) {
       unsigned long long* o1 = adv_wino4_stamps[blockIdx.x][wave][61];
       unsigned long long* o2 = adv_wino4_stamps[blockIdx.x][wave][62];
+      unsigned long long* o0 = adv_wino4_stamps[blockIdx.x][wave][60];
+#pragma unroll
+      for (int i = 0; i < 5; ++i) o0[i] = pst[i];
 #pragma unroll
       for (int i = 0; i < 5; ++i) o1[i] = est[i], o2[i] = est[5 + i];
     }
@@ -628,8 +648,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino4(const float* __restrict__ x
     }
 #endif
   };
+#ifdef ADV_WINO4_ONEBODY      // timing experiment only (wrong results): every wave runs the waves-0-3 body - half the code, the same work
+  body(std::false_type{});
+#else
   if (wave >= 4) body(std::true_type{});
   else body(std::false_type{});
+#endif
 }
 
 int round_up4(int v, int q) { return (v + q - 1) / q * q; }

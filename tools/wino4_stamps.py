@@ -28,6 +28,13 @@ def run(name, fn, half_steps, last_stage=60, life_only=False):
     if okl.any():
         print(json.dumps({"case": name, "workgroup_life_cycles_median": {"prologue": int(np.median((life[..., 1] - life[..., 0])[okl])),
                           "stage_loop": int(np.median((life[..., 2] - life[..., 1])[okl])), "epilogue_incl_store_drain": int(np.median((life[..., 3] - life[..., 2])[okl]))}}), flush=True)
+    p0 = s[:, :, 60, :]                                # the prologue: set-up done, requests issued, tiles landed, first barrier passed
+    okp = p0[..., 0] > 0
+    if okp.any():
+        medp = lambda a: int(np.median(a[okp]))
+        print(json.dumps({"case": name, "prologue_cycles_median": {
+            "entry_to_setup_done": medp(p0[..., 0] - life[..., 0]), "requests_issued": medp(p0[..., 1] - p0[..., 0]), "wait_for_tiles": medp(p0[..., 2] - p0[..., 1]),
+            "edge_fix_and_barrier": medp(p0[..., 3] - p0[..., 2]), "first_transform_and_barrier": medp(life[..., 1] - p0[..., 3])}}), flush=True)
     e1, e2 = s[:, :, 61, :], s[:, :, 62, :]          # the epilogue: round 0 in four steps, then every round's end
     oke = e1[..., 0] > 0
     if oke.any():
@@ -66,8 +73,12 @@ def main():
         xs = torch.randn((2, 256, 38, 125), device=dev)
         ps = ops.ConvWino4Prep(torch.randn((256, 256, 3, 3), device=dev) * 0.02)
         for tile in (0, 1):
-            for splits in (1, 3):
+            for splits in (1,):
                 run("256->256 [2,256,38,125] tile %d, %d part(s)" % (tile, splits), lambda: ops.conv_wino4(xs, ps, tile=tile, splits=splits), [36] * 8, life_only=True)
+        x3 = torch.randn((1, 32, 48, 96, 312), device=dev)
+        p3 = ops.ConvWino4Prep(torch.randn((32, 32, 3, 3, 3), device=dev) * 0.05)
+        b3 = torch.randn((32,), device=dev)
+        run("3D 32->32 [48,96,312] tile 3 (whole chip)", lambda: ops.conv_wino4(x3, p3, b3, None, True, tile=3), [18] * 8, last_stage=22, life_only=True)
         return
     x = torch.randn((2, 256, 150, 497), device=dev)
     prep = ops.ConvWino4Prep(torch.randn((256, 256, 3, 3), device=dev) * 0.02)
