@@ -738,8 +738,11 @@ __global__ void wino4_ksplit_sum(const float* __restrict__ part, float* __restri
   for (long long i = (blockIdx.x * 256LL + threadIdx.x) * V; i < n; i += 256LL * V * gridDim.x) {
     vf v = *reinterpret_cast<const vf*>(part + i);
     for (int s = 1; s < splits; ++s) v = v + *reinterpret_cast<const vf*>(part + s * n + i);
-    const int co = static_cast<int>((i / hw) % cout);
-    const float bv = epi.bias ? epi.bias[co] : 0.0f;
+    // (V = 4 needs only n % 4 == 0: four consecutive floats may straddle a channel boundary - the bias per element)
+    const long long pl = i / hw;
+    const int co = static_cast<int>(pl % cout), left = static_cast<int>(hw - (i - pl * hw));      // floats of this channel from i on
+    const int co1 = co + 1 < cout ? co + 1 : 0;
+    const float bv = epi.bias ? epi.bias[co] : 0.0f, bv1 = (V > 1 && epi.bias) ? epi.bias[co1] : 0.0f;
     vf r, m;
     if (epi.residual) r = *reinterpret_cast<const vf*>(epi.residual + i);
     if (epi.mask) m = *reinterpret_cast<const vf*>(epi.mask + i);
@@ -748,7 +751,7 @@ __global__ void wino4_ksplit_sum(const float* __restrict__ part, float* __restri
     for (int c = 0; c < V; ++c) {
       float t;
       if constexpr (V == 1) t = v; else t = v[c];
-      if (epi.bias) t = t + bv;
+      if (epi.bias) t = t + (c < left ? bv : bv1);
       if (epi.residual) { if constexpr (V == 1) t = t + r; else t = t + r[c]; }
       if (epi.relu) t = t > 0.0f ? t : 0.0f;
       if (epi.mask) { if constexpr (V == 1) t = m > 0.0f ? t : 0.0f; else t = m[c] > 0.0f ? t : 0.0f; }
@@ -905,7 +908,7 @@ int adv_conv2d_wino4_ksplit_f32(const float* x, const float* w_prep, const float
   if (const int rc = launch_wino4_tile<false>(t, x, w_prep, scratch, b, cin, cout, cinpad, round_up4(cout, kCO), 1, h, w, raw, st)) return rc;
   const long long hw = static_cast<long long>(h) * w, n = hw * cout * b;
   const Epi4 epi{bias, residual, mask, relu ? 1 : 0, 0, 0};
-  const bool v4 = hw % 4 == 0 && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(mask)) & 15) == 0;
+  const bool v4 = n % 4 == 0 && hw >= 4 && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(mask)) & 15) == 0;
   const long long items = v4 ? n / 4 : n;
   long long blocks = (items + 255) / 256;
   if (blocks > 4096) blocks = 4096;
