@@ -21,6 +21,15 @@
 #include "adv_internal.h"
 #include "advengine.h"
 
+#ifdef ADV_C2_STAMPS
+// diagnostic builds only (tools/build_variant.sh c2stamps conv2d.hip -DADV_C2_STAMPS; tools/c2_stamps.py): s_memtime stamps of the 1x1 kernel -
+// [workgroup < 16][wave < 4][stage < 62 | 62: life | 63: epilogue][5]
+__device__ unsigned long long adv_c2_stamps[16][4][64][5];
+extern "C" __attribute__((visibility("default"))) int adv_debug_c2_stamps(void* dst, size_t bytes) {
+  return static_cast<int>(hipMemcpyFromSymbol(dst, HIP_SYMBOL(adv_c2_stamps), bytes < sizeof(adv_c2_stamps) ? bytes : sizeof(adv_c2_stamps)));
+}
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -58,6 +67,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv2d_1x1_mfma(const float* 
   const int half = lane >> 5, l32 = lane & 31;
   const int wm = wave / WN, wn = wave % WN;
 
+#ifdef ADV_C2_STAMPS
+  const unsigned long long c2_entry = __builtin_amdgcn_s_memtime();
+  const bool c2_on = (blockIdx.x < 8 || blockIdx.x + 8 >= gridDim.x) && (WM * WN == 4);      // the first eight and the LAST eight workgroups
+  const int c2_slot = blockIdx.x < 8 ? blockIdx.x : 8 + static_cast<int>(blockIdx.x + 8 - gridDim.x);
+  const int c2_wave = threadIdx.x >> 6;
+#endif
   long long t = blockIdx.x;
   {
     const long long base = ntiles >> 3, rem = ntiles & 7, xcd = t & 7, j = t >> 3;
@@ -140,16 +155,42 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv2d_1x1_mfma(const float* 
     }
   };
 
+#ifdef ADV_C2_STAMPS
+  const unsigned long long c2_setup = __builtin_amdgcn_s_memtime();
+#endif
+  if (tid < G::kBM) lds[2 * G::kStage + tid] = epi.bias ? epi.bias[m0 + tid < M ? m0 + tid : 0] : 0.0f;      // the tile's bias values: read back in the epilogue without a memory round trip between stores
   fetch(0, sa);
   fetch(kKC, sb);
   commit(0, sa);
   __syncthreads();
+#ifdef ADV_C2_STAMPS
+  const unsigned long long c2_loop = __builtin_amdgcn_s_memtime();
+#endif
   auto stage = [&](int s, Set& fs, const Set& cs) {
+#ifdef ADV_C2_STAMPS
+    const unsigned long long q0 = __builtin_amdgcn_s_memtime();
+#endif
     fetch((s + 2) * kKC, fs);
     __builtin_amdgcn_sched_barrier(0);     // the loads stay AHEAD of the matrix instructions (the scheduler would sink them to their use)
+#ifdef ADV_C2_STAMPS
+    const unsigned long long q1 = __builtin_amdgcn_s_memtime();
+#endif
     products(s);
+#ifdef ADV_C2_STAMPS
+    const unsigned long long q2 = __builtin_amdgcn_s_memtime();
+#endif
     commit((s + 1) & 1, cs);
+#ifdef ADV_C2_STAMPS
+    const unsigned long long q3 = __builtin_amdgcn_s_memtime();
+#endif
     __syncthreads();
+#ifdef ADV_C2_STAMPS
+    const unsigned long long q4 = __builtin_amdgcn_s_memtime();
+    if (c2_on && s < 62 && (threadIdx.x & 63) == 0) {
+      unsigned long long* o = adv_c2_stamps[c2_slot][c2_wave][s];
+      o[0] = q0, o[1] = q1, o[2] = q2, o[3] = q3, o[4] = q4;
+    }
+#endif
   };
   int s = 0;
   for (; s + 1 < nstage; s += 2) {
@@ -157,6 +198,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv2d_1x1_mfma(const float* 
     stage(s + 1, sb, sa);
   }
   if (s < nstage) products(s);
+#ifdef ADV_C2_STAMPS
+  const unsigned long long c2_loop_end = __builtin_amdgcn_s_memtime();
+#endif
 
   // ---- epilogue: register v of a 32x32 accumulator = output channel (v & 3) + 8 * (v >> 2) + 4 * half, pixel = lane & 31
   const long long MP = static_cast<long long>(M) * P;
@@ -196,7 +240,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv2d_1x1_mfma(const float* 
         if (co >= M) continue;
         const long long at = static_cast<long long>(co) * P + p;
         float r = acc[i][jn][v];
-        if (epi.bias) r = r + epi.bias[co];
+        if (epi.bias) r = r + lds[2 * G::kStage + co - m0];
         if (resb) r = r + rv[v];
         if (epi.relu) r = r > 0.0f ? r : 0.0f;
         if (maskb) r = mv[v] > 0.0f ? r : 0.0f;
@@ -204,6 +248,16 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv2d_1x1_mfma(const float* 
       }
     }
   }
+#ifdef ADV_C2_STAMPS
+  const unsigned long long c2_issued = __builtin_amdgcn_s_memtime();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const unsigned long long c2_end = __builtin_amdgcn_s_memtime();
+  if (c2_on && (threadIdx.x & 63) == 0) {
+    unsigned long long* o = adv_c2_stamps[c2_slot][c2_wave][62];
+    o[0] = c2_entry, o[1] = c2_setup, o[2] = c2_loop, o[3] = c2_loop_end, o[4] = c2_end;
+    adv_c2_stamps[c2_slot][c2_wave][63][0] = c2_issued;
+  }
+#endif
 }
 
 __global__ void conv2d_1x1_prep_kernel(const float* __restrict__ w, float* __restrict__ out, int cout, int cin, int transpose, int kpad, int mpad) {
@@ -238,7 +292,7 @@ int launch_1x1(const float* x, const float* wp, float* y, int b, int K, int M, i
   // an image and the prepared weights are addressed with 32-bit byte offsets (buffer loads): both below 4 GiB
   const long long wbytes = static_cast<long long>(round_up(K, kKC)) * mpad * 4;
   if ((static_cast<long long>(K) + kKC) * P * 4 >= 0xfff00000LL || wbytes >= 0xfff00000LL) return ADV_EINVAL;
-  const size_t lds = 2 * sizeof(float) * static_cast<size_t>(G::kStage);
+  const size_t lds = sizeof(float) * (2 * static_cast<size_t>(G::kStage) + G::kBM);      // two stage buffers + the tile's bias
   if (lds > 64 * 1024 && !adv_internal_lds_limit<conv2d_1x1_mfma<WM, WN, TM, TN>>(lds)) return ADV_ELAUNCH;
   hipLaunchKernelGGL((conv2d_1x1_mfma<WM, WN, TM, TN>), dim3(static_cast<unsigned>(ntiles)), dim3(G::kT), lds, st, x, wp, y, K, M, mpad, P, tiles_m,
                      static_cast<int>(tiles_n), ntiles, wbytes, epi);
