@@ -292,7 +292,11 @@ int launch_1x1(const float* x, const float* wp, float* y, int b, int K, int M, i
   // an image and the prepared weights are addressed with 32-bit byte offsets (buffer loads): both below 4 GiB
   const long long wbytes = static_cast<long long>(round_up(K, kKC)) * mpad * 4;
   if ((static_cast<long long>(K) + kKC) * P * 4 >= 0xfff00000LL || wbytes >= 0xfff00000LL) return ADV_EINVAL;
-  const size_t lds = sizeof(float) * (2 * static_cast<size_t>(G::kStage) + G::kBM);      // two stage buffers + the tile's bias
+  size_t lds = sizeof(float) * (2 * static_cast<size_t>(G::kStage) + G::kBM);      // two stage buffers + the tile's bias
+  if (const char* occ = adv_hook_value("ADV_C2_OCC")) {      // test hook / A-B: at most this many workgroups per compute unit (LDS padding)
+    const int r = std::atoi(occ);
+    if (r >= 1 && r <= 8 && static_cast<size_t>(160 * 1024 / r) > lds) lds = static_cast<size_t>(160 * 1024 / r) & ~static_cast<size_t>(511);
+  }
   if (lds > 64 * 1024 && !adv_internal_lds_limit<conv2d_1x1_mfma<WM, WN, TM, TN>>(lds)) return ADV_ELAUNCH;
   hipLaunchKernelGGL((conv2d_1x1_mfma<WM, WN, TM, TN>), dim3(static_cast<unsigned>(ntiles)), dim3(G::kT), lds, st, x, wp, y, K, M, mpad, P, tiles_m,
                      static_cast<int>(tiles_n), ntiles, wbytes, epi);
