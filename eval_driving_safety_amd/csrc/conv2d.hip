@@ -170,7 +170,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv2d_1x1_mfma(const float* 
 #ifdef ADV_C2_STAMPS
     const unsigned long long q0 = __builtin_amdgcn_s_memtime();
 #endif
+#ifndef ADV_C2_NOFETCH      // (timing experiments, wrong results: no requests after the first two stages / no barrier / no LDS commit)
     fetch((s + 2) * kKC, fs);
+#endif
     __builtin_amdgcn_sched_barrier(0);     // the loads stay AHEAD of the matrix instructions (the scheduler would sink them to their use)
 #ifdef ADV_C2_STAMPS
     const unsigned long long q1 = __builtin_amdgcn_s_memtime();
@@ -179,11 +181,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv2d_1x1_mfma(const float* 
 #ifdef ADV_C2_STAMPS
     const unsigned long long q2 = __builtin_amdgcn_s_memtime();
 #endif
+#ifndef ADV_C2_NOCOMMIT
     commit((s + 1) & 1, cs);
+#endif
 #ifdef ADV_C2_STAMPS
     const unsigned long long q3 = __builtin_amdgcn_s_memtime();
 #endif
+#ifndef ADV_C2_NOBARRIER
     __syncthreads();
+#endif
 #ifdef ADV_C2_STAMPS
     const unsigned long long q4 = __builtin_amdgcn_s_memtime();
     if (c2_on && s < 62 && (threadIdx.x & 63) == 0) {
@@ -244,7 +250,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv2d_1x1_mfma(const float* 
         if (resb) r = r + rv[v];
         if (epi.relu) r = r > 0.0f ? r : 0.0f;
         if (maskb) r = mv[v] > 0.0f ? r : 0.0f;
+#ifdef ADV_C2_NOSTORE      // (timing experiment: the store only where the result is NaN - never, but the compiler keeps the arithmetic)
+        if (r != r) yb[at] = r;
+#else
         yb[at] = r;
+#endif
       }
     }
   }
