@@ -23,7 +23,7 @@ ADV_ELAUNCH = -5
 ADV_SPACE_AFFINE = 0
 ADV_SPACE_IDENTITY = 1
 ADV_SPACE_AFFINE_RCP = 2
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class AdvSpace(ctypes.Structure):

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ADV_ABI_VERSION 10
+#define ADV_ABI_VERSION 11
 #define ADV_API __attribute__((visibility("default"))) /* the library is built with -fvisibility=hidden */
 #define ADV_CHANNELS 3
 

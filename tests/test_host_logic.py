@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "libadvengine.so lacks %s" % name
     assert sorted(_lib.EXPORTED) == declared, "ctypes binding and header disagree"
-    assert lib.adv_abi_version() == _lib.ABI_VERSION == 10
+    assert lib.adv_abi_version() == _lib.ABI_VERSION == 11
     assert lib.adv_strerror(-22) == b"invalid argument"
 
 
@@ -59,7 +59,7 @@ def test_header_is_valid_c99(tmp_path):
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
                     "-L", lib_dir, "-l:libadvengine.so", "-Wl,-rpath," + lib_dir], check=True)
     out = subprocess.run([str(exe)], stdout=subprocess.PIPE, text=True)
-    assert out.returncode == 0 and out.stdout.split() == ["10", "0", "0.229"]
+    assert out.returncode == 0 and out.stdout.split() == ["11", "0", "0.229"]
 
 
 def test_space_constants_are_the_reference_constants():
