@@ -270,6 +270,126 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv2d_1x1_mfma(const float* 
 #endif
 }
 
+// ---- the same GEMM in HALF-SIZE wave units (tile index 5): 64 output channels x 32 pixels per workgroup, four waves, each wave 32 channels x
+// 16 pixels as two v_mfma_f32_16x16x4_f32 blocks that share their pixel operand.  The matrix pipes run the waves of a SIMD one after another,
+// so a launch takes ceil(waves / SIMDs) wave-times: 1024 -> 256 on [2,1024,38,125] is 2.33 waves of 32 x 32 per SIMD = 3 wave-times; in
+// half-size units it is 4.66 = 5 half wave-times (2.5).  The 16x16x4 instruction adds its four k in ascending order like the 32x32x2 one its
+// two: the same fmaf chain per output as every other shape - the same bits (tests/test_conv2d.py runs all six shapes against one oracle).
+// Stage = 32 input channels; LDS rows padded (pixels 32 -> 48 floats, channels 64 -> 80) so that the four 16-lane groups of an operand read
+// (k = lane / 16) fall into different banks.
+constexpr int kKC16 = 32, kXP16 = 48, kWP16 = 80, kStage16 = kKC16 * (kXP16 + kWP16);
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256, 2) void conv2d_1x1_mfma16(const float* __restrict__ x, const float* __restrict__ wp, float* __restrict__ y, int K, int M, int mpad,
+                                                            long long P, int tiles_m, int tiles_n, long long ntiles, long long wbytes, Epi2 epi) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, l16 = lane & 15;
+  const int wm = wave >> 1, wn = wave & 1;
+  long long t = blockIdx.x;
+  {
+    const long long base = ntiles >> 3, rem = ntiles & 7, xcd = t & 7, j = t >> 3;
+    t = xcd * base + (xcd < rem ? xcd : rem) + j;
+  }
+  const int mt = static_cast<int>(t % tiles_m);
+  const long long r = t / tiles_m;
+  const int nt = static_cast<int>(r % tiles_n);
+  const long long b = r / tiles_n;
+  const int m0 = mt * 64;
+  const long long n0 = static_cast<long long>(nt) * 32;
+  const long long KP = static_cast<long long>(K) * P;
+  f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+
+  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + b * KP), 0, static_cast<int>(static_cast<unsigned>(KP * 4)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wp), 0, static_cast<int>(static_cast<unsigned>(wbytes)), 0x00020000);
+  // one float4 of the pixel slab [32 rows][32 pixels] and two of the weight slab [32 rows][64 channels] per thread and stage
+  const int xrow = tid >> 3, xc4 = tid & 7;
+  const int xvo = static_cast<int>((static_cast<unsigned>(xrow) * static_cast<unsigned>(P) + static_cast<unsigned>(n0) + 4u * xc4) * 4u);
+  int wvo[2], wrow[2], wc4[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int f = tid + 256 * i;
+    wrow[i] = f >> 4, wc4[i] = f & 15;
+    wvo[i] = (wrow[i] * mpad + m0 + 4 * wc4[i]) * 4;
+  }
+  struct Set {
+    v4f x, w[2];
+  };
+  Set sa, sb;
+  const int nstage = (K + kKC16 - 1) / kKC16;
+  auto fetch = [&](int k0, Set& st) {
+    const int xo = static_cast<int>(static_cast<unsigned>(k0) * static_cast<unsigned>(P) * 4u);      // wave-uniform; rows >= K fail the range check: zeros
+    st.x = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsx, xvo + xo, 0, 0));
+    // (look-ahead stages past the last one re-read the last stage into a set nobody reads; the stage's offset travels in the VECTOR offset,
+    // which the range check covers - the prepared weights are padded to 16 rows, a 32-row stage may reach past them: zeros)
+    const int kw = k0 < nstage * kKC16 ? k0 : (nstage - 1) * kKC16;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) st.w[i] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsw, wvo[i] + kw * mpad * 4, 0, 0));
+  };
+  auto commit = [&](int buf, const Set& st) {
+    float* sx = lds + buf * kStage16;
+    float* sw = sx + kKC16 * kXP16;
+    *reinterpret_cast<v4f*>(sx + xrow * kXP16 + 4 * xc4) = st.x;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<v4f*>(sw + wrow[i] * kWP16 + 4 * wc4[i]) = st.w[i];
+  };
+  auto products = [&](int s) {
+    const float* sx = lds + (s & 1) * kStage16 + g * kXP16 + wn * 16 + l16;
+    const float* sw = lds + (s & 1) * kStage16 + kKC16 * kXP16 + g * kWP16 + wm * 32 + l16;
+#pragma unroll
+    for (int kk = 0; kk < kKC16; kk += 4) {
+      const float a0 = sw[kk * kWP16], a1 = sw[kk * kWP16 + 16], bv = sx[kk * kXP16];
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bv, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bv, acc1, 0, 0, 0);
+    }
+  };
+  if (tid < 64) lds[2 * kStage16 + tid] = epi.bias ? epi.bias[m0 + tid < M ? m0 + tid : 0] : 0.0f;
+  fetch(0, sa);
+  fetch(kKC16, sb);
+  commit(0, sa);
+  __syncthreads();
+  auto stage = [&](int s, Set& fs, const Set& cs) {
+    fetch((s + 2) * kKC16, fs);
+    __builtin_amdgcn_sched_barrier(0);
+    products(s);
+    commit((s + 1) & 1, cs);
+    __syncthreads();
+  };
+  int s = 0;
+  for (; s + 1 < nstage; s += 2) {
+    stage(s, sa, sb);
+    stage(s + 1, sb, sa);
+  }
+  if (s < nstage) products(s);
+
+  // ---- epilogue: register r of a 16 x 16 accumulator = output channel 4 (lane / 16) + r of its block, pixel = lane % 16
+  const long long MP = static_cast<long long>(M) * P;
+  float* yb = y + b * MP;
+  const float* resb = epi.residual ? epi.residual + b * MP : nullptr;
+  const float* maskb = epi.mask ? epi.mask + b * MP : nullptr;
+  const long long p = n0 + wn * 16 + l16;
+  if (p >= P) return;
+  const int cbase = m0 + wm * 32 + 4 * g;
+  float rv[8], mv[8];
+#pragma unroll
+  for (int v = 0; v < 8; ++v) {      // the skip connection and the mask first, unconditionally (see the 32 x 32 kernel)
+    const int co = cbase + 16 * (v >> 2) + (v & 3);
+    rv[v] = resb ? __builtin_nontemporal_load(co < M ? resb + static_cast<long long>(co) * P + p : epi.residual) : 0.0f;
+    mv[v] = maskb ? __builtin_nontemporal_load(co < M ? maskb + static_cast<long long>(co) * P + p : epi.mask) : 1.0f;
+  }
+#pragma unroll
+  for (int v = 0; v < 8; ++v) {
+    const int co = cbase + 16 * (v >> 2) + (v & 3);
+    if (co >= M) continue;
+    float o = v < 4 ? acc0[v & 3] : acc1[v & 3];
+    if (epi.bias) o = o + lds[2 * kStage16 + co - m0];
+    if (resb) o = o + rv[v];
+    if (epi.relu) o = o > 0.0f ? o : 0.0f;
+    if (maskb) o = mv[v] > 0.0f ? o : 0.0f;
+    yb[static_cast<long long>(co) * P + p] = o;
+  }
+}
+
 __global__ void conv2d_1x1_prep_kernel(const float* __restrict__ w, float* __restrict__ out, int cout, int cin, int transpose, int kpad, int mpad) {
   // forward:  out[k = ci][m = co] = w[co][ci];   transpose (backward w.r.t. the input): out[k = co][m = ci] = w[co][ci]
   const long long n = static_cast<long long>(kpad) * mpad;
@@ -313,20 +433,37 @@ int launch_1x1(const float* x, const float* wp, float* y, int b, int K, int M, i
   return adv_internal_finish_launch();
 }
 
-// which tile shape: 0 = 128x256, 1 = 128x128, 2 = 64x128, 3 = 64x64, 4 = 64x32 (output channels x pixels; 4: two waves).  One wave's work
+int launch_1x1_m16(const float* x, const float* wp, float* y, int b, int K, int M, int mpad, long long P, const Epi2& epi, hipStream_t st) {
+  const int tiles_m = (M + 63) / 64;
+  const long long tiles_n = (P + 31) / 32;
+  const long long ntiles = static_cast<long long>(tiles_m) * tiles_n * b;
+  if (tiles_n > 0x7fffffffLL || ntiles > 0x7fffffffLL) return ADV_EINVAL;
+  const long long wbytes = static_cast<long long>(round_up(K, kKC)) * mpad * 4;
+  if ((static_cast<long long>(K) + 3 * kKC16) * P * 4 >= 0xfff00000LL || wbytes + 3LL * kKC16 * mpad * 4 >= 0xfff00000LL) return ADV_EINVAL;
+  const size_t lds = sizeof(float) * (2 * static_cast<size_t>(kStage16) + 64);
+  hipLaunchKernelGGL(conv2d_1x1_mfma16, dim3(static_cast<unsigned>(ntiles)), dim3(256), lds, st, x, wp, y, K, M, mpad, P, tiles_m, static_cast<int>(tiles_n), ntiles,
+                     wbytes, epi);
+  return adv_internal_finish_launch();
+}
+
+// which tile shape: 0 = 128x256, 1 = 128x128, 2 = 64x128, 3 = 64x64, 4 = 64x32 (output channels x pixels; 4: two waves), 5 = 64x32 in four half-size waves.  One wave's work
 // is TM*TN accumulators over K; the matrix pipes run the waves of a SIMD one after another, so a launch takes about
 // ceil(waves / SIMDs) * TM*TN / efficiency(shape) - bigger tiles reuse more per staged byte, smaller ones fill the chip.
 int pick_1x1_tile(int b, int M, long long P, int simds) {
-  static const int bm[5] = {128, 128, 64, 64, 64}, bn[5] = {256, 128, 128, 64, 32}, work[5] = {8, 4, 2, 1, 1}, wg_waves[5] = {4, 4, 4, 4, 2};
+  static const int bm[6] = {128, 128, 64, 64, 64, 64}, bn[6] = {256, 128, 128, 64, 32, 32}, wg_waves[6] = {4, 4, 4, 4, 2, 4};
+  static const double work[6] = {8, 4, 2, 1, 1, 0.5};
   // relative efficiency of a wave's MFMA stream per tile shape, fitted to the sweep of the R101 1x1 layers on MI355X (round 5, after the
   // buffer-load staging: profiles/r05_conv2d_1x1_tile_sweep.jsonl - the small tiles gained most: several workgroups per compute unit
   // cover each other's prologue and epilogue; 0.07 ms per R101 step over the per-layer optimum, the round-3 fit {0.8, 1.08, 0.94, 1} 0.26).
   // <round 6> the 64 x 32 shape (profiles/r06_conv2d_1x1_tile_sweep.jsonl): as fast as 64 x 64 where the pixels fill whole tiles, 7 % faster
   // on the RoI heads' 14 x 14 maps (196 pixels per image: 7 tiles of 32 instead of 4 of 64) - it wins where it saves more than 5 % of the waves
-  static const double eff[5] = {0.75, 0.88, 0.99, 1.0, 0.95};
+  // the half-size units of shape 5 (conv2d_1x1_mfma16: four waves of 32 x 16 on a 64 x 32 tile) where the whole-wave rounding of the others
+  // hurts - 1024 -> 256 on [2,1024,38,125]: 2.33 waves per SIMD = 3 wave-times against 4.66 = 5 half ones: 0.0575 -> 0.0544 ms; 2048 -> 512
+  // on [2,2048,19,63]: 2 against 3 halves: 0.0713 -> 0.0607 ms; both fit an efficiency of 0.88 (profiles/r06_conv2d_1x1_half_units.jsonl)
+  static const double eff[6] = {0.75, 0.88, 0.99, 1.0, 0.95, 0.88};
   int best = 0;
   double best_t = 1e300;
-  for (int c = 0; c < 5; ++c) {
+  for (int c = 0; c < 6; ++c) {
     const double waves = static_cast<double>(wg_waves[c]) * ((M + bm[c] - 1) / bm[c]) * static_cast<double>((P + bn[c] - 1) / bn[c]) * b;
     const double rounds = static_cast<double>(static_cast<long long>((waves + simds - 1) / simds));
     const double tcost = rounds * work[c] / eff[c];
@@ -600,7 +737,7 @@ int adv_conv2d_1x1_prep_weights_f32(const float* w, float* w_prep, int cout, int
 
 int adv_conv2d_1x1_f32(const float* x, const float* w_prep, const float* bias, const float* residual, const float* mask, float* y, int b, int cin,
                        int cout, int64_t pixels, int relu, int tile, adv_stream_t stream) {
-  if (!x || !w_prep || !y || b < 1 || cin < 1 || cout < 1 || pixels < 1 || tile < -1 || tile > 4) return ADV_EINVAL;
+  if (!x || !w_prep || !y || b < 1 || cin < 1 || cout < 1 || pixels < 1 || tile < -1 || tile > 5) return ADV_EINVAL;
   if (static_cast<long long>(b) * cin * pixels < 4) return ADV_EINVAL;      // the kernels load whole float4s (clamped into the tensor)
   if (residual == y || mask == y || x == y) return ADV_EINVAL;
   if ((reinterpret_cast<uintptr_t>(x) & 3) || (reinterpret_cast<uintptr_t>(y) & 3) || (reinterpret_cast<uintptr_t>(w_prep) & 15) ||
@@ -616,6 +753,7 @@ int adv_conv2d_1x1_f32(const float* x, const float* w_prep, const float* bias, c
     case 1: return launch_1x1<2, 2, 2, 2>(x, w_prep, y, b, cin, cout, mpad, pixels, epi, st);
     case 2: return launch_1x1<2, 2, 1, 2>(x, w_prep, y, b, cin, cout, mpad, pixels, epi, st);
     case 4: return launch_1x1<2, 1, 1, 1>(x, w_prep, y, b, cin, cout, mpad, pixels, epi, st);      // 64 x 32, two waves
+    case 5: return launch_1x1_m16(x, w_prep, y, b, cin, cout, mpad, pixels, epi, st);              // 64 x 32, four waves of half-size units
     default: return launch_1x1<2, 2, 1, 1>(x, w_prep, y, b, cin, cout, mpad, pixels, epi, st);
   }
 }

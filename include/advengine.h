@@ -483,7 +483,8 @@ ADV_API int adv_bilinear_up_bwd_f32(const float* grad_out, float* grad_in, int64
  *     mask     DEVICE tensor laid out like y or NULL: the result is zeroed where mask <= 0, last of all.  In a backward call with
  *              mask = the layer's own input (a ReLU output) the result is the gradient w.r.t. the previous layer's PRE-activation:
  *              no separate ReLU-backward pass over the tensor;
- *     tile     -1 = pick by size; 0..4 force 128x256 / 128x128 / 64x128 / 64x64 / 64x32 (output channels x pixels per workgroup) - the
+ *     tile     -1 = pick by size; 0..5 force 128x256 / 128x128 / 64x128 / 64x64 / 64x32 / 64x32 in four half-size waves (output channels x
+ *              pixels per workgroup; 5 = 16x16x4 matrix instructions: finer whole-wave rounding on few-workgroup layers) - the
  *              result does not depend on it (one fmaf chain per output element, ci ascending).
  *     x, y, residual, mask need 4-byte alignment only (rows of odd length are the rule: 150 x 497, 38 x 125 ...). */
 ADV_API int64_t adv_conv2d_1x1_prep_floats(int cout, int cin, int transpose);

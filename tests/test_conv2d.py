@@ -62,7 +62,7 @@ def test_hip_conv2d_1x1_bit_exact_vs_oracle_every_tile_shape(shape):
     prep = ops.Conv2dPrep(tw)
     want_plain = C.conv2d(x, wt)
     want_full = C.conv2d(x, wt, bias, res, mask, relu=True)
-    for tile in (-1, 0, 1, 2, 3, 4):
+    for tile in (-1, 0, 1, 2, 3, 4, 5):
         assert ops.conv2d(tx, prep, tile=tile).cpu().numpy().tobytes() == want_plain.tobytes(), ("plain", tile)
         assert ops.conv2d(tx, prep, tb, tr, True, tm, tile=tile).cpu().numpy().tobytes() == want_full.tobytes(), ("bias + residual + relu + mask", tile)
     ref = F.conv2d(tx, tw, tb)
@@ -74,7 +74,7 @@ def test_hip_conv2d_1x1_bit_exact_vs_oracle_every_tile_shape(shape):
     tg, tgr = torch.tensor(g, device=dev), torch.tensor(gres, device=dev)
     assert ops.conv2d_dgrad(tg, prep).cpu().numpy().tobytes() == C.conv2d(g, wt, transpose=True).tobytes()
     want_b = C.conv2d(g, wt, residual=gres, mask=x, transpose=True)
-    for tile in (-1, 3, 4):
+    for tile in (-1, 3, 4, 5):
         assert ops.conv2d_dgrad(tg, prep, residual=tgr, mask=tx, tile=tile).cpu().numpy().tobytes() == want_b.tobytes(), tile
     refg = torch.nn.grad.conv2d_input(x.shape, tw, tg)
     assert float((ops.conv2d_dgrad(tg, prep) - refg).abs().max()) <= 1e-4 * max(1.0, float(refg.abs().max()))

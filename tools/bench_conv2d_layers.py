@@ -116,8 +116,8 @@ def main():
                 row.update({"wino_fwd_ms": round(ms_wf, 4), "wino_dgrad_ms": round(ms_wb, 4), "wino_fwd_tflops": round(flops / ms_wf / 1e9, 1),
                             "wino_dgrad_tflops": round(flops / ms_wb / 1e9, 1)})
             if args.sweep:      # every tile shape, forward and backward: what the host's choice should have been
-                row["hip_fwd_ms_by_tile"] = [round(timeit(lambda t=t: ops.conv2d(x, prep, bias, tile=t), args.reps), 4) for t in range(5)]
-                row["hip_dgrad_ms_by_tile"] = [round(timeit(lambda t=t: ops.conv2d_dgrad(g, prep, (h, w), tile=t), args.reps), 4) for t in range(5)]
+                row["hip_fwd_ms_by_tile"] = [round(timeit(lambda t=t: ops.conv2d(x, prep, bias, tile=t), args.reps), 4) for t in range(6)]
+                row["hip_dgrad_ms_by_tile"] = [round(timeit(lambda t=t: ops.conv2d_dgrad(g, prep, (h, w), tile=t), args.reps), 4) for t in range(6)]
         rows.append(row)
         print(json.dumps(row), flush=True)
         del x, wt, y, g
