@@ -94,7 +94,7 @@ def conv2d_case(rs, dev):
     relu = bool(rs.rand() < 0.5)
     pad = dil if k == 3 else 0
     chunk = 8 if k == 3 else 16
-    tile = int(rs.randint(-1, 4 if k == 1 else 3))
+    tile = int(rs.randint(-1, 6 if k == 1 else 3))      # 1x1: -1 .. 5 (all six shapes), 3x3: -1 .. 2
     t = lambda a: None if a is None else torch.tensor(a, device=dev)       # noqa: E731
     prep = ops.Conv2dPrep(t(wt), 1, pad, dil)
     y = ops.conv2d(t(x), prep, t(bias), t(res), relu, t(mask), tile=tile)
