@@ -87,25 +87,32 @@ def table_hash():
 
 def _wino4_pays(key):
     """a 3x3 / 3x3x3 stride-1 layer the table does not know: does F(4x4,3x3) pay?  Its workgroup computes 16 x 32 outputs of 64 channels
-    in one plane; it wins where the launch is at least ~0.8 rounds of the chip AND the tiles are mostly real outputs (maps of 5 or 10
-    rows are two thirds padding), F(2x2,3x3) otherwise - fitted to profiles/r05_routes_measured.jsonl (the sign of the measured
-    difference on 162 of the 185 layers measured both ways; summed over all of them the rule is 2 % over the per-layer optimum, always-F(2x2) 18 %).  A function of the key alone: no clock."""
+    in one plane (two images side by side on maps of at most 15 columns).  It wins (a) where the launch is at least ~0.6 rounds of the
+    chip and the tiles are at least 45 % real outputs (maps of 5 rows are two thirds padding), and (b) - 2D layers, since the K-split
+    launch - on SMALL maps with a long contraction (at most 128 tiles x channel blocks and at least 256 input channels: the contraction is
+    dealt to several workgroups per tile); F(2x2,3x3) otherwise.  Fitted to profiles/r06_routes_measured.jsonl: the sign of the measured
+    difference on 182 of the 188 layers measured both ways, 0.4 % over the per-layer optimum summed over all of them (the round-5 rule on
+    the same table: 149 of 188, 5.7 %).  A function of the key alone: no clock."""
     try:
         if key[0] in ("f", "b"):
             if key[1] != 3:
                 return False
-            out_ch = key[3] if key[0] == "f" else key[2]
+            out_ch, in_ch = (key[3], key[2]) if key[0] == "f" else (key[2], key[3])
             shape = key[5]
-            planes, h, w = shape[0], shape[2], shape[3]
+            planes, h, w, two_d = shape[0], shape[2], shape[3], True
         elif key[0] in ("f3", "b3"):
-            out_ch = key[2] if key[0] == "f3" else key[1]
+            out_ch, in_ch = (key[2], key[1]) if key[0] == "f3" else (key[1], key[2])
             shape = key[3]
-            planes, h, w = shape[0] * shape[2], shape[3], shape[4]
+            planes, h, w, two_d = shape[0] * shape[2], shape[3], shape[4], False
         else:
             return False
-        tiles = ((h + 15) // 16) * ((w + 31) // 32)
-        wgs = tiles * planes * ((out_ch + 63) // 64)
-        return wgs >= 200 and h * w >= 0.62 * tiles * 512
+        pair = two_d and w <= 15 and planes >= 2
+        tiles = ((h + 15) // 16) * (1 if pair else (w + 31) // 32)
+        wgs = tiles * ((planes + 1) // 2 if pair else planes) * ((out_ch + 63) // 64)
+        filled = h * w * (2 if pair else 1) >= 0.45 * tiles * 512
+        if out_ch < 16 or not filled:
+            return False
+        return wgs >= 150 or (two_d and wgs <= 128 and in_ch >= 256)
     except (TypeError, IndexError, ValueError):
         return False
 

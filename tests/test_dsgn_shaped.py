@@ -197,7 +197,9 @@ def test_route_table_is_committed_and_well_formed():
     four = {"hip": boom, "": boom, "wino": boom, "wino4": boom}
     assert routes.choose(("f", 3, 128, 128, 1, (2, 128, 190, 300), False, True), four) == "wino4"          # 140 tiles x 2 images x 2 channel blocks
     assert routes.choose(("b", 3, 128, 128, 1, (2, 128, 190, 300), False, False), four) == "wino4"
-    assert routes.choose(("f", 3, 256, 256, 1, (2, 256, 37, 120), False, True), four) == "wino"            # 96 workgroups: a third of the chip
+    assert routes.choose(("f", 3, 256, 256, 1, (2, 256, 37, 120), False, True), four) == "wino4"           # 96 workgroups, 256 input channels: the K-split launch
+    assert routes.choose(("f", 3, 64, 64, 1, (2, 64, 37, 120), False, True), four) == "wino"               # 24 workgroups and a short contraction: nothing to deal out
+    assert routes.choose(("f", 3, 128, 8, 1, (2, 128, 190, 300), False, True), four) == "wino"             # 8 output channels: a 64-channel tile is padding
     assert routes.choose(("f3", 128, 128, (1, 128, 47, 5, 76), False, True), {"direct": boom, "wino": boom, "wino4": boom}) == "wino"     # 5-row planes: padding
     assert routes.choose(("f3", 32, 32, (1, 32, 47, 96, 312), False, True), {"direct": boom, "wino": boom, "wino4": boom}) == "wino4"
     assert routes.choose(("f", 1, 128, 128, 1, (2, 128, 190, 300), False, True), {"hip": boom, "": boom}) == "hip"
